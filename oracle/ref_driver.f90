@@ -1,0 +1,268 @@
+!########################################################################
+! TEST INFRASTRUCTURE ONLY -- never linked into, imported by or called from the product path.
+!
+! C-callable driver around the *reference's own* Fortran modules, which the Makefile in this
+! directory compiles where they lie under /root/reference/src into oracle/_ref/ (nothing of the
+! reference is copied into this repository).  Every routine here only marshals arguments and calls
+! the reference:
+!
+!   FDM_CreatePlan              src/fdm/fdm.f90:143
+!   FDM_Der1_Solve/Der2_Solve   src/fdm/fdm_derivative.f90:218,413
+!   OPR_Partial_X/Y/Z           src/operators/opr_partial.f90:31,266,154
+!   TLab_Transpose              src/utils/tlab_transpose.f90:14
+!   FDM_Int1_Initialize/Solve   src/fdm/fdm_integral.f90:58,219
+!   OPR_ODE2_Factorize_*        src/operators/opr_odes.f90:37,165,265,391
+!
+! OPR_Burgers_{X,Y,Z} (src/physics/opr_burgers.f90) and OPR_Poisson (src/operators/opr_elliptic.f90)
+! cannot be compiled in this image: they pull in opr_fourier.f90, which needs the FFTW header
+! fftw3.f03 (absent; never stubbed).  ref_burgers below therefore reproduces the 30-line data flow of
+! OPR_Burgers_X/Y/Z + OPR_Burgers_1D (opr_burgers.f90:190-521, serial branch, no dealiasing, no
+! anelastic correction) on top of the reference's own solvers, including the nu-scaled LU of
+! OPR_Burgers_Initialize (opr_burgers.f90:100-111).
+!########################################################################
+module ref_state
+    use TLab_Constants, only: wp, wi
+    use TLab_Grid, only: grid_dt
+    use FDM, only: fdm_dt
+    use FDM_Integral, only: fdm_integral_dt
+    implicit none
+    save
+    type(fdm_dt), target :: gp(3)
+    type(grid_dt) :: gr(3)
+    type(fdm_integral_dt) :: fint(2)                ! scratch pair of first-order integral plans
+end module ref_state
+
+!########################################################################
+subroutine ref_init(nx, ny, nz) bind(C, name='ref_init')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_Arrays, only: wrk1d, wrk2d, wrk3d
+    use TLab_OpenMP, only: TLab_OMP_numThreads
+    implicit none
+    integer(c_int), value :: nx, ny, nz
+    integer(wi) n2d, n1d
+
+    TLab_OMP_numThreads = 1
+    if (allocated(wrk1d)) deallocate (wrk1d)
+    if (allocated(wrk2d)) deallocate (wrk2d)
+    if (allocated(wrk3d)) deallocate (wrk3d)
+    n1d = max(nx, ny, nz)
+    n2d = max(nx*ny, nx*nz, ny*nz, 3)
+    allocate (wrk1d(n1d, 20), wrk2d(n2d, 6), wrk3d((nx + 2)*ny*nz))
+    wrk1d = 0.0_wp; wrk2d = 0.0_wp; wrk3d = 0.0_wp
+end subroutine ref_init
+
+!########################################################################
+subroutine ref_fdm_create(idir, n, nodes, periodic, uniform, mode1, mode2) bind(C, name='ref_fdm_create')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use FDM, only: FDM_CreatePlan
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, n, periodic, uniform, mode1, mode2
+    real(c_double), intent(in) :: nodes(n)
+
+    gr(idir)%name = 'xyz'(idir:idir)
+    gr(idir)%size = n
+    gr(idir)%periodic = (periodic /= 0)
+    if (allocated(gr(idir)%nodes)) deallocate (gr(idir)%nodes)
+    allocate (gr(idir)%nodes(n))
+    gr(idir)%nodes(:) = nodes(:)
+    gr(idir)%scale = nodes(n) - nodes(1)
+
+    gp(idir)%name = gr(idir)%name
+    gp(idir)%periodic = (periodic /= 0)
+    gp(idir)%uniform = (uniform /= 0)
+    gp(idir)%der1%mode_fdm = mode1
+    gp(idir)%der2%mode_fdm = mode2
+    gp(idir)%der1%need_1der = .false.
+    gp(idir)%der2%need_1der = .false.
+    call FDM_CreatePlan(gr(idir), gp(idir))
+end subroutine ref_fdm_create
+
+!########################################################################
+! integer queries: 1 nb_diag1(1), 2 nb_diag1(2), 3 nb_diag2(1), 4 nb_diag2(2), 5 need_1der, 6 size(lu1,2), 7 size(lu2,2), 8 size(rhs2,2)
+integer(c_int) function ref_fdm_info(idir, what) bind(C, name='ref_fdm_info')
+    use iso_c_binding
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, what
+    ref_fdm_info = -1
+    select case (what)
+    case (1); ref_fdm_info = gp(idir)%der1%nb_diag(1)
+    case (2); ref_fdm_info = gp(idir)%der1%nb_diag(2)
+    case (3); ref_fdm_info = gp(idir)%der2%nb_diag(1)
+    case (4); ref_fdm_info = gp(idir)%der2%nb_diag(2)
+    case (5); ref_fdm_info = merge(1, 0, gp(idir)%der2%need_1der)
+    case (6); ref_fdm_info = size(gp(idir)%der1%lu, 2)
+    case (7); ref_fdm_info = size(gp(idir)%der2%lu, 2)
+    case (8); ref_fdm_info = size(gp(idir)%der2%rhs, 2)
+    end select
+end function ref_fdm_info
+
+!########################################################################
+! copy plan arrays out (column-major as in Fortran). which:
+!  1 der1%lhs(n,5)  2 der1%rhs(n,7)  3 der1%lu(n,*)  4 der1%rhs_b(4,0:7)  5 der1%rhs_t(0:4,7)  6 der1%mwn(n)
+!  7 der2%lhs(n,5)  8 der2%rhs(n,12) 9 der2%lu(n,*)  10 der2%mwn(n)      11 jac(n,3)
+subroutine ref_fdm_get(idir, which, buf, nbuf) bind(C, name='ref_fdm_get')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, which, nbuf
+    real(c_double), intent(out) :: buf(nbuf)
+    integer m
+
+    buf(:) = 0.0_wp
+    select case (which)
+    case (1); m = size(gp(idir)%der1%lhs); buf(1:m) = reshape(gp(idir)%der1%lhs, [m])
+    case (2); m = size(gp(idir)%der1%rhs); buf(1:m) = reshape(gp(idir)%der1%rhs, [m])
+    case (3); m = size(gp(idir)%der1%lu); buf(1:m) = reshape(gp(idir)%der1%lu, [m])
+    case (4); m = size(gp(idir)%der1%rhs_b); buf(1:m) = reshape(gp(idir)%der1%rhs_b, [m])
+    case (5); m = size(gp(idir)%der1%rhs_t); buf(1:m) = reshape(gp(idir)%der1%rhs_t, [m])
+    case (6)
+        if (gp(idir)%periodic) then
+            m = size(gp(idir)%der1%mwn); buf(1:m) = gp(idir)%der1%mwn
+        end if
+    case (7); m = size(gp(idir)%der2%lhs); buf(1:m) = reshape(gp(idir)%der2%lhs, [m])
+    case (8); m = size(gp(idir)%der2%rhs); buf(1:m) = reshape(gp(idir)%der2%rhs, [m])
+    case (9); m = size(gp(idir)%der2%lu); buf(1:m) = reshape(gp(idir)%der2%lu, [m])
+    case (10)
+        if (gp(idir)%periodic) then
+            m = size(gp(idir)%der2%mwn); buf(1:m) = gp(idir)%der2%mwn
+        end if
+    case (11); m = size(gp(idir)%jac); buf(1:m) = reshape(gp(idir)%jac, [m])
+    end select
+end subroutine ref_fdm_get
+
+!########################################################################
+! 1-D level: u(nlines, n) lines-fastest
+subroutine ref_der1_solve(idir, nlines, ibc, u, res) bind(C, name='ref_der1_solve')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_Arrays, only: wrk2d
+    use FDM_Derivative, only: FDM_Der1_Solve
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, nlines, ibc
+    real(c_double), intent(in) :: u(nlines, gp(idir)%size)
+    real(c_double), intent(out) :: res(nlines, gp(idir)%size)
+    real(wp), allocatable :: w(:)
+    allocate (w(nlines))
+    call FDM_Der1_Solve(nlines, ibc, gp(idir)%der1, gp(idir)%der1%lu, u, res, w)
+    deallocate (w)
+end subroutine ref_der1_solve
+
+subroutine ref_der2_solve(idir, nlines, u, du, res) bind(C, name='ref_der2_solve')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use FDM_Derivative, only: FDM_Der2_Solve
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, nlines
+    real(c_double), intent(in) :: u(nlines, gp(idir)%size), du(nlines, gp(idir)%size)
+    real(c_double), intent(out) :: res(nlines, gp(idir)%size)
+    real(wp), allocatable :: w(:)
+    allocate (w(nlines))
+    call FDM_Der2_Solve(nlines, gp(idir)%der2, gp(idir)%der2%lu, u, res, du, w)
+    deallocate (w)
+end subroutine ref_der2_solve
+
+!########################################################################
+subroutine ref_partial(idir, itype, nx, ny, nz, ibc, u, res, tmp1) bind(C, name='ref_partial')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use OPR_Partial
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, itype, nx, ny, nz, ibc
+    real(c_double), intent(in) :: u(nx*ny*nz)
+    real(c_double), intent(out) :: res(nx*ny*nz)
+    real(c_double), intent(inout) :: tmp1(nx*ny*nz)
+    integer(wi) bcs(2, 2)
+
+    bcs = 0
+    bcs(1, 1) = mod(ibc, 2)
+    bcs(2, 1) = ibc/2
+    select case (idir)
+    case (1); call OPR_Partial_X(itype, nx, ny, nz, bcs, gp(1), u, res, tmp1)
+    case (2); call OPR_Partial_Y(itype, nx, ny, nz, bcs, gp(2), u, res, tmp1)
+    case (3); call OPR_Partial_Z(itype, nx, ny, nz, bcs, gp(3), u, res, tmp1)
+    end select
+end subroutine ref_partial
+
+!########################################################################
+subroutine ref_transpose(a, nra, nca, b) bind(C, name='ref_transpose')
+    use iso_c_binding
+    implicit none
+    integer(c_int), value :: nra, nca
+    real(c_double), intent(in) :: a(nra, nca)
+    real(c_double), intent(out) :: b(nca, nra)
+    call TLab_Transpose(a, nra, nca, nra, b, nca)
+end subroutine ref_transpose
+
+!########################################################################
+! result = nu d2s/dx2 - vel ds/dx along idir; data flow of OPR_Burgers_X/Y/Z + OPR_Burgers_1D
+! (opr_burgers.f90:190-521, serial), with the nu-scaled LU of OPR_Burgers_Initialize (:100-111).
+! On return tmp1 holds the transposed operand exactly as the reference leaves it (X, Y with nz>1).
+subroutine ref_burgers(idir, nx, ny, nz, ibc, visc, s, vel, res, tmp1) bind(C, name='ref_burgers')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_Arrays, only: wrk2d, wrk3d
+    use FDM_Derivative, only: FDM_Der1_Solve, FDM_Der2_Solve
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, nx, ny, nz, ibc
+    real(c_double), value :: visc
+    real(c_double), intent(in) :: s(nx*ny*nz), vel(nx*ny*nz)
+    real(c_double), intent(out) :: res(nx*ny*nz)
+    real(c_double), intent(inout) :: tmp1(nx*ny*nz)
+
+    real(wp), allocatable :: lu2d(:, :), vel_t(:), dsdx(:)
+    integer(wi) nlines, n, ntot
+
+    n = gp(idir)%size
+    ntot = nx*ny*nz
+    nlines = ntot/n
+
+    allocate (lu2d(n, size(gp(idir)%der2%lu, 2)))
+    lu2d = gp(idir)%der2%lu
+    if (gp(idir)%periodic) then
+        lu2d(:, 2) = gp(idir)%der2%lu(:, 2)*visc
+        lu2d(:, 4) = gp(idir)%der2%lu(:, 4)/visc
+    else
+        lu2d(:, 2) = gp(idir)%der2%lu(:, 2)*visc
+        lu2d(:, 3) = gp(idir)%der2%lu(:, 3)/visc
+    end if
+
+    allocate (vel_t(ntot), dsdx(ntot))
+
+    select case (idir)
+    case (1)
+        call TLab_Transpose(s, n, nlines, n, tmp1, nlines)
+        call TLab_Transpose(vel, n, nlines, n, vel_t, nlines)
+        call FDM_Der1_Solve(nlines, ibc, gp(1)%der1, gp(1)%der1%lu, tmp1, dsdx, wrk2d)
+        call FDM_Der2_Solve(nlines, gp(1)%der2, lu2d, tmp1, wrk3d, dsdx, wrk2d)
+        wrk3d(1:ntot) = wrk3d(1:ntot) - vel_t(1:ntot)*dsdx(1:ntot)
+        call TLab_Transpose(wrk3d, nlines, n, nlines, res, n)
+    case (2)
+        if (nz == 1) then
+            call FDM_Der1_Solve(nlines, ibc, gp(2)%der1, gp(2)%der1%lu, s, dsdx, wrk2d)
+            call FDM_Der2_Solve(nlines, gp(2)%der2, lu2d, s, res, dsdx, wrk2d)
+            res(1:ntot) = res(1:ntot) - vel(1:ntot)*dsdx(1:ntot)
+        else
+            call TLab_Transpose(s, nx*ny, nz, nx*ny, tmp1, nz)
+            call TLab_Transpose(vel, nx*ny, nz, nx*ny, vel_t, nz)
+            call FDM_Der1_Solve(nlines, ibc, gp(2)%der1, gp(2)%der1%lu, tmp1, dsdx, wrk2d)
+            call FDM_Der2_Solve(nlines, gp(2)%der2, lu2d, tmp1, wrk3d, dsdx, wrk2d)
+            wrk3d(1:ntot) = wrk3d(1:ntot) - vel_t(1:ntot)*dsdx(1:ntot)
+            call TLab_Transpose(wrk3d, nz, nx*ny, nz, res, nx*ny)
+        end if
+    case (3)
+        call FDM_Der1_Solve(nlines, ibc, gp(3)%der1, gp(3)%der1%lu, s, dsdx, wrk2d)
+        call FDM_Der2_Solve(nlines, gp(3)%der2, lu2d, s, res, dsdx, wrk2d)
+        res(1:ntot) = res(1:ntot) - vel(1:ntot)*dsdx(1:ntot)
+    end select
+
+    deallocate (lu2d, vel_t, dsdx)
+end subroutine ref_burgers
