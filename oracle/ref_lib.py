@@ -1,0 +1,117 @@
+"""ctypes wrapper around oracle/_ref/libtlab_ref.so (the reference's own Fortran, compiled in place).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, tests/golden/make_golden.py and bench.py's cpu_baseline leg.
+The library is global-state based (module variables in the reference), so one plan per direction at a time.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libtlab_ref.so")
+
+c_int, c_dbl = ctypes.c_int, ctypes.c_double
+_P = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        # RTLD_LAZY: the IBM branch of opr_partial.f90 references ibm_spline_xyz_, never called here
+        L = ctypes.CDLL(_PATH, mode=os.RTLD_LAZY)
+        L.ref_init.argtypes = [c_int] * 3
+        L.ref_fdm_create.argtypes = [c_int, c_int, _P, c_int, c_int, c_int, c_int]
+        L.ref_fdm_info.argtypes = [c_int, c_int]
+        L.ref_fdm_info.restype = c_int
+        L.ref_fdm_get.argtypes = [c_int, c_int, _P, c_int]
+        L.ref_der1_solve.argtypes = [c_int, c_int, c_int, _P, _P]
+        L.ref_der2_solve.argtypes = [c_int, c_int, _P, _P, _P]
+        L.ref_partial.argtypes = [c_int] * 6 + [_P, _P, _P]
+        L.ref_transpose.argtypes = [_P, c_int, c_int, _P]
+        L.ref_burgers.argtypes = [c_int] * 5 + [c_dbl, _P, _P, _P, _P]
+        _lib = L
+    return _lib
+
+
+def init(nx, ny, nz):
+    lib().ref_init(nx, ny, nz)
+
+
+def fdm_create(idir, nodes, periodic, uniform, mode1=6, mode2=7):
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    lib().ref_fdm_create(idir, nodes.shape[0], nodes, int(periodic), int(uniform), mode1, mode2)
+
+
+def fdm_arrays(idir, n):
+    """Plan arrays of direction idir as numpy arrays in the oracle's (row, diagonal) convention."""
+    L = lib()
+    info = {k: L.ref_fdm_info(idir, i) for i, k in enumerate(
+        ["ndl1", "ndr1", "ndl2", "ndr2", "need_1der", "lu1_cols", "lu2_cols", "rhs2_cols"], start=1)}
+
+    def get(which, rows, cols):
+        buf = np.zeros(rows * cols)
+        L.ref_fdm_get(idir, which, buf, buf.shape[0])
+        return buf.reshape(cols, rows).T.copy()     # column-major -> [row, col]
+
+    out = dict(info)
+    out["lhs1"] = get(1, n, 5)
+    out["rhs1"] = get(2, n, 7)
+    out["lu1"] = get(3, n, info["lu1_cols"])
+    out["rhs_b1"] = get(4, 4, 8)
+    out["rhs_t1"] = get(5, 5, 7)
+    out["mwn1"] = get(6, n, 1)[:, 0]
+    out["lhs2"] = get(7, n, 5)
+    out["rhs2"] = get(8, n, info["rhs2_cols"])
+    out["lu2"] = get(9, n, info["lu2_cols"])
+    out["mwn2"] = get(10, n, 1)[:, 0]
+    out["jac"] = get(11, n, 3)
+    return out
+
+
+def der1_solve(idir, ibc, u):
+    """u: (n, nlines) C-ordered == Fortran (nlines, n)."""
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    r = np.empty_like(u)
+    lib().ref_der1_solve(idir, u.shape[1], ibc, u, r)
+    return r
+
+
+def der2_solve(idir, u, du):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    du = np.ascontiguousarray(du, dtype=np.float64)
+    r = np.empty_like(u)
+    lib().ref_der2_solve(idir, u.shape[1], u, du, r)
+    return r
+
+
+def partial(idir, itype, nx, ny, nz, ibc, u):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    r = np.zeros_like(u)
+    t = np.zeros_like(u)
+    lib().ref_partial(idir, itype, nx, ny, nz, ibc, u, r, t)
+    return r, t
+
+
+def transpose(a):
+    """a: C-ordered (nca, nra) == Fortran a(nra, nca); returns C-ordered (nra, nca) == Fortran b(nca, nra)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    nca, nra = a.shape
+    b = np.empty((nra, nca))
+    lib().ref_transpose(a, nra, nca, b)
+    return b
+
+
+def burgers(idir, nx, ny, nz, ibc, visc, s, vel):
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    vel = np.ascontiguousarray(vel, dtype=np.float64)
+    r = np.zeros_like(s)
+    t = np.zeros_like(s)
+    lib().ref_burgers(idir, nx, ny, nz, ibc, float(visc), s, vel, r, t)
+    return r, t
