@@ -1,0 +1,139 @@
+/* tlab_amd.h -- C ABI of the MI355X-native Tlab Navier-Stokes RHS operators.
+ *
+ * This is the drop-in boundary.  Tlab has no FFI: its boundary is Fortran module procedures
+ * (SURVEY.md 8b).  Each entry point below is what an ISO_C_BINDING interface in the same-named
+ * Fortran module binds to (tlab_amd/fortran/); the reference interface it replaces
+ * is cited as path:line relative to the reference's src/.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative TLAB_E* code otherwise; tlab_last_error() gives text.
+ *    (reference: operators stop the program through TLab_Stop, base/tlab_workflow.f90:105; the Fortran shim
+ *    maps non-zero to TLab_Write_ASCII(efile, ...) + TLab_Stop(DNS_ERROR_UNDEVELOP).)
+ *  - all field pointers are DEVICE pointers (hipMalloc / tlab_malloc / torch CUDA tensors), fp64,
+ *    x fastest: index = i + nx*(j + ny*k), exactly the host layout of the reference
+ *    (operators/opr_partial.f90:40: u(nx*ny*nz)).
+ *  - coefficient tables passed IN from a host (tlab_fdm_plan_create_from_arrays) are HOST pointers,
+ *    column-major as Fortran stores lhs(n,ndl), rhs(n,ndr).
+ *  - kernels are enqueued on the stream set by tlab_set_stream (default: the null stream); nothing
+ *    synchronises except tlab_sync() and the *_get / memcpy helpers.
+ *  - one in-flight operator per process, like the reference (module state).
+ */
+#ifndef TLAB_AMD_H
+#define TLAB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define TLAB_OK 0
+#define TLAB_EINVAL (-1)      /* bad argument (size, direction, type, aliasing)                  */
+#define TLAB_EUNSUPPORTED (-2)/* valid in the reference, not built here (falls to CPU in Fortran) */
+#define TLAB_EHIP (-3)        /* HIP / rocFFT / RCCL runtime error                               */
+#define TLAB_ENOMEM (-4)
+
+/* ---- constants mirrored from the reference ------------------------------------------------ */
+/* operators/opr_partial.f90:19-26 */
+#define TLAB_OPR_P1 1
+#define TLAB_OPR_P2 2
+#define TLAB_OPR_P2_P1 3
+/* physics/opr_burgers.f90:29-30 */
+#define TLAB_OPR_B_SELF 0
+#define TLAB_OPR_B_U_IN 1
+/* base/tlab_constants.f90:63-66 */
+#define TLAB_BCS_DD 0
+#define TLAB_BCS_ND 1
+#define TLAB_BCS_DN 2
+#define TLAB_BCS_NN 3
+/* fdm/fdm_derivative.f90:51-58 */
+#define TLAB_FDM_COM4_JACOBIAN 4
+#define TLAB_FDM_COM6_JACOBIAN 6
+#define TLAB_FDM_COM6_JACOBIAN_HYPER 7
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+int tlab_init(int device);                 /* hipSetDevice + library state; idempotent            */
+int tlab_finalize(void);
+const char *tlab_last_error(void);
+int tlab_set_stream(void *hip_stream);     /* hipStream_t; NULL = default stream                  */
+int tlab_sync(void);                       /* hipStreamSynchronize on the current stream          */
+/* allocation hook: replaces the allocate() inside TLab_Allocate_Real (base/tlab_memory.f90:306-331) so that
+ * q, s, txc, wrk3d, hq, hs live in HBM; the Fortran side wraps the pointer with c_f_pointer. */
+int tlab_malloc(void **p, size_t bytes);
+int tlab_free(void *p);
+int tlab_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int tlab_memcpy_d2h(void *dst, const void *src, size_t bytes);
+
+/* ---- FDM plans: type(fdm_dt) of fdm/fdm.f90:14-29 + type(fdm_derivative_dt) fdm_derivative.f90:16-29 ---- */
+typedef struct tlab_fdm_plan *tlab_fdm_plan_t;
+
+/* Replaces FDM_CreatePlan (fdm/fdm.f90:143-252): Jacobians from the node positions, compact schemes
+ * scheme1 (first derivative: TLAB_FDM_COM4_JACOBIAN | TLAB_FDM_COM6_JACOBIAN) and scheme2 (second derivative:
+ * COM4_JACOBIAN | COM6_JACOBIAN | COM6_JACOBIAN_HYPER), Neumann variants (FDM_Bcs_Neumann, fdm_base.f90:194),
+ * factorizations.  nodes: HOST pointer, n doubles.
+ * hyper_bc1_ext: value of the out-of-bounds coefficient the reference reads for the C2N6-Hyper wall row
+ * (fdm_com2_jacobian.f90:224 with icmax=4; DESIGN.md "reference defects"): pass 0.1 to reproduce the flang-built
+ * reference bit for bit, 0.0 for the consistent closure. */
+int tlab_fdm_plan_create(tlab_fdm_plan_t *out, int n, const double *nodes, int periodic, int uniform,
+                         int scheme1, int scheme2, double hyper_bc1_ext);
+
+/* Same plan from coefficient tables the (unchanged) Fortran host already built in FDM_Initialize:
+ * lhs1 = g%der1%lhs(n,1:ndl1), rhs1 = g%der1%rhs(n,1:ndr1), lhs2 = g%der2%lhs(n,1:ndl2),
+ * rhs2 = g%der2%rhs(n,1:ndr2+ndl2) (the last ndl2 columns are the Jacobian-correction diagonals,
+ * fdm_derivative.f90:356,437-440).  ndl* must be 3 (tridiagonal LHS; CompactJacobian6Penta is unsupported). */
+int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, int need_1der,
+                                     int ndl1, int ndr1, const double *lhs1, const double *rhs1,
+                                     int ndl2, int ndr2, const double *lhs2, const double *rhs2);
+int tlab_fdm_plan_destroy(tlab_fdm_plan_t p);
+
+/* read back plan tables (HOST buffer, column-major like the reference) for parity tests. which:
+ *  1 der1%lhs(n,5) 2 der1%rhs(n,7) 3 der1%lu(n,5|20) 4 der1%rhs_b(4,0:7) 5 der1%rhs_t(0:4,7) 6 der1%mwn(n)
+ *  7 der2%lhs(n,5) 8 der2%rhs(n,12) 9 der2%lu(n,5|3) 10 der2%mwn(n) 11 jac(n,3)
+ * returns the number of doubles written (or <0). */
+int tlab_fdm_plan_get(tlab_fdm_plan_t p, int which, double *buf, int nbuf);
+int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what); /* 0 n, 1 ndl1, 2 ndr1, 3 ndl2, 4 ndr2, 5 need_1der, 6 periodic */
+
+/* ---- operators ----------------------------------------------------------------------------- */
+/* OPR_Partial_X/Y/Z(type, nx, ny, nz, bcs, g, u, result, tmp1)   operators/opr_partial.f90:31,266,154
+ * dir = 1,2,3.  ibc = bcs(1,1) + 2*bcs(2,1) (opr_partial.f90:91).  type = TLAB_OPR_P1 | P2 | P2_P1.
+ * tmp1: first derivative on return for P2_P1; scratch (may be NULL when the plan needs no Jacobian
+ * correction) for P2; unused for P1.  u, result, tmp1 must not alias.  2-D guard: a direction of size 1
+ * returns zeros (opr_partial.f90:175-177,287-289). */
+int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int nz, int ibc,
+                     const double *u, double *result, double *tmp1);
+
+/* OPR_Burgers_X/Y/Z(ivel, is, nx, ny, nz, bcs, s, u, result, tmp1, u_t)   physics/opr_burgers.f90:190,277,359
+ * result = nu * d2s/dx2 - u * ds/dx along dir; nu = visc (is = 0) or visc/schmidt(is)
+ * (OPR_Burgers_Initialize, opr_burgers.f90:92-112, folds it into the LU; here it is an argument).
+ * ivel = TLAB_OPR_B_SELF: advecting velocity is s itself; TLAB_OPR_B_U_IN: it is u (natural layout).
+ * The reference additionally threads a *transposed* copy of the velocity through tmp1/u_t to save CPU
+ * transposes (opr_burgers.f90:236-240); the device kernels read u in its natural layout, so u_t is ignored.
+ * If write_transposed != 0 and ivel == SELF, tmp1 receives the transposed operand exactly as the
+ * reference leaves it (X: (ny*nz, nx); Y with nz > 1: (nz, nx*ny)), bit-exact; otherwise tmp1 is scratch
+ * (first derivative). */
+int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int nz, int ibc, double nu,
+                     const double *s, const double *u, double *result, double *tmp1, int write_transposed);
+
+/* TLab_Transpose(a, nra, nca, ma, b, mb)   utils/tlab_transpose.f90:14-82 : b(j,i) = a(i,j), bit-exact */
+int tlab_transpose(const double *a, int nra, int nca, double *b);
+
+/* which kernel family the last operator call used: 0 none, 1 generic (any n), 2 wave-per-line (x),
+ * 3 register-tile (y/z).  For tests / profiling. */
+int tlab_last_kernel_path(void);
+/* force a kernel family (0 = automatic). */
+int tlab_force_kernel_path(int path);
+/* tuning knobs for experiments: key 1 = rows per wave of the register-tile kernel (16 | 32 | 64, 0 = automatic). */
+int tlab_set_tuning(int key, int value);
+
+/* Debug aid, never on an operator path: runs the *device algorithm's* precomputed tables (chunked Thomas +
+ * separator system) through a scalar host emulation so the tables can be checked without a GPU.
+ * which = 1 (first derivative, variant ibc) or 2 (second derivative); chunks = number of chunks;
+ * f (HOST, n doubles): right-hand side in, solution out. */
+int tlab_debug_host_chunked_solve(tlab_fdm_plan_t p, int which, int ibc, int chunks, double *f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLAB_AMD_H */

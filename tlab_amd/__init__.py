@@ -1,0 +1,16 @@
+"""tlab_amd -- MI355X-native implementation of Tlab's Navier-Stokes RHS hot path.
+
+The compute path is hand-written HIP (tlab_amd/csrc) behind the C ABI of include/tlab_amd.h, loaded here with
+ctypes.  There is NO CPU fallback: importing works without a GPU (plan construction is host code), but every
+operator raises TlabError unless tlab_init() found an MI355X.
+"""
+from .lib import TlabError, load, lib_path  # noqa: F401
+from .operators import (  # noqa: F401
+    FdmPlan, init, sync,
+    OPR_P1, OPR_P2, OPR_P2_P1, OPR_B_SELF, OPR_B_U_IN,
+    BCS_DD, BCS_ND, BCS_DN, BCS_NN,
+    FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER,
+    OPR_Partial_X, OPR_Partial_Y, OPR_Partial_Z,
+    OPR_Burgers_X, OPR_Burgers_Y, OPR_Burgers_Z,
+    TLab_Transpose,
+)

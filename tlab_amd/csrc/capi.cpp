@@ -1,0 +1,582 @@
+// C ABI of include/tlab_amd.h: runtime, plans, operator dispatch.
+#include "../../include/tlab_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace tlab;
+
+namespace {
+
+thread_local std::string g_err;
+hipStream_t g_stream = nullptr;
+int g_device = -1;
+int g_last_path = 0;
+int g_force_path = 0;
+DeviceArray *g_ws = nullptr;  // grow-only scratch field
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string &s) : std::runtime_error(s) {}
+};
+struct Unsupported : std::runtime_error {
+    explicit Unsupported(const std::string &s) : std::runtime_error(s) {}
+};
+struct Invalid : std::runtime_error {
+    explicit Invalid(const std::string &s) : std::runtime_error(s) {}
+};
+
+void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw HipError(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        f();
+        return TLAB_OK;
+    } catch (const HipError &e) {
+        g_err = e.what();
+        return TLAB_EHIP;
+    } catch (const Unsupported &e) {
+        g_err = e.what();
+        return TLAB_EUNSUPPORTED;
+    } catch (const std::bad_alloc &) {
+        g_err = "out of memory";
+        return TLAB_ENOMEM;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return TLAB_EINVAL;
+    }
+}
+
+double *workspace(size_t n) {
+    if (!g_ws) g_ws = new DeviceArray();
+    if (g_ws->n < n) {
+        if (g_ws->p) hip_check(hipFree(g_ws->p), "hipFree");
+        g_ws->p = nullptr;
+        hip_check(hipMalloc((void **)&g_ws->p, n * sizeof(double)), "hipMalloc(workspace)");
+        g_ws->n = n;
+    }
+    return g_ws->p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// DeviceArray
+// ------------------------------------------------------------------------------------------------
+namespace tlab {
+DeviceArray::~DeviceArray() {
+    if (p) (void)hipFree(p);
+}
+void DeviceArray::upload(const std::vector<double> &h) {
+    if (p) hip_check(hipFree(p), "hipFree");
+    p = nullptr;
+    n = h.size();
+    if (n == 0) return;
+    hip_check(hipMalloc((void **)&p, n * sizeof(double)), "hipMalloc(table)");
+    hip_check(hipMemcpy(p, h.data(), n * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(table)");
+}
+}  // namespace tlab
+
+// ------------------------------------------------------------------------------------------------
+// plan: matrices, stencils, cached device systems
+// ------------------------------------------------------------------------------------------------
+TriDiag tlab_fdm_plan::tridiag(int which, int ibc) const {
+    const DerTables &d = (which == 1) ? t.der1 : t.der2;
+    const int n = d.n;
+    if (d.ndl != 3) throw Unsupported("only tridiagonal LHS schemes are built (CompactJacobian6Penta is not)");
+    std::vector<double> lhs(d.lhs.begin(), d.lhs.begin() + (size_t)3 * n);
+    TriDiag T;
+    T.n = n;
+    T.periodic = d.periodic;
+    if (which == 1 && !d.periodic && ibc != BCS_DD) {
+        double rb[4 * 8] = {0}, rt[5 * 7] = {0};
+        fdm_bcs_neumann(ibc, n, 3, lhs.data(), d.ndr, d.rhs.data(), rb, rt);
+    }
+    T.a.assign(lhs.begin(), lhs.begin() + n);
+    T.b.assign(lhs.begin() + n, lhs.begin() + 2 * n);
+    T.c.assign(lhs.begin() + 2 * n, lhs.begin() + 3 * n);
+    if (which == 1 && !d.periodic) {
+        if (ibc == BCS_ND || ibc == BCS_NN) {  // wall value forced to zero (fdm_derivative.f90:239-241): identity row
+            T.a[0] = 0; T.b[0] = 1; T.c[0] = 0; T.a[1] = 0;
+        }
+        if (ibc == BCS_DN || ibc == BCS_NN) {
+            T.a[n - 1] = 0; T.b[n - 1] = 1; T.c[n - 1] = 0; T.c[n - 2] = 0;
+        }
+    }
+    return T;
+}
+
+StencilDev tlab_fdm_plan::stencil(int which, int ibc) const {
+    const DerTables &d = (which == 1) ? t.der1 : t.der2;
+    const int nx = d.n;
+    StencilDev s;
+    std::memset(&s, 0, sizeof(s));
+    s.sym = (which == 2);
+    s.periodic = d.periodic ? 1 : 0;
+    const double *r = d.rhs.data();
+#define RI(i, k) r[((i)-1) + (size_t)nx * ((k)-1)]
+    if (which == 1) {
+        if (d.ndr != 3 && d.ndr != 5) throw Unsupported("first-derivative RHS must have 3 or 5 diagonals");
+        s.c2 = (d.ndr == 5) ? RI(4, 5) : 0.0;  // r5_loc, fdm_matmul.f90:373
+        if (!d.periodic) {
+            double rb[4 * 8] = {0}, rt[5 * 7] = {0};
+            const bool nb = (ibc == BCS_ND || ibc == BCS_NN), ntp = (ibc == BCS_DN || ibc == BCS_NN);
+            if (nb || ntp) {
+                std::vector<double> lhs(d.lhs.begin(), d.lhs.begin() + (size_t)3 * nx);
+                fdm_bcs_neumann(ibc, nx, 3, lhs.data(), d.ndr, d.rhs.data(), rb, rt);
+            }
+#define RB(j, c) rb[((j)-1) + 4 * (c)]
+#define RT(rr, c) rt[(rr) + 5 * ((c)-1)]
+            if (d.ndr == 5) {  // MatMul_5d_antisym :382-391, :406-415
+                if (nb) {
+                    s.bb[1][1] = RB(2, 3); s.bb[1][2] = RB(2, 4); s.bb[1][3] = RB(2, 5);
+                    s.bb[2][1] = RB(3, 2); s.bb[2][2] = RB(3, 3); s.bb[2][3] = RB(3, 4); s.bb[2][4] = RB(3, 5);
+                } else {
+                    s.bb[0][0] = RI(1, 3); s.bb[0][1] = RI(1, 4); s.bb[0][2] = RI(1, 5); s.bb[0][3] = RI(1, 1);
+                    s.bb[1][0] = RI(2, 2); s.bb[1][1] = RI(2, 3); s.bb[1][2] = RI(2, 4); s.bb[1][3] = RI(2, 5);
+                    s.bb[2][0] = RI(3, 1); s.bb[2][1] = RI(3, 2); s.bb[2][2] = RI(3, 3); s.bb[2][3] = RI(3, 4); s.bb[2][4] = RI(3, 5);
+                }
+                if (ntp) {
+                    s.bt[0][1] = RT(1, 1); s.bt[0][2] = RT(1, 2); s.bt[0][3] = RT(1, 3); s.bt[0][4] = RT(1, 4);
+                    s.bt[1][2] = RT(2, 1); s.bt[1][3] = RT(2, 2); s.bt[1][4] = RT(2, 3);
+                } else {
+                    s.bt[0][1] = RI(nx - 2, 1); s.bt[0][2] = RI(nx - 2, 2); s.bt[0][3] = RI(nx - 2, 3); s.bt[0][4] = RI(nx - 2, 4); s.bt[0][5] = RI(nx - 2, 5);
+                    s.bt[1][2] = RI(nx - 1, 1); s.bt[1][3] = RI(nx - 1, 2); s.bt[1][4] = RI(nx - 1, 3); s.bt[1][5] = RI(nx - 1, 4);
+                    s.bt[2][2] = RI(nx, 5); s.bt[2][3] = RI(nx, 1); s.bt[2][4] = RI(nx, 2); s.bt[2][5] = RI(nx, 3);
+                }
+            } else {  // MatMul_3d_antisym :177-186, :200-209 ; third row from each wall is an interior row
+                s.bb[2][1] = -1.0; s.bb[2][3] = 1.0;
+                s.bt[0][2] = -1.0; s.bt[0][4] = 1.0;
+                if (nb) {
+                    s.bb[1][1] = RB(2, 2); s.bb[1][2] = RB(2, 3);
+                } else {
+                    s.bb[0][0] = RI(1, 2); s.bb[0][1] = RI(1, 3); s.bb[0][2] = RI(1, 1);
+                    s.bb[1][0] = RI(2, 1); s.bb[1][1] = RI(2, 2); s.bb[1][2] = RI(2, 3);
+                }
+                if (ntp) {
+                    s.bt[1][3] = RT(1, 1); s.bt[1][4] = RT(1, 2);
+                } else {
+                    s.bt[1][3] = RI(nx - 1, 1); s.bt[1][4] = RI(nx - 1, 2); s.bt[1][5] = RI(nx - 1, 3);
+                    s.bt[2][3] = RI(nx, 3); s.bt[2][4] = RI(nx, 1); s.bt[2][5] = RI(nx, 2);
+                }
+            }
+#undef RB
+#undef RT
+        }
+    } else {
+        if (d.ndr == 7) {  // MatMul_7d_sym :578-580, :596-601, :628-635
+            s.c0 = RI(4, 4); s.c2 = RI(4, 6); s.c3 = RI(4, 7);
+            if (!d.periodic) {
+                s.bb[0][0] = RI(1, 4); s.bb[0][1] = RI(1, 5); s.bb[0][2] = RI(1, 6); s.bb[0][3] = RI(1, 7); s.bb[0][4] = RI(1, 1);
+                s.bb[1][0] = RI(2, 3); s.bb[1][1] = RI(2, 4); s.bb[1][2] = RI(2, 5); s.bb[1][3] = RI(2, 6); s.bb[1][4] = RI(2, 7);
+                for (int k = 0; k < 6; ++k) s.bb[2][k] = RI(3, 2 + k);
+                for (int k = 0; k < 6; ++k) s.bt[0][k] = RI(nx - 2, 1 + k);
+                for (int k = 0; k < 5; ++k) s.bt[1][1 + k] = RI(nx - 1, 1 + k);
+                s.bt[2][1] = RI(nx, 7); s.bt[2][2] = RI(nx, 1); s.bt[2][3] = RI(nx, 2); s.bt[2][4] = RI(nx, 3); s.bt[2][5] = RI(nx, 4);
+            }
+        } else if (d.ndr == 5) {  // MatMul_5d_sym :438-439, :450-453, :474-478
+            s.c0 = RI(3, 3); s.c2 = RI(3, 5); s.c3 = 0.0;
+            if (!d.periodic) {
+                s.bb[0][0] = RI(1, 3); s.bb[0][1] = RI(1, 4); s.bb[0][2] = RI(1, 5); s.bb[0][3] = RI(1, 1);
+                s.bb[1][0] = RI(2, 2); s.bb[1][1] = RI(2, 3); s.bb[1][2] = RI(2, 4); s.bb[1][3] = RI(2, 5);
+                s.bb[2][0] = s.c2; s.bb[2][1] = 1.0; s.bb[2][2] = s.c0; s.bb[2][3] = 1.0; s.bb[2][4] = s.c2;
+                s.bt[0][1] = s.c2; s.bt[0][2] = 1.0; s.bt[0][3] = s.c0; s.bt[0][4] = 1.0; s.bt[0][5] = s.c2;
+                s.bt[1][2] = RI(nx - 1, 1); s.bt[1][3] = RI(nx - 1, 2); s.bt[1][4] = RI(nx - 1, 3); s.bt[1][5] = RI(nx - 1, 4);
+                s.bt[2][2] = RI(nx, 5); s.bt[2][3] = RI(nx, 1); s.bt[2][4] = RI(nx, 2); s.bt[2][5] = RI(nx, 3);
+            }
+        } else {
+            throw Unsupported("second-derivative RHS must have 5 or 7 diagonals");
+        }
+    }
+#undef RI
+    return s;
+}
+
+SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
+    if (which == 2 || t.der1.periodic) ibc = 0;
+    auto key = std::make_tuple(which, ibc, P);
+    auto it = systems.find(key);
+    if (it != systems.end()) return *it->second;
+    auto e = std::make_unique<SystemEntry>();
+    TriDiag T = tridiag(which, ibc);
+    build_chunked(T, P, e->host);
+    const ChunkedTables &h = e->host;
+    const int n = h.n, m = h.m;
+    std::vector<double> rowtab((size_t)5 * n);
+    std::copy(h.Lm.begin(), h.Lm.end(), rowtab.begin());
+    std::copy(h.Dinv.begin(), h.Dinv.end(), rowtab.begin() + n);
+    std::copy(h.Cm.begin(), h.Cm.end(), rowtab.begin() + 2 * n);
+    std::copy(h.V.begin(), h.V.end(), rowtab.begin() + 3 * n);
+    std::copy(h.W.begin(), h.W.end(), rowtab.begin() + 4 * n);
+    e->rowtab.upload(rowtab);
+    bool inv = true;  // lane-invariant: all chunks carry bitwise identical tables (circulant matrix)
+    for (int tab = 0; tab < 5 && inv; ++tab)
+        for (int j = 1; j < P && inv; ++j)
+            for (int p = 0; p < m; ++p)
+                if (rowtab[(size_t)tab * n + j * m + p] != rowtab[(size_t)tab * n + p]) { inv = false; break; }
+    if (P == 64) {
+        if (h.pcr_steps != 6) throw std::runtime_error("internal: PCR schedule missing");
+        std::vector<double> red((size_t)13 * 64);
+        std::copy(h.pcr_k1.begin(), h.pcr_k1.end(), red.begin());
+        std::copy(h.pcr_k2.begin(), h.pcr_k2.end(), red.begin() + 6 * 64);
+        std::copy(h.pcr_dinv.begin(), h.pcr_dinv.end(), red.begin() + 12 * 64);
+        for (int q = 0; q < 13 && inv; ++q)
+            for (int j = 1; j < 64; ++j)
+                if (red[(size_t)q * 64 + j] != red[(size_t)q * 64]) { inv = false; break; }
+        e->red.upload(red);
+    } else {
+        e->red.upload(h.ginv);
+    }
+    e->lane_invariant = inv;
+    SystemEntry &ref = *e;
+    systems[key] = std::move(e);
+    return ref;
+}
+
+JacCorrDev tlab_fdm_plan::jaccorr() {
+    if (!t.der2.need_1der) return JacCorrDev{nullptr};
+    if (!jc) {
+        jc = std::make_unique<DeviceArray>();
+        const int n = t.n, ndr = t.der2.ndr;
+        std::vector<double> j(t.der2.rhs.begin() + (size_t)n * ndr, t.der2.rhs.begin() + (size_t)n * (ndr + 3));
+        jc->upload(j);
+    }
+    return JacCorrDev{jc->p};
+}
+
+// ------------------------------------------------------------------------------------------------
+// runtime
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *tlab_last_error(void) { return g_err.c_str(); }
+
+int tlab_init(int device) {
+    return guarded([&] {
+        int count = 0;
+        hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+        if (count <= 0) throw HipError("no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback)");
+        if (device < 0 || device >= count) throw Invalid("tlab_init: bad device index");
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        g_device = device;
+    });
+}
+
+int tlab_finalize(void) {
+    return guarded([&] {
+        delete g_ws;
+        g_ws = nullptr;
+    });
+}
+
+int tlab_set_stream(void *s) {
+    g_stream = (hipStream_t)s;
+    return TLAB_OK;
+}
+
+int tlab_sync(void) {
+    return guarded([&] { hip_check(hipStreamSynchronize(g_stream), "hipStreamSynchronize"); });
+}
+
+int tlab_malloc(void **p, size_t bytes) {
+    return guarded([&] { hip_check(hipMalloc(p, bytes), "hipMalloc"); });
+}
+int tlab_free(void *p) {
+    return guarded([&] { hip_check(hipFree(p), "hipFree"); });
+}
+int tlab_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    return guarded([&] {
+        hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream), "hipMemcpy h2d");
+        hip_check(hipStreamSynchronize(g_stream), "sync");
+    });
+}
+int tlab_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    return guarded([&] {
+        hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream), "hipMemcpy d2h");
+        hip_check(hipStreamSynchronize(g_stream), "sync");
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// plans
+// ------------------------------------------------------------------------------------------------
+int tlab_fdm_plan_create(tlab_fdm_plan_t *out, int n, const double *nodes, int periodic, int uniform, int scheme1,
+                         int scheme2, double hyper_bc1_ext) {
+    return guarded([&] {
+        if (!out || !nodes || n < 1) throw Invalid("tlab_fdm_plan_create: bad arguments");
+        if (periodic && !uniform) throw Invalid("grid must be uniform in a periodic direction (fdm.f90:117-120)");
+        if (n > 1 && n < 8) throw Invalid("tlab_fdm_plan_create: a direction needs 1 or >= 8 points");
+        auto p = std::make_unique<tlab_fdm_plan>();
+        try {
+            fdm_create_plan(p->t, n, nodes, periodic != 0, uniform != 0, scheme1, scheme2, hyper_bc1_ext);
+        } catch (const std::runtime_error &e) {
+            throw Unsupported(e.what());
+        }
+        *out = p.release();
+    });
+}
+
+int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, int need_1der, int ndl1, int ndr1,
+                                     const double *lhs1, const double *rhs1, int ndl2, int ndr2, const double *lhs2,
+                                     const double *rhs2) {
+    return guarded([&] {
+        if (!out || n < 8 || !lhs1 || !rhs1 || !lhs2 || !rhs2) throw Invalid("tlab_fdm_plan_create_from_arrays: bad arguments");
+        if (ndl1 != 3 || ndl2 != 3) throw Unsupported("only tridiagonal LHS schemes are built (CompactJacobian6Penta is not)");
+        if ((ndr1 != 3 && ndr1 != 5) || (ndr2 != 5 && ndr2 != 7)) throw Unsupported("unsupported number of RHS diagonals");
+        auto p = std::make_unique<tlab_fdm_plan>();
+        FdmTables &t = p->t;
+        t.n = n; t.periodic = periodic != 0; t.uniform = !need_1der;
+        for (DerTables *d : {&t.der1, &t.der2}) { d->n = n; d->periodic = t.periodic; d->lhs.assign((size_t)n * 5, 0.0); d->mwn.assign(n, 0.0); }
+        t.der1.ndl = 3; t.der1.ndr = ndr1; t.der1.rhs_cols = 7; t.der1.rhs.assign((size_t)n * 7, 0.0);
+        t.der2.ndl = 3; t.der2.ndr = ndr2; t.der2.rhs_cols = 12; t.der2.rhs.assign((size_t)n * 12, 0.0);
+        t.der2.need_1der = need_1der != 0;
+        std::copy(lhs1, lhs1 + (size_t)n * 3, t.der1.lhs.begin());
+        std::copy(rhs1, rhs1 + (size_t)n * ndr1, t.der1.rhs.begin());
+        std::copy(lhs2, lhs2 + (size_t)n * 3, t.der2.lhs.begin());
+        std::copy(rhs2, rhs2 + (size_t)n * (ndr2 + 3), t.der2.rhs.begin());
+        *out = p.release();
+    });
+}
+
+int tlab_fdm_plan_destroy(tlab_fdm_plan_t p) {
+    delete p;
+    return TLAB_OK;
+}
+
+int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what) {
+    if (!p) return TLAB_EINVAL;
+    switch (what) {
+    case 0: return p->t.n;
+    case 1: return p->t.der1.ndl;
+    case 2: return p->t.der1.ndr;
+    case 3: return p->t.der2.ndl;
+    case 4: return p->t.der2.ndr;
+    case 5: return p->t.der2.need_1der ? 1 : 0;
+    case 6: return p->t.periodic ? 1 : 0;
+    }
+    return TLAB_EINVAL;
+}
+
+int tlab_fdm_plan_get(tlab_fdm_plan_t p, int which, double *buf, int nbuf) {
+    if (!p || !buf) return TLAB_EINVAL;
+    const FdmTables &t = p->t;
+    const double *src = nullptr;
+    size_t m = 0;
+    switch (which) {
+    case 1: src = t.der1.lhs.data(); m = t.der1.lhs.size(); break;
+    case 2: src = t.der1.rhs.data(); m = t.der1.rhs.size(); break;
+    case 3: src = t.der1.lu.data(); m = t.der1.lu.size(); break;
+    case 4: src = t.der1.rhs_b; m = 32; break;
+    case 5: src = t.der1.rhs_t; m = 35; break;
+    case 6: src = t.der1.mwn.data(); m = t.der1.mwn.size(); break;
+    case 7: src = t.der2.lhs.data(); m = t.der2.lhs.size(); break;
+    case 8: src = t.der2.rhs.data(); m = t.der2.rhs.size(); break;
+    case 9: src = t.der2.lu.data(); m = t.der2.lu.size(); break;
+    case 10: src = t.der2.mwn.data(); m = t.der2.mwn.size(); break;
+    case 11: src = t.jac.data(); m = t.jac.size(); break;
+    default: return TLAB_EINVAL;
+    }
+    if ((size_t)nbuf < m) return TLAB_EINVAL;
+    std::copy(src, src + m, buf);
+    return (int)m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// operators
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+LineGeom make_geom(int dir, int nx, int ny, int nz) {
+    LineGeom g;
+    const long long ntot = (long long)nx * ny * nz;
+    if (dir == 1) { g.n = nx; g.row_stride = 1; g.lines_inner = 1; g.outer_stride = nx; }
+    else if (dir == 2) { g.n = ny; g.row_stride = nx; g.lines_inner = nx; g.outer_stride = (long long)nx * ny; }
+    else { g.n = nz; g.row_stride = (long long)nx * ny; g.lines_inner = nx * ny; g.outer_stride = 0; }
+    g.nlines = ntot / g.n;
+    return g;
+}
+
+enum { PATH_GENERIC = 1, PATH_XLINE = 2, PATH_RTILE = 3 };
+
+int choose_path(int dir, int n) {
+    int path = PATH_GENERIC;
+    if (dir == 1 && xline_supported(n)) path = PATH_XLINE;
+    if (dir != 1 && rtile_chunk(n) > 0) path = PATH_RTILE;
+    if (g_force_path == PATH_GENERIC) path = PATH_GENERIC;
+    if (g_force_path == PATH_RTILE && rtile_chunk(n) > 0 && dir != 1) path = PATH_RTILE;
+    return path;
+}
+
+void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, const double *in0, const double *d1in,
+                 double *out) {
+    GenericArgs a;
+    a.in0 = in0; a.in1 = d1in; a.out0 = out; a.g = geom;
+    a.s = g->stencil(which, ibc);
+    a.y = g->system(which, ibc, 1).dev();
+    a.jc = (which == 2 && d1in) ? g->jaccorr() : JacCorrDev{nullptr};
+    hip_check(launch_generic(which == 2, a, g_stream), "k_generic");
+}
+
+void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *in1,
+               const double *in2, double *out, double nu) {
+    const int P = geom.n / rtile_chunk(geom.n);
+    RTileArgs a;
+    a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.g = geom; a.nu = nu;
+    a.s1 = g->stencil(1, ibc);
+    a.s2 = g->stencil(2, 0);
+    a.y1 = g->system(1, ibc, P).dev();
+    a.y2 = g->system(2, 0, P).dev();
+    a.jc = (mode == MODE_P2_D1IN || mode == MODE_BURGERS_D1IN) ? g->jaccorr() : JacCorrDev{nullptr};
+    hip_check(launch_rtile(mode, a, g_stream), "k_rtile");
+}
+
+void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *in1,
+               double *out0, double *out1, double nu) {
+    XLineArgs a;
+    a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1; a.nlines = geom.nlines; a.nu = nu;
+    a.s1 = g->stencil(1, ibc);
+    a.s2 = g->stencil(2, 0);
+    SystemEntry &e1 = g->system(1, ibc, 64), &e2 = g->system(2, 0, 64);
+    a.y1 = e1.dev();
+    a.y2 = e2.dev();
+    const bool lv = !(e1.lane_invariant && e2.lane_invariant);
+    hip_check(launch_xline(mode, geom.n, lv, a, g_stream), "k_xline");
+}
+
+void check_common(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc) {
+    if (!g) throw Invalid("null plan");
+    if (dir < 1 || dir > 3) throw Invalid("dir must be 1, 2 or 3");
+    if (nx < 1 || ny < 1 || nz < 1) throw Invalid("bad sizes");
+    if ((long long)nx * ny * nz > 2147483647LL) throw Invalid("local field exceeds int32 indexing (reference limit, tlab_memory.f90:175)");
+    if (ibc < 0 || ibc > 3) throw Invalid("ibc must be 0..3");
+    const int n = (dir == 1) ? nx : (dir == 2) ? ny : nz;
+    if (g->t.n != n) throw Invalid("plan size does not match the field size along dir");
+    if (g_device < 0) throw HipError("tlab_init has not been called (no CPU fallback exists)");
+}
+
+}  // namespace
+
+extern "C" {
+
+int tlab_last_kernel_path(void) { return g_last_path; }
+int tlab_force_kernel_path(int path) {
+    g_force_path = path;
+    return TLAB_OK;
+}
+int tlab_set_tuning(int key, int value) {
+    if (key == 1) { rtile_force_chunk(value); return TLAB_OK; }
+    g_err = "tlab_set_tuning: unknown key";
+    return TLAB_EINVAL;
+}
+
+int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int nz, int ibc, const double *u,
+                     double *result, double *tmp1) {
+    return guarded([&] {
+        check_common(dir, g, nx, ny, nz, ibc);
+        if (type != TLAB_OPR_P1 && type != TLAB_OPR_P2 && type != TLAB_OPR_P2_P1)
+            throw Unsupported("OPR_Partial type not built on the device (interpolation / IBM variants stay on the CPU path)");
+        if (!u || !result || u == result || (tmp1 && (tmp1 == u || tmp1 == result))) throw Invalid("u, result, tmp1 must be distinct");
+        const long long ntot = (long long)nx * ny * nz;
+        const LineGeom geom = make_geom(dir, nx, ny, nz);
+        if (geom.n == 1) {  // 2-D guard (opr_partial.f90:175-177, :287-289)
+            hip_check(launch_fill(result, 0.0, ntot, g_stream), "fill");
+            if (type == TLAB_OPR_P2_P1 && tmp1) hip_check(launch_fill(tmp1, 0.0, ntot, g_stream), "fill");
+            return;
+        }
+        const bool corr = g->t.der2.need_1der;
+        if (type == TLAB_OPR_P2_P1 && !tmp1) throw Invalid("OPR_P2_P1 needs tmp1");
+        if (type == TLAB_OPR_P2 && corr && !tmp1) throw Invalid("OPR_P2 on a non-uniform grid needs tmp1 (opr_partial.f90:96)");
+        int path = choose_path(dir, geom.n);
+        if (path == PATH_XLINE && corr && type != TLAB_OPR_P1) path = PATH_GENERIC;  // non-uniform x: rare, generic kernel
+        g_last_path = path;
+        if (path == PATH_XLINE) {
+            const int mode = (type == TLAB_OPR_P1) ? MODE_P1 : (type == TLAB_OPR_P2) ? MODE_P2 : MODE_P2_P1;
+            run_xline(g, geom, mode, ibc, u, nullptr, result, tmp1, 0.0);
+        } else if (path == PATH_RTILE) {
+            if (type == TLAB_OPR_P1) {
+                run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0);
+            } else {
+                const bool need_d1 = corr || type == TLAB_OPR_P2_P1;
+                if (need_d1) run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, tmp1, 0.0);
+                if (corr) run_rtile(g, geom, MODE_P2_D1IN, ibc, u, tmp1, nullptr, result, 0.0);
+                else run_rtile(g, geom, MODE_P2, ibc, u, nullptr, nullptr, result, 0.0);
+            }
+        } else {
+            if (type == TLAB_OPR_P1) {
+                run_generic(g, geom, 1, ibc, u, nullptr, result);
+            } else {
+                const bool need_d1 = corr || type == TLAB_OPR_P2_P1;
+                if (need_d1) run_generic(g, geom, 1, ibc, u, nullptr, tmp1);
+                run_generic(g, geom, 2, 0, u, corr ? tmp1 : nullptr, result);
+            }
+        }
+    });
+}
+
+int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int nz, int ibc, double nu, const double *s,
+                     const double *u, double *result, double *tmp1, int write_transposed) {
+    return guarded([&] {
+        check_common(dir, g, nx, ny, nz, ibc);
+        if (ivel != TLAB_OPR_B_SELF && ivel != TLAB_OPR_B_U_IN) throw Invalid("ivel must be OPR_B_SELF or OPR_B_U_IN");
+        if (!s || !result || !tmp1 || s == result || tmp1 == s || tmp1 == result) throw Invalid("s, result, tmp1 must be distinct");
+        const double *vel = (ivel == TLAB_OPR_B_SELF) ? s : u;
+        if (!vel || vel == result || vel == tmp1) throw Invalid("velocity must not alias result / tmp1");
+        const long long ntot = (long long)nx * ny * nz;
+        const LineGeom geom = make_geom(dir, nx, ny, nz);
+        if (geom.n == 1) {  // opr_burgers.f90:207-210
+            hip_check(launch_fill(result, 0.0, ntot, g_stream), "fill");
+            return;
+        }
+        const bool corr = g->t.der2.need_1der;
+        const bool wt = write_transposed && ivel == TLAB_OPR_B_SELF && (dir == 1 || (dir == 2 && nz > 1));
+        double *d1 = wt ? workspace((size_t)ntot) : tmp1;
+        int path = choose_path(dir, geom.n);
+        if (path == PATH_XLINE && corr) path = PATH_GENERIC;
+        g_last_path = path;
+        if (path == PATH_XLINE) {
+            run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu);
+        } else if (path == PATH_RTILE) {
+            run_rtile(g, geom, MODE_P1, ibc, s, nullptr, nullptr, d1, 0.0);
+            run_rtile(g, geom, MODE_BURGERS_D1IN, ibc, s, d1, vel, result, nu);
+        } else {
+            run_generic(g, geom, 1, ibc, s, nullptr, d1);
+            run_generic(g, geom, 2, 0, s, corr ? d1 : nullptr, result);
+            hip_check(launch_burgers_epilogue(result, vel, d1, nu, ntot, g_stream), "burgers epilogue");
+        }
+        if (wt) {  // transposed operand exactly as the reference leaves it in tmp1 (opr_burgers.f90:250, :315)
+            if (dir == 1) hip_check(launch_transpose(s, tmp1, nx, ny * nz, g_stream), "transpose");
+            else hip_check(launch_transpose(s, tmp1, nx * ny, nz, g_stream), "transpose");
+        }
+    });
+}
+
+int tlab_transpose(const double *a, int nra, int nca, double *b) {
+    return guarded([&] {
+        if (!a || !b || a == b || nra < 1 || nca < 1) throw Invalid("tlab_transpose: bad arguments");
+        if (g_device < 0) throw HipError("tlab_init has not been called");
+        hip_check(launch_transpose(a, b, nra, nca, g_stream), "transpose");
+    });
+}
+
+int tlab_debug_host_chunked_solve(tlab_fdm_plan_t p, int which, int ibc, int chunks, double *f) {
+    return guarded([&] {
+        if (!p || !f || (which != 1 && which != 2)) throw Invalid("bad arguments");
+        TriDiag T = p->tridiag(which, (which == 2 || p->t.der1.periodic) ? 0 : ibc);
+        ChunkedTables t;
+        build_chunked(T, chunks, t);
+        chunked_solve_host(t, f, chunks == 64);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Host-side (init-time) construction of Tlab's compact finite-difference plans.
+// C++ restatement of fdm/fdm.f90, fdm_derivative.f90, fdm_com{1,2}_jacobian.f90, fdm_base.f90 (FDM_Bcs_Neumann)
+// and utils/linear3.f90 (TRIDFS/TRIDPFS).  Tables keep the reference's column-major (row, diagonal) layout:
+// T(i, k) == t[i + n*k] with 0-based i, k, so they can be compared with, or taken from, the Fortran host.
+#pragma once
+#include <vector>
+
+namespace tlab {
+
+enum { BCS_PERIODIC = -1, BCS_DD = 0, BCS_ND = 1, BCS_DN = 2, BCS_NN = 3 };
+enum { FDM_COM4_JACOBIAN = 4, FDM_COM6_JACOBIAN_PENTA = 5, FDM_COM6_JACOBIAN = 6, FDM_COM6_JACOBIAN_HYPER = 7,
+       FDM_COM6_DIRECT = 16, FDM_COM4_DIRECT = 17 };
+
+// type(fdm_derivative_dt), fdm/fdm_derivative.f90:16-29
+struct DerTables {
+    int mode_fdm = 0;
+    int n = 0;
+    bool periodic = false;
+    bool need_1der = false;
+    int ndl = 0, ndr = 0;              // nb_diag(1), nb_diag(2)
+    std::vector<double> lhs;           // (n,5)
+    std::vector<double> rhs;           // (n,7) first derivative, (n,12) second derivative
+    int rhs_cols = 0;
+    std::vector<double> mwn;           // (n)
+    std::vector<double> lu;            // (n, lu_cols)
+    int lu_cols = 0;
+    double rhs_b[4 * 8];               // rhs_b(4,0:7): [ (j-1) + 4*c ]
+    double rhs_t[5 * 7];               // rhs_t(0:4,7): [ r + 5*(c-1) ]
+    DerTables();
+};
+
+// type(fdm_dt), fdm/fdm.f90:14-29
+struct FdmTables {
+    int n = 0;
+    bool periodic = false, uniform = false;
+    std::vector<double> nodes;         // (n)
+    std::vector<double> jac;           // (n,3)
+    DerTables der1, der2;
+};
+
+// utils/linear3.f90:29-51, :269-316
+void tridfs(int nmax, double *a, double *b, double *c);
+void tridpfs(int nmax, double *a, double *b, double *c, double *d, double *e);
+// utils/linear3.f90:56-150, :321-442 for a single line (used for the Jacobian at plan creation, fdm.f90:201,224)
+void tridss1(int nmax, const double *a, const double *b, const double *c, double *f);
+
+// fdm/fdm_base.f90:194-300
+void fdm_bcs_neumann(int ibc, int n, int ndl, double *lhs /*(n,ndl)*/, int ndr, const double *rhs /*(n,>=ndr) ld n*/,
+                     double *rhs_b, double *rhs_t);
+
+// fdm/fdm_derivative.f90:63-142, :282-333 (CreateSystem + LU)
+void der1_initialize(DerTables &g, int n, const double *dx, bool periodic, const int *bcs_cases, int ncases);
+void der2_initialize(DerTables &g, int n, const double *dx2 /*(n,2)*/, bool periodic, bool uniform, double hyper_bc1_ext);
+
+// RHS product B*u for one line, reference operation order (fdm/fdm_matmul.f90); used at plan creation only
+void der1_matmul1(const DerTables &g, int ibc, const double *u, double *f);
+void der2_matmul1(const DerTables &g, int ibc, const double *u, double *f);
+
+// fdm/fdm.f90:143-252
+void fdm_create_plan(FdmTables &g, int n, const double *nodes, bool periodic, bool uniform, int mode1, int mode2,
+                     double hyper_bc1_ext);
+
+}  // namespace tlab

@@ -1,0 +1,538 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for Tlab's compact-FDM derivative operators.
+//
+// All kernels solve  A x = B u  per grid line, A tridiagonal (cyclic when periodic), B banded, with the
+// chunked factorization of chunked.hpp so that a line is read once and written once:
+//
+//  k_xline  : derivative along the contiguous index (OPR_Partial_X / OPR_Burgers_X).  One WAVE per line:
+//             lane l holds the M = n/64 consecutive points [l*M, (l+1)*M) in registers (coalesced 16-B loads),
+//             stencil halos come from the neighbouring lanes, the 64-unknown separator system is solved by
+//             parallel cyclic reduction with wave shuffles.  No LDS traffic for periodic (circulant) systems.
+//  k_rtile  : derivative along a strided index (Y, Z).  One WORKGROUP per tile of 64 lines x n points:
+//             lanes <-> 64 memory-contiguous lines (512-B coalesced rows), wave w holds rows [w*M, (w+1)*M) in
+//             registers, coefficient rows are wave-uniform scalar loads, the P x P separator system goes through LDS.
+//  k_generic: any n, any direction, one thread per line, three sweeps through the output array (fallback).
+//
+// The reference path these replace: TLab_Transpose + MatMul_* + TRIDSS/TRIDPSS.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "device_tables.hpp"
+#include "kernels.hpp"
+
+namespace tlab {
+
+// --------------------------------------------------------------------------------------------
+// helpers
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+template <bool SYM>
+__device__ __forceinline__ double stencil_interior(const StencilDev &s, double um3, double um2, double um1, double u0,
+                                                   double up1, double up2, double up3) {
+    if (SYM)  // MatMul_7d_sym / 5d_sym interior, fdm_matmul.f90:608-612 / :460-463 (c3 = 0)
+        return s.c0 * u0 + up1 + um1 + s.c2 * (up2 + um2) + s.c3 * (up3 + um3);
+    else      // MatMul_5d_antisym / 3d_antisym interior, fdm_matmul.f90:396-398 / :190-192 (c2 = 0)
+        return up1 - um1 + s.c2 * (up2 - um2);
+}
+
+__device__ __forceinline__ double dense6(const double (&c)[6], double a0, double a1, double a2, double a3, double a4, double a5) {
+    return a0 * c[0] + a1 * c[1] + a2 * c[2] + a3 * c[3] + a4 * c[4] + a5 * c[5];
+}
+
+// ============================================================================================
+// k_xline : one wave per line, lane-chunked
+// ============================================================================================
+struct XSys {                    // per-wave view of one chunked system
+    const double *rowtab;        // global [5][n]
+    const double *lds;           // LV: [5][M][64] in LDS
+    double k1[6], k2[6], dinv;   // PCR coefficients of this lane
+    double a_s, c_s;             // separator-row couplings of this lane
+};
+
+template <int M, bool LV>
+__device__ __forceinline__ double xcoef(const XSys &y, int tab, int p, int lane, int n) {
+    if (LV) return y.lds[(tab * M + p) * 64 + lane];
+    return y.rowtab[tab * n + p];  // lane-invariant: chunk 0's row p, wave-uniform address -> scalar load
+}
+
+template <int M, bool LV>
+__device__ __forceinline__ void xsys_init(XSys &y, const SystemDev &sd, const double *lds, int lane, int n) {
+    y.rowtab = sd.rowtab;
+    y.lds = lds;
+    const int src = LV ? lane : 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        y.k1[s] = sd.red[s * 64 + src];
+        y.k2[s] = sd.red[(6 + s) * 64 + src];
+    }
+    y.dinv = sd.red[12 * 64 + src];
+    y.a_s = sd.rowtab[0 * n + (LV ? lane * M : 0)];
+    y.c_s = sd.rowtab[2 * n + (LV ? lane * M : 0)];
+}
+
+// f[0..M-1] (this lane's chunk of the right-hand side) -> solution, in place
+template <int M, bool LV>
+__device__ __forceinline__ void xsolve(double (&f)[M], const XSys &y, int lane, int n) {
+    double g = 0.0;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        g = f[p] + xcoef<M, LV>(y, 0, p, lane, n) * g;
+        f[p] = g;
+    }
+    double yn = 0.0;
+#pragma unroll
+    for (int p = M - 1; p >= 1; --p) {
+        yn = f[p] * xcoef<M, LV>(y, 1, p, lane, n) + xcoef<M, LV>(y, 2, p, lane, n) * yn;
+        f[p] = yn;
+    }
+    const double yLprev = shfl_d(f[M - 1], (lane + 63) & 63);
+    double r = f[0] - y.a_s * yLprev - y.c_s * f[1];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int d = 1 << s;
+        const double rl = shfl_d(r, (lane - d) & 63);
+        const double rr = shfl_d(r, (lane + d) & 63);
+        r = r - y.k1[s] * rl - y.k2[s] * rr;
+    }
+    const double X = r * y.dinv;
+    const double Xr = shfl_d(X, (lane + 1) & 63);
+    f[0] = X;
+#pragma unroll
+    for (int p = 1; p < M; ++p) f[p] = f[p] + xcoef<M, LV>(y, 3, p, lane, n) * X + xcoef<M, LV>(y, 4, p, lane, n) * Xr;
+}
+
+// f = B u for this lane's chunk; um/up are the 3-point halos from the neighbouring lanes
+template <int M, bool SYM>
+__device__ __forceinline__ void xstencil(double (&f)[M], const double (&u)[M], const double (&um)[3], const double (&up)[3],
+                                         const StencilDev &s, int lane) {
+    double e[M + 6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e[k] = um[k]; e[M + 3 + k] = up[k]; }
+#pragma unroll
+    for (int p = 0; p < M; ++p) e[p + 3] = u[p];
+#pragma unroll
+    for (int p = 0; p < M; ++p) f[p] = stencil_interior<SYM>(s, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+    if (!s.periodic) {
+        // boundary closures: the six dense rows are computed wave-uniformly from broadcast values and
+        // selected into the owning lane/register (rows 0..2 and n-3..n-1).
+        constexpr int N = 64 * M;
+        double ub[6], ut[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            ub[k] = shfl_d(u[k % M], k / M);
+            ut[k] = shfl_d(u[(N - 6 + k) % M], (N - 6 + k) / M);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double vb = dense6(s.bb[r], ub[0], ub[1], ub[2], ub[3], ub[4], ub[5]);
+            const double vt = dense6(s.bt[r], ut[0], ut[1], ut[2], ut[3], ut[4], ut[5]);
+            if (lane == r / M) f[r % M] = vb;
+            if (lane == (N - 3 + r) / M) f[(N - 3 + r) % M] = vt;
+        }
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void xload(double (&u)[M], const double *__restrict__ p) {
+#pragma unroll
+    for (int q = 0; q < M / 2; ++q) {
+        const double2 v = reinterpret_cast<const double2 *>(p)[q];
+        u[2 * q] = v.x;
+        u[2 * q + 1] = v.y;
+    }
+}
+template <int M>
+__device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)[M]) {
+#pragma unroll
+    for (int q = 0; q < M / 2; ++q) reinterpret_cast<double2 *>(p)[q] = make_double2(u[2 * q], u[2 * q + 1]);
+}
+
+template <int M, int MODE, bool LV>
+__global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
+    extern __shared__ double xlds[];
+    constexpr bool NEED1 = (MODE != MODE_P2);
+    constexpr bool NEED2 = (MODE != MODE_P1);
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int n = 64 * M;
+
+    if (LV) {  // lane-variant tables (non-periodic): stage [5][M][64] per system in LDS once per block
+        for (int idx = threadIdx.x; idx < 5 * M * 64; idx += blockDim.x) {
+            const int l = idx & 63, p = (idx >> 6) % M, tab = idx / (64 * M);
+            if (NEED1) xlds[idx] = a.y1.rowtab[tab * n + l * M + p];
+            if (NEED2) xlds[5 * M * 64 + idx] = a.y2.rowtab[tab * n + l * M + p];
+        }
+        __syncthreads();
+    }
+    XSys y1, y2;
+    if (NEED1) xsys_init<M, LV>(y1, a.y1, xlds, lane, n);
+    if (NEED2) xsys_init<M, LV>(y2, a.y2, xlds + 5 * M * 64, lane, n);
+
+    const long long stride = (long long)gridDim.x * 4;
+    for (long long line = (long long)blockIdx.x * 4 + wib; line < a.nlines; line += stride) {
+        const long long off = line * n + lane * M;
+        double u[M];
+        xload<M>(u, a.in0 + off);
+        double um[3], up[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            um[k] = shfl_d(u[M - 3 + k], (lane + 63) & 63);
+            up[k] = shfl_d(u[k], (lane + 1) & 63);
+        }
+        double x1[M], x2[M];
+        if (NEED1) {
+            xstencil<M, false>(x1, u, um, up, a.s1, lane);
+            xsolve<M, LV>(x1, y1, lane, n);
+        }
+        if (NEED2) {
+            xstencil<M, true>(x2, u, um, up, a.s2, lane);
+            xsolve<M, LV>(x2, y2, lane, n);
+        }
+        if (MODE == MODE_P1) {
+            xstore<M>(a.out0 + off, x1);
+        } else if (MODE == MODE_P2) {
+            xstore<M>(a.out0 + off, x2);
+        } else if (MODE == MODE_P2_P1) {
+            xstore<M>(a.out0 + off, x2);
+            xstore<M>(a.out1 + off, x1);
+        } else {  // MODE_BURGERS: result = nu d2 - vel d1   (opr_burgers.f90:513)
+            double v[M];
+            xload<M>(v, a.in1 + off);
+#pragma unroll
+            for (int p = 0; p < M; ++p) x2[p] = a.nu * x2[p] - v[p] * x1[p];
+            xstore<M>(a.out0 + off, x2);
+        }
+    }
+}
+
+// ============================================================================================
+// k_rtile : one workgroup per 64-line tile, wave-chunked, data in registers
+// ============================================================================================
+template <int M, int MODE, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
+    __shared__ double s_yl[16 * 64];
+    __shared__ double s_r[16 * 64];
+    constexpr bool SECOND = (MODE != MODE_P1);  // which operator this launch solves
+    constexpr bool D1IN = (MODE == MODE_P2_D1IN || MODE == MODE_BURGERS_D1IN);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int P = blockDim.x >> 6;
+    const int n = a.g.n;
+    const long long rs = a.g.row_stride;
+    const StencilDev &st = SECOND ? a.s2 : a.s1;
+    const SystemDev &sy = SECOND ? a.y2 : a.y1;
+
+    const int tiles_inner = (a.g.lines_inner + 63) >> 6;
+    const long long outer = blockIdx.x / tiles_inner;
+    const int l0 = (int)(blockIdx.x % tiles_inner) << 6;
+    const bool valid = (l0 + lane) < a.g.lines_inner;
+    const long long base = outer * a.g.outer_stride + l0 + lane;
+    const int row0 = w * M;
+    const bool per = st.periodic != 0;
+
+    // ---- load this wave's M rows + 3-row halos (coalesced 512-B rows) ----
+    double e[M + 6];
+#pragma unroll
+    for (int p = 0; p < M; ++p) e[p + 3] = valid ? a.in0[base + (long long)(row0 + p) * rs] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int rl = row0 - 3 + k, rr = row0 + M + k;
+        const bool okl = per || rl >= 0, okr = per || rr < n;
+        if (rl < 0) rl += n;
+        if (rr >= n) rr -= n;
+        e[k] = (valid && okl) ? a.in0[base + (long long)rl * rs] : 0.0;
+        e[M + 3 + k] = (valid && okr) ? a.in0[base + (long long)rr * rs] : 0.0;
+    }
+
+    // ---- right-hand side ----
+    double f[M];
+#pragma unroll
+    for (int p = 0; p < M; ++p) f[p] = stencil_interior<SECOND>(st, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+    if (!per) {
+        if (w == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) f[r] = dense6(st.bb[r], e[3], e[4], e[5], e[6], e[7], e[8]);
+        }
+        if (w == P - 1) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) f[M - 3 + r] = dense6(st.bt[r], e[M - 3], e[M - 2], e[M - 1], e[M], e[M + 1], e[M + 2]);
+        }
+    }
+    if (D1IN && a.jc.j != nullptr) {
+        // Jacobian correction f += A2 dx2 du (MatMul_3d_add, fdm_matmul.f90:126-153); du is read from in1
+        const double *j1 = a.jc.j, *j2 = a.jc.j + n, *j3 = a.jc.j + 2 * n;
+        double dprev, dcur, dnext;
+        {
+            int rm = row0 - 1;
+            const bool ok = rm >= 0;
+            if (rm < 0) rm = 0;
+            dprev = (valid && ok) ? a.in1[base + (long long)rm * rs] : 0.0;
+            dcur = valid ? a.in1[base + (long long)row0 * rs] : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < M; ++p) {
+            int rn = row0 + p + 1;
+            const bool ok = rn < n;
+            if (rn >= n) rn = n - 1;
+            dnext = (valid && ok) ? a.in1[base + (long long)rn * rs] : 0.0;
+            const int row = row0 + p;
+            double add = dprev * j1[row] + dcur * j2[row] + dnext * j3[row];
+            if (row == 0) {  // extended stencil: r1(1) multiplies du(3)
+                const double d2v = valid ? a.in1[base + 2 * rs] : 0.0;
+                add = dcur * j2[0] + dnext * j3[0] + d2v * j1[0];
+            }
+            if (row == n - 1) {  // extended stencil: r3(n) multiplies du(n-2)
+                const double d3v = valid ? a.in1[base + (long long)(n - 3) * rs] : 0.0;
+                add = d3v * j3[n - 1] + dprev * j1[n - 1] + dcur * j2[n - 1];
+            }
+            f[p] = f[p] + add;
+            dprev = dcur;
+            dcur = dnext;
+        }
+    }
+
+    // ---- local Thomas solve of the interior rows; coefficient rows are wave-uniform (scalar loads) ----
+    const double *Lm = sy.rowtab + row0, *Di = sy.rowtab + n + row0, *Cm = sy.rowtab + 2 * n + row0;
+    const double *Vt = sy.rowtab + 3 * n + row0, *Wt = sy.rowtab + 4 * n + row0;
+    double g = 0.0;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        g = f[p] + Lm[p] * g;
+        f[p] = g;
+    }
+    double yn = 0.0;
+#pragma unroll
+    for (int p = M - 1; p >= 1; --p) {
+        yn = f[p] * Di[p] + Cm[p] * yn;
+        f[p] = yn;
+    }
+    // ---- separator system through LDS ----
+    s_yl[w * 64 + lane] = f[M - 1];
+    __syncthreads();
+    const int wm = (w + P - 1) % P, wp = (w + 1) % P;
+    const double yLprev = s_yl[wm * 64 + lane];
+    s_r[w * 64 + lane] = f[0] - Lm[0] * yLprev - Cm[0] * f[1];
+    __syncthreads();
+    double X = 0.0, Xr = 0.0;
+    for (int q = 0; q < P; ++q) {
+        const double rq = s_r[q * 64 + lane];
+        X += sy.red[w * P + q] * rq;
+        Xr += sy.red[wp * P + q] * rq;
+    }
+    f[0] = X;
+#pragma unroll
+    for (int p = 1; p < M; ++p) f[p] = f[p] + Vt[p] * X + Wt[p] * Xr;
+
+    // ---- epilogue ----
+    if (MODE == MODE_BURGERS_D1IN) {
+#pragma unroll
+        for (int p = 0; p < M; ++p) {
+            const long long idx = base + (long long)(row0 + p) * rs;
+            if (valid) a.out0[idx] = a.nu * f[p] - a.in2[idx] * a.in1[idx];
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < M; ++p)
+            if (valid) a.out0[base + (long long)(row0 + p) * rs] = f[p];
+    }
+}
+
+// ============================================================================================
+// k_generic : any n, one thread per line, single-chunk tables (P = 1), three sweeps through out
+// ============================================================================================
+template <bool SYM>
+__device__ __forceinline__ double generic_rhs_row(const double *__restrict__ u, long long base, long long rs, int i, int n,
+                                                  const StencilDev &s) {
+    if (s.periodic) {
+        auto at = [&](int k) {
+            int r = i + k;
+            if (r < 0) r += n;
+            if (r >= n) r -= n;
+            return u[base + (long long)r * rs];
+        };
+        return stencil_interior<SYM>(s, at(-3), at(-2), at(-1), at(0), at(1), at(2), at(3));
+    }
+    if (i < 3) return dense6(s.bb[i], u[base], u[base + rs], u[base + 2 * rs], u[base + 3 * rs], u[base + 4 * rs], u[base + 5 * rs]);
+    if (i >= n - 3) {
+        const long long b6 = base + (long long)(n - 6) * rs;
+        return dense6(s.bt[i - (n - 3)], u[b6], u[b6 + rs], u[b6 + 2 * rs], u[b6 + 3 * rs], u[b6 + 4 * rs], u[b6 + 5 * rs]);
+    }
+    const long long c = base + (long long)i * rs;
+    return stencil_interior<SYM>(s, u[c - 3 * rs], u[c - 2 * rs], u[c - rs], u[c], u[c + rs], u[c + 2 * rs], u[c + 3 * rs]);
+}
+
+__device__ __forceinline__ double generic_jc_row(const double *__restrict__ du, long long base, long long rs, int i, int n, const double *j) {
+    const double *j1 = j, *j2 = j + n, *j3 = j + 2 * n;
+    if (i == 0) return du[base] * j2[0] + du[base + rs] * j3[0] + du[base + 2 * rs] * j1[0];
+    if (i == n - 1)
+        return du[base + (long long)(n - 3) * rs] * j3[i] + du[base + (long long)(n - 2) * rs] * j1[i] + du[base + (long long)(n - 1) * rs] * j2[i];
+    const long long c = base + (long long)i * rs;
+    return du[c - rs] * j1[i] + du[c] * j2[i] + du[c + rs] * j3[i];
+}
+
+template <bool SYM>
+__global__ void __launch_bounds__(256) k_generic(GenericArgs a) {
+    const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.g.nlines) return;
+    const int n = a.g.n;
+    const long long rs = a.g.row_stride;
+    const long long base = (l / a.g.lines_inner) * a.g.outer_stride + (l % a.g.lines_inner) * (a.g.lines_inner == 1 ? 0 : 1);
+    const double *Lm = a.y.rowtab, *Di = a.y.rowtab + n, *Cm = a.y.rowtab + 2 * n, *Vt = a.y.rowtab + 3 * n, *Wt = a.y.rowtab + 4 * n;
+    const bool jc = a.jc.j != nullptr;
+
+    double f0 = generic_rhs_row<SYM>(a.in0, base, rs, 0, n, a.s);
+    if (jc) f0 += generic_jc_row(a.in1, base, rs, 0, n, a.jc.j);
+    double g = 0.0;
+    for (int i = 1; i < n; ++i) {
+        double fi = generic_rhs_row<SYM>(a.in0, base, rs, i, n, a.s);
+        if (jc) fi += generic_jc_row(a.in1, base, rs, i, n, a.jc.j);
+        g = fi + Lm[i] * g;
+        a.out0[base + (long long)i * rs] = g;
+    }
+    double yn = 0.0, y1 = 0.0, ylast = 0.0;
+    for (int i = n - 1; i >= 1; --i) {
+        yn = a.out0[base + (long long)i * rs] * Di[i] + Cm[i] * yn;
+        a.out0[base + (long long)i * rs] = yn;
+        if (i == n - 1) ylast = yn;
+        if (i == 1) y1 = yn;
+    }
+    const double X = (f0 - Lm[0] * ylast - Cm[0] * y1) * a.y.red[0];
+    a.out0[base] = X;
+    for (int i = 1; i < n; ++i) {
+        const long long idx = base + (long long)i * rs;
+        a.out0[idx] = a.out0[idx] + Vt[i] * X + Wt[i] * X;
+    }
+}
+
+// ============================================================================================
+// pointwise / data-movement kernels
+// ============================================================================================
+// out = nu * out - vel * d1   (OPR_Burgers_1D epilogue, opr_burgers.f90:510-516)
+__global__ void __launch_bounds__(256) k_burgers_epilogue(double *__restrict__ out, const double *__restrict__ vel,
+                                                          const double *__restrict__ d1, double nu, long long ntot) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ntot; i += stride) out[i] = nu * out[i] - vel[i] * d1[i];
+}
+
+__global__ void __launch_bounds__(256) k_fill(double *__restrict__ out, double v, long long ntot) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ntot; i += stride) out[i] = v;
+}
+
+// b(j,i) = a(i,j) for Fortran a(nra,nca) -> b(nca,nra)  (TLab_Transpose, utils/tlab_transpose.f90:14-82); 64x64 LDS tiles
+__global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a, double *__restrict__ b, int nra, int nca) {
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long i0 = (long long)blockIdx.x * 64, j0 = (long long)blockIdx.y * 64;
+    for (int jj = ty; jj < 64; jj += 4) {
+        const long long i = i0 + tx, j = j0 + jj;
+        if (i < nra && j < nca) tile[jj][tx] = a[i + (long long)nra * j];
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 64; ii += 4) {
+        const long long j = j0 + tx, i = i0 + ii;
+        if (i < nra && j < nca) b[j + (long long)nca * i] = tile[tx][ii];
+    }
+}
+
+// ============================================================================================
+// host-side launchers
+// ============================================================================================
+static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
+
+template <int M, bool LV>
+static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
+    const long long blocks_needed = (a.nlines + 3) / 4;
+    const int grid = imin(blocks_needed, 256 * 8);
+    const size_t lds = LV ? (size_t)2 * 5 * M * 64 * sizeof(double) : 0;
+    switch (mode) {
+    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV>), dim3(grid), dim3(256), lds, st, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+bool xline_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+
+hipError_t launch_xline(int mode, int n, bool lane_variant, const XLineArgs &a, hipStream_t st) {
+    switch (n) {
+    case 256: return lane_variant ? launch_xline_m<4, true>(mode, a, st) : launch_xline_m<4, false>(mode, a, st);
+    case 512: return lane_variant ? launch_xline_m<8, true>(mode, a, st) : launch_xline_m<8, false>(mode, a, st);
+    case 1024: return lane_variant ? launch_xline_m<16, true>(mode, a, st) : launch_xline_m<16, false>(mode, a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// chunk length (rows per wave) used by the register-tile kernel for a line length n (0 = unsupported).
+// M = 32 keeps the kernel under 128 VGPRs (16 waves per workgroup possible); TLAB_RTILE_M overrides for experiments.
+static int g_rtile_forced = -1;
+void rtile_force_chunk(int m) { g_rtile_forced = m; }
+int rtile_chunk(int n) {
+    if (g_rtile_forced < 0) {
+        const char *e = getenv("TLAB_RTILE_M");
+        g_rtile_forced = e ? atoi(e) : 0;
+    }
+    const int forced = g_rtile_forced;
+    if (forced == 16 || forced == 32 || forced == 64)
+        if (n % forced == 0 && n / forced <= 16) return forced;
+    if (n % 32 == 0 && n / 32 <= 16) return 32;
+    if (n % 64 == 0 && n / 64 <= 16) return 64;
+    if (n % 16 == 0 && n / 16 <= 16) return 16;
+    return 0;
+}
+
+template <int M, int MAXT>
+static hipError_t launch_rtile_m(int mode, int P, long long tiles, const RTileArgs &a, hipStream_t st) {
+    const dim3 grid((unsigned)tiles), block(64 * P);
+    switch (mode) {
+    case MODE_P1: hipLaunchKernelGGL((k_rtile<M, MODE_P1, MAXT>), grid, block, 0, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_rtile<M, MODE_P2, MAXT>), grid, block, 0, st, a); break;
+    case MODE_P2_D1IN: hipLaunchKernelGGL((k_rtile<M, MODE_P2_D1IN, MAXT>), grid, block, 0, st, a); break;
+    case MODE_BURGERS_D1IN: hipLaunchKernelGGL((k_rtile<M, MODE_BURGERS_D1IN, MAXT>), grid, block, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st) {
+    const int n = a.g.n;
+    const int M = rtile_chunk(n);
+    if (M == 0) return hipErrorInvalidValue;
+    const int P = n / M;
+    const long long tiles_inner = (a.g.lines_inner + 63) / 64;
+    const long long tiles = tiles_inner * (a.g.nlines / a.g.lines_inner);
+    if (M == 64) return (P <= 8) ? launch_rtile_m<64, 512>(mode, P, tiles, a, st) : launch_rtile_m<64, 1024>(mode, P, tiles, a, st);
+    if (M == 32) return (P <= 8) ? launch_rtile_m<32, 512>(mode, P, tiles, a, st) : launch_rtile_m<32, 1024>(mode, P, tiles, a, st);
+    return (P <= 8) ? launch_rtile_m<16, 512>(mode, P, tiles, a, st) : launch_rtile_m<16, 1024>(mode, P, tiles, a, st);
+}
+
+hipError_t launch_generic(bool sym, const GenericArgs &a, hipStream_t st) {
+    const int grid = (int)((a.g.nlines + 255) / 256);
+    if (sym) hipLaunchKernelGGL((k_generic<true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_generic<false>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_burgers_epilogue(double *out, const double *vel, const double *d1, double nu, long long ntot, hipStream_t st) {
+    const int grid = imin((ntot + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_burgers_epilogue, dim3(grid), dim3(256), 0, st, out, vel, d1, nu, ntot);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(double *out, double v, long long ntot, hipStream_t st) {
+    const int grid = imin((ntot + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, st, out, v, ntot);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose(const double *a, double *b, int nra, int nca, hipStream_t st) {
+    dim3 grid((nra + 63) / 64, (nca + 63) / 64);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, a, b, nra, nca);
+    return hipGetLastError();
+}
+
+}  // namespace tlab

@@ -1,0 +1,51 @@
+// Kernel argument blocks and host launchers (implemented in kernels.hip, pointwise.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_tables.hpp"
+
+namespace tlab {
+
+struct XLineArgs {          // k_xline: derivative along the contiguous index, n = 64*M
+    const double *in0;      // field (u or s)
+    const double *in1;      // advecting velocity (MODE_BURGERS)
+    double *out0, *out1;
+    long long nlines;
+    StencilDev s1, s2;      // first / second derivative RHS operators
+    SystemDev y1, y2;       // first / second derivative chunked systems (P = 64)
+    double nu;
+};
+
+struct RTileArgs {          // k_rtile: derivative along a strided index
+    const double *in0;      // field
+    const double *in1;      // first derivative (D1IN modes)
+    const double *in2;      // advecting velocity (MODE_BURGERS_D1IN)
+    double *out0;
+    LineGeom g;
+    StencilDev s1, s2;
+    SystemDev y1, y2;       // chunked with P = n / rtile_chunk(n)
+    JacCorrDev jc;
+    double nu;
+};
+
+struct GenericArgs {        // k_generic: any n
+    const double *in0;
+    const double *in1;      // first derivative for the Jacobian correction (may be NULL)
+    double *out0;
+    LineGeom g;
+    StencilDev s;
+    SystemDev y;            // chunked with P = 1; red[0] = 1 / beta
+    JacCorrDev jc;
+};
+
+bool xline_supported(int n);
+int rtile_chunk(int n);
+void rtile_force_chunk(int m);
+hipError_t launch_xline(int mode, int n, bool lane_variant, const XLineArgs &a, hipStream_t st);
+hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st);
+hipError_t launch_generic(bool sym, const GenericArgs &a, hipStream_t st);
+hipError_t launch_burgers_epilogue(double *out, const double *vel, const double *d1, double nu, long long ntot, hipStream_t st);
+hipError_t launch_fill(double *out, double v, long long ntot, hipStream_t st);
+hipError_t launch_transpose(const double *a, double *b, int nra, int nca, hipStream_t st);
+
+}  // namespace tlab

@@ -1,0 +1,47 @@
+// Plan objects behind the C ABI: host tables (reference layout) + lazily built device tables.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "chunked.hpp"
+#include "device_tables.hpp"
+#include "fdm_schemes.hpp"
+
+namespace tlab {
+
+struct DeviceArray {
+    double *p = nullptr;
+    size_t n = 0;
+    DeviceArray() = default;
+    DeviceArray(const DeviceArray &) = delete;
+    DeviceArray &operator=(const DeviceArray &) = delete;
+    ~DeviceArray();
+    void upload(const std::vector<double> &h);
+};
+
+struct SystemEntry {
+    ChunkedTables host;
+    DeviceArray rowtab, red;
+    bool lane_invariant = false;
+    SystemDev dev() const { return SystemDev{rowtab.p, red.p, lane_invariant ? 1 : 0}; }
+};
+
+}  // namespace tlab
+
+// the opaque handle of include/tlab_amd.h
+struct tlab_fdm_plan {
+    tlab::FdmTables t;
+    // (which = 1|2, ibc, P) -> chunked system; built on first use
+    std::map<std::tuple<int, int, int>, std::unique_ptr<tlab::SystemEntry>> systems;
+    std::unique_ptr<tlab::DeviceArray> jc;   // [3][n] Jacobian-correction diagonals (non-uniform grids)
+
+    tlab::TriDiag tridiag(int which, int ibc) const;            // tridiagonal matrix of the variant (wall rows -> identity)
+    tlab::StencilDev stencil(int which, int ibc) const;         // RHS operator of the variant
+    tlab::SystemEntry &system(int which, int ibc, int P);       // cached chunked factorization on the device
+    tlab::JacCorrDev jaccorr();
+};

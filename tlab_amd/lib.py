@@ -1,0 +1,67 @@
+"""ctypes binding of libtlab_amd.so (the C ABI declared in include/tlab_amd.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class TlabError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libtlab_amd.so")
+
+
+c_int, c_dbl, c_vp, c_sz = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); must list every entry point of include/tlab_amd.h (tests/test_capi_symbols.py checks)
+SIGNATURES = {
+    "tlab_init": (c_int, [c_int]),
+    "tlab_finalize": (c_int, []),
+    "tlab_last_error": (ctypes.c_char_p, []),
+    "tlab_set_stream": (c_int, [c_vp]),
+    "tlab_sync": (c_int, []),
+    "tlab_malloc": (c_int, [ctypes.POINTER(c_vp), c_sz]),
+    "tlab_free": (c_int, [c_vp]),
+    "tlab_memcpy_h2d": (c_int, [c_vp, c_vp, c_sz]),
+    "tlab_memcpy_d2h": (c_int, [c_vp, c_vp, c_sz]),
+    "tlab_fdm_plan_create": (c_int, [ctypes.POINTER(c_vp), c_int, _dp, c_int, c_int, c_int, c_int, c_dbl]),
+    "tlab_fdm_plan_create_from_arrays": (c_int, [ctypes.POINTER(c_vp), c_int, c_int, c_int, c_int, c_int, _dp, _dp, c_int, c_int, _dp, _dp]),
+    "tlab_fdm_plan_destroy": (c_int, [c_vp]),
+    "tlab_fdm_plan_get": (c_int, [c_vp, c_int, _dp, c_int]),
+    "tlab_fdm_plan_info": (c_int, [c_vp, c_int]),
+    "tlab_opr_partial": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tlab_opr_burgers": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_int]),
+    "tlab_transpose": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "tlab_last_kernel_path": (c_int, []),
+    "tlab_force_kernel_path": (c_int, [c_int]),
+    "tlab_set_tuning": (c_int, [c_int, c_int]),
+    "tlab_debug_host_chunked_solve": (c_int, [c_vp, c_int, c_int, c_int, _dp]),
+}
+
+
+def load():
+    """Load the HIP library; fails loudly when it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise TlabError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C tlab_amd/csrc` (there is no CPU fallback)" % path)
+    L = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)       # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().tlab_last_error()
+        raise TlabError("%s failed (%d): %s" % (what, code, msg.decode() if msg else ""))

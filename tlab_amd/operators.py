@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's operator interface for the hot path (same names, argument order and
+meaning as the Fortran module procedures), working on torch CUDA tensors whose storage is handed to the C ABI
+as raw device pointers.  torch is plumbing here (HBM allocation, streams); all arithmetic is in the HIP kernels.
+
+    OPR_Partial_X(type, nx, ny, nz, bcs, g, u, result, tmp1)        operators/opr_partial.f90:31
+    OPR_Burgers_X(ivel, is, nx, ny, nz, bcs, s, u, result, tmp1, u_t) physics/opr_burgers.f90:190
+    TLab_Transpose(a, nra, nca, ma, b, mb)                           utils/tlab_transpose.f90:14
+
+Fields are flat fp64 tensors of nx*ny*nz elements, x fastest, exactly the reference's u(nx*ny*nz).
+"""
+import ctypes
+import numpy as np
+
+from .lib import load, check, TlabError, c_vp
+
+# operators/opr_partial.f90:19-21, physics/opr_burgers.f90:29-30, base/tlab_constants.f90:63-66, fdm_derivative.f90:51-54
+OPR_P1, OPR_P2, OPR_P2_P1 = 1, 2, 3
+OPR_B_SELF, OPR_B_U_IN = 0, 1
+BCS_DD, BCS_ND, BCS_DN, BCS_NN = 0, 1, 2, 3
+FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER = 4, 6, 7
+
+_initialised = False
+
+
+def init(device=0):
+    """tlab_init: selects the GPU.  Raises TlabError if no MI355X is visible."""
+    global _initialised
+    check(load().tlab_init(int(device)), "tlab_init")
+    _initialised = True
+
+
+def sync():
+    check(load().tlab_sync(), "tlab_sync")
+
+
+def _use_torch_stream():
+    import torch
+    load().tlab_set_stream(c_vp(torch.cuda.current_stream().cuda_stream))
+
+
+def _ptr(t, n=None, name="tensor"):
+    import torch
+    if t is None:
+        return c_vp(0)
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+        raise TlabError("%s must be a contiguous float64 CUDA tensor" % name)
+    if n is not None and t.numel() < n:
+        raise TlabError("%s has %d elements, needs %d" % (name, t.numel(), n))
+    return c_vp(t.data_ptr())
+
+
+class FdmPlan:
+    """type(fdm_dt) (fdm/fdm.f90:14-29): compact-FDM plan of one direction, owned by the library.
+
+    FdmPlan(nodes, periodic, uniform, ...) restates FDM_CreatePlan (fdm/fdm.f90:143-252).
+    FdmPlan.from_arrays(...) takes the tables an unchanged Fortran host built in FDM_Initialize.
+    hyper_bc1_ext: see include/tlab_amd.h (0.1 reproduces the flang-built reference)."""
+
+    _KEYS = {"lhs1": (1, 5), "rhs1": (2, 7), "lu1": (3, None), "rhs_b1": (4, None), "rhs_t1": (5, None), "mwn1": (6, 1),
+             "lhs2": (7, 5), "rhs2": (8, 12), "lu2": (9, None), "mwn2": (10, 1), "jac": (11, 3)}
+
+    def __init__(self, nodes, periodic, uniform, scheme1=FDM_COM6_JACOBIAN, scheme2=FDM_COM6_JACOBIAN_HYPER,
+                 hyper_bc1_ext=0.1):
+        nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        self.size = int(nodes.shape[0])
+        self.periodic = bool(periodic)
+        self.uniform = bool(uniform)
+        self._h = c_vp(0)
+        check(load().tlab_fdm_plan_create(ctypes.byref(self._h), self.size,
+                                          nodes.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(self.periodic),
+                                          int(self.uniform), int(scheme1), int(scheme2), float(hyper_bc1_ext)),
+              "tlab_fdm_plan_create")
+
+    @classmethod
+    def from_arrays(cls, n, periodic, need_1der, lhs1, rhs1, lhs2, rhs2):
+        """lhs*/rhs*: numpy arrays [row, diagonal] (as oracle / golden files hold them); rhs2 includes the 3
+        Jacobian-correction columns after its ndr2 diagonals."""
+        self = cls.__new__(cls)
+        self.size, self.periodic, self.uniform = int(n), bool(periodic), not bool(need_1der)
+        self._h = c_vp(0)
+        ndr1, ndr2 = rhs1.shape[1], rhs2.shape[1] - 3
+        f = [np.asfortranarray(a, dtype=np.float64) for a in (lhs1[:, :3], rhs1, lhs2[:, :3], rhs2)]
+        dp = ctypes.POINTER(ctypes.c_double)
+        check(load().tlab_fdm_plan_create_from_arrays(ctypes.byref(self._h), self.size, int(periodic), int(need_1der),
+                                                      3, ndr1, f[0].ctypes.data_as(dp), f[1].ctypes.data_as(dp),
+                                                      3, ndr2, f[2].ctypes.data_as(dp), f[3].ctypes.data_as(dp)),
+              "tlab_fdm_plan_create_from_arrays")
+        return self
+
+    def info(self, what):
+        return load().tlab_fdm_plan_info(self._h, what)
+
+    @property
+    def need_1der(self):
+        return bool(self.info(5))
+
+    def table(self, key):
+        """Plan table as a numpy array indexed [row, diagonal] like the oracle's."""
+        which, cols = self._KEYS[key]
+        n = self.size
+        buf = np.zeros(n * 24 + 64)
+        m = load().tlab_fdm_plan_get(self._h, which, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), buf.shape[0])
+        if m < 0:
+            raise TlabError("tlab_fdm_plan_get(%s) failed" % key)
+        if key == "rhs_b1":
+            return buf[:m].reshape(8, 4).T.copy()
+        if key == "rhs_t1":
+            return buf[:m].reshape(7, 5).T.copy()
+        if cols == 1:
+            return buf[:m].copy()
+        return buf[:m].reshape(m // n, n).T.copy()
+
+    def debug_host_chunked_solve(self, which, ibc, chunks, f):
+        f = np.ascontiguousarray(f, dtype=np.float64).copy()
+        check(load().tlab_debug_host_chunked_solve(self._h, which, ibc, chunks, f.ctypes.data_as(ctypes.POINTER(ctypes.c_double))),
+              "tlab_debug_host_chunked_solve")
+        return f
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().tlab_fdm_plan_destroy(self._h)
+        except Exception:
+            pass
+
+
+def _ibc(bcs):
+    """ibc = bcs(1,1) + 2*bcs(2,1) (opr_partial.f90:91); bcs is the reference's 2x2 integer array (or an int ibc)."""
+    if isinstance(bcs, (int, np.integer)):
+        return int(bcs)
+    b = np.asarray(bcs)
+    return int(b[0, 0]) + 2 * int(b[1, 0])
+
+
+def _partial(idir, type, nx, ny, nz, bcs, g, u, result, tmp1=None):
+    n = nx * ny * nz
+    _use_torch_stream()
+    check(load().tlab_opr_partial(idir, g._h, int(type), nx, ny, nz, _ibc(bcs), _ptr(u, n, "u"), _ptr(result, n, "result"),
+                                  _ptr(tmp1, n, "tmp1")), "tlab_opr_partial")
+
+
+def OPR_Partial_X(type, nx, ny, nz, bcs, g, u, result, tmp1=None):
+    _partial(1, type, nx, ny, nz, bcs, g, u, result, tmp1)
+
+
+def OPR_Partial_Y(type, nx, ny, nz, bcs, g, u, result, tmp1=None):
+    _partial(2, type, nx, ny, nz, bcs, g, u, result, tmp1)
+
+
+def OPR_Partial_Z(type, nx, ny, nz, bcs, g, u, result, tmp1=None):
+    _partial(3, type, nx, ny, nz, bcs, g, u, result, tmp1)
+
+
+def _burgers(idir, ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, write_transposed):
+    n = nx * ny * nz
+    b = np.asarray(bcs) if not isinstance(bcs, (int, np.integer)) else None
+    if b is not None and b.shape == (2, 2) and int(b[0, 1]) + int(b[1, 1]) > 0:
+        raise TlabError("OPR_Burgers: only developed for biased BCs (opr_burgers.f90:460-463)")
+    _use_torch_stream()
+    check(load().tlab_opr_burgers(idir, g._h, int(ivel), nx, ny, nz, _ibc(bcs), float(nu), _ptr(s, n, "s"), _ptr(u, n, "u"),
+                                  _ptr(result, n, "result"), _ptr(tmp1, n, "tmp1"), int(write_transposed)),
+          "tlab_opr_burgers")
+
+
+# `is` (scalar index selecting the diffusivity in the reference's module state) becomes the diffusivity itself:
+# nu = visc for is = 0, visc/schmidt(is) otherwise (opr_burgers.f90:94-98).  u_t is accepted and ignored (see tlab_amd.h).
+def OPR_Burgers_X(ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, u_t=None, write_transposed=False):
+    _burgers(1, ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, write_transposed)
+
+
+def OPR_Burgers_Y(ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, u_t=None, write_transposed=False):
+    _burgers(2, ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, write_transposed)
+
+
+def OPR_Burgers_Z(ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, u_t=None, write_transposed=False):
+    _burgers(3, ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, write_transposed)
+
+
+def TLab_Transpose(a, nra, nca, b):
+    """b(nca, nra) = transpose of Fortran a(nra, nca); bit-exact."""
+    _use_torch_stream()
+    check(load().tlab_transpose(_ptr(a, nra * nca, "a"), nra, nca, _ptr(b, nra * nca, "b")), "tlab_transpose")
