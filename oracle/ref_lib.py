@@ -115,3 +115,53 @@ def burgers(idir, nx, ny, nz, ibc, visc, s, vel):
     t = np.zeros_like(s)
     lib().ref_burgers(idir, nx, ny, nz, ibc, float(visc), s, vel, r, t)
     return r, t
+
+
+# ---- Poisson-path entry points (oracle/ref_driver_poisson.f90) -------------------------------------------
+def _poisson_sigs():
+    L = lib()
+    if getattr(L, "_poisson_ready", False):
+        return L
+    L.ref_int1_create.argtypes = [c_dbl, c_int, c_int]
+    L.ref_int1_get.argtypes = [c_int, c_int, _P, c_int]
+    L.ref_int1_solve.argtypes = [c_int, c_int, _P, _P, _P]
+    L.ref_ode2.argtypes = [c_int, c_int, c_dbl, _P, _P, _P, _P]
+    L._poisson_ready = True
+    return L
+
+
+def int1_create(lam, ibc, factorize=True):
+    """FDM_Int1_Initialize (factorize) or FDM_Int1_CreateSystem on the y plan (direction 2 must exist)."""
+    _poisson_sigs().ref_int1_create(float(lam), int(ibc), int(factorize))
+
+
+def int1_tables(n, ibc):
+    L = _poisson_sigs()
+
+    def get(which, rows, cols):
+        buf = np.zeros(rows * cols)
+        L.ref_int1_get(int(ibc), which, buf, buf.shape[0])
+        return buf.reshape(cols, rows).T.copy()
+
+    return {"lhs": get(1, n, 5), "rhs": get(2, n, 3), "rhs_b": get(3, 5, 8), "rhs_t": get(4, 5, 8)}
+
+
+def int1_solve(ibc, f, res):
+    """f, res: (n, nlines) C-ordered; res carries the boundary value; returns (solution, du_boundary)."""
+    L = _poisson_sigs()
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    r = np.ascontiguousarray(res, dtype=np.float64).copy()
+    du = np.zeros(f.shape[1])
+    L.ref_int1_solve(int(ibc), f.shape[1], f, r, du)
+    return r, du
+
+
+def ode2(itype, lam, f, bcs):
+    """itype: 1 NN, 2 NN_Sing, 3 DD, 4 DD_Sing.  f: (n, nlines); bcs: (2, nlines).  Returns (u, v)."""
+    L = _poisson_sigs()
+    f = np.ascontiguousarray(f, dtype=np.float64).copy()
+    b = np.ascontiguousarray(bcs, dtype=np.float64).copy()
+    u = np.zeros_like(f)
+    v = np.zeros_like(f)
+    L.ref_ode2(int(itype), f.shape[1], float(lam), f, b, u, v)
+    return u, v

@@ -1,0 +1,413 @@
+"""CPU oracle, part 2: numpy restatement of OPR_Poisson_FourierXZ_Factorize and what it stands on.
+
+TEST INFRASTRUCTURE ONLY (same rules as tlab_oracle.py).  Parity status: PINNED for the per-mode arithmetic
+(FDM_Int1_*, PENTADFS/SS, OPR_ODE2_Factorize_*) against oracle/_ref (the reference's own Fortran) and the golden
+vectors generated from it; the FFTs are numpy.fft (the reference uses whichever FFTW3 provider it is linked with,
+un-vendored; FFT parity is pinned to ~1e-15 relative, not bitwise -- SURVEY.md 8c).
+
+Vectorisation: every per-mode quantity carries a trailing mode axis M, so the whole (kx,kz) plane is solved at once.
+  lambda: (M,)   lhs: (n, 5, M)   rhs: (n, 3)   rhs_b: (5, 8, M) [row-1, col]   rhs_t: (5, 8, M) [row, col-1]
+  lines:  (n, nlines, M)          boundary values: (nlines, M)
+"""
+import numpy as np
+
+from .tlab_oracle import BCS_MIN, BCS_MAX, BCS_BOTH, BCS_NN, BCS_DD
+
+
+# ######################################################################################
+# utils/linear5.f90
+# ######################################################################################
+def pentadfs(a, b, c, d, e):
+    """utils/linear5.f90:30-71 PENTADFS, in place; arrays (nmax, M)."""
+    nmax = a.shape[0]
+    b[1] = b[1] / c[0]
+    c[1] = c[1] - b[1] * d[0]
+    d[1] = d[1] - b[1] * e[0]
+    for n in range(2, nmax - 1):
+        a[n] = a[n] / c[n - 2]
+        b[n] = (b[n] - a[n] * d[n - 2]) / c[n - 1]
+        c[n] = c[n] - b[n] * d[n - 1] - a[n] * e[n - 2]
+        d[n] = d[n] - b[n] * e[n - 1]
+    n = nmax - 1
+    a[n] = a[n] / c[n - 2]
+    b[n] = (b[n] - a[n] * d[n - 2]) / c[n - 1]
+    c[n] = c[n] - b[n] * d[n - 1] - a[n] * e[n - 2]
+    a[2:] = -a[2:]
+    b[1:] = -b[1:]
+    c[:] = 1.0 / c
+    d[:nmax - 1] = -d[:nmax - 1]
+    e[:nmax - 2] = -e[:nmax - 2]
+
+
+def pentadss(a, b, c, d, e, f):
+    """utils/linear5.f90:76-131 PENTADSS; coefficients (nmax, M), f (nmax, nlines, M) in place."""
+    nmax = a.shape[0]
+    f[1] = f[1] + f[0] * b[1]
+    for n in range(2, nmax):
+        f[n] = f[n] + f[n - 1] * b[n] + f[n - 2] * a[n]
+    n = nmax - 1
+    f[n] = f[n] * c[n]
+    n = nmax - 2
+    f[n] = (f[n] + f[n + 1] * d[n]) * c[n]
+    for n in range(nmax - 3, -1, -1):
+        f[n] = (f[n] + f[n + 1] * d[n] + f[n + 2] * e[n]) * c[n]
+
+
+# ######################################################################################
+# fdm/fdm_base.f90:304-391 FDM_Bcs_Reduce
+# lhs (nx, ndl[, M]) modified in place; rhs (nx, ndr[, M]); rhs_b (>=4, 8[, M]) [row-1, col]; rhs_t (5, 8[, M]) [row, col-1]
+# ######################################################################################
+def fdm_bcs_reduce(ibc, lhs, rhs=None, rhs_b=None, rhs_t=None):
+    ndl = lhs.shape[1]
+    idl = ndl // 2 + 1
+    nx = lhs.shape[0]
+    if rhs is not None:
+        ndr = rhs.shape[1]
+        idr = ndr // 2 + 1
+        nx_t = idr
+        mx = max(idl, idr + 1)
+    if ibc in (BCS_MIN, BCS_BOTH):
+        dummy = 1.0 / lhs[0, idl - 1]
+        lhs[0, :] = -lhs[0, :] * dummy
+        lhs[0, idl - 1] = 1.0
+        for ir in range(1, idl):
+            for ic in range(idl + 1, ndl + 1):
+                lhs[ir, ic - ir - 1] = lhs[ir, ic - ir - 1] + lhs[ir, idl - ir - 1] * lhs[0, ic - 1]
+            ic = ndl + 1
+            lhs[ir, ic - ir - 1] = lhs[ir, ic - ir - 1] + lhs[ir, idl - ir - 1] * lhs[0, 0]
+        if rhs_b is not None:
+            rhs_b[0:mx, 1:ndr + 1] = rhs[0:mx, 0:ndr]
+            rhs_b[0, 1:ndr + 1] = rhs_b[0, 1:ndr + 1] * dummy
+            for ir in range(1, idl):
+                for ic in range(idr, ndr + 1):
+                    rhs_b[ir, ic - ir] = rhs_b[ir, ic - ir] - lhs[ir, idl - ir - 1] * rhs_b[0, ic]
+                ic = ndr + 1
+                rhs_b[ir, ic - ir] = rhs_b[ir, ic - ir] - lhs[ir, idl - ir - 1] * rhs_b[0, 1]
+    if ibc in (BCS_MAX, BCS_BOTH):
+        dummy = 1.0 / lhs[nx - 1, idl - 1]
+        lhs[nx - 1, :] = -lhs[nx - 1, :] * dummy
+        lhs[nx - 1, idl - 1] = 1.0
+        for ir in range(1, idl):
+            # ic = 0: longer stencil at the boundary
+            lhs[nx - ir - 1, ir - 1] = lhs[nx - ir - 1, ir - 1] + lhs[nx - ir - 1, idl + ir - 1] * lhs[nx - 1, ndl - 1]
+            for ic in range(1, idl):
+                lhs[nx - ir - 1, ic + ir - 1] = lhs[nx - ir - 1, ic + ir - 1] + lhs[nx - ir - 1, idl + ir - 1] * lhs[nx - 1, ic - 1]
+        if rhs_t is not None:
+            rhs_t[nx_t - mx + 1:nx_t + 1, 0:ndr] = rhs[nx - mx:nx, 0:ndr]
+            rhs_t[nx_t, 0:ndr] = rhs_t[nx_t, 0:ndr] * dummy
+            for ir in range(1, idl):
+                rhs_t[nx_t - ir, ir - 1] = rhs_t[nx_t - ir, ir - 1] - lhs[nx - ir - 1, idl + ir - 1] * rhs_t[nx_t, ndr - 1]
+                for ic in range(1, idr + 1):
+                    rhs_t[nx_t - ir, ic + ir - 1] = rhs_t[nx_t - ir, ic + ir - 1] - lhs[nx - ir - 1, idl + ir - 1] * rhs_t[nx_t, ic - 1]
+
+
+# ######################################################################################
+# fdm/fdm_integral.f90
+# ######################################################################################
+class Int1Plan:
+    """fdm/fdm_integral.f90:18-26 type fdm_integral_dt, for a vector of lambdas (trailing axis M)."""
+    pass
+
+
+def int1_create_system(g, lam, ibc):
+    """fdm/fdm_integral.f90:91-214 FDM_Int1_CreateSystem.  g: oracle DerPlan of the first derivative; lam: (M,)."""
+    lam = np.atleast_1d(np.asarray(lam, dtype=np.float64))
+    M = lam.shape[0]
+    ndl, ndr = g.nb_diag
+    idl, idr = ndl // 2 + 1, ndr // 2 + 1
+    nx = g.size
+    p = Int1Plan()
+    p.lam, p.bc, p.nx, p.ndl, p.ndr = lam, ibc, nx, ndr, ndl        # NB: lhs of the integral has ndr diagonals, rhs ndl
+    A = g.lhs[:, :ndl].copy()                                        # fdmi%rhs
+    rhsr_b = np.zeros((5, 8))
+    rhsr_t = np.zeros((5, 8))
+    fdm_bcs_reduce(ibc, A, g.rhs[:, :ndr], rhsr_b, rhsr_t)
+    rhs_b = np.zeros((5, 8))
+    rhs_t = np.zeros((5, 8))
+    if ibc == BCS_MIN:
+        rhs_b[0:idl + 1, 1:ndl + 1] = A[0:idl + 1, 0:ndl]
+        for ir in range(1, idr):
+            rhs_b[ir, idl - ir] = -rhsr_b[ir, idr - ir]
+    else:
+        rhs_t[0:idl + 1, 0:ndl] = A[nx - idl - 1:nx, 0:ndl]
+        for ir in range(1, idr):
+            rhs_t[idl - ir, idl + ir - 1] = -rhsr_t[idr - ir, idr + ir - 1]
+    # new lhs diagonals C = B + lambda A (lambda-dependent), :150-156
+    lhs = np.repeat(g.rhs[:, :ndr, None], M, axis=2).astype(np.float64)
+    lhs[:, idr - 1, :] = lhs[:, idr - 1, :] + lam * g.lhs[:, idl - 1, None]
+    for i in range(1, idl):
+        lhs[i:nx, idr - i - 1, :] = lhs[i:nx, idr - i - 1, :] + lam * g.lhs[i:nx, idl - i - 1, None]
+        lhs[0:nx - i, idr + i - 1, :] = lhs[0:nx - i, idr + i - 1, :] + lam * g.lhs[0:nx - i, idl + i - 1, None]
+    if ibc == BCS_MIN:
+        lhs[0:idr, 0:ndr, :] = rhsr_b[0:idr, 1:ndr + 1, None]
+        lhs[0, idr:idr + idl - 1, :] = lhs[0, idr:idr + idl - 1, :] - lam * rhs_b[0, idl + 1:ndl + 1, None]
+        for ir in range(1, idr):
+            lhs[ir, idr - idl:idr + idl - 1, :] = lhs[ir, idr - idl:idr + idl - 1, :] + lam * rhs_b[ir, 1:ndl + 1, None]
+    else:
+        lhs[nx - idr:nx, 0:ndr, :] = rhsr_t[1:idr + 1, 0:ndr, None]
+        lhs[nx - 1, idr - idl:idr - 1, :] = lhs[nx - 1, idr - idl:idr - 1, :] - lam * rhs_t[idl, 0:idl - 1, None]
+        for ir in range(1, idr):
+            lhs[nx - ir - 1, idr - idl:idr + idl - 1, :] = lhs[nx - ir - 1, idr - idl:idr + idl - 1, :] + lam * rhs_t[idl - ir, 0:ndl, None]
+    # normalisation (:175-201)
+    rhs = A
+    mx = max(idr, idl + 1)
+    for ir in range(1, mx + 1):
+        dummy = 1.0 / rhs[ir - 1, idl - 1]
+        rhs_b[ir - 1, 0:ndl + 1] = rhs_b[ir - 1, 0:ndl + 1] * dummy
+        dummy = 1.0 / rhs[nx - ir, idl - 1]
+        rhs_t[idl - ir + 1, 0:ndl + 1] = rhs_t[idl - ir + 1, 0:ndl + 1] * dummy
+        dummy = 1.0 / rhs[ir - 1, idl - 1]
+        rhs[ir - 1, 0:ndl] = rhs[ir - 1, 0:ndl] * dummy
+        lhs[ir - 1, 0:ndr, :] = lhs[ir - 1, 0:ndr, :] * dummy
+        dummy = 1.0 / rhs[nx - ir, idl - 1]
+        rhs[nx - ir, 0:ndl] = rhs[nx - ir, 0:ndl] * dummy
+        lhs[nx - ir, 0:ndr, :] = lhs[nx - ir, 0:ndr, :] * dummy
+    for ir in range(mx + 1, nx - mx + 1):
+        dummy = 1.0 / rhs[ir - 1, idl]
+        rhs[ir - 1, 0:ndl] = rhs[ir - 1, 0:ndl] * dummy
+        lhs[ir - 1, 0:ndr, :] = lhs[ir - 1, 0:ndr, :] * dummy
+    # reduce the opposite end (:203-211); makes rhs_b / rhs_t lambda-dependent
+    rhs_bM = np.repeat(rhs_b[:, :, None], M, axis=2)
+    rhs_tM = np.repeat(rhs_t[:, :, None], M, axis=2)
+    rhsM = np.repeat(rhs[:, :, None], M, axis=2)
+    if ibc == BCS_MIN:
+        fdm_bcs_reduce(BCS_MAX, lhs, rhsM, rhs_t=rhs_tM)
+    else:
+        fdm_bcs_reduce(BCS_MIN, lhs, rhsM, rhs_b=rhs_bM)
+    p.lhs, p.rhs, p.rhs_b, p.rhs_t = lhs, rhs, rhs_bM, rhs_tM
+    p.factorized = False
+    return p
+
+
+def int1_initialize(g, lam, ibc):
+    """fdm/fdm_integral.f90:58-87 FDM_Int1_Initialize (pentadiagonal case: C1N6 -> 5 LHS diagonals)."""
+    p = int1_create_system(g, lam, ibc)
+    assert p.lhs.shape[1] == 5, "oracle: only the pentadiagonal integral (C1N6) is restated"
+    cols = [p.lhs[1:p.nx - 1, k, :].copy() for k in range(5)]
+    pentadfs(*cols)
+    for k in range(5):
+        p.lhs[1:p.nx - 1, k, :] = cols[k]
+    p.factorized = True
+    return p
+
+
+def _matmul_3d_both(rhs, f, res, rhs_b, rhs_t):
+    """fdm/fdm_matmul.f90:70-121 MatMul_3d with ibc = BCS_BOTH, as called at fdm_integral.f90:249-250:
+    rhs_b = fdmi%rhs_b(1:3, 0:3), rhs_t = fdmi%rhs_t(0:2, 1:4).  res[0], res[nx-1] carry the boundary values.
+    Returns (bcs_b, bcs_t)."""
+    nx = rhs.shape[0]
+    r1, r2 = rhs[:, 0], rhs[:, 1]
+    rb = lambda j, c: rhs_b[j - 1, c]          # noqa: E731  rhs_b(j, c)
+    rt = lambda r, c: rhs_t[r, c - 1]          # noqa: E731  rhs_t(r, c)
+    bcs_b = res[0] * rb(1, 2) + f[1] * rb(1, 3) + f[2] * rb(1, 1)
+    res[1] = res[0] * rb(2, 1) + f[1] * rb(2, 2) + f[2] * rb(2, 3)
+    res[2] = res[0] * rb(3, 0) + f[1] * rb(3, 1) + f[2] * rb(3, 2) + f[3] * rb(3, 3)
+    for n in range(3, nx - 3):
+        res[n] = f[n - 1] * r1[n] + f[n] * r2[n] + f[n + 1]
+    res[nx - 3] = f[nx - 4] * rt(0, 1) + f[nx - 3] * rt(0, 2) + f[nx - 2] * rt(0, 3) + res[nx - 1] * rt(0, 4)
+    res[nx - 2] = f[nx - 3] * rt(1, 1) + f[nx - 2] * rt(1, 2) + res[nx - 1] * rt(1, 3)
+    bcs_t = f[nx - 3] * rt(2, 3) + f[nx - 2] * rt(2, 1) + res[nx - 1] * rt(2, 2)
+    return bcs_b, bcs_t
+
+
+def int1_solve(p, rhsi, f, res, want_du=False):
+    """fdm/fdm_integral.f90:219-314 FDM_Int1_Solve.  f, res: (n, nlines, M); res carries the boundary value
+    (res[0] for BCS_MIN, res[nx-1] for BCS_MAX) and is overwritten with the solution.  Returns du_boundary or None."""
+    nx = p.nx
+    lhs = p.lhs
+    if p.bc == BCS_MIN:
+        res[nx - 1] = f[nx - 1]
+    else:
+        res[0] = f[0]
+    bcs_b, bcs_t = _matmul_3d_both(rhsi, f, res, p.rhs_b, p.rhs_t)
+    sub = res[1:nx - 1]
+    pentadss(lhs[1:nx - 1, 0], lhs[1:nx - 1, 1], lhs[1:nx - 1, 2], lhs[1:nx - 1, 3], lhs[1:nx - 1, 4], sub)
+    du = None
+    idl, ndl, idr = 3, 5, 2
+    if p.bc == BCS_MAX:
+        res[0] = bcs_b
+        for ic in range(1, idl):
+            res[0] = res[0] + lhs[0, idl + ic - 1] * res[ic]
+        res[0] = res[0] + lhs[0, 0] * res[idl]
+        if want_du:
+            du = lhs[nx - 1, idl - 1] * res[nx - 1]
+            for ic in range(1, idl):
+                du = du + lhs[nx - 1, idl - ic - 1] * res[nx - 1 - ic]
+            du = du + lhs[nx - 1, ndl - 1] * res[nx - 1 - idl]
+            for ic in range(1, idr):
+                du = du + rhsi[nx - 1, idr - ic - 1] * f[nx - 1 - ic]
+    if p.bc == BCS_MIN:
+        res[nx - 1] = bcs_t
+        for ic in range(1, idl):
+            res[nx - 1] = res[nx - 1] + lhs[nx - 1, idl - ic - 1] * res[nx - 1 - ic]
+        res[nx - 1] = res[nx - 1] + lhs[nx - 1, ndl - 1] * res[nx - 1 - idl]
+        if want_du:
+            du = lhs[0, idl - 1] * res[0]
+            for ic in range(1, idl):
+                du = du + lhs[0, idl + ic - 1] * res[ic]
+            du = du + lhs[0, 0] * res[idl]
+            for ic in range(1, idr):
+                du = du + rhsi[0, idr + ic - 1] * f[ic]
+    return du
+
+
+# ######################################################################################
+# operators/opr_odes.f90
+# ######################################################################################
+def ode2_factorize_nn(fmin, fmax, f, bcs):
+    """operators/opr_odes.f90:265-386 OPR_ODE2_Factorize_NN.  fmin/fmax: Int1 plans (BCS_MIN, +lambda) / (BCS_MAX, -lambda);
+    f: (n, nlines, M) (modified like in the reference), bcs: (2, nlines, M) [bottom, top].  Returns (u, v)."""
+    lam = fmin.lam
+    nx = fmin.nx
+    nl, M = f.shape[1], f.shape[2]
+    u = np.zeros_like(f)
+    v = np.zeros_like(f)
+    # v^(0): v' + lambda v = f, v_1 = 0
+    f[nx - 1] = 0.0
+    v[0] = 0.0
+    int1_solve(fmin, fmin.rhs, f, v)
+    # v^(1), e^(-) (third line unused)
+    f1 = np.zeros((nx, 3, M))
+    h2 = np.zeros((nx, 3, M))          # (v1, em, dd)
+    f1[nx - 1, 0] = 1.0
+    h2[0, 0] = 0.0
+    h2[0, 1] = 1.0
+    h2[0, 2] = 0.0
+    int1_solve(fmin, fmin.rhs, f1, h2)
+    # u^(0): u' - lambda u = v, u_n = 0
+    u[nx - 1] = 0.0
+    du0_n = int1_solve(fmax, fmax.rhs, v, u, want_du=True)
+    # u^(1), s^(+), e^(+)
+    h1 = np.zeros((nx, 3, M))          # (u1, sp, ep)
+    h2[:, 2] = 0.0
+    h1[nx - 1, 0] = 0.0
+    h1[nx - 1, 1] = 0.0
+    h1[nx - 1, 2] = 1.0
+    der_bcs = int1_solve(fmax, fmax.rhs, h2, h1, want_du=True)
+    v1, em = h2[:, 0], h2[:, 1]
+    u1, sp, ep = h1[:, 0], h1[:, 1], h1[:, 2]
+    du1_n, dsp_n, dep_n = der_bcs[0], der_bcs[1], der_bcs[2]
+    a11 = 1.0 + lam * sp[0]; a21 = em[nx - 1]; a31 = dsp_n
+    a12 = lam * ep[0]; a22 = lam * np.ones(M); a32 = dep_n
+    a13 = lam * u1[0]; a23 = v1[nx - 1]; a33 = du1_n
+    a12 = a12 / a11
+    a22 = a22 - a21 * a12
+    a32 = a32 - a31 * a12
+    a13 = a13 / a11
+    a23 = (a23 - a21 * a13) / a22
+    a33 = a33 - a31 * a13 - a32 * a23
+    v[0] = (bcs[0] - lam * u[0]) / a11
+    u[nx - 1] = (bcs[1] - v[nx - 1] - a21 * v[0]) / a22
+    fn = (bcs[1] - du0_n - a31 * v[0] - a32 * u[nx - 1]) / a33
+    u[nx - 1] = u[nx - 1] - a23 * fn
+    v[0] = v[0] - a12 * u[nx - 1] - a13 * fn
+    i = nx - 1
+    v[i] = v[i] + fn * v1[i] + v[0] * em[i] + lam * u[i]
+    for i in range(nx - 2, 0, -1):
+        u[i] = u[i] + fn * u1[i] + v[0] * sp[i] + u[nx - 1] * ep[i]
+        v[i] = v[i] + fn * v1[i] + v[0] * em[i] + lam * u[i]
+    i = 0
+    u[i] = u[i] + fn * u1[i] + v[0] * sp[i] + u[nx - 1] * ep[i]
+    v[i] = v[i] + lam * u[i]
+    return u, v
+
+
+def ode2_factorize_dn_sing(fmin, fmax, f, bcs):
+    """operators/opr_odes.f90:37-96 OPR_ODE2_Factorize_DN_Sing (lambda = 0 plans)."""
+    nx = fmin.nx
+    M = f.shape[2]
+    u = np.zeros_like(f)
+    v = np.zeros_like(f)
+    f[0] = 0.0
+    v[nx - 1] = bcs[1]
+    int1_solve(fmax, fmax.rhs, f, v)
+    f1 = np.zeros((nx, 1, M)); f1[0, 0] = 1.0
+    v1 = np.zeros((nx, 1, M))
+    int1_solve(fmax, fmax.rhs, f1, v1)
+    u[0] = bcs[0]
+    du0_n = int1_solve(fmin, fmin.rhs, v, u, want_du=True)
+    u1 = np.zeros((nx, 1, M))
+    du1_n = int1_solve(fmin, fmin.rhs, v1, u1, want_du=True)
+    fac = 1.0 / (du1_n[0] - v1[0, 0])
+    c = (v[0] - du0_n) * fac
+    for i in range(nx):
+        u[i] = u[i] + c * u1[i, 0]
+        v[i] = v[i] + c * v1[i, 0]
+    return u, v
+
+
+def ode2_factorize_nn_sing(fmin, fmax, f, bcs):
+    """operators/opr_odes.f90:165-183 OPR_ODE2_Factorize_NN_Sing."""
+    bcs = bcs.copy()
+    bcs[0] = 0.0
+    return ode2_factorize_dn_sing(fmin, fmax, f, bcs)
+
+
+# ######################################################################################
+# operators/opr_elliptic.f90
+# ######################################################################################
+class PoissonPlan:
+    """operators/opr_elliptic.f90:86-250 OPR_Elliptic_Initialize (TYPE_FACTORIZE, serial): lambda(k,i), singular modes,
+    norm; the integral plans are rebuilt per call in this oracle (they are cheap here)."""
+
+    def __init__(self, gx, gy, gz, nx, ny, nz):
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.gy = gy
+        self.nxh = nx // 2 + 1
+        kx = gx.der1.mwn[: self.nxh]
+        if nz > 1:
+            kz = gz.der1.mwn[:nz]
+            self.lam2 = kx[None, :] ** 2.0 + kz[:, None] ** 2.0          # lambda(k, i)  [kz, kx]
+        else:
+            self.lam2 = (kx[None, :] ** 2.0) * np.ones((1, 1))
+        self.norm = 1.0 / float(nx * nz)
+        self.i_sing = (0, nx // 2)                                       # 0-based (1, nx/2+1)
+        self.k_sing = (0, nz // 2) if nz > 1 else (0, 0)
+        sing = np.zeros((max(nz, 1), self.nxh), dtype=bool)
+        for i in set(self.i_sing):
+            for k in set(self.k_sing):
+                sing[k, i] = True
+        self.sing = sing
+
+
+def opr_poisson_fxz(plan, p, bcs_hb, bcs_ht, ibc=BCS_NN):
+    """operators/opr_elliptic.f90:263-364 OPR_Poisson_FourierXZ_Factorize (ibc = BCS_NN).
+    p: flat forcing (nx*ny*nz, x fastest); bcs_hb, bcs_ht: (nz, nx) Neumann data.  Returns (p, dpdy) flat."""
+    assert ibc == BCS_NN, "oracle: only BCS_NN (the RHS call, rhs_global_incompressible_1.f90:284) is restated"
+    nx, ny, nz, nxh = plan.nx, plan.ny, plan.nz, plan.nxh
+    a = np.array(p, dtype=np.float64).reshape(nz, ny, nx).copy()
+    a[:, 0, :] = bcs_hb.reshape(nz, nx)                                  # :285-286
+    a[:, ny - 1, :] = bcs_ht.reshape(nz, nx)
+    c = np.fft.rfft(a, axis=2)                                           # OPR_Fourier_X_Forward (unnormalised, like FFTW)
+    if nz > 1:
+        c = np.fft.fft(c, axis=0)                                        # OPR_Fourier_Z_Forward
+    c = c * plan.norm                                                    # :295
+    # modes as a flat axis M = (kz, kx); lines = (Re, Im)
+    M = nz * nxh
+    f = np.empty((ny, 2, M))
+    f[:, 0, :] = c.real.transpose(1, 0, 2).reshape(ny, M)
+    f[:, 1, :] = c.imag.transpose(1, 0, 2).reshape(ny, M)
+    bcs = np.stack([f[0].copy(), f[ny - 1].copy()])                      # :310-311
+    lam = np.sqrt(plan.lam2.reshape(M))
+    sing = plan.sing.reshape(M)
+    u = np.zeros_like(f)
+    v = np.zeros_like(f)
+    reg = ~sing
+    g1 = plan.gy.der1
+    if reg.any():
+        fmin = int1_initialize(g1, lam[reg], BCS_MIN)                   # opr_elliptic.f90:205-209
+        fmax = int1_initialize(g1, -lam[reg], BCS_MAX)
+        u[:, :, reg], v[:, :, reg] = ode2_factorize_nn(fmin, fmax, f[:, :, reg].copy(), bcs[:, :, reg])
+    if sing.any():
+        ls = lam[sing]                                                   # exactly 0 at (0|Nyquist) x (0|Nyquist)
+        fmin = int1_initialize(g1, ls, BCS_MIN)
+        fmax = int1_initialize(g1, -ls, BCS_MAX)
+        u[:, :, sing], v[:, :, sing] = ode2_factorize_nn_sing(fmin, fmax, f[:, :, sing].copy(), bcs[:, :, sing])
+
+    def back(w):
+        cc = (w[:, 0, :] + 1j * w[:, 1, :]).reshape(ny, nz, nxh).transpose(1, 0, 2)
+        if nz > 1:
+            cc = np.fft.ifft(cc, axis=0) * nz                            # FFTW backward is unnormalised
+        return (np.fft.irfft(cc, n=nx, axis=2) * nx).reshape(-1)
+
+    return back(u), back(v)

@@ -1,0 +1,66 @@
+"""CPU tests: the numpy oracle of the Poisson path is pinned against the reference-generated golden vectors
+(per-mode FDM_Int1 systems, solves and OPR_ODE2_Factorize_NN/_NN_Sing), against oracle/_ref when present, and through the
+discrete identity  div(grad p) = f  (P1 o P1, as vpoisson.f90 / SURVEY.md 4.4)."""
+import numpy as np
+import pytest
+from conftest import golden_files, rel_err
+from oracle import tlab_oracle as O
+from oracle import tlab_oracle_poisson as OP
+
+TOL = 1e-13
+
+
+@pytest.mark.parametrize("path", golden_files("poisson_modes_"))
+def test_int1_and_ode2_match_golden(path):
+    g = np.load(path)
+    y = g["y"]; n = y.shape[0]
+    gy = O.FdmPlan(y, False, bool(g["uniform"]))
+    for il, lam in enumerate(g["lams"]):
+        for ibc, sgn in ((1, 1.0), (2, -1.0)):
+            p = OP.int1_create_system(gy.der1, sgn * lam, ibc)
+            for k, a in (("lhs", p.lhs[:, :, 0]), ("rhs", p.rhs), ("rhs_b", p.rhs_b[:, :, 0]), ("rhs_t", p.rhs_t[:, :, 0])):
+                assert rel_err(a, g["sys_l%d_bc%d_%s" % (il, ibc, k)]) <= TOL, (il, ibc, k)
+            p = OP.int1_initialize(gy.der1, sgn * lam, ibc)
+            assert rel_err(p.lhs[:, :, 0], g["lu_l%d_bc%d_lhs" % (il, ibc)]) <= TOL
+            f = g["int1_l%d_bc%d_f" % (il, ibc)]
+            r = g["int1_l%d_bc%d_res0" % (il, ibc)].copy().reshape(n, 3, 1)
+            du = OP.int1_solve(p, p.rhs, f.reshape(n, 3, 1), r, want_du=True)
+            assert rel_err(r[:, :, 0], g["int1_l%d_bc%d_res" % (il, ibc)]) <= TOL
+            assert rel_err(du[:, 0], g["int1_l%d_bc%d_du" % (il, ibc)]) <= TOL
+        fmin = OP.int1_initialize(gy.der1, lam, 1)
+        fmax = OP.int1_initialize(gy.der1, -lam, 2)
+        fn = OP.ode2_factorize_nn if int(g["ode2_l%d_type" % il]) == 1 else OP.ode2_factorize_nn_sing
+        u, v = fn(fmin, fmax, g["ode2_l%d_f" % il].reshape(n, 2, 1).copy(), g["ode2_l%d_bcs" % il].reshape(2, 2, 1))
+        assert rel_err(u[:, :, 0], g["ode2_l%d_u" % il]) <= 1e-12, il
+        assert rel_err(v[:, :, 0], g["ode2_l%d_v" % il]) <= 1e-12, il
+
+
+def _poisson_setup(nx, ny, nz, seed=0):
+    x = np.arange(nx) / nx * 2 * np.pi
+    z = np.arange(nz) / nz * 2 * np.pi
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5)) * 2.0
+    gx, gy, gz = O.FdmPlan(x, True, True), O.FdmPlan(y, False, False), O.FdmPlan(z, True, True)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    rng = np.random.default_rng(seed)
+    phi = (np.sin(X) * np.cos(2 * Z) * np.exp(0.5 * Y) + np.cos(3 * X + 1) * Y ** 2 + 0.3 * np.sin(2 * Z) * np.cos(2 * Y)
+           + 0.01 * rng.uniform(-1, 1, X.shape)).ravel()
+    return gx, gy, gz, phi
+
+
+@pytest.mark.parametrize("nx,ny,nz", [(32, 40, 16), (16, 24, 1), (64, 33, 8)])
+def test_poisson_discrete_identity(nx, ny, nz):
+    gx, gy, gz, phi = _poisson_setup(nx, ny, nz)
+
+    def P1(d, g, u):
+        return O.opr_partial(d, 1, nx, ny, nz, 0, g, u)[0]
+
+    dphidy = P1(2, gy, phi)
+    f = P1(1, gx, P1(1, gx, phi)) + P1(2, gy, dphidy) + P1(3, gz, P1(3, gz, phi))
+    d3 = dphidy.reshape(nz, ny, nx)
+    plan = OP.PoissonPlan(gx, gy, gz, nx, ny, nz)
+    p, dpdy = OP.opr_poisson_fxz(plan, f, d3[:, 0, :].copy(), d3[:, -1, :].copy())
+    assert rel_err(dpdy, dphidy) <= 1e-12
+    res = P1(1, gx, P1(1, gx, p)) + P1(2, gy, dpdy) + P1(3, gz, P1(3, gz, p)) - f
+    assert np.abs(res).max() / np.abs(f).max() <= 1e-12
+    # the reference pins p = 0 at the bottom wall for the mean mode (opr_odes.f90:179-180)
+    assert abs(p.reshape(nz, ny, nx)[:, 0, :].mean()) <= 1e-12 * np.abs(p).max()
