@@ -116,6 +116,24 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
 int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int nz, int ibc, double nu,
                      const double *s, const double *u, double *result, double *tmp1, int write_transposed);
 
+/* ---- Poisson solver --------------------------------------------------------------------------- */
+/* OPR_Elliptic_Initialize (operators/opr_elliptic.f90:86-250, TYPE_FACTORIZE) + OPR_Fourier_Initialize
+ * (operators/opr_fourier.f90:54-208): eigenvalues lambda(k,i) from the modified wavenumbers of the x and z plans,
+ * singular modes, first-order integral operators of the y plan, rocFFT plans, and the homogeneous solutions of
+ * every mode.  Serial decomposition (one GPU owns all of x and z). */
+typedef struct tlab_poisson_plan *tlab_poisson_plan_t;
+int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                             int nx, int ny, int nz);
+int tlab_poisson_plan_destroy(tlab_poisson_plan_t p);
+
+/* OPR_Poisson(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)   operators/opr_elliptic.f90:33-46, :263-364
+ * Solves lap p = f with periodic x, z and Neumann data bcs_hb, bcs_ht (nx*nz each) in y; ibc must be TLAB_BCS_NN
+ * (BCS_DD returns TLAB_EUNSUPPORTED).  p: forcing in, solution out (its wall planes are overwritten with the BC
+ * data first, like the reference :285-286).  tmp1, tmp2: work arrays of isize_txc_field = (nx+2)*ny*nz doubles
+ * (base/tlab_memory.f90:186-187), destroyed.  dpdy (may be NULL): dp/dy. */
+int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,
+                     const double *bcs_hb, const double *bcs_ht, double *dpdy);
+
 /* TLab_Transpose(a, nra, nca, ma, b, mb)   utils/tlab_transpose.f90:14-82 : b(j,i) = a(i,j), bit-exact */
 int tlab_transpose(const double *a, int nra, int nca, double *b);
 

@@ -1,0 +1,97 @@
+"""GPU parity tests of OPR_Poisson (rocFFT + per-mode ODE kernels, through the C ABI) against the numpy oracle
+(itself pinned against the reference's Fortran at the per-mode level) and through the discrete identity
+div(grad p) = f at BASELINE size.  Tolerance 1e-12 relative (north_star)."""
+import numpy as np
+import pytest
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    T.init(0)
+    return T
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def setup(nx, ny, nz, stretch=True):
+    x = np.arange(nx) / nx * 2 * np.pi
+    z = np.arange(nz) / max(nz, 1) * 2 * np.pi if nz > 1 else np.zeros(1)
+    if stretch:
+        y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5)) * 2.0
+    else:
+        y = np.arange(ny) / (ny - 1.0) * 2.0
+    return x, y, z
+
+
+@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (16, 24, 1, True), (64, 33, 8, False), (128, 64, 32, True), (8, 9, 8, False)])
+def test_poisson_vs_oracle(T, nx, ny, nz, stretch):
+    import torch
+    from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
+    x, y, z = setup(nx, ny, nz, stretch)
+    go = [O.FdmPlan(x, True, True), O.FdmPlan(y, False, not stretch), O.FdmPlan(z, True, True)]
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, not stretch), T.FdmPlan(z, True, True)]
+    rng = np.random.default_rng(nx + ny + nz)
+    N = nx * ny * nz
+    i = np.arange(N)
+    f = np.sin(0.3 * (i % nx)) * np.cos(0.07 * (i // nx)) + 0.2 * rng.uniform(-1, 1, N)
+    hb = rng.uniform(-1, 1, nx * nz)
+    ht = rng.uniform(-1, 1, nx * nz)
+    # make the mean mode compatible (the singular problem assumes it, opr_odes.f90:176): int f dy = ht - hb for the mean
+    plan_o = OP.PoissonPlan(go[0], go[1], go[2], nx, ny, nz)
+    p_ref, d_ref = OP.opr_poisson_fxz(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx))
+    plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+    p = dev(f)
+    t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda")
+    t2 = torch.empty_like(t1)
+    dpdy = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
+    T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p, t1, t2, dev(hb), dev(ht), dpdy)
+    assert rel_err(p.cpu().numpy(), p_ref) <= TOL
+    assert rel_err(dpdy.cpu().numpy(), d_ref) <= TOL
+    # second call on the same plan (module state must be reusable), without dpdy
+    p2 = dev(f)
+    T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p2, t1, t2, dev(hb), dev(ht), None)
+    assert rel_err(p2.cpu().numpy(), p_ref) <= TOL
+    with pytest.raises(T.TlabError):
+        T.OPR_Poisson(plan, nx, ny, nz, T.BCS_DD, p2, t1, t2, dev(hb), dev(ht), None)
+
+
+@pytest.mark.parametrize("n", [256])
+def test_poisson_full_size_identity(T, n):
+    """256^3: div(grad p) = f with the device operators (vpoisson.f90 / SURVEY 4.4 construction), dpdy = d/dy of phi."""
+    import torch
+    nx = ny = nz = n
+    x, y, z = setup(nx, ny, nz, True)
+    gx, gy, gz = T.FdmPlan(x, True, True), T.FdmPlan(y, False, False), T.FdmPlan(z, True, True)
+    N = n ** 3
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    X = torch.from_numpy(x).cuda().view(1, 1, nx); Y = torch.from_numpy(y).cuda().view(1, ny, 1); Z = torch.from_numpy(z).cuda().view(nz, 1, 1)
+    phi = (torch.sin(X) * torch.cos(2 * Z) * torch.exp(0.5 * Y) + torch.cos(3 * X + 1) * Y ** 2 + 0.3 * torch.sin(2 * Z) * torch.cos(2 * Y)).contiguous().view(-1)
+    phi = phi + 0.01 * (torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) - 0.5)
+    a, b, dphidy, f = (torch.empty_like(phi) for _ in range(4))
+    T.OPR_Partial_Y(T.OPR_P1, nx, ny, nz, 0, gy, phi, dphidy)
+    T.OPR_Partial_Y(T.OPR_P1, nx, ny, nz, 0, gy, dphidy, f)
+    T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, gx, phi, a); T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, gx, a, b); f += b
+    T.OPR_Partial_Z(T.OPR_P1, nx, ny, nz, 0, gz, phi, a); T.OPR_Partial_Z(T.OPR_P1, nx, ny, nz, 0, gz, a, b); f += b
+    d3 = dphidy.view(nz, ny, nx)
+    hb, ht = d3[:, 0, :].contiguous().view(-1), d3[:, ny - 1, :].contiguous().view(-1)
+    plan = T.PoissonPlan(gx, gy, gz, nx, ny, nz)
+    t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.empty_like(t1)
+    p = f.clone(); dpdy = torch.empty_like(p)
+    T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p, t1, t2, hb, ht, dpdy)
+    assert float((dpdy - dphidy).abs().max() / dphidy.abs().max()) <= 1e-11
+    res = torch.empty_like(p)
+    T.OPR_Partial_Y(T.OPR_P1, nx, ny, nz, 0, gy, dpdy, res)
+    T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, gx, p, a); T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, gx, a, b); res += b
+    T.OPR_Partial_Z(T.OPR_P1, nx, ny, nz, 0, gz, p, a); T.OPR_Partial_Z(T.OPR_P1, nx, ny, nz, 0, gz, a, b); res += b
+    assert float((res - f).abs().max() / f.abs().max()) <= 1e-11

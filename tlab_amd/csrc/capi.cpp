@@ -69,6 +69,11 @@ double *workspace(size_t n) {
 
 }  // namespace
 
+// hooks for the other translation units (poisson.hip, rhs.hip)
+hipStream_t tlab_current_stream() { return g_stream; }
+void tlab_set_error(const std::string &s) { g_err = s; }
+bool tlab_device_ready() { return g_device >= 0; }
+
 // ------------------------------------------------------------------------------------------------
 // DeviceArray
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,809 @@
+// OPR_Poisson_FourierXZ_Factorize (operators/opr_elliptic.f90:263-364) on the MI355X.
+//
+//   p  --rocFFT r2c (x)-->  --rocFFT c2c (z)-->  f^(kx, j, kz)            (OPR_Fourier_X/Z_Forward, opr_fourier.f90:219,333)
+//   per Fourier mode: (d/dy + l)(d/dy - l) p^ = f^,  l = sqrt(kx'^2 + kz'^2)  (OPR_ODE2_Factorize_NN, opr_odes.f90:265-386)
+//   p^, dp^/dy --c2c (z)--> --c2r (x)--> p, dpdy                          (OPR_Fourier_Z/X_Backward)
+//
+// The reference transposes the spectral array so that each mode's y-line is contiguous and loops over modes on one
+// core.  Here a mode is a THREAD: modes (kx fastest) lie across the lanes, y is the slow index, so every access is a
+// coalesced 16-B-per-lane row and no transpose is needed.  Each first-order integral solve (FDM_Int1_Solve,
+// fdm_integral.f90:219-314: tridiagonal matmul + pentadiagonal solve whose matrix B + l A depends on the mode) is one
+// kernel: the pentadiagonal LU (PENTADFS, linear5.f90:30-71) is recomputed on the fly per mode instead of being
+// stored (the reference stores 2 LUs per mode = 5.4 GB at 512^3), the forward-substituted lines and the three U
+// factors per row go through a scratch array, the backward sweep reads them back.  The three homogeneous solutions
+// the reference recomputes on every call (opr_odes.f90:308-324) depend only on the mode and are computed once at plan
+// creation.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tlab_amd.h"
+#include "plan.hpp"
+#include "poisson_host.hpp"
+
+namespace tlab {
+
+// ------------------------------------------------------------------------------------------------
+// device tables
+// ------------------------------------------------------------------------------------------------
+struct Int1Dev {
+    const double *L0, *L1, *R;   // row-major [n][5], [n][5], [n][3]
+    double rb[3][4], rt[3][4];
+    int n;
+};
+
+enum { FS_FIELD = 0, FS_LINEAR = 1, FS_UNIT = 2 };
+
+struct Int1Args {
+    Int1Dev T;
+    const double *lam;      // [nm] |lambda| of each mode; the kernel applies the sign of its system
+    double lam_sign;        // +1 (BCS_MIN system) or -1 (BCS_MAX system)
+    long long nm;           // number of modes handled (threads)
+    // f source
+    const double *fsrc;     // FS_FIELD: complex field (nxh, ny, nz); FS_LINEAR: SoA [(l*n + j)*nm + t]
+    int nlf;                // FS_LINEAR: number of stored lines (lines >= nlf are zero)
+    int unit_row;           // FS_UNIT: row of the unit entry of line 0
+    double fscale;          // FS_FIELD: normalisation 1/(nx*nz) folded into the load (opr_elliptic.f90:295)
+    int nxh, ny;            // FS_FIELD layout
+    int zero_bsave;         // 1: the f value saved as "opposite boundary value" is zero (f(:,nx)=0 / f(:,1)=0 in the callers)
+    // given boundary value per line: constants, or per-mode array [(l*nm) + t] if bv_ptr != NULL
+    double bv[3];
+    const double *bv_ptr;
+    // outputs
+    double *scratch;        // SoA [(k*n + j)*nm + t], k < NL + 3
+    double *dst;            // SoA [(l*n + j)*nm + t]
+    double *du;             // [(l*nm) + t] or NULL
+    double *bcs_save;       // FS_FIELD only: [(c*nm + t)], c = 0..3 = Re/Im at the bottom, Re/Im at the top (BC data)
+};
+
+__device__ __forceinline__ void lhs_row(const Int1Dev &T, int j, double lam, double (&r)[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = T.L0[j * 5 + k] + lam * T.L1[j * 5 + k];
+}
+
+template <int NL, int FS>
+__device__ __forceinline__ void load_f(const Int1Args &a, int j, long long t, long long fidx0, double (&f)[NL]) {
+    if (FS == FS_FIELD) {
+        const double2 v = reinterpret_cast<const double2 *>(a.fsrc)[fidx0 + (long long)j * a.nxh];
+        f[0] = v.x * a.fscale;
+        if (NL > 1) f[1] = v.y * a.fscale;
+    } else if (FS == FS_LINEAR) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) f[l] = (l < a.nlf) ? a.fsrc[((long long)l * a.T.n + j) * a.nm + t] : 0.0;
+    } else {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) f[l] = (l == 0 && j == a.unit_row) ? 1.0 : 0.0;
+    }
+}
+
+// One FDM_Int1_Solve per thread (mode).  BC = 1: value given at the bottom (BCS_MIN), BC = 2: at the top (BCS_MAX).
+template <int BC, int NL, int FS>
+__global__ void __launch_bounds__(256) k_int1(Int1Args a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nm) return;
+    const int n = a.T.n;
+    const long long nm = a.nm;
+    const double lam = a.lam_sign * a.lam[t];
+    const long long fidx0 = (FS == FS_FIELD) ? (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh) : 0;
+
+    // ---- boundary rows of the system of this mode (fdm_integral.f90:203-211 -> FDM_Bcs_Reduce at the opposite end) ----
+    double l0[5], l1[5], l2[5], lN[5], lN1[5], lN2[5], rb[3][4], rt[3][4];
+    lhs_row(a.T, 0, lam, l0); lhs_row(a.T, 1, lam, l1); lhs_row(a.T, 2, lam, l2);
+    lhs_row(a.T, n - 1, lam, lN); lhs_row(a.T, n - 2, lam, lN1); lhs_row(a.T, n - 3, lam, lN2);
+    if (BC == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rb[j][c] = a.T.rb[j][c];
+        const double d = 1.0 / lN[2];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) lN[k] = -lN[k] * d;
+        lN[2] = 1.0;
+        lN1[0] += lN1[3] * lN[4]; lN1[1] += lN1[3] * lN[0]; lN1[2] += lN1[3] * lN[1];
+        lN2[1] += lN2[4] * lN[4]; lN2[2] += lN2[4] * lN[0]; lN2[3] += lN2[4] * lN[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rt[2][c] = a.T.R[(n - 1) * 3 + c] * d;
+            rt[1][c] = a.T.R[(n - 2) * 3 + c];
+            rt[0][c] = a.T.R[(n - 3) * 3 + c];
+        }
+        rt[0][3] = rt[1][3] = rt[2][3] = 0.0;
+        rt[1][0] -= lN1[3] * rt[2][2]; rt[1][1] -= lN1[3] * rt[2][0]; rt[1][2] -= lN1[3] * rt[2][1];
+        rt[0][1] -= lN2[4] * rt[2][2]; rt[0][2] -= lN2[4] * rt[2][0]; rt[0][3] -= lN2[4] * rt[2][1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rt[j][c] = a.T.rt[j][c];
+        const double d = 1.0 / l0[2];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) l0[k] = -l0[k] * d;
+        l0[2] = 1.0;
+        l1[2] += l1[1] * l0[3]; l1[3] += l1[1] * l0[4]; l1[4] += l1[1] * l0[0];
+        l2[1] += l2[0] * l0[3]; l2[2] += l2[0] * l0[4]; l2[3] += l2[0] * l0[0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rb[0][c + 1] = a.T.R[0 * 3 + c] * d;
+            rb[1][c + 1] = a.T.R[1 * 3 + c];
+            rb[2][c + 1] = a.T.R[2 * 3 + c];
+        }
+        rb[0][0] = rb[1][0] = rb[2][0] = 0.0;
+        rb[1][1] -= l1[1] * rb[0][2]; rb[1][2] -= l1[1] * rb[0][3]; rb[1][3] -= l1[1] * rb[0][1];
+        rb[2][0] -= l2[0] * rb[0][2]; rb[2][1] -= l2[0] * rb[0][3]; rb[2][2] -= l2[0] * rb[0][1];
+    }
+
+    // ---- boundary values: res0 (row 0) and resN (row n-1) as MatMul_3d sees them (fdm_integral.f90:240-245) ----
+    double fb0[NL], fbN[NL], res0[NL], resN[NL];
+    load_f<NL, FS>(a, 0, t, fidx0, fb0);
+    load_f<NL, FS>(a, n - 1, t, fidx0, fbN);
+    if (FS == FS_FIELD && a.bcs_save != nullptr) {  // Neumann data travel in the forcing planes (opr_elliptic.f90:285-286,310-311)
+        a.bcs_save[0 * nm + t] = fb0[0]; a.bcs_save[1 * nm + t] = fb0[NL > 1 ? 1 : 0];
+        a.bcs_save[2 * nm + t] = fbN[0]; a.bcs_save[3 * nm + t] = fbN[NL > 1 ? 1 : 0];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const double given = a.bv_ptr ? a.bv_ptr[(long long)l * nm + t] : a.bv[l];
+        if (BC == 1) { res0[l] = given; resN[l] = a.zero_bsave ? 0.0 : fbN[l]; }
+        else { resN[l] = given; res0[l] = a.zero_bsave ? 0.0 : fb0[l]; }
+    }
+
+    // ---- forward: right-hand side (MatMul_3d, BCS_BOTH), LU on the fly (PENTADFS), forward substitution (PENTADSS) ----
+    double fm[NL], fc[NL], fp[NL];           // f[j-1], f[j], f[j+1]
+    load_f<NL, FS>(a, 1, t, fidx0, fc);
+    load_f<NL, FS>(a, 2, t, fidx0, fp);
+    double f1[NL], fn2[NL];                   // f[1] and f[n-2] are needed again for du
+    double bcs_b[NL], bcs_t[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        f1[l] = fc[l];
+        bcs_b[l] = res0[l] * rb[0][2] + fc[l] * rb[0][3] + fp[l] * rb[0][1];
+        fm[l] = 0.0;
+    }
+    double c1 = 0.0, c2 = 0.0, d1 = 0.0, d2 = 0.0, e1 = 0.0, e2 = 0.0;  // pivots of rows m-1, m-2
+    double y1[NL], y2[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) y1[l] = y2[l] = 0.0;
+    const int nmax = n - 2;
+    for (int j = 1; j <= nmax; ++j) {
+        double fq[NL];                        // f[j+2] prefetch -> becomes fp next iteration
+        if (j + 2 <= n - 1) load_f<NL, FS>(a, j + 2, t, fidx0, fq);
+        else {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) fq[l] = 0.0;
+        }
+        double r[5];
+        if (j == 1) { for (int k = 0; k < 5; ++k) r[k] = l1[k]; }
+        else if (j == 2) { for (int k = 0; k < 5; ++k) r[k] = l2[k]; }
+        else if (j == n - 3) { for (int k = 0; k < 5; ++k) r[k] = lN2[k]; }
+        else if (j == n - 2) { for (int k = 0; k < 5; ++k) r[k] = lN1[k]; }
+        else lhs_row(a.T, j, lam, r);
+        // right-hand side of row j
+        double rhs[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (j == 1) rhs[l] = res0[l] * rb[1][1] + fc[l] * rb[1][2] + fp[l] * rb[1][3];
+            else if (j == 2) rhs[l] = res0[l] * rb[2][0] + fm[l] * rb[2][1] + fc[l] * rb[2][2] + fp[l] * rb[2][3];
+            else if (j == n - 3) rhs[l] = fm[l] * rt[0][0] + fc[l] * rt[0][1] + fp[l] * rt[0][2] + resN[l] * rt[0][3];
+            else if (j == n - 2) rhs[l] = fm[l] * rt[1][0] + fc[l] * rt[1][1] + resN[l] * rt[1][2];
+            else rhs[l] = fm[l] * a.T.R[j * 3 + 0] + fc[l] * a.T.R[j * 3 + 1] + fp[l];
+        }
+        if (j == n - 2) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                fn2[l] = fc[l];
+                bcs_t[l] = fm[l] * rt[2][2] + fc[l] * rt[2][0] + resN[l] * rt[2][1];
+            }
+        }
+        // PENTADFS row m = j
+        double am = 0.0, bm = 0.0, cm = r[2], dm = r[3], em = r[4];
+        if (j == 2) {
+            bm = r[1] / c1;
+            cm = r[2] - bm * d1;
+            dm = r[3] - bm * e1;
+        } else if (j >= 3) {
+            am = r[0] / c2;
+            bm = (r[1] - am * d2) / c1;
+            cm = r[2] - bm * d1 - am * e2;
+            dm = r[3] - bm * e1;
+        }
+        const double cinv = 1.0 / cm;
+        // PENTADSS forward: f(n) = f(n) + f(n-1)*b(n) + f(n-2)*a(n) with a, b negated
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const double y = rhs[l] - y1[l] * bm - y2[l] * am;
+            a.scratch[((long long)l * n + j) * nm + t] = y;
+            y2[l] = y1[l];
+            y1[l] = y;
+        }
+        a.scratch[((long long)(NL + 0) * n + j) * nm + t] = cinv;
+        a.scratch[((long long)(NL + 1) * n + j) * nm + t] = -dm;
+        a.scratch[((long long)(NL + 2) * n + j) * nm + t] = -em;
+        c2 = c1; d2 = d1; e2 = e1;
+        c1 = cm; d1 = dm; e1 = em;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { fm[l] = fc[l]; fc[l] = fp[l]; fp[l] = fq[l]; }
+    }
+
+    // ---- backward substitution ----
+    double x1[NL], x2[NL];                    // x[j+1], x[j+2]
+    double xs1[NL], xs2[NL], xs3[NL];         // x[1], x[2], x[3]
+    double xe2[NL], xe3[NL], xe4[NL];         // x[n-2], x[n-3], x[n-4]
+#pragma unroll
+    for (int l = 0; l < NL; ++l) x1[l] = x2[l] = xs1[l] = xs2[l] = xs3[l] = xe2[l] = xe3[l] = xe4[l] = 0.0;
+    for (int j = nmax; j >= 1; --j) {
+        const double cinv = a.scratch[((long long)(NL + 0) * n + j) * nm + t];
+        const double dneg = a.scratch[((long long)(NL + 1) * n + j) * nm + t];
+        const double eneg = a.scratch[((long long)(NL + 2) * n + j) * nm + t];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const double y = a.scratch[((long long)l * n + j) * nm + t];
+            const double x = (y + x1[l] * dneg + x2[l] * eneg) * cinv;
+            a.dst[((long long)l * n + j) * nm + t] = x;
+            x2[l] = x1[l];
+            x1[l] = x;
+            if (j == 1) xs1[l] = x;
+            if (j == 2) xs2[l] = x;
+            if (j == 3) xs3[l] = x;
+            if (j == n - 2) xe2[l] = x;
+            if (j == n - 3) xe3[l] = x;
+            if (j == n - 4) xe4[l] = x;
+        }
+    }
+
+    // ---- boundary value at the free end and derivative at the given end (fdm_integral.f90:265-311) ----
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (BC == 2) {
+            const double r0 = bcs_b[l] + l0[3] * xs1[l] + l0[4] * xs2[l] + l0[0] * xs3[l];
+            a.dst[((long long)l * n + 0) * nm + t] = r0;
+            a.dst[((long long)l * n + (n - 1)) * nm + t] = resN[l];
+            if (a.du) a.du[(long long)l * nm + t] = lN[2] * resN[l] + lN[1] * xe2[l] + lN[0] * xe3[l] + lN[4] * xe4[l] + a.T.R[(n - 1) * 3 + 0] * fn2[l];
+        } else {
+            const double rN = bcs_t[l] + lN[1] * xe2[l] + lN[0] * xe3[l] + lN[4] * xe4[l];
+            a.dst[((long long)l * n + (n - 1)) * nm + t] = rN;
+            a.dst[((long long)l * n + 0) * nm + t] = res0[l];
+            if (a.du) a.du[(long long)l * nm + t] = l0[2] * res0[l] + l0[3] * xs1[l] + l0[4] * xs2[l] + l0[0] * xs3[l] + a.T.R[0 * 3 + 2] * f1[l];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-mode constants of OPR_ODE2_Factorize_NN: LU of the 3x3 constraint matrix (opr_odes.f90:329-348)
+// hom: SoA [(c*n + j)*nm + t], c = 0 v1, 1 em, 2 u1, 3 sp, 4 ep ; der: [(c*nm + t)], c = 0 du1_n, 1 dsp_n, 2 dep_n
+// cst: [(c*nm + t)], c = 0..8 = a11 a21 a31 a12 a22 a32 a13 a23 a33 (after the LU)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_nn_constants(const double *__restrict__ hom, const double *__restrict__ der,
+                                                      const double *__restrict__ lamv, double *__restrict__ cst, int n, long long nm) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nm) return;
+    const double lam = lamv[t];
+    auto H = [&](int c, int j) { return hom[((long long)c * n + j) * nm + t]; };
+    double a11 = 1.0 + lam * H(3, 0), a21 = H(1, n - 1), a31 = der[1 * nm + t];
+    double a12 = lam * H(4, 0), a22 = lam, a32 = der[2 * nm + t];
+    double a13 = lam * H(2, 0), a23 = H(0, n - 1), a33 = der[0 * nm + t];
+    a12 = a12 / a11;
+    a22 = a22 - a21 * a12;
+    a32 = a32 - a31 * a12;
+    a13 = a13 / a11;
+    a23 = (a23 - a21 * a13) / a22;
+    a33 = a33 - a31 * a13 - a32 * a23;
+    cst[0 * nm + t] = a11; cst[1 * nm + t] = a21; cst[2 * nm + t] = a31;
+    cst[3 * nm + t] = a12; cst[4 * nm + t] = a22; cst[5 * nm + t] = a32;
+    cst[6 * nm + t] = a13; cst[7 * nm + t] = a23; cst[8 * nm + t] = a33;
+}
+
+// ------------------------------------------------------------------------------------------------
+// superposition (opr_odes.f90:350-367): writes p^ and dp^/dy in the spectral field layout.
+// u0, v0: SoA [(l*n + j)*nm + t] (l = Re, Im); du0: [(l*nm + t)]; bcs: [(c*nm + t)] c = ReB, ImB, ReT, ImT
+// ------------------------------------------------------------------------------------------------
+struct CombineArgs {
+    const double *u0, *v0, *du0, *bcs, *hom, *cst, *lam;
+    const unsigned char *skip;   // [nm]: 1 for the singular modes (handled separately)
+    double *p_hat, *dp_hat;      // complex fields (nxh, ny, nz)
+    int n, nxh, ny;
+    long long nm;
+};
+
+__global__ void __launch_bounds__(256) k_nn_combine(CombineArgs a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nm) return;
+    if (a.skip[t]) return;
+    const int n = a.n;
+    const long long nm = a.nm;
+    const double lam = a.lam[t];
+    const long long fidx0 = (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh);
+    const double a11 = a.cst[0 * nm + t], a21 = a.cst[1 * nm + t], a31 = a.cst[2 * nm + t];
+    const double a12 = a.cst[3 * nm + t], a22 = a.cst[4 * nm + t], a32 = a.cst[5 * nm + t];
+    const double a13 = a.cst[6 * nm + t], a23 = a.cst[7 * nm + t], a33 = a.cst[8 * nm + t];
+    double v_1[2], u_n[2], fn[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const double bb = a.bcs[(long long)l * nm + t], bt = a.bcs[(long long)(2 + l) * nm + t];
+        const double u0_1 = a.u0[((long long)l * n + 0) * nm + t];
+        const double v0_n = a.v0[((long long)l * n + (n - 1)) * nm + t];
+        const double du0n = a.du0[(long long)l * nm + t];
+        v_1[l] = (bb - lam * u0_1) / a11;
+        u_n[l] = (bt - v0_n - a21 * v_1[l]) / a22;
+        fn[l] = (bt - du0n - a31 * v_1[l] - a32 * u_n[l]) / a33;
+        u_n[l] = u_n[l] - a23 * fn[l];
+        v_1[l] = v_1[l] - a12 * u_n[l] - a13 * fn[l];
+    }
+    double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
+    for (int j = 0; j < n; ++j) {
+        const double hv1 = a.hom[((long long)0 * n + j) * nm + t], hem = a.hom[((long long)1 * n + j) * nm + t];
+        const double hu1 = a.hom[((long long)2 * n + j) * nm + t], hsp = a.hom[((long long)3 * n + j) * nm + t];
+        const double hep = a.hom[((long long)4 * n + j) * nm + t];
+        double u[2], v[2];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const double u0 = a.u0[((long long)l * n + j) * nm + t], v0 = a.v0[((long long)l * n + j) * nm + t];
+            if (j == n - 1) {
+                u[l] = u_n[l];
+                v[l] = v0 + fn[l] * hv1 + v_1[l] * hem + lam * u[l];
+            } else if (j == 0) {
+                u[l] = u0 + fn[l] * hu1 + v_1[l] * hsp + u_n[l] * hep;
+                v[l] = v_1[l] + lam * u[l];
+            } else {
+                u[l] = u0 + fn[l] * hu1 + v_1[l] * hsp + u_n[l] * hep;
+                v[l] = v0 + fn[l] * hv1 + v_1[l] * hem + lam * u[l];
+            }
+        }
+        const long long idx = fidx0 + (long long)j * a.nxh;
+        P[idx] = make_double2(u[0], u[1]);
+        D[idx] = make_double2(v[0], v[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// singular modes (lambda = 0: OPR_ODE2_Factorize_NN_Sing -> _DN_Sing, opr_odes.f90:165-183, 37-96): <= 4 modes
+// ------------------------------------------------------------------------------------------------
+// gather f^ * norm of the singular modes into SoA [(l*n + j)*ns + s], with row 0 zeroed (f(:,1) = 0), and the top BC
+__global__ void k_sing_gather(const double *__restrict__ f_hat, const int *__restrict__ modes, int ns, int n, int nxh, int ny,
+                              double scale, double *__restrict__ fs, double *__restrict__ bct) {
+    const int s = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+    if (s >= ns || j >= n) return;
+    const long long t = modes[s];
+    const long long idx = (t % nxh) + (long long)nxh * ny * (t / nxh) + (long long)j * nxh;
+    const double2 v = reinterpret_cast<const double2 *>(f_hat)[idx];
+    fs[((long long)0 * n + j) * ns + s] = (j == 0) ? 0.0 : v.x * scale;
+    fs[((long long)1 * n + j) * ns + s] = (j == 0) ? 0.0 : v.y * scale;
+    if (j == n - 1) { bct[0 * ns + s] = v.x * scale; bct[1 * ns + s] = v.y * scale; }
+}
+
+// u = u0 + c u1, v = v0 + c v1, c = (v0(1) - du0_n) / (du1_n - v1(1)); scatter into the spectral fields
+__global__ void k_sing_combine(const double *__restrict__ u0, const double *__restrict__ v0, const double *__restrict__ u1,
+                               const double *__restrict__ v1, const double *__restrict__ du0, const double *__restrict__ du1,
+                               const int *__restrict__ modes, int ns, int n, int nxh, int ny, double *__restrict__ p_hat,
+                               double *__restrict__ dp_hat) {
+    const int s = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+    if (s >= ns || j >= n) return;
+    const long long t = modes[s];
+    const long long idx = (t % nxh) + (long long)nxh * ny * (t / nxh) + (long long)j * nxh;
+    const double f1 = 1.0 / (du1[0 * ns + s] - v1[((long long)0 * n + 0) * ns + s]);
+    double u[2], v[2];
+    for (int l = 0; l < 2; ++l) {
+        const double c = (v0[((long long)l * n + 0) * ns + s] - du0[l * ns + s]) * f1;
+        u[l] = u0[((long long)l * n + j) * ns + s] + c * u1[((long long)0 * n + j) * ns + s];
+        v[l] = v0[((long long)l * n + j) * ns + s] + c * v1[((long long)0 * n + j) * ns + s];
+    }
+    reinterpret_cast<double2 *>(p_hat)[idx] = make_double2(u[0], u[1]);
+    reinterpret_cast<double2 *>(dp_hat)[idx] = make_double2(v[0], v[1]);
+}
+
+// p(:,1,:) = bcs_hb, p(:,ny,:) = bcs_ht  (opr_elliptic.f90:285-286)
+__global__ void __launch_bounds__(256) k_set_wall_planes(double *__restrict__ p, const double *__restrict__ hb,
+                                                          const double *__restrict__ ht, int nx, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * nz) return;
+    const int ix = (int)(i % nx);
+    const long long k = i / nx;
+    p[ix + (long long)nx * (0 + (long long)ny * k)] = hb[i];
+    p[ix + (long long)nx * ((ny - 1) + (long long)ny * k)] = ht[i];
+}
+
+}  // namespace tlab
+
+// ================================================================================================
+// host side: plan, rocFFT, orchestration
+// ================================================================================================
+using namespace tlab;
+
+namespace {
+
+void hipc(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP ") + what + ": " + hipGetErrorString(e));
+}
+void fftc(rocfft_status s, const char *what) {
+    if (s != rocfft_status_success) throw std::runtime_error(std::string("rocFFT ") + what + " failed (status " + std::to_string((int)s) + ")");
+}
+
+struct DBuf {
+    double *p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = count;
+        if (count) hipc(hipMalloc((void **)&p, count * sizeof(double)), "hipMalloc");
+    }
+    void upload(const std::vector<double> &h) {
+        alloc(h.size());
+        if (n) hipc(hipMemcpy(p, h.data(), n * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+    }
+    ~DBuf() { if (p) (void)hipFree(p); }
+};
+
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *work = nullptr;
+    size_t work_bytes = 0;
+    ~FftPlan() {
+        if (info) rocfft_execution_info_destroy(info);
+        if (plan) rocfft_plan_destroy(plan);
+        if (work) (void)hipFree(work);
+    }
+    void finish() {
+        fftc(rocfft_plan_get_work_buffer_size(plan, &work_bytes), "work size");
+        fftc(rocfft_execution_info_create(&info), "info");
+        if (work_bytes) {
+            hipc(hipMalloc(&work, work_bytes), "hipMalloc(fft work)");
+            fftc(rocfft_execution_info_set_work_buffer(info, work, work_bytes), "set work");
+        }
+    }
+    void exec(void *in, void *out, hipStream_t st) {
+        fftc(rocfft_execution_info_set_stream(info, st), "set stream");
+        void *ib[1] = {in}, *ob[1] = {out};
+        fftc(rocfft_execute(plan, ib, ob, info), "execute");
+    }
+};
+
+bool g_rocfft_up = false;
+
+}  // namespace
+
+struct tlab_poisson_plan {
+    int nx = 0, ny = 0, nz = 0, nxh = 0;
+    long long nm = 0;                 // modes = nxh * nz
+    double norm = 1.0;
+    Int1Tables tmin, tmax;            // host copies
+    DBuf d_L0[2], d_L1[2], d_R[2];    // [0] BCS_MIN tables, [1] BCS_MAX tables
+    DBuf lam;                         // [nm]  sqrt(kx'^2 + kz'^2)
+    DBuf hom, der, cst;               // homogeneous solutions [5][ny][nm], their boundary derivatives [3][nm], 3x3 LU [9][nm]
+    DBuf scratch, v0, u0, du0, bcs;   // per-call work: [5][ny][nm], [2][ny][nm] x2, [2][nm], [4][nm]
+    DBuf cwork;                       // complex work field (nxh*ny*nz complex)
+    std::vector<int> sing_modes;      // flat mode indices t = kx + nxh*kz of the singular modes
+    int *d_sing = nullptr;
+    unsigned char *d_skip = nullptr;
+    DBuf s_lam, s_f, s_unit, s_bct, s_v0, s_v1, s_u0, s_u1, s_du0, s_du1, s_scr;
+    FftPlan fx_r2c, fx_c2r, fz_f, fz_b;
+    FftPlan f2_fwd, f2_bwd;           // optional fused 2-D (x,z) transforms, batch over y
+    bool use_2d = false;
+    hipStream_t side = nullptr;       // the <= 4 singular modes are solved beside the regular ones
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~tlab_poisson_plan() {
+        if (d_sing) (void)hipFree(d_sing);
+        if (d_skip) (void)hipFree(d_skip);
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
+    Int1Dev dev(int which) const {
+        const Int1Tables &T = which == 0 ? tmin : tmax;
+        Int1Dev d;
+        d.L0 = d_L0[which].p; d.L1 = d_L1[which].p; d.R = d_R[which].p; d.n = ny;
+        for (int j = 0; j < 3; ++j)
+            for (int c = 0; c < 4; ++c) { d.rb[j][c] = T.rb[j][c]; d.rt[j][c] = T.rt[j][c]; }
+        return d;
+    }
+};
+
+namespace {
+
+template <int BC, int NL, int FS>
+void launch_int1(const Int1Args &a, hipStream_t st) {
+    const int grid = (int)((a.nm + 255) / 256);
+    hipLaunchKernelGGL((k_int1<BC, NL, FS>), dim3(grid), dim3(256), 0, st, a);
+    hipc(hipGetLastError(), "k_int1");
+}
+
+Int1Args base_args(const tlab_poisson_plan &P, int which, const double *lam, long long nm, double *scratch) {
+    Int1Args a{};
+    a.T = P.dev(which);
+    a.lam = lam;
+    a.lam_sign = which == 0 ? 1.0 : -1.0;
+    a.nm = nm;
+    a.fscale = 1.0;
+    a.nxh = P.nxh;
+    a.ny = P.ny;
+    a.scratch = scratch;
+    return a;
+}
+
+void build_fft(tlab_poisson_plan &P) {
+    if (!g_rocfft_up) {
+        fftc(rocfft_setup(), "setup");
+        g_rocfft_up = true;
+    }
+    const size_t nx = P.nx, ny = P.ny, nz = P.nz, nxh = P.nxh;
+    {   // x: real -> complex, batch ny*nz (dfftw_plan_many_dft_r2c, opr_fourier.f90:163-166)
+        rocfft_plan_description d = nullptr;
+        fftc(rocfft_plan_description_create(&d), "desc");
+        size_t is[1] = {1}, os[1] = {1};
+        fftc(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr,
+                                                     1, is, nx, 1, os, nxh), "layout r2c");
+        size_t len[1] = {nx};
+        fftc(rocfft_plan_create(&P.fx_r2c.plan, rocfft_placement_notinplace, rocfft_transform_type_real_forward, rocfft_precision_double,
+                                1, len, ny * nz, d), "plan r2c");
+        rocfft_plan_description_destroy(d);
+        P.fx_r2c.finish();
+    }
+    {   // x: complex -> real (dfftw_plan_many_dft_c2r, :167-170)
+        rocfft_plan_description d = nullptr;
+        fftc(rocfft_plan_description_create(&d), "desc");
+        size_t is[1] = {1}, os[1] = {1};
+        fftc(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr, nullptr,
+                                                     1, is, nxh, 1, os, nx), "layout c2r");
+        size_t len[1] = {nx};
+        fftc(rocfft_plan_create(&P.fx_c2r.plan, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, rocfft_precision_double,
+                                1, len, ny * nz, d), "plan c2r");
+        rocfft_plan_description_destroy(d);
+        P.fx_c2r.finish();
+    }
+    if (nz > 1) {  // z: complex <-> complex, stride nxh*ny, batch nxh*ny with distance 1 (dfftw_plan_many_dft, :111-119)
+        for (int dir = 0; dir < 2; ++dir) {
+            rocfft_plan_description d = nullptr;
+            fftc(rocfft_plan_description_create(&d), "desc");
+            size_t st[1] = {nxh * ny};
+            fftc(rocfft_plan_description_set_data_layout(d, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved,
+                                                         nullptr, nullptr, 1, st, 1, 1, st, 1), "layout c2c");
+            size_t len[1] = {nz};
+            FftPlan &F = dir == 0 ? P.fz_f : P.fz_b;
+            fftc(rocfft_plan_create(&F.plan, rocfft_placement_notinplace,
+                                    dir == 0 ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
+                                    rocfft_precision_double, 1, len, nxh * ny, d), "plan c2c");
+            rocfft_plan_description_destroy(d);
+            F.finish();
+        }
+    }
+}
+
+// fused 2-D transforms over (x, z), one per y plane: same arithmetic as r2c(x) followed by c2c(z)
+void build_fft_2d(tlab_poisson_plan &P) {
+    const size_t nx = P.nx, ny = P.ny, nz = P.nz, nxh = P.nxh;
+    for (int dir = 0; dir < 2; ++dir) {
+        rocfft_plan_description d = nullptr;
+        fftc(rocfft_plan_description_create(&d), "desc");
+        size_t rs[2] = {1, nx * ny}, cs[2] = {1, nxh * ny};
+        if (dir == 0)
+            fftc(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr,
+                                                         2, rs, nx, 2, cs, nxh), "layout 2d fwd");
+        else
+            fftc(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr, nullptr,
+                                                         2, cs, nxh, 2, rs, nx), "layout 2d bwd");
+        size_t len[2] = {nx, nz};
+        FftPlan &F = dir == 0 ? P.f2_fwd : P.f2_bwd;
+        fftc(rocfft_plan_create(&F.plan, rocfft_placement_notinplace,
+                                dir == 0 ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
+                                rocfft_precision_double, 2, len, ny, d), "plan 2d");
+        rocfft_plan_description_destroy(d);
+        F.finish();
+    }
+}
+
+// homogeneous solutions and constraint LU of every mode (opr_odes.f90:308-348), once per plan
+void build_homogeneous(tlab_poisson_plan &P, hipStream_t st) {
+    const long long nm = P.nm;
+    const int n = P.ny;
+    // v^(1), e^(-): v' + l v = (delta_n, 0), v(1) = (0, 1)   [third line of the reference is identically zero]
+    Int1Args a = base_args(P, 0, P.lam.p, nm, P.scratch.p);
+    a.unit_row = n - 1;
+    a.zero_bsave = 0;
+    a.bv[0] = 0.0; a.bv[1] = 1.0; a.bv[2] = 0.0;
+    a.dst = P.hom.p;                                   // lines 0,1 -> v1, em
+    launch_int1<1, 2, FS_UNIT>(a, st);
+    // u^(1), s^(+), e^(+): u' - l u = (v1, em, 0), u(n) = (0, 0, 1)
+    Int1Args b = base_args(P, 1, P.lam.p, nm, P.scratch.p);
+    b.fsrc = P.hom.p;
+    b.nlf = 2;
+    b.zero_bsave = 0;
+    b.bv[0] = 0.0; b.bv[1] = 0.0; b.bv[2] = 1.0;
+    b.dst = P.hom.p + (size_t)2 * n * nm;              // lines 2,3,4 -> u1, sp, ep
+    b.du = P.der.p;
+    launch_int1<2, 3, FS_LINEAR>(b, st);
+    const int grid = (int)((nm + 255) / 256);
+    hipLaunchKernelGGL(k_nn_constants, dim3(grid), dim3(256), 0, st, P.hom.p, P.der.p, P.lam.p, P.cst.p, n, nm);
+    hipc(hipGetLastError(), "k_nn_constants");
+}
+
+}  // namespace
+
+extern hipStream_t tlab_current_stream();
+extern void tlab_set_error(const std::string &s);
+extern bool tlab_device_ready();
+
+extern "C" {
+
+int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
+                             int nz) {
+    try {
+        if (!out || !gx || !gy || !gz) throw std::invalid_argument("tlab_poisson_plan_create: null argument");
+        if (!tlab_device_ready()) throw std::runtime_error("tlab_init has not been called (no CPU fallback exists)");
+        if (gx->t.n != nx || gy->t.n != ny || gz->t.n != nz) throw std::invalid_argument("plan sizes do not match nx, ny, nz");
+        if (!gx->t.periodic || (nz > 1 && !gz->t.periodic) || gy->t.periodic)
+            throw std::invalid_argument("OPR_Poisson_FourierXZ needs periodic x, z and non-periodic y");
+        if (nx % 2 != 0) throw std::invalid_argument("Imax must be a multiple of 2 for the FFT operations (opr_fourier.f90:72-75)");
+        auto P = std::make_unique<tlab_poisson_plan>();
+        P->nx = nx; P->ny = ny; P->nz = nz; P->nxh = nx / 2 + 1;
+        P->nm = (long long)P->nxh * nz;
+        P->norm = 1.0 / ((double)nx * (double)nz);                      // opr_elliptic.f90:130
+        int1_build_tables(gy->t.der1, 1, P->tmin);
+        int1_build_tables(gy->t.der1, 2, P->tmax);
+        P->d_L0[0].upload(P->tmin.L0); P->d_L1[0].upload(P->tmin.L1); P->d_R[0].upload(P->tmin.R);
+        P->d_L0[1].upload(P->tmax.L0); P->d_L1[1].upload(P->tmax.L1); P->d_R[1].upload(P->tmax.R);
+        // lambda(k,i) = mwn_x(i)^2 + mwn_z(k)^2 (opr_elliptic.f90:199-203), stored as sqrt (:205-209)
+        const long long nm = P->nm;
+        std::vector<double> lam((size_t)nm);
+        std::vector<unsigned char> skip((size_t)nm, 0);
+        for (int k = 0; k < nz; ++k)
+            for (int i = 0; i < P->nxh; ++i) {
+                double l2 = std::pow(gx->t.der1.mwn[i], 2.0);
+                if (nz > 1) l2 += std::pow(gz->t.der1.mwn[k], 2.0);
+                lam[(size_t)i + (size_t)P->nxh * k] = std::sqrt(l2);
+            }
+        const int isg[2] = {0, nx / 2}, ksg[2] = {0, nz > 1 ? nz / 2 : 0};   // i_sing, k_sing (:148-149), 0-based
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                const int t = isg[a] + P->nxh * ksg[b];
+                if (!skip[t]) { skip[t] = 1; P->sing_modes.push_back(t); }
+            }
+        P->lam.upload(lam);
+        hipc(hipMalloc((void **)&P->d_skip, (size_t)nm), "hipMalloc");
+        hipc(hipMemcpy(P->d_skip, skip.data(), (size_t)nm, hipMemcpyHostToDevice), "hipMemcpy");
+        const int ns = (int)P->sing_modes.size();
+        hipc(hipMalloc((void **)&P->d_sing, ns * sizeof(int)), "hipMalloc");
+        hipc(hipMemcpy(P->d_sing, P->sing_modes.data(), ns * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
+        std::vector<double> slam(ns);
+        for (int s = 0; s < ns; ++s) slam[s] = lam[P->sing_modes[s]];
+        P->s_lam.upload(slam);
+        const size_t n = ny;
+        P->hom.alloc(5 * n * nm); P->der.alloc(3 * nm); P->cst.alloc(9 * nm);
+        P->scratch.alloc(6 * n * nm);      // NL + 3 components, NL <= 3
+        P->v0.alloc(2 * n * nm); P->u0.alloc(2 * n * nm); P->du0.alloc(2 * nm); P->bcs.alloc(4 * nm);
+        P->cwork.alloc((size_t)2 * P->nxh * ny * nz);
+        P->s_f.alloc(2 * n * ns); P->s_bct.alloc(2 * ns); P->s_v0.alloc(2 * n * ns); P->s_v1.alloc(2 * n * ns);
+        P->s_u0.alloc(2 * n * ns); P->s_u1.alloc(2 * n * ns); P->s_du0.alloc(2 * ns); P->s_du1.alloc(2 * ns); P->s_scr.alloc(5 * n * ns);
+        build_fft(*P);
+        {   // fused 2-D (x,z) transforms are ~2x faster than r2c(x) + strided c2c(z) at 512^3, but rocFFT does not build them
+            // for every layout: fall back to the two 1-D plans when plan creation fails (TLAB_FFT2D=0 forces the 1-D path)
+            const char *e = getenv("TLAB_FFT2D");
+            if (nz > 1 && !(e && atoi(e) == 0)) {
+                try {
+                    build_fft_2d(*P);
+                    P->use_2d = true;
+                } catch (const std::exception &) {
+                    P->use_2d = false;
+                }
+            }
+        }
+        hipc(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking), "stream");
+        hipc(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming), "event");
+        hipc(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), "event");
+        hipStream_t st = tlab_current_stream();
+        build_homogeneous(*P, st);
+        hipc(hipStreamSynchronize(st), "sync");
+        *out = P.release();
+        return TLAB_OK;
+    } catch (const std::invalid_argument &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EHIP;
+    }
+}
+
+int tlab_poisson_plan_destroy(tlab_poisson_plan_t p) {
+    delete p;
+    return TLAB_OK;
+}
+
+int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,
+                     const double *bcs_hb, const double *bcs_ht, double *dpdy) {
+    try {
+        if (!P || !p || !tmp1 || !tmp2 || !bcs_hb || !bcs_ht) throw std::invalid_argument("tlab_opr_poisson: null argument");
+        if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_poisson: sizes do not match the plan");
+        if (ibc != TLAB_BCS_NN) {
+            tlab_set_error("OPR_Poisson: only BCS_NN is built on the device (the RHS call, rhs_global_incompressible_1.f90:284)");
+            return TLAB_EUNSUPPORTED;
+        }
+        if (p == tmp1 || p == tmp2 || tmp1 == tmp2 || dpdy == p || dpdy == tmp1 || dpdy == tmp2) throw std::invalid_argument("arrays must be distinct");
+        hipStream_t st = tlab_current_stream();
+        const long long nm = P->nm;
+        const int n = ny, nxh = P->nxh;
+        // BC planes into the forcing (opr_elliptic.f90:285-286)
+        hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, p, bcs_hb, bcs_ht, nx, ny, nz);
+        // forward transforms: p -> tmp2 -> tmp1 (:288-293); the scaling by norm (:295) is folded into the loads below
+        double *f_hat = tmp1;
+        if (P->use_2d) {
+            P->f2_fwd.exec(p, tmp1, st);
+        } else if (nz > 1) {
+            P->fx_r2c.exec(p, tmp2, st);
+            P->fz_f.exec(tmp2, tmp1, st);
+        } else {
+            P->fx_r2c.exec(p, tmp1, st);
+        }
+        hipc(hipEventRecord(P->ev_fork, st), "event record");
+        hipc(hipStreamWaitEvent(P->side, P->ev_fork, 0), "stream wait");
+        // ---- regular modes: OPR_ODE2_Factorize_NN (opr_odes.f90:302-318) ----
+        Int1Args a = base_args(*P, 0, P->lam.p, nm, P->scratch.p);   // v' + l v = f, v(1) = 0
+        a.fsrc = f_hat; a.fscale = P->norm; a.zero_bsave = 1; a.bcs_save = P->bcs.p; a.dst = P->v0.p;
+        launch_int1<1, 2, FS_FIELD>(a, st);
+        Int1Args b = base_args(*P, 1, P->lam.p, nm, P->scratch.p);   // u' - l u = v, u(n) = 0
+        b.fsrc = P->v0.p; b.nlf = 2; b.zero_bsave = 0; b.dst = P->u0.p; b.du = P->du0.p;
+        launch_int1<2, 2, FS_LINEAR>(b, st);
+        // ---- singular modes: OPR_ODE2_Factorize_NN_Sing -> _DN_Sing (opr_odes.f90:165-183, 37-96) ----
+        const int ns = (int)P->sing_modes.size();
+        hipStream_t ss = P->side;   // independent of the regular modes until the scatter below
+        {
+            dim3 g(ns, (n + 63) / 64), blk(64);
+            hipLaunchKernelGGL(k_sing_gather, g, blk, 0, ss, f_hat, P->d_sing, ns, n, nxh, ny, P->norm, P->s_f.p, P->s_bct.p);
+            Int1Args s1 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v' = f (f(1)=0), v(n) = bcs_t
+            s1.fsrc = P->s_f.p; s1.nlf = 2; s1.zero_bsave = 0; s1.bv_ptr = P->s_bct.p; s1.dst = P->s_v0.p;
+            launch_int1<2, 2, FS_LINEAR>(s1, ss);
+            Int1Args s2 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v1' = delta_1, v1(n) = 0
+            s2.unit_row = 0; s2.zero_bsave = 0; s2.dst = P->s_v1.p;
+            launch_int1<2, 2, FS_UNIT>(s2, ss);
+            Int1Args s3 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u' = v, u(1) = bcs_b = 0
+            s3.fsrc = P->s_v0.p; s3.nlf = 2; s3.zero_bsave = 0; s3.dst = P->s_u0.p; s3.du = P->s_du0.p;
+            launch_int1<1, 2, FS_LINEAR>(s3, ss);
+            Int1Args s4 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u1' = v1, u1(1) = 0
+            s4.fsrc = P->s_v1.p; s4.nlf = 2; s4.zero_bsave = 0; s4.dst = P->s_u1.p; s4.du = P->s_du1.p;
+            launch_int1<1, 2, FS_LINEAR>(s4, ss);
+        }
+        // ---- superposition; p^ -> tmp1 (over f^), dp^/dy -> tmp2 ----
+        CombineArgs c{};
+        c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.hom = P->hom.p; c.cst = P->cst.p; c.lam = P->lam.p;
+        c.skip = P->d_skip; c.p_hat = tmp1; c.dp_hat = tmp2; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
+        hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+        {   // the singular modes write other entries of tmp1/tmp2 than k_nn_combine (which skips them), but f^ (= tmp1) must
+            // have been consumed by the regular v-solve first: order the scatter after it through the main stream
+            hipc(hipEventRecord(P->ev_join, ss), "event record");
+            hipc(hipStreamWaitEvent(st, P->ev_join, 0), "stream wait");
+            dim3 g(ns, (n + 63) / 64), blk(64);
+            hipLaunchKernelGGL(k_sing_combine, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->s_u1.p, P->s_v1.p, P->s_du0.p, P->s_du1.p,
+                               P->d_sing, ns, n, nxh, ny, tmp1, tmp2);
+        }
+        hipc(hipGetLastError(), "poisson kernels");
+        // ---- backward transforms (:341-356) ----
+        if (P->use_2d) {
+            P->f2_bwd.exec(tmp1, p, st);
+            if (dpdy) P->f2_bwd.exec(tmp2, dpdy, st);
+        } else if (nz > 1) {
+            P->fz_b.exec(tmp1, P->cwork.p, st);
+            P->fx_c2r.exec(P->cwork.p, p, st);
+            if (dpdy) {
+                P->fz_b.exec(tmp2, P->cwork.p, st);
+                P->fx_c2r.exec(P->cwork.p, dpdy, st);
+            }
+        } else {
+            P->fx_c2r.exec(tmp1, p, st);
+            if (dpdy) P->fx_c2r.exec(tmp2, dpdy, st);
+        }
+        return TLAB_OK;
+    } catch (const std::invalid_argument &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EHIP;
+    }
+}
+
+}  // extern "C"

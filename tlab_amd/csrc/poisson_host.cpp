@@ -1,0 +1,170 @@
+// Host (init-time) part of the Poisson solver: lambda-independent tables of the first-order integral operators.
+//
+// Restates FDM_Int1_CreateSystem (fdm/fdm_integral.f90:91-214) and FDM_Bcs_Reduce (fdm/fdm_base.f90:304-391) for the
+// tridiagonal-LHS / pentadiagonal-RHS first-derivative schemes (C1N6: ndl = 3, ndr = 5).  Everything the reference
+// computes per Fourier mode that is LINEAR in the mode's constant lambda is computed once here as a pair (c0, c1),
+// lhs(lambda) = L0 + lambda * L1; the only non-linear step (the reduction of the opposite boundary, :203-211, which
+// divides by a lambda-dependent pivot) and the pentadiagonal LU are done per mode on the device (poisson.hip).
+#include "poisson_host.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace tlab {
+
+namespace {
+
+struct Lin {  // c0 + lambda * c1
+    double c0 = 0.0, c1 = 0.0;
+};
+inline Lin operator*(Lin a, double s) { return Lin{a.c0 * s, a.c1 * s}; }
+
+// FDM_Bcs_Reduce for plain doubles (fdm_base.f90:304-391).  1-based accessors.
+struct Reduce {
+    int nx, ndl, ndr;
+    double *lhs;        // (nx, ndl) column-major
+    const double *rhs;  // (nx, ndr) column-major, leading dimension nx
+    double *rhs_b;      // rhs_b(1:5, 0:7)  -> [(j-1) + 5*c]
+    double *rhs_t;      // rhs_t(0:4, 1:8)  -> [r + 5*(c-1)]
+    double &L(int i, int k) { return lhs[(i - 1) + (size_t)nx * (k - 1)]; }
+    double R(int i, int k) const { return rhs[(i - 1) + (size_t)nx * (k - 1)]; }
+    double &RB(int j, int c) { return rhs_b[(j - 1) + 5 * c]; }
+    double &RT(int r, int c) { return rhs_t[r + 5 * (c - 1)]; }
+
+    void run(int ibc) {  // ibc: 1 = BCS_MIN, 2 = BCS_MAX
+        const int idl = ndl / 2 + 1, idr = ndr / 2 + 1, nx_t = idr, mx = std::max(idl, idr + 1);
+        if (ibc == 1) {
+            const double dummy = 1.0 / L(1, idl);
+            for (int k = 1; k <= ndl; ++k) L(1, k) = -L(1, k) * dummy;
+            L(1, idl) = 1.0;
+            for (int ir = 1; ir <= idl - 1; ++ir) {
+                for (int ic = idl + 1; ic <= ndl; ++ic) L(1 + ir, ic - ir) = L(1 + ir, ic - ir) + L(1 + ir, idl - ir) * L(1, ic);
+                const int ic = ndl + 1;
+                L(1 + ir, ic - ir) = L(1 + ir, ic - ir) + L(1 + ir, idl - ir) * L(1, 1);
+            }
+            for (int j = 1; j <= mx; ++j)
+                for (int c = 1; c <= ndr; ++c) RB(j, c) = R(j, c);
+            for (int c = 1; c <= ndr; ++c) RB(1, c) = RB(1, c) * dummy;
+            for (int ir = 1; ir <= idl - 1; ++ir) {
+                for (int ic = idr; ic <= ndr; ++ic) RB(1 + ir, ic - ir) = RB(1 + ir, ic - ir) - L(1 + ir, idl - ir) * RB(1, ic);
+                const int ic = ndr + 1;
+                RB(1 + ir, ic - ir) = RB(1 + ir, ic - ir) - L(1 + ir, idl - ir) * RB(1, 1);
+            }
+        } else {
+            const double dummy = 1.0 / L(nx, idl);
+            for (int k = 1; k <= ndl; ++k) L(nx, k) = -L(nx, k) * dummy;
+            L(nx, idl) = 1.0;
+            for (int ir = 1; ir <= idl - 1; ++ir) {
+                L(nx - ir, ir) = L(nx - ir, ir) + L(nx - ir, idl + ir) * L(nx, ndl);
+                for (int ic = 1; ic <= idl - 1; ++ic) L(nx - ir, ic + ir) = L(nx - ir, ic + ir) + L(nx - ir, idl + ir) * L(nx, ic);
+            }
+            for (int j = 0; j < mx; ++j)
+                for (int c = 1; c <= ndr; ++c) RT(nx_t - mx + 1 + j, c) = R(nx - mx + 1 + j, c);
+            for (int c = 1; c <= ndr; ++c) RT(nx_t, c) = RT(nx_t, c) * dummy;
+            for (int ir = 1; ir <= idl - 1; ++ir) {
+                RT(nx_t - ir, ir) = RT(nx_t - ir, ir) - L(nx - ir, idl + ir) * RT(nx_t, ndr);
+                for (int ic = 1; ic <= idr; ++ic) RT(nx_t - ir, ic + ir) = RT(nx_t - ir, ic + ir) - L(nx - ir, idl + ir) * RT(nx_t, ic);
+            }
+        }
+    }
+};
+
+}  // namespace
+
+void int1_build_tables(const DerTables &g, int ibc, Int1Tables &out) {
+    if (g.ndl != 3 || g.ndr != 5) throw std::runtime_error("Poisson: needs the CompactJacobian6 first derivative (3/5 diagonals)");
+    if (g.periodic) throw std::runtime_error("Poisson: the wall-normal direction must not be periodic");
+    const int nx = g.n, ndl = 3, ndr = 5, idl = 2, idr = 3;
+    if (nx < 8) throw std::runtime_error("Poisson: too few points in y");
+    out.n = nx;
+    out.bc = ibc;
+
+    std::vector<double> A(g.lhs.begin(), g.lhs.begin() + (size_t)nx * ndl);  // fdmi%rhs
+    double rhsr_b[5 * 8] = {0}, rhsr_t[5 * 8] = {0};
+    Reduce red{nx, ndl, ndr, A.data(), g.rhs.data(), rhsr_b, rhsr_t};
+    red.run(ibc);
+#define AA(i, k) A[((i)-1) + (size_t)nx * ((k)-1)]
+#define A0(i, k) g.lhs[((i)-1) + (size_t)nx * ((k)-1)]
+#define BB(i, k) g.rhs[((i)-1) + (size_t)nx * ((k)-1)]
+#define RRB(j, c) rhsr_b[((j)-1) + 5 * (c)]
+#define RRT(r, c) rhsr_t[(r) + 5 * ((c)-1)]
+    double rhs_b[5 * 8] = {0}, rhs_t[5 * 8] = {0};
+#define RB(j, c) rhs_b[((j)-1) + 5 * (c)]
+#define RT(r, c) rhs_t[(r) + 5 * ((c)-1)]
+    if (ibc == 1) {  // :134-138
+        for (int j = 1; j <= idl + 1; ++j)
+            for (int c = 1; c <= ndl; ++c) RB(j, c) = AA(j, c);
+        for (int ir = 1; ir <= idr - 1; ++ir) RB(1 + ir, idl - ir) = -RRB(1 + ir, idr - ir);
+    } else {  // :140-144
+        for (int r = 0; r <= idl; ++r)
+            for (int c = 1; c <= ndl; ++c) RT(r, c) = AA(nx - idl + r, c);
+        for (int ir = 1; ir <= idr - 1; ++ir) RT(idl - ir, idl + ir) = -RRT(idr - ir, idr + ir);
+    }
+    // lhs = B + lambda A  (:150-156), kept as (c0, c1)
+    std::vector<Lin> lhs((size_t)nx * ndr);
+#define LL(i, k) lhs[((i)-1) + (size_t)nx * ((k)-1)]
+    for (int k = 1; k <= ndr; ++k)
+        for (int i = 1; i <= nx; ++i) LL(i, k) = Lin{BB(i, k), 0.0};
+    for (int i = 1; i <= nx; ++i) LL(i, idr).c1 += A0(i, idl);
+    for (int ii = 1; ii <= idl - 1; ++ii) {
+        for (int i = 1 + ii; i <= nx; ++i) LL(i, idr - ii).c1 += A0(i, idl - ii);
+        for (int i = 1; i <= nx - ii; ++i) LL(i, idr + ii).c1 += A0(i, idl + ii);
+    }
+    if (ibc == 1) {  // :159-165
+        for (int j = 1; j <= idr; ++j)
+            for (int c = 1; c <= ndr; ++c) LL(j, c) = Lin{RRB(j, c), 0.0};
+        for (int c = 0; c < idl - 1; ++c) LL(1, idr + 1 + c).c1 -= RB(1, idl + 1 + c);
+        for (int ir = 1; ir <= idr - 1; ++ir)
+            for (int c = 0; c < ndl; ++c) LL(1 + ir, idr - idl + 1 + c).c1 += RB(1 + ir, 1 + c);
+    } else {  // :166-172
+        for (int j = 1; j <= idr; ++j)
+            for (int c = 1; c <= ndr; ++c) LL(nx - idr + j, c) = Lin{RRT(j, c), 0.0};
+        for (int c = 0; c < idl - 1; ++c) LL(nx, idr - idl + 1 + c).c1 -= RT(idl, 1 + c);
+        for (int ir = 1; ir <= idr - 1; ++ir)
+            for (int c = 0; c < ndl; ++c) LL(nx - ir, idr - idl + 1 + c).c1 += RT(idl - ir, 1 + c);
+    }
+    // normalisation (:175-201)
+    const int mx = std::max(idr, idl + 1);
+    for (int ir = 1; ir <= mx; ++ir) {
+        double dummy = 1.0 / AA(ir, idl);
+        for (int c = 0; c <= ndl; ++c) RB(ir, c) = RB(ir, c) * dummy;
+        dummy = 1.0 / AA(nx - ir + 1, idl);
+        for (int c = 1; c <= ndl + 1; ++c) RT(idl - ir + 1, c) = RT(idl - ir + 1, c) * dummy;
+        dummy = 1.0 / AA(ir, idl);
+        for (int c = 1; c <= ndl; ++c) AA(ir, c) = AA(ir, c) * dummy;
+        for (int c = 1; c <= ndr; ++c) LL(ir, c) = LL(ir, c) * dummy;
+        dummy = 1.0 / AA(nx - ir + 1, idl);
+        for (int c = 1; c <= ndl; ++c) AA(nx - ir + 1, c) = AA(nx - ir + 1, c) * dummy;
+        for (int c = 1; c <= ndr; ++c) LL(nx - ir + 1, c) = LL(nx - ir + 1, c) * dummy;
+    }
+    for (int ir = mx + 1; ir <= nx - mx; ++ir) {
+        const double dummy = 1.0 / AA(ir, idl + 1);
+        for (int c = 1; c <= ndl; ++c) AA(ir, c) = AA(ir, c) * dummy;
+        for (int c = 1; c <= ndr; ++c) LL(ir, c) = LL(ir, c) * dummy;
+    }
+    // pack row-major for the device
+    out.L0.assign((size_t)nx * 5, 0.0);
+    out.L1.assign((size_t)nx * 5, 0.0);
+    out.R.assign((size_t)nx * 3, 0.0);
+    for (int i = 1; i <= nx; ++i) {
+        for (int k = 1; k <= 5; ++k) {
+            out.L0[(size_t)(i - 1) * 5 + (k - 1)] = LL(i, k).c0;
+            out.L1[(size_t)(i - 1) * 5 + (k - 1)] = LL(i, k).c1;
+        }
+        for (int k = 1; k <= 3; ++k) out.R[(size_t)(i - 1) * 3 + (k - 1)] = AA(i, k);
+    }
+    for (int j = 1; j <= 3; ++j)
+        for (int c = 0; c <= 3; ++c) out.rb[j - 1][c] = RB(j, c);
+    for (int r = 0; r <= 2; ++r)
+        for (int c = 1; c <= 4; ++c) out.rt[r][c - 1] = RT(r, c);
+#undef AA
+#undef A0
+#undef BB
+#undef RRB
+#undef RRT
+#undef RB
+#undef RT
+#undef LL
+}
+
+}  // namespace tlab

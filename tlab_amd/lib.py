@@ -35,6 +35,9 @@ SIGNATURES = {
     "tlab_fdm_plan_info": (c_int, [c_vp, c_int]),
     "tlab_opr_partial": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tlab_opr_burgers": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_int]),
+    "tlab_poisson_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int]),
+    "tlab_poisson_plan_destroy": (c_int, [c_vp]),
+    "tlab_opr_poisson": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tlab_transpose": (c_int, [c_vp, c_int, c_int, c_vp]),
     "tlab_last_kernel_path": (c_int, []),
     "tlab_force_kernel_path": (c_int, [c_int]),

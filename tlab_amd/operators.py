@@ -176,6 +176,36 @@ def OPR_Burgers_Z(ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, u_t=None, wr
     _burgers(3, ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, write_transposed)
 
 
+class PoissonPlan:
+    """Module state of OPR_Elliptic (operators/opr_elliptic.f90:64-81) + OPR_Fourier plans, built by
+    OPR_Elliptic_Initialize / OPR_Fourier_Initialize in the reference; here one object owned by the library."""
+
+    def __init__(self, gx, gy, gz, nx, ny, nz):
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self.isize_txc_field = (self.nx + 2) * self.ny * self.nz     # base/tlab_memory.f90:186-187
+        self._keep = (gx, gy, gz)
+        self._h = c_vp(0)
+        check(load().tlab_poisson_plan_create(ctypes.byref(self._h), gx._h, gy._h, gz._h, self.nx, self.ny, self.nz),
+              "tlab_poisson_plan_create")
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().tlab_poisson_plan_destroy(self._h)
+        except Exception:
+            pass
+
+
+def OPR_Poisson(plan, nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy=None):
+    """OPR_Poisson(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)  operators/opr_elliptic.f90:33-46.
+    `plan` replaces the reference's module state.  tmp1, tmp2 need (nx+2)*ny*nz elements."""
+    n = nx * ny * nz
+    _use_torch_stream()
+    check(load().tlab_opr_poisson(plan._h, nx, ny, nz, int(ibc), _ptr(p, n, "p"), _ptr(tmp1, plan.isize_txc_field, "tmp1"),
+                                  _ptr(tmp2, plan.isize_txc_field, "tmp2"), _ptr(bcs_hb, nx * nz, "bcs_hb"),
+                                  _ptr(bcs_ht, nx * nz, "bcs_ht"), _ptr(dpdy, n, "dpdy")), "tlab_opr_poisson")
+
+
 def TLab_Transpose(a, nra, nca, b):
     """b(nca, nra) = transpose of Fortran a(nra, nca); bit-exact."""
     _use_torch_stream()
