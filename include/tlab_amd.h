@@ -134,6 +134,28 @@ int tlab_poisson_plan_destroy(tlab_poisson_plan_t p);
 int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,
                      const double *bcs_hb, const double *bcs_ht, double *dpdy);
 
+/* ---- RHS assembly and Runge-Kutta substep ("next" row n1 of SURVEY.md 8f) --------------------------------- */
+/* Module state the reference spreads over TLab_Memory / NavierStokes / OPR_Burgers / BOUNDARY_BCS: plans, sizes,
+ * visc = 1/Reynolds, schmidt(1:nscal) (physics/navierstokes.f90), wall boundary conditions (no-slip, Dirichlet scalars). */
+typedef struct tlab_dns *tlab_dns_t;
+int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                    tlab_poisson_plan_t poisson, int nx, int ny, int nz, int nscal, double visc, const double *schmidt);
+int tlab_dns_destroy(tlab_dns_t d);
+
+/* RHS_GLOBAL_INCOMPRESSIBLE_1()   tools/dns/rhs_global_incompressible_1.f90:15-405 (argument-less in the reference:
+ * it works on the module arrays q, s, hq, hs, txc and on dte).  q[3] = u,v,w; s[nscal]; hq[3], hs[nscal] are
+ * accumulated into; txc[9] = tmp1..tmp9, each of isize_txc_field = (nx+2)*ny*nz doubles.  HOST arrays of DEVICE pointers.
+ * Convective form, RhsMode = combined, remove_divergence = yes, no buffer zone / IBM / anelastic terms. */
+int tlab_rhs_global_incompressible_1(tlab_dns_t d, double dte, double *const *q, double *const *s, double *const *hq,
+                                     double *const *hs, double *const *txc);
+
+/* One explicit low-storage Runge-Kutta substep = the unit of the metric:
+ * TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT (tools/dns/time.f90:559-664): RHS, then q += dte*hq, s += dte*hs;
+ * followed, if scale_tendencies != 0, by hq *= kco, hs *= kco (time.f90:261-298, skipped after the last substep). */
+int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double kco, int scale_tendencies,
+                                              double *const *q, double *const *s, double *const *hq, double *const *hs,
+                                              double *const *txc);
+
 /* TLab_Transpose(a, nra, nca, ma, b, mb)   utils/tlab_transpose.f90:14-82 : b(j,i) = a(i,j), bit-exact */
 int tlab_transpose(const double *a, int nra, int nca, double *b);
 

@@ -1,0 +1,76 @@
+"""CPU oracle, part 3: numpy restatement of RHS_GLOBAL_INCOMPRESSIBLE_1 and of the explicit RK substep, composed from the
+operator oracles (tlab_oracle.py, tlab_oracle_poisson.py) in the reference's call order.
+
+TEST INFRASTRUCTURE ONLY.  Parity status: every operator it composes is pinned against the reference (see the two
+modules); the composition itself follows tools/dns/rhs_global_incompressible_1.f90:98-375 line by line (convective form,
+RhsMode = combined, remove_divergence, no-slip walls / Dirichlet scalars) and tools/dns/time.f90:645-664, :261-298.
+The reference's driver (dns.x) cannot be built in this image (needs fftw3.f03 through opr_fourier.f90), so this level is
+pinned through its parts plus the discrete invariant it must satisfy: div(q/dte + hq) = 0 in the interior."""
+import numpy as np
+
+from . import tlab_oracle as O
+from . import tlab_oracle_poisson as OP
+
+
+class DnsOracle:
+    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True):
+        self.nx, self.ny, self.nz = len(x), len(y), len(z)
+        self.n = self.nx * self.ny * self.nz
+        self.g = [O.FdmPlan(x, True, True), O.FdmPlan(y, False, yuniform), O.FdmPlan(z, True, True)]
+        self.poisson = OP.PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
+        self.nscal, self.visc, self.schmidt = nscal, visc, list(schmidt)
+        self.q = [np.zeros(self.n) for _ in range(3)]
+        self.s = [np.zeros(self.n) for _ in range(nscal)]
+        self.hq = [np.zeros(self.n) for _ in range(3)]
+        self.hs = [np.zeros(self.n) for _ in range(nscal)]
+
+    def burgers(self, d, nu, s, vel):
+        return O.opr_burgers(d, self.nx, self.ny, self.nz, 0, self.g[d - 1], nu, s, vel)[0]
+
+    def p1(self, d, u):
+        return O.opr_partial(d, O.OPR_P1, self.nx, self.ny, self.nz, 0, self.g[d - 1], u)[0]
+
+    def rhs_global_incompressible_1(self, dte):
+        nx, ny, nz = self.nx, self.ny, self.nz
+        u, v, w = self.q
+        hq, hs = self.hq, self.hs
+        nu = self.visc
+        tmp1 = self.burgers(1, nu, u, u); tmp2 = self.burgers(2, nu, v, v); tmp3 = self.burgers(3, nu, w, w)      # :98-100
+        tmp7 = self.burgers(2, nu, u, v); tmp8 = self.burgers(3, nu, u, w)                                          # :103-104
+        hq[0] = hq[0] + tmp1 + tmp7 + tmp8
+        tmp7 = self.burgers(1, nu, v, u); tmp8 = self.burgers(3, nu, v, w)                                          # :115-116
+        hq[1] = hq[1] + tmp2 + tmp7 + tmp8
+        tmp7 = self.burgers(1, nu, w, u); tmp8 = self.burgers(2, nu, w, v)                                          # :127-128
+        hq[2] = hq[2] + tmp3 + tmp7 + tmp8
+        for i in range(self.nscal):                                                                                # :149-162
+            kap = self.visc / self.schmidt[i]
+            t1 = self.burgers(1, kap, self.s[i], u); t2 = self.burgers(2, kap, self.s[i], v); t3 = self.burgers(3, kap, self.s[i], w)
+            hs[i] = hs[i] + t1 + t2 + t3
+        dummy = 1.0 / dte                                                                                           # :188-201
+        tmp2 = hq[1] + v * dummy
+        tmp3 = hq[0] + u * dummy
+        tmp4 = hq[2] + w * dummy
+        tmp1 = self.p1(2, tmp2); tmp2 = self.p1(1, tmp3); tmp3 = self.p1(3, tmp4)                                   # :228-230
+        tmp1 = tmp1 + tmp2 + tmp3                                                                                   # :258
+        h2 = hq[1].reshape(nz, ny, nx)
+        hb, ht = h2[:, 0, :].copy(), h2[:, ny - 1, :].copy()                                                        # :279-280
+        p, dpdy = OP.opr_poisson_fxz(self.poisson, tmp1, hb, ht)                                                    # :284
+        self.p = p
+        tmp2 = self.p1(1, p); tmp4 = self.p1(3, p)                                                                  # :319-320
+        hq[0] = hq[0] - tmp2; hq[1] = hq[1] - dpdy; hq[2] = hq[2] - tmp4                                            # :349-351
+        for a in hq + hs:                                                                                           # :373-375, :394-396
+            b = a.reshape(nz, ny, nx)
+            b[:, 0, :] = 0.0
+            b[:, ny - 1, :] = 0.0
+
+    def time_substep(self, dte, kco=1.0, scale=False):
+        self.rhs_global_incompressible_1(dte)
+        for i in range(3):
+            self.q[i] = self.q[i] + dte * self.hq[i]                                                                # time.f90:651
+        for i in range(self.nscal):
+            self.s[i] = self.s[i] + dte * self.hs[i]
+        if scale:
+            for i in range(3):
+                self.hq[i] = kco * self.hq[i]                                                                       # time.f90:283
+            for i in range(self.nscal):
+                self.hs[i] = kco * self.hs[i]

@@ -48,4 +48,14 @@ hipError_t launch_burgers_epilogue(double *out, const double *vel, const double 
 hipError_t launch_fill(double *out, double v, long long ntot, hipStream_t st);
 hipError_t launch_transpose(const double *a, double *b, int nra, int nca, hipStream_t st);
 
+// pointwise.hip
+hipError_t launch_add3(double *h, const double *a, const double *b, const double *c, long long n, hipStream_t st);
+hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1,
+                        const double *q2, const double *q3, double s, long long n, hipStream_t st);
+hipError_t launch_sum3(double *a, const double *b, const double *c, long long n, hipStream_t st);
+hipError_t launch_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n, hipStream_t st);
+hipError_t launch_rk_update(double *q, double *h, double dte, double kco, int scale, long long n, hipStream_t st);
+hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz, hipStream_t st);
+
 }  // namespace tlab

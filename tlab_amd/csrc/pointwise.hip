@@ -1,0 +1,141 @@
+// Pointwise kernels of the RHS assembly and of the low-storage Runge-Kutta update:
+// tools/dns/rhs_global_incompressible_1.f90:106-112,197-201,255-260,348-352,373-375 and tools/dns/time.f90:272-297,645-664.
+// All are streaming kernels with 16-B accesses per lane, grid-strided over at most 2048 workgroups.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace tlab {
+
+static inline int pw_grid(long long n2) {
+    const long long b = (n2 + 255) / 256;
+    return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+// h += a + b + c            (hq(ij,1) = hq(ij,1) + tmp1(ij) + tmp7(ij) + tmp8(ij))
+__global__ void __launch_bounds__(256) k_add3(double *__restrict__ h, const double *__restrict__ a, const double *__restrict__ b,
+                                              const double *__restrict__ c, long long n) {
+    const long long n2 = n >> 1, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 hv = reinterpret_cast<double2 *>(h)[i];
+        const double2 av = reinterpret_cast<const double2 *>(a)[i], bv = reinterpret_cast<const double2 *>(b)[i],
+                      cv = reinterpret_cast<const double2 *>(c)[i];
+        hv.x = hv.x + av.x + bv.x + cv.x;
+        hv.y = hv.y + av.y + bv.y + cv.y;
+        reinterpret_cast<double2 *>(h)[i] = hv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) h[n - 1] = h[n - 1] + a[n - 1] + b[n - 1] + c[n - 1];
+}
+
+// o1 = h1 + q1*s ; o2 = h2 + q2*s ; o3 = h3 + q3*s      (tmp = hq + q/dte, rhs_global_incompressible_1.f90:197-201)
+__global__ void __launch_bounds__(256) k_axpy3(double *__restrict__ o1, double *__restrict__ o2, double *__restrict__ o3,
+                                               const double *__restrict__ h1, const double *__restrict__ h2, const double *__restrict__ h3,
+                                               const double *__restrict__ q1, const double *__restrict__ q2, const double *__restrict__ q3,
+                                               double s, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        o1[i] = h1[i] + q1[i] * s;
+        o2[i] = h2[i] + q2[i] * s;
+        o3[i] = h3[i] + q3[i] * s;
+    }
+}
+
+// a = a + b + c             (tmp1 = tmp1 + tmp2 + tmp3, :257-259)
+__global__ void __launch_bounds__(256) k_sum3(double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, long long n) {
+    const long long n2 = n >> 1, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 av = reinterpret_cast<double2 *>(a)[i];
+        const double2 bv = reinterpret_cast<const double2 *>(b)[i], cv = reinterpret_cast<const double2 *>(c)[i];
+        av.x = av.x + bv.x + cv.x;
+        av.y = av.y + bv.y + cv.y;
+        reinterpret_cast<double2 *>(a)[i] = av;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) a[n - 1] = a[n - 1] + b[n - 1] + c[n - 1];
+}
+
+// h1 -= a ; h2 -= b ; h3 -= c     (hq = hq - grad p, :348-352)
+__global__ void __launch_bounds__(256) k_sub3(double *__restrict__ h1, double *__restrict__ h2, double *__restrict__ h3,
+                                              const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        h1[i] = h1[i] - a[i];
+        h2[i] = h2[i] - b[i];
+        h3[i] = h3[i] - c[i];
+    }
+}
+
+// q = q + dte*h  and then  h = kco*h  (time.f90:645-664 and :272-297; kco == 1 leaves h untouched as after the last substep)
+__global__ void __launch_bounds__(256) k_rk_update(double *__restrict__ q, double *__restrict__ h, double dte, double kco, int scale,
+                                                   long long n) {
+    const long long n2 = n >> 1, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 qv = reinterpret_cast<double2 *>(q)[i], hv = reinterpret_cast<double2 *>(h)[i];
+        qv.x = qv.x + dte * hv.x;
+        qv.y = qv.y + dte * hv.y;
+        reinterpret_cast<double2 *>(q)[i] = qv;
+        if (scale) {
+            hv.x = kco * hv.x;
+            hv.y = kco * hv.y;
+            reinterpret_cast<double2 *>(h)[i] = hv;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        q[n - 1] = q[n - 1] + dte * h[n - 1];
+        if (scale) h[n - 1] = kco * h[n - 1];
+    }
+}
+
+// hb(i,k) = f(i,1,k) ; ht(i,k) = f(i,ny,k)    (BcsFlowJmin%ref(:,:,2) = p_bcs(:,1,:), :279-280)
+__global__ void __launch_bounds__(256) k_get_wall_planes(const double *__restrict__ f, double *__restrict__ hb, double *__restrict__ ht,
+                                                          int nx, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * nz) return;
+    const int ix = (int)(i % nx);
+    const long long k = i / nx;
+    hb[i] = f[ix + (long long)nx * (0 + (long long)ny * k)];
+    ht[i] = f[ix + (long long)nx * ((ny - 1) + (long long)ny * k)];
+}
+
+// f(:,1,:) = vb ; f(:,ny,:) = vt   (p_bcs(:,1,:) = BcsFlowJmin%ref = 0 for Dirichlet walls, :373-375)
+__global__ void __launch_bounds__(256) k_fill_wall_planes(double *__restrict__ f, double vb, double vt, int nx, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * nz) return;
+    const int ix = (int)(i % nx);
+    const long long k = i / nx;
+    f[ix + (long long)nx * (0 + (long long)ny * k)] = vb;
+    f[ix + (long long)nx * ((ny - 1) + (long long)ny * k)] = vt;
+}
+
+#define CHECK_LAUNCH() hipGetLastError()
+
+hipError_t launch_add3(double *h, const double *a, const double *b, const double *c, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_add3, dim3(pw_grid(n / 2)), dim3(256), 0, st, h, a, b, c, n);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1,
+                        const double *q2, const double *q3, double s, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_axpy3, dim3(pw_grid(n)), dim3(256), 0, st, o1, o2, o3, h1, h2, h3, q1, q2, q3, s, n);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_sum3(double *a, const double *b, const double *c, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum3, dim3(pw_grid(n / 2)), dim3(256), 0, st, a, b, c, n);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_sub3, dim3(pw_grid(n)), dim3(256), 0, st, h1, h2, h3, a, b, c, n);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_rk_update(double *q, double *h, double dte, double kco, int scale, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_rk_update, dim3(pw_grid(n / 2)), dim3(256), 0, st, q, h, dte, kco, scale, n);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz, hipStream_t st) {
+    hipLaunchKernelGGL(k_get_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, f, hb, ht, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, f, vb, vt, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
+
+}  // namespace tlab

@@ -1,0 +1,91 @@
+"""Host-side mirror of the RK driver around the hot path: module arrays q, s, hq, hs, txc (base/tlab_memory.f90:10-17),
+RHS_GLOBAL_INCOMPRESSIBLE_1 (tools/dns/rhs_global_incompressible_1.f90:15), TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT and
+TIME_RUNGEKUTTA (tools/dns/time.f90:559, :185).  Fields are torch CUDA tensors (HBM residency); every arithmetic
+operation runs in the HIP library."""
+import ctypes
+import numpy as np
+
+from .lib import load, check, TlabError, c_vp
+from .operators import FdmPlan, PoissonPlan, _use_torch_stream
+
+RKM_EXP3, RKM_EXP4 = 3, 4
+
+
+def rk_coefficients(mode):
+    """TIME_INITIALIZE, tools/dns/time.f90:86-108."""
+    if mode == RKM_EXP3:   # Williamson 1980
+        return ([1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0], [-5.0 / 9.0, -153.0 / 128.0])
+    if mode == RKM_EXP4:   # Carpenter & Kennedy 1994
+        kdt = [1432997174477.0 / 9575080441755.0, 5161836677717.0 / 13612068292357.0, 1720146321549.0 / 2090206949498.0,
+               3134564353537.0 / 4481467310338.0, 2277821191437.0 / 14882151754819.0]
+        kco = [-567301805773.0 / 1357537059087.0, -2404267990393.0 / 2016746695238.0, -3550918686646.0 / 2091501179385.0,
+               -1275806237668.0 / 842570457699.0]
+        return (kdt, kco)
+    raise TlabError("only the explicit low-storage schemes RungeKuttaExplicit3/4 are built")
+
+
+class Dns:
+    """imax, jmax, kmax, inb_scal, visc, schmidt + the allocated arrays of TLab_Initialize_Memory (tlab_memory.f90:164-216)."""
+
+    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
+                 hyper_bc1_ext=0.1, device="cuda"):
+        import torch
+        self.nx, self.ny, self.nz = len(x), len(y), len(z)
+        self.n = self.nx * self.ny * self.nz
+        self.nscal = int(nscal)
+        self.visc = float(visc)
+        self.schmidt = np.ascontiguousarray(schmidt, dtype=np.float64)[: self.nscal]
+        self.g = [FdmPlan(x, True, True, hyper_bc1_ext=hyper_bc1_ext), FdmPlan(y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext),
+                  FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
+        self.poisson = PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
+        self.isize_txc_field = self.poisson.isize_txc_field
+        f = lambda m: [torch.zeros(m, dtype=torch.float64, device=device) for _ in range(1)][0]   # noqa: E731
+        self.q = [f(self.n) for _ in range(3)]
+        self.s = [f(self.n) for _ in range(self.nscal)]
+        self.hq = [f(self.n) for _ in range(3)]
+        self.hs = [f(self.n) for _ in range(self.nscal)]
+        self.txc = [f(self.isize_txc_field) for _ in range(9)]          # inb_txc = 9 (dns_read_local.f90:711)
+        self.kdt, self.kco = rk_coefficients(rkm_mode)
+        self.rkm_endstep = len(self.kdt)
+        self._h = c_vp(0)
+        sc = self.schmidt if self.nscal else np.zeros(1)
+        check(load().tlab_dns_create(ctypes.byref(self._h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.poisson._h,
+                                     self.nx, self.ny, self.nz, self.nscal, self.visc,
+                                     sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "tlab_dns_create")
+        self._ptrs = None
+
+    def _arrays(self):
+        if self._ptrs is None:
+            def arr(ts):
+                a = (c_vp * max(len(ts), 1))()
+                for i, t in enumerate(ts):
+                    a[i] = t.data_ptr()
+                return a
+            self._ptrs = tuple(arr(t) for t in (self.q, self.s, self.hq, self.hs, self.txc))
+        return self._ptrs
+
+    def RHS_GLOBAL_INCOMPRESSIBLE_1(self, dte):
+        _use_torch_stream()
+        q, s, hq, hs, txc = self._arrays()
+        check(load().tlab_rhs_global_incompressible_1(self._h, float(dte), q, s, hq, hs, txc), "tlab_rhs_global_incompressible_1")
+
+    def TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(self, dte, kco=1.0, scale_tendencies=False):
+        _use_torch_stream()
+        q, s, hq, hs, txc = self._arrays()
+        check(load().tlab_time_substep_incompressible_explicit(self._h, float(dte), float(kco), int(scale_tendencies), q, s, hq, hs, txc),
+              "tlab_time_substep_incompressible_explicit")
+
+    def TIME_RUNGEKUTTA(self, dtime):
+        """One time step: hq = hs = 0, then rkm_endstep substeps (time.f90:212-298)."""
+        for t in self.hq + self.hs:
+            t.zero_()
+        for k in range(self.rkm_endstep):
+            last = k == self.rkm_endstep - 1
+            self.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * self.kdt[k], 1.0 if last else self.kco[k], not last)
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().tlab_dns_destroy(self._h)
+        except Exception:
+            pass

@@ -38,6 +38,10 @@ SIGNATURES = {
     "tlab_poisson_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int]),
     "tlab_poisson_plan_destroy": (c_int, [c_vp]),
     "tlab_opr_poisson": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tlab_dns_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, _dp]),
+    "tlab_dns_destroy": (c_int, [c_vp]),
+    "tlab_rhs_global_incompressible_1": (c_int, [c_vp, c_dbl, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
+    "tlab_time_substep_incompressible_explicit": (c_int, [c_vp, c_dbl, c_dbl, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
     "tlab_transpose": (c_int, [c_vp, c_int, c_int, c_vp]),
     "tlab_last_kernel_path": (c_int, []),
     "tlab_force_kernel_path": (c_int, [c_int]),
