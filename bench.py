@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: grid-point-updates/s per Runge-Kutta substep of the incompressible Navier-Stokes
+RHS hot path (OPR_Burgers x (12+3 ns), OPR_Partial x 5, OPR_Poisson, pointwise assembly, RK update), fp64,
+512^3, 1 scalar, on N MI355X (BASELINE.json: metric / configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one explicit RK substep (TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT, tools/dns/time.f90:559) on synthetic fields
+already resident in HBM.  Prints ONE JSON line on rank 0.  The `roofline` object is measured live with HIP events placed
+by the library around every kernel launch on its own stream; `cpu_baseline` times the numpy oracle (a port of the
+reference's CPU path, oracle/) on a bounded sample of the same workload on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synthetic_fields(d, seed):
+    """smooth modes + 0.1 * uniform(-1,1) noise from a fixed-seed generator, generated on the device."""
+    import torch
+    nx, ny, nz = d.nx, d.ny, d.nz
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20250509 + seed)
+    x = torch.arange(nx, dtype=torch.float64, device="cuda").view(1, 1, nx) / nx
+    y = torch.arange(ny, dtype=torch.float64, device="cuda").view(1, ny, 1) / (ny - 1)
+    z = torch.arange(nz, dtype=torch.float64, device="cuda").view(nz, 1, 1) / nz
+    two_pi = 2.0 * np.pi
+    wall = torch.sin(np.pi * y)
+    shapes = [torch.sin(two_pi * x) * torch.cos(2 * two_pi * y) * torch.sin(3 * two_pi * z),
+              torch.cos(two_pi * x) * torch.sin(two_pi * y) * torch.sin(2 * two_pi * z),
+              torch.sin(2 * two_pi * x) * torch.cos(two_pi * y) * torch.cos(two_pi * z),
+              torch.cos(3 * two_pi * x) * torch.cos(two_pi * y) * torch.sin(two_pi * z)]
+    for t, sh in zip(d.q + d.s, shapes):
+        t.copy_(((sh + 0.1 * (2.0 * torch.rand(nz, ny, nx, dtype=torch.float64, device="cuda", generator=gen) - 1.0)) * wall).reshape(-1))
+
+
+def cpu_baseline(n, nscal):
+    """Times one substep of the numpy oracle (port of the reference's CPU algorithm) on an n^3 sample of the workload."""
+    from oracle.tlab_oracle_rhs import DnsOracle
+    x = np.arange(n) / n
+    y = np.arange(n) / (n - 1.0)
+    o = DnsOracle(x, y, x.copy(), nscal, 1.0 / 5000.0, (1.0,) * nscal, True)
+    rng = np.random.default_rng(20250509)
+    for i in range(3):
+        o.q[i] = rng.uniform(-1, 1, n ** 3) * 0.1
+    for i in range(nscal):
+        o.s[i] = rng.uniform(-1, 1, n ** 3)
+    t0 = time.time()
+    o.time_substep(1e-3, 1.0, False)
+    dt = time.time() - t0
+    return {"value": n ** 3 / dt, "unit": "grid-point-updates/s per RK substep", "cores": 1, "kind": "port",
+            "sample": "one RK substep of the numpy oracle (oracle/tlab_oracle_rhs.py) on a %d^3 box, %d scalar(s), %.1f s" % (n, nscal, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=512, help="box size n^3 per GPU (BASELINE: 512)")
+    ap.add_argument("--nscal", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=192, help="n of the n^3 CPU-baseline sample (0 disables)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import tlab_amd as T
+    from tlab_amd.dns import Dns, RKM_EXP3
+    from tlab_amd.lib import load
+    T.init(local_rank)
+    n = args.n
+    x = np.arange(n) / n
+    y = np.arange(n) / (n - 1.0)
+    d = Dns(x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
+    synthetic_fields(d, rank)
+    dtime = 1e-3
+    L = load()
+
+    def substep(k):
+        s = k % d.rkm_endstep
+        if s == 0:
+            for t in d.hq + d.hs:
+                t.zero_()
+        last = s == d.rkm_endstep - 1
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * d.kdt[s], 1.0 if last else d.kco[s], not last)
+
+    for k in range(args.warmup):
+        substep(k)
+    L.tlab_profile_reset()
+    L.tlab_profile_enable(1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        substep(args.warmup + k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.tlab_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = all(bool(torch.isfinite(t).all()) for t in d.q + d.s)
+
+    if rank == 0:
+        import ctypes
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.tlab_profile_report(buf, len(buf))
+        kernels = []
+        for line in buf.value.decode().strip().split("\n"):
+            if not line:
+                continue
+            name, calls, ms, nbytes = line.split("\t")
+            kernels.append({"kernel": name, "calls": int(calls), "total_ms": float(ms), "avg_ms": float(ms) / int(calls),
+                            "alg_bytes_per_launch": float(nbytes) / int(calls)})
+        kernels.sort(key=lambda k: -k["total_ms"])
+        for k in kernels:
+            k["alg_GBps"] = k["alg_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9 if k["avg_ms"] > 0 else 0.0
+        dom = next((k for k in kernels if k["alg_bytes_per_launch"] > 0), None)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if collected (profiles/README.md)
+        if dom and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom["kernel"])
+            except Exception:
+                traffic = None
+        npts = float(n) ** 3 * world
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "grid-point-updates/s per RK substep",
+            "value": npts * args.steps / elapsed,
+            "unit": "grid-point-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 incompressible box per GPU, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
+                                   % (n, args.nscal),
+                       "grid": [n, n, n], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper", "reynolds": 5000,
+                       "parallelism": "single GPU" if world == 1 else "replicas (one box per GPU; pencil transposes not built yet)",
+                       "fields_finite": finite},
+            "roofline": None if dom is None else {
+                "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "launches": dom["calls"],
+                "share_of_step": dom["total_ms"] / (ms_per_step * args.steps)},
+            "substep_alg_GBps": (736.0 + 152.0 * args.nscal) * float(n) ** 3 / (ms_per_step * 1e-3) / 1e9,
+            "kernels": [{k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in k.items()} for k in kernels],
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.nscal)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,12 @@ int tlab_force_kernel_path(int path);
 /* tuning knobs for experiments: key 1 = rows per wave of the register-tile kernel (16 | 32 | 64, 0 = automatic). */
 int tlab_set_tuning(int key, int value);
 
+/* Live kernel timing (HIP events on the library's stream around every kernel launch) for bench.py's roofline object.
+ * tlab_profile_report writes one line per kernel: "name<TAB>calls<TAB>total_ms<TAB>total_algorithmic_bytes". */
+int tlab_profile_enable(int on);
+int tlab_profile_reset(void);
+int tlab_profile_report(char *buf, int nbuf);
+
 /* Debug aid, never on an operator path: runs the *device algorithm's* precomputed tables (chunked Thomas +
  * separator system) through a scalar host emulation so the tables can be checked without a GPU.
  * which = 1 (first derivative, variant ibc) or 2 (second derivative); chunks = number of chunks;

@@ -19,6 +19,7 @@
 
 #include "device_tables.hpp"
 #include "kernels.hpp"
+#include "profile.hpp"
 
 namespace tlab {
 
@@ -446,12 +447,16 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     const long long blocks_needed = (a.nlines + 3) / 4;
     const int grid = imin(blocks_needed, 256 * 8);
     const size_t lds = LV ? (size_t)2 * 5 * M * 64 * sizeof(double) : 0;
+    const double pts = (double)a.nlines * 64 * M;
+    static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
+    const double bpp[5] = {0, 16, 16, 24, 24};
+    if (mode < 1 || mode > 4) return hipErrorInvalidValue;
+    ProfScope ps(names[mode], st, pts * bpp[mode]);
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV>), dim3(grid), dim3(256), lds, st, a); break;
     case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
     case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV>), dim3(grid), dim3(256), lds, st, a); break;
-    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
@@ -488,6 +493,10 @@ int rtile_chunk(int n) {
 template <int M, int MAXT>
 static hipError_t launch_rtile_m(int mode, int P, long long tiles, const RTileArgs &a, hipStream_t st) {
     const dim3 grid((unsigned)tiles), block(64 * P);
+    const double pts = (double)a.g.nlines * a.g.n;
+    const char *name = mode == MODE_P1 ? "k_rtile<P1>" : mode == MODE_P2 ? "k_rtile<P2>" : mode == MODE_P2_D1IN ? "k_rtile<P2_D1IN>" : "k_rtile<BURGERS_D1IN>";
+    const double bpp = mode == MODE_P1 || mode == MODE_P2 ? 16 : mode == MODE_P2_D1IN ? 24 : 32;   // operand reads + writes of this launch
+    ProfScope ps(name, st, pts * bpp);
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_rtile<M, MODE_P1, MAXT>), grid, block, 0, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_rtile<M, MODE_P2, MAXT>), grid, block, 0, st, a); break;
@@ -512,6 +521,7 @@ hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st) {
 
 hipError_t launch_generic(bool sym, const GenericArgs &a, hipStream_t st) {
     const int grid = (int)((a.g.nlines + 255) / 256);
+    ProfScope ps("k_generic", st, (double)a.g.nlines * a.g.n * 16);
     if (sym) hipLaunchKernelGGL((k_generic<true>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_generic<false>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
@@ -519,6 +529,7 @@ hipError_t launch_generic(bool sym, const GenericArgs &a, hipStream_t st) {
 
 hipError_t launch_burgers_epilogue(double *out, const double *vel, const double *d1, double nu, long long ntot, hipStream_t st) {
     const int grid = imin((ntot + 255) / 256, 256 * 8);
+    ProfScope ps("k_burgers_epilogue", st, (double)ntot * 32);
     hipLaunchKernelGGL(k_burgers_epilogue, dim3(grid), dim3(256), 0, st, out, vel, d1, nu, ntot);
     return hipGetLastError();
 }
@@ -531,6 +542,7 @@ hipError_t launch_fill(double *out, double v, long long ntot, hipStream_t st) {
 
 hipError_t launch_transpose(const double *a, double *b, int nra, int nca, hipStream_t st) {
     dim3 grid((nra + 63) / 64, (nca + 63) / 64);
+    ProfScope ps("k_transpose", st, (double)nra * nca * 16);
     hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, a, b, nra, nca);
     return hipGetLastError();
 }

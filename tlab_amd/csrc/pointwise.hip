@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
+#include "profile.hpp"
 
 namespace tlab {
 
@@ -109,23 +110,28 @@ __global__ void __launch_bounds__(256) k_fill_wall_planes(double *__restrict__ f
 #define CHECK_LAUNCH() hipGetLastError()
 
 hipError_t launch_add3(double *h, const double *a, const double *b, const double *c, long long n, hipStream_t st) {
+    ProfScope ps("k_add3", st, (double)n * 40);
     hipLaunchKernelGGL(k_add3, dim3(pw_grid(n / 2)), dim3(256), 0, st, h, a, b, c, n);
     return CHECK_LAUNCH();
 }
 hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1,
                         const double *q2, const double *q3, double s, long long n, hipStream_t st) {
+    ProfScope ps("k_axpy3", st, (double)n * 72);
     hipLaunchKernelGGL(k_axpy3, dim3(pw_grid(n)), dim3(256), 0, st, o1, o2, o3, h1, h2, h3, q1, q2, q3, s, n);
     return CHECK_LAUNCH();
 }
 hipError_t launch_sum3(double *a, const double *b, const double *c, long long n, hipStream_t st) {
+    ProfScope ps("k_sum3", st, (double)n * 32);
     hipLaunchKernelGGL(k_sum3, dim3(pw_grid(n / 2)), dim3(256), 0, st, a, b, c, n);
     return CHECK_LAUNCH();
 }
 hipError_t launch_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n, hipStream_t st) {
+    ProfScope ps("k_sub3", st, (double)n * 72);
     hipLaunchKernelGGL(k_sub3, dim3(pw_grid(n)), dim3(256), 0, st, h1, h2, h3, a, b, c, n);
     return CHECK_LAUNCH();
 }
 hipError_t launch_rk_update(double *q, double *h, double dte, double kco, int scale, long long n, hipStream_t st) {
+    ProfScope ps("k_rk_update", st, (double)n * (scale ? 32 : 24));
     hipLaunchKernelGGL(k_rk_update, dim3(pw_grid(n / 2)), dim3(256), 0, st, q, h, dte, kco, scale, n);
     return CHECK_LAUNCH();
 }

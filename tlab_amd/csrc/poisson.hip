@@ -26,6 +26,7 @@
 #include "../../include/tlab_amd.h"
 #include "plan.hpp"
 #include "poisson_host.hpp"
+#include "profile.hpp"
 
 namespace tlab {
 
@@ -457,7 +458,8 @@ struct FftPlan {
             fftc(rocfft_execution_info_set_work_buffer(info, work, work_bytes), "set work");
         }
     }
-    void exec(void *in, void *out, hipStream_t st) {
+    void exec(void *in, void *out, hipStream_t st, double bytes = 0.0) {
+        ProfScope ps("rocfft", st, bytes);
         fftc(rocfft_execution_info_set_stream(info, st), "set stream");
         void *ib[1] = {in}, *ob[1] = {out};
         fftc(rocfft_execute(plan, ib, ob, info), "execute");
@@ -509,6 +511,10 @@ namespace {
 template <int BC, int NL, int FS>
 void launch_int1(const Int1Args &a, hipStream_t st) {
     const int grid = (int)((a.nm + 255) / 256);
+    // operand traffic of one integral solve: read NL lines, write NL lines (scratch traffic is overhead, not algorithmic)
+    const bool few = a.nm <= 8;   // the <= 4 singular modes, solved beside the regular ones on the side stream
+    ProfScope ps(few ? "k_int1<singular modes>" : (FS == FS_FIELD ? "k_int1<field>" : (FS == FS_LINEAR ? "k_int1<linear>" : "k_int1<unit>")), st,
+                 (double)a.nm * a.T.n * 16.0 * NL);
     hipLaunchKernelGGL((k_int1<BC, NL, FS>), dim3(grid), dim3(256), 0, st, a);
     hipc(hipGetLastError(), "k_int1");
 }
@@ -771,7 +777,10 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
         CombineArgs c{};
         c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.hom = P->hom.p; c.cst = P->cst.p; c.lam = P->lam.p;
         c.skip = P->d_skip; c.p_hat = tmp1; c.dp_hat = tmp2; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
-        hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+        {
+            ProfScope ps("k_nn_combine", st, (double)nm * n * (9 + 4) * 8.0);
+            hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+        }
         {   // the singular modes write other entries of tmp1/tmp2 than k_nn_combine (which skips them), but f^ (= tmp1) must
             // have been consumed by the regular v-solve first: order the scatter after it through the main stream
             hipc(hipEventRecord(P->ev_join, ss), "event record");

@@ -1,0 +1,23 @@
+// Optional in-library kernel timing with HIP events on the library's stream (bench.py's "roofline" object needs the average
+// duration of a kernel measured live over the timed region, on the stream the kernel is launched on).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tlab {
+
+bool prof_enabled();
+void prof_begin(const char *tag, hipStream_t st, double bytes);   // bytes = algorithmic (compulsory operand) bytes of this launch
+void prof_end(hipStream_t st);
+
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    ProfScope(const char *tag, hipStream_t s, double bytes) : st(s), on(prof_enabled()) {
+        if (on) prof_begin(tag, st, bytes);
+    }
+    ~ProfScope() {
+        if (on) prof_end(st);
+    }
+};
+
+}  // namespace tlab

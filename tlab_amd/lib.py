@@ -46,6 +46,9 @@ SIGNATURES = {
     "tlab_last_kernel_path": (c_int, []),
     "tlab_force_kernel_path": (c_int, [c_int]),
     "tlab_set_tuning": (c_int, [c_int, c_int]),
+    "tlab_profile_enable": (c_int, [c_int]),
+    "tlab_profile_reset": (c_int, []),
+    "tlab_profile_report": (c_int, [ctypes.c_char_p, c_int]),
     "tlab_debug_host_chunked_solve": (c_int, [c_vp, c_int, c_int, c_int, _dp]),
 }
 
