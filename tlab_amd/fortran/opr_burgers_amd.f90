@@ -1,0 +1,92 @@
+!########################################################################
+! Drop-in replacement of module OPR_Burgers (physics/opr_burgers.f90:23-30,190-431): same names and signatures.
+! The reference folds the diffusivity of field `is` into a copy of the LU (OPR_Burgers_Initialize, :92-112); the device
+! kernels take it as a number, so OPR_Burgers_Initialize only records visc and schmidt(:).
+!########################################################################
+#ifndef TLAB_AMD_BURGERS_MODULE
+#define TLAB_AMD_BURGERS_MODULE OPR_Burgers
+#endif
+#ifndef TLAB_AMD_PARTIAL_MODULE
+#define TLAB_AMD_PARTIAL_MODULE OPR_Partial
+#endif
+module TLAB_AMD_BURGERS_MODULE
+    use, intrinsic :: iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use FDM, only: fdm_dt
+    use TLab_AMD_C
+    use TLAB_AMD_PARTIAL_MODULE, only: OPR_Partial_AMD_Plan
+    implicit none
+    private
+
+    public :: OPR_Burgers_Initialize_AMD     ! (visc, schmidt): what OPR_Burgers_Initialize(inifile) takes from module NavierStokes
+    public :: OPR_Burgers_X
+    public :: OPR_Burgers_Y
+    public :: OPR_Burgers_Z
+    public :: OPR_Burgers_SetPlans
+
+    integer, parameter, public :: OPR_B_SELF = 0
+    integer, parameter, public :: OPR_B_U_IN = 1
+
+    real(wp), save :: diffusivity(0:16) = 0.0_wp
+    type(fdm_dt), pointer, save :: gp(:) => null()      ! the host plans g(1:3) of module FDM
+
+contains
+    subroutine OPR_Burgers_Initialize_AMD(visc, schmidt)
+        real(wp), intent(in) :: visc, schmidt(:)
+        integer is
+        diffusivity(0) = visc                             ! opr_burgers.f90:94-98
+        do is = 1, size(schmidt)
+            diffusivity(is) = visc/schmidt(is)
+        end do
+    end subroutine OPR_Burgers_Initialize_AMD
+
+    subroutine OPR_Burgers_SetPlans(g)
+        type(fdm_dt), intent(in), target :: g(3)
+        gp => g
+    end subroutine OPR_Burgers_SetPlans
+
+    subroutine burgers_any(idir, ivel, is, nx, ny, nz, bcs, s, u, result, tmp1)
+        integer, intent(in) :: idir, ivel, is
+        integer(wi), intent(in) :: nx, ny, nz, bcs(2, 2)
+        real(wp), intent(in), target :: s(*), u(*)
+        real(wp), intent(out), target :: result(*)
+        real(wp), intent(inout), target :: tmp1(*)
+        integer(c_int) rc
+        if (bcs(1, 2) + bcs(2, 2) > 0) error stop 'OPR_Burgers: only developed for biased BCs'     ! opr_burgers.f90:460-463
+        rc = tlab_opr_burgers(int(idir, c_int), OPR_Partial_AMD_Plan(idir, gp(idir)), int(ivel, c_int), int(nx, c_int), int(ny, c_int), &
+                              int(nz, c_int), int(bcs(1, 1) + bcs(2, 1)*2, c_int), diffusivity(is), c_loc(s), c_loc(u), c_loc(result), &
+                              c_loc(tmp1), 0_c_int)
+        call TLab_AMD_Check(rc, 'tlab_opr_burgers')
+    end subroutine burgers_any
+
+    subroutine OPR_Burgers_X(ivel, is, nx, ny, nz, bcs, s, u, result, tmp1, u_t)
+        integer, intent(in) :: ivel, is
+        integer(wi), intent(in) :: nx, ny, nz, bcs(2, 2)
+        real(wp), intent(in) :: s(nx*ny*nz), u(nx*ny*nz)
+        real(wp), intent(out) :: result(nx*ny*nz)
+        real(wp), intent(inout) :: tmp1(nx*ny*nz)
+        real(wp), intent(in), optional :: u_t(nx*ny*nz)   ! ignored: the device kernels read u in its natural layout
+        call burgers_any(1, ivel, is, nx, ny, nz, bcs, s, u, result, tmp1)
+    end subroutine OPR_Burgers_X
+
+    subroutine OPR_Burgers_Y(ivel, is, nx, ny, nz, bcs, s, u, result, tmp1, u_t)
+        integer, intent(in) :: ivel, is
+        integer(wi), intent(in) :: nx, ny, nz, bcs(2, 2)
+        real(wp), intent(in) :: s(nx*ny*nz), u(nx*ny*nz)
+        real(wp), intent(out) :: result(nx*ny*nz)
+        real(wp), intent(inout) :: tmp1(nx*ny*nz)
+        real(wp), intent(in), optional :: u_t(nx*ny*nz)
+        call burgers_any(2, ivel, is, nx, ny, nz, bcs, s, u, result, tmp1)
+    end subroutine OPR_Burgers_Y
+
+    subroutine OPR_Burgers_Z(ivel, is, nx, ny, nz, bcs, s, u, result, tmp1, u_t)
+        integer, intent(in) :: ivel, is
+        integer(wi), intent(in) :: nx, ny, nz, bcs(2, 2)
+        real(wp), intent(in) :: s(nx*ny*nz), u(nx*ny*nz)
+        real(wp), intent(out) :: result(nx*ny*nz)
+        real(wp), intent(inout) :: tmp1(nx*ny*nz)
+        real(wp), intent(in), optional :: u_t(nx*ny*nz)
+        call burgers_any(3, ivel, is, nx, ny, nz, bcs, s, u, result, tmp1)
+    end subroutine OPR_Burgers_Z
+
+end module TLAB_AMD_BURGERS_MODULE

@@ -1,0 +1,105 @@
+!########################################################################
+! Drop-in replacement of module OPR_Partial (operators/opr_partial.f90): same public names, same signatures, bodies that
+! only marshal to the C ABI.  The device plan of a direction is created on first use from the coefficient tables the
+! unchanged host code built in FDM_Initialize (g%der1%lhs, g%der1%rhs, g%der2%lhs, g%der2%rhs).
+!
+! u, result, tmp1 must live in device memory, i.e. have been allocated through the allocation hook
+! (tlab_malloc in TLab_Allocate_Real, see INTEGRATION.md); c_loc() of such an array is the device pointer.
+!
+! Build with -DTLAB_AMD_PARTIAL_MODULE=OPR_Partial (default) for the drop-in; the test program compiles it under another
+! name to run it side by side with the reference's CPU module.
+!########################################################################
+#ifndef TLAB_AMD_PARTIAL_MODULE
+#define TLAB_AMD_PARTIAL_MODULE OPR_Partial
+#endif
+module TLAB_AMD_PARTIAL_MODULE
+    use, intrinsic :: iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use FDM, only: fdm_dt
+    use TLab_AMD_C
+    implicit none
+    private
+
+    public :: OPR_Partial_X
+    public :: OPR_Partial_Y
+    public :: OPR_Partial_Z
+    public :: OPR_Partial_AMD_Plan          ! device plan handle of a direction (shared with OPR_Burgers / OPR_Elliptic shims)
+
+    integer, parameter, public :: OPR_P1 = 1
+    integer, parameter, public :: OPR_P2 = 2
+    integer, parameter, public :: OPR_P2_P1 = 3
+    integer, parameter, public :: OPR_P1_INT_VP = 5
+    integer, parameter, public :: OPR_P1_INT_PV = 6
+    integer, parameter, public :: OPR_P0_INT_VP = 7
+    integer, parameter, public :: OPR_P0_INT_PV = 8
+    integer, parameter, public :: OPR_P0_IBM = 9
+
+    type(c_ptr), save :: plans(3) = [c_null_ptr, c_null_ptr, c_null_ptr]
+
+contains
+    ! ###################################################################
+    function OPR_Partial_AMD_Plan(idir, g) result(p)
+        integer, intent(in) :: idir
+        type(fdm_dt), intent(in) :: g
+        type(c_ptr) :: p
+        integer(c_int) rc
+        if (.not. c_associated(plans(idir))) then
+            rc = tlab_fdm_plan_create_from_arrays(plans(idir), int(g%size, c_int), merge(1_c_int, 0_c_int, g%periodic), &
+                                                  merge(1_c_int, 0_c_int, g%der2%need_1der), &
+                                                  int(g%der1%nb_diag(1), c_int), int(g%der1%nb_diag(2), c_int), g%der1%lhs, g%der1%rhs, &
+                                                  int(g%der2%nb_diag(1), c_int), int(g%der2%nb_diag(2), c_int), g%der2%lhs, g%der2%rhs)
+            call TLab_AMD_Check(rc, 'tlab_fdm_plan_create_from_arrays')
+        end if
+        p = plans(idir)
+    end function OPR_Partial_AMD_Plan
+
+    ! ###################################################################
+    subroutine partial_any(idir, type, nx, ny, nz, bcs, g, u, result, tmp1)
+        integer, intent(in) :: idir
+        integer(wi), intent(in) :: type, nx, ny, nz
+        integer(wi), intent(in) :: bcs(:, :)
+        type(fdm_dt), intent(in) :: g
+        real(wp), intent(in), target :: u(*)
+        real(wp), intent(out), target :: result(*)
+        real(wp), intent(inout), target, optional :: tmp1(*)
+        type(c_ptr) :: pt
+        integer(c_int) rc, ibc
+        ibc = int(bcs(1, 1) + bcs(2, 1)*2, c_int)                 ! opr_partial.f90:91
+        pt = c_null_ptr
+        if (present(tmp1)) pt = c_loc(tmp1)
+        rc = tlab_opr_partial(int(idir, c_int), OPR_Partial_AMD_Plan(idir, g), int(type, c_int), int(nx, c_int), int(ny, c_int), &
+                              int(nz, c_int), ibc, c_loc(u), c_loc(result), pt)
+        call TLab_AMD_Check(rc, 'tlab_opr_partial')               ! non-target types return TLAB_EUNSUPPORTED: route them to the CPU module
+    end subroutine partial_any
+
+    subroutine OPR_Partial_X(type, nx, ny, nz, bcs, g, u, result, tmp1)
+        integer(wi), intent(in) :: type, nx, ny, nz
+        integer(wi), intent(in) :: bcs(:, :)
+        type(fdm_dt), intent(in) :: g
+        real(wp), intent(in) :: u(nx*ny*nz)
+        real(wp), intent(out) :: result(nx*ny*nz)
+        real(wp), intent(inout), optional :: tmp1(nx*ny*nz)
+        call partial_any(1, type, nx, ny, nz, bcs, g, u, result, tmp1)
+    end subroutine OPR_Partial_X
+
+    subroutine OPR_Partial_Y(type, nx, ny, nz, bcs, g, u, result, tmp1)
+        integer(wi), intent(in) :: type, nx, ny, nz
+        integer(wi), intent(in) :: bcs(:, :)
+        type(fdm_dt), intent(in) :: g
+        real(wp), intent(in) :: u(nx*ny*nz)
+        real(wp), intent(out) :: result(nx*ny*nz)
+        real(wp), intent(inout), optional :: tmp1(nx*ny*nz)
+        call partial_any(2, type, nx, ny, nz, bcs, g, u, result, tmp1)
+    end subroutine OPR_Partial_Y
+
+    subroutine OPR_Partial_Z(type, nx, ny, nz, bcs, g, u, result, tmp1)
+        integer(wi), intent(in) :: type, nx, ny, nz
+        integer(wi), intent(in) :: bcs(:, :)
+        type(fdm_dt), intent(in) :: g
+        real(wp), intent(in) :: u(nx*ny*nz)
+        real(wp), intent(out) :: result(nx*ny*nz)
+        real(wp), intent(inout), optional :: tmp1(nx*ny*nz)
+        call partial_any(3, type, nx, ny, nz, bcs, g, u, result, tmp1)
+    end subroutine OPR_Partial_Z
+
+end module TLAB_AMD_PARTIAL_MODULE

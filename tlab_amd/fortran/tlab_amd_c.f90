@@ -1,0 +1,101 @@
+!########################################################################
+! ISO_C_BINDING interfaces of the C ABI in include/tlab_amd.h.
+! One interface per entry point; names and argument order are those of the header.
+!########################################################################
+module TLab_AMD_C
+    use, intrinsic :: iso_c_binding
+    implicit none
+    public
+
+    interface
+        integer(c_int) function tlab_init(device) bind(C, name='tlab_init')
+            import :: c_int
+            integer(c_int), value :: device
+        end function
+        integer(c_int) function tlab_sync() bind(C, name='tlab_sync')
+            import :: c_int
+        end function
+        function tlab_last_error() bind(C, name='tlab_last_error') result(p)
+            import :: c_ptr
+            type(c_ptr) :: p
+        end function
+        integer(c_int) function tlab_malloc(p, bytes) bind(C, name='tlab_malloc')
+            import :: c_int, c_ptr, c_size_t
+            type(c_ptr), intent(out) :: p
+            integer(c_size_t), value :: bytes
+        end function
+        integer(c_int) function tlab_free(p) bind(C, name='tlab_free')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: p
+        end function
+        integer(c_int) function tlab_memcpy_h2d(dst, src, bytes) bind(C, name='tlab_memcpy_h2d')
+            import :: c_int, c_ptr, c_size_t
+            type(c_ptr), value :: dst, src
+            integer(c_size_t), value :: bytes
+        end function
+        integer(c_int) function tlab_memcpy_d2h(dst, src, bytes) bind(C, name='tlab_memcpy_d2h')
+            import :: c_int, c_ptr, c_size_t
+            type(c_ptr), value :: dst, src
+            integer(c_size_t), value :: bytes
+        end function
+        integer(c_int) function tlab_fdm_plan_create_from_arrays(plan, n, periodic, need_1der, ndl1, ndr1, lhs1, rhs1, &
+                                                                 ndl2, ndr2, lhs2, rhs2) bind(C, name='tlab_fdm_plan_create_from_arrays')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), intent(out) :: plan
+            integer(c_int), value :: n, periodic, need_1der, ndl1, ndr1, ndl2, ndr2
+            real(c_double), intent(in) :: lhs1(*), rhs1(*), lhs2(*), rhs2(*)
+        end function
+        integer(c_int) function tlab_fdm_plan_destroy(plan) bind(C, name='tlab_fdm_plan_destroy')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+        end function
+        integer(c_int) function tlab_opr_partial(dir, plan, itype, nx, ny, nz, ibc, u, res, tmp1) bind(C, name='tlab_opr_partial')
+            import :: c_int, c_ptr
+            integer(c_int), value :: dir, itype, nx, ny, nz, ibc
+            type(c_ptr), value :: plan, u, res, tmp1
+        end function
+        integer(c_int) function tlab_opr_burgers(dir, plan, ivel, nx, ny, nz, ibc, nu, s, u, res, tmp1, write_transposed) &
+            bind(C, name='tlab_opr_burgers')
+            import :: c_int, c_ptr, c_double
+            integer(c_int), value :: dir, ivel, nx, ny, nz, ibc, write_transposed
+            real(c_double), value :: nu
+            type(c_ptr), value :: plan, s, u, res, tmp1
+        end function
+        integer(c_int) function tlab_poisson_plan_create(plan, gx, gy, gz, nx, ny, nz) bind(C, name='tlab_poisson_plan_create')
+            import :: c_int, c_ptr
+            type(c_ptr), intent(out) :: plan
+            type(c_ptr), value :: gx, gy, gz
+            integer(c_int), value :: nx, ny, nz
+        end function
+        integer(c_int) function tlab_opr_poisson(plan, nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy) bind(C, name='tlab_opr_poisson')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy
+            integer(c_int), value :: nx, ny, nz, ibc
+        end function
+        integer(c_int) function tlab_transpose(a, nra, nca, b) bind(C, name='tlab_transpose')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: a, b
+            integer(c_int), value :: nra, nca
+        end function
+    end interface
+
+contains
+    ! Error convention of the reference: write the message and stop the program (TLab_Write_ASCII(efile, ...) + TLab_Stop,
+    ! base/tlab_workflow.f90:105-166).  In a full Tlab build replace the body by those two calls.
+    subroutine TLab_AMD_Check(rc, what)
+        integer(c_int), intent(in) :: rc
+        character(len=*), intent(in) :: what
+        character(kind=c_char), pointer :: msg(:)
+        integer i
+        if (rc == 0) return
+        call c_f_pointer(tlab_last_error(), msg, [512])
+        write (*, '(a)', advance='no') 'tlab_amd: '//what//' failed: '
+        do i = 1, 512
+            if (msg(i) == c_null_char) exit
+            write (*, '(a)', advance='no') msg(i)
+        end do
+        write (*, *)
+        error stop 91       ! DNS_ERROR_UNDEVELOP in a full build
+    end subroutine TLab_AMD_Check
+
+end module TLab_AMD_C
