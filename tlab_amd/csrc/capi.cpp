@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -223,11 +225,16 @@ SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
     std::copy(h.V.begin(), h.V.end(), rowtab.begin() + 3 * n);
     std::copy(h.W.begin(), h.W.end(), rowtab.begin() + 4 * n);
     e->rowtab.upload(rowtab);
-    bool inv = true;  // lane-invariant: all chunks carry bitwise identical tables (circulant matrix)
+    // lane-invariant: all chunks carry bitwise identical tables (circulant matrix with exactly uniform coefficients), so that the
+    // kernel can use wave-uniform scalar loads.  NOTE: plans made by FDM_CreatePlan are NOT invariant: the reference derives the
+    // "uniform" spacing numerically (fdm.f90:194-201) and its a,b,c wander by ~eps*n (2e-13 at n = 512).  Replacing them by chunk 0's
+    // values would cost that much parity, so only exact equality qualifies; otherwise the per-lane tables are staged through LDS.
+    auto close = [](double a, double b) { return a == b; };
+    bool inv = h.periodic;
     for (int tab = 0; tab < 5 && inv; ++tab)
         for (int j = 1; j < P && inv; ++j)
             for (int p = 0; p < m; ++p)
-                if (rowtab[(size_t)tab * n + j * m + p] != rowtab[(size_t)tab * n + p]) { inv = false; break; }
+                if (!close(rowtab[(size_t)tab * n + j * m + p], rowtab[(size_t)tab * n + p])) { inv = false; break; }
     if (P == 64) {
         if (h.pcr_steps != 6) throw std::runtime_error("internal: PCR schedule missing");
         std::vector<double> red((size_t)13 * 64);
@@ -236,7 +243,7 @@ SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
         std::copy(h.pcr_dinv.begin(), h.pcr_dinv.end(), red.begin() + 12 * 64);
         for (int q = 0; q < 13 && inv; ++q)
             for (int j = 1; j < 64; ++j)
-                if (red[(size_t)q * 64 + j] != red[(size_t)q * 64]) { inv = false; break; }
+                if (!close(red[(size_t)q * 64 + j], red[(size_t)q * 64])) { inv = false; break; }
         e->red.upload(red);
     } else {
         e->red.upload(h.ginv);
@@ -456,6 +463,8 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.y1 = e1.dev();
     a.y2 = e2.dev();
     const bool lv = !(e1.lane_invariant && e2.lane_invariant);
+    static const bool dbg = getenv("TLAB_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[tlab] k_xline mode %d n %d lane_variant %d\n", mode, geom.n, (int)lv);
     hip_check(launch_xline(mode, geom.n, lv, a, g_stream), "k_xline");
 }
 
