@@ -134,6 +134,18 @@ int tlab_poisson_plan_destroy(tlab_poisson_plan_t p);
 int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,
                      const double *bcs_hb, const double *bcs_ht, double *dpdy);
 
+/* z-slab variant (ims_npro_k = nproc_k ranks, one GPU each; base/tlab_mpi_procs.f90:76-94): this rank owns planes
+ * [koffset, koffset + kmax) of nz_total.  The per-mode tables are built for the rank's own kz range (opr_elliptic.f90:167-194)
+ * and the z transform works on the K-transposed layout (nlines = (nx/2+1)*ny/nproc_k lines of nz_total points).  Such a plan is
+ * driven stage by stage, with the caller's all-to-all (TLabMPI_Trp_ExecK_*, base/tlab_mpi_transpose.f90:343-458) in between:
+ *   set_wall_planes, fft_x(+1), [K-forward], fft_z(+1), [K-backward], ode, [K-forward], fft_z(-1), [K-backward], fft_x(-1).  */
+int tlab_poisson_plan_create_slab(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                                  int nx, int ny, int kmax, int nz_total, int koffset, int nproc_k);
+int tlab_poisson_set_wall_planes(tlab_poisson_plan_t plan, double *p, const double *bcs_hb, const double *bcs_ht);
+int tlab_poisson_fft_x(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* OPR_Fourier_X_Forward/Backward, opr_fourier.f90:219,277 */
+int tlab_poisson_fft_z(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* the FFT inside OPR_Fourier_Z_*, :355,422 */
+int tlab_poisson_ode(tlab_poisson_plan_t plan, double *f_hat, double *p_hat, double *dp_hat); /* mode loop of opr_elliptic.f90:308-333 */
+
 /* ---- RHS assembly and Runge-Kutta substep ("next" row n1 of SURVEY.md 8f) --------------------------------- */
 /* Module state the reference spreads over TLab_Memory / NavierStokes / OPR_Burgers / BOUNDARY_BCS: plans, sizes,
  * visc = 1/Reynolds, schmidt(1:nscal) (physics/navierstokes.f90), wall boundary conditions (no-slip, Dirichlet scalars). */
@@ -155,6 +167,17 @@ int tlab_rhs_global_incompressible_1(tlab_dns_t d, double dte, double *const *q,
 int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double kco, int scale_tendencies,
                                               double *const *q, double *const *s, double *const *hq, double *const *hs,
                                               double *const *txc);
+
+/* The pointwise loops of the RHS / RK update as separate calls (rhs_global_incompressible_1.f90:106-112, :197-201, :257-259,
+ * :348-352, :279-280, :373-375; time.f90:645-664 + :272-297), for drivers that interleave communication. */
+int tlab_pw_add3(double *h, const double *a, const double *b, const double *c, long long n);             /* h += a + b + c   */
+int tlab_pw_axpy3(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3,
+                  const double *q1, const double *q2, const double *q3, double s, long long n);          /* o = h + q*s, x3  */
+int tlab_pw_sum3(double *a, const double *b, const double *c, long long n);                              /* a = a + b + c    */
+int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n); /* h -= .., x3 */
+int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n);             /* q += dte h; h *= kco */
+int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz);
+int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz);
 
 /* TLab_Transpose(a, nra, nca, ma, b, mb)   utils/tlab_transpose.f90:14-82 : b(j,i) = a(i,j), bit-exact */
 int tlab_transpose(const double *a, int nra, int nca, double *b);

@@ -124,6 +124,29 @@ def test_y_register_tile_kernel(T, nx, ny, nz, m):
         load().tlab_set_tuning(1, 0)
 
 
+@pytest.mark.parametrize("policy", [1, 2])
+@pytest.mark.parametrize("nx,ny,nz,d", [(64, 64, 3, 2), (48, 128, 2, 2), (32, 512, 2, 2), (40, 1024, 1, 2), (64, 2, 256, 3), (16, 4, 1024, 3), (96, 192, 1, 2)])
+def test_half_wave_tile_kernel_policies(T, nx, ny, nz, d, policy):
+    """k_htile (32-line tiles, fused two-derivative modes) forced on (2) and off (1): both must match the oracle."""
+    from oracle import tlab_oracle as O
+    from tlab_amd.lib import load
+    load().tlab_set_tuning(2, policy)
+    try:
+        n = (nx, ny, nz)[d - 1]
+        for stretch in ((True, False) if d == 2 else (False,)):
+            if d == 2:
+                _, nodes, _ = grids(8, n, 8, ystretch=stretch)
+                per, uni = False, not stretch
+            else:
+                nodes, per, uni = np.arange(n) / n * 2.0, True, True
+            gp, op = T.FdmPlan(nodes, per, uni), O.FdmPlan(nodes, per, uni)
+            u, v = fields(nx, ny, nz, n + policy)
+            run_all_ops(T, O, d, gp, op, nx, ny, nz, (0, 1, 2, 3) if d == 2 else (0,), u, v, 1.0 / 400.0, tag="htile policy %d" % policy)
+            assert load().tlab_last_kernel_path() == 3
+    finally:
+        load().tlab_set_tuning(2, 0)
+
+
 @pytest.mark.parametrize("m", [0, 64])
 @pytest.mark.parametrize("nx,ny,nz", [(64, 3, 32), (40, 5, 64), (64, 2, 256), (32, 6, 512), (16, 4, 1024)])
 def test_z_register_tile_kernel(T, nx, ny, nz, m):

@@ -424,9 +424,9 @@ enum { PATH_GENERIC = 1, PATH_XLINE = 2, PATH_RTILE = 3 };
 int choose_path(int dir, int n) {
     int path = PATH_GENERIC;
     if (dir == 1 && xline_supported(n)) path = PATH_XLINE;
-    if (dir != 1 && rtile_chunk(n) > 0) path = PATH_RTILE;
+    if (dir != 1 && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0)) path = PATH_RTILE;
     if (g_force_path == PATH_GENERIC) path = PATH_GENERIC;
-    if (g_force_path == PATH_RTILE && rtile_chunk(n) > 0 && dir != 1) path = PATH_RTILE;
+    if (g_force_path == PATH_RTILE && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0) && dir != 1) path = PATH_RTILE;
     return path;
 }
 
@@ -444,13 +444,30 @@ void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
                const double *in2, double *out, double nu) {
     const int P = geom.n / rtile_chunk(geom.n);
     RTileArgs a;
-    a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.g = geom; a.nu = nu;
+    a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.out1 = nullptr; a.g = geom; a.nu = nu;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     a.y1 = g->system(1, ibc, P).dev();
     a.y2 = g->system(2, 0, P).dev();
     a.jc = (mode == MODE_P2_D1IN || mode == MODE_BURGERS_D1IN) ? g->jaccorr() : JacCorrDev{nullptr};
     hip_check(launch_rtile(mode, a, g_stream), "k_rtile");
+}
+
+int g_htile_policy = 0;   // 0 automatic, 1 never (two-launch k_rtile path), 2 always when the size allows
+
+bool htile_ok(int n, int mode) { return g_htile_policy != 1 && htile_chunk(n, mode) > 0; }
+
+void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *vel, double *out0,
+               double *out1, double nu) {
+    const int C = geom.n / htile_chunk(geom.n, mode);
+    RTileArgs a;
+    a.in0 = in0; a.in1 = nullptr; a.in2 = vel; a.out0 = out0; a.out1 = out1; a.g = geom; a.nu = nu;
+    a.s1 = g->stencil(1, ibc);
+    a.s2 = g->stencil(2, 0);
+    a.y1 = g->system(1, ibc, C).dev();
+    a.y2 = g->system(2, 0, C).dev();
+    a.jc = (mode != MODE_P1) ? g->jaccorr() : JacCorrDev{nullptr};
+    hip_check(launch_htile(mode, a, g_stream), "k_htile");
 }
 
 void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *in1,
@@ -490,6 +507,7 @@ int tlab_force_kernel_path(int path) {
 }
 int tlab_set_tuning(int key, int value) {
     if (key == 1) { rtile_force_chunk(value); return TLAB_OK; }
+    if (key == 2) { g_htile_policy = value; return TLAB_OK; }
     g_err = "tlab_set_tuning: unknown key";
     return TLAB_EINVAL;
 }
@@ -518,8 +536,14 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
             const int mode = (type == TLAB_OPR_P1) ? MODE_P1 : (type == TLAB_OPR_P2) ? MODE_P2 : MODE_P2_P1;
             run_xline(g, geom, mode, ibc, u, nullptr, result, tmp1, 0.0);
         } else if (path == PATH_RTILE) {
+            const bool r64 = rtile_chunk(geom.n) > 0 && g_htile_policy != 2;     // 64-line tiles: best for one line-set
             if (type == TLAB_OPR_P1) {
-                run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0);
+                if (r64) run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0);
+                else run_htile(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0);
+            } else if (type == TLAB_OPR_P2_P1 && htile_ok(geom.n, MODE_P2_P1)) {
+                run_htile(g, geom, MODE_P2_P1, ibc, u, nullptr, result, tmp1, 0.0);              // fused, one load of u
+            } else if (type == TLAB_OPR_P2 && ((corr && htile_ok(geom.n, MODE_P2)) || !r64)) {
+                run_htile(g, geom, MODE_P2, ibc, u, nullptr, result, nullptr, 0.0);              // first derivative stays in registers
             } else {
                 const bool need_d1 = corr || type == TLAB_OPR_P2_P1;
                 if (need_d1) run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, tmp1, 0.0);
@@ -560,6 +584,8 @@ int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int n
         g_last_path = path;
         if (path == PATH_XLINE) {
             run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu);
+        } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {
+            run_htile(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu);                  // fully fused: s and vel read once
         } else if (path == PATH_RTILE) {
             run_rtile(g, geom, MODE_P1, ibc, s, nullptr, nullptr, d1, 0.0);
             run_rtile(g, geom, MODE_BURGERS_D1IN, ibc, s, d1, vel, result, nu);

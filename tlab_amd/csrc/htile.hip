@@ -1,0 +1,254 @@
+// k_htile : y/z-direction derivative kernel on HALF-wave tiles (32 memory-contiguous lines x n rows per workgroup).
+//
+// Same chunked Thomas as k_rtile (kernels.hip), but a wave holds TWO chunks: lanes 0-31 own rows [2w*M, (2w+1)*M) of the 32
+// lines, lanes 32-63 rows [(2w+1)*M, (2w+2)*M).  A tile is then 32 x n x 8 B = 128 KiB at n = 512 instead of 256 KiB, which
+// leaves room in the register file for TWO line-sets at once: the first and the second derivative of OPR_Burgers /
+// OPR_P2_P1 are computed from one load of the operand (24 B/point instead of the 48 B/point of the two-launch k_rtile path),
+// including the Jacobian correction of stretched grids (the first derivative never leaves the registers; only the two edge
+// values of each chunk go through LDS).  It also reaches n = 1024 (32 chunks of 32 rows, or 16 of 64).
+// Price: 256-B instead of 512-B contiguous rows, and coefficient rows that differ between the two halves of a wave (vector
+// loads that hit L1 instead of scalar loads).
+#include <hip/hip_runtime.h>
+
+#include "device_tables.hpp"
+#include "kernels.hpp"
+#include "profile.hpp"
+
+namespace tlab {
+
+template <bool SYM>
+__device__ __forceinline__ double h_stencil(const StencilDev &s, double um3, double um2, double um1, double u0, double up1, double up2,
+                                            double up3) {
+    if (SYM) return s.c0 * u0 + up1 + um1 + s.c2 * (up2 + um2) + s.c3 * (up3 + um3);
+    return up1 - um1 + s.c2 * (up2 - um2);
+}
+__device__ __forceinline__ double h_dense6(const double (&c)[6], double a0, double a1, double a2, double a3, double a4, double a5) {
+    return a0 * c[0] + a1 * c[1] + a2 * c[2] + a3 * c[3] + a4 * c[4] + a5 * c[5];
+}
+
+// local Thomas solve of one chunk + separator system through LDS.  f: right-hand side in, solution out.
+template <int M>
+__device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, const double *ginv, int n, int row0, int c, int C, int l32,
+                                        double *s_yl, double *s_r) {
+    const double *Lm = rowtab + row0, *Di = rowtab + n + row0, *Cm = rowtab + 2 * n + row0;
+    const double *Vt = rowtab + 3 * n + row0, *Wt = rowtab + 4 * n + row0;
+    double g = 0.0;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        g = f[p] + Lm[p] * g;
+        f[p] = g;
+    }
+    double yn = 0.0;
+#pragma unroll
+    for (int p = M - 1; p >= 1; --p) {
+        yn = f[p] * Di[p] + Cm[p] * yn;
+        f[p] = yn;
+    }
+    s_yl[c * 32 + l32] = f[M - 1];
+    __syncthreads();
+    const int cm = (c + C - 1) % C, cp = (c + 1) % C;
+    const double yLprev = s_yl[cm * 32 + l32];
+    s_r[c * 32 + l32] = f[0] - Lm[0] * yLprev - Cm[0] * f[1];
+    __syncthreads();
+    double X = 0.0, Xr = 0.0;
+    const double *g0 = ginv + c * C, *g1 = ginv + cp * C;
+    for (int q = 0; q < C; ++q) {
+        const double rq = s_r[q * 32 + l32];
+        X += g0[q] * rq;
+        Xr += g1[q] * rq;
+    }
+    f[0] = X;
+#pragma unroll
+    for (int p = 1; p < M; ++p) f[p] = f[p] + Vt[p] * X + Wt[p] * Xr;
+}
+
+template <int M, int MODE, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
+    __shared__ double s_yl[32 * 32];
+    __shared__ double s_r[32 * 32];
+    __shared__ double s_e[2 * 32 * 32];   // first-derivative edge values of every chunk (Jacobian correction)
+    extern __shared__ double s_tab[];     // coefficient rows of both systems, separator inverses, Jacobian-correction diagonals
+    constexpr bool NEED1 = (MODE == MODE_P1 || MODE == MODE_P2_P1 || MODE == MODE_BURGERS);
+    constexpr bool NEED2 = (MODE != MODE_P1);
+    const int lane = threadIdx.x & 63;
+    const int l32 = lane & 31;
+    const int c = 2 * (threadIdx.x >> 6) + (lane >> 5);
+    const int C = blockDim.x >> 5;
+    const int n = a.g.n;
+    const long long rs = a.g.row_stride;
+    const bool per = a.s1.periodic != 0;
+    const bool corr = a.jc.j != nullptr;        // non-uniform grid: second derivative needs the first one
+
+    // stage the tables once per workgroup: the two halves of a wave work on different rows, so the coefficient rows are not
+    // wave-uniform here; LDS reads with two distinct addresses per wave are broadcast, vector loads from L1 cost ~120 cycles each
+    double *t1 = s_tab, *t2 = s_tab + 5 * n, *gi1 = s_tab + 10 * n, *gi2 = gi1 + C * C, *tj = gi2 + C * C;
+    {
+        const bool use1 = NEED1 || corr;
+        for (int i = threadIdx.x; i < 5 * n; i += blockDim.x) {
+            if (use1) t1[i] = a.y1.rowtab[i];
+            if (NEED2) t2[i] = a.y2.rowtab[i];
+        }
+        for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+            if (use1) gi1[i] = a.y1.red[i];
+            if (NEED2) gi2[i] = a.y2.red[i];
+        }
+        if (NEED2 && corr)
+            for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) tj[i] = a.jc.j[i];
+    }
+    // (the first __syncthreads inside h_solve would be too late for the coefficient reads of the local sweeps)
+    __syncthreads();
+
+    const int tiles_inner = (a.g.lines_inner + 31) >> 5;
+    const long long outer = blockIdx.x / tiles_inner;
+    const int l0 = (int)(blockIdx.x % tiles_inner) << 5;
+    const bool valid = (l0 + l32) < a.g.lines_inner;
+    const long long base = outer * a.g.outer_stride + l0 + l32;
+    const int row0 = c * M;
+
+    // ---- operand rows + 3-row halos ----
+    double e[M + 6];
+#pragma unroll
+    for (int p = 0; p < M; ++p) e[p + 3] = valid ? a.in0[base + (long long)(row0 + p) * rs] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int rl = row0 - 3 + k, rr = row0 + M + k;
+        const bool okl = per || rl >= 0, okr = per || rr < n;
+        if (rl < 0) rl += n;
+        if (rr >= n) rr -= n;
+        e[k] = (valid && okl) ? a.in0[base + (long long)rl * rs] : 0.0;
+        e[M + 3 + k] = (valid && okr) ? a.in0[base + (long long)rr * rs] : 0.0;
+    }
+
+    // ---- right-hand sides of both systems from the one operand ----
+    double x1[M], x2[NEED2 ? M : 1];
+    if (NEED1 || (NEED2 && corr)) {
+#pragma unroll
+        for (int p = 0; p < M; ++p) x1[p] = h_stencil<false>(a.s1, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+        if (!per) {
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) x1[r] = h_dense6(a.s1.bb[r], e[3], e[4], e[5], e[6], e[7], e[8]);
+            }
+            if (c == C - 1) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) x1[M - 3 + r] = h_dense6(a.s1.bt[r], e[M - 3], e[M - 2], e[M - 1], e[M], e[M + 1], e[M + 2]);
+            }
+        }
+    }
+    if constexpr (NEED2) {
+#pragma unroll
+        for (int p = 0; p < M; ++p) x2[p] = h_stencil<true>(a.s2, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+        if (!per) {
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) x2[r] = h_dense6(a.s2.bb[r], e[3], e[4], e[5], e[6], e[7], e[8]);
+            }
+            if (c == C - 1) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) x2[M - 3 + r] = h_dense6(a.s2.bt[r], e[M - 3], e[M - 2], e[M - 1], e[M], e[M + 1], e[M + 2]);
+            }
+        }
+    }
+
+    // advecting velocity: issued now (the operand registers are dead) so that its latency hides behind the two solves
+    double vl[MODE == MODE_BURGERS ? M : 1];
+    if constexpr (MODE == MODE_BURGERS) {
+#pragma unroll
+        for (int p = 0; p < M; ++p) vl[p] = valid ? a.in2[base + (long long)(row0 + p) * rs] : 0.0;
+    }
+
+    // ---- first derivative ----
+    if (NEED1 || (NEED2 && corr)) h_solve<M>(x1, t1, gi1, n, row0, c, C, l32, s_yl, s_r);
+
+    // ---- second derivative (+ Jacobian correction  f += A2 dx2 du, MatMul_3d_add fdm_matmul.f90:126-153) ----
+    if constexpr (NEED2) {
+        if (corr) {
+            s_e[(2 * c + 0) * 32 + l32] = x1[0];
+            s_e[(2 * c + 1) * 32 + l32] = x1[M - 1];
+            __syncthreads();
+            const double dl = (c > 0) ? s_e[(2 * (c - 1) + 1) * 32 + l32] : 0.0;   // du at row0 - 1
+            const double dr = (c < C - 1) ? s_e[(2 * (c + 1) + 0) * 32 + l32] : 0.0;  // du at row0 + M
+            const double *j1 = tj + row0, *j2 = tj + n + row0, *j3 = tj + 2 * n + row0;
+#pragma unroll
+            for (int p = 0; p < M; ++p) {
+                const double dm = (p == 0) ? dl : x1[p > 0 ? p - 1 : 0];
+                const double dp = (p == M - 1) ? dr : x1[p < M - 1 ? p + 1 : M - 1];
+                double add = dm * j1[p] + x1[p] * j2[p] + dp * j3[p];
+                if (p == 0 && c == 0) add = x1[0] * j2[0] + x1[1] * j3[0] + x1[2] * j1[0];                          // r1(1) extended stencil
+                if (p == M - 1 && c == C - 1) add = x1[M - 3] * j3[M - 1] + x1[M - 2] * j1[M - 1] + x1[M - 1] * j2[M - 1];  // r3(n)
+                x2[p] = x2[p] + add;
+            }
+        }
+        h_solve<M>(x2, t2, gi2, n, row0, c, C, l32, s_yl, s_r);
+    }
+
+    // ---- epilogue ----
+    if (!valid) return;
+    if constexpr (MODE == MODE_P1) {
+#pragma unroll
+        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x1[p];
+    } else if constexpr (MODE == MODE_P2) {
+#pragma unroll
+        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x2[p];
+    } else if constexpr (MODE == MODE_P2_P1) {
+#pragma unroll
+        for (int p = 0; p < M; ++p) {
+            a.out0[base + (long long)(row0 + p) * rs] = x2[p];
+            a.out1[base + (long long)(row0 + p) * rs] = x1[p];
+        }
+    } else {  // MODE_BURGERS: result = nu d2 - vel d1 (opr_burgers.f90:513)
+#pragma unroll
+        for (int p = 0; p < M; ++p) {
+            const long long idx = base + (long long)(row0 + p) * rs;
+            a.out0[idx] = a.nu * x2[p] - vl[p] * x1[p];
+        }
+    }
+}
+
+// chunk length of the half-wave-tile kernel for a line length n and a mode (0 = unsupported)
+int htile_chunk(int n, int mode) {
+    const bool two = (mode == MODE_P2_P1 || mode == MODE_BURGERS);   // two line-sets live in registers
+    auto ok = [&](int m, int cmax) { return n % m == 0 && (n / m) % 2 == 0 && n / m <= cmax; };   // two chunks per wave -> even count
+    if (two) {
+        if (ok(32, 16)) return 32;      // <= 512 threads -> 256-VGPR budget
+        if (ok(16, 16)) return 16;
+        return 0;
+    }
+    if (ok(32, 32)) return 32;          // up to n = 1024 with 1024 threads (P1/P2: < 128 VGPRs)
+    if (ok(64, 16)) return 64;
+    if (ok(16, 32)) return 16;
+    return 0;
+}
+
+template <int M, int MAXT>
+static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileArgs &a, hipStream_t st) {
+    const dim3 grid((unsigned)tiles), block(32 * C);
+    const size_t lds = ((size_t)13 * a.g.n + (size_t)2 * C * C) * sizeof(double);
+    const double pts = (double)a.g.nlines * a.g.n;
+    const char *name = mode == MODE_P1 ? "k_htile<P1>" : mode == MODE_P2 ? "k_htile<P2>" : mode == MODE_P2_P1 ? "k_htile<P2_P1>" : "k_htile<BURGERS>";
+    const double bpp = (mode == MODE_P1 || mode == MODE_P2) ? 16 : 24;
+    ProfScope ps(name, st, pts * bpp);
+    switch (mode) {
+    case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT>), grid, block, lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_htile<M, MODE_P2, MAXT>), grid, block, lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_htile<M, MODE_P2_P1, MAXT>), grid, block, lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT>), grid, block, lds, st, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st) {
+    const int n = a.g.n;
+    const int M = htile_chunk(n, mode);
+    if (M == 0) return hipErrorInvalidValue;
+    const int C = n / M;
+    if (C & 1) return hipErrorInvalidValue;      // two chunks per wave
+    const long long tiles_inner = (a.g.lines_inner + 31) / 32;
+    const long long tiles = tiles_inner * (a.g.nlines / a.g.lines_inner);
+    if (M == 64) return launch_htile_m<64, 512>(mode, C, tiles, a, st);
+    if (M == 32) return (C <= 16) ? launch_htile_m<32, 512>(mode, C, tiles, a, st) : launch_htile_m<32, 1024>(mode, C, tiles, a, st);
+    return (C <= 16) ? launch_htile_m<16, 512>(mode, C, tiles, a, st) : launch_htile_m<16, 1024>(mode, C, tiles, a, st);
+}
+
+}  // namespace tlab

@@ -21,9 +21,10 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     const double *in1;      // first derivative (D1IN modes)
     const double *in2;      // advecting velocity (MODE_BURGERS_D1IN)
     double *out0;
+    double *out1;           // first derivative (MODE_P2_P1 of k_htile)
     LineGeom g;
     StencilDev s1, s2;
-    SystemDev y1, y2;       // chunked with P = n / rtile_chunk(n)
+    SystemDev y1, y2;       // chunked with P = n / rtile_chunk(n)  (k_htile: n / htile_chunk(n, mode))
     JacCorrDev jc;
     double nu;
 };
@@ -43,6 +44,8 @@ int rtile_chunk(int n);
 void rtile_force_chunk(int m);
 hipError_t launch_xline(int mode, int n, bool lane_variant, const XLineArgs &a, hipStream_t st);
 hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st);
+int htile_chunk(int n, int mode);
+hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st);
 hipError_t launch_generic(bool sym, const GenericArgs &a, hipStream_t st);
 hipError_t launch_burgers_epilogue(double *out, const double *vel, const double *d1, double nu, long long ntot, hipStream_t st);
 hipError_t launch_fill(double *out, double v, long long ntot, hipStream_t st);

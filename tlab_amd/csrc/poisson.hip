@@ -471,8 +471,9 @@ bool g_rocfft_up = false;
 }  // namespace
 
 struct tlab_poisson_plan {
-    int nx = 0, ny = 0, nz = 0, nxh = 0;
-    long long nm = 0;                 // modes = nxh * nz
+    int nx = 0, ny = 0, nz = 0, nxh = 0;   // nz = local number of z planes (kmax)
+    int nzt = 0, koff = 0, nproc = 1;      // global nz, first global plane of this slab, number of z slabs
+    long long nm = 0;                 // local modes = nxh * nz
     double norm = 1.0;
     Int1Tables tmin, tmax;            // host copies
     DBuf d_L0[2], d_L1[2], d_R[2];    // [0] BCS_MIN tables, [1] BCS_MAX tables
@@ -562,18 +563,20 @@ void build_fft(tlab_poisson_plan &P) {
         rocfft_plan_description_destroy(d);
         P.fx_c2r.finish();
     }
-    if (nz > 1) {  // z: complex <-> complex, stride nxh*ny, batch nxh*ny with distance 1 (dfftw_plan_many_dft, :111-119)
+    if (P.nzt > 1) {  // z: complex <-> complex, stride = batch = nlines with distance 1 (dfftw_plan_many_dft, :111-119);
+        // nlines = (imax/2+1)*jmax, or tmpi_plan_fftz%nlines = that / npro_k after the K-transposition (opr_fourier.f90:85-98)
+        const size_t nlines = nxh * ny * nz / (size_t)P.nzt;
         for (int dir = 0; dir < 2; ++dir) {
             rocfft_plan_description d = nullptr;
             fftc(rocfft_plan_description_create(&d), "desc");
-            size_t st[1] = {nxh * ny};
+            size_t st[1] = {nlines};
             fftc(rocfft_plan_description_set_data_layout(d, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved,
                                                          nullptr, nullptr, 1, st, 1, 1, st, 1), "layout c2c");
-            size_t len[1] = {nz};
+            size_t len[1] = {(size_t)P.nzt};
             FftPlan &F = dir == 0 ? P.fz_f : P.fz_b;
             fftc(rocfft_plan_create(&F.plan, rocfft_placement_notinplace,
                                     dir == 0 ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
-                                    rocfft_precision_double, 1, len, nxh * ny, d), "plan c2c");
+                                    rocfft_precision_double, 1, len, nlines, d), "plan c2c");
             rocfft_plan_description_destroy(d);
             F.finish();
         }
@@ -636,19 +639,22 @@ extern bool tlab_device_ready();
 
 extern "C" {
 
-int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
-                             int nz) {
+static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
+                                    int nz, int nzt, int koff, int nproc) {
     try {
         if (!out || !gx || !gy || !gz) throw std::invalid_argument("tlab_poisson_plan_create: null argument");
         if (!tlab_device_ready()) throw std::runtime_error("tlab_init has not been called (no CPU fallback exists)");
-        if (gx->t.n != nx || gy->t.n != ny || gz->t.n != nz) throw std::invalid_argument("plan sizes do not match nx, ny, nz");
-        if (!gx->t.periodic || (nz > 1 && !gz->t.periodic) || gy->t.periodic)
+        if (gx->t.n != nx || gy->t.n != ny || gz->t.n != nzt) throw std::invalid_argument("plan sizes do not match nx, ny, nz");
+        if (!gx->t.periodic || (nzt > 1 && !gz->t.periodic) || gy->t.periodic)
             throw std::invalid_argument("OPR_Poisson_FourierXZ needs periodic x, z and non-periodic y");
         if (nx % 2 != 0) throw std::invalid_argument("Imax must be a multiple of 2 for the FFT operations (opr_fourier.f90:72-75)");
+        if (nproc < 1 || nz * nproc != nzt || koff < 0 || koff + nz > nzt) throw std::invalid_argument("bad z-slab decomposition");
+        if (((long long)(nx / 2 + 1) * ny) % nproc != 0) throw std::invalid_argument("(imax/2+1)*jmax must be divisible by the number of z slabs (tlab_mpi_transpose.f90:292)");
         auto P = std::make_unique<tlab_poisson_plan>();
         P->nx = nx; P->ny = ny; P->nz = nz; P->nxh = nx / 2 + 1;
+        P->nzt = nzt; P->koff = koff; P->nproc = nproc;
         P->nm = (long long)P->nxh * nz;
-        P->norm = 1.0 / ((double)nx * (double)nz);                      // opr_elliptic.f90:130
+        P->norm = 1.0 / ((double)nx * (double)nzt);                     // opr_elliptic.f90:130
         int1_build_tables(gy->t.der1, 1, P->tmin);
         int1_build_tables(gy->t.der1, 2, P->tmax);
         P->d_L0[0].upload(P->tmin.L0); P->d_L1[0].upload(P->tmin.L1); P->d_R[0].upload(P->tmin.R);
@@ -660,21 +666,23 @@ int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_
         for (int k = 0; k < nz; ++k)
             for (int i = 0; i < P->nxh; ++i) {
                 double l2 = std::pow(gx->t.der1.mwn[i], 2.0);
-                if (nz > 1) l2 += std::pow(gz->t.der1.mwn[k], 2.0);
+                if (nzt > 1) l2 += std::pow(gz->t.der1.mwn[koff + k], 2.0);   // kglobal = k + ims_offset_k (:191)
                 lam[(size_t)i + (size_t)P->nxh * k] = std::sqrt(l2);
             }
-        const int isg[2] = {0, nx / 2}, ksg[2] = {0, nz > 1 ? nz / 2 : 0};   // i_sing, k_sing (:148-149), 0-based
+        const int isg[2] = {0, nx / 2}, ksg[2] = {0, nzt > 1 ? nzt / 2 : 0};   // i_sing, k_sing (:148-149), 0-based, global
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b) {
-                const int t = isg[a] + P->nxh * ksg[b];
+                const int kl = ksg[b] - koff;                               // task-local index (:177-178)
+                if (kl < 0 || kl >= nz) continue;
+                const int t = isg[a] + P->nxh * kl;
                 if (!skip[t]) { skip[t] = 1; P->sing_modes.push_back(t); }
             }
         P->lam.upload(lam);
         hipc(hipMalloc((void **)&P->d_skip, (size_t)nm), "hipMalloc");
         hipc(hipMemcpy(P->d_skip, skip.data(), (size_t)nm, hipMemcpyHostToDevice), "hipMemcpy");
         const int ns = (int)P->sing_modes.size();
-        hipc(hipMalloc((void **)&P->d_sing, ns * sizeof(int)), "hipMalloc");
-        hipc(hipMemcpy(P->d_sing, P->sing_modes.data(), ns * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
+        hipc(hipMalloc((void **)&P->d_sing, (ns + 1) * sizeof(int)), "hipMalloc");
+        if (ns) hipc(hipMemcpy(P->d_sing, P->sing_modes.data(), ns * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
         std::vector<double> slam(ns);
         for (int s = 0; s < ns; ++s) slam[s] = lam[P->sing_modes[s]];
         P->s_lam.upload(slam);
@@ -689,7 +697,7 @@ int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_
         {   // fused 2-D (x,z) transforms are ~2x faster than r2c(x) + strided c2c(z) at 512^3, but rocFFT does not build them
             // for every layout: fall back to the two 1-D plans when plan creation fails (TLAB_FFT2D=0 forces the 1-D path)
             const char *e = getenv("TLAB_FFT2D");
-            if (nz > 1 && !(e && atoi(e) == 0)) {
+            if (nzt > 1 && nproc == 1 && !(e && atoi(e) == 0)) {
                 try {
                     build_fft_2d(*P);
                     P->use_2d = true;
@@ -715,104 +723,160 @@ int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_
     }
 }
 
+int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
+                             int nz) {
+    return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, nz, nz, 0, 1);
+}
+
+int tlab_poisson_plan_create_slab(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
+                                  int kmax, int nz_total, int koffset, int nproc_k) {
+    return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, kmax, nz_total, koffset, nproc_k);
+}
+
 int tlab_poisson_plan_destroy(tlab_poisson_plan_t p) {
     delete p;
     return TLAB_OK;
 }
 
+// ODE stage on the local modes: f_hat (complex (nxh, ny, kmax), unnormalised FFT output) -> p_hat, dp_hat.
+// p_hat may alias f_hat (the reference also overwrites); dp_hat must be a different array.
+static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
+    const long long nm = P->nm;
+    const int n = P->ny, nxh = P->nxh, ny = P->ny;
+    hipc(hipEventRecord(P->ev_fork, st), "event record");
+    hipc(hipStreamWaitEvent(P->side, P->ev_fork, 0), "stream wait");
+    // ---- regular modes: OPR_ODE2_Factorize_NN (opr_odes.f90:302-318) ----
+    Int1Args a = base_args(*P, 0, P->lam.p, nm, P->scratch.p);   // v' + l v = f, v(1) = 0
+    a.fsrc = f_hat; a.fscale = P->norm; a.zero_bsave = 1; a.bcs_save = P->bcs.p; a.dst = P->v0.p;
+    launch_int1<1, 2, FS_FIELD>(a, st);
+    Int1Args b = base_args(*P, 1, P->lam.p, nm, P->scratch.p);   // u' - l u = v, u(n) = 0
+    b.fsrc = P->v0.p; b.nlf = 2; b.zero_bsave = 0; b.dst = P->u0.p; b.du = P->du0.p;
+    launch_int1<2, 2, FS_LINEAR>(b, st);
+    // ---- singular modes: OPR_ODE2_Factorize_NN_Sing -> _DN_Sing (opr_odes.f90:165-183, 37-96) ----
+    const int ns = (int)P->sing_modes.size();
+    hipStream_t ss = P->side;   // independent of the regular modes until the scatter below
+    if (ns > 0) {
+        dim3 g(ns, (n + 63) / 64), blk(64);
+        hipLaunchKernelGGL(k_sing_gather, g, blk, 0, ss, f_hat, P->d_sing, ns, n, nxh, ny, P->norm, P->s_f.p, P->s_bct.p);
+        Int1Args s1 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v' = f (f(1)=0), v(n) = bcs_t
+        s1.fsrc = P->s_f.p; s1.nlf = 2; s1.zero_bsave = 0; s1.bv_ptr = P->s_bct.p; s1.dst = P->s_v0.p;
+        launch_int1<2, 2, FS_LINEAR>(s1, ss);
+        Int1Args s2 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v1' = delta_1, v1(n) = 0
+        s2.unit_row = 0; s2.zero_bsave = 0; s2.dst = P->s_v1.p;
+        launch_int1<2, 2, FS_UNIT>(s2, ss);
+        Int1Args s3 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u' = v, u(1) = bcs_b = 0
+        s3.fsrc = P->s_v0.p; s3.nlf = 2; s3.zero_bsave = 0; s3.dst = P->s_u0.p; s3.du = P->s_du0.p;
+        launch_int1<1, 2, FS_LINEAR>(s3, ss);
+        Int1Args s4 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u1' = v1, u1(1) = 0
+        s4.fsrc = P->s_v1.p; s4.nlf = 2; s4.zero_bsave = 0; s4.dst = P->s_u1.p; s4.du = P->s_du1.p;
+        launch_int1<1, 2, FS_LINEAR>(s4, ss);
+    }
+    // ---- superposition ----
+    CombineArgs c{};
+    c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.hom = P->hom.p; c.cst = P->cst.p; c.lam = P->lam.p;
+    c.skip = P->d_skip; c.p_hat = p_hat; c.dp_hat = dp_hat; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
+    {
+        ProfScope ps("k_nn_combine", st, (double)nm * n * (9 + 4) * 8.0);
+        hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+    }
+    // the singular modes write other entries than k_nn_combine (which skips them), but f^ must have been consumed by the regular
+    // v-solve first when p_hat aliases it: order the scatter after it through the main stream
+    hipc(hipEventRecord(P->ev_join, ss), "event record");
+    hipc(hipStreamWaitEvent(st, P->ev_join, 0), "stream wait");
+    if (ns > 0) {
+        dim3 g(ns, (n + 63) / 64), blk(64);
+        hipLaunchKernelGGL(k_sing_combine, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->s_u1.p, P->s_v1.p, P->s_du0.p, P->s_du1.p,
+                           P->d_sing, ns, n, nxh, ny, p_hat, dp_hat);
+    }
+    hipc(hipGetLastError(), "poisson kernels");
+}
+
+#define POISSON_GUARD_BEGIN try {
+#define POISSON_GUARD_END                           \
+    return TLAB_OK;                                 \
+    }                                               \
+    catch (const std::invalid_argument &e) {        \
+        tlab_set_error(e.what());                   \
+        return TLAB_EINVAL;                         \
+    }                                               \
+    catch (const std::exception &e) {               \
+        tlab_set_error(e.what());                   \
+        return TLAB_EHIP;                           \
+    }
+
 int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,
                      const double *bcs_hb, const double *bcs_ht, double *dpdy) {
-    try {
-        if (!P || !p || !tmp1 || !tmp2 || !bcs_hb || !bcs_ht) throw std::invalid_argument("tlab_opr_poisson: null argument");
-        if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_poisson: sizes do not match the plan");
-        if (ibc != TLAB_BCS_NN) {
-            tlab_set_error("OPR_Poisson: only BCS_NN is built on the device (the RHS call, rhs_global_incompressible_1.f90:284)");
-            return TLAB_EUNSUPPORTED;
-        }
-        if (p == tmp1 || p == tmp2 || tmp1 == tmp2 || dpdy == p || dpdy == tmp1 || dpdy == tmp2) throw std::invalid_argument("arrays must be distinct");
-        hipStream_t st = tlab_current_stream();
-        const long long nm = P->nm;
-        const int n = ny, nxh = P->nxh;
-        // BC planes into the forcing (opr_elliptic.f90:285-286)
-        hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, p, bcs_hb, bcs_ht, nx, ny, nz);
-        // forward transforms: p -> tmp2 -> tmp1 (:288-293); the scaling by norm (:295) is folded into the loads below
-        double *f_hat = tmp1;
-        if (P->use_2d) {
-            P->f2_fwd.exec(p, tmp1, st);
-        } else if (nz > 1) {
-            P->fx_r2c.exec(p, tmp2, st);
-            P->fz_f.exec(tmp2, tmp1, st);
-        } else {
-            P->fx_r2c.exec(p, tmp1, st);
-        }
-        hipc(hipEventRecord(P->ev_fork, st), "event record");
-        hipc(hipStreamWaitEvent(P->side, P->ev_fork, 0), "stream wait");
-        // ---- regular modes: OPR_ODE2_Factorize_NN (opr_odes.f90:302-318) ----
-        Int1Args a = base_args(*P, 0, P->lam.p, nm, P->scratch.p);   // v' + l v = f, v(1) = 0
-        a.fsrc = f_hat; a.fscale = P->norm; a.zero_bsave = 1; a.bcs_save = P->bcs.p; a.dst = P->v0.p;
-        launch_int1<1, 2, FS_FIELD>(a, st);
-        Int1Args b = base_args(*P, 1, P->lam.p, nm, P->scratch.p);   // u' - l u = v, u(n) = 0
-        b.fsrc = P->v0.p; b.nlf = 2; b.zero_bsave = 0; b.dst = P->u0.p; b.du = P->du0.p;
-        launch_int1<2, 2, FS_LINEAR>(b, st);
-        // ---- singular modes: OPR_ODE2_Factorize_NN_Sing -> _DN_Sing (opr_odes.f90:165-183, 37-96) ----
-        const int ns = (int)P->sing_modes.size();
-        hipStream_t ss = P->side;   // independent of the regular modes until the scatter below
-        {
-            dim3 g(ns, (n + 63) / 64), blk(64);
-            hipLaunchKernelGGL(k_sing_gather, g, blk, 0, ss, f_hat, P->d_sing, ns, n, nxh, ny, P->norm, P->s_f.p, P->s_bct.p);
-            Int1Args s1 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v' = f (f(1)=0), v(n) = bcs_t
-            s1.fsrc = P->s_f.p; s1.nlf = 2; s1.zero_bsave = 0; s1.bv_ptr = P->s_bct.p; s1.dst = P->s_v0.p;
-            launch_int1<2, 2, FS_LINEAR>(s1, ss);
-            Int1Args s2 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v1' = delta_1, v1(n) = 0
-            s2.unit_row = 0; s2.zero_bsave = 0; s2.dst = P->s_v1.p;
-            launch_int1<2, 2, FS_UNIT>(s2, ss);
-            Int1Args s3 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u' = v, u(1) = bcs_b = 0
-            s3.fsrc = P->s_v0.p; s3.nlf = 2; s3.zero_bsave = 0; s3.dst = P->s_u0.p; s3.du = P->s_du0.p;
-            launch_int1<1, 2, FS_LINEAR>(s3, ss);
-            Int1Args s4 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u1' = v1, u1(1) = 0
-            s4.fsrc = P->s_v1.p; s4.nlf = 2; s4.zero_bsave = 0; s4.dst = P->s_u1.p; s4.du = P->s_du1.p;
-            launch_int1<1, 2, FS_LINEAR>(s4, ss);
-        }
-        // ---- superposition; p^ -> tmp1 (over f^), dp^/dy -> tmp2 ----
-        CombineArgs c{};
-        c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.hom = P->hom.p; c.cst = P->cst.p; c.lam = P->lam.p;
-        c.skip = P->d_skip; c.p_hat = tmp1; c.dp_hat = tmp2; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
-        {
-            ProfScope ps("k_nn_combine", st, (double)nm * n * (9 + 4) * 8.0);
-            hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
-        }
-        {   // the singular modes write other entries of tmp1/tmp2 than k_nn_combine (which skips them), but f^ (= tmp1) must
-            // have been consumed by the regular v-solve first: order the scatter after it through the main stream
-            hipc(hipEventRecord(P->ev_join, ss), "event record");
-            hipc(hipStreamWaitEvent(st, P->ev_join, 0), "stream wait");
-            dim3 g(ns, (n + 63) / 64), blk(64);
-            hipLaunchKernelGGL(k_sing_combine, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->s_u1.p, P->s_v1.p, P->s_du0.p, P->s_du1.p,
-                               P->d_sing, ns, n, nxh, ny, tmp1, tmp2);
-        }
-        hipc(hipGetLastError(), "poisson kernels");
-        // ---- backward transforms (:341-356) ----
-        if (P->use_2d) {
-            P->f2_bwd.exec(tmp1, p, st);
-            if (dpdy) P->f2_bwd.exec(tmp2, dpdy, st);
-        } else if (nz > 1) {
-            P->fz_b.exec(tmp1, P->cwork.p, st);
-            P->fx_c2r.exec(P->cwork.p, p, st);
-            if (dpdy) {
-                P->fz_b.exec(tmp2, P->cwork.p, st);
-                P->fx_c2r.exec(P->cwork.p, dpdy, st);
-            }
-        } else {
-            P->fx_c2r.exec(tmp1, p, st);
-            if (dpdy) P->fx_c2r.exec(tmp2, dpdy, st);
-        }
-        return TLAB_OK;
-    } catch (const std::invalid_argument &e) {
-        tlab_set_error(e.what());
-        return TLAB_EINVAL;
-    } catch (const std::exception &e) {
-        tlab_set_error(e.what());
-        return TLAB_EHIP;
+    POISSON_GUARD_BEGIN
+    if (!P || !p || !tmp1 || !tmp2 || !bcs_hb || !bcs_ht) throw std::invalid_argument("tlab_opr_poisson: null argument");
+    if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_poisson: sizes do not match the plan");
+    if (P->nproc != 1) throw std::invalid_argument("tlab_opr_poisson: plan is a z-slab plan; drive its stages with the transposes in between");
+    if (ibc != TLAB_BCS_NN) {
+        tlab_set_error("OPR_Poisson: only BCS_NN is built on the device (the RHS call, rhs_global_incompressible_1.f90:284)");
+        return TLAB_EUNSUPPORTED;
     }
+    if (p == tmp1 || p == tmp2 || tmp1 == tmp2 || dpdy == p || dpdy == tmp1 || dpdy == tmp2) throw std::invalid_argument("arrays must be distinct");
+    hipStream_t st = tlab_current_stream();
+    // BC planes into the forcing (opr_elliptic.f90:285-286)
+    hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, p, bcs_hb, bcs_ht, nx, ny, nz);
+    // forward transforms: p -> tmp2 -> tmp1 (:288-293); the scaling by norm (:295) is folded into the loads of the ODE stage
+    if (P->use_2d) {
+        P->f2_fwd.exec(p, tmp1, st);
+    } else if (nz > 1) {
+        P->fx_r2c.exec(p, tmp2, st);
+        P->fz_f.exec(tmp2, tmp1, st);
+    } else {
+        P->fx_r2c.exec(p, tmp1, st);
+    }
+    poisson_ode_stage(P, tmp1, tmp1, tmp2, st);      // p^ -> tmp1 (over f^), dp^/dy -> tmp2
+    // backward transforms (:341-356)
+    if (P->use_2d) {
+        P->f2_bwd.exec(tmp1, p, st);
+        if (dpdy) P->f2_bwd.exec(tmp2, dpdy, st);
+    } else if (nz > 1) {
+        P->fz_b.exec(tmp1, P->cwork.p, st);
+        P->fx_c2r.exec(P->cwork.p, p, st);
+        if (dpdy) {
+            P->fz_b.exec(tmp2, P->cwork.p, st);
+            P->fx_c2r.exec(P->cwork.p, dpdy, st);
+        }
+    } else {
+        P->fx_c2r.exec(tmp1, p, st);
+        if (dpdy) P->fx_c2r.exec(tmp2, dpdy, st);
+    }
+    POISSON_GUARD_END
+}
+
+// ---- stages, for the z-slab (multi-GPU) driver: the K-transposes of OPR_Fourier_Z_* (opr_fourier.f90:343-376) happen between them ----
+int tlab_poisson_set_wall_planes(tlab_poisson_plan_t P, double *p, const double *bcs_hb, const double *bcs_ht) {
+    POISSON_GUARD_BEGIN
+    if (!P || !p || !bcs_hb || !bcs_ht) throw std::invalid_argument("null argument");
+    hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)P->nx * P->nz + 255) / 256)), dim3(256), 0, tlab_current_stream(), p,
+                       bcs_hb, bcs_ht, P->nx, P->ny, P->nz);
+    POISSON_GUARD_END
+}
+// dir = +1: real (nx,ny,kmax) -> complex (nx/2+1,ny,kmax)  [OPR_Fourier_X_Forward]; dir = -1: the inverse [OPR_Fourier_X_Backward]
+int tlab_poisson_fft_x(tlab_poisson_plan_t P, int dir, double *in, double *out) {
+    POISSON_GUARD_BEGIN
+    if (!P || !in || !out || in == out) throw std::invalid_argument("tlab_poisson_fft_x: bad arguments");
+    if (dir > 0) P->fx_r2c.exec(in, out, tlab_current_stream());
+    else P->fx_c2r.exec(in, out, tlab_current_stream());
+    POISSON_GUARD_END
+}
+// complex (nlines, nz_total) lines-fastest (the K-transposed layout; nlines = (nx/2+1)*ny/nproc_k), out of place
+int tlab_poisson_fft_z(tlab_poisson_plan_t P, int dir, double *in, double *out) {
+    POISSON_GUARD_BEGIN
+    if (!P || !in || !out || in == out) throw std::invalid_argument("tlab_poisson_fft_z: bad arguments");
+    if (P->nzt <= 1) throw std::invalid_argument("tlab_poisson_fft_z: no z direction");
+    if (dir > 0) P->fz_f.exec(in, out, tlab_current_stream());
+    else P->fz_b.exec(in, out, tlab_current_stream());
+    POISSON_GUARD_END
+}
+// per-mode ODE solves on the local (kx, kz) modes: f_hat -> p_hat (may alias f_hat), dp_hat
+int tlab_poisson_ode(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat) {
+    POISSON_GUARD_BEGIN
+    if (!P || !f_hat || !p_hat || !dp_hat || dp_hat == f_hat || dp_hat == p_hat) throw std::invalid_argument("tlab_poisson_ode: bad arguments");
+    poisson_ode_stage(P, f_hat, p_hat, dp_hat, tlab_current_stream());
+    POISSON_GUARD_END
 }
 
 }  // extern "C"

@@ -131,6 +131,25 @@ int tlab_rhs_global_incompressible_1(tlab_dns_t d, double dte, double *const *q,
     }
 }
 
+// ---- the pointwise pieces on their own, for drivers that interleave communication (z-slab decomposition) ----
+#define PW_GUARD(expr)                                          \
+    try {                                                       \
+        if (!tlab_device_ready()) throw Fail(TLAB_EHIP, "tlab_init has not been called"); \
+        hk((expr), "pointwise kernel");                         \
+        return TLAB_OK;                                         \
+    } catch (const Fail &f) {                                   \
+        tlab_set_error(f.what());                               \
+        return f.code;                                          \
+    }
+int tlab_pw_add3(double *h, const double *a, const double *b, const double *c, long long n) { PW_GUARD(launch_add3(h, a, b, c, n, tlab_current_stream())) }
+int tlab_pw_axpy3(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1, const double *q2,
+                  const double *q3, double s, long long n) { PW_GUARD(launch_axpy3(o1, o2, o3, h1, h2, h3, q1, q2, q3, s, n, tlab_current_stream())) }
+int tlab_pw_sum3(double *a, const double *b, const double *c, long long n) { PW_GUARD(launch_sum3(a, b, c, n, tlab_current_stream())) }
+int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n) { PW_GUARD(launch_sub3(h1, h2, h3, a, b, c, n, tlab_current_stream())) }
+int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n) { PW_GUARD(launch_rk_update(q, h, dte, kco, scale, n, tlab_current_stream())) }
+int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz) { PW_GUARD(launch_get_wall_planes(f, hb, ht, nx, ny, nz, tlab_current_stream())) }
+int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz) { PW_GUARD(launch_fill_wall_planes(f, vb, vt, nx, ny, nz, tlab_current_stream())) }
+
 int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double kco, int scale_tendencies, double *const *q,
                                               double *const *s, double *const *hq, double *const *hs, double *const *txc) {
     int rc = tlab_rhs_global_incompressible_1(d, dte, q, s, hq, hs, txc);

@@ -38,6 +38,18 @@ SIGNATURES = {
     "tlab_poisson_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int]),
     "tlab_poisson_plan_destroy": (c_int, [c_vp]),
     "tlab_opr_poisson": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tlab_poisson_plan_create_slab": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "tlab_poisson_set_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "tlab_poisson_fft_x": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "tlab_poisson_fft_z": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "tlab_poisson_ode": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "tlab_pw_add3": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_longlong]),
+    "tlab_pw_axpy3": (c_int, [c_vp] * 9 + [c_dbl, ctypes.c_longlong]),
+    "tlab_pw_sum3": (c_int, [c_vp, c_vp, c_vp, ctypes.c_longlong]),
+    "tlab_pw_sub3": (c_int, [c_vp] * 6 + [ctypes.c_longlong]),
+    "tlab_pw_rk_update": (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, ctypes.c_longlong]),
+    "tlab_pw_get_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int]),
+    "tlab_pw_fill_wall_planes": (c_int, [c_vp, c_dbl, c_dbl, c_int, c_int, c_int]),
     "tlab_dns_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, _dp]),
     "tlab_dns_destroy": (c_int, [c_vp]),
     "tlab_rhs_global_incompressible_1": (c_int, [c_vp, c_dbl, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
