@@ -25,23 +25,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def synthetic_fields(d, seed):
-    """smooth modes + 0.1 * uniform(-1,1) noise from a fixed-seed generator, generated on the device."""
+def synthetic_fields(targets, nx, ny, nz_total, k0, kmax, seed):
+    """smooth modes + 0.1 * uniform(-1,1) noise from a fixed-seed generator, generated on the device.
+    targets: the 3 velocity + ns scalar tensors of the planes [k0, k0+kmax) of the global box."""
     import torch
-    nx, ny, nz = d.nx, d.ny, d.nz
     gen = torch.Generator(device="cuda")
     gen.manual_seed(20250509 + seed)
     x = torch.arange(nx, dtype=torch.float64, device="cuda").view(1, 1, nx) / nx
     y = torch.arange(ny, dtype=torch.float64, device="cuda").view(1, ny, 1) / (ny - 1)
-    z = torch.arange(nz, dtype=torch.float64, device="cuda").view(nz, 1, 1) / nz
+    z = (k0 + torch.arange(kmax, dtype=torch.float64, device="cuda")).view(kmax, 1, 1) / nz_total
     two_pi = 2.0 * np.pi
     wall = torch.sin(np.pi * y)
     shapes = [torch.sin(two_pi * x) * torch.cos(2 * two_pi * y) * torch.sin(3 * two_pi * z),
               torch.cos(two_pi * x) * torch.sin(two_pi * y) * torch.sin(2 * two_pi * z),
               torch.sin(2 * two_pi * x) * torch.cos(two_pi * y) * torch.cos(two_pi * z),
               torch.cos(3 * two_pi * x) * torch.cos(two_pi * y) * torch.sin(two_pi * z)]
-    for t, sh in zip(d.q + d.s, shapes):
-        t.copy_(((sh + 0.1 * (2.0 * torch.rand(nz, ny, nx, dtype=torch.float64, device="cuda", generator=gen) - 1.0)) * wall).reshape(-1))
+    for t, sh in zip(targets, shapes):
+        t.copy_(((sh + 0.1 * (2.0 * torch.rand(kmax, ny, nx, dtype=torch.float64, device="cuda", generator=gen) - 1.0)) * wall).reshape(-1))
 
 
 def cpu_baseline(n, nscal):
@@ -67,8 +67,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="box size n^3 per GPU (BASELINE: 512)")
+    ap.add_argument("--n", type=int, default=512, help="box size n^3 (BASELINE: 512), split into z-slabs over the GPUs")
     ap.add_argument("--nscal", type=int, default=1)
+    ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
+                    "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
     ap.add_argument("--cpu-sample", type=int, default=192, help="n of the n^3 CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
@@ -90,18 +92,43 @@ def main():
     n = args.n
     x = np.arange(n) / n
     y = np.arange(n) / (n - 1.0)
-    d = Dns(x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
-    synthetic_fields(d, rank)
     dtime = 1e-3
     L = load()
+    if world == 1 and args.loopback > 1:
+        from tlab_amd.parallel import SlabDns, LoopbackComm
+        d = SlabDns(LoopbackComm(args.loopback), x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True,
+                    rkm_mode=RKM_EXP3)
+        state_fields = []
+        for r in range(args.loopback):
+            S = d.st[r]
+            synthetic_fields(S["q"] + S["s"], n, n, n, r * d.kmax, d.kmax, r)
+            state_fields += S["q"] + S["s"]
 
-    def substep(k):
-        s = k % d.rkm_endstep
-        if s == 0:
-            for t in d.hq + d.hs:
-                t.zero_()
-        last = s == d.rkm_endstep - 1
-        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * d.kdt[s], 1.0 if last else d.kco[s], not last)
+        def substep(k):
+            d.substep_of_cycle(k, dtime)
+    elif world == 1:
+        # one GPU owns the whole box: the C++ driver (tlab_amd/csrc/rhs.cpp) runs the substep
+        d = Dns(x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
+        synthetic_fields(d.q + d.s, n, n, n, 0, n, rank)
+        state_fields = d.q + d.s
+
+        def substep(k):
+            s = k % d.rkm_endstep
+            if s == 0:
+                for t in d.hq + d.hs:
+                    t.zero_()
+            last = s == d.rkm_endstep - 1
+            d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * d.kdt[s], 1.0 if last else d.kco[s], not last)
+    else:
+        # STRONG scaling of the same n^3 box: z-slabs (1 x N pencils), K-transposes by RCCL all-to-all (tlab_amd/parallel.py)
+        from tlab_amd.parallel import SlabDns, DistComm
+        d = SlabDns(DistComm(), x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
+        S = d.st[rank]
+        synthetic_fields(S["q"] + S["s"], n, n, n, rank * d.kmax, d.kmax, rank)
+        state_fields = S["q"] + S["s"]
+
+        def substep(k):
+            d.substep_of_cycle(k, dtime)
 
     for k in range(args.warmup):
         substep(k)
@@ -122,7 +149,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    finite = all(bool(torch.isfinite(t).all()) for t in d.q + d.s)
+    finite = all(bool(torch.isfinite(t).all()) for t in state_fields)
 
     if rank == 0:
         import ctypes
@@ -148,7 +175,7 @@ def main():
                 traffic = json.load(open(tpath)).get(dom["kernel"])
             except Exception:
                 traffic = None
-        npts = float(n) ** 3 * world
+        npts = float(n) ** 3            # strong scaling: the same box on 1/2/4/8 GPUs (BASELINE.json metric)
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "grid-point-updates/s per RK substep",
@@ -159,14 +186,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%d^3 incompressible box per GPU, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
+            "config": {"workload": "%d^3 incompressible box, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
                                    % (n, args.nscal),
                        "grid": [n, n, n], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper", "reynolds": 5000,
-                       "parallelism": "single GPU" if world == 1 else "replicas (one box per GPU; pencil transposes not built yet)",
+                       "parallelism": ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks executed back to back on one GPU, no communication" % args.loopback) if world == 1 else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world,
                        "fields_finite": finite},
             "roofline": None if dom is None else {
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

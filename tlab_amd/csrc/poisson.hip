@@ -171,64 +171,74 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) y1[l] = y2[l] = 0.0;
     const int nmax = n - 2;
-    for (int j = 1; j <= nmax; ++j) {
-        double fq[NL];                        // f[j+2] prefetch -> becomes fp next iteration
-        if (j + 2 <= n - 1) load_f<NL, FS>(a, j + 2, t, fidx0, fq);
-        else {
+    constexpr int U = 8;   // rows per block: the loads of a block are issued together so that only one memory latency is exposed per U rows
+    for (int jb = 1; jb <= nmax; jb += U) {
+        double fqb[U][NL];                    // f[jb+2 .. jb+U+1]
 #pragma unroll
-            for (int l = 0; l < NL; ++l) fq[l] = 0.0;
-        }
-        double r[5];
-        if (j == 1) { for (int k = 0; k < 5; ++k) r[k] = l1[k]; }
-        else if (j == 2) { for (int k = 0; k < 5; ++k) r[k] = l2[k]; }
-        else if (j == n - 3) { for (int k = 0; k < 5; ++k) r[k] = lN2[k]; }
-        else if (j == n - 2) { for (int k = 0; k < 5; ++k) r[k] = lN1[k]; }
-        else lhs_row(a.T, j, lam, r);
-        // right-hand side of row j
-        double rhs[NL];
+        for (int u = 0; u < U; ++u) {
+            const int jr = jb + u + 2;
+            if (jr <= n - 1) load_f<NL, FS>(a, jr, t, fidx0, fqb[u]);
+            else {
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            if (j == 1) rhs[l] = res0[l] * rb[1][1] + fc[l] * rb[1][2] + fp[l] * rb[1][3];
-            else if (j == 2) rhs[l] = res0[l] * rb[2][0] + fm[l] * rb[2][1] + fc[l] * rb[2][2] + fp[l] * rb[2][3];
-            else if (j == n - 3) rhs[l] = fm[l] * rt[0][0] + fc[l] * rt[0][1] + fp[l] * rt[0][2] + resN[l] * rt[0][3];
-            else if (j == n - 2) rhs[l] = fm[l] * rt[1][0] + fc[l] * rt[1][1] + resN[l] * rt[1][2];
-            else rhs[l] = fm[l] * a.T.R[j * 3 + 0] + fc[l] * a.T.R[j * 3 + 1] + fp[l];
-        }
-        if (j == n - 2) {
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                fn2[l] = fc[l];
-                bcs_t[l] = fm[l] * rt[2][2] + fc[l] * rt[2][0] + resN[l] * rt[2][1];
+                for (int l = 0; l < NL; ++l) fqb[u][l] = 0.0;
             }
         }
-        // PENTADFS row m = j
-        double am = 0.0, bm = 0.0, cm = r[2], dm = r[3], em = r[4];
-        if (j == 2) {
-            bm = r[1] / c1;
-            cm = r[2] - bm * d1;
-            dm = r[3] - bm * e1;
-        } else if (j >= 3) {
-            am = r[0] / c2;
-            bm = (r[1] - am * d2) / c1;
-            cm = r[2] - bm * d1 - am * e2;
-            dm = r[3] - bm * e1;
-        }
-        const double cinv = 1.0 / cm;
-        // PENTADSS forward: f(n) = f(n) + f(n-1)*b(n) + f(n-2)*a(n) with a, b negated
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const double y = rhs[l] - y1[l] * bm - y2[l] * am;
-            a.scratch[((long long)l * n + j) * nm + t] = y;
-            y2[l] = y1[l];
-            y1[l] = y;
-        }
-        a.scratch[((long long)(NL + 0) * n + j) * nm + t] = cinv;
-        a.scratch[((long long)(NL + 1) * n + j) * nm + t] = -dm;
-        a.scratch[((long long)(NL + 2) * n + j) * nm + t] = -em;
-        c2 = c1; d2 = d1; e2 = e1;
-        c1 = cm; d1 = dm; e1 = em;
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u;
+            if (j > nmax) break;
+            double r[5];
+            if (j == 1) { for (int k = 0; k < 5; ++k) r[k] = l1[k]; }
+            else if (j == 2) { for (int k = 0; k < 5; ++k) r[k] = l2[k]; }
+            else if (j == n - 3) { for (int k = 0; k < 5; ++k) r[k] = lN2[k]; }
+            else if (j == n - 2) { for (int k = 0; k < 5; ++k) r[k] = lN1[k]; }
+            else lhs_row(a.T, j, lam, r);
+            // right-hand side of row j
+            double rhs[NL];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) { fm[l] = fc[l]; fc[l] = fp[l]; fp[l] = fq[l]; }
+            for (int l = 0; l < NL; ++l) {
+                if (j == 1) rhs[l] = res0[l] * rb[1][1] + fc[l] * rb[1][2] + fp[l] * rb[1][3];
+                else if (j == 2) rhs[l] = res0[l] * rb[2][0] + fm[l] * rb[2][1] + fc[l] * rb[2][2] + fp[l] * rb[2][3];
+                else if (j == n - 3) rhs[l] = fm[l] * rt[0][0] + fc[l] * rt[0][1] + fp[l] * rt[0][2] + resN[l] * rt[0][3];
+                else if (j == n - 2) rhs[l] = fm[l] * rt[1][0] + fc[l] * rt[1][1] + resN[l] * rt[1][2];
+                else rhs[l] = fm[l] * a.T.R[j * 3 + 0] + fc[l] * a.T.R[j * 3 + 1] + fp[l];
+            }
+            if (j == n - 2) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    fn2[l] = fc[l];
+                    bcs_t[l] = fm[l] * rt[2][2] + fc[l] * rt[2][0] + resN[l] * rt[2][1];
+                }
+            }
+            // PENTADFS row m = j
+            double am = 0.0, bm = 0.0, cm = r[2], dm = r[3], em = r[4];
+            if (j == 2) {
+                bm = r[1] / c1;
+                cm = r[2] - bm * d1;
+                dm = r[3] - bm * e1;
+            } else if (j >= 3) {
+                am = r[0] / c2;
+                bm = (r[1] - am * d2) / c1;
+                cm = r[2] - bm * d1 - am * e2;
+                dm = r[3] - bm * e1;
+            }
+            const double cinv = 1.0 / cm;
+            // PENTADSS forward: f(n) = f(n) + f(n-1)*b(n) + f(n-2)*a(n) with a, b negated
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const double y = rhs[l] - y1[l] * bm - y2[l] * am;
+                a.scratch[((long long)l * n + j) * nm + t] = y;
+                y2[l] = y1[l];
+                y1[l] = y;
+            }
+            a.scratch[((long long)(NL + 0) * n + j) * nm + t] = cinv;
+            a.scratch[((long long)(NL + 1) * n + j) * nm + t] = -dm;
+            a.scratch[((long long)(NL + 2) * n + j) * nm + t] = -em;
+            c2 = c1; d2 = d1; e2 = e1;
+            c1 = cm; d1 = dm; e1 = em;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) { fm[l] = fc[l]; fc[l] = fp[l]; fp[l] = fqb[u][l]; }
+        }
     }
 
     // ---- backward substitution ----
@@ -237,23 +247,35 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     double xe2[NL], xe3[NL], xe4[NL];         // x[n-2], x[n-3], x[n-4]
 #pragma unroll
     for (int l = 0; l < NL; ++l) x1[l] = x2[l] = xs1[l] = xs2[l] = xs3[l] = xe2[l] = xe3[l] = xe4[l] = 0.0;
-    for (int j = nmax; j >= 1; --j) {
-        const double cinv = a.scratch[((long long)(NL + 0) * n + j) * nm + t];
-        const double dneg = a.scratch[((long long)(NL + 1) * n + j) * nm + t];
-        const double eneg = a.scratch[((long long)(NL + 2) * n + j) * nm + t];
+    for (int jb = nmax; jb >= 1; jb -= U) {
+        double yb[U][NL], cb[U], db[U], eb[U];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const double y = a.scratch[((long long)l * n + j) * nm + t];
-            const double x = (y + x1[l] * dneg + x2[l] * eneg) * cinv;
-            a.dst[((long long)l * n + j) * nm + t] = x;
-            x2[l] = x1[l];
-            x1[l] = x;
-            if (j == 1) xs1[l] = x;
-            if (j == 2) xs2[l] = x;
-            if (j == 3) xs3[l] = x;
-            if (j == n - 2) xe2[l] = x;
-            if (j == n - 3) xe3[l] = x;
-            if (j == n - 4) xe4[l] = x;
+        for (int u = 0; u < U; ++u) {
+            const int j = jb - u;
+            const int jr = j >= 1 ? j : 1;
+            cb[u] = a.scratch[((long long)(NL + 0) * n + jr) * nm + t];
+            db[u] = a.scratch[((long long)(NL + 1) * n + jr) * nm + t];
+            eb[u] = a.scratch[((long long)(NL + 2) * n + jr) * nm + t];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) yb[u][l] = a.scratch[((long long)l * n + jr) * nm + t];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb - u;
+            if (j < 1) break;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const double x = (yb[u][l] + x1[l] * db[u] + x2[l] * eb[u]) * cb[u];
+                a.dst[((long long)l * n + j) * nm + t] = x;
+                x2[l] = x1[l];
+                x1[l] = x;
+                if (j == 1) xs1[l] = x;
+                if (j == 2) xs2[l] = x;
+                if (j == 3) xs3[l] = x;
+                if (j == n - 2) xe2[l] = x;
+                if (j == n - 3) xe3[l] = x;
+                if (j == n - 4) xe4[l] = x;
+            }
         }
     }
 
