@@ -153,6 +153,9 @@ typedef struct tlab_dns *tlab_dns_t;
 int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                     tlab_poisson_plan_t poisson, int nx, int ny, int nz, int nscal, double visc, const double *schmidt);
 int tlab_dns_destroy(tlab_dns_t d);
+/* on (default): the pointwise sums of the RHS are folded into the operator kernels (same summation order as the reference);
+ * off: the reference's literal sequence of temporaries + pointwise loops.  Both give the same result to round-off. */
+int tlab_dns_set_fusion(tlab_dns_t d, int on);
 
 /* RHS_GLOBAL_INCOMPRESSIBLE_1()   tools/dns/rhs_global_incompressible_1.f90:15-405 (argument-less in the reference:
  * it works on the module arrays q, s, hq, hs, txc and on dte).  q[3] = u,v,w; s[nscal]; hq[3], hs[nscal] are

@@ -35,8 +35,9 @@ def init_fields(nx, ny, nz, x, y, z, seed):
     return [a.ravel() for a in (u, v, w)], [s.ravel()]
 
 
-@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (64, 32, 32, False)])
-def test_substep_vs_oracle(T, nx, ny, nz, stretch):
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (64, 32, 32, False), (256, 64, 64, True)])
+def test_substep_vs_oracle(T, nx, ny, nz, stretch, fuse):
     import torch
     from tlab_amd.dns import Dns
     from oracle.tlab_oracle_rhs import DnsOracle
@@ -45,6 +46,7 @@ def test_substep_vs_oracle(T, nx, ny, nz, stretch):
     q0, s0 = init_fields(nx, ny, nz, x, y, z, 3)
     d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch)
     o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch)
+    d.set_fusion(fuse)
     for i in range(3):
         d.q[i].copy_(torch.from_numpy(q0[i])); o.q[i] = q0[i].copy()
     d.s[0].copy_(torch.from_numpy(s0[0])); o.s[0] = s0[0].copy()

@@ -421,6 +421,14 @@ LineGeom make_geom(int dir, int nx, int ny, int nz) {
 
 enum { PATH_GENERIC = 1, PATH_XLINE = 2, PATH_RTILE = 3 };
 
+// fusions used by the RHS driver (rhs.cpp): operand = in0 + scale*in0b (P1), result accumulated into the output (P1, Burgers)
+struct OpExtra {
+    const double *in0b = nullptr;
+    double scale = 0.0;
+    bool acc = false;
+};
+const OpExtra kNoExtra{};
+
 int choose_path(int dir, int n) {
     int path = PATH_GENERIC;
     if (dir == 1 && xline_supported(n)) path = PATH_XLINE;
@@ -441,10 +449,11 @@ void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, co
 }
 
 void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *in1,
-               const double *in2, double *out, double nu) {
+               const double *in2, double *out, double nu, const OpExtra &ex = kNoExtra) {
     const int P = geom.n / rtile_chunk(geom.n);
     RTileArgs a;
     a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.out1 = nullptr; a.g = geom; a.nu = nu;
+    a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     a.y1 = g->system(1, ibc, P).dev();
@@ -458,10 +467,11 @@ int g_htile_policy = 0;   // 0 automatic, 1 never (two-launch k_rtile path), 2 a
 bool htile_ok(int n, int mode) { return g_htile_policy != 1 && htile_chunk(n, mode) > 0; }
 
 void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *vel, double *out0,
-               double *out1, double nu) {
+               double *out1, double nu, const OpExtra &ex = kNoExtra) {
     const int C = geom.n / htile_chunk(geom.n, mode);
     RTileArgs a;
     a.in0 = in0; a.in1 = nullptr; a.in2 = vel; a.out0 = out0; a.out1 = out1; a.g = geom; a.nu = nu;
+    a.in0b = nullptr; a.in0b_scale = 0.0; a.acc = ex.acc ? 1 : 0;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     a.y1 = g->system(1, ibc, C).dev();
@@ -471,9 +481,10 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
 }
 
 void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *in1,
-               double *out0, double *out1, double nu) {
+               double *out0, double *out1, double nu, const OpExtra &ex = kNoExtra) {
     XLineArgs a;
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1; a.nlines = geom.nlines; a.nu = nu;
+    a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     SystemEntry &e1 = g->system(1, ibc, 64), &e2 = g->system(2, 0, 64);
@@ -497,6 +508,53 @@ void check_common(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc) {
 }
 
 }  // namespace
+
+// ---- internal fused variants for the RHS driver; return false when the sizes are not on a fused fast path ----
+// result (+)= d/dx_dir (u + scale*ub)
+bool tlab_internal_partial_p1_fusable(int dir, int nx, int ny, int nz) {
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (geom.n == 1) return false;
+    const int path = choose_path(dir, geom.n);
+    return path == PATH_XLINE || (path == PATH_RTILE && rtile_chunk(geom.n) > 0);
+}
+bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub,
+                                    double scale, double *result, bool acc) {
+    check_common(dir, g, nx, ny, nz, ibc);
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (geom.n == 1) return false;
+    OpExtra ex;
+    ex.in0b = ub; ex.scale = scale; ex.acc = acc;
+    const int path = choose_path(dir, geom.n);
+    if (path == PATH_XLINE) {
+        run_xline(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0, ex);
+    } else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) {
+        run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0, ex);
+    } else {
+        return false;
+    }
+    g_last_path = path;
+    return true;
+}
+// result += nu d2s - vel ds   (only when the fully fused Burgers kernels apply)
+bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
+                               double *result) {
+    check_common(dir, g, nx, ny, nz, ibc);
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (geom.n == 1) return false;
+    OpExtra ex;
+    ex.acc = true;
+    const bool corr = g->t.der2.need_1der;
+    const int path = choose_path(dir, geom.n);
+    if (path == PATH_XLINE && !corr) {
+        run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu, ex);
+    } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {
+        run_htile(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu, ex);
+    } else {
+        return false;
+    }
+    g_last_path = path;
+    return true;
+}
 
 extern "C" {
 

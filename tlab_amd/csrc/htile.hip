@@ -198,10 +198,15 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
         }
     } else {  // MODE_BURGERS: result = nu d2 - vel d1 (opr_burgers.f90:513)
 #pragma unroll
-        for (int p = 0; p < M; ++p) {
-            const long long idx = base + (long long)(row0 + p) * rs;
-            a.out0[idx] = a.nu * x2[p] - vl[p] * x1[p];
+        for (int p = 0; p < M; ++p) x2[p] = a.nu * x2[p] - vl[p] * x1[p];
+        if (a.acc) {   // accumulate into the tendency: all loads first (the compiler cannot move them across the stores itself)
+#pragma unroll
+            for (int p = 0; p < M; ++p) x1[p] = a.out0[base + (long long)(row0 + p) * rs];
+#pragma unroll
+            for (int p = 0; p < M; ++p) x2[p] = x1[p] + x2[p];
         }
+#pragma unroll
+        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x2[p];
     }
 }
 
@@ -227,7 +232,7 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
     const double pts = (double)a.g.nlines * a.g.n;
     const char *name = mode == MODE_P1 ? "k_htile<P1>" : mode == MODE_P2 ? "k_htile<P2>" : mode == MODE_P2_P1 ? "k_htile<P2_P1>" : "k_htile<BURGERS>";
     const double bpp = (mode == MODE_P1 || mode == MODE_P2) ? 16 : 24;
-    ProfScope ps(name, st, pts * bpp);
+    ProfScope ps(name, st, pts * (bpp + (a.acc ? 8 : 0)));
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT>), grid, block, lds, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_htile<M, MODE_P2, MAXT>), grid, block, lds, st, a); break;

@@ -175,6 +175,12 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
         const long long off = line * n + lane * M;
         double u[M];
         xload<M>(u, a.in0 + off);
+        if (MODE == MODE_P1 && a.in0b != nullptr) {   // operand = in0 + s * in0b
+            double ub[M];
+            xload<M>(ub, a.in0b + off);
+#pragma unroll
+            for (int p = 0; p < M; ++p) u[p] = u[p] + ub[p] * a.in0b_scale;
+        }
         double um[3], up[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -191,6 +197,12 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             xsolve<M, LV>(x2, y2, lane, n);
         }
         if (MODE == MODE_P1) {
+            if (a.acc) {
+                double o[M];
+                xload<M>(o, a.out0 + off);
+#pragma unroll
+                for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+            }
             xstore<M>(a.out0 + off, x1);
         } else if (MODE == MODE_P2) {
             xstore<M>(a.out0 + off, x2);
@@ -202,6 +214,12 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             xload<M>(v, a.in1 + off);
 #pragma unroll
             for (int p = 0; p < M; ++p) x2[p] = a.nu * x2[p] - v[p] * x1[p];
+            if (a.acc) {
+                double o[M];
+                xload<M>(o, a.out0 + off);
+#pragma unroll
+                for (int p = 0; p < M; ++p) x2[p] = o[p] + x2[p];
+            }
             xstore<M>(a.out0 + off, x2);
         }
     }
@@ -244,6 +262,20 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
         if (rr >= n) rr -= n;
         e[k] = (valid && okl) ? a.in0[base + (long long)rl * rs] : 0.0;
         e[M + 3 + k] = (valid && okr) ? a.in0[base + (long long)rr * rs] : 0.0;
+    }
+    if (MODE == MODE_P1 && a.in0b != nullptr) {   // operand = in0 + s * in0b (same rows, same halos)
+#pragma unroll
+        for (int p = 0; p < M; ++p)
+            if (valid) e[p + 3] = e[p + 3] + a.in0b[base + (long long)(row0 + p) * rs] * a.in0b_scale;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int rl = row0 - 3 + k, rr = row0 + M + k;
+            const bool okl = per || rl >= 0, okr = per || rr < n;
+            if (rl < 0) rl += n;
+            if (rr >= n) rr -= n;
+            if (valid && okl) e[k] = e[k] + a.in0b[base + (long long)rl * rs] * a.in0b_scale;
+            if (valid && okr) e[M + 3 + k] = e[M + 3 + k] + a.in0b[base + (long long)rr * rs] * a.in0b_scale;
+        }
     }
 
     // ---- right-hand side ----
@@ -333,6 +365,13 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
             if (valid) a.out0[idx] = a.nu * f[p] - a.in2[idx] * a.in1[idx];
         }
     } else {
+        if (MODE == MODE_P1 && a.acc && valid) {   // all loads first: the compiler cannot move them across the stores itself
+            double o[M];
+#pragma unroll
+            for (int p = 0; p < M; ++p) o[p] = a.out0[base + (long long)(row0 + p) * rs];
+#pragma unroll
+            for (int p = 0; p < M; ++p) f[p] = o[p] + f[p];
+        }
 #pragma unroll
         for (int p = 0; p < M; ++p)
             if (valid) a.out0[base + (long long)(row0 + p) * rs] = f[p];
@@ -451,7 +490,7 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
-    ProfScope ps(names[mode], st, pts * bpp[mode]);
+    ProfScope ps(names[mode], st, pts * (bpp[mode] + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0)));
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV>), dim3(grid), dim3(256), lds, st, a); break;
@@ -496,7 +535,7 @@ static hipError_t launch_rtile_m(int mode, int P, long long tiles, const RTileAr
     const double pts = (double)a.g.nlines * a.g.n;
     const char *name = mode == MODE_P1 ? "k_rtile<P1>" : mode == MODE_P2 ? "k_rtile<P2>" : mode == MODE_P2_D1IN ? "k_rtile<P2_D1IN>" : "k_rtile<BURGERS_D1IN>";
     const double bpp = mode == MODE_P1 || mode == MODE_P2 ? 16 : mode == MODE_P2_D1IN ? 24 : 32;   // operand reads + writes of this launch
-    ProfScope ps(name, st, pts * bpp);
+    ProfScope ps(name, st, pts * (bpp + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0)));
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_rtile<M, MODE_P1, MAXT>), grid, block, 0, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_rtile<M, MODE_P2, MAXT>), grid, block, 0, st, a); break;

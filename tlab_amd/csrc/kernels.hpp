@@ -10,6 +10,9 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     const double *in0;      // field (u or s)
     const double *in1;      // advecting velocity (MODE_BURGERS)
     double *out0, *out1;
+    const double *in0b;     // optional: operand = in0 + in0b_scale * in0b   (tmp = hq + q/dte fused into the divergence, P1 only)
+    double in0b_scale;
+    int acc;                // 1: out0 += value instead of out0 = value (MODE_P1, MODE_BURGERS)
     long long nlines;
     StencilDev s1, s2;      // first / second derivative RHS operators
     SystemDev y1, y2;       // first / second derivative chunked systems (P = 64)
@@ -22,6 +25,9 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     const double *in2;      // advecting velocity (MODE_BURGERS_D1IN)
     double *out0;
     double *out1;           // first derivative (MODE_P2_P1 of k_htile)
+    const double *in0b;     // optional second operand term: operand = in0 + in0b_scale * in0b (k_rtile MODE_P1)
+    double in0b_scale;
+    int acc;                // 1: out0 += value (k_rtile MODE_P1, k_htile MODE_BURGERS)
     LineGeom g;
     StencilDev s1, s2;
     SystemDev y1, y2;       // chunked with P = n / rtile_chunk(n)  (k_htile: n / htile_chunk(n, mode))
@@ -60,5 +66,6 @@ hipError_t launch_sub3(double *h1, double *h2, double *h3, const double *a, cons
 hipError_t launch_rk_update(double *q, double *h, double dte, double kco, int scale, long long n, hipStream_t st);
 hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz, hipStream_t st);
 hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_final_update(double *q, double *h, const double *g, double dte, double kco, int scale, int nx, int ny, int nz, hipStream_t st);
 
 }  // namespace tlab

@@ -107,7 +107,28 @@ __global__ void __launch_bounds__(256) k_fill_wall_planes(double *__restrict__ f
     f[ix + (long long)nx * ((ny - 1) + (long long)ny * k)] = vt;
 }
 
+// fused tail of the substep for one velocity component (rhs_global_incompressible_1.f90:348-352, :373-375; time.f90:645-664, :272-297):
+//   h = h - g (pressure gradient); h = 0 on the wall planes j = 1, ny; q = q + dte*h; h = kco*h (if scale)
+__global__ void __launch_bounds__(256) k_final_update(double *__restrict__ q, double *__restrict__ h, const double *__restrict__ g, double dte,
+                                                      double kco, int scale, int nx, int ny, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int j = (int)((i / nx) % ny);
+        double hv = g ? h[i] - g[i] : h[i];
+        if (j == 0 || j == ny - 1) hv = 0.0;
+        q[i] = q[i] + dte * hv;
+        h[i] = scale ? kco * hv : hv;
+    }
+}
+
 #define CHECK_LAUNCH() hipGetLastError()
+
+hipError_t launch_final_update(double *q, double *h, const double *g, double dte, double kco, int scale, int nx, int ny, int nz, hipStream_t st) {
+    const long long n = (long long)nx * ny * nz;
+    ProfScope ps("k_final_update", st, (double)n * (g ? 40 : 32));
+    hipLaunchKernelGGL(k_final_update, dim3(pw_grid(n)), dim3(256), 0, st, q, h, g, dte, kco, scale, nx, ny, n);
+    return CHECK_LAUNCH();
+}
 
 hipError_t launch_add3(double *h, const double *a, const double *b, const double *c, long long n, hipStream_t st) {
     ProfScope ps("k_add3", st, (double)n * 40);

@@ -84,7 +84,7 @@ __device__ __forceinline__ void load_f(const Int1Args &a, int j, long long t, lo
 }
 
 // One FDM_Int1_Solve per thread (mode).  BC = 1: value given at the bottom (BCS_MIN), BC = 2: at the top (BCS_MAX).
-template <int BC, int NL, int FS>
+template <int BC, int NL, int FS, int U>
 __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.nm) return;
@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) y1[l] = y2[l] = 0.0;
     const int nmax = n - 2;
-    constexpr int U = 8;   // rows per block: the loads of a block are issued together so that only one memory latency is exposed per U rows
+    // U = rows per block: the loads of a block are issued together so that only one memory latency is exposed per U rows.  Large U
+    // pays on small slabs (few modes -> few waves -> latency-bound), small U keeps the registers down when the grid fills the chip.
     for (int jb = 1; jb <= nmax; jb += U) {
         double fqb[U][NL];                    // f[jb+2 .. jb+U+1]
 #pragma unroll
@@ -538,7 +539,8 @@ void launch_int1(const Int1Args &a, hipStream_t st) {
     const bool few = a.nm <= 8;   // the <= 4 singular modes, solved beside the regular ones on the side stream
     ProfScope ps(few ? "k_int1<singular modes>" : (FS == FS_FIELD ? "k_int1<field>" : (FS == FS_LINEAR ? "k_int1<linear>" : "k_int1<unit>")), st,
                  (double)a.nm * a.T.n * 16.0 * NL);
-    hipLaunchKernelGGL((k_int1<BC, NL, FS>), dim3(grid), dim3(256), 0, st, a);
+    if (a.nm < 65536) hipLaunchKernelGGL((k_int1<BC, NL, FS, 8>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_int1<BC, NL, FS, 2>), dim3(grid), dim3(256), 0, st, a);
     hipc(hipGetLastError(), "k_int1");
 }
 

@@ -19,6 +19,11 @@ using namespace tlab;
 extern hipStream_t tlab_current_stream();
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
+bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub,
+                                    double scale, double *result, bool acc);
+bool tlab_internal_partial_p1_fusable(int dir, int nx, int ny, int nz);
+bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
+                               double *result);
 
 struct tlab_dns {
     tlab_fdm_plan_t g[3];
@@ -27,6 +32,7 @@ struct tlab_dns {
     double visc;
     std::vector<double> schmidt;
     double *bcs_hb = nullptr, *bcs_ht = nullptr;   // BcsFlowJmin%ref(:,:,2), BcsFlowJmax%ref(:,:,2)
+    bool fuse = true;                              // fold the pointwise sums into the operator kernels where the fast kernels apply
     ~tlab_dns() {
         if (bcs_hb) (void)hipFree(bcs_hb);
         if (bcs_ht) (void)hipFree(bcs_ht);
@@ -74,61 +80,124 @@ int tlab_dns_destroy(tlab_dns_t d) {
     return TLAB_OK;
 }
 
-int tlab_rhs_global_incompressible_1(tlab_dns_t d, double dte, double *const *q, double *const *s, double *const *hq,
-                                     double *const *hs, double *const *txc) {
-    try {
-        if (!d || !q || !hq || !txc || (d->nscal > 0 && (!s || !hs)) || dte <= 0.0) throw Fail(TLAB_EINVAL, "tlab_rhs_global_incompressible_1: bad arguments");
-        const int nx = d->nx, ny = d->ny, nz = d->nz;
-        const long long n = (long long)nx * ny * nz;
-        hipStream_t st = tlab_current_stream();
-        double *u = q[0], *v = q[1], *w = q[2];
-        double *tmp1 = txc[0], *tmp2 = txc[1], *tmp3 = txc[2], *tmp4 = txc[3], *tmp5 = txc[4], *tmp6 = txc[5], *tmp7 = txc[6],
-               *tmp8 = txc[7], *tmp9 = txc[8];
-        tlab_fdm_plan_t gx = d->g[0], gy = d->g[1], gz = d->g[2];
-        const int B0 = 0;  // bcs = 0: biased, non-zero (:67)
-        const double nu = d->visc;
-        // ---- diffusion and advection (:98-136); the SELF calls leave their scratch in tmp4..6 ----
-        ok(tlab_opr_burgers(1, gx, TLAB_OPR_B_SELF, nx, ny, nz, B0, nu, u, u, tmp1, tmp4, 0), "OPR_Burgers_X(u)");
-        ok(tlab_opr_burgers(2, gy, TLAB_OPR_B_SELF, nx, ny, nz, B0, nu, v, v, tmp2, tmp5, 0), "OPR_Burgers_Y(v)");
-        ok(tlab_opr_burgers(3, gz, TLAB_OPR_B_SELF, nx, ny, nz, B0, nu, w, w, tmp3, tmp6, 0), "OPR_Burgers_Z(w)");
-        ok(tlab_opr_burgers(2, gy, TLAB_OPR_B_U_IN, nx, ny, nz, B0, nu, u, v, tmp7, tmp9, 0), "OPR_Burgers_Y(u)");
-        ok(tlab_opr_burgers(3, gz, TLAB_OPR_B_U_IN, nx, ny, nz, B0, nu, u, w, tmp8, tmp9, 0), "OPR_Burgers_Z(u)");
-        hk(launch_add3(hq[0], tmp1, tmp7, tmp8, n, st), "add3");
-        ok(tlab_opr_burgers(1, gx, TLAB_OPR_B_U_IN, nx, ny, nz, B0, nu, v, u, tmp7, tmp9, 0), "OPR_Burgers_X(v)");
-        ok(tlab_opr_burgers(3, gz, TLAB_OPR_B_U_IN, nx, ny, nz, B0, nu, v, w, tmp8, tmp9, 0), "OPR_Burgers_Z(v)");
-        hk(launch_add3(hq[1], tmp2, tmp7, tmp8, n, st), "add3");
-        ok(tlab_opr_burgers(1, gx, TLAB_OPR_B_U_IN, nx, ny, nz, B0, nu, w, u, tmp7, tmp9, 0), "OPR_Burgers_X(w)");
-        ok(tlab_opr_burgers(2, gy, TLAB_OPR_B_U_IN, nx, ny, nz, B0, nu, w, v, tmp8, tmp9, 0), "OPR_Burgers_Y(w)");
-        hk(launch_add3(hq[2], tmp3, tmp7, tmp8, n, st), "add3");
-        // ---- scalars (:149-162) ----
-        for (int is = 0; is < d->nscal; ++is) {
-            const double kap = d->visc / d->schmidt[is];   // opr_burgers.f90:97
-            ok(tlab_opr_burgers(1, gx, TLAB_OPR_B_U_IN, nx, ny, nz, B0, kap, s[is], u, tmp1, tmp9, 0), "OPR_Burgers_X(s)");
-            ok(tlab_opr_burgers(2, gy, TLAB_OPR_B_U_IN, nx, ny, nz, B0, kap, s[is], v, tmp2, tmp9, 0), "OPR_Burgers_Y(s)");
-            ok(tlab_opr_burgers(3, gz, TLAB_OPR_B_U_IN, nx, ny, nz, B0, kap, s[is], w, tmp3, tmp9, 0), "OPR_Burgers_Z(s)");
-            hk(launch_add3(hs[is], tmp1, tmp2, tmp3, n, st), "add3");
+// dst += Burgers_dir(s; vel): fused accumulation when the fast kernels apply, otherwise the reference's temp + add path
+static void burgers_into(tlab_dns_t d, int dir, double nu, const double *s, const double *vel, bool self, double *dst, double *tmp,
+                         double *scratch, bool &pending_add, double **pend, int &npend) {
+    const int nx = d->nx, ny = d->ny, nz = d->nz;
+    if (d->fuse && tlab_internal_burgers_acc(dir, d->g[dir - 1], nx, ny, nz, 0, nu, s, vel, dst)) return;
+    ok(tlab_opr_burgers(dir, d->g[dir - 1], self ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, nx, ny, nz, 0, nu, s, vel, tmp, scratch, 0), "OPR_Burgers");
+    pend[npend++] = tmp;
+    pending_add = true;
+}
+
+static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *s, double *const *hq, double *const *hs,
+                     double *const *txc, bool tail_update, double kco, int scale_tendencies) {
+    const int nx = d->nx, ny = d->ny, nz = d->nz;
+    const long long n = (long long)nx * ny * nz;
+    hipStream_t st = tlab_current_stream();
+    double *u = q[0], *v = q[1], *w = q[2];
+    double *tmp1 = txc[0], *tmp2 = txc[1], *tmp3 = txc[2], *tmp4 = txc[3], *tmp7 = txc[6], *tmp8 = txc[7], *tmp9 = txc[8];
+    tlab_fdm_plan_t gx = d->g[0], gy = d->g[1], gz = d->g[2];
+    const int B0 = 0;  // bcs = 0: biased, non-zero (:67)
+    const double nu = d->visc;
+    // ---- diffusion and advection (:98-136), scalars (:149-162).  Reference: every OPR_Burgers result goes to a tmp array and
+    // hq = hq + tmp_a + tmp_b + tmp_c afterwards; here each kernel adds its result to hq directly (same summation order)
+    // when the fused kernels apply, and falls back to tmp + k_add3 per equation otherwise. ----
+    struct Eq { double *dst; const double *fld; double nu; int order[3]; };   // order = directions in the reference's summation order
+    std::vector<Eq> eqs = {{hq[0], u, nu, {1, 2, 3}},      // hq1 + tmp1(X) + tmp7(Y) + tmp8(Z)   (:110)
+                           {hq[1], v, nu, {2, 1, 3}},      // hq2 + tmp2(Y) + tmp7(X) + tmp8(Z)   (:122)
+                           {hq[2], w, nu, {3, 1, 2}}};     // hq3 + tmp3(Z) + tmp7(X) + tmp8(Y)   (:134)
+    for (int is = 0; is < d->nscal; ++is) eqs.push_back({hs[is], s[is], d->visc / d->schmidt[is], {1, 2, 3}});   // :158, opr_burgers.f90:97
+    const double *vel[3] = {u, v, w};
+    double *tmps[3] = {tmp1, tmp7, tmp8};
+    for (size_t e = 0; e < eqs.size(); ++e) {
+        bool pending = false;
+        double *pend[3];
+        int npend = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int dir = eqs[e].order[k];
+            burgers_into(d, dir, eqs[e].nu, eqs[e].fld, vel[dir - 1], eqs[e].fld == vel[dir - 1], eqs[e].dst, tmps[k], tmp9, pending, pend, npend);
         }
-        // ---- pressure (:177-260, remove_divergence branch): forcing = div(hq + q/dte) ----
-        hk(launch_axpy3(tmp2, tmp3, tmp4, hq[1], hq[0], hq[2], v, u, w, 1.0 / dte, n, st), "axpy3");
+        if (pending) {
+            if (npend == 3) hk(launch_add3(eqs[e].dst, pend[0], pend[1], pend[2], n, st), "add3");
+            else {   // mixed: add the temporaries one at a time (k_add3 with zero-sized partners is not worth a kernel)
+                hk(hipMemsetAsync(tmp9, 0, (size_t)n * sizeof(double), st), "memset");
+                hk(launch_add3(eqs[e].dst, pend[0], npend > 1 ? pend[1] : tmp9, tmp9, n, st), "add3");
+            }
+        }
+    }
+    // ---- pressure (:177-260, remove_divergence branch): forcing = div(hq + q/dte) ----
+    const double idte = 1.0 / dte;
+    bool fused_div = d->fuse && tlab_internal_partial_p1_fusable(1, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, nx, ny, nz) &&
+                     tlab_internal_partial_p1_fusable(3, nx, ny, nz);
+    if (fused_div) {
+        fused_div = tlab_internal_partial_p1_fused(2, gy, nx, ny, nz, B0, hq[1], v, idte, tmp1, false);
+        if (fused_div) {
+            const bool okx = tlab_internal_partial_p1_fused(1, gx, nx, ny, nz, B0, hq[0], u, idte, tmp1, true);
+            const bool okz = okx && tlab_internal_partial_p1_fused(3, gz, nx, ny, nz, B0, hq[2], w, idte, tmp1, true);
+            if (!okx || !okz) throw Fail(TLAB_EINVAL, "internal: inconsistent fused divergence path");
+        }
+    }
+    if (!fused_div) {
+        hk(launch_axpy3(tmp2, tmp3, tmp4, hq[1], hq[0], hq[2], v, u, w, idte, n, st), "axpy3");
         ok(tlab_opr_partial(2, gy, TLAB_OPR_P1, nx, ny, nz, B0, tmp2, tmp1, nullptr), "OPR_Partial_Y");
         ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp3, tmp2, nullptr), "OPR_Partial_X");
         ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp4, tmp3, nullptr), "OPR_Partial_Z");
         hk(launch_sum3(tmp1, tmp2, tmp3, n, st), "sum3");
-        // Neumann BCs in d/dy(p) s.t. v = 0 (:263-281)
-        hk(launch_get_wall_planes(hq[1], d->bcs_hb, d->bcs_ht, nx, ny, nz, st), "wall planes");
-        // pressure in tmp1, Oy derivative in tmp3 (:284)
-        ok(tlab_opr_poisson(d->poisson, nx, ny, nz, TLAB_BCS_NN, tmp1, tmp2, tmp4, d->bcs_hb, d->bcs_ht, tmp3), "OPR_Poisson");
-        ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
-        ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
+    }
+    // Neumann BCs in d/dy(p) s.t. v = 0 (:263-281)
+    hk(launch_get_wall_planes(hq[1], d->bcs_hb, d->bcs_ht, nx, ny, nz, st), "wall planes");
+    // pressure in tmp1, Oy derivative in tmp3 (:284)
+    ok(tlab_opr_poisson(d->poisson, nx, ny, nz, TLAB_BCS_NN, tmp1, tmp2, tmp4, d->bcs_hb, d->bcs_ht, tmp3), "OPR_Poisson");
+    ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
+    ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
+    if (tail_update) {
+        // hq -= grad p (:348-352), wall planes (:373-375), q += dte hq (time.f90:645-664), hq *= kco (:272-297) in one pass per field
+        double *gp[3] = {tmp2, tmp3, tmp4};
+        for (int iq = 0; iq < 3; ++iq) hk(launch_final_update(q[iq], hq[iq], gp[iq], dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+        for (int is = 0; is < d->nscal; ++is) hk(launch_final_update(s[is], hs[is], nullptr, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+    } else {
         hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
-        // ---- boundary conditions (:360-398): no-slip walls / Dirichlet scalars -> tendencies vanish on the wall planes ----
+        // boundary conditions (:360-398): no-slip walls / Dirichlet scalars -> tendencies vanish on the wall planes
         for (int iq = 0; iq < 3; ++iq) hk(launch_fill_wall_planes(hq[iq], 0.0, 0.0, nx, ny, nz, st), "wall planes");
         for (int is = 0; is < d->nscal; ++is) hk(launch_fill_wall_planes(hs[is], 0.0, 0.0, nx, ny, nz, st), "wall planes");
+    }
+}
+
+int tlab_rhs_global_incompressible_1(tlab_dns_t d, double dte, double *const *q, double *const *s, double *const *hq,
+                                     double *const *hs, double *const *txc) {
+    try {
+        if (!d || !q || !hq || !txc || (d->nscal > 0 && (!s || !hs)) || dte <= 0.0) throw Fail(TLAB_EINVAL, "tlab_rhs_global_incompressible_1: bad arguments");
+        rhs_impl(d, dte, q, s, hq, hs, txc, false, 1.0, 0);
         return TLAB_OK;
     } catch (const Fail &f) {
         tlab_set_error(f.what());
         return f.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
     }
+}
+
+int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double kco, int scale_tendencies, double *const *q,
+                                              double *const *s, double *const *hq, double *const *hs, double *const *txc) {
+    try {
+        if (!d || !q || !hq || !txc || (d->nscal > 0 && (!s || !hs)) || dte <= 0.0) throw Fail(TLAB_EINVAL, "tlab_time_substep_incompressible_explicit: bad arguments");
+        rhs_impl(d, dte, q, s, hq, hs, txc, true, kco, scale_tendencies);
+        return TLAB_OK;
+    } catch (const Fail &f) {
+        tlab_set_error(f.what());
+        return f.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    }
+}
+
+int tlab_dns_set_fusion(tlab_dns_t d, int on) {
+    if (!d) return TLAB_EINVAL;
+    d->fuse = on != 0;
+    return TLAB_OK;
 }
 
 // ---- the pointwise pieces on their own, for drivers that interleave communication (z-slab decomposition) ----
@@ -149,21 +218,5 @@ int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const doub
 int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n) { PW_GUARD(launch_rk_update(q, h, dte, kco, scale, n, tlab_current_stream())) }
 int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz) { PW_GUARD(launch_get_wall_planes(f, hb, ht, nx, ny, nz, tlab_current_stream())) }
 int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz) { PW_GUARD(launch_fill_wall_planes(f, vb, vt, nx, ny, nz, tlab_current_stream())) }
-
-int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double kco, int scale_tendencies, double *const *q,
-                                              double *const *s, double *const *hq, double *const *hs, double *const *txc) {
-    int rc = tlab_rhs_global_incompressible_1(d, dte, q, s, hq, hs, txc);
-    if (rc != TLAB_OK) return rc;
-    try {
-        const long long n = (long long)d->nx * d->ny * d->nz;
-        hipStream_t st = tlab_current_stream();
-        for (int iq = 0; iq < 3; ++iq) hk(launch_rk_update(q[iq], hq[iq], dte, kco, scale_tendencies, n, st), "rk update");
-        for (int is = 0; is < d->nscal; ++is) hk(launch_rk_update(s[is], hs[is], dte, kco, scale_tendencies, n, st), "rk update");
-        return TLAB_OK;
-    } catch (const Fail &f) {
-        tlab_set_error(f.what());
-        return f.code;
-    }
-}
 
 }  // extern "C"

@@ -54,6 +54,10 @@ class Dns:
                                      sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "tlab_dns_create")
         self._ptrs = None
 
+    def set_fusion(self, on):
+        """on (default): pointwise sums folded into the operator kernels; off: the reference's literal sequence."""
+        check(load().tlab_dns_set_fusion(self._h, int(bool(on))), "tlab_dns_set_fusion")
+
     def _arrays(self):
         if self._ptrs is None:
             def arr(ts):
