@@ -173,6 +173,20 @@ def test_generic_kernel_odd_sizes(T, nx, ny, nz):
         run_all_ops(T, O, d, gp, op, nx, ny, nz, (0, 1, 2, 3) if d == 2 else (0,), u, v, 1e-2, tag="generic")
 
 
+@pytest.mark.parametrize("m1,m2", [(4, 4), (6, 6), (4, 7)])
+def test_other_schemes_on_fast_kernels(T, m1, m2):
+    """CompactJacobian4 (3-diagonal RHS) and CompactJacobian6 (5-diagonal second-derivative RHS) through the same fast kernels."""
+    from oracle import tlab_oracle as O
+    from tlab_amd.lib import load
+    nx, ny, nz = 256, 64, 32
+    x, y, z = grids(nx, ny, nz)
+    u, v = fields(nx, ny, nz, m1 * 10 + m2)
+    for d, (nodes, per, uni) in {1: (x, True, True), 2: (y, False, False), 3: (z, True, True)}.items():
+        gp, op = T.FdmPlan(nodes, per, uni, m1, m2), O.FdmPlan(nodes, per, uni, m1, m2)
+        run_all_ops(T, O, d, gp, op, nx, ny, nz, (0, 1, 2, 3) if d == 2 else (0,), u, v, 1e-2, tag="schemes %d/%d" % (m1, m2))
+        assert load().tlab_last_kernel_path() in (2, 3)
+
+
 def test_two_dimensional_guard_and_errors(T):
     """opr_partial.f90:175-177: a direction of size 1 returns zeros; bad calls are refused, not computed."""
     import torch
