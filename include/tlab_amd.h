@@ -156,6 +156,20 @@ int tlab_dns_destroy(tlab_dns_t d);
 /* on (default): the pointwise sums of the RHS are folded into the operator kernels (same summation order as the reference);
  * off: the reference's literal sequence of temporaries + pointwise loops.  Both give the same result to round-off. */
 int tlab_dns_set_fusion(tlab_dns_t d, int on);
+/* Wall boundary conditions in y: BcsFlowJmin%type(1:3), BcsFlowJmax%type(1:3), BcsScalJmin%type(1:nscal), BcsScalJmax%type(1:nscal)
+ * (tools/dns/boundary_bcs.f90:24-27, read at :102-190).  Values as in the reference: DNS_BCS_DIRICHLET / DNS_BCS_NEUMANN.
+ * Default at creation: all Dirichlet ('noslip'; the reference's 'freeslip' is {NEUMANN, DIRICHLET, NEUMANN} for (u,v,w)).
+ * The normal velocity (index 1 here, 0-based) must stay Dirichlet: the pressure solver's Neumann data assume v = 0 at the walls. */
+#define TLAB_DNS_BCS_DIRICHLET 3
+#define TLAB_DNS_BCS_NEUMANN 4
+int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
+
+/* BOUNDARY_BCS_NEUMANN_Y(ibc, nx, ny, nz, g, u, bcs_hb, bcs_ht, tmp1)   tools/dns/boundary_bcs.f90:368-473
+ * Wall values of u (planes of nx*nz, x fastest) such that du/dy = 0 at the bottom (ibc = 1), top (2) or both (3) walls,
+ * from the Neumann-reduced first-derivative system of g.  u is read only (its wall planes are not used); a plane not selected
+ * by ibc is left untouched; tmp1 is work space of nx*ny*nz. */
+int tlab_boundary_bcs_neumann_y(tlab_fdm_plan_t g, int ibc, int nx, int ny, int nz, const double *u, double *bcs_hb,
+                                double *bcs_ht, double *tmp1);
 
 /* RHS_GLOBAL_INCOMPRESSIBLE_1()   tools/dns/rhs_global_incompressible_1.f90:15-405 (argument-less in the reference:
  * it works on the module arrays q, s, hq, hs, txc and on dte).  q[3] = u,v,w; s[nscal]; hq[3], hs[nscal] are
@@ -181,6 +195,7 @@ int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const doub
 int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n);             /* q += dte h; h *= kco */
 int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz);
 int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz);
+int tlab_pw_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz);      /* NULL plane = zeros */
 
 /* TLab_Transpose(a, nra, nca, ma, b, mb)   utils/tlab_transpose.f90:14-82 : b(j,i) = a(i,j), bit-exact */
 int tlab_transpose(const double *a, int nra, int nca, double *b);

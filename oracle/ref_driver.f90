@@ -266,3 +266,58 @@ subroutine ref_burgers(idir, nx, ny, nz, ibc, visc, s, vel, res, tmp1) bind(C, n
 
     deallocate (lu2d, vel_t, dsdx)
 end subroutine ref_burgers
+
+!########################################################################
+! BOUNDARY_BCS_NEUMANN_Y (tools/dns/boundary_bcs.f90:368-473; that module cannot be compiled here: it drags in the whole dns
+! tool).  Same statements on the reference's own matmul / TRIDSS, serial branch: wall values of u s.t. du/dy = 0 there.
+subroutine ref_bcs_neumann_y(ibc, nx, ny, nz, u, bcs_hb, bcs_ht) bind(C, name='ref_bcs_neumann_y')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi, BCS_ND, BCS_DN, BCS_NN
+    use ref_state
+    implicit none
+    integer(c_int), value :: ibc, nx, ny, nz
+    real(c_double), intent(in) :: u(nx*ny*nz)
+    real(c_double), intent(out) :: bcs_hb(nx*nz), bcs_ht(nx*nz)
+    real(wp), allocatable :: org(:, :), dst(:, :), hb(:), ht(:)
+    integer(wi) nxz, ip, idl, ic, nmin, nmax, nsize
+
+    nxz = nx*nz
+    allocate (org(nxz, ny), dst(nxz, ny), hb(nxz), ht(nxz))
+    hb = 0.0_wp; ht = 0.0_wp
+    if (nz > 1) then
+        call TLab_Transpose(u, nx*ny, nz, nx*ny, org, nz)
+    else
+        org = reshape(u, [nxz, ny])
+    end if
+    ip = ibc*5
+    nmin = 1; nmax = ny
+    if (any([BCS_ND, BCS_NN] == ibc)) then
+        dst(:, 1) = 0.0_wp
+        nmin = nmin + 1
+    end if
+    if (any([BCS_DN, BCS_NN] == ibc)) then
+        dst(:, ny) = 0.0_wp
+        nmax = nmax - 1
+    end if
+    nsize = nmax - nmin + 1
+    call gp(2)%der1%matmul(gp(2)%der1%rhs, org, dst, ibc, gp(2)%der1%rhs_b, gp(2)%der1%rhs_t, hb, ht)
+    call TRIDSS(nsize, nxz, gp(2)%der1%lu(nmin:nmax, ip + 1), gp(2)%der1%lu(nmin:nmax, ip + 2), gp(2)%der1%lu(nmin:nmax, ip + 3), dst(:, nmin:nmax))
+    idl = gp(2)%der1%nb_diag(1)/2 + 1
+    if (any([BCS_ND, BCS_NN] == ibc)) then
+        do ic = 1, idl - 1
+            hb(:) = hb(:) + gp(2)%der1%lu(1, ip + idl + ic)*dst(:, 1 + ic)
+        end do
+    end if
+    if (any([BCS_DN, BCS_NN] == ibc)) then
+        do ic = 1, idl - 1
+            ht(:) = ht(:) + gp(2)%der1%lu(ny, ip + idl - ic)*dst(:, ny - ic)
+        end do
+    end if
+    if (nz > 1) then
+        call TLab_Transpose(hb, nz, nx, nz, bcs_hb, nx)
+        call TLab_Transpose(ht, nz, nx, nz, bcs_ht, nx)
+    else
+        bcs_hb = hb; bcs_ht = ht
+    end if
+    deallocate (org, dst, hb, ht)
+end subroutine ref_bcs_neumann_y

@@ -165,3 +165,14 @@ def ode2(itype, lam, f, bcs):
     v = np.zeros_like(f)
     L.ref_ode2(int(itype), f.shape[1], float(lam), f, b, u, v)
     return u, v
+
+
+def bcs_neumann_y(ibc, nx, ny, nz, u):
+    """BOUNDARY_BCS_NEUMANN_Y on the y plan (direction 2): returns (bcs_hb, bcs_ht), each nx*nz."""
+    L = lib()
+    L.ref_bcs_neumann_y.argtypes = [c_int] * 4 + [_P, _P, _P]
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    hb = np.zeros(nx * nz)
+    ht = np.zeros(nx * nz)
+    L.ref_bcs_neumann_y(int(ibc), nx, ny, nz, u, hb, ht)
+    return hb, ht

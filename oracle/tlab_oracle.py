@@ -809,3 +809,36 @@ def opr_burgers(idir, nx, ny, nz, ibc, g, nu, s, vel):
     r = der2_solve(g.der2, g.diffusion_lu(nu), sl, dsdx)
     r = r - vl * dsdx
     return _from_lines(r, nx, ny, nz, idir), sl.ravel()
+
+
+def boundary_bcs_neumann_y(ibc, nx, ny, nz, g, u):
+    """tools/dns/boundary_bcs.f90:368-473 BOUNDARY_BCS_NEUMANN_Y (serial; C1N6, i.e. MatMul_5d_antisym with its bcs_b/bcs_t outputs,
+    fdm_matmul.f90:384,410): wall values of u such that du/dy = 0 at the walls selected by ibc.  Returns (bcs_hb, bcs_ht) as (nz, nx)."""
+    d = g.der1
+    assert d.nb_diag == (3, 5), "oracle: BOUNDARY_BCS_NEUMANN_Y restated for the CompactJacobian6 first derivative"
+    n = ny
+    ul = _to_lines(np.asarray(u, dtype=np.float64), nx, ny, nz, 2)       # (ny, nx*nz), line = k + nz*i
+    dst = np.empty_like(ul)
+    ip = ibc * 5
+    nmin, nmax = 0, n
+    if ibc in (BCS_ND, BCS_NN):
+        dst[0] = 0.0
+        nmin += 1
+    if ibc in (BCS_DN, BCS_NN):
+        dst[n - 1] = 0.0
+        nmax -= 1
+    rb, rt = d.rhs_b, d.rhs_t
+    hb = np.zeros(ul.shape[1])
+    ht = np.zeros(ul.shape[1])
+    if ibc in (BCS_ND, BCS_NN):
+        hb = dst[0] * rb[0, 3] + ul[1] * rb[0, 4] + ul[2] * rb[0, 5] + ul[3] * rb[0, 1]
+    matmul_5d_antisym(d.rhs, ul, dst, ibc, rb, rt)
+    if ibc in (BCS_DN, BCS_NN):
+        ht = ul[n - 4] * rt[3, 4] + ul[n - 3] * rt[3, 0] + ul[n - 2] * rt[3, 1] + dst[n - 1] * rt[3, 2]
+    tridss(d.lu[nmin:nmax, ip], d.lu[nmin:nmax, ip + 1], d.lu[nmin:nmax, ip + 2], dst[nmin:nmax])
+    if ibc in (BCS_ND, BCS_NN):
+        hb = hb + d.lu[0, ip + 2] * dst[1]
+    if ibc in (BCS_DN, BCS_NN):
+        ht = ht + d.lu[n - 1, ip + 0] * dst[n - 2]
+    # lines are (k fastest, then i): put the planes back in (nz, nx) order (x fastest)
+    return (np.ascontiguousarray(hb.reshape(nx, nz).T), np.ascontiguousarray(ht.reshape(nx, nz).T))

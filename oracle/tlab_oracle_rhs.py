@@ -3,7 +3,7 @@ operator oracles (tlab_oracle.py, tlab_oracle_poisson.py) in the reference's cal
 
 TEST INFRASTRUCTURE ONLY.  Parity status: every operator it composes is pinned against the reference (see the two
 modules); the composition itself follows tools/dns/rhs_global_incompressible_1.f90:98-375 line by line (convective form,
-RhsMode = combined, remove_divergence, no-slip walls / Dirichlet scalars) and tools/dns/time.f90:645-664, :261-298.
+RhsMode = combined, remove_divergence; wall BCs Dirichlet or Neumann per field, :360-398) and tools/dns/time.f90:645-664, :261-298.
 The reference's driver (dns.x) cannot be built in this image (needs fftw3.f03 through opr_fourier.f90), so this level is
 pinned through its parts plus the discrete invariant it must satisfy: div(q/dte + hq) = 0 in the interior."""
 import numpy as np
@@ -23,6 +23,9 @@ class DnsOracle:
         self.s = [np.zeros(self.n) for _ in range(nscal)]
         self.hq = [np.zeros(self.n) for _ in range(3)]
         self.hs = [np.zeros(self.n) for _ in range(nscal)]
+        # BcsFlowJmin/Jmax%type, BcsScalJmin/Jmax%type (boundary_bcs.f90:18-27): 3 = DNS_BCS_DIRICHLET, 4 = DNS_BCS_NEUMANN
+        self.flow_jmin, self.flow_jmax = [3, 3, 3], [3, 3, 3]
+        self.scal_jmin, self.scal_jmax = [3] * nscal, [3] * nscal
 
     def burgers(self, d, nu, s, vel):
         return O.opr_burgers(d, self.nx, self.ny, self.nz, 0, self.g[d - 1], nu, s, vel)[0]
@@ -58,10 +61,19 @@ class DnsOracle:
         self.p = p
         tmp2 = self.p1(1, p); tmp4 = self.p1(3, p)                                                                  # :319-320
         hq[0] = hq[0] - tmp2; hq[1] = hq[1] - dpdy; hq[2] = hq[2] - tmp4                                            # :349-351
-        for a in hq + hs:                                                                                           # :373-375, :394-396
+        types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
+        for a, (tmin, tmax) in zip(hq + hs, types):                                                                 # :363-375, :379-396
+            ref_b = np.zeros((nz, nx)); ref_t = np.zeros((nz, nx))
+            ibc = (1 if tmin == 4 else 0) + (2 if tmax == 4 else 0)
+            if ibc > 0:
+                nb, nt = O.boundary_bcs_neumann_y(ibc, nx, ny, nz, self.g[1], a)
+                if ibc & 1:
+                    ref_b = nb
+                if ibc & 2:
+                    ref_t = nt
             b = a.reshape(nz, ny, nx)
-            b[:, 0, :] = 0.0
-            b[:, ny - 1, :] = 0.0
+            b[:, 0, :] = ref_b
+            b[:, ny - 1, :] = ref_t
 
     def time_substep(self, dte, kco=1.0, scale=False):
         self.rhs_global_incompressible_1(dte)

@@ -57,6 +57,9 @@ def derivs_case(name, nx, ny, nz, ystretch, mode1=6, mode2=7):
             out["burgers_d%d_bc%d" % (d, ibc)] = r
             if d != 3:
                 out["burgers_d%d_bc%d_tmp1" % (d, ibc)] = t1
+    for ibc in (1, 2, 3):               # BOUNDARY_BCS_NEUMANN_Y wall planes (ref_driver.f90: ref_bcs_neumann_y)
+        hb, ht = R.bcs_neumann_y(ibc, nx, ny, nz, u)
+        out["bcsn_bc%d_hb" % ibc], out["bcsn_bc%d_ht" % ibc] = hb, ht
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name, sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")) // 1024, "KiB raw")
 

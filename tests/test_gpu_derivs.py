@@ -187,6 +187,42 @@ def test_other_schemes_on_fast_kernels(T, m1, m2):
         assert load().tlab_last_kernel_path() in (2, 3)
 
 
+@pytest.mark.parametrize("nx,ny,nz,stretch,m1", [(16, 12, 8, True, 6), (64, 128, 4, True, 6), (64, 512, 2, False, 6), (40, 33, 3, True, 4), (32, 64, 1, True, 4)])
+def test_boundary_bcs_neumann_y(T, nx, ny, nz, stretch, m1):
+    """BOUNDARY_BCS_NEUMANN_Y vs the oracle (C1N6) or, for C1N4, through the property it exists for: du/dy = 0 at the wall."""
+    import torch
+    from oracle import tlab_oracle as O
+    x, y, z = grids(nx, ny, nz, stretch)
+    gp = T.FdmPlan(y, False, not stretch, m1, 7 if m1 == 6 else 4)
+    op = O.FdmPlan(y, False, not stretch, m1, 7 if m1 == 6 else 4)
+    u, _ = fields(nx, ny, nz, 21)
+    du = dev(u)
+    tmp = torch.empty_like(du)
+    for ibc in (1, 2, 3):
+        hb = torch.full((nx * nz,), float("nan"), dtype=torch.float64, device="cuda")
+        ht = hb.clone()
+        T.BOUNDARY_BCS_NEUMANN_Y(ibc, nx, ny, nz, gp, du, hb, ht, tmp)
+        assert bool(torch.isnan(hb).all()) == (ibc == 2) and bool(torch.isnan(ht).all()) == (ibc == 1)    # untouched when not selected
+        if m1 == 6:
+            ob, ot = O.boundary_bcs_neumann_y(ibc, nx, ny, nz, op, u)
+            if ibc & 1:
+                assert rel_err(host(hb), ob.ravel()) <= TOL
+            if ibc & 2:
+                assert rel_err(host(ht), ot.ravel()) <= TOL
+        a = u.reshape(nz, ny, nx).copy()
+        if ibc & 1:
+            a[:, 0, :] = host(hb).reshape(nz, nx)
+        if ibc & 2:
+            a[:, -1, :] = host(ht).reshape(nz, nx)
+        d = O.opr_partial(2, O.OPR_P1, nx, ny, nz, 0, op, a.ravel())[0].reshape(nz, ny, nx)
+        if ibc & 1:
+            assert np.abs(d[:, 0, :]).max() <= 1e-10 * np.abs(d).max()
+        if ibc & 2:
+            assert np.abs(d[:, -1, :]).max() <= 1e-10 * np.abs(d).max()
+    with pytest.raises(T.TlabError):
+        T.BOUNDARY_BCS_NEUMANN_Y(0, nx, ny, nz, gp, du, hb, ht, tmp)
+
+
 def test_two_dimensional_guard_and_errors(T):
     """opr_partial.f90:175-177: a direction of size 1 returns zeros; bad calls are refused, not computed."""
     import torch

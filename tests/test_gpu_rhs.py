@@ -63,6 +63,71 @@ def test_substep_vs_oracle(T, nx, ny, nz, stretch, fuse):
         assert rel_err(d.hs[0].cpu().numpy(), o.hs[0]) <= 1e-11
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("vel,scal", [(("freeslip", "freeslip"), ("neumann", "dirichlet")), (("noslip", "freeslip"), ("dirichlet", "neumann"))])
+def test_substep_with_neumann_walls_vs_oracle(T, vel, scal, fuse):
+    """Free-slip walls / Neumann scalars (the reference's default VelocityJmin = freeslip, boundary_bcs.f90:114):
+    BOUNDARY_BCS_NEUMANN_Y sets the wall tendencies (rhs_global_incompressible_1.f90:363-396)."""
+    import torch
+    from tlab_amd.dns import Dns, velocity_bcs, scalar_bcs
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz, stretch = 64, 64, 32, True
+    x, y, z = grids(nx, ny, nz, stretch)
+    visc, sc = 1.0 / 800.0, (0.7,)
+    rng = np.random.default_rng(11)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * Y)
+    q0 = [(np.sin(np.pi * X) * np.cos(2 * np.pi * Z) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel(),
+          ((np.cos(np.pi * X) * np.sin(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel(),
+          (np.sin(2 * np.pi * X + 1) * np.sin(2 * np.pi * Z) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    s0 = [(np.cos(np.pi * X) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch)
+    o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch)
+    d.set_fusion(fuse)
+    d.set_bcs(vel[0], vel[1], scal[0], scal[1])
+    o.flow_jmin, o.flow_jmax = velocity_bcs(vel[0]), velocity_bcs(vel[1])
+    o.scal_jmin, o.scal_jmax = [scalar_bcs(scal[0])], [scalar_bcs(scal[1])]
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i])); o.q[i] = q0[i].copy()
+    d.s[0].copy_(torch.from_numpy(s0[0])); o.s[0] = s0[0].copy()
+    dtime = 2e-3
+    for k in range(2):
+        dte, kco = dtime * d.kdt[k], d.kco[k]
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, True)
+        o.time_substep(dte, kco, True)
+        for i in range(3):
+            assert rel_err(d.q[i].cpu().numpy(), o.q[i]) <= 1e-12, (k, "q", i)
+            assert rel_err(d.hq[i].cpu().numpy(), o.hq[i]) <= 1e-11, (k, "hq", i)
+        assert rel_err(d.s[0].cpu().numpy(), o.s[0]) <= 1e-12
+        assert rel_err(d.hs[0].cpu().numpy(), o.hs[0]) <= 1e-11
+    # the wall tendencies are not zero where Neumann was asked for, and the RHS entry point agrees with the fused substep
+    hq0 = o.hq[0].reshape(nz, ny, nx)
+    assert np.abs(hq0[:, -1, :]).max() > 0
+    with pytest.raises(T.TlabError):
+        d.set_bcs(velocity_jmin="noslip", velocity_jmax="noslip", scalar_jmin="robin")
+
+
+def test_rhs_entry_with_neumann_walls_vs_oracle(T):
+    import torch
+    from tlab_amd.dns import Dns, velocity_bcs
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 32, 48, 16
+    x, y, z = grids(nx, ny, nz, False)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 9)
+    d = Dns(x, y, z, nscal=1, visc=1e-3, schmidt=(1.0,), yuniform=True)
+    o = DnsOracle(x, y, z, nscal=1, visc=1e-3, schmidt=(1.0,), yuniform=True)
+    d.set_bcs("freeslip", "noslip", "neumann", "neumann")
+    o.flow_jmin, o.scal_jmin, o.scal_jmax = velocity_bcs("freeslip"), [4], [4]
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i])); o.q[i] = q0[i].copy()
+    d.s[0].copy_(torch.from_numpy(s0[0])); o.s[0] = s0[0].copy()
+    d.RHS_GLOBAL_INCOMPRESSIBLE_1(1e-3)
+    o.rhs_global_incompressible_1(1e-3)
+    for i in range(3):
+        assert rel_err(d.hq[i].cpu().numpy(), o.hq[i]) <= 1e-11
+    assert rel_err(d.hs[0].cpu().numpy(), o.hs[0]) <= 1e-11
+
+
 def test_projection_makes_interior_divergence_vanish(T):
     """max|div(u/dte + hq)| * dte ~ 2e-15 in the interior after the pressure correction."""
     import torch

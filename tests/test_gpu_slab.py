@@ -18,8 +18,8 @@ def T():
     return T
 
 
-@pytest.mark.parametrize("P,nx,ny,nz", [(2, 64, 32, 32), (4, 32, 64, 64), (8, 64, 32, 64)])
-def test_slab_substep_equals_single_domain(T, P, nx, ny, nz):
+@pytest.mark.parametrize("P,nx,ny,nz,bcs", [(2, 64, 32, 32, "noslip"), (4, 32, 64, 64, "noslip"), (8, 64, 32, 64, "noslip"), (4, 64, 32, 32, "freeslip")])
+def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs):
     import torch
     from tlab_amd.dns import Dns
     from tlab_amd.parallel import SlabDns, LoopbackComm
@@ -33,6 +33,9 @@ def test_slab_substep_equals_single_domain(T, P, nx, ny, nz):
     visc, sc = 1.0 / 600.0, (0.8,)
     one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
     slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+    if bcs == "freeslip":
+        one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+        slab.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
     for i in range(3):
         t = torch.from_numpy(fields[i]).cuda()
         one.q[i].copy_(t); slab.scatter("q", i, t)

@@ -53,6 +53,23 @@ def test_operators_match_golden(path):
                 assert np.array_equal(st, g["burgers_d%d_bc%d_tmp1" % (d, ibc)])
 
 
+@pytest.mark.parametrize("path", golden_files("derivs_"))
+def test_boundary_bcs_neumann_matches_golden(path):
+    g = np.load(path)
+    nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
+    gy = plans_from_golden(g)[2]
+    for ibc in (1, 2, 3):
+        hb, ht = O.boundary_bcs_neumann_y(ibc, nx, ny, nz, gy, g["u"])
+        assert rel_err(hb.ravel(), g["bcsn_bc%d_hb" % ibc]) <= TOL if ibc & 1 else not hb.any()
+        assert rel_err(ht.ravel(), g["bcsn_bc%d_ht" % ibc]) <= TOL if ibc & 2 else not ht.any()
+    # the property the routine exists for: with these wall values the y-derivative vanishes at the walls
+    a = g["u"].reshape(nz, ny, nx).copy()
+    a[:, 0, :] = g["bcsn_bc3_hb"].reshape(nz, nx)
+    a[:, -1, :] = g["bcsn_bc3_ht"].reshape(nz, nx)
+    d = O.opr_partial(2, O.OPR_P1, nx, ny, nz, 0, gy, a.ravel())[0].reshape(nz, ny, nx)
+    assert np.abs(d[:, 0, :]).max() <= 1e-11 * np.abs(d).max() and np.abs(d[:, -1, :]).max() <= 1e-11 * np.abs(d).max()
+
+
 def test_hyper_wall_closure_defect_is_what_the_reference_does():
     """DESIGN.md 'reference defects': the flang-built reference reads coef_bc1(7) out of bounds and gets 0.1."""
     g = np.load(golden_files("derivs_stretched")[0])

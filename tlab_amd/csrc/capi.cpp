@@ -570,6 +570,41 @@ int tlab_set_tuning(int key, int value) {
     return TLAB_EINVAL;
 }
 
+// BOUNDARY_BCS_NEUMANN_Y (tools/dns/boundary_bcs.f90:368-473): the reduced derivative (zero at the chosen walls) is the ordinary
+// OPR_Partial_Y under ibc; the wall values follow from the first / last row of the compact scheme in a plane kernel.
+int tlab_boundary_bcs_neumann_y(tlab_fdm_plan_t g, int ibc, int nx, int ny, int nz, const double *u, double *bcs_hb, double *bcs_ht,
+                                double *tmp1) {
+    return guarded([&] {
+        check_common(2, g, nx, ny, nz, ibc);
+        if (ibc != BCS_ND && ibc != BCS_DN && ibc != BCS_NN) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: ibc must be 1 (jmin), 2 (jmax) or 3 (both)");
+        if (g->t.periodic) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: periodic direction");
+        if (!u || !tmp1 || u == tmp1 || !bcs_hb || !bcs_ht) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: null or aliased arrays");
+        const DerTables &d = g->t.der1;
+        if (d.ndl != 3 || (d.ndr != 3 && d.ndr != 5)) throw Unsupported("BOUNDARY_BCS_NEUMANN_Y: tridiagonal first-derivative schemes only");
+        if (ny < 8) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: ny too small");
+        std::vector<double> lhs(d.lhs.begin(), d.lhs.begin() + (size_t)3 * ny);
+        double rb[4 * 8] = {0}, rt[5 * 7] = {0};
+        fdm_bcs_neumann(ibc, ny, 3, lhs.data(), d.ndr, d.rhs.data(), rb, rt);
+        double cb[4] = {0, 0, 0, 0}, ct[4] = {0, 0, 0, 0};
+#define RB(j, c) rb[((j)-1) + 4 * (c)]
+#define RT(rr, c) rt[(rr) + 5 * ((c)-1)]
+        if (d.ndr == 5) {   // MatMul_5d_antisym, fdm_matmul.f90:384,410
+            cb[0] = RB(1, 4); cb[1] = RB(1, 5); cb[2] = RB(1, 1);
+            ct[0] = RT(3, 5); ct[1] = RT(3, 1); ct[2] = RT(3, 2);
+        } else {            // MatMul_3d_antisym, fdm_matmul.f90:179,203
+            cb[0] = RB(1, 3); cb[1] = RB(1, 1);
+            ct[1] = RT(2, 3); ct[2] = RT(2, 1);
+        }
+#undef RB
+#undef RT
+        cb[3] = lhs[0 + (size_t)ny * 2];          // lu(1, ip+idl+1): first row of the reduced LHS is not touched by TRIDFS
+        ct[3] = lhs[(ny - 1) + (size_t)ny * 0];   // lu(ny, ip+idl-1)
+        const int rc = tlab_opr_partial(2, g, TLAB_OPR_P1, nx, ny, nz, ibc, u, tmp1, nullptr);
+        if (rc != TLAB_OK) throw Invalid(std::string("BOUNDARY_BCS_NEUMANN_Y: ") + tlab_last_error());
+        hip_check(launch_neumann_planes(u, tmp1, cb, ct, (ibc & 1), (ibc & 2), bcs_hb, bcs_ht, nx, ny, nz, g_stream), "k_neumann_planes");
+    });
+}
+
 int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int nz, int ibc, const double *u,
                      double *result, double *tmp1) {
     return guarded([&] {

@@ -66,6 +66,10 @@ hipError_t launch_sub3(double *h1, double *h2, double *h3, const double *a, cons
 hipError_t launch_rk_update(double *q, double *h, double dte, double kco, int scale, long long n, hipStream_t st);
 hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz, hipStream_t st);
 hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz, hipStream_t st);
-hipError_t launch_final_update(double *q, double *h, const double *g, double dte, double kco, int scale, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
+                               int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_neumann_planes(const double *u, const double *du, const double *cb, const double *ct, int do_b, int do_t, double *hb,
+                                 double *ht, int nx, int ny, int nz, hipStream_t st);
 
 }  // namespace tlab

@@ -107,15 +107,47 @@ __global__ void __launch_bounds__(256) k_fill_wall_planes(double *__restrict__ f
     f[ix + (long long)nx * ((ny - 1) + (long long)ny * k)] = vt;
 }
 
+// f(:,1,:) = pb(:,:) ; f(:,ny,:) = pt(:,:)   (p_bcs(:,1,:) = BcsFlowJmin%ref(:,:,iq), :373-375; a null plane stands for ref = 0)
+__global__ void __launch_bounds__(256) k_set_wall_planes_opt(double *__restrict__ f, const double *__restrict__ pb, const double *__restrict__ pt,
+                                                         int nx, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * nz) return;
+    const int ix = (int)(i % nx);
+    const long long k = i / nx;
+    f[ix + (long long)nx * (0 + (long long)ny * k)] = pb ? pb[i] : 0.0;
+    f[ix + (long long)nx * ((ny - 1) + (long long)ny * k)] = pt ? pt[i] : 0.0;
+}
+
+// BOUNDARY_BCS_NEUMANN_Y (tools/dns/boundary_bcs.f90:368-473), last step: with du = the y-derivative of u computed under the
+// Neumann variant ibc (zero at the chosen walls), the wall value that makes du/dy vanish there is
+//   bcs_hb = u(2) r_b(1,.) + u(3) r_b(1,.) + u(4) r_b(1,.) + lu(1, ip+idl+1) du(2)       (fdm_matmul.f90:384 + boundary_bcs.f90:452)
+//   bcs_ht = u(n-3) r_t(.,.) + u(n-2) r_t(.,.) + u(n-1) r_t(.,.) + lu(n, ip+idl-1) du(n-1)   (fdm_matmul.f90:410 + boundary_bcs.f90:457)
+// cb/ct = the three stencil coefficients in that order followed by the LHS coefficient.
+struct NeumannCoef { double cb[4], ct[4]; };
+__global__ void __launch_bounds__(256) k_neumann_planes(const double *__restrict__ u, const double *__restrict__ du, NeumannCoef c, int do_b,
+                                                        int do_t, double *__restrict__ hb, double *__restrict__ ht, int nx, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * nz) return;
+    const int ix = (int)(i % nx);
+    const long long k = i / nx;
+    const long long base = ix + (long long)nx * ny * k;
+#define AT(a, j) a[base + (long long)nx * (j)]
+    if (do_b) hb[i] = ((AT(u, 1) * c.cb[0] + AT(u, 2) * c.cb[1]) + AT(u, 3) * c.cb[2]) + c.cb[3] * AT(du, 1);
+    if (do_t) ht[i] = ((AT(u, ny - 4) * c.ct[0] + AT(u, ny - 3) * c.ct[1]) + AT(u, ny - 2) * c.ct[2]) + c.ct[3] * AT(du, ny - 2);
+#undef AT
+}
+
 // fused tail of the substep for one velocity component (rhs_global_incompressible_1.f90:348-352, :373-375; time.f90:645-664, :272-297):
 //   h = h - g (pressure gradient); h = 0 on the wall planes j = 1, ny; q = q + dte*h; h = kco*h (if scale)
-__global__ void __launch_bounds__(256) k_final_update(double *__restrict__ q, double *__restrict__ h, const double *__restrict__ g, double dte,
+__global__ void __launch_bounds__(256) k_final_update(double *__restrict__ q, double *__restrict__ h, const double *__restrict__ g,
+                                                      const double *__restrict__ pb, const double *__restrict__ pt, double dte,
                                                       double kco, int scale, int nx, int ny, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int j = (int)((i / nx) % ny);
         double hv = g ? h[i] - g[i] : h[i];
-        if (j == 0 || j == ny - 1) hv = 0.0;
+        if (j == 0) hv = pb ? pb[(i % nx) + (long long)nx * (i / ((long long)nx * ny))] : 0.0;
+        else if (j == ny - 1) hv = pt ? pt[(i % nx) + (long long)nx * (i / ((long long)nx * ny))] : 0.0;
         q[i] = q[i] + dte * hv;
         h[i] = scale ? kco * hv : hv;
     }
@@ -123,10 +155,11 @@ __global__ void __launch_bounds__(256) k_final_update(double *__restrict__ q, do
 
 #define CHECK_LAUNCH() hipGetLastError()
 
-hipError_t launch_final_update(double *q, double *h, const double *g, double dte, double kco, int scale, int nx, int ny, int nz, hipStream_t st) {
+hipError_t launch_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
+                               int nx, int ny, int nz, hipStream_t st) {
     const long long n = (long long)nx * ny * nz;
     ProfScope ps("k_final_update", st, (double)n * (g ? 40 : 32));
-    hipLaunchKernelGGL(k_final_update, dim3(pw_grid(n)), dim3(256), 0, st, q, h, g, dte, kco, scale, nx, ny, n);
+    hipLaunchKernelGGL(k_final_update, dim3(pw_grid(n)), dim3(256), 0, st, q, h, g, pb, pt, dte, kco, scale, nx, ny, n);
     return CHECK_LAUNCH();
 }
 
@@ -162,6 +195,18 @@ hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int n
 }
 hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz, hipStream_t st) {
     hipLaunchKernelGGL(k_fill_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, f, vb, vt, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
+
+hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_wall_planes_opt, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, f, pb, pt, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_neumann_planes(const double *u, const double *du, const double *cb, const double *ct, int do_b, int do_t, double *hb,
+                                 double *ht, int nx, int ny, int nz, hipStream_t st) {
+    NeumannCoef c;
+    for (int i = 0; i < 4; ++i) { c.cb[i] = cb[i]; c.ct[i] = ct[i]; }
+    hipLaunchKernelGGL(k_neumann_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, u, du, c, do_b, do_t, hb, ht, nx, ny, nz);
     return CHECK_LAUNCH();
 }
 

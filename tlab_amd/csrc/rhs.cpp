@@ -33,6 +33,9 @@ struct tlab_dns {
     std::vector<double> schmidt;
     double *bcs_hb = nullptr, *bcs_ht = nullptr;   // BcsFlowJmin%ref(:,:,2), BcsFlowJmax%ref(:,:,2)
     bool fuse = true;                              // fold the pointwise sums into the operator kernels where the fast kernels apply
+    int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};   // BcsFlowJmin%type
+    int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
+    std::vector<int> scal_jmin, scal_jmax;         // BcsScalJmin%type, BcsScalJmax%type
     ~tlab_dns() {
         if (bcs_hb) (void)hipFree(bcs_hb);
         if (bcs_ht) (void)hipFree(bcs_ht);
@@ -65,6 +68,8 @@ int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tla
         d->poisson = poisson;
         d->nx = nx; d->ny = ny; d->nz = nz; d->nscal = nscal; d->visc = visc;
         d->schmidt.assign(schmidt, schmidt + nscal);
+        d->scal_jmin.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
+        d->scal_jmax.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
         hk(hipMalloc((void **)&d->bcs_hb, (size_t)nx * nz * sizeof(double)), "hipMalloc");
         hk(hipMalloc((void **)&d->bcs_ht, (size_t)nx * nz * sizeof(double)), "hipMalloc");
         *out = d.release();
@@ -151,16 +156,45 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     ok(tlab_opr_poisson(d->poisson, nx, ny, nz, TLAB_BCS_NN, tmp1, tmp2, tmp4, d->bcs_hb, d->bcs_ht, tmp3), "OPR_Poisson");
     ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
     ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
+    // ---- boundary conditions (:360-398): Dirichlet -> the tendency vanishes on the wall plane; Neumann -> the wall tendency
+    // keeps d/dy = 0 there (BOUNDARY_BCS_NEUMANN_Y on the finished tendency; tmp1 is its work array as in the reference) ----
+    auto ibc_of = [](int tmin, int tmax) { return (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0); };
+    int ibc_q[3], any_q = 0;
+    for (int iq = 0; iq < 3; ++iq) any_q |= (ibc_q[iq] = ibc_of(d->flow_jmin[iq], d->flow_jmax[iq]));
+    // planes of a field: Neumann values where selected, zeros (null) elsewhere
+    auto planes = [&](int ibc, const double *h, const double *&pb, const double *&pt) {
+        pb = pt = nullptr;
+        if (ibc == 0) return;
+        ok(tlab_boundary_bcs_neumann_y(gy, ibc, nx, ny, nz, h, d->bcs_hb, d->bcs_ht, tmp1), "BOUNDARY_BCS_NEUMANN_Y");
+        if (ibc & 1) pb = d->bcs_hb;
+        if (ibc & 2) pt = d->bcs_ht;
+    };
+    const double *pb, *pt;
     if (tail_update) {
         // hq -= grad p (:348-352), wall planes (:373-375), q += dte hq (time.f90:645-664), hq *= kco (:272-297) in one pass per field
         double *gp[3] = {tmp2, tmp3, tmp4};
-        for (int iq = 0; iq < 3; ++iq) hk(launch_final_update(q[iq], hq[iq], gp[iq], dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
-        for (int is = 0; is < d->nscal; ++is) hk(launch_final_update(s[is], hs[is], nullptr, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+        if (any_q) {   // the Neumann planes need the finished tendency first
+            hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
+            gp[0] = gp[1] = gp[2] = nullptr;
+        }
+        for (int iq = 0; iq < 3; ++iq) {
+            planes(ibc_q[iq], hq[iq], pb, pt);
+            hk(launch_final_update(q[iq], hq[iq], gp[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+        }
+        for (int is = 0; is < d->nscal; ++is) {
+            planes(ibc_of(d->scal_jmin[is], d->scal_jmax[is]), hs[is], pb, pt);
+            hk(launch_final_update(s[is], hs[is], nullptr, pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+        }
     } else {
         hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
-        // boundary conditions (:360-398): no-slip walls / Dirichlet scalars -> tendencies vanish on the wall planes
-        for (int iq = 0; iq < 3; ++iq) hk(launch_fill_wall_planes(hq[iq], 0.0, 0.0, nx, ny, nz, st), "wall planes");
-        for (int is = 0; is < d->nscal; ++is) hk(launch_fill_wall_planes(hs[is], 0.0, 0.0, nx, ny, nz, st), "wall planes");
+        for (int iq = 0; iq < 3; ++iq) {
+            planes(ibc_q[iq], hq[iq], pb, pt);
+            hk(launch_set_wall_planes(hq[iq], pb, pt, nx, ny, nz, st), "wall planes");
+        }
+        for (int is = 0; is < d->nscal; ++is) {
+            planes(ibc_of(d->scal_jmin[is], d->scal_jmax[is]), hs[is], pb, pt);
+            hk(launch_set_wall_planes(hs[is], pb, pt, nx, ny, nz, st), "wall planes");
+        }
     }
 }
 
@@ -194,6 +228,25 @@ int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double k
     }
 }
 
+int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax) {
+    auto valid = [](int t) { return t == TLAB_DNS_BCS_DIRICHLET || t == TLAB_DNS_BCS_NEUMANN; };
+    if (!d || !flow_jmin || !flow_jmax || (d->nscal > 0 && (!scal_jmin || !scal_jmax))) {
+        tlab_set_error("tlab_dns_set_bcs: bad arguments");
+        return TLAB_EINVAL;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (!valid(flow_jmin[i]) || !valid(flow_jmax[i])) { tlab_set_error("tlab_dns_set_bcs: type must be DNS_BCS_DIRICHLET or DNS_BCS_NEUMANN"); return TLAB_EINVAL; }
+    for (int i = 0; i < d->nscal; ++i)
+        if (!valid(scal_jmin[i]) || !valid(scal_jmax[i])) { tlab_set_error("tlab_dns_set_bcs: type must be DNS_BCS_DIRICHLET or DNS_BCS_NEUMANN"); return TLAB_EINVAL; }
+    if (flow_jmin[1] != TLAB_DNS_BCS_DIRICHLET || flow_jmax[1] != TLAB_DNS_BCS_DIRICHLET) {
+        tlab_set_error("tlab_dns_set_bcs: the wall-normal velocity must be Dirichlet (impermeable walls; the pressure BCs assume v = 0)");
+        return TLAB_EUNSUPPORTED;
+    }
+    for (int i = 0; i < 3; ++i) { d->flow_jmin[i] = flow_jmin[i]; d->flow_jmax[i] = flow_jmax[i]; }
+    for (int i = 0; i < d->nscal; ++i) { d->scal_jmin[i] = scal_jmin[i]; d->scal_jmax[i] = scal_jmax[i]; }
+    return TLAB_OK;
+}
+
 int tlab_dns_set_fusion(tlab_dns_t d, int on) {
     if (!d) return TLAB_EINVAL;
     d->fuse = on != 0;
@@ -218,5 +271,6 @@ int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const doub
 int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n) { PW_GUARD(launch_rk_update(q, h, dte, kco, scale, n, tlab_current_stream())) }
 int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz) { PW_GUARD(launch_get_wall_planes(f, hb, ht, nx, ny, nz, tlab_current_stream())) }
 int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz) { PW_GUARD(launch_fill_wall_planes(f, vb, vt, nx, ny, nz, tlab_current_stream())) }
+int tlab_pw_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz) { PW_GUARD(launch_set_wall_planes(f, pb, pt, nx, ny, nz, tlab_current_stream())) }
 
 }  // extern "C"

@@ -9,6 +9,36 @@ from .lib import load, check, TlabError, c_vp
 from .operators import FdmPlan, PoissonPlan, _use_torch_stream
 
 RKM_EXP3, RKM_EXP4 = 3, 4
+DNS_BCS_DIRICHLET, DNS_BCS_NEUMANN = 3, 4          # tools/dns/boundary_bcs.f90:18-19
+
+
+def velocity_bcs(kind):
+    """[BoundaryConditions] VelocityJmin/Jmax keyword -> BcsFlowJm%type(1:3), tools/dns/boundary_bcs.f90:112-121."""
+    kind = kind.strip().lower()
+    if kind == "noslip":
+        return [DNS_BCS_DIRICHLET] * 3
+    if kind == "freeslip":
+        return [DNS_BCS_NEUMANN, DNS_BCS_DIRICHLET, DNS_BCS_NEUMANN]
+    raise TlabError("BoundaryConditions.Velocity: noslip or freeslip")
+
+
+def scalar_bcs(kind):
+    kind = kind.strip().lower()
+    if kind == "dirichlet":
+        return DNS_BCS_DIRICHLET
+    if kind == "neumann":
+        return DNS_BCS_NEUMANN
+    raise TlabError("BoundaryConditions.Scalar: dirichlet or neumann")
+
+
+def _bcs_arrays(nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax):
+    IA = ctypes.c_int * 3
+    fj0, fj1 = IA(*velocity_bcs(velocity_jmin)), IA(*velocity_bcs(velocity_jmax))
+    SA = ctypes.c_int * max(nscal, 1)
+    as_list = lambda v: [v] * nscal if isinstance(v, str) else list(v)      # noqa: E731
+    sj0 = SA(*[scalar_bcs(k) for k in as_list(scalar_jmin)] or [DNS_BCS_DIRICHLET])
+    sj1 = SA(*[scalar_bcs(k) for k in as_list(scalar_jmax)] or [DNS_BCS_DIRICHLET])
+    return fj0, fj1, sj0, sj1
 
 
 def rk_coefficients(mode):
@@ -53,6 +83,11 @@ class Dns:
                                      self.nx, self.ny, self.nz, self.nscal, self.visc,
                                      sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "tlab_dns_create")
         self._ptrs = None
+
+    def set_bcs(self, velocity_jmin="noslip", velocity_jmax="noslip", scalar_jmin="dirichlet", scalar_jmax="dirichlet"):
+        """Wall boundary conditions in y by the reference's dns.ini keywords ([BoundaryConditions], boundary_bcs.f90:102-190)."""
+        fj0, fj1, sj0, sj1 = _bcs_arrays(self.nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax)
+        check(load().tlab_dns_set_bcs(self._h, fj0, fj1, sj0, sj1), "tlab_dns_set_bcs")
 
     def set_fusion(self, on):
         """on (default): pointwise sums folded into the operator kernels; off: the reference's literal sequence."""

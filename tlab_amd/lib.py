@@ -53,6 +53,9 @@ SIGNATURES = {
     "tlab_dns_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, _dp]),
     "tlab_dns_destroy": (c_int, [c_vp]),
     "tlab_dns_set_fusion": (c_int, [c_vp, c_int]),
+    "tlab_dns_set_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "tlab_boundary_bcs_neumann_y": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "tlab_pw_set_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int]),
     "tlab_rhs_global_incompressible_1": (c_int, [c_vp, c_dbl, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
     "tlab_time_substep_incompressible_explicit": (c_int, [c_vp, c_dbl, c_dbl, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
     "tlab_transpose": (c_int, [c_vp, c_int, c_int, c_vp]),

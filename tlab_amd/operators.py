@@ -151,6 +151,14 @@ def OPR_Partial_Z(type, nx, ny, nz, bcs, g, u, result, tmp1=None):
     _partial(3, type, nx, ny, nz, bcs, g, u, result, tmp1)
 
 
+def BOUNDARY_BCS_NEUMANN_Y(ibc, nx, ny, nz, g, u, bcs_hb, bcs_ht, tmp1):
+    """tools/dns/boundary_bcs.f90:368: wall planes (nx*nz) of u such that du/dy = 0 at jmin (ibc=1), jmax (2) or both (3)."""
+    n = nx * ny * nz
+    _use_torch_stream()
+    check(load().tlab_boundary_bcs_neumann_y(g._h, int(ibc), nx, ny, nz, _ptr(u, n, "u"), _ptr(bcs_hb, nx * nz, "bcs_hb"),
+                                             _ptr(bcs_ht, nx * nz, "bcs_ht"), _ptr(tmp1, n, "tmp1")), "tlab_boundary_bcs_neumann_y")
+
+
 def _burgers(idir, ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, write_transposed):
     n = nx * ny * nz
     b = np.asarray(bcs) if not isinstance(bcs, (int, np.integer)) else None

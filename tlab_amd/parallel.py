@@ -21,7 +21,7 @@ import numpy as np
 
 from .lib import load, check, TlabError, c_vp
 from .operators import FdmPlan, _use_torch_stream, _ptr
-from .dns import rk_coefficients, RKM_EXP3
+from .dns import rk_coefficients, RKM_EXP3, DNS_BCS_DIRICHLET, DNS_BCS_NEUMANN, _bcs_arrays
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -115,6 +115,8 @@ class SlabDns:
                   FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
         self.kdt, self.kco = rk_coefficients(rkm_mode)
         self.rkm_endstep = len(self.kdt)
+        self.flow_jmin, self.flow_jmax = [DNS_BCS_DIRICHLET] * 3, [DNS_BCS_DIRICHLET] * 3
+        self.scal_jmin, self.scal_jmax = [DNS_BCS_DIRICHLET] * self.nscal, [DNS_BCS_DIRICHLET] * self.nscal
         self.isize_txc = (self.nx + 2) * self.ny * self.kmax
         L = load()
         self.st = {}
@@ -245,8 +247,24 @@ class SlabDns:
         self.partial_z(0, 3)                                                                                               # :320
         self._local(lambda r, S: check(L.tlab_pw_sub3(_ptr(S["hq"][0]), _ptr(S["hq"][1]), _ptr(S["hq"][2]), _ptr(T(S, 1)), _ptr(T(S, 2)),
                                                       _ptr(T(S, 3)), n), "sub3"))
-        for key in ("hq", "hs"):                                                                                           # :373-375, :394-396
-            self._local(lambda r, S: [check(L.tlab_pw_fill_wall_planes(_ptr(t), 0.0, 0.0, nx, ny, kmax), "walls") for t in S[key]])
+        # boundary conditions (:360-398); y is local to a z-slab, so BOUNDARY_BCS_NEUMANN_Y needs no communication
+        types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
+
+        def walls(r, S):
+            for h, (tmin, tmax) in zip(S["hq"] + S["hs"], types):
+                ibc = (1 if tmin == DNS_BCS_NEUMANN else 0) + (2 if tmax == DNS_BCS_NEUMANN else 0)
+                if ibc:
+                    check(L.tlab_boundary_bcs_neumann_y(gy._h, ibc, nx, ny, kmax, _ptr(h), _ptr(S["hb"]), _ptr(S["ht"]), _ptr(T(S, 0))), "bcs_neumann_y")
+                check(L.tlab_pw_set_wall_planes(_ptr(h), _ptr(S["hb"]) if ibc & 1 else None, _ptr(S["ht"]) if ibc & 2 else None, nx, ny, kmax), "walls")
+        self._local(walls)
+
+    def set_bcs(self, velocity_jmin="noslip", velocity_jmax="noslip", scalar_jmin="dirichlet", scalar_jmax="dirichlet"):
+        """As Dns.set_bcs (dns.ini [BoundaryConditions] keywords, boundary_bcs.f90:102-190)."""
+        fj0, fj1, sj0, sj1 = _bcs_arrays(self.nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax)
+        if fj0[1] != DNS_BCS_DIRICHLET or fj1[1] != DNS_BCS_DIRICHLET:
+            raise TlabError("the wall-normal velocity must be Dirichlet")
+        self.flow_jmin, self.flow_jmax = list(fj0), list(fj1)
+        self.scal_jmin, self.scal_jmax = list(sj0)[: self.nscal], list(sj1)[: self.nscal]
 
     def TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(self, dte, kco=1.0, scale_tendencies=False):
         self.RHS_GLOBAL_INCOMPRESSIBLE_1(dte)
