@@ -141,10 +141,45 @@ int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, 
  *   set_wall_planes, fft_x(+1), [K-forward], fft_z(+1), [K-backward], ode, [K-forward], fft_z(-1), [K-backward], fft_x(-1).  */
 int tlab_poisson_plan_create_slab(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                                   int nx, int ny, int kmax, int nz_total, int koffset, int nproc_k);
+/* kx-pencil variant: the physical box is the z-slab (nx, ny, kmax); the spectral box holds the kx range [ioffset, ioffset+nxl) of
+ * ALL kz: (nxl, ny, nz_total).  One all-to-all (slab -> pencil) after fft_x(+1) and one before fft_x(-1) replace the four
+ * K-transposes per field of the plan above; fft_z and ode then work on the pencil:
+ *   set_wall_planes, fft_x(+1), [slab->pencil], fft_z(+1), ode, fft_z(-1), [pencil->slab], fft_x(-1).  */
+int tlab_poisson_plan_create_pencil(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                                    int nx, int ny, int kmax, int nz_total, int ioffset, int nxl);
 int tlab_poisson_set_wall_planes(tlab_poisson_plan_t plan, double *p, const double *bcs_hb, const double *bcs_ht);
 int tlab_poisson_fft_x(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* OPR_Fourier_X_Forward/Backward, opr_fourier.f90:219,277 */
 int tlab_poisson_fft_z(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* the FFT inside OPR_Fourier_Z_*, :355,422 */
 int tlab_poisson_ode(tlab_poisson_plan_t plan, double *f_hat, double *p_hat, double *dp_hat); /* mode loop of opr_elliptic.f90:308-333 */
+
+/* Accumulating forms of the two operators, as the RHS uses them (hq = hq + OPR_Burgers(...), tmp = tmp + OPR_Partial(hq + q/dte)):
+ *   tlab_opr_burgers_add : result += nu d2s/dx2 - vel ds/dx                       (rhs_global_incompressible_1.f90:98-136 + :106-112)
+ *   tlab_opr_partial_add : result (+)= d/dx (u + scale*ub)   (ub may be NULL; acc = 0 overwrites)        (:197-201, :228-230, :257-259)
+ * One fused kernel when the sizes are on a fast path; otherwise the reference's own sequence with the temporaries tmp1, tmp2. */
+int tlab_opr_burgers_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
+                         double *result, double *tmp1, double *tmp2);
+int tlab_opr_partial_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub, double scale,
+                         double *result, int acc, double *tmp1, double *tmp2);
+
+/* ---- z-derivatives on a z-slab without transposes (multi-GPU) ---------------------------------------------
+ * Replaces TLabMPI_Trp_ExecK_Forward + OPR_Partial_Z / OPR_Burgers_Z + TLabMPI_Trp_ExecK_Backward (opr_partial.f90:154-262,
+ * opr_burgers.f90:331-440, base/tlab_mpi_transpose.f90:343-458) for a periodic z split into slabs of kmax planes: the compact
+ * system is partitioned at the slab boundaries, so that a slab only needs 3 halo planes of the operand and, per line and
+ * implicit system, one value from each neighbour (see tlab_amd/csrc/zslab.hip).  Two-phase protocol per operator:
+ *   phase 1: head[nsys][nx*ny], tail[nsys][nx*ny] are written          (nsys = 1 for partial_z, 2 for burgers_z)
+ *   caller:  tail -> right neighbour (arrives as tail_left), head -> left neighbour (arrives as head_right)
+ *   phase 2: result = d/dz (u [+ scale*ub])   resp.   nu d2s/dz2 - vel ds/dz ;  acc != 0: result += ...
+ * Every operand pointer addresses the first plane of the slab and must have 3 valid planes before it and after the slab
+ * (the neighbours' planes, periodic in z).  plan_create returns TLAB_EUNSUPPORTED when the slab is too thin for the coupling
+ * between slab separators to vanish in double precision (kmax >~ 48 for the sixth-order schemes): keep the transpose path then.
+ * chunk: rows per wave (0 = automatic, 16 or 32). */
+typedef struct tlab_zslab_plan *tlab_zslab_plan_t;
+int tlab_zslab_plan_create(tlab_zslab_plan_t *out, tlab_fdm_plan_t gz, int kmax, int koffset, int chunk);
+int tlab_zslab_plan_destroy(tlab_zslab_plan_t plan);
+int tlab_zslab_partial_z(tlab_zslab_plan_t plan, int phase, int nx, int ny, const double *u, const double *ub, double scale,
+                         double *head, double *tail, const double *tail_left, const double *head_right, double *result, int acc);
+int tlab_zslab_burgers_z(tlab_zslab_plan_t plan, int phase, int nx, int ny, double nu, const double *s, const double *vel,
+                         double *head, double *tail, const double *tail_left, const double *head_right, double *result, int acc);
 
 /* ---- RHS assembly and Runge-Kutta substep ("next" row n1 of SURVEY.md 8f) --------------------------------- */
 /* Module state the reference spreads over TLab_Memory / NavierStokes / OPR_Burgers / BOUNDARY_BCS: plans, sizes,
@@ -193,6 +228,10 @@ int tlab_pw_axpy3(double *o1, double *o2, double *o3, const double *h1, const do
 int tlab_pw_sum3(double *a, const double *b, const double *c, long long n);                              /* a = a + b + c    */
 int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n); /* h -= .., x3 */
 int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n);             /* q += dte h; h *= kco */
+/* fused tail of a substep for one field: h -= g (g may be NULL); wall planes of h = pb / pt (NULL = zeros); q += dte h; h *= kco if scale
+ * (rhs_global_incompressible_1.f90:348-352, :373-375; time.f90:645-664, :272-297) */
+int tlab_pw_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
+                         int nx, int ny, int nz);
 int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz);
 int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz);
 int tlab_pw_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz);      /* NULL plane = zeros */

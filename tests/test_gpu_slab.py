@@ -18,8 +18,12 @@ def T():
     return T
 
 
-@pytest.mark.parametrize("P,nx,ny,nz,bcs", [(2, 64, 32, 32, "noslip"), (4, 32, 64, 64, "noslip"), (8, 64, 32, 64, "noslip"), (4, 64, 32, 32, "freeslip")])
-def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs):
+@pytest.mark.parametrize("P,nx,ny,nz,bcs,zmode,zchunk", [
+    (2, 64, 32, 32, "noslip", "auto", 0), (4, 32, 64, 64, "noslip", "auto", 0), (8, 64, 32, 64, "noslip", "auto", 0), (4, 64, 32, 32, "freeslip", "auto", 0),
+    # thick slabs: the transpose-free algorithm (halo planes + interface values from the neighbours, kx-pencil Poisson)
+    (2, 32, 16, 128, "noslip", "halo", 0), (2, 32, 16, 128, "noslip", "halo", 16), (4, 64, 24, 256, "freeslip", "halo", 0), (8, 32, 16, 512, "noslip", "halo", 0),
+    (2, 32, 16, 128, "noslip", "transpose", 0), (3, 48, 16, 192, "noslip", "halo", 0)])
+def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs, zmode, zchunk):
     import torch
     from tlab_amd.dns import Dns
     from tlab_amd.parallel import SlabDns, LoopbackComm
@@ -32,7 +36,8 @@ def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs):
     fields = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
     visc, sc = 1.0 / 600.0, (0.8,)
     one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
-    slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+    slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, zmode=zmode, zchunk=zchunk)
+    assert slab.zmode == ("transpose" if nz // P < 48 else zmode if zmode != "auto" else "halo")
     if bcs == "freeslip":
         one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
         slab.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
@@ -51,3 +56,13 @@ def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs):
             got = torch.cat([slab.st[r][name][i] for r in range(P)])
             err = float((got - rf).abs().max() / rf.abs().max())
             assert err <= 1e-11, (name, i, err)
+
+
+def test_thin_slabs_refuse_halo_mode(T):
+    from tlab_amd.parallel import SlabDns, LoopbackComm
+    x = np.arange(32) / 32.0
+    y = np.arange(16) / 15.0
+    z = np.arange(64) / 64.0
+    with pytest.raises(T.TlabError):
+        SlabDns(LoopbackComm(4), x, y, z, zmode="halo")          # kmax = 16: slab separators still couple at 1e-7
+    assert SlabDns(LoopbackComm(4), x, y, z, zmode="auto").zmode == "transpose"

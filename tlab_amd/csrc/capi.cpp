@@ -570,6 +570,40 @@ int tlab_set_tuning(int key, int value) {
     return TLAB_EINVAL;
 }
 
+// Accumulating variants (no counterpart in the reference, which always goes through a temporary and a pointwise loop,
+// rhs_global_incompressible_1.f90:106-112, :257-259): fused kernels when the sizes are on a fast path, the reference's sequence otherwise.
+int tlab_opr_burgers_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
+                         double *result, double *tmp1, double *tmp2) {
+    return guarded([&] {
+        check_common(dir, g, nx, ny, nz, ibc);
+        if (!s || !vel || !result || result == s || result == vel) throw Invalid("tlab_opr_burgers_add: null or aliased arrays");
+        if (tlab_internal_burgers_acc(dir, g, nx, ny, nz, ibc, nu, s, vel, result)) return;
+        if (!tmp1 || !tmp2 || tmp1 == tmp2 || tmp1 == result || tmp2 == result) throw Invalid("tlab_opr_burgers_add: the unfused path needs tmp1, tmp2");
+        const int rc = tlab_opr_burgers(dir, g, s == vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, nx, ny, nz, ibc, nu, s, vel, tmp1, tmp2, 0);
+        if (rc != TLAB_OK) throw Invalid(std::string("tlab_opr_burgers_add: ") + g_err);
+        hip_check(launch_add1(result, tmp1, (long long)nx * ny * nz, g_stream), "k_add1");
+    });
+}
+
+int tlab_opr_partial_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub, double scale,
+                         double *result, int acc, double *tmp1, double *tmp2) {
+    return guarded([&] {
+        check_common(dir, g, nx, ny, nz, ibc);
+        if (!u || !result || result == u || result == ub) throw Invalid("tlab_opr_partial_add: null or aliased arrays");
+        if (tlab_internal_partial_p1_fused(dir, g, nx, ny, nz, ibc, u, ub, scale, result, acc != 0)) return;
+        if (!tmp1 || !tmp2 || tmp1 == tmp2 || tmp1 == result || tmp2 == result) throw Invalid("tlab_opr_partial_add: the unfused path needs tmp1, tmp2");
+        const long long n = (long long)nx * ny * nz;
+        const double *operand = u;
+        if (ub) {
+            hip_check(launch_axpy1(tmp1, u, ub, scale, n, g_stream), "k_axpy1");
+            operand = tmp1;
+        }
+        const int rc = tlab_opr_partial(dir, g, TLAB_OPR_P1, nx, ny, nz, ibc, operand, acc ? tmp2 : result, nullptr);
+        if (rc != TLAB_OK) throw Invalid(std::string("tlab_opr_partial_add: ") + g_err);
+        if (acc) hip_check(launch_add1(result, tmp2, n, g_stream), "k_add1");
+    });
+}
+
 // BOUNDARY_BCS_NEUMANN_Y (tools/dns/boundary_bcs.f90:368-473): the reduced derivative (zero at the chosen walls) is the ordinary
 // OPR_Partial_Y under ibc; the wall values follow from the first / last row of the compact scheme in a plane kernel.
 int tlab_boundary_bcs_neumann_y(tlab_fdm_plan_t g, int ibc, int nx, int ny, int nz, const double *u, double *bcs_hb, double *bcs_ht,

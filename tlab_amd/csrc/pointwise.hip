@@ -153,7 +153,28 @@ __global__ void __launch_bounds__(256) k_final_update(double *__restrict__ q, do
     }
 }
 
+// h += a ; o = a + s*b   (fallbacks of the fused accumulate entry points)
+__global__ void __launch_bounds__(256) k_add1(double *__restrict__ h, const double *__restrict__ a, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) h[i] = h[i] + a[i];
+}
+__global__ void __launch_bounds__(256) k_axpy1(double *__restrict__ o, const double *__restrict__ a, const double *__restrict__ b, double s, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = a[i] + b[i] * s;
+}
+
 #define CHECK_LAUNCH() hipGetLastError()
+
+hipError_t launch_add1(double *h, const double *a, long long n, hipStream_t st) {
+    ProfScope ps("k_add1", st, (double)n * 24);
+    hipLaunchKernelGGL(k_add1, dim3(pw_grid(n)), dim3(256), 0, st, h, a, n);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_axpy1(double *o, const double *a, const double *b, double s, long long n, hipStream_t st) {
+    ProfScope ps("k_axpy1", st, (double)n * 24);
+    hipLaunchKernelGGL(k_axpy1, dim3(pw_grid(n)), dim3(256), 0, st, o, a, b, s, n);
+    return CHECK_LAUNCH();
+}
 
 hipError_t launch_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
                                int nx, int ny, int nz, hipStream_t st) {

@@ -496,6 +496,8 @@ bool g_rocfft_up = false;
 struct tlab_poisson_plan {
     int nx = 0, ny = 0, nz = 0, nxh = 0;   // nz = local number of z planes (kmax)
     int nzt = 0, koff = 0, nproc = 1;      // global nz, first global plane of this slab, number of z slabs
+    int ioff = 0;                          // first global kx of the local spectral box (kx-pencil plans; nxh is then the local count)
+    int fx_nxh = 0, fx_nz = 0;             // x-transform geometry: complex row length nx/2+1 and number of planes it is batched over
     long long nm = 0;                 // local modes = nxh * nz
     double norm = 1.0;
     Int1Tables tmin, tmax;            // host copies
@@ -562,7 +564,8 @@ void build_fft(tlab_poisson_plan &P) {
         fftc(rocfft_setup(), "setup");
         g_rocfft_up = true;
     }
-    const size_t nx = P.nx, ny = P.ny, nz = P.nz, nxh = P.nxh;
+    const size_t nx = P.nx, ny = P.ny, nxh = P.fx_nxh;
+    size_t nz = P.fx_nz;
     {   // x: real -> complex, batch ny*nz (dfftw_plan_many_dft_r2c, opr_fourier.f90:163-166)
         rocfft_plan_description d = nullptr;
         fftc(rocfft_plan_description_create(&d), "desc");
@@ -589,7 +592,8 @@ void build_fft(tlab_poisson_plan &P) {
     }
     if (P.nzt > 1) {  // z: complex <-> complex, stride = batch = nlines with distance 1 (dfftw_plan_many_dft, :111-119);
         // nlines = (imax/2+1)*jmax, or tmpi_plan_fftz%nlines = that / npro_k after the K-transposition (opr_fourier.f90:85-98)
-        const size_t nlines = nxh * ny * nz / (size_t)P.nzt;
+        nz = P.nz;
+        const size_t nlines = (size_t)P.nxh * ny * nz / (size_t)P.nzt;
         for (int dir = 0; dir < 2; ++dir) {
             rocfft_plan_description d = nullptr;
             fftc(rocfft_plan_description_create(&d), "desc");
@@ -663,8 +667,9 @@ extern bool tlab_device_ready();
 
 extern "C" {
 
+// nz: planes of the local spectral box; [ioff, ioff+nxl) its kx range (nxl = 0: all nx/2+1); fx_nz: planes of the local PHYSICAL box
 static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
-                                    int nz, int nzt, int koff, int nproc) {
+                                    int nz, int nzt, int koff, int nproc, int ioff = 0, int nxl = 0, int fx_nz = 0) {
     try {
         if (!out || !gx || !gy || !gz) throw std::invalid_argument("tlab_poisson_plan_create: null argument");
         if (!tlab_device_ready()) throw std::runtime_error("tlab_init has not been called (no CPU fallback exists)");
@@ -675,7 +680,10 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         if (nproc < 1 || nz * nproc != nzt || koff < 0 || koff + nz > nzt) throw std::invalid_argument("bad z-slab decomposition");
         if (((long long)(nx / 2 + 1) * ny) % nproc != 0) throw std::invalid_argument("(imax/2+1)*jmax must be divisible by the number of z slabs (tlab_mpi_transpose.f90:292)");
         auto P = std::make_unique<tlab_poisson_plan>();
-        P->nx = nx; P->ny = ny; P->nz = nz; P->nxh = nx / 2 + 1;
+        if (nxl < 0 || ioff < 0 || ioff + nxl > nx / 2 + 1) throw std::invalid_argument("bad kx range");
+        P->nx = nx; P->ny = ny; P->nz = nz; P->nxh = nxl > 0 ? nxl : nx / 2 + 1;
+        P->ioff = nxl > 0 ? ioff : 0;
+        P->fx_nxh = nx / 2 + 1; P->fx_nz = fx_nz > 0 ? fx_nz : nz;
         P->nzt = nzt; P->koff = koff; P->nproc = nproc;
         P->nm = (long long)P->nxh * nz;
         P->norm = 1.0 / ((double)nx * (double)nzt);                     // opr_elliptic.f90:130
@@ -689,7 +697,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         std::vector<unsigned char> skip((size_t)nm, 0);
         for (int k = 0; k < nz; ++k)
             for (int i = 0; i < P->nxh; ++i) {
-                double l2 = std::pow(gx->t.der1.mwn[i], 2.0);
+                double l2 = std::pow(gx->t.der1.mwn[P->ioff + i], 2.0);
                 if (nzt > 1) l2 += std::pow(gz->t.der1.mwn[koff + k], 2.0);   // kglobal = k + ims_offset_k (:191)
                 lam[(size_t)i + (size_t)P->nxh * k] = std::sqrt(l2);
             }
@@ -697,8 +705,9 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b) {
                 const int kl = ksg[b] - koff;                               // task-local index (:177-178)
-                if (kl < 0 || kl >= nz) continue;
-                const int t = isg[a] + P->nxh * kl;
+                const int il = isg[a] - P->ioff;
+                if (kl < 0 || kl >= nz || il < 0 || il >= P->nxh) continue;
+                const int t = il + P->nxh * kl;
                 if (!skip[t]) { skip[t] = 1; P->sing_modes.push_back(t); }
             }
         P->lam.upload(lam);
@@ -721,7 +730,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         {   // fused 2-D (x,z) transforms are ~2x faster than r2c(x) + strided c2c(z) at 512^3, but rocFFT does not build them
             // for every layout: fall back to the two 1-D plans when plan creation fails (TLAB_FFT2D=0 forces the 1-D path)
             const char *e = getenv("TLAB_FFT2D");
-            if (nzt > 1 && nproc == 1 && !(e && atoi(e) == 0)) {
+            if (nzt > 1 && nproc == 1 && nxl == 0 && !(e && atoi(e) == 0)) {
                 try {
                     build_fft_2d(*P);
                     P->use_2d = true;
@@ -755,6 +764,15 @@ int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_
 int tlab_poisson_plan_create_slab(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
                                   int kmax, int nz_total, int koffset, int nproc_k) {
     return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, kmax, nz_total, koffset, nproc_k);
+}
+
+int tlab_poisson_plan_create_pencil(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
+                                    int kmax, int nz_total, int ioffset, int nxl) {
+    if (nxl <= 0 || kmax <= 0 || nz_total % kmax != 0) {
+        tlab_set_error("tlab_poisson_plan_create_pencil: bad decomposition");
+        return TLAB_EINVAL;
+    }
+    return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, nz_total, nz_total, 0, 1, ioffset, nxl, kmax);
 }
 
 int tlab_poisson_plan_destroy(tlab_poisson_plan_t p) {
@@ -833,7 +851,8 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
     POISSON_GUARD_BEGIN
     if (!P || !p || !tmp1 || !tmp2 || !bcs_hb || !bcs_ht) throw std::invalid_argument("tlab_opr_poisson: null argument");
     if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_poisson: sizes do not match the plan");
-    if (P->nproc != 1) throw std::invalid_argument("tlab_opr_poisson: plan is a z-slab plan; drive its stages with the transposes in between");
+    if (P->nproc != 1 || P->nxh != P->fx_nxh || P->fx_nz != P->nz)
+        throw std::invalid_argument("tlab_opr_poisson: plan is a z-slab / kx-pencil plan; drive its stages with the transposes in between");
     if (ibc != TLAB_BCS_NN) {
         tlab_set_error("OPR_Poisson: only BCS_NN is built on the device (the RHS call, rhs_global_incompressible_1.f90:284)");
         return TLAB_EUNSUPPORTED;
@@ -874,8 +893,8 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
 int tlab_poisson_set_wall_planes(tlab_poisson_plan_t P, double *p, const double *bcs_hb, const double *bcs_ht) {
     POISSON_GUARD_BEGIN
     if (!P || !p || !bcs_hb || !bcs_ht) throw std::invalid_argument("null argument");
-    hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)P->nx * P->nz + 255) / 256)), dim3(256), 0, tlab_current_stream(), p,
-                       bcs_hb, bcs_ht, P->nx, P->ny, P->nz);
+    hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)P->nx * P->fx_nz + 255) / 256)), dim3(256), 0, tlab_current_stream(), p,
+                       bcs_hb, bcs_ht, P->nx, P->ny, P->fx_nz);
     POISSON_GUARD_END
 }
 // dir = +1: real (nx,ny,kmax) -> complex (nx/2+1,ny,kmax)  [OPR_Fourier_X_Forward]; dir = -1: the inverse [OPR_Fourier_X_Backward]

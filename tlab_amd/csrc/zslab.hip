@@ -1,0 +1,383 @@
+// z-derivative operators on a z-SLAB without transposing the field (multi-GPU, one slab of kmax planes per GPU).
+//
+// The reference computes d/dz on a decomposed domain by transposing every operand to complete z-lines with an all-to-all
+// (TLabMPI_Trp_ExecK_Forward/Backward around OPR_Partial_Z / OPR_Burgers_Z, opr_partial.f90:154-262, opr_burgers.f90:331-440).
+// On point-to-point xGMI that moves the whole field twice per operator.  Here the implicit (compact) system is split at the
+// slab boundaries instead -- the same partitioned Thomas algorithm the single-GPU kernels use between the waves of a workgroup
+// (chunked.hpp), one level up:
+//
+//   slab of rank r = rows [k0, k0+kmax) of the periodic line; row k0 is the slab's separator S_r, the rest its interior.
+//   interior:   x = y + X_r V + X_{r+1} W,   y = T_loc^-1 [0, f_1 .. f_{kmax-1}]   (T_loc: slab rows, identity first row)
+//   separator:  alpha X_{r-1} + beta X_r + gamma X_{r+1} = f_S - a_S y^{r-1}_last - c_S y^r_1
+//
+// alpha, gamma are the far ends of the slab-level spikes, ~0.38^kmax for the sixth-order compact schemes: below 1e-19 beta for
+// kmax >= 48, i.e. exactly zero in double precision (checked at plan creation; thinner slabs are refused and the caller keeps
+// the transpose path).  The interface system is then diagonal and each slab needs only
+//   tail  = y_last            from its left  neighbour    (8 B per line and system)
+//   head  = f_S - c_S y_1     from its right neighbour
+// plus 3 halo planes of the operand for the explicit stencils: a neighbour exchange of a few planes instead of two
+// all-to-alls of the field.  Phase A computes head/tail, the caller exchanges them, phase B recomputes y (cheaper than storing
+// it), adds the spikes and runs the usual epilogue (first derivative / Burgers, optional accumulation into the tendency).
+//
+// Kernel layout as k_rtile: 64 memory-contiguous lines per workgroup, wave w owns rows [w*M, (w+1)*M) of the slab in registers,
+// coefficient rows are wave-uniform scalar loads, sub-chunks are coupled through LDS with the dense inverse of their separator
+// system.  Fields must carry 3 valid planes before and after the slab (the caller's halo exchange fills them).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tlab_amd.h"
+#include "chunked.hpp"
+#include "device_tables.hpp"
+#include "plan.hpp"
+#include "profile.hpp"
+
+extern hipStream_t tlab_current_stream();
+extern void tlab_set_error(const std::string &s);
+extern bool tlab_device_ready();
+
+namespace tlab {
+
+struct ZSysDev {
+    const double *rowtab;   // [5][kmax] Lm, Dinv, Cm, V, W of the sub-chunked local system T_loc
+    const double *ginv;     // [C][C]
+    const double *vw;       // [2][kmax] slab-level spikes V, W
+    double cS, aS, binv;    // separator row of this slab: head = f_S - cS y_1 ; X = (head - aS tail_left) * binv
+    double aSn, binvn;      // separator row of the right neighbour: X_right = (head_right - aSn tail_mine) * binvn
+};
+
+struct ZSlabArgs {
+    const double *in0;      // operand (first plane of the slab; planes -3..-1 and kmax..kmax+2 are valid halos)
+    const double *in0b;     // optional: operand = in0 + scale * in0b (same halo rule)
+    double scale;
+    const double *vel;      // advecting velocity (Burgers), no halo needed
+    double *out0;
+    int acc;
+    long long nlines;       // nx*ny = row stride
+    int kmax;
+    double c2_1;                    // first-derivative stencil  f = (u+1 - u-1) + c2 (u+2 - u-2)
+    double c0_2, c2_2, c3_2;        // second-derivative stencil f = c0 u + (u+1 + u-1) + c2 (u+2 + u-2) + c3 (u+3 + u-3)
+    ZSysDev y1, y2;
+    double nu;
+    double *head, *tail;                    // phase A out: [nsys][nlines]
+    const double *tail_left, *head_right;   // phase B in:  [nsys][nlines]
+};
+
+// local solve of the slab system (sub-chunks through LDS), then phase handling. f: RHS in, y (phase A) / x (phase B) out
+template <int M, int PHASE>
+__device__ __forceinline__ void z_solve(double (&f)[M], const ZSysDev &sy, int kmax, int w, int C, int lane, bool valid, long long line,
+                                        long long nlines, int isys, const ZSlabArgs &a, double *s_yl, double *s_r, double *s_x) {
+    const int row0 = w * M;
+    double fS = 0.0;
+    if (w == 0) { fS = f[0]; f[0] = 0.0; }
+    const double *Lm = sy.rowtab + row0, *Di = sy.rowtab + kmax + row0, *Cm = sy.rowtab + 2 * kmax + row0;
+    const double *Vt = sy.rowtab + 3 * kmax + row0, *Wt = sy.rowtab + 4 * kmax + row0;
+    double g = 0.0;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        g = f[p] + Lm[p] * g;
+        f[p] = g;
+    }
+    double yn = 0.0;
+#pragma unroll
+    for (int p = M - 1; p >= 1; --p) {
+        yn = f[p] * Di[p] + Cm[p] * yn;
+        f[p] = yn;
+    }
+    s_yl[w * 64 + lane] = f[M - 1];
+    __syncthreads();
+    const int wm = (w + C - 1) % C, wp = (w + 1) % C;
+    const double yLprev = s_yl[wm * 64 + lane];
+    s_r[w * 64 + lane] = f[0] - Lm[0] * yLprev - Cm[0] * f[1];
+    __syncthreads();
+    double X = 0.0, Xr = 0.0;
+    for (int q = 0; q < C; ++q) {
+        const double rq = s_r[q * 64 + lane];
+        X += sy.ginv[w * C + q] * rq;
+        Xr += sy.ginv[wp * C + q] * rq;
+    }
+    f[0] = X;
+#pragma unroll
+    for (int p = 1; p < M; ++p) f[p] = f[p] + Vt[p] * X + Wt[p] * Xr;
+    // f = y now.  Slab-level interface
+    if (PHASE == 1) {
+        if (valid) {
+            if (w == 0) a.head[(long long)isys * nlines + line] = fS - sy.cS * f[1];
+            if (w == C - 1) a.tail[(long long)isys * nlines + line] = f[M - 1];
+        }
+        __syncthreads();   // s_yl / s_r are reused by the next system
+    } else {
+        if (w == 0) s_x[lane] = fS - sy.cS * f[1];
+        if (w == C - 1) s_x[64 + lane] = f[M - 1];
+        __syncthreads();
+        const double tl = valid ? a.tail_left[(long long)isys * nlines + line] : 0.0;
+        const double hr = valid ? a.head_right[(long long)isys * nlines + line] : 0.0;
+        const double XS = (s_x[lane] - sy.aS * tl) * sy.binv;
+        const double XR = (hr - sy.aSn * s_x[64 + lane]) * sy.binvn;
+        const double *Vr = sy.vw + row0, *Wr = sy.vw + kmax + row0;
+#pragma unroll
+        for (int p = 0; p < M; ++p) f[p] = f[p] + Vr[p] * XS + Wr[p] * XR;
+        __syncthreads();
+    }
+}
+
+template <int M, int MODE, int PHASE>
+__global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
+    __shared__ double s_yl[8 * 64];
+    __shared__ double s_r[8 * 64];
+    __shared__ double s_x[2 * 64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: coefficient rows become scalar loads
+    const int C = blockDim.x >> 6;
+    const long long line = (long long)blockIdx.x * 64 + lane;
+    const bool valid = line < a.nlines;
+    const long long rs = a.nlines;
+    const int row0 = w * M;
+    const long long base = valid ? line : 0;
+
+    // operand rows + 3-row halos; no wrap: the rows before / after the slab are the neighbours' planes
+    double e[M + 6];
+#pragma unroll
+    for (int p = 0; p < M + 6; ++p) e[p] = valid ? a.in0[base + (long long)(row0 - 3 + p) * rs] : 0.0;
+    if (MODE == MODE_P1 && a.in0b != nullptr) {
+        double eb[M + 6];
+#pragma unroll
+        for (int p = 0; p < M + 6; ++p) eb[p] = valid ? a.in0b[base + (long long)(row0 - 3 + p) * rs] : 0.0;
+#pragma unroll
+        for (int p = 0; p < M + 6; ++p) e[p] = e[p] + eb[p] * a.scale;
+    }
+    double x1[M], x2[MODE == MODE_BURGERS ? M : 1];
+#pragma unroll
+    for (int p = 0; p < M; ++p) x1[p] = e[p + 4] - e[p + 2] + a.c2_1 * (e[p + 5] - e[p + 1]);
+    if constexpr (MODE == MODE_BURGERS) {
+#pragma unroll
+        for (int p = 0; p < M; ++p)
+            x2[p] = a.c0_2 * e[p + 3] + e[p + 4] + e[p + 2] + a.c2_2 * (e[p + 5] + e[p + 1]) + a.c3_2 * (e[p + 6] + e[p]);
+    }
+    z_solve<M, PHASE>(x1, a.y1, a.kmax, w, C, lane, valid, line, a.nlines, 0, a, s_yl, s_r, s_x);
+    double vl[(MODE == MODE_BURGERS && PHASE == 2) ? M : 1];
+    if constexpr (MODE == MODE_BURGERS && PHASE == 2) {   // issued before the second solve: its latency hides behind it
+#pragma unroll
+        for (int p = 0; p < M; ++p) vl[p] = valid ? a.vel[base + (long long)(row0 + p) * rs] : 0.0;
+    }
+    if constexpr (MODE == MODE_BURGERS) z_solve<M, PHASE>(x2, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, 1, a, s_yl, s_r, s_x);
+    if constexpr (PHASE == 2) {
+        if (!valid) return;
+        if constexpr (MODE == MODE_BURGERS) {
+#pragma unroll
+            for (int p = 0; p < M; ++p) x1[p] = a.nu * x2[p] - vl[p] * x1[p];     // opr_burgers.f90:513
+        }
+        if (a.acc) {
+            double o[M];
+#pragma unroll
+            for (int p = 0; p < M; ++p) o[p] = a.out0[base + (long long)(row0 + p) * rs];
+#pragma unroll
+            for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+        }
+#pragma unroll
+        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x1[p];
+    }
+}
+
+struct ZSysHost {
+    DeviceArray rowtab, ginv, vw;
+    double cS = 0, aS = 0, binv = 0, aSn = 0, binvn = 0;
+    ZSysDev dev() const { return ZSysDev{rowtab.p, ginv.p, vw.p, cS, aS, binv, aSn, binvn}; }
+};
+
+}  // namespace tlab
+
+using namespace tlab;
+
+struct tlab_zslab_plan {
+    int nz = 0, kmax = 0, k0 = 0, M = 0, C = 0;
+    double c2_1 = 0, c0_2 = 0, c2_2 = 0, c3_2 = 0;
+    ZSysHost sys[2];
+};
+
+namespace {
+
+struct Fail : std::runtime_error {
+    int code;
+    Fail(int c, const std::string &s) : std::runtime_error(s), code(c) {}
+};
+
+typedef long double ld;
+
+// slab-level spikes of the slab that starts at global row k0: V = T_loc^-1 e_0, W = T_loc^-1 (-c_last e_last)
+void slab_spikes(const TriDiag &G, int k0, int kmax, TriDiag &Tloc, std::vector<double> &V, std::vector<double> &W) {
+    const int nz = G.n;
+    Tloc.n = kmax;
+    Tloc.periodic = false;
+    Tloc.a.assign(kmax, 0.0); Tloc.b.assign(kmax, 0.0); Tloc.c.assign(kmax, 0.0);
+    Tloc.b[0] = 1.0;
+    for (int i = 1; i < kmax; ++i) {
+        const int g = (k0 + i) % nz;
+        Tloc.a[i] = G.a[g]; Tloc.b[i] = G.b[g]; Tloc.c[i] = (i < kmax - 1) ? G.c[g] : 0.0;
+    }
+    V.assign(kmax, 0.0); W.assign(kmax, 0.0);
+    V[0] = 1.0;
+    W[kmax - 1] = -G.c[(k0 + kmax - 1) % nz];
+    tridiag_solve_direct(Tloc, V.data());
+    tridiag_solve_direct(Tloc, W.data());
+}
+
+void build_system(tlab_zslab_plan &P, const TriDiag &G, ZSysHost &out) {
+    const int nz = G.n, kmax = P.kmax, k0 = P.k0;
+    const int kprev = ((k0 - kmax) % nz + nz) % nz, knext = (k0 + kmax) % nz;
+    TriDiag Tm, Tp, Tn;
+    std::vector<double> Vm, Wm, Vp, Wp, Vn, Wn;
+    slab_spikes(G, k0, kmax, Tm, Vm, Wm);
+    slab_spikes(G, kprev, kmax, Tp, Vp, Wp);
+    slab_spikes(G, knext, kmax, Tn, Vn, Wn);
+    // interface rows: alpha X_{r-1} + beta X_r + gamma X_{r+1}
+    const double aS = G.a[k0], bS = G.b[k0], cS = G.c[k0];
+    const double beta = bS + aS * Wp[kmax - 1] + cS * Vm[1];
+    const double alpha = aS * Vp[kmax - 1], gamma = cS * Wm[1];
+    const double aSn = G.a[knext], bSn = G.b[knext], cSn = G.c[knext];
+    const double betan = bSn + aSn * Wm[kmax - 1] + cSn * Vn[1];
+    const double alphan = aSn * Vm[kmax - 1], gamman = cSn * Wn[1];
+    const double tol = 1e-19;
+    if (std::fabs(alpha) > tol * std::fabs(beta) || std::fabs(gamma) > tol * std::fabs(beta) || std::fabs(alphan) > tol * std::fabs(betan) ||
+        std::fabs(gamman) > tol * std::fabs(betan))
+        throw Fail(TLAB_EUNSUPPORTED, "z-slab operators: slab too thin, the coupling between slab separators (" + std::to_string(std::fabs(alpha / beta)) +
+                                          ") is not below double precision; use the K-transpose path");
+    ChunkedTables ct;
+    build_chunked(Tm, P.C, ct);
+    if ((int)ct.ginv.size() != P.C * P.C) throw Fail(TLAB_EINVAL, "internal: dense separator inverse missing");
+    std::vector<double> rowtab((size_t)5 * kmax);
+    std::copy(ct.Lm.begin(), ct.Lm.end(), rowtab.begin());
+    std::copy(ct.Dinv.begin(), ct.Dinv.end(), rowtab.begin() + kmax);
+    std::copy(ct.Cm.begin(), ct.Cm.end(), rowtab.begin() + 2 * kmax);
+    std::copy(ct.V.begin(), ct.V.end(), rowtab.begin() + 3 * kmax);
+    std::copy(ct.W.begin(), ct.W.end(), rowtab.begin() + 4 * kmax);
+    out.rowtab.upload(rowtab);
+    out.ginv.upload(ct.ginv);
+    std::vector<double> vw((size_t)2 * kmax);
+    std::copy(Vm.begin(), Vm.end(), vw.begin());
+    std::copy(Wm.begin(), Wm.end(), vw.begin() + kmax);
+    out.vw.upload(vw);
+    out.cS = cS; out.aS = aS; out.binv = (double)((ld)1 / (ld)beta);
+    out.aSn = aSn; out.binvn = (double)((ld)1 / (ld)betan);
+}
+
+template <class F>
+int guard(F &&f) {
+    try {
+        if (!tlab_device_ready()) throw Fail(TLAB_EHIP, "tlab_init has not been called (no CPU fallback exists)");
+        f();
+        return TLAB_OK;
+    } catch (const Fail &e) {
+        tlab_set_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    }
+}
+
+template <int M, int MODE>
+void launch_m(int phase, int C, const ZSlabArgs &a, hipStream_t st) {
+    const dim3 grid((unsigned)((a.nlines + 63) / 64)), block(64 * C);
+    if (phase == 1) hipLaunchKernelGGL((k_zslab<M, MODE, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_zslab<M, MODE, 2>), grid, block, 0, st, a);
+}
+
+void launch(const tlab_zslab_plan &P, int mode, int phase, const ZSlabArgs &a, hipStream_t st) {
+    const double pts = (double)a.nlines * a.kmax;
+    const char *name = mode == MODE_P1 ? (phase == 1 ? "k_zslab<P1,A>" : "k_zslab<P1,B>") : (phase == 1 ? "k_zslab<BURGERS,A>" : "k_zslab<BURGERS,B>");
+    double bpp = 8.0 * ((a.in0b && mode == MODE_P1) ? 2 : 1);
+    if (phase == 2) bpp += 8.0 + (mode == MODE_BURGERS ? 8.0 : 0.0) + (a.acc ? 8.0 : 0.0);
+    ProfScope ps(name, st, pts * bpp);
+    if (P.M == 32) {
+        if (mode == MODE_P1) launch_m<32, MODE_P1>(phase, P.C, a, st);
+        else launch_m<32, MODE_BURGERS>(phase, P.C, a, st);
+    } else {
+        if (mode == MODE_P1) launch_m<16, MODE_P1>(phase, P.C, a, st);
+        else launch_m<16, MODE_BURGERS>(phase, P.C, a, st);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Fail(TLAB_EHIP, std::string("k_zslab launch: ") + hipGetErrorString(e));
+}
+
+ZSlabArgs base_args(const tlab_zslab_plan &P, int nx, int ny) {
+    ZSlabArgs a{};
+    a.nlines = (long long)nx * ny;
+    a.kmax = P.kmax;
+    a.c2_1 = P.c2_1; a.c0_2 = P.c0_2; a.c2_2 = P.c2_2; a.c3_2 = P.c3_2;
+    a.y1 = P.sys[0].dev();
+    a.y2 = P.sys[1].dev();
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tlab_zslab_plan_create(tlab_zslab_plan_t *out, tlab_fdm_plan_t gz, int kmax, int koffset, int chunk) {
+    return guard([&] {
+        if (!out || !gz) throw Fail(TLAB_EINVAL, "tlab_zslab_plan_create: null argument");
+        const int nz = gz->t.n;
+        if (!gz->t.periodic) throw Fail(TLAB_EUNSUPPORTED, "z-slab operators: the decomposed direction must be periodic");
+        if (kmax <= 0 || nz % kmax || koffset < 0 || koffset % kmax || koffset >= nz) throw Fail(TLAB_EINVAL, "tlab_zslab_plan_create: bad slab");
+        if (nz / kmax < 2) throw Fail(TLAB_EINVAL, "tlab_zslab_plan_create: needs at least 2 slabs");
+        auto P = std::make_unique<tlab_zslab_plan>();
+        P->nz = nz; P->kmax = kmax; P->k0 = koffset;
+        int M = chunk;
+        if (M == 0) M = (kmax % 32 == 0 && kmax / 32 <= 8) ? 32 : 16;
+        if ((M != 16 && M != 32) || kmax % M || kmax / M > 8 || kmax / M < 1)
+            throw Fail(TLAB_EUNSUPPORTED, "z-slab operators: kmax must be a multiple of 16 or 32 with at most 8 sub-chunks");
+        P->M = M; P->C = kmax / M;
+        const StencilDev s1 = gz->stencil(1, 0), s2 = gz->stencil(2, 0);
+        P->c2_1 = s1.c2;
+        P->c0_2 = s2.c0; P->c2_2 = s2.c2; P->c3_2 = s2.c3;
+        build_system(*P, gz->tridiag(1, 0), P->sys[0]);
+        build_system(*P, gz->tridiag(2, 0), P->sys[1]);
+        *out = P.release();
+    });
+}
+
+int tlab_zslab_plan_destroy(tlab_zslab_plan_t p) {
+    delete p;
+    return TLAB_OK;
+}
+
+int tlab_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny, const double *u, const double *ub, double scale, double *head,
+                         double *tail, const double *tail_left, const double *head_right, double *result, int acc) {
+    return guard([&] {
+        if (!P || !u || nx < 1 || ny < 1 || (phase != 1 && phase != 2)) throw Fail(TLAB_EINVAL, "tlab_zslab_partial_z: bad arguments");
+        ZSlabArgs a = base_args(*P, nx, ny);
+        a.in0 = u; a.in0b = ub; a.scale = scale;
+        if (phase == 1) {
+            if (!head || !tail) throw Fail(TLAB_EINVAL, "tlab_zslab_partial_z: phase A needs head and tail");
+            a.head = head; a.tail = tail;
+        } else {
+            if (!tail_left || !head_right || !result || result == u || result == ub) throw Fail(TLAB_EINVAL, "tlab_zslab_partial_z: phase B arguments");
+            a.tail_left = tail_left; a.head_right = head_right; a.out0 = result; a.acc = acc;
+        }
+        launch(*P, MODE_P1, phase, a, tlab_current_stream());
+    });
+}
+
+int tlab_zslab_burgers_z(tlab_zslab_plan_t P, int phase, int nx, int ny, double nu, const double *s, const double *vel, double *head,
+                         double *tail, const double *tail_left, const double *head_right, double *result, int acc) {
+    return guard([&] {
+        if (!P || !s || nx < 1 || ny < 1 || (phase != 1 && phase != 2)) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z: bad arguments");
+        ZSlabArgs a = base_args(*P, nx, ny);
+        a.in0 = s; a.nu = nu;
+        if (phase == 1) {
+            if (!head || !tail) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z: phase A needs head and tail");
+            a.head = head; a.tail = tail;
+        } else {
+            if (!tail_left || !head_right || !result || !vel || result == s || result == vel) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z: phase B arguments");
+            a.vel = vel; a.tail_left = tail_left; a.head_right = head_right; a.out0 = result; a.acc = acc;
+        }
+        launch(*P, MODE_BURGERS, phase, a, tlab_current_stream());
+    });
+}
+
+}  // extern "C"

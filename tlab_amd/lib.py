@@ -39,6 +39,7 @@ SIGNATURES = {
     "tlab_poisson_plan_destroy": (c_int, [c_vp]),
     "tlab_opr_poisson": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tlab_poisson_plan_create_slab": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "tlab_poisson_plan_create_pencil": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
     "tlab_poisson_set_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "tlab_poisson_fft_x": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tlab_poisson_fft_z": (c_int, [c_vp, c_int, c_vp, c_vp]),
@@ -48,11 +49,18 @@ SIGNATURES = {
     "tlab_pw_sum3": (c_int, [c_vp, c_vp, c_vp, ctypes.c_longlong]),
     "tlab_pw_sub3": (c_int, [c_vp] * 6 + [ctypes.c_longlong]),
     "tlab_pw_rk_update": (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, ctypes.c_longlong]),
+    "tlab_pw_final_update": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_int, c_int]),
     "tlab_pw_get_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int]),
     "tlab_pw_fill_wall_planes": (c_int, [c_vp, c_dbl, c_dbl, c_int, c_int, c_int]),
     "tlab_dns_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, _dp]),
     "tlab_dns_destroy": (c_int, [c_vp]),
     "tlab_dns_set_fusion": (c_int, [c_vp, c_int]),
+    "tlab_opr_burgers_add": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tlab_opr_partial_add": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_int, c_vp, c_vp]),
+    "tlab_zslab_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_int, c_int, c_int]),
+    "tlab_zslab_plan_destroy": (c_int, [c_vp]),
+    "tlab_zslab_partial_z": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
+    "tlab_zslab_burgers_z": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "tlab_dns_set_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "tlab_boundary_bcs_neumann_y": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "tlab_pw_set_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int]),

@@ -12,6 +12,17 @@ The collective is torch.distributed.all_to_all_single (RCCL over xGMI on the GPU
 around it are strided torch copies (pure index work, bit-exact).  All arithmetic stays in the HIP library (C ABI): in the
 transposed layout a z-operator is just the dir = 3 operator on a (nlines, 1, nz_total) box.
 
+Two algorithms are built on that decomposition:
+
+  zmode = "transpose": the reference's scheme.  Every z-operator and the z-FFT go through a K-transposition (12 + 6 field
+      all-to-alls per substep); kept for thin slabs and as the cross-check of the second one.
+  zmode = "halo" (default when the slabs are thick enough, kmax >~ 48): no field is transposed for a derivative.  The compact
+      z-systems are partitioned at the slab boundaries (tlab_amd/csrc/zslab.hip): an operator needs 3 halo planes of its
+      operand and one value per line and system from each neighbour -- two small point-to-point messages over the xGMI link
+      to each neighbour, overlapped with the x/y operators.  The Poisson solver goes from the z-slab to a kx-pencil with ONE
+      all-to-all after the x-FFT (z-FFT, ODEs and inverse z-FFT are then local) and back with one per output field:
+      3 field all-to-alls per substep instead of 18.
+
 `LoopbackComm` runs all npro_k ranks inside ONE process on one device, exchanging blocks by direct copies: the complete
 decomposed algorithm (index maps, per-rank wavenumber offsets, singular-mode ownership) can then be verified against the
 single-domain result on a single GPU (tests/test_gpu_slab.py) although only the driver's 8-GPU node can run it for real.
@@ -38,13 +49,71 @@ class DistComm:
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
 
+        # functional testing of the multi-process path on a box with fewer GPUs than ranks: gloo cannot move device memory in
+        # every collective, so the payload is staged through the host (never used for measurements)
+        self.stage_host = dist.get_backend(group) == "gloo"
+
     def all_to_all(self, sends):
         """sends: {rank: tensor [size, chunk]} (contiguous).  Returns {rank: tensor [size(src), chunk]}."""
         import torch
         (r, s), = sends.items()
+        if self.stage_host and s.is_cuda:
+            hs = s.cpu()
+            ho = torch.empty_like(hs)
+            self.dist.all_to_all_single(ho, hs, group=self.group)
+            return {r: ho.to(s.device)}
         out = torch.empty_like(s)
         self.dist.all_to_all_single(out, s, group=self.group)
         return {r: out}
+
+    def all_to_all_v(self, send, send_counts, recv, recv_counts):
+        """send/recv: {rank: flat tensor}; *_counts: {rank: [elements per peer]}.  In place into recv.  Returns a waitable."""
+        r = self.rank
+        if self.stage_host and send[r].is_cuda:
+            import torch
+            hs = send[r].cpu()
+            ho = torch.empty(recv[r].numel(), dtype=hs.dtype)
+            self.dist.all_to_all_single(ho, hs, output_split_sizes=list(recv_counts[r]), input_split_sizes=list(send_counts[r]), group=self.group)
+            recv[r].copy_(ho)
+            return _Done()
+        w = self.dist.all_to_all_single(recv[r], send[r], output_split_sizes=list(recv_counts[r]), input_split_sizes=list(send_counts[r]),
+                                        group=self.group, async_op=True)
+        return _Works([w])
+
+    def neighbor_exchange(self, to_left, to_right, from_right, from_left):
+        """Periodic ring: to_left[r][i] lands in from_right[r-1][i], to_right[r][i] in from_left[r+1][i].  Lists of contiguous
+        tensors per rank.  Posting order (sends: left then right; receives: from right then from left) keeps the pairing right
+        when both neighbours are the same rank (2 ranks)."""
+        dist, r, P = self.dist, self.rank, self.size
+        left, right = (r - 1) % P, (r + 1) % P
+        if self.stage_host and (to_left[r] + to_right[r]) and (to_left[r] + to_right[r])[0].is_cuda:
+            import torch
+            sl, sr = [t.cpu() for t in to_left[r]], [t.cpu() for t in to_right[r]]
+            rr, rl = [torch.empty(t.shape, dtype=t.dtype) for t in from_right[r]], [torch.empty(t.shape, dtype=t.dtype) for t in from_left[r]]
+            ops = [dist.P2POp(dist.isend, t, left, self.group) for t in sl] + [dist.P2POp(dist.isend, t, right, self.group) for t in sr]
+            ops += [dist.P2POp(dist.irecv, t, right, self.group) for t in rr] + [dist.P2POp(dist.irecv, t, left, self.group) for t in rl]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for d, h in zip(from_right[r] + from_left[r], rr + rl):
+                d.copy_(h)
+            return _Done()
+        ops = [dist.P2POp(dist.isend, t, left, self.group) for t in to_left[r]] + [dist.P2POp(dist.isend, t, right, self.group) for t in to_right[r]]
+        ops += [dist.P2POp(dist.irecv, t, right, self.group) for t in from_right[r]] + [dist.P2POp(dist.irecv, t, left, self.group) for t in from_left[r]]
+        return _Works(dist.batch_isend_irecv(ops))
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()          # NCCL: makes the current stream wait for the collective; does not block the host
 
 
 class LoopbackComm:
@@ -61,6 +130,27 @@ class LoopbackComm:
         for r in self.local_ranks:
             out[r] = torch.stack([sends[p][r] for p in range(self.size)])
         return out
+
+    def all_to_all_v(self, send, send_counts, recv, recv_counts):
+        P = self.size
+        for dst in range(P):
+            ro = 0
+            for src in range(P):
+                so = sum(send_counts[src][:dst])
+                cnt = send_counts[src][dst]
+                assert cnt == recv_counts[dst][src]
+                recv[dst][ro:ro + cnt].copy_(send[src][so:so + cnt])
+                ro += cnt
+        return _Done()
+
+    def neighbor_exchange(self, to_left, to_right, from_right, from_left):
+        P = self.size
+        for r in range(P):
+            for t, d in zip(to_left[r], from_right[(r - 1) % P]):
+                d.copy_(t)
+            for t, d in zip(to_right[r], from_left[(r + 1) % P]):
+                d.copy_(t)
+        return _Done()
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -94,8 +184,10 @@ class SlabDns:
     Same operator sequence as tlab_amd/csrc/rhs.cpp (= tools/dns/rhs_global_incompressible_1.f90:98-375); the z-operators
     go through the K-transposes, the transposed w is kept and reused like the reference does with tmp6 (:100,104,116,152)."""
 
+    HALO = 3          # planes each side: the 7-diagonal right-hand side of the second derivative reaches 3 rows
+
     def __init__(self, comm, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
-                 hyper_bc1_ext=0.1, device="cuda"):
+                 hyper_bc1_ext=0.1, device="cuda", zmode="auto", zchunk=0):
         import torch
         self.comm = comm
         P = comm.size
@@ -106,8 +198,6 @@ class SlabDns:
         self.npage = self.nx * self.ny
         self.nxh = self.nx // 2 + 1
         self.n = self.npage * self.kmax
-        if self.npage % P or (self.nxh * self.ny) % P:
-            raise TlabError("imax*jmax and (imax/2+1)*jmax must be divisible by the number of z slabs")
         self.nlines = self.npage // P
         self.nscal, self.visc = int(nscal), float(visc)
         self.schmidt = [float(v) for v in schmidt][: self.nscal]
@@ -119,16 +209,60 @@ class SlabDns:
         self.scal_jmin, self.scal_jmax = [DNS_BCS_DIRICHLET] * self.nscal, [DNS_BCS_DIRICHLET] * self.nscal
         self.isize_txc = (self.nx + 2) * self.ny * self.kmax
         L = load()
+        if zmode not in ("auto", "halo", "transpose"):
+            raise TlabError("zmode: auto, halo or transpose")
+        # ---- z-slab operator plans (halo mode); a slab too thin for them sends everything to the transpose path ----
+        zplans = {}
+        if zmode != "transpose" and P > 1:
+            for r in comm.local_ranks:
+                h = c_vp(0)
+                rc = L.tlab_zslab_plan_create(ctypes.byref(h), self.g[2]._h, self.kmax, r * self.kmax, int(zchunk))
+                if rc != 0:
+                    for hh in zplans.values():
+                        L.tlab_zslab_plan_destroy(hh)
+                    zplans = {}
+                    if zmode == "halo":
+                        check(rc, "tlab_zslab_plan_create")
+                    break
+                zplans[r] = h
+        self.zmode = "halo" if zplans else "transpose"
+        if self.zmode == "transpose" and (self.npage % P or (self.nxh * self.ny) % P):
+            raise TlabError("imax*jmax and (imax/2+1)*jmax must be divisible by the number of z slabs (tlab_mpi_transpose.f90:292)")
+        # kx ranges of the pencils: [ioff[r], ioff[r] + nxl[r])
+        base, rem = divmod(self.nxh, P)
+        self.nxl = [base + (1 if r < rem else 0) for r in range(P)]
+        self.ioff = [r * base + min(r, rem) for r in range(P)]
+        if self.zmode == "halo" and min(self.nxl) < 1:
+            raise TlabError("fewer kx modes than ranks")
+        Hn = self.HALO * self.npage
         self.st = {}
         for r in comm.local_ranks:
+            def field(m):
+                """m doubles with HALO planes of room on both sides: the slab's first plane is at ext[HALO*npage]."""
+                ext = torch.zeros(m + 2 * Hn, dtype=torch.float64, device=device)
+                return ext, ext[Hn:Hn + m]
             z0 = lambda m: torch.zeros(m, dtype=torch.float64, device=device)   # noqa: E731
             h = c_vp(0)
-            check(L.tlab_poisson_plan_create_slab(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
-                                                  self.kmax, self.nzt, r * self.kmax, P), "tlab_poisson_plan_create_slab")
-            self.st[r] = dict(q=[z0(self.n) for _ in range(3)], s=[z0(self.n) for _ in range(self.nscal)],
-                              hq=[z0(self.n) for _ in range(3)], hs=[z0(self.n) for _ in range(self.nscal)],
-                              txc=[z0(self.isize_txc) for _ in range(9)], rt=z0(self.n), hb=z0(self.nx * self.kmax),
-                              ht=z0(self.nx * self.kmax), poisson=h)
+            if self.zmode == "halo":
+                check(L.tlab_poisson_plan_create_pencil(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
+                                                        self.kmax, self.nzt, self.ioff[r], self.nxl[r]), "tlab_poisson_plan_create_pencil")
+            else:
+                check(L.tlab_poisson_plan_create_slab(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
+                                                      self.kmax, self.nzt, r * self.kmax, P), "tlab_poisson_plan_create_slab")
+            S = dict(ext={}, rt=z0(self.n), hb=z0(self.nx * self.kmax), ht=z0(self.nx * self.kmax), poisson=h)
+            for name, cnt, m in (("q", 3, self.n), ("s", self.nscal, self.n), ("hq", 3, self.n), ("hs", self.nscal, self.n), ("txc", 9, self.isize_txc)):
+                pairs = [field(m) for _ in range(cnt)]
+                S["ext"][name] = [e for e, _ in pairs]
+                S[name] = [i for _, i in pairs]
+            if self.zmode == "halo":
+                S["zplan"] = zplans[r]
+                nmsg = 2 * (3 + self.nscal)                               # (first, second derivative) x fields of one batch
+                for k in ("head", "tail", "head_right", "tail_left"):
+                    S[k] = z0(nmsg * self.npage)
+                npen = 2 * self.nxl[r] * self.ny * self.nzt               # doubles of a complex pencil (nxl, ny, nz_total)
+                S["pen"] = [z0(npen) for _ in range(3)]
+                S["pack"] = [z0(2 * self.nxh * self.ny * self.kmax) for _ in range(2)]
+            self.st[r] = S
 
     # ---- thin wrappers over the C ABI -------------------------------------------------------------------------------
     def _burgers(self, d, g, ivel, nx, ny, nz, nu, s, u, res, tmp):
@@ -204,9 +338,186 @@ class SlabDns:
                 S["txc"][src][:nc].copy_(bk[r])
                 check(L.tlab_poisson_fft_x(S["poisson"], -1, _ptr(S["txc"][src]), _ptr(S["txc"][dst])), "fft_x")
 
+    # ---- halo mode: neighbour exchanges -----------------------------------------------------------------------------------
+    def _halo_start(self, fields, nplanes=None):
+        """Starts the exchange of the halo planes of fields = [(name, idx), ...]: my last planes go to the right neighbour's
+        planes -H..-1, my first planes to the left neighbour's planes kmax..kmax+H-1 (periodic in z).  Zero-copy: the planes are
+        contiguous in memory on both sides."""
+        H = self.HALO if nplanes is None else nplanes
+        Hn, Hfull, n = H * self.npage, self.HALO * self.npage, self.n
+        tl, tr, fr, fl = {}, {}, {}, {}
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            tl[r] = [S[nm][i][:Hn] for nm, i in fields]
+            tr[r] = [S[nm][i][n - Hn:n] for nm, i in fields]
+            fr[r] = [S["ext"][nm][i][Hfull + n:Hfull + n + Hn] for nm, i in fields]          # planes kmax .. kmax+H-1
+            fl[r] = [S["ext"][nm][i][Hfull - Hn:Hfull] for nm, i in fields]                  # planes -H .. -1
+        return self.comm.neighbor_exchange(tl, tr, fr, fl)
+
+    def _msg_start(self, nrows):
+        """head -> left neighbour (its head_right), tail -> right neighbour (its tail_left); nrows lines-sets of nx*ny."""
+        m = nrows * self.npage
+        c = self.comm
+        return c.neighbor_exchange({r: [self.st[r]["head"][:m]] for r in c.local_ranks}, {r: [self.st[r]["tail"][:m]] for r in c.local_ranks},
+                                   {r: [self.st[r]["head_right"][:m]] for r in c.local_ranks}, {r: [self.st[r]["tail_left"][:m]] for r in c.local_ranks})
+
+    def _zburgers(self, phase, S, row, nu, s, vel, res):
+        """Phase 1 / 2 of OPR_Burgers_Z on the slab; row = first message row (2 rows per call: first, second derivative)."""
+        o = row * self.npage * 8
+        P = lambda t: c_vp(t.data_ptr() + o)                 # noqa: E731
+        check(load().tlab_zslab_burgers_z(S["zplan"], phase, self.nx, self.ny, float(nu), _ptr(s), _ptr(vel) if vel is not None else None,
+                                          P(S["head"]), P(S["tail"]), P(S["tail_left"]), P(S["head_right"]),
+                                          _ptr(res) if res is not None else None, 1), "tlab_zslab_burgers_z")
+
+    def _zpartial(self, phase, S, u, ub, scale, res, acc):
+        check(load().tlab_zslab_partial_z(S["zplan"], phase, self.nx, self.ny, _ptr(u), _ptr(ub) if ub is not None else None, float(scale),
+                                          _ptr(S["head"]), _ptr(S["tail"]), _ptr(S["tail_left"]), _ptr(S["head_right"]),
+                                          _ptr(res) if res is not None else None, int(acc)), "tlab_zslab_partial_z")
+
+    def _pencil_forward(self, src_idx):
+        """complex slab txc[src] (nxh, ny, kmax) of every rank -> pen[0] (nxl, ny, nz_total): ONE all-to-all; the receive side
+        needs no unpacking because z is the slowest index of the pencil."""
+        c, P = self.comm, self.comm.size
+        send, scnt, recv, rcnt = {}, {}, {}, {}
+        for r in c.local_ranks:
+            S = self.st[r]
+            a = S["txc"][src_idx][:2 * self.nxh * self.ny * self.kmax].view(self.kmax, self.ny, self.nxh, 2)
+            buf, off, cnts = S["pack"][0], 0, []
+            for p in range(P):
+                m = 2 * self.nxl[p] * self.ny * self.kmax
+                buf[off:off + m].view(self.kmax, self.ny, self.nxl[p], 2).copy_(a[:, :, self.ioff[p]:self.ioff[p] + self.nxl[p], :])
+                cnts.append(m)
+                off += m
+            send[r], scnt[r] = buf, cnts
+            recv[r], rcnt[r] = S["pen"][0], [2 * self.nxl[r] * self.ny * self.kmax] * P
+        return c.all_to_all_v(send, scnt, recv, rcnt)
+
+    def _pencil_backward_start(self, pen_idx, pack_idx):
+        c, P = self.comm, self.comm.size
+        send, scnt, recv, rcnt = {}, {}, {}, {}
+        for r in c.local_ranks:
+            S = self.st[r]
+            send[r], scnt[r] = S["pen"][pen_idx], [2 * self.nxl[r] * self.ny * self.kmax] * P
+            recv[r], rcnt[r] = S["pack"][pack_idx], [2 * self.nxl[p] * self.ny * self.kmax for p in range(P)]
+        return c.all_to_all_v(send, scnt, recv, rcnt)
+
+    def _pencil_backward_finish(self, pack_idx, dst_idx):
+        P = self.comm.size
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            a = S["txc"][dst_idx][:2 * self.nxh * self.ny * self.kmax].view(self.kmax, self.ny, self.nxh, 2)
+            buf, off = S["pack"][pack_idx], 0
+            for p in range(P):
+                m = 2 * self.nxl[p] * self.ny * self.kmax
+                a[:, :, self.ioff[p]:self.ioff[p] + self.nxl[p], :].copy_(buf[off:off + m].view(self.kmax, self.ny, self.nxl[p], 2))
+                off += m
+
+    def _poisson_pencil(self):
+        """OPR_Poisson_FourierXZ_Factorize on kx-pencils: forcing in tmp1, Neumann data in hb/ht; p -> tmp1, dp/dy -> tmp3."""
+        L = load()
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            check(L.tlab_poisson_set_wall_planes(S["poisson"], _ptr(S["txc"][0]), _ptr(S["hb"]), _ptr(S["ht"])), "set_wall_planes")
+            check(L.tlab_poisson_fft_x(S["poisson"], 1, _ptr(S["txc"][0]), _ptr(S["txc"][1])), "fft_x")          # p -> tmp2 (complex slab)
+        self._pencil_forward(1).wait()
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            b0, b1, b2 = S["pen"]
+            check(L.tlab_poisson_fft_z(S["poisson"], 1, _ptr(b0), _ptr(b1)), "fft_z")
+            check(L.tlab_poisson_ode(S["poisson"], _ptr(b1), _ptr(b1), _ptr(b2)), "ode")                          # p^ over f^, dp^ in b2
+            check(L.tlab_poisson_fft_z(S["poisson"], -1, _ptr(b1), _ptr(b0)), "fft_z")
+        w0 = self._pencil_backward_start(0, 0)                                                                     # p travels ...
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            check(L.tlab_poisson_fft_z(S["poisson"], -1, _ptr(S["pen"][2]), _ptr(S["pen"][1])), "fft_z")          # ... while dp/dy is transformed
+        w1 = self._pencil_backward_start(1, 1)
+        w0.wait()
+        self._pencil_backward_finish(0, 1)
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            check(L.tlab_poisson_fft_x(S["poisson"], -1, _ptr(S["txc"][1]), _ptr(S["txc"][0])), "fft_x")         # p -> tmp1
+        w1.wait()
+        self._pencil_backward_finish(1, 3)
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            check(L.tlab_poisson_fft_x(S["poisson"], -1, _ptr(S["txc"][3]), _ptr(S["txc"][2])), "fft_x")         # dp/dy -> tmp3
+
+    def _rhs_halo(self, dte, tail=None):
+        """Same terms as rhs.cpp / rhs_global_incompressible_1.f90:98-398; the z-terms are added last in every equation so that the
+        neighbour messages travel while the x/y operators run (the reference's order differs in the third equation: rounding only).
+        tail = (dte, kco, scale): fold the RK update into the last pass (TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT)."""
+        L = load()
+        nx, ny, kmax, n = self.nx, self.ny, self.kmax, self.n
+        gx, gy = self.g[0], self.g[1]
+        nu = self.visc
+        ns = self.nscal
+        T = lambda S, i: S["txc"][i]          # noqa: E731
+        eqs = lambda S: [(S["q"][0], S["hq"][0], nu), (S["q"][1], S["hq"][1], nu), (S["q"][2], S["hq"][2], nu)] + \
+            [(S["s"][i], S["hs"][i], self.visc / self.schmidt[i]) for i in range(ns)]            # noqa: E731
+
+        def badd(d, g, S, f, h, kap):
+            check(L.tlab_opr_burgers_add(d, g._h, nx, ny, kmax, 0, float(kap), _ptr(f), _ptr(S["q"][d - 1]), _ptr(h), _ptr(T(S, 6)), _ptr(T(S, 7))),
+                  "tlab_opr_burgers_add")
+
+        def padd(d, g, S, u, ub, scale, res, acc):
+            check(L.tlab_opr_partial_add(d, g._h, nx, ny, kmax, 0, _ptr(u), _ptr(ub) if ub is not None else None, float(scale), _ptr(res), int(acc),
+                                         _ptr(T(S, 6)), _ptr(T(S, 7))), "tlab_opr_partial_add")
+
+        # ---- diffusion + advection (:98-162) ----
+        w = self._halo_start([("q", 0), ("q", 1), ("q", 2)] + [("s", i) for i in range(ns)])
+        self._local(lambda r, S: [badd(1, gx, S, f, h, kap) for f, h, kap in eqs(S)])
+        w.wait()
+        self._local(lambda r, S: [self._zburgers(1, S, 2 * i, kap, f, None, None) for i, (f, h, kap) in enumerate(eqs(S))])
+        w = self._msg_start(2 * (3 + ns))
+        self._local(lambda r, S: [badd(2, gy, S, f, h, kap) for f, h, kap in eqs(S)])
+        w.wait()
+        self._local(lambda r, S: [self._zburgers(2, S, 2 * i, kap, f, S["q"][2], h) for i, (f, h, kap) in enumerate(eqs(S))])
+        # ---- pressure forcing: div(hq + q/dte) (:188-260) ----
+        idte = 1.0 / dte
+        w = self._halo_start([("hq", 2)])                                   # w's halo planes are still valid
+        self._local(lambda r, S: padd(2, gy, S, S["hq"][1], S["q"][1], idte, T(S, 0), 0))
+        self._local(lambda r, S: padd(1, gx, S, S["hq"][0], S["q"][0], idte, T(S, 0), 1))
+        w.wait()
+        self._local(lambda r, S: self._zpartial(1, S, S["hq"][2], S["q"][2], idte, None, 0))
+        w = self._msg_start(1)
+        self._local(lambda r, S: check(L.tlab_pw_get_wall_planes(_ptr(S["hq"][1]), _ptr(S["hb"]), _ptr(S["ht"]), nx, ny, kmax), "walls"))
+        w.wait()
+        self._local(lambda r, S: self._zpartial(2, S, S["hq"][2], S["q"][2], idte, T(S, 0), 1))
+        # ---- pressure (:284) and its gradient (:319-320) ----
+        self._poisson_pencil()
+        w = self._halo_start([("txc", 0)])
+        self._local(lambda r, S: padd(1, gx, S, T(S, 0), None, 0.0, T(S, 1), 0))
+        w.wait()
+        self._local(lambda r, S: self._zpartial(1, S, T(S, 0), None, 0.0, None, 0))
+        w = self._msg_start(1)
+        w.wait()
+        self._local(lambda r, S: self._zpartial(2, S, T(S, 0), None, 0.0, T(S, 3), 0))
+        # ---- hq -= grad p, boundary conditions (:348-398) [+ RK update] ----
+        types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
+
+        def finish(r, S):
+            grads = [T(S, 1), T(S, 2), T(S, 3)] + [None] * ns
+            fields = list(zip(S["q"] + S["s"], S["hq"] + S["hs"], grads, types))
+            if any(tmin == DNS_BCS_NEUMANN or tmax == DNS_BCS_NEUMANN for _, _, _, (tmin, tmax) in fields[:3]) or tail is None:
+                check(L.tlab_pw_sub3(_ptr(S["hq"][0]), _ptr(S["hq"][1]), _ptr(S["hq"][2]), _ptr(T(S, 1)), _ptr(T(S, 2)), _ptr(T(S, 3)), n), "sub3")
+                fields = [(q, h, None, t) for q, h, _, t in fields]
+            for q, h, g, (tmin, tmax) in fields:
+                ibc = (1 if tmin == DNS_BCS_NEUMANN else 0) + (2 if tmax == DNS_BCS_NEUMANN else 0)
+                if ibc:       # needs the finished tendency (g is None here)
+                    check(L.tlab_boundary_bcs_neumann_y(gy._h, ibc, nx, ny, kmax, _ptr(h), _ptr(S["hb"]), _ptr(S["ht"]), _ptr(T(S, 0))), "bcs_neumann_y")
+                pb, pt = (_ptr(S["hb"]) if ibc & 1 else None), (_ptr(S["ht"]) if ibc & 2 else None)
+                if tail is None:
+                    check(L.tlab_pw_set_wall_planes(_ptr(h), pb, pt, nx, ny, kmax), "walls")
+                else:
+                    check(L.tlab_pw_final_update(_ptr(q), _ptr(h), _ptr(g) if g is not None else None, pb, pt, float(tail[0]), float(tail[1]),
+                                                 int(tail[2]), nx, ny, kmax), "final_update")
+        self._local(finish)
+
     # ---- the RHS ---------------------------------------------------------------------------------------------------------
     def RHS_GLOBAL_INCOMPRESSIBLE_1(self, dte):
         _use_torch_stream()
+        if self.zmode == "halo":
+            return self._rhs_halo(dte)
         L = load()
         nx, ny, kmax, n = self.nx, self.ny, self.kmax, self.n
         gx, gy = self.g[0], self.g[1]
@@ -267,6 +578,9 @@ class SlabDns:
         self.scal_jmin, self.scal_jmax = list(sj0)[: self.nscal], list(sj1)[: self.nscal]
 
     def TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(self, dte, kco=1.0, scale_tendencies=False):
+        if self.zmode == "halo":
+            _use_torch_stream()
+            return self._rhs_halo(dte, tail=(dte, kco, scale_tendencies))
         self.RHS_GLOBAL_INCOMPRESSIBLE_1(dte)
         L = load()
         for r in self.comm.local_ranks:
@@ -298,5 +612,7 @@ class SlabDns:
         try:
             for S in self.st.values():
                 load().tlab_poisson_plan_destroy(S["poisson"])
+                if "zplan" in S:
+                    load().tlab_zslab_plan_destroy(S["zplan"])
         except Exception:
             pass
