@@ -81,9 +81,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    backend = os.environ.get("TLAB_DIST_BACKEND", "nccl")      # gloo: functional runs with several ranks on one GPU (host-staged)
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import tlab_amd as T
     from tlab_amd.dns import Dns, RKM_EXP3
@@ -146,7 +152,7 @@ def main():
     elapsed = time.perf_counter() - t0
     L.tlab_profile_enable(0)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = all(bool(torch.isfinite(t).all()) for t in state_fields)
@@ -193,7 +199,8 @@ def main():
             "config": {"workload": "%d^3 incompressible box, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
                                    % (n, args.nscal),
                        "grid": [n, n, n], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper", "reynolds": 5000,
-                       "parallelism": ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks executed back to back on one GPU, no communication" % args.loopback) if world == 1 else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world,
+                       "parallelism": ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode) executed back to back on one GPU, no communication" % (args.loopback, d.zmode)) if world == 1 else
+                       ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep), RCCL" % world if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
                        "fields_finite": finite},
             "roofline": None if dom is None else {
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

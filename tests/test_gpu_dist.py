@@ -1,0 +1,26 @@
+"""Multi-PROCESS run of the z-slab algorithm on the GPU box: P ranks (processes) share the one GPU, torch.distributed runs on gloo
+with host-staged payloads (tlab_amd/parallel.py DistComm.stage_host), every arithmetic operation is the HIP library.  Checks the
+per-process code path the 8-GPU job uses (rank-local plans, neighbour pairing, uneven kx-pencils) against the single-domain step."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,zmode,nz,bcs", [(2, "halo", 128, "noslip"), (3, "halo", 192, "freeslip"), (2, "transpose", 64, "noslip")])
+def test_multiprocess_slabs(world, zmode, nz, bcs):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, TLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29540 + world + (7 if zmode == "halo" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_check.py"), "--zmode", zmode, "--nz", str(nz), "--bcs", bcs,
+           "--nx", "32" if world != 3 else "48"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "DIST_CHECK" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]

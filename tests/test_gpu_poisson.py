@@ -34,7 +34,8 @@ def setup(nx, ny, nz, stretch=True):
     return x, y, z
 
 
-@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (16, 24, 1, True), (64, 33, 8, False), (128, 64, 32, True), (8, 9, 8, False)])
+@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (16, 24, 1, True), (64, 33, 8, False), (128, 64, 32, True), (8, 9, 8, False),
+                                              (32, 512, 8, True), (16, 256, 8, False), (24, 1024, 8, True), (40, 16, 8, True)])
 def test_poisson_vs_oracle(T, nx, ny, nz, stretch):
     import torch
     from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
@@ -64,6 +65,29 @@ def test_poisson_vs_oracle(T, nx, ny, nz, stretch):
     assert rel_err(p2.cpu().numpy(), p_ref) <= TOL
     with pytest.raises(T.TlabError):
         T.OPR_Poisson(plan, nx, ny, nz, T.BCS_DD, p2, t1, t2, dev(hb), dev(ht), None)
+
+
+def test_chunked_and_marching_ode_kernels_agree(T, monkeypatch):
+    """ny % 8 == 0 runs the register-chunked k_ode_nn; TLAB_ODE_CHUNKED=0 (read at plan creation) keeps the marching k_int1 kernels.
+    Same discrete equations, same pivots: the two must agree to round-off on a large-lambda-range case."""
+    import torch
+    nx, ny, nz = 128, 128, 64
+    x, y, z = setup(nx, ny, nz, True)
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, False), T.FdmPlan(z, True, True)]
+    rng = np.random.default_rng(5)
+    N = nx * ny * nz
+    f, hb, ht = rng.uniform(-1, 1, N), rng.uniform(-1, 1, nx * nz), rng.uniform(-1, 1, nx * nz)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TLAB_ODE_CHUNKED", flag)
+        plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+        p = dev(f)
+        t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.empty_like(t1)
+        dpdy = torch.empty(N, dtype=torch.float64, device="cuda")
+        T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p, t1, t2, dev(hb), dev(ht), dpdy)
+        outs.append((p.cpu().numpy(), dpdy.cpu().numpy()))
+    assert rel_err(outs[0][0], outs[1][0]) <= 1e-13
+    assert rel_err(outs[0][1], outs[1][1]) <= 1e-13
 
 
 @pytest.mark.parametrize("n", [256])

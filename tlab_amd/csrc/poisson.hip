@@ -68,6 +68,12 @@ __device__ __forceinline__ void lhs_row(const Int1Dev &T, int j, double lam, dou
     for (int k = 0; k < 5; ++k) r[k] = T.L0[j * 5 + k] + lam * T.L1[j * 5 + k];
 }
 
+template <class TT>
+__device__ __forceinline__ void lhs_row_t(const TT &T, int j, double lam, double (&r)[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = T.L0[(unsigned)(j * 5 + k)] + lam * T.L1[(unsigned)(j * 5 + k)];
+}
+
 template <int NL, int FS>
 __device__ __forceinline__ void load_f(const Int1Args &a, int j, long long t, long long fidx0, double (&f)[NL]) {
     if (FS == FS_FIELD) {
@@ -297,6 +303,542 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     }
 }
 
+// ================================================================================================
+// k_ode_nn : OPR_ODE2_Factorize_NN for a group of modes with the y-line cut into chunks of 8 rows that live in registers.
+//
+// k_int1 marches one thread per mode along the whole line: 512 dependent steps, twice, with every intermediate of the
+// pentadiagonal solve (5 doubles per row) written to and read back from HBM -- latency-bound on small slabs, traffic-bound
+// (22 GB per Poisson solve at 512^3) on large ones.  Here a workgroup owns NM modes x all rows, thread (m, c) owns rows
+// [8c, 8c+8) of mode m:
+//   * the LU factors of its rows are regenerated from a CHECKPOINT of the PENTADFS recurrence (pivots of the two rows before
+//     the chunk, 6 doubles per chunk and mode, written once at plan creation by k_ode_checkpoint): the same numbers the serial
+//     elimination produces (the system B + lambda A is not diagonally dominant -- partitioned eliminations with their own
+//     local pivots lose up to 6 digits for small lambda, measured -- so the serial pivot sequence is kept);
+//   * forward and backward substitution are two-term linear recurrences: every chunk computes its particular end values and its
+//     2x2 transfer matrix, a parallel scan over the chunks (lane shuffles inside a wave, wave totals through LDS) gives every
+//     chunk its inflow, and the chunk repeats its 8 rows with it;
+//   * v0, u0 stay in registers until the three constants of the 3x3 constraint system are known, and the superposition with the
+//     homogeneous solutions of the mode (5 arrays computed at plan creation, opr_odes.f90:350-367) is the epilogue of the same kernel.
+//     (Running the pair of solves a second time with the final boundary values instead of reading them was measured: the kernel is
+//     bound by dependent fp64 latency at 8 waves per CU, not by HBM, and the second pass doubled its time.)
+// HBM traffic per mode and row: f^ 16 B, p^ + dp^/dy 32 B, homogeneous solutions 40 B, checkpoints 12 B; no scratch.
+// ================================================================================================
+constexpr int OM = 8;   // rows per thread
+
+struct OdeSys {                  // Int1Dev without the by-value boundary constants (they would sit in ~100 SGPRs)
+    const double *L0, *L1, *R;   // row-major [n][5], [n][5], [n][3]
+    const double *bt;            // [3][4]: rhs_b of the BCS_MIN system / rhs_t of the BCS_MAX system
+    int n;
+};
+
+struct OdeArgs {
+    OdeSys T1, T2;               // BCS_MIN (+lambda) and BCS_MAX (-lambda) tables
+    const double *lam;           // [nm]
+    const unsigned char *skip;   // [nm] singular modes: computed elsewhere
+    const double *chk1, *chk2;   // [C][6][nm] PENTADFS state before the first row of each chunk
+    const double *cst;           // [9][nm] LU of the constraint matrix (k_nn_constants)
+    const double *hom;           // [5][n][nm] homogeneous solutions v1, em, u1, sp, ep (build_homogeneous)
+    const double *f_hat;
+    double *p_hat, *dp_hat;
+    double fscale;
+    int n, nxh, ny, C;
+    long long nm;
+};
+
+// boundary rows of the system of one mode (the prologue of k_int1)
+struct OdeRows {
+    double l0[5], l1[5], l2[5], lN[5], lN1[5], lN2[5], rb[3][4], rt[3][4];
+};
+
+template <int BC>
+__device__ __forceinline__ void ode_boundary_rows(const OdeSys &T, double lam, OdeRows &k) {
+    const int n = T.n;
+    lhs_row_t(T, 0, lam, k.l0); lhs_row_t(T, 1, lam, k.l1); lhs_row_t(T, 2, lam, k.l2);
+    lhs_row_t(T, n - 1, lam, k.lN); lhs_row_t(T, n - 2, lam, k.lN1); lhs_row_t(T, n - 3, lam, k.lN2);
+    if (BC == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) k.rb[j][c] = T.bt[j * 4 + c];
+        const double d = 1.0 / k.lN[2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) k.lN[q] = -k.lN[q] * d;
+        k.lN[2] = 1.0;
+        k.lN1[0] += k.lN1[3] * k.lN[4]; k.lN1[1] += k.lN1[3] * k.lN[0]; k.lN1[2] += k.lN1[3] * k.lN[1];
+        k.lN2[1] += k.lN2[4] * k.lN[4]; k.lN2[2] += k.lN2[4] * k.lN[0]; k.lN2[3] += k.lN2[4] * k.lN[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            k.rt[2][c] = T.R[(n - 1) * 3 + c] * d;
+            k.rt[1][c] = T.R[(n - 2) * 3 + c];
+            k.rt[0][c] = T.R[(n - 3) * 3 + c];
+        }
+        k.rt[0][3] = k.rt[1][3] = k.rt[2][3] = 0.0;
+        k.rt[1][0] -= k.lN1[3] * k.rt[2][2]; k.rt[1][1] -= k.lN1[3] * k.rt[2][0]; k.rt[1][2] -= k.lN1[3] * k.rt[2][1];
+        k.rt[0][1] -= k.lN2[4] * k.rt[2][2]; k.rt[0][2] -= k.lN2[4] * k.rt[2][0]; k.rt[0][3] -= k.lN2[4] * k.rt[2][1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) k.rt[j][c] = T.bt[j * 4 + c];
+        const double d = 1.0 / k.l0[2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) k.l0[q] = -k.l0[q] * d;
+        k.l0[2] = 1.0;
+        k.l1[2] += k.l1[1] * k.l0[3]; k.l1[3] += k.l1[1] * k.l0[4]; k.l1[4] += k.l1[1] * k.l0[0];
+        k.l2[1] += k.l2[0] * k.l0[3]; k.l2[2] += k.l2[0] * k.l0[4]; k.l2[3] += k.l2[0] * k.l0[0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            k.rb[0][c + 1] = T.R[0 * 3 + c] * d;
+            k.rb[1][c + 1] = T.R[1 * 3 + c];
+            k.rb[2][c + 1] = T.R[2 * 3 + c];
+        }
+        k.rb[0][0] = k.rb[1][0] = k.rb[2][0] = 0.0;
+        k.rb[1][1] -= k.l1[1] * k.rb[0][2]; k.rb[1][2] -= k.l1[1] * k.rb[0][3]; k.rb[1][3] -= k.l1[1] * k.rb[0][1];
+        k.rb[2][0] -= k.l2[0] * k.rb[0][2]; k.rb[2][1] -= k.l2[0] * k.rb[0][3]; k.rb[2][2] -= k.l2[0] * k.rb[0][1];
+    }
+}
+
+// matrix row j of the reduced system of one mode
+__device__ __forceinline__ void ode_row(const OdeSys &T, const OdeRows &k, int j, double lam, double (&r)[5]) {
+    const int n = T.n;
+    if (j == 1) { for (int q = 0; q < 5; ++q) r[q] = k.l1[q]; }
+    else if (j == 2) { for (int q = 0; q < 5; ++q) r[q] = k.l2[q]; }
+    else if (j == n - 3) { for (int q = 0; q < 5; ++q) r[q] = k.lN2[q]; }
+    else if (j == n - 2) { for (int q = 0; q < 5; ++q) r[q] = k.lN1[q]; }
+    else lhs_row_t(T, j, lam, r);
+}
+
+// The boundary rows depend on the mode only: one thread per mode computes them into LDS (54 doubles per mode), the two chunks that
+// touch a boundary read what they need from there, and no thread keeps them in registers.  Layout: [field][NM], fields:
+//   0-4 l0, 5-9 l1, 10-14 l2, 15-19 lN, 20-24 lN1, 25-29 lN2, 30-41 rb[3][4], 42-53 rt[3][4]
+constexpr int OK_L0 = 0, OK_L1 = 5, OK_L2 = 10, OK_LN = 15, OK_LN1 = 20, OK_LN2 = 25, OK_RB = 30, OK_RT = 42, OK_SIZE = 54;
+template <int NM>
+__device__ __forceinline__ void ode_rows_to_lds(const OdeRows &k, double *s_k, int m) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        s_k[(OK_L0 + q) * NM + m] = k.l0[q]; s_k[(OK_L1 + q) * NM + m] = k.l1[q]; s_k[(OK_L2 + q) * NM + m] = k.l2[q];
+        s_k[(OK_LN + q) * NM + m] = k.lN[q]; s_k[(OK_LN1 + q) * NM + m] = k.lN1[q]; s_k[(OK_LN2 + q) * NM + m] = k.lN2[q];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s_k[(OK_RB + j * 4 + c) * NM + m] = k.rb[j][c]; s_k[(OK_RT + j * 4 + c) * NM + m] = k.rt[j][c]; }
+}
+template <int NM>
+__device__ __forceinline__ void ode_row_lds(const OdeSys &T, const double *s_k, int m, int j, double lam, double (&r)[5]) {
+    const int n = T.n;
+    const int off = (j == 1) ? OK_L1 : (j == 2) ? OK_L2 : (j == n - 3) ? OK_LN2 : (j == n - 2) ? OK_LN1 : -1;
+    if (off >= 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r[q] = s_k[(off + q) * NM + m];
+    } else {
+        lhs_row_t(T, j, lam, r);
+    }
+}
+
+// one PENTADFS step (linear5.f90:30-71) for row j; st = (c1, d1, e1, c2, d2, e2) of rows j-1, j-2
+__device__ __forceinline__ void ode_factor_step(int j, const double (&r)[5], double (&st)[6], double &am, double &bm, double &cinv, double &nd,
+                                                double &ne) {
+    double cm = r[2], dm = r[3];
+    const double em = r[4];
+    am = 0.0; bm = 0.0;
+    if (j == 2) {
+        bm = r[1] / st[0];
+        cm = r[2] - bm * st[1];
+        dm = r[3] - bm * st[2];
+    } else if (j >= 3) {
+        am = r[0] / st[3];
+        bm = (r[1] - am * st[4]) / st[0];
+        cm = r[2] - bm * st[1] - am * st[5];
+        dm = r[3] - bm * st[2];
+    }
+    cinv = 1.0 / cm; nd = -dm; ne = -em;
+    st[3] = st[0]; st[4] = st[1]; st[5] = st[2];
+    st[0] = cm; st[1] = dm; st[2] = em;
+}
+
+// checkpoints of the factor recurrence: state before rows 8, 16, ... (chunk 0 starts from zeros)
+template <int BC>
+__global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *__restrict__ lamv, double lam_sign, double *__restrict__ chk,
+                                                        long long nm) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nm) return;
+    const int n = T.n;
+    const double lam = lam_sign * lamv[t];
+    OdeRows k;
+    ode_boundary_rows<BC>(T, lam, k);
+    double st[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 1; j <= n - 2; ++j) {
+        if ((j % OM) == 0) {
+            const int c = j / OM;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) chk[((long long)c * 6 + q) * nm + t] = st[q];
+        }
+        double r[5], am, bm, cinv, nd, ne;
+        ode_row(T, k, j, lam, r);
+        ode_factor_step(j, r, st, am, bm, cinv, nd, ne);
+    }
+}
+
+// Inflow of every chunk from the chunks before it (DIR = +1: c-1, c-2, ... ; DIR = -1: c+1, c+2, ...), i.e. the exclusive prefix of the
+// affine maps in -> Phi in + e of the chunks, composed in the direction of the sweep.  Lanes hold (mode m, chunk c) with m fastest, so a
+// wave owns 64/NM consecutive chunks of NM modes: Hillis-Steele with lane shuffles inside the wave, the wave totals through LDS.
+//   phi = {p00, p01, p10, p11}, e[l] = {e1, e2} per line; returns in[l] = {in1, in2}.     s_w: [nwaves][8][NM] doubles
+template <int NM, int DIR>
+__device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[2][2], int c, int C, int m, double *s_w, double (&in)[2][2]) {
+    constexpr int CPW = 64 / NM;                       // chunks per wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int cw = lane / NM;                          // chunk index inside the wave
+    // position along the sweep inside the wave: DIR = +1 -> cw, DIR = -1 -> reversed
+#pragma unroll
+    for (int d = 1; d < CPW; d <<= 1) {
+        double q[4], f[2][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = (DIR > 0) ? __shfl_up(phi[k], d * NM) : __shfl_down(phi[k], d * NM);
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) f[l][k] = (DIR > 0) ? __shfl_up(e[l][k], d * NM) : __shfl_down(e[l][k], d * NM);
+        const bool has = (DIR > 0) ? (cw >= d) : (cw + d < CPW && c + d < C);
+        if (has) {      // (phi, e) <- (phi * q, phi * f + e): the partner's chunks come first in the sweep
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double n1 = phi[0] * f[l][0] + phi[1] * f[l][1] + e[l][0];
+                const double n2 = phi[2] * f[l][0] + phi[3] * f[l][1] + e[l][1];
+                e[l][0] = n1; e[l][1] = n2;
+            }
+            const double r00 = phi[0] * q[0] + phi[1] * q[2], r01 = phi[0] * q[1] + phi[1] * q[3];
+            const double r10 = phi[2] * q[0] + phi[3] * q[2], r11 = phi[2] * q[1] + phi[3] * q[3];
+            phi[0] = r00; phi[1] = r01; phi[2] = r10; phi[3] = r11;
+        }
+    }
+    // wave totals = the inclusive value of the last chunk of the wave along the sweep
+    const bool last_in_wave = (DIR > 0) ? (cw == CPW - 1 || c == C - 1) : (cw == 0);
+    if (last_in_wave) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_w[(w * 8 + k) * NM + m] = phi[k];
+        s_w[(w * 8 + 4) * NM + m] = e[0][0]; s_w[(w * 8 + 5) * NM + m] = e[0][1];
+        s_w[(w * 8 + 6) * NM + m] = e[1][0]; s_w[(w * 8 + 7) * NM + m] = e[1][1];
+    }
+    __syncthreads();
+    // what enters my wave: the waves before it along the sweep, composed in order
+    const int nw = (blockDim.x + 63) >> 6;
+    double pe[2][2] = {{0, 0}, {0, 0}};
+    if (DIR > 0) {
+        for (int v = 0; v < w; ++v) {
+            const double a0 = s_w[(v * 8 + 0) * NM + m], a1 = s_w[(v * 8 + 1) * NM + m], a2 = s_w[(v * 8 + 2) * NM + m], a3 = s_w[(v * 8 + 3) * NM + m];
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double n1 = a0 * pe[l][0] + a1 * pe[l][1] + s_w[(v * 8 + 4 + 2 * l) * NM + m];
+                const double n2 = a2 * pe[l][0] + a3 * pe[l][1] + s_w[(v * 8 + 5 + 2 * l) * NM + m];
+                pe[l][0] = n1; pe[l][1] = n2;
+            }
+        }
+    } else {
+        for (int v = nw - 1; v > w; --v) {
+            const double a0 = s_w[(v * 8 + 0) * NM + m], a1 = s_w[(v * 8 + 1) * NM + m], a2 = s_w[(v * 8 + 2) * NM + m], a3 = s_w[(v * 8 + 3) * NM + m];
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double n1 = a0 * pe[l][0] + a1 * pe[l][1] + s_w[(v * 8 + 4 + 2 * l) * NM + m];
+                const double n2 = a2 * pe[l][0] + a3 * pe[l][1] + s_w[(v * 8 + 5 + 2 * l) * NM + m];
+                pe[l][0] = n1; pe[l][1] = n2;
+            }
+        }
+    }
+    // inclusive value of my chunk over the whole line, then the previous chunk's along the sweep = my inflow
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const double f1 = phi[0] * pe[l][0] + phi[1] * pe[l][1] + e[l][0];
+        const double f2 = phi[2] * pe[l][0] + phi[3] * pe[l][1] + e[l][1];
+        const double g1 = (DIR > 0) ? __shfl_up(f1, NM) : __shfl_down(f1, NM);
+        const double g2 = (DIR > 0) ? __shfl_up(f2, NM) : __shfl_down(f2, NM);
+        const bool first_in_wave = (DIR > 0) ? (cw == 0) : (cw == CPW - 1 || c == C - 1);
+        in[l][0] = first_in_wave ? pe[l][0] : g1;
+        in[l][1] = first_in_wave ? pe[l][1] : g2;
+    }
+    __syncthreads();      // s_w is reused by the next scan
+}
+
+// One FDM_Int1_Solve of BOTH lines (Re, Im) for the rows of this thread.
+//   fl[p][l], p = 0..9: f rows j0-1 .. j0+8 (the halo rows are only read where they exist)
+//   res0 / resN: the boundary values as MatMul_3d sees them (fdm_integral.f90:240-245)
+//   x[p][l]: solution rows j0..j0+7 (boundary rows included after the reconstruction)
+//   ext[l]: BC == 1: unused; BC == 2: du at the top (valid in the last chunk)
+// LDS: s_w [nwaves][8][NM] (scan), s_k [OK_SIZE][NM] (boundary rows), s_fac [threads][25] (backward factors)
+template <int BC, int NM>
+__device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const double *__restrict__ chk, int nm, int t, int c, int C, int m,
+                                          const double (&fl)[OM + 2][2], const double (&res0)[2], const double (&resN)[2],
+                                          double (&x)[OM][2], double (&ext)[2], double *s_w, double *s_k, double *s_fac) {
+    const int n = T.n, j0 = c * OM;
+    if (c == 1) {              // C >= 2; chunk 1 never touches a boundary row itself
+        OdeRows k;
+        ode_boundary_rows<BC>(T, lam, k);
+        ode_rows_to_lds<NM>(k, s_k, m);
+    }
+    __syncthreads();
+#define KK(field, q) s_k[((field) + (q)) * NM + m]
+#define KRB(j, cc) s_k[(OK_RB + (j) * 4 + (cc)) * NM + m]
+#define KRT(j, cc) s_k[(OK_RT + (j) * 4 + (cc)) * NM + m]
+    // ---- factors of my rows, from the checkpoint ----
+    double st[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) st[q] = (c == 0) ? 0.0 : chk[(unsigned)((c * 6 + q) * nm + t)];      // 32-bit indices: checked on the host
+    double am[OM], bm[OM];             // forward multipliers in registers; the backward factors (1/c, -d, -e) wait in LDS
+    double *my_fac = s_fac + threadIdx.x * (3 * OM + 1);      // thread-major with an odd stride: constant offsets, no bank conflicts
+#define FAC(p, q) my_fac[(p) * 3 + (q)]
+    double (&rhs)[OM][2] = x;          // right-hand side -> y -> x in place
+    const double fn2[2] = {fl[OM - 1][0], fl[OM - 1][1]};      // f(n-2) of the last chunk, for du (the only use of fl after the rhs)
+    double bcs_b[2] = {0, 0}, bcs_t[2] = {0, 0};
+    // The special rows sit at fixed positions of the first and the last chunk (requires n = 8 C): row 0 / n-1 are not part of the
+    // system, rows 1, 2 / n-3, n-2 carry the reduced boundary closures.  Conditions are written on the unrolled p so that they fold away
+    // everywhere else, and the special cases are selections of coefficients, not branches.
+    const bool lo = (c == 0), hi = (c == C - 1);
+#pragma unroll
+    for (int p = 0; p < OM; ++p) {
+        const int j = j0 + p;
+        const bool off = (p == 0 && lo) || (p == OM - 1 && hi);         // boundary rows
+        double r[5];
+        lhs_row_t(T, j, lam, r);
+        double c0 = T.R[(unsigned)(j * 3 + 0)], c1 = T.R[(unsigned)(j * 3 + 1)], c2 = 1.0, cb = 0.0, ct = 0.0;     // rhs = c0 f(j-1) + c1 f(j) + c2 f(j+1) + cb res0 + ct resN
+        if (p == 1 && lo) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = KK(OK_L1, q);
+            c0 = 0.0; c1 = KRB(1, 2); c2 = KRB(1, 3); cb = KRB(1, 1);
+        }
+        if (p == 2 && lo) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = KK(OK_L2, q);
+            c0 = KRB(2, 1); c1 = KRB(2, 2); c2 = KRB(2, 3); cb = KRB(2, 0);
+        }
+        if (p == OM - 3 && hi) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = KK(OK_LN2, q);
+            c0 = KRT(0, 0); c1 = KRT(0, 1); c2 = KRT(0, 2); ct = KRT(0, 3);
+        }
+        if (p == OM - 2 && hi) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = KK(OK_LN1, q);
+            c0 = KRT(1, 0); c1 = KRT(1, 1); c2 = 0.0; ct = KRT(1, 2);
+        }
+        // PENTADFS step (linear5.f90:30-71): row 1 starts the elimination, row 2 has one sub-diagonal, the rest two
+        double a_m = 0.0, b_m = 0.0, cm = r[2], dm = r[3];
+        const double em = r[4];
+        if (p >= 3 || !lo) {
+            a_m = r[0] / st[3];
+            b_m = (r[1] - a_m * st[4]) / st[0];
+            cm = r[2] - b_m * st[1] - a_m * st[5];
+            dm = r[3] - b_m * st[2];
+        } else if (p == 2) {
+            b_m = r[1] / st[0];
+            cm = r[2] - b_m * st[1];
+            dm = r[3] - b_m * st[2];
+        }
+        if (off) { a_m = 0.0; b_m = 0.0; }
+        am[p] = a_m; bm[p] = b_m;
+        FAC(p, 0) = off ? 1.0 : 1.0 / cm; FAC(p, 1) = off ? 0.0 : -dm; FAC(p, 2) = off ? 0.0 : -em;
+        if (!off) {
+            st[3] = st[0]; st[4] = st[1]; st[5] = st[2];
+            st[0] = cm; st[1] = dm; st[2] = em;
+        }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const double fm = fl[p][l], fc = fl[p + 1][l], fp = fl[p + 2][l];
+            double v = fm * c0 + fc * c1 + fp * c2;
+            if ((p == 1 || p == 2) && lo) v = res0[l] * cb + v;          // (order of the reference: boundary term first, fdm_matmul.f90:93-94)
+            if ((p == OM - 3 || p == OM - 2) && hi) v = v + resN[l] * ct;
+            rhs[p][l] = off ? 0.0 : v;
+            if (p == 1 && lo) bcs_b[l] = res0[l] * KRB(0, 2) + fc * KRB(0, 3) + fp * KRB(0, 1);
+            if (p == OM - 2 && hi) bcs_t[l] = fm * KRT(2, 2) + fc * KRT(2, 0) + resN[l] * KRT(2, 1);
+        }
+        if (p & 1) __builtin_amdgcn_sched_barrier(0);      // table loads of two rows in flight, not of all eight (96 doubles)
+    }
+    // ---- forward substitution: particular end values + transfer matrix, scan, repeat with the inflow ----
+    double inflow[2][2];
+    {
+        double y1[2] = {0, 0}, y2[2] = {0, 0};
+        double h1a = 1.0, h2a = 0.0, h1b = 0.0, h2b = 1.0;     // responses to unit inflows (y[j0-1], y[j0-2]) = (1,0), (0,1)
+#pragma unroll
+        for (int p = 0; p < OM; ++p) {
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double y = rhs[p][l] - y1[l] * bm[p] - y2[l] * am[p];
+                y2[l] = y1[l]; y1[l] = y;
+            }
+            const double ha = -h1a * bm[p] - h2a * am[p]; h2a = h1a; h1a = ha;
+            const double hb = -h1b * bm[p] - h2b * am[p]; h2b = h1b; h1b = hb;
+        }
+        // out = (y[j0+7], y[j0+6]) = Phi (in1, in2) + end
+        double phi[4] = {h1a, h1b, h2a, h2b}, ee[2][2] = {{y1[0], y2[0]}, {y1[1], y2[1]}};
+        ode_chain<NM, +1>(phi, ee, c, C, m, s_w, inflow);
+    }
+    double (&y)[OM][2] = x;
+    {
+        double y1[2] = {inflow[0][0], inflow[1][0]}, y2[2] = {inflow[0][1], inflow[1][1]};
+#pragma unroll
+        for (int p = 0; p < OM; ++p)
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double v = rhs[p][l] - y1[l] * bm[p] - y2[l] * am[p];
+                y[p][l] = v; y2[l] = y1[l]; y1[l] = v;
+            }
+    }
+    __syncthreads();
+    // ---- backward substitution, same scheme downwards: in = (x[j0+8], x[j0+9]), out = (x[j0], x[j0+1]) ----
+    {
+        double x1[2] = {0, 0}, x2[2] = {0, 0};
+        double h1a = 1.0, h2a = 0.0, h1b = 0.0, h2b = 1.0;
+#pragma unroll
+        for (int p = OM - 1; p >= 0; --p) {
+            const double cinv_p = FAC(p, 0), nd_p = FAC(p, 1), ne_p = FAC(p, 2);
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double v = (y[p][l] + x1[l] * nd_p + x2[l] * ne_p) * cinv_p;
+                x2[l] = x1[l]; x1[l] = v;
+            }
+            const double ha = (h1a * nd_p + h2a * ne_p) * cinv_p; h2a = h1a; h1a = ha;
+            const double hb = (h1b * nd_p + h2b * ne_p) * cinv_p; h2b = h1b; h1b = hb;
+        }
+        double phi[4] = {h1a, h1b, h2a, h2b}, ee[2][2] = {{x1[0], x2[0]}, {x1[1], x2[1]}};
+        ode_chain<NM, -1>(phi, ee, c, C, m, s_w, inflow);
+    }
+    {
+        double x1[2] = {inflow[0][0], inflow[1][0]}, x2[2] = {inflow[0][1], inflow[1][1]};
+#pragma unroll
+        for (int p = OM - 1; p >= 0; --p) {
+            const double cinv_p = FAC(p, 0), nd_p = FAC(p, 1), ne_p = FAC(p, 2);
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double v = (y[p][l] + x1[l] * nd_p + x2[l] * ne_p) * cinv_p;
+                x[p][l] = v; x2[l] = x1[l]; x1[l] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- boundary value at the free end, derivative at the given end (fdm_integral.f90:265-311) ----
+    ext[0] = ext[1] = 0.0;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (BC == 2) {
+            if (c == 0) x[0][l] = bcs_b[l] + KK(OK_L0, 3) * x[1][l] + KK(OK_L0, 4) * x[2][l] + KK(OK_L0, 0) * x[3][l];
+            if (c == C - 1) {
+                x[OM - 1][l] = resN[l];
+                // rows n-2, n-3, n-4 = p 6, 5, 4 ; f[n-2] = fl[7]
+                ext[l] = KK(OK_LN, 2) * resN[l] + KK(OK_LN, 1) * x[OM - 2][l] + KK(OK_LN, 0) * x[OM - 3][l] + KK(OK_LN, 4) * x[OM - 4][l] +
+                         T.R[(n - 1) * 3 + 0] * fn2[l];
+            }
+        } else {
+            if (c == C - 1) x[OM - 1][l] = bcs_t[l] + KK(OK_LN, 1) * x[OM - 2][l] + KK(OK_LN, 0) * x[OM - 3][l] + KK(OK_LN, 4) * x[OM - 4][l];
+            if (c == 0) x[0][l] = res0[l];
+        }
+    }
+    __syncthreads();       // s_k is rewritten by the next solve
+#undef KK
+#undef KRB
+#undef KRT
+#undef FAC
+}
+
+template <int NM>
+__global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
+    extern __shared__ double lds[];
+    const int C = a.C, n = a.n;
+    const int m = threadIdx.x % NM, c = threadIdx.x / NM;
+    double *s_w = lds, *s_x = lds + 8 * 8 * NM;                                                  // s_w: [8 waves][8][NM]; s_x: [C][2 lines][2][NM]
+    double *s_sc = s_x + (size_t)C * 4 * NM;                                                     // [10][NM]
+    double *s_k = s_sc + 10 * NM;                                                                // [OK_SIZE][NM]
+    double *s_fac = s_k + OK_SIZE * NM;                                                          // [OM][3][threads]
+    // 32-bit index arithmetic throughout (the host checks that every array has < 2^31 elements): 64-bit address pairs for the ~50
+    // distinct rows this thread touches would otherwise be precomputed and kept in registers
+    const int nm = (int)a.nm;
+    int t = blockIdx.x * NM + m;
+    const bool live = t < nm;
+    if (!live) t = nm - 1;
+    const bool store = live && !a.skip[t];
+    const double lam = a.lam[t];
+    const unsigned fidx0 = (unsigned)((t % a.nxh) + a.nxh * a.ny * (t / a.nxh));
+    const int j0 = c * OM;
+    const double2 *F = reinterpret_cast<const double2 *>(a.f_hat);
+    double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
+
+    double u[OM][2], ext[2];
+    double v_1[2] = {0, 0}, u_n[2] = {0, 0}, fn[2] = {0, 0}, bb[2], bt[2];
+    double vh[OM + 2][2];        // rows j0-1 .. j0+8 of the u-solve's right-hand side v; vh[1..8] is where the v-solve puts v
+    {
+        // ---- f rows j0-1 .. j0+8 (normalised).  f(n) itself is never read by the solves: the callers' f(n) = 0 enters as resN (opr_odes.f90:303)
+        double fl[OM + 2][2];
+#pragma unroll
+        for (int p = 0; p < OM + 2; ++p) {
+            const int j = j0 - 1 + p;
+            double2 w = make_double2(0.0, 0.0);
+            if (j >= 0 && j <= n - 1) w = F[fidx0 + (unsigned)(j * a.nxh)];
+            fl[p][0] = w.x * a.fscale; fl[p][1] = w.y * a.fscale;
+        }
+        // Neumann data travel in the boundary rows of the forcing (opr_elliptic.f90:310-311)
+        if (c == 0) { s_sc[0 * NM + m] = fl[1][0]; s_sc[1 * NM + m] = fl[1][1]; }
+        if (c == C - 1) { s_sc[2 * NM + m] = fl[OM][0]; s_sc[3 * NM + m] = fl[OM][1]; }
+        __syncthreads();
+        bb[0] = s_sc[0 * NM + m]; bb[1] = s_sc[1 * NM + m]; bt[0] = s_sc[2 * NM + m]; bt[1] = s_sc[3 * NM + m];
+        // ---- v0' + lambda v0 = f, v0(1) = 0 ; f(n) = 0 ----
+        ode_solve<1, NM>(a.T1, lam, a.chk1, nm, t, c, C, m, fl, v_1, fn, reinterpret_cast<double (&)[OM][2]>(vh[1]), ext, s_w, s_k, s_fac);
+    }
+    // halo rows of v0 for the right-hand side of the u-solve
+#pragma unroll
+    for (int l = 0; l < 2; ++l) { s_x[((c * 2 + l) * 2 + 0) * NM + m] = vh[1][l]; s_x[((c * 2 + l) * 2 + 1) * NM + m] = vh[OM][l]; }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        vh[0][l] = (c > 0) ? s_x[(((c - 1) * 2 + l) * 2 + 1) * NM + m] : 0.0;
+        vh[OM + 1][l] = (c < C - 1) ? s_x[(((c + 1) * 2 + l) * 2 + 0) * NM + m] : 0.0;
+    }
+    if (c == C - 1) { s_sc[6 * NM + m] = vh[OM][0]; s_sc[7 * NM + m] = vh[OM][1]; }     // v0(n)
+    // ---- u0' - lambda u0 = v0, u0(n) = 0 ; the "opposite boundary value" is v0(1) = 0 (res(1) = f(1), fdm_integral.f90:243) ----
+    ode_solve<2, NM>(a.T2, -lam, a.chk2, nm, t, c, C, m, vh, v_1, u_n, u, ext, s_w, s_k, s_fac);
+    // ---- u0(1), v0(n), du0(n) -> the three constants (opr_odes.f90:350-356 with the LU of k_nn_constants) ----
+    if (c == 0) { s_sc[4 * NM + m] = u[0][0]; s_sc[5 * NM + m] = u[0][1]; }
+    if (c == C - 1) { s_sc[8 * NM + m] = ext[0]; s_sc[9 * NM + m] = ext[1]; }
+    __syncthreads();
+    {
+        const double a11 = a.cst[(unsigned)(0 * nm + t)], a21 = a.cst[(unsigned)(1 * nm + t)], a31 = a.cst[(unsigned)(2 * nm + t)];
+        const double a12 = a.cst[(unsigned)(3 * nm + t)], a22 = a.cst[(unsigned)(4 * nm + t)], a32 = a.cst[(unsigned)(5 * nm + t)];
+        const double a13 = a.cst[(unsigned)(6 * nm + t)], a23 = a.cst[(unsigned)(7 * nm + t)], a33 = a.cst[(unsigned)(8 * nm + t)];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const double u0_1 = s_sc[(4 + l) * NM + m], v0_n = s_sc[(6 + l) * NM + m], du0n = s_sc[(8 + l) * NM + m];
+            v_1[l] = (bb[l] - lam * u0_1) / a11;
+            u_n[l] = (bt[l] - v0_n - a21 * v_1[l]) / a22;
+            fn[l] = (bt[l] - du0n - a31 * v_1[l] - a32 * u_n[l]) / a33;
+            u_n[l] = u_n[l] - a23 * fn[l];
+            v_1[l] = v_1[l] - a12 * u_n[l] - a13 * fn[l];
+        }
+    }
+    // ---- superposition with the stored homogeneous solutions (opr_odes.f90:358-367); p^ = u, dp^/dy = v ----
+    if (!store) return;
+#pragma unroll
+    for (int p = 0; p < OM; ++p) {
+        const int j = j0 + p;
+        const unsigned h = (unsigned)(j * nm + t), hs = (unsigned)(n * nm);
+        const double hv1 = a.hom[h], hem = a.hom[h + hs], hu1 = a.hom[h + 2 * hs], hsp = a.hom[h + 3 * hs], hep = a.hom[h + 4 * hs];
+        double uu[2], vv[2];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const double u0 = u[p][l], v0 = vh[p + 1][l];
+            if (j == n - 1) {
+                uu[l] = u_n[l];
+                vv[l] = v0 + fn[l] * hv1 + v_1[l] * hem + lam * uu[l];
+            } else if (j == 0) {
+                uu[l] = u0 + fn[l] * hu1 + v_1[l] * hsp + u_n[l] * hep;
+                vv[l] = v_1[l] + lam * uu[l];
+            } else {
+                uu[l] = u0 + fn[l] * hu1 + v_1[l] * hsp + u_n[l] * hep;
+                vv[l] = v0 + fn[l] * hv1 + v_1[l] * hem + lam * uu[l];
+            }
+        }
+        const unsigned idx = fidx0 + (unsigned)(j * a.nxh);
+        P[idx] = make_double2(uu[0], uu[1]);
+        D[idx] = make_double2(vv[0], vv[1]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-mode constants of OPR_ODE2_Factorize_NN: LU of the 3x3 constraint matrix (opr_odes.f90:329-348)
 // hom: SoA [(c*n + j)*nm + t], c = 0 v1, 1 em, 2 u1, 3 sp, 4 ep ; der: [(c*nm + t)], c = 0 du1_n, 1 dsp_n, 2 dep_n
@@ -506,6 +1048,9 @@ struct tlab_poisson_plan {
     DBuf hom, der, cst;               // homogeneous solutions [5][ny][nm], their boundary derivatives [3][nm], 3x3 LU [9][nm]
     DBuf scratch, v0, u0, du0, bcs;   // per-call work: [5][ny][nm], [2][ny][nm] x2, [2][nm], [4][nm]
     DBuf cwork;                       // complex work field (nxh*ny*nz complex)
+    DBuf d_bt[2], chk[2];             // chunked ODE kernel: boundary constants [3][4] and PENTADFS checkpoints [C][6][nm] of both systems
+    bool use_chunked = false;
+    int ode_nm_per_wg = 0;
     std::vector<int> sing_modes;      // flat mode indices t = kx + nxh*kz of the singular modes
     int *d_sing = nullptr;
     unsigned char *d_skip = nullptr;
@@ -521,6 +1066,11 @@ struct tlab_poisson_plan {
         if (side) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+    }
+    OdeSys sys(int which) const {
+        OdeSys d;
+        d.L0 = d_L0[which].p; d.L1 = d_L1[which].p; d.R = d_R[which].p; d.bt = d_bt[which].p; d.n = ny;
+        return d;
     }
     Int1Dev dev(int which) const {
         const Int1Tables &T = which == 0 ? tmin : tmax;
@@ -557,6 +1107,61 @@ Int1Args base_args(const tlab_poisson_plan &P, int which, const double *lam, lon
     a.ny = P.ny;
     a.scratch = scratch;
     return a;
+}
+
+// ---- chunked ODE kernel: geometry, checkpoints, launch ----
+int ode_modes_per_wg(int C) {
+    int nmw = 64;
+    while (nmw > 4 && nmw * C > 512) nmw >>= 1;
+    return (nmw * C <= 512) ? nmw : 0;
+}
+size_t ode_lds_bytes(int C, int NM) { return ((size_t)(64 + 4 * C + 10 + OK_SIZE) * NM + (size_t)(3 * OM + 1) * NM * C) * sizeof(double); }
+
+template <int NM>
+void launch_ode_nm(const OdeArgs &a, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ode_nn<NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((a.nm + NM - 1) / NM);
+    hipLaunchKernelGGL((k_ode_nn<NM>), dim3(grid), dim3(NM * a.C), lds, st, a);
+}
+
+void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
+    OdeArgs a{};
+    a.T1 = P.sys(0); a.T2 = P.sys(1);
+    a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = P.cst.p; a.hom = P.hom.p;
+    a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
+    a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.nm = P.nm;
+    const int NM = P.ode_nm_per_wg;
+    const size_t lds = ode_lds_bytes(a.C, NM);
+    ProfScope ps("k_ode_nn", st, (double)P.nm * P.ny * 48.0);
+    switch (NM) {
+    case 4: launch_ode_nm<4>(a, lds, st); break;
+    case 8: launch_ode_nm<8>(a, lds, st); break;
+    case 16: launch_ode_nm<16>(a, lds, st); break;
+    case 32: launch_ode_nm<32>(a, lds, st); break;
+    default: launch_ode_nm<64>(a, lds, st); break;
+    }
+    hipc(hipGetLastError(), "k_ode_nn");
+}
+
+void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
+    const int C = P.ny / OM;
+    for (int w = 0; w < 2; ++w) {
+        const Int1Tables &T = w == 0 ? P.tmin : P.tmax;
+        std::vector<double> bt(12);
+        for (int j = 0; j < 3; ++j)
+            for (int c = 0; c < 4; ++c) bt[j * 4 + c] = (w == 0) ? T.rb[j][c] : T.rt[j][c];
+        P.d_bt[w].upload(bt);
+        P.chk[w].alloc((size_t)C * 6 * P.nm);
+    }
+    const int grid = (int)((P.nm + 255) / 256);
+    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(grid), dim3(256), 0, st, P.sys(0), P.lam.p, 1.0, P.chk[0].p, P.nm);
+    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(grid), dim3(256), 0, st, P.sys(1), P.lam.p, -1.0, P.chk[1].p, P.nm);
+    hipc(hipGetLastError(), "k_ode_checkpoint");
 }
 
 void build_fft(tlab_poisson_plan &P) {
@@ -744,7 +1349,21 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         hipc(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), "event");
         hipStream_t st = tlab_current_stream();
         build_homogeneous(*P, st);
+        {   // chunked ODE kernel (k_ode_nn) when the line splits into 8-row chunks and 32-bit indices suffice; TLAB_ODE_CHUNKED=0 keeps k_int1
+            const char *e = getenv("TLAB_ODE_CHUNKED");
+            const int C = ny / OM;
+            const long long big = std::max<long long>((long long)5 * ny * nm, std::max<long long>(9 * nm, (long long)P->nxh * ny * nz));
+            if (!(e && atoi(e) == 0) && ny % OM == 0 && C >= 2 && ode_modes_per_wg(C) > 0 && big < (1LL << 31) &&
+                ode_lds_bytes(C, ode_modes_per_wg(C)) <= (size_t)160 * 1024) {
+                P->ode_nm_per_wg = ode_modes_per_wg(C);
+                build_checkpoints(*P, st);
+                P->use_chunked = true;
+            }
+        }
         hipc(hipStreamSynchronize(st), "sync");
+        if (P->use_chunked) {   // the scratch of the marching kernels is not needed any more
+            P->scratch.alloc(0); P->v0.alloc(0); P->u0.alloc(0);
+        }
         *out = P.release();
         return TLAB_OK;
     } catch (const std::invalid_argument &e) {
@@ -788,12 +1407,14 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
     hipc(hipEventRecord(P->ev_fork, st), "event record");
     hipc(hipStreamWaitEvent(P->side, P->ev_fork, 0), "stream wait");
     // ---- regular modes: OPR_ODE2_Factorize_NN (opr_odes.f90:302-318) ----
-    Int1Args a = base_args(*P, 0, P->lam.p, nm, P->scratch.p);   // v' + l v = f, v(1) = 0
-    a.fsrc = f_hat; a.fscale = P->norm; a.zero_bsave = 1; a.bcs_save = P->bcs.p; a.dst = P->v0.p;
-    launch_int1<1, 2, FS_FIELD>(a, st);
-    Int1Args b = base_args(*P, 1, P->lam.p, nm, P->scratch.p);   // u' - l u = v, u(n) = 0
-    b.fsrc = P->v0.p; b.nlf = 2; b.zero_bsave = 0; b.dst = P->u0.p; b.du = P->du0.p;
-    launch_int1<2, 2, FS_LINEAR>(b, st);
+    if (!P->use_chunked) {
+        Int1Args a = base_args(*P, 0, P->lam.p, nm, P->scratch.p);   // v' + l v = f, v(1) = 0
+        a.fsrc = f_hat; a.fscale = P->norm; a.zero_bsave = 1; a.bcs_save = P->bcs.p; a.dst = P->v0.p;
+        launch_int1<1, 2, FS_FIELD>(a, st);
+        Int1Args b = base_args(*P, 1, P->lam.p, nm, P->scratch.p);   // u' - l u = v, u(n) = 0
+        b.fsrc = P->v0.p; b.nlf = 2; b.zero_bsave = 0; b.dst = P->u0.p; b.du = P->du0.p;
+        launch_int1<2, 2, FS_LINEAR>(b, st);
+    }
     // ---- singular modes: OPR_ODE2_Factorize_NN_Sing -> _DN_Sing (opr_odes.f90:165-183, 37-96) ----
     const int ns = (int)P->sing_modes.size();
     hipStream_t ss = P->side;   // independent of the regular modes until the scatter below
@@ -814,12 +1435,14 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
         launch_int1<1, 2, FS_LINEAR>(s4, ss);
     }
     // ---- superposition ----
-    CombineArgs c{};
-    c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.hom = P->hom.p; c.cst = P->cst.p; c.lam = P->lam.p;
-    c.skip = P->d_skip; c.p_hat = p_hat; c.dp_hat = dp_hat; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
-    {
+    if (!P->use_chunked) {
+        CombineArgs c{};
+        c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.hom = P->hom.p; c.cst = P->cst.p; c.lam = P->lam.p;
+        c.skip = P->d_skip; c.p_hat = p_hat; c.dp_hat = dp_hat; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
         ProfScope ps("k_nn_combine", st, (double)nm * n * (9 + 4) * 8.0);
         hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+    } else {
+        launch_ode(*P, f_hat, p_hat, dp_hat, st);      // both solves, the constants and the final pass in one kernel
     }
     // the singular modes write other entries than k_nn_combine (which skips them), but f^ must have been consumed by the regular
     // v-solve first when p_hat aliases it: order the scatter after it through the main stream

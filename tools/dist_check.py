@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Multi-process check of the z-slab algorithm: every rank runs its slab through SlabDns(DistComm) and compares with the
+single-domain substep computed redundantly on its own device.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node P --master-addr 127.0.0.1 --master-port 29533 tools/dist_check.py [--zmode halo]
+
+On an N-GPU node it uses RCCL (backend nccl).  With TLAB_DIST_BACKEND=gloo all ranks may share one GPU (payloads staged through
+the host): that is how the multi-process logic is exercised on the single-GPU test box (tests/test_gpu_dist.py)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=32)
+    ap.add_argument("--ny", type=int, default=24)
+    ap.add_argument("--nz", type=int, default=128)
+    ap.add_argument("--zmode", default="auto")
+    ap.add_argument("--bcs", default="noslip")
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("TLAB_DIST_BACKEND", "nccl")
+    dev = local % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend)
+    import tlab_amd as T
+    from tlab_amd.dns import Dns
+    from tlab_amd.parallel import SlabDns, DistComm
+    T.init(dev)
+    nx, ny, nz = args.nx, args.ny, args.nz
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(7)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    fields = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
+    one = Dns(x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False)
+    slab = SlabDns(DistComm(), x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, zmode=args.zmode)
+    if args.bcs == "freeslip":
+        one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+        slab.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+    for i in range(3):
+        t = torch.from_numpy(fields[i]).cuda()
+        one.q[i].copy_(t); slab.scatter("q", i, t)
+    t = torch.from_numpy(fields[3]).cuda()
+    one.s[0].copy_(t); slab.scatter("s", 0, t)
+    dtime = 2e-3
+    for k in range(3):
+        if k == 0:
+            for h in one.hq + one.hs:
+                h.zero_()
+        last = k == 2
+        one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * one.kdt[k], 1.0 if last else one.kco[k], not last)
+        slab.substep_of_cycle(k, dtime)
+    worst = 0.0
+    n = slab.n
+    for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
+        for i, rf in enumerate(ref):
+            got = slab.st[rank][name][i]
+            err = float((got - rf[rank * n:(rank + 1) * n]).abs().max() / rf.abs().max())
+            worst = max(worst, err)
+    tt = torch.tensor([worst], dtype=torch.float64)
+    if backend == "nccl":
+        tt = tt.cuda()
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print("DIST_CHECK world=%d zmode=%s backend=%s worst_rel_err=%.3e %s" % (world, slab.zmode, backend, float(tt.item()),
+                                                                                 "OK" if float(tt.item()) <= 1e-11 else "FAIL"))
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if float(tt.item()) <= 1e-11 else 1)
+
+
+if __name__ == "__main__":
+    main()
