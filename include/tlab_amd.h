@@ -160,6 +160,10 @@ int tlab_opr_burgers_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int
                          double *result, double *tmp1, double *tmp2);
 int tlab_opr_partial_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub, double scale,
                          double *result, int acc, double *tmp1, double *tmp2);
+/* nf (1..4) transported fields advected by the same velocity (the u-, v-, w- and scalar equations all call OPR_Burgers_X with u, etc.):
+ * result[f] += nu[f] d2s[f]/dx2 - vel ds[f]/dx in one launch, the velocity being fetched from HBM once.  HOST arrays of DEVICE pointers. */
+int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
+                           const double *vel, double *const *result, double *tmp1, double *tmp2);
 
 /* ---- z-derivatives on a z-slab without transposes (multi-GPU) ---------------------------------------------
  * Replaces TLabMPI_Trp_ExecK_Forward + OPR_Partial_Z / OPR_Burgers_Z + TLabMPI_Trp_ExecK_Backward (opr_partial.f90:154-262,

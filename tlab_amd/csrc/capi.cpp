@@ -426,6 +426,11 @@ struct OpExtra {
     const double *in0b = nullptr;
     double scale = 0.0;
     bool acc = false;
+    // MODE_BURGERS with several transported fields and one advecting velocity
+    int nf = 0;
+    const double *fs[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *fo[4] = {nullptr, nullptr, nullptr, nullptr};
+    double fnu[4] = {0, 0, 0, 0};
 };
 const OpExtra kNoExtra{};
 
@@ -454,6 +459,7 @@ void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     RTileArgs a;
     a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.out1 = nullptr; a.g = geom; a.nu = nu;
     a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
+    a.nf = 0;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     a.y1 = g->system(1, ibc, P).dev();
@@ -472,6 +478,8 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     RTileArgs a;
     a.in0 = in0; a.in1 = nullptr; a.in2 = vel; a.out0 = out0; a.out1 = out1; a.g = geom; a.nu = nu;
     a.in0b = nullptr; a.in0b_scale = 0.0; a.acc = ex.acc ? 1 : 0;
+    a.nf = ex.nf > 0 ? ex.nf : 1;
+    for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; }
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     a.y1 = g->system(1, ibc, C).dev();
@@ -485,6 +493,8 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     XLineArgs a;
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1; a.nlines = geom.nlines; a.nu = nu;
     a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
+    a.nf = ex.nf > 0 ? ex.nf : 1;
+    for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; }
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     SystemEntry &e1 = g->system(1, ibc, 64), &e2 = g->system(2, 0, 64);
@@ -556,6 +566,36 @@ bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int n
     return true;
 }
 
+bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz) {
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (geom.n == 1) return false;
+    const int path = choose_path(dir, geom.n);
+    return (path == PATH_XLINE && !g->t.der2.need_1der) || (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS));
+}
+// several transported fields, one advecting velocity: result[f] += nu[f] d2 s[f] - vel d s[f]
+bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
+                                 const double *vel, double *const *result) {
+    check_common(dir, g, nx, ny, nz, ibc);
+    if (nf < 1 || nf > 4) throw Invalid("1 to 4 fields per call");
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (geom.n == 1) return false;
+    OpExtra ex;
+    ex.acc = true;
+    ex.nf = nf;
+    for (int f = 0; f < nf; ++f) { ex.fs[f] = s[f]; ex.fo[f] = result[f]; ex.fnu[f] = nu[f]; }
+    const bool corr = g->t.der2.need_1der;
+    const int path = choose_path(dir, geom.n);
+    if (path == PATH_XLINE && !corr) {
+        run_xline(g, geom, MODE_BURGERS, ibc, s[0], vel, result[0], nullptr, nu[0], ex);
+    } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {
+        run_htile(g, geom, MODE_BURGERS, ibc, s[0], vel, result[0], nullptr, nu[0], ex);
+    } else {
+        return false;
+    }
+    g_last_path = path;
+    return true;
+}
+
 extern "C" {
 
 int tlab_last_kernel_path(void) { return g_last_path; }
@@ -582,6 +622,21 @@ int tlab_opr_burgers_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int
         const int rc = tlab_opr_burgers(dir, g, s == vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, nx, ny, nz, ibc, nu, s, vel, tmp1, tmp2, 0);
         if (rc != TLAB_OK) throw Invalid(std::string("tlab_opr_burgers_add: ") + g_err);
         hip_check(launch_add1(result, tmp1, (long long)nx * ny * nz, g_stream), "k_add1");
+    });
+}
+
+int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
+                           const double *vel, double *const *result, double *tmp1, double *tmp2) {
+    return guarded([&] {
+        check_common(dir, g, nx, ny, nz, ibc);
+        if (nf < 1 || nf > 4 || !nu || !s || !vel || !result) throw Invalid("tlab_opr_burgers_add_n: bad arguments (1 to 4 fields)");
+        for (int f = 0; f < nf; ++f)
+            if (!s[f] || !result[f] || result[f] == s[f] || result[f] == vel) throw Invalid("tlab_opr_burgers_add_n: null or aliased arrays");
+        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result)) return;
+        for (int f = 0; f < nf; ++f) {
+            const int rc = tlab_opr_burgers_add(dir, g, nx, ny, nz, ibc, nu[f], s[f], vel, result[f], tmp1, tmp2);
+            if (rc != TLAB_OK) throw Invalid(std::string("tlab_opr_burgers_add_n: ") + g_err);
+        }
     });
 }
 

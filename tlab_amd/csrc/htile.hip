@@ -98,25 +98,40 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
     // (the first __syncthreads inside h_solve would be too late for the coefficient reads of the local sweeps)
     __syncthreads();
 
+    // MODE_BURGERS: one launch serves every transported field that shares the advecting velocity.  Workgroup ids are dealt round-robin
+    // to the 8 XCDs (each with its own L2), so the nf workgroups of a tile get ids with the same residue mod 8 and follow each other
+    // closely in the dispatch order: bid = x + 8 (f + nf y), tile = x + 8 y.  The velocity tile is then fetched from HBM once and the
+    // other fields' reads of it hit (or merge in) that XCD's L2.
     const int tiles_inner = (a.g.lines_inner + 31) >> 5;
-    const long long outer = blockIdx.x / tiles_inner;
-    const int l0 = (int)(blockIdx.x % tiles_inner) << 5;
+    long long tile = blockIdx.x;
+    int fi = 0;
+    if (MODE == MODE_BURGERS) {
+        const long long q = blockIdx.x >> 3;
+        fi = (int)(q % a.nf);
+        tile = (blockIdx.x & 7) + 8 * (q / a.nf);
+        if (tile >= (long long)tiles_inner * (a.g.nlines / a.g.lines_inner)) return;     // whole workgroup, before any barrier
+    }
+    const long long outer = tile / tiles_inner;
+    const int l0 = (int)(tile % tiles_inner) << 5;
     const bool valid = (l0 + l32) < a.g.lines_inner;
     const long long base = outer * a.g.outer_stride + l0 + l32;
     const int row0 = c * M;
+    const double *__restrict__ in0 = (MODE == MODE_BURGERS) ? a.fs[fi] : a.in0;
+    double *__restrict__ out0 = (MODE == MODE_BURGERS) ? a.fo[fi] : a.out0;
+    const double nu = (MODE == MODE_BURGERS) ? a.fnu[fi] : a.nu;
 
     // ---- operand rows + 3-row halos ----
     double e[M + 6];
 #pragma unroll
-    for (int p = 0; p < M; ++p) e[p + 3] = valid ? a.in0[base + (long long)(row0 + p) * rs] : 0.0;
+    for (int p = 0; p < M; ++p) e[p + 3] = valid ? in0[base + (long long)(row0 + p) * rs] : 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int rl = row0 - 3 + k, rr = row0 + M + k;
         const bool okl = per || rl >= 0, okr = per || rr < n;
         if (rl < 0) rl += n;
         if (rr >= n) rr -= n;
-        e[k] = (valid && okl) ? a.in0[base + (long long)rl * rs] : 0.0;
-        e[M + 3 + k] = (valid && okr) ? a.in0[base + (long long)rr * rs] : 0.0;
+        e[k] = (valid && okl) ? in0[base + (long long)rl * rs] : 0.0;
+        e[M + 3 + k] = (valid && okr) ? in0[base + (long long)rr * rs] : 0.0;
     }
 
     // ---- right-hand sides of both systems from the one operand ----
@@ -183,31 +198,32 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
     }
 
     // ---- epilogue ----
-    if (!valid) return;
+    if (valid) {
     if constexpr (MODE == MODE_P1) {
 #pragma unroll
-        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x1[p];
+        for (int p = 0; p < M; ++p) out0[base + (long long)(row0 + p) * rs] = x1[p];
     } else if constexpr (MODE == MODE_P2) {
 #pragma unroll
-        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x2[p];
+        for (int p = 0; p < M; ++p) out0[base + (long long)(row0 + p) * rs] = x2[p];
     } else if constexpr (MODE == MODE_P2_P1) {
 #pragma unroll
         for (int p = 0; p < M; ++p) {
-            a.out0[base + (long long)(row0 + p) * rs] = x2[p];
+            out0[base + (long long)(row0 + p) * rs] = x2[p];
             a.out1[base + (long long)(row0 + p) * rs] = x1[p];
         }
     } else {  // MODE_BURGERS: result = nu d2 - vel d1 (opr_burgers.f90:513)
 #pragma unroll
-        for (int p = 0; p < M; ++p) x2[p] = a.nu * x2[p] - vl[p] * x1[p];
+        for (int p = 0; p < M; ++p) x2[p] = nu * x2[p] - vl[p] * x1[p];
         if (a.acc) {   // accumulate into the tendency: all loads first (the compiler cannot move them across the stores itself)
 #pragma unroll
-            for (int p = 0; p < M; ++p) x1[p] = a.out0[base + (long long)(row0 + p) * rs];
+            for (int p = 0; p < M; ++p) x1[p] = out0[base + (long long)(row0 + p) * rs];
 #pragma unroll
             for (int p = 0; p < M; ++p) x2[p] = x1[p] + x2[p];
         }
 #pragma unroll
-        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x2[p];
+        for (int p = 0; p < M; ++p) out0[base + (long long)(row0 + p) * rs] = x2[p];
     }
+    }   // valid
 }
 
 // chunk length of the half-wave-tile kernel for a line length n and a mode (0 = unsupported)
@@ -227,12 +243,18 @@ int htile_chunk(int n, int mode) {
 
 template <int M, int MAXT>
 static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileArgs &a, hipStream_t st) {
-    const dim3 grid((unsigned)tiles), block(32 * C);
+    const long long nwg = (mode == MODE_BURGERS) ? 8LL * a.nf * ((tiles + 7) / 8) : tiles;      // see the blockIdx mapping in the kernel
+    const dim3 grid((unsigned)nwg), block(32 * C);
     const size_t lds = ((size_t)13 * a.g.n + (size_t)2 * C * C) * sizeof(double);
     const double pts = (double)a.g.nlines * a.g.n;
     const char *name = mode == MODE_P1 ? "k_htile<P1>" : mode == MODE_P2 ? "k_htile<P2>" : mode == MODE_P2_P1 ? "k_htile<P2_P1>" : "k_htile<BURGERS>";
     const double bpp = (mode == MODE_P1 || mode == MODE_P2) ? 16 : 24;
-    ProfScope ps(name, st, pts * (bpp + (a.acc ? 8 : 0)));
+    double bytes = pts * (bpp + (a.acc ? 8 : 0));
+    if (mode == MODE_BURGERS) {   // velocity once (re-reads are L2 hits by construction) + per field: operand unless it is the velocity, result, old result
+        bytes = pts * 8;
+        for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in2 ? 0 : 8) + 8 + (a.acc ? 8 : 0));
+    }
+    ProfScope ps(name, st, bytes);
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT>), grid, block, lds, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_htile<M, MODE_P2, MAXT>), grid, block, lds, st, a); break;

@@ -173,54 +173,81 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     const long long stride = (long long)gridDim.x * 4;
     for (long long line = (long long)blockIdx.x * 4 + wib; line < a.nlines; line += stride) {
         const long long off = line * n + lane * M;
-        double u[M];
-        xload<M>(u, a.in0 + off);
-        if (MODE == MODE_P1 && a.in0b != nullptr) {   // operand = in0 + s * in0b
-            double ub[M];
-            xload<M>(ub, a.in0b + off);
-#pragma unroll
-            for (int p = 0; p < M; ++p) u[p] = u[p] + ub[p] * a.in0b_scale;
-        }
-        double um[3], up[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            um[k] = shfl_d(u[M - 3 + k], (lane + 63) & 63);
-            up[k] = shfl_d(u[k], (lane + 1) & 63);
-        }
-        double x1[M], x2[M];
-        if (NEED1) {
-            xstencil<M, false>(x1, u, um, up, a.s1, lane);
-            xsolve<M, LV>(x1, y1, lane, n);
-        }
-        if (NEED2) {
-            xstencil<M, true>(x2, u, um, up, a.s2, lane);
-            xsolve<M, LV>(x2, y2, lane, n);
-        }
-        if (MODE == MODE_P1) {
-            if (a.acc) {
-                double o[M];
-                xload<M>(o, a.out0 + off);
-#pragma unroll
-                for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
-            }
-            xstore<M>(a.out0 + off, x1);
-        } else if (MODE == MODE_P2) {
-            xstore<M>(a.out0 + off, x2);
-        } else if (MODE == MODE_P2_P1) {
-            xstore<M>(a.out0 + off, x2);
-            xstore<M>(a.out1 + off, x1);
-        } else {  // MODE_BURGERS: result = nu d2 - vel d1   (opr_burgers.f90:513)
+        if constexpr (MODE == MODE_BURGERS) {
+            // the advecting velocity of the line is loaded once and serves every transported field (rhs_global_incompressible_1.f90:
+            // 98-162 calls OPR_Burgers_X four times with the same u)
             double v[M];
             xload<M>(v, a.in1 + off);
+            for (int f = 0; f < a.nf; ++f) {
+                const double *src = a.fs[f];
+                double *dst = a.fo[f];
+                const double nuf = a.fnu[f];
+                double u[M];
+                if (src == a.in1) {
 #pragma unroll
-            for (int p = 0; p < M; ++p) x2[p] = a.nu * x2[p] - v[p] * x1[p];
-            if (a.acc) {
-                double o[M];
-                xload<M>(o, a.out0 + off);
+                    for (int p = 0; p < M; ++p) u[p] = v[p];
+                } else {
+                    xload<M>(u, src + off);
+                }
+                double um[3], up[3];
 #pragma unroll
-                for (int p = 0; p < M; ++p) x2[p] = o[p] + x2[p];
+                for (int k = 0; k < 3; ++k) {
+                    um[k] = shfl_d(u[M - 3 + k], (lane + 63) & 63);
+                    up[k] = shfl_d(u[k], (lane + 1) & 63);
+                }
+                double x1[M], x2[M];
+                xstencil<M, false>(x1, u, um, up, a.s1, lane);
+                xsolve<M, LV>(x1, y1, lane, n);
+                xstencil<M, true>(x2, u, um, up, a.s2, lane);
+                xsolve<M, LV>(x2, y2, lane, n);
+#pragma unroll
+                for (int p = 0; p < M; ++p) x2[p] = nuf * x2[p] - v[p] * x1[p];      // opr_burgers.f90:513
+                if (a.acc) {
+                    double o[M];
+                    xload<M>(o, dst + off);
+#pragma unroll
+                    for (int p = 0; p < M; ++p) x2[p] = o[p] + x2[p];
+                }
+                xstore<M>(dst + off, x2);
             }
-            xstore<M>(a.out0 + off, x2);
+        } else {
+            double u[M];
+            xload<M>(u, a.in0 + off);
+            if (MODE == MODE_P1 && a.in0b != nullptr) {   // operand = in0 + s * in0b
+                double ub[M];
+                xload<M>(ub, a.in0b + off);
+#pragma unroll
+                for (int p = 0; p < M; ++p) u[p] = u[p] + ub[p] * a.in0b_scale;
+            }
+            double um[3], up[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                um[k] = shfl_d(u[M - 3 + k], (lane + 63) & 63);
+                up[k] = shfl_d(u[k], (lane + 1) & 63);
+            }
+            double x1[M], x2[M];
+            if (NEED1) {
+                xstencil<M, false>(x1, u, um, up, a.s1, lane);
+                xsolve<M, LV>(x1, y1, lane, n);
+            }
+            if (NEED2) {
+                xstencil<M, true>(x2, u, um, up, a.s2, lane);
+                xsolve<M, LV>(x2, y2, lane, n);
+            }
+            if (MODE == MODE_P1) {
+                if (a.acc) {
+                    double o[M];
+                    xload<M>(o, a.out0 + off);
+#pragma unroll
+                    for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+                }
+                xstore<M>(a.out0 + off, x1);
+            } else if (MODE == MODE_P2) {
+                xstore<M>(a.out0 + off, x2);
+            } else {   // MODE_P2_P1
+                xstore<M>(a.out0 + off, x2);
+                xstore<M>(a.out1 + off, x1);
+            }
         }
     }
 }
@@ -490,7 +517,12 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
-    ProfScope ps(names[mode], st, pts * (bpp[mode] + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0)));
+    double bytes = pts * (bpp[mode] + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0));
+    if (mode == MODE_BURGERS) {   // velocity once + per field: operand (unless it is the velocity), result, previous result when accumulating
+        bytes = pts * 8;
+        for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in1 ? 0 : 8) + 8 + (a.acc ? 8 : 0));
+    }
+    ProfScope ps(names[mode], st, bytes);
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV>), dim3(grid), dim3(256), lds, st, a); break;

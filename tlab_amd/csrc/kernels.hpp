@@ -17,6 +17,12 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     StencilDev s1, s2;      // first / second derivative RHS operators
     SystemDev y1, y2;       // first / second derivative chunked systems (P = 64)
     double nu;
+    // MODE_BURGERS with several transported fields sharing the advecting velocity in1 (nf >= 1): field f reads fs[f], adds to (acc) or
+    // overwrites fo[f] with fnu[f] d2 - in1 d1.  in0 / out0 / nu are ignored then.
+    int nf;
+    const double *fs[4];
+    double *fo[4];
+    double fnu[4];
 };
 
 struct RTileArgs {          // k_rtile: derivative along a strided index
@@ -33,6 +39,10 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     SystemDev y1, y2;       // chunked with P = n / rtile_chunk(n)  (k_htile: n / htile_chunk(n, mode))
     JacCorrDev jc;
     double nu;
+    int nf;                 // k_htile MODE_BURGERS: as in XLineArgs (velocity = in2)
+    const double *fs[4];
+    double *fo[4];
+    double fnu[4];
 };
 
 struct GenericArgs {        // k_generic: any n

@@ -459,8 +459,10 @@ __device__ __forceinline__ void ode_factor_step(int j, const double (&r)[5], dou
 
 // checkpoints of the factor recurrence: state before rows 8, 16, ... (chunk 0 starts from zeros)
 template <int BC>
+// Layout of everything k_ode_nn reads per mode: blocked by the NM modes of a workgroup, [block][...][NM], so that a workgroup's reads are
+// one contiguous stream (mode-minor [..][nm] rows would be 64-B pieces of 128-B lines at NM = 8: measured 2x over-fetch).
 __global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *__restrict__ lamv, double lam_sign, double *__restrict__ chk,
-                                                        long long nm) {
+                                                        long long nm, int NM, int C) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nm) return;
     const int n = T.n;
@@ -472,7 +474,7 @@ __global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *
         if ((j % OM) == 0) {
             const int c = j / OM;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) chk[((long long)c * 6 + q) * nm + t] = st[q];
+            for (int q = 0; q < 6; ++q) chk[(((t / NM) * C + c) * 6 + q) * NM + (t % NM)] = st[q];
         }
         double r[5], am, bm, cinv, nd, ne;
         ode_row(T, k, j, lam, r);
@@ -559,6 +561,14 @@ __device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[2][2], i
     __syncthreads();      // s_w is reused by the next scan
 }
 
+// src[a][j][nm] -> dst[blk][a][j][NM]
+__global__ void __launch_bounds__(256) k_ode_block_layout(const double *__restrict__ src, double *__restrict__ dst, int A, int n, long long nm, int NM) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)A * n * nm) return;
+    const long long t = i % nm, aj = i / nm;          // aj = a * n + j
+    dst[((t / NM) * A * n + aj) * NM + (t % NM)] = src[i];
+}
+
 // One FDM_Int1_Solve of BOTH lines (Re, Im) for the rows of this thread.
 //   fl[p][l], p = 0..9: f rows j0-1 .. j0+8 (the halo rows are only read where they exist)
 //   res0 / resN: the boundary values as MatMul_3d sees them (fdm_integral.f90:240-245)
@@ -582,7 +592,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
     // ---- factors of my rows, from the checkpoint ----
     double st[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) st[q] = (c == 0) ? 0.0 : chk[(unsigned)((c * 6 + q) * nm + t)];      // 32-bit indices: checked on the host
+    for (int q = 0; q < 6; ++q) st[q] = (c == 0) ? 0.0 : chk[(unsigned)((((t / NM) * C + c) * 6 + q) * NM + m)];      // 32-bit indices: checked on the host
     double am[OM], bm[OM];             // forward multipliers in registers; the backward factors (1/c, -d, -e) wait in LDS
     double *my_fac = s_fac + threadIdx.x * (3 * OM + 1);      // thread-major with an odd stride: constant offsets, no bank conflicts
 #define FAC(p, q) my_fac[(p) * 3 + (q)]
@@ -816,7 +826,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
 #pragma unroll
     for (int p = 0; p < OM; ++p) {
         const int j = j0 + p;
-        const unsigned h = (unsigned)(j * nm + t), hs = (unsigned)(n * nm);
+        const unsigned h = (unsigned)(((t / NM) * 5 * n + j) * NM + m), hs = (unsigned)(n * NM);       // hom_blocked[blk][5][n][NM]
         const double hv1 = a.hom[h], hem = a.hom[h + hs], hu1 = a.hom[h + 2 * hs], hsp = a.hom[h + 3 * hs], hep = a.hom[h + 4 * hs];
         double uu[2], vv[2];
 #pragma unroll
@@ -1048,7 +1058,8 @@ struct tlab_poisson_plan {
     DBuf hom, der, cst;               // homogeneous solutions [5][ny][nm], their boundary derivatives [3][nm], 3x3 LU [9][nm]
     DBuf scratch, v0, u0, du0, bcs;   // per-call work: [5][ny][nm], [2][ny][nm] x2, [2][nm], [4][nm]
     DBuf cwork;                       // complex work field (nxh*ny*nz complex)
-    DBuf d_bt[2], chk[2];             // chunked ODE kernel: boundary constants [3][4] and PENTADFS checkpoints [C][6][nm] of both systems
+    DBuf d_bt[2], chk[2], homb;       // chunked ODE kernel: boundary constants [3][4], PENTADFS checkpoints [blk][C][6][NM] of both systems,
+                                      // homogeneous solutions re-laid out as [blk][5][ny][NM]
     bool use_chunked = false;
     int ode_nm_per_wg = 0;
     std::vector<int> sing_modes;      // flat mode indices t = kx + nxh*kz of the singular modes
@@ -1132,12 +1143,12 @@ void launch_ode_nm(const OdeArgs &a, size_t lds, hipStream_t st) {
 void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
     OdeArgs a{};
     a.T1 = P.sys(0); a.T2 = P.sys(1);
-    a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = P.cst.p; a.hom = P.hom.p;
+    a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = P.cst.p; a.hom = P.homb.p;
     a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
     a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.nm = P.nm;
     const int NM = P.ode_nm_per_wg;
     const size_t lds = ode_lds_bytes(a.C, NM);
-    ProfScope ps("k_ode_nn", st, (double)P.nm * P.ny * 48.0);
+    ProfScope ps("k_ode_nn", st, (double)P.nm * P.ny * (48.0 + 40.0 + 12.0));      // f^, p^, dp^ + homogeneous solutions + checkpoints
     switch (NM) {
     case 4: launch_ode_nm<4>(a, lds, st); break;
     case 8: launch_ode_nm<8>(a, lds, st); break;
@@ -1149,19 +1160,24 @@ void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_h
 }
 
 void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
-    const int C = P.ny / OM;
+    const int C = P.ny / OM, NM = P.ode_nm_per_wg;
+    const long long nblk = (P.nm + NM - 1) / NM;
     for (int w = 0; w < 2; ++w) {
         const Int1Tables &T = w == 0 ? P.tmin : P.tmax;
         std::vector<double> bt(12);
         for (int j = 0; j < 3; ++j)
             for (int c = 0; c < 4; ++c) bt[j * 4 + c] = (w == 0) ? T.rb[j][c] : T.rt[j][c];
         P.d_bt[w].upload(bt);
-        P.chk[w].alloc((size_t)C * 6 * P.nm);
+        P.chk[w].alloc((size_t)C * 6 * nblk * NM);
     }
     const int grid = (int)((P.nm + 255) / 256);
-    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(grid), dim3(256), 0, st, P.sys(0), P.lam.p, 1.0, P.chk[0].p, P.nm);
-    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(grid), dim3(256), 0, st, P.sys(1), P.lam.p, -1.0, P.chk[1].p, P.nm);
+    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(grid), dim3(256), 0, st, P.sys(0), P.lam.p, 1.0, P.chk[0].p, P.nm, NM, C);
+    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(grid), dim3(256), 0, st, P.sys(1), P.lam.p, -1.0, P.chk[1].p, P.nm, NM, C);
     hipc(hipGetLastError(), "k_ode_checkpoint");
+    P.homb.alloc((size_t)5 * P.ny * nblk * NM);
+    const long long tot = (long long)5 * P.ny * P.nm;
+    hipLaunchKernelGGL(k_ode_block_layout, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.hom.p, P.homb.p, 5, P.ny, P.nm, NM);
+    hipc(hipGetLastError(), "k_ode_block_layout");
 }
 
 void build_fft(tlab_poisson_plan &P) {
@@ -1352,7 +1368,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         {   // chunked ODE kernel (k_ode_nn) when the line splits into 8-row chunks and 32-bit indices suffice; TLAB_ODE_CHUNKED=0 keeps k_int1
             const char *e = getenv("TLAB_ODE_CHUNKED");
             const int C = ny / OM;
-            const long long big = std::max<long long>((long long)5 * ny * nm, std::max<long long>(9 * nm, (long long)P->nxh * ny * nz));
+            const long long big = std::max<long long>((long long)5 * ny * (nm + 64), std::max<long long>(9 * nm, (long long)P->nxh * ny * nz));
             if (!(e && atoi(e) == 0) && ny % OM == 0 && C >= 2 && ode_modes_per_wg(C) > 0 && big < (1LL << 31) &&
                 ode_lds_bytes(C, ode_modes_per_wg(C)) <= (size_t)160 * 1024) {
                 P->ode_nm_per_wg = ode_modes_per_wg(C);
@@ -1362,7 +1378,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         }
         hipc(hipStreamSynchronize(st), "sync");
         if (P->use_chunked) {   // the scratch of the marching kernels is not needed any more
-            P->scratch.alloc(0); P->v0.alloc(0); P->u0.alloc(0);
+            P->scratch.alloc(0); P->v0.alloc(0); P->u0.alloc(0); P->hom.alloc(0);      // hom lives on in its blocked copy
         }
         *out = P.release();
         return TLAB_OK;

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -24,6 +25,9 @@ bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, 
 bool tlab_internal_partial_p1_fusable(int dir, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
                                double *result);
+bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
+bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
+                                 const double *vel, double *const *result);
 
 struct tlab_dns {
     tlab_fdm_plan_t g[3];
@@ -115,7 +119,21 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     for (int is = 0; is < d->nscal; ++is) eqs.push_back({hs[is], s[is], d->visc / d->schmidt[is], {1, 2, 3}});   // :158, opr_burgers.f90:97
     const double *vel[3] = {u, v, w};
     double *tmps[3] = {tmp1, tmp7, tmp8};
-    for (size_t e = 0; e < eqs.size(); ++e) {
+    // Fused path: one launch per direction serves all equations (they share the advecting velocity of that direction), four fields per
+    // launch.  The terms of an equation are then added in the order x, y, z instead of the reference's {1,2,3},{2,1,3},{3,1,2}: rounding only.
+    const bool batched = d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
+                         tlab_internal_burgers_fusable(3, gz, nx, ny, nz);
+    if (batched) {
+        for (int dir = 1; dir <= 3; ++dir)
+            for (size_t e0 = 0; e0 < eqs.size(); e0 += 4) {
+                const int nf = (int)std::min<size_t>(4, eqs.size() - e0);
+                const double *sp[4]; double *rp[4]; double nup[4];
+                for (int f = 0; f < nf; ++f) { sp[f] = eqs[e0 + f].fld; rp[f] = eqs[e0 + f].dst; nup[f] = eqs[e0 + f].nu; }
+                if (!tlab_internal_burgers_acc_n(dir, d->g[dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[dir - 1], rp))
+                    throw Fail(TLAB_EINVAL, "internal: inconsistent fused Burgers path");
+            }
+    }
+    for (size_t e = 0; e < eqs.size() && !batched; ++e) {
         bool pending = false;
         double *pend[3];
         int npend = 0;

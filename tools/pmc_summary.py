@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 outputs into the summaries kept under profiles/:
+
+    python tools/pmc_summary.py stats  <dir of `rocprofv3 --kernel-trace --stats --output-format csv`>  > profiles/rNN/rocprofv3_kernel_stats_*.csv
+    python tools/pmc_summary.py pmc    <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [traffic.json to update]
+
+HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE KiB (gfx950: FETCH_SIZE counts half of the bytes of wide coalesced reads,
+MI355X_MICROARCH.md section HBM; calibrated on a 4-array streaming kernel, profiles/README.md)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+MODES = {1: "P1", 2: "P2", 3: "P2_P1", 4: "BURGERS", 5: "P2_D1IN", 6: "BURGERS_D1IN"}
+
+
+def tag(name):
+    """rocprof kernel name -> the tag the library's own profiler (and bench.py) uses."""
+    name = re.sub(r"^void\s+", "", name).replace("tlab::", "")
+    m = re.match(r"k_(xline|rtile|htile)<(\d+), (\d+)", name)
+    if m:
+        return "k_%s<%s>" % (m.group(1), MODES.get(int(m.group(3)), m.group(3)))
+    m = re.match(r"k_zslab<(\d+), (\d+), (\d+)>", name)
+    if m:
+        return "k_zslab<%s,%s>" % (MODES.get(int(m.group(2)), m.group(2)), "A" if m.group(3) == "1" else "B")
+    m = re.match(r"k_int1<(\d+), (\d+), (\d+)", name)
+    if m:
+        return "k_int1<%s>" % {"0": "field", "1": "linear", "2": "unit"}[m.group(3)]
+    m = re.match(r"(k_[a-z0-9_]+)", name)
+    return m.group(1) if m else name[:60]
+
+
+def find(d, pattern):
+    r = sorted(glob.glob(os.path.join(d, "**", pattern), recursive=True))
+    if not r:
+        sys.exit("no %s under %s" % (pattern, d))
+    return r
+
+
+def stats(d):
+    rows = []
+    for f in find(d, "*kernel_stats.csv"):
+        rows += list(csv.DictReader(open(f)))
+    w = csv.writer(sys.stdout)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([r.get("Name"), r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage"), r.get("MinNs"), r.get("MaxNs")])
+
+
+def counters(d, cname):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != cname:
+                continue
+            a = acc[r["Kernel_Name"]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return acc
+
+
+def pmc(dfetch, dwrite, tjson=None):
+    fe, wr = counters(dfetch, "FETCH_SIZE"), counters(dwrite, "WRITE_SIZE")
+    out = {}
+    print("%-44s %-22s %8s %20s %20s  HBM bytes/launch = (2*FETCH+WRITE) KiB" % ("kernel (rocprof name)", "bench tag", "launches", "FETCH_SIZE[KiB]/launch", "WRITE_SIZE[KiB]/launch"))
+    for k in sorted(fe, key=lambda k: -fe[k][0]):
+        if "tlab" not in k and not k.startswith("k_") and "void k_" not in k:
+            continue
+        f = fe[k][0] / fe[k][1]
+        w = wr[k][0] / wr[k][1] if k in wr and wr[k][1] else float("nan")
+        b = (2 * f + w) * 1024.0
+        t = tag(k)
+        short = re.sub(r"^void\s+", "", k).replace("tlab::", "")[:43]
+        print("%-44s %-22s %8d %20.1f %20.1f  %.4e" % (short, t, fe[k][1], f, w, b))
+        if t not in out or fe[k][1] > out[t][1]:
+            out[t] = (b, fe[k][1])
+    if tjson:
+        json.dump({k: v[0] for k, v in out.items()}, open(tjson, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    elif len(sys.argv) >= 4 and sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+    else:
+        sys.exit(__doc__)
