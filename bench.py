@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--nscal", type=int, default=1)
     ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
                     "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="n of the n^3 CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="n of the n^3 CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
     import torch
