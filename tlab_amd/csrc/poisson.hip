@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(256) k_ode_block_layout(const double *__restri
 //   fl[p][l], p = 0..9: f rows j0-1 .. j0+8 (the halo rows are only read where they exist)
 //   res0 / resN: the boundary values as MatMul_3d sees them (fdm_integral.f90:240-245)
 //   x[p][l]: solution rows j0..j0+7 (boundary rows included after the reconstruction)
-//   ext[l]: BC == 1: unused; BC == 2: du at the top (valid in the last chunk)
+//   ext[l]: derivative at the given end: BC == 1 at the bottom (valid in chunk 0), BC == 2 at the top (valid in the last chunk)
 // LDS: s_w [nwaves][8][NM] (scan), s_k [OK_SIZE][NM] (boundary rows), s_fac [threads][25] (backward factors)
 template <int BC, int NM>
 __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const double *__restrict__ chk, int nm, int t, int c, int C, int m,
@@ -598,6 +598,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
 #define FAC(p, q) my_fac[(p) * 3 + (q)]
     double (&rhs)[OM][2] = x;          // right-hand side -> y -> x in place
     const double fn2[2] = {fl[OM - 1][0], fl[OM - 1][1]};      // f(n-2) of the last chunk, for du (the only use of fl after the rhs)
+    const double f1s[2] = {fl[2][0], fl[2][1]};                  // f(1) of the first chunk, for du of the BCS_MIN system
     double bcs_b[2] = {0, 0}, bcs_t[2] = {0, 0};
     // The special rows sit at fixed positions of the first and the last chunk (requires n = 8 C): row 0 / n-1 are not part of the
     // system, rows 1, 2 / n-3, n-2 carry the reduced boundary closures.  Conditions are written on the unrolled p so that they fold away
@@ -738,7 +739,10 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
             }
         } else {
             if (c == C - 1) x[OM - 1][l] = bcs_t[l] + KK(OK_LN, 1) * x[OM - 2][l] + KK(OK_LN, 0) * x[OM - 3][l] + KK(OK_LN, 4) * x[OM - 4][l];
-            if (c == 0) x[0][l] = res0[l];
+            if (c == 0) {
+                x[0][l] = res0[l];
+                ext[l] = KK(OK_L0, 2) * res0[l] + KK(OK_L0, 3) * x[1][l] + KK(OK_L0, 4) * x[2][l] + KK(OK_L0, 0) * x[3][l] + T.R[0 * 3 + 2] * f1s[l];
+            }
         }
     }
     __syncthreads();       // s_k is rewritten by the next solve
@@ -846,6 +850,80 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
         const unsigned idx = fidx0 + (unsigned)(j * a.nxh);
         P[idx] = make_double2(uu[0], uu[1]);
         D[idx] = make_double2(vv[0], vv[1]);
+    }
+}
+
+// The <= 4 singular modes (lambda = 0): OPR_ODE2_Factorize_NN_Sing -> _DN_Sing (opr_odes.f90:165-183, 37-96) with the same chunked
+// solves, one workgroup: v0' = f (f(1) = 0), v0(n) = bcs_t ; u0' = v0, u0(1) = 0 ; u = u0 + c u1, v = v0 + c v1 with
+// c = (v0(1) - du0(1)) / (du1(1) - v1(1)); u1, v1, du1 depend on the mode only (plan creation).
+struct OdeSingArgs {
+    OdeSys T1, T2;
+    const double *chk1, *chk2;          // checkpoints of the ns singular modes, blocked [0][C][6][NM]
+    const int *modes;                   // [ns] flat mode indices
+    const double *v1, *u1, *du1;        // [n][ns] (line 0 of the stored pairs), [ns]
+    const double *f_hat;
+    double *p_hat, *dp_hat;
+    double fscale;
+    int n, nxh, ny, C, ns;
+};
+
+template <int NM>
+__global__ void __launch_bounds__(512) k_ode_sing(OdeSingArgs a) {
+    extern __shared__ double lds[];
+    const int C = a.C, n = a.n;
+    const int m = threadIdx.x % NM, c = threadIdx.x / NM;
+    double *s_w = lds, *s_x = lds + 8 * 8 * NM;
+    double *s_sc = s_x + (size_t)C * 4 * NM;
+    double *s_k = s_sc + 10 * NM;
+    double *s_fac = s_k + OK_SIZE * NM;
+    const bool live = m < a.ns;
+    const int t = a.modes[live ? m : 0];
+    const unsigned fidx0 = (unsigned)((t % a.nxh) + a.nxh * a.ny * (t / a.nxh));
+    const int j0 = c * OM;
+    const double2 *F = reinterpret_cast<const double2 *>(a.f_hat);
+    double vh[OM + 2][2], u[OM][2], ext[2];
+    double zero[2] = {0, 0}, bct[2];
+    {
+        double fl[OM + 2][2];
+#pragma unroll
+        for (int p = 0; p < OM + 2; ++p) {
+            const int j = j0 - 1 + p;
+            double2 w = make_double2(0.0, 0.0);
+            if (j >= 0 && j <= n - 1) w = F[fidx0 + (unsigned)(j * a.nxh)];
+            fl[p][0] = w.x * a.fscale; fl[p][1] = w.y * a.fscale;
+        }
+        if (c == C - 1) { s_sc[2 * NM + m] = fl[OM][0]; s_sc[3 * NM + m] = fl[OM][1]; }      // Neumann datum at the top (opr_elliptic.f90:310-311)
+        if (c == 0) { fl[1][0] = 0.0; fl[1][1] = 0.0; }                                     // f(1) = 0 (opr_odes.f90:59 via :179)
+        __syncthreads();
+        bct[0] = s_sc[2 * NM + m]; bct[1] = s_sc[3 * NM + m];
+        ode_solve<2, NM>(a.T2, 0.0, a.chk2, 0, m, c, C, m, fl, zero, bct, reinterpret_cast<double (&)[OM][2]>(vh[1]), ext, s_w, s_k, s_fac);
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) { s_x[((c * 2 + l) * 2 + 0) * NM + m] = vh[1][l]; s_x[((c * 2 + l) * 2 + 1) * NM + m] = vh[OM][l]; }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        vh[0][l] = (c > 0) ? s_x[(((c - 1) * 2 + l) * 2 + 1) * NM + m] : 0.0;
+        vh[OM + 1][l] = (c < C - 1) ? s_x[(((c + 1) * 2 + l) * 2 + 0) * NM + m] : 0.0;
+    }
+    if (c == 0) { s_sc[4 * NM + m] = vh[1][0]; s_sc[5 * NM + m] = vh[1][1]; }                 // v0(1)
+    ode_solve<1, NM>(a.T1, 0.0, a.chk1, 0, m, c, C, m, vh, zero, bct, u, ext, s_w, s_k, s_fac);
+    if (c == 0) { s_sc[6 * NM + m] = ext[0]; s_sc[7 * NM + m] = ext[1]; }                   // du0 at the bottom
+    __syncthreads();
+    if (!live) return;
+    const int ns = a.ns;
+    const double f1 = 1.0 / (a.du1[m] - a.v1[(0 * n + 0) * ns + m]);
+    double cc[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) cc[l] = (s_sc[(4 + l) * NM + m] - s_sc[(6 + l) * NM + m]) * f1;
+    double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
+#pragma unroll
+    for (int p = 0; p < OM; ++p) {
+        const int j = j0 + p;
+        const double hu = a.u1[j * ns + m], hv = a.v1[j * ns + m];
+        const unsigned idx = fidx0 + (unsigned)(j * a.nxh);
+        P[idx] = make_double2(u[p][0] + cc[0] * hu, u[p][1] + cc[1] * hu);
+        D[idx] = make_double2(vh[p + 1][0] + cc[0] * hv, vh[p + 1][1] + cc[1] * hv);
     }
 }
 
@@ -1058,7 +1136,7 @@ struct tlab_poisson_plan {
     DBuf hom, der, cst;               // homogeneous solutions [5][ny][nm], their boundary derivatives [3][nm], 3x3 LU [9][nm]
     DBuf scratch, v0, u0, du0, bcs;   // per-call work: [5][ny][nm], [2][ny][nm] x2, [2][nm], [4][nm]
     DBuf cwork;                       // complex work field (nxh*ny*nz complex)
-    DBuf d_bt[2], chk[2], homb;       // chunked ODE kernel: boundary constants [3][4], PENTADFS checkpoints [blk][C][6][NM] of both systems,
+    DBuf d_bt[2], chk[2], chk_s[2], homb;       // chunked ODE kernel: boundary constants [3][4], PENTADFS checkpoints [blk][C][6][NM] of both systems,
                                       // homogeneous solutions re-laid out as [blk][5][ny][NM]
     bool use_chunked = false;
     int ode_nm_per_wg = 0;
@@ -1178,6 +1256,47 @@ void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
     const long long tot = (long long)5 * P.ny * P.nm;
     hipLaunchKernelGGL(k_ode_block_layout, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.hom.p, P.homb.p, 5, P.ny, P.nm, NM);
     hipc(hipGetLastError(), "k_ode_block_layout");
+}
+
+// v1, u1, du1 of the singular modes depend on the mode only (opr_odes.f90:64-73): once per plan
+void build_singular_homogeneous(tlab_poisson_plan &P, hipStream_t st) {
+    const int ns = (int)P.sing_modes.size();
+    if (ns == 0) return;
+    Int1Args s2 = base_args(P, 1, P.s_lam.p, ns, P.s_scr.p);   // v1' = delta_1, v1(n) = 0
+    s2.unit_row = 0; s2.zero_bsave = 0; s2.dst = P.s_v1.p;
+    launch_int1<2, 2, FS_UNIT>(s2, st);
+    Int1Args s4 = base_args(P, 0, P.s_lam.p, ns, P.s_scr.p);   // u1' = v1, u1(1) = 0
+    s4.fsrc = P.s_v1.p; s4.nlf = 2; s4.zero_bsave = 0; s4.dst = P.s_u1.p; s4.du = P.s_du1.p;
+    launch_int1<1, 2, FS_LINEAR>(s4, st);
+}
+
+void build_singular_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
+    const int ns = (int)P.sing_modes.size();
+    if (ns == 0) return;
+    const int C = P.ny / OM, NM = 8;
+    for (int w = 0; w < 2; ++w) P.chk_s[w].alloc((size_t)C * 6 * NM);
+    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(1), dim3(256), 0, st, P.sys(0), P.s_lam.p, 1.0, P.chk_s[0].p, (long long)ns, NM, C);
+    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(1), dim3(256), 0, st, P.sys(1), P.s_lam.p, -1.0, P.chk_s[1].p, (long long)ns, NM, C);
+    hipc(hipGetLastError(), "k_ode_checkpoint (singular)");
+}
+
+void launch_ode_sing(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
+    constexpr int NM = 8;
+    OdeSingArgs a{};
+    a.T1 = P.sys(0); a.T2 = P.sys(1);
+    a.chk1 = P.chk_s[0].p; a.chk2 = P.chk_s[1].p; a.modes = P.d_sing;
+    a.v1 = P.s_v1.p; a.u1 = P.s_u1.p; a.du1 = P.s_du1.p;
+    a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
+    a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.ns = (int)P.sing_modes.size();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ode_sing<NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    ProfScope ps("k_ode_sing", st, (double)a.ns * P.ny * 48.0);
+    hipLaunchKernelGGL((k_ode_sing<NM>), dim3(1), dim3(NM * a.C), ode_lds_bytes(a.C, NM), st, a);
+    hipc(hipGetLastError(), "k_ode_sing");
 }
 
 void build_fft(tlab_poisson_plan &P) {
@@ -1365,6 +1484,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         hipc(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), "event");
         hipStream_t st = tlab_current_stream();
         build_homogeneous(*P, st);
+        build_singular_homogeneous(*P, st);
         {   // chunked ODE kernel (k_ode_nn) when the line splits into 8-row chunks and 32-bit indices suffice; TLAB_ODE_CHUNKED=0 keeps k_int1
             const char *e = getenv("TLAB_ODE_CHUNKED");
             const int C = ny / OM;
@@ -1374,6 +1494,8 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                 P->ode_nm_per_wg = ode_modes_per_wg(C);
                 build_checkpoints(*P, st);
                 P->use_chunked = true;
+                if (8 * C <= 512 && ode_lds_bytes(C, 8) <= (size_t)160 * 1024) build_singular_checkpoints(*P, st);
+                else P->use_chunked = false;      // (the singular-mode kernel is built for 8 lanes per chunk)
             }
         }
         hipc(hipStreamSynchronize(st), "sync");
@@ -1434,21 +1556,17 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
     // ---- singular modes: OPR_ODE2_Factorize_NN_Sing -> _DN_Sing (opr_odes.f90:165-183, 37-96) ----
     const int ns = (int)P->sing_modes.size();
     hipStream_t ss = P->side;   // independent of the regular modes until the scatter below
-    if (ns > 0) {
+    if (ns > 0 && P->use_chunked) {
+        launch_ode_sing(*P, f_hat, p_hat, dp_hat, ss);      // one workgroup beside the regular modes; writes only the singular entries
+    } else if (ns > 0) {
         dim3 g(ns, (n + 63) / 64), blk(64);
         hipLaunchKernelGGL(k_sing_gather, g, blk, 0, ss, f_hat, P->d_sing, ns, n, nxh, ny, P->norm, P->s_f.p, P->s_bct.p);
         Int1Args s1 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v' = f (f(1)=0), v(n) = bcs_t
         s1.fsrc = P->s_f.p; s1.nlf = 2; s1.zero_bsave = 0; s1.bv_ptr = P->s_bct.p; s1.dst = P->s_v0.p;
         launch_int1<2, 2, FS_LINEAR>(s1, ss);
-        Int1Args s2 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);   // v1' = delta_1, v1(n) = 0
-        s2.unit_row = 0; s2.zero_bsave = 0; s2.dst = P->s_v1.p;
-        launch_int1<2, 2, FS_UNIT>(s2, ss);
         Int1Args s3 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u' = v, u(1) = bcs_b = 0
         s3.fsrc = P->s_v0.p; s3.nlf = 2; s3.zero_bsave = 0; s3.dst = P->s_u0.p; s3.du = P->s_du0.p;
         launch_int1<1, 2, FS_LINEAR>(s3, ss);
-        Int1Args s4 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);   // u1' = v1, u1(1) = 0
-        s4.fsrc = P->s_v1.p; s4.nlf = 2; s4.zero_bsave = 0; s4.dst = P->s_u1.p; s4.du = P->s_du1.p;
-        launch_int1<1, 2, FS_LINEAR>(s4, ss);
     }
     // ---- superposition ----
     if (!P->use_chunked) {
@@ -1464,7 +1582,7 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
     // v-solve first when p_hat aliases it: order the scatter after it through the main stream
     hipc(hipEventRecord(P->ev_join, ss), "event record");
     hipc(hipStreamWaitEvent(st, P->ev_join, 0), "stream wait");
-    if (ns > 0) {
+    if (ns > 0 && !P->use_chunked) {
         dim3 g(ns, (n + 63) / 64), blk(64);
         hipLaunchKernelGGL(k_sing_combine, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->s_u1.p, P->s_v1.p, P->s_du0.p, P->s_du1.p,
                            P->d_sing, ns, n, nxh, ny, p_hat, dp_hat);

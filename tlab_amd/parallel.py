@@ -455,9 +455,17 @@ class SlabDns:
         eqs = lambda S: [(S["q"][0], S["hq"][0], nu), (S["q"][1], S["hq"][1], nu), (S["q"][2], S["hq"][2], nu)] + \
             [(S["s"][i], S["hs"][i], self.visc / self.schmidt[i]) for i in range(ns)]            # noqa: E731
 
-        def badd(d, g, S, f, h, kap):
-            check(L.tlab_opr_burgers_add(d, g._h, nx, ny, kmax, 0, float(kap), _ptr(f), _ptr(S["q"][d - 1]), _ptr(h), _ptr(T(S, 6)), _ptr(T(S, 7))),
-                  "tlab_opr_burgers_add")
+        def badd_all(d, g, S):
+            """hq, hs += Burgers_d of every transported field, four per launch (they share the advecting velocity q_d)."""
+            E = eqs(S)
+            for e0 in range(0, len(E), 4):
+                grp = E[e0:e0 + 4]
+                nf = len(grp)
+                nus = (ctypes.c_double * nf)(*[float(kap) for _, _, kap in grp])
+                sp = (c_vp * nf)(*[f.data_ptr() for f, _, _ in grp])
+                rp = (c_vp * nf)(*[h.data_ptr() for _, h, _ in grp])
+                check(L.tlab_opr_burgers_add_n(d, g._h, nx, ny, kmax, 0, nf, nus, sp, _ptr(S["q"][d - 1]), rp, _ptr(T(S, 6)), _ptr(T(S, 7))),
+                      "tlab_opr_burgers_add_n")
 
         def padd(d, g, S, u, ub, scale, res, acc):
             check(L.tlab_opr_partial_add(d, g._h, nx, ny, kmax, 0, _ptr(u), _ptr(ub) if ub is not None else None, float(scale), _ptr(res), int(acc),
@@ -465,11 +473,11 @@ class SlabDns:
 
         # ---- diffusion + advection (:98-162) ----
         w = self._halo_start([("q", 0), ("q", 1), ("q", 2)] + [("s", i) for i in range(ns)])
-        self._local(lambda r, S: [badd(1, gx, S, f, h, kap) for f, h, kap in eqs(S)])
+        self._local(lambda r, S: badd_all(1, gx, S))
         w.wait()
         self._local(lambda r, S: [self._zburgers(1, S, 2 * i, kap, f, None, None) for i, (f, h, kap) in enumerate(eqs(S))])
         w = self._msg_start(2 * (3 + ns))
-        self._local(lambda r, S: [badd(2, gy, S, f, h, kap) for f, h, kap in eqs(S)])
+        self._local(lambda r, S: badd_all(2, gy, S))
         w.wait()
         self._local(lambda r, S: [self._zburgers(2, S, 2 * i, kap, f, S["q"][2], h) for i, (f, h, kap) in enumerate(eqs(S))])
         # ---- pressure forcing: div(hq + q/dte) (:188-260) ----
