@@ -90,6 +90,32 @@ def test_chunked_and_marching_ode_kernels_agree(T, monkeypatch):
     assert rel_err(outs[0][1], outs[1][1]) <= 1e-13
 
 
+@pytest.mark.parametrize("nz", [16, 32, 64, 128, 256, 512, 1024])
+def test_own_z_fft_matches_numpy(T, nz):
+    """k_fftz (strided Stockham, fftz.hip) against numpy on the kx-pencil layout (nxl, ny, nz); lengths 8^a * {1,2,4}."""
+    import ctypes
+    import torch
+    from tlab_amd.lib import load, check, c_vp
+    nx, ny, kmax, nxl, ioff = 16, 16, nz // 2, 5, 2
+    x, y, z = np.arange(nx) / nx, np.arange(ny) / (ny - 1.0), np.arange(nz) / nz
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, True), T.FdmPlan(z, True, True)]
+    h = c_vp(0)
+    L = load()
+    check(L.tlab_poisson_plan_create_pencil(ctypes.byref(h), gp[0]._h, gp[1]._h, gp[2]._h, nx, ny, kmax, nz, ioff, nxl), "pencil plan")
+    rng = np.random.default_rng(nz)
+    a = rng.uniform(-1, 1, (nz, ny, nxl)) + 1j * rng.uniform(-1, 1, (nz, ny, nxl))
+    da = torch.from_numpy(np.ascontiguousarray(a).view(np.float64).reshape(-1)).cuda()
+    db = torch.empty_like(da)
+    check(L.tlab_poisson_fft_z(h, 1, da.data_ptr(), db.data_ptr()), "fft_z")
+    fwd = db.cpu().numpy().view(np.complex128).reshape(nz, ny, nxl)
+    ref = np.fft.fft(a, axis=0)
+    assert np.abs(fwd - ref).max() <= 1e-13 * np.abs(ref).max()
+    check(L.tlab_poisson_fft_z(h, -1, db.data_ptr(), da.data_ptr()), "fft_z")           # unnormalised inverse, like FFTW / rocFFT
+    back = da.cpu().numpy().view(np.complex128).reshape(nz, ny, nxl)
+    assert np.abs(back - nz * a).max() <= 1e-13 * nz * np.abs(a).max()
+    check(L.tlab_poisson_plan_destroy(h), "destroy")
+
+
 @pytest.mark.parametrize("n", [256])
 def test_poisson_full_size_identity(T, n):
     """256^3: div(grad p) = f with the device operators (vpoisson.f90 / SURVEY 4.4 construction), dpdy = d/dy of phi."""

@@ -1,0 +1,252 @@
+// k_fftz : complex-to-complex FFT along a STRIDED index, lines contiguous across the batch (the z-transform of the spectral array:
+// element (line l, point k) at l + nlines*k; OPR_Fourier_Z_Forward/Backward, opr_fourier.f90:343-428, dfftw_plan_many_dft :111-119).
+//
+// rocFFT serves this layout with a row kernel behind transposes when it is given as a 1-D strided batch (measured on the kx-pencils of
+// the multi-GPU Poisson solver: 0.26 ms for 138 MB in + 138 MB out = 1.06 TB/s; its 2-D plans use a column kernel at 2.9 TB/s but
+// also transform x).  Here a workgroup owns T = 8 neighbouring lines (128-B rows): Stockham autosort radix-8 passes (+ one radix-4 or
+// radix-2 pass), the first pass reads HBM, the last one writes it, the passes in between exchange through one LDS buffer.  One read and
+// one write of the array; twiddles from a table made in long double on the host.  Unnormalised in both directions like FFTW.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fftz.hpp"
+#include "profile.hpp"
+
+namespace tlab {
+
+struct cd {
+    double x, y;
+};
+__device__ __forceinline__ cd operator+(cd a, cd b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cmul(cd a, cd b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// multiply by exp(SGN * i * pi/2) = SGN * i
+template <int SGN>
+__device__ __forceinline__ cd mul_pm_i(cd a) {
+    return SGN > 0 ? cd{-a.y, a.x} : cd{a.y, -a.x};
+}
+
+// R-point DFT in place, kernel exp(SGN * 2 pi i j k / R), natural order
+template <int SGN>
+__device__ __forceinline__ void dft2(cd &a, cd &b) {
+    const cd t = a - b;
+    a = a + b;
+    b = t;
+}
+template <int SGN>
+__device__ __forceinline__ void dft4(cd &a0, cd &a1, cd &a2, cd &a3) {
+    const cd t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_pm_i<SGN>(a1 - a3);
+    a0 = t0 + t2; a1 = t1 + t3; a2 = t0 - t2; a3 = t1 - t3;
+}
+template <int SGN>
+__device__ __forceinline__ void dft8(cd (&v)[8]) {
+    cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4<SGN>(e0, e1, e2, e3);
+    dft4<SGN>(o0, o1, o2, o3);
+    const double h = 0.70710678118654752440;
+    // W8^k = exp(SGN * 2 pi i k / 8)
+    const cd w1 = {h, SGN * h}, w3 = {-h, SGN * h};
+    o1 = cmul(o1, w1);
+    o2 = mul_pm_i<SGN>(o2);
+    o3 = cmul(o3, w3);
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+
+struct FftzArgs {
+    const double2 *in;
+    double2 *out;
+    const double2 *tw;      // exp(-2 pi i k / n), k < n  (conjugated for the backward transform)
+    long long nlines;       // = stride between consecutive points of a line
+    int n;
+    int npass;
+    int radix[8];
+};
+
+// one Stockham pass for work item (column t, index j): radix R, Ns = product of the radices done before
+template <int R, int SGN, int T>
+__device__ __forceinline__ void fftz_pass(const FftzArgs &a, int t, int j, int Ns, bool first, bool last, long long col, bool colok, cd *lds) {
+    const int n = a.n, m = n / R;
+    cd v[R];
+    if (first) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double2 w = make_double2(0.0, 0.0);
+            if (colok) w = a.in[col + (long long)(j + r * m) * a.nlines];
+            v[r] = {w.x, w.y};
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = lds[(j + r * m) * T + t];
+    }
+    // twiddles exp(SGN 2 pi i (j % Ns) r / (Ns R))
+    const int k0 = (j % Ns) * (n / (Ns * R));
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+        const double2 w = a.tw[(k0 * r) % n];
+        v[r] = cmul(v[r], cd{w.x, SGN > 0 ? -w.y : w.y});
+    }
+    if (R == 8) dft8<SGN>(reinterpret_cast<cd(&)[8]>(v));
+    else if (R == 4) dft4<SGN>(v[0], v[1 % R], v[2 % R], v[3 % R]);
+    else dft2<SGN>(v[0], v[1 % R]);
+    const int j0 = (j / Ns) * Ns * R + (j % Ns);
+    if (!first) __syncthreads();          // every item of this pass has read its inputs from the buffer
+    if (last) {
+        if (colok) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) a.out[col + (long long)(j0 + r * Ns) * a.nlines] = make_double2(v[r].x, v[r].y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds[(j0 + r * Ns) * T + t] = v[r];
+        __syncthreads();
+    }
+}
+
+// n = 8^a * {1,2,4}; every pass has n/R <= n/2 items per column; blockDim = T * n / 8 (all radix-8 passes: one item per thread; a final
+// radix-4 / radix-2 pass has 2 / 4 items per thread).  The barriers inside fftz_pass are reached uniformly: the loops below have the
+// same trip count for every thread.
+template <int SGN, int T>
+__global__ void __launch_bounds__(1024) k_fftz(FftzArgs a) {
+    extern __shared__ double2 fz_lds[];
+    cd *lds = reinterpret_cast<cd *>(fz_lds);
+    const int t = threadIdx.x % T;
+    const int jt = threadIdx.x / T;              // 0 .. n/8 - 1
+    const long long col = (long long)blockIdx.x * T + t;
+    const bool colok = col < a.nlines;
+    int Ns = 1;
+    for (int p = 0; p < a.npass; ++p) {
+        const int R = a.radix[p];
+        const bool first = p == 0, last = p == a.npass - 1;
+        const int items = 8 / R;                  // items of this pass per thread
+        if (R == 8) {
+            fftz_pass<8, SGN, T>(a, t, jt, Ns, first, last, col, colok, lds);
+        } else {
+            // a thread owns items jt + q * (n/8): reads of all its items first, then one barrier, then the writes -> unroll by hand
+            const int m8 = a.n / 8;
+            if (R == 4) {
+                cd keep[2][4];
+                int j0s[2];
+                for (int q = 0; q < 2; ++q) {
+                    const int j = jt + q * m8, m = a.n / 4;
+                    for (int r = 0; r < 4; ++r) {
+                        if (first) {
+                            double2 w = make_double2(0.0, 0.0);
+                            if (colok) w = a.in[col + (long long)(j + r * m) * a.nlines];
+                            keep[q][r] = {w.x, w.y};
+                        } else {
+                            keep[q][r] = lds[(j + r * m) * T + t];
+                        }
+                    }
+                    const int k0 = (j % Ns) * (a.n / (Ns * 4));
+                    for (int r = 1; r < 4; ++r) {
+                        const double2 w = a.tw[(k0 * r) % a.n];
+                        keep[q][r] = cmul(keep[q][r], cd{w.x, SGN > 0 ? -w.y : w.y});
+                    }
+                    dft4<SGN>(keep[q][0], keep[q][1], keep[q][2], keep[q][3]);
+                    j0s[q] = (j / Ns) * Ns * 4 + (j % Ns);
+                }
+                if (!first) __syncthreads();
+                for (int q = 0; q < 2; ++q)
+                    for (int r = 0; r < 4; ++r) {
+                        if (last) {
+                            if (colok) a.out[col + (long long)(j0s[q] + r * Ns) * a.nlines] = make_double2(keep[q][r].x, keep[q][r].y);
+                        } else {
+                            lds[(j0s[q] + r * Ns) * T + t] = keep[q][r];
+                        }
+                    }
+                if (!last) __syncthreads();
+            } else {
+                cd keep[4][2];
+                int j0s[4];
+                for (int q = 0; q < 4; ++q) {
+                    const int j = jt + q * m8, m = a.n / 2;
+                    for (int r = 0; r < 2; ++r) {
+                        if (first) {
+                            double2 w = make_double2(0.0, 0.0);
+                            if (colok) w = a.in[col + (long long)(j + r * m) * a.nlines];
+                            keep[q][r] = {w.x, w.y};
+                        } else {
+                            keep[q][r] = lds[(j + r * m) * T + t];
+                        }
+                    }
+                    const int k0 = (j % Ns) * (a.n / (Ns * 2));
+                    const double2 w = a.tw[k0 % a.n];
+                    keep[q][1] = cmul(keep[q][1], cd{w.x, SGN > 0 ? -w.y : w.y});
+                    dft2<SGN>(keep[q][0], keep[q][1]);
+                    j0s[q] = (j / Ns) * Ns * 2 + (j % Ns);
+                }
+                if (!first) __syncthreads();
+                for (int q = 0; q < 4; ++q)
+                    for (int r = 0; r < 2; ++r) {
+                        if (last) {
+                            if (colok) a.out[col + (long long)(j0s[q] + r * Ns) * a.nlines] = make_double2(keep[q][r].x, keep[q][r].y);
+                        } else {
+                            lds[(j0s[q] + r * Ns) * T + t] = keep[q][r];
+                        }
+                    }
+                if (!last) __syncthreads();
+            }
+            (void)items;
+        }
+        Ns *= R;
+    }
+}
+
+bool FftzPlan::supported(int n) {
+    if (n < 16 || n > 1024) return false;
+    int m = n;
+    while (m % 8 == 0) m /= 8;
+    return m == 1 || m == 2 || m == 4;
+}
+
+FftzPlan::FftzPlan(int n_, long long nlines_) : n(n_), nlines(nlines_) {
+    if (!supported(n)) throw std::runtime_error("FftzPlan: unsupported length");
+    int m = n;
+    while (m % 8 == 0) { radix.push_back(8); m /= 8; }
+    if (m > 1) radix.push_back(m);
+    std::vector<double> tw((size_t)2 * n);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < n; ++k) {
+        tw[2 * k] = (double)cosl(two_pi * k / n);
+        tw[2 * k + 1] = (double)(-sinl(two_pi * k / n));
+    }
+    if (hipMalloc((void **)&d_tw, tw.size() * sizeof(double)) != hipSuccess) throw std::runtime_error("FftzPlan: hipMalloc");
+    if (hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("FftzPlan: hipMemcpy");
+}
+
+FftzPlan::~FftzPlan() {
+    if (d_tw) (void)hipFree(d_tw);
+}
+
+void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) const {
+    constexpr int T = 8;
+    FftzArgs a{};
+    a.in = reinterpret_cast<const double2 *>(in);
+    a.out = reinterpret_cast<double2 *>(out);
+    a.tw = reinterpret_cast<const double2 *>(d_tw);
+    a.nlines = nlines; a.n = n; a.npass = (int)radix.size();
+    for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
+    const unsigned grid = (unsigned)((nlines + T - 1) / T);
+    const unsigned block = (unsigned)(T * n / 8);
+    const size_t lds = (size_t)n * T * sizeof(double2);
+    ProfScope ps("k_fftz", st, (double)nlines * n * 32.0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fftz<-1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fftz<+1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    if (dir > 0) hipLaunchKernelGGL((k_fftz<-1, T>), dim3(grid), dim3(block), lds, st, a);      // forward: exp(-i ...)
+    else hipLaunchKernelGGL((k_fftz<+1, T>), dim3(grid), dim3(block), lds, st, a);
+    if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftz launch failed");
+}
+
+}  // namespace tlab

@@ -25,6 +25,7 @@
 
 #include "../../include/tlab_amd.h"
 #include "plan.hpp"
+#include "fftz.hpp"
 #include "poisson_host.hpp"
 #include "profile.hpp"
 
@@ -1146,7 +1147,9 @@ struct tlab_poisson_plan {
     DBuf s_lam, s_f, s_unit, s_bct, s_v0, s_v1, s_u0, s_u1, s_du0, s_du1, s_scr;
     FftPlan fx_r2c, fx_c2r, fz_f, fz_b;
     FftPlan f2_fwd, f2_bwd;           // optional fused 2-D (x,z) transforms, batch over y
+    std::unique_ptr<FftzPlan> fz_own;  // own strided z-transform (fftz.hip) where its lengths apply; rocFFT's fz_f / fz_b otherwise
     bool use_2d = false;
+    bool fz_inplace = false;          // z-transform plans built in place (kx-pencil plans: rocFFT then picks its column kernel, ~3x faster)
     hipStream_t side = nullptr;       // the <= 4 singular modes are solved beside the regular ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~tlab_poisson_plan() {
@@ -1334,6 +1337,10 @@ void build_fft(tlab_poisson_plan &P) {
         // nlines = (imax/2+1)*jmax, or tmpi_plan_fftz%nlines = that / npro_k after the K-transposition (opr_fourier.f90:85-98)
         nz = P.nz;
         const size_t nlines = (size_t)P.nxh * ny * nz / (size_t)P.nzt;
+        {
+            const char *e = getenv("TLAB_FFTZ");          // TLAB_FFTZ=0 keeps rocFFT for the z-transform
+            if (!(e && atoi(e) == 0) && FftzPlan::supported(P.nzt)) P.fz_own = std::make_unique<FftzPlan>(P.nzt, (long long)nlines);
+        }
         for (int dir = 0; dir < 2; ++dir) {
             rocfft_plan_description d = nullptr;
             fftc(rocfft_plan_description_create(&d), "desc");
@@ -1342,7 +1349,7 @@ void build_fft(tlab_poisson_plan &P) {
                                                          nullptr, nullptr, 1, st, 1, 1, st, 1), "layout c2c");
             size_t len[1] = {(size_t)P.nzt};
             FftPlan &F = dir == 0 ? P.fz_f : P.fz_b;
-            fftc(rocfft_plan_create(&F.plan, rocfft_placement_notinplace,
+            fftc(rocfft_plan_create(&F.plan, P.fz_inplace ? rocfft_placement_inplace : rocfft_placement_notinplace,
                                     dir == 0 ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
                                     rocfft_precision_double, 1, len, nlines, d), "plan c2c");
             rocfft_plan_description_destroy(d);
@@ -1424,6 +1431,10 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         P->nx = nx; P->ny = ny; P->nz = nz; P->nxh = nxl > 0 ? nxl : nx / 2 + 1;
         P->ioff = nxl > 0 ? ioff : 0;
         P->fx_nxh = nx / 2 + 1; P->fx_nz = fx_nz > 0 ? fx_nz : nz;
+        {
+            const char *e = getenv("TLAB_FFTZ_INPLACE");
+            P->fz_inplace = e ? atoi(e) != 0 : false;
+        }
         P->nzt = nzt; P->koff = koff; P->nproc = nproc;
         P->nm = (long long)P->nxh * nz;
         P->norm = 1.0 / ((double)nx * (double)nzt);                     // opr_elliptic.f90:130
@@ -1470,7 +1481,9 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         {   // fused 2-D (x,z) transforms are ~2x faster than r2c(x) + strided c2c(z) at 512^3, but rocFFT does not build them
             // for every layout: fall back to the two 1-D plans when plan creation fails (TLAB_FFT2D=0 forces the 1-D path)
             const char *e = getenv("TLAB_FFT2D");
-            if (nzt > 1 && nproc == 1 && nxl == 0 && !(e && atoi(e) == 0)) {
+            // ... and slower than r2c(x) + the own strided z-transform (fftz.hip: 0.49 + 0.53 ms against 1.14 ms at 512^3), so they are only
+            // built where that kernel does not apply (TLAB_FFTZ=0 or a length that is not 8^a * {1,2,4})
+            if (nzt > 1 && nproc == 1 && nxl == 0 && !P->fz_own && !(e && atoi(e) == 0)) {
                 try {
                     build_fft_2d(*P);
                     P->use_2d = true;
@@ -1623,7 +1636,8 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
         P->f2_fwd.exec(p, tmp1, st);
     } else if (nz > 1) {
         P->fx_r2c.exec(p, tmp2, st);
-        P->fz_f.exec(tmp2, tmp1, st);
+        if (P->fz_own) P->fz_own->exec(1, tmp2, tmp1, st);
+        else P->fz_f.exec(tmp2, tmp1, st);
     } else {
         P->fx_r2c.exec(p, tmp1, st);
     }
@@ -1633,10 +1647,12 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
         P->f2_bwd.exec(tmp1, p, st);
         if (dpdy) P->f2_bwd.exec(tmp2, dpdy, st);
     } else if (nz > 1) {
-        P->fz_b.exec(tmp1, P->cwork.p, st);
+        if (P->fz_own) P->fz_own->exec(-1, tmp1, P->cwork.p, st);
+        else P->fz_b.exec(tmp1, P->cwork.p, st);
         P->fx_c2r.exec(P->cwork.p, p, st);
         if (dpdy) {
-            P->fz_b.exec(tmp2, P->cwork.p, st);
+            if (P->fz_own) P->fz_own->exec(-1, tmp2, P->cwork.p, st);
+            else P->fz_b.exec(tmp2, P->cwork.p, st);
             P->fx_c2r.exec(P->cwork.p, dpdy, st);
         }
     } else {
@@ -1665,10 +1681,20 @@ int tlab_poisson_fft_x(tlab_poisson_plan_t P, int dir, double *in, double *out) 
 // complex (nlines, nz_total) lines-fastest (the K-transposed layout; nlines = (nx/2+1)*ny/nproc_k), out of place
 int tlab_poisson_fft_z(tlab_poisson_plan_t P, int dir, double *in, double *out) {
     POISSON_GUARD_BEGIN
-    if (!P || !in || !out || in == out) throw std::invalid_argument("tlab_poisson_fft_z: bad arguments");
+    if (!P || !in || !out || (in == out && !P->fz_inplace && !P->fz_own)) throw std::invalid_argument("tlab_poisson_fft_z: bad arguments");
     if (P->nzt <= 1) throw std::invalid_argument("tlab_poisson_fft_z: no z direction");
-    if (dir > 0) P->fz_f.exec(in, out, tlab_current_stream());
-    else P->fz_b.exec(in, out, tlab_current_stream());
+    if (P->fz_own) {
+        P->fz_own->exec(dir, in, out, tlab_current_stream());
+    } else if (P->fz_inplace) {      // in place on out (in == out allowed and cheapest)
+        if (in != out)
+            hipc(hipMemcpyAsync(out, in, (size_t)2 * P->nxh * P->ny * P->nz * sizeof(double), hipMemcpyDeviceToDevice, tlab_current_stream()), "copy");
+        if (dir > 0) P->fz_f.exec(out, out, tlab_current_stream());
+        else P->fz_b.exec(out, out, tlab_current_stream());
+    } else if (dir > 0) {
+        P->fz_f.exec(in, out, tlab_current_stream());
+    } else {
+        P->fz_b.exec(in, out, tlab_current_stream());
+    }
     POISSON_GUARD_END
 }
 // per-mode ODE solves on the local (kx, kz) modes: f_hat -> p_hat (may alias f_hat), dp_hat
