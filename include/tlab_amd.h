@@ -210,6 +210,18 @@ int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, c
 int tlab_boundary_bcs_neumann_y(tlab_fdm_plan_t g, int ibc, int nx, int ny, int nz, const double *u, double *bcs_hb,
                                 double *bcs_ht, double *tmp1);
 
+/* ---- per-iteration monitors ("next" row n2 of SURVEY.md 8f) -------------------------------------------------------------
+ * TIME_COURANT()   tools/dns/time.f90:365-548 (incompressible branch; constants of TIME_INITIALIZE :138-176):
+ *   pmax[0] = max |u|/dx + |v|/dy + |w|/dz over the local box, pmax[1] = schmidtfactor * max(1/dx^2 + 1/dy^2 + 1/dz^2);
+ *   dtime (may be NULL) = min(cfla / pmax[0], cfld / pmax[1]) if cfla > 0.  With several ranks the caller MPI_MAX-reduces pmax first
+ *   (time.f90:522) -- tlab_dns_set_slab tells a z-slab its first global plane (ims_offset_k).  Synchronises the stream.
+ * FI_INVARIANT_P(nx,ny,nz,u,v,w,result,tmp1)   mappings/fi_vectorcalculus.f90:111-141 : result = -div(u,v,w)
+ * MINMAX(imax,jmax,kmax,a,amn,amx)             utils/minmax.f90:6 (local part; DNS_BOUNDS_CONTROL dns_local.f90:184-187 uses both) */
+int tlab_dns_set_slab(tlab_dns_t d, int koffset);
+int tlab_time_courant(tlab_dns_t d, double *const *q, double cfla, double cfld, double *pmax, double *dtime);
+int tlab_fi_invariant_p(tlab_dns_t d, const double *u, const double *v, const double *w, double *result, double *tmp1);
+int tlab_minmax(tlab_dns_t d, const double *a, int nx, int ny, int nz, double *amn, double *amx);
+
 /* RHS_GLOBAL_INCOMPRESSIBLE_1()   tools/dns/rhs_global_incompressible_1.f90:15-405 (argument-less in the reference:
  * it works on the module arrays q, s, hq, hs, txc and on dte).  q[3] = u,v,w; s[nscal]; hq[3], hs[nscal] are
  * accumulated into; txc[9] = tmp1..tmp9, each of isize_txc_field = (nx+2)*ny*nz doubles.  HOST arrays of DEVICE pointers.

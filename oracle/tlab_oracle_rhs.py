@@ -75,6 +75,31 @@ class DnsOracle:
             b[:, 0, :] = ref_b
             b[:, ny - 1, :] = ref_t
 
+    def time_courant(self, cfla, cfld):
+        """tools/dns/time.f90:365-548 (incompressible) with the constants of TIME_INITIALIZE :138-176."""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        o1 = [1.0 / g.jac[:, 0] for g in self.g]
+        u, v, w = (a.reshape(nz, ny, nx) for a in self.q)
+        f = np.abs(u) * o1[0][None, None, :] + np.abs(v) * o1[1][None, :, None]
+        if nz > 1:
+            f = f + np.abs(w) * o1[2][:, None, None]
+        pmax1 = f.max()
+        sf = 1.0
+        for sc in self.schmidt[:self.nscal]:
+            sf = max(sf, 1.0 / sc)
+        sf = sf * self.visc
+        dx2i = sum((o * o).max() for o, n in zip(o1, (nx, ny, nz)) if n > 1)
+        pmax2 = sf * dx2i
+        dtc = cfla / pmax1 if pmax1 > 0 else 1e300
+        dtd = cfld / pmax2 if pmax2 > 0 else 1e300
+        return (pmax1, pmax2), min(dtc, dtd)
+
+    def fi_invariant_p(self):
+        """mappings/fi_vectorcalculus.f90:111-141."""
+        r = self.p1(1, self.q[0])
+        r = r + self.p1(2, self.q[1])
+        return -(r + self.p1(3, self.q[2]))
+
     def time_substep(self, dte, kco=1.0, scale=False):
         self.rhs_global_incompressible_1(dte)
         for i in range(3):

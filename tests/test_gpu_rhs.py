@@ -128,6 +128,27 @@ def test_rhs_entry_with_neumann_walls_vs_oracle(T):
     assert rel_err(d.hs[0].cpu().numpy(), o.hs[0]) <= 1e-11
 
 
+def test_time_courant_and_dilatation_vs_oracle(T):
+    """TIME_COURANT (time.f90:365) and the dilatation monitor (FI_INVARIANT_P + MINMAX, dns_local.f90:157-187)."""
+    import torch
+    from tlab_amd.dns import Dns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 64, 48, 32
+    x, y, z = grids(nx, ny, nz, True)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 13)
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 700.0, schmidt=(0.5,), yuniform=False)
+    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 700.0, schmidt=(0.5,), yuniform=False)
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i])); o.q[i] = q0[i].copy()
+    (p1, p2), dt = d.TIME_COURANT(1.2, 0.25)
+    (r1, r2), rdt = o.time_courant(1.2, 0.25)
+    assert abs(p1 - r1) <= 1e-14 * abs(r1) and abs(p2 - r2) <= 1e-14 * abs(r2) and abs(dt - rdt) <= 1e-14 * rdt
+    dmin, dmax = d.dilatation_bounds()
+    ref = -o.fi_invariant_p()
+    assert abs(dmin - ref.min()) <= 1e-12 * np.abs(ref).max() and abs(dmax - ref.max()) <= 1e-12 * np.abs(ref).max()
+    assert rel_err(d.txc[0][: d.n].cpu().numpy(), -ref) <= 1e-13
+
+
 def test_projection_makes_interior_divergence_vanish(T):
     """max|div(u/dte + hq)| * dte ~ 2e-15 in the interior after the pressure correction."""
     import torch

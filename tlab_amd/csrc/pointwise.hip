@@ -163,7 +163,53 @@ __global__ void __launch_bounds__(256) k_axpy1(double *__restrict__ o, const dou
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = a[i] + b[i] * s;
 }
 
+// ---- reductions (TIME_COURANT tools/dns/time.f90:365-548, MINMAX utils/minmax.f90:6) -----------------------------------------
+// per-block partial (min, max) of a[i] (mode 0) or of |u|/dx(i) + |v|/dy(j) + |w|/dz(k) (mode 1); part: [2][gridDim.x]
+__global__ void __launch_bounds__(256) k_minmax_partial(const double *__restrict__ a, const double *__restrict__ v, const double *__restrict__ w,
+                                                        const double *__restrict__ odx, const double *__restrict__ ody,
+                                                        const double *__restrict__ odz, int mode, int nx, int ny, int nz, int koff,
+                                                        double *__restrict__ part) {
+    __shared__ double smn[4], smx[4];
+    const long long n = (long long)nx * ny * nz, stride = (long long)gridDim.x * blockDim.x;
+    double mn = 1.0e300, mx = -1.0e300;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double val = a[i];
+        if (mode == 1) {
+            const int ix = (int)(i % nx), j = (int)((i / nx) % ny), k = (int)(i / ((long long)nx * ny));
+            val = fabs(a[i]) * odx[ix] + fabs(v[i]) * ody[j];
+            if (nz > 1 || koff > 0) val += fabs(w[i]) * odz[k + koff];
+        }
+        mn = fmin(mn, val); mx = fmax(mx, val);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, d, 64));
+        mx = fmax(mx, __shfl_xor(mx, d, 64));
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smn[wv] = mn; smx[wv] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
+        part[gridDim.x + blockIdx.x] = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+    }
+}
+__global__ void __launch_bounds__(256) k_negate(double *__restrict__ a, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = -a[i];
+}
+
 #define CHECK_LAUNCH() hipGetLastError()
+
+hipError_t launch_minmax_partial(const double *a, const double *v, const double *w, const double *odx, const double *ody, const double *odz,
+                                 int mode, int nx, int ny, int nz, int koff, double *part, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nblocks), dim3(256), 0, st, a, v, w, odx, ody, odz, mode, nx, ny, nz, koff, part);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_negate(double *a, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_negate, dim3(pw_grid(n)), dim3(256), 0, st, a, n);
+    return CHECK_LAUNCH();
+}
 
 hipError_t launch_add1(double *h, const double *a, long long n, hipStream_t st) {
     ProfScope ps("k_add1", st, (double)n * 24);

@@ -40,9 +40,17 @@ struct tlab_dns {
     int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};   // BcsFlowJmin%type
     int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
     std::vector<int> scal_jmin, scal_jmax;         // BcsScalJmin%type, BcsScalJmax%type
+    // TIME_COURANT (tools/dns/time.f90:138-176): ds(ig)%one_ov_ds1 = 1/jac(:,1) on the device, dx2i, schmidtfactor
+    double *od[3] = {nullptr, nullptr, nullptr};
+    double *part = nullptr;                        // [2][NPART] partial (min, max) of the reductions
+    double dx2i = 0.0, schmidtfactor = 0.0;
+    int koffset = 0, nz_total = 0;                 // z-slab: first global plane and global nz (one_ov_ds1 of z is indexed globally)
     ~tlab_dns() {
         if (bcs_hb) (void)hipFree(bcs_hb);
         if (bcs_ht) (void)hipFree(bcs_ht);
+        for (int i = 0; i < 3; ++i)
+            if (od[i]) (void)hipFree(od[i]);
+        if (part) (void)hipFree(part);
     }
 };
 
@@ -76,6 +84,25 @@ int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tla
         d->scal_jmax.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
         hk(hipMalloc((void **)&d->bcs_hb, (size_t)nx * nz * sizeof(double)), "hipMalloc");
         hk(hipMalloc((void **)&d->bcs_ht, (size_t)nx * nz * sizeof(double)), "hipMalloc");
+        // TIME_INITIALIZE, tools/dns/time.f90:138-176
+        d->nz_total = gz->t.n;
+        double sf = 1.0;                                            // (prandtl = 1: incompressible)
+        for (int is = 0; is < nscal; ++is) sf = std::max(sf, 1.0 / schmidt[is]);
+        d->schmidtfactor = sf * visc;
+        std::vector<double> o2[3];
+        tlab_fdm_plan_t gg[3] = {gx, gy, gz};
+        for (int ig = 0; ig < 3; ++ig) {
+            const int m = gg[ig]->t.n;
+            std::vector<double> o1(m);
+            o2[ig].resize(m);
+            for (int i = 0; i < m; ++i) { o1[i] = 1.0 / gg[ig]->t.jac[i]; o2[ig][i] = o1[i] * o1[i]; }
+            hk(hipMalloc((void **)&d->od[ig], (size_t)m * sizeof(double)), "hipMalloc");
+            hk(hipMemcpy(d->od[ig], o1.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+        }
+        d->dx2i = 0.0;      // separable maximum of the sum = sum of the maxima over the directions with more than one point
+        for (int ig = 0; ig < 3; ++ig)
+            if (gg[ig]->t.n > 1) d->dx2i += *std::max_element(o2[ig].begin(), o2[ig].end());
+        hk(hipMalloc((void **)&d->part, (size_t)2 * 1024 * sizeof(double)), "hipMalloc");
         *out = d.release();
         return TLAB_OK;
     } catch (const Fail &f) {
@@ -263,6 +290,76 @@ int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, c
     for (int i = 0; i < 3; ++i) { d->flow_jmin[i] = flow_jmin[i]; d->flow_jmax[i] = flow_jmax[i]; }
     for (int i = 0; i < d->nscal; ++i) { d->scal_jmin[i] = scal_jmin[i]; d->scal_jmax[i] = scal_jmax[i]; }
     return TLAB_OK;
+}
+
+// min / max of a device array through per-block partials reduced on the host (diagnostics: once per time step, not per substep)
+static void minmax_impl(tlab_dns_t d, const double *a, const double *v, const double *w, int mode, int nx, int ny, int nz, double *mn, double *mx) {
+    hipStream_t st = tlab_current_stream();
+    const long long n = (long long)nx * ny * nz;
+    const int nb = (int)std::min<long long>(1024, (n + 255) / 256);
+    hk(launch_minmax_partial(a, v, w, d->od[0], d->od[1], d->od[2], mode, nx, ny, nz, d->koffset, d->part, nb, st), "k_minmax_partial");
+    std::vector<double> h((size_t)2 * nb);
+    hk(hipMemcpyAsync(h.data(), d->part, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpy");
+    hk(hipStreamSynchronize(st), "sync");
+    *mn = *std::min_element(h.begin(), h.begin() + nb);
+    *mx = *std::max_element(h.begin() + nb, h.end());
+}
+
+int tlab_dns_set_slab(tlab_dns_t d, int koffset) {
+    if (!d || koffset < 0 || koffset + d->nz > d->nz_total) { tlab_set_error("tlab_dns_set_slab: bad offset"); return TLAB_EINVAL; }
+    d->koffset = koffset;
+    return TLAB_OK;
+}
+
+int tlab_time_courant(tlab_dns_t d, double *const *q, double cfla, double cfld, double *pmax, double *dtime) {
+    try {
+        if (!d || !q || !pmax) throw Fail(TLAB_EINVAL, "tlab_time_courant: bad arguments");
+        double mn, mx;
+        minmax_impl(d, q[0], q[1], q[2], 1, d->nx, d->ny, d->nz, &mn, &mx);
+        pmax[0] = mx;                                   // max of |u|/dx + |v|/dy + |w|/dz over the local box (time.f90:402-451)
+        pmax[1] = d->schmidtfactor * d->dx2i;           // time.f90:466
+        if (dtime && cfla > 0.0) {                      // time.f90:523-538, explicit RK: min of the two limits
+            double dtc = 1.0e300, dtd = 1.0e300;
+            if (pmax[0] > 0.0) dtc = cfla / pmax[0];
+            if (pmax[1] > 0.0) dtd = cfld / pmax[1];
+            *dtime = std::min(dtc, dtd);
+        }
+        return TLAB_OK;
+    } catch (const Fail &f) {
+        tlab_set_error(f.what());
+        return f.code;
+    }
+}
+
+int tlab_fi_invariant_p(tlab_dns_t d, const double *u, const double *v, const double *w, double *result, double *tmp1) {
+    try {
+        if (!d || !u || !v || !w || !result || !tmp1) throw Fail(TLAB_EINVAL, "tlab_fi_invariant_p: bad arguments");
+        const int nx = d->nx, ny = d->ny, nz = d->nz;
+        const long long n = (long long)nx * ny * nz;
+        hipStream_t st = tlab_current_stream();
+        // result = -((du/dx + dv/dy) + dw/dz), fi_vectorcalculus.f90:130-136
+        ok(tlab_opr_partial(1, d->g[0], TLAB_OPR_P1, nx, ny, nz, 0, u, result, nullptr), "OPR_Partial_X");
+        ok(tlab_opr_partial(2, d->g[1], TLAB_OPR_P1, nx, ny, nz, 0, v, tmp1, nullptr), "OPR_Partial_Y");
+        hk(launch_add1(result, tmp1, n, st), "add");
+        ok(tlab_opr_partial(3, d->g[2], TLAB_OPR_P1, nx, ny, nz, 0, w, tmp1, nullptr), "OPR_Partial_Z");
+        hk(launch_add1(result, tmp1, n, st), "add");
+        hk(launch_negate(result, n, st), "negate");
+        return TLAB_OK;
+    } catch (const Fail &f) {
+        tlab_set_error(f.what());
+        return f.code;
+    }
+}
+
+int tlab_minmax(tlab_dns_t d, const double *a, int nx, int ny, int nz, double *amn, double *amx) {
+    try {
+        if (!d || !a || !amn || !amx) throw Fail(TLAB_EINVAL, "tlab_minmax: bad arguments");
+        minmax_impl(d, a, nullptr, nullptr, 0, nx, ny, nz, amn, amx);
+        return TLAB_OK;
+    } catch (const Fail &f) {
+        tlab_set_error(f.what());
+        return f.code;
+    }
 }
 
 int tlab_dns_set_fusion(tlab_dns_t d, int on) {

@@ -114,6 +114,28 @@ class Dns:
         check(load().tlab_time_substep_incompressible_explicit(self._h, float(dte), float(kco), int(scale_tendencies), q, s, hq, hs, txc),
               "tlab_time_substep_incompressible_explicit")
 
+    def TIME_COURANT(self, cfla, cfld):
+        """tools/dns/time.f90:365-548.  Returns ((pmax1, pmax2), dtime): the CFL and diffusion maxima and the time step they allow."""
+        _use_torch_stream()
+        q = self._arrays()[0]
+        pmax = (ctypes.c_double * 2)()
+        dt = ctypes.c_double(0.0)
+        check(load().tlab_time_courant(self._h, q, float(cfla), float(cfld), pmax, ctypes.byref(dt)), "tlab_time_courant")
+        return (pmax[0], pmax[1]), dt.value
+
+    def FI_INVARIANT_P(self, result, tmp1):
+        """mappings/fi_vectorcalculus.f90:111: result = -div(q)."""
+        _use_torch_stream()
+        check(load().tlab_fi_invariant_p(self._h, self.q[0].data_ptr(), self.q[1].data_ptr(), self.q[2].data_ptr(), result.data_ptr(), tmp1.data_ptr()),
+              "tlab_fi_invariant_p")
+
+    def dilatation_bounds(self):
+        """DNS_BOUNDS_CONTROL, tools/dns/dns_local.f90:157-187 (incompressible): (DilMin, DilMax) = logs_data(10:11) of dns.out."""
+        self.FI_INVARIANT_P(self.txc[0], self.txc[1])
+        mn, mx = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        check(load().tlab_minmax(self._h, self.txc[0].data_ptr(), self.nx, self.ny, self.nz, ctypes.byref(mn), ctypes.byref(mx)), "tlab_minmax")
+        return -mx.value, -mn.value
+
     def TIME_RUNGEKUTTA(self, dtime):
         """One time step: hq = hs = 0, then rkm_endstep substeps (time.f90:212-298)."""
         for t in self.hq + self.hs:
