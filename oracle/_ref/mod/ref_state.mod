@@ -1,7 +1,7 @@
-﻿!mod$ v1 sum:50f0cdc01ccd4766
+﻿!mod$ v1 sum:ad86fbe3b97a3a42
 !need$ 8d4bae2479538272 n fdm_integral
-!need$ 370470eb4a3adeb1 n tlab_constants
 !need$ ff3fca9ebc58e858 n tlab_grid
+!need$ 370470eb4a3adeb1 n tlab_constants
 !need$ 06183c4da53c4dbe n fdm
 module ref_state
 use tlab_constants,only:wp

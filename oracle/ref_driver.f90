@@ -321,3 +321,104 @@ subroutine ref_bcs_neumann_y(ibc, nx, ny, nz, u, bcs_hb, bcs_ht) bind(C, name='r
     end if
     deallocate (org, dst, hb, ht)
 end subroutine ref_bcs_neumann_y
+
+!########################################################################
+! Restart-file formats (SURVEY.md 8f n4): TLab_Grid_Write/Read (base/tlab_grid.f90:26,72) and IO_Write_Fields/IO_Read_Fields
+! (base/io_fields.f90:346,150) of the reference itself, called with C strings.
+subroutine ref_grid_write(cname, nx, ny, nz, x, y, z) bind(C, name='ref_grid_write')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_Grid, only: grid_dt, TLab_Grid_Write
+    implicit none
+    character(kind=c_char), intent(in) :: cname(*)
+    integer(c_int), value :: nx, ny, nz
+    real(c_double), intent(in) :: x(nx), y(ny), z(nz)
+    type(grid_dt) gx, gy, gz
+    character(len=256) name
+    integer i
+    name = ' '
+    do i = 1, 255
+        if (cname(i) == c_null_char) exit
+        name(i:i) = cname(i)
+    end do
+    gx%size = nx; gy%size = ny; gz%size = nz
+    allocate (gx%nodes(nx), gy%nodes(ny), gz%nodes(nz))
+    gx%nodes = x; gy%nodes = y; gz%nodes = z
+    gx%scale = x(nx) - x(1); gy%scale = y(ny) - y(1); gz%scale = z(nz) - z(1)
+    call TLab_Grid_Write(trim(name), gx, gy, gz)
+end subroutine ref_grid_write
+
+subroutine ref_grid_read(cname, nx, ny, nz, x, y, z, scales) bind(C, name='ref_grid_read')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_Grid, only: grid_dt, TLab_Grid_Read
+    implicit none
+    character(kind=c_char), intent(in) :: cname(*)
+    integer(c_int), value :: nx, ny, nz
+    real(c_double), intent(out) :: x(nx), y(ny), z(nz), scales(3)
+    type(grid_dt) gx, gy, gz
+    character(len=256) name
+    integer i
+    name = ' '
+    do i = 1, 255
+        if (cname(i) == c_null_char) exit
+        name(i:i) = cname(i)
+    end do
+    call TLab_Grid_Read(trim(name), gx, gy, gz, [nx, ny, nz])
+    x = gx%nodes; y = gy%nodes; z = gz%nodes
+    scales = [gx%scale, gy%scale, gz%scale]
+end subroutine ref_grid_read
+
+subroutine ref_io_write_fields(cname, nx, ny, nz, nt, nfield, a, nparams, params) bind(C, name='ref_io_write_fields')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use IO_Fields
+    implicit none
+    character(kind=c_char), intent(in) :: cname(*)
+    integer(c_int), value :: nx, ny, nz, nt, nfield, nparams
+    real(c_double), intent(in) :: a(nx*ny*nz, nfield), params(max(nparams, 1))
+    character(len=256) name
+    integer i
+    name = ' '
+    do i = 1, 255
+        if (cname(i) == c_null_char) exit
+        name(i:i) = cname(i)
+    end do
+    io_fileformat = IO_MPIIO
+    io_datatype = IO_TYPE_DOUBLE
+    if (nparams > 0) then
+        io_header_q(1)%size = nparams
+        io_header_q(1)%params(1:nparams) = params(1:nparams)
+        call IO_Write_Fields(trim(name), nx, ny, nz, nt, nfield, a, io_header_q(1:1))
+    else
+        call IO_Write_Fields(trim(name), nx, ny, nz, nt, nfield, a)
+    end if
+end subroutine ref_io_write_fields
+
+subroutine ref_io_read_fields(cname, nx, ny, nz, nt, nfield, a, nparams, params) bind(C, name='ref_io_read_fields')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use IO_Fields
+    implicit none
+    character(kind=c_char), intent(in) :: cname(*)
+    integer(c_int), value :: nx, ny, nz, nt, nfield, nparams
+    real(c_double), intent(out) :: a(nx*ny*nz, nfield)
+    real(c_double), intent(inout) :: params(max(nparams, 1))
+    real(wp) :: p(max(nparams, 1))
+    character(len=256) name
+    integer i
+    name = ' '
+    do i = 1, 255
+        if (cname(i) == c_null_char) exit
+        name(i:i) = cname(i)
+    end do
+    io_fileformat = IO_MPIIO
+    io_datatype = IO_TYPE_DOUBLE
+    p = 0.0_wp
+    if (nparams > 0) then
+        call IO_Read_Fields(trim(name), nx, ny, nz, nt, nfield, 0, a, p(1:nparams))
+    else
+        call IO_Read_Fields(trim(name), nx, ny, nz, nt, nfield, 0, a, p(1:0))
+    end if
+    params(1:max(nparams, 1)) = p
+end subroutine ref_io_read_fields

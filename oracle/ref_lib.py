@@ -176,3 +176,35 @@ def bcs_neumann_y(ibc, nx, ny, nz, u):
     ht = np.zeros(nx * nz)
     L.ref_bcs_neumann_y(int(ibc), nx, ny, nz, u, hb, ht)
     return hb, ht
+
+
+def grid_write(name, x, y, z):
+    L = lib()
+    x, y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z))
+    L.ref_grid_write.argtypes = [ctypes.c_char_p, c_int, c_int, c_int, _P, _P, _P]
+    L.ref_grid_write(name.encode(), x.size, y.size, z.size, x, y, z)
+
+
+def grid_read(name, nx, ny, nz):
+    L = lib()
+    x, y, z, sc = np.zeros(nx), np.zeros(ny), np.zeros(nz), np.zeros(3)
+    L.ref_grid_read.argtypes = [ctypes.c_char_p, c_int, c_int, c_int, _P, _P, _P, _P]
+    L.ref_grid_read(name.encode(), nx, ny, nz, x, y, z, sc)
+    return x, y, z, sc
+
+
+def io_write_fields(name, nx, ny, nz, nt, fields, params=()):
+    L = lib()
+    a = np.ascontiguousarray(np.stack([np.asarray(f, dtype=np.float64).reshape(-1) for f in fields]))      # (nfield, n) = Fortran a(n, nfield)
+    p = np.ascontiguousarray(params if len(params) else [0.0], dtype=np.float64)
+    L.ref_io_write_fields.argtypes = [ctypes.c_char_p] + [c_int] * 5 + [_P, c_int, _P]
+    L.ref_io_write_fields(name.encode(), nx, ny, nz, nt, len(fields), a, len(params), p)
+
+
+def io_read_fields(name, nx, ny, nz, nt, nfield, nparams):
+    L = lib()
+    a = np.zeros((nfield, nx * ny * nz))
+    p = np.zeros(max(nparams, 1))
+    L.ref_io_read_fields.argtypes = [ctypes.c_char_p] + [c_int] * 5 + [_P, c_int, _P]
+    L.ref_io_read_fields(name.encode(), nx, ny, nz, nt, nfield, a, nparams, p)
+    return [a[i] for i in range(nfield)], p[:nparams]

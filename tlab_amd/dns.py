@@ -114,6 +114,27 @@ class Dns:
         check(load().tlab_time_substep_incompressible_explicit(self._h, float(dte), float(kco), int(scale_tendencies), q, s, hq, hs, txc),
               "tlab_time_substep_incompressible_explicit")
 
+    def load_fields(self, flow_name=None, scal_name=None):
+        """Restart files of the reference: <flow_name>.1..3 = u, v, w; <scal_name>.1..nscal (IO_Read_Fields, io_fields.f90:150).
+        Returns (nt, params) of the last header read."""
+        import torch
+        from . import io as tio
+        nt, params = None, None
+        for name, dst in ((flow_name, self.q), (scal_name, self.s)):
+            if name is None or not dst:
+                continue
+            fields, nt, params = tio.io_read_fields(name, self.nx, self.ny, self.nz, len(dst))
+            for t, a in zip(dst, fields):
+                t.copy_(torch.from_numpy(a))
+        return nt, params
+
+    def save_fields(self, flow_name=None, scal_name=None, nt=0, params=()):
+        """IO_Write_Fields (io_fields.f90:346): files the reference's own tools (averages.x, visuals.x, dns.x) read back."""
+        from . import io as tio
+        for name, src in ((flow_name, self.q), (scal_name, self.s)):
+            if name is not None and src:
+                tio.io_write_fields(name, self.nx, self.ny, self.nz, nt, [t.cpu().numpy() for t in src], params)
+
     def TIME_COURANT(self, cfla, cfld):
         """tools/dns/time.f90:365-548.  Returns ((pmax1, pmax2), dtime): the CFL and diffusion maxima and the time step they allow."""
         _use_torch_stream()
