@@ -128,6 +128,73 @@ def test_rhs_entry_with_neumann_walls_vs_oracle(T):
     assert rel_err(d.hs[0].cpu().numpy(), o.hs[0]) <= 1e-11
 
 
+def test_case01_shaped_two_dimensional_step(T):
+    """BASELINE configs[0] = examples/Case01: 512 x 256 x 1, RungeKuttaExplicit4, free-slip walls, Neumann scalar, time step from
+    TimeCFL = 1.2 (tlab.ini).  Its initial fields come from the reference's initialisation tools (out of scope), so the same
+    plumbing runs on synthetic shear-layer fields: one full RK4 step + TIME_COURANT + dilatation bounds against the oracle."""
+    import torch
+    from tlab_amd.dns import Dns, RKM_EXP4, velocity_bcs
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 512, 256, 1
+    x = np.arange(nx) / nx * 2.0
+    y = np.arange(ny) / (ny - 1.0)
+    z = np.zeros(1)
+    rng = np.random.default_rng(101)
+    Y, X = np.meshgrid(y, x, indexing="ij")
+    u0 = 0.5 * np.tanh((Y - 0.5) / (2 * 0.005859375 * 8)) + 0.02 * rng.uniform(-1, 1, X.shape) * np.exp(-((Y - 0.5) / 0.1) ** 2)
+    v0 = 0.02 * rng.uniform(-1, 1, X.shape) * np.exp(-((Y - 0.5) / 0.1) ** 2) * np.sin(np.pi * Y)
+    s0 = 0.5 - 0.5 * np.tanh((Y - 0.5) / (2 * 0.005859375 * 8))
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP4)
+    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True)
+    d.set_bcs("freeslip", "freeslip", "neumann", "neumann")
+    o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin = o.scal_jmax = [4]
+    for i, a in enumerate((u0, v0, np.zeros_like(u0))):
+        d.q[i].copy_(torch.from_numpy(a.ravel())); o.q[i] = a.ravel().copy()
+    d.s[0].copy_(torch.from_numpy(s0.ravel())); o.s[0] = s0.ravel().copy()
+    (p1, p2), dt = d.TIME_COURANT(1.2, 0.25)
+    (r1, r2), rdt = o.time_courant(1.2, 0.25)
+    assert abs(dt - rdt) <= 1e-14 * rdt
+    kdt, kco = d.kdt, d.kco
+    assert len(kdt) == 5
+    for k in range(5):                      # TIME_RUNGEKUTTA, time.f90:212-298
+        last = k == 4
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dt * kdt[k], 1.0 if last else kco[k], not last)
+        o.time_substep(rdt * kdt[k], 1.0 if last else kco[k], not last)
+    for i in range(2):
+        assert rel_err(d.q[i].cpu().numpy(), o.q[i]) <= 1e-12, i
+    assert float(d.q[2].abs().max()) == 0.0 and np.abs(o.q[2]).max() == 0.0         # no z-dynamics in 2-D
+    assert rel_err(d.s[0].cpu().numpy(), o.s[0]) <= 1e-12
+    dmin, dmax = d.dilatation_bounds()
+    ref = -o.fi_invariant_p()
+    assert abs(dmin - ref.min()) <= 1e-11 * max(1.0, np.abs(ref).max()) and abs(dmax - ref.max()) <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("nscal", [0, 3])
+def test_other_scalar_counts(T, nscal):
+    """configs[4] carries 3 active scalars (two Burgers launches per direction: 4 + 2 fields); nscal = 0 is the pure flow case."""
+    import torch
+    from tlab_amd.dns import Dns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 256, 64, 32
+    x, y, z = grids(nx, ny, nz, True)
+    sc = (0.7, 1.0, 2.5)[:nscal]
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 17)
+    d = Dns(x, y, z, nscal=nscal, visc=1.0 / 900.0, schmidt=sc if nscal else (1.0,), yuniform=False)
+    o = DnsOracle(x, y, z, nscal=nscal, visc=1.0 / 900.0, schmidt=sc if nscal else (1.0,), yuniform=False)
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i])); o.q[i] = q0[i].copy()
+    for i in range(nscal):
+        a = s0[0] * (1.0 + 0.3 * i) + 0.1 * i
+        d.s[i].copy_(torch.from_numpy(a)); o.s[i] = a.copy()
+    for k in range(2):
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(2e-3 * d.kdt[k], d.kco[k], True)
+        o.time_substep(2e-3 * d.kdt[k], d.kco[k], True)
+    for i in range(3):
+        assert rel_err(d.q[i].cpu().numpy(), o.q[i]) <= 1e-12
+    for i in range(nscal):
+        assert rel_err(d.s[i].cpu().numpy(), o.s[i]) <= 1e-12 and rel_err(d.hs[i].cpu().numpy(), o.hs[i]) <= 1e-11
+
+
 def test_time_courant_and_dilatation_vs_oracle(T):
     """TIME_COURANT (time.f90:365) and the dilatation monitor (FI_INVARIANT_P + MINMAX, dns_local.f90:157-187)."""
     import torch
