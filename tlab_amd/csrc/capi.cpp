@@ -431,6 +431,10 @@ struct OpExtra {
     const double *fs[4] = {nullptr, nullptr, nullptr, nullptr};
     double *fo[4] = {nullptr, nullptr, nullptr, nullptr};
     double fnu[4] = {0, 0, 0, 0};
+    // MODE_P1 final-update epilogue
+    double *fq = nullptr;
+    double fdte = 0.0, fkco = 1.0;
+    int fscale = 0, fnx = 1, fny = 1;
 };
 const OpExtra kNoExtra{};
 
@@ -460,6 +464,7 @@ void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.out1 = nullptr; a.g = geom; a.nu = nu;
     a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
     a.nf = 0;
+    a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     a.y1 = g->system(1, ibc, P).dev();
@@ -478,6 +483,7 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     RTileArgs a;
     a.in0 = in0; a.in1 = nullptr; a.in2 = vel; a.out0 = out0; a.out1 = out1; a.g = geom; a.nu = nu;
     a.in0b = nullptr; a.in0b_scale = 0.0; a.acc = ex.acc ? 1 : 0;
+    a.fq = nullptr; a.fdte = 0.0; a.fkco = 1.0; a.fscale = 0; a.fnx = 1; a.fny = 1;
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; }
     a.s1 = g->stencil(1, ibc);
@@ -493,6 +499,7 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     XLineArgs a;
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1; a.nlines = geom.nlines; a.nu = nu;
     a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
+    a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny;
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; }
     a.s1 = g->stencil(1, ibc);
@@ -542,6 +549,23 @@ bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, 
     } else {
         return false;
     }
+    g_last_path = path;
+    return true;
+}
+// h -= d/dx_dir p ; walls ; q += dte h ; h *= kco : the last pass over a velocity component folded into the gradient of the pressure.
+// Dirichlet walls only (the tendency is zero on the wall planes); dir = 1 or 3.
+bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
+                                  double kco, int scale) {
+    check_common(dir, g, nx, ny, nz, 0);
+    if (dir == 2) return false;
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (geom.n == 1) return false;
+    OpExtra ex;
+    ex.fq = q; ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fnx = nx; ex.fny = ny;
+    const int path = choose_path(dir, geom.n);
+    if (path == PATH_XLINE) run_xline(g, geom, MODE_P1, 0, p, nullptr, h, nullptr, 0.0, ex);
+    else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_rtile(g, geom, MODE_P1, 0, p, nullptr, nullptr, h, 0.0, ex);
+    else return false;
     g_last_path = path;
     return true;
 }

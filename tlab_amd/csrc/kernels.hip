@@ -235,13 +235,29 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 xsolve<M, LV>(x2, y2, lane, n);
             }
             if (MODE == MODE_P1) {
-                if (a.acc) {
-                    double o[M];
-                    xload<M>(o, a.out0 + off);
+                if (a.fq != nullptr) {          // final-update epilogue: the line is (j, k) = (line % ny, line / ny)
+                    double h[M], qv[M];
+                    xload<M>(h, a.out0 + off);
+                    xload<M>(qv, a.fq + off);
+                    const int j = (int)(line % a.fny);
+                    const bool wall = (j == 0) || (j == a.fny - 1);
 #pragma unroll
-                    for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+                    for (int p = 0; p < M; ++p) {
+                        const double hv = wall ? 0.0 : h[p] - x1[p];
+                        qv[p] = qv[p] + a.fdte * hv;
+                        h[p] = a.fscale ? a.fkco * hv : hv;
+                    }
+                    xstore<M>(a.fq + off, qv);
+                    xstore<M>(a.out0 + off, h);
+                } else {
+                    if (a.acc) {
+                        double o[M];
+                        xload<M>(o, a.out0 + off);
+#pragma unroll
+                        for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+                    }
+                    xstore<M>(a.out0 + off, x1);
                 }
-                xstore<M>(a.out0 + off, x1);
             } else if (MODE == MODE_P2) {
                 xstore<M>(a.out0 + off, x2);
             } else {   // MODE_P2_P1
@@ -391,6 +407,33 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
             const long long idx = base + (long long)(row0 + p) * rs;
             if (valid) a.out0[idx] = a.nu * f[p] - a.in2[idx] * a.in1[idx];
         }
+    } else if (MODE == MODE_P1 && a.fq != nullptr) {
+        // final-update epilogue (z-direction lines: lane = (ix, j) inside the plane, rows = k)
+        if (valid) {
+            const int j = ((l0 + lane) / a.fnx) % a.fny;
+            const bool wall = (j == 0) || (j == a.fny - 1);
+            // 8 rows at a time: 16 loads in flight, then their stores (f[M] + h[M] + q[M] would not fit the 128 VGPRs of the 1024-thread launch)
+#pragma unroll
+            for (int p0 = 0; p0 < M; p0 += 8) {
+                double h[8], qv[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    h[p] = a.out0[base + (long long)(row0 + p0 + p) * rs];
+                    qv[p] = a.fq[base + (long long)(row0 + p0 + p) * rs];
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const double hv = wall ? 0.0 : h[p] - f[p0 + p];
+                    qv[p] = qv[p] + a.fdte * hv;
+                    h[p] = a.fscale ? a.fkco * hv : hv;
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    a.fq[base + (long long)(row0 + p0 + p) * rs] = qv[p];
+                    a.out0[base + (long long)(row0 + p0 + p) * rs] = h[p];
+                }
+            }
+        }
     } else {
         if (MODE == MODE_P1 && a.acc && valid) {   // all loads first: the compiler cannot move them across the stores itself
             double o[M];
@@ -517,7 +560,7 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
-    double bytes = pts * (bpp[mode] + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0));
+    double bytes = pts * (bpp[mode] + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0) + (a.fq ? 24 : 0));
     if (mode == MODE_BURGERS) {   // velocity once + per field: operand (unless it is the velocity), result, previous result when accumulating
         bytes = pts * 8;
         for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in1 ? 0 : 8) + 8 + (a.acc ? 8 : 0));
@@ -567,7 +610,7 @@ static hipError_t launch_rtile_m(int mode, int P, long long tiles, const RTileAr
     const double pts = (double)a.g.nlines * a.g.n;
     const char *name = mode == MODE_P1 ? "k_rtile<P1>" : mode == MODE_P2 ? "k_rtile<P2>" : mode == MODE_P2_D1IN ? "k_rtile<P2_D1IN>" : "k_rtile<BURGERS_D1IN>";
     const double bpp = mode == MODE_P1 || mode == MODE_P2 ? 16 : mode == MODE_P2_D1IN ? 24 : 32;   // operand reads + writes of this launch
-    ProfScope ps(name, st, pts * (bpp + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0)));
+    ProfScope ps(name, st, pts * (bpp + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0) + (a.fq ? 24 : 0)));
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_rtile<M, MODE_P1, MAXT>), grid, block, 0, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_rtile<M, MODE_P2, MAXT>), grid, block, 0, st, a); break;

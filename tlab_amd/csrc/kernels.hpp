@@ -23,6 +23,12 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     const double *fs[4];
     double *fo[4];
     double fnu[4];
+    // MODE_P1 "final update" epilogue (fq != NULL): instead of storing d = D1 u, finish the substep of one velocity component with it:
+    //   h = out0 (tendency) ; hv = h - d ; hv = 0 on the wall planes j = 0, fny-1 ; fq += fdte hv ; h = fscale ? fkco hv : hv
+    // (rhs_global_incompressible_1.f90:348-352, :373-375 for Dirichlet walls; time.f90:645-664, :272-297)
+    double *fq;
+    double fdte, fkco;
+    int fscale, fnx, fny;
 };
 
 struct RTileArgs {          // k_rtile: derivative along a strided index
@@ -43,6 +49,12 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     const double *fs[4];
     double *fo[4];
     double fnu[4];
+    // MODE_P1 "final update" epilogue (fq != NULL): instead of storing d = D1 u, finish the substep of one velocity component with it:
+    //   h = out0 (tendency) ; hv = h - d ; hv = 0 on the wall planes j = 0, fny-1 ; fq += fdte hv ; h = fscale ? fkco hv : hv
+    // (rhs_global_incompressible_1.f90:348-352, :373-375 for Dirichlet walls; time.f90:645-664, :272-297)
+    double *fq;
+    double fdte, fkco;
+    int fscale, fnx, fny;
 };
 
 struct GenericArgs {        // k_generic: any n

@@ -25,6 +25,8 @@ bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, 
 bool tlab_internal_partial_p1_fusable(int dir, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
                                double *result);
+bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
+                                  double kco, int scale);
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result);
@@ -199,8 +201,23 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     hk(launch_get_wall_planes(hq[1], d->bcs_hb, d->bcs_ht, nx, ny, nz, st), "wall planes");
     // pressure in tmp1, Oy derivative in tmp3 (:284)
     ok(tlab_opr_poisson(d->poisson, nx, ny, nz, TLAB_BCS_NN, tmp1, tmp2, tmp4, d->bcs_hb, d->bcs_ht, tmp3), "OPR_Poisson");
-    ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
-    ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
+    // ---- pressure gradient (:319-320).  With Dirichlet walls and the RK update folded in (tail_update), the x- and z-gradient kernels
+    // finish u and w themselves: hq -= dp/dx; wall planes; q += dte hq; hq *= kco (no gradient array is written or re-read) ----
+    bool grad_final = false;
+    if (tail_update && d->fuse && nz > 1) {
+        bool dirichlet = true;
+        for (int iq = 0; iq < 3; ++iq) dirichlet = dirichlet && d->flow_jmin[iq] == TLAB_DNS_BCS_DIRICHLET && d->flow_jmax[iq] == TLAB_DNS_BCS_DIRICHLET;
+        if (dirichlet && tlab_internal_partial_p1_fusable(1, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, nx, ny, nz)) {
+            const bool okx = tlab_internal_gradient_final(1, gx, nx, ny, nz, tmp1, q[0], hq[0], dte, kco, scale_tendencies);
+            const bool okz = okx && tlab_internal_gradient_final(3, gz, nx, ny, nz, tmp1, q[2], hq[2], dte, kco, scale_tendencies);
+            if (okx != okz) throw Fail(TLAB_EINVAL, "internal: inconsistent fused gradient path");
+            grad_final = okx;
+        }
+    }
+    if (!grad_final) {
+        ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
+        ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
+    }
     // ---- boundary conditions (:360-398): Dirichlet -> the tendency vanishes on the wall plane; Neumann -> the wall tendency
     // keeps d/dy = 0 there (BOUNDARY_BCS_NEUMANN_Y on the finished tendency; tmp1 is its work array as in the reference) ----
     auto ibc_of = [](int tmin, int tmax) { return (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0); };
@@ -223,6 +240,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             gp[0] = gp[1] = gp[2] = nullptr;
         }
         for (int iq = 0; iq < 3; ++iq) {
+            if (grad_final && iq != 1) continue;          // u and w are finished already
             planes(ibc_q[iq], hq[iq], pb, pt);
             hk(launch_final_update(q[iq], hq[iq], gp[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
