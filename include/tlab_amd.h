@@ -86,6 +86,9 @@ int tlab_fdm_plan_create(tlab_fdm_plan_t *out, int n, const double *nodes, int p
 int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, int need_1der,
                                      int ndl1, int ndr1, const double *lhs1, const double *rhs1,
                                      int ndl2, int ndr2, const double *lhs2, const double *rhs2);
+/* Remaining members of type(fdm_dt) a host-built plan may carry (any pointer may be NULL): der1%mwn(n), der2%mwn(n) (periodic directions:
+ * OPR_Poisson needs der1%mwn of x and z, opr_elliptic.f90:199-203), jac(n,3) (TIME_COURANT, time.f90:148), nodes(n). */
+int tlab_fdm_plan_set_aux(tlab_fdm_plan_t plan, const double *mwn1, const double *mwn2, const double *jac, const double *nodes);
 int tlab_fdm_plan_destroy(tlab_fdm_plan_t p);
 
 /* read back plan tables (HOST buffer, column-major like the reference) for parity tests. which:

@@ -359,6 +359,19 @@ int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, 
     });
 }
 
+// what else the Poisson solver and the monitors take from type(fdm_dt): modified wavenumbers (fdm_derivative.f90:193-211, periodic
+// directions; opr_elliptic.f90:199-203), Jacobian (fdm.f90:194-224; time.f90:148-152), node positions
+int tlab_fdm_plan_set_aux(tlab_fdm_plan_t p, const double *mwn1, const double *mwn2, const double *jac, const double *nodes) {
+    return guarded([&] {
+        if (!p) throw Invalid("tlab_fdm_plan_set_aux: null plan");
+        const int n = p->t.n;
+        if (mwn1) p->t.der1.mwn.assign(mwn1, mwn1 + n);
+        if (mwn2) p->t.der2.mwn.assign(mwn2, mwn2 + n);
+        if (jac) p->t.jac.assign(jac, jac + (size_t)3 * n);
+        if (nodes) p->t.nodes.assign(nodes, nodes + n);
+    });
+}
+
 int tlab_fdm_plan_destroy(tlab_fdm_plan_t p) {
     delete p;
     return TLAB_OK;

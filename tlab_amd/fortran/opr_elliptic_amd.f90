@@ -1,0 +1,79 @@
+!########################################################################
+! Drop-in replacement of the Poisson entry of module OPR_Elliptic (operators/opr_elliptic.f90): the procedure pointer OPR_Poisson with
+! the abstract interface of :33-46, bound to the device solver (OPR_Poisson_FourierXZ_Factorize, :263-364; BCS_NN).
+! OPR_Elliptic_Initialize(inifile) of the reference reads [Main] EllipticOrder and builds lambda / fdm_int1 (:86-250); here the plan is
+! built from the host plans g(1:3) the unchanged FDM_Initialize made (their coefficient tables and modified wavenumbers).
+! p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy must be device arrays (allocation hook, INTEGRATION.md section 3).
+!########################################################################
+#ifndef TLAB_AMD_ELLIPTIC_MODULE
+#define TLAB_AMD_ELLIPTIC_MODULE OPR_Elliptic
+#endif
+#ifndef TLAB_AMD_PARTIAL_MODULE
+#define TLAB_AMD_PARTIAL_MODULE OPR_Partial
+#endif
+module TLAB_AMD_ELLIPTIC_MODULE
+    use, intrinsic :: iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use FDM, only: fdm_dt
+    use TLab_AMD_C
+    use TLAB_AMD_PARTIAL_MODULE, only: OPR_Partial_AMD_Plan
+    implicit none
+    private
+
+    public :: OPR_Elliptic_Initialize_AMD       ! (g, nx, ny, nz): what OPR_Elliptic_Initialize takes from modules FDM / TLab_Memory
+    public :: OPR_Poisson
+
+    abstract interface
+        subroutine OPR_Poisson_interface(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)      ! opr_elliptic.f90:33-46
+            use TLab_Constants, only: wi, wp
+            integer(wi), intent(in) :: nx, ny, nz
+            integer, intent(in) :: ibc
+            real(wp), intent(inout) :: p(nx, ny, nz)
+            real(wp), intent(inout), target :: tmp1(2*ny, nz, nx/2 + 1)
+            real(wp), intent(inout), target :: tmp2(2*ny, nz, nx/2 + 1)
+            real(wp), intent(in) :: bcs_hb(nx, nz), bcs_ht(nx, nz)
+            real(wp), intent(out), optional :: dpdy(nx, ny, nz)
+        end subroutine
+    end interface
+    procedure(OPR_Poisson_interface), pointer :: OPR_Poisson => OPR_Poisson_AMD
+
+    type(c_ptr), save :: plan = c_null_ptr
+
+contains
+    subroutine OPR_Elliptic_Initialize_AMD(g, nx, ny, nz)
+        type(fdm_dt), intent(in) :: g(3)
+        integer(wi), intent(in) :: nx, ny, nz
+        integer(c_int) rc
+        rc = tlab_poisson_plan_create(plan, OPR_Partial_AMD_Plan(1, g(1)), OPR_Partial_AMD_Plan(2, g(2)), OPR_Partial_AMD_Plan(3, g(3)), &
+                                      int(nx, c_int), int(ny, c_int), int(nz, c_int))
+        call TLab_AMD_Check(rc, 'tlab_poisson_plan_create')
+        OPR_Poisson => OPR_Poisson_AMD
+    end subroutine OPR_Elliptic_Initialize_AMD
+
+    subroutine OPR_Poisson_AMD(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)      ! exactly the abstract interface
+        integer(wi), intent(in) :: nx, ny, nz
+        integer, intent(in) :: ibc
+        real(wp), intent(inout) :: p(nx, ny, nz)
+        real(wp), intent(inout), target :: tmp1(2*ny, nz, nx/2 + 1)
+        real(wp), intent(inout), target :: tmp2(2*ny, nz, nx/2 + 1)
+        real(wp), intent(in) :: bcs_hb(nx, nz), bcs_ht(nx, nz)
+        real(wp), intent(out), optional :: dpdy(nx, ny, nz)
+        call poisson_any(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)
+    end subroutine OPR_Poisson_AMD
+
+    subroutine poisson_any(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)           ! c_loc needs the TARGET attribute
+        integer(wi), intent(in) :: nx, ny, nz
+        integer, intent(in) :: ibc
+        real(wp), intent(inout), target :: p(*), tmp1(*), tmp2(*)
+        real(wp), intent(in), target :: bcs_hb(*), bcs_ht(*)
+        real(wp), intent(inout), target, optional :: dpdy(*)
+        type(c_ptr) :: pd
+        integer(c_int) rc
+        pd = c_null_ptr
+        if (present(dpdy)) pd = c_loc(dpdy)
+        rc = tlab_opr_poisson(plan, int(nx, c_int), int(ny, c_int), int(nz, c_int), int(ibc, c_int), c_loc(p), c_loc(tmp1), c_loc(tmp2), &
+                              c_loc(bcs_hb), c_loc(bcs_ht), pd)
+        call TLab_AMD_Check(rc, 'tlab_opr_poisson')          ! BCS_DD and the direct/Helmholtz variants return TLAB_EUNSUPPORTED
+    end subroutine poisson_any
+
+end module TLAB_AMD_ELLIPTIC_MODULE

@@ -40,8 +40,8 @@ contains
     ! ###################################################################
     function OPR_Partial_AMD_Plan(idir, g) result(p)
         integer, intent(in) :: idir
-        type(fdm_dt), intent(in) :: g
-        type(c_ptr) :: p
+        type(fdm_dt), intent(in), target :: g
+        type(c_ptr) :: p, pm1, pm2
         integer(c_int) rc
         if (.not. c_associated(plans(idir))) then
             rc = tlab_fdm_plan_create_from_arrays(plans(idir), int(g%size, c_int), merge(1_c_int, 0_c_int, g%periodic), &
@@ -49,6 +49,11 @@ contains
                                                   int(g%der1%nb_diag(1), c_int), int(g%der1%nb_diag(2), c_int), g%der1%lhs, g%der1%rhs, &
                                                   int(g%der2%nb_diag(1), c_int), int(g%der2%nb_diag(2), c_int), g%der2%lhs, g%der2%rhs)
             call TLab_AMD_Check(rc, 'tlab_fdm_plan_create_from_arrays')
+            pm1 = c_null_ptr; pm2 = c_null_ptr                    ! modified wavenumbers exist in periodic directions only
+            if (allocated(g%der1%mwn)) pm1 = c_loc(g%der1%mwn)
+            if (allocated(g%der2%mwn)) pm2 = c_loc(g%der2%mwn)
+            rc = tlab_fdm_plan_set_aux(plans(idir), pm1, pm2, c_loc(g%jac), c_null_ptr)
+            call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_aux')
         end if
         p = plans(idir)
     end function OPR_Partial_AMD_Plan

@@ -45,6 +45,10 @@ module TLab_AMD_C
             integer(c_int), value :: n, periodic, need_1der, ndl1, ndr1, ndl2, ndr2
             real(c_double), intent(in) :: lhs1(*), rhs1(*), lhs2(*), rhs2(*)
         end function
+        integer(c_int) function tlab_fdm_plan_set_aux(plan, mwn1, mwn2, jac, nodes) bind(C, name='tlab_fdm_plan_set_aux')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, mwn1, mwn2, jac, nodes
+        end function
         integer(c_int) function tlab_fdm_plan_destroy(plan) bind(C, name='tlab_fdm_plan_destroy')
             import :: c_int, c_ptr
             type(c_ptr), value :: plan
