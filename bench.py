@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="box size n^3 (BASELINE: 512), split into z-slabs over the GPUs")
+    ap.add_argument("--n", "--box", dest="n", type=int, default=512, help="box size n^3 (BASELINE: 512), split into z-slabs over the GPUs")
     ap.add_argument("--nscal", type=int, default=1)
     ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
                     "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
@@ -176,7 +176,7 @@ def main():
         dom = next((k for k in kernels if k["alg_bytes_per_launch"] > 1e6), None)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if collected (profiles/README.md)
-        if dom and os.path.exists(tpath):
+        if dom and os.path.exists(tpath) and world == 1 and args.loopback <= 1 and n == 512 and args.nscal == 1:      # measured for this workload only
             try:
                 traffic = json.load(open(tpath)).get(dom["kernel"])
             except Exception:
@@ -200,7 +200,7 @@ def main():
                                    % (n, args.nscal),
                        "grid": [n, n, n], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper", "reynolds": 5000,
                        "parallelism": ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode) executed back to back on one GPU, no communication" % (args.loopback, d.zmode)) if world == 1 else
-                       ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep), RCCL" % world if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
+                       ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep), %s" % (world, "RCCL" if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
                        "fields_finite": finite},
             "roofline": None if dom is None else {
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
