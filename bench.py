@@ -121,8 +121,7 @@ def main():
         def substep(k):
             s = k % d.rkm_endstep
             if s == 0:
-                for t in d.hq + d.hs:
-                    t.zero_()
+                d.begin_step()          # hq = hs = 0 of TIME_RUNGEKUTTA (time.f90:212-216): the first operator launch overwrites instead
             last = s == d.rkm_endstep - 1
             d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * d.kdt[s], 1.0 if last else d.kco[s], not last)
     else:

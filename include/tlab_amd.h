@@ -164,9 +164,10 @@ int tlab_opr_burgers_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int
 int tlab_opr_partial_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub, double scale,
                          double *result, int acc, double *tmp1, double *tmp2);
 /* nf (1..4) transported fields advected by the same velocity (the u-, v-, w- and scalar equations all call OPR_Burgers_X with u, etc.):
- * result[f] += nu[f] d2s[f]/dx2 - vel ds[f]/dx in one launch, the velocity being fetched from HBM once.  HOST arrays of DEVICE pointers. */
+ * result[f] += nu[f] d2s[f]/dx2 - vel ds[f]/dx in one launch, the velocity being fetched from HBM once.  HOST arrays of DEVICE pointers.
+ * overwrite != 0: result[f] = ... (the tendencies are zero at the start of a Runge-Kutta step, time.f90:212-216: no fill, no read). */
 int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
-                           const double *vel, double *const *result, double *tmp1, double *tmp2);
+                           const double *vel, double *const *result, double *tmp1, double *tmp2, int overwrite);
 
 /* ---- z-derivatives on a z-slab without transposes (multi-GPU) ---------------------------------------------
  * Replaces TLabMPI_Trp_ExecK_Forward + OPR_Partial_Z / OPR_Burgers_Z + TLabMPI_Trp_ExecK_Backward (opr_partial.f90:154-262,
@@ -198,6 +199,10 @@ int tlab_dns_destroy(tlab_dns_t d);
 /* on (default): the pointwise sums of the RHS are folded into the operator kernels (same summation order as the reference);
  * off: the reference's literal sequence of temporaries + pointwise loops.  Both give the same result to round-off. */
 int tlab_dns_set_fusion(tlab_dns_t d, int on);
+/* Start of a Runge-Kutta step: TIME_RUNGEKUTTA sets hq = 0, hs = 0 there (tools/dns/time.f90:212-216).  Instead of filling the arrays,
+ * tell the driver: the next tlab_rhs_global_incompressible_1 / tlab_time_substep_incompressible_explicit treats them as zero (its first
+ * operator launch overwrites instead of accumulating), whatever they contain. */
+int tlab_dns_begin_step(tlab_dns_t d);
 /* Wall boundary conditions in y: BcsFlowJmin%type(1:3), BcsFlowJmax%type(1:3), BcsScalJmin%type(1:nscal), BcsScalJmax%type(1:nscal)
  * (tools/dns/boundary_bcs.f90:24-27, read at :102-190).  Values as in the reference: DNS_BCS_DIRICHLET / DNS_BCS_NEUMANN.
  * Default at creation: all Dirichlet ('noslip'; the reference's 'freeslip' is {NEUMANN, DIRICHLET, NEUMANN} for (u,v,w)).

@@ -195,6 +195,36 @@ def test_other_scalar_counts(T, nscal):
         assert rel_err(d.s[i].cpu().numpy(), o.s[i]) <= 1e-12 and rel_err(d.hs[i].cpu().numpy(), o.hs[i]) <= 1e-11
 
 
+@pytest.mark.parametrize("fuse,nx", [(True, 256), (False, 256), (True, 48)])
+def test_full_rk_step_with_begin_step(T, fuse, nx):
+    """TIME_RUNGEKUTTA (time.f90:185-298): hq = hs = 0 at the start of the step is a flag here (tlab_dns_begin_step): the arrays may hold
+    anything (poisoned with NaN below) and the first operator launch overwrites them.  nx = 48 takes the unfused kernels (memset path)."""
+    import torch
+    from tlab_amd.dns import Dns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    ny, nz = 64, 32
+    x, y, z = grids(nx, ny, nz, True)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 23)
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False)
+    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False)
+    d.set_fusion(fuse)
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i])); o.q[i] = q0[i].copy()
+    d.s[0].copy_(torch.from_numpy(s0[0])); o.s[0] = s0[0].copy()
+    for t in d.hq + d.hs:
+        t.fill_(float("nan"))
+    dtime = 2e-3
+    d.TIME_RUNGEKUTTA(dtime)
+    for a in o.hq + o.hs:
+        a[:] = 0.0
+    for k in range(3):
+        last = k == 2
+        o.time_substep(dtime * d.kdt[k], 1.0 if last else d.kco[k], not last)
+    for i in range(3):
+        assert rel_err(d.q[i].cpu().numpy(), o.q[i]) <= 1e-12
+    assert rel_err(d.s[0].cpu().numpy(), o.s[0]) <= 1e-12
+
+
 def test_time_courant_and_dilatation_vs_oracle(T):
     """TIME_COURANT (time.f90:365) and the dilatation monitor (FI_INVARIANT_P + MINMAX, dns_local.f90:157-187)."""
     import torch

@@ -611,13 +611,13 @@ bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, i
 }
 // several transported fields, one advecting velocity: result[f] += nu[f] d2 s[f] - vel d s[f]
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
-                                 const double *vel, double *const *result) {
+                                 const double *vel, double *const *result, bool overwrite) {
     check_common(dir, g, nx, ny, nz, ibc);
     if (nf < 1 || nf > 4) throw Invalid("1 to 4 fields per call");
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
     OpExtra ex;
-    ex.acc = true;
+    ex.acc = !overwrite;        // overwrite: the tendency is known to be zero (start of a Runge-Kutta step): neither zero-filled nor read
     ex.nf = nf;
     for (int f = 0; f < nf; ++f) { ex.fs[f] = s[f]; ex.fo[f] = result[f]; ex.fnu[f] = nu[f]; }
     const bool corr = g->t.der2.need_1der;
@@ -663,14 +663,15 @@ int tlab_opr_burgers_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int
 }
 
 int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
-                           const double *vel, double *const *result, double *tmp1, double *tmp2) {
+                           const double *vel, double *const *result, double *tmp1, double *tmp2, int overwrite) {
     return guarded([&] {
         check_common(dir, g, nx, ny, nz, ibc);
         if (nf < 1 || nf > 4 || !nu || !s || !vel || !result) throw Invalid("tlab_opr_burgers_add_n: bad arguments (1 to 4 fields)");
         for (int f = 0; f < nf; ++f)
             if (!s[f] || !result[f] || result[f] == s[f] || result[f] == vel) throw Invalid("tlab_opr_burgers_add_n: null or aliased arrays");
-        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result)) return;
+        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result, overwrite != 0)) return;
         for (int f = 0; f < nf; ++f) {
+            if (overwrite) hip_check(hipMemsetAsync(result[f], 0, (size_t)nx * ny * nz * sizeof(double), g_stream), "memset");
             const int rc = tlab_opr_burgers_add(dir, g, nx, ny, nz, ibc, nu[f], s[f], vel, result[f], tmp1, tmp2);
             if (rc != TLAB_OK) throw Invalid(std::string("tlab_opr_burgers_add_n: ") + g_err);
         }

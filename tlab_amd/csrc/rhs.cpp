@@ -29,7 +29,7 @@ bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, in
                                   double kco, int scale);
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
-                                 const double *vel, double *const *result);
+                                 const double *vel, double *const *result, bool overwrite);
 
 struct tlab_dns {
     tlab_fdm_plan_t g[3];
@@ -39,6 +39,7 @@ struct tlab_dns {
     std::vector<double> schmidt;
     double *bcs_hb = nullptr, *bcs_ht = nullptr;   // BcsFlowJmin%ref(:,:,2), BcsFlowJmax%ref(:,:,2)
     bool fuse = true;                              // fold the pointwise sums into the operator kernels where the fast kernels apply
+    bool fresh = false;                            // one-shot: hq, hs count as zero on entry of the next substep (tlab_dns_begin_step)
     int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};   // BcsFlowJmin%type
     int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
     std::vector<int> scal_jmin, scal_jmax;         // BcsScalJmin%type, BcsScalJmax%type
@@ -152,13 +153,18 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // launch.  The terms of an equation are then added in the order x, y, z instead of the reference's {1,2,3},{2,1,3},{3,1,2}: rounding only.
     const bool batched = d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
                          tlab_internal_burgers_fusable(3, gz, nx, ny, nz);
+    const bool fresh = d->fresh;       // TIME_RUNGEKUTTA zeroes hq, hs at the start of a step (time.f90:212-216): the first launch overwrites instead
+    d->fresh = false;
+    if (fresh && !batched) {
+        for (size_t e = 0; e < eqs.size(); ++e) hk(hipMemsetAsync(eqs[e].dst, 0, (size_t)n * sizeof(double), st), "memset");
+    }
     if (batched) {
         for (int dir = 1; dir <= 3; ++dir)
             for (size_t e0 = 0; e0 < eqs.size(); e0 += 4) {
                 const int nf = (int)std::min<size_t>(4, eqs.size() - e0);
                 const double *sp[4]; double *rp[4]; double nup[4];
                 for (int f = 0; f < nf; ++f) { sp[f] = eqs[e0 + f].fld; rp[f] = eqs[e0 + f].dst; nup[f] = eqs[e0 + f].nu; }
-                if (!tlab_internal_burgers_acc_n(dir, d->g[dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[dir - 1], rp))
+                if (!tlab_internal_burgers_acc_n(dir, d->g[dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[dir - 1], rp, fresh && dir == 1))
                     throw Fail(TLAB_EINVAL, "internal: inconsistent fused Burgers path");
             }
     }
@@ -378,6 +384,12 @@ int tlab_minmax(tlab_dns_t d, const double *a, int nx, int ny, int nz, double *a
         tlab_set_error(f.what());
         return f.code;
     }
+}
+
+int tlab_dns_begin_step(tlab_dns_t d) {
+    if (!d) return TLAB_EINVAL;
+    d->fresh = true;
+    return TLAB_OK;
 }
 
 int tlab_dns_set_fusion(tlab_dns_t d, int on) {

@@ -157,10 +157,13 @@ class Dns:
         check(load().tlab_minmax(self._h, self.txc[0].data_ptr(), self.nx, self.ny, self.nz, ctypes.byref(mn), ctypes.byref(mx)), "tlab_minmax")
         return -mx.value, -mn.value
 
+    def begin_step(self):
+        """hq = hs = 0 of TIME_RUNGEKUTTA (time.f90:212-216) without touching the arrays: the next substep overwrites them."""
+        check(load().tlab_dns_begin_step(self._h), "tlab_dns_begin_step")
+
     def TIME_RUNGEKUTTA(self, dtime):
         """One time step: hq = hs = 0, then rkm_endstep substeps (time.f90:212-298)."""
-        for t in self.hq + self.hs:
-            t.zero_()
+        self.begin_step()
         for k in range(self.rkm_endstep):
             last = k == self.rkm_endstep - 1
             self.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * self.kdt[k], 1.0 if last else self.kco[k], not last)

@@ -56,12 +56,13 @@ SIGNATURES = {
     "tlab_dns_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, _dp]),
     "tlab_dns_destroy": (c_int, [c_vp]),
     "tlab_dns_set_fusion": (c_int, [c_vp, c_int]),
+    "tlab_dns_begin_step": (c_int, [c_vp]),
     "tlab_dns_set_slab": (c_int, [c_vp, c_int]),
     "tlab_time_courant": (c_int, [c_vp, ctypes.POINTER(c_vp), c_dbl, c_dbl, _dp, _dp]),
     "tlab_fi_invariant_p": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tlab_minmax": (c_int, [c_vp, c_vp, c_int, c_int, c_int, _dp, _dp]),
     "tlab_opr_burgers_add": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "tlab_opr_burgers_add_n": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, _dp, ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), c_vp, c_vp]),
+    "tlab_opr_burgers_add_n": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, _dp, ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, c_int]),
     "tlab_opr_partial_add": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_int, c_vp, c_vp]),
     "tlab_zslab_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_int, c_int, c_int]),
     "tlab_zslab_plan_destroy": (c_int, [c_vp]),

@@ -205,6 +205,7 @@ class SlabDns:
                   FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
         self.kdt, self.kco = rk_coefficients(rkm_mode)
         self.rkm_endstep = len(self.kdt)
+        self._fresh = False
         self.flow_jmin, self.flow_jmax = [DNS_BCS_DIRICHLET] * 3, [DNS_BCS_DIRICHLET] * 3
         self.scal_jmin, self.scal_jmax = [DNS_BCS_DIRICHLET] * self.nscal, [DNS_BCS_DIRICHLET] * self.nscal
         self.isize_txc = (self.nx + 2) * self.ny * self.kmax
@@ -455,7 +456,7 @@ class SlabDns:
         eqs = lambda S: [(S["q"][0], S["hq"][0], nu), (S["q"][1], S["hq"][1], nu), (S["q"][2], S["hq"][2], nu)] + \
             [(S["s"][i], S["hs"][i], self.visc / self.schmidt[i]) for i in range(ns)]            # noqa: E731
 
-        def badd_all(d, g, S):
+        def badd_all(d, g, S, overwrite=False):
             """hq, hs += Burgers_d of every transported field, four per launch (they share the advecting velocity q_d)."""
             E = eqs(S)
             for e0 in range(0, len(E), 4):
@@ -464,8 +465,8 @@ class SlabDns:
                 nus = (ctypes.c_double * nf)(*[float(kap) for _, _, kap in grp])
                 sp = (c_vp * nf)(*[f.data_ptr() for f, _, _ in grp])
                 rp = (c_vp * nf)(*[h.data_ptr() for _, h, _ in grp])
-                check(L.tlab_opr_burgers_add_n(d, g._h, nx, ny, kmax, 0, nf, nus, sp, _ptr(S["q"][d - 1]), rp, _ptr(T(S, 6)), _ptr(T(S, 7))),
-                      "tlab_opr_burgers_add_n")
+                check(L.tlab_opr_burgers_add_n(d, g._h, nx, ny, kmax, 0, nf, nus, sp, _ptr(S["q"][d - 1]), rp, _ptr(T(S, 6)), _ptr(T(S, 7)),
+                                               int(overwrite)), "tlab_opr_burgers_add_n")
 
         def padd(d, g, S, u, ub, scale, res, acc):
             check(L.tlab_opr_partial_add(d, g._h, nx, ny, kmax, 0, _ptr(u), _ptr(ub) if ub is not None else None, float(scale), _ptr(res), int(acc),
@@ -473,7 +474,8 @@ class SlabDns:
 
         # ---- diffusion + advection (:98-162) ----
         w = self._halo_start([("q", 0), ("q", 1), ("q", 2)] + [("s", i) for i in range(ns)])
-        self._local(lambda r, S: badd_all(1, gx, S))
+        fresh, self._fresh = self._fresh, False        # start of a Runge-Kutta step: hq = hs = 0 (time.f90:212-216) -> the x-terms overwrite
+        self._local(lambda r, S: badd_all(1, gx, S, fresh))
         w.wait()
         self._local(lambda r, S: [self._zburgers(1, S, 2 * i, kap, f, None, None) for i, (f, h, kap) in enumerate(eqs(S))])
         w = self._msg_start(2 * (3 + ns))
@@ -600,9 +602,12 @@ class SlabDns:
         """k-th substep of consecutive RK steps (zeroes the tendencies at the start of each step, time.f90:212-216)."""
         s = k % self.rkm_endstep
         if s == 0:
-            for r in self.comm.local_ranks:
-                for t in self.st[r]["hq"] + self.st[r]["hs"]:
-                    t.zero_()
+            if self.zmode == "halo":
+                self._fresh = True
+            else:
+                for r in self.comm.local_ranks:
+                    for t in self.st[r]["hq"] + self.st[r]["hs"]:
+                        t.zero_()
         last = s == self.rkm_endstep - 1
         self.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * self.kdt[s], 1.0 if last else self.kco[s], not last)
 
