@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--box", dest="n", type=int, default=512, help="box size n^3 (BASELINE: 512), split into z-slabs over the GPUs")
+    ap.add_argument("--grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"), help="non-cubic box (diagnostics; e.g. 1024 512 1024 = BASELINE configs[3])")
     ap.add_argument("--nscal", type=int, default=1)
     ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
                     "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
@@ -96,26 +97,28 @@ def main():
     from tlab_amd.lib import load
     T.init(local_rank)
     n = args.n
-    x = np.arange(n) / n
-    y = np.arange(n) / (n - 1.0)
+    nx, ny, nz = (args.grid if args.grid else (n, n, n))
+    x = np.arange(nx) / nx
+    y = np.arange(ny) / (ny - 1.0)
+    z = np.arange(nz) / nz
     dtime = 1e-3
     L = load()
     if world == 1 and args.loopback > 1:
         from tlab_amd.parallel import SlabDns, LoopbackComm
-        d = SlabDns(LoopbackComm(args.loopback), x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True,
+        d = SlabDns(LoopbackComm(args.loopback), x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True,
                     rkm_mode=RKM_EXP3)
         state_fields = []
         for r in range(args.loopback):
             S = d.st[r]
-            synthetic_fields(S["q"] + S["s"], n, n, n, r * d.kmax, d.kmax, r)
+            synthetic_fields(S["q"] + S["s"], nx, ny, nz, r * d.kmax, d.kmax, r)
             state_fields += S["q"] + S["s"]
 
         def substep(k):
             d.substep_of_cycle(k, dtime)
     elif world == 1:
         # one GPU owns the whole box: the C++ driver (tlab_amd/csrc/rhs.cpp) runs the substep
-        d = Dns(x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
-        synthetic_fields(d.q + d.s, n, n, n, 0, n, rank)
+        d = Dns(x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
+        synthetic_fields(d.q + d.s, nx, ny, nz, 0, nz, rank)
         state_fields = d.q + d.s
 
         def substep(k):
@@ -127,9 +130,9 @@ def main():
     else:
         # STRONG scaling of the same n^3 box: z-slabs (1 x N pencils), K-transposes by RCCL all-to-all (tlab_amd/parallel.py)
         from tlab_amd.parallel import SlabDns, DistComm
-        d = SlabDns(DistComm(), x, y, x.copy(), nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
+        d = SlabDns(DistComm(), x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3)
         S = d.st[rank]
-        synthetic_fields(S["q"] + S["s"], n, n, n, rank * d.kmax, d.kmax, rank)
+        synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
         state_fields = S["q"] + S["s"]
 
         def substep(k):
@@ -175,12 +178,12 @@ def main():
         dom = next((k for k in kernels if k["alg_bytes_per_launch"] > 1e6), None)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if collected (profiles/README.md)
-        if dom and os.path.exists(tpath) and world == 1 and args.loopback <= 1 and n == 512 and args.nscal == 1:      # measured for this workload only
+        if dom and os.path.exists(tpath) and world == 1 and args.loopback <= 1 and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:      # measured for this workload only
             try:
                 traffic = json.load(open(tpath)).get(dom["kernel"])
             except Exception:
                 traffic = None
-        npts = float(n) ** 3            # strong scaling: the same box on 1/2/4/8 GPUs (BASELINE.json metric)
+        npts = float(nx) * ny * nz      # strong scaling: the same box on 1/2/4/8 GPUs (BASELINE.json metric)
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "grid-point-updates/s per RK substep",
@@ -195,9 +198,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%d^3 incompressible box, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
-                                   % (n, args.nscal),
-                       "grid": [n, n, n], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper", "reynolds": 5000,
+            "config": {"workload": "%dx%dx%d incompressible box, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
+                                   % (nx, ny, nz, args.nscal),
+                       "grid": [nx, ny, nz], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper", "reynolds": 5000,
                        "parallelism": ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode) executed back to back on one GPU, no communication" % (args.loopback, d.zmode)) if world == 1 else
                        ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep), %s" % (world, "RCCL" if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
                        "fields_finite": finite},
@@ -205,7 +208,7 @@ def main():
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "launches": dom["calls"],
                 "share_of_step": dom["total_ms"] / (ms_per_step * args.steps)},
-            "substep_alg_GBps": (736.0 + 152.0 * args.nscal) * float(n) ** 3 / (ms_per_step * 1e-3) / 1e9,
+            "substep_alg_GBps": (736.0 + 152.0 * args.nscal) * npts / (ms_per_step * 1e-3) / 1e9,
             "kernels": [{k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in k.items()} for k in kernels],
         }
         if args.cpu_sample > 0:
