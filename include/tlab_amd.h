@@ -163,6 +163,11 @@ int tlab_opr_burgers_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int
                          double *result, double *tmp1, double *tmp2);
 int tlab_opr_partial_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub, double scale,
                          double *result, int acc, double *tmp1, double *tmp2);
+/* Last pass over a velocity component folded into the pressure gradient (Dirichlet walls): h -= dp/dx_dir; h = 0 on the wall planes
+ * j = 1, ny; q += dte h; h *= kco if scale (rhs_global_incompressible_1.f90:319-320, :348-352, :373-375; time.f90:645-664, :272-297).
+ * One kernel on a fast path (dir = 1, 3), otherwise OPR_Partial into tmp1 + the pointwise pass. */
+int tlab_opr_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
+                            double kco, int scale, double *tmp1);
 /* nf (1..4) transported fields advected by the same velocity (the u-, v-, w- and scalar equations all call OPR_Burgers_X with u, etc.):
  * result[f] += nu[f] d2s[f]/dx2 - vel ds[f]/dx in one launch, the velocity being fetched from HBM once.  HOST arrays of DEVICE pointers.
  * overwrite != 0: result[f] = ... (the tendencies are zero at the start of a Runge-Kutta step, time.f90:212-216: no fill, no read). */
@@ -188,6 +193,13 @@ int tlab_zslab_partial_z(tlab_zslab_plan_t plan, int phase, int nx, int ny, cons
                          double *head, double *tail, const double *tail_left, const double *head_right, double *result, int acc);
 int tlab_zslab_burgers_z(tlab_zslab_plan_t plan, int phase, int nx, int ny, double nu, const double *s, const double *vel,
                          double *head, double *tail, const double *tail_left, const double *head_right, double *result, int acc);
+/* nf (1..4) transported fields per launch; head, tail, tail_left, head_right: [nf][2][nx*ny] */
+int tlab_zslab_burgers_z_n(tlab_zslab_plan_t plan, int phase, int nx, int ny, int nf, const double *nu, const double *const *s,
+                           const double *vel, double *head, double *tail, const double *tail_left, const double *head_right,
+                           double *const *result, int acc);
+/* phase 2 of d/dz p with the final update of w as its epilogue (as tlab_opr_gradient_final; phase 1 = tlab_zslab_partial_z(plan, 1, ...)) */
+int tlab_zslab_gradient_final_z(tlab_zslab_plan_t plan, int nx, int ny, const double *p, const double *tail_left, const double *head_right,
+                                double *q, double *h, double dte, double kco, int scale);
 
 /* ---- RHS assembly and Runge-Kutta substep ("next" row n1 of SURVEY.md 8f) --------------------------------- */
 /* Module state the reference spreads over TLab_Memory / NavierStokes / OPR_Burgers / BOUNDARY_BCS: plans, sizes,

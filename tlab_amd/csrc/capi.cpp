@@ -678,6 +678,19 @@ int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, i
     });
 }
 
+int tlab_opr_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte, double kco,
+                            int scale, double *tmp1) {
+    return guarded([&] {
+        check_common(dir, g, nx, ny, nz, 0);
+        if (!p || !q || !h || q == h || p == q || p == h) throw Invalid("tlab_opr_gradient_final: null or aliased arrays");
+        if (tlab_internal_gradient_final(dir, g, nx, ny, nz, p, q, h, dte, kco, scale)) return;
+        if (!tmp1 || tmp1 == p || tmp1 == q || tmp1 == h) throw Invalid("tlab_opr_gradient_final: the unfused path needs tmp1");
+        const int rc = tlab_opr_partial(dir, g, TLAB_OPR_P1, nx, ny, nz, 0, p, tmp1, nullptr);
+        if (rc != TLAB_OK) throw Invalid(std::string("tlab_opr_gradient_final: ") + g_err);
+        hip_check(launch_final_update(q, h, tmp1, nullptr, nullptr, dte, kco, scale, nx, ny, nz, g_stream), "k_final_update");
+    });
+}
+
 int tlab_opr_partial_add(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub, double scale,
                          double *result, int acc, double *tmp1, double *tmp2) {
     return guarded([&] {

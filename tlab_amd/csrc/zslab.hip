@@ -63,8 +63,17 @@ struct ZSlabArgs {
     double c0_2, c2_2, c3_2;        // second-derivative stencil f = c0 u + (u+1 + u-1) + c2 (u+2 + u-2) + c3 (u+3 + u-3)
     ZSysDev y1, y2;
     double nu;
-    double *head, *tail;                    // phase A out: [nsys][nlines]
+    double *head, *tail;                    // phase A out: [nsys][nlines]   (Burgers with nf fields: [nf][2][nlines])
     const double *tail_left, *head_right;   // phase B in:  [nsys][nlines]
+    // Burgers: nf transported fields share the advecting velocity (one launch; the workgroups of a tile sit on one XCD, see k_htile)
+    int nf;
+    const double *fs[4];
+    double *fo[4];
+    double fnu[4];
+    // MODE_P1 phase B "final update" epilogue (fq != NULL), as in k_xline / k_rtile: out0 = tendency h, hv = h - d/dz, walls, q += dte hv
+    double *fq;
+    double fdte, fkco;
+    int fscale, fnx, fny;
 };
 
 // local solve of the slab system (sub-chunks through LDS), then phase handling. f: RHS in, y (phase A) / x (phase B) out
@@ -133,16 +142,28 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: coefficient rows become scalar loads
     const int C = blockDim.x >> 6;
-    const long long line = (long long)blockIdx.x * 64 + lane;
+    long long tile = blockIdx.x;
+    int fi = 0;
+    if (MODE == MODE_BURGERS) {           // bid = x + 8 (f + nf y), tile = x + 8 y
+        const long long q = blockIdx.x >> 3;
+        fi = (int)(q % a.nf);
+        tile = (blockIdx.x & 7) + 8 * (q / a.nf);
+        if (tile * 64 >= a.nlines) return;          // whole workgroup, before any barrier
+    }
+    const long long line = tile * 64 + lane;
     const bool valid = line < a.nlines;
     const long long rs = a.nlines;
     const int row0 = w * M;
     const long long base = valid ? line : 0;
+    const double *__restrict__ in0 = (MODE == MODE_BURGERS) ? a.fs[fi] : a.in0;
+    double *__restrict__ out0 = (MODE == MODE_BURGERS) ? a.fo[fi] : a.out0;
+    const double nu = (MODE == MODE_BURGERS) ? a.fnu[fi] : a.nu;
+    const int msg0 = (MODE == MODE_BURGERS) ? 2 * fi : 0;       // first message row of this field
 
     // operand rows + 3-row halos; no wrap: the rows before / after the slab are the neighbours' planes
     double e[M + 6];
 #pragma unroll
-    for (int p = 0; p < M + 6; ++p) e[p] = valid ? a.in0[base + (long long)(row0 - 3 + p) * rs] : 0.0;
+    for (int p = 0; p < M + 6; ++p) e[p] = valid ? in0[base + (long long)(row0 - 3 + p) * rs] : 0.0;
     if (MODE == MODE_P1 && a.in0b != nullptr) {
         double eb[M + 6];
 #pragma unroll
@@ -158,28 +179,53 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
         for (int p = 0; p < M; ++p)
             x2[p] = a.c0_2 * e[p + 3] + e[p + 4] + e[p + 2] + a.c2_2 * (e[p + 5] + e[p + 1]) + a.c3_2 * (e[p + 6] + e[p]);
     }
-    z_solve<M, PHASE>(x1, a.y1, a.kmax, w, C, lane, valid, line, a.nlines, 0, a, s_yl, s_r, s_x);
+    z_solve<M, PHASE>(x1, a.y1, a.kmax, w, C, lane, valid, line, a.nlines, msg0, a, s_yl, s_r, s_x);
     double vl[(MODE == MODE_BURGERS && PHASE == 2) ? M : 1];
     if constexpr (MODE == MODE_BURGERS && PHASE == 2) {   // issued before the second solve: its latency hides behind it
 #pragma unroll
         for (int p = 0; p < M; ++p) vl[p] = valid ? a.vel[base + (long long)(row0 + p) * rs] : 0.0;
     }
-    if constexpr (MODE == MODE_BURGERS) z_solve<M, PHASE>(x2, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, 1, a, s_yl, s_r, s_x);
+    if constexpr (MODE == MODE_BURGERS) z_solve<M, PHASE>(x2, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, msg0 + 1, a, s_yl, s_r, s_x);
     if constexpr (PHASE == 2) {
         if (!valid) return;
         if constexpr (MODE == MODE_BURGERS) {
 #pragma unroll
-            for (int p = 0; p < M; ++p) x1[p] = a.nu * x2[p] - vl[p] * x1[p];     // opr_burgers.f90:513
+            for (int p = 0; p < M; ++p) x1[p] = nu * x2[p] - vl[p] * x1[p];     // opr_burgers.f90:513
+        }
+        if (MODE == MODE_P1 && a.fq != nullptr) {      // final-update epilogue (lane = (ix, j) in the plane, rows = k)
+            const int j = (int)((line / a.fnx) % a.fny);
+            const bool wall = (j == 0) || (j == a.fny - 1);
+#pragma unroll
+            for (int p0 = 0; p0 < M; p0 += 8) {
+                double h[8], qv[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    h[p] = out0[base + (long long)(row0 + p0 + p) * rs];
+                    qv[p] = a.fq[base + (long long)(row0 + p0 + p) * rs];
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const double hv = wall ? 0.0 : h[p] - x1[p0 + p];
+                    qv[p] = qv[p] + a.fdte * hv;
+                    h[p] = a.fscale ? a.fkco * hv : hv;
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    a.fq[base + (long long)(row0 + p0 + p) * rs] = qv[p];
+                    out0[base + (long long)(row0 + p0 + p) * rs] = h[p];
+                }
+            }
+            return;
         }
         if (a.acc) {
             double o[M];
 #pragma unroll
-            for (int p = 0; p < M; ++p) o[p] = a.out0[base + (long long)(row0 + p) * rs];
+            for (int p = 0; p < M; ++p) o[p] = out0[base + (long long)(row0 + p) * rs];
 #pragma unroll
             for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
         }
 #pragma unroll
-        for (int p = 0; p < M; ++p) a.out0[base + (long long)(row0 + p) * rs] = x1[p];
+        for (int p = 0; p < M; ++p) out0[base + (long long)(row0 + p) * rs] = x1[p];
     }
 }
 
@@ -282,7 +328,9 @@ int guard(F &&f) {
 
 template <int M, int MODE>
 void launch_m(int phase, int C, const ZSlabArgs &a, hipStream_t st) {
-    const dim3 grid((unsigned)((a.nlines + 63) / 64)), block(64 * C);
+    const long long tiles = (a.nlines + 63) / 64;
+    const long long nwg = (MODE == MODE_BURGERS) ? 8LL * a.nf * ((tiles + 7) / 8) : tiles;
+    const dim3 grid((unsigned)nwg), block(64 * C);
     if (phase == 1) hipLaunchKernelGGL((k_zslab<M, MODE, 1>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_zslab<M, MODE, 2>), grid, block, 0, st, a);
 }
@@ -291,7 +339,12 @@ void launch(const tlab_zslab_plan &P, int mode, int phase, const ZSlabArgs &a, h
     const double pts = (double)a.nlines * a.kmax;
     const char *name = mode == MODE_P1 ? (phase == 1 ? "k_zslab<P1,A>" : "k_zslab<P1,B>") : (phase == 1 ? "k_zslab<BURGERS,A>" : "k_zslab<BURGERS,B>");
     double bpp = 8.0 * ((a.in0b && mode == MODE_P1) ? 2 : 1);
-    if (phase == 2) bpp += 8.0 + (mode == MODE_BURGERS ? 8.0 : 0.0) + (a.acc ? 8.0 : 0.0);
+    if (phase == 2) bpp += 8.0 + (a.acc ? 8.0 : 0.0) + (a.fq ? 24.0 : 0.0);
+    if (mode == MODE_BURGERS) {        // per field: operand (+ result, old result in phase B); the velocity once in phase B
+        bpp = 0.0;
+        for (int f = 0; f < a.nf; ++f) bpp += 8.0 + (phase == 2 ? 8.0 + (a.acc ? 8.0 : 0.0) : 0.0);
+        if (phase == 2) bpp += 8.0;
+    }
     ProfScope ps(name, st, pts * bpp);
     if (P.M == 32) {
         if (mode == MODE_P1) launch_m<32, MODE_P1>(phase, P.C, a, st);
@@ -311,6 +364,7 @@ ZSlabArgs base_args(const tlab_zslab_plan &P, int nx, int ny) {
     a.c2_1 = P.c2_1; a.c0_2 = P.c0_2; a.c2_2 = P.c2_2; a.c3_2 = P.c3_2;
     a.y1 = P.sys[0].dev();
     a.y2 = P.sys[1].dev();
+    a.nf = 1;
     return a;
 }
 
@@ -369,6 +423,7 @@ int tlab_zslab_burgers_z(tlab_zslab_plan_t P, int phase, int nx, int ny, double 
         if (!P || !s || nx < 1 || ny < 1 || (phase != 1 && phase != 2)) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z: bad arguments");
         ZSlabArgs a = base_args(*P, nx, ny);
         a.in0 = s; a.nu = nu;
+        a.nf = 1; a.fs[0] = s; a.fo[0] = result; a.fnu[0] = nu;
         if (phase == 1) {
             if (!head || !tail) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z: phase A needs head and tail");
             a.head = head; a.tail = tail;
@@ -377,6 +432,43 @@ int tlab_zslab_burgers_z(tlab_zslab_plan_t P, int phase, int nx, int ny, double 
             a.vel = vel; a.tail_left = tail_left; a.head_right = head_right; a.out0 = result; a.acc = acc;
         }
         launch(*P, MODE_BURGERS, phase, a, tlab_current_stream());
+    });
+}
+
+int tlab_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s, const double *vel,
+                           double *head, double *tail, const double *tail_left, const double *head_right, double *const *result, int acc) {
+    return guard([&] {
+        if (!P || !s || !nu || nf < 1 || nf > 4 || nx < 1 || ny < 1 || (phase != 1 && phase != 2)) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: bad arguments");
+        ZSlabArgs a = base_args(*P, nx, ny);
+        a.nf = nf;
+        for (int f = 0; f < nf; ++f) {
+            if (!s[f]) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: null operand");
+            a.fs[f] = s[f]; a.fnu[f] = nu[f]; a.fo[f] = nullptr;
+        }
+        if (phase == 1) {
+            if (!head || !tail) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: phase A needs head and tail");
+            a.head = head; a.tail = tail;
+        } else {
+            if (!tail_left || !head_right || !result || !vel) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: phase B arguments");
+            for (int f = 0; f < nf; ++f) {
+                if (!result[f] || result[f] == s[f] || result[f] == vel) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: null or aliased result");
+                a.fo[f] = result[f];
+            }
+            a.vel = vel; a.tail_left = tail_left; a.head_right = head_right; a.acc = acc;
+        }
+        launch(*P, MODE_BURGERS, phase, a, tlab_current_stream());
+    });
+}
+
+// phase 2 of d/dz p with the final update of w as its epilogue: h -= dp/dz; wall planes (Dirichlet); q += dte h; h *= kco
+int tlab_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *tail_left, const double *head_right, double *q,
+                                double *h, double dte, double kco, int scale) {
+    return guard([&] {
+        if (!P || !p || !tail_left || !head_right || !q || !h || q == h) throw Fail(TLAB_EINVAL, "tlab_zslab_gradient_final_z: bad arguments");
+        ZSlabArgs a = base_args(*P, nx, ny);
+        a.in0 = p; a.tail_left = tail_left; a.head_right = head_right; a.out0 = h;
+        a.fq = q; a.fdte = dte; a.fkco = kco; a.fscale = scale; a.fnx = nx; a.fny = ny;
+        launch(*P, MODE_P1, 2, a, tlab_current_stream());
     });
 }
 

@@ -64,6 +64,9 @@ SIGNATURES = {
     "tlab_opr_burgers_add": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tlab_opr_burgers_add_n": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, _dp, ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, c_int]),
     "tlab_opr_partial_add": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_int, c_vp, c_vp]),
+    "tlab_opr_gradient_final": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_vp]),
+    "tlab_zslab_burgers_z_n": (c_int, [c_vp, c_int, c_int, c_int, c_int, _dp, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), c_int]),
+    "tlab_zslab_gradient_final_z": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int]),
     "tlab_zslab_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_int, c_int, c_int]),
     "tlab_zslab_plan_destroy": (c_int, [c_vp]),
     "tlab_zslab_partial_z": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),

@@ -477,11 +477,24 @@ class SlabDns:
         fresh, self._fresh = self._fresh, False        # start of a Runge-Kutta step: hq = hs = 0 (time.f90:212-216) -> the x-terms overwrite
         self._local(lambda r, S: badd_all(1, gx, S, fresh))
         w.wait()
-        self._local(lambda r, S: [self._zburgers(1, S, 2 * i, kap, f, None, None) for i, (f, h, kap) in enumerate(eqs(S))])
+        def zburgers_all(phase, S):
+            E = eqs(S)
+            for e0 in range(0, len(E), 4):
+                grp = E[e0:e0 + 4]
+                nf = len(grp)
+                nus = (ctypes.c_double * nf)(*[float(kap) for _, _, kap in grp])
+                sp = (c_vp * nf)(*[f.data_ptr() for f, _, _ in grp])
+                rp = (c_vp * nf)(*[h.data_ptr() for _, h, _ in grp])
+                o = 2 * e0 * self.npage * 8
+                P = lambda t: c_vp(t.data_ptr() + o)                 # noqa: E731
+                check(L.tlab_zslab_burgers_z_n(S["zplan"], phase, nx, ny, nf, nus, sp, _ptr(S["q"][2]) if phase == 2 else None,
+                                               P(S["head"]), P(S["tail"]), P(S["tail_left"]), P(S["head_right"]), rp if phase == 2 else None, 1),
+                      "tlab_zslab_burgers_z_n")
+        self._local(lambda r, S: zburgers_all(1, S))
         w = self._msg_start(2 * (3 + ns))
         self._local(lambda r, S: badd_all(2, gy, S))
         w.wait()
-        self._local(lambda r, S: [self._zburgers(2, S, 2 * i, kap, f, S["q"][2], h) for i, (f, h, kap) in enumerate(eqs(S))])
+        self._local(lambda r, S: zburgers_all(2, S))
         # ---- pressure forcing: div(hq + q/dte) (:188-260) ----
         idte = 1.0 / dte
         w = self._halo_start([("hq", 2)])                                   # w's halo planes are still valid
@@ -495,20 +508,32 @@ class SlabDns:
         self._local(lambda r, S: self._zpartial(2, S, S["hq"][2], S["q"][2], idte, T(S, 0), 1))
         # ---- pressure (:284) and its gradient (:319-320) ----
         self._poisson_pencil()
+        types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
+        grad_final = tail is not None and all(t == DNS_BCS_DIRICHLET for pair in types[:3] for t in pair)
         w = self._halo_start([("txc", 0)])
-        self._local(lambda r, S: padd(1, gx, S, T(S, 0), None, 0.0, T(S, 1), 0))
+        if grad_final:   # u and w are finished by the gradient kernels themselves (no gradient array)
+            self._local(lambda r, S: check(L.tlab_opr_gradient_final(1, gx._h, nx, ny, kmax, _ptr(T(S, 0)), _ptr(S["q"][0]), _ptr(S["hq"][0]), float(tail[0]),
+                                                                     float(tail[1]), int(tail[2]), _ptr(T(S, 1))), "tlab_opr_gradient_final"))
+        else:
+            self._local(lambda r, S: padd(1, gx, S, T(S, 0), None, 0.0, T(S, 1), 0))
         w.wait()
         self._local(lambda r, S: self._zpartial(1, S, T(S, 0), None, 0.0, None, 0))
         w = self._msg_start(1)
         w.wait()
-        self._local(lambda r, S: self._zpartial(2, S, T(S, 0), None, 0.0, T(S, 3), 0))
+        if grad_final:
+            self._local(lambda r, S: check(L.tlab_zslab_gradient_final_z(S["zplan"], nx, ny, _ptr(T(S, 0)), _ptr(S["tail_left"]), _ptr(S["head_right"]),
+                                                                         _ptr(S["q"][2]), _ptr(S["hq"][2]), float(tail[0]), float(tail[1]), int(tail[2])),
+                                           "tlab_zslab_gradient_final_z"))
+        else:
+            self._local(lambda r, S: self._zpartial(2, S, T(S, 0), None, 0.0, T(S, 3), 0))
         # ---- hq -= grad p, boundary conditions (:348-398) [+ RK update] ----
-        types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
-
         def finish(r, S):
             grads = [T(S, 1), T(S, 2), T(S, 3)] + [None] * ns
             fields = list(zip(S["q"] + S["s"], S["hq"] + S["hs"], grads, types))
-            if any(tmin == DNS_BCS_NEUMANN or tmax == DNS_BCS_NEUMANN for _, _, _, (tmin, tmax) in fields[:3]) or tail is None:
+            if grad_final:
+                fields = [fields[1]] + fields[3:]          # v and the scalars; u, w are done
+            neumann_vel = any(t == DNS_BCS_NEUMANN for pair in types[:3] for t in pair)
+            if not grad_final and (neumann_vel or tail is None):
                 check(L.tlab_pw_sub3(_ptr(S["hq"][0]), _ptr(S["hq"][1]), _ptr(S["hq"][2]), _ptr(T(S, 1)), _ptr(T(S, 2)), _ptr(T(S, 3)), n), "sub3")
                 fields = [(q, h, None, t) for q, h, _, t in fields]
             for q, h, g, (tmin, tmax) in fields:
