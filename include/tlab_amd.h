@@ -150,6 +150,10 @@ int tlab_poisson_plan_create_slab(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, 
  *   set_wall_planes, fft_x(+1), [slab->pencil], fft_z(+1), ode, fft_z(-1), [pencil->slab], fft_x(-1).  */
 int tlab_poisson_plan_create_pencil(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                                     int nx, int ny, int kmax, int nz_total, int ioffset, int nxl);
+/* Repacking around the slab <-> pencil all-to-all: slab = complex (nxh, ny, kmax); buffer = for every peer p the block [kmax][ny][nxl_p] of
+ * its kx range [ioff[p], ioff[p+1]) (ioff[nproc] = nxh implied), blocks back to back.  dir = +1 slab -> buffer, -1 buffer -> slab.  nproc <= 8.
+ * (The pencil side needs no repacking: z is its slowest index.)  Bit-exact index work. */
+int tlab_pencil_repack(double *slab, double *buffer, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir);
 int tlab_poisson_set_wall_planes(tlab_poisson_plan_t plan, double *p, const double *bcs_hb, const double *bcs_ht);
 int tlab_poisson_fft_x(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* OPR_Fourier_X_Forward/Backward, opr_fourier.f90:219,277 */
 int tlab_poisson_fft_z(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* the FFT inside OPR_Fourier_Z_*, :355,422 */

@@ -163,6 +163,25 @@ __global__ void __launch_bounds__(256) k_axpy1(double *__restrict__ o, const dou
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = a[i] + b[i] * s;
 }
 
+// ---- z-slab <-> kx-pencil repacking around the all-to-all of the Poisson solver (tlab_amd/parallel.py) ----------------------
+// slab a(nxh, ny, kmax) complex, x fastest; buffer = for every peer p the block [kmax][ny][nxl_p] of its kx range [ioff_p, ioff_p + nxl_p),
+// blocks one after the other.  dir = +1: a -> buffer (before sending), dir = -1: buffer -> a (after receiving).  Pure index work.
+struct PencilMap { int nproc; int ioff[9]; long long base[9]; };      // base[p] = first complex element of block p (base[nproc] = total)
+__global__ void __launch_bounds__(256) k_pencil_repack(double2 *__restrict__ a, double2 *__restrict__ buf, PencilMap m, int nxh, int ny, int kmax,
+                                                       int dir) {
+    const long long n = (long long)nxh * ny * kmax, stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int i = (int)(e % nxh);
+        const long long jk = e / nxh;                 // j + ny * k
+        int p = 0;
+        while (p + 1 < m.nproc && i >= m.ioff[p + 1]) ++p;
+        const int nxl = (p + 1 < m.nproc ? m.ioff[p + 1] : nxh) - m.ioff[p];
+        const long long b = m.base[p] + jk * nxl + (i - m.ioff[p]);
+        if (dir > 0) buf[b] = a[e];
+        else a[e] = buf[b];
+    }
+}
+
 // ---- reductions (TIME_COURANT tools/dns/time.f90:365-548, MINMAX utils/minmax.f90:6) -----------------------------------------
 // per-block partial (min, max) of a[i] (mode 0) or of |u|/dx(i) + |v|/dy(j) + |w|/dz(k) (mode 1); part: [2][gridDim.x]
 __global__ void __launch_bounds__(256) k_minmax_partial(const double *__restrict__ a, const double *__restrict__ v, const double *__restrict__ w,
@@ -204,6 +223,23 @@ __global__ void __launch_bounds__(256) k_negate(double *__restrict__ a, long lon
 hipError_t launch_minmax_partial(const double *a, const double *v, const double *w, const double *odx, const double *ody, const double *odz,
                                  int mode, int nx, int ny, int nz, int koff, double *part, int nblocks, hipStream_t st) {
     hipLaunchKernelGGL(k_minmax_partial, dim3(nblocks), dim3(256), 0, st, a, v, w, odx, ody, odz, mode, nx, ny, nz, koff, part);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir, hipStream_t st) {
+    if (nproc < 1 || nproc > 8) return hipErrorInvalidValue;
+    PencilMap m;
+    m.nproc = nproc;
+    long long acc = 0;
+    for (int p = 0; p < nproc; ++p) {
+        m.ioff[p] = ioff[p];
+        m.base[p] = acc;
+        acc += (long long)((p + 1 < nproc ? ioff[p + 1] : nxh) - ioff[p]) * ny * kmax;
+    }
+    m.ioff[nproc] = nxh; m.base[nproc] = acc;
+    const long long n = (long long)nxh * ny * kmax;
+    ProfScope ps("k_pencil_repack", st, (double)n * 32.0);
+    hipLaunchKernelGGL(k_pencil_repack, dim3(pw_grid(n)), dim3(256), 0, st, reinterpret_cast<double2 *>(a), reinterpret_cast<double2 *>(buf), m, nxh, ny,
+                       kmax, dir);
     return CHECK_LAUNCH();
 }
 hipError_t launch_negate(double *a, long long n, hipStream_t st) {

@@ -416,6 +416,10 @@ int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const doub
 int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n) { PW_GUARD(launch_rk_update(q, h, dte, kco, scale, n, tlab_current_stream())) }
 int tlab_pw_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale, int nx, int ny,
                          int nz) { PW_GUARD(launch_final_update(q, h, g, pb, pt, dte, kco, scale, nx, ny, nz, tlab_current_stream())) }
+int tlab_pencil_repack(double *slab, double *buffer, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir) {
+    if (!slab || !buffer || !ioff || nproc < 1 || nproc > 8 || nxh < nproc) { tlab_set_error("tlab_pencil_repack: bad arguments (1..8 peers)"); return TLAB_EINVAL; }
+    PW_GUARD(launch_pencil_repack(slab, buffer, nxh, ny, kmax, nproc, ioff, dir, tlab_current_stream()))
+}
 int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz) { PW_GUARD(launch_get_wall_planes(f, hb, ht, nx, ny, nz, tlab_current_stream())) }
 int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz) { PW_GUARD(launch_fill_wall_planes(f, vb, vt, nx, ny, nz, tlab_current_stream())) }
 int tlab_pw_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz) { PW_GUARD(launch_set_wall_planes(f, pb, pt, nx, ny, nz, tlab_current_stream())) }

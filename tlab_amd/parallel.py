@@ -233,6 +233,7 @@ class SlabDns:
         base, rem = divmod(self.nxh, P)
         self.nxl = [base + (1 if r < rem else 0) for r in range(P)]
         self.ioff = [r * base + min(r, rem) for r in range(P)]
+        self._ioff_c = (ctypes.c_int * P)(*self.ioff)
         if self.zmode == "halo" and min(self.nxl) < 1:
             raise TlabError("fewer kx modes than ranks")
         Hn = self.HALO * self.npage
@@ -382,13 +383,17 @@ class SlabDns:
         send, scnt, recv, rcnt = {}, {}, {}, {}
         for r in c.local_ranks:
             S = self.st[r]
-            a = S["txc"][src_idx][:2 * self.nxh * self.ny * self.kmax].view(self.kmax, self.ny, self.nxh, 2)
-            buf, off, cnts = S["pack"][0], 0, []
-            for p in range(P):
-                m = 2 * self.nxl[p] * self.ny * self.kmax
-                buf[off:off + m].view(self.kmax, self.ny, self.nxl[p], 2).copy_(a[:, :, self.ioff[p]:self.ioff[p] + self.nxl[p], :])
-                cnts.append(m)
-                off += m
+            buf = S["pack"][0]
+            if P <= 8:      # one HIP kernel
+                check(load().tlab_pencil_repack(_ptr(S["txc"][src_idx]), _ptr(buf), self.nxh, self.ny, self.kmax, P, self._ioff_c, 1), "tlab_pencil_repack")
+            else:           # torch strided copies
+                a = S["txc"][src_idx][:2 * self.nxh * self.ny * self.kmax].view(self.kmax, self.ny, self.nxh, 2)
+                off = 0
+                for p in range(P):
+                    m = 2 * self.nxl[p] * self.ny * self.kmax
+                    buf[off:off + m].view(self.kmax, self.ny, self.nxl[p], 2).copy_(a[:, :, self.ioff[p]:self.ioff[p] + self.nxl[p], :])
+                    off += m
+            cnts = [2 * self.nxl[p] * self.ny * self.kmax for p in range(P)]
             send[r], scnt[r] = buf, cnts
             recv[r], rcnt[r] = S["pen"][0], [2 * self.nxl[r] * self.ny * self.kmax] * P
         return c.all_to_all_v(send, scnt, recv, rcnt)
@@ -406,8 +411,12 @@ class SlabDns:
         P = self.comm.size
         for r in self.comm.local_ranks:
             S = self.st[r]
+            buf = S["pack"][pack_idx]
+            if P <= 8:
+                check(load().tlab_pencil_repack(_ptr(S["txc"][dst_idx]), _ptr(buf), self.nxh, self.ny, self.kmax, P, self._ioff_c, -1), "tlab_pencil_repack")
+                continue
             a = S["txc"][dst_idx][:2 * self.nxh * self.ny * self.kmax].view(self.kmax, self.ny, self.nxh, 2)
-            buf, off = S["pack"][pack_idx], 0
+            off = 0
             for p in range(P):
                 m = 2 * self.nxl[p] * self.ny * self.kmax
                 a[:, :, self.ioff[p]:self.ioff[p] + self.nxl[p], :].copy_(buf[off:off + m].view(self.kmax, self.ny, self.nxl[p], 2))
