@@ -98,13 +98,17 @@ int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tla
             const int m = gg[ig]->t.n;
             std::vector<double> o1(m);
             o2[ig].resize(m);
-            for (int i = 0; i < m; ++i) { o1[i] = 1.0 / gg[ig]->t.jac[i]; o2[ig][i] = o1[i] * o1[i]; }
+            const bool have_jac = (int)gg[ig]->t.jac.size() >= m;      // host-built plans carry it only after tlab_fdm_plan_set_aux
+            if (!have_jac) d->dx2i = -1.0;
+            for (int i = 0; i < m; ++i) { o1[i] = have_jac ? 1.0 / gg[ig]->t.jac[i] : 0.0; o2[ig][i] = o1[i] * o1[i]; }
             hk(hipMalloc((void **)&d->od[ig], (size_t)m * sizeof(double)), "hipMalloc");
             hk(hipMemcpy(d->od[ig], o1.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
         }
-        d->dx2i = 0.0;      // separable maximum of the sum = sum of the maxima over the directions with more than one point
-        for (int ig = 0; ig < 3; ++ig)
-            if (gg[ig]->t.n > 1) d->dx2i += *std::max_element(o2[ig].begin(), o2[ig].end());
+        if (d->dx2i >= 0.0) {   // separable maximum of the sum = sum of the maxima over the directions with more than one point
+            d->dx2i = 0.0;
+            for (int ig = 0; ig < 3; ++ig)
+                if (gg[ig]->t.n > 1) d->dx2i += *std::max_element(o2[ig].begin(), o2[ig].end());
+        }
         hk(hipMalloc((void **)&d->part, (size_t)2 * 1024 * sizeof(double)), "hipMalloc");
         *out = d.release();
         return TLAB_OK;
@@ -338,6 +342,7 @@ int tlab_dns_set_slab(tlab_dns_t d, int koffset) {
 int tlab_time_courant(tlab_dns_t d, double *const *q, double cfla, double cfld, double *pmax, double *dtime) {
     try {
         if (!d || !q || !pmax) throw Fail(TLAB_EINVAL, "tlab_time_courant: bad arguments");
+        if (d->dx2i < 0.0) throw Fail(TLAB_EINVAL, "tlab_time_courant: the plans carry no Jacobian (tlab_fdm_plan_set_aux)");
         double mn, mx;
         minmax_impl(d, q[0], q[1], q[2], 1, d->nx, d->ny, d->nz, &mn, &mx);
         pmax[0] = mx;                                   // max of |u|/dx + |v|/dy + |w|/dz over the local box (time.f90:402-451)
