@@ -1424,6 +1424,14 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         if (!gx->t.periodic || (nzt > 1 && !gz->t.periodic) || gy->t.periodic)
             throw std::invalid_argument("OPR_Poisson_FourierXZ needs periodic x, z and non-periodic y");
         if (nx % 2 != 0) throw std::invalid_argument("Imax must be a multiple of 2 for the FFT operations (opr_fourier.f90:72-75)");
+        {   // host-built plans (tlab_fdm_plan_create_from_arrays) carry the modified wavenumbers only after tlab_fdm_plan_set_aux
+            auto no_mwn = [](const tlab::DerTables &d) {
+                for (double v : d.mwn) if (v != 0.0) return false;
+                return true;
+            };
+            if (no_mwn(gx->t.der1) || (nzt > 1 && no_mwn(gz->t.der1)))
+                throw std::invalid_argument("the x / z plans carry no modified wavenumbers (der1%mwn): call tlab_fdm_plan_set_aux");
+        }
         if (nproc < 1 || nz * nproc != nzt || koff < 0 || koff + nz > nzt) throw std::invalid_argument("bad z-slab decomposition");
         if (((long long)(nx / 2 + 1) * ny) % nproc != 0) throw std::invalid_argument("(imax/2+1)*jmax must be divisible by the number of z slabs (tlab_mpi_transpose.f90:292)");
         auto P = std::make_unique<tlab_poisson_plan>();
