@@ -69,3 +69,103 @@ def test_k_transposes_two_processes_gloo(width):
         p.join(timeout=60)
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] and r[2] for r in res), res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# primitives of the transpose-free algorithm: ring exchange with the two neighbours, uneven all-to-all of the kx-pencils
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _ring_payload(P):
+    """Per rank: two tensors for the left and two for the right neighbour, values encode (sender, direction, index)."""
+    tl = {r: [torch.full((5,), 100.0 * r + 1.0), torch.full((3,), 100.0 * r + 2.0)] for r in range(P)}
+    tr = {r: [torch.full((5,), 100.0 * r + 3.0), torch.full((3,), 100.0 * r + 4.0)] for r in range(P)}
+    return tl, tr
+
+
+def _ring_expect(P, r):
+    right, left = (r + 1) % P, (r - 1) % P
+    return ([torch.full((5,), 100.0 * right + 1.0), torch.full((3,), 100.0 * right + 2.0)],      # what my right neighbour sent left
+            [torch.full((5,), 100.0 * left + 3.0), torch.full((3,), 100.0 * left + 4.0)])        # what my left neighbour sent right
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_neighbor_exchange_loopback(P):
+    comm = LoopbackComm(P)
+    tl, tr = _ring_payload(P)
+    fr = {r: [torch.zeros(5), torch.zeros(3)] for r in range(P)}
+    fl = {r: [torch.zeros(5), torch.zeros(3)] for r in range(P)}
+    comm.neighbor_exchange(tl, tr, fr, fl).wait()
+    for r in range(P):
+        er, el = _ring_expect(P, r)
+        assert all(torch.equal(a, b) for a, b in zip(fr[r], er)) and all(torch.equal(a, b) for a, b in zip(fl[r], el)), r
+
+
+def _pencil_case(P, nxh, ny, kmax):
+    base, rem = divmod(nxh, P)
+    nxl = [base + (1 if r < rem else 0) for r in range(P)]
+    ioff = [r * base + min(r, rem) for r in range(P)]
+    nz = kmax * P
+    g = torch.arange(nz * ny * nxh, dtype=torch.float64).view(nz, ny, nxh)       # global spectral array, value = its own index
+    return nxl, ioff, g
+
+
+def _pencil_send(P, r, nxl, ioff, g, ny, kmax):
+    a = g[r * kmax:(r + 1) * kmax]                                               # my slab (kmax, ny, nxh)
+    blocks = [a[:, :, ioff[p]:ioff[p] + nxl[p]].reshape(-1) for p in range(P)]
+    return torch.cat(blocks), [b.numel() for b in blocks]
+
+
+@pytest.mark.parametrize("P,nxh,ny,kmax", [(2, 9, 3, 2), (3, 17, 2, 2), (8, 33, 2, 1)])
+def test_pencil_all_to_all_loopback(P, nxh, ny, kmax):
+    comm = LoopbackComm(P)
+    nxl, ioff, g = _pencil_case(P, nxh, ny, kmax)
+    send, scnt, recv, rcnt = {}, {}, {}, {}
+    for r in range(P):
+        send[r], scnt[r] = _pencil_send(P, r, nxl, ioff, g, ny, kmax)
+        recv[r], rcnt[r] = torch.zeros(kmax * P * ny * nxl[r], dtype=torch.float64), [kmax * ny * nxl[r]] * P
+    comm.all_to_all_v(send, scnt, recv, rcnt).wait()
+    for r in range(P):      # the pencil of rank r: all z, its kx range, with NO unpacking on the receive side
+        assert torch.equal(recv[r].view(kmax * P, ny, nxl[r]), g[:, :, ioff[r]:ioff[r] + nxl[r]]), r
+
+
+def _worker_ring(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = DistComm()
+        tl, tr = _ring_payload(world)
+        fr = {rank: [torch.zeros(5), torch.zeros(3)]}
+        fl = {rank: [torch.zeros(5), torch.zeros(3)]}
+        comm.neighbor_exchange({rank: tl[rank]}, {rank: tr[rank]}, fr, fl).wait()
+        er, el = _ring_expect(world, rank)
+        ok_ring = all(torch.equal(a, b) for a, b in zip(fr[rank], er)) and all(torch.equal(a, b) for a, b in zip(fl[rank], el))
+        nxh, ny, kmax = 9, 3, 2
+        nxl, ioff, g = _pencil_case(world, nxh, ny, kmax)
+        s, sc = _pencil_send(world, rank, nxl, ioff, g, ny, kmax)
+        rv = {rank: torch.zeros(kmax * world * ny * nxl[rank], dtype=torch.float64)}
+        comm.all_to_all_v({rank: s}, {rank: sc}, rv, {rank: [kmax * ny * nxl[rank]] * world}).wait()
+        ok_pen = torch.equal(rv[rank].view(kmax * world, ny, nxl[rank]), g[:, :, ioff[rank]:ioff[rank] + nxl[rank]])
+        q.put((rank, bool(ok_ring), bool(ok_pen)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_and_pencil_exchanges_real_processes_gloo(world):
+    """2 ranks: both neighbours are the same peer (the posting order in DistComm.neighbor_exchange must pair the messages);
+    3 ranks: distinct neighbours; uneven kx ranges (9 = 5 + 4 = 3 + 3 + 3)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ring, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] and r[2] for r in res), res
