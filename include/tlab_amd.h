@@ -89,6 +89,10 @@ int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, 
 /* Remaining members of type(fdm_dt) a host-built plan may carry (any pointer may be NULL): der1%mwn(n), der2%mwn(n) (periodic directions:
  * OPR_Poisson needs der1%mwn of x and z, opr_elliptic.f90:199-203), jac(n,3) (TIME_COURANT, time.f90:148), nodes(n). */
 int tlab_fdm_plan_set_aux(tlab_fdm_plan_t plan, const double *mwn1, const double *mwn2, const double *jac, const double *nodes);
+/* mode_fdm of the two derivatives of a host-built plan (fdm_derivative.f90:52-58).  FDM_COM6_DIRECT (16) / FDM_COM4_DIRECT (17) as mode2
+ * make rhs2 a per-row pentadiagonal operator (MatMul_5d) -- [Main] SpaceOrder2 = CompactDirect6 of examples/Case81-93; the coefficient
+ * tables of fdm_comx_direct.f90 are the host's (tlab_fdm_plan_create_from_arrays).  Direct FIRST derivatives: TLAB_EUNSUPPORTED. */
+int tlab_fdm_plan_set_scheme(tlab_fdm_plan_t plan, int mode1, int mode2);
 int tlab_fdm_plan_destroy(tlab_fdm_plan_t p);
 
 /* read back plan tables (HOST buffer, column-major like the reference) for parity tests. which:

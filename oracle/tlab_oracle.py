@@ -485,6 +485,28 @@ def matmul_5d_sym(rhs, u, f, ibc):
             f[nx - 1] = 0.0
 
 
+def matmul_5d(rhs, u, f, ibc=BCS_DD):
+    """fdm/fdm_matmul.f90:265-319 MatMul_5d (B pentadiagonal with per-row coefficients, first upper diagonal = 1 in the interior;
+    the direct schemes of fdm_comx_direct.f90).  Only the branches without boundary data (ibc = BCS_DD / none) are restated:
+    FDM_Der2_Solve calls it with BCS_DD for non-periodic directions, and periodic directions never carry a direct scheme (fdm.f90:155-158)."""
+    nx = rhs.shape[0]
+    r1, r2, r3, r4, r5 = (rhs[:, k] for k in range(5))
+    f[0] = u[0] * r3[0] + u[1] * r4[0] + u[2] * r5[0] + u[3] * r1[0]
+    f[1] = u[0] * r2[1] + u[1] * r3[1] + u[2] * r4[1] + u[3] * r5[1]
+    f[2] = u[0] * r1[2] + u[1] * r2[2] + u[2] * r3[2] + u[3] * r4[2] + u[4] * r5[2]
+    f[3] = u[1] * r1[3] + u[2] * r2[3] + u[3] * r3[3] + u[4] * r4[3] + u[5] * r5[3]
+    for n in range(4, nx - 4):
+        f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] + u[n + 2] * r5[n]
+    n = nx - 4
+    f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n] + u[n + 2] * r5[n]
+    n = nx - 3
+    f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n] + u[n + 2] * r5[n]
+    n = nx - 2
+    f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n]
+    n = nx - 1
+    f[n] = u[n - 3] * r5[n] + u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n]
+
+
 def matmul_7d_sym(rhs, u, f, ibc):
     """fdm/fdm_matmul.f90:562-642 MatMul_7d_sym (default second-derivative RHS, C2N6-Hyper)."""
     nx = rhs.shape[0]
@@ -674,7 +696,9 @@ def der2_solve(g, lu, u, du):
     """fdm/fdm_derivative.f90:413-459 FDM_Der2_Solve. lu is an argument (Burgers passes the nu-scaled one)."""
     res = np.empty_like(u)
     ibc = BCS_PERIODIC if g.periodic else BCS_DD
-    if g.nb_diag[1] == 5:
+    if getattr(g, "direct", False):          # FDM_COM4_DIRECT / FDM_COM6_DIRECT: g%matmul => MatMul_5d (fdm_derivative.f90:318-323)
+        matmul_5d(g.rhs, u, res, ibc)
+    elif g.nb_diag[1] == 5:
         matmul_5d_sym(g.rhs, u, res, ibc)
     elif g.nb_diag[1] == 7:
         matmul_7d_sym(g.rhs, u, res, ibc)
@@ -739,6 +763,31 @@ class FdmPlan:
         der2_initialize(self.der2, self.jac[:, 1:3].copy(), periodic, uniform)
         if self.der2.periodic:
             self.der2.mwn = self.der2.mwn / (self.jac[0, 0] ** 2)
+
+    @classmethod
+    def from_tables(cls, tab, periodic=False, mode1=FDM_COM6_JACOBIAN, mode2=FDM_COM6_DIRECT):
+        """Plan from coefficient tables the reference built (tests/golden: the direct schemes of fdm_comx_direct.f90 are not restated;
+        their tables come from FDM_CreatePlan itself).  tab: dict as oracle/ref_lib.fdm_arrays."""
+        self = cls.__new__(cls)
+        n = tab["lhs1"].shape[0]
+        self.size, self.periodic, self.uniform = n, periodic, not bool(tab["need_1der"]) and mode2 not in (FDM_COM4_DIRECT, FDM_COM6_DIRECT)
+        self.jac = np.array(tab["jac"], dtype=np.float64)
+        self.nodes = np.array(tab["nodes"], dtype=np.float64) if "nodes" in tab else None
+        self.der1, self.der2 = DerPlan(mode1), DerPlan(mode2)
+        for d, k in ((self.der1, "1"), (self.der2, "2")):
+            d.size, d.periodic = n, periodic
+            d.nb_diag = (int(tab["ndl" + k]), int(tab["ndr" + k]))
+            d.lhs = np.array(tab["lhs" + k], dtype=np.float64)
+            d.rhs = np.array(tab["rhs" + k], dtype=np.float64)
+            d.lu = np.array(tab["lu" + k], dtype=np.float64)
+            d.mwn = np.array(tab["mwn" + k], dtype=np.float64)
+        self.der1.rhs_b = np.array(tab["rhs_b1"], dtype=np.float64)
+        self.der1.rhs_t = np.array(tab["rhs_t1"], dtype=np.float64)
+        self.der2.need_1der = bool(tab["need_1der"])
+        self.der2.direct = mode2 in (FDM_COM4_DIRECT, FDM_COM6_DIRECT)
+        if mode1 in (FDM_COM4_DIRECT, FDM_COM6_DIRECT):
+            raise NotImplementedError("oracle: direct first-derivative schemes")
+        return self
 
     def diffusion_lu(self, nu):
         """physics/opr_burgers.f90:100-111: LU of the second derivative with the diffusivity folded in."""

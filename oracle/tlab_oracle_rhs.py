@@ -13,10 +13,10 @@ from . import tlab_oracle_poisson as OP
 
 
 class DnsOracle:
-    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True):
+    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None):
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
-        self.g = [O.FdmPlan(x, True, True), O.FdmPlan(y, False, yuniform), O.FdmPlan(z, True, True)]
+        self.g = list(plans) if plans is not None else [O.FdmPlan(x, True, True), O.FdmPlan(y, False, yuniform), O.FdmPlan(z, True, True)]
         self.poisson = OP.PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
         self.nscal, self.visc, self.schmidt = nscal, visc, list(schmidt)
         self.q = [np.zeros(self.n) for _ in range(3)]

@@ -1,0 +1,101 @@
+"""SpaceOrder2 = CompactDirect6 in the non-periodic direction (fdm_comx_direct.f90 + MatMul_5d).  The coefficient
+tables are the reference's own (tests/golden/direct_y.npz, made by FDM_CreatePlan through oracle/_ref); what is tested is the operator
+path on top of them: oracle (MatMul_5d restatement) on CPU, device kernels with per-row right-hand sides on the GPU."""
+import os
+
+import numpy as np
+import pytest
+from conftest import rel_err
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "direct_y.npz"))
+KEYS = ("ndl1", "ndr1", "ndl2", "ndr2", "need_1der", "lhs1", "rhs1", "lu1", "rhs_b1", "rhs_t1", "mwn1", "lhs2", "rhs2", "lu2", "mwn2", "jac", "nodes")
+
+
+def tables(ny):
+    return {k: G["ny%d_%s" % (ny, k)] for k in KEYS}
+
+
+def test_oracle_direct_scheme_matches_reference_outputs():
+    from oracle import tlab_oracle as O
+    nx, ny, nz = 16, 24, 8
+    g = O.FdmPlan.from_tables(tables(ny), mode2=O.FDM_COM6_DIRECT)
+    assert g.der2.direct and not g.der2.need_1der and int(G["x_ndr2"]) == 7
+    u, v, visc = G["u"], G["v"], float(G["visc"])
+    for t in (1, 2, 3):
+        r, t1 = O.opr_partial(2, t, nx, ny, nz, 0, g, u)
+        assert rel_err(r, G["partial_t%d" % t]) <= 1e-14
+        if t == 3:
+            assert rel_err(t1, G["partial_t3_tmp1"]) <= 1e-14
+    assert rel_err(O.opr_burgers(2, nx, ny, nz, 0, g, visc, u, v)[0], G["burgers"]) <= 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ny,nx,nz", [(24, 16, 8), (64, 64, 3), (128, 48, 2), (512, 32, 2)])
+def test_device_direct_scheme(ny, nx, nz):
+    """24: generic kernel against the reference's outputs; 64 / 128 / 512: register-tile and half-wave-tile kernels against the oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    from oracle import tlab_oracle as O
+    T.init(0)
+    tab = tables(ny)
+    gp = T.FdmPlan.from_tables(tab, periodic=False, scheme1=T.FDM_COM6_JACOBIAN, scheme2=T.FDM_COM6_DIRECT)
+    go = O.FdmPlan.from_tables(tab, mode2=O.FDM_COM6_DIRECT)
+    if ny == 24:
+        u, v, visc = G["u"], G["v"], float(G["visc"])
+    else:
+        rng = np.random.default_rng(ny)
+        u, v, visc = rng.uniform(-1, 1, nx * ny * nz), rng.uniform(-1, 1, nx * ny * nz), 1.0 / 300.0
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    res, tmp = torch.empty_like(du), torch.empty_like(du)
+    for t in (T.OPR_P1, T.OPR_P2, T.OPR_P2_P1):
+        res.fill_(float("nan")); tmp.fill_(float("nan"))
+        T.OPR_Partial_Y(t, nx, ny, nz, 0, gp, du, res, tmp)
+        r, t1 = O.opr_partial(2, t, nx, ny, nz, 0, go, u)
+        assert rel_err(res.cpu().numpy(), r) <= 1e-12, t
+        if t == T.OPR_P2_P1:
+            assert rel_err(tmp.cpu().numpy(), t1) <= 1e-12
+        if ny == 24:
+            assert rel_err(res.cpu().numpy(), G["partial_t%d" % t]) <= 1e-12
+    res.fill_(float("nan"))
+    T.OPR_Burgers_Y(T.OPR_B_U_IN, visc, nx, ny, nz, 0, gp, du, dv, res, tmp)
+    assert rel_err(res.cpu().numpy(), O.opr_burgers(2, nx, ny, nz, 0, go, visc, u, v)[0]) <= 1e-12
+    if ny == 24:
+        assert rel_err(res.cpu().numpy(), G["burgers"]) <= 1e-12
+    with pytest.raises(T.TlabError):        # direct FIRST derivatives are not built
+        T.FdmPlan.from_tables(tab, periodic=False, scheme1=T.FDM_COM6_DIRECT, scheme2=T.FDM_COM6_DIRECT)
+
+
+@pytest.mark.gpu
+def test_substep_with_direct_second_derivative_in_y():
+    """The scheme set of examples/Case81-93 (SpaceOrder2 = CompactDirect6, everything else default): full substeps against the oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    from tlab_amd.dns import Dns
+    from oracle import tlab_oracle as O
+    from oracle.tlab_oracle_rhs import DnsOracle
+    T.init(0)
+    nx, ny, nz = 256, 64, 32
+    tab = tables(ny)
+    x, y, z = np.arange(nx) / nx * 2.0, tab["nodes"], np.arange(nz) / nz
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan.from_tables(tab, False, T.FDM_COM6_JACOBIAN, T.FDM_COM6_DIRECT), T.FdmPlan(z, True, True)]
+    go = [O.FdmPlan(x, True, True), O.FdmPlan.from_tables(tab, mode2=O.FDM_COM6_DIRECT), O.FdmPlan(z, True, True)]
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=gp)
+    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=go)
+    rng = np.random.default_rng(81)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * Y)
+    for i in range(3):
+        a = ((np.sin(np.pi * X + i) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel()
+        d.q[i].copy_(torch.from_numpy(a)); o.q[i] = a.copy()
+    a = (np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()
+    d.s[0].copy_(torch.from_numpy(a)); o.s[0] = a.copy()
+    for k in range(2):
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(2e-3 * d.kdt[k], d.kco[k], True)
+        o.time_substep(2e-3 * d.kdt[k], d.kco[k], True)
+        for i in range(3):
+            assert rel_err(d.q[i].cpu().numpy(), o.q[i]) <= 1e-12, (k, i)
+        assert rel_err(d.s[0].cpu().numpy(), o.s[0]) <= 1e-12

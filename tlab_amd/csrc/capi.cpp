@@ -122,7 +122,7 @@ TriDiag tlab_fdm_plan::tridiag(int which, int ibc) const {
     return T;
 }
 
-StencilDev tlab_fdm_plan::stencil(int which, int ibc) const {
+StencilDev tlab_fdm_plan::stencil(int which, int ibc) {
     const DerTables &d = (which == 1) ? t.der1 : t.der2;
     const int nx = d.n;
     StencilDev s;
@@ -179,6 +179,23 @@ StencilDev tlab_fdm_plan::stencil(int which, int ibc) const {
 #undef RB
 #undef RT
         }
+    } else if (d.direct) {   // MatMul_5d, fdm_matmul.f90:291-318 (no boundary data: FDM_Der2_Solve passes BCS_DD)
+        if (d.ndr != 5 || d.periodic) throw Unsupported("direct schemes: pentadiagonal RHS in a non-periodic direction only");
+        s.bb[0][0] = RI(1, 3); s.bb[0][1] = RI(1, 4); s.bb[0][2] = RI(1, 5); s.bb[0][3] = RI(1, 1);
+        s.bb[1][0] = RI(2, 2); s.bb[1][1] = RI(2, 3); s.bb[1][2] = RI(2, 4); s.bb[1][3] = RI(2, 5);
+        for (int k = 0; k < 5; ++k) s.bb[2][k] = RI(3, 1 + k);
+        for (int k = 0; k < 5; ++k) s.bt[0][1 + k] = RI(nx - 2, 1 + k);
+        for (int k = 0; k < 4; ++k) s.bt[1][2 + k] = RI(nx - 1, 1 + k);
+        s.bt[2][2] = RI(nx, 5); s.bt[2][3] = RI(nx, 1); s.bt[2][4] = RI(nx, 2); s.bt[2][5] = RI(nx, 3);
+        if (!rowc2) {
+            std::vector<double> rc((size_t)5 * nx, 0.0);
+            for (int i = 1; i <= nx; ++i)
+                for (int k = 1; k <= 5; ++k) rc[(size_t)(i - 1) * 5 + (k - 1)] = RI(i, k);
+            for (int i = 5; i <= nx - 4; ++i) rc[(size_t)(i - 1) * 5 + 3] = 1.0;       // the interior loop has no r4 factor (:303-305)
+            rowc2 = std::make_unique<DeviceArray>();
+            rowc2->upload(rc);
+        }
+        s.rowc = rowc2->p;
     } else {
         if (d.ndr == 7) {  // MatMul_7d_sym :578-580, :596-601, :628-635
             s.c0 = RI(4, 4); s.c2 = RI(4, 6); s.c3 = RI(4, 7);
@@ -369,6 +386,21 @@ int tlab_fdm_plan_set_aux(tlab_fdm_plan_t p, const double *mwn1, const double *m
         if (mwn2) p->t.der2.mwn.assign(mwn2, mwn2 + n);
         if (jac) p->t.jac.assign(jac, jac + (size_t)3 * n);
         if (nodes) p->t.nodes.assign(nodes, nodes + n);
+    });
+}
+
+// mode_fdm of the two derivatives of a host-built plan (FDM_COM6_DIRECT = 16, FDM_COM4_DIRECT = 17 change how rhs is read)
+int tlab_fdm_plan_set_scheme(tlab_fdm_plan_t p, int mode1, int mode2) {
+    return guarded([&] {
+        if (!p) throw Invalid("tlab_fdm_plan_set_scheme: null plan");
+        auto direct = [](int m) { return m == FDM_COM6_DIRECT || m == FDM_COM4_DIRECT; };
+        if (direct(mode1)) throw Unsupported("direct first-derivative schemes are not built on the device");
+        if (direct(mode2) && (p->t.periodic || p->t.der2.ndr != 5)) throw Invalid("direct second derivative: non-periodic direction with 5 RHS diagonals");
+        p->t.der1.mode_fdm = mode1; p->t.der2.mode_fdm = mode2;
+        p->t.der2.direct = direct(mode2);
+        if (p->t.der2.direct) p->t.der2.need_1der = false;                 // fdm_derivative.f90:379,383
+        p->systems.clear();
+        p->rowc2.reset();
     });
 }
 

@@ -17,6 +17,7 @@ struct DerTables {
     int n = 0;
     bool periodic = false;
     bool need_1der = false;
+    bool direct = false;               // FDM_COM4_DIRECT / FDM_COM6_DIRECT: per-row RHS (MatMul_5d); tables come from the host (from_arrays)
     int ndl = 0, ndr = 0;              // nb_diag(1), nb_diag(2)
     std::vector<double> lhs;           // (n,5)
     std::vector<double> rhs;           // (n,7) first derivative, (n,12) second derivative

@@ -94,6 +94,8 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
         }
         if (NEED2 && corr)
             for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) tj[i] = a.jc.j[i];
+        if (NEED2 && a.s2.rowc != nullptr)      // direct second derivative: per-row RHS coefficients (never together with the correction)
+            for (int i = threadIdx.x; i < 5 * n; i += blockDim.x) tj[i] = a.s2.rowc[i];
     }
     // (the first __syncthreads inside h_solve would be too late for the coefficient reads of the local sweeps)
     __syncthreads();
@@ -153,6 +155,12 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
     if constexpr (NEED2) {
 #pragma unroll
         for (int p = 0; p < M; ++p) x2[p] = h_stencil<true>(a.s2, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+        if (a.s2.rowc != nullptr) {   // MatMul_5d interior (fdm_matmul.f90:303-305) with the per-row coefficients staged in LDS
+            const double *rc = tj + row0 * 5;
+#pragma unroll
+            for (int p = 0; p < M; ++p)
+                x2[p] = e[p + 1] * rc[p * 5 + 0] + e[p + 2] * rc[p * 5 + 1] + e[p + 3] * rc[p * 5 + 2] + e[p + 4] * rc[p * 5 + 3] + e[p + 5] * rc[p * 5 + 4];
+        }
         if (!per) {
             if (c == 0) {
 #pragma unroll
@@ -245,7 +253,7 @@ template <int M, int MAXT>
 static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileArgs &a, hipStream_t st) {
     const long long nwg = (mode == MODE_BURGERS) ? 8LL * a.nf * ((tiles + 7) / 8) : tiles;      // see the blockIdx mapping in the kernel
     const dim3 grid((unsigned)nwg), block(32 * C);
-    const size_t lds = ((size_t)13 * a.g.n + (size_t)2 * C * C) * sizeof(double);
+    const size_t lds = ((size_t)(a.s2.rowc ? 15 : 13) * a.g.n + (size_t)2 * C * C) * sizeof(double);     // 10n tables + max(3n correction, 5n per-row RHS)
     const double pts = (double)a.g.nlines * a.g.n;
     const char *name = mode == MODE_P1 ? "k_htile<P1>" : mode == MODE_P2 ? "k_htile<P2>" : mode == MODE_P2_P1 ? "k_htile<P2_P1>" : "k_htile<BURGERS>";
     const double bpp = (mode == MODE_P1 || mode == MODE_P2) ? 16 : 24;

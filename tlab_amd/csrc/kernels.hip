@@ -323,8 +323,15 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
 
     // ---- right-hand side ----
     double f[M];
+    if (SECOND && st.rowc != nullptr) {       // direct scheme: per-row coefficients, wave-uniform -> scalar loads
+        const double *rc = st.rowc + (long long)row0 * 5;
 #pragma unroll
-    for (int p = 0; p < M; ++p) f[p] = stencil_interior<SECOND>(st, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+        for (int p = 0; p < M; ++p)
+            f[p] = e[p + 1] * rc[p * 5 + 0] + e[p + 2] * rc[p * 5 + 1] + e[p + 3] * rc[p * 5 + 2] + e[p + 4] * rc[p * 5 + 3] + e[p + 5] * rc[p * 5 + 4];
+    } else {
+#pragma unroll
+        for (int p = 0; p < M; ++p) f[p] = stencil_interior<SECOND>(st, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+    }
     if (!per) {
         if (w == 0) {
 #pragma unroll
@@ -469,6 +476,10 @@ __device__ __forceinline__ double generic_rhs_row(const double *__restrict__ u, 
         return dense6(s.bt[i - (n - 3)], u[b6], u[b6 + rs], u[b6 + 2 * rs], u[b6 + 3 * rs], u[b6 + 4 * rs], u[b6 + 5 * rs]);
     }
     const long long c = base + (long long)i * rs;
+    if (SYM && s.rowc != nullptr) {
+        const double *rc = s.rowc + (long long)i * 5;
+        return u[c - 2 * rs] * rc[0] + u[c - rs] * rc[1] + u[c] * rc[2] + u[c + rs] * rc[3] + u[c + 2 * rs] * rc[4];
+    }
     return stencil_interior<SYM>(s, u[c - 3 * rs], u[c - 2 * rs], u[c - rs], u[c], u[c + rs], u[c + 2 * rs], u[c + 3 * rs]);
 }
 

@@ -39,9 +39,10 @@ struct tlab_fdm_plan {
     // (which = 1|2, ibc, P) -> chunked system; built on first use
     std::map<std::tuple<int, int, int>, std::unique_ptr<tlab::SystemEntry>> systems;
     std::unique_ptr<tlab::DeviceArray> jc;   // [3][n] Jacobian-correction diagonals (non-uniform grids)
+    std::unique_ptr<tlab::DeviceArray> rowc2;  // [n][5] per-row RHS of a direct second-derivative scheme
 
     tlab::TriDiag tridiag(int which, int ibc) const;            // tridiagonal matrix of the variant (wall rows -> identity)
-    tlab::StencilDev stencil(int which, int ibc) const;         // RHS operator of the variant
+    tlab::StencilDev stencil(int which, int ibc);               // RHS operator of the variant
     tlab::SystemEntry &system(int which, int ibc, int P);       // cached chunked factorization on the device
     tlab::JacCorrDev jaccorr();
 };

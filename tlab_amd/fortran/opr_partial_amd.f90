@@ -54,6 +54,8 @@ contains
             if (allocated(g%der2%mwn)) pm2 = c_loc(g%der2%mwn)
             rc = tlab_fdm_plan_set_aux(plans(idir), pm1, pm2, c_loc(g%jac), c_null_ptr)
             call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_aux')
+            rc = tlab_fdm_plan_set_scheme(plans(idir), int(g%der1%mode_fdm, c_int), int(g%der2%mode_fdm, c_int))     ! CompactDirect6: per-row rhs
+            call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_scheme')
         end if
         p = plans(idir)
     end function OPR_Partial_AMD_Plan

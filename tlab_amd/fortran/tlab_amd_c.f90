@@ -49,6 +49,11 @@ module TLab_AMD_C
             import :: c_int, c_ptr
             type(c_ptr), value :: plan, mwn1, mwn2, jac, nodes
         end function
+        integer(c_int) function tlab_fdm_plan_set_scheme(plan, mode1, mode2) bind(C, name='tlab_fdm_plan_set_scheme')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: mode1, mode2
+        end function
         integer(c_int) function tlab_fdm_plan_destroy(plan) bind(C, name='tlab_fdm_plan_destroy')
             import :: c_int, c_ptr
             type(c_ptr), value :: plan

@@ -18,6 +18,7 @@ OPR_P1, OPR_P2, OPR_P2_P1 = 1, 2, 3
 OPR_B_SELF, OPR_B_U_IN = 0, 1
 BCS_DD, BCS_ND, BCS_DN, BCS_NN = 0, 1, 2, 3
 FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER = 4, 6, 7
+FDM_COM6_DIRECT, FDM_COM4_DIRECT = 16, 17
 
 _initialised = False
 
@@ -85,6 +86,24 @@ class FdmPlan:
                                                       3, ndr1, f[0].ctypes.data_as(dp), f[1].ctypes.data_as(dp),
                                                       3, ndr2, f[2].ctypes.data_as(dp), f[3].ctypes.data_as(dp)),
               "tlab_fdm_plan_create_from_arrays")
+        return self
+
+    @classmethod
+    def from_tables(cls, tab, periodic=False, scheme1=FDM_COM6_JACOBIAN, scheme2=FDM_COM6_JACOBIAN_HYPER):
+        """Everything a Fortran host hands over for one direction: tab = dict with ndr1, ndr2, need_1der, lhs1, rhs1, lhs2, rhs2, mwn1,
+        mwn2, jac (as oracle/ref_lib.fdm_arrays / the golden files hold them), plus the mode_fdm of both derivatives
+        (FDM_COM6_DIRECT = 16 as scheme2: per-row right-hand side, SpaceOrder2 = CompactDirect6)."""
+        rhs1 = np.asarray(tab["rhs1"])[:, :int(tab["ndr1"])]
+        rhs2 = np.asarray(tab["rhs2"])[:, :int(tab["ndr2"]) + 3]
+        self = cls.from_arrays(np.asarray(tab["lhs1"]).shape[0], periodic, int(tab["need_1der"]), np.asarray(tab["lhs1"]), rhs1,
+                               np.asarray(tab["lhs2"]), rhs2)
+        dp = ctypes.POINTER(ctypes.c_double)
+        aux = [np.ascontiguousarray(tab[k], dtype=np.float64) if k in tab else None for k in ("mwn1", "mwn2")]
+        jac = np.asfortranarray(tab["jac"], dtype=np.float64) if "jac" in tab else None
+        ptr = lambda a: a.ctypes.data_as(dp) if a is not None else None      # noqa: E731
+        check(load().tlab_fdm_plan_set_aux(self._h, ctypes.cast(ptr(aux[0]), c_vp), ctypes.cast(ptr(aux[1]), c_vp),
+                                           ctypes.cast(ptr(jac), c_vp), None), "tlab_fdm_plan_set_aux")
+        check(load().tlab_fdm_plan_set_scheme(self._h, int(scheme1), int(scheme2)), "tlab_fdm_plan_set_scheme")
         return self
 
     def info(self, what):
