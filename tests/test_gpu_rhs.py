@@ -270,3 +270,42 @@ def test_projection_makes_interior_divergence_vanish(T):
     scale = float((d.q[0].abs().max() / dte))
     interior = div.view(nz, ny, nx)[:, 36:-36, :]
     assert float(interior.abs().max()) / scale * (x[1] - x[0]) <= 1e-11
+
+
+def test_full_size_substep_properties(T):
+    """BASELINE configs[2] size (512^3, one scalar), where the oracle is out of reach: (1) the fused driver (multi-field Burgers launches,
+    operand / gradient / update fusions, chunked ODE kernel, own z-FFT) and the literal operator sequence of the reference (set_fusion(False))
+    must agree to round-off after a full RK3 step; (2) the projected velocity is solenoidal in the interior."""
+    import torch
+    from tlab_amd.dns import Dns
+    n = 512
+    x = np.arange(n) / n
+    y = np.arange(n) / (n - 1.0)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(512)
+    X = torch.arange(n, dtype=torch.float64, device="cuda").view(1, 1, n) / n
+    Y = torch.arange(n, dtype=torch.float64, device="cuda").view(1, n, 1) / (n - 1)
+    Z = torch.arange(n, dtype=torch.float64, device="cuda").view(n, 1, 1) / n
+    wall = torch.sin(np.pi * Y)
+    two_pi = 2 * np.pi
+    shapes = [torch.sin(two_pi * X) * torch.cos(2 * two_pi * Y) * torch.sin(3 * two_pi * Z), torch.cos(two_pi * X) * torch.sin(two_pi * Y) * torch.sin(2 * two_pi * Z),
+              torch.sin(2 * two_pi * X) * torch.cos(two_pi * Y) * torch.cos(two_pi * Z), torch.cos(3 * two_pi * X) * torch.cos(two_pi * Y) * torch.sin(two_pi * Z)]
+    fields = [((sh + 0.1 * (2 * torch.rand(n, n, n, dtype=torch.float64, device="cuda", generator=gen) - 1)) * wall).reshape(-1) for sh in shapes]
+    out = []
+    for fuse in (True, False):
+        d = Dns(x, y, x.copy(), nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True)
+        d.set_fusion(fuse)
+        for t, f in zip(d.q + d.s, fields):
+            t.copy_(f)
+        d.TIME_RUNGEKUTTA(1e-3)
+        out.append([t.clone() for t in d.q + d.s])
+        if fuse:
+            # interior divergence of the new velocity (the last substep's projection), cf. test_projection_makes_interior_divergence_vanish
+            dmin, dmax = None, None
+            d.FI_INVARIANT_P(d.txc[0], d.txc[1])
+            div = d.txc[0][: d.n].view(n, n, n)[:, 40:-40, :]
+            scale = float(d.q[0].abs().max()) * n
+            assert float(div.abs().max()) / scale <= 1e-10
+        del d
+        torch.cuda.empty_cache()
+    for a, b in zip(*out):
+        assert float((a - b).abs().max() / b.abs().max()) <= 1e-12

@@ -66,3 +66,36 @@ def test_thin_slabs_refuse_halo_mode(T):
     with pytest.raises(T.TlabError):
         SlabDns(LoopbackComm(4), x, y, z, zmode="halo")          # kmax = 16: slab separators still couple at 1e-7
     assert SlabDns(LoopbackComm(4), x, y, z, zmode="auto").zmode == "transpose"
+
+
+def test_full_size_eight_slabs_equal_single_domain(T):
+    """The strong-scaling case of the benchmark itself: 512^3 split into 8 slabs of 64 planes (halo mode, kx-pencils 33 + 7 x 32,
+    k_zslab with two 32-row sub-chunks, k_fftz of length 512) against the single-domain driver, after one RK3 step."""
+    import torch
+    from tlab_amd.dns import Dns
+    from tlab_amd.parallel import SlabDns, LoopbackComm
+    n, P = 512, 8
+    x = np.arange(n) / n
+    y = np.arange(n) / (n - 1.0)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(8)
+    Y = torch.arange(n, dtype=torch.float64, device="cuda").view(1, n, 1) / (n - 1)
+    wall = torch.sin(np.pi * Y)
+    fields = [((torch.rand(n, n, n, dtype=torch.float64, device="cuda", generator=gen) - 0.5) * wall).reshape(-1) for _ in range(4)]
+    one = Dns(x, y, x.copy(), nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True)
+    for t, f in zip(one.q + one.s, fields):
+        t.copy_(f)
+    one.TIME_RUNGEKUTTA(1e-3)
+    ref = [t.clone() for t in one.q + one.s]
+    del one
+    torch.cuda.empty_cache()
+    slab = SlabDns(LoopbackComm(P), x, y, x.copy(), nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True)
+    assert slab.zmode == "halo"
+    for i in range(3):
+        slab.scatter("q", i, fields[i])
+    slab.scatter("s", 0, fields[3])
+    for k in range(3):
+        slab.substep_of_cycle(k, 1e-3)
+    for i, rf in enumerate(ref):
+        name, idx = ("q", i) if i < 3 else ("s", 0)
+        got = torch.cat([slab.st[r][name][idx] for r in range(P)])
+        assert float((got - rf).abs().max() / rf.abs().max()) <= 1e-11, (name, idx)
