@@ -1,3 +1,4 @@
+"""Diagnostic: host-side enqueue time of the z-slab driver per substep (all ranks simulated in this process) against the device time."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
