@@ -99,3 +99,29 @@ def test_substep_with_direct_second_derivative_in_y():
         for i in range(3):
             assert rel_err(d.q[i].cpu().numpy(), o.q[i]) <= 1e-12, (k, i)
         assert rel_err(d.s[0].cpu().numpy(), o.s[0]) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_direct_scheme_along_x_takes_the_generic_kernel():
+    """A non-periodic, stretched x with a direct second derivative (n = 512 would otherwise select the wave-per-line kernel, which only
+    knows the constant stencils of the Jacobian schemes)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    from oracle import tlab_oracle as O
+    from tlab_amd.lib import load
+    T.init(0)
+    nx, ny, nz = 512, 4, 3
+    tab = tables(nx)
+    gp = T.FdmPlan.from_tables(tab, periodic=False, scheme1=T.FDM_COM6_JACOBIAN, scheme2=T.FDM_COM6_DIRECT)
+    go = O.FdmPlan.from_tables(tab, mode2=O.FDM_COM6_DIRECT)
+    rng = np.random.default_rng(3)
+    u, v = rng.uniform(-1, 1, nx * ny * nz), rng.uniform(-1, 1, nx * ny * nz)
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    res, tmp = torch.empty_like(du), torch.empty_like(du)
+    T.OPR_Partial_X(T.OPR_P2, nx, ny, nz, 0, gp, du, res, tmp)
+    assert load().tlab_last_kernel_path() == 1
+    assert rel_err(res.cpu().numpy(), O.opr_partial(1, O.OPR_P2, nx, ny, nz, 0, go, u)[0]) <= 1e-12
+    T.OPR_Burgers_X(T.OPR_B_U_IN, 1e-2, nx, ny, nz, 0, gp, du, dv, res, tmp)
+    assert rel_err(res.cpu().numpy(), O.opr_burgers(1, nx, ny, nz, 0, go, 1e-2, u, v)[0]) <= 1e-12

@@ -622,7 +622,7 @@ bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int n
     if (geom.n == 1) return false;
     OpExtra ex;
     ex.acc = true;
-    const bool corr = g->t.der2.need_1der;
+    const bool corr = g->t.der2.need_1der || g->t.der2.direct;      // (the x-line kernel only knows the constant stencils)
     const int path = choose_path(dir, geom.n);
     if (path == PATH_XLINE && !corr) {
         run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu, ex);
@@ -639,7 +639,7 @@ bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, i
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
     const int path = choose_path(dir, geom.n);
-    return (path == PATH_XLINE && !g->t.der2.need_1der) || (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS));
+    return (path == PATH_XLINE && !g->t.der2.need_1der && !g->t.der2.direct) || (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS));
 }
 // several transported fields, one advecting velocity: result[f] += nu[f] d2 s[f] - vel d s[f]
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
@@ -652,7 +652,7 @@ bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int
     ex.acc = !overwrite;        // overwrite: the tendency is known to be zero (start of a Runge-Kutta step): neither zero-filled nor read
     ex.nf = nf;
     for (int f = 0; f < nf; ++f) { ex.fs[f] = s[f]; ex.fo[f] = result[f]; ex.fnu[f] = nu[f]; }
-    const bool corr = g->t.der2.need_1der;
+    const bool corr = g->t.der2.need_1der || g->t.der2.direct;
     const int path = choose_path(dir, geom.n);
     if (path == PATH_XLINE && !corr) {
         run_xline(g, geom, MODE_BURGERS, ibc, s[0], vel, result[0], nullptr, nu[0], ex);
@@ -795,7 +795,7 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
         if (type == TLAB_OPR_P2_P1 && !tmp1) throw Invalid("OPR_P2_P1 needs tmp1");
         if (type == TLAB_OPR_P2 && corr && !tmp1) throw Invalid("OPR_P2 on a non-uniform grid needs tmp1 (opr_partial.f90:96)");
         int path = choose_path(dir, geom.n);
-        if (path == PATH_XLINE && corr && type != TLAB_OPR_P1) path = PATH_GENERIC;  // non-uniform x: rare, generic kernel
+        if (path == PATH_XLINE && (corr || g->t.der2.direct) && type != TLAB_OPR_P1) path = PATH_GENERIC;  // non-uniform / direct-scheme x: rare, generic kernel
         g_last_path = path;
         if (path == PATH_XLINE) {
             const int mode = (type == TLAB_OPR_P1) ? MODE_P1 : (type == TLAB_OPR_P2) ? MODE_P2 : MODE_P2_P1;
@@ -845,7 +845,7 @@ int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int n
         const bool wt = write_transposed && ivel == TLAB_OPR_B_SELF && (dir == 1 || (dir == 2 && nz > 1));
         double *d1 = wt ? workspace((size_t)ntot) : tmp1;
         int path = choose_path(dir, geom.n);
-        if (path == PATH_XLINE && corr) path = PATH_GENERIC;
+        if (path == PATH_XLINE && (corr || g->t.der2.direct)) path = PATH_GENERIC;
         g_last_path = path;
         if (path == PATH_XLINE) {
             run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu);
