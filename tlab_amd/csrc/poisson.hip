@@ -1273,32 +1273,40 @@ void build_singular_homogeneous(tlab_poisson_plan &P, hipStream_t st) {
     launch_int1<1, 2, FS_LINEAR>(s4, st);
 }
 
+// lanes per chunk of the singular-mode kernel: 8 (<= 4 modes in use), 4 when the line has more than 64 chunks (512 threads at most)
+inline int ode_sing_nm(int C) { return C > 64 ? 4 : 8; }
+
 void build_singular_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
     const int ns = (int)P.sing_modes.size();
     if (ns == 0) return;
-    const int C = P.ny / OM, NM = 8;
+    const int C = P.ny / OM, NM = ode_sing_nm(C);
     for (int w = 0; w < 2; ++w) P.chk_s[w].alloc((size_t)C * 6 * NM);
     hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(1), dim3(256), 0, st, P.sys(0), P.s_lam.p, 1.0, P.chk_s[0].p, (long long)ns, NM, C);
     hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(1), dim3(256), 0, st, P.sys(1), P.s_lam.p, -1.0, P.chk_s[1].p, (long long)ns, NM, C);
     hipc(hipGetLastError(), "k_ode_checkpoint (singular)");
 }
 
-void launch_ode_sing(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
-    constexpr int NM = 8;
-    OdeSingArgs a{};
-    a.T1 = P.sys(0); a.T2 = P.sys(1);
-    a.chk1 = P.chk_s[0].p; a.chk2 = P.chk_s[1].p; a.modes = P.d_sing;
-    a.v1 = P.s_v1.p; a.u1 = P.s_u1.p; a.du1 = P.s_du1.p;
-    a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
-    a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.ns = (int)P.sing_modes.size();
+template <int NM>
+void launch_ode_sing_nm(const OdeSingArgs &a, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ode_sing<NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         (void)hipGetLastError();
         attr_done = true;
     }
-    ProfScope ps("k_ode_sing", st, (double)a.ns * P.ny * 48.0);
     hipLaunchKernelGGL((k_ode_sing<NM>), dim3(1), dim3(NM * a.C), ode_lds_bytes(a.C, NM), st, a);
+}
+
+void launch_ode_sing(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
+    OdeSingArgs a{};
+    a.T1 = P.sys(0); a.T2 = P.sys(1);
+    a.chk1 = P.chk_s[0].p; a.chk2 = P.chk_s[1].p; a.modes = P.d_sing;
+    a.v1 = P.s_v1.p; a.u1 = P.s_u1.p; a.du1 = P.s_du1.p;
+    a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
+    a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.ns = (int)P.sing_modes.size();
+    ProfScope ps("k_ode_sing", st, (double)a.ns * P.ny * 48.0);
+    if (ode_sing_nm(a.C) == 8) launch_ode_sing_nm<8>(a, st);
+    else launch_ode_sing_nm<4>(a, st);
     hipc(hipGetLastError(), "k_ode_sing");
 }
 
@@ -1515,8 +1523,9 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                 P->ode_nm_per_wg = ode_modes_per_wg(C);
                 build_checkpoints(*P, st);
                 P->use_chunked = true;
-                if (8 * C <= 512 && ode_lds_bytes(C, 8) <= (size_t)160 * 1024) build_singular_checkpoints(*P, st);
-                else P->use_chunked = false;      // (the singular-mode kernel is built for 8 lanes per chunk)
+                if (ode_sing_nm(C) * C <= 512 && (int)P->sing_modes.size() <= ode_sing_nm(C) && ode_lds_bytes(C, ode_sing_nm(C)) <= (size_t)160 * 1024)
+                    build_singular_checkpoints(*P, st);
+                else P->use_chunked = false;
             }
         }
         hipc(hipStreamSynchronize(st), "sync");
