@@ -90,7 +90,7 @@ def test_chunked_and_marching_ode_kernels_agree(T, monkeypatch):
     assert rel_err(outs[0][1], outs[1][1]) <= 1e-13
 
 
-@pytest.mark.parametrize("nz", [16, 32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("nz", [16, 32, 64, 128, 256, 512, 1024, 2048])
 def test_own_z_fft_matches_numpy(T, nz):
     """k_fftz (strided Stockham, fftz.hip) against numpy on the kx-pencil layout (nxl, ny, nz); lengths 8^a * {1,2,4}."""
     import ctypes

@@ -109,7 +109,7 @@ __device__ __forceinline__ void fftz_pass(const FftzArgs &a, int t, int j, int N
     }
 }
 
-// n = 8^a * {1,2,4}; every pass has n/R <= n/2 items per column; blockDim = T * n / 8 (all radix-8 passes: one item per thread; a final
+// n = 8^a * {1,2,4} (16 .. 2048); every pass has n/R <= n/2 items per column; blockDim = T * n / 8 (all radix-8 passes: one item per thread; a final
 // radix-4 / radix-2 pass has 2 / 4 items per thread).  The barriers inside fftz_pass are reached uniformly: the loops below have the
 // same trip count for every thread.
 template <int SGN, int T>
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_fftz(FftzArgs a) {
 }
 
 bool FftzPlan::supported(int n) {
-    if (n < 16 || n > 1024) return false;
+    if (n < 16 || n > 2048) return false;
     int m = n;
     while (m % 8 == 0) m /= 8;
     return m == 1 || m == 2 || m == 4;
@@ -225,18 +225,11 @@ FftzPlan::~FftzPlan() {
     if (d_tw) (void)hipFree(d_tw);
 }
 
-void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) const {
-    constexpr int T = 8;
-    FftzArgs a{};
-    a.in = reinterpret_cast<const double2 *>(in);
-    a.out = reinterpret_cast<double2 *>(out);
-    a.tw = reinterpret_cast<const double2 *>(d_tw);
-    a.nlines = nlines; a.n = n; a.npass = (int)radix.size();
-    for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
-    const unsigned grid = (unsigned)((nlines + T - 1) / T);
-    const unsigned block = (unsigned)(T * n / 8);
-    const size_t lds = (size_t)n * T * sizeof(double2);
-    ProfScope ps("k_fftz", st, (double)nlines * n * 32.0);
+template <int T>
+static void fftz_launch(int dir, const FftzArgs &a, hipStream_t st) {
+    const unsigned grid = (unsigned)((a.nlines + T - 1) / T);
+    const unsigned block = (unsigned)(T * a.n / 8);
+    const size_t lds = (size_t)a.n * T * sizeof(double2);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fftz<-1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -246,6 +239,18 @@ void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) cons
     }
     if (dir > 0) hipLaunchKernelGGL((k_fftz<-1, T>), dim3(grid), dim3(block), lds, st, a);      // forward: exp(-i ...)
     else hipLaunchKernelGGL((k_fftz<+1, T>), dim3(grid), dim3(block), lds, st, a);
+}
+
+void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) const {
+    FftzArgs a{};
+    a.in = reinterpret_cast<const double2 *>(in);
+    a.out = reinterpret_cast<double2 *>(out);
+    a.tw = reinterpret_cast<const double2 *>(d_tw);
+    a.nlines = nlines; a.n = n; a.npass = (int)radix.size();
+    for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
+    ProfScope ps("k_fftz", st, (double)nlines * n * 32.0);
+    if (n <= 1024) fftz_launch<8>(dir, a, st);       // 8 neighbouring lines per workgroup (128-B rows), n * 8 * 16 B of LDS
+    else fftz_launch<4>(dir, a, st);                 // n = 2048: 4 lines (64-B rows) to stay within 1024 threads / 128 KB
     if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftz launch failed");
 }
 

@@ -8,7 +8,7 @@ namespace tlab {
 
 class FftzPlan {
 public:
-    static bool supported(int n);                       // n = 8^a * {1, 2, 4}, 16 <= n <= 1024
+    static bool supported(int n);                       // n = 8^a * {1, 2, 4}, 16 <= n <= 2048
     FftzPlan(int n, long long nlines);                  // element (line l, point k) at l + nlines * k, complex interleaved
     ~FftzPlan();
     FftzPlan(const FftzPlan &) = delete;
