@@ -192,7 +192,7 @@ int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, i
  *   phase 2: result = d/dz (u [+ scale*ub])   resp.   nu d2s/dz2 - vel ds/dz ;  acc != 0: result += ...
  * Every operand pointer addresses the first plane of the slab and must have 3 valid planes before it and after the slab
  * (the neighbours' planes, periodic in z).  plan_create returns TLAB_EUNSUPPORTED when the slab is too thin for the coupling
- * between slab separators to vanish in double precision (kmax >~ 48 for the sixth-order schemes): keep the transpose path then.
+ * between slab separators to vanish in double precision (kmax >~ 50 for the sixth-order schemes): keep the transpose path then.
  * chunk: rows per wave (0 = automatic, 16 or 32). */
 typedef struct tlab_zslab_plan *tlab_zslab_plan_t;
 int tlab_zslab_plan_create(tlab_zslab_plan_t *out, tlab_fdm_plan_t gz, int kmax, int koffset, int chunk);

@@ -37,7 +37,7 @@ def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs, zmode, zchunk)
     visc, sc = 1.0 / 600.0, (0.8,)
     one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
     slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, zmode=zmode, zchunk=zchunk)
-    assert slab.zmode == ("transpose" if nz // P < 48 else zmode if zmode != "auto" else "halo")
+    assert slab.zmode == ("transpose" if nz // P < 56 else zmode if zmode != "auto" else "halo")
     if bcs == "freeslip":
         one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
         slab.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
@@ -66,6 +66,8 @@ def test_thin_slabs_refuse_halo_mode(T):
     with pytest.raises(T.TlabError):
         SlabDns(LoopbackComm(4), x, y, z, zmode="halo")          # kmax = 16: slab separators still couple at 1e-7
     assert SlabDns(LoopbackComm(4), x, y, z, zmode="auto").zmode == "transpose"
+    z48 = np.arange(192) / 192.0                                 # 48 planes per slab: 0.38^47 is still above the 1e-19 gate
+    assert SlabDns(LoopbackComm(4), x, y, z48, zmode="auto").zmode == "transpose"
 
 
 def test_full_size_eight_slabs_equal_single_domain(T):

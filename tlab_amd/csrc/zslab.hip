@@ -11,7 +11,7 @@
 //   separator:  alpha X_{r-1} + beta X_r + gamma X_{r+1} = f_S - a_S y^{r-1}_last - c_S y^r_1
 //
 // alpha, gamma are the far ends of the slab-level spikes, ~0.38^kmax for the sixth-order compact schemes: below 1e-19 beta for
-// kmax >= 48, i.e. exactly zero in double precision (checked at plan creation; thinner slabs are refused and the caller keeps
+// kmax >~ 50 (64 with the 16- or 32-row sub-chunks), i.e. exactly zero in double precision (checked at plan creation; thinner slabs are refused and the caller keeps
 // the transpose path).  The interface system is then diagonal and each slab needs only
 //   tail  = y_last            from its left  neighbour    (8 B per line and system)
 //   head  = f_S - c_S y_1     from its right neighbour
@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -290,8 +291,12 @@ void build_system(tlab_zslab_plan &P, const TriDiag &G, ZSysHost &out) {
     const double tol = 1e-19;
     if (std::fabs(alpha) > tol * std::fabs(beta) || std::fabs(gamma) > tol * std::fabs(beta) || std::fabs(alphan) > tol * std::fabs(betan) ||
         std::fabs(gamman) > tol * std::fabs(betan))
-        throw Fail(TLAB_EUNSUPPORTED, "z-slab operators: slab too thin, the coupling between slab separators (" + std::to_string(std::fabs(alpha / beta)) +
-                                          ") is not below double precision; use the K-transpose path");
+    {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%.2e", std::fabs(alpha / beta));
+        throw Fail(TLAB_EUNSUPPORTED, std::string("z-slab operators: slab too thin, the coupling between slab separators (") + buf +
+                                          ") is not below 1e-19; use the K-transpose path");
+    }
     ChunkedTables ct;
     build_chunked(Tm, P.C, ct);
     if ((int)ct.ginv.size() != P.C * P.C) throw Fail(TLAB_EINVAL, "internal: dense separator inverse missing");

@@ -16,7 +16,7 @@ Two algorithms are built on that decomposition:
 
   zmode = "transpose": the reference's scheme.  Every z-operator and the z-FFT go through a K-transposition (12 + 6 field
       all-to-alls per substep); kept for thin slabs and as the cross-check of the second one.
-  zmode = "halo" (default when the slabs are thick enough, kmax >~ 48): no field is transposed for a derivative.  The compact
+  zmode = "halo" (default when the slabs are thick enough, kmax >~ 50): no field is transposed for a derivative.  The compact
       z-systems are partitioned at the slab boundaries (tlab_amd/csrc/zslab.hip): an operator needs 3 halo planes of its
       operand and one value per line and system from each neighbour -- two small point-to-point messages over the xGMI link
       to each neighbour, overlapped with the x/y operators.  The Poisson solver goes from the z-slab to a kx-pencil with ONE
