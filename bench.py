@@ -211,7 +211,7 @@ def main():
             "substep_alg_GBps": (736.0 + 152.0 * args.nscal) * npts / (ms_per_step * 1e-3) / 1e9,
             "kernels": [{k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in k.items()} for k in kernels],
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1 and args.loopback <= 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.nscal)
         print(json.dumps(out))
     if world > 1:
