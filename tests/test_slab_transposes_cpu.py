@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tlab_amd.parallel import LoopbackComm, DistComm, trp_k_forward, trp_k_backward
+from tlab_amd.parallel import LoopbackComm, DistComm, trp_k_forward, trp_k_backward, trp_i_forward, trp_i_backward
 
 
 def global_field(nx, ny, nz, width):
@@ -168,4 +168,57 @@ def test_ring_and_pencil_exchanges_real_processes_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] and r[2] for r in res), res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# I-transposes (x pencils): TLabMPI_Trp_ExecI_*, tlab_mpi_transpose.f90:205-286
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P,imax,ny,nz,width", [(2, 4, 3, 2, 1), (4, 8, 2, 6, 1), (2, 5, 2, 4, 2), (8, 2, 4, 4, 1)])
+def test_i_transposes_loopback(P, imax, ny, nz, width):
+    comm = LoopbackComm(P)
+    nxg, npage = imax * P, ny * nz
+    nl = npage // P
+    g = torch.arange(nxg * npage * width, dtype=torch.float64).view(npage, nxg, width) + 0.5        # global (line, x_global)
+    a = {r: g[:, r * imax:(r + 1) * imax, :].reshape(-1).clone() for r in range(P)}                 # rank r owns the x range [r*imax, (r+1)*imax)
+    b = trp_i_forward(comm, a, imax, npage, width)
+    for r in range(P):       # rank r now owns the complete x-lines [r*nl, (r+1)*nl)
+        assert torch.equal(b[r], g[r * nl:(r + 1) * nl].reshape(-1)), r
+    back = trp_i_backward(comm, b, imax, npage, width)
+    for r in range(P):
+        assert torch.equal(back[r], a[r]), r
+
+
+def _worker_i(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = DistComm()
+        imax, ny, nz, width = 4, 3, 2, 1
+        nxg, npage = imax * world, ny * nz
+        nl = npage // world
+        g = torch.arange(nxg * npage * width, dtype=torch.float64).view(npage, nxg, width) + 0.5
+        a = {rank: g[:, rank * imax:(rank + 1) * imax, :].reshape(-1).clone()}
+        b = trp_i_forward(comm, a, imax, npage, width)
+        back = trp_i_backward(comm, b, imax, npage, width)
+        q.put((rank, bool(torch.equal(b[rank], g[rank * nl:(rank + 1) * nl].reshape(-1))), bool(torch.equal(back[rank], a[rank]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_i_transposes_two_processes_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_i, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
     assert all(r[1] and r[2] for r in res), res

@@ -176,6 +176,34 @@ def trp_k_backward(comm, b, npage, kmax, width=1):
     return {r: recv[r].view(P, kmax, nl).transpose(0, 1).reshape(-1) for r in comm.local_ranks}   # a(k, src*nlines + l)
 
 
+def trp_i_forward(comm, a, imax, npage, width=1):
+    """TLabMPI_Trp_ExecI_Forward (tlab_mpi_transpose.f90:232-256, plan :205-230): local a(imax, npage) (x fastest, npage = jmax*kmax lines)
+    -> b(imax*npro_i, nlines), nlines = npage/npro_i: peer p gets my lines [p*nlines, (p+1)*nlines) and stores my x-segment at x-offset
+    my_rank*imax of each of its lines.  The send side needs no packing (a block of lines is contiguous), the receive side one strided copy.
+    Not used by the 1 x N slab driver; completes the transposition layer of SURVEY 8a a14."""
+    import torch
+    P = comm.size
+    if npage % P != 0:
+        raise TlabError("I-transposition: npage must be divisible by the number of x pencils (tlab_mpi_transpose.f90:223)")
+    nl = npage // P
+    recv = comm.all_to_all({r: a[r].view(P, nl * imax * width) for r in comm.local_ranks})      # [src][line][x of src]
+    out = {}
+    for r in comm.local_ranks:
+        b = torch.empty(nl, P, imax * width, dtype=a[r].dtype, device=a[r].device)
+        b.copy_(recv[r].view(P, nl, imax * width).transpose(0, 1))
+        out[r] = b.reshape(-1)                                                                 # b(x_global, line), x fastest
+    return out
+
+
+def trp_i_backward(comm, b, imax, npage, width=1):
+    """TLabMPI_Trp_ExecI_Backward (tlab_mpi_transpose.f90:260-286): exact inverse of trp_i_forward."""
+    P = comm.size
+    nl = npage // P
+    sends = {r: b[r].view(nl, P, imax * width).transpose(0, 1).contiguous().view(P, nl * imax * width) for r in comm.local_ranks}
+    recv = comm.all_to_all(sends)                                                              # [src = owner of the lines][line][my x]
+    return {r: recv[r].reshape(-1) for r in comm.local_ranks}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # the decomposed RK substep
 # ------------------------------------------------------------------------------------------------------------------
