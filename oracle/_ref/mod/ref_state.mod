@@ -1,4 +1,4 @@
-﻿!mod$ v1 sum:ad86fbe3b97a3a42
+﻿!mod$ v1 sum:a3162f7a7bbbaa31
 !need$ 8d4bae2479538272 n fdm_integral
 !need$ ff3fca9ebc58e858 n tlab_grid
 !need$ 370470eb4a3adeb1 n tlab_constants
@@ -12,4 +12,5 @@ use fdm_integral,only:fdm_integral_dt
 type(fdm_dt),target::gp(1_8:3_8)
 type(grid_dt)::gr(1_8:3_8)
 type(fdm_integral_dt)::fint(1_8:2_8)
+type(fdm_integral_dt)::fint2
 end

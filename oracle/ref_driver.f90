@@ -30,6 +30,7 @@ module ref_state
     type(fdm_dt), target :: gp(3)
     type(grid_dt) :: gr(3)
     type(fdm_integral_dt) :: fint(2)                ! scratch pair of first-order integral plans
+    type(fdm_integral_dt) :: fint2                  ! scratch second-order integral plan (direct elliptic solver)
 end module ref_state
 
 !########################################################################

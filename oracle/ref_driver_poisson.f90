@@ -97,3 +97,57 @@ subroutine ref_ode2(itype, nlines, lambda, f, bcs, u, v) bind(C, name='ref_ode2'
     end select
     deallocate (w1, w2)
 end subroutine ref_ode2
+
+
+!########################################################################
+! Second-order integral operators of the DIRECT elliptic solver (EllipticOrder = CompactDirect*,
+! OPR_Poisson_FourierXZ_Direct, src/operators/opr_elliptic.f90:368-455):
+!   FDM_Int2_CreateSystem / FDM_Int2_Initialize / FDM_Int2_Solve     src/fdm/fdm_integral.f90:366,334,626
+! built from gp(2)%der2 exactly as OPR_Elliptic_Initialize does (opr_elliptic.f90:236-242); lambda2 = kx^2 + kz^2 here.
+!########################################################################
+subroutine ref_int2_create(lambda2, ibc, factorize) bind(C, name='ref_int2_create')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use FDM_Integral
+    use ref_state
+    implicit none
+    real(c_double), value :: lambda2
+    integer(c_int), value :: ibc, factorize
+
+    ! (FDM_Int2_CreateSystem is private to the module: only the factorized system can be inspected)
+    call FDM_Int2_Initialize(gp(2)%nodes(:), gp(2)%der2, lambda2, ibc, fint2)
+end subroutine ref_int2_create
+
+! which: 1 lhs(n,ndr)  2 rhs(n,ndl)  3 rhs_b(5,0:7)  4 rhs_t(0:4,8)
+subroutine ref_int2_get(which, buf, nbuf) bind(C, name='ref_int2_get')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use ref_state
+    implicit none
+    integer(c_int), value :: which, nbuf
+    real(c_double), intent(out) :: buf(nbuf)
+    integer m
+    buf(:) = 0.0_wp
+    select case (which)
+    case (1); m = size(fint2%lhs); buf(1:m) = reshape(fint2%lhs, [m])
+    case (2); m = size(fint2%rhs); buf(1:m) = reshape(fint2%rhs, [m])
+    case (3); m = size(fint2%rhs_b); buf(1:m) = reshape(fint2%rhs_b, [m])
+    case (4); m = size(fint2%rhs_t); buf(1:m) = reshape(fint2%rhs_t, [m])
+    end select
+end subroutine ref_int2_get
+
+! f(nlines, n) in; res(nlines, n) inout (carries both boundary values)
+subroutine ref_int2_solve(nlines, f, res) bind(C, name='ref_int2_solve')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use FDM_Integral
+    use ref_state
+    implicit none
+    integer(c_int), value :: nlines
+    real(c_double), intent(in) :: f(nlines, gp(2)%size)
+    real(c_double), intent(inout) :: res(nlines, gp(2)%size)
+    real(wp), allocatable :: w(:, :)
+    allocate (w(nlines, 2))
+    call FDM_Int2_Solve(nlines, fint2, fint2%rhs, f, res, w)
+    deallocate (w)
+end subroutine ref_int2_solve

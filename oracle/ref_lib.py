@@ -126,6 +126,9 @@ def _poisson_sigs():
     L.ref_int1_get.argtypes = [c_int, c_int, _P, c_int]
     L.ref_int1_solve.argtypes = [c_int, c_int, _P, _P, _P]
     L.ref_ode2.argtypes = [c_int, c_int, c_dbl, _P, _P, _P, _P]
+    L.ref_int2_create.argtypes = [c_dbl, c_int, c_int]
+    L.ref_int2_get.argtypes = [c_int, _P, c_int]
+    L.ref_int2_solve.argtypes = [c_int, _P, _P]
     L._poisson_ready = True
     return L
 
@@ -154,6 +157,31 @@ def int1_solve(ibc, f, res):
     du = np.zeros(f.shape[1])
     L.ref_int1_solve(int(ibc), f.shape[1], f, r, du)
     return r, du
+
+
+def int2_create(lam2, ibc, factorize=True):
+    """FDM_Int2_Initialize (factorize) or FDM_Int2_CreateSystem from the y plan's second derivative; ibc = BCS_DD/ND/DN/NN = 0..3."""
+    _poisson_sigs().ref_int2_create(float(lam2), int(ibc), int(factorize))
+
+
+def int2_tables(n, ndr=5, ndl=3):
+    L = _poisson_sigs()
+
+    def get(which, rows, cols):
+        buf = np.zeros(rows * cols)
+        L.ref_int2_get(which, buf, buf.shape[0])
+        return buf.reshape(cols, rows).T.copy()
+
+    return {"lhs": get(1, n, ndr), "rhs": get(2, n, ndl), "rhs_b": get(3, 5, 8), "rhs_t": get(4, 5, 8)}
+
+
+def int2_solve(f, res):
+    """f, res: (n, nlines) C-ordered; res carries the two boundary values; returns the solution."""
+    L = _poisson_sigs()
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    r = np.ascontiguousarray(res, dtype=np.float64).copy()
+    L.ref_int2_solve(f.shape[1], f, r)
+    return r
 
 
 def ode2(itype, lam, f, bcs):

@@ -11,7 +11,7 @@ Vectorisation: every per-mode quantity carries a trailing mode axis M, so the wh
 """
 import numpy as np
 
-from .tlab_oracle import BCS_MIN, BCS_MAX, BCS_BOTH, BCS_NN, BCS_DD
+from .tlab_oracle import BCS_MIN, BCS_MAX, BCS_BOTH, BCS_NN, BCS_DD, BCS_ND, BCS_DN
 
 
 # ######################################################################################
@@ -411,3 +411,244 @@ def opr_poisson_fxz(plan, p, bcs_hb, bcs_ht, ibc=BCS_NN):
         return (np.fft.irfft(cc, n=nx, axis=2) * nx).reshape(-1)
 
     return back(u), back(v)
+
+
+# ######################################################################################
+# DIRECT elliptic solver (EllipticOrder = CompactDirect4/6): fdm/fdm_integral.f90:318-673, operators/opr_elliptic.f90:368-455
+# ######################################################################################
+def _Pi(x, j, idx):
+    """fdm/fdm_base.f90:31-44 (1-based j, idx)."""
+    f = 1.0
+    for k in idx:
+        f = f * (x[j - 1] - x[k - 1])
+    return f
+
+
+def _Pi_p(x, j, idx):
+    """fdm/fdm_base.f90:47-67."""
+    f = 0.0
+    for k in range(len(idx)):
+        dummy = 1.0
+        for m in range(len(idx)):
+            if m != k:
+                dummy = dummy * (x[j - 1] - x[idx[m] - 1])
+        f = f + dummy
+    return f
+
+
+def _Pi_pp_3(x, j, idx):
+    """fdm/fdm_base.f90:70-78."""
+    return 2.0 * (x[j - 1] - x[idx[0] - 1] + x[j - 1] - x[idx[1] - 1] + x[j - 1] - x[idx[2] - 1])
+
+
+def _Lag(x, j, i, idx):
+    """fdm/fdm_base.f90:82-97."""
+    f = 1.0
+    for k in idx:
+        if k != i:
+            f = f * (x[j - 1] - x[k - 1]) / (x[i - 1] - x[k - 1])
+    return f
+
+
+def _Lag_p(x, j, i, idx):
+    """fdm/fdm_base.f90:100-125."""
+    den, f = 1.0, 0.0
+    for k in range(len(idx)):
+        if idx[k] != i:
+            dummy = 1.0
+            for m in range(len(idx)):
+                if idx[m] != i and m != k:
+                    dummy = dummy * (x[j - 1] - x[idx[m] - 1])
+            f = f + dummy
+            den = den * (x[i - 1] - x[idx[k] - 1])
+    return f / den
+
+
+def coef_c1n4_biased(x, i, backwards=False):
+    """fdm/fdm_integral.f90:560-621 (contained in FDM_Int2_CreateSystem): p'_1 = b1 p1 + b2 p2 + b3 p3 + b4 p4 + a2 p''_2.  1-based i."""
+    i1 = i
+    i2, i3, i4 = (i - 1, i - 2, i - 3) if backwards else (i + 1, i + 2, i + 3)
+    X = lambda k: x[k - 1]      # noqa: E731
+    dx1, dx3, dx4 = X(i2) - X(i1), X(i2) - X(i3), X(i2) - X(i4)
+    sm = [i1, i3, i4]
+    a2 = 0.5 * (_Pi(x, i1, sm) - dx1 * _Pi_p(x, i1, sm)) / _Pi_p(x, i2, sm)
+    b2 = _Pi_p(x, i1, sm) * (2.0 * _Pi_p(x, i2, sm) + dx1 * _Pi_pp_3(x, i2, sm)) - _Pi(x, i1, sm) * _Pi_pp_3(x, i2, sm)
+    b2 = 0.5 * b2 / _Pi(x, i2, sm) / _Pi_p(x, i2, sm)
+
+    def bk(ik, dxk):
+        D = _Lag(x, i2, ik, sm) + dxk * _Lag_p(x, i2, ik, sm)
+        b = _Lag(x, i1, ik, sm) * (_Lag(x, i2, ik, sm) + 2 * dx1 * _Lag_p(x, i2, ik, sm)) \
+            - dx1 * _Lag_p(x, i1, ik, sm) * (_Lag(x, i2, ik, sm) + dx1 * _Lag_p(x, i2, ik, sm))
+        return -b / dxk / D
+
+    return np.array([bk(i1, dx1), b2, bk(i3, dx3), bk(i4, dx4), a2])
+
+
+class Int2Plan:
+    pass
+
+
+def int2_create_system(g, x, lam2, ibc):
+    """fdm/fdm_integral.f90:366-557 FDM_Int2_CreateSystem: (B - lambda2 A) u = A f with both boundary values given (Dirichlet), or the
+    Neumann values folded in through a 4th-order biased formula.  g: oracle DerPlan of the second derivative (tables), x: nodes,
+    lam2: (M,), ibc in BCS_DD/ND/DN/NN.  lhs: (n, ndr, M); rhs (n, ndl), rhs_b, rhs_t: lambda-independent."""
+    lam = np.atleast_1d(np.asarray(lam2, dtype=np.float64))
+    M = lam.shape[0]
+    ndl, ndr = g.nb_diag
+    idl, idr = ndl // 2 + 1, ndr // 2 + 1
+    nx = g.size
+    assert abs(idl - idr) <= 1
+    p = Int2Plan()
+    p.lam, p.bc, p.nx = lam, ibc, nx
+    A = g.lhs[:, :ndl].copy()                                           # fdmi%rhs (:393)
+    rhsr_b, rhsr_t = np.zeros((5, 8)), np.zeros((5, 8))
+    fdm_bcs_reduce(BCS_BOTH, A, g.rhs[:, :ndr], rhsr_b, rhsr_t)         # :395
+    rhs_b, rhs_t = np.zeros((5, 8)), np.zeros((5, 8))
+    rhs_b[0:idl + 1, 1:ndl + 1] = A[0:idl + 1, 0:ndl]                   # :400-403
+    for ir in range(1, idr):
+        rhs_b[ir, idl - ir] = -rhsr_b[ir, idr - ir]
+    rhs_t[0:idl + 1, 0:ndl] = A[nx - idl - 1:nx, 0:ndl]                 # :405-408
+    for ir in range(1, idr):
+        rhs_t[idl - ir, idl + ir - 1] = -rhsr_t[idr - ir, idr + ir - 1]
+    # new lhs diagonals C = B - lambda2 A (:412-418)
+    lhs = np.repeat(g.rhs[:, :ndr, None], M, axis=2).astype(np.float64)
+    lhs[:, idr - 1, :] = lhs[:, idr - 1, :] - lam * g.lhs[:, idl - 1, None]
+    for i in range(1, idl):
+        lhs[i:nx, idr - i - 1, :] = lhs[i:nx, idr - i - 1, :] - lam * g.lhs[i:nx, idl - i - 1, None]
+        lhs[0:nx - i, idr + i - 1, :] = lhs[0:nx - i, idr + i - 1, :] - lam * g.lhs[0:nx - i, idl + i - 1, None]
+    lhs[1:idr, 0:ndr, :] = rhsr_b[1:idr, 1:ndr + 1, None]               # :422-425
+    for ir in range(1, idr):
+        lhs[ir, idr - idl:idr + idl - 1, :] = lhs[ir, idr - idl:idr + idl - 1, :] - lam * rhs_b[ir, 1:ndl + 1, None]
+    lhs[nx - idr:nx - 1, 0:ndr, :] = rhsr_t[1:idr, 0:ndr, None]         # :429-432
+    for ir in range(1, idr):
+        lhs[nx - ir - 1, idr - idl:idr + idl - 1, :] = lhs[nx - ir - 1, idr - idl:idr + idl - 1, :] - lam * rhs_t[idl - ir, 0:ndl, None]
+    # Neumann corrections (:436-514)
+    if ibc in (BCS_ND, BCS_NN):
+        coef = coef_c1n4_biased(x, 1)
+        lhs[0, :, :] = 0.0
+        lhs[0, 0:3, :] = (-coef[1:4] / coef[0])[:, None]
+        rhs_b[0, :] = 0.0
+        rhs_b[0, idl] = 1.0 / coef[0]
+        rhs_b[0, idl + 1] = -coef[4] / coef[0]
+        lhs[0, 0, :] = lhs[0, 0, :] + lam * rhs_b[0, idl + 1]
+        for ir in range(1, idr):
+            lhs[ir, idr - ir:idr - ir + 3, :] = lhs[ir, idr - ir:idr - ir + 3, :] - rhs_b[ir, idl - ir] * lhs[0, 0:3, :]
+            rhs_b[ir, idl - ir + 1] = rhs_b[ir, idl - ir + 1] + rhs_b[ir, idl - ir] * rhs_b[0, idl + 1]
+            rhs_b[ir, idl - ir] = rhs_b[ir, idl - ir] * rhs_b[0, idl]
+    if ibc in (BCS_DN, BCS_NN):
+        coef = coef_c1n4_biased(x, nx, backwards=True)
+        lhs[nx - 1, :, :] = 0.0
+        lhs[nx - 1, ndr - 3:ndr, :] = (-coef[[3, 2, 1]] / coef[0])[:, None]
+        rhs_t[idl, :] = 0.0
+        rhs_t[idl, idl - 1] = 1.0 / coef[0]
+        rhs_t[idl, idl - 2] = -coef[4] / coef[0]
+        lhs[nx - 1, ndr - 1, :] = lhs[nx - 1, ndr - 1, :] + lam * rhs_t[idl, idl - 2]
+        for ir in range(1, idr):
+            lhs[nx - ir - 1, ir - 1:ir + 2, :] = lhs[nx - ir - 1, ir - 1:ir + 2, :] - rhs_t[idl - ir, idl + ir - 1] * lhs[nx - 1, ndr - 3:ndr, :]
+            rhs_t[idl - ir, idl + ir - 2] = rhs_t[idl - ir, idl + ir - 2] + rhs_t[idl - ir, idl + ir - 1] * rhs_t[idl, idl - 2]
+            rhs_t[idl - ir, idl + ir - 1] = rhs_t[idl - ir, idl + ir - 1] * rhs_t[idl, idl - 1]
+    # normalisation (:518-540): rows 2.. only
+    rhs = A
+    mx = max(idr, idl + 1)
+    for ir in range(2, mx + 1):
+        dummy = 1.0 / rhs[ir - 1, idl - 1]
+        rhs_b[ir - 1, 0:ndl + 1] = rhs_b[ir - 1, 0:ndl + 1] * dummy
+        dummy = 1.0 / rhs[nx - ir, idl - 1]
+        rhs_t[idl - ir + 1, 0:ndl + 1] = rhs_t[idl - ir + 1, 0:ndl + 1] * dummy
+        dummy = 1.0 / rhs[ir - 1, idl - 1]
+        rhs[ir - 1, 0:ndl] = rhs[ir - 1, 0:ndl] * dummy
+        lhs[ir - 1, 0:ndr, :] = lhs[ir - 1, 0:ndr, :] * dummy
+        dummy = 1.0 / rhs[nx - ir, idl - 1]
+        rhs[nx - ir, 0:ndl] = rhs[nx - ir, 0:ndl] * dummy
+        lhs[nx - ir, 0:ndr, :] = lhs[nx - ir, 0:ndr, :] * dummy
+    for ir in range(mx + 1, nx - mx + 1):
+        dummy = 1.0 / rhs[ir - 1, idl]
+        rhs[ir - 1, 0:ndl] = rhs[ir - 1, 0:ndl] * dummy
+        lhs[ir - 1, 0:ndr, :] = lhs[ir - 1, 0:ndr, :] * dummy
+    p.lhs, p.rhs, p.rhs_b, p.rhs_t = lhs, rhs, rhs_b, rhs_t
+    p.factorized = False
+    return p
+
+
+def int2_initialize(g, x, lam2, ibc):
+    """fdm/fdm_integral.f90:334-361 FDM_Int2_Initialize (5 LHS diagonals: PENTADFS on rows 2..n-1)."""
+    p = int2_create_system(g, x, lam2, ibc)
+    assert p.lhs.shape[1] == 5, "oracle: only the pentadiagonal second-order integral (tridiagonal A, pentadiagonal B) is restated"
+    cols = [p.lhs[1:p.nx - 1, k, :].copy() for k in range(5)]
+    pentadfs(*cols)
+    for k in range(5):
+        p.lhs[1:p.nx - 1, k, :] = cols[k]
+    p.factorized = True
+    return p
+
+
+def int2_solve(p, rhsi, f, res):
+    """fdm/fdm_integral.f90:626-671 FDM_Int2_Solve.  f, res: (n, nlines, M); res[0], res[n-1] carry the boundary values (function value for
+    a Dirichlet end, derivative for a Neumann end); res is overwritten with the solution."""
+    nx, lhs = p.nx, p.lhs
+    assert rhsi.shape[1] == 3
+    bcs_b, bcs_t = _matmul_3d_both(rhsi, f, res, p.rhs_b, p.rhs_t)
+    pentadss(lhs[1:nx - 1, 0], lhs[1:nx - 1, 1], lhs[1:nx - 1, 2], lhs[1:nx - 1, 3], lhs[1:nx - 1, 4], res[1:nx - 1])
+    ndl = 5
+    if p.bc in (BCS_ND, BCS_NN):
+        res[0] = bcs_b + lhs[0, 0] * res[1] + lhs[0, 1] * res[2] + lhs[0, 2] * res[3]
+    if p.bc in (BCS_DN, BCS_NN):
+        res[nx - 1] = bcs_t + lhs[nx - 1, ndl - 1] * res[nx - 2] + lhs[nx - 1, ndl - 2] * res[nx - 3] + lhs[nx - 1, ndl - 3] * res[nx - 4]
+    return res
+
+
+class PoissonDirectPlan:
+    """operators/opr_elliptic.f90:152-163,228-245 OPR_Elliptic_Initialize (TYPE_DIRECT, serial): lambda(k,i) from the SECOND-derivative
+    modified wavenumbers of x and z, one singular mode (1,1) solved with BCS_DN.  gy.der2 must hold a direct scheme (tables)."""
+
+    def __init__(self, gx, gy, gz, nx, ny, nz):
+        self.nx, self.ny, self.nz, self.nxh = nx, ny, nz, nx // 2 + 1
+        self.gy = gy
+        kx = gx.der2.mwn[: self.nxh]
+        if nz > 1:
+            self.lam2 = kx[None, :] + gz.der2.mwn[:nz][:, None]
+        else:
+            self.lam2 = kx[None, :] * np.ones((1, 1))
+        self.norm = 1.0 / float(nx * nz)
+        self.sing = np.zeros((max(nz, 1), self.nxh), dtype=bool)
+        self.sing[0, 0] = True
+
+
+def opr_poisson_fxz_direct(plan, p, bcs_hb, bcs_ht, ibc=BCS_NN, gy_der=None):
+    """operators/opr_elliptic.f90:368-455 OPR_Poisson_FourierXZ_Direct.  Returns (p, dpdy) flat; dpdy = OPR_Partial_Y(OPR_P1) of p with the
+    y plan of the derivatives (gy_der, default plan.gy), :447-449."""
+    from .tlab_oracle import opr_partial
+    nx, ny, nz, nxh = plan.nx, plan.ny, plan.nz, plan.nxh
+    a = np.array(p, dtype=np.float64).reshape(nz, ny, nx).copy()
+    a[:, 0, :] = bcs_hb.reshape(nz, nx)                                  # :392-393
+    a[:, ny - 1, :] = bcs_ht.reshape(nz, nx)
+    c = np.fft.rfft(a, axis=2)
+    if nz > 1:
+        c = np.fft.fft(c, axis=0)
+    c = c * plan.norm                                                    # :402
+    M = nz * nxh
+    f = np.empty((ny, 2, M))
+    f[:, 0, :] = c.real.transpose(1, 0, 2).reshape(ny, M)
+    f[:, 1, :] = c.imag.transpose(1, 0, 2).reshape(ny, M)
+    u = np.zeros_like(f)
+    u[0], u[ny - 1] = f[0], f[ny - 1]                                    # :416-417
+    lam = plan.lam2.reshape(M)
+    sing = plan.sing.reshape(M)
+    g2, x = plan.gy.der2, plan.gy.nodes
+    reg = ~sing if ibc == BCS_NN else np.ones(M, dtype=bool)
+    pr = int2_initialize(g2, x, lam[reg], ibc)
+    ur = u[:, :, reg]
+    int2_solve(pr, pr.rhs, f[:, :, reg], ur)
+    u[:, :, reg] = ur
+    if ibc == BCS_NN:                                                    # :420-424 with :236-240: compatibility constraint, p = 0 at the bottom
+        ps = int2_initialize(g2, x, lam[sing], BCS_DN)
+        us = u[:, :, sing]
+        us[0] = 0.0
+        int2_solve(ps, ps.rhs, f[:, :, sing], us)
+        u[:, :, sing] = us
+    cc = (u[:, 0, :] + 1j * u[:, 1, :]).reshape(ny, nz, nxh).transpose(1, 0, 2)
+    if nz > 1:
+        cc = np.fft.ifft(cc, axis=0) * nz
+    pout = (np.fft.irfft(cc, n=nx, axis=2) * nx).reshape(-1)
+    dpdy = opr_partial(2, 1, nx, ny, nz, 0, gy_der if gy_der is not None else plan.gy, pout)[0]
+    return pout, dpdy

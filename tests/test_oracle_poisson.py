@@ -64,3 +64,78 @@ def test_poisson_discrete_identity(nx, ny, nz):
     assert np.abs(res).max() / np.abs(f).max() <= 1e-12
     # the reference pins p = 0 at the bottom wall for the mean mode (opr_odes.f90:179-180)
     assert abs(p.reshape(nz, ny, nx)[:, 0, :].mean()) <= 1e-12 * np.abs(p).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# DIRECT elliptic solver (EllipticOrder = CompactDirect6): FDM_Int2_* and OPR_Poisson_FourierXZ_Direct
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _direct_plan_from(g, prefix="tab_", nodes_key="y"):
+    tab = {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+    tab["nodes"] = g[nodes_key]
+    return O.FdmPlan.from_tables(tab)
+
+
+@pytest.mark.parametrize("path", golden_files("poisson_direct_modes_"))
+def test_int2_matches_golden(path):
+    g = np.load(path)
+    y = g["y"]; n = y.shape[0]
+    gy = _direct_plan_from(g)
+    for il, lam in enumerate(g["lams"]):
+        for ibc in (0, 1, 2, 3):
+            if "lu_l%d_bc%d_lhs" % (il, ibc) not in g.files:
+                continue
+            p = OP.int2_initialize(gy.der2, y, lam, ibc)
+            for k, a in (("lhs", p.lhs[:, :, 0]), ("rhs", p.rhs), ("rhs_b", p.rhs_b), ("rhs_t", p.rhs_t)):
+                assert rel_err(a, g["lu_l%d_bc%d_%s" % (il, ibc, k)]) <= TOL, (il, ibc, k)
+            f = g["int2_l%d_bc%d_f" % (il, ibc)]
+            r = g["int2_l%d_bc%d_res0" % (il, ibc)].copy().reshape(n, 2, 1)
+            OP.int2_solve(p, p.rhs, f.reshape(n, 2, 1), r)
+            assert rel_err(r[:, :, 0], g["int2_l%d_bc%d_res" % (il, ibc)]) <= TOL, (il, ibc)
+
+
+@pytest.mark.parametrize("ny,nx,nz,ibc", [(24, 16, 8, 3), (64, 16, 1, 3), (64, 8, 8, 0), (24, 8, 8, 1), (24, 8, 8, 2)])
+def test_poisson_direct_discrete_identity(ny, nx, nz, ibc):
+    """(d2/dx2 + d2/dy2 + d2/dz2) p = f at the interior rows with the second-derivative operators of the plans (direct in y), and the
+    boundary rows carry the data: Dirichlet value, or -- Neumann -- the 4th-order biased derivative of fdm_integral.f90:436-514."""
+    g = np.load(golden_files("direct_y")[0])
+    tab = {k[len("ny%d_" % ny):]: g[k] for k in g.files if k.startswith("ny%d_" % ny)}
+    gy = O.FdmPlan.from_tables(tab)
+    y = gy.nodes
+    x = np.arange(nx) / nx * 2 * np.pi
+    z = np.arange(nz) / nz * 2 * np.pi
+    gx, gz = O.FdmPlan(x, True, True), O.FdmPlan(z, True, True)
+    rng = np.random.default_rng(ny + ibc)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    f = (np.sin(X) * np.cos(Z) * np.exp(Y) + 0.2 * rng.uniform(-1, 1, X.shape)).ravel()
+    hb, ht = rng.uniform(-1, 1, (nz, nx)), rng.uniform(-1, 1, (nz, nx))
+    plan = OP.PoissonDirectPlan(gx, gy, gz, nx, ny, nz)
+    p, dpdy = OP.opr_poisson_fxz_direct(plan, f, hb, ht, ibc)
+
+    def P2(d, gg, u):
+        return O.opr_partial(d, 2, nx, ny, nz, 0, gg, u)[0]
+
+    lap = P2(1, gx, p) + P2(2, gy, p) + (P2(3, gz, p) if nz > 1 else 0.0)
+    L3, F3, P3 = lap.reshape(nz, ny, nx), f.reshape(nz, ny, nx), p.reshape(nz, ny, nx)
+    if ibc == 3:      # the mean mode is solved with p = 0 at the bottom instead of its Neumann datum: compare without the xz-mean
+        L3 = L3 - L3.mean(axis=(0, 2), keepdims=True)
+        F3 = F3 - F3.mean(axis=(0, 2), keepdims=True)
+    assert rel_err(L3[:, 3:ny - 3, :], F3[:, 3:ny - 3, :]) <= 1e-9
+    if ibc in (0, 2):
+        assert rel_err(P3[:, 0, :], hb) <= 1e-12
+    if ibc in (0, 1):
+        assert rel_err(P3[:, ny - 1, :], ht) <= 1e-12
+    # Neumann ends: p'_1 = b1 p1 + b2 p2 + b3 p3 + b4 p4 + a2 p''_2 with p''_2 = (f - d2p/dx2 - d2p/dz2)_2 (fdm_integral.f90:436-514)
+    rest = f.reshape(nz, ny, nx) - (P2(1, gx, p) + (P2(3, gz, p) if nz > 1 else 0.0)).reshape(nz, ny, nx)
+    if ibc in (1, 3):
+        c = OP.coef_c1n4_biased(y, 1)
+        got = c[0] * P3[:, 0] + c[1] * P3[:, 1] + c[2] * P3[:, 2] + c[3] * P3[:, 3] + c[4] * rest[:, 1]
+        want = hb
+        if ibc == 3:      # the mean mode has p = 0 at the bottom instead (compatibility constraint, opr_elliptic.f90:420-421)
+            got, want = got - got.mean(), want - want.mean()
+            assert abs(P3[:, 0].mean()) <= 1e-13 * np.abs(P3).max()
+        assert rel_err(got, want) <= 1e-10
+    if ibc in (2, 3):
+        c = OP.coef_c1n4_biased(y, ny, backwards=True)
+        got = c[0] * P3[:, ny - 1] + c[1] * P3[:, ny - 2] + c[2] * P3[:, ny - 3] + c[3] * P3[:, ny - 4] + c[4] * rest[:, ny - 2]
+        assert rel_err(got, ht) <= 1e-10
+    assert np.isfinite(dpdy).all()

@@ -675,6 +675,7 @@ int tlab_force_kernel_path(int path) {
 int tlab_set_tuning(int key, int value) {
     if (key == 1) { rtile_force_chunk(value); return TLAB_OK; }
     if (key == 2) { g_htile_policy = value; return TLAB_OK; }
+    if (key == 3 && (value == 16 || value == 32)) { htile_set_lines(value); return TLAB_OK; }
     g_err = "tlab_set_tuning: unknown key";
     return TLAB_EINVAL;
 }

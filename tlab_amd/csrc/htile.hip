@@ -10,6 +10,8 @@
 // loads that hit L1 instead of scalar loads).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_tables.hpp"
 #include "kernels.hpp"
 #include "profile.hpp"
@@ -27,7 +29,7 @@ __device__ __forceinline__ double h_dense6(const double (&c)[6], double a0, doub
 }
 
 // local Thomas solve of one chunk + separator system through LDS.  f: right-hand side in, solution out.
-template <int M>
+template <int M, int L>
 __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, const double *ginv, int n, int row0, int c, int C, int l32,
                                         double *s_yl, double *s_r) {
     const double *Lm = rowtab + row0, *Di = rowtab + n + row0, *Cm = rowtab + 2 * n + row0;
@@ -44,16 +46,16 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
         yn = f[p] * Di[p] + Cm[p] * yn;
         f[p] = yn;
     }
-    s_yl[c * 32 + l32] = f[M - 1];
+    s_yl[c * L + l32] = f[M - 1];
     __syncthreads();
     const int cm = (c + C - 1) % C, cp = (c + 1) % C;
-    const double yLprev = s_yl[cm * 32 + l32];
-    s_r[c * 32 + l32] = f[0] - Lm[0] * yLprev - Cm[0] * f[1];
+    const double yLprev = s_yl[cm * L + l32];
+    s_r[c * L + l32] = f[0] - Lm[0] * yLprev - Cm[0] * f[1];
     __syncthreads();
     double X = 0.0, Xr = 0.0;
     const double *g0 = ginv + c * C, *g1 = ginv + cp * C;
     for (int q = 0; q < C; ++q) {
-        const double rq = s_r[q * 32 + l32];
+        const double rq = s_r[q * L + l32];
         X += g0[q] * rq;
         Xr += g1[q] * rq;
     }
@@ -62,18 +64,19 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
     for (int p = 1; p < M; ++p) f[p] = f[p] + Vt[p] * X + Wt[p] * Xr;
 }
 
-template <int M, int MODE, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
-    __shared__ double s_yl[32 * 32];
-    __shared__ double s_r[32 * 32];
-    __shared__ double s_e[2 * 32 * 32];   // first-derivative edge values of every chunk (Jacobian correction)
+// L = lines per tile: 32 (a wave holds two chunks) or 16 (four chunks; half the tile, so that TWO workgroups fit a CU and one can
+// load or store while the other solves)
+template <int M, int MODE, int MAXT, int L>
+__global__ void __launch_bounds__(MAXT, (L == 16 ? 2 : 1)) k_htile(RTileArgs a) {
+    __shared__ double s_yl[32 * L];
+    __shared__ double s_r[32 * L];
+    __shared__ double s_e[2 * 32 * L];   // first-derivative edge values of every chunk (Jacobian correction)
     extern __shared__ double s_tab[];     // coefficient rows of both systems, separator inverses, Jacobian-correction diagonals
     constexpr bool NEED1 = (MODE == MODE_P1 || MODE == MODE_P2_P1 || MODE == MODE_BURGERS);
     constexpr bool NEED2 = (MODE != MODE_P1);
-    const int lane = threadIdx.x & 63;
-    const int l32 = lane & 31;
-    const int c = 2 * (threadIdx.x >> 6) + (lane >> 5);
-    const int C = blockDim.x >> 5;
+    const int l32 = threadIdx.x & (L - 1);
+    const int c = threadIdx.x / L;
+    const int C = blockDim.x / L;
     const int n = a.g.n;
     const long long rs = a.g.row_stride;
     const bool per = a.s1.periodic != 0;
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
     // to the 8 XCDs (each with its own L2), so the nf workgroups of a tile get ids with the same residue mod 8 and follow each other
     // closely in the dispatch order: bid = x + 8 (f + nf y), tile = x + 8 y.  The velocity tile is then fetched from HBM once and the
     // other fields' reads of it hit (or merge in) that XCD's L2.
-    const int tiles_inner = (a.g.lines_inner + 31) >> 5;
+    const int tiles_inner = (a.g.lines_inner + L - 1) / L;
     long long tile = blockIdx.x;
     int fi = 0;
     if (MODE == MODE_BURGERS) {
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
         if (tile >= (long long)tiles_inner * (a.g.nlines / a.g.lines_inner)) return;     // whole workgroup, before any barrier
     }
     const long long outer = tile / tiles_inner;
-    const int l0 = (int)(tile % tiles_inner) << 5;
+    const int l0 = (int)(tile % tiles_inner) * L;
     const bool valid = (l0 + l32) < a.g.lines_inner;
     const long long base = outer * a.g.outer_stride + l0 + l32;
     const int row0 = c * M;
@@ -181,16 +184,16 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
     }
 
     // ---- first derivative ----
-    if (NEED1 || (NEED2 && corr)) h_solve<M>(x1, t1, gi1, n, row0, c, C, l32, s_yl, s_r);
+    if (NEED1 || (NEED2 && corr)) h_solve<M, L>(x1, t1, gi1, n, row0, c, C, l32, s_yl, s_r);
 
     // ---- second derivative (+ Jacobian correction  f += A2 dx2 du, MatMul_3d_add fdm_matmul.f90:126-153) ----
     if constexpr (NEED2) {
         if (corr) {
-            s_e[(2 * c + 0) * 32 + l32] = x1[0];
-            s_e[(2 * c + 1) * 32 + l32] = x1[M - 1];
+            s_e[(2 * c + 0) * L + l32] = x1[0];
+            s_e[(2 * c + 1) * L + l32] = x1[M - 1];
             __syncthreads();
-            const double dl = (c > 0) ? s_e[(2 * (c - 1) + 1) * 32 + l32] : 0.0;   // du at row0 - 1
-            const double dr = (c < C - 1) ? s_e[(2 * (c + 1) + 0) * 32 + l32] : 0.0;  // du at row0 + M
+            const double dl = (c > 0) ? s_e[(2 * (c - 1) + 1) * L + l32] : 0.0;   // du at row0 - 1
+            const double dr = (c < C - 1) ? s_e[(2 * (c + 1) + 0) * L + l32] : 0.0;  // du at row0 + M
             const double *j1 = tj + row0, *j2 = tj + n + row0, *j3 = tj + 2 * n + row0;
 #pragma unroll
             for (int p = 0; p < M; ++p) {
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
                 x2[p] = x2[p] + add;
             }
         }
-        h_solve<M>(x2, t2, gi2, n, row0, c, C, l32, s_yl, s_r);
+        h_solve<M, L>(x2, t2, gi2, n, row0, c, C, l32, s_yl, s_r);
     }
 
     // ---- epilogue ----
@@ -234,6 +237,9 @@ __global__ void __launch_bounds__(MAXT) k_htile(RTileArgs a) {
     }   // valid
 }
 
+static int g_htile_lines = [] { const char *e = getenv("TLAB_HTILE_LINES"); return (e && atoi(e) == 16) ? 16 : 32; }();
+void htile_set_lines(int lines) { g_htile_lines = lines; }
+
 // chunk length of the half-wave-tile kernel for a line length n and a mode (0 = unsupported)
 int htile_chunk(int n, int mode) {
     const bool two = (mode == MODE_P2_P1 || mode == MODE_BURGERS);   // two line-sets live in registers
@@ -249,10 +255,10 @@ int htile_chunk(int n, int mode) {
     return 0;
 }
 
-template <int M, int MAXT>
+template <int M, int MAXT, int L = 32>
 static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileArgs &a, hipStream_t st) {
     const long long nwg = (mode == MODE_BURGERS) ? 8LL * a.nf * ((tiles + 7) / 8) : tiles;      // see the blockIdx mapping in the kernel
-    const dim3 grid((unsigned)nwg), block(32 * C);
+    const dim3 grid((unsigned)nwg), block(L * C);
     const size_t lds = ((size_t)(a.s2.rowc ? 15 : 13) * a.g.n + (size_t)2 * C * C) * sizeof(double);     // 10n tables + max(3n correction, 5n per-row RHS)
     const double pts = (double)a.g.nlines * a.g.n;
     const char *name = mode == MODE_P1 ? "k_htile<P1>" : mode == MODE_P2 ? "k_htile<P2>" : mode == MODE_P2_P1 ? "k_htile<P2_P1>" : "k_htile<BURGERS>";
@@ -264,10 +270,10 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
     }
     ProfScope ps(name, st, bytes);
     switch (mode) {
-    case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT>), grid, block, lds, st, a); break;
-    case MODE_P2: hipLaunchKernelGGL((k_htile<M, MODE_P2, MAXT>), grid, block, lds, st, a); break;
-    case MODE_P2_P1: hipLaunchKernelGGL((k_htile<M, MODE_P2_P1, MAXT>), grid, block, lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT>), grid, block, lds, st, a); break;
+    case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT, L>), grid, block, lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_htile<M, MODE_P2, MAXT, L>), grid, block, lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_htile<M, MODE_P2_P1, MAXT, L>), grid, block, lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -279,8 +285,11 @@ hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st) {
     if (M == 0) return hipErrorInvalidValue;
     const int C = n / M;
     if (C & 1) return hipErrorInvalidValue;      // two chunks per wave
-    const long long tiles_inner = (a.g.lines_inner + 31) / 32;
+    const bool narrow = (g_htile_lines == 16) && mode == MODE_BURGERS && M == 32 && C <= 16;
+    const int L = narrow ? 16 : 32;
+    const long long tiles_inner = (a.g.lines_inner + L - 1) / L;
     const long long tiles = tiles_inner * (a.g.nlines / a.g.lines_inner);
+    if (narrow) return launch_htile_m<32, 256, 16>(mode, C, tiles, a, st);
     if (M == 64) return launch_htile_m<64, 512>(mode, C, tiles, a, st);
     if (M == 32) return (C <= 16) ? launch_htile_m<32, 512>(mode, C, tiles, a, st) : launch_htile_m<32, 1024>(mode, C, tiles, a, st);
     return (C <= 16) ? launch_htile_m<16, 512>(mode, C, tiles, a, st) : launch_htile_m<16, 1024>(mode, C, tiles, a, st);

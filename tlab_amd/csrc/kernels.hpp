@@ -73,6 +73,7 @@ void rtile_force_chunk(int m);
 hipError_t launch_xline(int mode, int n, bool lane_variant, const XLineArgs &a, hipStream_t st);
 hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st);
 int htile_chunk(int n, int mode);
+void htile_set_lines(int lines);   // tuning: 16 = narrow Burgers tiles (two workgroups per CU)
 hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st);
 hipError_t launch_generic(bool sym, const GenericArgs &a, hipStream_t st);
 hipError_t launch_burgers_epilogue(double *out, const double *vel, const double *d1, double nu, long long ntot, hipStream_t st);
