@@ -141,6 +141,18 @@ int tlab_poisson_plan_destroy(tlab_poisson_plan_t p);
 int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,
                      const double *bcs_hb, const double *bcs_ht, double *dpdy);
 
+/* EllipticOrder = CompactDirect6: OPR_Elliptic_Initialize with TYPE_DIRECT (operators/opr_elliptic.f90:107-163, 228-245) and
+ * OPR_Poisson_FourierXZ_Direct (:368-455).  gy_elliptic is the reference's fdm_loc: a y plan whose second derivative holds the CompactDirect6
+ * tables (tlab_fdm_plan_create_from_arrays + tlab_fdm_plan_set_scheme(.., 16) + tlab_fdm_plan_set_aux(.. nodes)); gy stays the plan of the
+ * derivatives (dp/dy = OPR_Partial_Y(OPR_P1, p), :447-449; NOT owned, must outlive the Poisson plan).  lambda(k,i) = mwn2_x(i) + mwn2_z(k) from
+ * the SECOND-derivative modified wavenumbers of gx, gz; one singular mode (1,1), solved with BCS_DN and p = 0 at the bottom.  Per mode one
+ * second-order integral solve (FDM_Int2_Initialize / FDM_Int2_Solve, fdm/fdm_integral.f90:334-673).  With such a plan tlab_opr_poisson accepts
+ * ibc = TLAB_BCS_DD / ND / DN / NN (bcs_hb, bcs_ht: function value at a D end, derivative at an N end).  Single-rank boxes only. */
+int tlab_poisson_plan_create_direct(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                                    int nx, int ny, int nz, tlab_fdm_plan_t gy_elliptic);
+/* the per-mode stage of a direct plan on spectral fields (nx/2+1, ny, nz) complex: f_hat -> p_hat (may alias) */
+int tlab_poisson_direct_ode(tlab_poisson_plan_t plan, int ibc, double *f_hat, double *p_hat);
+
 /* z-slab variant (ims_npro_k = nproc_k ranks, one GPU each; base/tlab_mpi_procs.f90:76-94): this rank owns planes
  * [koffset, koffset + kmax) of nz_total.  The per-mode tables are built for the rank's own kz range (opr_elliptic.f90:167-194)
  * and the z transform works on the K-transposed layout (nlines = (nx/2+1)*ny/nproc_k lines of nz_total points).  Such a plan is

@@ -305,6 +305,192 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 }
 
 // ================================================================================================
+// k_int2 : FDM_Int2_Solve of the DIRECT elliptic solver (EllipticOrder = CompactDirect6; OPR_Poisson_FourierXZ_Direct,
+// opr_elliptic.f90:368-455): ONE pentadiagonal solve per Fourier mode, (B - lambda2 A) p^ = A f^ with both boundary data in the wall
+// planes of f^.  Same marching scheme as k_int1 (thread = mode, LU of the mode regenerated on the fly, forward-substituted line and U
+// factors through a scratch array), and the solution goes straight into the spectral field p^ (no superposition stage).  The Neumann
+// problem amplifies last-bit differences of the matrix entries and of the elimination to 1e-12 .. 5e-12 in p (measured with an affine
+// table and fused multiply-adds), so this kernel repeats the reference's operations in the reference's order with FP contraction OFF:
+// given the same f^ it returns the same bits as FDM_Int2_Initialize + FDM_Int2_Solve on the CPU.
+// ================================================================================================
+struct Int2Dev {
+    const double *Bt, *A5, *s, *R;   // row-major [n][5], [n][5], [n], [n][3] (poisson_host.hpp)
+    double rb[3][4], rt[3][4];
+    double c1[3], e1, nb[2], cn[3], en, nt[2];
+    int n;
+};
+
+struct Int2Args {
+    Int2Dev T;
+    const double *lam;      // [nm] lambda2 = mwn2_x + mwn2_z of each mode
+    long long nm;           // modes of the spectral box
+    long long first, count; // threads cover modes [first, first + count)
+    long long skip;         // mode left out (the singular one, solved by its own launch with the BCS_DN tables), or -1
+    const double *fsrc;     // complex field (nxh, ny, nz)
+    double *dst;            // complex field (nxh, ny, nz); may alias fsrc (a thread reads its whole column before it writes it)
+    double fscale;          // 1/(nx*nz) (opr_elliptic.f90:402)
+    int nxh, ny;
+    int zero_bottom;        // compatibility constraint of the singular mode: p = 0 at the bottom (opr_elliptic.f90:420-421)
+    int neumann_b, neumann_t;
+    double *scratch;        // SoA [(k*n + j)*nm + t], k < 5
+};
+
+template <int U>
+__global__ void __launch_bounds__(256) k_int2(Int2Args a) {
+#pragma clang fp contract(off)
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.count) return;
+    const long long t = a.first + q;
+    if (t == a.skip) return;
+    const int n = a.T.n;
+    const long long nm = a.nm;
+    const double lam = a.lam[t];
+    const long long fidx0 = (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh);
+    const double2 *__restrict__ fs = reinterpret_cast<const double2 *>(a.fsrc);
+    auto loadf = [&](int j, double (&f)[2]) {
+        const double2 v = fs[fidx0 + (long long)j * a.nxh];
+        f[0] = v.x * a.fscale; f[1] = v.y * a.fscale;
+    };
+    // rows 1 and n of the Neumann system (fdm_integral.f90:446-452, 485-491)
+    double l1[3] = {a.T.c1[0], a.T.c1[1], a.T.c1[2]}, lN[3] = {a.T.cn[0], a.T.cn[1], a.T.cn[2]};
+    l1[0] = l1[0] + lam * a.T.e1;
+    lN[2] = lN[2] + lam * a.T.en;
+    double res0[2], resN[2], fm[2] = {0.0, 0.0}, fc[2], fp[2];
+    loadf(0, res0); loadf(n - 1, resN);                       // u(1:2) = f(1:2), u(2ny-1:2ny) = f(...) (opr_elliptic.f90:416-417)
+    if (a.zero_bottom) res0[0] = res0[1] = 0.0;
+    loadf(1, fc); loadf(2, fp);
+    double bcs_b[2], bcs_t[2] = {0.0, 0.0};
+#pragma unroll
+    for (int l = 0; l < 2; ++l) bcs_b[l] = res0[l] * a.T.rb[0][2] + fc[l] * a.T.rb[0][3] + fp[l] * a.T.rb[0][1];   // MatMul_3d, BCS_BOTH
+
+    // ---- forward: right-hand side (MatMul_3d), LU on the fly (PENTADFS), forward substitution (PENTADSS) ----
+    double c1 = 0.0, c2 = 0.0, d1 = 0.0, d2 = 0.0, e1 = 0.0, e2 = 0.0;
+    double y1[2] = {0.0, 0.0}, y2[2] = {0.0, 0.0};
+    const int nmax = n - 2;
+    for (int jb = 1; jb <= nmax; jb += U) {
+        double fqb[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jr = jb + u + 2;
+            if (jr <= n - 1) loadf(jr, fqb[u]);
+            else fqb[u][0] = fqb[u][1] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u;
+            if (j > nmax) break;
+            double r[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) r[k] = a.T.Bt[j * 5 + k] - lam * a.T.A5[j * 5 + k];      // :412-432
+            if (a.neumann_b && (j == 1 || j == 2)) {       // rows 2, 3: lhs(1+ir, idr-ir+1 : idr-ir+3) -= rhs_b(1+ir, idl-ir) * lhs(1, 1:3)  (:462-464)
+                const int k0 = 3 - j;
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) r[k0 + qq] = r[k0 + qq] - a.T.nb[j - 1] * l1[qq];
+            }
+            if (a.neumann_t && (j == n - 2 || j == n - 3)) {   // rows n-1, n-2: lhs(nx-ir, ir : ir+2) -= rhs_t(idl-ir, idl+ir) * lhs(nx, ndr-2:ndr)  (:501-503)
+                const int ir = n - 1 - j;
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) r[ir - 1 + qq] = r[ir - 1 + qq] - a.T.nt[ir - 1] * lN[qq];
+            }
+            {
+                const double sj = a.T.s[j];                  // :518-540
+#pragma unroll
+                for (int k = 0; k < 5; ++k) r[k] = r[k] * sj;
+            }
+            double rhs[2];
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                if (j == 1) rhs[l] = res0[l] * a.T.rb[1][1] + fc[l] * a.T.rb[1][2] + fp[l] * a.T.rb[1][3];
+                else if (j == 2) rhs[l] = res0[l] * a.T.rb[2][0] + fm[l] * a.T.rb[2][1] + fc[l] * a.T.rb[2][2] + fp[l] * a.T.rb[2][3];
+                else if (j == n - 3) rhs[l] = fm[l] * a.T.rt[0][0] + fc[l] * a.T.rt[0][1] + fp[l] * a.T.rt[0][2] + resN[l] * a.T.rt[0][3];
+                else if (j == n - 2) rhs[l] = fm[l] * a.T.rt[1][0] + fc[l] * a.T.rt[1][1] + resN[l] * a.T.rt[1][2];
+                else rhs[l] = fm[l] * a.T.R[j * 3 + 0] + fc[l] * a.T.R[j * 3 + 1] + fp[l];
+            }
+            if (j == n - 2) {
+#pragma unroll
+                for (int l = 0; l < 2; ++l) bcs_t[l] = fm[l] * a.T.rt[2][2] + fc[l] * a.T.rt[2][0] + resN[l] * a.T.rt[2][1];
+            }
+            double am = 0.0, bm = 0.0, cm = r[2], dm = r[3], em = r[4];
+            if (j == 2) {
+                bm = r[1] / c1;
+                cm = r[2] - bm * d1;
+                dm = r[3] - bm * e1;
+            } else if (j >= 3) {
+                am = r[0] / c2;
+                bm = (r[1] - am * d2) / c1;
+                cm = r[2] - bm * d1 - am * e2;
+                dm = r[3] - bm * e1;
+            }
+            const double cinv = 1.0 / cm;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double y = rhs[l] - y1[l] * bm - y2[l] * am;
+                a.scratch[((long long)l * n + j) * nm + t] = y;
+                y2[l] = y1[l];
+                y1[l] = y;
+            }
+            a.scratch[((long long)2 * n + j) * nm + t] = cinv;
+            a.scratch[((long long)3 * n + j) * nm + t] = -dm;
+            a.scratch[((long long)4 * n + j) * nm + t] = -em;
+            c2 = c1; d2 = d1; e2 = e1;
+            c1 = cm; d1 = dm; e1 = em;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) { fm[l] = fc[l]; fc[l] = fp[l]; fp[l] = fqb[u][l]; }
+        }
+    }
+
+    // ---- backward substitution, straight into the spectral field ----
+    double2 *__restrict__ ds = reinterpret_cast<double2 *>(a.dst);
+    double x1[2] = {0.0, 0.0}, x2[2] = {0.0, 0.0};
+    double xs[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};     // x[1..3]
+    double xe[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};     // x[n-2], x[n-3], x[n-4]
+    for (int jb = nmax; jb >= 1; jb -= U) {
+        double yb[U][2], cb[U], db[U], eb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb - u;
+            const int jr = j >= 1 ? j : 1;
+            cb[u] = a.scratch[((long long)2 * n + jr) * nm + t];
+            db[u] = a.scratch[((long long)3 * n + jr) * nm + t];
+            eb[u] = a.scratch[((long long)4 * n + jr) * nm + t];
+            yb[u][0] = a.scratch[((long long)0 * n + jr) * nm + t];
+            yb[u][1] = a.scratch[((long long)1 * n + jr) * nm + t];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb - u;
+            if (j < 1) break;
+            double x[2];
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                x[l] = (yb[u][l] + x1[l] * db[u] + x2[l] * eb[u]) * cb[u];
+                x2[l] = x1[l];
+                x1[l] = x[l];
+                if (j <= 3) xs[j - 1][l] = x[l];
+                if (j >= n - 4) xe[n - 2 - j][l] = x[l];
+            }
+            ds[fidx0 + (long long)j * a.nxh] = make_double2(x[0], x[1]);
+        }
+    }
+
+    // ---- end values: given (Dirichlet) or from the biased first-derivative formula (Neumann), fdm_integral.f90:659-668 ----
+    double r0[2], rN[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) { r0[l] = res0[l]; rN[l] = resN[l]; }
+    if (a.neumann_b) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) r0[l] = bcs_b[l] + l1[0] * xs[0][l] + l1[1] * xs[1][l] + l1[2] * xs[2][l];
+    }
+    if (a.neumann_t) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) rN[l] = bcs_t[l] + lN[2] * xe[0][l] + lN[1] * xe[1][l] + lN[0] * xe[2][l];
+    }
+    ds[fidx0] = make_double2(r0[0], r0[1]);
+    ds[fidx0 + (long long)(n - 1) * a.nxh] = make_double2(rN[0], rN[1]);
+}
+
+
+// ================================================================================================
 // k_ode_nn : OPR_ODE2_Factorize_NN for a group of modes with the y-line cut into chunks of 8 rows that live in registers.
 //
 // k_int1 marches one thread per mode along the whole line: 512 dependent steps, twice, with every intermediate of the
@@ -1151,6 +1337,31 @@ struct tlab_poisson_plan {
     bool use_2d = false;
     bool fz_inplace = false;          // z-transform plans built in place (kx-pencil plans: rocFFT then picks its column kernel, ~3x faster)
     hipStream_t side = nullptr;       // the <= 4 singular modes are solved beside the regular ones
+    // DIRECT elliptic solver (EllipticOrder = CompactDirect6): one second-order integral operator per boundary type, built on first use
+    bool direct = false;
+    tlab_fdm_plan_t gy_der = nullptr;         // y plan of the derivatives (dp/dy = OPR_Partial_Y(p), opr_elliptic.f90:447-449); not owned
+    DerTables ell_der2;                       // second derivative of the elliptic y plan (fdm_loc%der2)
+    std::vector<double> ell_nodes;
+    struct Int2Set { Int2Tables host; DBuf Bt, A5, s, R; };
+    std::unique_ptr<Int2Set> int2[4];
+    long long sing_direct = -1;               // local index of the mode (1,1), or -1 when another rank owns it
+    Int2Dev dev2(int ibc) {
+        if (!int2[ibc]) {
+            auto e = std::make_unique<Int2Set>();
+            int2_build_tables(ell_der2, ell_nodes, ibc, e->host);
+            e->Bt.upload(e->host.Bt); e->A5.upload(e->host.A5); e->s.upload(e->host.s); e->R.upload(e->host.R);
+            int2[ibc] = std::move(e);
+        }
+        Int2Set &E = *int2[ibc];
+        Int2Dev d;
+        d.Bt = E.Bt.p; d.A5 = E.A5.p; d.s = E.s.p; d.R = E.R.p; d.n = ny;
+        for (int j = 0; j < 3; ++j)
+            for (int c = 0; c < 4; ++c) { d.rb[j][c] = E.host.rb[j][c]; d.rt[j][c] = E.host.rt[j][c]; }
+        for (int q = 0; q < 3; ++q) { d.c1[q] = E.host.c1[q]; d.cn[q] = E.host.cn[q]; }
+        d.e1 = E.host.e1; d.en = E.host.en;
+        for (int q = 0; q < 2; ++q) { d.nb[q] = E.host.nb[q]; d.nt[q] = E.host.nt[q]; }
+        return d;
+    }
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~tlab_poisson_plan() {
         if (d_sing) (void)hipFree(d_sing);
@@ -1424,7 +1635,8 @@ extern "C" {
 
 // nz: planes of the local spectral box; [ioff, ioff+nxl) its kx range (nxl = 0: all nx/2+1); fx_nz: planes of the local PHYSICAL box
 static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
-                                    int nz, int nzt, int koff, int nproc, int ioff = 0, int nxl = 0, int fx_nz = 0) {
+                                    int nz, int nzt, int koff, int nproc, int ioff = 0, int nxl = 0, int fx_nz = 0,
+                                    tlab_fdm_plan_t gy_ell = nullptr) {
     try {
         if (!out || !gx || !gy || !gz) throw std::invalid_argument("tlab_poisson_plan_create: null argument");
         if (!tlab_device_ready()) throw std::runtime_error("tlab_init has not been called (no CPU fallback exists)");
@@ -1437,8 +1649,13 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                 for (double v : d.mwn) if (v != 0.0) return false;
                 return true;
             };
-            if (no_mwn(gx->t.der1) || (nzt > 1 && no_mwn(gz->t.der1)))
+            if (!gy_ell && (no_mwn(gx->t.der1) || (nzt > 1 && no_mwn(gz->t.der1))))
                 throw std::invalid_argument("the x / z plans carry no modified wavenumbers (der1%mwn): call tlab_fdm_plan_set_aux");
+            if (gy_ell && (no_mwn(gx->t.der2) || (nzt > 1 && no_mwn(gz->t.der2))))
+                throw std::invalid_argument("the x / z plans carry no second-derivative modified wavenumbers (der2%mwn): call tlab_fdm_plan_set_aux");
+            if (gy_ell && (gy_ell->t.n != ny || gy_ell->t.periodic || !gy_ell->t.der2.direct || gy_ell->t.der2.ndl != 3 || gy_ell->t.der2.ndr != 5 ||
+                           (int)gy_ell->t.nodes.size() != ny))
+                throw std::invalid_argument("direct elliptic solver: the elliptic y plan must hold a CompactDirect6 second derivative (3/5 diagonals) and its nodes");
         }
         if (nproc < 1 || nz * nproc != nzt || koff < 0 || koff + nz > nzt) throw std::invalid_argument("bad z-slab decomposition");
         if (((long long)(nx / 2 + 1) * ny) % nproc != 0) throw std::invalid_argument("(imax/2+1)*jmax must be divisible by the number of z slabs (tlab_mpi_transpose.f90:292)");
@@ -1454,6 +1671,29 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         P->nzt = nzt; P->koff = koff; P->nproc = nproc;
         P->nm = (long long)P->nxh * nz;
         P->norm = 1.0 / ((double)nx * (double)nzt);                     // opr_elliptic.f90:130
+        if (gy_ell) {   // TYPE_DIRECT (opr_elliptic.f90:152-163, 228-245)
+            P->direct = true;
+            P->gy_der = gy;
+            P->ell_der2 = gy_ell->t.der2;
+            P->ell_nodes = gy_ell->t.nodes;
+            const long long nm = P->nm;
+            std::vector<double> lam((size_t)nm);
+            for (int k = 0; k < nz; ++k)
+                for (int i = 0; i < P->nxh; ++i) {
+                    double l2 = gx->t.der2.mwn[P->ioff + i];                       // lambda = mwn2_x + mwn2_z (:230-234)
+                    if (nzt > 1) l2 += gz->t.der2.mwn[koff + k];
+                    lam[(size_t)i + (size_t)P->nxh * k] = l2;
+                }
+            if (P->ioff == 0 && koff == 0) P->sing_direct = 0;                      // i_sing = k_sing = [1, 1] (:160-161)
+            P->lam.upload(lam);
+            (void)P->dev2(TLAB_BCS_NN);
+            if (P->sing_direct >= 0) (void)P->dev2(TLAB_BCS_DN);
+            P->scratch.alloc((size_t)5 * ny * nm);
+            P->cwork.alloc((size_t)2 * P->nxh * ny * nz);
+            build_fft(*P);
+            *out = P.release();
+            return TLAB_OK;
+        }
         int1_build_tables(gy->t.der1, 1, P->tmin);
         int1_build_tables(gy->t.der1, 2, P->tmax);
         P->d_L0[0].upload(P->tmin.L0); P->d_L1[0].upload(P->tmin.L1); P->d_R[0].upload(P->tmin.R);
@@ -1548,6 +1788,15 @@ int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_
     return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, nz, nz, 0, 1);
 }
 
+int tlab_poisson_plan_create_direct(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
+                                    int nz, tlab_fdm_plan_t gy_elliptic) {
+    if (!gy_elliptic) {
+        tlab_set_error("tlab_poisson_plan_create_direct: null elliptic plan");
+        return TLAB_EINVAL;
+    }
+    return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, nz, nz, 0, 1, 0, 0, 0, gy_elliptic);
+}
+
 int tlab_poisson_plan_create_slab(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
                                   int kmax, int nz_total, int koffset, int nproc_k) {
     return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, kmax, nz_total, koffset, nproc_k);
@@ -1569,7 +1818,32 @@ int tlab_poisson_plan_destroy(tlab_poisson_plan_t p) {
 
 // ODE stage on the local modes: f_hat (complex (nxh, ny, kmax), unnormalised FFT output) -> p_hat, dp_hat.
 // p_hat may alias f_hat (the reference also overwrites); dp_hat must be a different array.
+// FDM_Int2_Solve of every local mode (opr_elliptic.f90:413-434)
+static void poisson_direct_stage(tlab_poisson_plan_t P, int ibc, double *f_hat, double *p_hat, hipStream_t st) {
+    Int2Args a{};
+    a.T = P->dev2(ibc);
+    a.lam = P->lam.p; a.nm = P->nm; a.first = 0; a.count = P->nm;
+    a.skip = (ibc == TLAB_BCS_NN) ? P->sing_direct : -1;           // singular mode: BCS_DN system with p = 0 at the bottom (:236-240, :420-424)
+    a.fsrc = f_hat; a.dst = p_hat; a.fscale = P->norm; a.nxh = P->nxh; a.ny = P->ny;
+    a.zero_bottom = 0;
+    a.neumann_b = (ibc == TLAB_BCS_ND || ibc == TLAB_BCS_NN) ? 1 : 0;
+    a.neumann_t = (ibc == TLAB_BCS_DN || ibc == TLAB_BCS_NN) ? 1 : 0;
+    a.scratch = P->scratch.p;
+    {
+        ProfScope ps("k_int2", st, (double)P->nm * P->ny * 32.0);
+        hipLaunchKernelGGL((k_int2<4>), dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, st, a);
+    }
+    if (a.skip >= 0) {
+        Int2Args b = a;
+        b.T = P->dev2(TLAB_BCS_DN);
+        b.first = a.skip; b.count = 1; b.skip = -1; b.zero_bottom = 1; b.neumann_b = 0; b.neumann_t = 1;
+        hipLaunchKernelGGL((k_int2<4>), dim3(1), dim3(64), 0, st, b);
+    }
+    hipc(hipGetLastError(), "k_int2");
+}
+
 static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
+    if (P->direct) throw std::invalid_argument("direct elliptic plan: use tlab_poisson_direct_ode (there is no dp^/dy; dp/dy is OPR_Partial_Y of p)");
     const long long nm = P->nm;
     const int n = P->ny, nxh = P->nxh, ny = P->ny;
     hipc(hipEventRecord(P->ev_fork, st), "event record");
@@ -1640,11 +1914,36 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
     if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_poisson: sizes do not match the plan");
     if (P->nproc != 1 || P->nxh != P->fx_nxh || P->fx_nz != P->nz)
         throw std::invalid_argument("tlab_opr_poisson: plan is a z-slab / kx-pencil plan; drive its stages with the transposes in between");
-    if (ibc != TLAB_BCS_NN) {
-        tlab_set_error("OPR_Poisson: only BCS_NN is built on the device (the RHS call, rhs_global_incompressible_1.f90:284)");
+    if (ibc != TLAB_BCS_NN && !P->direct) {
+        tlab_set_error("OPR_Poisson (factorized): only BCS_NN is built on the device (the RHS call, rhs_global_incompressible_1.f90:284)");
         return TLAB_EUNSUPPORTED;
     }
+    if (ibc < TLAB_BCS_DD || ibc > TLAB_BCS_NN) throw std::invalid_argument("tlab_opr_poisson: bad ibc");
     if (p == tmp1 || p == tmp2 || tmp1 == tmp2 || dpdy == p || dpdy == tmp1 || dpdy == tmp2) throw std::invalid_argument("arrays must be distinct");
+    if (P->direct) {    // OPR_Poisson_FourierXZ_Direct (opr_elliptic.f90:368-455)
+        hipStream_t st = tlab_current_stream();
+        hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, p, bcs_hb, bcs_ht, nx, ny, nz);
+        if (nz > 1) {
+            P->fx_r2c.exec(p, tmp2, st);
+            if (P->fz_own) P->fz_own->exec(1, tmp2, tmp1, st);
+            else P->fz_f.exec(tmp2, tmp1, st);
+        } else {
+            P->fx_r2c.exec(p, tmp1, st);
+        }
+        poisson_direct_stage(P, ibc, tmp1, tmp1, st);
+        if (nz > 1) {
+            if (P->fz_own) P->fz_own->exec(-1, tmp1, P->cwork.p, st);
+            else P->fz_b.exec(tmp1, P->cwork.p, st);
+            P->fx_c2r.exec(P->cwork.p, p, st);
+        } else {
+            P->fx_c2r.exec(tmp1, p, st);
+        }
+        if (dpdy) {     // :447-449, with the y plan of the derivatives
+            const int rc = tlab_opr_partial(2, P->gy_der, TLAB_OPR_P1, nx, ny, nz, 0, p, dpdy, tmp1);
+            if (rc != TLAB_OK) return rc;
+        }
+        return TLAB_OK;
+    }
     hipStream_t st = tlab_current_stream();
     // BC planes into the forcing (opr_elliptic.f90:285-286)
     hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, p, bcs_hb, bcs_ht, nx, ny, nz);
@@ -1719,6 +2018,16 @@ int tlab_poisson_ode(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double
     POISSON_GUARD_BEGIN
     if (!P || !f_hat || !p_hat || !dp_hat || dp_hat == f_hat || dp_hat == p_hat) throw std::invalid_argument("tlab_poisson_ode: bad arguments");
     poisson_ode_stage(P, f_hat, p_hat, dp_hat, tlab_current_stream());
+    POISSON_GUARD_END
+}
+
+// direct plans: FDM_Int2_Solve of the local modes, f_hat -> p_hat (may alias)
+int tlab_poisson_direct_ode(tlab_poisson_plan_t P, int ibc, double *f_hat, double *p_hat) {
+    POISSON_GUARD_BEGIN
+    if (!P || !f_hat || !p_hat) throw std::invalid_argument("tlab_poisson_direct_ode: bad arguments");
+    if (!P->direct) throw std::invalid_argument("tlab_poisson_direct_ode: not a direct plan");
+    if (ibc < TLAB_BCS_DD || ibc > TLAB_BCS_NN) throw std::invalid_argument("tlab_poisson_direct_ode: bad ibc");
+    poisson_direct_stage(P, ibc, f_hat, p_hat, tlab_current_stream());
     POISSON_GUARD_END
 }
 

@@ -1,6 +1,7 @@
 !########################################################################
 ! Drop-in replacement of the Poisson entry of module OPR_Elliptic (operators/opr_elliptic.f90): the procedure pointer OPR_Poisson with
-! the abstract interface of :33-46, bound to the device solver (OPR_Poisson_FourierXZ_Factorize, :263-364; BCS_NN).
+! the abstract interface of :33-46, bound to the device solver: OPR_Poisson_FourierXZ_Factorize (:263-364; BCS_NN), or -- when the host hands
+! over the elliptic plan fdm_loc it made for EllipticOrder = CompactDirect6 (:107-124) -- OPR_Poisson_FourierXZ_Direct (:368-455; all four BCs).
 ! OPR_Elliptic_Initialize(inifile) of the reference reads [Main] EllipticOrder and builds lambda / fdm_int1 (:86-250); here the plan is
 ! built from the host plans g(1:3) the unchanged FDM_Initialize made (their coefficient tables and modified wavenumbers).
 ! p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy must be device arrays (allocation hook, INTEGRATION.md section 3).
@@ -20,7 +21,7 @@ module TLAB_AMD_ELLIPTIC_MODULE
     implicit none
     private
 
-    public :: OPR_Elliptic_Initialize_AMD       ! (g, nx, ny, nz): what OPR_Elliptic_Initialize takes from modules FDM / TLab_Memory
+    public :: OPR_Elliptic_Initialize_AMD       ! (g, nx, ny, nz [, fdm_loc]): what OPR_Elliptic_Initialize takes from modules FDM / TLab_Memory
     public :: OPR_Poisson
 
     abstract interface
@@ -38,15 +39,34 @@ module TLAB_AMD_ELLIPTIC_MODULE
     procedure(OPR_Poisson_interface), pointer :: OPR_Poisson => OPR_Poisson_AMD
 
     type(c_ptr), save :: plan = c_null_ptr
+    type(c_ptr), save :: plan_elliptic_y = c_null_ptr      ! device copy of fdm_loc (direct solver only)
 
 contains
-    subroutine OPR_Elliptic_Initialize_AMD(g, nx, ny, nz)
+    subroutine OPR_Elliptic_Initialize_AMD(g, nx, ny, nz, fdm_elliptic)
         type(fdm_dt), intent(in) :: g(3)
         integer(wi), intent(in) :: nx, ny, nz
+        type(fdm_dt), intent(in), target, optional :: fdm_elliptic     ! fdm_loc after FDM_CreatePlan(y, fdm_loc) with der2%mode_fdm = FDM_COM6_DIRECT
         integer(c_int) rc
-        rc = tlab_poisson_plan_create(plan, OPR_Partial_AMD_Plan(1, g(1)), OPR_Partial_AMD_Plan(2, g(2)), OPR_Partial_AMD_Plan(3, g(3)), &
-                                      int(nx, c_int), int(ny, c_int), int(nz, c_int))
-        call TLab_AMD_Check(rc, 'tlab_poisson_plan_create')
+        if (present(fdm_elliptic)) then
+            ! only the second derivative and the nodes of fdm_loc are used (FDM_Int2_*); its first derivative is handed over as it is
+            rc = tlab_fdm_plan_create_from_arrays(plan_elliptic_y, int(fdm_elliptic%size, c_int), 0_c_int, 0_c_int, &
+                                                  int(fdm_elliptic%der1%nb_diag(1), c_int), int(fdm_elliptic%der1%nb_diag(2), c_int), &
+                                                  fdm_elliptic%der1%lhs, fdm_elliptic%der1%rhs, &
+                                                  int(fdm_elliptic%der2%nb_diag(1), c_int), int(fdm_elliptic%der2%nb_diag(2), c_int), &
+                                                  fdm_elliptic%der2%lhs, fdm_elliptic%der2%rhs)
+            call TLab_AMD_Check(rc, 'tlab_fdm_plan_create_from_arrays')
+            rc = tlab_fdm_plan_set_aux(plan_elliptic_y, c_null_ptr, c_null_ptr, c_loc(fdm_elliptic%jac), c_loc(fdm_elliptic%nodes))
+            call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_aux')
+            rc = tlab_fdm_plan_set_scheme(plan_elliptic_y, 6_c_int, int(fdm_elliptic%der2%mode_fdm, c_int))
+            call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_scheme')
+            rc = tlab_poisson_plan_create_direct(plan, OPR_Partial_AMD_Plan(1, g(1)), OPR_Partial_AMD_Plan(2, g(2)), OPR_Partial_AMD_Plan(3, g(3)), &
+                                                 int(nx, c_int), int(ny, c_int), int(nz, c_int), plan_elliptic_y)
+            call TLab_AMD_Check(rc, 'tlab_poisson_plan_create_direct')
+        else
+            rc = tlab_poisson_plan_create(plan, OPR_Partial_AMD_Plan(1, g(1)), OPR_Partial_AMD_Plan(2, g(2)), OPR_Partial_AMD_Plan(3, g(3)), &
+                                          int(nx, c_int), int(ny, c_int), int(nz, c_int))
+            call TLab_AMD_Check(rc, 'tlab_poisson_plan_create')
+        end if
         OPR_Poisson => OPR_Poisson_AMD
     end subroutine OPR_Elliptic_Initialize_AMD
 
@@ -73,7 +93,7 @@ contains
         if (present(dpdy)) pd = c_loc(dpdy)
         rc = tlab_opr_poisson(plan, int(nx, c_int), int(ny, c_int), int(nz, c_int), int(ibc, c_int), c_loc(p), c_loc(tmp1), c_loc(tmp2), &
                               c_loc(bcs_hb), c_loc(bcs_ht), pd)
-        call TLab_AMD_Check(rc, 'tlab_opr_poisson')          ! BCS_DD and the direct/Helmholtz variants return TLAB_EUNSUPPORTED
+        call TLab_AMD_Check(rc, 'tlab_opr_poisson')          ! factorized plan: ibc /= BCS_NN returns TLAB_EUNSUPPORTED; Helmholtz is not built
     end subroutine poisson_any
 
 end module TLAB_AMD_ELLIPTIC_MODULE

@@ -6,14 +6,14 @@
 !########################################################################
 program test_dropin
     use, intrinsic :: iso_c_binding
-    use TLab_Constants, only: wp, wi, BCS_NN
+    use TLab_Constants, only: wp, wi, BCS_NN, BCS_DD
     use TLab_Arrays, only: wrk1d, wrk2d, wrk3d
     use TLab_OpenMP, only: TLab_OMP_numThreads
     use TLab_Grid, only: grid_dt
     use FDM, only: fdm_dt, FDM_CreatePlan
-    use FDM_Derivative, only: FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER
+    use FDM_Derivative, only: FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER, FDM_COM6_DIRECT
     use OPR_Partial, only: CPU_Partial_X => OPR_Partial_X, CPU_Partial_Y => OPR_Partial_Y, CPU_Partial_Z => OPR_Partial_Z, &
-                           OPR_P1, OPR_P2_P1
+                           OPR_P1, OPR_P2, OPR_P2_P1
     use OPR_Partial_AMD, only: GPU_Partial_X => OPR_Partial_X, GPU_Partial_Y => OPR_Partial_Y, GPU_Partial_Z => OPR_Partial_Z
     use OPR_Burgers_AMD
     use OPR_Elliptic_AMD
@@ -23,7 +23,7 @@ program test_dropin
     integer(wi), parameter :: nx = 256, ny = 96, nz = 64
     integer(wi), parameter :: n = nx*ny*nz
     type(grid_dt) :: gr(3)
-    type(fdm_dt), target :: g(3)
+    type(fdm_dt), target :: g(3), fdm_loc
     real(wp), allocatable, target :: u(:), v(:), r_cpu(:), t_cpu(:), r_gpu(:), b_ref(:)
     real(wp), pointer :: d_u(:), d_v(:), d_r(:), d_t(:), d_t1(:), d_t2(:), d_hb(:), d_ht(:)
     type(c_ptr) :: p_u, p_v, p_r, p_t, p_t1, p_t2, p_hb, p_ht
@@ -134,6 +134,30 @@ program test_dropin
     call CPU_Partial_X(OPR_P1, nx, ny, nz, bcs, g(1), phi, w2)
     err = maxval(abs(w1 - w2))/maxval(abs(w2)); worst = max(worst, err)
     print '(a,es10.3)', 'OPR_Poisson (drop-in pointer) dp/dx rel-err ', err
+    ! ---- EllipticOrder = CompactDirect6 (OPR_Poisson_FourierXZ_Direct): the host builds fdm_loc exactly as OPR_Elliptic_Initialize does
+    ! (opr_elliptic.f90:107-124) and hands it over; Dirichlet data = phi at the walls, forcing = (d2/dx2 + d2/dy2 + d2/dz2) phi with the
+    ! reference's CPU second-derivative operators (direct scheme in y): the discrete solution is phi itself ----
+    fdm_loc%name = 'y'; fdm_loc%periodic = .false.; fdm_loc%uniform = .false.
+    fdm_loc%der1%mode_fdm = FDM_COM6_DIRECT; fdm_loc%der2%mode_fdm = FDM_COM6_DIRECT
+    call FDM_CreatePlan(gr(2), fdm_loc)
+    call CPU_Partial_Y(OPR_P2, nx, ny, nz, bcs, fdm_loc, phi, f, w1)
+    call CPU_Partial_X(OPR_P2, nx, ny, nz, bcs, g(1), phi, w2, w1); f = f + w2
+    call CPU_Partial_Z(OPR_P2, nx, ny, nz, bcs, g(3), phi, w2, w1); f = f + w2
+    do k = 1, nz; do i = 1, nx
+        hb(i + nx*(k - 1)) = phi(i + nx*(0 + ny*(k - 1)))
+        ht(i + nx*(k - 1)) = phi(i + nx*(ny - 1 + ny*(k - 1)))
+    end do; end do
+    call TLab_AMD_Check(tlab_memcpy_h2d(p_u, c_loc(f), int(n, c_size_t)*8_c_size_t), 'h2d')
+    call TLab_AMD_Check(tlab_memcpy_h2d(p_hb, c_loc(hb), int(nx*nz, c_size_t)*8_c_size_t), 'h2d')
+    call TLab_AMD_Check(tlab_memcpy_h2d(p_ht, c_loc(ht), int(nx*nz, c_size_t)*8_c_size_t), 'h2d')
+    call OPR_Elliptic_Initialize_AMD(g, nx, ny, nz, fdm_loc)
+    call OPR_Poisson(nx, ny, nz, BCS_DD, d_u, d_t1, d_t2, d_hb, d_ht, d_r)
+    call TLab_AMD_Check(tlab_memcpy_d2h(c_loc(r_gpu), p_u, int(n, c_size_t)*8_c_size_t), 'd2h')
+    err = maxval(abs(r_gpu - phi))/maxval(abs(phi)); worst = max(worst, err)
+    print '(a,es10.3)', 'OPR_Poisson (direct, BCS_DD) p rel-err vs phi ', err
+    call TLab_AMD_Check(tlab_memcpy_d2h(c_loc(r_gpu), p_r, int(n, c_size_t)*8_c_size_t), 'd2h')
+    err = maxval(abs(r_gpu - dphidy))/maxval(abs(dphidy)); worst = max(worst, err)
+    print '(a,es10.3)', 'OPR_Poisson (direct, BCS_DD) dp/dy rel-err vs d(phi)/dy of the CPU operators ', err
     print '(a,es10.3)', 'worst ', worst
     if (worst > 1.0e-11_wp) error stop 1
     print '(a)', 'dropin ok'

@@ -76,6 +76,13 @@ module TLab_AMD_C
             type(c_ptr), value :: gx, gy, gz
             integer(c_int), value :: nx, ny, nz
         end function
+        integer(c_int) function tlab_poisson_plan_create_direct(plan, gx, gy, gz, nx, ny, nz, gy_elliptic) &
+            bind(C, name='tlab_poisson_plan_create_direct')
+            import :: c_int, c_ptr
+            type(c_ptr), intent(out) :: plan
+            type(c_ptr), value :: gx, gy, gz, gy_elliptic
+            integer(c_int), value :: nx, ny, nz
+        end function
         integer(c_int) function tlab_opr_poisson(plan, nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy) bind(C, name='tlab_opr_poisson')
             import :: c_int, c_ptr
             type(c_ptr), value :: plan, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy

@@ -100,9 +100,10 @@ class FdmPlan:
         dp = ctypes.POINTER(ctypes.c_double)
         aux = [np.ascontiguousarray(tab[k], dtype=np.float64) if k in tab else None for k in ("mwn1", "mwn2")]
         jac = np.asfortranarray(tab["jac"], dtype=np.float64) if "jac" in tab else None
+        nodes = np.ascontiguousarray(tab["nodes"], dtype=np.float64) if "nodes" in tab else None
         ptr = lambda a: a.ctypes.data_as(dp) if a is not None else None      # noqa: E731
         check(load().tlab_fdm_plan_set_aux(self._h, ctypes.cast(ptr(aux[0]), c_vp), ctypes.cast(ptr(aux[1]), c_vp),
-                                           ctypes.cast(ptr(jac), c_vp), None), "tlab_fdm_plan_set_aux")
+                                           ctypes.cast(ptr(jac), c_vp), ctypes.cast(ptr(nodes), c_vp)), "tlab_fdm_plan_set_aux")
         check(load().tlab_fdm_plan_set_scheme(self._h, int(scheme1), int(scheme2)), "tlab_fdm_plan_set_scheme")
         return self
 
@@ -207,13 +208,20 @@ class PoissonPlan:
     """Module state of OPR_Elliptic (operators/opr_elliptic.f90:64-81) + OPR_Fourier plans, built by
     OPR_Elliptic_Initialize / OPR_Fourier_Initialize in the reference; here one object owned by the library."""
 
-    def __init__(self, gx, gy, gz, nx, ny, nz):
+    def __init__(self, gx, gy, gz, nx, ny, nz, gy_elliptic=None):
+        """gy_elliptic: the reference's fdm_loc of EllipticOrder = CompactDirect6 (a y plan with the direct second derivative and its nodes,
+        FdmPlan.from_tables) -> OPR_Poisson_FourierXZ_Direct; None -> the factorized solver built from gy%der1."""
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.isize_txc_field = (self.nx + 2) * self.ny * self.nz     # base/tlab_memory.f90:186-187
-        self._keep = (gx, gy, gz)
+        self._keep = (gx, gy, gz, gy_elliptic)
         self._h = c_vp(0)
-        check(load().tlab_poisson_plan_create(ctypes.byref(self._h), gx._h, gy._h, gz._h, self.nx, self.ny, self.nz),
-              "tlab_poisson_plan_create")
+        self.direct = gy_elliptic is not None
+        if self.direct:
+            check(load().tlab_poisson_plan_create_direct(ctypes.byref(self._h), gx._h, gy._h, gz._h, self.nx, self.ny, self.nz, gy_elliptic._h),
+                  "tlab_poisson_plan_create_direct")
+        else:
+            check(load().tlab_poisson_plan_create(ctypes.byref(self._h), gx._h, gy._h, gz._h, self.nx, self.ny, self.nz),
+                  "tlab_poisson_plan_create")
 
     def __del__(self):
         try:
