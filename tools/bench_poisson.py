@@ -6,12 +6,18 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import tlab_amd as T
 
 ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=512); ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--direct", action="store_true", help="EllipticOrder=CompactDirect6 (y tables of tests/golden/direct_y.npz: n = 24, 64, 128, 512)")
 args = ap.parse_args(); n = args.n
 T.init(0)
 x = np.arange(n) / n; y = 0.5 * (1 + np.tanh(2 * (2 * np.arange(n) / (n - 1) - 1)) / np.tanh(2))
 gx, gy, gz = T.FdmPlan(x, True, True), T.FdmPlan(y, False, False), T.FdmPlan(x, True, True)
 torch.cuda.synchronize(); import time; t0 = time.time()
-plan = T.PoissonPlan(gx, gy, gz, n, n, n)
+gy_ell = None
+if args.direct:
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "direct_y.npz"))
+    tab = {k[len("ny%d_" % n):]: g[k] for k in g.files if k.startswith("ny%d_" % n)}
+    gy = gy_ell = T.FdmPlan.from_tables(tab, scheme1=6, scheme2=16)
+plan = T.PoissonPlan(gx, gy, gz, n, n, n, gy_elliptic=gy_ell)
 torch.cuda.synchronize(); print("plan creation %.2f s" % (time.time() - t0))
 N = n ** 3
 f = torch.rand(N, dtype=torch.float64, device="cuda") - 0.5
