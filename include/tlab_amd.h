@@ -150,6 +150,12 @@ int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, 
  * ibc = TLAB_BCS_DD / ND / DN / NN (bcs_hb, bcs_ht: function value at a D end, derivative at an N end).  Single-rank boxes only. */
 int tlab_poisson_plan_create_direct(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                                     int nx, int ny, int nz, tlab_fdm_plan_t gy_elliptic);
+/* OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)   operators/opr_elliptic.f90:48-62, OPR_Helmholtz_FourierXZ_Direct :562-628
+ * Solves lap a + alpha a = f on a DIRECT plan (per mode the second-order integral system with constant lambda2 - alpha, any of the four
+ * boundary types, no singular-mode treatment: alpha < 0 in the implicit RK that calls it).  The factorized variant (:466-557) is not built:
+ * a factorized plan returns TLAB_EUNSUPPORTED.  a: forcing in, solution out; tmp1, tmp2 as tlab_opr_poisson. */
+int tlab_opr_helmholtz(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double alpha, double *a, double *tmp1, double *tmp2,
+                       const double *bcs_hb, const double *bcs_ht);
 /* the per-mode stage of a direct plan on spectral fields (nx/2+1, ny, nz) complex: f_hat -> p_hat (may alias) */
 int tlab_poisson_direct_ode(tlab_poisson_plan_t plan, int ibc, double *f_hat, double *p_hat);
 

@@ -652,3 +652,28 @@ def opr_poisson_fxz_direct(plan, p, bcs_hb, bcs_ht, ibc=BCS_NN, gy_der=None):
     pout = (np.fft.irfft(cc, n=nx, axis=2) * nx).reshape(-1)
     dpdy = opr_partial(2, 1, nx, ny, nz, 0, gy_der if gy_der is not None else plan.gy, pout)[0]
     return pout, dpdy
+
+
+def opr_helmholtz_fxz_direct(plan, a, bcs_hb, bcs_ht, ibc, alpha):
+    """operators/opr_elliptic.f90:562-628 OPR_Helmholtz_FourierXZ_Direct: lap a + alpha a = f; per mode FDM_Int2 with the constant
+    lambda(k,i) - alpha and the boundary type ibc, no singular-mode treatment.  Returns a flat."""
+    nx, ny, nz, nxh = plan.nx, plan.ny, plan.nz, plan.nxh
+    w = np.array(a, dtype=np.float64).reshape(nz, ny, nx).copy()
+    w[:, 0, :] = bcs_hb.reshape(nz, nx)                                  # :581-582
+    w[:, ny - 1, :] = bcs_ht.reshape(nz, nx)
+    c = np.fft.rfft(w, axis=2)
+    if nz > 1:
+        c = np.fft.fft(c, axis=0)
+    c = c * plan.norm                                                    # :591
+    M = nz * nxh
+    f = np.empty((ny, 2, M))
+    f[:, 0, :] = c.real.transpose(1, 0, 2).reshape(ny, M)
+    f[:, 1, :] = c.imag.transpose(1, 0, 2).reshape(ny, M)
+    u = np.zeros_like(f)
+    u[0], u[ny - 1] = f[0], f[ny - 1]                                    # :601-602
+    pr = int2_initialize(plan.gy.der2, plan.gy.nodes, plan.lam2.reshape(M) - alpha, ibc)     # :604
+    int2_solve(pr, pr.rhs, f, u)
+    cc = (u[:, 0, :] + 1j * u[:, 1, :]).reshape(ny, nz, nxh).transpose(1, 0, 2)
+    if nz > 1:
+        cc = np.fft.ifft(cc, axis=0) * nz
+    return (np.fft.irfft(cc, n=nx, axis=2) * nx).reshape(-1)

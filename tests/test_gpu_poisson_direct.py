@@ -64,6 +64,34 @@ def test_poisson_direct_matches_oracle(T, nx, ny, nz, ibc):
     assert rel_err(dpdy.cpu().numpy(), dp_ref) <= 1e-11, rel_err(dpdy.cpu().numpy(), dp_ref)
 
 
+@pytest.mark.parametrize("nx,ny,nz,ibc,alpha", [(16, 24, 8, 0, -12.5), (16, 64, 8, 3, -400.0), (32, 128, 8, 1, -3.0), (16, 64, 1, 2, -50.0), (64, 512, 16, 0, -1.0e4)])
+def test_helmholtz_direct_matches_oracle(T, nx, ny, nz, ibc, alpha):
+    import torch
+    (ogx, ogy, ogz), (gx, gy, gz), f, hb, ht = _setup(T, nx, ny, nz, ny + ibc + 7)
+    oplan = OP.PoissonDirectPlan(ogx, ogy, ogz if nz > 1 else ogx, nx, ny, nz)
+    a_ref = OP.opr_helmholtz_fxz_direct(oplan, f, hb, ht, ibc, alpha)
+    plan = T.PoissonPlan(gx, gy, gz, nx, ny, nz, gy_elliptic=gy)
+    a = torch.from_numpy(f.copy()).cuda()
+    tmp1 = torch.zeros(plan.isize_txc_field, dtype=torch.float64, device="cuda")
+    tmp2 = torch.zeros_like(tmp1)
+    T.OPR_Helmholtz(plan, nx, ny, nz, ibc, alpha, a, tmp1, tmp2, torch.from_numpy(hb.ravel().copy()).cuda(), torch.from_numpy(ht.ravel().copy()).cuda())
+    torch.cuda.synchronize()
+    assert rel_err(a.cpu().numpy(), a_ref) <= TOL, rel_err(a.cpu().numpy(), a_ref)
+
+
+def test_helmholtz_needs_a_direct_plan(T):
+    import torch
+    x = np.arange(16) / 16.0
+    y = np.arange(24) / 23.0
+    gx, gy = T.FdmPlan(x, True, True), T.FdmPlan(y, False, True)
+    plan = T.PoissonPlan(gx, gy, gx, 16, 24, 16)
+    a = torch.zeros(16 * 24 * 16, dtype=torch.float64, device="cuda")
+    t1 = torch.zeros(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.zeros_like(t1)
+    hb = torch.zeros(256, dtype=torch.float64, device="cuda")
+    with pytest.raises(T.TlabError):
+        T.OPR_Helmholtz(plan, 16, 24, 16, 0, -1.0, a, t1, t2, hb, hb.clone())
+
+
 def test_direct_plan_needs_the_direct_tables(T):
     x = np.arange(16) / 16.0
     y = np.arange(24) / 23.0

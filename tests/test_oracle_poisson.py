@@ -139,3 +139,27 @@ def test_poisson_direct_discrete_identity(ny, nx, nz, ibc):
         got = c[0] * P3[:, ny - 1] + c[1] * P3[:, ny - 2] + c[2] * P3[:, ny - 3] + c[3] * P3[:, ny - 4] + c[4] * rest[:, ny - 2]
         assert rel_err(got, ht) <= 1e-10
     assert np.isfinite(dpdy).all()
+
+
+@pytest.mark.parametrize("ibc", [0, 1, 2, 3])
+def test_helmholtz_direct_discrete_identity(ibc):
+    """(lap + alpha) a = f at the interior rows with the second-derivative operators of the plans (OPR_Helmholtz_FourierXZ_Direct)."""
+    ny, nx, nz, alpha = 64, 16, 8, -37.5
+    g = np.load(golden_files("direct_y")[0])
+    tab = {k[len("ny%d_" % ny):]: g[k] for k in g.files if k.startswith("ny%d_" % ny)}
+    gy = O.FdmPlan.from_tables(tab)
+    x = np.arange(nx) / nx * 2 * np.pi
+    z = np.arange(nz) / nz * 2 * np.pi
+    gx, gz = O.FdmPlan(x, True, True), O.FdmPlan(z, True, True)
+    rng = np.random.default_rng(ibc)
+    f = rng.uniform(-1, 1, nx * ny * nz)
+    hb, ht = rng.uniform(-1, 1, (nz, nx)), rng.uniform(-1, 1, (nz, nx))
+    plan = OP.PoissonDirectPlan(gx, gy, gz, nx, ny, nz)
+    a = OP.opr_helmholtz_fxz_direct(plan, f, hb, ht, ibc, alpha)
+    lap = sum(O.opr_partial(d, 2, nx, ny, nz, 0, gg, a)[0] for d, gg in ((1, gx), (2, gy), (3, gz))) + alpha * a
+    assert rel_err(lap.reshape(nz, ny, nx)[:, 3:ny - 3], f.reshape(nz, ny, nx)[:, 3:ny - 3]) <= 1e-9
+    A3 = a.reshape(nz, ny, nx)
+    if ibc in (0, 2):
+        assert rel_err(A3[:, 0], hb) <= 1e-12
+    if ibc in (0, 1):
+        assert rel_err(A3[:, ny - 1], ht) <= 1e-12

@@ -323,6 +323,7 @@ struct Int2Dev {
 struct Int2Args {
     Int2Dev T;
     const double *lam;      // [nm] lambda2 = mwn2_x + mwn2_z of each mode
+    double alpha;           // Helmholtz: the system constant is lambda2 - alpha (opr_elliptic.f90:604); 0 for Poisson
     long long nm;           // modes of the spectral box
     long long first, count; // threads cover modes [first, first + count)
     long long skip;         // mode left out (the singular one, solved by its own launch with the BCS_DN tables), or -1
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256) k_int2(Int2Args a) {
     if (t == a.skip) return;
     const int n = a.T.n;
     const long long nm = a.nm;
-    const double lam = a.lam[t];
+    const double lam = a.lam[t] - a.alpha;
     const long long fidx0 = (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh);
     const double2 *__restrict__ fs = reinterpret_cast<const double2 *>(a.fsrc);
     auto loadf = [&](int j, double (&f)[2]) {
@@ -1819,11 +1820,13 @@ int tlab_poisson_plan_destroy(tlab_poisson_plan_t p) {
 // ODE stage on the local modes: f_hat (complex (nxh, ny, kmax), unnormalised FFT output) -> p_hat, dp_hat.
 // p_hat may alias f_hat (the reference also overwrites); dp_hat must be a different array.
 // FDM_Int2_Solve of every local mode (opr_elliptic.f90:413-434)
-static void poisson_direct_stage(tlab_poisson_plan_t P, int ibc, double *f_hat, double *p_hat, hipStream_t st) {
+// helmholtz: OPR_Helmholtz_FourierXZ_Direct (:562-628): system constant lambda2 - alpha for every mode, no singular-mode treatment
+static void poisson_direct_stage(tlab_poisson_plan_t P, int ibc, double *f_hat, double *p_hat, hipStream_t st, bool helmholtz = false, double alpha = 0.0) {
     Int2Args a{};
     a.T = P->dev2(ibc);
     a.lam = P->lam.p; a.nm = P->nm; a.first = 0; a.count = P->nm;
-    a.skip = (ibc == TLAB_BCS_NN) ? P->sing_direct : -1;           // singular mode: BCS_DN system with p = 0 at the bottom (:236-240, :420-424)
+    a.alpha = helmholtz ? alpha : 0.0;
+    a.skip = (ibc == TLAB_BCS_NN && !helmholtz) ? P->sing_direct : -1;   // singular mode: BCS_DN system with p = 0 at the bottom (:236-240, :420-424)
     a.fsrc = f_hat; a.dst = p_hat; a.fscale = P->norm; a.nxh = P->nxh; a.ny = P->ny;
     a.zero_bottom = 0;
     a.neumann_b = (ibc == TLAB_BCS_ND || ibc == TLAB_BCS_NN) ? 1 : 0;
@@ -2018,6 +2021,38 @@ int tlab_poisson_ode(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double
     POISSON_GUARD_BEGIN
     if (!P || !f_hat || !p_hat || !dp_hat || dp_hat == f_hat || dp_hat == p_hat) throw std::invalid_argument("tlab_poisson_ode: bad arguments");
     poisson_ode_stage(P, f_hat, p_hat, dp_hat, tlab_current_stream());
+    POISSON_GUARD_END
+}
+
+// OPR_Helmholtz_FourierXZ_Direct(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)  operators/opr_elliptic.f90:562-628
+int tlab_opr_helmholtz(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, double alpha, double *a, double *tmp1, double *tmp2,
+                       const double *bcs_hb, const double *bcs_ht) {
+    POISSON_GUARD_BEGIN
+    if (!P || !a || !tmp1 || !tmp2 || !bcs_hb || !bcs_ht) throw std::invalid_argument("tlab_opr_helmholtz: null argument");
+    if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_helmholtz: sizes do not match the plan");
+    if (!P->direct) {
+        tlab_set_error("OPR_Helmholtz: only the direct variant (EllipticOrder = CompactDirect6) is built on the device");
+        return TLAB_EUNSUPPORTED;
+    }
+    if (ibc < TLAB_BCS_DD || ibc > TLAB_BCS_NN) throw std::invalid_argument("tlab_opr_helmholtz: bad ibc");
+    if (a == tmp1 || a == tmp2 || tmp1 == tmp2) throw std::invalid_argument("arrays must be distinct");
+    hipStream_t st = tlab_current_stream();
+    hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, a, bcs_hb, bcs_ht, nx, ny, nz);
+    if (nz > 1) {
+        P->fx_r2c.exec(a, tmp2, st);
+        if (P->fz_own) P->fz_own->exec(1, tmp2, tmp1, st);
+        else P->fz_f.exec(tmp2, tmp1, st);
+    } else {
+        P->fx_r2c.exec(a, tmp1, st);
+    }
+    poisson_direct_stage(P, ibc, tmp1, tmp1, st, true, alpha);
+    if (nz > 1) {
+        if (P->fz_own) P->fz_own->exec(-1, tmp1, P->cwork.p, st);
+        else P->fz_b.exec(tmp1, P->cwork.p, st);
+        P->fx_c2r.exec(P->cwork.p, a, st);
+    } else {
+        P->fx_c2r.exec(tmp1, a, st);
+    }
     POISSON_GUARD_END
 }
 

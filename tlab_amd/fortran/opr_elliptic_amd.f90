@@ -23,6 +23,7 @@ module TLAB_AMD_ELLIPTIC_MODULE
 
     public :: OPR_Elliptic_Initialize_AMD       ! (g, nx, ny, nz [, fdm_loc]): what OPR_Elliptic_Initialize takes from modules FDM / TLab_Memory
     public :: OPR_Poisson
+    public :: OPR_Helmholtz                     ! direct plans only (OPR_Helmholtz_FourierXZ_Direct, :562-628)
 
     abstract interface
         subroutine OPR_Poisson_interface(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)      ! opr_elliptic.f90:33-46
@@ -37,6 +38,20 @@ module TLAB_AMD_ELLIPTIC_MODULE
         end subroutine
     end interface
     procedure(OPR_Poisson_interface), pointer :: OPR_Poisson => OPR_Poisson_AMD
+
+    abstract interface
+        subroutine OPR_Helmholtz_interface(nx, ny, nz, ibc, alpha, p, tmp1, tmp2, bcs_hb, bcs_ht)   ! opr_elliptic.f90:48-62
+            use TLab_Constants, only: wi, wp
+            integer(wi), intent(in) :: nx, ny, nz
+            integer, intent(in) :: ibc
+            real(wp), intent(in) :: alpha
+            real(wp), intent(inout) :: p(nx, ny, nz)
+            real(wp), intent(inout), target :: tmp1(2*ny, nz, nx/2 + 1)
+            real(wp), intent(inout), target :: tmp2(2*ny, nz, nx/2 + 1)
+            real(wp), intent(in) :: bcs_hb(nx, nz), bcs_ht(nx, nz)
+        end subroutine
+    end interface
+    procedure(OPR_Helmholtz_interface), pointer :: OPR_Helmholtz => OPR_Helmholtz_AMD
 
     type(c_ptr), save :: plan = c_null_ptr
     type(c_ptr), save :: plan_elliptic_y = c_null_ptr      ! device copy of fdm_loc (direct solver only)
@@ -80,6 +95,29 @@ contains
         real(wp), intent(out), optional :: dpdy(nx, ny, nz)
         call poisson_any(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)
     end subroutine OPR_Poisson_AMD
+
+    subroutine OPR_Helmholtz_AMD(nx, ny, nz, ibc, alpha, p, tmp1, tmp2, bcs_hb, bcs_ht)    ! exactly the abstract interface
+        integer(wi), intent(in) :: nx, ny, nz
+        integer, intent(in) :: ibc
+        real(wp), intent(in) :: alpha
+        real(wp), intent(inout) :: p(nx, ny, nz)
+        real(wp), intent(inout), target :: tmp1(2*ny, nz, nx/2 + 1)
+        real(wp), intent(inout), target :: tmp2(2*ny, nz, nx/2 + 1)
+        real(wp), intent(in) :: bcs_hb(nx, nz), bcs_ht(nx, nz)
+        call helmholtz_any(nx, ny, nz, ibc, alpha, p, tmp1, tmp2, bcs_hb, bcs_ht)
+    end subroutine OPR_Helmholtz_AMD
+
+    subroutine helmholtz_any(nx, ny, nz, ibc, alpha, p, tmp1, tmp2, bcs_hb, bcs_ht)
+        integer(wi), intent(in) :: nx, ny, nz
+        integer, intent(in) :: ibc
+        real(wp), intent(in) :: alpha
+        real(wp), intent(inout), target :: p(*), tmp1(*), tmp2(*)
+        real(wp), intent(in), target :: bcs_hb(*), bcs_ht(*)
+        integer(c_int) rc
+        rc = tlab_opr_helmholtz(plan, int(nx, c_int), int(ny, c_int), int(nz, c_int), int(ibc, c_int), real(alpha, c_double), c_loc(p), &
+                                c_loc(tmp1), c_loc(tmp2), c_loc(bcs_hb), c_loc(bcs_ht))
+        call TLab_AMD_Check(rc, 'tlab_opr_helmholtz')        ! a factorized plan returns TLAB_EUNSUPPORTED
+    end subroutine helmholtz_any
 
     subroutine poisson_any(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)           ! c_loc needs the TARGET attribute
         integer(wi), intent(in) :: nx, ny, nz

@@ -88,6 +88,12 @@ module TLab_AMD_C
             type(c_ptr), value :: plan, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy
             integer(c_int), value :: nx, ny, nz, ibc
         end function
+        integer(c_int) function tlab_opr_helmholtz(plan, nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht) bind(C, name='tlab_opr_helmholtz')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: plan, a, tmp1, tmp2, bcs_hb, bcs_ht
+            integer(c_int), value :: nx, ny, nz, ibc
+            real(c_double), value :: alpha
+        end function
         integer(c_int) function tlab_transpose(a, nra, nca, b) bind(C, name='tlab_transpose')
             import :: c_int, c_ptr
             type(c_ptr), value :: a, b

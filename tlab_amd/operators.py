@@ -241,6 +241,16 @@ def OPR_Poisson(plan, nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy=None)
                                   _ptr(bcs_ht, nx * nz, "bcs_ht"), _ptr(dpdy, n, "dpdy")), "tlab_opr_poisson")
 
 
+def OPR_Helmholtz(plan, nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht):
+    """OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)  operators/opr_elliptic.f90:48-62 (direct variant :562-628):
+    lap a + alpha a = f; `plan` must be a direct plan (PoissonPlan(..., gy_elliptic=...))."""
+    n = nx * ny * nz
+    _use_torch_stream()
+    check(load().tlab_opr_helmholtz(plan._h, nx, ny, nz, int(ibc), float(alpha), _ptr(a, n, "a"), _ptr(tmp1, plan.isize_txc_field, "tmp1"),
+                                    _ptr(tmp2, plan.isize_txc_field, "tmp2"), _ptr(bcs_hb, nx * nz, "bcs_hb"), _ptr(bcs_ht, nx * nz, "bcs_ht")),
+          "tlab_opr_helmholtz")
+
+
 def TLab_Transpose(a, nra, nca, b):
     """b(nca, nra) = transpose of Fortran a(nra, nca); bit-exact."""
     _use_torch_stream()
