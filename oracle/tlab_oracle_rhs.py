@@ -13,11 +13,15 @@ from . import tlab_oracle_poisson as OP
 
 
 class DnsOracle:
-    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None):
+    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None, gy_elliptic=None):
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
         self.g = list(plans) if plans is not None else [O.FdmPlan(x, True, True), O.FdmPlan(y, False, yuniform), O.FdmPlan(z, True, True)]
-        self.poisson = OP.PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
+        self.direct = gy_elliptic is not None         # EllipticOrder = CompactDirect6: OPR_Poisson => OPR_Poisson_FourierXZ_Direct (opr_elliptic.f90:153)
+        if self.direct:
+            self.poisson = OP.PoissonDirectPlan(self.g[0], gy_elliptic, self.g[2], self.nx, self.ny, self.nz)
+        else:
+            self.poisson = OP.PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
         self.nscal, self.visc, self.schmidt = nscal, visc, list(schmidt)
         self.q = [np.zeros(self.n) for _ in range(3)]
         self.s = [np.zeros(self.n) for _ in range(nscal)]
@@ -57,7 +61,10 @@ class DnsOracle:
         tmp1 = tmp1 + tmp2 + tmp3                                                                                   # :258
         h2 = hq[1].reshape(nz, ny, nx)
         hb, ht = h2[:, 0, :].copy(), h2[:, ny - 1, :].copy()                                                        # :279-280
-        p, dpdy = OP.opr_poisson_fxz(self.poisson, tmp1, hb, ht)                                                    # :284
+        if self.direct:
+            p, dpdy = OP.opr_poisson_fxz_direct(self.poisson, tmp1, hb, ht, gy_der=self.g[1])
+        else:
+            p, dpdy = OP.opr_poisson_fxz(self.poisson, tmp1, hb, ht)                                                # :284
         self.p = p
         tmp2 = self.p1(1, p); tmp4 = self.p1(3, p)                                                                  # :319-320
         hq[0] = hq[0] - tmp2; hq[1] = hq[1] - dpdy; hq[2] = hq[2] - tmp4                                            # :349-351

@@ -68,8 +68,10 @@ def test_device_direct_scheme(ny, nx, nz):
 
 
 @pytest.mark.gpu
-def test_substep_with_direct_second_derivative_in_y():
-    """The scheme set of examples/Case81-93 (SpaceOrder2 = CompactDirect6, everything else default): full substeps against the oracle."""
+@pytest.mark.parametrize("elliptic_direct", [False, True])
+def test_substep_with_direct_second_derivative_in_y(elliptic_direct):
+    """The scheme set of examples/Case81-93 (SpaceOrder2 = CompactDirect6; with and without EllipticOrder = CompactDirect6, everything else
+    default): full substeps against the oracle."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -83,8 +85,8 @@ def test_substep_with_direct_second_derivative_in_y():
     x, y, z = np.arange(nx) / nx * 2.0, tab["nodes"], np.arange(nz) / nz
     gp = [T.FdmPlan(x, True, True), T.FdmPlan.from_tables(tab, False, T.FDM_COM6_JACOBIAN, T.FDM_COM6_DIRECT), T.FdmPlan(z, True, True)]
     go = [O.FdmPlan(x, True, True), O.FdmPlan.from_tables(tab, mode2=O.FDM_COM6_DIRECT), O.FdmPlan(z, True, True)]
-    d = Dns(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=gp)
-    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=go)
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=gp, gy_elliptic=gp[1] if elliptic_direct else None)
+    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=go, gy_elliptic=go[1] if elliptic_direct else None)
     rng = np.random.default_rng(81)
     Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
     wall = np.sin(np.pi * Y)

@@ -58,7 +58,7 @@ class Dns:
     """imax, jmax, kmax, inb_scal, visc, schmidt + the allocated arrays of TLab_Initialize_Memory (tlab_memory.f90:164-216)."""
 
     def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
-                 hyper_bc1_ext=0.1, device="cuda", plans=None):
+                 hyper_bc1_ext=0.1, device="cuda", plans=None, gy_elliptic=None):
         import torch
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
@@ -69,7 +69,8 @@ class Dns:
         self.g = list(plans) if plans is not None else [
             FdmPlan(x, True, True, hyper_bc1_ext=hyper_bc1_ext), FdmPlan(y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext),
             FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
-        self.poisson = PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
+        # gy_elliptic: the y plan of EllipticOrder = CompactDirect6 (fdm_loc, opr_elliptic.f90:107-124) -> OPR_Poisson_FourierXZ_Direct
+        self.poisson = PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz, gy_elliptic=gy_elliptic)
         self.isize_txc_field = self.poisson.isize_txc_field
         f = lambda m: [torch.zeros(m, dtype=torch.float64, device=device) for _ in range(1)][0]   # noqa: E731
         self.q = [f(self.n) for _ in range(3)]
