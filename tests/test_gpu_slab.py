@@ -101,3 +101,29 @@ def test_full_size_eight_slabs_equal_single_domain(T):
         name, idx = ("q", i) if i < 3 else ("s", 0)
         got = torch.cat([slab.st[r][name][idx] for r in range(P)])
         assert float((got - rf).abs().max() / rf.abs().max()) <= 1e-11, (name, idx)
+
+
+@pytest.mark.parametrize("P,nz,zmode", [(2, 128, "halo"), (4, 64, "transpose")])
+def test_slab_monitors_equal_single_domain(T, P, nz, zmode):
+    """TIME_COURANT (time.f90:365-548, MPI_MAX :522) and the dilatation bounds of DNS_BOUNDS_CONTROL on slabs against the single domain."""
+    import torch
+    from tlab_amd.dns import Dns
+    from tlab_amd.parallel import SlabDns, LoopbackComm
+    nx, ny = 32, 24
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz * 3.0
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(nz)
+    one = Dns(x, y, z, nscal=1, visc=1.0 / 300.0, schmidt=(0.5,), yuniform=False)
+    slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, visc=1.0 / 300.0, schmidt=(0.5,), yuniform=False, zmode=zmode)
+    assert slab.zmode == zmode
+    for i in range(3):
+        t = torch.from_numpy(rng.uniform(-1, 1, nx * ny * nz)).cuda()
+        one.q[i].copy_(t); slab.scatter("q", i, t)
+    (a1, a2), dta = one.TIME_COURANT(1.2, 0.3)
+    (b1, b2), dtb = slab.TIME_COURANT(1.2, 0.3)
+    assert a1 == b1 and a2 == b2 and dta == dtb            # maxima of the same numbers
+    dmin, dmax = one.dilatation_bounds()
+    smin, smax = slab.dilatation_bounds()
+    scale = max(abs(dmin), abs(dmax))
+    assert abs(dmin - smin) <= 1e-12 * scale and abs(dmax - smax) <= 1e-12 * scale

@@ -222,3 +222,36 @@ def test_i_transposes_two_processes_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] and r[2] for r in res), res
+
+
+def _worker_allreduce(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = DistComm()
+        mx = comm.all_reduce({rank: [1.0 + rank, -3.0 * rank]}, "max")
+        mn = comm.all_reduce({rank: [1.0 + rank, -3.0 * rank]}, "min")
+        q.put((rank, mx, mn))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_reduce_two_processes_gloo():
+    """MPI_ALLREDUCE(MPI_MAX) of TIME_COURANT (time.f90:522) and the MINMAX pair of DNS_BOUNDS_CONTROL over the z communicator."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_allreduce, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for _, mx, mn in res:
+        assert mx == [2.0, 0.0] and mn == [1.0, -3.0]
+    assert LoopbackComm(3).all_reduce({0: [1.0], 1: [5.0], 2: [-2.0]}, "max") == [5.0]

@@ -102,6 +102,16 @@ class DistComm:
         return _Works(dist.batch_isend_irecv(ops))
 
 
+    def all_reduce(self, values, op="max"):
+        """values: {rank: list of floats}.  MPI_ALLREDUCE(MPI_MAX / MPI_MIN) of a few scalars (time.f90:522, minmax.f90)."""
+        import torch
+        (r, v), = values.items()
+        dev = "cpu" if self.stage_host or not torch.cuda.is_available() else "cuda"
+        t = torch.tensor(list(v), dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.MIN, group=self.group)
+        return [float(x) for x in t.cpu()]
+
+
 class _Done:
     def wait(self):
         pass
@@ -151,6 +161,12 @@ class LoopbackComm:
             for t, d in zip(to_right[r], from_left[(r + 1) % P]):
                 d.copy_(t)
         return _Done()
+
+
+    def all_reduce(self, values, op="max"):
+        f = max if op == "max" else min
+        n = len(next(iter(values.values())))
+        return [f(values[r][i] for r in self.local_ranks) for i in range(n)]
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -648,6 +664,62 @@ class SlabDns:
             raise TlabError("the wall-normal velocity must be Dirichlet")
         self.flow_jmin, self.flow_jmax = list(fj0), list(fj1)
         self.scal_jmin, self.scal_jmax = list(sj0)[: self.nscal], list(sj1)[: self.nscal]
+
+    # ---- per-iteration monitors on slabs: local device reductions + one MPI_MAX / MPI_MIN of two scalars ----
+    def _dns_handle(self, r):
+        """tlab_dns handle of the local box (nx, ny, kmax) with the GLOBAL z plan and the slab's first plane (ims_offset_k)."""
+        S = self.st[r]
+        if "dns" not in S:
+            h = c_vp(0)
+            sc = np.ascontiguousarray(self.schmidt if self.nscal else [1.0], dtype=np.float64)
+            check(load().tlab_dns_create(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, S["poisson"], self.nx, self.ny, self.kmax,
+                                         self.nscal, self.visc, sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "tlab_dns_create")
+            check(load().tlab_dns_set_slab(h, r * self.kmax), "tlab_dns_set_slab")
+            S["dns"] = h
+        return S["dns"]
+
+    def TIME_COURANT(self, cfla, cfld):
+        """tools/dns/time.f90:365-548 with the MPI_MAX of :522.  Returns ((pmax1, pmax2), dtime), the same on every rank."""
+        _use_torch_stream()
+        loc = {}
+        for r in self.comm.local_ranks:
+            q = (c_vp * 3)(*[t.data_ptr() for t in self.st[r]["q"]])
+            pmax = (ctypes.c_double * 2)()
+            check(load().tlab_time_courant(self._dns_handle(r), q, float(cfla), float(cfld), pmax, None), "tlab_time_courant")
+            loc[r] = [pmax[0], pmax[1]]
+        p1, p2 = self.comm.all_reduce(loc, "max")
+        dtc = cfla / p1 if p1 > 0.0 else 1.0e300
+        dtd = cfld / p2 if p2 > 0.0 else 1.0e300
+        return (p1, p2), (min(dtc, dtd) if cfla > 0.0 else 0.0)
+
+    def dilatation_bounds(self):
+        """DNS_BOUNDS_CONTROL (dns_local.f90:157-187): (DilMin, DilMax) = extremes of div(q) (FI_INVARIANT_P = -div, fi_vectorcalculus.f90:111-141);
+        the z-derivative takes the slab route of the RHS (halo planes + interface values, or the K-transposes)."""
+        _use_torch_stream()
+        L = load()
+        nx, ny, kmax, n = self.nx, self.ny, self.kmax, self.n
+        T = lambda S, i: S["txc"][i]        # noqa: E731
+        halo = self.zmode == "halo"
+        w = self._halo_start([("q", 2)]) if halo else None
+        self._local(lambda r, S: self._partial(1, self.g[0], nx, ny, kmax, S["q"][0], T(S, 0)))
+        self._local(lambda r, S: self._partial(2, self.g[1], nx, ny, kmax, S["q"][1], T(S, 1)))
+        self._local(lambda r, S: T(S, 0)[:n].add_(T(S, 1)[:n]))
+        if halo:
+            w.wait()
+            self._local(lambda r, S: self._zpartial(1, S, S["q"][2], None, 0.0, None, 0))
+            self._msg_start(1).wait()
+            self._local(lambda r, S: self._zpartial(2, S, S["q"][2], None, 0.0, T(S, 0), 1))
+        else:
+            self._local(lambda r, S: T(S, 3)[:n].copy_(S["q"][2]))
+            self.partial_z(3, 2)
+            self._local(lambda r, S: T(S, 0)[:n].add_(T(S, 2)[:n]))
+        loc_mn, loc_mx = {}, {}
+        for r in self.comm.local_ranks:
+            S = self.st[r]
+            mn, mx = ctypes.c_double(0.0), ctypes.c_double(0.0)
+            check(L.tlab_minmax(self._dns_handle(r), _ptr(T(S, 0)), nx, ny, kmax, ctypes.byref(mn), ctypes.byref(mx)), "tlab_minmax")
+            loc_mn[r], loc_mx[r] = [mn.value], [mx.value]
+        return self.comm.all_reduce(loc_mn, "min")[0], self.comm.all_reduce(loc_mx, "max")[0]
 
     def TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(self, dte, kco=1.0, scale_tendencies=False):
         if self.zmode == "halo":
