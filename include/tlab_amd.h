@@ -141,6 +141,16 @@ int tlab_poisson_plan_destroy(tlab_poisson_plan_t p);
 int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,
                      const double *bcs_hb, const double *bcs_ht, double *dpdy);
 
+/* Which per-mode solver the factorized plans created AFTER this call use (also TLAB_POISSON_EXACT=1 in the environment):
+ *   0 (default): k_ode_nn, the register-chunked solver (2.8 ms at 512^3).  Its substitutions run as a parallel scan over 8-row chunks, i.e. in
+ *      another order than the reference's serial sweeps: it is as accurate as the reference, but where the problem amplifies rounding (the
+ *      projection of a non-solenoidal field: forcing div(q)/dte ~ 1e4-1e6 for a pressure of 1e2-1e3) the two differ by what two builds of
+ *      the reference itself differ by (with / without fused multiply-adds: 4e-12 in p, 1.4e-11 in dp/dy on 512-point lines; one ulp of
+ *      forcing noise -- another FFT library -- gives 6e-13 and 2.5e-12).  <= 3e-13 / 9e-13 on forcing without that cancellation.
+ *   1: the marching kernels (k_int1: one thread per mode, 5.8 ms at 512^3), which repeat FDM_Int1_Solve / OPR_ODE2_Factorize_NN operation by
+ *      operation, in the reference's order and without fused multiply-adds: 4e-13 / 1.7e-12 on the same case, i.e. at the FFT-noise floor. */
+int tlab_poisson_set_exact(int on);
+
 /* EllipticOrder = CompactDirect6: OPR_Elliptic_Initialize with TYPE_DIRECT (operators/opr_elliptic.f90:107-163, 228-245) and
  * OPR_Poisson_FourierXZ_Direct (:368-455).  gy_elliptic is the reference's fdm_loc: a y plan whose second derivative holds the CompactDirect6
  * tables (tlab_fdm_plan_create_from_arrays + tlab_fdm_plan_set_scheme(.., 16) + tlab_fdm_plan_set_aux(.. nodes)); gy stays the plan of the

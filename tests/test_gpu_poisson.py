@@ -145,3 +145,49 @@ def test_poisson_full_size_identity(T, n):
     T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, gx, p, a); T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, gx, a, b); res += b
     T.OPR_Partial_Z(T.OPR_P1, nx, ny, nz, 0, gz, p, a); T.OPR_Partial_Z(T.OPR_P1, nx, ny, nz, 0, gz, a, b); res += b
     assert float((res - f).abs().max() / f.abs().max()) <= 1e-11
+
+
+def test_exact_mode_on_a_projection_forcing(T):
+    """The forcing of the pressure equation in the first substep of a non-solenoidal field, div(hq + q/dte) ~ 3e4 for a pressure of 4e2 on
+    512-point lines: the solve amplifies rounding, one ulp of white forcing noise moves the oracle's own p by 6e-13 and dp/dy by 2.5e-12.
+    tlab_poisson_set_exact(1) (marching kernels, the reference's operations one by one, no fused multiply-adds) stays at that floor; the
+    default chunked solver differs by what two builds of the reference differ by (with / without FMA)."""
+    import torch
+    import test_gpu_rhs as M
+    from oracle.tlab_oracle_rhs import DnsOracle
+    import oracle.tlab_oracle_rhs as R
+    nx, ny, nz = 64, 512, 16
+    x, y, z = M.grids(nx, ny, nz, False)
+    q0, s0 = M.init_fields(nx, ny, nz, x, y, z, 23, noise=1e-3)
+    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(0.7,), yuniform=True)
+    for i in range(3):
+        o.q[i] = q0[i].copy()
+    o.s[0] = s0[0].copy()
+    cap = {}
+    orig = R.OP.opr_poisson_fxz
+
+    def spy(plan, f, hb, ht, *a, **k):
+        cap["f"], cap["hb"], cap["ht"] = f.copy(), hb.copy(), ht.copy()
+        cap["p"], cap["dp"] = orig(plan, f, hb, ht, *a, **k)
+        return cap["p"], cap["dp"]
+    R.OP.opr_poisson_fxz = spy
+    try:
+        o.rhs_global_incompressible_1(1e-3 / 3)
+    finally:
+        R.OP.opr_poisson_fxz = orig
+    g = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, True), T.FdmPlan(z, True, True)]
+    err = {}
+    for exact in (False, True):
+        T.poisson_set_exact(exact)
+        try:
+            plan = T.PoissonPlan(g[0], g[1], g[2], nx, ny, nz)
+        finally:
+            T.poisson_set_exact(False)
+        p = torch.from_numpy(cap["f"].copy()).cuda()
+        t1 = torch.zeros(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.zeros_like(t1); dp = torch.zeros_like(p)
+        T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p, t1, t2, torch.from_numpy(cap["hb"].ravel().copy()).cuda(),
+                      torch.from_numpy(cap["ht"].ravel().copy()).cuda(), dp)
+        err[exact] = (rel_err(p.cpu().numpy(), cap["p"]), rel_err(dp.cpu().numpy(), cap["dp"]))
+    print("projection forcing: fast p %.1e dpdy %.1e | exact p %.1e dpdy %.1e" % (err[False] + err[True]))
+    assert err[True][0] <= 1e-12 and err[True][1] <= 4e-12, err
+    assert err[False][0] <= 1e-11 and err[False][1] <= 4e-11, err

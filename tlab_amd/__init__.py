@@ -12,5 +12,5 @@ from .operators import (  # noqa: F401
     FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER, FDM_COM6_DIRECT, FDM_COM4_DIRECT,
     OPR_Partial_X, OPR_Partial_Y, OPR_Partial_Z,
     OPR_Burgers_X, OPR_Burgers_Y, OPR_Burgers_Z,
-    TLab_Transpose, PoissonPlan, OPR_Poisson, OPR_Helmholtz, BOUNDARY_BCS_NEUMANN_Y,
+    TLab_Transpose, PoissonPlan, OPR_Poisson, OPR_Helmholtz, poisson_set_exact, BOUNDARY_BCS_NEUMANN_Y,
 )

@@ -2,9 +2,10 @@
 //
 // Restates FDM_Int1_CreateSystem (fdm/fdm_integral.f90:91-214) and FDM_Bcs_Reduce (fdm/fdm_base.f90:304-391) for the
 // tridiagonal-LHS / pentadiagonal-RHS first-derivative schemes (C1N6: ndl = 3, ndr = 5).  Everything the reference
-// computes per Fourier mode that is LINEAR in the mode's constant lambda is computed once here as a pair (c0, c1),
-// lhs(lambda) = L0 + lambda * L1; the only non-linear step (the reduction of the opposite boundary, :203-211, which
-// divides by a lambda-dependent pivot) and the pentadiagonal LU are done per mode on the device (poisson.hip).
+// computes per Fourier mode that is LINEAR in the mode's constant lambda is kept here as its operands (c0, c1) and the row
+// normalisation S: lhs(lambda) = (L0 + lambda * L1) * S is evaluated per mode on the device with the reference's roundings
+// (two per entry + one for S), as are the only non-linear step (the reduction of the opposite boundary, :203-211, which
+// divides by a lambda-dependent pivot) and the pentadiagonal LU (poisson.hip).
 #include "poisson_host.hpp"
 
 #include <algorithm>
@@ -125,6 +126,7 @@ void int1_build_tables(const DerTables &g, int ibc, Int1Tables &out) {
             for (int c = 0; c < ndl; ++c) LL(nx - ir, idr - idl + 1 + c).c1 += RT(idl - ir, 1 + c);
     }
     // normalisation (:175-201)
+    std::vector<double> S((size_t)nx, 1.0);
     const int mx = std::max(idr, idl + 1);
     for (int ir = 1; ir <= mx; ++ir) {
         double dummy = 1.0 / AA(ir, idl);
@@ -133,19 +135,20 @@ void int1_build_tables(const DerTables &g, int ibc, Int1Tables &out) {
         for (int c = 1; c <= ndl + 1; ++c) RT(idl - ir + 1, c) = RT(idl - ir + 1, c) * dummy;
         dummy = 1.0 / AA(ir, idl);
         for (int c = 1; c <= ndl; ++c) AA(ir, c) = AA(ir, c) * dummy;
-        for (int c = 1; c <= ndr; ++c) LL(ir, c) = LL(ir, c) * dummy;
+        S[ir - 1] = dummy;                           // lhs(ir, :) * dummy is done per mode on the device, after B + lambda A
         dummy = 1.0 / AA(nx - ir + 1, idl);
         for (int c = 1; c <= ndl; ++c) AA(nx - ir + 1, c) = AA(nx - ir + 1, c) * dummy;
-        for (int c = 1; c <= ndr; ++c) LL(nx - ir + 1, c) = LL(nx - ir + 1, c) * dummy;
+        S[nx - ir] = dummy;
     }
     for (int ir = mx + 1; ir <= nx - mx; ++ir) {
         const double dummy = 1.0 / AA(ir, idl + 1);
         for (int c = 1; c <= ndl; ++c) AA(ir, c) = AA(ir, c) * dummy;
-        for (int c = 1; c <= ndr; ++c) LL(ir, c) = LL(ir, c) * dummy;
+        S[ir - 1] = dummy;
     }
     // pack row-major for the device
-    out.L0.assign((size_t)nx * 5, 0.0);
+    out.L0.assign((size_t)nx * 5 + nx, 0.0);         // [n][5] c0, then the row normalisation [n]
     out.L1.assign((size_t)nx * 5, 0.0);
+    for (int i = 0; i < nx; ++i) out.L0[(size_t)nx * 5 + i] = S[i];
     out.R.assign((size_t)nx * 3, 0.0);
     for (int i = 1; i <= nx; ++i) {
         for (int k = 1; k <= 5; ++k) {

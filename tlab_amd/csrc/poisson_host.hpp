@@ -9,7 +9,8 @@ namespace tlab {
 struct Int1Tables {
     int n = 0;
     int bc = 0;                  // 1 = BCS_MIN (value given at the bottom), 2 = BCS_MAX
-    std::vector<double> L0, L1;  // [n][5] row-major: lhs(lambda) = L0 + lambda L1, before the opposite-end reduction
+    std::vector<double> L0, L1;  // [n][5] row-major: lhs(lambda) = (L0 + lambda L1) * S before the opposite-end reduction; S [n] (the row
+                                 // normalisation of fdm_integral.f90:175-201) is stored behind L0's [n][5] block
     std::vector<double> R;       // [n][3] row-major: rhs (A, reduced + normalised)
     double rb[3][4];             // rhs_b(1:3, 0:3): final for BCS_MIN; for BCS_MAX rebuilt per mode from R
     double rt[3][4];             // rhs_t(0:2, 1:4): final for BCS_MAX; for BCS_MIN rebuilt per mode from R

@@ -241,6 +241,12 @@ def OPR_Poisson(plan, nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy=None)
                                   _ptr(bcs_ht, nx * nz, "bcs_ht"), _ptr(dpdy, n, "dpdy")), "tlab_opr_poisson")
 
 
+def poisson_set_exact(on):
+    """Factorized Poisson plans created after this call use the marching per-mode solver that repeats the reference's operations one by one
+    (bit-faithful up to the FFTs, 2x the time of the per-mode stage) instead of the register-chunked one; include/tlab_amd.h."""
+    check(load().tlab_poisson_set_exact(int(bool(on))), "tlab_poisson_set_exact")
+
+
 def OPR_Helmholtz(plan, nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht):
     """OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)  operators/opr_elliptic.f90:48-62 (direct variant :562-628):
     lap a + alpha a = f; `plan` must be a direct plan (PoissonPlan(..., gy_elliptic=...))."""
