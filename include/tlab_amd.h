@@ -157,7 +157,7 @@ int tlab_poisson_set_exact(int on);
  * derivatives (dp/dy = OPR_Partial_Y(OPR_P1, p), :447-449; NOT owned, must outlive the Poisson plan).  lambda(k,i) = mwn2_x(i) + mwn2_z(k) from
  * the SECOND-derivative modified wavenumbers of gx, gz; one singular mode (1,1), solved with BCS_DN and p = 0 at the bottom.  Per mode one
  * second-order integral solve (FDM_Int2_Initialize / FDM_Int2_Solve, fdm/fdm_integral.f90:334-673).  With such a plan tlab_opr_poisson accepts
- * ibc = TLAB_BCS_DD / ND / DN / NN (bcs_hb, bcs_ht: function value at a D end, derivative at an N end).  Single-rank boxes only. */
+ * ibc = TLAB_BCS_DD / ND / DN / NN (bcs_hb, bcs_ht: function value at a D end, derivative at an N end). */
 int tlab_poisson_plan_create_direct(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                                     int nx, int ny, int nz, tlab_fdm_plan_t gy_elliptic);
 /* OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)   operators/opr_elliptic.f90:48-62, OPR_Helmholtz_FourierXZ_Direct :562-628
@@ -166,6 +166,11 @@ int tlab_poisson_plan_create_direct(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
  * a factorized plan returns TLAB_EUNSUPPORTED.  a: forcing in, solution out; tmp1, tmp2 as tlab_opr_poisson. */
 int tlab_opr_helmholtz(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double alpha, double *a, double *tmp1, double *tmp2,
                        const double *bcs_hb, const double *bcs_ht);
+/* Decomposed direct plans, driven stage by stage like the factorized ones (set_wall_planes, fft_x, [exchange], fft_z, tlab_poisson_direct_ode,
+ * fft_z, [exchange], fft_x) -- with ONE field on the way back: dp/dy is OPR_Partial_Y of p on the slab (y is never split).
+ * mode 0: z-slab plan, (a, b) = (koffset, nproc_k) as tlab_poisson_plan_create_slab; mode 1: kx-pencil plan, (a, b) = (ioffset, nxl). */
+int tlab_poisson_plan_create_direct_decomposed(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                                               int nx, int ny, int kmax, int nz_total, int mode, int a, int b, tlab_fdm_plan_t gy_elliptic);
 /* the per-mode stage of a direct plan on spectral fields (nx/2+1, ny, nz) complex: f_hat -> p_hat (may alias) */
 int tlab_poisson_direct_ode(tlab_poisson_plan_t plan, int ibc, double *f_hat, double *p_hat);
 

@@ -127,3 +127,38 @@ def test_slab_monitors_equal_single_domain(T, P, nz, zmode):
     smin, smax = slab.dilatation_bounds()
     scale = max(abs(dmin), abs(dmax))
     assert abs(dmin - smin) <= 1e-12 * scale and abs(dmax - smax) <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("P,nz,zmode", [(2, 128, "halo"), (4, 64, "transpose")])
+def test_slabs_with_the_direct_schemes_equal_single_domain(T, P, nz, zmode):
+    """The scheme set of examples/Case81-93 on slabs: SpaceOrder2 = CompactDirect6 in y (host tables, tests/golden/direct_y.npz) and
+    EllipticOrder = CompactDirect6 (OPR_Poisson_FourierXZ_Direct: per-mode FDM_Int2 on the pencils / transposed slabs, ONE field on the way
+    back, dp/dy = OPR_Partial_Y(p) on the slab) against the single-domain driver."""
+    import os
+    import torch
+    from tlab_amd.dns import Dns
+    from tlab_amd.parallel import SlabDns, LoopbackComm
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "direct_y.npz"))
+    nx, ny = 32, 64
+    tab = {k[len("ny%d_" % ny):]: G[k] for k in G.files if k.startswith("ny%d_" % ny)}
+    x, y, z = np.arange(nx) / nx * 2.0, tab["nodes"], np.arange(nz) / nz
+    mk = lambda: [T.FdmPlan(x, True, True), T.FdmPlan.from_tables(tab, False, T.FDM_COM6_JACOBIAN, T.FDM_COM6_DIRECT), T.FdmPlan(z, True, True)]   # noqa: E731
+    g1, g2 = mk(), mk()
+    one = Dns(x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, plans=g1, gy_elliptic=g1[1])
+    slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, zmode=zmode, plans=g2, gy_elliptic=g2[1])
+    assert slab.zmode == zmode
+    rng = np.random.default_rng(P)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    for i in range(4):
+        a = torch.from_numpy((((np.sin(np.pi * X + i) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel())).cuda()
+        (one.q[i] if i < 3 else one.s[0]).copy_(a)
+        slab.scatter("q" if i < 3 else "s", i if i < 3 else 0, a)
+    for k in range(2):
+        one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(2e-3 * one.kdt[k], one.kco[k], True)
+        slab.substep_of_cycle(k, 2e-3)
+    for name, ref in (("q", one.q), ("s", one.s)):
+        for i, rf in enumerate(ref):
+            got = torch.cat([slab.st[r][name][i] for r in range(P)])
+            err = float((got - rf).abs().max() / rf.abs().max())
+            assert err <= 1e-11, (name, i, err)

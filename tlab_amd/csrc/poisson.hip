@@ -1841,6 +1841,18 @@ int tlab_poisson_plan_create_pencil(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
     return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, nz_total, nz_total, 0, 1, ioffset, nxl, kmax);
 }
 
+// decomposed variants of a direct plan (EllipticOrder = CompactDirect6): mode = 0 z-slab (K-transposes), 1 kx-pencil; a, b as in the
+// factorized creators: (koffset, nproc_k) or (ioffset, nxl)
+int tlab_poisson_plan_create_direct_decomposed(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx,
+                                               int ny, int kmax, int nz_total, int mode, int a, int b, tlab_fdm_plan_t gy_elliptic) {
+    if (!gy_elliptic || kmax <= 0 || nz_total % kmax != 0 || (mode != 0 && mode != 1) || (mode == 1 && b <= 0)) {
+        tlab_set_error("tlab_poisson_plan_create_direct_decomposed: bad arguments");
+        return TLAB_EINVAL;
+    }
+    if (mode == 0) return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, kmax, nz_total, a, b, 0, 0, 0, gy_elliptic);
+    return poisson_plan_create_impl(out, gx, gy, gz, nx, ny, nz_total, nz_total, 0, 1, a, b, kmax, gy_elliptic);
+}
+
 int tlab_poisson_plan_destroy(tlab_poisson_plan_t p) {
     delete p;
     return TLAB_OK;

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tlab_poisson_plan_create_direct": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "tlab_poisson_direct_ode": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tlab_poisson_set_exact": (c_int, [c_int]),
+    "tlab_poisson_plan_create_direct_decomposed": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tlab_opr_helmholtz": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tlab_pw_add3": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_longlong]),
     "tlab_pw_axpy3": (c_int, [c_vp] * 9 + [c_dbl, ctypes.c_longlong]),

@@ -231,7 +231,9 @@ class SlabDns:
     HALO = 3          # planes each side: the 7-diagonal right-hand side of the second derivative reaches 3 rows
 
     def __init__(self, comm, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
-                 hyper_bc1_ext=0.1, device="cuda", zmode="auto", zchunk=0):
+                 hyper_bc1_ext=0.1, device="cuda", zmode="auto", zchunk=0, plans=None, gy_elliptic=None):
+        """plans: optional (gx, gy, gz) built elsewhere (FdmPlan.from_tables with a host's CompactDirect6 tables in y); gy_elliptic: the y plan of
+        EllipticOrder = CompactDirect6 -> OPR_Poisson_FourierXZ_Direct on the slabs (the scheme set of examples/Case81-93)."""
         import torch
         self.comm = comm
         P = comm.size
@@ -245,8 +247,10 @@ class SlabDns:
         self.nlines = self.npage // P
         self.nscal, self.visc = int(nscal), float(visc)
         self.schmidt = [float(v) for v in schmidt][: self.nscal]
-        self.g = [FdmPlan(x, True, True, hyper_bc1_ext=hyper_bc1_ext), FdmPlan(y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext),
-                  FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
+        self.g = list(plans) if plans is not None else [
+            FdmPlan(x, True, True, hyper_bc1_ext=hyper_bc1_ext), FdmPlan(y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext),
+            FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
+        self.gy_elliptic = gy_elliptic
         self.kdt, self.kco = rk_coefficients(rkm_mode)
         self.rkm_endstep = len(self.kdt)
         self._fresh = False
@@ -289,7 +293,12 @@ class SlabDns:
                 return ext, ext[Hn:Hn + m]
             z0 = lambda m: torch.zeros(m, dtype=torch.float64, device=device)   # noqa: E731
             h = c_vp(0)
-            if self.zmode == "halo":
+            if gy_elliptic is not None:
+                mode, a, b = (1, self.ioff[r], self.nxl[r]) if self.zmode == "halo" else (0, r * self.kmax, P)
+                check(L.tlab_poisson_plan_create_direct_decomposed(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
+                                                                   self.kmax, self.nzt, mode, a, b, gy_elliptic._h),
+                      "tlab_poisson_plan_create_direct_decomposed")
+            elif self.zmode == "halo":
                 check(L.tlab_poisson_plan_create_pencil(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
                                                         self.kmax, self.nzt, self.ioff[r], self.nxl[r]), "tlab_poisson_plan_create_pencil")
             else:
@@ -371,8 +380,11 @@ class SlabDns:
         for r in c.local_ranks:
             S = self.st[r]
             S["txc"][3][:nc].copy_(fh[r])                                                                           # f^ -> tmp4
-            check(L.tlab_poisson_ode(S["poisson"], _ptr(S["txc"][3]), _ptr(S["txc"][3]), _ptr(S["txc"][1])), "ode")  # p^ -> tmp4, dp^ -> tmp2
-        for src, dst in ((3, 0), (1, 2)):                                                                            # p -> tmp1, dpdy -> tmp3
+            if self.gy_elliptic is not None:
+                check(L.tlab_poisson_direct_ode(S["poisson"], 3, _ptr(S["txc"][3]), _ptr(S["txc"][3])), "direct_ode")  # p^ -> tmp4 (BCS_NN)
+            else:
+                check(L.tlab_poisson_ode(S["poisson"], _ptr(S["txc"][3]), _ptr(S["txc"][3]), _ptr(S["txc"][1])), "ode")  # p^ -> tmp4, dp^ -> tmp2
+        for src, dst in (((3, 0),) if self.gy_elliptic is not None else ((3, 0), (1, 2))):                          # p -> tmp1, dpdy -> tmp3
             ct = trp_k_forward(c, {r: self.st[r]["txc"][src][:nc] for r in c.local_ranks}, npage_c, self.kmax, width=2)
             zb = {}
             for r in c.local_ranks:
@@ -383,6 +395,8 @@ class SlabDns:
                 S = self.st[r]
                 S["txc"][src][:nc].copy_(bk[r])
                 check(L.tlab_poisson_fft_x(S["poisson"], -1, _ptr(S["txc"][src]), _ptr(S["txc"][dst])), "fft_x")
+        if self.gy_elliptic is not None:     # dp/dy = OPR_Partial_Y(p) with the plan of the derivatives (opr_elliptic.f90:447-449)
+            self._local(lambda r, S: self._partial(2, self.g[1], self.nx, self.ny, self.kmax, S["txc"][0], S["txc"][2]))
 
     # ---- halo mode: neighbour exchanges -----------------------------------------------------------------------------------
     def _halo_start(self, fields, nplanes=None):
@@ -478,9 +492,20 @@ class SlabDns:
             S = self.st[r]
             b0, b1, b2 = S["pen"]
             check(L.tlab_poisson_fft_z(S["poisson"], 1, _ptr(b0), _ptr(b1)), "fft_z")
-            check(L.tlab_poisson_ode(S["poisson"], _ptr(b1), _ptr(b1), _ptr(b2)), "ode")                          # p^ over f^, dp^ in b2
+            if self.gy_elliptic is not None:
+                check(L.tlab_poisson_direct_ode(S["poisson"], 3, _ptr(b1), _ptr(b1)), "direct_ode")                # p^ over f^ (BCS_NN)
+            else:
+                check(L.tlab_poisson_ode(S["poisson"], _ptr(b1), _ptr(b1), _ptr(b2)), "ode")                      # p^ over f^, dp^ in b2
             check(L.tlab_poisson_fft_z(S["poisson"], -1, _ptr(b1), _ptr(b0)), "fft_z")
         w0 = self._pencil_backward_start(0, 0)                                                                     # p travels ...
+        if self.gy_elliptic is not None:     # one field on the way back; dp/dy = OPR_Partial_Y(p) on the slab (opr_elliptic.f90:447-449)
+            w0.wait()
+            self._pencil_backward_finish(0, 1)
+            for r in self.comm.local_ranks:
+                S = self.st[r]
+                check(L.tlab_poisson_fft_x(S["poisson"], -1, _ptr(S["txc"][1]), _ptr(S["txc"][0])), "fft_x")     # p -> tmp1
+                self._partial(2, self.g[1], self.nx, self.ny, self.kmax, S["txc"][0], S["txc"][2])                 # dp/dy -> tmp3
+            return
         for r in self.comm.local_ranks:
             S = self.st[r]
             check(L.tlab_poisson_fft_z(S["poisson"], -1, _ptr(S["pen"][2]), _ptr(S["pen"][1])), "fft_z")          # ... while dp/dy is transformed
