@@ -178,6 +178,11 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             // 98-162 calls OPR_Burgers_X four times with the same u)
             double v[M];
             xload<M>(v, a.in1 + off);
+            // software pipeline over the fields: with one wave per SIMD nothing else hides the memory latency, so the operand of the NEXT
+            // field and the old tendency of THIS one are requested before the two solves of this field start (2.9-3.0 -> 2.65-2.75 ms at 512^3;
+            // requesting the next LINE's velocity during the last field as well did not add anything, measured)
+            double un[M];
+            bool have_next = false;
             for (int f = 0; f < a.nf; ++f) {
                 const double *src = a.fs[f];
                 double *dst = a.fo[f];
@@ -186,9 +191,16 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 if (src == a.in1) {
 #pragma unroll
                     for (int p = 0; p < M; ++p) u[p] = v[p];
+                } else if (have_next) {
+#pragma unroll
+                    for (int p = 0; p < M; ++p) u[p] = un[p];
                 } else {
                     xload<M>(u, src + off);
                 }
+                double o[M];
+                if (a.acc) xload<M>(o, dst + off);
+                have_next = (f + 1 < a.nf) && (a.fs[f + 1] != a.in1);
+                if (have_next) xload<M>(un, a.fs[f + 1] + off);
                 double um[3], up[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -203,8 +215,6 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
 #pragma unroll
                 for (int p = 0; p < M; ++p) x2[p] = nuf * x2[p] - v[p] * x1[p];      // opr_burgers.f90:513
                 if (a.acc) {
-                    double o[M];
-                    xload<M>(o, dst + off);
 #pragma unroll
                     for (int p = 0; p < M; ++p) x2[p] = o[p] + x2[p];
                 }
@@ -218,6 +228,16 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 xload<M>(ub, a.in0b + off);
 #pragma unroll
                 for (int p = 0; p < M; ++p) u[p] = u[p] + ub[p] * a.in0b_scale;
+            }
+            // old tendency / velocity of the epilogues: requested before the solve (one wave per SIMD: nothing else hides the latency)
+            double h[MODE == MODE_P1 ? M : 1], qv[MODE == MODE_P1 ? M : 1];
+            if constexpr (MODE == MODE_P1) {
+                if (a.fq != nullptr) {
+                    xload<M>(h, a.out0 + off);
+                    xload<M>(qv, a.fq + off);
+                } else if (a.acc) {
+                    xload<M>(h, a.out0 + off);
+                }
             }
             double um[3], up[3];
 #pragma unroll
@@ -234,11 +254,8 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 xstencil<M, true>(x2, u, um, up, a.s2, lane);
                 xsolve<M, LV>(x2, y2, lane, n);
             }
-            if (MODE == MODE_P1) {
+            if constexpr (MODE == MODE_P1) {
                 if (a.fq != nullptr) {          // final-update epilogue: the line is (j, k) = (line % ny, line / ny)
-                    double h[M], qv[M];
-                    xload<M>(h, a.out0 + off);
-                    xload<M>(qv, a.fq + off);
                     const int j = (int)(line % a.fny);
                     const bool wall = (j == 0) || (j == a.fny - 1);
 #pragma unroll
@@ -251,14 +268,12 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                     xstore<M>(a.out0 + off, h);
                 } else {
                     if (a.acc) {
-                        double o[M];
-                        xload<M>(o, a.out0 + off);
 #pragma unroll
-                        for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+                        for (int p = 0; p < M; ++p) x1[p] = h[p] + x1[p];
                     }
                     xstore<M>(a.out0 + off, x1);
                 }
-            } else if (MODE == MODE_P2) {
+            } else if constexpr (MODE == MODE_P2) {
                 xstore<M>(a.out0 + off, x2);
             } else {   // MODE_P2_P1
                 xstore<M>(a.out0 + off, x2);
