@@ -82,27 +82,6 @@ __global__ void __launch_bounds__(MAXT, (L == 16 ? 2 : 1)) k_htile(RTileArgs a) 
     const bool per = a.s1.periodic != 0;
     const bool corr = a.jc.j != nullptr;        // non-uniform grid: second derivative needs the first one
 
-    // stage the tables once per workgroup: the two halves of a wave work on different rows, so the coefficient rows are not
-    // wave-uniform here; LDS reads with two distinct addresses per wave are broadcast, vector loads from L1 cost ~120 cycles each
-    double *t1 = s_tab, *t2 = s_tab + 5 * n, *gi1 = s_tab + 10 * n, *gi2 = gi1 + C * C, *tj = gi2 + C * C;
-    {
-        const bool use1 = NEED1 || corr;
-        for (int i = threadIdx.x; i < 5 * n; i += blockDim.x) {
-            if (use1) t1[i] = a.y1.rowtab[i];
-            if (NEED2) t2[i] = a.y2.rowtab[i];
-        }
-        for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
-            if (use1) gi1[i] = a.y1.red[i];
-            if (NEED2) gi2[i] = a.y2.red[i];
-        }
-        if (NEED2 && corr)
-            for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) tj[i] = a.jc.j[i];
-        if (NEED2 && a.s2.rowc != nullptr)      // direct second derivative: per-row RHS coefficients (never together with the correction)
-            for (int i = threadIdx.x; i < 5 * n; i += blockDim.x) tj[i] = a.s2.rowc[i];
-    }
-    // (the first __syncthreads inside h_solve would be too late for the coefficient reads of the local sweeps)
-    __syncthreads();
-
     // MODE_BURGERS: one launch serves every transported field that shares the advecting velocity.  Workgroup ids are dealt round-robin
     // to the 8 XCDs (each with its own L2), so the nf workgroups of a tile get ids with the same residue mod 8 and follow each other
     // closely in the dispatch order: bid = x + 8 (f + nf y), tile = x + 8 y.  The velocity tile is then fetched from HBM once and the
@@ -125,7 +104,7 @@ __global__ void __launch_bounds__(MAXT, (L == 16 ? 2 : 1)) k_htile(RTileArgs a) 
     double *__restrict__ out0 = (MODE == MODE_BURGERS) ? a.fo[fi] : a.out0;
     const double nu = (MODE == MODE_BURGERS) ? a.fnu[fi] : a.nu;
 
-    // ---- operand rows + 3-row halos ----
+    // ---- operand rows + 3-row halos: requested BEFORE the tables are staged, so that the two latencies overlap ----
     double e[M + 6];
 #pragma unroll
     for (int p = 0; p < M; ++p) e[p + 3] = valid ? in0[base + (long long)(row0 + p) * rs] : 0.0;
@@ -138,6 +117,28 @@ __global__ void __launch_bounds__(MAXT, (L == 16 ? 2 : 1)) k_htile(RTileArgs a) 
         e[k] = (valid && okl) ? in0[base + (long long)rl * rs] : 0.0;
         e[M + 3 + k] = (valid && okr) ? in0[base + (long long)rr * rs] : 0.0;
     }
+
+
+    // stage the tables once per workgroup: the two halves of a wave work on different rows, so the coefficient rows are not
+    // wave-uniform here; LDS reads with two distinct addresses per wave are broadcast, vector loads from L1 cost ~120 cycles each
+    double *t1 = s_tab, *t2 = s_tab + 5 * n, *gi1 = s_tab + 10 * n, *gi2 = gi1 + C * C, *tj = gi2 + C * C;
+    {
+        const bool use1 = NEED1 || corr;
+        for (int i = threadIdx.x; i < 5 * n; i += blockDim.x) {
+            if (use1) t1[i] = a.y1.rowtab[i];
+            if (NEED2) t2[i] = a.y2.rowtab[i];
+        }
+        for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+            if (use1) gi1[i] = a.y1.red[i];
+            if (NEED2) gi2[i] = a.y2.red[i];
+        }
+        if (NEED2 && corr)
+            for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) tj[i] = a.jc.j[i];
+        if (NEED2 && a.s2.rowc != nullptr)      // direct second derivative: per-row RHS coefficients (never together with the correction)
+            for (int i = threadIdx.x; i < 5 * n; i += blockDim.x) tj[i] = a.s2.rowc[i];
+    }
+    // (the first __syncthreads inside h_solve would be too late for the coefficient reads of the local sweeps)
+    __syncthreads();
 
     // ---- right-hand sides of both systems from the one operand ----
     double x1[M], x2[NEED2 ? M : 1];
