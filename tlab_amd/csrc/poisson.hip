@@ -1438,8 +1438,14 @@ Int1Args base_args(const tlab_poisson_plan &P, int which, const double *lam, lon
 
 // ---- chunked ODE kernel: geometry, checkpoints, launch ----
 int ode_modes_per_wg(int C) {
+    // 256 threads per workgroup where the line allows it: two workgroups then share a CU (the kernel needs ~230 VGPRs, i.e. 8 waves per CU
+    // either way) and one runs while the other waits at one of its ~40 barriers: 2.85 -> 2.55 ms at 512^3 against one 512-thread workgroup
     int nmw = 64;
-    while (nmw > 4 && nmw * C > 512) nmw >>= 1;
+    while (nmw > 4 && nmw * C > 256) nmw >>= 1;
+    if (const char *e = getenv("TLAB_ODE_NM")) {      // experiments
+        const int v = atoi(e);
+        if ((v == 4 || v == 8 || v == 16 || v == 32 || v == 64) && v * C <= 512) nmw = v;
+    }
     return (nmw * C <= 512) ? nmw : 0;
 }
 size_t ode_lds_bytes(int C, int NM) { return ((size_t)(64 + 4 * C + 10 + OK_SIZE) * NM + (size_t)(3 * OM + 1) * NM * C) * sizeof(double); }
