@@ -32,3 +32,11 @@ for it in range(args.iters + 1):
     if it: ts.append(a.elapsed_time(b))
 ts.sort(); med = ts[len(ts) // 2]
 print("OPR_Poisson %d^3: %.3f ms  %.3e pts/s  %.1f GB/s alg (24 B/pt)  mem %.1f GB" % (n, med, N / med * 1e3, 24 * N / med / 1e6, torch.cuda.memory_allocated() / 1e9))
+if os.environ.get("TLAB_PROFILE_REPORT"):
+    import ctypes
+    from tlab_amd.lib import load
+    L = load(); L.tlab_profile_reset(); L.tlab_profile_enable(1)
+    for it in range(5):
+        p.copy_(f); T.OPR_Poisson(plan, n, n, n, T.BCS_NN, p, t1, t2, hb, ht, d)
+    torch.cuda.synchronize(); L.tlab_profile_enable(0)
+    buf = ctypes.create_string_buffer(8192); L.tlab_profile_report(buf, 8192); print(buf.value.decode())
