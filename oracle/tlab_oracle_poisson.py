@@ -343,6 +343,73 @@ def ode2_factorize_nn_sing(fmin, fmax, f, bcs):
     return ode2_factorize_dn_sing(fmin, fmax, f, bcs)
 
 
+def ode2_factorize_dd(fmin, fmax, f, bcs):
+    """operators/opr_odes.f90:391-478 OPR_ODE2_Factorize_DD: u given at both ends.  Same conventions as ode2_factorize_nn."""
+    lam = fmin.lam
+    nx = fmin.nx
+    M = f.shape[2]
+    u = np.zeros_like(f)
+    v = np.zeros_like(f)
+    f[nx - 1] = 0.0                                     # v^(0): v' + lambda v = f, v_1 = 0
+    v[0] = 0.0
+    int1_solve(fmin, fmin.rhs, f, v)
+    f1 = np.zeros((nx, 2, M))                           # v^(1), e^(-)
+    h2 = np.zeros((nx, 2, M))
+    f1[nx - 1, 0] = 1.0
+    h2[0, 0] = 0.0
+    h2[0, 1] = 1.0
+    int1_solve(fmin, fmin.rhs, f1, h2)
+    u[nx - 1] = bcs[1]                                  # u^(0): u' - lambda u = v, u_n given
+    du0_n = int1_solve(fmax, fmax.rhs, v, u, want_du=True)
+    h1 = np.zeros((nx, 2, M))                           # u^(1), s^(+)
+    der_bcs = int1_solve(fmax, fmax.rhs, h2, h1, want_du=True)
+    v1, em = h2[:, 0], h2[:, 1]
+    u1, sp = h1[:, 0], h1[:, 1]
+    du1_n, dsp_n = der_bcs[0], der_bcs[1]
+    aa = du1_n - v1[nx - 1]
+    bb = dsp_n - em[nx - 1]
+    dummy = 1.0 / (aa * sp[0] - bb * u1[0])
+    q1 = (aa * (bcs[0] - u[0]) - u1[0] * (lam * bcs[1] - du0_n + v[nx - 1])) * dummy
+    fn = (sp[0] * (lam * bcs[1] - du0_n + v[nx - 1]) - bb * (bcs[0] - u[0])) * dummy
+    v[0] = q1
+    for i in range(nx - 1, 0, -1):
+        u[i] = u[i] + fn * u1[i] + v[0] * sp[i]
+        v[i] = v[i] + fn * v1[i] + v[0] * em[i] + lam * u[i]
+    u[0] = bcs[0]
+    v[0] = v[0] + lam * u[0]
+    return u, v
+
+
+def ode2_factorize_dd_sing(fmin, fmax, f, bcs):
+    """operators/opr_odes.f90:188-260 OPR_ODE2_Factorize_DD_Sing (lambda = 0 plans)."""
+    nx = fmin.nx
+    M = f.shape[2]
+    u = np.zeros_like(f)
+    v = np.zeros_like(f)
+    f[nx - 1] = 0.0                                     # v^(0): v' = f, v_1 = 0
+    v[0] = 0.0
+    int1_solve(fmin, fmin.rhs, f, v)
+    f1 = np.zeros((nx, 1, M)); f1[nx - 1, 0] = 1.0      # v^(1)
+    v1 = np.zeros((nx, 1, M))
+    int1_solve(fmin, fmin.rhs, f1, v1)
+    u[nx - 1] = bcs[1]                                  # u^(0): u' = v, u_n given
+    du0_n = int1_solve(fmax, fmax.rhs, v, u, want_du=True)
+    u1 = np.zeros((nx, 1, M))                           # u^(1)
+    du1_n = int1_solve(fmax, fmax.rhs, v1, u1, want_du=True)
+    f1 = np.ones((nx, 1, M))                            # s^(+) = x - x_n
+    sp = np.zeros((nx, 1, M))
+    int1_solve(fmax, fmax.rhs, f1, sp)
+    fn = 1.0 / (du1_n[0] - v1[nx - 1, 0])
+    c = (v[nx - 1] - du0_n) * fn
+    dummy = 1.0 / sp[0, 0]
+    v[0] = (bcs[0] - (u[0] + c * u1[0, 0])) * dummy
+    u[0] = bcs[0]
+    for i in range(1, nx):
+        u[i] = u[i] + c * u1[i, 0] + v[0] * sp[i, 0]
+        v[i] = v[i] + c * v1[i, 0] + v[0]
+    return u, v
+
+
 # ######################################################################################
 # operators/opr_elliptic.f90
 # ######################################################################################
@@ -373,7 +440,7 @@ class PoissonPlan:
 def opr_poisson_fxz(plan, p, bcs_hb, bcs_ht, ibc=BCS_NN):
     """operators/opr_elliptic.f90:263-364 OPR_Poisson_FourierXZ_Factorize (ibc = BCS_NN).
     p: flat forcing (nx*ny*nz, x fastest); bcs_hb, bcs_ht: (nz, nx) Neumann data.  Returns (p, dpdy) flat."""
-    assert ibc == BCS_NN, "oracle: only BCS_NN (the RHS call, rhs_global_incompressible_1.f90:284) is restated"
+    assert ibc in (BCS_NN, BCS_DD), "oracle: BCS_NN (the RHS call, rhs_global_incompressible_1.f90:284) and BCS_DD are restated"
     nx, ny, nz, nxh = plan.nx, plan.ny, plan.nz, plan.nxh
     a = np.array(p, dtype=np.float64).reshape(nz, ny, nx).copy()
     a[:, 0, :] = bcs_hb.reshape(nz, nx)                                  # :285-286
@@ -397,12 +464,14 @@ def opr_poisson_fxz(plan, p, bcs_hb, bcs_ht, ibc=BCS_NN):
     if reg.any():
         fmin = int1_initialize(g1, lam[reg], BCS_MIN)                   # opr_elliptic.f90:205-209
         fmax = int1_initialize(g1, -lam[reg], BCS_MAX)
-        u[:, :, reg], v[:, :, reg] = ode2_factorize_nn(fmin, fmax, f[:, :, reg].copy(), bcs[:, :, reg])
+        solve = ode2_factorize_nn if ibc == BCS_NN else ode2_factorize_dd                  # :315-329
+        u[:, :, reg], v[:, :, reg] = solve(fmin, fmax, f[:, :, reg].copy(), bcs[:, :, reg])
     if sing.any():
         ls = lam[sing]                                                   # exactly 0 at (0|Nyquist) x (0|Nyquist)
         fmin = int1_initialize(g1, ls, BCS_MIN)
         fmax = int1_initialize(g1, -ls, BCS_MAX)
-        u[:, :, sing], v[:, :, sing] = ode2_factorize_nn_sing(fmin, fmax, f[:, :, sing].copy(), bcs[:, :, sing])
+        solve = ode2_factorize_nn_sing if ibc == BCS_NN else ode2_factorize_dd_sing
+        u[:, :, sing], v[:, :, sing] = solve(fmin, fmax, f[:, :, sing].copy(), bcs[:, :, sing])
 
     def back(w):
         cc = (w[:, 0, :] + 1j * w[:, 1, :]).reshape(ny, nz, nxh).transpose(1, 0, 2)

@@ -42,6 +42,18 @@ def case(name, n, stretch):
         out["ode2_l%d_bcs" % il] = bcs
         out["ode2_l%d_u" % il] = u
         out["ode2_l%d_v" % il] = v
+    # OPR_ODE2_Factorize_DD / _DD_Sing (ibc = BCS_DD of OPR_Poisson, opr_elliptic.f90:322-329); own generator: the entries above stay as they were
+    rng = np.random.default_rng(20250511 + n)
+    for il, lam in enumerate(lams):
+        f = rng.uniform(-1, 1, (n, 2))
+        bcs = rng.uniform(-1, 1, (2, 2))
+        itype = 3 if lam > 1e-10 else 4
+        u, v = R.ode2(itype, lam, f, bcs)
+        out["ode2dd_l%d_type" % il] = itype
+        out["ode2dd_l%d_f" % il] = f
+        out["ode2dd_l%d_bcs" % il] = bcs
+        out["ode2dd_l%d_u" % il] = u
+        out["ode2dd_l%d_v" % il] = v
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name)
 

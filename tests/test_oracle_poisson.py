@@ -33,6 +33,10 @@ def test_int1_and_ode2_match_golden(path):
         u, v = fn(fmin, fmax, g["ode2_l%d_f" % il].reshape(n, 2, 1).copy(), g["ode2_l%d_bcs" % il].reshape(2, 2, 1))
         assert rel_err(u[:, :, 0], g["ode2_l%d_u" % il]) <= 1e-12, il
         assert rel_err(v[:, :, 0], g["ode2_l%d_v" % il]) <= 1e-12, il
+        fn = OP.ode2_factorize_dd if int(g["ode2dd_l%d_type" % il]) == 3 else OP.ode2_factorize_dd_sing
+        u, v = fn(fmin, fmax, g["ode2dd_l%d_f" % il].reshape(n, 2, 1).copy(), g["ode2dd_l%d_bcs" % il].reshape(2, 2, 1))
+        assert rel_err(u[:, :, 0], g["ode2dd_l%d_u" % il]) <= 1e-12, il
+        assert rel_err(v[:, :, 0], g["ode2dd_l%d_v" % il]) <= 1e-12, il
 
 
 def _poisson_setup(nx, ny, nz, seed=0):
@@ -45,6 +49,23 @@ def _poisson_setup(nx, ny, nz, seed=0):
     phi = (np.sin(X) * np.cos(2 * Z) * np.exp(0.5 * Y) + np.cos(3 * X + 1) * Y ** 2 + 0.3 * np.sin(2 * Z) * np.cos(2 * Y)
            + 0.01 * rng.uniform(-1, 1, X.shape)).ravel()
     return gx, gy, gz, phi
+
+
+@pytest.mark.parametrize("nx,ny,nz", [(32, 40, 16), (16, 24, 1)])
+def test_poisson_dirichlet_discrete_identity(nx, ny, nz):
+    """ibc = BCS_DD (OPR_ODE2_Factorize_DD / _DD_Sing per mode): p takes the given wall values and div(grad p) = f with P1 o P1."""
+    gx, gy, gz, phi = _poisson_setup(nx, ny, nz, seed=3)
+
+    def P1(d, g, u):
+        return O.opr_partial(d, 1, nx, ny, nz, 0, g, u)[0]
+
+    dphidy = P1(2, gy, phi)
+    f = P1(1, gx, P1(1, gx, phi)) + P1(2, gy, dphidy) + (P1(3, gz, P1(3, gz, phi)) if nz > 1 else 0.0)
+    p3 = phi.reshape(nz, ny, nx)
+    plan = OP.PoissonPlan(gx, gy, gz, nx, ny, nz)
+    p, dpdy = OP.opr_poisson_fxz(plan, f, p3[:, 0, :].copy(), p3[:, ny - 1, :].copy(), ibc=O.BCS_DD)
+    assert rel_err(p, phi) <= 1e-9                      # Dirichlet data pin the solution itself
+    assert rel_err(dpdy, dphidy) <= 1e-8
 
 
 @pytest.mark.parametrize("nx,ny,nz", [(32, 40, 16), (16, 24, 1), (64, 33, 8)])
