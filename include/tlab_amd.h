@@ -134,8 +134,10 @@ int tlab_poisson_plan_create(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_
 int tlab_poisson_plan_destroy(tlab_poisson_plan_t p);
 
 /* OPR_Poisson(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)   operators/opr_elliptic.f90:33-46, :263-364
- * Solves lap p = f with periodic x, z and Neumann data bcs_hb, bcs_ht (nx*nz each) in y; ibc must be TLAB_BCS_NN
- * (BCS_DD returns TLAB_EUNSUPPORTED).  p: forcing in, solution out (its wall planes are overwritten with the BC
+ * Solves lap p = f with periodic x, z.  ibc = TLAB_BCS_NN: bcs_hb, bcs_ht (nx*nz each) are dp/dy at the walls (OPR_ODE2_Factorize_NN / _NN_Sing per
+ * mode: the call of the RHS); ibc = TLAB_BCS_DD: they are p at the walls (OPR_ODE2_Factorize_DD / _DD_Sing, opr_elliptic.f90:322-329; marching
+ * kernels, 2.4x the time of the per-mode stage, work arrays allocated on first use).  The reference has no other type for the factorized solver
+ * (:312-331); direct plans (below) take all four.  p: forcing in, solution out (its wall planes are overwritten with the BC
  * data first, like the reference :285-286).  tmp1, tmp2: work arrays of isize_txc_field = (nx+2)*ny*nz doubles
  * (base/tlab_memory.f90:186-187), destroyed.  dpdy (may be NULL): dp/dy. */
 int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double *p, double *tmp1, double *tmp2,

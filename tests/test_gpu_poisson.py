@@ -198,3 +198,39 @@ def test_exact_mode_on_a_projection_forcing(T):
     assert err["default"][0] <= 1e-12 and err["default"][1] <= 4e-12, err
     assert err["exact"][0] <= 1e-12 and err["exact"][1] <= 4e-12, err
     assert err["chunked only"][0] <= 1e-11 and err["chunked only"][1] <= 4e-11, err
+
+
+@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (16, 24, 1, True), (64, 33, 8, False), (128, 64, 32, True),
+                                              (32, 512, 8, True), (16, 256, 8, False)])
+def test_poisson_dirichlet_vs_oracle(T, nx, ny, nz, stretch):
+    """ibc = BCS_DD of the factorized solver (OPR_ODE2_Factorize_DD / _DD_Sing per mode, opr_elliptic.f90:322-329): bcs_hb, bcs_ht are the
+    wall VALUES of p.  Chunked plans (ny % 8 == 0) and marching plans (ny = 33) take the same marching route for this boundary type."""
+    import torch
+    from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
+    x, y, z = setup(nx, ny, nz, stretch)
+    go = [O.FdmPlan(x, True, True), O.FdmPlan(y, False, not stretch), O.FdmPlan(z, True, True)]
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, not stretch), T.FdmPlan(z, True, True)]
+    rng = np.random.default_rng(nx + ny + nz + 1)
+    N = nx * ny * nz
+    i = np.arange(N)
+    f = np.sin(0.3 * (i % nx)) * np.cos(0.07 * (i // nx)) + 0.2 * rng.uniform(-1, 1, N)
+    hb = rng.uniform(-1, 1, nx * nz)
+    ht = rng.uniform(-1, 1, nx * nz)
+    plan_o = OP.PoissonPlan(go[0], go[1], go[2], nx, ny, nz)
+    p_ref, d_ref = OP.opr_poisson_fxz(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx), ibc=O.BCS_DD)
+    plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+    t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda")
+    t2 = torch.empty_like(t1)
+    for rep in range(2):          # twice: the second call finds the lazily built pieces in place; and an NN solve in between still works
+        p = dev(f)
+        dpdy = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
+        T.OPR_Poisson(plan, nx, ny, nz, T.BCS_DD, p, t1, t2, dev(hb), dev(ht), dpdy)
+        assert rel_err(p.cpu().numpy(), p_ref) <= TOL, rel_err(p.cpu().numpy(), p_ref)
+        assert rel_err(dpdy.cpu().numpy(), d_ref) <= 1e-11, rel_err(dpdy.cpu().numpy(), d_ref)
+        p3 = p.view(nz, ny, nx)
+        assert float((p3[:, 0, :].reshape(-1) - dev(hb)).abs().max()) <= 1e-13 and float((p3[:, ny - 1, :].reshape(-1) - dev(ht)).abs().max()) <= 1e-13
+        if rep == 0:
+            q = dev(f)
+            T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, q, t1, t2, dev(hb), dev(ht), dpdy)
+            qn, _ = OP.opr_poisson_fxz(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx))
+            assert rel_err(q.cpu().numpy(), qn) <= TOL

@@ -1304,6 +1304,112 @@ __global__ void k_sing_combine(const double *__restrict__ u0, const double *__re
     reinterpret_cast<double2 *>(dp_hat)[idx] = make_double2(v[0], v[1]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// ibc = BCS_DD of the factorized solver: OPR_ODE2_Factorize_DD (opr_odes.f90:391-478) and _DD_Sing (:188-260).  Marching kernels only
+// (the chunked kernel is the BCS_NN solver of the RHS); same two integral solves as BCS_NN with the top value of u given, other constants.
+// ------------------------------------------------------------------------------------------------
+struct DDCombineArgs {
+    const double *u0, *v0, *du0, *bcs, *hom, *der, *lam;
+    const int *sing;             // singular modes (handled separately)
+    int ns;
+    int hom_nm_block;            // 0: hom is SoA [(c*n + j)*nm + t]; NM > 0: blocked [blk][5][n][NM] (k_ode_block_layout)
+    double *p_hat, *dp_hat;
+    int n, nxh, ny;
+    long long nm;
+};
+
+__global__ void __launch_bounds__(256) k_dd_combine(DDCombineArgs a) {
+#pragma clang fp contract(off)
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nm) return;
+    for (int s = 0; s < a.ns; ++s)
+        if (a.sing[s] == t) return;
+    const int n = a.n;
+    const long long nm = a.nm;
+    const double lam = a.lam[t];
+    const long long fidx0 = (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh);
+    auto H = [&](int c, int j) {
+        if (a.hom_nm_block > 0) {
+            const int NM = a.hom_nm_block;
+            return a.hom[(((t / NM) * 5 + c) * n + j) * NM + (t % NM)];
+        }
+        return a.hom[((long long)c * n + j) * nm + t];
+    };
+    // c = 0 v1, 1 em, 2 u1, 3 sp ; der: 0 du1_n, 1 dsp_n
+    const double aa = a.der[0 * nm + t] - H(0, n - 1);
+    const double bb = a.der[1 * nm + t] - H(1, n - 1);
+    const double dummy = 1.0 / (aa * H(3, 0) - bb * H(2, 0));
+    double q1[2], fn[2], bb_[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const double bcb = a.bcs[(long long)l * nm + t], bct = a.bcs[(long long)(2 + l) * nm + t];
+        const double u0_1 = a.u0[((long long)l * n + 0) * nm + t];
+        const double v0_n = a.v0[((long long)l * n + (n - 1)) * nm + t];
+        const double w = lam * bct - a.du0[(long long)l * nm + t] + v0_n;
+        q1[l] = (aa * (bcb - u0_1) - H(2, 0) * w) * dummy;
+        fn[l] = (H(3, 0) * w - bb * (bcb - u0_1)) * dummy;
+        bb_[l] = bcb;
+    }
+    double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
+    for (int j = n - 1; j >= 1; --j) {
+        const double hv1 = H(0, j), hem = H(1, j), hu1 = H(2, j), hsp = H(3, j);
+        double u[2], v[2];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            u[l] = a.u0[((long long)l * n + j) * nm + t] + fn[l] * hu1 + q1[l] * hsp;
+            v[l] = a.v0[((long long)l * n + j) * nm + t] + fn[l] * hv1 + q1[l] * hem + lam * u[l];
+        }
+        P[fidx0 + (long long)j * a.nxh] = make_double2(u[0], u[1]);
+        D[fidx0 + (long long)j * a.nxh] = make_double2(v[0], v[1]);
+    }
+    P[fidx0] = make_double2(bb_[0], bb_[1]);
+    D[fidx0] = make_double2(q1[0] + lam * bb_[0], q1[1] + lam * bb_[1]);
+}
+
+// singular modes: f^ * norm into SoA [(l*n + j)*ns + s] (all rows), bottom / top values into bcb / bct [l*ns + s]
+__global__ void k_sing_gather_dd(const double *__restrict__ f_hat, const int *__restrict__ modes, int ns, int n, int nxh, int ny, double scale,
+                                 double *__restrict__ fs, double *__restrict__ bcb, double *__restrict__ bct) {
+    const int s = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+    if (s >= ns || j >= n) return;
+    const long long t = modes[s];
+    const double2 v = reinterpret_cast<const double2 *>(f_hat)[(t % nxh) + (long long)nxh * ny * (t / nxh) + (long long)j * nxh];
+    fs[((long long)0 * n + j) * ns + s] = v.x * scale;
+    fs[((long long)1 * n + j) * ns + s] = v.y * scale;
+    if (j == 0) { bcb[0 * ns + s] = v.x * scale; bcb[1 * ns + s] = v.y * scale; }
+    if (j == n - 1) { bct[0 * ns + s] = v.x * scale; bct[1 * ns + s] = v.y * scale; }
+}
+__global__ void k_fill_ones(double *__restrict__ a, long long m) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) a[i] = 1.0;
+}
+// opr_odes.f90:238-251
+__global__ void k_sing_combine_dd(const double *__restrict__ u0, const double *__restrict__ v0, const double *__restrict__ u1,
+                                  const double *__restrict__ v1, const double *__restrict__ sp, const double *__restrict__ du0,
+                                  const double *__restrict__ du1, const double *__restrict__ bcb, const int *__restrict__ modes, int ns, int n,
+                                  int nxh, int ny, double *__restrict__ p_hat, double *__restrict__ dp_hat) {
+#pragma clang fp contract(off)
+    const int s = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+    if (s >= ns || j >= n) return;
+    const long long t = modes[s];
+    const long long idx = (t % nxh) + (long long)nxh * ny * (t / nxh) + (long long)j * nxh;
+    const double fn = 1.0 / (du1[0 * ns + s] - v1[((long long)0 * n + (n - 1)) * ns + s]);
+    const double dummy = 1.0 / sp[((long long)0 * n + 0) * ns + s];
+    double u[2], v[2];
+    for (int l = 0; l < 2; ++l) {
+        const double c = (v0[((long long)l * n + (n - 1)) * ns + s] - du0[l * ns + s]) * fn;
+        const double q = (bcb[l * ns + s] - (u0[((long long)l * n + 0) * ns + s] + c * u1[((long long)0 * n + 0) * ns + s])) * dummy;
+        if (j == 0) {
+            u[l] = bcb[l * ns + s];
+            v[l] = q;
+        } else {
+            u[l] = u0[((long long)l * n + j) * ns + s] + c * u1[((long long)0 * n + j) * ns + s] + q * sp[((long long)0 * n + j) * ns + s];
+            v[l] = v0[((long long)l * n + j) * ns + s] + c * v1[((long long)0 * n + j) * ns + s] + q;
+        }
+    }
+    reinterpret_cast<double2 *>(p_hat)[idx] = make_double2(u[0], u[1]);
+    reinterpret_cast<double2 *>(dp_hat)[idx] = make_double2(v[0], v[1]);
+}
+
 // p(:,1,:) = bcs_hb, p(:,ny,:) = bcs_ht  (opr_elliptic.f90:285-286)
 __global__ void __launch_bounds__(256) k_set_wall_planes(double *__restrict__ p, const double *__restrict__ hb,
                                                           const double *__restrict__ ht, int nx, int ny, int nz) {
@@ -1405,6 +1511,8 @@ struct tlab_poisson_plan {
     int *d_sing = nullptr;
     unsigned char *d_skip = nullptr;
     DBuf s_lam, s_f, s_unit, s_bct, s_v0, s_v1, s_u0, s_u1, s_du0, s_du1, s_scr;
+    DBuf dd_v1, dd_u1, dd_du1, dd_sp, dd_ones, dd_bcb;      // BCS_DD: homogeneous solutions of the singular modes (built on first use)
+    bool dd_ready = false;
     FftPlan fx_r2c, fx_c2r, fz_f, fz_b;
     FftPlan f2_fwd, f2_bwd;           // optional fused 2-D (x,z) transforms, batch over y
     std::unique_ptr<FftzPlan> fz_own;  // own strided z-transform (fftz.hip) where its lengths apply; rocFFT's fz_f / fz_b otherwise
@@ -2009,6 +2117,62 @@ static void poisson_direct_stage(tlab_poisson_plan_t P, int ibc, double *f_hat, 
     hipc(hipGetLastError(), "k_int2");
 }
 
+// ibc = BCS_DD on a factorized plan (opr_elliptic.f90:322-329): marching kernels for every mode
+static void poisson_dd_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
+    const long long nm = P->nm;
+    const int n = P->ny, nxh = P->nxh, ny = P->ny;
+    const int ns = (int)P->sing_modes.size();
+    if (P->scratch.n == 0) {     // a chunked plan released the work arrays of the marching kernels: BCS_DD brings them back
+        P->scratch.alloc((size_t)6 * n * nm); P->v0.alloc((size_t)2 * n * nm); P->u0.alloc((size_t)2 * n * nm);
+    }
+    // ---- singular modes first (they read f^ before the regular combine may overwrite it when p_hat aliases f_hat) ----
+    if (ns > 0) {
+        if (!P->dd_ready) {      // v^(1): v' = delta_n, v(1) = 0 ; u^(1): u' = v1, u(n) = 0 ; s^(+): u' = 1, u(n) = 0   (opr_odes.f90:216-236)
+            P->dd_v1.alloc((size_t)2 * n * ns); P->dd_u1.alloc((size_t)2 * n * ns); P->dd_du1.alloc((size_t)2 * ns);
+            P->dd_sp.alloc((size_t)2 * n * ns); P->dd_ones.alloc((size_t)n * ns); P->dd_bcb.alloc((size_t)2 * ns);
+            hipLaunchKernelGGL(k_fill_ones, dim3((unsigned)(((long long)n * ns + 255) / 256)), dim3(256), 0, st, P->dd_ones.p, (long long)n * ns);
+            Int1Args h1 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);
+            h1.unit_row = n - 1; h1.zero_bsave = 0; h1.dst = P->dd_v1.p;
+            launch_int1<1, 2, FS_UNIT>(h1, st);
+            Int1Args h2 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);
+            h2.fsrc = P->dd_v1.p; h2.nlf = 1; h2.zero_bsave = 0; h2.dst = P->dd_u1.p; h2.du = P->dd_du1.p;
+            launch_int1<2, 2, FS_LINEAR>(h2, st);
+            Int1Args h3 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);
+            h3.fsrc = P->dd_ones.p; h3.nlf = 1; h3.zero_bsave = 0; h3.dst = P->dd_sp.p;
+            launch_int1<2, 2, FS_LINEAR>(h3, st);
+            P->dd_ready = true;
+        }
+        dim3 g(ns, (n + 63) / 64), blk(64);
+        hipLaunchKernelGGL(k_sing_gather_dd, g, blk, 0, st, f_hat, P->d_sing, ns, n, nxh, ny, P->norm, P->s_f.p, P->dd_bcb.p, P->s_bct.p);
+        Int1Args s1 = base_args(*P, 0, P->s_lam.p, ns, P->s_scr.p);        // v' = f (f(n) = 0), v(1) = 0
+        s1.fsrc = P->s_f.p; s1.nlf = 2; s1.zero_bsave = 1; s1.dst = P->s_v0.p;
+        launch_int1<1, 2, FS_LINEAR>(s1, st);
+        Int1Args s2 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);        // u' = v, u(n) = bcs_t
+        s2.fsrc = P->s_v0.p; s2.nlf = 2; s2.zero_bsave = 0; s2.bv_ptr = P->s_bct.p; s2.dst = P->s_u0.p; s2.du = P->s_du0.p;
+        launch_int1<2, 2, FS_LINEAR>(s2, st);
+    }
+    // ---- regular modes ----
+    Int1Args a = base_args(*P, 0, P->lam.p, nm, P->scratch.p);             // v' + l v = f, v(1) = 0
+    a.fsrc = f_hat; a.fscale = P->norm; a.zero_bsave = 1; a.bcs_save = P->bcs.p; a.dst = P->v0.p;
+    launch_int1<1, 2, FS_FIELD>(a, st);
+    Int1Args b = base_args(*P, 1, P->lam.p, nm, P->scratch.p);             // u' - l u = v, u(n) = bcs_t
+    b.fsrc = P->v0.p; b.nlf = 2; b.zero_bsave = 0; b.bv_ptr = P->bcs.p + (size_t)2 * nm; b.dst = P->u0.p; b.du = P->du0.p;
+    launch_int1<2, 2, FS_LINEAR>(b, st);
+    DDCombineArgs c{};
+    c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.der = P->der.p; c.lam = P->lam.p;
+    c.hom = P->use_chunked ? P->homb.p : P->hom.p;
+    c.hom_nm_block = P->use_chunked ? P->ode_nm_per_wg : 0;
+    c.sing = P->d_sing; c.ns = ns;
+    c.p_hat = p_hat; c.dp_hat = dp_hat; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
+    hipLaunchKernelGGL(k_dd_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+    if (ns > 0) {
+        dim3 g(ns, (n + 63) / 64), blk(64);
+        hipLaunchKernelGGL(k_sing_combine_dd, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->dd_u1.p, P->dd_v1.p, P->dd_sp.p, P->s_du0.p, P->dd_du1.p,
+                           P->dd_bcb.p, P->d_sing, ns, n, nxh, ny, p_hat, dp_hat);
+    }
+    hipc(hipGetLastError(), "BCS_DD kernels");
+}
+
 static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
     if (P->direct) throw std::invalid_argument("direct elliptic plan: use tlab_poisson_direct_ode (there is no dp^/dy; dp/dy is OPR_Partial_Y of p)");
     const long long nm = P->nm;
@@ -2095,8 +2259,8 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
     if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_poisson: sizes do not match the plan");
     if (P->nproc != 1 || P->nxh != P->fx_nxh || P->fx_nz != P->nz)
         throw std::invalid_argument("tlab_opr_poisson: plan is a z-slab / kx-pencil plan; drive its stages with the transposes in between");
-    if (ibc != TLAB_BCS_NN && !P->direct) {
-        tlab_set_error("OPR_Poisson (factorized): only BCS_NN is built on the device (the RHS call, rhs_global_incompressible_1.f90:284)");
+    if (ibc != TLAB_BCS_NN && ibc != TLAB_BCS_DD && !P->direct) {
+        tlab_set_error("OPR_Poisson (factorized): BCS_NN and BCS_DD only, like the reference (opr_elliptic.f90:312-331)");
         return TLAB_EUNSUPPORTED;
     }
     if (ibc < TLAB_BCS_DD || ibc > TLAB_BCS_NN) throw std::invalid_argument("tlab_opr_poisson: bad ibc");
@@ -2138,7 +2302,8 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
     } else {
         P->fx_r2c.exec(p, tmp1, st);
     }
-    poisson_ode_stage(P, tmp1, tmp1, tmp2, st);      // p^ -> tmp1 (over f^), dp^/dy -> tmp2
+    if (ibc == TLAB_BCS_DD) poisson_dd_stage(P, tmp1, tmp1, tmp2, st);
+    else poisson_ode_stage(P, tmp1, tmp1, tmp2, st);      // p^ -> tmp1 (over f^), dp^/dy -> tmp2
     // backward transforms (:341-356)
     if (P->use_2d) {
         P->f2_bwd.exec(tmp1, p, st);

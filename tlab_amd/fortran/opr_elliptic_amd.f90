@@ -1,6 +1,6 @@
 !########################################################################
 ! Drop-in replacement of the Poisson entry of module OPR_Elliptic (operators/opr_elliptic.f90): the procedure pointer OPR_Poisson with
-! the abstract interface of :33-46, bound to the device solver: OPR_Poisson_FourierXZ_Factorize (:263-364; BCS_NN), or -- when the host hands
+! the abstract interface of :33-46, bound to the device solver: OPR_Poisson_FourierXZ_Factorize (:263-364; BCS_NN and BCS_DD), or -- when the host hands
 ! over the elliptic plan fdm_loc it made for EllipticOrder = CompactDirect6 (:107-124) -- OPR_Poisson_FourierXZ_Direct (:368-455; all four BCs).
 ! OPR_Elliptic_Initialize(inifile) of the reference reads [Main] EllipticOrder and builds lambda / fdm_int1 (:86-250); here the plan is
 ! built from the host plans g(1:3) the unchanged FDM_Initialize made (their coefficient tables and modified wavenumbers).
@@ -131,7 +131,7 @@ contains
         if (present(dpdy)) pd = c_loc(dpdy)
         rc = tlab_opr_poisson(plan, int(nx, c_int), int(ny, c_int), int(nz, c_int), int(ibc, c_int), c_loc(p), c_loc(tmp1), c_loc(tmp2), &
                               c_loc(bcs_hb), c_loc(bcs_ht), pd)
-        call TLab_AMD_Check(rc, 'tlab_opr_poisson')          ! factorized plan: ibc /= BCS_NN returns TLAB_EUNSUPPORTED; Helmholtz is not built
+        call TLab_AMD_Check(rc, 'tlab_opr_poisson')          ! factorized plan: BCS_NN / BCS_DD like the reference; the mixed types need the direct plan
     end subroutine poisson_any
 
 end module TLAB_AMD_ELLIPTIC_MODULE
