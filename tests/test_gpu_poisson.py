@@ -63,8 +63,8 @@ def test_poisson_vs_oracle(T, nx, ny, nz, stretch):
     p2 = dev(f)
     T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p2, t1, t2, dev(hb), dev(ht), None)
     assert rel_err(p2.cpu().numpy(), p_ref) <= TOL
-    with pytest.raises(T.TlabError):
-        T.OPR_Poisson(plan, nx, ny, nz, T.BCS_DD, p2, t1, t2, dev(hb), dev(ht), None)
+    with pytest.raises(T.TlabError):        # the factorized solver has BCS_NN and BCS_DD only, like the reference (opr_elliptic.f90:312-331)
+        T.OPR_Poisson(plan, nx, ny, nz, T.BCS_ND, p2, t1, t2, dev(hb), dev(ht), None)
 
 
 def test_chunked_and_marching_ode_kernels_agree(T, monkeypatch):
