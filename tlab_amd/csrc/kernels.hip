@@ -197,9 +197,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 } else {
                     xload<M>(u, src + off);
                 }
+                constexpr bool PIPE = (M <= 8);      // 16 rows per lane (n = 1024): the extra line-sets would spill
                 double o[M];
-                if (a.acc) xload<M>(o, dst + off);
-                have_next = (f + 1 < a.nf) && (a.fs[f + 1] != a.in1);
+                if (PIPE && a.acc) xload<M>(o, dst + off);
+                have_next = PIPE && (f + 1 < a.nf) && (a.fs[f + 1] != a.in1);
                 if (have_next) xload<M>(un, a.fs[f + 1] + off);
                 double um[3], up[3];
 #pragma unroll
@@ -215,6 +216,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
 #pragma unroll
                 for (int p = 0; p < M; ++p) x2[p] = nuf * x2[p] - v[p] * x1[p];      // opr_burgers.f90:513
                 if (a.acc) {
+                    if (!PIPE) xload<M>(o, dst + off);
 #pragma unroll
                     for (int p = 0; p < M; ++p) x2[p] = o[p] + x2[p];
                 }
