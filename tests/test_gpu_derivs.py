@@ -295,3 +295,33 @@ def test_full_size_properties(T, n):
     a.fill_(3.25)
     T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, gp, a, ra)
     assert float(ra.abs().max()) <= 1e-12 * n
+
+
+def test_x_lines_of_2048_take_the_wave_per_line_kernel(T):
+    """BASELINE configs[4]: x lines of 2048 points.  32 rows per lane; the lane-variant tables (164 KB as doubles for the two systems) are
+    kept as chunk 0's value + a float difference, which the plan verifies to be exact on the host (capi.cpp xline_wide_ok).  All operator
+    types against the oracle; a non-periodic x of 2048 points (not compressible) still takes the generic kernel."""
+    import torch
+    from oracle import tlab_oracle as O
+    nx, ny, nz = 2048, 16, 8
+    x = np.arange(nx) / nx * 3.0
+    g, og = T.FdmPlan(x, True, True), O.FdmPlan(x, True, True)
+    rng = np.random.default_rng(2048)
+    u = rng.uniform(-1, 1, nx * ny * nz); v = rng.uniform(-1, 1, nx * ny * nz)
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    r = torch.zeros_like(du); t = torch.zeros_like(du)
+    for typ in (1, 2, 3):
+        T.OPR_Partial_X(typ, nx, ny, nz, 0, g, du, r, t)
+        assert T.load().tlab_last_kernel_path() == 2                      # wave-per-line
+        ro, to = O.opr_partial(1, typ, nx, ny, nz, 0, og, u)
+        assert rel_err(r.cpu().numpy(), ro) <= 1e-12, typ
+        if typ == 3:
+            assert rel_err(t.cpu().numpy(), to) <= 1e-12
+    T.OPR_Burgers_X(T.OPR_B_U_IN, 2e-4, nx, ny, nz, 0, g, du, dv, r, t)
+    assert T.load().tlab_last_kernel_path() == 2
+    assert rel_err(r.cpu().numpy(), O.opr_burgers(1, nx, ny, nz, 0, og, 2e-4, u, v)[0]) <= 1e-12
+    xs = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(nx) / (nx - 1) - 1)) / np.tanh(1.5))
+    gs, ogs = T.FdmPlan(xs, False, False), O.FdmPlan(xs, False, False)
+    T.OPR_Partial_X(1, nx, ny, nz, 0, gs, du, r, t)
+    assert T.load().tlab_last_kernel_path() == 1                          # generic
+    assert rel_err(r.cpu().numpy(), O.opr_partial(1, 1, nx, ny, nz, 0, ogs, u)[0]) <= 1e-12

@@ -483,9 +483,37 @@ struct OpExtra {
 };
 const OpExtra kNoExtra{};
 
-int choose_path(int dir, int n) {
+// x lines of 2048 points (BASELINE configs[4]): the wave-per-line kernel holds 32 rows per lane and keeps the lane-variant tables as float
+// differences from chunk 0 (kernels.hip, xcoef); that is exact only while the chunks differ by rounding-level amounts (periodic "uniform"
+// grids), which is checked here once per plan on the host tables.  Everything else takes the generic kernel.
+bool xline_wide_ok(tlab_fdm_plan_t g) {
+    if (!g || g->t.n != 2048 || !g->t.periodic) return false;
+    if (g->wide_ok >= 0) return g->wide_ok != 0;
+    bool ok = true;
+    for (int which = 1; which <= 2 && ok; ++which) {
+        const SystemEntry &e = g->system(which, 0, 64);
+        if (e.lane_invariant) continue;
+        const ChunkedTables &h = e.host;
+        const int n = h.n, m = h.m;
+        const std::vector<double> *tabs[5] = {&h.Lm, &h.Dinv, &h.Cm, &h.V, &h.W};
+        for (int t = 0; t < 5 && ok; ++t)
+            for (int l = 0; l < 64 && ok; ++l)
+                for (int p = 0; p < m; ++p) {
+                    const double c = (*tabs[t])[(size_t)l * m + p], b = (*tabs[t])[p];
+                    const volatile float df = (float)(c - b);
+                    const volatile double r = b + (double)df;
+                    if (r != c) { ok = false; break; }
+                }
+        (void)n;
+    }
+    g->wide_ok = ok ? 1 : 0;
+    return ok;
+}
+
+int choose_path(int dir, int n, tlab_fdm_plan_t g = nullptr) {
     int path = PATH_GENERIC;
     if (dir == 1 && xline_supported(n)) path = PATH_XLINE;
+    if (dir == 1 && n == 2048 && xline_wide_ok(g)) path = PATH_XLINE;
     if (dir != 1 && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0)) path = PATH_RTILE;
     if (g_force_path == PATH_GENERIC) path = PATH_GENERIC;
     if (g_force_path == PATH_RTILE && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0) && dir != 1) path = PATH_RTILE;
@@ -576,7 +604,7 @@ void check_common(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc) {
 bool tlab_internal_partial_p1_fusable(int dir, int nx, int ny, int nz) {
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
-    const int path = choose_path(dir, geom.n);
+    const int path = choose_path(dir, geom.n);       // no plan here: x lines of 2048 take the unfused sequence
     return path == PATH_XLINE || (path == PATH_RTILE && rtile_chunk(geom.n) > 0);
 }
 bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub,
@@ -586,7 +614,7 @@ bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, 
     if (geom.n == 1) return false;
     OpExtra ex;
     ex.in0b = ub; ex.scale = scale; ex.acc = acc;
-    const int path = choose_path(dir, geom.n);
+    const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE) {
         run_xline(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0, ex);
     } else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) {
@@ -607,7 +635,7 @@ bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, in
     if (geom.n == 1) return false;
     OpExtra ex;
     ex.fq = q; ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fnx = nx; ex.fny = ny;
-    const int path = choose_path(dir, geom.n);
+    const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE) run_xline(g, geom, MODE_P1, 0, p, nullptr, h, nullptr, 0.0, ex);
     else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_rtile(g, geom, MODE_P1, 0, p, nullptr, nullptr, h, 0.0, ex);
     else return false;
@@ -623,7 +651,7 @@ bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int n
     OpExtra ex;
     ex.acc = true;
     const bool corr = g->t.der2.need_1der || g->t.der2.direct;      // (the x-line kernel only knows the constant stencils)
-    const int path = choose_path(dir, geom.n);
+    const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE && !corr) {
         run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu, ex);
     } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {
@@ -638,7 +666,7 @@ bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int n
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz) {
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
-    const int path = choose_path(dir, geom.n);
+    const int path = choose_path(dir, geom.n, g);
     return (path == PATH_XLINE && !g->t.der2.need_1der && !g->t.der2.direct) || (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS));
 }
 // several transported fields, one advecting velocity: result[f] += nu[f] d2 s[f] - vel d s[f]
@@ -653,7 +681,7 @@ bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int
     ex.nf = nf;
     for (int f = 0; f < nf; ++f) { ex.fs[f] = s[f]; ex.fo[f] = result[f]; ex.fnu[f] = nu[f]; }
     const bool corr = g->t.der2.need_1der || g->t.der2.direct;
-    const int path = choose_path(dir, geom.n);
+    const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE && !corr) {
         run_xline(g, geom, MODE_BURGERS, ibc, s[0], vel, result[0], nullptr, nu[0], ex);
     } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {
@@ -795,7 +823,7 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
         const bool corr = g->t.der2.need_1der;
         if (type == TLAB_OPR_P2_P1 && !tmp1) throw Invalid("OPR_P2_P1 needs tmp1");
         if (type == TLAB_OPR_P2 && corr && !tmp1) throw Invalid("OPR_P2 on a non-uniform grid needs tmp1 (opr_partial.f90:96)");
-        int path = choose_path(dir, geom.n);
+        int path = choose_path(dir, geom.n, g);
         if (path == PATH_XLINE && (corr || g->t.der2.direct) && type != TLAB_OPR_P1) path = PATH_GENERIC;  // non-uniform / direct-scheme x: rare, generic kernel
         g_last_path = path;
         if (path == PATH_XLINE) {
@@ -845,7 +873,7 @@ int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int n
         const bool corr = g->t.der2.need_1der;
         const bool wt = write_transposed && ivel == TLAB_OPR_B_SELF && (dir == 1 || (dir == 2 && nz > 1));
         double *d1 = wt ? workspace((size_t)ntot) : tmp1;
-        int path = choose_path(dir, geom.n);
+        int path = choose_path(dir, geom.n, g);
         if (path == PATH_XLINE && (corr || g->t.der2.direct)) path = PATH_GENERIC;
         g_last_path = path;
         if (path == PATH_XLINE) {

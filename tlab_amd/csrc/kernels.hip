@@ -51,13 +51,18 @@ struct XSys {                    // per-wave view of one chunked system
     double a_s, c_s;             // separator-row couplings of this lane
 };
 
-template <int M, bool LV>
+// LV = 0: every chunk has the same tables (scalar loads of chunk 0); 1: lane-variant tables [5][M][64] doubles in LDS; 2: lane-variant tables
+// kept as chunk 0's value (scalar load) + a float difference in LDS -- for M = 32 (n = 2048), where two systems of doubles (164 KB) do not fit.
+// The reconstruction is exact when the chunks differ by less than 2^-29 relative (the 1e-13 wander of a "uniform" reference grid): the plan
+// checks every entry on the host (xline_wide_ok, capi.cpp) and takes the generic kernel otherwise.
+template <int M, int LV>
 __device__ __forceinline__ double xcoef(const XSys &y, int tab, int p, int lane, int n) {
-    if (LV) return y.lds[(tab * M + p) * 64 + lane];
+    if (LV == 1) return y.lds[(tab * M + p) * 64 + lane];
+    if (LV == 2) return y.rowtab[tab * n + p] + (double)reinterpret_cast<const float *>(y.lds)[(tab * M + p) * 64 + lane];
     return y.rowtab[tab * n + p];  // lane-invariant: chunk 0's row p, wave-uniform address -> scalar load
 }
 
-template <int M, bool LV>
+template <int M, int LV>
 __device__ __forceinline__ void xsys_init(XSys &y, const SystemDev &sd, const double *lds, int lane, int n) {
     y.rowtab = sd.rowtab;
     y.lds = lds;
@@ -73,7 +78,7 @@ __device__ __forceinline__ void xsys_init(XSys &y, const SystemDev &sd, const do
 }
 
 // f[0..M-1] (this lane's chunk of the right-hand side) -> solution, in place
-template <int M, bool LV>
+template <int M, int LV>
 __device__ __forceinline__ void xsolve(double (&f)[M], const XSys &y, int lane, int n) {
     double g = 0.0;
 #pragma unroll
@@ -149,7 +154,7 @@ __device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)
     for (int q = 0; q < M / 2; ++q) reinterpret_cast<double2 *>(p)[q] = make_double2(u[2 * q], u[2 * q + 1]);
 }
 
-template <int M, int MODE, bool LV>
+template <int M, int MODE, int LV>
 __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     extern __shared__ double xlds[];
     constexpr bool NEED1 = (MODE != MODE_P2);
@@ -158,7 +163,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     const int wib = threadIdx.x >> 6;
     const int n = 64 * M;
 
-    if (LV) {  // lane-variant tables (non-periodic): stage [5][M][64] per system in LDS once per block
+    if (LV == 1) {  // lane-variant tables (non-periodic): stage [5][M][64] per system in LDS once per block
         for (int idx = threadIdx.x; idx < 5 * M * 64; idx += blockDim.x) {
             const int l = idx & 63, p = (idx >> 6) % M, tab = idx / (64 * M);
             if (NEED1) xlds[idx] = a.y1.rowtab[tab * n + l * M + p];
@@ -166,9 +171,19 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
         }
         __syncthreads();
     }
+    if (LV == 2) {  // the same as float differences from chunk 0
+        float *xf = reinterpret_cast<float *>(xlds);
+        for (int idx = threadIdx.x; idx < 5 * M * 64; idx += blockDim.x) {
+            const int l = idx & 63, p = (idx >> 6) % M, tab = idx / (64 * M);
+            if (NEED1) xf[idx] = (float)(a.y1.rowtab[tab * n + l * M + p] - a.y1.rowtab[tab * n + p]);
+            if (NEED2) xf[5 * M * 64 + idx] = (float)(a.y2.rowtab[tab * n + l * M + p] - a.y2.rowtab[tab * n + p]);
+        }
+        __syncthreads();
+    }
     XSys y1, y2;
+    const double *lds2 = (LV == 2) ? reinterpret_cast<const double *>(reinterpret_cast<const float *>(xlds) + 5 * M * 64) : xlds + 5 * M * 64;
     if (NEED1) xsys_init<M, LV>(y1, a.y1, xlds, lane, n);
-    if (NEED2) xsys_init<M, LV>(y2, a.y2, xlds + 5 * M * 64, lane, n);
+    if (NEED2) xsys_init<M, LV>(y2, a.y2, lds2, lane, n);
 
     const long long stride = (long long)gridDim.x * 4;
     for (long long line = (long long)blockIdx.x * 4 + wib; line < a.nlines; line += stride) {
@@ -579,11 +594,11 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a,
 // ============================================================================================
 static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
 
-template <int M, bool LV>
+template <int M, int LV>
 static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     const long long blocks_needed = (a.nlines + 3) / 4;
     const int grid = imin(blocks_needed, 256 * 8);
-    const size_t lds = LV ? (size_t)2 * 5 * M * 64 * sizeof(double) : 0;
+    const size_t lds = LV == 1 ? (size_t)2 * 5 * M * 64 * sizeof(double) : LV == 2 ? (size_t)2 * 5 * M * 64 * sizeof(float) : 0;
     const double pts = (double)a.nlines * 64 * M;
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};
@@ -603,13 +618,14 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
-bool xline_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+bool xline_supported(int n) { return n == 256 || n == 512 || n == 1024; }      // n = 2048: see launch_xline / xline_wide_ok
 
 hipError_t launch_xline(int mode, int n, bool lane_variant, const XLineArgs &a, hipStream_t st) {
     switch (n) {
-    case 256: return lane_variant ? launch_xline_m<4, true>(mode, a, st) : launch_xline_m<4, false>(mode, a, st);
-    case 512: return lane_variant ? launch_xline_m<8, true>(mode, a, st) : launch_xline_m<8, false>(mode, a, st);
-    case 1024: return lane_variant ? launch_xline_m<16, true>(mode, a, st) : launch_xline_m<16, false>(mode, a, st);
+    case 256: return lane_variant ? launch_xline_m<4, 1>(mode, a, st) : launch_xline_m<4, 0>(mode, a, st);
+    case 512: return lane_variant ? launch_xline_m<8, 1>(mode, a, st) : launch_xline_m<8, 0>(mode, a, st);
+    case 1024: return lane_variant ? launch_xline_m<16, 1>(mode, a, st) : launch_xline_m<16, 0>(mode, a, st);
+    case 2048: return lane_variant ? launch_xline_m<32, 2>(mode, a, st) : launch_xline_m<32, 0>(mode, a, st);     // the caller checked xline_wide_ok
     }
     return hipErrorInvalidValue;
 }
