@@ -325,3 +325,27 @@ def test_x_lines_of_2048_take_the_wave_per_line_kernel(T):
     T.OPR_Partial_X(1, nx, ny, nz, 0, gs, du, r, t)
     assert T.load().tlab_last_kernel_path() == 1                          # generic
     assert rel_err(r.cpu().numpy(), O.opr_partial(1, 1, nx, ny, nz, 0, ogs, u)[0]) <= 1e-12
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_lines_of_1024_points_fused_on_16_line_tiles(T, d):
+    """BASELINE configs[3]/[4]: y / z lines of 1024 points.  OPR_P2_P1 and OPR_Burgers keep two line-sets in registers on 16-line tiles
+    (32 chunks of 32 rows, 512 threads) instead of taking two launches; stretched grid along y (Jacobian correction in-kernel)."""
+    import torch
+    from oracle import tlab_oracle as O
+    n = 1024
+    nx, ny, nz = (32, n, 8) if d == 2 else (32, 8, n)
+    stretched = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(n) / (n - 1) - 1)) / np.tanh(1.5))
+    nodes = stretched if d == 2 else np.arange(n) / n
+    g = T.FdmPlan(nodes, d == 3, d == 3)
+    og = O.FdmPlan(nodes, d == 3, d == 3)
+    rng = np.random.default_rng(d)
+    u = rng.uniform(-1, 1, nx * ny * nz); v = rng.uniform(-1, 1, nx * ny * nz)
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    r = torch.zeros_like(du); t = torch.zeros_like(du)
+    part, burg = (T.OPR_Partial_Y, T.OPR_Burgers_Y) if d == 2 else (T.OPR_Partial_Z, T.OPR_Burgers_Z)
+    part(T.OPR_P2_P1, nx, ny, nz, 0, g, du, r, t)
+    ro, to = O.opr_partial(d, 3, nx, ny, nz, 0, og, u)
+    assert rel_err(r.cpu().numpy(), ro) <= 1e-12 and rel_err(t.cpu().numpy(), to) <= 1e-12
+    burg(T.OPR_B_U_IN, 3e-4, nx, ny, nz, 0, g, du, dv, r, t)
+    assert rel_err(r.cpu().numpy(), O.opr_burgers(d, nx, ny, nz, 0, og, 3e-4, u, v)[0]) <= 1e-12

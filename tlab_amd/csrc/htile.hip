@@ -67,7 +67,7 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
 // L = lines per tile: 32 (a wave holds two chunks) or 16 (four chunks; half the tile, so that TWO workgroups fit a CU and one can
 // load or store while the other solves)
 template <int M, int MODE, int MAXT, int L>
-__global__ void __launch_bounds__(MAXT, (L == 16 ? 2 : 1)) k_htile(RTileArgs a) {
+__global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_htile(RTileArgs a) {
     __shared__ double s_yl[32 * L];
     __shared__ double s_r[32 * L];
     __shared__ double s_e[2 * 32 * L];   // first-derivative edge values of every chunk (Jacobian correction)
@@ -248,6 +248,7 @@ int htile_chunk(int n, int mode) {
     if (two) {
         if (ok(32, 16)) return 32;      // <= 512 threads -> 256-VGPR budget
         if (ok(16, 16)) return 16;
+        if (n == 1024) return 32;       // 32 chunks of 32 rows on 16-LINE tiles: still 512 threads (launch_htile)
         return 0;
     }
     if (ok(32, 32)) return 32;          // up to n = 1024 with 1024 threads (P1/P2: < 128 VGPRs)
@@ -286,11 +287,14 @@ hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st) {
     if (M == 0) return hipErrorInvalidValue;
     const int C = n / M;
     if (C & 1) return hipErrorInvalidValue;      // two chunks per wave
+    const bool two = (mode == MODE_P2_P1 || mode == MODE_BURGERS);
     const bool narrow = (g_htile_lines == 16) && mode == MODE_BURGERS && M == 32 && C <= 16;
-    const int L = narrow ? 16 : 32;
+    const bool long16 = two && M == 32 && C == 32;     // lines of 1024 points with two line-sets in registers: 16-line tiles, 4 chunks per wave
+    const int L = (narrow || long16) ? 16 : 32;
     const long long tiles_inner = (a.g.lines_inner + L - 1) / L;
     const long long tiles = tiles_inner * (a.g.nlines / a.g.lines_inner);
     if (narrow) return launch_htile_m<32, 256, 16>(mode, C, tiles, a, st);
+    if (long16) return launch_htile_m<32, 512, 16>(mode, C, tiles, a, st);
     if (M == 64) return launch_htile_m<64, 512>(mode, C, tiles, a, st);
     if (M == 32) return (C <= 16) ? launch_htile_m<32, 512>(mode, C, tiles, a, st) : launch_htile_m<32, 1024>(mode, C, tiles, a, st);
     return (C <= 16) ? launch_htile_m<16, 512>(mode, C, tiles, a, st) : launch_htile_m<16, 1024>(mode, C, tiles, a, st);
