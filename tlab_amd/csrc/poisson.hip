@@ -1998,11 +1998,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                 }
             }
         }
-        {   // the side stream carries a few latency-bound launches beside k_ode_nn: highest priority, so that they are not queued behind its workgroups
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            hipc(hipStreamCreateWithPriority(&P->side, hipStreamNonBlocking, hi), "stream");
-        }
+        hipc(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking), "stream");
         hipc(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming), "event");
         hipc(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), "event");
         hipStream_t st = tlab_current_stream();
