@@ -235,6 +235,19 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
 #pragma unroll
                     for (int p = 0; p < M; ++p) x2[p] = o[p] + x2[p];
                 }
+                if constexpr (M <= 8) {
+                    if (a.ffin[f]) {          // the tendency of this field is complete: wall planes, Runge-Kutta update, scaling (k_final_update's arithmetic)
+                        const int j = (int)(line % a.fny);
+                        const bool wall = (j == 0) || (j == a.fny - 1);
+#pragma unroll
+                        for (int p = 0; p < M; ++p) {
+                            const double hv = wall ? 0.0 : x2[p];
+                            u[p] = u[p] + a.fdte * hv;
+                            x2[p] = a.fscale ? a.fkco * hv : hv;
+                        }
+                        xstore<M>(const_cast<double *>(src) + off, u);
+                    }
+                }
                 xstore<M>(dst + off, x2);
             }
         } else {

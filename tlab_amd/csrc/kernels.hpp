@@ -29,6 +29,10 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     double *fq;
     double fdte, fkco;
     int fscale, fnx, fny;
+    // MODE_BURGERS, 8 rows per lane at most: ffin[f] != 0 finishes the substep of transported field f (a scalar: no pressure term) in the epilogue
+    // of this launch, which must be the LAST one that adds to its tendency:  h = fo[f] (+ this term) ; h = 0 on the wall planes ;
+    // fs[f] += fdte h ; fo[f] = fscale ? fkco h : h     (time.f90:645-664, :272-297; Dirichlet walls)
+    int ffin[4];
 };
 
 struct RTileArgs {          // k_rtile: derivative along a strided index

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -28,8 +29,9 @@ bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int n
 bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
                                   double kco, int scale);
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
+bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
-                                 const double *vel, double *const *result, bool overwrite);
+                                 const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale);
 
 struct tlab_dns {
     tlab_fdm_plan_t g[3];
@@ -162,15 +164,32 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     if (fresh && !batched) {
         for (size_t e = 0; e < eqs.size(); ++e) hk(hipMemsetAsync(eqs[e].dst, 0, (size_t)n * sizeof(double), st), "memset");
     }
+    // The scalars have no pressure term: with Dirichlet walls their Runge-Kutta update (s += dte hs, hs *= kco; time.f90:645-664, :272-297) can
+    // ride on the LAST Burgers launch that adds to hs, if that launch is the x one (the wave-per-line kernel has the registers for it; the
+    // y/z tile kernels do not, measured).  The directions then run z, y, x instead of x, y, z: the terms are summed in another order, rounding only.
+    static const bool finish_off = [] { const char *e = getenv("TLAB_SCALAR_FINISH"); return e && atoi(e) == 0; }();
+    bool finish_scal = !finish_off && batched && tail_update && d->nscal > 0 && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
+    for (int is = 0; is < d->nscal; ++is)
+        finish_scal = finish_scal && d->scal_jmin[is] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[is] == TLAB_DNS_BCS_DIRICHLET;
     if (batched) {
-        for (int dir = 1; dir <= 3; ++dir)
+        const int order_xyz[3] = {1, 2, 3}, order_zyx[3] = {3, 2, 1};
+        const int *order = finish_scal ? order_zyx : order_xyz;
+        for (int k = 0; k < 3; ++k) {
+            const int dir = order[k];
             for (size_t e0 = 0; e0 < eqs.size(); e0 += 4) {
                 const int nf = (int)std::min<size_t>(4, eqs.size() - e0);
                 const double *sp[4]; double *rp[4]; double nup[4];
-                for (int f = 0; f < nf; ++f) { sp[f] = eqs[e0 + f].fld; rp[f] = eqs[e0 + f].dst; nup[f] = eqs[e0 + f].nu; }
-                if (!tlab_internal_burgers_acc_n(dir, d->g[dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[dir - 1], rp, fresh && dir == 1))
+                int fin[4] = {0, 0, 0, 0};
+                for (int f = 0; f < nf; ++f) {
+                    sp[f] = eqs[e0 + f].fld; rp[f] = eqs[e0 + f].dst; nup[f] = eqs[e0 + f].nu;
+                    fin[f] = (finish_scal && k == 2 && e0 + f >= 3) ? 1 : 0;        // equations 3.. are the scalars
+                }
+                const bool any_fin = fin[0] || fin[1] || fin[2] || fin[3];
+                if (!tlab_internal_burgers_acc_n(dir, d->g[dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[dir - 1], rp, fresh && k == 0,
+                                                 any_fin ? fin : nullptr, dte, kco, scale_tendencies ? 1 : 0))
                     throw Fail(TLAB_EINVAL, "internal: inconsistent fused Burgers path");
             }
+        }
     }
     for (size_t e = 0; e < eqs.size() && !batched; ++e) {
         bool pending = false;
@@ -254,7 +273,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             planes(ibc_q[iq], hq[iq], pb, pt);
             hk(launch_final_update(q[iq], hq[iq], gp[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
-        for (int is = 0; is < d->nscal; ++is) {
+        for (int is = 0; is < d->nscal && !finish_scal; ++is) {      // (finish_scal: done in the epilogue of the x Burgers launch)
             planes(ibc_of(d->scal_jmin[is], d->scal_jmax[is]), hs[is], pb, pt);
             hk(launch_final_update(s[is], hs[is], nullptr, pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
