@@ -481,6 +481,8 @@ struct OpExtra {
     double fdte = 0.0, fkco = 1.0;
     int fscale = 0, fnx = 1, fny = 1;
     int ffin[4] = {0, 0, 0, 0};
+    double *fdiv = nullptr;
+    double fidte = 0.0;
 };
 const OpExtra kNoExtra{};
 
@@ -576,6 +578,7 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny;
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; a.ffin[f] = ex.ffin[f]; }
+    a.fdiv = ex.fdiv; a.fidte = ex.fidte;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     SystemEntry &e1 = g->system(1, ibc, 64), &e2 = g->system(2, 0, 64);
@@ -681,7 +684,7 @@ bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny
 // (s += dte h, h = scale ? kco h : h, h = 0 on the wall planes); only where tlab_internal_burgers_can_finish says so
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco,
-                                 int scale) {
+                                 int scale, double *divx, double idte) {
     check_common(dir, g, nx, ny, nz, ibc);
     if (nf < 1 || nf > 4) throw Invalid("1 to 4 fields per call");
     const LineGeom geom = make_geom(dir, nx, ny, nz);
@@ -694,6 +697,10 @@ bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int
         if (!tlab_internal_burgers_can_finish(dir, g, nx, ny, nz)) throw Invalid("internal: this Burgers launch cannot finish a field");
         for (int f = 0; f < nf; ++f) ex.ffin[f] = finish[f];
         ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fny = ny;
+    }
+    if (divx) {      // divx: the launch also writes d/dx (h + idte vel) of the field that is the velocity itself (x term of the pressure forcing)
+        if (!tlab_internal_burgers_can_finish(dir, g, nx, ny, nz)) throw Invalid("internal: this Burgers launch cannot write the forcing term");
+        ex.fdiv = divx; ex.fidte = idte;
     }
     const bool corr = g->t.der2.need_1der || g->t.der2.direct;
     const int path = choose_path(dir, geom.n, g);
@@ -745,7 +752,7 @@ int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, i
         if (nf < 1 || nf > 4 || !nu || !s || !vel || !result) throw Invalid("tlab_opr_burgers_add_n: bad arguments (1 to 4 fields)");
         for (int f = 0; f < nf; ++f)
             if (!s[f] || !result[f] || result[f] == s[f] || result[f] == vel) throw Invalid("tlab_opr_burgers_add_n: null or aliased arrays");
-        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result, overwrite != 0, nullptr, 0.0, 1.0, 0)) return;
+        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result, overwrite != 0, nullptr, 0.0, 1.0, 0, nullptr, 0.0)) return;
         for (int f = 0; f < nf; ++f) {
             if (overwrite) hip_check(hipMemsetAsync(result[f], 0, (size_t)nx * ny * nz * sizeof(double), g_stream), "memset");
             const int rc = tlab_opr_burgers_add(dir, g, nx, ny, nz, ibc, nu[f], s[f], vel, result[f], tmp1, tmp2);

@@ -236,6 +236,19 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                     for (int p = 0; p < M; ++p) x2[p] = o[p] + x2[p];
                 }
                 if constexpr (M <= 8) {
+                    if (a.fdiv != nullptr && src == a.in1) {     // tendency of u complete: x term of the pressure forcing from the registers
+                        double wq[M];
+#pragma unroll
+                        for (int p = 0; p < M; ++p) wq[p] = x2[p] + v[p] * a.fidte;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            um[k] = shfl_d(wq[M - 3 + k], (lane + 63) & 63);
+                            up[k] = shfl_d(wq[k], (lane + 1) & 63);
+                        }
+                        xstencil<M, false>(x1, wq, um, up, a.s1, lane);
+                        xsolve<M, LV>(x1, y1, lane, n);
+                        xstore<M>(a.fdiv + off, x1);
+                    }
                     if (a.ffin[f]) {          // the tendency of this field is complete: wall planes, Runge-Kutta update, scaling (k_final_update's arithmetic)
                         const int j = (int)(line % a.fny);
                         const bool wall = (j == 0) || (j == a.fny - 1);

@@ -33,6 +33,10 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     // of this launch, which must be the LAST one that adds to its tendency:  h = fo[f] (+ this term) ; h = 0 on the wall planes ;
     // fs[f] += fdte h ; fo[f] = fscale ? fkco h : h     (time.f90:645-664, :272-297; Dirichlet walls)
     int ffin[4];
+    // ... and fdiv != NULL: for the field whose operand is the advecting velocity itself (u along x) the launch also writes the x term of the
+    // pressure forcing, d/dx (h + fidte u) with the finished tendency h (rhs_global_incompressible_1.f90:197-230), into fdiv
+    double *fdiv;
+    double fidte;
 };
 
 struct RTileArgs {          // k_rtile: derivative along a strided index

@@ -31,7 +31,8 @@ bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, in
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
-                                 const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale);
+                                 const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale,
+                                 double *divx, double idte);
 
 struct tlab_dns {
     tlab_fdm_plan_t g[3];
@@ -171,9 +172,14 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     bool finish_scal = !finish_off && batched && tail_update && d->nscal > 0 && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
     for (int is = 0; is < d->nscal; ++is)
         finish_scal = finish_scal && d->scal_jmin[is] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[is] == TLAB_DNS_BCS_DIRICHLET;
+    // Likewise the x term of the pressure forcing, d/dx (hq1 + u/dte) (:197-230): when the x Burgers launch runs last it holds the finished
+    // tendency of u in registers, line by line, and differentiates it on the spot instead of a separate launch re-reading hq1 and u.
+    const double idte = 1.0 / dte;
+    const bool x_last = !finish_off && batched && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
+    const bool div_in_burgers = x_last && d->fuse && tlab_internal_partial_p1_fusable(2, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, nx, ny, nz);
     if (batched) {
         const int order_xyz[3] = {1, 2, 3}, order_zyx[3] = {3, 2, 1};
-        const int *order = finish_scal ? order_zyx : order_xyz;
+        const int *order = x_last ? order_zyx : order_xyz;
         for (int k = 0; k < 3; ++k) {
             const int dir = order[k];
             for (size_t e0 = 0; e0 < eqs.size(); e0 += 4) {
@@ -185,8 +191,9 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
                     fin[f] = (finish_scal && k == 2 && e0 + f >= 3) ? 1 : 0;        // equations 3.. are the scalars
                 }
                 const bool any_fin = fin[0] || fin[1] || fin[2] || fin[3];
+                double *divx = (div_in_burgers && dir == 1 && e0 == 0) ? tmp1 : nullptr;       // batch 0 holds u
                 if (!tlab_internal_burgers_acc_n(dir, d->g[dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[dir - 1], rp, fresh && k == 0,
-                                                 any_fin ? fin : nullptr, dte, kco, scale_tendencies ? 1 : 0))
+                                                 any_fin ? fin : nullptr, dte, kco, scale_tendencies ? 1 : 0, divx, idte))
                     throw Fail(TLAB_EINVAL, "internal: inconsistent fused Burgers path");
             }
         }
@@ -208,10 +215,14 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         }
     }
     // ---- pressure (:177-260, remove_divergence branch): forcing = div(hq + q/dte) ----
-    const double idte = 1.0 / dte;
     bool fused_div = d->fuse && tlab_internal_partial_p1_fusable(1, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, nx, ny, nz) &&
                      tlab_internal_partial_p1_fusable(3, nx, ny, nz);
-    if (fused_div) {
+    if (div_in_burgers) {     // tmp1 holds the x term already
+        const bool oky = tlab_internal_partial_p1_fused(2, gy, nx, ny, nz, B0, hq[1], v, idte, tmp1, true);
+        const bool okz = oky && tlab_internal_partial_p1_fused(3, gz, nx, ny, nz, B0, hq[2], w, idte, tmp1, true);
+        if (!oky || !okz) throw Fail(TLAB_EINVAL, "internal: inconsistent fused divergence path");
+        fused_div = true;
+    } else if (fused_div) {
         fused_div = tlab_internal_partial_p1_fused(2, gy, nx, ny, nz, B0, hq[1], v, idte, tmp1, false);
         if (fused_div) {
             const bool okx = tlab_internal_partial_p1_fused(1, gx, nx, ny, nz, B0, hq[0], u, idte, tmp1, true);
