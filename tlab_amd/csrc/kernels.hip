@@ -632,7 +632,8 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     double bytes = pts * (bpp[mode] + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0) + (a.fq ? 24 : 0));
     if (mode == MODE_BURGERS) {   // velocity once + per field: operand (unless it is the velocity), result, previous result when accumulating
         bytes = pts * 8;
-        for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in1 ? 0 : 8) + 8 + (a.acc ? 8 : 0));
+        for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in1 ? 0 : 8) + 8 + (a.acc ? 8 : 0) + (a.ffin[f] ? 8 : 0));
+        if (a.fdiv) bytes += pts * 8;       // epilogues: updated scalar, x term of the pressure forcing
     }
     ProfScope ps(names[mode], st, bytes);
     switch (mode) {
