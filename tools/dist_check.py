@@ -70,6 +70,13 @@ def main():
             got = slab.st[rank][name][i]
             err = float((got - rf[rank * n:(rank + 1) * n]).abs().max() / rf.abs().max())
             worst = max(worst, err)
+    # per-iteration monitors on slabs: the same maxima as the single domain (MPI_MAX / MPI_MIN of two scalars, time.f90:522)
+    (a1, a2), dta = one.TIME_COURANT(1.2, 0.3)
+    (b1, b2), dtb = slab.TIME_COURANT(1.2, 0.3)
+    worst = max(worst, abs(a1 - b1) / a1, abs(a2 - b2) / a2, abs(dta - dtb) / dta)
+    dmin, dmax = one.dilatation_bounds()
+    smin, smax = slab.dilatation_bounds()
+    worst = max(worst, abs(dmin - smin) / a1, abs(dmax - smax) / a1)      # a1 = max(|u_i|/h_i): the size of the terms of div(q)
     tt = torch.tensor([worst], dtype=torch.float64)
     if backend == "nccl":
         tt = tt.cuda()
