@@ -24,3 +24,21 @@ def test_multiprocess_slabs(world, zmode, nz, bcs):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "DIST_CHECK" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_rccl_operations_of_the_slab_driver():
+    """DistComm on the RCCL backend with device buffers (what `bench.py --gpus N` uses).  The test box has one GPU, so one rank:
+    every peer is the rank itself, but the calls, the grouped send/recv and the stream ordering are RCCL's.  Followed by the
+    slab substep on that backend against the single-domain substep."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TLAB_DIST_BACKEND", None)
+    for script, mark, extra in (("rccl_check.py", "RCCL_CHECK", []), ("dist_check.py", "DIST_CHECK", ["--zmode", "transpose"])):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29557", os.path.join(ROOT, "tools", script)] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        assert mark in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
+        assert "backend=nccl" in out.stdout or script == "rccl_check.py"
