@@ -153,6 +153,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         substep(args.warmup + k)
+    enqueue = time.perf_counter() - t0          # host time to issue the K substeps (this rank); the rest of `elapsed` is the GPU finishing
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -198,6 +199,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "host_issue_ms_per_step": enqueue / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
