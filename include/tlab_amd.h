@@ -165,10 +165,14 @@ int tlab_poisson_set_exact(int on);
  * ibc = TLAB_BCS_DD / ND / DN / NN (bcs_hb, bcs_ht: function value at a D end, derivative at an N end). */
 int tlab_poisson_plan_create_direct(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                                     int nx, int ny, int nz, tlab_fdm_plan_t gy_elliptic);
-/* OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)   operators/opr_elliptic.f90:48-62, OPR_Helmholtz_FourierXZ_Direct :562-628
- * Solves lap a + alpha a = f on a DIRECT plan (per mode the second-order integral system with constant lambda2 - alpha, any of the four
- * boundary types, no singular-mode treatment: alpha < 0 in the implicit RK that calls it).  The factorized variant (:466-557) is not built:
- * a factorized plan returns TLAB_EUNSUPPORTED.  a: forcing in, solution out; tmp1, tmp2 as tlab_opr_poisson. */
+/* OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)   operators/opr_elliptic.f90:48-62
+ * Solves lap a + alpha a = f (the solver of the implicit RK, alpha < 0).  a: forcing in, solution out; tmp1, tmp2 as tlab_opr_poisson.
+ * - DIRECT plan: OPR_Helmholtz_FourierXZ_Direct (:562-628), per mode the second-order integral system with constant lambda2 - alpha, any of
+ *   the four boundary types, no singular-mode treatment.
+ * - factorized plan of tlab_poisson_plan_create: OPR_Helmholtz_FourierXZ_Factorize (:466-557), per mode OPR_ODE2_Factorize_NN / _DD with
+ *   sqrt(lambda - alpha) (must be positive for every mode), ibc = TLAB_BCS_NN or TLAB_BCS_DD (others: TLAB_EUNSUPPORTED, like the reference).
+ *   Where the reference factorizes 2 systems per mode on every call (:518-522), the tables of an alpha are built on its first call and kept
+ *   (the 4 most recent alphas; about 6 field-sized arrays each); the x, y, z plans given to tlab_poisson_plan_create must still be alive. */
 int tlab_opr_helmholtz(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, double alpha, double *a, double *tmp1, double *tmp2,
                        const double *bcs_hb, const double *bcs_ht);
 /* Decomposed direct plans, driven stage by stage like the factorized ones (set_wall_planes, fft_x, [exchange], fft_z, tlab_poisson_direct_ode,

@@ -482,6 +482,34 @@ def opr_poisson_fxz(plan, p, bcs_hb, bcs_ht, ibc=BCS_NN):
     return back(u), back(v)
 
 
+def opr_helmholtz_fxz_factorize(plan, a, bcs_hb, bcs_ht, ibc, alpha):
+    """operators/opr_elliptic.f90:466-557 OPR_Helmholtz_FourierXZ_Factorize: lap a + alpha a = f.  Per mode the two first-order systems of
+    OPR_ODE2_Factorize_NN / _DD with sqrt(lambda(k,i) - alpha) (:518-522), every mode a regular one (no singular-mode branch).  Returns a flat."""
+    assert ibc in (BCS_NN, BCS_DD)                                       # :524-532
+    nx, ny, nz, nxh = plan.nx, plan.ny, plan.nz, plan.nxh
+    w = np.array(a, dtype=np.float64).reshape(nz, ny, nx).copy()
+    w[:, 0, :] = bcs_hb.reshape(nz, nx)                                  # :487-488
+    w[:, ny - 1, :] = bcs_ht.reshape(nz, nx)
+    c = np.fft.rfft(w, axis=2)
+    if nz > 1:
+        c = np.fft.fft(c, axis=0)
+    c = c * plan.norm                                                    # :497
+    M = nz * nxh
+    f = np.empty((ny, 2, M))
+    f[:, 0, :] = c.real.transpose(1, 0, 2).reshape(ny, M)
+    f[:, 1, :] = c.imag.transpose(1, 0, 2).reshape(ny, M)
+    bcs = np.stack([f[0].copy(), f[ny - 1].copy()])                      # :514-515
+    lam = np.sqrt(plan.lam2.reshape(M) - alpha)
+    fmin = int1_initialize(plan.gy.der1, lam, BCS_MIN)
+    fmax = int1_initialize(plan.gy.der1, -lam, BCS_MAX)
+    solve = ode2_factorize_nn if ibc == BCS_NN else ode2_factorize_dd
+    u, _ = solve(fmin, fmax, f.copy(), bcs)
+    cc = (u[:, 0, :] + 1j * u[:, 1, :]).reshape(ny, nz, nxh).transpose(1, 0, 2)
+    if nz > 1:
+        cc = np.fft.ifft(cc, axis=0) * nz
+    return (np.fft.irfft(cc, n=nx, axis=2) * nx).reshape(-1)
+
+
 # ######################################################################################
 # DIRECT elliptic solver (EllipticOrder = CompactDirect4/6): fdm/fdm_integral.f90:318-673, operators/opr_elliptic.f90:368-455
 # ######################################################################################

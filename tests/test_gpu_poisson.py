@@ -234,3 +234,39 @@ def test_poisson_dirichlet_vs_oracle(T, nx, ny, nz, stretch):
             T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, q, t1, t2, dev(hb), dev(ht), dpdy)
             qn, _ = OP.opr_poisson_fxz(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx))
             assert rel_err(q.cpu().numpy(), qn) <= TOL
+
+
+@pytest.mark.parametrize("nx,ny,nz,stretch,ibc,alphas", [
+    (32, 40, 16, True, 3, (-7.5,)), (16, 24, 1, True, 0, (-120.0,)), (64, 33, 8, False, 3, (-2.0e3,)), (128, 64, 32, True, 0, (-0.5, -40.0)),
+    (32, 512, 8, True, 3, (-1.0e4, -3.0)), (16, 256, 8, False, 3, (-1.0, -2.0, -3.0, -4.0, -5.0, -1.0))])
+def test_factorized_helmholtz_vs_oracle(T, nx, ny, nz, stretch, ibc, alphas):
+    """OPR_Helmholtz_FourierXZ_Factorize (opr_elliptic.f90:466-557) on the plan of OPR_Poisson: per mode OPR_ODE2_Factorize_NN / _DD with
+    sqrt(lambda - alpha).  Chunked (ny % 8 == 0) and marching (ny = 33) plans; the last case walks through more alphas than the plan keeps
+    tables for and comes back to the first; a Poisson solve on the same plan afterwards is untouched."""
+    import torch
+    from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
+    x, y, z = setup(nx, ny, nz, stretch)
+    go = [O.FdmPlan(x, True, True), O.FdmPlan(y, False, not stretch), O.FdmPlan(z, True, True)]
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, not stretch), T.FdmPlan(z, True, True)]
+    rng = np.random.default_rng(nx + ny + nz + ibc)
+    N = nx * ny * nz
+    i = np.arange(N)
+    f = np.sin(0.3 * (i % nx)) * np.cos(0.07 * (i // nx)) + 0.2 * rng.uniform(-1, 1, N)
+    hb = rng.uniform(-1, 1, nx * nz)
+    ht = rng.uniform(-1, 1, nx * nz)
+    plan_o = OP.PoissonPlan(go[0], go[1], go[2], nx, ny, nz)
+    plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+    t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda")
+    t2 = torch.empty_like(t1)
+    refs = {}
+    for alpha in alphas:
+        if alpha not in refs:
+            refs[alpha] = OP.opr_helmholtz_fxz_factorize(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx), ibc, alpha)
+        a = dev(f)
+        T.OPR_Helmholtz(plan, nx, ny, nz, ibc, alpha, a, t1, t2, dev(hb), dev(ht))
+        assert rel_err(a.cpu().numpy(), refs[alpha]) <= TOL, (alpha, rel_err(a.cpu().numpy(), refs[alpha]))
+    p = dev(f)
+    dpdy = torch.empty(N, dtype=torch.float64, device="cuda")
+    T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p, t1, t2, dev(hb), dev(ht), dpdy)
+    p_ref, _ = OP.opr_poisson_fxz(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx))
+    assert rel_err(p.cpu().numpy(), p_ref) <= TOL

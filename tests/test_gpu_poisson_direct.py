@@ -79,7 +79,8 @@ def test_helmholtz_direct_matches_oracle(T, nx, ny, nz, ibc, alpha):
     assert rel_err(a.cpu().numpy(), a_ref) <= TOL, rel_err(a.cpu().numpy(), a_ref)
 
 
-def test_helmholtz_needs_a_direct_plan(T):
+def test_factorized_helmholtz_refuses_mixed_boundary_types(T):
+    """OPR_Helmholtz_FourierXZ_Factorize knows BCS_NN and BCS_DD (opr_elliptic.f90:524-532)."""
     import torch
     x = np.arange(16) / 16.0
     y = np.arange(24) / 23.0
@@ -89,7 +90,9 @@ def test_helmholtz_needs_a_direct_plan(T):
     t1 = torch.zeros(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.zeros_like(t1)
     hb = torch.zeros(256, dtype=torch.float64, device="cuda")
     with pytest.raises(T.TlabError):
-        T.OPR_Helmholtz(plan, 16, 24, 16, 0, -1.0, a, t1, t2, hb, hb.clone())
+        T.OPR_Helmholtz(plan, 16, 24, 16, 1, -1.0, a, t1, t2, hb, hb.clone())
+    with pytest.raises(T.TlabError):      # lambda - alpha must be positive (the mean mode has lambda = 0)
+        T.OPR_Helmholtz(plan, 16, 24, 16, 3, 0.0, a, t1, t2, hb, hb.clone())
 
 
 def test_direct_plan_needs_the_direct_tables(T):

@@ -87,6 +87,23 @@ def test_poisson_discrete_identity(nx, ny, nz):
     assert abs(p.reshape(nz, ny, nx)[:, 0, :].mean()) <= 1e-12 * np.abs(p).max()
 
 
+@pytest.mark.parametrize("nx,ny,nz,ibc,alpha", [(32, 40, 16, O.BCS_NN, -7.5), (16, 24, 1, O.BCS_DD, -120.0), (16, 48, 8, O.BCS_DD, -0.5)])
+def test_helmholtz_factorized_discrete_identity(nx, ny, nz, ibc, alpha):
+    """OPR_Helmholtz_FourierXZ_Factorize: with f = (P1 o P1 Laplacian + alpha) phi and phi's own wall data the solver returns phi (alpha < 0: no
+    null space, so the data pin the solution for both boundary types)."""
+    gx, gy, gz, phi = _poisson_setup(nx, ny, nz, seed=5)
+
+    def P1(d, g, u):
+        return O.opr_partial(d, 1, nx, ny, nz, 0, g, u)[0]
+
+    dphidy = P1(2, gy, phi)
+    f = P1(1, gx, P1(1, gx, phi)) + P1(2, gy, dphidy) + (P1(3, gz, P1(3, gz, phi)) if nz > 1 else 0.0) + alpha * phi
+    w = (dphidy if ibc == O.BCS_NN else phi).reshape(nz, ny, nx)
+    plan = OP.PoissonPlan(gx, gy, gz, nx, ny, nz)
+    a = OP.opr_helmholtz_fxz_factorize(plan, f, w[:, 0, :].copy(), w[:, ny - 1, :].copy(), ibc, alpha)
+    assert rel_err(a, phi) <= 1e-10
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # DIRECT elliptic solver (EllipticOrder = CompactDirect6): FDM_Int2_* and OPR_Poisson_FourierXZ_Direct
 # ---------------------------------------------------------------------------------------------------------------------------------

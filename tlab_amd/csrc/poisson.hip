@@ -16,11 +16,13 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/tlab_amd.h"
@@ -1522,6 +1524,11 @@ struct tlab_poisson_plan {
     // DIRECT elliptic solver (EllipticOrder = CompactDirect6): one second-order integral operator per boundary type, built on first use
     bool direct = false;
     tlab_fdm_plan_t gy_der = nullptr;         // y plan of the derivatives (dp/dy = OPR_Partial_Y(p), opr_elliptic.f90:447-449); not owned
+    // factorized Helmholtz (opr_elliptic.f90:466-557): the per-mode tables depend on alpha, so every alpha in use is a sub-plan of its own
+    // (tables only; transforms and work field are the parent's).  The implicit RK cycles through a few alphas: the last 4 are kept.
+    tlab_fdm_plan_t g3[3] = {nullptr, nullptr, nullptr};      // x, y, z plans of a single-device factorized plan; not owned
+    bool helmholtz = false;
+    std::vector<std::pair<double, std::unique_ptr<tlab_poisson_plan>>> helm;
     DerTables ell_der2;                       // second derivative of the elliptic y plan (fdm_loc%der2)
     std::vector<double> ell_nodes;
     struct Int2Set { Int2Tables host; DBuf Bt, A5, s, R; };
@@ -1886,7 +1893,7 @@ extern "C" {
 // nz: planes of the local spectral box; [ioff, ioff+nxl) its kx range (nxl = 0: all nx/2+1); fx_nz: planes of the local PHYSICAL box
 static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
                                     int nz, int nzt, int koff, int nproc, int ioff = 0, int nxl = 0, int fx_nz = 0,
-                                    tlab_fdm_plan_t gy_ell = nullptr) {
+                                    tlab_fdm_plan_t gy_ell = nullptr, bool helmholtz = false, double alpha = 0.0) {
     try {
         if (!out || !gx || !gy || !gz) throw std::invalid_argument("tlab_poisson_plan_create: null argument");
         if (!tlab_device_ready()) throw std::runtime_error("tlab_init has not been called (no CPU fallback exists)");
@@ -1956,10 +1963,14 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
             for (int i = 0; i < P->nxh; ++i) {
                 double l2 = std::pow(gx->t.der1.mwn[P->ioff + i], 2.0);
                 if (nzt > 1) l2 += std::pow(gz->t.der1.mwn[koff + k], 2.0);   // kglobal = k + ims_offset_k (:191)
+                if (helmholtz) {                                             // sqrt(lambda(k,i) - alpha) (:518-522)
+                    if (!(l2 - alpha > 0.0)) throw std::invalid_argument("OPR_Helmholtz (factorized): lambda - alpha must be positive for every mode");
+                    l2 = l2 - alpha;
+                }
                 lam[(size_t)i + (size_t)P->nxh * k] = std::sqrt(l2);
             }
         const int isg[2] = {0, nx / 2}, ksg[2] = {0, nzt > 1 ? nzt / 2 : 0};   // i_sing, k_sing (:148-149), 0-based, global
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2 && !helmholtz; ++a)                           // Helmholtz: every mode is a regular one (:512-531)
             for (int b = 0; b < 2; ++b) {
                 const int kl = ksg[b] - koff;                               // task-local index (:177-178)
                 const int il = isg[a] - P->ioff;
@@ -1980,16 +1991,18 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         P->hom.alloc(5 * n * nm); P->der.alloc(3 * nm); P->cst.alloc(9 * nm);
         P->scratch.alloc(6 * n * nm);      // NL + 3 components, NL <= 3
         P->v0.alloc(2 * n * nm); P->u0.alloc(2 * n * nm); P->du0.alloc(2 * nm); P->bcs.alloc(4 * nm);
-        P->cwork.alloc((size_t)2 * P->nxh * ny * nz);
+        P->helmholtz = helmholtz;
+        if (!helmholtz) P->cwork.alloc((size_t)2 * P->nxh * ny * nz);
+        if (nproc == 1 && nxl == 0) { P->g3[0] = gx; P->g3[1] = gy; P->g3[2] = gz; }
         P->s_f.alloc(2 * n * ns); P->s_bct.alloc(2 * ns); P->s_v0.alloc(2 * n * ns); P->s_v1.alloc(2 * n * ns);
         P->s_u0.alloc(2 * n * ns); P->s_u1.alloc(2 * n * ns); P->s_du0.alloc(2 * ns); P->s_du1.alloc(2 * ns); P->s_scr.alloc(5 * n * ns);
-        build_fft(*P);
+        if (!helmholtz) build_fft(*P);
         {   // fused 2-D (x,z) transforms are ~2x faster than r2c(x) + strided c2c(z) at 512^3, but rocFFT does not build them
             // for every layout: fall back to the two 1-D plans when plan creation fails (TLAB_FFT2D=0 forces the 1-D path)
             const char *e = getenv("TLAB_FFT2D");
             // ... and slower than r2c(x) + the own strided z-transform (fftz.hip: 0.49 + 0.53 ms against 1.14 ms at 512^3), so they are only
             // built where that kernel does not apply (TLAB_FFTZ=0 or a length that is not 8^a * {1,2,4})
-            if (nzt > 1 && nproc == 1 && nxl == 0 && !P->fz_own && !(e && atoi(e) == 0)) {
+            if (!helmholtz && nzt > 1 && nproc == 1 && nxl == 0 && !P->fz_own && !(e && atoi(e) == 0)) {
                 try {
                     build_fft_2d(*P);
                     P->use_2d = true;
@@ -2363,29 +2376,54 @@ int tlab_poisson_ode(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double
     POISSON_GUARD_END
 }
 
-// OPR_Helmholtz_FourierXZ_Direct(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)  operators/opr_elliptic.f90:562-628
+// OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht): OPR_Helmholtz_FourierXZ_Direct (operators/opr_elliptic.f90:562-628) on a
+// direct plan, OPR_Helmholtz_FourierXZ_Factorize (:466-557) on a factorized one
 int tlab_opr_helmholtz(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, double alpha, double *a, double *tmp1, double *tmp2,
                        const double *bcs_hb, const double *bcs_ht) {
     POISSON_GUARD_BEGIN
     if (!P || !a || !tmp1 || !tmp2 || !bcs_hb || !bcs_ht) throw std::invalid_argument("tlab_opr_helmholtz: null argument");
     if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_helmholtz: sizes do not match the plan");
-    if (!P->direct) {
-        tlab_set_error("OPR_Helmholtz: only the direct variant (EllipticOrder = CompactDirect6) is built on the device");
-        return TLAB_EUNSUPPORTED;
-    }
     if (ibc < TLAB_BCS_DD || ibc > TLAB_BCS_NN) throw std::invalid_argument("tlab_opr_helmholtz: bad ibc");
     if (a == tmp1 || a == tmp2 || tmp1 == tmp2) throw std::invalid_argument("arrays must be distinct");
+    tlab_poisson_plan *H = nullptr;
+    if (!P->direct) {
+        if (ibc != TLAB_BCS_NN && ibc != TLAB_BCS_DD) {
+            tlab_set_error("OPR_Helmholtz (factorized): BCS_NN and BCS_DD only, like the reference (opr_elliptic.f90:524-532)");
+            return TLAB_EUNSUPPORTED;
+        }
+        if (!P->g3[0] || P->helmholtz) throw std::invalid_argument("tlab_opr_helmholtz: needs a single-device plan of tlab_poisson_plan_create");
+        for (size_t i = 0; i < P->helm.size(); ++i)
+            if (P->helm[i].first == alpha) {      // most recently used last
+                std::rotate(P->helm.begin() + i, P->helm.begin() + i + 1, P->helm.end());
+                H = P->helm.back().second.get();
+                break;
+            }
+        if (!H) {
+            tlab_poisson_plan_t h = nullptr;
+            const int rc = poisson_plan_create_impl(&h, P->g3[0], P->g3[1], P->g3[2], nx, ny, nz, nz, 0, 1, 0, 0, 0, nullptr, true, alpha);
+            if (rc != TLAB_OK) return rc;
+            if (P->helm.size() >= 4) P->helm.erase(P->helm.begin());
+            P->helm.emplace_back(alpha, std::unique_ptr<tlab_poisson_plan>(h));
+            H = h;
+        }
+    }
     hipStream_t st = tlab_current_stream();
     hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, a, bcs_hb, bcs_ht, nx, ny, nz);
-    if (nz > 1) {
+    if (P->use_2d) {
+        P->f2_fwd.exec(a, tmp1, st);
+    } else if (nz > 1) {
         P->fx_r2c.exec(a, tmp2, st);
         if (P->fz_own) P->fz_own->exec(1, tmp2, tmp1, st);
         else P->fz_f.exec(tmp2, tmp1, st);
     } else {
         P->fx_r2c.exec(a, tmp1, st);
     }
-    poisson_direct_stage(P, ibc, tmp1, tmp1, st, true, alpha);
-    if (nz > 1) {
+    if (P->direct) poisson_direct_stage(P, ibc, tmp1, tmp1, st, true, alpha);
+    else if (ibc == TLAB_BCS_DD) poisson_dd_stage(H, tmp1, tmp1, tmp2, st);      // u over f^; v = u' + sqrt(lambda - alpha) u (not returned) in tmp2
+    else poisson_ode_stage(H, tmp1, tmp1, tmp2, st);
+    if (P->use_2d) {
+        P->f2_bwd.exec(tmp1, a, st);
+    } else if (nz > 1) {
         if (P->fz_own) P->fz_own->exec(-1, tmp1, P->cwork.p, st);
         else P->fz_b.exec(tmp1, P->cwork.p, st);
         P->fx_c2r.exec(P->cwork.p, a, st);

@@ -23,7 +23,7 @@ module TLAB_AMD_ELLIPTIC_MODULE
 
     public :: OPR_Elliptic_Initialize_AMD       ! (g, nx, ny, nz [, fdm_loc]): what OPR_Elliptic_Initialize takes from modules FDM / TLab_Memory
     public :: OPR_Poisson
-    public :: OPR_Helmholtz                     ! direct plans only (OPR_Helmholtz_FourierXZ_Direct, :562-628)
+    public :: OPR_Helmholtz                     ! _FourierXZ_Direct (:562-628) or _FourierXZ_Factorize (:466-557), by the plan's type
 
     abstract interface
         subroutine OPR_Poisson_interface(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)      ! opr_elliptic.f90:33-46
@@ -116,7 +116,7 @@ contains
         integer(c_int) rc
         rc = tlab_opr_helmholtz(plan, int(nx, c_int), int(ny, c_int), int(nz, c_int), int(ibc, c_int), real(alpha, c_double), c_loc(p), &
                                 c_loc(tmp1), c_loc(tmp2), c_loc(bcs_hb), c_loc(bcs_ht))
-        call TLab_AMD_Check(rc, 'tlab_opr_helmholtz')        ! a factorized plan returns TLAB_EUNSUPPORTED
+        call TLab_AMD_Check(rc, 'tlab_opr_helmholtz')        ! factorized plans: BCS_NN and BCS_DD only, like the reference
     end subroutine helmholtz_any
 
     subroutine poisson_any(nx, ny, nz, ibc, p, tmp1, tmp2, bcs_hb, bcs_ht, dpdy)           ! c_loc needs the TARGET attribute

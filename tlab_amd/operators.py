@@ -248,8 +248,9 @@ def poisson_set_exact(on):
 
 
 def OPR_Helmholtz(plan, nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht):
-    """OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)  operators/opr_elliptic.f90:48-62 (direct variant :562-628):
-    lap a + alpha a = f; `plan` must be a direct plan (PoissonPlan(..., gy_elliptic=...))."""
+    """OPR_Helmholtz(nx, ny, nz, ibc, alpha, a, tmp1, tmp2, bcs_hb, bcs_ht)  operators/opr_elliptic.f90:48-62: lap a + alpha a = f.
+    Direct plan (PoissonPlan(..., gy_elliptic=...)): OPR_Helmholtz_FourierXZ_Direct :562-628, any boundary type; factorized plan:
+    OPR_Helmholtz_FourierXZ_Factorize :466-557, BCS_NN or BCS_DD (the tables of an alpha are built on its first call)."""
     n = nx * ny * nz
     _use_torch_stream()
     check(load().tlab_opr_helmholtz(plan._h, nx, ny, nz, int(ibc), float(alpha), _ptr(a, n, "a"), _ptr(tmp1, plan.isize_txc_field, "tmp1"),
