@@ -574,6 +574,7 @@ struct OdeArgs {
     const double *chk1, *chk2;   // [C][6][nm] PENTADFS state before the first row of each chunk
     const double *cst;           // [9][nm] LU of the constraint matrix (k_nn_constants)
     const double *hom;           // [5][n][nm] homogeneous solutions v1, em, u1, sp, ep (build_homogeneous)
+    int pair_xcd;                // see k_ode_nn
     const double *f_hat;
     double *p_hat, *dp_hat;
     double fscale;
@@ -1000,7 +1001,12 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // 32-bit index arithmetic throughout (the host checks that every array has < 2^31 elements): 64-bit address pairs for the ~50
     // distinct rows this thread touches would otherwise be precomputed and kept in registers
     const int nm = (int)a.nm;
-    int t = blockIdx.x * NM + m;
+    // NM = 4: a workgroup's row of f^ / p^ / dp^ is 64 B, half a 128-B line.  Workgroups go round-robin over the 8 XCDs (each with its own L2), so
+    // the neighbour that owns the other half would sit on another XCD and the line would cross the fabric twice (PMC: 9.3 GB per launch against
+    // 6.7 algorithmic).  Pair them: of every 16 consecutive workgroups, XCD x gets the adjacent blocks 2x and 2x + 1.
+    unsigned blk = blockIdx.x;
+    if (NM == 4 && a.pair_xcd && (blk | 15u) < gridDim.x) blk = (blk & ~15u) + 2u * (blk & 7u) + ((blk >> 3) & 1u);
+    int t = (int)blk * NM + m;
     const bool live = t < nm;
     if (!live) t = nm - 1;
     const bool store = live && !a.skip[t];
@@ -1635,6 +1641,11 @@ void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_h
     a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
     a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.nm = P.nm;
     const int NM = P.ode_nm_per_wg;
+    {
+        static int pair = -1;
+        if (pair < 0) { const char *e = getenv("TLAB_ODE_PAIR_XCD"); pair = e ? atoi(e) : 1; }
+        a.pair_xcd = pair;
+    }
     const size_t lds = ode_lds_bytes(a.C, NM);
     ProfScope ps("k_ode_nn", st, (double)P.nm * P.ny * (48.0 + 40.0 + 12.0));      // f^, p^, dp^ + homogeneous solutions + checkpoints
     switch (NM) {
