@@ -200,6 +200,10 @@ int tlab_poisson_plan_create_pencil(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
  * its kx range [ioff[p], ioff[p+1]) (ioff[nproc] = nxh implied), blocks back to back.  dir = +1 slab -> buffer, -1 buffer -> slab.  nproc <= 8.
  * (The pencil side needs no repacking: z is its slowest index.)  Bit-exact index work. */
 int tlab_pencil_repack(double *slab, double *buffer, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir);
+/* The same with up to 16 blocks placed anywhere in the buffer: block b = kx range [start[b], start[b+1]) (the last one ends at nx/2+1), laid out
+ * [kmax][ny][width] from complex element base[b] on.  Used by the slab driver to send every peer's kx range in two halves, all first halves
+ * ahead of all second halves, so that the solves of one half run while the other half is on the wire (tlab_amd/parallel.py). */
+int tlab_pencil_repack_blocks(double *slab, double *buffer, int nxh, int ny, int kmax, int nblocks, const int *start, const long long *base, int dir);
 int tlab_poisson_set_wall_planes(tlab_poisson_plan_t plan, double *p, const double *bcs_hb, const double *bcs_ht);
 int tlab_poisson_fft_x(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* OPR_Fourier_X_Forward/Backward, opr_fourier.f90:219,277 */
 int tlab_poisson_fft_z(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* the FFT inside OPR_Fourier_Z_*, :355,422 */

@@ -162,3 +162,35 @@ def test_slabs_with_the_direct_schemes_equal_single_domain(T, P, nz, zmode):
             got = torch.cat([slab.st[r][name][i] for r in range(P)])
             err = float((got - rf).abs().max() / rf.abs().max())
             assert err <= 1e-11, (name, i, err)
+
+
+@pytest.mark.parametrize("P,nx,nz", [(2, 32, 128), (3, 48, 192), (8, 64, 512)])
+def test_two_stage_pencil_poisson_is_bit_identical(T, P, nx, nz, monkeypatch):
+    """The kx-pencil Poisson solve sends every rank's kx range in two halves so that the solves of one half run under the transfers of the other
+    (SlabDns._poisson_pencil_staged).  Same kernels on the same modes: p and dp/dy equal those of the one-piece exchange to the bit (uneven
+    pencils at P = 3 and at nx/2+1 = 33 over 8 ranks included)."""
+    import torch
+    from tlab_amd.parallel import SlabDns, LoopbackComm
+    ny = 16
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(P + nx)
+    f = rng.uniform(-1, 1, nx * ny * nz)
+    hb, ht = rng.uniform(-1, 1, nx * nz), rng.uniform(-1, 1, nx * nz)
+    out = {}
+    for stages in ("1", "2"):
+        monkeypatch.setenv("TLAB_PENCIL_STAGES", stages)
+        slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, yuniform=False, zmode="halo")
+        assert slab.stages == int(stages)
+        kmax, n = slab.kmax, slab.n
+        for r in range(P):
+            S = slab.st[r]
+            S["txc"][0][:n].copy_(torch.from_numpy(f[r * n:(r + 1) * n]))
+            S["hb"].copy_(torch.from_numpy(hb.reshape(nz, nx)[r * kmax:(r + 1) * kmax].ravel()))
+            S["ht"].copy_(torch.from_numpy(ht.reshape(nz, nx)[r * kmax:(r + 1) * kmax].ravel()))
+        slab._poisson_pencil()
+        torch.cuda.synchronize()
+        out[stages] = [torch.cat([slab.st[r]["txc"][i][:n] for r in range(P)]).cpu().numpy() for i in (0, 2)]
+    assert np.isfinite(out["2"][0]).all() and np.abs(out["2"][0]).max() > 0
+    assert np.array_equal(out["1"][0], out["2"][0]) and np.array_equal(out["1"][1], out["2"][1])

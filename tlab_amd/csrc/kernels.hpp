@@ -95,7 +95,8 @@ hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, co
 hipError_t launch_minmax_partial(const double *a, const double *v, const double *w, const double *odx, const double *ody, const double *odz,
                                  int mode, int nx, int ny, int nz, int koff, double *part, int nblocks, hipStream_t st);
 hipError_t launch_negate(double *a, long long n, hipStream_t st);
-hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir, hipStream_t st);
+hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kmax, int nproc, const int *ioff, const long long *base, int dir,
+                                hipStream_t st);
 hipError_t launch_add1(double *h, const double *a, long long n, hipStream_t st);
 hipError_t launch_axpy1(double *o, const double *a, const double *b, double s, long long n, hipStream_t st);
 hipError_t launch_sum3(double *a, const double *b, const double *c, long long n, hipStream_t st);

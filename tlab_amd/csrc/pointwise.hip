@@ -166,17 +166,31 @@ __global__ void __launch_bounds__(256) k_axpy1(double *__restrict__ o, const dou
 // ---- z-slab <-> kx-pencil repacking around the all-to-all of the Poisson solver (tlab_amd/parallel.py) ----------------------
 // slab a(nxh, ny, kmax) complex, x fastest; buffer = for every peer p the block [kmax][ny][nxl_p] of its kx range [ioff_p, ioff_p + nxl_p),
 // blocks one after the other.  dir = +1: a -> buffer (before sending), dir = -1: buffer -> a (after receiving).  Pure index work.
-struct PencilMap { int nproc; int ioff[9]; long long base[9]; };      // base[p] = first complex element of block p (base[nproc] = total)
+struct PencilMap { int nproc; int ioff[17]; long long base[17]; };    // block p = kx range [ioff[p], ioff[p+1]); base[p] = its first complex element in the buffer
 __global__ void __launch_bounds__(256) k_pencil_repack(double2 *__restrict__ a, double2 *__restrict__ buf, PencilMap m, int nxh, int ny, int kmax,
                                                        int dir) {
     const long long n = (long long)nxh * ny * kmax, stride = (long long)gridDim.x * blockDim.x;
+    __shared__ unsigned char s_blk[4096];             // block of every kx (when the row fits)
+    __shared__ int s_off[17];
+    __shared__ long long s_base[17];
+    if (threadIdx.x <= m.nproc) { s_off[threadIdx.x] = m.ioff[threadIdx.x]; s_base[threadIdx.x] = m.base[threadIdx.x]; }
+    const bool table = nxh <= 4096;
+    if (table) {
+        for (int i = threadIdx.x; i < nxh; i += blockDim.x) {
+            int p = 0;
+            while (p + 1 < m.nproc && i >= m.ioff[p + 1]) ++p;
+            s_blk[i] = (unsigned char)p;
+        }
+    }
+    __syncthreads();
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const int i = (int)(e % nxh);
         const long long jk = e / nxh;                 // j + ny * k
         int p = 0;
-        while (p + 1 < m.nproc && i >= m.ioff[p + 1]) ++p;
-        const int nxl = (p + 1 < m.nproc ? m.ioff[p + 1] : nxh) - m.ioff[p];
-        const long long b = m.base[p] + jk * nxl + (i - m.ioff[p]);
+        if (table) p = s_blk[i];
+        else while (p + 1 < m.nproc && i >= m.ioff[p + 1]) ++p;
+        const int nxl = s_off[p + 1] - s_off[p];      // s_off[nproc] = nxh
+        const long long b = s_base[p] + jk * nxl + (i - s_off[p]);
         if (dir > 0) buf[b] = a[e];
         else a[e] = buf[b];
     }
@@ -225,14 +239,16 @@ hipError_t launch_minmax_partial(const double *a, const double *v, const double 
     hipLaunchKernelGGL(k_minmax_partial, dim3(nblocks), dim3(256), 0, st, a, v, w, odx, ody, odz, mode, nx, ny, nz, koff, part);
     return CHECK_LAUNCH();
 }
-hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir, hipStream_t st) {
-    if (nproc < 1 || nproc > 8) return hipErrorInvalidValue;
+// base == nullptr: the blocks follow each other in the buffer; otherwise base[p] = first complex element of block p (any order, no overlap)
+hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kmax, int nproc, const int *ioff, const long long *base, int dir,
+                                hipStream_t st) {
+    if (nproc < 1 || nproc > 16) return hipErrorInvalidValue;
     PencilMap m;
     m.nproc = nproc;
     long long acc = 0;
     for (int p = 0; p < nproc; ++p) {
         m.ioff[p] = ioff[p];
-        m.base[p] = acc;
+        m.base[p] = base ? base[p] : acc;
         acc += (long long)((p + 1 < nproc ? ioff[p + 1] : nxh) - ioff[p]) * ny * kmax;
     }
     m.ioff[nproc] = nxh; m.base[nproc] = acc;

@@ -453,7 +453,13 @@ int tlab_pw_final_update(double *q, double *h, const double *g, const double *pb
                          int nz) { PW_GUARD(launch_final_update(q, h, g, pb, pt, dte, kco, scale, nx, ny, nz, tlab_current_stream())) }
 int tlab_pencil_repack(double *slab, double *buffer, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir) {
     if (!slab || !buffer || !ioff || nproc < 1 || nproc > 8 || nxh < nproc) { tlab_set_error("tlab_pencil_repack: bad arguments (1..8 peers)"); return TLAB_EINVAL; }
-    PW_GUARD(launch_pencil_repack(slab, buffer, nxh, ny, kmax, nproc, ioff, dir, tlab_current_stream()))
+    PW_GUARD(launch_pencil_repack(slab, buffer, nxh, ny, kmax, nproc, ioff, nullptr, dir, tlab_current_stream()))
+}
+int tlab_pencil_repack_blocks(double *slab, double *buffer, int nxh, int ny, int kmax, int nblocks, const int *start, const long long *base, int dir) {
+    if (!slab || !buffer || !start || !base || nblocks < 1 || nblocks > 16 || start[0] != 0) { tlab_set_error("tlab_pencil_repack_blocks: bad arguments (1..16 blocks, the first at kx = 0)"); return TLAB_EINVAL; }
+    for (int p = 0; p + 1 < nblocks; ++p)
+        if (start[p + 1] < start[p] || start[p + 1] > nxh) { tlab_set_error("tlab_pencil_repack_blocks: block starts must increase within [0, nx/2+1]"); return TLAB_EINVAL; }
+    PW_GUARD(launch_pencil_repack(slab, buffer, nxh, ny, kmax, nblocks, start, base, dir, tlab_current_stream()))
 }
 int tlab_pw_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz) { PW_GUARD(launch_get_wall_planes(f, hb, ht, nx, ny, nz, tlab_current_stream())) }
 int tlab_pw_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz) { PW_GUARD(launch_fill_wall_planes(f, vb, vt, nx, ny, nz, tlab_current_stream())) }

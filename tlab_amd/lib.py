@@ -43,6 +43,7 @@ SIGNATURES = {
     "tlab_poisson_plan_create_slab": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
     "tlab_poisson_plan_create_pencil": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
     "tlab_pencil_repack": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int]),
+    "tlab_pencil_repack_blocks": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong), c_int]),
     "tlab_poisson_set_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "tlab_poisson_fft_x": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tlab_poisson_fft_z": (c_int, [c_vp, c_int, c_vp, c_vp]),

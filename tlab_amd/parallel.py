@@ -28,6 +28,7 @@ decomposed algorithm (index maps, per-rank wavenumber offsets, singular-mode own
 single-domain result on a single GPU (tests/test_gpu_slab.py) although only the driver's 8-GPU node can run it for real.
 """
 import ctypes
+import os
 import numpy as np
 
 from .lib import load, check, TlabError, c_vp
@@ -284,6 +285,10 @@ class SlabDns:
         self._ioff_c = (ctypes.c_int * P)(*self.ioff)
         if self.zmode == "halo" and min(self.nxl) < 1:
             raise TlabError("fewer kx modes than ranks")
+        # two-stage pencil Poisson (see _poisson_pencil_staged); TLAB_PENCIL_STAGES=1 keeps the one-piece exchange
+        self.stages = 2 if (self.zmode == "halo" and gy_elliptic is None and min(self.nxl) >= 2 and 2 * P <= 16
+                            and os.environ.get("TLAB_PENCIL_STAGES", "2") != "1") else 1
+        self.nxa = [(w + 1) // 2 for w in self.nxl]
         Hn = self.HALO * self.npage
         self.st = {}
         for r in comm.local_ranks:
@@ -298,6 +303,14 @@ class SlabDns:
                 check(L.tlab_poisson_plan_create_direct_decomposed(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
                                                                    self.kmax, self.nzt, mode, a, b, gy_elliptic._h),
                       "tlab_poisson_plan_create_direct_decomposed")
+            elif self.zmode == "halo" and self.stages == 2:
+                # the kx range of every rank in two halves, each with its own plan: the solves of one half hide the transfers of the other
+                hb_ = c_vp(0)
+                check(L.tlab_poisson_plan_create_pencil(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
+                                                        self.kmax, self.nzt, self.ioff[r], self.nxa[r]), "tlab_poisson_plan_create_pencil")
+                check(L.tlab_poisson_plan_create_pencil(ctypes.byref(hb_), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
+                                                        self.kmax, self.nzt, self.ioff[r] + self.nxa[r], self.nxl[r] - self.nxa[r]),
+                      "tlab_poisson_plan_create_pencil")
             elif self.zmode == "halo":
                 check(L.tlab_poisson_plan_create_pencil(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
                                                         self.kmax, self.nzt, self.ioff[r], self.nxl[r]), "tlab_poisson_plan_create_pencil")
@@ -305,6 +318,8 @@ class SlabDns:
                 check(L.tlab_poisson_plan_create_slab(ctypes.byref(h), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
                                                       self.kmax, self.nzt, r * self.kmax, P), "tlab_poisson_plan_create_slab")
             S = dict(ext={}, rt=z0(self.n), hb=z0(self.nx * self.kmax), ht=z0(self.nx * self.kmax), poisson=h)
+            if self.zmode == "halo" and self.stages == 2:
+                S["poisson_b"] = hb_
             for name, cnt, m in (("q", 3, self.n), ("s", self.nscal, self.n), ("hq", 3, self.n), ("hs", self.nscal, self.n), ("txc", 9, self.isize_txc)):
                 pairs = [field(m) for _ in range(cnt)]
                 S["ext"][name] = [e for e, _ in pairs]
@@ -480,8 +495,82 @@ class SlabDns:
                 a[:, :, self.ioff[p]:self.ioff[p] + self.nxl[p], :].copy_(buf[off:off + m].view(self.kmax, self.ny, self.nxl[p], 2))
                 off += m
 
+    def _poisson_pencil_staged(self):
+        """The same solve with every rank's kx range cut in two halves A, B (plans S["poisson"], S["poisson_b"]).  The pack buffer holds all A blocks
+        ahead of all B blocks, so each half is one all-to-all of its own; the collectives queue up in the order fwd A, fwd B, back p A, back dp A,
+        back p B, back dp B and the z-transforms and per-mode solves of A run under fwd B, those of B under the returns of A.  Exposed: about
+        half of one forward and of the two backward exchanges instead of all three.  Same kernels on the same modes: the result is that of
+        _poisson_pencil to the bit."""
+        L = load()
+        c, P = self.comm, self.comm.size
+        ny, kmax, nzt = self.ny, self.kmax, self.nzt
+        nxa, nxb = self.nxa, [w - a for w, a in zip(self.nxl, self.nxa)]
+        if not hasattr(self, "_stage_maps"):
+            start, base = [], []
+            offa, offb = 0, sum(nxa) * ny * kmax                  # complex elements: all A blocks, then all B blocks
+            for p in range(P):
+                start += [self.ioff[p], self.ioff[p] + nxa[p]]
+                base += [offa, offb]
+                offa += nxa[p] * ny * kmax
+                offb += nxb[p] * ny * kmax
+            self._stage_maps = ((ctypes.c_int * (2 * P))(*start), (ctypes.c_longlong * (2 * P))(*base), 2 * sum(nxa) * ny * kmax)
+        start, base, split = self._stage_maps                      # split: doubles of the A part of a pack buffer
+        halves = (("poisson", nxa, 0), ("poisson_b", nxb, 1))
+
+        def pen(S, i, h):
+            """buffer i of half h of this rank's pencil (nx_half, ny, nz_total), carved out of pen[i]"""
+            ma = 2 * nxa[S["rank"]] * ny * nzt
+            return S["pen"][i][:ma] if h == 0 else S["pen"][i][ma:]
+
+        def pack(S, i, h):
+            return S["pack"][i][:split] if h == 0 else S["pack"][i][split:]
+
+        def exchange(i_pen, i_pack, h, nxh_, forward):
+            send, scnt, recv, rcnt = {}, {}, {}, {}
+            for r in c.local_ranks:
+                S = self.st[r]
+                slab_side, cnt_slab = pack(S, i_pack, h), [2 * nxh_[p] * ny * kmax for p in range(P)]
+                pen_side, cnt_pen = pen(S, i_pen, h), [2 * nxh_[r] * ny * kmax] * P
+                if forward:
+                    send[r], scnt[r], recv[r], rcnt[r] = slab_side, cnt_slab, pen_side, cnt_pen
+                else:
+                    send[r], scnt[r], recv[r], rcnt[r] = pen_side, cnt_pen, slab_side, cnt_slab
+            return c.all_to_all_v(send, scnt, recv, rcnt)
+
+        for r in c.local_ranks:
+            S = self.st[r]
+            S["rank"] = r
+            check(L.tlab_poisson_set_wall_planes(S["poisson"], _ptr(S["txc"][0]), _ptr(S["hb"]), _ptr(S["ht"])), "set_wall_planes")
+            check(L.tlab_poisson_fft_x(S["poisson"], 1, _ptr(S["txc"][0]), _ptr(S["txc"][1])), "fft_x")
+            check(L.tlab_pencil_repack_blocks(_ptr(S["txc"][1]), _ptr(S["pack"][0]), self.nxh, ny, kmax, 2 * P, start, base, 1), "tlab_pencil_repack_blocks")
+        fwd = [exchange(0, 0, h, nx_, True) for _, nx_, h in halves]
+        back = []
+        for key, nx_, h in halves:
+            fwd[h].wait()
+            for r in c.local_ranks:
+                S = self.st[r]
+                b0, b1, b2 = pen(S, 0, h), pen(S, 1, h), pen(S, 2, h)
+                check(L.tlab_poisson_fft_z(S[key], 1, _ptr(b0), _ptr(b1)), "fft_z")
+                check(L.tlab_poisson_ode(S[key], _ptr(b1), _ptr(b1), _ptr(b2)), "ode")
+                check(L.tlab_poisson_fft_z(S[key], -1, _ptr(b1), _ptr(b0)), "fft_z")
+            wp = exchange(0, 0, h, nx_, False)                       # p^ of this half travels (its forward block of pack[0] has been consumed) ...
+            for r in c.local_ranks:
+                S = self.st[r]
+                check(L.tlab_poisson_fft_z(S[key], -1, _ptr(pen(S, 2, h)), _ptr(pen(S, 1, h))), "fft_z")       # ... while dp^/dy is transformed
+            back.append((wp, exchange(1, 1, h, nx_, False)))
+        for i_pack, slab, out in ((0, 1, 0), (1, 3, 2)):             # p -> tmp1, dp/dy -> tmp3
+            for wpair in back:
+                wpair[i_pack].wait()
+            for r in c.local_ranks:
+                S = self.st[r]
+                check(L.tlab_pencil_repack_blocks(_ptr(S["txc"][slab]), _ptr(S["pack"][i_pack]), self.nxh, ny, kmax, 2 * P, start, base, -1),
+                      "tlab_pencil_repack_blocks")
+                check(L.tlab_poisson_fft_x(S["poisson"], -1, _ptr(S["txc"][slab]), _ptr(S["txc"][out])), "fft_x")
+
     def _poisson_pencil(self):
         """OPR_Poisson_FourierXZ_Factorize on kx-pencils: forcing in tmp1, Neumann data in hb/ht; p -> tmp1, dp/dy -> tmp3."""
+        if self.stages == 2:
+            return self._poisson_pencil_staged()
         L = load()
         for r in self.comm.local_ranks:
             S = self.st[r]
@@ -784,6 +873,8 @@ class SlabDns:
         try:
             for S in self.st.values():
                 load().tlab_poisson_plan_destroy(S["poisson"])
+                if "poisson_b" in S:
+                    load().tlab_poisson_plan_destroy(S["poisson_b"])
                 if "zplan" in S:
                     load().tlab_zslab_plan_destroy(S["zplan"])
         except Exception:
