@@ -677,22 +677,6 @@ class SlabDns:
         self._poisson_pencil()
         types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
         grad_final = tail is not None and all(t == DNS_BCS_DIRICHLET for pair in types[:3] for t in pair)
-        w = self._halo_start([("txc", 0)])
-        if grad_final:   # u and w are finished by the gradient kernels themselves (no gradient array)
-            self._local(lambda r, S: check(L.tlab_opr_gradient_final(1, gx._h, nx, ny, kmax, _ptr(T(S, 0)), _ptr(S["q"][0]), _ptr(S["hq"][0]), float(tail[0]),
-                                                                     float(tail[1]), int(tail[2]), _ptr(T(S, 1))), "tlab_opr_gradient_final"))
-        else:
-            self._local(lambda r, S: padd(1, gx, S, T(S, 0), None, 0.0, T(S, 1), 0))
-        w.wait()
-        self._local(lambda r, S: self._zpartial(1, S, T(S, 0), None, 0.0, None, 0))
-        w = self._msg_start(1)
-        w.wait()
-        if grad_final:
-            self._local(lambda r, S: check(L.tlab_zslab_gradient_final_z(S["zplan"], nx, ny, _ptr(T(S, 0)), _ptr(S["tail_left"]), _ptr(S["head_right"]),
-                                                                         _ptr(S["q"][2]), _ptr(S["hq"][2]), float(tail[0]), float(tail[1]), int(tail[2])),
-                                           "tlab_zslab_gradient_final_z"))
-        else:
-            self._local(lambda r, S: self._zpartial(2, S, T(S, 0), None, 0.0, T(S, 3), 0))
         # ---- hq -= grad p, boundary conditions (:348-398) [+ RK update] ----
         def finish(r, S):
             grads = [T(S, 1), T(S, 2), T(S, 3)] + [None] * ns
@@ -713,7 +697,29 @@ class SlabDns:
                 else:
                     check(L.tlab_pw_final_update(_ptr(q), _ptr(h), _ptr(g) if g is not None else None, pb, pt, float(tail[0]), float(tail[1]),
                                                  int(tail[2]), nx, ny, kmax), "final_update")
-        self._local(finish)
+        w = self._halo_start([("txc", 0)])
+        if grad_final:   # u and w are finished by the gradient kernels themselves (no gradient array)
+            self._local(lambda r, S: check(L.tlab_opr_gradient_final(1, gx._h, nx, ny, kmax, _ptr(T(S, 0)), _ptr(S["q"][0]), _ptr(S["hq"][0]), float(tail[0]),
+                                                                     float(tail[1]), int(tail[2]), _ptr(T(S, 1))), "tlab_opr_gradient_final"))
+        else:
+            self._local(lambda r, S: padd(1, gx, S, T(S, 0), None, 0.0, T(S, 1), 0))
+        w.wait()
+        self._local(lambda r, S: self._zpartial(1, S, T(S, 0), None, 0.0, None, 0))
+        w = self._msg_start(1)
+        # v and the scalars do not wait for dp/dz: their update runs while the interface values travel (not with Neumann scalars, whose
+        # boundary routine takes tmp1 = p as scratch)
+        early_finish = grad_final and all(t == DNS_BCS_DIRICHLET for pair in types[3:] for t in pair)
+        if early_finish:
+            self._local(lambda r, S: finish(r, S))
+        w.wait()
+        if grad_final:
+            self._local(lambda r, S: check(L.tlab_zslab_gradient_final_z(S["zplan"], nx, ny, _ptr(T(S, 0)), _ptr(S["tail_left"]), _ptr(S["head_right"]),
+                                                                         _ptr(S["q"][2]), _ptr(S["hq"][2]), float(tail[0]), float(tail[1]), int(tail[2])),
+                                           "tlab_zslab_gradient_final_z"))
+        else:
+            self._local(lambda r, S: self._zpartial(2, S, T(S, 0), None, 0.0, T(S, 3), 0))
+        if not early_finish:
+            self._local(finish)
 
     # ---- the RHS ---------------------------------------------------------------------------------------------------------
     def RHS_GLOBAL_INCOMPRESSIBLE_1(self, dte):
