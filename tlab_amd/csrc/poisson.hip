@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // distinct rows this thread touches would otherwise be precomputed and kept in registers
     const int nm = (int)a.nm;
     // NM = 4: a workgroup's row of f^ / p^ / dp^ is 64 B, half a 128-B line.  Workgroups go round-robin over the 8 XCDs (each with its own L2), so
-    // the neighbour that owns the other half would sit on another XCD and the line would cross the fabric twice (PMC: 9.3 GB per launch against
+    // the neighbour that owns the other half would sit on another XCD and the line would cross the fabric twice (PMC: 9.3 GB per launch, 8.3 with the pairing, against
     // 6.7 algorithmic).  Pair them: of every 16 consecutive workgroups, XCD x gets the adjacent blocks 2x and 2x + 1.
     unsigned blk = blockIdx.x;
     if (NM == 4 && a.pair_xcd && (blk | 15u) < gridDim.x) blk = (blk & ~15u) + 2u * (blk & 7u) + ((blk >> 3) & 1u);
