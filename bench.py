@@ -55,11 +55,13 @@ def cpu_baseline(n, nscal):
         o.q[i] = rng.uniform(-1, 1, n ** 3) * 0.1
     for i in range(nscal):
         o.s[i] = rng.uniform(-1, 1, n ** 3)
+    nsub = 3                                    # one Runge-Kutta step: 3 substeps, 15-20 s on one host core at 256^3
     t0 = time.time()
-    o.time_substep(1e-3, 1.0, False)
+    for _ in range(nsub):
+        o.time_substep(1e-3, 1.0, False)
     dt = time.time() - t0
-    return {"value": n ** 3 / dt, "unit": "grid-point-updates/s per RK substep", "cores": 1, "kind": "port",
-            "sample": "one RK substep of the numpy oracle (oracle/tlab_oracle_rhs.py) on a %d^3 box, %d scalar(s), %.1f s" % (n, nscal, dt)}
+    return {"value": nsub * n ** 3 / dt, "unit": "grid-point-updates/s per RK substep", "cores": 1, "kind": "port",
+            "sample": "%d RK substeps of the numpy oracle (oracle/tlab_oracle_rhs.py) on a %d^3 box, %d scalar(s), %.1f s" % (nsub, n, nscal, dt)}
 
 
 def main():
