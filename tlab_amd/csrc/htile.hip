@@ -226,14 +226,16 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     } else {  // MODE_BURGERS: result = nu d2 - vel d1 (opr_burgers.f90:513)
 #pragma unroll
         for (int p = 0; p < M; ++p) x2[p] = nu * x2[p] - vl[p] * x1[p];
+        // the old tendency is read once and the new one is not read again before 4 GB of other traffic have passed: non-temporal accesses keep
+        // them out of the way of the operand rows in L2 (3 % of the launch, measured A/B in one binary)
         if (a.acc) {   // accumulate into the tendency: all loads first (the compiler cannot move them across the stores itself)
 #pragma unroll
-            for (int p = 0; p < M; ++p) x1[p] = out0[base + (long long)(row0 + p) * rs];
+            for (int p = 0; p < M; ++p) x1[p] = __builtin_nontemporal_load(&out0[base + (long long)(row0 + p) * rs]);
 #pragma unroll
             for (int p = 0; p < M; ++p) x2[p] = x1[p] + x2[p];
         }
 #pragma unroll
-        for (int p = 0; p < M; ++p) out0[base + (long long)(row0 + p) * rs] = x2[p];
+        for (int p = 0; p < M; ++p) __builtin_nontemporal_store(x2[p], &out0[base + (long long)(row0 + p) * rs]);
     }
     }   // valid
 }

@@ -218,6 +218,18 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
             }
             return;
         }
+        if (MODE == MODE_BURGERS) {     // tendencies: read once, written once -> non-temporal (as in k_htile; 2 % of the launch)
+            if (a.acc) {
+                double o[M];
+#pragma unroll
+                for (int p = 0; p < M; ++p) o[p] = __builtin_nontemporal_load(&out0[base + (long long)(row0 + p) * rs]);
+#pragma unroll
+                for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+            }
+#pragma unroll
+            for (int p = 0; p < M; ++p) __builtin_nontemporal_store(x1[p], &out0[base + (long long)(row0 + p) * rs]);
+            return;
+        }
         if (a.acc) {
             double o[M];
 #pragma unroll
