@@ -352,3 +352,42 @@ def test_full_size_substep_properties(T):
         torch.cuda.empty_cache()
     for a, b in zip(*out):
         assert float((a - b).abs().max() / b.abs().max()) <= 1e-12
+
+
+@pytest.mark.parametrize("stretch", [False, True])
+def test_hundred_steps_of_decaying_flow_stay_bounded(T, stretch):
+    """What the domain offers at any size: without forcing the kinetic energy of the flow between no-slip walls decays, the scalar stays inside
+    its initial bounds (up to the dispersion of the scheme) and the dilatation stays at the level the projection leaves.  100 Runge-Kutta
+    steps (300 substeps, each with its Poisson solve) with the time step of TIME_COURANT, consistent wall closure of the second derivative
+    (hyper_bc1_ext = 0: the value the reference reads past its coefficient array is unstable over this many steps on a stretched grid,
+    DESIGN.md section 2)."""
+    import torch
+    from tlab_amd.dns import Dns
+    nx, ny, nz = 128, 96, 64
+    x, y, z = grids(nx, ny, nz, stretch)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 31)
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 1500.0, schmidt=(1.0,), yuniform=not stretch, hyper_bc1_ext=0.0)
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i]))
+    d.s[0].copy_(torch.from_numpy(s0[0]))
+
+    def energy():
+        return float(sum((t * t).sum() for t in d.q))
+
+    e_hist, dil = [energy()], []
+    smin0, smax0 = float(d.s[0].min()), float(d.s[0].max())
+    for step in range(100):
+        _, dt = d.TIME_COURANT(1.2, 0.25)
+        assert 0.0 < dt < 1.0
+        d.TIME_RUNGEKUTTA(dt)
+        if step % 10 == 9:
+            e_hist.append(energy())
+            dmin, dmax = d.dilatation_bounds()
+            dil.append(max(abs(dmin), abs(dmax)))
+    assert all(bool(torch.isfinite(t).all()) for t in d.q + d.s)
+    assert all(b < a for a, b in zip(e_hist, e_hist[1:])), e_hist                  # monotone viscous decay
+    assert e_hist[-1] > 0.02 * e_hist[0]                                           # ... of a flow that is still there
+    span = smax0 - smin0
+    assert float(d.s[0].min()) >= smin0 - 0.05 * span and float(d.s[0].max()) <= smax0 + 0.05 * span
+    (p1, _), _ = d.TIME_COURANT(1.2, 0.25)                                         # p1 = max(|u_i| / h_i): the size of the terms of div(q)
+    assert max(dil) <= 0.05 * max(p1, 1e-300) or max(dil) <= dil[0] * 2.0, (dil, p1)
