@@ -194,3 +194,41 @@ def test_two_stage_pencil_poisson_is_bit_identical(T, P, nx, nz, monkeypatch):
         out[stages] = [torch.cat([slab.st[r]["txc"][i][:n] for r in range(P)]).cpu().numpy() for i in (0, 2)]
     assert np.isfinite(out["2"][0]).all() and np.abs(out["2"][0]).max() > 0
     assert np.array_equal(out["1"][0], out["2"][0]) and np.array_equal(out["1"][1], out["2"][1])
+
+
+@pytest.mark.parametrize("P,nz,zmode", [(2, 128, "halo"), (4, 64, "transpose")])
+def test_slabs_track_the_single_domain_over_many_steps(T, P, nz, zmode):
+    """20 Runge-Kutta steps (60 substeps, the time step from the slab monitors each step): nothing in the slab driver's step-to-step state (fresh
+    tendencies, halo planes, interface messages, staged pencil buffers) drifts away from the single domain."""
+    import torch
+    from tlab_amd.dns import Dns
+    from tlab_amd.parallel import SlabDns, LoopbackComm
+    nx, ny = 32, 24
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(P + 40)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    fields = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
+    kw = dict(nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, hyper_bc1_ext=0.0)
+    one = Dns(x, y, z, **kw)
+    slab = SlabDns(LoopbackComm(P), x, y, z, zmode=zmode, **kw)
+    for i in range(3):
+        t = torch.from_numpy(fields[i]).cuda()
+        one.q[i].copy_(t); slab.scatter("q", i, t)
+    t = torch.from_numpy(fields[3]).cuda()
+    one.s[0].copy_(t); slab.scatter("s", 0, t)
+    for step in range(20):
+        _, dt = slab.TIME_COURANT(1.2, 0.25)
+        _, dt1 = one.TIME_COURANT(1.2, 0.25)
+        assert abs(dt - dt1) <= 1e-9 * dt1
+        one.TIME_RUNGEKUTTA(dt)
+        for k in range(3):
+            slab.substep_of_cycle(3 * step + k, dt)
+    for name, ref in (("q", one.q), ("s", one.s)):
+        for i, rf in enumerate(ref):
+            got = torch.cat([slab.st[r][name][i] for r in range(P)])
+            assert bool(torch.isfinite(got).all())
+            err = float((got - rf).abs().max() / rf.abs().max())
+            assert err <= 1e-9, (name, i, err)
