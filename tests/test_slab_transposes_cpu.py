@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tlab_amd.parallel import LoopbackComm, DistComm, trp_k_forward, trp_k_backward, trp_i_forward, trp_i_backward
+from tlab_amd.parallel import LoopbackComm, DistComm, trp_k_forward, trp_k_backward, trp_i_forward, trp_i_backward, pencil_stage_layout
 
 
 def global_field(nx, ny, nz, width):
@@ -169,6 +169,79 @@ def test_ring_and_pencil_exchanges_real_processes_gloo(world):
         p.join(timeout=60)
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] and r[2] for r in res), res
+
+
+def _staged_pack(P, r, ioff, nxl, g, ny, kmax):
+    """What tlab_pencil_repack_blocks writes for rank r's slab (one value per element here): blocks [kmax][ny][width] at base[b]."""
+    start, base, split, nxa, nxb = pencil_stage_layout(ioff, nxl, ny, kmax)
+    a = g[r * kmax:(r + 1) * kmax]
+    buf = torch.full((a.numel(),), -1.0, dtype=torch.float64)
+    ends = start[1:] + [g.shape[2]]
+    for b in range(2 * P):
+        blk = a[:, :, start[b]:ends[b]].reshape(-1)
+        buf[base[b]:base[b] + blk.numel()] = blk
+    return buf, split, nxa, nxb
+
+
+def _staged_exchange(comm, ranks, P, ioff, nxl, g, ny, kmax):
+    """Both halves forward through views of ONE pack buffer per rank (as SlabDns._poisson_pencil_staged posts them); returns {rank: (penA, penB)}."""
+    packs, pens = {}, {}
+    for r in ranks:
+        packs[r], split, nxa, nxb = _staged_pack(P, r, ioff, nxl, g, ny, kmax)
+        assert not bool((packs[r] < 0).any())                      # the blocks tile the buffer
+        pens[r] = (torch.zeros(kmax * P * ny * nxa[r], dtype=torch.float64), torch.zeros(kmax * P * ny * nxb[r], dtype=torch.float64))
+    works = []
+    for h, nxh_ in ((0, nxa), (1, nxb)):
+        send = {r: (packs[r][:split] if h == 0 else packs[r][split:]) for r in ranks}
+        scnt = {r: [nxh_[p] * ny * kmax for p in range(P)] for r in ranks}
+        recv = {r: pens[r][h] for r in ranks}
+        rcnt = {r: [nxh_[r] * ny * kmax] * P for r in ranks}
+        works.append(comm.all_to_all_v(send, scnt, recv, rcnt))
+    for w in works:
+        w.wait()
+    return pens, nxa, nxb
+
+
+@pytest.mark.parametrize("P,nxh,ny,kmax", [(2, 9, 3, 2), (3, 17, 2, 2), (8, 33, 2, 1)])
+def test_staged_pencil_exchange_loopback(P, nxh, ny, kmax):
+    """Two-stage pencil exchange: halves A and B of every kx range arrive as (nz, ny, half width) with no unpacking, uneven ranges included."""
+    nxl, ioff, g = _pencil_case(P, nxh, ny, kmax)
+    pens, nxa, nxb = _staged_exchange(LoopbackComm(P), range(P), P, ioff, nxl, g, ny, kmax)
+    for r in range(P):
+        assert torch.equal(pens[r][0].view(kmax * P, ny, nxa[r]), g[:, :, ioff[r]:ioff[r] + nxa[r]]), r
+        assert torch.equal(pens[r][1].view(kmax * P, ny, nxb[r]), g[:, :, ioff[r] + nxa[r]:ioff[r] + nxl[r]]), r
+
+
+def _worker_staged(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nxh, ny, kmax = 9, 3, 2
+        nxl, ioff, g = _pencil_case(world, nxh, ny, kmax)
+        pens, nxa, nxb = _staged_exchange(DistComm(), [rank], world, ioff, nxl, g, ny, kmax)
+        ok = torch.equal(pens[rank][0].view(kmax * world, ny, nxa[rank]), g[:, :, ioff[rank]:ioff[rank] + nxa[rank]]) and \
+            torch.equal(pens[rank][1].view(kmax * world, ny, nxb[rank]), g[:, :, ioff[rank] + nxa[rank]:ioff[rank] + nxl[rank]])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_staged_pencil_exchange_two_processes_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_staged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

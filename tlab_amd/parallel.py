@@ -224,6 +224,24 @@ def trp_i_backward(comm, b, imax, npage, width=1):
 # ------------------------------------------------------------------------------------------------------------------
 # the decomposed RK substep
 # ------------------------------------------------------------------------------------------------------------------
+def pencil_stage_layout(ioff, nxl, ny, kmax):
+    """Block map of the two-stage pencil exchange (SlabDns._poisson_pencil_staged, tlab_pencil_repack_blocks): every rank's kx range
+    [ioff[p], ioff[p] + nxl[p]) is cut into halves A (the first ceil(nxl/2) columns) and B; the pack buffer holds all A blocks (by rank) ahead of
+    all B blocks.  Returns (start, base, split, nxa, nxb): block 2p / 2p+1 = half A / B of rank p starts at kx = start[.] and at element
+    base[.] of the buffer, [kmax][ny][width] each; split = elements of the A part."""
+    P = len(nxl)
+    nxa = [(w + 1) // 2 for w in nxl]
+    nxb = [w - a for w, a in zip(nxl, nxa)]
+    start, base = [], []
+    offa, offb = 0, sum(nxa) * ny * kmax
+    for p in range(P):
+        start += [ioff[p], ioff[p] + nxa[p]]
+        base += [offa, offb]
+        offa += nxa[p] * ny * kmax
+        offb += nxb[p] * ny * kmax
+    return start, base, sum(nxa) * ny * kmax, nxa, nxb
+
+
 class SlabDns:
     """RHS_GLOBAL_INCOMPRESSIBLE_1 + TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT with ims_npro_k = comm.size.
     Same operator sequence as tlab_amd/csrc/rhs.cpp (= tools/dns/rhs_global_incompressible_1.f90:98-375); the z-operators
@@ -506,14 +524,8 @@ class SlabDns:
         ny, kmax, nzt = self.ny, self.kmax, self.nzt
         nxa, nxb = self.nxa, [w - a for w, a in zip(self.nxl, self.nxa)]
         if not hasattr(self, "_stage_maps"):
-            start, base = [], []
-            offa, offb = 0, sum(nxa) * ny * kmax                  # complex elements: all A blocks, then all B blocks
-            for p in range(P):
-                start += [self.ioff[p], self.ioff[p] + nxa[p]]
-                base += [offa, offb]
-                offa += nxa[p] * ny * kmax
-                offb += nxb[p] * ny * kmax
-            self._stage_maps = ((ctypes.c_int * (2 * P))(*start), (ctypes.c_longlong * (2 * P))(*base), 2 * sum(nxa) * ny * kmax)
+            start, base, split_c, _, _ = pencil_stage_layout(self.ioff, self.nxl, ny, kmax)      # in complex elements
+            self._stage_maps = ((ctypes.c_int * (2 * P))(*start), (ctypes.c_longlong * (2 * P))(*base), 2 * split_c)
         start, base, split = self._stage_maps                      # split: doubles of the A part of a pack buffer
         halves = (("poisson", nxa, 0), ("poisson_b", nxb, 1))
 
