@@ -188,6 +188,12 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     const long long stride = (long long)gridDim.x * 4;
     for (long long line = (long long)blockIdx.x * 4 + wib; line < a.nlines; line += stride) {
         const long long off = line * n + lane * M;
+        if constexpr (LV == 2) {
+            // 32 rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x 32 of them in registers
+            // (182 spilled VGPRs); an opaque copy of the LDS pointers per line makes it re-read them where they are used
+            if (NEED1) asm volatile("" : "+v"(y1.lds));
+            if (NEED2) asm volatile("" : "+v"(y2.lds));
+        }
         if constexpr (MODE == MODE_BURGERS) {
             // the advecting velocity of the line is loaded once and serves every transported field (rhs_global_incompressible_1.f90:
             // 98-162 calls OPR_Burgers_X four times with the same u)
@@ -202,6 +208,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 const double *src = a.fs[f];
                 double *dst = a.fo[f];
                 const double nuf = a.fnu[f];
+                if constexpr (LV == 2) {      // ... and per field
+                    asm volatile("" : "+v"(y1.lds));
+                    asm volatile("" : "+v"(y2.lds));
+                }
                 double u[M];
                 if (src == a.in1) {
 #pragma unroll
