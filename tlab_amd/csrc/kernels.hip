@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     const long long stride = (long long)gridDim.x * 4;
     for (long long line = (long long)blockIdx.x * 4 + wib; line < a.nlines; line += stride) {
         const long long off = line * n + lane * M;
-        if constexpr (LV == 2) {
+        if constexpr (LV == 2 || (LV == 1 && M >= 16)) {
             // 32 rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x 32 of them in registers
             // (182 spilled VGPRs); an opaque copy of the LDS pointers per line makes it re-read them where they are used
             if (NEED1) asm volatile("" : "+v"(y1.lds));
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 const double *src = a.fs[f];
                 double *dst = a.fo[f];
                 const double nuf = a.fnu[f];
-                if constexpr (LV == 2) {      // ... and per field
+                if constexpr (LV == 2 || (LV == 1 && M >= 16)) {      // ... and per field
                     asm volatile("" : "+v"(y1.lds));
                     asm volatile("" : "+v"(y2.lds));
                 }
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 } else {
                     xload<M>(u, src + off);
                 }
-                constexpr bool PIPE = (M <= 8);      // 16 rows per lane (n = 1024): the extra line-sets would spill
+                constexpr bool PIPE = (M <= 16);     // 32 rows per lane (n = 2048): the extra line-sets would spill
                 double o[M];
                 if (PIPE && a.acc) xload<M>(o, dst + off);
                 have_next = PIPE && (f + 1 < a.nf) && (a.fs[f + 1] != a.in1);
