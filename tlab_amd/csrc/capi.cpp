@@ -605,10 +605,10 @@ void check_common(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc) {
 
 // ---- internal fused variants for the RHS driver; return false when the sizes are not on a fused fast path ----
 // result (+)= d/dx_dir (u + scale*ub)
-bool tlab_internal_partial_p1_fusable(int dir, int nx, int ny, int nz) {
+bool tlab_internal_partial_p1_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz) {
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
-    const int path = choose_path(dir, geom.n);       // no plan here: x lines of 2048 take the unfused sequence
+    const int path = choose_path(dir, geom.n, g);    // with the plan: x lines of 2048 points take k_xline when their tables allow it
     return path == PATH_XLINE || (path == PATH_RTILE && rtile_chunk(geom.n) > 0);
 }
 bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub,

@@ -23,7 +23,7 @@ extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
 bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub,
                                     double scale, double *result, bool acc);
-bool tlab_internal_partial_p1_fusable(int dir, int nx, int ny, int nz);
+bool tlab_internal_partial_p1_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
                                double *result);
 bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
@@ -176,7 +176,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // tendency of u in registers, line by line, and differentiates it on the spot instead of a separate launch re-reading hq1 and u.
     const double idte = 1.0 / dte;
     const bool x_last = !finish_off && batched && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
-    const bool div_in_burgers = x_last && d->fuse && tlab_internal_partial_p1_fusable(2, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, nx, ny, nz);
+    const bool div_in_burgers = x_last && d->fuse && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
     if (batched) {
         const int order_xyz[3] = {1, 2, 3}, order_zyx[3] = {3, 2, 1};
         const int *order = x_last ? order_zyx : order_xyz;
@@ -215,8 +215,8 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         }
     }
     // ---- pressure (:177-260, remove_divergence branch): forcing = div(hq + q/dte) ----
-    bool fused_div = d->fuse && tlab_internal_partial_p1_fusable(1, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, nx, ny, nz) &&
-                     tlab_internal_partial_p1_fusable(3, nx, ny, nz);
+    bool fused_div = d->fuse && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) &&
+                     tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
     if (div_in_burgers) {     // tmp1 holds the x term already
         const bool oky = tlab_internal_partial_p1_fused(2, gy, nx, ny, nz, B0, hq[1], v, idte, tmp1, true);
         const bool okz = oky && tlab_internal_partial_p1_fused(3, gz, nx, ny, nz, B0, hq[2], w, idte, tmp1, true);
@@ -247,7 +247,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     if (tail_update && d->fuse && nz > 1) {
         bool dirichlet = true;
         for (int iq = 0; iq < 3; ++iq) dirichlet = dirichlet && d->flow_jmin[iq] == TLAB_DNS_BCS_DIRICHLET && d->flow_jmax[iq] == TLAB_DNS_BCS_DIRICHLET;
-        if (dirichlet && tlab_internal_partial_p1_fusable(1, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, nx, ny, nz)) {
+        if (dirichlet && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz)) {
             const bool okx = tlab_internal_gradient_final(1, gx, nx, ny, nz, tmp1, q[0], hq[0], dte, kco, scale_tendencies);
             const bool okz = okx && tlab_internal_gradient_final(3, gz, nx, ny, nz, tmp1, q[2], hq[2], dte, kco, scale_tendencies);
             if (okx != okz) throw Fail(TLAB_EINVAL, "internal: inconsistent fused gradient path");
