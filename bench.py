@@ -77,6 +77,22 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="n of the n^3 CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: start the N ranks as a CHILD torch.distributed.run (nothing has touched the GPU yet in this process: no
+    # re-exec after GPU initialisation) and relay its single JSON line.  Under a launcher, --gpus must agree with WORLD_SIZE.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        argv = [a if a != "--n" else "--box" for a in sys.argv[1:]]     # torch.distributed.run's parser rejects --n as ambiguous
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + argv
+        sys.exit(subprocess.run(cmd).returncode)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s (launch with --nproc-per-node %d, or let `python bench.py --gpus %d` start the ranks itself)"
+                 % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus, args.gpus))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

@@ -720,8 +720,18 @@ def der2_solve(g, lu, u, du):
 class FdmPlan:
     """fdm/fdm.f90:14-29 type fdm_dt."""
 
-    def __init__(self, nodes, periodic, uniform, mode1=FDM_COM6_JACOBIAN, mode2=FDM_COM6_JACOBIAN_HYPER):
-        """fdm/fdm.f90:143-252 FDM_CreatePlan."""
+    def __init__(self, nodes, periodic, uniform, mode1=FDM_COM6_JACOBIAN, mode2=FDM_COM6_JACOBIAN_HYPER, hyper_bc1_ext=None):
+        """fdm/fdm.f90:143-252 FDM_CreatePlan.  hyper_bc1_ext: None = the module's HYPER_BC1_EXT (what the flang-built reference reads)."""
+        global HYPER_BC1_EXT
+        saved = HYPER_BC1_EXT
+        if hyper_bc1_ext is not None:
+            HYPER_BC1_EXT = float(hyper_bc1_ext)
+        try:
+            self._create(nodes, periodic, uniform, mode1, mode2)
+        finally:
+            HYPER_BC1_EXT = saved
+
+    def _create(self, nodes, periodic, uniform, mode1, mode2):
         nodes = np.asarray(nodes, dtype=np.float64)
         if periodic and mode1 == FDM_COM4_DIRECT: mode1 = FDM_COM4_JACOBIAN
         if periodic and mode1 == FDM_COM6_DIRECT: mode1 = FDM_COM6_JACOBIAN

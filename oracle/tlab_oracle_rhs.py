@@ -13,10 +13,12 @@ from . import tlab_oracle_poisson as OP
 
 
 class DnsOracle:
-    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None, gy_elliptic=None):
+    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None, gy_elliptic=None, hyper_bc1_ext=None):
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
-        self.g = list(plans) if plans is not None else [O.FdmPlan(x, True, True), O.FdmPlan(y, False, yuniform), O.FdmPlan(z, True, True)]
+        h = hyper_bc1_ext                      # None: O.HYPER_BC1_EXT = the flang-built reference's wall closure (defect 1)
+        self.g = list(plans) if plans is not None else [O.FdmPlan(x, True, True, hyper_bc1_ext=h), O.FdmPlan(y, False, yuniform, hyper_bc1_ext=h),
+                                                        O.FdmPlan(z, True, True, hyper_bc1_ext=h)]
         self.direct = gy_elliptic is not None         # EllipticOrder = CompactDirect6: OPR_Poisson => OPR_Poisson_FourierXZ_Direct (opr_elliptic.f90:153)
         if self.direct:
             self.poisson = OP.PoissonDirectPlan(self.g[0], gy_elliptic, self.g[2], self.nx, self.ny, self.nz)

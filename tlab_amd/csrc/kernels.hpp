@@ -93,7 +93,7 @@ hipError_t launch_add3(double *h, const double *a, const double *b, const double
 hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1,
                         const double *q2, const double *q3, double s, long long n, hipStream_t st);
 hipError_t launch_minmax_partial(const double *a, const double *v, const double *w, const double *odx, const double *ody, const double *odz,
-                                 int mode, int nx, int ny, int nz, int koff, double *part, int nblocks, hipStream_t st);
+                                 int mode, int nx, int ny, int nz, int koff, int zon, double *part, int nblocks, hipStream_t st);
 hipError_t launch_negate(double *a, long long n, hipStream_t st);
 hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kmax, int nproc, const int *ioff, const long long *base, int dir,
                                 hipStream_t st);

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_pencil_repack(double2 *__restrict__ a, 
 // per-block partial (min, max) of a[i] (mode 0) or of |u|/dx(i) + |v|/dy(j) + |w|/dz(k) (mode 1); part: [2][gridDim.x]
 __global__ void __launch_bounds__(256) k_minmax_partial(const double *__restrict__ a, const double *__restrict__ v, const double *__restrict__ w,
                                                         const double *__restrict__ odx, const double *__restrict__ ody,
-                                                        const double *__restrict__ odz, int mode, int nx, int ny, int nz, int koff,
+                                                        const double *__restrict__ odz, int mode, int nx, int ny, int nz, int koff, int zon,
                                                         double *__restrict__ part) {
     __shared__ double smn[4], smx[4];
     const long long n = (long long)nx * ny * nz, stride = (long long)gridDim.x * blockDim.x;
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_minmax_partial(const double *__restrict
         if (mode == 1) {
             const int ix = (int)(i % nx), j = (int)((i / nx) % ny), k = (int)(i / ((long long)nx * ny));
             val = fabs(a[i]) * odx[ix] + fabs(v[i]) * ody[j];
-            if (nz > 1 || koff > 0) val += fabs(w[i]) * odz[k + koff];
+            if (zon) val += fabs(w[i]) * odz[k + koff];      // the GLOBAL z%size > 1 (time.f90:402), not the slab depth
         }
         mn = fmin(mn, val); mx = fmax(mx, val);
     }
@@ -235,8 +235,8 @@ __global__ void __launch_bounds__(256) k_negate(double *__restrict__ a, long lon
 #define CHECK_LAUNCH() hipGetLastError()
 
 hipError_t launch_minmax_partial(const double *a, const double *v, const double *w, const double *odx, const double *ody, const double *odz,
-                                 int mode, int nx, int ny, int nz, int koff, double *part, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_minmax_partial, dim3(nblocks), dim3(256), 0, st, a, v, w, odx, ody, odz, mode, nx, ny, nz, koff, part);
+                                 int mode, int nx, int ny, int nz, int koff, int zon, double *part, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nblocks), dim3(256), 0, st, a, v, w, odx, ody, odz, mode, nx, ny, nz, koff, zon, part);
     return CHECK_LAUNCH();
 }
 // base == nullptr: the blocks follow each other in the buffer; otherwise base[p] = first complex element of block p (any order, no overlap)

@@ -355,7 +355,7 @@ static void minmax_impl(tlab_dns_t d, const double *a, const double *v, const do
     hipStream_t st = tlab_current_stream();
     const long long n = (long long)nx * ny * nz;
     const int nb = (int)std::min<long long>(1024, (n + 255) / 256);
-    hk(launch_minmax_partial(a, v, w, d->od[0], d->od[1], d->od[2], mode, nx, ny, nz, d->koffset, d->part, nb, st), "k_minmax_partial");
+    hk(launch_minmax_partial(a, v, w, d->od[0], d->od[1], d->od[2], mode, nx, ny, nz, d->koffset, d->nz_total > 1 ? 1 : 0, d->part, nb, st), "k_minmax_partial");
     std::vector<double> h((size_t)2 * nb);
     hk(hipMemcpyAsync(h.data(), d->part, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpy");
     hk(hipStreamSynchronize(st), "sync");

@@ -58,7 +58,7 @@ class Dns:
     """imax, jmax, kmax, inb_scal, visc, schmidt + the allocated arrays of TLab_Initialize_Memory (tlab_memory.f90:164-216)."""
 
     def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
-                 hyper_bc1_ext=0.1, device="cuda", plans=None, gy_elliptic=None):
+                 hyper_bc1_ext=0.0, device="cuda", plans=None, gy_elliptic=None):
         import torch
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz

@@ -250,7 +250,7 @@ class SlabDns:
     HALO = 3          # planes each side: the 7-diagonal right-hand side of the second derivative reaches 3 rows
 
     def __init__(self, comm, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
-                 hyper_bc1_ext=0.1, device="cuda", zmode="auto", zchunk=0, plans=None, gy_elliptic=None):
+                 hyper_bc1_ext=0.0, device="cuda", zmode="auto", zchunk=0, plans=None, gy_elliptic=None):
         """plans: optional (gx, gy, gz) built elsewhere (FdmPlan.from_tables with a host's CompactDirect6 tables in y); gy_elliptic: the y plan of
         EllipticOrder = CompactDirect6 -> OPR_Poisson_FourierXZ_Direct on the slabs (the scheme set of examples/Case81-93)."""
         import torch
@@ -895,5 +895,7 @@ class SlabDns:
                     load().tlab_poisson_plan_destroy(S["poisson_b"])
                 if "zplan" in S:
                     load().tlab_zslab_plan_destroy(S["zplan"])
+                if "dns" in S:
+                    load().tlab_dns_destroy(S["dns"])
         except Exception:
             pass
