@@ -1,0 +1,68 @@
+"""Conditioning of the composed paths, MEASURED on the oracle: how far do the oracle's own results move when its inputs are moved by
+one unit in the last place?  The projection step of the pressure solver amplifies rounding (forcing div(q)/dte ~ 1e4-1e6 for a pressure of
+1e2-1e3), so a composed-path tolerance cannot be a constant: the parity bound for such a path is
+
+        device_err <= max(1e-12, 2 * scatter)
+
+with `scatter` = max over a few one-ulp white-noise perturbations of the inputs of rel_err(oracle(perturbed), oracle(inputs)).  Where the
+scatter is below 1e-12 the north-star tolerance applies unchanged.  TEST INFRASTRUCTURE (uses oracle/ only)."""
+import numpy as np
+
+FLOOR = 1e-12          # north_star: fp64 rel-err <= 1e-12
+
+
+def one_ulp_noise(a, rng):
+    """a moved by -1, 0 or +1 unit in the last place, independently per element (white noise of one ulp)."""
+    a = np.asarray(a, dtype=np.float64)
+    r = rng.integers(-1, 2, a.shape)
+    up = np.nextafter(a, np.inf)
+    dn = np.nextafter(a, -np.inf)
+    return np.where(r > 0, up, np.where(r < 0, dn, a))
+
+
+def _rel(a, b):
+    s = np.abs(b).max()
+    return float(np.abs(a - b).max() / (s if s > 0 else 1.0))
+
+
+def scatter_of(fn, inputs, nsamples=2, seed=1234):
+    """fn(*inputs) -> tuple of arrays.  Returns (base_outputs, [scatter per output]) with the inputs perturbed by one-ulp white noise."""
+    rng = np.random.default_rng(seed)
+    base = fn(*[np.array(a, copy=True) for a in inputs])
+    sc = [0.0] * len(base)
+    for _ in range(nsamples):
+        out = fn(*[one_ulp_noise(a, rng) for a in inputs])
+        sc = [max(s, _rel(o, b)) for s, o, b in zip(sc, out, base)]
+    return base, sc
+
+
+def bound(scatter, factor=2.0):
+    return max(FLOOR, factor * scatter)
+
+
+def substep_scatter(make_oracle, q0, s0, schedule, nsamples=1, seed=77):
+    """Oracle run of the substeps in `schedule` = [(dte, kco, scale), ...] from the fields q0 (3) + s0 (nscal), plus `nsamples` runs from
+    one-ulp perturbations of those fields.  Returns (base, scat): per substep a dict name -> list of arrays / of scatters for
+    name in q, hq, s, hs."""
+    ns = len(s0)
+
+    def run(*fields):
+        o = make_oracle()
+        for i in range(3):
+            o.q[i] = np.array(fields[i], copy=True)
+        for i in range(ns):
+            o.s[i] = np.array(fields[3 + i], copy=True)
+        outs = []
+        for dte, kco, scale in schedule:
+            o.time_substep(dte, kco, scale)
+            outs += [a.copy() for a in o.q + o.hq + o.s + o.hs]
+        return tuple(outs)
+
+    base, sc = scatter_of(run, list(q0) + list(s0), nsamples, seed)
+    per = 6 + 2 * ns
+    B, S = [], []
+    for k in range(len(schedule)):
+        b, s = base[k * per:(k + 1) * per], sc[k * per:(k + 1) * per]
+        B.append({"q": b[0:3], "hq": b[3:6], "s": b[6:6 + ns], "hs": b[6 + ns:6 + 2 * ns]})
+        S.append({"q": s[0:3], "hq": s[3:6], "s": s[6:6 + ns], "hs": s[6 + ns:6 + 2 * ns]})
+    return B, S

