@@ -76,14 +76,30 @@ def cpu_baseline(n, nscal, budget_s=25.0):
     for i in range(nscal):
         c.s[i][:] = rng.uniform(-1, 1, n ** 3)
     c.time_substep(1e-3, 1.0, False)                            # untimed: first touch of the work arrays
+    # thread count: the reference's production mode is one MPI rank per core; the OpenMP partition of this restatement stops scaling earlier on
+    # a many-socket host (transposes, NUMA), so the best of a few counts is what gets reported
+    L = C.load()
+    tmax = L.tlabcpu_num_threads()
+    cand = sorted({t for t in (8, 16, 32, 64, 128, 256, tmax) if t <= tmax})
+    best, trials = None, {}
+    for t in cand:
+        L.tlabcpu_set_num_threads(t)
+        c.time_substep(1e-3, 1.0, False)
+        t0 = time.time()
+        c.time_substep(1e-3, 1.0, False)
+        trials[t] = time.time() - t0
+        if best is None or trials[t] < trials[best]:
+            best = t
+    L.tlabcpu_set_num_threads(best)
     nsub, t0 = 0, time.time()
     while nsub < 3 or (time.time() - t0 < 0.4 * budget_s and nsub < 30):
         c.time_substep(1e-3, 1.0, False)
         nsub += 1
     dt = time.time() - t0
-    threads = C.load().tlabcpu_num_threads()
+    L.tlabcpu_set_num_threads(tmax)
+    threads = best
     return {"value": nsub * n ** 3 / dt, "unit": "grid-point-updates/s per RK substep", "cores": threads, "kind": "port",
-            "cpu_model": model, "host_cpus": ncpu,
+            "cpu_model": model, "host_cpus": ncpu, "seconds_per_substep_by_threads": {str(k): round(v, 3) for k, v in trials.items()},
             "sample": "%d RK substeps of the C/OpenMP restatement of the reference's CPU path (oracle/tlab_cpu.c) on a %d^3 box, %d scalar(s), "
                       "%d threads on '%s' (%d logical CPUs), %.1f s timed after %.1f s of plan construction" % (nsub, n, nscal, threads, model, ncpu, dt, t_init)}
 

@@ -801,6 +801,21 @@ int tlabcpu_time_substep(const cpu_dns_t *D, double dte, double kco, int scale, 
     return 0;
 }
 
+/* threads of the following calls (0: leave) */
+void tlabcpu_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+/* first touch of a freshly mapped array with the static partition the operators use, so that its pages land on the NUMA nodes of the
+ * threads that will work on them (the reference does the same implicitly: every MPI rank allocates its own slab) */
+void tlabcpu_fill(double *a, long long n, double value) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < n; ++i) a[i] = value;
+}
+
 int tlabcpu_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

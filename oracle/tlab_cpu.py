@@ -46,6 +46,8 @@ def load():
         L.tlabcpu_time_substep.argtypes = [c_vp, c_dbl, c_dbl, c_int] + [c_vp] * 9
         L.tlabcpu_transpose.argtypes = [c_vp, c_int, c_int, c_vp]
         L.tlabcpu_num_threads.restype = c_int
+        L.tlabcpu_set_num_threads.argtypes = [c_int]
+        L.tlabcpu_fill.argtypes = [c_vp, c_ll, c_dbl]
         _LIB = L
     return _LIB
 
@@ -177,12 +179,16 @@ class CpuDnsDriver:
         self.t = [FdmTables(g) for g in self.g]
         self.poisson = CpuPoisson(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
         nt = self.poisson.isize_txc_field
-        self.q = [np.zeros(self.n) for _ in range(3)]
-        self.s = [np.zeros(self.n) for _ in range(nscal)]
-        self.hq = [np.zeros(self.n) for _ in range(3)]
-        self.hs = [np.zeros(self.n) for _ in range(nscal)]
-        self.txc = [np.zeros(nt) for _ in range(9)]
-        self.wrk3d = np.zeros(nt)
+        def zeros(m):                                   # first touch in parallel (NUMA placement), tlab_cpu.c tlabcpu_fill
+            a = np.empty(m)
+            load().tlabcpu_fill(_p(a), m, 0.0)
+            return a
+        self.q = [zeros(self.n) for _ in range(3)]
+        self.s = [zeros(self.n) for _ in range(nscal)]
+        self.hq = [zeros(self.n) for _ in range(3)]
+        self.hs = [zeros(self.n) for _ in range(nscal)]
+        self.txc = [zeros(nt) for _ in range(9)]
+        self.wrk3d = zeros(nt)
         self.wrk2d = np.zeros(max(self.n // self.nx, self.n // self.ny, self.n // max(self.nz, 1)))
         self.hb, self.ht = np.zeros(self.nx * self.nz), np.zeros(self.nx * self.nz)
         self.c = CpuDns()
