@@ -318,6 +318,8 @@ int tlab_pw_axpy3(double *o1, double *o2, double *o3, const double *h1, const do
 int tlab_pw_sum3(double *a, const double *b, const double *c, long long n);                              /* a = a + b + c    */
 int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n); /* h -= .., x3 */
 int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n);             /* q += dte h; h *= kco */
+int tlab_pw_fill(double *a, double value, long long n);      /* a = value   (hq = 0.0_wp at the start of a Runge-Kutta step, time.f90:212-216) */
+int tlab_pw_scale(double *a, double alpha, long long n);     /* a = alpha a (hq = kco hq between substeps, time.f90:272-297)                    */
 /* fused tail of a substep for one field: h -= g (g may be NULL); wall planes of h = pb / pt (NULL = zeros); q += dte h; h *= kco if scale
  * (rhs_global_incompressible_1.f90:348-352, :373-375; time.f90:645-664, :272-297) */
 int tlab_pw_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,

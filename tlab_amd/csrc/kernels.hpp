@@ -95,6 +95,7 @@ hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, co
 hipError_t launch_minmax_partial(const double *a, const double *v, const double *w, const double *odx, const double *ody, const double *odz,
                                  int mode, int nx, int ny, int nz, int koff, int zon, double *part, int nblocks, hipStream_t st);
 hipError_t launch_negate(double *a, long long n, hipStream_t st);
+hipError_t launch_scale(double *a, double alpha, long long n, hipStream_t st);
 hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kmax, int nproc, const int *ioff, const long long *base, int dir,
                                 hipStream_t st);
 hipError_t launch_add1(double *h, const double *a, long long n, hipStream_t st);

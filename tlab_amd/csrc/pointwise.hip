@@ -227,6 +227,11 @@ __global__ void __launch_bounds__(256) k_minmax_partial(const double *__restrict
         part[gridDim.x + blockIdx.x] = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
     }
 }
+// a = value (hq = 0.0_wp of TIME_RUNGEKUTTA, time.f90:212-216) ; a = alpha * a (the tendency scaling, time.f90:272-297)
+__global__ void __launch_bounds__(256) k_scale(double *__restrict__ a, double alpha, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = alpha * a[i];
+}
 __global__ void __launch_bounds__(256) k_negate(double *__restrict__ a, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = -a[i];
@@ -256,6 +261,10 @@ hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kma
     ProfScope ps("k_pencil_repack", st, (double)n * 32.0);
     hipLaunchKernelGGL(k_pencil_repack, dim3(pw_grid(n)), dim3(256), 0, st, reinterpret_cast<double2 *>(a), reinterpret_cast<double2 *>(buf), m, nxh, ny,
                        kmax, dir);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_scale(double *a, double alpha, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale, dim3(pw_grid(n)), dim3(256), 0, st, a, alpha, n);
     return CHECK_LAUNCH();
 }
 hipError_t launch_negate(double *a, long long n, hipStream_t st) {

@@ -449,6 +449,8 @@ int tlab_pw_axpy3(double *o1, double *o2, double *o3, const double *h1, const do
 int tlab_pw_sum3(double *a, const double *b, const double *c, long long n) { PW_GUARD(launch_sum3(a, b, c, n, tlab_current_stream())) }
 int tlab_pw_sub3(double *h1, double *h2, double *h3, const double *a, const double *b, const double *c, long long n) { PW_GUARD(launch_sub3(h1, h2, h3, a, b, c, n, tlab_current_stream())) }
 int tlab_pw_rk_update(double *q, double *h, double dte, double kco, int scale, long long n) { PW_GUARD(launch_rk_update(q, h, dte, kco, scale, n, tlab_current_stream())) }
+int tlab_pw_fill(double *a, double value, long long n) { PW_GUARD(launch_fill(a, value, n, tlab_current_stream())) }
+int tlab_pw_scale(double *a, double alpha, long long n) { PW_GUARD(launch_scale(a, alpha, n, tlab_current_stream())) }
 int tlab_pw_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale, int nx, int ny,
                          int nz) { PW_GUARD(launch_final_update(q, h, g, pb, pt, dte, kco, scale, nx, ny, nz, tlab_current_stream())) }
 int tlab_pencil_repack(double *slab, double *buffer, int nxh, int ny, int kmax, int nproc, const int *ioff, int dir) {

@@ -2,6 +2,10 @@
 ! Drop-in replacement of module OPR_Burgers (physics/opr_burgers.f90:23-30,190-431): same names and signatures.
 ! The reference folds the diffusivity of field `is` into a copy of the LU (OPR_Burgers_Initialize, :92-112); the device
 ! kernels take it as a number, so OPR_Burgers_Initialize only records visc and schmidt(:).
+!
+! With -DTLAB_AMD_FULL_HOST (a complete Tlab host: modules NavierStokes, TLab_Memory present) the module also carries the reference's own
+! entry OPR_Burgers_Initialize(inifile), which takes visc, schmidt from module NavierStokes, inb_scal from TLab_Memory and g from FDM exactly
+! like physics/opr_burgers.f90:52-114, so that dns_main.f90:129 compiles unchanged.
 !########################################################################
 #ifndef TLAB_AMD_BURGERS_MODULE
 #define TLAB_AMD_BURGERS_MODULE OPR_Burgers
@@ -19,6 +23,11 @@ module TLAB_AMD_BURGERS_MODULE
     private
 
     public :: OPR_Burgers_Initialize_AMD     ! (visc, schmidt): what OPR_Burgers_Initialize(inifile) takes from module NavierStokes
+#ifdef TLAB_AMD_FULL_HOST
+    public :: OPR_Burgers_Initialize         ! (inifile): physics/opr_burgers.f90:52
+#endif
+    logical, public :: OPR_Burgers_AMD_write_transposed = .true.   ! OPR_B_SELF leaves the transposed operand in tmp1 (opr_burgers.f90:236-240); .false.
+    !                                                                saves that write when no caller consumes it (the device kernels ignore u_t)
     public :: OPR_Burgers_X
     public :: OPR_Burgers_Y
     public :: OPR_Burgers_Z
@@ -40,6 +49,37 @@ contains
         end do
     end subroutine OPR_Burgers_Initialize_AMD
 
+#ifdef TLAB_AMD_FULL_HOST
+    ! OPR_Burgers_Initialize(inifile)   physics/opr_burgers.f90:52-186
+    subroutine OPR_Burgers_Initialize(inifile)
+        use FDM, only: g
+        use NavierStokes, only: visc, schmidt
+        use TLab_Memory, only: inb_scal
+        use TLab_Constants, only: efile
+        use TLab_WorkFlow, only: TLab_Write_ASCII, TLab_Stop
+        character(len=*), intent(in) :: inifile
+        character(len=32) bakfile
+        character(len=512) sRes
+        integer ig
+        integer, parameter :: DNS_ERROR_OPTION = 85, DNS_ERROR_UNDEVELOP = 104      ! include/dns_error.h
+        bakfile = trim(adjustl(inifile))//'.bak'
+        call ScanFile_Char(bakfile, inifile, 'Dealiasing', 'Type', 'none', sRes)    ! FILTER_READBLOCK(.., 'Dealiasing', ..), opr_burgers.f90:71
+        if (trim(adjustl(sRes)) /= 'none') then
+            call TLab_Write_ASCII(efile, __FILE__//'. Dealiasing inside OPR_Burgers is not built on the device path.')
+            call TLab_Stop(DNS_ERROR_UNDEVELOP)
+        end if
+        do ig = 1, 3                                                               ! :75-83
+            if (g(ig)%size == 1) cycle
+            if (g(ig)%der2%nb_diag(1) /= 3) then
+                call TLab_Write_ASCII(efile, __FILE__//'. Undeveloped for more than 3 LHS diagonals in 2. order derivatives.')
+                call TLab_Stop(DNS_ERROR_OPTION)
+            end if
+        end do
+        call OPR_Burgers_Initialize_AMD(visc, schmidt(1:inb_scal))                  ! :92-98
+        call OPR_Burgers_SetPlans(g)
+    end subroutine OPR_Burgers_Initialize
+#endif
+
     subroutine OPR_Burgers_SetPlans(g)
         type(fdm_dt), intent(in), target :: g(3)
         gp => g
@@ -51,11 +91,13 @@ contains
         real(wp), intent(in), target :: s(*), u(*)
         real(wp), intent(out), target :: result(*)
         real(wp), intent(inout), target :: tmp1(*)
-        integer(c_int) rc
+        integer(c_int) rc, wt
         if (bcs(1, 2) + bcs(2, 2) > 0) error stop 'OPR_Burgers: only developed for biased BCs'     ! opr_burgers.f90:460-463
+        wt = 0_c_int
+        if (ivel == OPR_B_SELF .and. OPR_Burgers_AMD_write_transposed) wt = 1_c_int               ! the contract of :236-240 (X, Y; Z has no local transpose)
         rc = tlab_opr_burgers(int(idir, c_int), OPR_Partial_AMD_Plan(idir, gp(idir)), int(ivel, c_int), int(nx, c_int), int(ny, c_int), &
                               int(nz, c_int), int(bcs(1, 1) + bcs(2, 1)*2, c_int), diffusivity(is), c_loc(s), c_loc(u), c_loc(result), &
-                              c_loc(tmp1), 0_c_int)
+                              c_loc(tmp1), wt)
         call TLab_AMD_Check(rc, 'tlab_opr_burgers')
     end subroutine burgers_any
 

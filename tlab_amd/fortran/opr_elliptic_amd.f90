@@ -22,6 +22,10 @@ module TLAB_AMD_ELLIPTIC_MODULE
     private
 
     public :: OPR_Elliptic_Initialize_AMD       ! (g, nx, ny, nz [, fdm_loc]): what OPR_Elliptic_Initialize takes from modules FDM / TLab_Memory
+#ifdef TLAB_AMD_FULL_HOST
+    public :: OPR_Elliptic_Initialize           ! (inifile): operators/opr_elliptic.f90:86, in a complete host (modules TLab_Memory, TLab_Grid present)
+#endif
+    public :: OPR_Elliptic_AMD_Plan             ! the device plan (for the RHS driver, tlab_dns_create)
     public :: OPR_Poisson
     public :: OPR_Helmholtz                     ! _FourierXZ_Direct (:562-628) or _FourierXZ_Factorize (:466-557), by the plan's type
 
@@ -55,8 +59,44 @@ module TLAB_AMD_ELLIPTIC_MODULE
 
     type(c_ptr), save :: plan = c_null_ptr
     type(c_ptr), save :: plan_elliptic_y = c_null_ptr      ! device copy of fdm_loc (direct solver only)
+    type(fdm_dt), save, target :: fdm_loc                  ! opr_elliptic.f90:65
 
 contains
+    function OPR_Elliptic_AMD_Plan() result(p)
+        type(c_ptr) :: p
+        p = plan
+    end function OPR_Elliptic_AMD_Plan
+
+#ifdef TLAB_AMD_FULL_HOST
+    ! OPR_Elliptic_Initialize(inifile)   operators/opr_elliptic.f90:86-250: [Main] EllipticOrder selects the factorized (default: the scheme of
+    ! the derivatives) or the direct solver; the direct one differentiates with its own plan fdm_loc = FDM_CreatePlan(y, ...) (:107-124).
+    subroutine OPR_Elliptic_Initialize(inifile)
+        use FDM, only: g, FDM_CreatePlan
+        use FDM_Derivative, only: FDM_COM4_DIRECT, FDM_COM6_DIRECT
+        use TLab_Grid, only: y
+        use TLab_Memory, only: imax, jmax, kmax
+        use TLab_Constants, only: efile
+        use TLab_WorkFlow, only: TLab_Write_ASCII, TLab_Stop
+        character(len=*), intent(in) :: inifile
+        character(len=512) sRes
+        character(len=32) bakfile
+        integer, parameter :: DNS_ERROR_UNDEVELOP = 104
+        bakfile = trim(adjustl(inifile))//'.bak'
+        call ScanFile_Char(bakfile, inifile, 'Main', 'EllipticOrder', 'void', sRes)
+        if (trim(adjustl(sRes)) == 'compactdirect6') then
+            fdm_loc%der1%mode_fdm = FDM_COM6_DIRECT
+            fdm_loc%der2%mode_fdm = FDM_COM6_DIRECT
+            call FDM_CreatePlan(y, fdm_loc)
+            call OPR_Elliptic_Initialize_AMD(g, imax, jmax, kmax, fdm_loc)
+        else if (trim(adjustl(sRes)) == 'compactdirect4') then
+            call TLab_Write_ASCII(efile, __FILE__//'. EllipticOrder = CompactDirect4 is not built on the device path.')
+            call TLab_Stop(DNS_ERROR_UNDEVELOP)
+        else
+            call OPR_Elliptic_Initialize_AMD(g, imax, jmax, kmax)
+        end if
+    end subroutine OPR_Elliptic_Initialize
+#endif
+
     subroutine OPR_Elliptic_Initialize_AMD(g, nx, ny, nz, fdm_elliptic)
         type(fdm_dt), intent(in) :: g(3)
         integer(wi), intent(in) :: nx, ny, nz

@@ -1,0 +1,36 @@
+!########################################################################
+! Link-time replacement of the external subroutine RHS_GLOBAL_INCOMPRESSIBLE_1() (tools/dns/rhs_global_incompressible_1.f90:15-405),
+! called by TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT (tools/dns/time.f90:612).  Argument-less like the reference's: it works on the module arrays
+! q, s, txc (TLab_Arrays), hq, hs (DNS_ARRAYS) and on dte (TIME), all of which live on the device through the allocation hook, and runs
+! the whole assembly -- 12 + 3 ns OPR_Burgers, the pressure forcing, OPR_Poisson, the pressure gradient and the wall boundary conditions --
+! in tlab_rhs_global_incompressible_1 without a field ever visiting the host.
+!########################################################################
+subroutine RHS_GLOBAL_INCOMPRESSIBLE_1()
+    use, intrinsic :: iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_Memory, only: inb_flow, inb_scal, inb_txc
+    use TLab_Arrays
+    use DNS_ARRAYS
+    use TIME, only: dte
+    use TLab_AMD_C
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle
+    implicit none
+
+    type(c_ptr) :: pq(3), ps(16), phq(3), phs(16), ptxc(16)
+    integer is
+    integer(c_int) rc
+
+    do is = 1, 3
+        pq(is) = c_loc(q(1, is)); phq(is) = c_loc(hq(1, is))
+    end do
+    ps = c_null_ptr; phs = c_null_ptr
+    do is = 1, inb_scal
+        ps(is) = c_loc(s(1, is)); phs(is) = c_loc(hs(1, is))
+    end do
+    do is = 1, min(int(inb_txc), 16)
+        ptxc(is) = c_loc(txc(1, is))
+    end do
+    rc = tlab_rhs_global_incompressible_1(TLab_AMD_DNS_Handle(), real(dte, c_double), pq, ps, phq, phs, ptxc)
+    call TLab_AMD_Check(rc, 'tlab_rhs_global_incompressible_1')
+
+end subroutine RHS_GLOBAL_INCOMPRESSIBLE_1

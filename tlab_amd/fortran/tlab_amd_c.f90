@@ -8,6 +8,9 @@ module TLab_AMD_C
     public
 
     interface
+        integer(c_int) function tlab_finalize() bind(C, name='tlab_finalize')
+            import :: c_int
+        end function
         integer(c_int) function tlab_init(device) bind(C, name='tlab_init')
             import :: c_int
             integer(c_int), value :: device
@@ -99,25 +102,96 @@ module TLab_AMD_C
             type(c_ptr), value :: a, b
             integer(c_int), value :: nra, nca
         end function
+        ! ---- RHS assembly / Runge-Kutta substep / wall boundary conditions (include/tlab_amd.h, "next" row n1) ----
+        integer(c_int) function tlab_dns_create(dns, gx, gy, gz, poisson, nx, ny, nz, nscal, visc, schmidt) bind(C, name='tlab_dns_create')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), intent(out) :: dns
+            type(c_ptr), value :: gx, gy, gz, poisson
+            integer(c_int), value :: nx, ny, nz, nscal
+            real(c_double), value :: visc
+            real(c_double), intent(in) :: schmidt(*)
+        end function
+        integer(c_int) function tlab_dns_destroy(dns) bind(C, name='tlab_dns_destroy')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: dns
+        end function
+        integer(c_int) function tlab_dns_set_bcs(dns, flow_jmin, flow_jmax, scal_jmin, scal_jmax) bind(C, name='tlab_dns_set_bcs')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: dns
+            integer(c_int), intent(in) :: flow_jmin(3), flow_jmax(3), scal_jmin(*), scal_jmax(*)
+        end function
+        integer(c_int) function tlab_dns_begin_step(dns) bind(C, name='tlab_dns_begin_step')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: dns
+        end function
+        integer(c_int) function tlab_rhs_global_incompressible_1(dns, dte, q, s, hq, hs, txc) bind(C, name='tlab_rhs_global_incompressible_1')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: dns
+            real(c_double), value :: dte
+            type(c_ptr), intent(in) :: q(*), s(*), hq(*), hs(*), txc(*)        ! host arrays of device pointers
+        end function
+        integer(c_int) function tlab_time_substep_incompressible_explicit(dns, dte, kco, scale_tendencies, q, s, hq, hs, txc) &
+            bind(C, name='tlab_time_substep_incompressible_explicit')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: dns
+            real(c_double), value :: dte, kco
+            integer(c_int), value :: scale_tendencies
+            type(c_ptr), intent(in) :: q(*), s(*), hq(*), hs(*), txc(*)
+        end function
+        integer(c_int) function tlab_time_courant(dns, q, cfla, cfld, pmax, dtime) bind(C, name='tlab_time_courant')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: dns
+            type(c_ptr), intent(in) :: q(*)
+            real(c_double), value :: cfla, cfld
+            real(c_double), intent(out) :: pmax(2), dtime
+        end function
+        integer(c_int) function tlab_pw_rk_update(q, h, dte, kco, scale, n) bind(C, name='tlab_pw_rk_update')
+            import :: c_int, c_ptr, c_double, c_long_long
+            type(c_ptr), value :: q, h
+            real(c_double), value :: dte, kco
+            integer(c_int), value :: scale
+            integer(c_long_long), value :: n
+        end function
+        integer(c_int) function tlab_pw_fill(a, val, n) bind(C, name='tlab_pw_fill')
+            import :: c_int, c_ptr, c_double, c_long_long
+            type(c_ptr), value :: a
+            real(c_double), value :: val
+            integer(c_long_long), value :: n
+        end function
+        integer(c_int) function tlab_pw_scale(a, alpha, n) bind(C, name='tlab_pw_scale')
+            import :: c_int, c_ptr, c_double, c_long_long
+            type(c_ptr), value :: a
+            real(c_double), value :: alpha
+            integer(c_long_long), value :: n
+        end function
+        integer(c_int) function tlab_boundary_bcs_neumann_y(plan, ibc, nx, ny, nz, u, bcs_hb, bcs_ht, tmp1) bind(C, name='tlab_boundary_bcs_neumann_y')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, u, bcs_hb, bcs_ht, tmp1
+            integer(c_int), value :: ibc, nx, ny, nz
+        end function
     end interface
 
 contains
-    ! Error convention of the reference: write the message and stop the program (TLab_Write_ASCII(efile, ...) + TLab_Stop,
-    ! base/tlab_workflow.f90:105-166).  In a full Tlab build replace the body by those two calls.
+    ! Error convention of the reference: a line in tlab.err and TLab_Stop (base/tlab_workflow.f90:105-207); codes from include/dns_error.h.
     subroutine TLab_AMD_Check(rc, what)
+        use TLab_Constants, only: efile
+        use TLab_WorkFlow, only: TLab_Write_ASCII, TLab_Stop
         integer(c_int), intent(in) :: rc
         character(len=*), intent(in) :: what
         character(kind=c_char), pointer :: msg(:)
+        character(len=512) :: text
         integer i
+        integer, parameter :: DNS_ERROR_UNDEVELOP = 104          ! include/dns_error.h:99
         if (rc == 0) return
         call c_f_pointer(tlab_last_error(), msg, [512])
-        write (*, '(a)', advance='no') 'tlab_amd: '//what//' failed: '
+        text = ''
         do i = 1, 512
             if (msg(i) == c_null_char) exit
-            write (*, '(a)', advance='no') msg(i)
+            text(i:i) = msg(i)
         end do
-        write (*, *)
-        error stop 91       ! DNS_ERROR_UNDEVELOP in a full build
+        call TLab_Write_ASCII(efile, 'tlab_amd. '//what//' failed: '//trim(text))
+        write (*, '(a)') 'tlab_amd: '//what//' failed: '//trim(text)
+        call TLab_Stop(DNS_ERROR_UNDEVELOP)
     end subroutine TLab_AMD_Check
 
 end module TLab_AMD_C

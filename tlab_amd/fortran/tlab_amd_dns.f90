@@ -1,0 +1,140 @@
+!########################################################################
+! Device side of the Runge-Kutta driver, for a Fortran host that keeps tools/dns/time.f90 and dns_main.f90:
+!   module TLab_AMD_DNS            the handle of tlab_dns_create, built lazily from what the reference's own modules hold
+!                                  (FDM: g ; TLab_Memory: imax, jmax, kmax, inb_scal ; NavierStokes: visc, schmidt ;
+!                                  BOUNDARY_BCS: Bcs{Flow,Scal}J{min,max}%type ; OPR_Elliptic: the Poisson plan)
+!   subroutine DAXPY, DSCAL        the two BLAS-1 routines TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT and TIME_RUNGEKUTTA call in their -DUSE_BLAS
+!                                  branches (tools/dns/time.f90:649, :281, :291) on q, hq, s, hs -- here for DEVICE arrays, so that those
+!                                  statements stay textually what they are
+!   subroutine TLab_AMD_Zero       hq = 0.0_wp (time.f90:213-214) for a device array: the one statement of the loop with no BLAS branch
+!   module IO_Fields_AMD           IO_Read_Fields / IO_Write_Fields (base/io_fields.f90:150, :346) for device arrays: the reference's own
+!                                  routines on a host buffer + tlab_memcpy_h2d / d2h
+!########################################################################
+module TLab_AMD_DNS
+    use, intrinsic :: iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_AMD_C
+    implicit none
+    private
+
+    public :: TLab_AMD_DNS_Handle          ! type(c_ptr): creates the device driver state on first use
+    public :: TLab_AMD_DNS_Begin_Step      ! optional: tells the device RHS that hq, hs are zero (no fill, no read of the old tendencies)
+    public :: TLab_AMD_Zero
+    public :: TLab_AMD_DNS_Finalize
+
+    type(c_ptr), save :: dns = c_null_ptr
+
+contains
+    function TLab_AMD_DNS_Handle() result(h)
+        use FDM, only: g
+        use TLab_Memory, only: imax, jmax, kmax, inb_scal
+        use NavierStokes, only: visc, schmidt
+        use BOUNDARY_BCS, only: BcsFlowJmin, BcsFlowJmax, BcsScalJmin, BcsScalJmax
+        use OPR_Partial, only: OPR_Partial_AMD_Plan
+        use OPR_Elliptic, only: OPR_Elliptic_AMD_Plan
+        type(c_ptr) :: h
+        integer(c_int) :: rc, fj0(3), fj1(3), sj0(16), sj1(16)
+        real(c_double) :: sc(16)
+        integer ns
+        if (.not. c_associated(dns)) then
+            ns = max(1, int(inb_scal))
+            sc = 1.0_c_double
+            sc(1:inb_scal) = schmidt(1:inb_scal)
+            rc = tlab_dns_create(dns, OPR_Partial_AMD_Plan(1, g(1)), OPR_Partial_AMD_Plan(2, g(2)), OPR_Partial_AMD_Plan(3, g(3)), &
+                                 OPR_Elliptic_AMD_Plan(), int(imax, c_int), int(jmax, c_int), int(kmax, c_int), int(inb_scal, c_int), &
+                                 real(visc, c_double), sc)
+            call TLab_AMD_Check(rc, 'tlab_dns_create')
+            fj0 = BcsFlowJmin%type(1:3); fj1 = BcsFlowJmax%type(1:3)
+            sj0 = 3; sj1 = 3
+            sj0(1:inb_scal) = BcsScalJmin%type(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%type(1:inb_scal)
+            rc = tlab_dns_set_bcs(dns, fj0, fj1, sj0, sj1)
+            call TLab_AMD_Check(rc, 'tlab_dns_set_bcs')
+        end if
+        h = dns
+    end function TLab_AMD_DNS_Handle
+
+    subroutine TLab_AMD_DNS_Begin_Step()
+        call TLab_AMD_Check(tlab_dns_begin_step(TLab_AMD_DNS_Handle()), 'tlab_dns_begin_step')
+    end subroutine TLab_AMD_DNS_Begin_Step
+
+    ! a = 0.0_wp for a device array of any rank (sequence association: pass the array, its size)
+    subroutine TLab_AMD_Zero(a, n)
+        real(wp), intent(inout), target :: a(*)
+        integer(wi), intent(in) :: n
+        call TLab_AMD_Check(tlab_pw_fill(c_loc(a), 0.0_c_double, int(n, c_long_long)), 'tlab_pw_fill')
+    end subroutine TLab_AMD_Zero
+
+    subroutine TLab_AMD_DNS_Finalize()
+        integer(c_int) rc
+        if (c_associated(dns)) rc = tlab_dns_destroy(dns)
+        dns = c_null_ptr
+        rc = tlab_sync()
+    end subroutine TLab_AMD_DNS_Finalize
+
+end module TLab_AMD_DNS
+
+! ###################################################################
+! DAXPY / DSCAL on device arrays (the -DUSE_BLAS branches of tools/dns/time.f90:649-660, :279-293)
+subroutine DAXPY(n, da, dx, incx, dy, incy)
+    use, intrinsic :: iso_c_binding
+    use TLab_AMD_C
+    implicit none
+    integer, intent(in) :: n, incx, incy
+    real(c_double), intent(in) :: da
+    real(c_double), intent(in), target :: dx(*)
+    real(c_double), intent(inout), target :: dy(*)
+    if (incx /= 1 .or. incy /= 1) call TLab_AMD_Check(-1_c_int, 'DAXPY on device arrays (unit strides only)')
+    call TLab_AMD_Check(tlab_pw_rk_update(c_loc(dy), c_loc(dx), da, 1.0_c_double, 0_c_int, int(n, c_long_long)), 'tlab_pw_rk_update')    ! y = y + a x
+end subroutine DAXPY
+
+subroutine DSCAL(n, da, dx, incx)
+    use, intrinsic :: iso_c_binding
+    use TLab_AMD_C
+    implicit none
+    integer, intent(in) :: n, incx
+    real(c_double), intent(in) :: da
+    real(c_double), intent(inout), target :: dx(*)
+    if (incx /= 1) call TLab_AMD_Check(-1_c_int, 'DSCAL on device arrays (unit stride only)')
+    call TLab_AMD_Check(tlab_pw_scale(c_loc(dx), da, int(n, c_long_long)), 'tlab_pw_scale')
+end subroutine DSCAL
+
+! ###################################################################
+module IO_Fields_AMD
+    use, intrinsic :: iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_AMD_C
+    use IO_Fields, only: IO_Read_Fields, IO_Write_Fields          ! the reference's own, base/io_fields.f90, compiled where it lies
+    implicit none
+    private
+    public :: IO_Read_Fields_AMD, IO_Write_Fields_AMD
+
+contains
+    ! IO_Read_Fields(fname, nx, ny, nz, nt, nfield, iread, a, params) with a(nx*ny*nz, *) on the device
+    subroutine IO_Read_Fields_AMD(fname, nx, ny, nz, nt, nfield, iread, a, params)
+        character(len=*) fname
+        integer, intent(in) :: nfield, iread
+        integer(wi), intent(in) :: nx, ny, nz, nt
+        real(wp), intent(out), target :: a(nx*ny*nz, *)
+        real(wp), intent(inout) :: params(:)
+        real(wp), allocatable, target :: host(:, :)
+        integer nloc
+        nloc = merge(nfield, 1, iread == 0)
+        allocate (host(nx*ny*nz, nloc))
+        call IO_Read_Fields(fname, nx, ny, nz, nt, nfield, iread, host, params)
+        call TLab_AMD_Check(tlab_memcpy_h2d(c_loc(a), c_loc(host), int(nx, c_size_t)*ny*nz*nloc*8_c_size_t), 'tlab_memcpy_h2d')
+        deallocate (host)
+    end subroutine IO_Read_Fields_AMD
+
+    subroutine IO_Write_Fields_AMD(fname, nx, ny, nz, nt, nfield, a)
+        character(len=*), intent(in) :: fname
+        integer, intent(in) :: nfield
+        integer(wi), intent(in) :: nx, ny, nz, nt
+        real(wp), intent(in), target :: a(nx*ny*nz, nfield)
+        real(wp), allocatable, target :: host(:, :)
+        allocate (host(nx*ny*nz, nfield))
+        call TLab_AMD_Check(tlab_memcpy_d2h(c_loc(host), c_loc(a), int(nx, c_size_t)*ny*nz*nfield*8_c_size_t), 'tlab_memcpy_d2h')
+        call IO_Write_Fields(fname, nx, ny, nz, nt, nfield, host)
+        deallocate (host)
+    end subroutine IO_Write_Fields_AMD
+
+end module IO_Fields_AMD

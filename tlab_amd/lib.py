@@ -58,6 +58,8 @@ SIGNATURES = {
     "tlab_pw_sum3": (c_int, [c_vp, c_vp, c_vp, ctypes.c_longlong]),
     "tlab_pw_sub3": (c_int, [c_vp] * 6 + [ctypes.c_longlong]),
     "tlab_pw_rk_update": (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, ctypes.c_longlong]),
+    "tlab_pw_fill": (c_int, [c_vp, c_dbl, ctypes.c_longlong]),
+    "tlab_pw_scale": (c_int, [c_vp, c_dbl, ctypes.c_longlong]),
     "tlab_pw_final_update": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_int, c_int]),
     "tlab_pw_get_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int]),
     "tlab_pw_fill_wall_planes": (c_int, [c_vp, c_dbl, c_dbl, c_int, c_int, c_int]),
