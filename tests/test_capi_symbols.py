@@ -10,10 +10,10 @@ from tlab_amd import lib as tl
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def declared_symbols():
+def declared_symbols(which="tlab_amd.h"):
     names = []
     for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
-        if not hdr.endswith(".h"):
+        if hdr != which:
             continue
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
@@ -44,3 +44,14 @@ def test_load_fails_loudly_without_the_library(monkeypatch, tmp_path):
     monkeypatch.setattr(tl, "_HERE", str(tmp_path))
     with pytest.raises(tl.TlabError):
         tl.load()
+
+
+def test_comm_library_exports_every_declared_symbol_and_the_binding_matches():
+    """include/tlab_amd_comm.h (RCCL transpositions) lives in its own library, libtlab_amd_comm.so, bound by tlab_amd/comm.py."""
+    from tlab_amd import comm as tc
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["tlab_amd.h", "tlab_amd_comm.h"]
+    decl = set(declared_symbols("tlab_amd_comm.h"))
+    assert len(decl) >= 13
+    L = tc.load()
+    assert not [n for n in decl if not hasattr(L, n)]
+    assert decl == set(tc.SIGNATURES), (sorted(decl - set(tc.SIGNATURES)), sorted(set(tc.SIGNATURES) - decl))

@@ -1,0 +1,294 @@
+// libtlab_amd_comm.so -- pencil transpositions of the hot path over RCCL (include/tlab_amd_comm.h).
+//
+// Reference: TLabMPI_Trp_PlanI / PlanK and TLabMPI_Trp_Exec{I,K}_{Forward,Backward} (base/tlab_mpi_transpose.f90:205-553), which move the data with
+// MPI_ISEND/IRECV or MPI_ALLTOALLW on derived vector datatypes (:557-610).  RCCL has neither derived datatypes nor alltoallw; here every
+// transposition has exactly ONE strided side (see below), served by one HIP copy kernel, and the exchange itself is a grouped ncclSend / ncclRecv of
+// contiguous blocks straight from / into the caller's array on the other side -- one staging buffer per plan, one extra pass over the local data.
+//
+//   strided array S and wire format W share one index pattern (m = inner length in doubles, c = outer count, P = ranks of the direction):
+//       S[(q m + r) + (m P) o]   <->   W[q (m c) + r + m o]          q = peer, r < m, o < c
+//   I (x pencils): m = imax e, c = nlines ; S = b(imax P, nlines), W = blocks of my lines' x-segments      (tlab_mpi_transpose.f90:232-256)
+//   K (z pencils): m = nlines e, c = kmax ; S = a(npage, kmax),    W = blocks (nlines, kmax) per peer      (:301-325)
+//   e = 1 (real) or 2 (complex).  Forward I unpacks (W -> S), backward I packs; forward K packs (S -> W), backward K unpacks.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../include/tlab_amd.h"
+#include "../../include/tlab_amd_comm.h"
+
+extern hipStream_t tlab_current_stream();
+extern void tlab_set_error(const std::string &s);
+extern bool tlab_device_ready();
+
+namespace {
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+void hipc(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Fail{TLAB_EHIP, std::string(what) + ": " + hipGetErrorString(e)};
+}
+void ncc(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) throw Fail{TLAB_EHIP, std::string(what) + ": " + ncclGetErrorString(r)};
+}
+
+// to_wire != 0: W[i] = S[..]; else S[..] = W[i].  i runs over the wire order, so the W side is a plain stream and the S side is contiguous in
+// runs of m doubles.  VEC = 2: 16-byte accesses (m even, bases 16-byte aligned).
+template <int VEC>
+__global__ void __launch_bounds__(256) k_trp_copy(double *__restrict__ S, double *__restrict__ W, long long m, int P, long long c, int to_wire) {
+    const long long mv = m / VEC, total = mv * c * P, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long r = i % mv, o = (i / mv) % c, q = i / (mv * c);
+        const long long s = (q * mv + r) + (mv * P) * o;
+        if (VEC == 2) {
+            double2 *S2 = reinterpret_cast<double2 *>(S), *W2 = reinterpret_cast<double2 *>(W);
+            if (to_wire) W2[i] = S2[s];
+            else S2[s] = W2[i];
+        } else {
+            if (to_wire) W[i] = S[s];
+            else S[s] = W[i];
+        }
+    }
+}
+
+}  // namespace
+
+struct tlab_comm {
+    ncclComm_t world = nullptr, cx = nullptr, cz = nullptr;
+    int nranks = 1, rank = 0, npro_i = 1, npro_k = 1, pro_i = 0, pro_k = 0;
+    hipStream_t stream = nullptr;      // the library's communication stream
+};
+
+struct tlab_trp_plan {
+    tlab_comm *comm = nullptr;
+    ncclComm_t nc = nullptr;
+    int dir = 0, P = 1, rank = 0, e = 1;
+    long long m = 0, c = 0, blk = 0, local = 0, nlines = 0;
+    double *stage = nullptr;
+    hipStream_t stream = nullptr;      // comm->stream, or an own one for plans without a communicator
+    bool own_stream = false;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    // the transposition in flight
+    bool pending = false, pending_unpack = false;
+    double *pending_out = nullptr;
+};
+
+namespace {
+
+void copy_strided(const tlab_trp_plan *p, double *S, double *W, int to_wire, hipStream_t st) {
+    const long long total = p->m * p->c * p->P;
+    const bool vec = (p->m % 2 == 0) && ((reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
+    const long long work = vec ? total / 2 : total;
+    const int grid = (int)std::min<long long>(4096, std::max<long long>(1, (work + 255) / 256));
+    if (vec) hipLaunchKernelGGL(k_trp_copy<2>, dim3(grid), dim3(256), 0, st, S, W, p->m, p->P, p->c, to_wire);
+    else hipLaunchKernelGGL(k_trp_copy<1>, dim3(grid), dim3(256), 0, st, S, W, p->m, p->P, p->c, to_wire);
+    hipc(hipGetLastError(), "k_trp_copy");
+}
+bool strided_on_send(const tlab_trp_plan *p, int forward) { return (p->dir == 1 && !forward) || (p->dir == 3 && forward); }
+
+int guard(const Fail &f) {
+    tlab_set_error(f.msg);
+    return f.code;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tlab_comm_get_unique_id(void *id_bytes) {
+    try {
+        if (!id_bytes) throw Fail{TLAB_EINVAL, "tlab_comm_get_unique_id: null buffer"};
+        static_assert(sizeof(ncclUniqueId) == TLAB_COMM_ID_BYTES, "ncclUniqueId size");
+        ncclUniqueId id;
+        ncc(ncclGetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id_bytes, &id, sizeof(id));
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_comm_init(tlab_comm_t *out, const void *id_bytes, int nranks, int rank, int npro_i, int npro_k) {
+    try {
+        if (!out || !id_bytes) throw Fail{TLAB_EINVAL, "tlab_comm_init: null argument"};
+        if (!tlab_device_ready()) throw Fail{TLAB_EHIP, "tlab_comm_init: tlab_init has not been called"};
+        if (nranks < 1 || rank < 0 || rank >= nranks || npro_i < 1 || npro_k < 1 || npro_i * npro_k != nranks)
+            throw Fail{TLAB_EINVAL, "tlab_comm_init: nranks must equal npro_i * npro_k (tlab_mpi_procs.f90:58-66)"};
+        auto *c = new tlab_comm();
+        c->nranks = nranks; c->rank = rank; c->npro_i = npro_i; c->npro_k = npro_k;
+        c->pro_i = rank % npro_i;               // tlab_mpi_procs.f90:76-86
+        c->pro_k = rank / npro_i;
+        ncclUniqueId id;
+        std::memcpy(&id, id_bytes, sizeof(id));
+        ncc(ncclCommInitRank(&c->world, nranks, id, rank), "ncclCommInitRank");
+        // ims_comm_x: equal ims_pro_k, ordered by ims_pro_i ; ims_comm_z: equal ims_pro_i, ordered by ims_pro_k
+        if (npro_i > 1) ncc(ncclCommSplit(c->world, c->pro_k, c->pro_i, &c->cx, nullptr), "ncclCommSplit (x)");
+        if (npro_k > 1) ncc(ncclCommSplit(c->world, c->pro_i, c->pro_k, &c->cz, nullptr), "ncclCommSplit (z)");
+        hipc(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+        *out = c;
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_comm_destroy(tlab_comm_t c) {
+    if (!c) return TLAB_OK;
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->cx) (void)ncclCommDestroy(c->cx);
+    if (c->cz) (void)ncclCommDestroy(c->cz);
+    if (c->world) (void)ncclCommDestroy(c->world);
+    delete c;
+    return TLAB_OK;
+}
+
+int tlab_comm_info(tlab_comm_t c, int what) {
+    if (!c) return TLAB_EINVAL;
+    switch (what) {
+        case 0: return c->rank;
+        case 1: return c->nranks;
+        case 2: return c->pro_i;
+        case 3: return c->npro_i;
+        case 4: return c->pro_k;
+        case 5: return c->npro_k;
+    }
+    return TLAB_EINVAL;
+}
+
+int tlab_comm_allreduce_max(tlab_comm_t c, double *v, int n) {
+    try {
+        if (!c || !v || n < 1) throw Fail{TLAB_EINVAL, "tlab_comm_allreduce_max: bad arguments"};
+        if (c->nranks > 1) ncc(ncclAllReduce(v, v, (size_t)n, ncclDouble, ncclMax, c->world, tlab_current_stream()), "ncclAllReduce");
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_trp_plan_create(tlab_trp_plan_t *out, tlab_comm_t comm, int dir, int nmax, int npage, int elem_doubles, int rank_dir, int npro_dir) {
+    try {
+        if (!out) throw Fail{TLAB_EINVAL, "tlab_trp_plan_create: null argument"};
+        if (!tlab_device_ready()) throw Fail{TLAB_EHIP, "tlab_trp_plan_create: tlab_init has not been called"};
+        if ((dir != 1 && dir != 3) || nmax < 1 || npage < 1 || (elem_doubles != 1 && elem_doubles != 2))
+            throw Fail{TLAB_EINVAL, "tlab_trp_plan_create: dir = 1 (I) or 3 (K), elem_doubles = 1 or 2"};
+        auto *p = new tlab_trp_plan();
+        p->dir = dir; p->e = elem_doubles; p->comm = comm;
+        if (comm) {
+            p->P = dir == 1 ? comm->npro_i : comm->npro_k;
+            p->rank = dir == 1 ? comm->pro_i : comm->pro_k;
+            p->nc = dir == 1 ? comm->cx : comm->cz;
+            p->stream = comm->stream;
+        } else {
+            if (npro_dir < 1 || rank_dir < 0 || rank_dir >= npro_dir) { delete p; throw Fail{TLAB_EINVAL, "tlab_trp_plan_create: rank_dir of npro_dir"}; }
+            p->P = npro_dir; p->rank = rank_dir;
+            hipc(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking), "hipStreamCreate");
+            p->own_stream = true;
+        }
+        if (npage % p->P != 0) {               // tlab_mpi_transpose.f90:223, :292
+            delete p;
+            throw Fail{TLAB_EINVAL, "tlab_trp_plan_create: npage must be a multiple of the number of ranks of the direction"};
+        }
+        p->nlines = npage / p->P;
+        if (dir == 1) { p->m = (long long)nmax * p->e; p->c = p->nlines; }
+        else { p->m = p->nlines * p->e; p->c = nmax; }
+        p->blk = p->m * p->c;
+        p->local = p->blk * p->P;
+        hipc(hipMalloc((void **)&p->stage, (size_t)p->local * sizeof(double)), "hipMalloc (staging buffer)");
+        hipc(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming), "hipEventCreate");
+        hipc(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming), "hipEventCreate");
+        *out = p;
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_trp_plan_destroy(tlab_trp_plan_t p) {
+    if (!p) return TLAB_OK;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->stage) (void)hipFree(p->stage);
+    if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
+    if (p->ev_done) (void)hipEventDestroy(p->ev_done);
+    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return TLAB_OK;
+}
+
+int tlab_trp_plan_info(tlab_trp_plan_t p, int what) {
+    if (!p) return TLAB_EINVAL;
+    switch (what) {
+        case 0: return (int)p->nlines;
+        case 1: return p->P;
+        case 2: return p->rank;
+        case 3: return (int)p->blk;
+        case 4: return (int)p->local;
+    }
+    return TLAB_EINVAL;
+}
+
+int tlab_trp_pack(tlab_trp_plan_t p, int forward, const double *in, double *sendbuf) {
+    try {
+        if (!p || !in || !sendbuf || in == sendbuf) throw Fail{TLAB_EINVAL, "tlab_trp_pack: bad arguments"};
+        hipStream_t st = tlab_current_stream();
+        if (strided_on_send(p, forward)) copy_strided(p, const_cast<double *>(in), sendbuf, 1, st);
+        else hipc(hipMemcpyAsync(sendbuf, in, (size_t)p->local * sizeof(double), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_trp_unpack(tlab_trp_plan_t p, int forward, const double *recvbuf, double *out) {
+    try {
+        if (!p || !recvbuf || !out || recvbuf == out) throw Fail{TLAB_EINVAL, "tlab_trp_unpack: bad arguments"};
+        hipStream_t st = tlab_current_stream();
+        if (!strided_on_send(p, forward)) copy_strided(p, out, const_cast<double *>(recvbuf), 0, st);
+        else hipc(hipMemcpyAsync(out, recvbuf, (size_t)p->local * sizeof(double), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_trp_start(tlab_trp_plan_t p, int forward, const double *in, double *out) {
+    try {
+        if (!p || !in || !out || in == out) throw Fail{TLAB_EINVAL, "tlab_trp_start: bad arguments (in and out must differ)"};
+        if (p->pending) throw Fail{TLAB_EINVAL, "tlab_trp_start: a transposition of this plan is still in flight (tlab_trp_wait)"};
+        if (p->P > 1 && !p->nc) throw Fail{TLAB_EINVAL, "tlab_trp_start: the plan has no communicator (use tlab_trp_pack / tlab_trp_unpack)"};
+        hipStream_t cur = tlab_current_stream(), cs = p->stream;
+        const bool pack = strided_on_send(p, forward);
+        const double *src = in;       // blocked by peer
+        double *dst = out;            // blocked by peer
+        if (pack) { copy_strided(p, const_cast<double *>(in), p->stage, 1, cur); src = p->stage; }
+        else dst = p->stage;
+        hipc(hipEventRecord(p->ev_ready, cur), "hipEventRecord");          // in (and the packed copy) are ready; earlier readers of out are done
+        hipc(hipStreamWaitEvent(cs, p->ev_ready, 0), "hipStreamWaitEvent");
+        const size_t bytes = (size_t)p->blk * sizeof(double);
+        hipc(hipMemcpyAsync(dst + (size_t)p->rank * p->blk, src + (size_t)p->rank * p->blk, bytes, hipMemcpyDeviceToDevice, cs), "hipMemcpyAsync (own block)");
+        if (p->P > 1) {
+            ncc(ncclGroupStart(), "ncclGroupStart");
+            for (int q = 0; q < p->P; ++q) {
+                if (q == p->rank) continue;
+                ncc(ncclSend(src + (size_t)q * p->blk, (size_t)p->blk, ncclDouble, q, p->nc, cs), "ncclSend");
+                ncc(ncclRecv(dst + (size_t)q * p->blk, (size_t)p->blk, ncclDouble, q, p->nc, cs), "ncclRecv");
+            }
+            ncc(ncclGroupEnd(), "ncclGroupEnd");
+        }
+        hipc(hipEventRecord(p->ev_done, cs), "hipEventRecord");
+        p->pending = true; p->pending_unpack = !pack; p->pending_out = out;
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_trp_wait(tlab_trp_plan_t p) {
+    try {
+        if (!p) throw Fail{TLAB_EINVAL, "tlab_trp_wait: null plan"};
+        if (!p->pending) return TLAB_OK;
+        hipStream_t cur = tlab_current_stream();
+        hipc(hipStreamWaitEvent(cur, p->ev_done, 0), "hipStreamWaitEvent");
+        if (p->pending_unpack) copy_strided(p, p->pending_out, p->stage, 0, cur);
+        p->pending = false;
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
+int tlab_trp_exec(tlab_trp_plan_t p, int forward, const double *in, double *out) {
+    const int rc = tlab_trp_start(p, forward, in, out);
+    return rc != TLAB_OK ? rc : tlab_trp_wait(p);
+}
+
+}  // extern "C"

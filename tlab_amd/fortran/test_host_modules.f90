@@ -20,3 +20,11 @@ module DNS_ARRAYS
     real(wp), pointer, contiguous, public :: hs(:, :) => null()
 end module DNS_ARRAYS
 
+
+module TLabMPI_VARS                                                  ! base/tlab_mpi_vars.f90:6-15 (the decomposition; set by TLabMPI_Initialize)
+    use TLab_Constants, only: wi
+    implicit none
+    integer :: ims_pro = 0, ims_npro = 1
+    integer :: ims_pro_i = 0, ims_npro_i = 1, ims_pro_k = 0, ims_npro_k = 1
+    integer(wi) :: ims_offset_i = 0, ims_offset_k = 0
+end module TLabMPI_VARS

@@ -181,8 +181,23 @@ program test_rk_driver
     use DNS_ARRAYS
     use TIME
     use TLab_AMD_DNS, only: TLab_AMD_DNS_Finalize
+    use TLabMPI_VARS
+    use TLabMPI_Transpose
+    use TLab_AMD_C, only: tlab_sync, tlab_memcpy_d2h, TLab_AMD_Check
+    use, intrinsic :: iso_c_binding
     implicit none
 
+    interface
+        integer(c_int) function tlab_comm_get_unique_id(id) bind(C, name='tlab_comm_get_unique_id')
+            import :: c_int, c_char
+            character(kind=c_char), intent(out) :: id(128)
+        end function
+    end interface
+    character(kind=c_char) :: comm_id(128)
+    type(tmpi_transpose_dt) :: plan_i, plan_k
+    real(wp), allocatable, target :: h1(:), h2(:)
+    real(wp) :: resid
+    character(len=64) line
     character(len=32) fname, bakfile
     character(len=512) sRes
     integer(wi) nitera_first, nitera_last, itime
@@ -253,6 +268,28 @@ program test_rk_driver
     call IO_Read_Fields_AMD(fname, imax, jmax, kmax, itime, inb_flow, 0, q, params(1:2))           ! :154
     rtime = params(1)
 
+    ! ###################################################################
+    ! Transposition layer on one rank (ims_npro = 1): TLabMPI_Trp_Initialize + the round trip of OPR_CHECK (operators/opr_check.f90:46-91),
+    ! forward then backward = identity, through the RCCL communicator and the same-named module procedures (real and complex plans)
+    ! ###################################################################
+    call TLab_AMD_Check(tlab_comm_get_unique_id(comm_id), 'tlab_comm_get_unique_id')      ! rank 0 + MPI_Bcast in a parallel host
+    call TLabMPI_Trp_AMD_Comm(comm_id)
+    call TLabMPI_Trp_Initialize(ifile)                                         ! dns_main.f90:67
+    plan_i = TLabMPI_Trp_PlanI(imax, jmax*kmax, message='check Ox')
+    plan_k = TLabMPI_Trp_PlanK(kmax, imax*jmax, message='check Oz')
+    allocate (h1(isize_field), h2(isize_field))
+    call TLabMPI_Trp_ExecI_Forward(q(:, 1), txc(:, 1), plan_i)
+    call TLabMPI_Trp_ExecI_Backward(txc(:, 1), txc(:, 2), plan_i)
+    call TLabMPI_Trp_ExecK_Forward(txc(:, 2), txc(:, 3), plan_k)
+    call TLabMPI_Trp_ExecK_Backward(txc(:, 3), txc(:, 4), plan_k)
+    call TLab_AMD_Check(tlab_sync(), 'tlab_sync')
+    call TLab_AMD_Check(tlab_memcpy_d2h(c_loc(h1), c_loc(q(1, 1)), int(isize_field, c_size_t)*8_c_size_t), 'd2h')
+    call TLab_AMD_Check(tlab_memcpy_d2h(c_loc(h2), c_loc(txc(1, 4)), int(isize_field, c_size_t)*8_c_size_t), 'd2h')
+    resid = maxval(abs(h1 - h2))
+    write (line, '(a,es10.3)') 'Checking transposition round trip: residual ', resid
+    call TLab_Write_ASCII(lfile, line)
+    deallocate (h1, h2)
+
     call BOUNDARY_BCS_INITIALIZE()                                             ! :193
     call TIME_INITIALIZE()                                                     ! :224
 
@@ -272,6 +309,7 @@ program test_rk_driver
         call IO_Write_Fields_AMD(fname, imax, jmax, kmax, itime, inb_scal, s)
     end if
 
+    call TLabMPI_Trp_AMD_Finalize()
     call TLab_AMD_DNS_Finalize()
     call TLab_Write_ASCII(lfile, 'test_rk_driver finished.')
     call TLab_Stop(0)
