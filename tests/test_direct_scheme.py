@@ -106,6 +106,46 @@ def test_substep_with_direct_second_derivative_in_y(elliptic_direct):
 
 
 @pytest.mark.gpu
+def test_jacobian_derivatives_with_direct_elliptic_solver():
+    """[Main] EllipticOrder = CompactDirect6 on its own (the derivatives keep CompactJacobian6 / CompactJacobian6Hyper): the Poisson solver uses
+    fdm_loc's direct second derivative while dp/dy and the divergence use the Jacobian first derivative (opr_elliptic.f90:107-124, :447-449)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    from tlab_amd.dns import Dns
+    from oracle import tlab_oracle as O
+    from oracle.tlab_oracle_rhs import DnsOracle
+    from scatter import substep_scatter, bound
+    T.init(0)
+    nx, ny, nz = 256, 64, 32
+    tab = tables(ny)
+    x, y, z = np.arange(nx) / nx * 2.0, tab["nodes"], np.arange(nz) / nz
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, False), T.FdmPlan(z, True, True)]
+    ge = T.FdmPlan.from_tables(tab, False, T.FDM_COM6_JACOBIAN, T.FDM_COM6_DIRECT)
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=gp, gy_elliptic=ge, hyper_bc1_ext=REF_HYPER)
+
+    def make_oracle():
+        go = [O.FdmPlan(x, True, True), O.FdmPlan(y, False, False), O.FdmPlan(z, True, True)]
+        return DnsOracle(x, y, z, nscal=1, visc=1.0 / 800.0, schmidt=(0.7,), yuniform=False, plans=go, gy_elliptic=O.FdmPlan.from_tables(tab, mode2=O.FDM_COM6_DIRECT))
+    rng = np.random.default_rng(82)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    q0 = [((np.sin(np.pi * X + i) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for i in range(3)]
+    s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i]))
+    d.s[0].copy_(torch.from_numpy(s0[0]))
+    sched = [(2e-3 * d.kdt[k], d.kco[k], True) for k in range(2)]
+    B, S = substep_scatter(make_oracle, q0, s0, sched, nsamples=1)
+    for k, (dte, kco, scale) in enumerate(sched):
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
+    for i in range(3):
+        assert rel_err(d.q[i].cpu().numpy(), B[1]["q"][i]) <= bound(S[1]["q"][i]), (i, rel_err(d.q[i].cpu().numpy(), B[1]["q"][i]), S[1]["q"][i])
+    assert rel_err(d.s[0].cpu().numpy(), B[1]["s"][0]) <= bound(S[1]["s"][0])
+
+
+@pytest.mark.gpu
 def test_direct_scheme_along_x_takes_the_generic_kernel():
     """A non-periodic, stretched x with a direct second derivative (n = 512 would otherwise select the wave-per-line kernel, which only
     knows the constant stencils of the Jacobian schemes)."""
