@@ -47,7 +47,8 @@ def test_hyper_closure_switch():
 
 @pytest.mark.parametrize("n,periodic,stretch,chunks", [
     (64, True, False, 1), (128, True, False, 64), (256, True, False, 64), (256, True, False, 8),
-    (96, False, True, 3), (128, False, True, 64), (128, False, False, 4), (512, False, True, 16), (50, False, True, 1)])
+    (96, False, True, 3), (128, False, True, 64), (128, False, False, 4), (512, False, True, 16), (50, False, True, 1),
+    (1024, True, False, 128), (2048, True, False, 256)])      # two / four waves per x line (k_xline WPL = 2, 4)
 def test_device_tables_solve_the_systems(n, periodic, stretch, chunks):
     """Host emulation of the kernels' chunked Thomas (same tables, same operation order) vs the oracle's TRIDSS/TRIDPSS."""
     rng = np.random.default_rng(n + chunks)

@@ -252,15 +252,16 @@ SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
         for (int j = 1; j < P && inv; ++j)
             for (int p = 0; p < m; ++p)
                 if (!close(rowtab[(size_t)tab * n + j * m + p], rowtab[(size_t)tab * n + p])) { inv = false; break; }
-    if (P == 64) {
-        if (h.pcr_steps != 6) throw std::runtime_error("internal: PCR schedule missing");
-        std::vector<double> red((size_t)13 * 64);
+    if (P == 64 || P == 128 || P == 256) {      // wave-per-line kernels: parallel cyclic reduction over the 64 lanes of 1, 2 or 4 waves
+        const int steps = h.pcr_steps;
+        if ((1 << steps) != P) throw std::runtime_error("internal: PCR schedule missing");
+        std::vector<double> red((size_t)(2 * steps + 1) * P);
         std::copy(h.pcr_k1.begin(), h.pcr_k1.end(), red.begin());
-        std::copy(h.pcr_k2.begin(), h.pcr_k2.end(), red.begin() + 6 * 64);
-        std::copy(h.pcr_dinv.begin(), h.pcr_dinv.end(), red.begin() + 12 * 64);
-        for (int q = 0; q < 13 && inv; ++q)
-            for (int j = 1; j < 64; ++j)
-                if (!close(red[(size_t)q * 64 + j], red[(size_t)q * 64])) { inv = false; break; }
+        std::copy(h.pcr_k2.begin(), h.pcr_k2.end(), red.begin() + (size_t)steps * P);
+        std::copy(h.pcr_dinv.begin(), h.pcr_dinv.end(), red.begin() + (size_t)2 * steps * P);
+        for (int q = 0; q < 2 * steps + 1 && inv; ++q)
+            for (int j = 1; j < P; ++j)
+                if (!close(red[(size_t)q * P + j], red[(size_t)q * P])) { inv = false; break; }
         e->red.upload(red);
     } else {
         e->red.upload(h.ginv);
@@ -486,37 +487,45 @@ struct OpExtra {
 };
 const OpExtra kNoExtra{};
 
-// x lines of 2048 points (BASELINE configs[4]): the wave-per-line kernel holds 32 rows per lane and keeps the lane-variant tables as float
-// differences from chunk 0 (kernels.hip, xcoef); that is exact only while the chunks differ by rounding-level amounts (periodic "uniform"
-// grids), which is checked here once per plan on the host tables.  Everything else takes the generic kernel.
-bool xline_wide_ok(tlab_fdm_plan_t g) {
-    if (!g || g->t.n != 2048 || !g->t.periodic) return false;
-    if (g->wide_ok >= 0) return g->wide_ok != 0;
+// Periodic x lines on P chunks whose lane-variant tables the kernel keeps as float differences from chunk 0 (kernels.hip, xcoef): exact only
+// while the chunks differ by rounding-level amounts (periodic "uniform" grids), which is checked here once per plan and P on the host tables.
+bool xline_wide_ok(tlab_fdm_plan_t g, int P) {
+    if (!g || !g->t.periodic || (P != 64 && P != 128 && P != 256) || g->t.n % P != 0) return false;
+    int &cache = g->wide_ok[P == 64 ? 0 : P == 128 ? 1 : 2];
+    if (cache >= 0) return cache != 0;
     bool ok = true;
     for (int which = 1; which <= 2 && ok; ++which) {
-        const SystemEntry &e = g->system(which, 0, 64);
+        const SystemEntry &e = g->system(which, 0, P);
         if (e.lane_invariant) continue;
         const ChunkedTables &h = e.host;
-        const int n = h.n, m = h.m;
+        const int m = h.m;
         const std::vector<double> *tabs[5] = {&h.Lm, &h.Dinv, &h.Cm, &h.V, &h.W};
         for (int t = 0; t < 5 && ok; ++t)
-            for (int l = 0; l < 64 && ok; ++l)
+            for (int l = 0; l < P && ok; ++l)
                 for (int p = 0; p < m; ++p) {
                     const double c = (*tabs[t])[(size_t)l * m + p], b = (*tabs[t])[p];
                     const volatile float df = (float)(c - b);
                     const volatile double r = b + (double)df;
                     if (r != c) { ok = false; break; }
                 }
-        (void)n;
     }
-    g->wide_ok = ok ? 1 : 0;
+    cache = ok ? 1 : 0;
     return ok;
+}
+
+// chunks per x line of the wave-per-line kernel (0: not on that kernel).  Lines of 1024 / 2048 periodic points go on 2 / 4 waves with 8 rows
+// per lane (128 / 256 chunks) when their tables allow the float-difference form; TLAB_XLINE_WIDE=0 keeps the one-wave forms (16 / 32 rows per lane).
+int xline_chunks(int n, tlab_fdm_plan_t g) {
+    static const bool wide = [] { const char *e = getenv("TLAB_XLINE_WIDE"); return !(e && atoi(e) == 0); }();
+    if (g && wide && n == 1024 && xline_wide_ok(g, 128)) return 128;
+    if (g && wide && n == 2048 && xline_wide_ok(g, 256)) return 256;
+    if (n == 2048) return (g && xline_wide_ok(g, 64)) ? 64 : 0;
+    return xline_supported(n) ? 64 : 0;
 }
 
 int choose_path(int dir, int n, tlab_fdm_plan_t g = nullptr) {
     int path = PATH_GENERIC;
-    if (dir == 1 && xline_supported(n)) path = PATH_XLINE;
-    if (dir == 1 && n == 2048 && xline_wide_ok(g)) path = PATH_XLINE;
+    if (dir == 1 && xline_chunks(n, g) > 0) path = PATH_XLINE;
     if (dir != 1 && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0)) path = PATH_RTILE;
     if (g_force_path == PATH_GENERIC) path = PATH_GENERIC;
     if (g_force_path == PATH_RTILE && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0) && dir != 1) path = PATH_RTILE;
@@ -581,13 +590,14 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.fdiv = ex.fdiv; a.fidte = ex.fidte;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
-    SystemEntry &e1 = g->system(1, ibc, 64), &e2 = g->system(2, 0, 64);
+    const int P = xline_chunks(geom.n, g);
+    SystemEntry &e1 = g->system(1, ibc, P), &e2 = g->system(2, 0, P);
     a.y1 = e1.dev();
     a.y2 = e2.dev();
     const bool lv = !(e1.lane_invariant && e2.lane_invariant);
     static const bool dbg = getenv("TLAB_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[tlab] k_xline mode %d n %d lane_variant %d\n", mode, geom.n, (int)lv);
-    hip_check(launch_xline(mode, geom.n, lv, a, g_stream), "k_xline");
+    if (dbg) fprintf(stderr, "[tlab] k_xline mode %d n %d chunks %d lane_variant %d\n", mode, geom.n, P, (int)lv);
+    hip_check(launch_xline(mode, geom.n, P, lv, a, g_stream), "k_xline");
 }
 
 void check_common(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc) {
@@ -676,7 +686,7 @@ bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, i
 // several transported fields, one advecting velocity: result[f] += nu[f] d2 s[f] - vel d s[f]
 // x lines of at most 512 points on the wave-per-line kernel: the launch can finish the substep of a transported field in its epilogue
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz) {
-    if (dir != 1 || nx > 512) return false;
+    if (dir != 1 || nx / std::max(xline_chunks(nx, g), 1) > 8) return false;      // the epilogue exists in the 8-rows-per-lane forms
     return tlab_internal_burgers_fusable(dir, g, nx, ny, nz) && choose_path(1, nx, g) == PATH_XLINE;
 }
 
@@ -931,7 +941,7 @@ int tlab_debug_host_chunked_solve(tlab_fdm_plan_t p, int which, int ibc, int chu
         TriDiag T = p->tridiag(which, (which == 2 || p->t.der1.periodic) ? 0 : ibc);
         ChunkedTables t;
         build_chunked(T, chunks, t);
-        chunked_solve_host(t, f, chunks == 64);
+        chunked_solve_host(t, f, chunks >= 64);
     });
 }
 

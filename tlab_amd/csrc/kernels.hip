@@ -42,70 +42,142 @@ __device__ __forceinline__ double dense6(const double (&c)[6], double a0, double
 }
 
 // ============================================================================================
-// k_xline : one wave per line, lane-chunked
+// k_xline : WPL waves per line, lane-chunked
 // ============================================================================================
-struct XSys {                    // per-wave view of one chunked system
+// WPL = 1: one wave per line (n = 64 M), every exchange between chunks is a wave shuffle.
+// WPL = 2, 4: a line of n = 64 WPL M points is spread over WPL waves of the workgroup (lane gl = 64 wl + lane owns rows [gl M, (gl + 1) M)):
+//   the register footprint per lane -- and with it the occupancy and the field pipelining -- stays that of the 512-point kernel for lines of
+//   1024 and 2048 points (configs[3], configs[4] of BASELINE.json), where 16 / 32 rows per lane left one wave per SIMD and no room to request
+//   the next operand ahead of the solves (2.1-2.5 TB/s).  The exchanges between chunks (stencil halos, previous chunk's last row, the
+//   log2(64 WPL) parallel-cyclic-reduction steps of the separator system, next separator) go through LDS, one workgroup barrier each, the
+//   reduction buffer double-buffered by parity.  Periodic lines only.
+template <int WPL>
+struct XCtx {
+    int lane, gl;                // lane of the wave / of the line
+    double *xb, *hb;             // WPL > 1: this line's exchange buffers in LDS, [2][64 WPL] and [6][64 WPL]
+    int par;
+};
+template <int WPL>
+__device__ __forceinline__ double xget(XCtx<WPL> &c, double v, int d) {      // v of lane gl + d (cyclic over the line)
+    constexpr int P = 64 * WPL;
+    if constexpr (WPL == 1) {
+        return shfl_d(v, (c.lane + d) & 63);
+    } else {
+        double *b = c.xb + c.par * P;
+        b[c.gl] = v;
+        __syncthreads();
+        const double r = b[(c.gl + d) & (P - 1)];
+        c.par ^= 1;
+        return r;
+    }
+}
+template <int WPL>
+__device__ __forceinline__ void xget2(XCtx<WPL> &c, double v, int d, double &lo, double &hi) {      // v of lanes gl - d and gl + d
+    constexpr int P = 64 * WPL;
+    if constexpr (WPL == 1) {
+        lo = shfl_d(v, (c.lane - d) & 63);
+        hi = shfl_d(v, (c.lane + d) & 63);
+    } else {
+        double *b = c.xb + c.par * P;
+        b[c.gl] = v;
+        __syncthreads();
+        lo = b[(c.gl - d) & (P - 1)];
+        hi = b[(c.gl + d) & (P - 1)];
+        c.par ^= 1;
+    }
+}
+// 3-point halos of the chunk from the neighbouring lanes
+template <int M, int WPL>
+__device__ __forceinline__ void xhalo(XCtx<WPL> &c, const double (&u)[M], double (&um)[3], double (&up)[3]) {
+    constexpr int P = 64 * WPL;
+    if constexpr (WPL == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            um[k] = shfl_d(u[M - 3 + k], (c.lane + 63) & 63);
+            up[k] = shfl_d(u[k], (c.lane + 1) & 63);
+        }
+    } else {
+        // the previous use of hb (the halos of the previous field / line) lies at least one solve = several barriers back
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            c.hb[k * P + c.gl] = u[M - 3 + k];
+            c.hb[(3 + k) * P + c.gl] = u[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            um[k] = c.hb[k * P + ((c.gl - 1) & (P - 1))];
+            up[k] = c.hb[(3 + k) * P + ((c.gl + 1) & (P - 1))];
+        }
+    }
+}
+
+template <int WPL>
+struct XSys {                    // per-lane view of one chunked system
+    static constexpr int STEPS = WPL == 1 ? 6 : WPL == 2 ? 7 : 8;       // log2(64 WPL) reduction steps
     const double *rowtab;        // global [5][n]
-    const double *lds;           // LV: [5][M][64] in LDS
-    double k1[6], k2[6], dinv;   // PCR coefficients of this lane
+    const double *lds;           // LV: [5][M][64 WPL] in LDS
+    double k1[STEPS], k2[STEPS], dinv;   // PCR coefficients of this lane
     double a_s, c_s;             // separator-row couplings of this lane
 };
 
-// LV = 0: every chunk has the same tables (scalar loads of chunk 0); 1: lane-variant tables [5][M][64] doubles in LDS; 2: lane-variant tables
-// kept as chunk 0's value (scalar load) + a float difference in LDS -- for M = 32 (n = 2048), where two systems of doubles (164 KB) do not fit.
+// LV = 0: every chunk has the same tables (scalar loads of chunk 0); 1: lane-variant tables [5][M][P] doubles in LDS; 2: lane-variant tables
+// kept as chunk 0's value (scalar load) + a float difference in LDS -- where two systems of doubles do not fit (n >= 1024 with both systems).
 // The reconstruction is exact when the chunks differ by less than 2^-29 relative (the 1e-13 wander of a "uniform" reference grid): the plan
-// checks every entry on the host (xline_wide_ok, capi.cpp) and takes the generic kernel otherwise.
-template <int M, int LV>
-__device__ __forceinline__ double xcoef(const XSys &y, int tab, int p, int lane, int n) {
-    if (LV == 1) return y.lds[(tab * M + p) * 64 + lane];
-    if (LV == 2) return y.rowtab[tab * n + p] + (double)reinterpret_cast<const float *>(y.lds)[(tab * M + p) * 64 + lane];
+// checks every entry on the host (xline_wide_ok, capi.cpp) and takes another kernel otherwise.
+template <int M, int LV, int WPL>
+__device__ __forceinline__ double xcoef(const XSys<WPL> &y, int tab, int p, int gl, int n) {
+    constexpr int P = 64 * WPL;
+    if (LV == 1) return y.lds[(tab * M + p) * P + gl];
+    if (LV == 2) return y.rowtab[tab * n + p] + (double)reinterpret_cast<const float *>(y.lds)[(tab * M + p) * P + gl];
     return y.rowtab[tab * n + p];  // lane-invariant: chunk 0's row p, wave-uniform address -> scalar load
 }
 
-template <int M, int LV>
-__device__ __forceinline__ void xsys_init(XSys &y, const SystemDev &sd, const double *lds, int lane, int n) {
+template <int M, int LV, int WPL>
+__device__ __forceinline__ void xsys_init(XSys<WPL> &y, const SystemDev &sd, const double *lds, int gl, int n) {
+    constexpr int P = 64 * WPL, STEPS = XSys<WPL>::STEPS;
     y.rowtab = sd.rowtab;
     y.lds = lds;
-    const int src = LV ? lane : 0;
+    const int src = LV ? gl : 0;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        y.k1[s] = sd.red[s * 64 + src];
-        y.k2[s] = sd.red[(6 + s) * 64 + src];
+    for (int s = 0; s < STEPS; ++s) {
+        y.k1[s] = sd.red[s * P + src];
+        y.k2[s] = sd.red[(STEPS + s) * P + src];
     }
-    y.dinv = sd.red[12 * 64 + src];
-    y.a_s = sd.rowtab[0 * n + (LV ? lane * M : 0)];
-    y.c_s = sd.rowtab[2 * n + (LV ? lane * M : 0)];
+    y.dinv = sd.red[2 * STEPS * P + src];
+    y.a_s = sd.rowtab[0 * n + (LV ? gl * M : 0)];
+    y.c_s = sd.rowtab[2 * n + (LV ? gl * M : 0)];
 }
 
 // f[0..M-1] (this lane's chunk of the right-hand side) -> solution, in place
-template <int M, int LV>
-__device__ __forceinline__ void xsolve(double (&f)[M], const XSys &y, int lane, int n) {
+template <int M, int LV, int WPL>
+__device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL> &y, XCtx<WPL> &c, int n) {
+    const int gl = c.gl;
     double g = 0.0;
 #pragma unroll
     for (int p = 1; p < M; ++p) {
-        g = f[p] + xcoef<M, LV>(y, 0, p, lane, n) * g;
+        g = f[p] + xcoef<M, LV, WPL>(y, 0, p, gl, n) * g;
         f[p] = g;
     }
     double yn = 0.0;
 #pragma unroll
     for (int p = M - 1; p >= 1; --p) {
-        yn = f[p] * xcoef<M, LV>(y, 1, p, lane, n) + xcoef<M, LV>(y, 2, p, lane, n) * yn;
+        yn = f[p] * xcoef<M, LV, WPL>(y, 1, p, gl, n) + xcoef<M, LV, WPL>(y, 2, p, gl, n) * yn;
         f[p] = yn;
     }
-    const double yLprev = shfl_d(f[M - 1], (lane + 63) & 63);
+    const double yLprev = xget<WPL>(c, f[M - 1], -1);
     double r = f[0] - y.a_s * yLprev - y.c_s * f[1];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int d = 1 << s;
-        const double rl = shfl_d(r, (lane - d) & 63);
-        const double rr = shfl_d(r, (lane + d) & 63);
+    for (int s = 0; s < XSys<WPL>::STEPS; ++s) {
+        double rl, rr;
+        xget2<WPL>(c, r, 1 << s, rl, rr);
         r = r - y.k1[s] * rl - y.k2[s] * rr;
     }
     const double X = r * y.dinv;
-    const double Xr = shfl_d(X, (lane + 1) & 63);
+    const double Xr = xget<WPL>(c, X, +1);
     f[0] = X;
 #pragma unroll
-    for (int p = 1; p < M; ++p) f[p] = f[p] + xcoef<M, LV>(y, 3, p, lane, n) * X + xcoef<M, LV>(y, 4, p, lane, n) * Xr;
+    for (int p = 1; p < M; ++p) f[p] = f[p] + xcoef<M, LV, WPL>(y, 3, p, gl, n) * X + xcoef<M, LV, WPL>(y, 4, p, gl, n) * Xr;
 }
 
 // f = B u for this lane's chunk; um/up are the 3-point halos from the neighbouring lanes
@@ -120,7 +192,7 @@ __device__ __forceinline__ void xstencil(double (&f)[M], const double (&u)[M], c
 #pragma unroll
     for (int p = 0; p < M; ++p) f[p] = stencil_interior<SYM>(s, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
     if (!s.periodic) {
-        // boundary closures: the six dense rows are computed wave-uniformly from broadcast values and
+        // boundary closures (one wave per line only): the six dense rows are computed wave-uniformly from broadcast values and
         // selected into the owning lane/register (rows 0..2 and n-3..n-1).
         constexpr int N = 64 * M;
         double ub[6], ut[6];
@@ -138,6 +210,21 @@ __device__ __forceinline__ void xstencil(double (&f)[M], const double (&u)[M], c
         }
     }
 }
+template <int M, bool SYM>
+__device__ __forceinline__ void xstencil_periodic(double (&f)[M], const double (&u)[M], const double (&um)[3], const double (&up)[3], const StencilDev &s) {
+    double e[M + 6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e[k] = um[k]; e[M + 3 + k] = up[k]; }
+#pragma unroll
+    for (int p = 0; p < M; ++p) e[p + 3] = u[p];
+#pragma unroll
+    for (int p = 0; p < M; ++p) f[p] = stencil_interior<SYM>(s, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+}
+template <int M, bool SYM, int WPL>
+__device__ __forceinline__ void xsten(double (&f)[M], const double (&u)[M], const double (&um)[3], const double (&up)[3], const StencilDev &s, int lane) {
+    if constexpr (WPL == 1) xstencil<M, SYM>(f, u, um, up, s, lane);
+    else xstencil_periodic<M, SYM>(f, u, um, up, s);
+}
 
 template <int M>
 __device__ __forceinline__ void xload(double (&u)[M], const double *__restrict__ p) {
@@ -154,43 +241,60 @@ __device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)
     for (int q = 0; q < M / 2; ++q) reinterpret_cast<double2 *>(p)[q] = make_double2(u[2 * q], u[2 * q + 1]);
 }
 
-template <int M, int MODE, int LV>
+template <int M, int MODE, int LV, int WPL>
 __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     extern __shared__ double xlds[];
     constexpr bool NEED1 = (MODE != MODE_P2);
     constexpr bool NEED2 = (MODE != MODE_P1);
+    constexpr int P = 64 * WPL, LPB = 4 / WPL;           // chunks per line, lines per workgroup
+    constexpr int TAB = 5 * M * P;                        // table entries per system
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int n = 64 * M;
+    const int lib = wib / WPL, wl = wib % WPL;            // line of the workgroup, wave of the line
+    const int gl = wl * 64 + lane;
+    const int n = P * M;
 
-    if (LV == 1) {  // lane-variant tables (non-periodic): stage [5][M][64] per system in LDS once per block
-        for (int idx = threadIdx.x; idx < 5 * M * 64; idx += blockDim.x) {
-            const int l = idx & 63, p = (idx >> 6) % M, tab = idx / (64 * M);
-            if (NEED1) xlds[idx] = a.y1.rowtab[tab * n + l * M + p];
-            if (NEED2) xlds[5 * M * 64 + idx] = a.y2.rowtab[tab * n + l * M + p];
+    // LDS: [system 1 tables][system 2 tables] (only those this MODE solves), then the exchange buffers of the LPB lines (WPL > 1)
+    constexpr size_t TABW = LV == 1 ? (size_t)TAB : LV == 2 ? (size_t)(TAB / 2) : 0;      // doubles per system
+    const double *lds1 = xlds, *lds2 = xlds + (NEED1 ? TABW : 0);
+    if (LV == 1) {  // lane-variant tables: stage [5][M][P] per system in LDS once per block
+        for (int idx = threadIdx.x; idx < TAB; idx += blockDim.x) {
+            const int l = idx % P, p = (idx / P) % M, tab = idx / (P * M);
+            if (NEED1) const_cast<double *>(lds1)[idx] = a.y1.rowtab[tab * n + l * M + p];
+            if (NEED2) const_cast<double *>(lds2)[idx] = a.y2.rowtab[tab * n + l * M + p];
         }
-        __syncthreads();
     }
     if (LV == 2) {  // the same as float differences from chunk 0
-        float *xf = reinterpret_cast<float *>(xlds);
-        for (int idx = threadIdx.x; idx < 5 * M * 64; idx += blockDim.x) {
-            const int l = idx & 63, p = (idx >> 6) % M, tab = idx / (64 * M);
-            if (NEED1) xf[idx] = (float)(a.y1.rowtab[tab * n + l * M + p] - a.y1.rowtab[tab * n + p]);
-            if (NEED2) xf[5 * M * 64 + idx] = (float)(a.y2.rowtab[tab * n + l * M + p] - a.y2.rowtab[tab * n + p]);
+        float *f1 = reinterpret_cast<float *>(const_cast<double *>(lds1)), *f2 = reinterpret_cast<float *>(const_cast<double *>(lds2));
+        for (int idx = threadIdx.x; idx < TAB; idx += blockDim.x) {
+            const int l = idx % P, p = (idx / P) % M, tab = idx / (P * M);
+            if (NEED1) f1[idx] = (float)(a.y1.rowtab[tab * n + l * M + p] - a.y1.rowtab[tab * n + p]);
+            if (NEED2) f2[idx] = (float)(a.y2.rowtab[tab * n + l * M + p] - a.y2.rowtab[tab * n + p]);
         }
-        __syncthreads();
     }
-    XSys y1, y2;
-    const double *lds2 = (LV == 2) ? reinterpret_cast<const double *>(reinterpret_cast<const float *>(xlds) + 5 * M * 64) : xlds + 5 * M * 64;
-    if (NEED1) xsys_init<M, LV>(y1, a.y1, xlds, lane, n);
-    if (NEED2) xsys_init<M, LV>(y2, a.y2, lds2, lane, n);
+    XCtx<WPL> cx;
+    cx.lane = lane; cx.gl = gl; cx.par = 0; cx.xb = nullptr; cx.hb = nullptr;
+    if constexpr (WPL > 1) {
+        double *ex = xlds + ((NEED1 ? TABW : 0) + (NEED2 ? TABW : 0)) + (size_t)lib * 8 * P;
+        cx.xb = ex; cx.hb = ex + 2 * P;
+    }
+    if (LV != 0 || WPL > 1) __syncthreads();
+    XSys<WPL> y1, y2;
+    if (NEED1) xsys_init<M, LV, WPL>(y1, a.y1, lds1, gl, n);
+    if (NEED2) xsys_init<M, LV, WPL>(y2, a.y2, lds2, gl, n);
 
-    const long long stride = (long long)gridDim.x * 4;
-    for (long long line = (long long)blockIdx.x * 4 + wib; line < a.nlines; line += stride) {
-        const long long off = line * n + lane * M;
+    const long long stride = (long long)gridDim.x * LPB;
+    for (long long line0 = (long long)blockIdx.x * LPB; line0 < a.nlines; line0 += stride) {
+        long long line = line0 + lib;
+        const bool live = line < a.nlines;
+        if (!live) {
+            if constexpr (WPL == 1) continue;       // independent waves
+            line = a.nlines - 1;                    // the waves of a workgroup meet at barriers: compute, do not store
+        }
+        const long long off = line * n + gl * M;
         if constexpr (LV == 2 || (LV == 1 && M >= 16)) {
-            // 32 rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x 32 of them in registers
-            // (182 spilled VGPRs); an opaque copy of the LDS pointers per line makes it re-read them where they are used
+            // many rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x M of them in registers
+            // (182 spilled VGPRs at M = 32); an opaque copy of the LDS pointers per line makes it re-read them where they are used
             if (NEED1) asm volatile("" : "+v"(y1.lds));
             if (NEED2) asm volatile("" : "+v"(y2.lds));
         }
@@ -222,22 +326,18 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 } else {
                     xload<M>(u, src + off);
                 }
-                constexpr bool PIPE = (M <= 16);     // 32 rows per lane (n = 2048): the extra line-sets would spill
+                constexpr bool PIPE = (M <= 16);     // 32 rows per lane: the extra line-sets would spill
                 double o[M];
                 if (PIPE && a.acc) xload<M>(o, dst + off);
                 have_next = PIPE && (f + 1 < a.nf) && (a.fs[f + 1] != a.in1);
                 if (have_next) xload<M>(un, a.fs[f + 1] + off);
                 double um[3], up[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    um[k] = shfl_d(u[M - 3 + k], (lane + 63) & 63);
-                    up[k] = shfl_d(u[k], (lane + 1) & 63);
-                }
+                xhalo<M, WPL>(cx, u, um, up);
                 double x1[M], x2[M];
-                xstencil<M, false>(x1, u, um, up, a.s1, lane);
-                xsolve<M, LV>(x1, y1, lane, n);
-                xstencil<M, true>(x2, u, um, up, a.s2, lane);
-                xsolve<M, LV>(x2, y2, lane, n);
+                xsten<M, false, WPL>(x1, u, um, up, a.s1, lane);
+                xsolve<M, LV, WPL>(x1, y1, cx, n);
+                xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
+                xsolve<M, LV, WPL>(x2, y2, cx, n);
 #pragma unroll
                 for (int p = 0; p < M; ++p) x2[p] = nuf * x2[p] - v[p] * x1[p];      // opr_burgers.f90:513
                 if (a.acc) {
@@ -250,14 +350,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                         double wq[M];
 #pragma unroll
                         for (int p = 0; p < M; ++p) wq[p] = x2[p] + v[p] * a.fidte;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            um[k] = shfl_d(wq[M - 3 + k], (lane + 63) & 63);
-                            up[k] = shfl_d(wq[k], (lane + 1) & 63);
-                        }
-                        xstencil<M, false>(x1, wq, um, up, a.s1, lane);
-                        xsolve<M, LV>(x1, y1, lane, n);
-                        xstore<M>(a.fdiv + off, x1);
+                        xhalo<M, WPL>(cx, wq, um, up);
+                        xsten<M, false, WPL>(x1, wq, um, up, a.s1, lane);
+                        xsolve<M, LV, WPL>(x1, y1, cx, n);
+                        if (live) xstore<M>(a.fdiv + off, x1);
                     }
                     if (a.ffin[f]) {          // the tendency of this field is complete: wall planes, Runge-Kutta update, scaling (k_final_update's arithmetic)
                         const int j = (int)(line % a.fny);
@@ -268,10 +364,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                             u[p] = u[p] + a.fdte * hv;
                             x2[p] = a.fscale ? a.fkco * hv : hv;
                         }
-                        xstore<M>(const_cast<double *>(src) + off, u);
+                        if (live) xstore<M>(const_cast<double *>(src) + off, u);
                     }
                 }
-                xstore<M>(dst + off, x2);
+                if (live) xstore<M>(dst + off, x2);
             }
         } else {
             double u[M];
@@ -293,20 +389,17 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 }
             }
             double um[3], up[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                um[k] = shfl_d(u[M - 3 + k], (lane + 63) & 63);
-                up[k] = shfl_d(u[k], (lane + 1) & 63);
-            }
+            xhalo<M, WPL>(cx, u, um, up);
             double x1[M], x2[M];
             if (NEED1) {
-                xstencil<M, false>(x1, u, um, up, a.s1, lane);
-                xsolve<M, LV>(x1, y1, lane, n);
+                xsten<M, false, WPL>(x1, u, um, up, a.s1, lane);
+                xsolve<M, LV, WPL>(x1, y1, cx, n);
             }
             if (NEED2) {
-                xstencil<M, true>(x2, u, um, up, a.s2, lane);
-                xsolve<M, LV>(x2, y2, lane, n);
+                xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
+                xsolve<M, LV, WPL>(x2, y2, cx, n);
             }
+            if (!live) continue;                     // (WPL > 1: after the last barrier of this line)
             if constexpr (MODE == MODE_P1) {
                 if (a.fq != nullptr) {          // final-update epilogue: the line is (j, k) = (line % ny, line / ny)
                     const int j = (int)(line % a.fny);
@@ -630,39 +723,55 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a,
 // ============================================================================================
 static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
 
-template <int M, int LV>
+template <int M, int LV, int WPL>
 static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
-    const long long blocks_needed = (a.nlines + 3) / 4;
+    constexpr int P = 64 * WPL, LPB = 4 / WPL;
+    const long long blocks_needed = (a.nlines + LPB - 1) / LPB;
     const int grid = imin(blocks_needed, 256 * 8);
-    const size_t lds = LV == 1 ? (size_t)2 * 5 * M * 64 * sizeof(double) : LV == 2 ? (size_t)2 * 5 * M * 64 * sizeof(float) : 0;
-    const double pts = (double)a.nlines * 64 * M;
+    if (mode < 1 || mode > 4) return hipErrorInvalidValue;
+    const int nsys = (mode == MODE_P1 || mode == MODE_P2) ? 1 : 2;       // tables of the systems this mode solves
+    const size_t tab = LV == 1 ? (size_t)5 * M * P * sizeof(double) : LV == 2 ? (size_t)5 * M * P * sizeof(float) : 0;
+    const size_t lds = nsys * tab + (WPL > 1 ? (size_t)LPB * 8 * P * sizeof(double) : 0);
+    const double pts = (double)a.nlines * P * M;
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};
-    if (mode < 1 || mode > 4) return hipErrorInvalidValue;
     double bytes = pts * (bpp[mode] + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0) + (a.fq ? 24 : 0));
     if (mode == MODE_BURGERS) {   // velocity once + per field: operand (unless it is the velocity), result, previous result when accumulating
         bytes = pts * 8;
         for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in1 ? 0 : 8) + 8 + (a.acc ? 8 : 0) + (a.ffin[f] ? 8 : 0));
         if (a.fdiv) bytes += pts * 8;       // epilogues: updated scalar, x term of the pressure forcing
     }
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     ProfScope ps(names[mode], st, bytes);
     switch (mode) {
-    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
     }
     return hipGetLastError();
 }
 
-bool xline_supported(int n) { return n == 256 || n == 512 || n == 1024; }      // n = 2048: see launch_xline / xline_wide_ok
+bool xline_supported(int n) { return n == 256 || n == 512 || n == 1024; }      // n = 2048, and n = 1024 on several waves: see xline_chunks (capi.cpp)
 
-hipError_t launch_xline(int mode, int n, bool lane_variant, const XLineArgs &a, hipStream_t st) {
+// chunks = 64: one wave per line (n = 64 M); 128 / 256: two / four waves per line with 8 rows per lane (periodic lines of 1024 / 2048 points
+// whose tables pass xline_wide_ok; float-difference tables when they are lane-variant)
+hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XLineArgs &a, hipStream_t st) {
+    if (chunks == 128 && n == 1024) return lane_variant ? launch_xline_m<8, 2, 2>(mode, a, st) : launch_xline_m<8, 0, 2>(mode, a, st);
+    if (chunks == 256 && n == 2048) return lane_variant ? launch_xline_m<8, 2, 4>(mode, a, st) : launch_xline_m<8, 0, 4>(mode, a, st);
+    if (chunks != 64) return hipErrorInvalidValue;
     switch (n) {
-    case 256: return lane_variant ? launch_xline_m<4, 1>(mode, a, st) : launch_xline_m<4, 0>(mode, a, st);
-    case 512: return lane_variant ? launch_xline_m<8, 1>(mode, a, st) : launch_xline_m<8, 0>(mode, a, st);
-    case 1024: return lane_variant ? launch_xline_m<16, 1>(mode, a, st) : launch_xline_m<16, 0>(mode, a, st);
-    case 2048: return lane_variant ? launch_xline_m<32, 2>(mode, a, st) : launch_xline_m<32, 0>(mode, a, st);     // the caller checked xline_wide_ok
+    case 256: return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);
+    case 512: return lane_variant ? launch_xline_m<8, 1, 1>(mode, a, st) : launch_xline_m<8, 0, 1>(mode, a, st);
+    case 1024: return lane_variant ? launch_xline_m<16, 1, 1>(mode, a, st) : launch_xline_m<16, 0, 1>(mode, a, st);
+    case 2048: return lane_variant ? launch_xline_m<32, 2, 1>(mode, a, st) : launch_xline_m<32, 0, 1>(mode, a, st);     // the caller checked xline_wide_ok
     }
     return hipErrorInvalidValue;
 }

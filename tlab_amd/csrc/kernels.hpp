@@ -78,7 +78,7 @@ struct GenericArgs {        // k_generic: any n
 bool xline_supported(int n);
 int rtile_chunk(int n);
 void rtile_force_chunk(int m);
-hipError_t launch_xline(int mode, int n, bool lane_variant, const XLineArgs &a, hipStream_t st);
+hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XLineArgs &a, hipStream_t st);
 hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st);
 int htile_chunk(int n, int mode);
 void htile_set_lines(int lines);   // tuning: 16 = narrow Burgers tiles (two workgroups per CU)
