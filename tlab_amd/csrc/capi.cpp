@@ -252,17 +252,20 @@ SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
         for (int j = 1; j < P && inv; ++j)
             for (int p = 0; p < m; ++p)
                 if (!close(rowtab[(size_t)tab * n + j * m + p], rowtab[(size_t)tab * n + p])) { inv = false; break; }
-    if (P == 64 || P == 128 || P == 256) {      // wave-per-line kernels: parallel cyclic reduction over the 64 lanes of 1, 2 or 4 waves
-        const int steps = h.pcr_steps;
-        if ((1 << steps) != P) throw std::runtime_error("internal: PCR schedule missing");
-        std::vector<double> red((size_t)(2 * steps + 1) * P);
+    if (P == 64) {      // wave-per-line kernel: parallel cyclic reduction over the 64 lanes
+        if (h.pcr_steps != 6) throw std::runtime_error("internal: PCR schedule missing");
+        std::vector<double> red((size_t)13 * 64);
         std::copy(h.pcr_k1.begin(), h.pcr_k1.end(), red.begin());
-        std::copy(h.pcr_k2.begin(), h.pcr_k2.end(), red.begin() + (size_t)steps * P);
-        std::copy(h.pcr_dinv.begin(), h.pcr_dinv.end(), red.begin() + (size_t)2 * steps * P);
-        for (int q = 0; q < 2 * steps + 1 && inv; ++q)
-            for (int j = 1; j < P; ++j)
-                if (!close(red[(size_t)q * P + j], red[(size_t)q * P])) { inv = false; break; }
+        std::copy(h.pcr_k2.begin(), h.pcr_k2.end(), red.begin() + 6 * 64);
+        std::copy(h.pcr_dinv.begin(), h.pcr_dinv.end(), red.begin() + 12 * 64);
+        for (int q = 0; q < 13 && inv; ++q)
+            for (int j = 1; j < 64; ++j)
+                if (!close(red[(size_t)q * 64 + j], red[(size_t)q * 64])) { inv = false; break; }
         e->red.upload(red);
+    } else if (P == 128 || P == 256) {      // several waves per line: two-level reduction tables [21][P] (chunked.hpp); per-lane by construction
+        if (h.tl_waves * 64 != P) throw std::runtime_error("two-level separator tables unavailable for this system");
+        inv = false;
+        e->red.upload(h.tl);
     } else {
         e->red.upload(h.ginv);
     }
@@ -495,7 +498,9 @@ bool xline_wide_ok(tlab_fdm_plan_t g, int P) {
     if (cache >= 0) return cache != 0;
     bool ok = true;
     for (int which = 1; which <= 2 && ok; ++which) {
-        const SystemEntry &e = g->system(which, 0, P);
+        const SystemEntry *ep = nullptr;
+        try { ep = &g->system(which, 0, P); } catch (const std::exception &) { ok = false; break; }      // e.g. no two-level tables
+        const SystemEntry &e = *ep;
         if (e.lane_invariant) continue;
         const ChunkedTables &h = e.host;
         const int m = h.m;

@@ -156,6 +156,88 @@ void build_chunked(const TriDiag &T, int P, ChunkedTables &t) {
             t.pcr_dinv[j] = (double)(1 / A[(size_t)j * P + j]);
         }
     }
+    // (3) two-level reduction for W = P / 64 waves (see chunked.hpp)
+    t.tl_waves = 0;
+    t.tl.clear();
+    if (P > 64 && P % 64 == 0) {
+        const int W = P / 64, B = 64;
+        std::vector<double> tl((size_t)21 * P, 0.0);
+        std::vector<ld> vs((size_t)P), ws((size_t)P);
+        bool ok = true;
+        for (int w = 0; w < W && ok; ++w) {
+            const int j0 = w * B;
+            // PCR schedule of the isolated block (no wrap-around: out-of-range neighbours carry zero coefficients)
+            std::vector<ld> A((size_t)B * B, 0), Bm((size_t)B * B);
+            for (int l = 0; l < B; ++l) {
+                A[(size_t)l * B + l] = be[j0 + l];
+                if (l > 0) A[(size_t)l * B + l - 1] = al[j0 + l];
+                if (l < B - 1) A[(size_t)l * B + l + 1] = ga[j0 + l];
+            }
+            for (int s = 0; s < 6; ++s) {
+                const int dd = 1 << s;
+                for (int l = 0; l < B; ++l) {
+                    const int jl = l - dd, jr = l + dd;
+                    const bool hasl = jl >= 0, hasr = jr < B;
+                    ld k1 = 0, k2 = 0;
+                    if (hasl) k1 = A[(size_t)l * B + jl] / A[(size_t)jl * B + jl];
+                    if (hasr) k2 = A[(size_t)l * B + jr] / A[(size_t)jr * B + jr];
+                    for (int q = 0; q < B; ++q) {
+                        ld val = A[(size_t)l * B + q];
+                        if (hasl) val -= k1 * A[(size_t)jl * B + q];
+                        if (hasr) val -= k2 * A[(size_t)jr * B + q];
+                        Bm[(size_t)l * B + q] = val;
+                    }
+                    if (hasl) Bm[(size_t)l * B + jl] = 0;
+                    if (hasr) Bm[(size_t)l * B + jr] = 0;
+                    tl[(size_t)s * P + j0 + l] = (double)k1;
+                    tl[(size_t)(6 + s) * P + j0 + l] = (double)k2;
+                }
+                A.swap(Bm);
+            }
+            for (int l = 0; l < B; ++l) {
+                ld off = 0;
+                for (int q = 0; q < B; ++q)
+                    if (q != l) off = std::fmax(off, fabsl(A[(size_t)l * B + q]));
+                if (off > 1e-13L * fabsl(A[(size_t)l * B + l])) ok = false;
+                tl[(size_t)12 * P + j0 + l] = (double)(1 / A[(size_t)l * B + l]);
+            }
+            // spikes of the block: S_w^{-1} e_first al_first, S_w^{-1} e_last ga_last (Thomas, long double)
+            std::vector<ld> dd(B), r1(B, 0), r2(B, 0);
+            r1[0] = al[j0]; r2[B - 1] = ga[j0 + B - 1];
+            dd[0] = be[j0];
+            for (int l = 1; l < B; ++l) {
+                const ld m2 = al[j0 + l] / dd[l - 1];
+                dd[l] = be[j0 + l] - m2 * ga[j0 + l - 1];
+                r1[l] -= m2 * r1[l - 1]; r2[l] -= m2 * r2[l - 1];
+            }
+            r1[B - 1] /= dd[B - 1]; r2[B - 1] /= dd[B - 1];
+            for (int l = B - 2; l >= 0; --l) {
+                r1[l] = (r1[l] - ga[j0 + l] * r1[l + 1]) / dd[l];
+                r2[l] = (r2[l] - ga[j0 + l] * r2[l + 1]) / dd[l];
+            }
+            for (int l = 0; l < B; ++l) { vs[j0 + l] = r1[l]; ws[j0 + l] = r2[l]; }
+            if (fabsl(r1[B - 1]) > 1e-30L || fabsl(r2[0]) > 1e-30L) ok = false;      // coupling across a whole block must vanish
+        }
+        if (ok) {
+            for (int w = 0; w < W; ++w) {
+                const int j0 = w * B, wn = (w + 1) % W, wp = (w + W - 1) % W;
+                const ld wL = ws[j0 + B - 1], vF = vs[(size_t)wn * B], wLp = ws[(size_t)wp * B + B - 1], vFm = vs[j0];
+                for (int l = 0; l < B; ++l) {
+                    const int j = j0 + l;
+                    tl[(size_t)13 * P + j] = (double)vs[j];
+                    tl[(size_t)14 * P + j] = (double)ws[j];
+                    tl[(size_t)15 * P + j] = (double)wL;
+                    tl[(size_t)16 * P + j] = (double)vF;
+                    tl[(size_t)17 * P + j] = (double)(1 / (1 - wL * vF));
+                    tl[(size_t)18 * P + j] = (double)wLp;
+                    tl[(size_t)19 * P + j] = (double)vFm;
+                    tl[(size_t)20 * P + j] = (double)(1 / (1 - wLp * vFm));
+                }
+            }
+            t.tl.swap(tl);
+            t.tl_waves = W;
+        }
+    }
 }
 
 void chunked_solve_host(const ChunkedTables &t, double *f, bool use_pcr) {
@@ -174,7 +256,28 @@ void chunked_solve_host(const ChunkedTables &t, double *f, bool use_pcr) {
         double yL = y[jm * m + m - 1];  // multiplied by a_s = 0 when there is no left neighbour
         r[j] = f[s] - t.Lm[s] * yL - t.Cm[s] * y[s + 1];
     }
-    if (use_pcr) {
+    if (use_pcr && t.tl_waves > 0) {        // the two-level reduction exactly as k_xline does it on several waves per line
+        const int W = t.tl_waves, B = 64;
+        auto TL = [&](int q, int j) { return t.tl[(size_t)q * P + j]; };
+        std::vector<double> Y(r), Y2(P);
+        for (int s = 0; s < 6; ++s) {
+            const int dd = 1 << s;
+            for (int j = 0; j < P; ++j) {
+                const int w = j / B, l = j % B;
+                const double rl = Y[w * B + ((l - dd) & (B - 1))], rr = Y[w * B + ((l + dd) & (B - 1))];      // wrap inside the wave: zero coefficients there
+                Y2[j] = Y[j] - TL(s, j) * rl - TL(6 + s, j) * rr;
+            }
+            Y.swap(Y2);
+        }
+        for (int j = 0; j < P; ++j) Y[j] = Y[j] * TL(12, j);
+        for (int j = 0; j < P; ++j) {
+            const int w = j / B, wn = (w + 1) % W, wp = (w + W - 1) % W;
+            const double myF = Y[w * B], myL = Y[w * B + B - 1], YpL = Y[wp * B + B - 1], YnF = Y[wn * B];
+            const double XL = (myL - TL(15, j) * YnF) * TL(17, j), XnF = YnF - TL(16, j) * XL;
+            const double XpL = (YpL - TL(18, j) * myF) * TL(20, j);
+            X[j] = Y[j] - TL(13, j) * XpL - TL(14, j) * XnF;
+        }
+    } else if (use_pcr) {
         if (t.pcr_steps == 0 && P > 1) throw std::runtime_error("chunked: no PCR tables");
         std::vector<double> r2(P);
         for (int s = 0; s < t.pcr_steps; ++s) {

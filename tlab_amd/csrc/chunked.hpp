@@ -35,13 +35,20 @@ struct ChunkedTables {
     std::vector<double> pcr_k1, pcr_k2;          // (nsteps*P): r_j -= k1*r_{j-d} + k2*r_{j+d}, d = 2^s (filled when P is a power of 2)
     std::vector<double> pcr_dinv;                // (P)
     int pcr_steps = 0;
+    // Two-level reduction for P = 64 W chunks handled by W waves of 64 lanes (k_xline on several waves per line): every wave reduces the
+    // isolated 64 x 64 block of its own separator unknowns with wave shuffles (PCR schedule of that block), the blocks are coupled through
+    // one value at each end (the coupling across a whole block is ~(4e-4)^63: zero), and the block spikes correct the lanes next to the ends.
+    //   tl[q][P], q = 0-5 k1, 6-11 k2, 12 dinv, 13 vs, 14 ws (x = y - vs X_prev_last - ws X_next_first),
+    //   15 wL = ws[63] of the lane's wave, 16 vF = vs[0] of the next wave, 17 1/(1 - wL vF), 18-20 the same for the interface with the previous wave.
+    std::vector<double> tl;
+    int tl_waves = 0;                            // 0: not available (P not a multiple of 64 > 64, or the neglected couplings are not negligible)
 };
 
 // Builds the tables; throws std::runtime_error if n is not divisible by P, m < 2, or a pivot vanishes.
 void build_chunked(const TriDiag &T, int P, ChunkedTables &out);
 
 // Scalar emulation of the device algorithm (debug/tests only): f (n) in, x out.  use_pcr selects the PCR path.
-void chunked_solve_host(const ChunkedTables &t, double *f, bool use_pcr);
+void chunked_solve_host(const ChunkedTables &t, double *f, bool use_pcr);      // P = 128, 256 with use_pcr: the two-level reduction (tl) when available
 
 // Reference direct solve (Gaussian elimination on the cyclic tridiagonal, long double) for self-checks.
 void tridiag_solve_direct(const TriDiag &T, double *f);

@@ -46,79 +46,69 @@ __device__ __forceinline__ double dense6(const double (&c)[6], double a0, double
 // ============================================================================================
 // WPL = 1: one wave per line (n = 64 M), every exchange between chunks is a wave shuffle.
 // WPL = 2, 4: a line of n = 64 WPL M points is spread over WPL waves of the workgroup (lane gl = 64 wl + lane owns rows [gl M, (gl + 1) M)):
-//   the register footprint per lane -- and with it the occupancy and the field pipelining -- stays that of the 512-point kernel for lines of
-//   1024 and 2048 points (configs[3], configs[4] of BASELINE.json), where 16 / 32 rows per lane left one wave per SIMD and no room to request
-//   the next operand ahead of the solves (2.1-2.5 TB/s).  The exchanges between chunks (stencil halos, previous chunk's last row, the
-//   log2(64 WPL) parallel-cyclic-reduction steps of the separator system, next separator) go through LDS, one workgroup barrier each, the
-//   reduction buffer double-buffered by parity.  Periodic lines only.
+//   the register footprint per lane -- and with it the field pipelining -- stays that of the 512-point kernel for lines of 1024 and 2048
+//   points (configs[3], configs[4] of BASELINE.json), where 16 / 32 rows per lane left no room to request the next operand ahead of the solves.
+//   Inside a wave everything stays a shuffle; what crosses a wave boundary goes through LDS with one workgroup barrier: the stencil halos of
+//   the two edge lanes, the previous chunk's last row for lane 0, and ONE value from each end of the wave's block of separator unknowns --
+//   the separator system is reduced in two levels (chunked.hpp: PCR of the isolated 64 x 64 block by shuffles, 2 x 2 interface systems,
+//   spike correction of the lanes next to the block ends).  Five barriers per transported field instead of one per reduction step.
+//   Periodic lines only.
 template <int WPL>
 struct XCtx {
-    int lane, gl;                // lane of the wave / of the line
-    double *xb, *hb;             // WPL > 1: this line's exchange buffers in LDS, [2][64 WPL] and [6][64 WPL]
+    int lane, gl, wl;            // lane of the wave / of the line, wave of the line
+    double *eb, *hb;             // WPL > 1: this line's exchange buffers in LDS, eb[2][WPL][4] (parity-double-buffered) and hb[WPL][6]
     int par;
 };
+// v of the previous lane of the line (cyclic)
 template <int WPL>
-__device__ __forceinline__ double xget(XCtx<WPL> &c, double v, int d) {      // v of lane gl + d (cyclic over the line)
-    constexpr int P = 64 * WPL;
-    if constexpr (WPL == 1) {
-        return shfl_d(v, (c.lane + d) & 63);
-    } else {
-        double *b = c.xb + c.par * P;
-        b[c.gl] = v;
+__device__ __forceinline__ double xprev(XCtx<WPL> &c, double v) {
+    double r = shfl_d(v, (c.lane + 63) & 63);
+    if constexpr (WPL > 1) {
+        double *b = c.eb + c.par * (WPL * 4);
+        if (c.lane == 63) b[c.wl * 4 + 0] = v;
         __syncthreads();
-        const double r = b[(c.gl + d) & (P - 1)];
-        c.par ^= 1;
-        return r;
-    }
-}
-template <int WPL>
-__device__ __forceinline__ void xget2(XCtx<WPL> &c, double v, int d, double &lo, double &hi) {      // v of lanes gl - d and gl + d
-    constexpr int P = 64 * WPL;
-    if constexpr (WPL == 1) {
-        lo = shfl_d(v, (c.lane - d) & 63);
-        hi = shfl_d(v, (c.lane + d) & 63);
-    } else {
-        double *b = c.xb + c.par * P;
-        b[c.gl] = v;
-        __syncthreads();
-        lo = b[(c.gl - d) & (P - 1)];
-        hi = b[(c.gl + d) & (P - 1)];
+        if (c.lane == 0) r = b[((c.wl + WPL - 1) & (WPL - 1)) * 4 + 0];
         c.par ^= 1;
     }
+    return r;
 }
 // 3-point halos of the chunk from the neighbouring lanes
 template <int M, int WPL>
 __device__ __forceinline__ void xhalo(XCtx<WPL> &c, const double (&u)[M], double (&um)[3], double (&up)[3]) {
-    constexpr int P = 64 * WPL;
-    if constexpr (WPL == 1) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            um[k] = shfl_d(u[M - 3 + k], (c.lane + 63) & 63);
-            up[k] = shfl_d(u[k], (c.lane + 1) & 63);
+    for (int k = 0; k < 3; ++k) {
+        um[k] = shfl_d(u[M - 3 + k], (c.lane + 63) & 63);
+        up[k] = shfl_d(u[k], (c.lane + 1) & 63);
+    }
+    if constexpr (WPL > 1) {
+        // the previous use of hb (the halos of the previous field / line) lies at least one solve = two barriers back
+        if (c.lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c.hb[c.wl * 6 + k] = u[M - 3 + k];
         }
-    } else {
-        // the previous use of hb (the halos of the previous field / line) lies at least one solve = several barriers back
+        if (c.lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            c.hb[k * P + c.gl] = u[M - 3 + k];
-            c.hb[(3 + k) * P + c.gl] = u[k];
+            for (int k = 0; k < 3; ++k) c.hb[c.wl * 6 + 3 + k] = u[k];
         }
         __syncthreads();
+        if (c.lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            um[k] = c.hb[k * P + ((c.gl - 1) & (P - 1))];
-            up[k] = c.hb[(3 + k) * P + ((c.gl + 1) & (P - 1))];
+            for (int k = 0; k < 3; ++k) um[k] = c.hb[((c.wl + WPL - 1) & (WPL - 1)) * 6 + k];
+        }
+        if (c.lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) up[k] = c.hb[((c.wl + 1) & (WPL - 1)) * 6 + 3 + k];
         }
     }
 }
 
 template <int WPL>
 struct XSys {                    // per-lane view of one chunked system
-    static constexpr int STEPS = WPL == 1 ? 6 : WPL == 2 ? 7 : 8;       // log2(64 WPL) reduction steps
     const double *rowtab;        // global [5][n]
     const double *lds;           // LV: [5][M][64 WPL] in LDS
-    double k1[STEPS], k2[STEPS], dinv;   // PCR coefficients of this lane
+    double k1[6], k2[6], dinv;   // PCR coefficients of this lane (WPL = 1: cyclic over the 64 chunks; WPL > 1: of the wave's isolated block)
     double a_s, c_s;             // separator-row couplings of this lane
+    double vs, ws, wL, vF, dn, wLp, vFm, dp;      // WPL > 1: two-level reduction (chunked.hpp)
 };
 
 // LV = 0: every chunk has the same tables (scalar loads of chunk 0); 1: lane-variant tables [5][M][P] doubles in LDS; 2: lane-variant tables
@@ -135,16 +125,21 @@ __device__ __forceinline__ double xcoef(const XSys<WPL> &y, int tab, int p, int 
 
 template <int M, int LV, int WPL>
 __device__ __forceinline__ void xsys_init(XSys<WPL> &y, const SystemDev &sd, const double *lds, int gl, int n) {
-    constexpr int P = 64 * WPL, STEPS = XSys<WPL>::STEPS;
+    constexpr int P = 64 * WPL;
     y.rowtab = sd.rowtab;
     y.lds = lds;
-    const int src = LV ? gl : 0;
+    const int src = (LV || WPL > 1) ? gl : 0;
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
+    for (int s = 0; s < 6; ++s) {
         y.k1[s] = sd.red[s * P + src];
-        y.k2[s] = sd.red[(STEPS + s) * P + src];
+        y.k2[s] = sd.red[(6 + s) * P + src];
     }
-    y.dinv = sd.red[2 * STEPS * P + src];
+    y.dinv = sd.red[12 * P + src];
+    if constexpr (WPL > 1) {
+        y.vs = sd.red[13 * P + src]; y.ws = sd.red[14 * P + src];
+        y.wL = sd.red[15 * P + src]; y.vF = sd.red[16 * P + src]; y.dn = sd.red[17 * P + src];
+        y.wLp = sd.red[18 * P + src]; y.vFm = sd.red[19 * P + src]; y.dp = sd.red[20 * P + src];
+    }
     y.a_s = sd.rowtab[0 * n + (LV ? gl * M : 0)];
     y.c_s = sd.rowtab[2 * n + (LV ? gl * M : 0)];
 }
@@ -152,7 +147,7 @@ __device__ __forceinline__ void xsys_init(XSys<WPL> &y, const SystemDev &sd, con
 // f[0..M-1] (this lane's chunk of the right-hand side) -> solution, in place
 template <int M, int LV, int WPL>
 __device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL> &y, XCtx<WPL> &c, int n) {
-    const int gl = c.gl;
+    const int gl = c.gl, lane = c.lane;
     double g = 0.0;
 #pragma unroll
     for (int p = 1; p < M; ++p) {
@@ -165,16 +160,33 @@ __device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL> &y, XCtx<
         yn = f[p] * xcoef<M, LV, WPL>(y, 1, p, gl, n) + xcoef<M, LV, WPL>(y, 2, p, gl, n) * yn;
         f[p] = yn;
     }
-    const double yLprev = xget<WPL>(c, f[M - 1], -1);
+    const double yLprev = xprev<WPL>(c, f[M - 1]);
     double r = f[0] - y.a_s * yLprev - y.c_s * f[1];
 #pragma unroll
-    for (int s = 0; s < XSys<WPL>::STEPS; ++s) {
-        double rl, rr;
-        xget2<WPL>(c, r, 1 << s, rl, rr);
-        r = r - y.k1[s] * rl - y.k2[s] * rr;
+    for (int s = 0; s < 6; ++s) {
+        const int d = 1 << s;
+        const double rl = shfl_d(r, (lane - d) & 63);
+        const double rr = shfl_d(r, (lane + d) & 63);
+        r = r - y.k1[s] * rl - y.k2[s] * rr;       // WPL > 1: the coefficients of neighbours outside the wave's block are zero
     }
-    const double X = r * y.dinv;
-    const double Xr = xget<WPL>(c, X, +1);
+    double X = r * y.dinv, Xr;
+    if constexpr (WPL == 1) {
+        Xr = shfl_d(X, (lane + 1) & 63);
+    } else {
+        double *b = c.eb + c.par * (WPL * 4);
+        if (lane == 0) b[c.wl * 4 + 1] = X;
+        if (lane == 63) b[c.wl * 4 + 2] = X;
+        __syncthreads();
+        const double YpL = b[((c.wl + WPL - 1) & (WPL - 1)) * 4 + 2], YnF = b[((c.wl + 1) & (WPL - 1)) * 4 + 1];
+        const double myF = b[c.wl * 4 + 1], myL = b[c.wl * 4 + 2];
+        c.par ^= 1;
+        const double XL = (myL - y.wL * YnF) * y.dn;          // last unknown of this wave and first one of the next: 2 x 2 interface system
+        const double XnF = YnF - y.vF * XL;
+        const double XpL = (YpL - y.wLp * myF) * y.dp;        // last unknown of the previous wave (its interface with this one)
+        X = X - y.vs * XpL - y.ws * XnF;
+        Xr = shfl_d(X, (lane + 1) & 63);
+        if (lane == 63) Xr = XnF;
+    }
     f[0] = X;
 #pragma unroll
     for (int p = 1; p < M; ++p) f[p] = f[p] + xcoef<M, LV, WPL>(y, 3, p, gl, n) * X + xcoef<M, LV, WPL>(y, 4, p, gl, n) * Xr;
@@ -273,10 +285,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
         }
     }
     XCtx<WPL> cx;
-    cx.lane = lane; cx.gl = gl; cx.par = 0; cx.xb = nullptr; cx.hb = nullptr;
+    cx.lane = lane; cx.gl = gl; cx.wl = wl; cx.par = 0; cx.eb = nullptr; cx.hb = nullptr;
     if constexpr (WPL > 1) {
-        double *ex = xlds + ((NEED1 ? TABW : 0) + (NEED2 ? TABW : 0)) + (size_t)lib * 8 * P;
-        cx.xb = ex; cx.hb = ex + 2 * P;
+        double *ex = xlds + ((NEED1 ? TABW : 0) + (NEED2 ? TABW : 0)) + (size_t)lib * (14 * WPL);
+        cx.eb = ex; cx.hb = ex + 8 * WPL;
     }
     if (LV != 0 || WPL > 1) __syncthreads();
     XSys<WPL> y1, y2;
@@ -731,7 +743,7 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
     const int nsys = (mode == MODE_P1 || mode == MODE_P2) ? 1 : 2;       // tables of the systems this mode solves
     const size_t tab = LV == 1 ? (size_t)5 * M * P * sizeof(double) : LV == 2 ? (size_t)5 * M * P * sizeof(float) : 0;
-    const size_t lds = nsys * tab + (WPL > 1 ? (size_t)LPB * 8 * P * sizeof(double) : 0);
+    const size_t lds = nsys * tab + (WPL > 1 ? (size_t)LPB * 14 * WPL * sizeof(double) : 0);
     const double pts = (double)a.nlines * P * M;
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};

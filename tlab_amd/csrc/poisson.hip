@@ -574,6 +574,7 @@ struct OdeArgs {
     const double *chk1, *chk2;   // [C][6][nm] PENTADFS state before the first row of each chunk
     const double *cst;           // [9][nm] LU of the constraint matrix (k_nn_constants)
     const double *hom;           // [5][n][nm] homogeneous solutions v1, em, u1, sp, ep (build_homogeneous)
+    const int *band;             // [2][nm] (may be NULL): rows (jb, jt) exclusive where all five homogeneous solutions of the mode are negligible
     int pair_xcd;                // see k_ode_nn
     const double *f_hat;
     double *p_hat, *dp_hat;
@@ -796,6 +797,29 @@ __device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[2][2], i
         in[l][1] = first_in_wave ? pe[l][1] : g2;
     }
     __syncthreads();      // s_w is reused by the next scan
+}
+
+// Per mode: the rows between which all five homogeneous solutions are below 1e-40 of their own maximum, found from the middle of the line
+// outwards (band[t] = last significant row of the lower half, band[nm + t] = first one of the upper half).  hom: [5][n][nm].
+__global__ void __launch_bounds__(256) k_ode_hom_band(const double *__restrict__ hom, int n, long long nm, int *__restrict__ band) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nm) return;
+    double thr[5];
+    for (int a = 0; a < 5; ++a) {
+        double mx = 0.0;
+        for (int j = 0; j < n; ++j) mx = fmax(mx, fabs(hom[((size_t)a * n + j) * nm + t]));
+        thr[a] = mx * 1.0e-40;
+    }
+    const int mid = n / 2;
+    int jb = -1, jt = n;
+    for (int j = 0; j < n; ++j) {
+        bool sig = false;
+        for (int a = 0; a < 5; ++a) sig = sig || !(fabs(hom[((size_t)a * n + j) * nm + t]) <= thr[a]);      // NaN counts as significant
+        if (sig && j < mid) jb = j;
+        if (sig && j >= mid && j < jt) jt = j;
+    }
+    band[t] = jb;
+    band[nm + t] = jt;
 }
 
 // src[a][j][nm] -> dst[blk][a][j][NM]
@@ -1069,11 +1093,17 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     }
     // ---- superposition with the stored homogeneous solutions (opr_odes.f90:358-367); p^ = u, dp^/dy = v ----
     if (!store) return;
+    // The homogeneous solutions decay like exp(-sqrt(lambda) distance from their wall): for all but the lowest modes they are below 1e-40 of
+    // their maximum a few tens of rows away from the walls, where adding them changes no bit of the sum.  The plan records that band per
+    // mode (k_ode_hom_band); chunks inside it skip the five loads (40 of the 100 B per mode and row this kernel would otherwise move).
+    bool need = true;
+    if (a.band != nullptr) need = (j0 <= a.band[t]) || (j0 + OM - 1 >= a.band[nm + t]);
 #pragma unroll
     for (int p = 0; p < OM; ++p) {
         const int j = j0 + p;
         const unsigned h = (unsigned)(((t / NM) * 5 * n + j) * NM + m), hs = (unsigned)(n * NM);       // hom_blocked[blk][5][n][NM]
-        const double hv1 = a.hom[h], hem = a.hom[h + hs], hu1 = a.hom[h + 2 * hs], hsp = a.hom[h + 3 * hs], hep = a.hom[h + 4 * hs];
+        double hv1 = 0.0, hem = 0.0, hu1 = 0.0, hsp = 0.0, hep = 0.0;
+        if (need) { hv1 = a.hom[h]; hem = a.hom[h + hs]; hu1 = a.hom[h + 2 * hs]; hsp = a.hom[h + 3 * hs]; hep = a.hom[h + 4 * hs]; }
         double uu[2], vv[2];
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
@@ -1513,6 +1543,7 @@ struct tlab_poisson_plan {
     std::unique_ptr<tlab_poisson_plan> low;
     DBuf fac[2];                      // sub-plan only: stored LU factors of its two systems (Int1Args::fac)
     int *d_low_modes = nullptr;
+    int *d_hom_band = nullptr;                  // [2][nm] rows between which the homogeneous solutions of a mode are negligible (k_ode_hom_band)
     int n_low = 0;
     DBuf low_f, low_p, low_dp;
     std::vector<int> sing_modes;      // flat mode indices t = kx + nxh*kz of the singular modes
@@ -1562,6 +1593,7 @@ struct tlab_poisson_plan {
         if (d_sing) (void)hipFree(d_sing);
         if (d_skip) (void)hipFree(d_skip);
         if (d_low_modes) (void)hipFree(d_low_modes);
+        if (d_hom_band) (void)hipFree(d_hom_band);
         if (side) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -1637,7 +1669,7 @@ void launch_ode_nm(const OdeArgs &a, size_t lds, hipStream_t st) {
 void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
     OdeArgs a{};
     a.T1 = P.sys(0); a.T2 = P.sys(1);
-    a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = P.cst.p; a.hom = P.homb.p;
+    a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = P.cst.p; a.hom = P.homb.p; a.band = P.d_hom_band;
     a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
     a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.nm = P.nm;
     const int NM = P.ode_nm_per_wg;
@@ -1647,7 +1679,7 @@ void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_h
         a.pair_xcd = pair;
     }
     const size_t lds = ode_lds_bytes(a.C, NM);
-    ProfScope ps("k_ode_nn", st, (double)P.nm * P.ny * (48.0 + 40.0 + 12.0));      // f^, p^, dp^ + homogeneous solutions + checkpoints
+    ProfScope ps("k_ode_nn", st, (double)P.nm * P.ny * 48.0);      // algorithmic bytes: f^ in, p^ and dp^/dy out (its own tables -- checkpoints 12 B, the band of the homogeneous solutions -- come on top)
     switch (NM) {
     case 4: launch_ode_nm<4>(a, lds, st); break;
     case 8: launch_ode_nm<8>(a, lds, st); break;
@@ -1677,6 +1709,12 @@ void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
     const long long tot = (long long)5 * P.ny * P.nm;
     hipLaunchKernelGGL(k_ode_block_layout, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.hom.p, P.homb.p, 5, P.ny, P.nm, NM);
     hipc(hipGetLastError(), "k_ode_block_layout");
+    static const bool band_on = [] { const char *e = getenv("TLAB_ODE_HOM_BAND"); return !(e && atoi(e) == 0); }();
+    if (band_on) {
+        hipc(hipMalloc((void **)&P.d_hom_band, (size_t)2 * P.nm * sizeof(int)), "hipMalloc");
+        hipLaunchKernelGGL(k_ode_hom_band, dim3(grid), dim3(256), 0, st, P.hom.p, P.ny, P.nm, P.d_hom_band);
+        hipc(hipGetLastError(), "k_ode_hom_band");
+    }
 }
 
 // v1, u1, du1 of the singular modes depend on the mode only (opr_odes.f90:64-73): once per plan
