@@ -67,3 +67,31 @@ def test_live_against_reference_build(tmp_path):
         assert np.array_equal(yr, y) and sc[2] == z[-1] - z[0]
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.gpu
+def test_device_driver_round_trip_through_reference_written_files(tmp_path):
+    """n4 on the device path: Dns.load_fields reads the restart files the reference's IO_Write_Fields wrote (tests/golden/io_*) into HBM, a
+    Runge-Kutta step runs on them, Dns.save_fields writes files the reference's tools read back; an untouched load -> save round trip is
+    byte-identical to the reference's files (the Fortran host takes the same route through IO_Fields_AMD, tests/test_gpu_fortran_dropin.py)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    from tlab_amd.dns import Dns
+    T.init(0)
+    x, y, z, f = inputs()
+    xr, yr, zr, _ = tio.grid_read(os.path.join(G, "io_grid"), (NX, NY, NZ))
+    d = Dns(xr, yr, zr, nscal=1, visc=2.0e-4, schmidt=(1.0,), yuniform=False)
+    nt, params = d.load_fields(os.path.join(G, "io_flow"), os.path.join(G, "io_scal"))
+    assert nt == 1234
+    for t, a in zip(d.q + d.s, f):
+        assert np.array_equal(t.cpu().numpy(), a)
+    d.save_fields(str(tmp_path / "flow"), None, nt=1234, params=[0.5, 2.0e-4, 3.0, 1.0])
+    d.save_fields(None, str(tmp_path / "scal"), nt=1234, params=[])
+    for name, ref in (("flow.1", "io_flow.1"), ("flow.2", "io_flow.2"), ("flow.3", "io_flow.3"), ("scal.1", "io_scal.1")):
+        assert open(tmp_path / name, "rb").read() == open(os.path.join(G, ref), "rb").read(), name
+    d.TIME_RUNGEKUTTA(1e-4)                      # the loaded state is a usable state
+    d.save_fields(str(tmp_path / "flow2"), str(tmp_path / "scal2"), nt=1235, params=[0.5001, 2.0e-4])
+    back, nt2, p2 = tio.io_read_fields(str(tmp_path / "flow2"), NX, NY, NZ, 3)
+    assert nt2 == 1235 and all(np.isfinite(a).all() for a in back) and np.array_equal(back[0], d.q[0].cpu().numpy())

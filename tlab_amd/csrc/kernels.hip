@@ -253,7 +253,8 @@ __device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)
     for (int q = 0; q < M / 2; ++q) reinterpret_cast<double2 *>(p)[q] = make_double2(u[2 * q], u[2 * q + 1]);
 }
 
-template <int M, int MODE, int LV, int WPL>
+// LV / LV2: table form of the first- / second-derivative system (see xcoef)
+template <int M, int MODE, int LV, int WPL, int LV2 = LV>
 __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     extern __shared__ double xlds[];
     constexpr bool NEED1 = (MODE != MODE_P2);
@@ -267,33 +268,36 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     const int n = P * M;
 
     // LDS: [system 1 tables][system 2 tables] (only those this MODE solves), then the exchange buffers of the LPB lines (WPL > 1)
-    constexpr size_t TABW = LV == 1 ? (size_t)TAB : LV == 2 ? (size_t)(TAB / 2) : 0;      // doubles per system
-    const double *lds1 = xlds, *lds2 = xlds + (NEED1 ? TABW : 0);
-    if (LV == 1) {  // lane-variant tables: stage [5][M][P] per system in LDS once per block
-        for (int idx = threadIdx.x; idx < TAB; idx += blockDim.x) {
-            const int l = idx % P, p = (idx / P) % M, tab = idx / (P * M);
-            if (NEED1) const_cast<double *>(lds1)[idx] = a.y1.rowtab[tab * n + l * M + p];
-            if (NEED2) const_cast<double *>(lds2)[idx] = a.y2.rowtab[tab * n + l * M + p];
+    constexpr size_t TABW1 = LV == 1 ? (size_t)TAB : LV == 2 ? (size_t)(TAB / 2) : 0;       // doubles of system 1 / 2
+    constexpr size_t TABW2 = LV2 == 1 ? (size_t)TAB : LV2 == 2 ? (size_t)(TAB / 2) : 0;
+    const double *lds1 = xlds, *lds2 = xlds + (NEED1 ? TABW1 : 0);
+    auto stage = [&](const double *rowtab, const double *dst, int lv) {      // lane-variant tables: [5][M][P] per system in LDS once per block
+        if (lv == 1) {
+            double *d = const_cast<double *>(dst);
+            for (int idx = threadIdx.x; idx < TAB; idx += blockDim.x) {
+                const int l = idx % P, p = (idx / P) % M, tab = idx / (P * M);
+                d[idx] = rowtab[tab * n + l * M + p];
+            }
+        } else if (lv == 2) {                                                 // ... as float differences from chunk 0
+            float *d = reinterpret_cast<float *>(const_cast<double *>(dst));
+            for (int idx = threadIdx.x; idx < TAB; idx += blockDim.x) {
+                const int l = idx % P, p = (idx / P) % M, tab = idx / (P * M);
+                d[idx] = (float)(rowtab[tab * n + l * M + p] - rowtab[tab * n + p]);
+            }
         }
-    }
-    if (LV == 2) {  // the same as float differences from chunk 0
-        float *f1 = reinterpret_cast<float *>(const_cast<double *>(lds1)), *f2 = reinterpret_cast<float *>(const_cast<double *>(lds2));
-        for (int idx = threadIdx.x; idx < TAB; idx += blockDim.x) {
-            const int l = idx % P, p = (idx / P) % M, tab = idx / (P * M);
-            if (NEED1) f1[idx] = (float)(a.y1.rowtab[tab * n + l * M + p] - a.y1.rowtab[tab * n + p]);
-            if (NEED2) f2[idx] = (float)(a.y2.rowtab[tab * n + l * M + p] - a.y2.rowtab[tab * n + p]);
-        }
-    }
+    };
+    if (NEED1) stage(a.y1.rowtab, lds1, LV);
+    if (NEED2) stage(a.y2.rowtab, lds2, LV2);
     XCtx<WPL> cx;
     cx.lane = lane; cx.gl = gl; cx.wl = wl; cx.par = 0; cx.eb = nullptr; cx.hb = nullptr;
     if constexpr (WPL > 1) {
-        double *ex = xlds + ((NEED1 ? TABW : 0) + (NEED2 ? TABW : 0)) + (size_t)lib * (14 * WPL);
+        double *ex = xlds + ((NEED1 ? TABW1 : 0) + (NEED2 ? TABW2 : 0)) + (size_t)lib * (14 * WPL);
         cx.eb = ex; cx.hb = ex + 8 * WPL;
     }
-    if (LV != 0 || WPL > 1) __syncthreads();
+    if (LV != 0 || LV2 != 0 || WPL > 1) __syncthreads();
     XSys<WPL> y1, y2;
     if (NEED1) xsys_init<M, LV, WPL>(y1, a.y1, lds1, gl, n);
-    if (NEED2) xsys_init<M, LV, WPL>(y2, a.y2, lds2, gl, n);
+    if (NEED2) xsys_init<M, LV2, WPL>(y2, a.y2, lds2, gl, n);
 
     const long long stride = (long long)gridDim.x * LPB;
     for (long long line0 = (long long)blockIdx.x * LPB; line0 < a.nlines; line0 += stride) {
@@ -304,12 +308,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             line = a.nlines - 1;                    // the waves of a workgroup meet at barriers: compute, do not store
         }
         const long long off = line * n + gl * M;
-        if constexpr (LV == 2 || (LV == 1 && M >= 16)) {
-            // many rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x M of them in registers
-            // (182 spilled VGPRs at M = 32); an opaque copy of the LDS pointers per line makes it re-read them where they are used
-            if (NEED1) asm volatile("" : "+v"(y1.lds));
-            if (NEED2) asm volatile("" : "+v"(y2.lds));
-        }
+        // many rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x M of them in registers
+        // (182 spilled VGPRs at M = 32); an opaque copy of the LDS pointers per line makes it re-read them where they are used
+        if constexpr (LV == 2 || (LV == 1 && M >= 16)) { if (NEED1) asm volatile("" : "+v"(y1.lds)); }
+        if constexpr (LV2 == 2 || (LV2 == 1 && M >= 16)) { if (NEED2) asm volatile("" : "+v"(y2.lds)); }
         if constexpr (MODE == MODE_BURGERS) {
             // the advecting velocity of the line is loaded once and serves every transported field (rhs_global_incompressible_1.f90:
             // 98-162 calls OPR_Burgers_X four times with the same u)
@@ -324,10 +326,8 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 const double *src = a.fs[f];
                 double *dst = a.fo[f];
                 const double nuf = a.fnu[f];
-                if constexpr (LV == 2 || (LV == 1 && M >= 16)) {      // ... and per field
-                    asm volatile("" : "+v"(y1.lds));
-                    asm volatile("" : "+v"(y2.lds));
-                }
+                if constexpr (LV == 2 || (LV == 1 && M >= 16)) asm volatile("" : "+v"(y1.lds));      // ... and per field
+                if constexpr (LV2 == 2 || (LV2 == 1 && M >= 16)) asm volatile("" : "+v"(y2.lds));
                 double u[M];
                 if (src == a.in1) {
 #pragma unroll
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 xsten<M, false, WPL>(x1, u, um, up, a.s1, lane);
                 xsolve<M, LV, WPL>(x1, y1, cx, n);
                 xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
-                xsolve<M, LV, WPL>(x2, y2, cx, n);
+                xsolve<M, LV2, WPL>(x2, y2, cx, n);
 #pragma unroll
                 for (int p = 0; p < M; ++p) x2[p] = nuf * x2[p] - v[p] * x1[p];      // opr_burgers.f90:513
                 if (a.acc) {
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             }
             if (NEED2) {
                 xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
-                xsolve<M, LV, WPL>(x2, y2, cx, n);
+                xsolve<M, LV2, WPL>(x2, y2, cx, n);
             }
             if (!live) continue;                     // (WPL > 1: after the last barrier of this line)
             if constexpr (MODE == MODE_P1) {
@@ -735,15 +735,14 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a,
 // ============================================================================================
 static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
 
-template <int M, int LV, int WPL>
+template <int M, int LV, int WPL, int LV2 = LV>
 static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     constexpr int P = 64 * WPL, LPB = 4 / WPL;
     const long long blocks_needed = (a.nlines + LPB - 1) / LPB;
     const int grid = imin(blocks_needed, 256 * 8);
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
-    const int nsys = (mode == MODE_P1 || mode == MODE_P2) ? 1 : 2;       // tables of the systems this mode solves
-    const size_t tab = LV == 1 ? (size_t)5 * M * P * sizeof(double) : LV == 2 ? (size_t)5 * M * P * sizeof(float) : 0;
-    const size_t lds = nsys * tab + (WPL > 1 ? (size_t)LPB * 14 * WPL * sizeof(double) : 0);
+    auto tabbytes = [](int lv) { return lv == 1 ? (size_t)5 * M * P * sizeof(double) : lv == 2 ? (size_t)5 * M * P * sizeof(float) : (size_t)0; };
+    const size_t lds = (mode != MODE_P2 ? tabbytes(LV) : 0) + (mode != MODE_P1 ? tabbytes(LV2) : 0) + (WPL > 1 ? (size_t)LPB * 14 * WPL * sizeof(double) : 0);
     const double pts = (double)a.nlines * P * M;
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};
@@ -755,18 +754,18 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     ProfScope ps(names[mode], st, bytes);
     switch (mode) {
-    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
     }
     return hipGetLastError();
 }
@@ -776,8 +775,12 @@ bool xline_supported(int n) { return n == 256 || n == 512 || n == 1024; }      /
 // chunks = 64: one wave per line (n = 64 M); 128 / 256: two / four waves per line with 8 rows per lane (periodic lines of 1024 / 2048 points
 // whose tables pass xline_wide_ok; float-difference tables when they are lane-variant)
 hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XLineArgs &a, hipStream_t st) {
-    if (chunks == 128 && n == 1024) return lane_variant ? launch_xline_m<8, 2, 2>(mode, a, st) : launch_xline_m<8, 0, 2>(mode, a, st);
-    if (chunks == 256 && n == 2048) return lane_variant ? launch_xline_m<8, 2, 4>(mode, a, st) : launch_xline_m<8, 0, 4>(mode, a, st);
+    // table forms on several waves per line: doubles in LDS where they fit (1024 points: both systems, 80 KB; 2048 points: one system, 80 KB),
+    // the second-derivative system of the two-system modes at 2048 points as float differences (40 KB) -- the reconstruction costs a scalar
+    // load, a conversion and an add per coefficient, which is why doubles are preferred
+    if (chunks == 128 && n == 1024) return launch_xline_m<8, 1, 2, 1>(mode, a, st);
+    if (chunks == 256 && n == 2048)
+        return (mode == MODE_P1 || mode == MODE_P2) ? launch_xline_m<8, 1, 4, 1>(mode, a, st) : launch_xline_m<8, 1, 4, 2>(mode, a, st);
     if (chunks != 64) return hipErrorInvalidValue;
     switch (n) {
     case 256: return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);
