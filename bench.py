@@ -293,6 +293,45 @@ def main():
             out["copy_ceiling"] = {"GBps": copy_gbs, "what": "device copy of one %d-point fp64 field, read + write bytes, 10 repetitions" % src.numel()}
             if out["roofline"] is not None:
                 out["roofline"]["frac_of_copy"] = out["roofline"]["achieved"] / copy_gbs
+        if world == 1 and args.loopback <= 1:
+            # the north-star's own target kernel, standalone on this box: OPR_Partial_{X,Y,Z}(OPR_P1) at the benchmark's grid, 16 B per point
+            # (SURVEY.md 8d), >= 40 % of the 8 TB/s HBM peak asked for OPR_Partial_X at 512^3
+            targets = {}
+            a, r = d.txc[0][: d.n], d.txc[1][: d.n]
+            a.copy_(d.q[0])
+            for name, fn, g in (("OPR_Partial_X", T.OPR_Partial_X, d.g[0]), ("OPR_Partial_Y", T.OPR_Partial_Y, d.g[1]), ("OPR_Partial_Z", T.OPR_Partial_Z, d.g[2])):
+                for _ in range(2):
+                    fn(T.OPR_P1, nx, ny, nz, 0, g, a, r, None)
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for e0, e1 in ev:
+                    e0.record(); fn(T.OPR_P1, nx, ny, nz, 0, g, a, r, None); e1.record()
+                torch.cuda.synchronize()
+                ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[5]
+                gbs = 16.0 * npts / (ms * 1e-3) / 1e9
+                targets[name + "(OPR_P1)"] = {"ms": ms, "GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "points_per_s": npts / (ms * 1e-3)}
+            targets["north_star"] = ">= 40 % of the HBM roofline (8 TB/s) on OPR_Partial_X at 512^3: <= 0.67 ms per call"
+            out["targets"] = targets
+            # the substep against the bytes it really moves: PMC-measured HBM traffic per launch (profiles/traffic.json, this workload only) x
+            # the launches of one step; rocFFT's transforms are counted at their algorithmic 2 x 8 B per point of the complex field
+            tj = None
+            if os.path.exists(tpath) and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:
+                try:
+                    tj = json.load(open(tpath))
+                except Exception:
+                    tj = None
+            if tj:
+                moved, missing = 0.0, []
+                for k in kernels:
+                    per = tj.get(k["kernel"])
+                    if per is None and k["kernel"] == "rocfft":
+                        per = 2.0 * 8.0 * (nx + 2) * ny * nz
+                    if per is None:
+                        missing.append(k["kernel"])
+                        continue
+                    moved += per * k["calls"] / args.steps
+                out["substep_traffic"] = {"hbm_bytes_per_step": moved, "GBps": moved / (ms_per_step * 1e-3) / 1e9,
+                                          "frac_of_peak": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels_without_counter_data": missing,
+                                          "what": "sum over the kernels of a step of the HBM bytes per launch measured with rocprofv3 PMC counters (profiles/traffic.json)"}
         if args.cpu_sample > 0 and world == 1 and args.loopback <= 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.nscal)
             if args.cpu_sample_large > args.cpu_sample and (os.cpu_count() or 1) >= args.cpu_large_min_cores:

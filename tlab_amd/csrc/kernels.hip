@@ -300,6 +300,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
     if (NEED2) xsys_init<M, LV2, WPL>(y2, a.y2, lds2, gl, n);
 
     const long long stride = (long long)gridDim.x * LPB;
+    // software pipeline over the lines of this workgroup: the operand of the NEXT line is requested before the solves of this one (with few
+    // waves per CU -- one workgroup of 98-120 KB LDS at 2048 points -- nothing else hides the 1.5-2 us of a load from HBM)
+    double pn[M], pbn[(MODE == MODE_P1) ? M : 1];
+    bool have_pn = false;
     for (long long line0 = (long long)blockIdx.x * LPB; line0 < a.nlines; line0 += stride) {
         long long line = line0 + lib;
         const bool live = line < a.nlines;
@@ -308,6 +312,10 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             line = a.nlines - 1;                    // the waves of a workgroup meet at barriers: compute, do not store
         }
         const long long off = line * n + gl * M;
+        const bool next = line0 + stride < a.nlines;            // workgroup-uniform
+        long long nline = line0 + stride + lib;
+        if (nline >= a.nlines) nline = a.nlines - 1;
+        const long long noff = nline * n + gl * M;
         // many rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x M of them in registers
         // (182 spilled VGPRs at M = 32); an opaque copy of the LDS pointers per line makes it re-read them where they are used
         if constexpr (LV == 2 || (LV == 1 && M >= 16)) { if (NEED1) asm volatile("" : "+v"(y1.lds)); }
@@ -316,7 +324,13 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             // the advecting velocity of the line is loaded once and serves every transported field (rhs_global_incompressible_1.f90:
             // 98-162 calls OPR_Burgers_X four times with the same u)
             double v[M];
-            xload<M>(v, a.in1 + off);
+            if (have_pn) {
+#pragma unroll
+                for (int p = 0; p < M; ++p) v[p] = pn[p];
+            } else {
+                xload<M>(v, a.in1 + off);
+            }
+            have_pn = false;
             // software pipeline over the fields: with one wave per SIMD nothing else hides the memory latency, so the operand of the NEXT
             // field and the old tendency of THIS one are requested before the two solves of this field start (2.9-3.0 -> 2.65-2.75 ms at 512^3;
             // requesting the next LINE's velocity during the last field as well did not add anything, measured)
@@ -343,6 +357,7 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
                 if (PIPE && a.acc) xload<M>(o, dst + off);
                 have_next = PIPE && (f + 1 < a.nf) && (a.fs[f + 1] != a.in1);
                 if (have_next) xload<M>(un, a.fs[f + 1] + off);
+                if (PIPE && M <= 8 && f + 1 == a.nf && next) { xload<M>(pn, a.in1 + noff); have_pn = true; }     // the next line's velocity
                 double um[3], up[3];
                 xhalo<M, WPL>(cx, u, um, up);
                 double x1[M], x2[M];
@@ -383,12 +398,30 @@ __global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
             }
         } else {
             double u[M];
-            xload<M>(u, a.in0 + off);
+            if (have_pn) {
+#pragma unroll
+                for (int p = 0; p < M; ++p) u[p] = pn[p];
+            } else {
+                xload<M>(u, a.in0 + off);
+            }
             if (MODE == MODE_P1 && a.in0b != nullptr) {   // operand = in0 + s * in0b
                 double ub[M];
-                xload<M>(ub, a.in0b + off);
+                if (have_pn) {
+#pragma unroll
+                    for (int p = 0; p < M; ++p) ub[p] = pbn[p];
+                } else {
+                    xload<M>(ub, a.in0b + off);
+                }
 #pragma unroll
                 for (int p = 0; p < M; ++p) u[p] = u[p] + ub[p] * a.in0b_scale;
+            }
+            have_pn = false;
+            if constexpr (M <= 8) {
+                if (next) {
+                    xload<M>(pn, a.in0 + noff);
+                    if constexpr (MODE == MODE_P1) { if (a.in0b != nullptr) xload<M>(pbn, a.in0b + noff); }
+                    have_pn = true;
+                }
             }
             // old tendency / velocity of the epilogues: requested before the solve (one wave per SIMD: nothing else hides the latency)
             double h[MODE == MODE_P1 ? M : 1], qv[MODE == MODE_P1 ? M : 1];
