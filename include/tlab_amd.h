@@ -50,6 +50,7 @@ extern "C" {
 #define TLAB_BCS_NN 3
 /* fdm/fdm_derivative.f90:51-58 */
 #define TLAB_FDM_COM4_JACOBIAN 4
+#define TLAB_FDM_COM6_JACOBIAN_PENTA 5
 #define TLAB_FDM_COM6_JACOBIAN 6
 #define TLAB_FDM_COM6_JACOBIAN_HYPER 7
 
@@ -70,7 +71,7 @@ int tlab_memcpy_d2h(void *dst, const void *src, size_t bytes);
 typedef struct tlab_fdm_plan *tlab_fdm_plan_t;
 
 /* Replaces FDM_CreatePlan (fdm/fdm.f90:143-252): Jacobians from the node positions, compact schemes
- * scheme1 (first derivative: TLAB_FDM_COM4_JACOBIAN | TLAB_FDM_COM6_JACOBIAN) and scheme2 (second derivative:
+ * scheme1 (first derivative: TLAB_FDM_COM4_JACOBIAN | TLAB_FDM_COM6_JACOBIAN | TLAB_FDM_COM6_JACOBIAN_PENTA) and scheme2 (second derivative:
  * COM4_JACOBIAN | COM6_JACOBIAN | COM6_JACOBIAN_HYPER), Neumann variants (FDM_Bcs_Neumann, fdm_base.f90:194),
  * factorizations.  nodes: HOST pointer, n doubles.
  * hyper_bc1_ext: value of the out-of-bounds coefficient the reference reads for the C2N6-Hyper wall row
@@ -82,7 +83,8 @@ int tlab_fdm_plan_create(tlab_fdm_plan_t *out, int n, const double *nodes, int p
 /* Same plan from coefficient tables the (unchanged) Fortran host already built in FDM_Initialize:
  * lhs1 = g%der1%lhs(n,1:ndl1), rhs1 = g%der1%rhs(n,1:ndr1), lhs2 = g%der2%lhs(n,1:ndl2),
  * rhs2 = g%der2%rhs(n,1:ndr2+ndl2) (the last ndl2 columns are the Jacobian-correction diagonals,
- * fdm_derivative.f90:356,437-440).  ndl* must be 3 (tridiagonal LHS; CompactJacobian6Penta is unsupported). */
+ * fdm_derivative.f90:356,437-440).  ndl2 must be 3; ndl1 = 3, or 5 with ndr1 = 7 (CompactJacobian6Penta: the library factorizes with
+ * PENTADFS2 / PENTADPFS as fdm_derivative.f90:90-119 does; the derivative then runs one line per thread, no chunked fast path). */
 int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, int need_1der,
                                      int ndl1, int ndr1, const double *lhs1, const double *rhs1,
                                      int ndl2, int ndr2, const double *lhs2, const double *rhs2);

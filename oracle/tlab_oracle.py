@@ -40,6 +40,8 @@ OPR_B_SELF, OPR_B_U_IN = 0, 1
 # value the flang-built reference picks up for the out-of-bounds coef_bc1(7) of the C2N6-Hyper wall closure
 # (see fdm_c2n6_hyper_jacobian below); part of the parity definition, documented in DESIGN.md
 HYPER_BC1_EXT = 0.1
+# the same defect in the first-derivative closure of CompactJacobian6Penta (fdm_com1_jacobian.f90:237): coef_bc1(7) reads coef_bc2(1) = 1/6
+PENTA_BC1_EXT = 1.0 / 6.0
 
 
 # ######################################################################################
@@ -104,6 +106,98 @@ def tridpss(a, b, c, d, e, f):
     f[nmax - 2] = e[nmax - 2] * f[nmax - 1] + f[nmax - 2]
     for n in range(nmax - 3, -1, -1):
         f[n] = f[n] + c[n] * f[n + 1] + e[n] * f[nmax - 1]
+
+
+# ######################################################################################
+# utils/linear5.f90 -- pentadiagonal LU in reverse ordering (CompactJacobian6Penta) and its periodic (Sherman-Morrison-Woodbury) form
+# ######################################################################################
+def pentadfs2(a, b, c, d, e):
+    """utils/linear5.f90:156-203 PENTADFS2.  In place; arrays (nmax,)."""
+    nmax = a.shape[0]
+    n = nmax - 1
+    e[n] = 1.0
+    d[n] = 1.0
+    n = nmax - 2
+    e[n] = 1.0
+    d[n] = d[n] / c[n + 1]
+    c[n] = c[n] - d[n] * b[n + 1]
+    b[n] = b[n] - d[n] * a[n + 1]
+    for n in range(nmax - 3, 1, -1):
+        e[n] = e[n] / c[n + 2]
+        d[n] = (d[n] - e[n] * b[n + 2]) / c[n + 1]
+        c[n] = c[n] - d[n] * b[n + 1] - e[n] * a[n + 2]
+        b[n] = b[n] - d[n] * a[n + 1]
+    n = 1
+    e[n] = e[n] / c[n + 2]
+    d[n] = (d[n] - e[n] * b[n + 2]) / c[n + 1]
+    c[n] = c[n] - d[n] * b[n + 1] - e[n] * a[n + 2]
+    b[n] = b[n] - d[n] * a[n + 1]
+    a[n] = 1.0
+    n = 0
+    e[n] = e[n] / c[n + 2]
+    d[n] = (d[n] - e[n] * b[n + 2]) / c[n + 1]
+    c[n] = c[n] - d[n] * b[n + 1] - e[n] * a[n + 2]
+    b[n] = 1.0
+    a[n] = 1.0
+
+
+def pentadss2(a, b, c, d, e, f):
+    """utils/linear5.f90:207-244 PENTADSS2.  f: (nmax, len) in place."""
+    nmax = a.shape[0]
+    n = nmax - 2
+    f[n] = f[n] - f[n + 1] * d[n]
+    for n in range(nmax - 3, -1, -1):
+        f[n] = f[n] - f[n + 1] * d[n] - f[n + 2] * e[n]
+    f[0] = f[0] / c[0]
+    f[1] = (f[1] - f[0] * b[1]) / c[1]
+    for n in range(2, nmax):
+        f[n] = (f[n] - f[n - 1] * b[n] - f[n - 2] * a[n]) / c[n]
+
+
+def pentadpfs(a, b, c, d, e, f, g):
+    """utils/linear5.f90:273-347 PENTADPFS.  In place; f, g are outputs (the two Woodbury vectors)."""
+    nmax = a.shape[0]
+    a0, b0, en, dn = a[0], b[0], e[nmax - 1], d[nmax - 1]
+    b[1] = b[1] - d[nmax - 1]
+    c[0] = c[0] - e[nmax - 1]
+    c[1] = c[1] - e[nmax - 1]
+    c[nmax - 2] = c[nmax - 2] - a[0]
+    c[nmax - 1] = c[nmax - 1] - a[0]
+    d[nmax - 2] = d[nmax - 2] - b[0]
+    a[0] = 0.0; a[1] = 0.0; b[0] = 0.0
+    d[nmax - 1] = 0.0; e[nmax - 1] = 0.0; e[nmax - 2] = 0.0
+    pentadfs2(a, b, c, d, e)
+    a[0] = a0; b[0] = b0; e[nmax - 1] = en; d[nmax - 1] = dn
+    f[:] = 0.0; f[0] = 1.0; f[nmax - 2] = 1.0
+    g[:] = 0.0; g[1] = 1.0; g[nmax - 1] = 1.0
+    ff, gg = f.reshape(nmax, 1), g.reshape(nmax, 1)
+    pentadss2(a, b, c, d, e, ff)
+    pentadss2(a, b, c, d, e, gg)
+
+
+def pentadpss(a, b, c, d, e, f, g, frc):
+    """utils/linear5.f90:352-411 PENTADPSS.  frc: (nmax, len) in place."""
+    nmax = a.shape[0]
+    pentadss2(a, b, c, d, e, frc)
+    m1 = e[nmax - 1] * f[0] + a[0] * f[nmax - 2] + b[0] * f[nmax - 1] + 1.0
+    m2 = e[nmax - 1] * g[0] + a[0] * g[nmax - 2] + b[0] * g[nmax - 1]
+    m3 = d[nmax - 1] * f[0] + e[nmax - 1] * f[1] + a[0] * f[nmax - 1]
+    m4 = d[nmax - 1] * g[0] + e[nmax - 1] * g[1] + a[0] * g[nmax - 1] + 1.0
+    di = 1 / (m1 * m4 - m2 * m3)
+    d11 = di * (m4 * e[nmax - 1] - m2 * d[nmax - 1])
+    d12 = di * (m4 * b[0] - m2 * a[0])
+    d13 = di * m4 * a[0]
+    d14 = di * m2 * e[nmax - 1]
+    d21 = di * (m1 * d[nmax - 1] - m3 * e[nmax - 1])
+    d22 = di * (m1 * a[0] - m3 * b[0])
+    d23 = di * m3 * a[0]
+    d24 = di * m1 * e[nmax - 1]
+    dummy1 = d11 * frc[0] + d12 * frc[nmax - 1] + d13 * frc[nmax - 2] - d14 * frc[1]
+    dummy2 = d21 * frc[0] + d22 * frc[nmax - 1] - d23 * frc[nmax - 2] + d24 * frc[1]
+    for n in range(2, nmax - 3):                       # main loop, rows 3 .. nmax-3 (1-based)
+        frc[n] = frc[n] - dummy1 * f[n] - dummy2 * g[n]
+    for n in (0, 1, nmax - 3, nmax - 2, nmax - 1):     # boundaries, from the still unmodified rows 1, 2, nmax-1, nmax
+        frc[n] = frc[n] - dummy1 * f[n] - dummy2 * g[n]
 
 
 # ######################################################################################
@@ -194,10 +288,34 @@ def fdm_c1n6_jacobian(dx, periodic):
     if periodic:
         lhs, rhs = create_system_1der(dx, 3, 5, coef)
     else:
-        bc1 = np.array([2.0, 0.0, -2.5, 2.0, 0.5, 0.0])
+        # REFERENCE DEFECT reproduced deliberately (the twin of the one in the C2N6-Hyper closure): with 7 RHS diagonals Create_System_1der reads
+        # coef_bc1(3 + icmax) = coef_bc1(7) of a 6-element array (fdm_com1_jacobian.f90:237, icmax = 4); in the flang-built reference the next
+        # stack slot is coef_bc2(1) = 1/6 (declared right after, :146), which becomes the "extended stencil" entry rhs(1,1) of the wall rows.
+        bc1 = np.array([2.0, 0.0, -2.5, 2.0, 0.5, 0.0, PENTA_BC1_EXT])
         bc2 = np.array([1.0 / 6.0, 0.5, -5.0 / 9.0, -0.5, 1.0, 1.0 / 18.0])
         lhs, rhs = create_system_1der(dx, 3, 5, coef, bc1, bc2)
     return lhs, rhs, (3, 5), coef
+
+
+def fdm_c1n6_jacobian_penta(dx, periodic):
+    """fdm/fdm_com1_jacobian.f90:136-192 (FDM_C1N6_Jacobian_Penta): pentadiagonal LHS, 7-diagonal antisymmetric RHS, alpha = 0.56."""
+    coef = np.zeros(5)
+    coef[0] = 0.56
+    coef[1] = 0.4 * (-1.0 / 3.0 + coef[0])
+    coef[2] = 0.5 * (1.0 / 6.0) * (9.0 + coef[0] - 20.0 * coef[1])
+    coef[3] = 0.25 * (1.0 / 15.0) * (-9.0 + 32.0 * coef[0] + 62.0 * coef[1])
+    coef[4] = (1.0 / 6.0) * (1.0 / 10.0) * (1.0 - 3.0 * coef[0] + 12.0 * coef[1])
+    if periodic:
+        lhs, rhs = create_system_1der(dx, 5, 7, coef)
+    else:
+        # REFERENCE DEFECT reproduced deliberately (the twin of the one in the C2N6-Hyper closure): with 7 RHS diagonals Create_System_1der reads
+        # coef_bc1(3 + icmax) = coef_bc1(7) of a 6-element array (fdm_com1_jacobian.f90:237, icmax = 4); in the flang-built reference the next
+        # stack slot is coef_bc2(1) = 1/6 (declared right after, :146), which becomes the "extended stencil" entry rhs(1,1) of the wall rows.
+        bc1 = np.array([2.0, 0.0, -2.5, 2.0, 0.5, 0.0, PENTA_BC1_EXT])
+        bc2 = np.array([1.0 / 6.0, 0.5, -5.0 / 9.0, -0.5, 1.0, 1.0 / 18.0])
+        bc3 = np.array([1.0 / 3.0, 1.0 / 3.0, -1.0 / 36.0, -7.0 / 9.0, 0.0, 7.0 / 9.0, 1.0 / 36.0, 0.0])
+        lhs, rhs = create_system_1der(dx, 5, 7, coef, bc1, bc2, bc3)
+    return lhs, rhs, (5, 7), coef
 
 
 def create_system_2der(dx2, ndl, ndr, coef_int, coef_bc1=None, coef_bc2=None, coef_bc3=None):
@@ -459,6 +577,49 @@ def matmul_5d_antisym(rhs, u, f, ibc, rhs_b=None, rhs_t=None):
         f[nx - 1] = u[nx - 4] * r5[nx - 1] + u[nx - 3] * r1[nx - 1] + u[nx - 2] * r2[nx - 1] + u[nx - 1] * r3[nx - 1]
 
 
+def matmul_7d_antisym(rhs, u, f, ibc, rhs_b=None, rhs_t=None):
+    """fdm/fdm_matmul.f90:491-558 MatMul_7d_antisym (first-derivative RHS of CompactJacobian6Penta)."""
+    nx = rhs.shape[0]
+    r1, r2, r3, r4, r5, r6, r7 = (rhs[:, k] for k in range(7))
+    r6_loc, r7_loc = r6[4], r7[4]
+    if ibc == BCS_PERIODIC:
+        f[0] = u[1] - u[nx - 1] + r6_loc * (u[2] - u[nx - 2]) + r7_loc * (u[3] - u[nx - 3])
+        f[1] = u[2] - u[0] + r6_loc * (u[3] - u[nx - 1]) + r7_loc * (u[4] - u[nx - 2])
+        f[2] = u[3] - u[1] + r6_loc * (u[4] - u[0]) + r7_loc * (u[5] - u[nx - 1])
+        f[3] = u[4] - u[2] + r6_loc * (u[5] - u[1]) + r7_loc * (u[6] - u[0])
+    elif ibc in (BCS_ND, BCS_NN):
+        rb = rhs_b      # rhs_b(j, c) -> rb[j-1, c]
+        f[1] = f[0] * rb[1, 3] + u[1] * rb[1, 4] + u[2] * rb[1, 5] + u[3] * rb[1, 6] + u[4] * rb[1, 7]
+        f[2] = f[0] * rb[2, 2] + u[1] * rb[2, 3] + u[2] * rb[2, 4] + u[3] * rb[2, 5] + u[4] * rb[2, 6] + u[5] * rb[2, 7]
+        f[3] = f[0] * rb[3, 1] + u[1] * rb[3, 2] + u[2] * rb[3, 3] + u[3] * rb[3, 4] + u[4] * rb[3, 5] + u[5] * rb[3, 6] + u[6] * rb[3, 7]
+    else:
+        f[0] = u[0] * r4[0] + u[1] * r5[0] + u[2] * r6[0] + u[3] * r7[0] + u[4] * r1[0]
+        f[1] = u[0] * r3[1] + u[1] * r4[1] + u[2] * r5[1] + u[3] * r6[1] + u[4] * r7[1]
+        f[2] = u[0] * r2[2] + u[1] * r3[2] + u[2] * r4[2] + u[3] * r5[2] + u[4] * r6[2] + u[5] * r7[2]
+        f[3] = u[0] * r1[3] + u[1] * r2[3] + u[2] * r3[3] + u[3] * r4[3] + u[4] * r5[3] + u[5] * r6[3] + u[6] * r7[3]
+    for n in range(4, nx - 4):
+        f[n] = u[n + 1] - u[n - 1] + r6_loc * (u[n + 2] - u[n - 2]) + r7_loc * (u[n + 3] - u[n - 3])
+    if ibc == BCS_PERIODIC:
+        f[nx - 4] = u[nx - 3] - u[nx - 5] + r6_loc * (u[nx - 2] - u[nx - 6]) + r7_loc * (u[nx - 1] - u[nx - 7])
+        f[nx - 3] = u[nx - 2] - u[nx - 4] + r6_loc * (u[nx - 1] - u[nx - 5]) + r7_loc * (u[0] - u[nx - 6])
+        f[nx - 2] = u[nx - 1] - u[nx - 3] + r6_loc * (u[0] - u[nx - 4]) + r7_loc * (u[1] - u[nx - 5])
+        f[nx - 1] = u[0] - u[nx - 2] + r6_loc * (u[1] - u[nx - 3]) + r7_loc * (u[2] - u[nx - 4])
+    elif ibc in (BCS_DN, BCS_NN):
+        rt = rhs_t      # rhs_t(r, c) -> rt[r, c-1]
+        f[nx - 4] = u[nx - 7] * rt[1, 0] + u[nx - 6] * rt[1, 1] + u[nx - 5] * rt[1, 2] + u[nx - 4] * rt[1, 3] + u[nx - 3] * rt[1, 4] + u[nx - 2] * rt[1, 5] + f[nx - 1] * rt[1, 6]
+        f[nx - 3] = u[nx - 6] * rt[2, 0] + u[nx - 5] * rt[2, 1] + u[nx - 4] * rt[2, 2] + u[nx - 3] * rt[2, 3] + u[nx - 2] * rt[2, 4] + f[nx - 1] * rt[2, 5]
+        f[nx - 2] = u[nx - 5] * rt[3, 0] + u[nx - 4] * rt[3, 1] + u[nx - 3] * rt[3, 2] + u[nx - 2] * rt[3, 3] + f[nx - 1] * rt[3, 4]
+    else:
+        n = nx - 4
+        f[n] = u[n - 3] * r1[n] + u[n - 2] * r2[n] + u[n - 1] * r3[n] + u[n] * r4[n] + u[n + 1] * r5[n] + u[n + 2] * r6[n] + u[n + 3] * r7[n]
+        n = nx - 3
+        f[n] = u[n - 3] * r1[n] + u[n - 2] * r2[n] + u[n - 1] * r3[n] + u[n] * r4[n] + u[n + 1] * r5[n] + u[n + 2] * r6[n]
+        n = nx - 2
+        f[n] = u[n - 3] * r1[n] + u[n - 2] * r2[n] + u[n - 1] * r3[n] + u[n] * r4[n] + u[n + 1] * r5[n]
+        n = nx - 1
+        f[n] = u[n - 4] * r7[n] + u[n - 3] * r1[n] + u[n - 2] * r2[n] + u[n - 1] * r3[n] + u[n] * r4[n]
+
+
 def matmul_5d_sym(rhs, u, f, ibc):
     """fdm/fdm_matmul.f90:423-485 MatMul_5d_sym (C2N4/C2N6 second-derivative RHS)."""
     nx = rhs.shape[0]
@@ -569,6 +730,8 @@ def der1_create_system(g, dx, periodic):
         lhs, rhs, nb, coef = fdm_c1n4_jacobian(dx, periodic)
     elif g.mode_fdm in (FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER):
         lhs, rhs, nb, coef = fdm_c1n6_jacobian(dx, periodic)
+    elif g.mode_fdm == FDM_COM6_JACOBIAN_PENTA:
+        lhs, rhs, nb, coef = fdm_c1n6_jacobian_penta(dx, periodic)
     else:
         raise NotImplementedError("oracle: first-derivative scheme %d" % g.mode_fdm)
     g.lhs = np.zeros((nx, 5)); g.lhs[:, :nb[0]] = lhs
@@ -589,9 +752,12 @@ def der1_initialize(g, dx, periodic, bcs_cases):
     if periodic:
         g.lu = np.zeros((nx, ndl + 2))
         g.lu[:, :ndl] = g.lhs[:, :ndl]
-        cols = [g.lu[:, k].copy() for k in range(5)]
-        tridpfs(*cols)
-        for k in range(5):
+        cols = [g.lu[:, k].copy() for k in range(ndl + 2)]
+        if ndl == 3:
+            tridpfs(*cols)
+        else:
+            pentadpfs(*cols)                       # fdm_derivative.f90:90-91
+        for k in range(ndl + 2):
             g.lu[:, k] = cols[k]
     else:
         g.lu = np.zeros((nx, 20))
@@ -604,9 +770,13 @@ def der1_initialize(g, dx, periodic, bcs_cases):
                 nmin += 1
             if bc in (BCS_DN, BCS_NN):
                 nmax -= 1
-            a, b, c = blk[nmin:nmax, 0].copy(), blk[nmin:nmax, 1].copy(), blk[nmin:nmax, 2].copy()
-            tridfs(a, b, c)
-            blk[nmin:nmax, 0], blk[nmin:nmax, 1], blk[nmin:nmax, 2] = a, b, c
+            cols = [blk[nmin:nmax, k].copy() for k in range(ndl)]
+            if ndl == 3:
+                tridfs(*cols)
+            else:
+                pentadfs2(*cols)                   # :112-113
+            for k in range(ndl):
+                blk[nmin:nmax, k] = cols[k]
             g.lu[:, ip:ip + ndl] = blk
 
 
@@ -615,6 +785,8 @@ def der1_matmul(g, u, f, ibc):
         matmul_3d_antisym(g.rhs, u, f, ibc, g.rhs_b, g.rhs_t)
     elif g.nb_diag[1] == 5:
         matmul_5d_antisym(g.rhs, u, f, ibc, g.rhs_b, g.rhs_t)
+    elif g.nb_diag[1] == 7:
+        matmul_7d_antisym(g.rhs, u, f, ibc, g.rhs_b, g.rhs_t)
     else:
         raise NotImplementedError
 
@@ -637,9 +809,15 @@ def der1_solve(g, ibc, u, lu1=None):
         nmax -= 1
     der1_matmul(g, u, res, ibc_loc)
     if g.periodic:
-        tridpss(lu1[:, 0], lu1[:, 1], lu1[:, 2], lu1[:, 3], lu1[:, 4], res)
+        if g.nb_diag[0] == 3:
+            tridpss(lu1[:, 0], lu1[:, 1], lu1[:, 2], lu1[:, 3], lu1[:, 4], res)
+        else:
+            pentadpss(*(lu1[:, k] for k in range(7)), res)
     else:
-        tridss(lu1[nmin:nmax, ip], lu1[nmin:nmax, ip + 1], lu1[nmin:nmax, ip + 2], res[nmin:nmax])
+        if g.nb_diag[0] == 3:
+            tridss(lu1[nmin:nmax, ip], lu1[nmin:nmax, ip + 1], lu1[nmin:nmax, ip + 2], res[nmin:nmax])
+        else:
+            pentadss2(*(lu1[nmin:nmax, ip + k] for k in range(5)), res[nmin:nmax])
     return res
 
 

@@ -96,9 +96,27 @@ def test_from_arrays_roundtrip():
     assert p.need_1der
 
 
+def test_penta_plan_tables_match_the_reference():
+    """SpaceOrder1 = CompactJacobian6Penta: the C++ restatement (fdm_schemes.cpp: FDM_C1N6_Jacobian_Penta, PENTADFS2, PENTADPFS, the
+    out-of-bounds wall coefficient included) against the tables the reference itself produced (tests/golden/derivs_penta_*.npz)."""
+    g = np.load(golden_files("derivs_penta")[0])
+    for d, (nodes, per, uni) in {1: (g["x"], True, True), 2: (g["y"], False, False), 3: (g["z"], True, True)}.items():
+        p = T.FdmPlan(nodes, per, uni, scheme1=5, scheme2=6)
+        for key in ("lhs1", "rhs1", "lu1", "rhs_b1", "rhs_t1", "mwn1", "lhs2", "rhs2", "lu2", "jac"):
+            a, b = np.asarray(p.table(key)), g["plan%d_%s" % (d, key)]
+            if a.ndim == 2:
+                m = min(a.shape[1], b.shape[1])
+                a, b = a[:, :m], b[:, :m]
+            assert rel_err(a, b) <= 1e-14, (d, key)
+    # the host's own tables through from_arrays: the library factorizes them the reference's way
+    n = int(g["ny"])
+    q = T.FdmPlan.from_arrays(n, False, int(g["plan2_need_1der"]), g["plan2_lhs1"], g["plan2_rhs1"][:, :7], g["plan2_lhs2"], g["plan2_rhs2"][:, :10], ndl1=5)
+    assert rel_err(q.table("lu1"), g["plan2_lu1"]) <= 1e-14 and rel_err(q.table("rhs_t1"), g["plan2_rhs_t1"]) <= 1e-14
+
+
 def test_unsupported_and_invalid_are_reported():
     with pytest.raises(T.TlabError):
-        T.FdmPlan(np.arange(32) / 32.0, True, True, scheme1=5)          # CompactJacobian6Penta: not built
+        T.FdmPlan(np.arange(32) / 31.0, False, True, scheme1=16)        # direct FIRST derivatives (fdm_comx_direct.f90): not built
     with pytest.raises(T.TlabError):
         T.FdmPlan(np.arange(32) ** 1.5, True, False)                    # periodic must be uniform (fdm.f90:117)
 

@@ -91,6 +91,22 @@ def test_golden_vectors(T, path):
         run_all_ops(T, O, d, gp, op, nx, ny, nz, (0, 1, 2, 3) if d == 2 else (0,), g["u"], g["v"], float(g["visc"]), expect=g, tag=path)
 
 
+@pytest.mark.parametrize("nx,ny,nz", [(96, 64, 40), (256, 130, 6)])
+def test_penta_first_derivative(T, nx, ny, nz):
+    """SpaceOrder1 = CompactJacobian6Penta (fdm_com1_jacobian.f90:136-192; k_penta1, one line per thread) in the three directions, all
+    operator types and the Burgers operator, against the oracle (itself bitwise equal to the reference for this scheme, tests/golden/
+    derivs_penta_*.npz); the plan also built from the host's tables (tlab_fdm_plan_create_from_arrays, ndl1 = 5)."""
+    from oracle import tlab_oracle as O
+    x, y, z = grids(nx, ny, nz, ystretch=True)
+    u, v = fields(nx, ny, nz, 5 * nx + ny)
+    for d, (nodes, per) in {1: (x, True), 2: (y, False), 3: (z, True)}.items():
+        gp, op = T.FdmPlan(nodes, per, per, 5, 7), O.FdmPlan(nodes, per, per, 5, 7)
+        run_all_ops(T, O, d, gp, op, nx, ny, nz, (0,) if per else (0, 1, 2, 3), u, v, 1.0 / 500.0, tag="penta")
+    nd2 = op.der2
+    hp = T.FdmPlan.from_arrays(nz, True, 0, op.der1.lhs, op.der1.rhs[:, :7], nd2.lhs, nd2.rhs[:, :nd2.nb_diag[1] + 3], ndl1=5)
+    run_all_ops(T, O, 3, hp, op, nx, ny, nz, (0,), u, v, 1.0 / 500.0, tag="penta from_arrays")
+
+
 @pytest.mark.parametrize("nx,ny,nz,xper", [(256, 5, 3, True), (512, 3, 5, True), (1024, 2, 3, True), (256, 4, 3, False), (512, 3, 2, False)])
 def test_x_wave_per_line_kernel(T, nx, ny, nz, xper):
     from oracle import tlab_oracle as O

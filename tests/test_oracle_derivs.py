@@ -56,6 +56,8 @@ def test_operators_match_golden(path):
 @pytest.mark.parametrize("path", golden_files("derivs_"))
 def test_boundary_bcs_neumann_matches_golden(path):
     g = np.load(path)
+    if "bcsn_bc1_hb" not in g.files:
+        pytest.skip("no BOUNDARY_BCS_NEUMANN_Y vectors in this file (the routine is written for the CompactJacobian6 first derivative)")
     nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
     gy = plans_from_golden(g)[2]
     for ibc in (1, 2, 3):

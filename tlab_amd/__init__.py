@@ -9,7 +9,7 @@ from .operators import (  # noqa: F401
     FdmPlan, init, sync,
     OPR_P1, OPR_P2, OPR_P2_P1, OPR_B_SELF, OPR_B_U_IN,
     BCS_DD, BCS_ND, BCS_DN, BCS_NN,
-    FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER, FDM_COM6_DIRECT, FDM_COM4_DIRECT,
+    FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN_PENTA, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER, FDM_COM6_DIRECT, FDM_COM4_DIRECT,
     OPR_Partial_X, OPR_Partial_Y, OPR_Partial_Z,
     OPR_Burgers_X, OPR_Burgers_Y, OPR_Burgers_Z,
     TLab_Transpose, PoissonPlan, OPR_Poisson, OPR_Helmholtz, poisson_set_exact, BOUNDARY_BCS_NEUMANN_Y,

@@ -363,19 +363,25 @@ int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, 
                                      const double *rhs2) {
     return guarded([&] {
         if (!out || n < 8 || !lhs1 || !rhs1 || !lhs2 || !rhs2) throw Invalid("tlab_fdm_plan_create_from_arrays: bad arguments");
-        if (ndl1 != 3 || ndl2 != 3) throw Unsupported("only tridiagonal LHS schemes are built (CompactJacobian6Penta is not)");
-        if ((ndr1 != 3 && ndr1 != 5) || (ndr2 != 5 && ndr2 != 7)) throw Unsupported("unsupported number of RHS diagonals");
+        const bool penta = (ndl1 == 5 && ndr1 == 7);      // CompactJacobian6Penta first derivative (generic kernel, reference operation order)
+        if ((ndl1 != 3 && !penta) || ndl2 != 3) throw Unsupported("LHS: 3 diagonals (first derivative: or 5 with 7 RHS diagonals, CompactJacobian6Penta)");
+        if ((!penta && ndr1 != 3 && ndr1 != 5) || (ndr2 != 5 && ndr2 != 7)) throw Unsupported("unsupported number of RHS diagonals");
         auto p = std::make_unique<tlab_fdm_plan>();
         FdmTables &t = p->t;
         t.n = n; t.periodic = periodic != 0; t.uniform = !need_1der;
         for (DerTables *d : {&t.der1, &t.der2}) { d->n = n; d->periodic = t.periodic; d->lhs.assign((size_t)n * 5, 0.0); d->mwn.assign(n, 0.0); }
-        t.der1.ndl = 3; t.der1.ndr = ndr1; t.der1.rhs_cols = 7; t.der1.rhs.assign((size_t)n * 7, 0.0);
+        t.der1.ndl = ndl1; t.der1.ndr = ndr1; t.der1.rhs_cols = 7; t.der1.rhs.assign((size_t)n * 7, 0.0);
         t.der2.ndl = 3; t.der2.ndr = ndr2; t.der2.rhs_cols = 12; t.der2.rhs.assign((size_t)n * 12, 0.0);
         t.der2.need_1der = need_1der != 0;
-        std::copy(lhs1, lhs1 + (size_t)n * 3, t.der1.lhs.begin());
+        std::copy(lhs1, lhs1 + (size_t)n * ndl1, t.der1.lhs.begin());
         std::copy(rhs1, rhs1 + (size_t)n * ndr1, t.der1.rhs.begin());
         std::copy(lhs2, lhs2 + (size_t)n * 3, t.der2.lhs.begin());
         std::copy(rhs2, rhs2 + (size_t)n * (ndr2 + 3), t.der2.rhs.begin());
+        if (penta) {      // the kernel follows the reference's PENTADSS2 / PENTADPSS: factorize the host's lhs the reference's way (fdm_derivative.f90:78-119)
+            t.der1.mode_fdm = FDM_COM6_JACOBIAN_PENTA;
+            const int all[4] = {BCS_DD, BCS_ND, BCS_DN, BCS_NN};
+            try { der1_factorize(t.der1, all, 4); } catch (const std::runtime_error &e) { throw Unsupported(e.what()); }
+        }
         *out = p.release();
     });
 }
@@ -530,6 +536,7 @@ int xline_chunks(int n, tlab_fdm_plan_t g) {
 
 int choose_path(int dir, int n, tlab_fdm_plan_t g = nullptr) {
     int path = PATH_GENERIC;
+    if (g && g->t.der1.ndl == 5) return PATH_GENERIC;      // CompactJacobian6Penta: the first derivative runs on k_penta1, nothing is fused
     if (dir == 1 && xline_chunks(n, g) > 0) path = PATH_XLINE;
     if (dir != 1 && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0)) path = PATH_RTILE;
     if (g_force_path == PATH_GENERIC) path = PATH_GENERIC;
@@ -539,6 +546,23 @@ int choose_path(int dir, int n, tlab_fdm_plan_t g = nullptr) {
 
 void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, const double *in0, const double *d1in,
                  double *out) {
+    if (which == 1 && g->t.der1.ndl == 5) {      // CompactJacobian6Penta (fdm_com1_jacobian.f90:136-192)
+        const DerTables &d = g->t.der1;
+        if (d.ndr != 7 || d.lu.empty()) throw Unsupported("pentadiagonal first derivative: 7 RHS diagonals and the LU factors are required");
+        if (!g->penta_rhs) {
+            g->penta_rhs = std::make_unique<DeviceArray>();
+            g->penta_rhs->upload(d.rhs);
+            g->penta_lu = std::make_unique<DeviceArray>();
+            g->penta_lu->upload(d.lu);
+        }
+        PentaArgs a;
+        a.in0 = in0; a.out0 = out; a.g = geom; a.rhs = g->penta_rhs->p; a.lu = g->penta_lu->p;
+        a.periodic = d.periodic ? 1 : 0; a.ibc = d.periodic ? 0 : ibc;
+        std::copy(d.rhs_b, d.rhs_b + 32, a.rb);
+        std::copy(d.rhs_t, d.rhs_t + 35, a.rt);
+        hip_check(launch_penta1(a, g_stream), "k_penta1");
+        return;
+    }
     GenericArgs a;
     a.in0 = in0; a.in1 = d1in; a.out0 = out; a.g = geom;
     a.s = g->stencil(which, ibc);

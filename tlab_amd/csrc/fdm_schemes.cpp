@@ -65,6 +65,70 @@ void tridss1(int nmax, const double *a, const double *b, const double *c, double
 // fdm/fdm_com1_jacobian.f90:195-291 and fdm/fdm_com2_jacobian.f90:179-282
 // 1-based helper views: L(i,k), R(i,k) with i = 1..nx, k = 1..nd
 // ------------------------------------------------------------------------------------------------
+// utils/linear5.f90:156-203 (0-based n below = the reference's n - 1)
+void pentadfs2(int nmax, double *a, double *b, double *c, double *d, double *e) {
+    int n = nmax - 1;
+    e[n] = 1.0; d[n] = 1.0;
+    n = nmax - 2;
+    e[n] = 1.0;
+    d[n] = d[n] / c[n + 1];
+    c[n] = c[n] - d[n] * b[n + 1];
+    b[n] = b[n] - d[n] * a[n + 1];
+    for (n = nmax - 3; n >= 2; --n) {
+        e[n] = e[n] / c[n + 2];
+        d[n] = (d[n] - e[n] * b[n + 2]) / c[n + 1];
+        c[n] = c[n] - d[n] * b[n + 1] - e[n] * a[n + 2];
+        b[n] = b[n] - d[n] * a[n + 1];
+    }
+    n = 1;
+    e[n] = e[n] / c[n + 2];
+    d[n] = (d[n] - e[n] * b[n + 2]) / c[n + 1];
+    c[n] = c[n] - d[n] * b[n + 1] - e[n] * a[n + 2];
+    b[n] = b[n] - d[n] * a[n + 1];
+    a[n] = 1.0;
+    n = 0;
+    e[n] = e[n] / c[n + 2];
+    d[n] = (d[n] - e[n] * b[n + 2]) / c[n + 1];
+    c[n] = c[n] - d[n] * b[n + 1] - e[n] * a[n + 2];
+    b[n] = 1.0;
+    a[n] = 1.0;
+}
+
+// utils/linear5.f90:207-244, len = 1
+void pentadss2_1(int nmax, const double *a, const double *b, const double *c, const double *d, const double *e, double *f) {
+    int n = nmax - 2;
+    f[n] = f[n] - f[n + 1] * d[n];
+    for (n = nmax - 3; n >= 0; --n) f[n] = f[n] - f[n + 1] * d[n] - f[n + 2] * e[n];
+    f[0] = f[0] / c[0];
+    f[1] = (f[1] - f[0] * b[1]) / c[1];
+    for (n = 2; n < nmax; ++n) f[n] = (f[n] - f[n - 1] * b[n] - f[n - 2] * a[n]) / c[n];
+}
+
+// utils/linear5.f90:273-347
+void pentadpfs(int nmax, double *a, double *b, double *c, double *d, double *e, double *f, double *g) {
+    const double a0 = a[0], b0 = b[0], en = e[nmax - 1], dn = d[nmax - 1];
+    b[1] = b[1] - d[nmax - 1];
+    c[0] = c[0] - e[nmax - 1];
+    c[1] = c[1] - e[nmax - 1];
+    c[nmax - 2] = c[nmax - 2] - a[0];
+    c[nmax - 1] = c[nmax - 1] - a[0];
+    d[nmax - 2] = d[nmax - 2] - b[0];
+    a[0] = 0.0; a[1] = 0.0; b[0] = 0.0;
+    d[nmax - 1] = 0.0; e[nmax - 1] = 0.0; e[nmax - 2] = 0.0;
+    pentadfs2(nmax, a, b, c, d, e);
+    a[0] = a0; b[0] = b0; e[nmax - 1] = en; d[nmax - 1] = dn;
+    for (int n = 0; n < nmax; ++n) { f[n] = 0.0; g[n] = 0.0; }
+    f[0] = 1.0; f[nmax - 2] = 1.0;
+    g[1] = 1.0; g[nmax - 1] = 1.0;
+    pentadss2_1(nmax, a, b, c, d, e, f);
+    pentadss2_1(nmax, a, b, c, d, e, g);
+    const double m1 = e[nmax - 1] * f[0] + a[0] * f[nmax - 2] + b[0] * f[nmax - 1] + 1.0;
+    const double m2 = e[nmax - 1] * g[0] + a[0] * g[nmax - 2] + b[0] * g[nmax - 1];
+    const double m3 = d[nmax - 1] * f[0] + e[nmax - 1] * f[1] + a[0] * f[nmax - 1];
+    const double m4 = d[nmax - 1] * g[0] + e[nmax - 1] * g[1] + a[0] * g[nmax - 1] + 1.0;
+    if ((m1 * m4 - m2 * m3) < 1e-8) throw std::runtime_error("FDM_CreatePlan. Pendad - matrix M not invertible.");     // :333-336
+}
+
 namespace {
 
 inline double cshift(const double *v, int nx, int i /*0-based*/, int s) {  // Fortran cshift(v, s)(i) = v(i+s) circular
@@ -247,7 +311,7 @@ void fdm_bcs_neumann(int ibc, int nx, int ndl, double *lhs, int ndr, const doubl
 // ------------------------------------------------------------------------------------------------
 // fdm/fdm_derivative.f90
 // ------------------------------------------------------------------------------------------------
-void der1_initialize(DerTables &g, int nx, const double *dx, bool periodic, const int *bcs_cases, int ncases) {
+void der1_initialize(DerTables &g, int nx, const double *dx, bool periodic, const int *bcs_cases, int ncases, double penta_bc1_ext) {
     g.n = nx;
     g.periodic = periodic;
     g.lhs.assign((size_t)nx * 5, 0.0);
@@ -271,8 +335,20 @@ void der1_initialize(DerTables &g, int nx, const double *dx, bool periodic, cons
         create_system(false, nx, dx, nullptr, 3, 5, g.lhs.data(), g.rhs.data(), nullptr, coef,
                       periodic ? Coefs{} : Coefs{bc1, 6}, periodic ? Coefs{} : Coefs{bc2, 6}, Coefs{}, 0.0);
         break;
+    case FDM_COM6_JACOBIAN_PENTA: {  // com1 :136-192: pentadiagonal LHS, 7-diagonal RHS, alpha = 0.56
+        g.ndl = 5; g.ndr = 7;
+        coef[0] = 0.56;
+        coef[1] = 0.4 * (-1.0 / 3.0 + coef[0]);
+        coef[2] = 0.5 * (1.0 / 6.0) * (9.0 + coef[0] - 20.0 * coef[1]);
+        coef[3] = 0.25 * (1.0 / 15.0) * (-9.0 + 32.0 * coef[0] + 62.0 * coef[1]);
+        coef[4] = (1.0 / 6.0) * (1.0 / 10.0) * (1.0 - 3.0 * coef[0] + 12.0 * coef[1]);
+        const double bc3[8] = {1.0 / 3.0, 1.0 / 3.0, -1.0 / 36.0, -7.0 / 9.0, 0.0, 7.0 / 9.0, 1.0 / 36.0, 0.0};
+        create_system(false, nx, dx, nullptr, 5, 7, g.lhs.data(), g.rhs.data(), nullptr, coef,
+                      periodic ? Coefs{} : Coefs{bc1, 6}, periodic ? Coefs{} : Coefs{bc2, 6}, periodic ? Coefs{} : Coefs{bc3, 8}, penta_bc1_ext);
+        break;
+    }
     default:
-        throw std::runtime_error("first-derivative scheme not supported (CompactJacobian4/6 only)");
+        throw std::runtime_error("first-derivative scheme not supported (CompactJacobian4/6/6Penta only)");
     }
     if (periodic) {  // :193-211 (cos(wn) with coef(2) kept as in the reference)
         std::vector<double> wn;
@@ -281,13 +357,19 @@ void der1_initialize(DerTables &g, int nx, const double *dx, bool periodic, cons
             g.mwn[i] = 2.0 * (coef[2] * std::sin(wn[i]) + coef[3] * std::sin(2.0 * wn[i]) + coef[4] * std::sin(3.0 * wn[i])) /
                        (1.0 + 2.0 * coef[0] * std::cos(wn[i]) + 2.0 * coef[1] * std::cos(wn[i]));
     }
-    // LU (:78-119)
-    if (periodic) {
+    der1_factorize(g, bcs_cases, ncases);
+}
+
+// LU of the first-derivative system and its Neumann variants (fdm_derivative.f90:78-119); also fills rhs_b / rhs_t (FDM_Bcs_Neumann)
+void der1_factorize(DerTables &g, const int *bcs_cases, int ncases) {
+    const int nx = g.n;
+    if (g.periodic) {
         g.lu_cols = g.ndl + 2;
         g.lu.assign((size_t)nx * g.lu_cols, 0.0);
         std::copy(g.lhs.begin(), g.lhs.begin() + (size_t)nx * g.ndl, g.lu.begin());
         double *p = g.lu.data();
-        tridpfs(nx, p, p + nx, p + 2 * nx, p + 3 * nx, p + 4 * nx);
+        if (g.ndl == 3) tridpfs(nx, p, p + nx, p + 2 * nx, p + 3 * nx, p + 4 * nx);
+        else pentadpfs(nx, p, p + nx, p + 2 * nx, p + 3 * nx, p + 4 * nx, p + 5 * nx, p + 6 * nx);      // :90-91
     } else {
         g.lu_cols = 20;
         g.lu.assign((size_t)nx * 20, 0.0);
@@ -298,7 +380,8 @@ void der1_initialize(DerTables &g, int nx, const double *dx, bool periodic, cons
             int nmin = 0, nmax = nx;
             if (bcs_cases[ib] == BCS_ND || bcs_cases[ib] == BCS_NN) nmin++;
             if (bcs_cases[ib] == BCS_DN || bcs_cases[ib] == BCS_NN) nmax--;
-            tridfs(nmax - nmin, blk + nmin, blk + nx + nmin, blk + 2 * nx + nmin);
+            if (g.ndl == 3) tridfs(nmax - nmin, blk + nmin, blk + nx + nmin, blk + 2 * nx + nmin);
+            else pentadfs2(nmax - nmin, blk + nmin, blk + nx + nmin, blk + 2 * nx + nmin, blk + 3 * nx + nmin, blk + 4 * nx + nmin);      // :112-113
         }
     }
 }
@@ -361,7 +444,8 @@ void der2_initialize(DerTables &g, int nx, const double *dx2, bool periodic, boo
         g.lu.assign((size_t)nx * g.lu_cols, 0.0);
         std::copy(g.lhs.begin(), g.lhs.begin() + (size_t)nx * g.ndl, g.lu.begin());
         double *p = g.lu.data();
-        tridpfs(nx, p, p + nx, p + 2 * nx, p + 3 * nx, p + 4 * nx);
+        if (g.ndl == 3) tridpfs(nx, p, p + nx, p + 2 * nx, p + 3 * nx, p + 4 * nx);
+        else pentadpfs(nx, p, p + nx, p + 2 * nx, p + 3 * nx, p + 4 * nx, p + 5 * nx, p + 6 * nx);      // :90-91
     } else {
         g.lu_cols = g.ndl;
         g.lu.assign((size_t)nx * g.lu_cols, 0.0);
@@ -387,6 +471,17 @@ void der1_matmul1(const DerTables &g, int ibc, const double *u, double *f) {
         for (int n = 3; n <= nx - 2; ++n) F(n) = U(n + 1) - U(n - 1);
         F(nx - 1) = U(nx - 2) * RI(nx - 1, 1) + U(nx - 1) * RI(nx - 1, 2) + U(nx) * RI(nx - 1, 3);
         F(nx) = U(nx - 2) * RI(nx, 3) + U(nx - 1) * RI(nx, 1) + U(nx) * RI(nx, 2);
+    } else if (g.ndr == 7) {  // MatMul_7d_antisym :491-558 (biased rows)
+        const double r6 = RI(5, 6), r7 = RI(5, 7);
+        F(1) = U(1) * RI(1, 4) + U(2) * RI(1, 5) + U(3) * RI(1, 6) + U(4) * RI(1, 7) + U(5) * RI(1, 1);
+        F(2) = U(1) * RI(2, 3) + U(2) * RI(2, 4) + U(3) * RI(2, 5) + U(4) * RI(2, 6) + U(5) * RI(2, 7);
+        F(3) = U(1) * RI(3, 2) + U(2) * RI(3, 3) + U(3) * RI(3, 4) + U(4) * RI(3, 5) + U(5) * RI(3, 6) + U(6) * RI(3, 7);
+        F(4) = U(1) * RI(4, 1) + U(2) * RI(4, 2) + U(3) * RI(4, 3) + U(4) * RI(4, 4) + U(5) * RI(4, 5) + U(6) * RI(4, 6) + U(7) * RI(4, 7);
+        for (int n = 5; n <= nx - 4; ++n) F(n) = U(n + 1) - U(n - 1) + r6 * (U(n + 2) - U(n - 2)) + r7 * (U(n + 3) - U(n - 3));
+        F(nx - 3) = U(nx - 6) * RI(nx - 3, 1) + U(nx - 5) * RI(nx - 3, 2) + U(nx - 4) * RI(nx - 3, 3) + U(nx - 3) * RI(nx - 3, 4) + U(nx - 2) * RI(nx - 3, 5) + U(nx - 1) * RI(nx - 3, 6) + U(nx) * RI(nx - 3, 7);
+        F(nx - 2) = U(nx - 5) * RI(nx - 2, 1) + U(nx - 4) * RI(nx - 2, 2) + U(nx - 3) * RI(nx - 2, 3) + U(nx - 2) * RI(nx - 2, 4) + U(nx - 1) * RI(nx - 2, 5) + U(nx) * RI(nx - 2, 6);
+        F(nx - 1) = U(nx - 4) * RI(nx - 1, 1) + U(nx - 3) * RI(nx - 1, 2) + U(nx - 2) * RI(nx - 1, 3) + U(nx - 1) * RI(nx - 1, 4) + U(nx) * RI(nx - 1, 5);
+        F(nx) = U(nx - 4) * RI(nx, 7) + U(nx - 3) * RI(nx, 1) + U(nx - 2) * RI(nx, 2) + U(nx - 1) * RI(nx, 3) + U(nx) * RI(nx, 4);
     } else {  // MatMul_5d_antisym :359-419
         const double r5 = RI(4, 5);
         F(1) = U(1) * RI(1, 3) + U(2) * RI(1, 4) + U(3) * RI(1, 5) + U(4) * RI(1, 1);
@@ -430,7 +525,7 @@ void der2_matmul1(const DerTables &g, int ibc, const double *u, double *f) {
 // fdm/fdm.f90:143-252 FDM_CreatePlan
 // ------------------------------------------------------------------------------------------------
 void fdm_create_plan(FdmTables &g, int nx, const double *nodes, bool periodic, bool uniform, int mode1, int mode2,
-                     double hyper_bc1_ext) {
+                     double hyper_bc1_ext, double penta_bc1_ext) {
     if (periodic && mode1 == FDM_COM4_DIRECT) mode1 = FDM_COM4_JACOBIAN;  // :155-158
     if (periodic && mode1 == FDM_COM6_DIRECT) mode1 = FDM_COM6_JACOBIAN;
     if (periodic && mode2 == FDM_COM4_DIRECT) mode2 = FDM_COM4_JACOBIAN;
@@ -449,12 +544,16 @@ void fdm_create_plan(FdmTables &g, int nx, const double *nodes, bool periodic, b
     // first derivative: Jacobian dx/ds from a unit-grid derivative of the node positions (:194-201)
     std::vector<double> ones(nx, 1.0), tmp(nx);
     const int dd[1] = {BCS_DD};
-    der1_initialize(g.der1, nx, ones.data(), false, dd, 1);
+    der1_initialize(g.der1, nx, ones.data(), false, dd, 1, penta_bc1_ext);
     der1_matmul1(g.der1, BCS_DD, nodes, tmp.data());
-    tridss1(nx, g.der1.lu.data(), g.der1.lu.data() + nx, g.der1.lu.data() + 2 * nx, tmp.data());
+    {
+        const double *lu = g.der1.lu.data();
+        if (g.der1.ndl == 3) tridss1(nx, lu, lu + nx, lu + 2 * nx, tmp.data());
+        else pentadss2_1(nx, lu, lu + nx, lu + 2 * nx, lu + 3 * nx, lu + 4 * nx, tmp.data());
+    }
     std::copy(tmp.begin(), tmp.end(), g.jac.begin());
     const int all[4] = {BCS_DD, BCS_ND, BCS_DN, BCS_NN};
-    der1_initialize(g.der1, nx, g.jac.data(), periodic, all, 4);  // :207
+    der1_initialize(g.der1, nx, g.jac.data(), periodic, all, 4, penta_bc1_ext);  // :207
     if (periodic)
         for (int i = 0; i < nx; ++i) g.der1.mwn[i] = g.der1.mwn[i] / g.jac[0];  // :209
 

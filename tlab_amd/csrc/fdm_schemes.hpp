@@ -44,13 +44,20 @@ void tridfs(int nmax, double *a, double *b, double *c);
 void tridpfs(int nmax, double *a, double *b, double *c, double *d, double *e);
 // utils/linear3.f90:56-150, :321-442 for a single line (used for the Jacobian at plan creation, fdm.f90:201,224)
 void tridss1(int nmax, const double *a, const double *b, const double *c, double *f);
+// utils/linear5.f90:156-203 PENTADFS2, :273-347 PENTADPFS (f, g: the two Woodbury vectors), :207-244 PENTADSS2 for a single line
+void pentadfs2(int nmax, double *a, double *b, double *c, double *d, double *e);
+void pentadpfs(int nmax, double *a, double *b, double *c, double *d, double *e, double *f, double *g);
+void pentadss2_1(int nmax, const double *a, const double *b, const double *c, const double *d, const double *e, double *f);
 
 // fdm/fdm_base.f90:194-300
 void fdm_bcs_neumann(int ibc, int n, int ndl, double *lhs /*(n,ndl)*/, int ndr, const double *rhs /*(n,>=ndr) ld n*/,
                      double *rhs_b, double *rhs_t);
 
 // fdm/fdm_derivative.f90:63-142, :282-333 (CreateSystem + LU)
-void der1_initialize(DerTables &g, int n, const double *dx, bool periodic, const int *bcs_cases, int ncases);
+// penta_bc1_ext: the out-of-bounds coefficient the reference reads for the wall row of CompactJacobian6Penta (fdm_com1_jacobian.f90:237 with
+// icmax = 4: coef_bc1(7) of a 6-element array; 1/6 in the flang-built reference, the twin of hyper_bc1_ext)
+void der1_initialize(DerTables &g, int n, const double *dx, bool periodic, const int *bcs_cases, int ncases, double penta_bc1_ext = 1.0 / 6.0);
+void der1_factorize(DerTables &g, const int *bcs_cases, int ncases);      // the LU part of der1_initialize, for host-built lhs / rhs tables
 void der2_initialize(DerTables &g, int n, const double *dx2 /*(n,2)*/, bool periodic, bool uniform, double hyper_bc1_ext);
 
 // RHS product B*u for one line, reference operation order (fdm/fdm_matmul.f90); used at plan creation only
@@ -59,6 +66,6 @@ void der2_matmul1(const DerTables &g, int ibc, const double *u, double *f);
 
 // fdm/fdm.f90:143-252
 void fdm_create_plan(FdmTables &g, int n, const double *nodes, bool periodic, bool uniform, int mode1, int mode2,
-                     double hyper_bc1_ext);
+                     double hyper_bc1_ext, double penta_bc1_ext = 1.0 / 6.0);
 
 }  // namespace tlab

@@ -254,12 +254,12 @@ __device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)
 }
 
 // LV / LV2: table form of the first- / second-derivative system (see xcoef)
-template <int M, int MODE, int LV, int WPL, int LV2 = LV>
-__global__ void __launch_bounds__(256) k_xline(XLineArgs a) {
+template <int M, int MODE, int LV, int WPL, int LV2 = LV, int TPB = 256>
+__global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
     extern __shared__ double xlds[];
     constexpr bool NEED1 = (MODE != MODE_P2);
     constexpr bool NEED2 = (MODE != MODE_P1);
-    constexpr int P = 64 * WPL, LPB = 4 / WPL;           // chunks per line, lines per workgroup
+    constexpr int P = 64 * WPL, LPB = TPB / 64 / WPL;    // chunks per line, lines per workgroup
     constexpr int TAB = 5 * M * P;                        // table entries per system
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
@@ -736,6 +736,96 @@ __global__ void __launch_bounds__(256) k_generic(GenericArgs a) {
 // pointwise / data-movement kernels
 // ============================================================================================
 // out = nu * out - vel * d1   (OPR_Burgers_1D epilogue, opr_burgers.f90:510-516)
+// ============================================================================================
+// k_penta1 : CompactJacobian6Penta first derivative, one thread per line, reference operation order
+// ============================================================================================
+__global__ void __launch_bounds__(256) k_penta1(PentaArgs a) {
+    const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= a.g.nlines) return;
+    const int n = a.g.n;
+    const long long rs = a.g.row_stride;
+    const long long base = (line / a.g.lines_inner) * a.g.outer_stride + (line % a.g.lines_inner);
+    const double *u = a.in0 + base;
+    double *f = a.out0 + base;
+#define U(i) u[(long long)((i)-1) * rs]
+#define F(i) f[(long long)((i)-1) * rs]
+#define RI(i, k) a.rhs[((i)-1) + (size_t)n * ((k)-1)]
+#define RB(j, c) a.rb[((j)-1) + 4 * (c)]
+#define RT(r, c) a.rt[(r) + 5 * ((c)-1)]
+    const double r6 = RI(5, 6), r7 = RI(5, 7);
+    const int ibc = a.periodic ? -1 : a.ibc;
+    const bool nb = (ibc == 1 || ibc == 3), nt = (ibc == 2 || ibc == 3);
+    int nmin = 1, nmax = n;
+    if (nb) { F(1) = 0.0; nmin = 2; }            // homogeneous Neumann (fdm_derivative.f90:238-246)
+    if (nt) { F(n) = 0.0; nmax = n - 1; }
+    // ---- MatMul_7d_antisym ----
+    if (ibc == -1) {
+        F(1) = U(2) - U(n) + r6 * (U(3) - U(n - 1)) + r7 * (U(4) - U(n - 2));
+        F(2) = U(3) - U(1) + r6 * (U(4) - U(n)) + r7 * (U(5) - U(n - 1));
+        F(3) = U(4) - U(2) + r6 * (U(5) - U(1)) + r7 * (U(6) - U(n));
+        F(4) = U(5) - U(3) + r6 * (U(6) - U(2)) + r7 * (U(7) - U(1));
+    } else if (nb) {
+        const double f1 = 0.0;
+        F(2) = f1 * RB(2, 3) + U(2) * RB(2, 4) + U(3) * RB(2, 5) + U(4) * RB(2, 6) + U(5) * RB(2, 7);
+        F(3) = f1 * RB(3, 2) + U(2) * RB(3, 3) + U(3) * RB(3, 4) + U(4) * RB(3, 5) + U(5) * RB(3, 6) + U(6) * RB(3, 7);
+        F(4) = f1 * RB(4, 1) + U(2) * RB(4, 2) + U(3) * RB(4, 3) + U(4) * RB(4, 4) + U(5) * RB(4, 5) + U(6) * RB(4, 6) + U(7) * RB(4, 7);
+    } else {
+        F(1) = U(1) * RI(1, 4) + U(2) * RI(1, 5) + U(3) * RI(1, 6) + U(4) * RI(1, 7) + U(5) * RI(1, 1);
+        F(2) = U(1) * RI(2, 3) + U(2) * RI(2, 4) + U(3) * RI(2, 5) + U(4) * RI(2, 6) + U(5) * RI(2, 7);
+        F(3) = U(1) * RI(3, 2) + U(2) * RI(3, 3) + U(3) * RI(3, 4) + U(4) * RI(3, 5) + U(5) * RI(3, 6) + U(6) * RI(3, 7);
+        F(4) = U(1) * RI(4, 1) + U(2) * RI(4, 2) + U(3) * RI(4, 3) + U(4) * RI(4, 4) + U(5) * RI(4, 5) + U(6) * RI(4, 6) + U(7) * RI(4, 7);
+    }
+    for (int i = 5; i <= n - 4; ++i) F(i) = U(i + 1) - U(i - 1) + r6 * (U(i + 2) - U(i - 2)) + r7 * (U(i + 3) - U(i - 3));
+    if (ibc == -1) {
+        F(n - 3) = U(n - 2) - U(n - 4) + r6 * (U(n - 1) - U(n - 5)) + r7 * (U(n) - U(n - 6));
+        F(n - 2) = U(n - 1) - U(n - 3) + r6 * (U(n) - U(n - 4)) + r7 * (U(1) - U(n - 5));
+        F(n - 1) = U(n) - U(n - 2) + r6 * (U(1) - U(n - 3)) + r7 * (U(2) - U(n - 4));
+        F(n) = U(1) - U(n - 1) + r6 * (U(2) - U(n - 2)) + r7 * (U(3) - U(n - 3));
+    } else if (nt) {
+        const double fn = 0.0;
+        F(n - 3) = U(n - 6) * RT(1, 1) + U(n - 5) * RT(1, 2) + U(n - 4) * RT(1, 3) + U(n - 3) * RT(1, 4) + U(n - 2) * RT(1, 5) + U(n - 1) * RT(1, 6) + fn * RT(1, 7);
+        F(n - 2) = U(n - 5) * RT(2, 1) + U(n - 4) * RT(2, 2) + U(n - 3) * RT(2, 3) + U(n - 2) * RT(2, 4) + U(n - 1) * RT(2, 5) + fn * RT(2, 6);
+        F(n - 1) = U(n - 4) * RT(3, 1) + U(n - 3) * RT(3, 2) + U(n - 2) * RT(3, 3) + U(n - 1) * RT(3, 4) + fn * RT(3, 5);
+    } else {
+        F(n - 3) = U(n - 6) * RI(n - 3, 1) + U(n - 5) * RI(n - 3, 2) + U(n - 4) * RI(n - 3, 3) + U(n - 3) * RI(n - 3, 4) + U(n - 2) * RI(n - 3, 5) + U(n - 1) * RI(n - 3, 6) + U(n) * RI(n - 3, 7);
+        F(n - 2) = U(n - 5) * RI(n - 2, 1) + U(n - 4) * RI(n - 2, 2) + U(n - 3) * RI(n - 2, 3) + U(n - 2) * RI(n - 2, 4) + U(n - 1) * RI(n - 2, 5) + U(n) * RI(n - 2, 6);
+        F(n - 1) = U(n - 4) * RI(n - 1, 1) + U(n - 3) * RI(n - 1, 2) + U(n - 2) * RI(n - 1, 3) + U(n - 1) * RI(n - 1, 4) + U(n) * RI(n - 1, 5);
+        F(n) = U(n - 4) * RI(n, 7) + U(n - 3) * RI(n, 1) + U(n - 2) * RI(n, 2) + U(n - 1) * RI(n, 3) + U(n) * RI(n, 4);
+    }
+    // ---- PENTADSS2 on rows nmin .. nmax with the LU columns of the variant (offset nmin, fdm_derivative.f90:270-272) ----
+    const int ip = a.periodic ? 0 : a.ibc * 5;
+    const double *A = a.lu + (size_t)n * (ip + 0) + (nmin - 1), *B = a.lu + (size_t)n * (ip + 1) + (nmin - 1), *C = a.lu + (size_t)n * (ip + 2) + (nmin - 1);
+    const double *D = a.lu + (size_t)n * (ip + 3) + (nmin - 1), *E = a.lu + (size_t)n * (ip + 4) + (nmin - 1);
+    const int m = nmax - nmin + 1;
+#define G(i) f[(long long)((i) + nmin - 2) * rs]      /* 1-based inside the reduced system */
+    G(m - 1) = G(m - 1) - G(m) * D[m - 2];
+    for (int i = m - 2; i >= 1; --i) G(i) = G(i) - G(i + 1) * D[i - 1] - G(i + 2) * E[i - 1];
+    G(1) = G(1) / C[0];
+    G(2) = (G(2) - G(1) * B[1]) / C[1];
+    for (int i = 3; i <= m; ++i) G(i) = (G(i) - G(i - 1) * B[i - 1] - G(i - 2) * A[i - 1]) / C[i - 1];
+    if (a.periodic) {        // PENTADPSS :352-411 : Sherman-Morrison-Woodbury correction with the two stored vectors
+        const double *Fv = a.lu + (size_t)n * 5, *Gv = a.lu + (size_t)n * 6;
+        const double m1 = E[n - 1] * Fv[0] + A[0] * Fv[n - 2] + B[0] * Fv[n - 1] + 1.0;
+        const double m2 = E[n - 1] * Gv[0] + A[0] * Gv[n - 2] + B[0] * Gv[n - 1];
+        const double m3 = D[n - 1] * Fv[0] + E[n - 1] * Fv[1] + A[0] * Fv[n - 1];
+        const double m4 = D[n - 1] * Gv[0] + E[n - 1] * Gv[1] + A[0] * Gv[n - 1] + 1.0;
+        const double di = 1 / (m1 * m4 - m2 * m3);
+        const double d11 = di * (m4 * E[n - 1] - m2 * D[n - 1]), d12 = di * (m4 * B[0] - m2 * A[0]), d13 = di * m4 * A[0], d14 = di * m2 * E[n - 1];
+        const double d21 = di * (m1 * D[n - 1] - m3 * E[n - 1]), d22 = di * (m1 * A[0] - m3 * B[0]), d23 = di * m3 * A[0], d24 = di * m1 * E[n - 1];
+        const double dummy1 = d11 * F(1) + d12 * F(n) + d13 * F(n - 1) - d14 * F(2);
+        const double dummy2 = d21 * F(1) + d22 * F(n) - d23 * F(n - 1) + d24 * F(2);
+        for (int i = 3; i <= n - 3; ++i) F(i) = F(i) - dummy1 * Fv[i - 1] - dummy2 * Gv[i - 1];
+        for (int i = 1; i <= 2; ++i) F(i) = F(i) - dummy1 * Fv[i - 1] - dummy2 * Gv[i - 1];
+        for (int i = n - 2; i <= n; ++i) F(i) = F(i) - dummy1 * Fv[i - 1] - dummy2 * Gv[i - 1];
+    }
+#undef U
+#undef F
+#undef RI
+#undef RB
+#undef RT
+#undef G
+}
+
 __global__ void __launch_bounds__(256) k_burgers_epilogue(double *__restrict__ out, const double *__restrict__ vel,
                                                           const double *__restrict__ d1, double nu, long long ntot) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -768,11 +858,11 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a,
 // ============================================================================================
 static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
 
-template <int M, int LV, int WPL, int LV2 = LV>
+template <int M, int LV, int WPL, int LV2 = LV, int TPB = 256>
 static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
-    constexpr int P = 64 * WPL, LPB = 4 / WPL;
+    constexpr int P = 64 * WPL, LPB = TPB / 64 / WPL;
     const long long blocks_needed = (a.nlines + LPB - 1) / LPB;
-    const int grid = imin(blocks_needed, 256 * 8);
+    const int grid = imin(blocks_needed, 256 * 8 * 256 / TPB);
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
     auto tabbytes = [](int lv) { return lv == 1 ? (size_t)5 * M * P * sizeof(double) : lv == 2 ? (size_t)5 * M * P * sizeof(float) : (size_t)0; };
     const size_t lds = (mode != MODE_P2 ? tabbytes(LV) : 0) + (mode != MODE_P1 ? tabbytes(LV2) : 0) + (WPL > 1 ? (size_t)LPB * 14 * WPL * sizeof(double) : 0);
@@ -787,19 +877,26 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     ProfScope ps(names[mode], st, bytes);
     switch (mode) {
-    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2>), dim3(grid), dim3(256), lds, st, a); break;
+    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_penta1(const PentaArgs &a, hipStream_t st) {
+    const double pts = (double)a.g.nlines * a.g.n;
+    ProfScope ps("k_penta1", st, pts * 16.0);
+    hipLaunchKernelGGL(k_penta1, dim3((unsigned)((a.g.nlines + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -813,7 +910,8 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
     // load, a conversion and an add per coefficient, which is why doubles are preferred
     if (chunks == 128 && n == 1024) return launch_xline_m<8, 1, 2, 1>(mode, a, st);
     if (chunks == 256 && n == 2048)
-        return (mode == MODE_P1 || mode == MODE_P2) ? launch_xline_m<8, 1, 4, 1>(mode, a, st) : launch_xline_m<8, 1, 4, 2>(mode, a, st);
+        // one system (80 KB of tables): two lines per 512-thread workgroup share them, i.e. 8 waves per CU instead of 4
+        return (mode == MODE_P1 || mode == MODE_P2) ? launch_xline_m<8, 1, 4, 1, 512>(mode, a, st) : launch_xline_m<8, 1, 4, 2>(mode, a, st);
     if (chunks != 64) return hipErrorInvalidValue;
     switch (n) {
     case 256: return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);

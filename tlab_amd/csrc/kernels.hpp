@@ -75,6 +75,20 @@ struct GenericArgs {        // k_generic: any n
     JacCorrDev jc;
 };
 
+// k_penta1: first derivative of CompactJacobian6Penta (pentadiagonal LHS, 7-diagonal antisymmetric RHS), one thread per line, the
+// reference's own operation sequence: MatMul_7d_antisym (fdm_matmul.f90:491-558) + PENTADSS2 / PENTADPSS (utils/linear5.f90:207-411)
+struct PentaArgs {
+    const double *in0;
+    double *out0;
+    LineGeom g;
+    const double *rhs;      // [7][n] device, column-major g%der1%rhs
+    const double *lu;       // [7][n] periodic | [20][n] (4 Neumann variants x 5 columns), exactly g%der1%lu
+    int periodic, ibc;
+    double rb[4 * 8];       // rhs_b(4,0:7): [(j-1) + 4 c]
+    double rt[5 * 7];       // rhs_t(0:4,7): [r + 5 (c-1)]
+};
+hipError_t launch_penta1(const PentaArgs &a, hipStream_t st);
+
 bool xline_supported(int n);
 int rtile_chunk(int n);
 void rtile_force_chunk(int m);

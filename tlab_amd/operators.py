@@ -17,7 +17,7 @@ from .lib import load, check, TlabError, c_vp
 OPR_P1, OPR_P2, OPR_P2_P1 = 1, 2, 3
 OPR_B_SELF, OPR_B_U_IN = 0, 1
 BCS_DD, BCS_ND, BCS_DN, BCS_NN = 0, 1, 2, 3
-FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER = 4, 6, 7
+FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN_PENTA, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER = 4, 5, 6, 7
 FDM_COM6_DIRECT, FDM_COM4_DIRECT = 16, 17
 
 _initialised = False
@@ -73,17 +73,17 @@ class FdmPlan:
               "tlab_fdm_plan_create")
 
     @classmethod
-    def from_arrays(cls, n, periodic, need_1der, lhs1, rhs1, lhs2, rhs2):
+    def from_arrays(cls, n, periodic, need_1der, lhs1, rhs1, lhs2, rhs2, ndl1=3):
         """lhs*/rhs*: numpy arrays [row, diagonal] (as oracle / golden files hold them); rhs2 includes the 3
-        Jacobian-correction columns after its ndr2 diagonals."""
+        Jacobian-correction columns after its ndr2 diagonals.  ndl1 = 5 with 7 rhs1 diagonals: CompactJacobian6Penta."""
         self = cls.__new__(cls)
         self.size, self.periodic, self.uniform = int(n), bool(periodic), not bool(need_1der)
         self._h = c_vp(0)
         ndr1, ndr2 = rhs1.shape[1], rhs2.shape[1] - 3
-        f = [np.asfortranarray(a, dtype=np.float64) for a in (lhs1[:, :3], rhs1, lhs2[:, :3], rhs2)]
+        f = [np.asfortranarray(a, dtype=np.float64) for a in (lhs1[:, :ndl1], rhs1, lhs2[:, :3], rhs2)]
         dp = ctypes.POINTER(ctypes.c_double)
         check(load().tlab_fdm_plan_create_from_arrays(ctypes.byref(self._h), self.size, int(periodic), int(need_1der),
-                                                      3, ndr1, f[0].ctypes.data_as(dp), f[1].ctypes.data_as(dp),
+                                                      int(ndl1), ndr1, f[0].ctypes.data_as(dp), f[1].ctypes.data_as(dp),
                                                       3, ndr2, f[2].ctypes.data_as(dp), f[3].ctypes.data_as(dp)),
               "tlab_fdm_plan_create_from_arrays")
         return self
