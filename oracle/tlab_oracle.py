@@ -173,6 +173,12 @@ def pentadpfs(a, b, c, d, e, f, g):
     ff, gg = f.reshape(nmax, 1), g.reshape(nmax, 1)
     pentadss2(a, b, c, d, e, ff)
     pentadss2(a, b, c, d, e, gg)
+    m1 = e[nmax - 1] * f[0] + a[0] * f[nmax - 2] + b[0] * f[nmax - 1] + 1.0
+    m2 = e[nmax - 1] * g[0] + a[0] * g[nmax - 2] + b[0] * g[nmax - 1]
+    m3 = d[nmax - 1] * f[0] + e[nmax - 1] * f[1] + a[0] * f[nmax - 1]
+    m4 = d[nmax - 1] * g[0] + e[nmax - 1] * g[1] + a[0] * g[nmax - 1] + 1.0
+    if (m1 * m4 - m2 * m3) < 1e-8:                     # :340-344: TLab_Stop(DNS_ERROR_PENTADP)
+        raise ValueError("FDM_CreatePlan. Pendad - matrix M not invertible.")
 
 
 def pentadpss(a, b, c, d, e, f, g, frc):

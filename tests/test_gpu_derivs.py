@@ -91,7 +91,7 @@ def test_golden_vectors(T, path):
         run_all_ops(T, O, d, gp, op, nx, ny, nz, (0, 1, 2, 3) if d == 2 else (0,), g["u"], g["v"], float(g["visc"]), expect=g, tag=path)
 
 
-@pytest.mark.parametrize("nx,ny,nz", [(96, 64, 40), (256, 130, 6)])
+@pytest.mark.parametrize("nx,ny,nz", [(96, 64, 40), (256, 130, 12)])
 def test_penta_first_derivative(T, nx, ny, nz):
     """SpaceOrder1 = CompactJacobian6Penta (fdm_com1_jacobian.f90:136-192; k_penta1, one line per thread) in the three directions, all
     operator types and the Burgers operator, against the oracle (itself bitwise equal to the reference for this scheme, tests/golden/

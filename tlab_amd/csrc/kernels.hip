@@ -911,7 +911,13 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
     if (chunks == 128 && n == 1024) return launch_xline_m<8, 1, 2, 1>(mode, a, st);
     if (chunks == 256 && n == 2048)
         // one system (80 KB of tables): two lines per 512-thread workgroup share them, i.e. 8 waves per CU instead of 4
-        return (mode == MODE_P1 || mode == MODE_P2) ? launch_xline_m<8, 1, 4, 1, 512>(mode, a, st) : launch_xline_m<8, 1, 4, 2>(mode, a, st);
+    {
+        static const int tpb = [] { const char *e = getenv("TLAB_XLINE_TPB"); return e ? atoi(e) : 0; }();
+        const bool one = (mode == MODE_P1 || mode == MODE_P2);
+        if (tpb == 256) return one ? launch_xline_m<8, 1, 4, 1, 256>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 256>(mode, a, st);
+        if (tpb == 1024) return one ? launch_xline_m<8, 1, 4, 1, 1024>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 1024>(mode, a, st);
+        return one ? launch_xline_m<8, 1, 4, 1, 512>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 512>(mode, a, st);
+    }
     if (chunks != 64) return hipErrorInvalidValue;
     switch (n) {
     case 256: return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);
