@@ -93,7 +93,9 @@ int tlab_fdm_plan_create_from_arrays(tlab_fdm_plan_t *out, int n, int periodic, 
 int tlab_fdm_plan_set_aux(tlab_fdm_plan_t plan, const double *mwn1, const double *mwn2, const double *jac, const double *nodes);
 /* mode_fdm of the two derivatives of a host-built plan (fdm_derivative.f90:52-58).  FDM_COM6_DIRECT (16) / FDM_COM4_DIRECT (17) as mode2
  * make rhs2 a per-row pentadiagonal operator (MatMul_5d) -- [Main] SpaceOrder2 = CompactDirect6 of examples/Case81-93; the coefficient
- * tables of fdm_comx_direct.f90 are the host's (tlab_fdm_plan_create_from_arrays).  Direct FIRST derivatives: TLAB_EUNSUPPORTED. */
+ * tables of fdm_comx_direct.f90 are the host's (tlab_fdm_plan_create_from_arrays).  As mode1 (SpaceOrder1 = CompactDirect4 / CompactDirect6,
+ * FDM_C1N4_Direct / FDM_C1N6_Direct: 3 / 5 per-row RHS diagonals, MatMul_3d / MatMul_5d with the Neumann-reduced rows of FDM_Bcs_Neumann)
+ * in non-periodic directions (periodic ones fall back to the Jacobian schemes, fdm.f90:155-158). */
 int tlab_fdm_plan_set_scheme(tlab_fdm_plan_t plan, int mode1, int mode2);
 int tlab_fdm_plan_destroy(tlab_fdm_plan_t p);
 

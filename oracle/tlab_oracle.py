@@ -652,26 +652,42 @@ def matmul_5d_sym(rhs, u, f, ibc):
             f[nx - 1] = 0.0
 
 
-def matmul_5d(rhs, u, f, ibc=BCS_DD):
+def matmul_5d(rhs, u, f, ibc=BCS_DD, rhs_b=None, rhs_t=None):
     """fdm/fdm_matmul.f90:265-319 MatMul_5d (B pentadiagonal with per-row coefficients, first upper diagonal = 1 in the interior;
-    the direct schemes of fdm_comx_direct.f90).  Only the branches without boundary data (ibc = BCS_DD / none) are restated:
-    FDM_Der2_Solve calls it with BCS_DD for non-periodic directions, and periodic directions never carry a direct scheme (fdm.f90:155-158)."""
+    the direct schemes of fdm_comx_direct.f90).  f[0] / f[nx-1] carry the boundary value where ibc says so (:283-288, :303-308).
+    Returns (bcs_b, bcs_t) (None when not applicable)."""
     nx = rhs.shape[0]
     r1, r2, r3, r4, r5 = (rhs[:, k] for k in range(5))
-    f[0] = u[0] * r3[0] + u[1] * r4[0] + u[2] * r5[0] + u[3] * r1[0]
-    f[1] = u[0] * r2[1] + u[1] * r3[1] + u[2] * r4[1] + u[3] * r5[1]
-    f[2] = u[0] * r1[2] + u[1] * r2[2] + u[2] * r3[2] + u[3] * r4[2] + u[4] * r5[2]
-    f[3] = u[1] * r1[3] + u[2] * r2[3] + u[3] * r3[3] + u[4] * r4[3] + u[5] * r5[3]
+    bcs_b = bcs_t = None
+    if ibc in (BCS_MIN, BCS_BOTH):
+        b = rhs_b
+        bcs_b = f[0] * b[0, 3] + u[1] * b[0, 4] + u[2] * b[0, 5] + u[3] * b[0, 1]
+        f[1] = f[0] * b[1, 2] + u[1] * b[1, 3] + u[2] * b[1, 4] + u[3] * b[1, 5]
+        f[2] = f[0] * b[2, 1] + u[1] * b[2, 2] + u[2] * b[2, 3] + u[3] * b[2, 4] + u[4] * b[2, 5]
+        f[3] = f[0] * b[3, 0] + u[1] * b[3, 1] + u[2] * b[3, 2] + u[3] * b[3, 3] + u[4] * b[3, 4] + u[5] * b[3, 5]
+    else:
+        f[0] = u[0] * r3[0] + u[1] * r4[0] + u[2] * r5[0] + u[3] * r1[0]
+        f[1] = u[0] * r2[1] + u[1] * r3[1] + u[2] * r4[1] + u[3] * r5[1]
+        f[2] = u[0] * r1[2] + u[1] * r2[2] + u[2] * r3[2] + u[3] * r4[2] + u[4] * r5[2]
+        f[3] = u[1] * r1[3] + u[2] * r2[3] + u[3] * r3[3] + u[4] * r4[3] + u[5] * r5[3]
     for n in range(4, nx - 4):
         f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] + u[n + 2] * r5[n]
-    n = nx - 4
-    f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n] + u[n + 2] * r5[n]
-    n = nx - 3
-    f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n] + u[n + 2] * r5[n]
-    n = nx - 2
-    f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n]
-    n = nx - 1
-    f[n] = u[n - 3] * r5[n] + u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n]
+    if ibc in (BCS_MAX, BCS_BOTH):
+        t = rhs_t                      # rhs_t(0:, 1:) -> [row, col - 1]
+        f[nx - 4] = u[nx - 6] * t[0, 0] + u[nx - 5] * t[0, 1] + u[nx - 4] * t[0, 2] + u[nx - 3] * t[0, 3] + u[nx - 2] * t[0, 4] + f[nx - 1] * t[0, 5]
+        f[nx - 3] = u[nx - 5] * t[1, 0] + u[nx - 4] * t[1, 1] + u[nx - 3] * t[1, 2] + u[nx - 2] * t[1, 3] + f[nx - 1] * t[1, 4]
+        f[nx - 2] = u[nx - 4] * t[2, 0] + u[nx - 3] * t[2, 1] + u[nx - 2] * t[2, 2] + f[nx - 1] * t[2, 3]
+        bcs_t = u[nx - 4] * t[3, 4] + u[nx - 3] * t[3, 0] + u[nx - 2] * t[3, 1] + f[nx - 1] * t[3, 2]
+    else:
+        n = nx - 4
+        f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n] + u[n + 2] * r5[n]
+        n = nx - 3
+        f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n] + u[n + 2] * r5[n]
+        n = nx - 2
+        f[n] = u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n] + u[n + 1] * r4[n]
+        n = nx - 1
+        f[n] = u[n - 3] * r5[n] + u[n - 2] * r1[n] + u[n - 1] * r2[n] + u[n] * r3[n]
+    return bcs_b, bcs_t
 
 
 def matmul_7d_sym(rhs, u, f, ibc):
@@ -787,7 +803,14 @@ def der1_initialize(g, dx, periodic, bcs_cases):
 
 
 def der1_matmul(g, u, f, ibc):
-    if g.nb_diag[1] == 3:
+    if getattr(g, "direct", False):          # FDM_COM4_DIRECT / FDM_COM6_DIRECT: g%matmul => MatMul_3d / MatMul_5d (fdm_derivative.f90:123-129)
+        if g.nb_diag[1] == 3:
+            matmul_3d(g.rhs, u, f, ibc, g.rhs_b, g.rhs_t)
+        elif g.nb_diag[1] == 5:
+            matmul_5d(g.rhs, u, f, ibc, g.rhs_b, g.rhs_t)
+        else:
+            raise NotImplementedError
+    elif g.nb_diag[1] == 3:
         matmul_3d_antisym(g.rhs, u, f, ibc, g.rhs_b, g.rhs_t)
     elif g.nb_diag[1] == 5:
         matmul_5d_antisym(g.rhs, u, f, ibc, g.rhs_b, g.rhs_t)
@@ -979,8 +1002,7 @@ class FdmPlan:
         self.der1.rhs_t = np.array(tab["rhs_t1"], dtype=np.float64)
         self.der2.need_1der = bool(tab["need_1der"])
         self.der2.direct = mode2 in (FDM_COM4_DIRECT, FDM_COM6_DIRECT)
-        if mode1 in (FDM_COM4_DIRECT, FDM_COM6_DIRECT):
-            raise NotImplementedError("oracle: direct first-derivative schemes")
+        self.der1.direct = mode1 in (FDM_COM4_DIRECT, FDM_COM6_DIRECT)
         return self
 
     def diffusion_lu(self, nu):

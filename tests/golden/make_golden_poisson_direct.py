@@ -16,13 +16,14 @@ from oracle import ref_lib as R  # noqa: E402
 KEYS = ("ndl1", "ndr1", "ndl2", "ndr2", "need_1der", "lhs1", "rhs1", "lu1", "rhs_b1", "rhs_t1", "mwn1", "lhs2", "rhs2", "lu2", "mwn2", "jac")
 
 
-def case(name, n):
+def case(name, n, mode2=16):
     y = 0.5 * (1 + np.tanh(2 * (2 * np.arange(n) / (n - 1) - 1)) / np.tanh(2))
     R.init(4, n, 4)
-    R.fdm_create(2, y, False, False, 6, 16)
+    R.fdm_create(2, y, False, False, 6, mode2)
     tab = R.fdm_arrays(2, n)
     out = {"tab_" + k: np.asarray(tab[k]) for k in KEYS}
     out["y"] = y
+    out["mode2"] = mode2
     rng = np.random.default_rng(20250510 + n)
     lams = np.array([0.0, 1e-3, 0.5, 39.47841760435743, 3.0e3, 2.6e5])
     out["lams"] = lams
@@ -48,3 +49,4 @@ if __name__ == "__main__":
         sys.exit("oracle/_ref/libtlab_ref.so missing")
     case("poisson_direct_modes_24", 24)
     case("poisson_direct_modes_96", 96)
+    case("poisson_direct_modes_c4_40", 40, mode2=17)      # EllipticOrder = CompactDirect4 (FDM_C2N4_Direct: same (3, 5) diagonals, opr_elliptic.f90:113-116)

@@ -31,6 +31,108 @@ def test_oracle_direct_scheme_matches_reference_outputs():
     assert rel_err(O.opr_burgers(2, nx, ny, nz, 0, g, visc, u, v)[0], G["burgers"]) <= 1e-14
 
 
+G1 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "direct1_y.npz"))
+
+
+def tables1(mode, ny):
+    t = {k: G1["m%d_ny%d_%s" % (mode, ny, k)] for k in KEYS if k != "nodes"}
+    t["nodes"] = G1["ny%d_nodes" % ny]
+    return t
+
+
+def direct1_cases(mode, ny):
+    """(operator, type, ibc, expected[, expected tmp1]) of the fixture for one plan"""
+    pre = "m%d_ny%d_" % (mode, ny)
+    for ibc in (0, 1, 2, 3):
+        for t in (1, 2, 3):
+            k = pre + "partial_t%d_bc%d" % (t, ibc)
+            if k in G1:
+                yield "partial", t, ibc, G1[k], (G1[pre + "partial_t3_bc%d_tmp1" % ibc] if t == 3 else None)
+        k = pre + "burgers_bc%d" % ibc
+        if k in G1:
+            yield "burgers", 0, ibc, G1[k], None
+
+
+@pytest.mark.parametrize("mode", [17, 16])
+@pytest.mark.parametrize("ny", [24, 72])
+def test_oracle_direct_first_derivative_matches_reference_outputs(mode, ny):
+    """SpaceOrder1 = CompactDirect4 / CompactDirect6: MatMul_3d / MatMul_5d with the Neumann rows (fdm_matmul.f90:70-121, 265-319)."""
+    from oracle import tlab_oracle as O
+    nx, nz = int(G1["nx"]), int(G1["nz"])
+    g = O.FdmPlan.from_tables(tables1(mode, ny), mode1=mode, mode2=mode)
+    assert g.der1.direct and g.der1.nb_diag == (3, 3 if mode == 17 else 5)
+    u, v, visc = G1["ny%d_u" % ny], G1["ny%d_v" % ny], float(G1["visc"])
+    for op, t, ibc, want, want1 in direct1_cases(mode, ny):
+        if op == "partial":
+            r, t1 = O.opr_partial(2, t, nx, ny, nz, ibc, g, u)
+            assert rel_err(r, want) <= 1e-14, (t, ibc)
+            if want1 is not None:
+                assert rel_err(t1, want1) <= 1e-14, (t, ibc)
+        else:
+            assert rel_err(O.opr_burgers(2, nx, ny, nz, ibc, g, visc, u, v)[0], want) <= 1e-14, ibc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [17, 16])
+@pytest.mark.parametrize("ny", [24, 72])
+def test_device_direct_first_derivative(mode, ny):
+    """The device path of the same plans (tables from the host, tlab_fdm_plan_create_from_arrays + tlab_fdm_plan_set_modes; k_line1: one
+    line per thread, per-row right-hand side) against the reference's outputs."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    T.init(0)
+    nx, nz = int(G1["nx"]), int(G1["nz"])
+    gp = T.FdmPlan.from_tables(tables1(mode, ny), periodic=False, scheme1=mode, scheme2=mode)
+    u, v, visc = G1["ny%d_u" % ny], G1["ny%d_v" % ny], float(G1["visc"])
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    res, tmp = torch.empty_like(du), torch.empty_like(du)
+    for op, t, ibc, want, want1 in direct1_cases(mode, ny):
+        res.fill_(float("nan")); tmp.fill_(float("nan"))
+        if op == "partial":
+            T.OPR_Partial_Y(t, nx, ny, nz, ibc, gp, du, res, tmp)
+            assert rel_err(res.cpu().numpy(), want) <= 1e-12, (t, ibc)
+            if want1 is not None:
+                assert rel_err(tmp.cpu().numpy(), want1) <= 1e-12, (t, ibc)
+        else:
+            T.OPR_Burgers_Y(T.OPR_B_U_IN, visc, nx, ny, nz, ibc, gp, du, dv, res, tmp)
+            assert rel_err(res.cpu().numpy(), want) <= 1e-12, ibc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [17, 16])
+def test_device_direct_first_derivative_on_the_tile_kernels(mode):
+    """128-point lines (register-tile kernel for OPR_P1, half-wave tiles for the fused forms) against the oracle on the reference's tables."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    from tlab_amd.lib import load
+    from oracle import tlab_oracle as O
+    T.init(0)
+    nx, ny, nz = 48, 128, 3
+    tab = tables1(mode, ny)
+    gp = T.FdmPlan.from_tables(tab, periodic=False, scheme1=mode, scheme2=mode)
+    go = O.FdmPlan.from_tables(tab, mode1=mode, mode2=mode)
+    rng = np.random.default_rng(mode)
+    u, v, visc = rng.uniform(-1, 1, nx * ny * nz), rng.uniform(-1, 1, nx * ny * nz), 1.0 / 300.0
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    res, tmp = torch.empty_like(du), torch.empty_like(du)
+    for ibc in (0, 1, 2, 3):
+        for t in (T.OPR_P1, T.OPR_P2_P1):
+            res.fill_(float("nan")); tmp.fill_(float("nan"))
+            T.OPR_Partial_Y(t, nx, ny, nz, ibc, gp, du, res, tmp)
+            assert load().tlab_last_kernel_path() == 3
+            r, t1 = O.opr_partial(2, t, nx, ny, nz, ibc, go, u)
+            assert rel_err(res.cpu().numpy(), r) <= 1e-12, (t, ibc)
+            if t == T.OPR_P2_P1:
+                assert rel_err(tmp.cpu().numpy(), t1) <= 1e-12, (t, ibc)
+        res.fill_(float("nan"))
+        T.OPR_Burgers_Y(T.OPR_B_U_IN, visc, nx, ny, nz, ibc, gp, du, dv, res, tmp)
+        assert rel_err(res.cpu().numpy(), O.opr_burgers(2, nx, ny, nz, ibc, go, visc, u, v)[0]) <= 1e-12, ibc
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ny,nx,nz", [(24, 16, 8), (64, 64, 3), (128, 48, 2), (512, 32, 2)])
 def test_device_direct_scheme(ny, nx, nz):
@@ -65,8 +167,6 @@ def test_device_direct_scheme(ny, nx, nz):
     assert rel_err(res.cpu().numpy(), O.opr_burgers(2, nx, ny, nz, 0, go, visc, u, v)[0]) <= 1e-12
     if ny == 24:
         assert rel_err(res.cpu().numpy(), G["burgers"]) <= 1e-12
-    with pytest.raises(T.TlabError):        # direct FIRST derivatives are not built
-        T.FdmPlan.from_tables(tab, periodic=False, scheme1=T.FDM_COM6_DIRECT, scheme2=T.FDM_COM6_DIRECT)
 
 
 @pytest.mark.gpu

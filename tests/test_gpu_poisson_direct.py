@@ -22,20 +22,25 @@ def T():
 
 
 def _tab(ny):
+    if ny == 40:      # EllipticOrder = CompactDirect4: the (CompactJacobian6, CompactDirect4) y plan of tests/golden/poisson_direct_modes_c4_40.npz
+        g = np.load([f for f in golden_files("poisson_direct_modes_c4")][0])
+        tab = {k[len("tab_"):]: g[k] for k in g.files if k.startswith("tab_")}
+        tab["nodes"] = g["y"]
+        return tab, 17
     g = np.load(golden_files("direct_y")[0])
-    return {k[len("ny%d_" % ny):]: g[k] for k in g.files if k.startswith("ny%d_" % ny)}
+    return {k[len("ny%d_" % ny):]: g[k] for k in g.files if k.startswith("ny%d_" % ny)}, 16
 
 
 def _setup(T, nx, ny, nz, seed):
-    tab = _tab(ny)
+    tab, mode2 = _tab(ny)
     y = tab["nodes"]
     x = np.arange(nx) / nx * 2 * np.pi
     z = np.arange(nz) / nz * np.pi if nz > 1 else np.zeros(1)
     ogx, ogz = O.FdmPlan(x, True, True), O.FdmPlan(z, True, True) if nz > 1 else None
-    ogy = O.FdmPlan.from_tables(tab)
+    ogy = O.FdmPlan.from_tables(tab, mode2=mode2)
     gx = T.FdmPlan(x, True, True)
     gz = T.FdmPlan(z, True, True) if nz > 1 else T.FdmPlan(np.zeros(1), True, True)
-    gy = T.FdmPlan.from_tables(tab, scheme1=6, scheme2=16)           # the derivative plan of the run: (CompactJacobian6, CompactDirect6)
+    gy = T.FdmPlan.from_tables(tab, scheme1=6, scheme2=mode2)        # the derivative plan of the run: (CompactJacobian6, CompactDirect6 | 4)
     rng = np.random.default_rng(seed)
     Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
     f = (np.sin(X) * np.cos(2 * Z) * np.exp(Y) + 0.3 * rng.uniform(-1, 1, X.shape)).ravel()
@@ -44,7 +49,8 @@ def _setup(T, nx, ny, nz, seed):
 
 
 @pytest.mark.parametrize("nx,ny,nz,ibc", [(16, 24, 8, 3), (16, 24, 8, 0), (16, 24, 8, 1), (16, 24, 8, 2), (32, 64, 16, 3), (16, 64, 1, 3),
-                                          (32, 128, 8, 3), (32, 128, 8, 0), (64, 512, 16, 3)])
+                                          (32, 128, 8, 3), (32, 128, 8, 0), (64, 512, 16, 3),
+                                          (16, 40, 8, 3), (16, 40, 8, 0), (16, 40, 8, 1), (16, 40, 8, 2)])      # 40: CompactDirect4
 def test_poisson_direct_matches_oracle(T, nx, ny, nz, ibc):
     import torch
     (ogx, ogy, ogz), (gx, gy, gz), f, hb, ht = _setup(T, nx, ny, nz, ny + ibc)

@@ -131,7 +131,69 @@ StencilDev tlab_fdm_plan::stencil(int which, int ibc) {
     s.periodic = d.periodic ? 1 : 0;
     const double *r = d.rhs.data();
 #define RI(i, k) r[((i)-1) + (size_t)nx * ((k)-1)]
-    if (which == 1) {
+    if (which == 1 && d.direct) {   // MatMul_3d / MatMul_5d (fdm_matmul.f90:70-121, 265-319) with the Neumann-reduced rows of the variant
+        if ((d.ndr != 3 && d.ndr != 5) || d.periodic) throw Unsupported("direct first derivative: 3 or 5 RHS diagonals in a non-periodic direction");
+        double rb[4 * 8] = {0}, rt[5 * 7] = {0};
+        const bool nb = (ibc == BCS_ND || ibc == BCS_NN), ntp = (ibc == BCS_DN || ibc == BCS_NN);
+        if (nb || ntp) {
+            std::vector<double> lhs(d.lhs.begin(), d.lhs.begin() + (size_t)3 * nx);
+            fdm_bcs_neumann(ibc, nx, 3, lhs.data(), d.ndr, d.rhs.data(), rb, rt);
+        }
+#define RB(j, c) rb[((j)-1) + 4 * (c)]
+#define RT(rr, c) rt[(rr) + 5 * ((c)-1)]
+        std::vector<double> rc((size_t)5 * nx, 0.0);
+        if (d.ndr == 5) {
+            for (int i = 1; i <= nx; ++i)
+                for (int k = 1; k <= 5; ++k) rc[(size_t)(i - 1) * 5 + (k - 1)] = RI(i, k);
+            for (int i = 5; i <= nx - 4; ++i) rc[(size_t)(i - 1) * 5 + 3] = 1.0;       // the interior loop has no r4 factor (:303-305)
+            if (nb) {       // f(1) carries the boundary value, 0 (fdm_derivative.f90:240): its terms are dropped
+                s.bb[1][1] = RB(2, 3); s.bb[1][2] = RB(2, 4); s.bb[1][3] = RB(2, 5);
+                s.bb[2][1] = RB(3, 2); s.bb[2][2] = RB(3, 3); s.bb[2][3] = RB(3, 4); s.bb[2][4] = RB(3, 5);
+                for (int k = 1; k <= 5; ++k) rc[(size_t)3 * 5 + (k - 1)] = RB(4, k);
+            } else {
+                s.bb[0][0] = RI(1, 3); s.bb[0][1] = RI(1, 4); s.bb[0][2] = RI(1, 5); s.bb[0][3] = RI(1, 1);
+                s.bb[1][0] = RI(2, 2); s.bb[1][1] = RI(2, 3); s.bb[1][2] = RI(2, 4); s.bb[1][3] = RI(2, 5);
+                for (int k = 0; k < 5; ++k) s.bb[2][k] = RI(3, 1 + k);
+            }
+            if (ntp) {
+                for (int k = 1; k <= 5; ++k) rc[(size_t)(nx - 4) * 5 + (k - 1)] = RT(0, k);
+                s.bt[0][1] = RT(1, 1); s.bt[0][2] = RT(1, 2); s.bt[0][3] = RT(1, 3); s.bt[0][4] = RT(1, 4);
+                s.bt[1][2] = RT(2, 1); s.bt[1][3] = RT(2, 2); s.bt[1][4] = RT(2, 3);
+            } else {
+                for (int k = 0; k < 5; ++k) s.bt[0][1 + k] = RI(nx - 2, 1 + k);
+                for (int k = 0; k < 4; ++k) s.bt[1][2 + k] = RI(nx - 1, 1 + k);
+                s.bt[2][2] = RI(nx, 5); s.bt[2][3] = RI(nx, 1); s.bt[2][4] = RI(nx, 2); s.bt[2][5] = RI(nx, 3);
+            }
+        } else {
+            for (int i = 1; i <= nx; ++i) {       // (0, r1, r2, 1, 0): the interior loop has no r3 factor (:103-105)
+                rc[(size_t)(i - 1) * 5 + 1] = RI(i, 1); rc[(size_t)(i - 1) * 5 + 2] = RI(i, 2); rc[(size_t)(i - 1) * 5 + 3] = 1.0;
+            }
+            if (nb) {
+                s.bb[1][1] = RB(2, 2); s.bb[1][2] = RB(2, 3);
+                s.bb[2][1] = RB(3, 1); s.bb[2][2] = RB(3, 2); s.bb[2][3] = RB(3, 3);
+            } else {
+                s.bb[0][0] = RI(1, 2); s.bb[0][1] = RI(1, 3); s.bb[0][2] = RI(1, 1);
+                s.bb[1][0] = RI(2, 1); s.bb[1][1] = RI(2, 2); s.bb[1][2] = RI(2, 3);
+                s.bb[2][1] = RI(3, 1); s.bb[2][2] = RI(3, 2); s.bb[2][3] = RI(3, 3);
+            }
+            if (ntp) {
+                s.bt[0][2] = RT(0, 1); s.bt[0][3] = RT(0, 2); s.bt[0][4] = RT(0, 3);
+                s.bt[1][3] = RT(1, 1); s.bt[1][4] = RT(1, 2);
+            } else {
+                s.bt[0][2] = RI(nx - 2, 1); s.bt[0][3] = RI(nx - 2, 2); s.bt[0][4] = RI(nx - 2, 3);
+                s.bt[1][3] = RI(nx - 1, 1); s.bt[1][4] = RI(nx - 1, 2); s.bt[1][5] = RI(nx - 1, 3);
+                s.bt[2][3] = RI(nx, 3); s.bt[2][4] = RI(nx, 1); s.bt[2][5] = RI(nx, 2);
+            }
+        }
+#undef RB
+#undef RT
+        auto &slot = rowc1[ibc & 3];
+        if (!slot) {
+            slot = std::make_unique<DeviceArray>();
+            slot->upload(rc);
+        }
+        s.rowc = slot->p;
+    } else if (which == 1) {
         if (d.ndr != 3 && d.ndr != 5) throw Unsupported("first-derivative RHS must have 3 or 5 diagonals");
         s.c2 = (d.ndr == 5) ? RI(4, 5) : 0.0;  // r5_loc, fdm_matmul.f90:373
         if (!d.periodic) {
@@ -404,13 +466,16 @@ int tlab_fdm_plan_set_scheme(tlab_fdm_plan_t p, int mode1, int mode2) {
     return guarded([&] {
         if (!p) throw Invalid("tlab_fdm_plan_set_scheme: null plan");
         auto direct = [](int m) { return m == FDM_COM6_DIRECT || m == FDM_COM4_DIRECT; };
-        if (direct(mode1)) throw Unsupported("direct first-derivative schemes are not built on the device");
+        if (direct(mode1) && (p->t.periodic || p->t.der1.ndl != 3 || (p->t.der1.ndr != 3 && p->t.der1.ndr != 5)))
+            throw Invalid("direct first derivative: non-periodic direction, tridiagonal LHS, 3 or 5 RHS diagonals (FDM_C1N4_Direct / FDM_C1N6_Direct)");
         if (direct(mode2) && (p->t.periodic || p->t.der2.ndr != 5)) throw Invalid("direct second derivative: non-periodic direction with 5 RHS diagonals");
         p->t.der1.mode_fdm = mode1; p->t.der2.mode_fdm = mode2;
+        p->t.der1.direct = direct(mode1);
         p->t.der2.direct = direct(mode2);
         if (p->t.der2.direct) p->t.der2.need_1der = false;                 // fdm_derivative.f90:379,383
         p->systems.clear();
         p->rowc2.reset();
+        for (auto &r : p->rowc1) r.reset();
     });
 }
 
@@ -537,6 +602,7 @@ int xline_chunks(int n, tlab_fdm_plan_t g) {
 int choose_path(int dir, int n, tlab_fdm_plan_t g = nullptr) {
     int path = PATH_GENERIC;
     if (g && g->t.der1.ndl == 5) return PATH_GENERIC;      // CompactJacobian6Penta: the first derivative runs on k_penta1, nothing is fused
+    if (g && g->t.der1.direct && dir == 1) return PATH_GENERIC;      // per-row first-derivative RHS: not in the wave-per-line kernel
     if (dir == 1 && xline_chunks(n, g) > 0) path = PATH_XLINE;
     if (dir != 1 && (rtile_chunk(n) > 0 || htile_chunk(n, MODE_P1) > 0)) path = PATH_RTILE;
     if (g_force_path == PATH_GENERIC) path = PATH_GENERIC;

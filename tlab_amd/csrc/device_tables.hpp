@@ -15,7 +15,8 @@ struct StencilDev {
     double bt[3][6];
     // Direct schemes (fdm_comx_direct.f90, MatMul_5d fdm_matmul.f90:265-319): per-row pentadiagonal B.  rowc != NULL: [n][5] = r1..r5 of
     // every row, f = r1 u[-2] + r2 u[-1] + r3 u[0] + r4 u[+1] + r5 u[+2] in the interior, with r4 stored as exactly 1.0 where the
-    // reference's loop omits the factor (rows 5 .. n-4, 1-based) and as its table value in rows 4 and n-3.
+    // reference's loop omits the factor (rows 5 .. n-4, 1-based) and as its table value in rows 4 and n-3.  Direct FIRST derivatives use the
+    // same form: MatMul_5d with the Neumann-reduced rows 4 / n-3 of the variant written into the table, MatMul_3d (:70-121) as (0, r1, r2, 1, 0).
     const double *rowc;
 };
 

@@ -145,6 +145,12 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     if (NEED1 || (NEED2 && corr)) {
 #pragma unroll
         for (int p = 0; p < M; ++p) x1[p] = h_stencil<false>(a.s1, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+        if (a.s1.rowc != nullptr) {   // direct first derivative (MatMul_3d / MatMul_5d): per-row coefficients, read where they lie (rare scheme)
+            const double *rc = a.s1.rowc + row0 * 5;
+#pragma unroll
+            for (int p = 0; p < M; ++p)
+                x1[p] = e[p + 1] * rc[p * 5 + 0] + e[p + 2] * rc[p * 5 + 1] + e[p + 3] * rc[p * 5 + 2] + e[p + 4] * rc[p * 5 + 3] + e[p + 5] * rc[p * 5 + 4];
+        }
         if (!per) {
             if (c == 0) {
 #pragma unroll

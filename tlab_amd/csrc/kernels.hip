@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
 
     // ---- right-hand side ----
     double f[M];
-    if (SECOND && st.rowc != nullptr) {       // direct scheme: per-row coefficients, wave-uniform -> scalar loads
+    if (st.rowc != nullptr) {       // direct scheme (either derivative): per-row coefficients, wave-uniform -> scalar loads
         const double *rc = st.rowc + (long long)row0 * 5;
 #pragma unroll
         for (int p = 0; p < M; ++p)
@@ -682,7 +682,7 @@ __device__ __forceinline__ double generic_rhs_row(const double *__restrict__ u, 
         return dense6(s.bt[i - (n - 3)], u[b6], u[b6 + rs], u[b6 + 2 * rs], u[b6 + 3 * rs], u[b6 + 4 * rs], u[b6 + 5 * rs]);
     }
     const long long c = base + (long long)i * rs;
-    if (SYM && s.rowc != nullptr) {
+    if (s.rowc != nullptr) {
         const double *rc = s.rowc + (long long)i * 5;
         return u[c - 2 * rs] * rc[0] + u[c - rs] * rc[1] + u[c] * rc[2] + u[c + rs] * rc[3] + u[c + 2 * rs] * rc[4];
     }

@@ -40,6 +40,7 @@ struct tlab_fdm_plan {
     std::map<std::tuple<int, int, int>, std::unique_ptr<tlab::SystemEntry>> systems;
     std::unique_ptr<tlab::DeviceArray> jc;   // [3][n] Jacobian-correction diagonals (non-uniform grids)
     std::unique_ptr<tlab::DeviceArray> rowc2;  // [n][5] per-row RHS of a direct second-derivative scheme
+    std::unique_ptr<tlab::DeviceArray> rowc1[4];   // the same for a direct first derivative, one per Neumann variant (rows 4 and n-3 differ)
     std::unique_ptr<tlab::DeviceArray> penta_rhs, penta_lu;   // CompactJacobian6Penta first derivative: g%der1%rhs (n,7) and g%der1%lu on the device
     int wide_ok[3] = {-1, -1, -1};             // x lines on 64 / 128 / 256 chunks: float-difference tables exact? (-1 = not checked yet; capi.cpp xline_wide_ok)
 
