@@ -125,7 +125,7 @@ def test_configs4_rank_share_fused_vs_literal_and_divergence(T):
         assert err <= bound(sc), (i, err, sc)
 
 
-def test_configs3_eight_loopback_slabs_equal_single_domain(T):
+def test_configs3_eight_loopback_ranks_equal_single_domain(T):
     """configs[3]: 1024 x 512 x 1024 over 8 ranks (z-slabs of 128 planes), every rank's work executed on this one GPU (LoopbackComm: only the
     exchanges are copies), against the single-domain driver after one RK3 step; interior divergence of the slab result."""
     import torch
@@ -169,5 +169,34 @@ def test_configs3_eight_loopback_slabs_equal_single_domain(T):
         errs.append(float((got - rf).abs().max() / rf.abs().max()))
         del got
     print("configs[3] loopback-8: one-ulp scatter", ["%.1e" % v for v in scat], "slabs vs single domain", ["%.1e" % v for v in errs])
+    for i, (e, sc) in enumerate(zip(errs, scat)):
+        assert e <= bound(sc), (i, e, sc)
+    # the same box "x/z-decomposed" as BASELINE configs[3] words it: 2 x 4 blocks of 512 x 512 x 256 (tlab_amd/pencil.py: I-transpositions in
+    # the x communicators, K-transpositions in the z communicators, Poisson on the 1 x 8 slabs the I-transposition leaves)
+    fields = device_fields(nx, ny, nz, 4, 1024)
+    del slab
+    torch.cuda.empty_cache()
+    from tlab_amd.pencil import PencilDns, loopback_comms
+    pen = PencilDns(loopback_comms(2, 4), 2, 4, x, y, z, **kw)
+    assert (pen.imax, pen.kmax, pen.kmax2) == (512, 256, 128)
+    for i in range(3):
+        pen.scatter("q", i, fields[i])
+    pen.scatter("s", 0, fields[3])
+    del fields
+    for k in range(3):
+        pen.substep_of_cycle(k, 5e-4)
+    torch.cuda.synchronize()
+    errs = []
+    for i, rf in enumerate(ref):
+        name, idx = ("q", i) if i < 3 else ("s", 0)
+        got = torch.empty(nz, ny, nx, dtype=torch.float64, device="cuda")
+        for r, t in pen.gather_local(name, idx).items():
+            pi, pk = pen.pro(r)
+            got[pk * pen.kmax:(pk + 1) * pen.kmax, :, pi * pen.imax:(pi + 1) * pen.imax] = t.view(pen.kmax, ny, pen.imax)
+        got = got.reshape(-1)
+        assert bool(torch.isfinite(got).all())
+        errs.append(float((got - rf).abs().max() / rf.abs().max()))
+        del got
+    print("configs[3] loopback 2 x 4: pencils vs single domain", ["%.1e" % v for v in errs])
     for i, (e, sc) in enumerate(zip(errs, scat)):
         assert e <= bound(sc), (i, e, sc)

@@ -1,0 +1,90 @@
+"""x/z pencil decomposition (ims_npro_i x ims_npro_k, tlab_amd/pencil.py) against the single domain on ONE GPU: all ranks are simulated
+in-process (loopback communicators), so the complete decomposed algorithm -- I- and K-transpositions inside the x / z communicators, the
+transposed-velocity reuse, the Poisson solver on the 1 x (npro_i npro_k) slabs the I-transposition leaves behind, per-rank kx ranges -- runs
+for real; only the transport of the blocks is replaced by copies."""
+import numpy as np
+import pytest
+from scatter import bound, substep_scatter
+
+pytestmark = pytest.mark.gpu
+REF_HYPER = 0.1
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    T.init(0)
+    return T
+
+
+def grids(nx, ny, nz):
+    x = np.arange(nx) / nx * 2 * np.pi
+    z = np.arange(nz) / nz * np.pi
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    return x, y, z
+
+
+def gather(D, name, idx, nx, ny, nz):
+    import torch
+    out = torch.empty(nz, ny, nx, dtype=torch.float64)
+    for r, t in D.gather_local(name, idx).items():
+        pi, pk = D.pro(r)
+        out[pk * D.kmax:(pk + 1) * D.kmax, :, pi * D.imax:(pi + 1) * D.imax] = t.cpu().view(D.kmax, D.ny, D.imax)
+    return out.reshape(-1).numpy()
+
+
+@pytest.mark.parametrize("npi,npk,nx,ny,nz,bcs", [(2, 2, 32, 24, 16, "noslip"), (2, 4, 32, 16, 32, "noslip"), (4, 2, 64, 16, 16, "freeslip"),
+                                                   (2, 1, 32, 24, 8, "noslip"), (8, 1, 64, 8, 16, "noslip"), (1, 4, 32, 16, 16, "noslip")])
+def test_pencil_substeps_match_single_domain(T, npi, npk, nx, ny, nz, bcs):
+    import torch
+    from tlab_amd.dns import Dns, velocity_bcs
+    from tlab_amd.pencil import PencilDns, loopback_comms
+    from oracle.tlab_oracle_rhs import DnsOracle
+    x, y, z = grids(nx, ny, nz)
+    rng = np.random.default_rng(10 * npi + npk)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    fields = [((np.sin(X + k) * np.cos(2 * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
+    visc, sc = 1.0 / 300.0, (0.7,)
+    one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    D = PencilDns(loopback_comms(npi, npk), npi, npk, x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    if bcs == "freeslip":
+        one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+        D.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+    for i in range(3):
+        t = torch.from_numpy(fields[i]).cuda()
+        one.q[i].copy_(t); D.scatter("q", i, t)
+    t = torch.from_numpy(fields[3]).cuda()
+    one.s[0].copy_(t); D.scatter("s", 0, t)
+    dtime = 2e-3
+    for k in range(2):
+        one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * one.kdt[k], one.kco[k], True)
+        D.substep_of_cycle(k, dtime)
+    torch.cuda.synchronize()
+
+    # the bound: max(1e-12, 2 x the ORACLE's own scatter under one ulp of input noise) (tests/scatter.py), against the single domain and the oracle
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        if bcs == "freeslip":
+            o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
+        return o
+    B, S = substep_scatter(make_oracle, fields[:3], fields[3:], [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=2)
+    for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
+        for i, rf in enumerate(ref):
+            got = gather(D, name, i, nx, ny, nz)
+            tol = bound(S[1][name][i])
+            rf = rf.cpu().numpy()
+            err = float(np.abs(got - rf).max() / np.abs(rf).max())
+            assert err <= tol, ("pencils vs single domain", name, i, err, tol)
+            err = float(np.abs(got - B[1][name][i]).max() / np.abs(B[1][name][i]).max())
+            assert err <= tol, ("pencils vs oracle", name, i, err, tol)
+
+
+def test_pencil_layout_is_refused_where_the_reference_refuses(T):
+    from tlab_amd.pencil import PencilDns, loopback_comms
+    x, y, z = grids(32, 16, 12)
+    with pytest.raises(T.TlabError):
+        PencilDns(loopback_comms(4, 2), 4, 2, x, y, z)          # kmax = 6 is not a multiple of npro_i = 4

@@ -42,13 +42,16 @@ from .dns import rk_coefficients, RKM_EXP3, DNS_BCS_DIRICHLET, DNS_BCS_NEUMANN, 
 class DistComm:
     """ims_comm_z over torch.distributed: one rank per process."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, key=None):
+        """key: what the tensors of this process are filed under in the {rank: tensor} arguments (default: the rank inside the group; the
+        pencil driver files everything under the WORLD rank, whichever communicator carries it)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.local_ranks = [self.rank]
+        self.key = self.rank if key is None else key
+        self.local_ranks = [self.key]
 
         # functional testing of the multi-process path on a box with fewer GPUs than ranks: gloo cannot move device memory in
         # every collective, so the payload is staged through the host (never used for measurements)
@@ -69,7 +72,7 @@ class DistComm:
 
     def all_to_all_v(self, send, send_counts, recv, recv_counts):
         """send/recv: {rank: flat tensor}; *_counts: {rank: [elements per peer]}.  In place into recv.  Returns a waitable."""
-        r = self.rank
+        r = self.key
         if self.stage_host and send[r].is_cuda:
             import torch
             hs = send[r].cpu()
@@ -85,8 +88,8 @@ class DistComm:
         """Periodic ring: to_left[r][i] lands in from_right[r-1][i], to_right[r][i] in from_left[r+1][i].  Lists of contiguous
         tensors per rank.  Posting order (sends: left then right; receives: from right then from left) keeps the pairing right
         when both neighbours are the same rank (2 ranks)."""
-        dist, r, P = self.dist, self.rank, self.size
-        left, right = (r - 1) % P, (r + 1) % P
+        dist, r, P = self.dist, self.key, self.size
+        left, right = (self.rank - 1) % P, (self.rank + 1) % P
         if self.stage_host and (to_left[r] + to_right[r]) and (to_left[r] + to_right[r])[0].is_cuda:
             import torch
             sl, sr = [t.cpu() for t in to_left[r]], [t.cpu() for t in to_right[r]]
