@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--nscal", type=int, default=1)
     ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
                     "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
+    ap.add_argument("--decomp", default="", metavar="IxK", help="diagnostic: x/z pencil decomposition npro_i x npro_k (tlab_amd/pencil.py), e.g. 2x4: with "
+                    "--gpus N = I*K one block per GPU, otherwise all I*K ranks inside this one process/GPU (loopback); the default multi-GPU run is 1 x N z-slabs")
     ap.add_argument("--cpu-sample", type=int, default=256, help="n of the n^3 CPU-baseline sample (0 disables)")
     ap.add_argument("--cpu-sample-large", type=int, default=512, help="second, larger CPU-baseline sample, run only on hosts with at least --cpu-large-min-cores CPUs (0 disables)")
     ap.add_argument("--cpu-large-min-cores", type=int, default=48)
@@ -166,7 +168,25 @@ def main():
     # past the end of a coefficient array (defect 1) -- same kernels and bytes, but that scheme is unstable over many steps.
     HYPER_BC1_EXT = 0.0
     L = load()
-    if world == 1 and args.loopback > 1:
+    if args.decomp:
+        from tlab_amd.pencil import PencilDns, loopback_comms, dist_comms
+        npi, npk = (int(v) for v in args.decomp.lower().split("x"))
+        if world > 1 and world != npi * npk:
+            raise SystemExit("--decomp IxK needs --gpus I*K (or one process for the loopback)")
+        d = PencilDns(dist_comms(npi, npk) if world > 1 else loopback_comms(npi, npk), npi, npk, x, y, z, nscal=args.nscal, visc=1.0 / 5000.0,
+                      schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
+        state_fields = []
+        full = [torch.empty(nx * ny * nz, dtype=torch.float64, device="cuda") for _ in range(3 + args.nscal)]
+        synthetic_fields(full, nx, ny, nz, 0, nz, 0)
+        for i, f in enumerate(full):
+            d.scatter("q" if i < 3 else "s", i if i < 3 else i - 3, f)
+        del full
+        for r in d.world.local_ranks:
+            state_fields += d.st[r]["q"] + d.st[r]["s"]
+
+        def substep(k):
+            d.substep_of_cycle(k, dtime)
+    elif world == 1 and args.loopback > 1:
         from tlab_amd.parallel import SlabDns, LoopbackComm
         d = SlabDns(LoopbackComm(args.loopback), x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True,
                     rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
@@ -244,7 +264,7 @@ def main():
         dom = next((k for k in kernels if k["alg_bytes_per_launch"] > 1e6), None)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if collected (profiles/README.md)
-        if dom and os.path.exists(tpath) and world == 1 and args.loopback <= 1 and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:      # measured for this workload only
+        if dom and os.path.exists(tpath) and world == 1 and args.loopback <= 1 and not args.decomp and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:      # measured for this workload only
             try:
                 traffic = json.load(open(tpath)).get(dom["kernel"])
             except Exception:
@@ -268,7 +288,8 @@ def main():
             "config": {"workload": "%dx%dx%d incompressible box, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
                                    % (nx, ny, nz, args.nscal),
                        "grid": [nx, ny, nz], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper (consistent wall closure)", "reynolds": 5000,
-                       "parallelism": ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode) executed back to back on one GPU, no communication" % (args.loopback, d.zmode)) if world == 1 else
+                       "parallelism": ("DIAGNOSTIC: x/z pencils %s (%s), I-/K-transpositions per x/z operator, Poisson on kx-pencils" % (args.decomp, "one block per GPU" if world > 1 else "all ranks back to back on one GPU, exchanges = copies")) if args.decomp else
+                                      ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode) executed back to back on one GPU, no communication" % (args.loopback, d.zmode)) if world == 1 else
                        ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep), %s" % (world, "RCCL" if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
                        "fields_finite": finite},
             "roofline": None if dom is None else {
@@ -278,7 +299,8 @@ def main():
             "substep_alg_GBps": (736.0 + 152.0 * args.nscal) * npts / (ms_per_step * 1e-3) / 1e9,
             "kernels": [{k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in k.items()} for k in kernels],
         }
-        if world == 1 and args.loopback <= 1:
+        single = world == 1 and args.loopback <= 1 and not args.decomp
+        if single:
             # context for the roofline fraction: what a plain device copy of one field reaches on THIS box (read + write bytes), after the timed
             # region.  The 8 TB/s peak is not reachable by any kernel; the streaming kernels above are to be read against this figure too.
             src, dst = d.hq[0], d.hs[0]
@@ -293,7 +315,7 @@ def main():
             out["copy_ceiling"] = {"GBps": copy_gbs, "what": "device copy of one %d-point fp64 field, read + write bytes, 10 repetitions" % src.numel()}
             if out["roofline"] is not None:
                 out["roofline"]["frac_of_copy"] = out["roofline"]["achieved"] / copy_gbs
-        if world == 1 and args.loopback <= 1:
+        if single:
             # the north-star's own target kernel, standalone on this box: OPR_Partial_{X,Y,Z}(OPR_P1) at the benchmark's grid, 16 B per point
             # (SURVEY.md 8d), >= 40 % of the 8 TB/s HBM peak asked for OPR_Partial_X at 512^3
             targets = {}
