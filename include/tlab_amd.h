@@ -154,7 +154,7 @@ int tlab_opr_poisson(tlab_poisson_plan_t plan, int nx, int ny, int nz, int ibc, 
  *      the reference itself differ by (with / without fused multiply-adds: 4e-12 in p, 1.4e-11 in dp/dy on 512-point lines; one ulp of
  *      forcing noise -- another FFT library -- gives 6e-13 and 2.5e-12).  That difference sits in the few modes with lambda h^2 << 1, so on a
  *      single device those (at most 128 modes, sqrt(lambda) mean(h) <= 0.06) are solved by a marching sub-plan beside k_ode_nn
- *      (TLAB_POISSON_LOW_MODES=0/1 overrides; decomposed plans leave it off: only the rank that owns kx = 0.. would pay for it): 7.6e-13 /
+ *      (TLAB_POISSON_LOW_MODES=0 turns it off; decomposed plans run it on the rank that owns kx = 0..): 7.6e-13 /
  *      3.1e-12 on that projection, <= 3e-13 / 9e-13 on forcing without the cancellation; costs 0.1-0.2 ms per solve.
  *   1: the marching kernels (k_int1: one thread per mode, 5.8 ms at 512^3), which repeat FDM_Int1_Solve / OPR_ODE2_Factorize_NN operation by
  *      operation, in the reference's order and without fused multiply-adds: 4e-13 / 1.7e-12 on the same case, i.e. at the FFT-noise floor. */
