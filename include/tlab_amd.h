@@ -126,6 +126,12 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
  * (first derivative). */
 int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int nz, int ibc, double nu,
                      const double *s, const double *u, double *result, double *tmp1, int write_transposed);
+/* The anelastic branch of OPR_Burgers_1D (physics/opr_burgers.f90:504-507) with the module state OPR_Burgers_Initialize sets up for
+ * nse_eqns == DNS_EQNS_ANELASTIC (:128-183): the diffusion term is multiplied by ribackground(j) -- rhoinv(1), rhoinv(3) along x and z, the
+ * scaled U factors of fdmDiffusion(2) along y (the same product, rounding aside).  HOST pointers, ny values each; ny = 0 or NULL: off.
+ * While it is on, tlab_opr_burgers runs the two derivatives unfused and a weighted epilogue.  The dealiasing branch (:478-500, OPR_FILTER_1D) is
+ * not built: TLAB_EUNSUPPORTED is the answer of the Fortran shim when [Dealiasing] selects a filter. */
+int tlab_opr_burgers_set_anelastic(int ny, const double *rbackground, const double *ribackground);
 
 /* ---- Poisson solver --------------------------------------------------------------------------- */
 /* OPR_Elliptic_Initialize (operators/opr_elliptic.f90:86-250, TYPE_FACTORIZE) + OPR_Fourier_Initialize
@@ -280,6 +286,12 @@ int tlab_dns_begin_step(tlab_dns_t d);
 #define TLAB_DNS_BCS_DIRICHLET 3
 #define TLAB_DNS_BCS_NEUMANN 4
 int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
+/* nse_eqns == DNS_EQNS_ANELASTIC: the density weights of the RHS (Thermo_Anelastic_WEIGHT_INPLACE / _SUBTRACT with rbackground / ribackground,
+ * tools/dns/rhs_global_incompressible_1.f90:211-214, :326-329; the Neumann data of the pressure times rbackground at the walls, :275-277) and of
+ * OPR_Burgers (below).  rbackground, ribackground: HOST pointers, ny values each, ribackground = 1 / rbackground -- the profiles the host's
+ * thermodynamics made (Thermo_Anelastic is outside the path); NULL switches back to the incompressible equations.  Anelastic substeps take the
+ * literal operator sequence (no fused forms). */
+int tlab_dns_set_anelastic(tlab_dns_t d, const double *rbackground, const double *ribackground);
 
 /* BOUNDARY_BCS_NEUMANN_Y(ibc, nx, ny, nz, g, u, bcs_hb, bcs_ht, tmp1)   tools/dns/boundary_bcs.f90:368-473
  * Wall values of u (planes of nx*nz, x fastest) such that du/dy = 0 at the bottom (ibc = 1), top (2) or both (3) walls,

@@ -1061,9 +1061,13 @@ def opr_partial(idir, itype, nx, ny, nz, ibc, g, u):
     raise NotImplementedError
 
 
-def opr_burgers(idir, nx, ny, nz, ibc, g, nu, s, vel):
+def opr_burgers(idir, nx, ny, nz, ibc, g, nu, s, vel, anelastic=None):
     """physics/opr_burgers.f90:190-273 (X), :277-355 (Y), :359-431 (Z) + OPR_Burgers_1D :439-521
-    (serial, no dealiasing, no anelastic): result = nu d2s - vel ds along idir.
+    (serial, no dealiasing): result = nu d2s - vel ds along idir.
+    anelastic = (rbackground, ribackground) (ny values each; nse_eqns == DNS_EQNS_ANELASTIC, opr_burgers.f90:128-183): along x and z the
+    diffusion term is multiplied by rhoinv%values(line) = ribackground(y index of the line) (:134-151, :164-181, :504-507); along y the
+    correction sits in the LU factors of the diffusion system (:153-160): U's inverse diagonal times ribackground, its superdiagonal times
+    rbackground(2:).
     Returns (result, s_transposed) with s_transposed the flat (lines-fastest) operand the reference leaves in tmp1."""
     n = (nx, ny, nz)[idir - 1]
     if n == 1:
@@ -1071,8 +1075,19 @@ def opr_burgers(idir, nx, ny, nz, ibc, g, nu, s, vel):
     sl = _to_lines(np.asarray(s, dtype=np.float64), nx, ny, nz, idir)
     vl = _to_lines(np.asarray(vel, dtype=np.float64), nx, ny, nz, idir)
     dsdx = der1_solve(g.der1, ibc, sl)
-    r = der2_solve(g.der2, g.diffusion_lu(nu), sl, dsdx)
-    r = r - vl * dsdx
+    lu = g.diffusion_lu(nu)
+    if anelastic is not None and idir == 2:
+        rb, ri = (np.asarray(a, dtype=np.float64) for a in anelastic)
+        lu[:, 1] = lu[:, 1] * ri
+        lu[:n - 1, 2] = lu[:n - 1, 2] * rb[1:]
+    r = der2_solve(g.der2, lu, sl, dsdx)
+    if anelastic is not None and idir != 2:
+        ri = np.asarray(anelastic[1], dtype=np.float64)
+        nl = sl.shape[1]
+        jy = (np.arange(nl) % ny) if idir == 1 else (np.arange(nl) // nx)       # ip of :149 / :179
+        r = r * ri[jy][None, :] - vl * dsdx
+    else:
+        r = r - vl * dsdx
     return _from_lines(r, nx, ny, nz, idir), sl.ravel()
 
 

@@ -13,7 +13,12 @@ from . import tlab_oracle_poisson as OP
 
 
 class DnsOracle:
-    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None, gy_elliptic=None, hyper_bc1_ext=None):
+    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None, gy_elliptic=None, hyper_bc1_ext=None,
+                 anelastic=None):
+        """anelastic = (rbackground, ribackground): nse_eqns == DNS_EQNS_ANELASTIC with those background profiles (ny values each): the density
+        weights of rhs_global_incompressible_1.f90:211-214, :275-277, :326-329 and of OPR_Burgers (opr_burgers.f90:128-183).  The buoyancy and
+        the thermodynamics that PRODUCE the profiles are outside the path."""
+        self.anelastic = None if anelastic is None else tuple(np.asarray(a, dtype=np.float64) for a in anelastic)
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
         h = hyper_bc1_ext                      # None: O.HYPER_BC1_EXT = the flang-built reference's wall closure (DESIGN.md section 2, defect 1)
@@ -34,7 +39,11 @@ class DnsOracle:
         self.scal_jmin, self.scal_jmax = [3] * nscal, [3] * nscal
 
     def burgers(self, d, nu, s, vel):
-        return O.opr_burgers(d, self.nx, self.ny, self.nz, 0, self.g[d - 1], nu, s, vel)[0]
+        return O.opr_burgers(d, self.nx, self.ny, self.nz, 0, self.g[d - 1], nu, s, vel, anelastic=self.anelastic)[0]
+
+    def weight(self, w, a):
+        """Thermo_Anelastic_WEIGHT_* (thermodynamics/thermo_anelastic.f90:377-448): a(i, j, k) * w(j)"""
+        return (a.reshape(self.nz, self.ny, self.nx) * w[None, :, None]).ravel()
 
     def p1(self, d, u):
         return O.opr_partial(d, O.OPR_P1, self.nx, self.ny, self.nz, 0, self.g[d - 1], u)[0]
@@ -59,17 +68,25 @@ class DnsOracle:
         tmp2 = hq[1] + v * dummy
         tmp3 = hq[0] + u * dummy
         tmp4 = hq[2] + w * dummy
+        if self.anelastic is not None:                                                                              # :211-214
+            rb, ri = self.anelastic
+            tmp2, tmp3, tmp4 = self.weight(rb, tmp2), self.weight(rb, tmp3), self.weight(rb, tmp4)
         tmp1 = self.p1(2, tmp2); tmp2 = self.p1(1, tmp3); tmp3 = self.p1(3, tmp4)                                   # :228-230
         tmp1 = tmp1 + tmp2 + tmp3                                                                                   # :258
         h2 = hq[1].reshape(nz, ny, nx)
         hb, ht = h2[:, 0, :].copy(), h2[:, ny - 1, :].copy()                                                        # :279-280
+        if self.anelastic is not None:                                                                              # :275-277
+            hb, ht = hb * rb[0], ht * rb[ny - 1]
         if self.direct:
             p, dpdy = OP.opr_poisson_fxz_direct(self.poisson, tmp1, hb, ht, gy_der=self.g[1])
         else:
             p, dpdy = OP.opr_poisson_fxz(self.poisson, tmp1, hb, ht)                                                # :284
         self.p = p
         tmp2 = self.p1(1, p); tmp4 = self.p1(3, p)                                                                  # :319-320
-        hq[0] = hq[0] - tmp2; hq[1] = hq[1] - dpdy; hq[2] = hq[2] - tmp4                                            # :349-351
+        if self.anelastic is not None:                                                                              # :326-329
+            hq[0] = hq[0] - self.weight(ri, tmp2); hq[1] = hq[1] - self.weight(ri, dpdy); hq[2] = hq[2] - self.weight(ri, tmp4)
+        else:
+            hq[0] = hq[0] - tmp2; hq[1] = hq[1] - dpdy; hq[2] = hq[2] - tmp4                                        # :349-351
         types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
         for a, (tmin, tmax) in zip(hq + hs, types):                                                                 # :363-375, :379-396
             ref_b = np.zeros((nz, nx)); ref_t = np.zeros((nz, nx))

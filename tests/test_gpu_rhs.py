@@ -414,3 +414,81 @@ def test_hundred_steps_of_decaying_flow_stay_bounded(T, stretch):
     assert float(d.s[0].min()) >= smin0 - 0.05 * span and float(d.s[0].max()) <= smax0 + 0.05 * span
     (p1, _), _ = d.TIME_COURANT(1.2, 0.25)                                         # p1 = max(|u_i| / h_i): the size of the terms of div(q)
     assert max(dil) <= 0.05 * max(p1, 1e-300) or max(dil) <= dil[0] * 2.0, (dil, p1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# nse_eqns = anelastic: the density weights of the RHS and of OPR_Burgers (rhs_global_incompressible_1.f90:211-214, 275-277, 326-329;
+# opr_burgers.f90:128-183, 504-507) with given background profiles
+# ---------------------------------------------------------------------------------------------------------------------------------
+def background(y):
+    rb = 1.0 + 0.6 * np.exp(-2.5 * (y - y[0]) / (y[-1] - y[0]))          # a density decreasing with height
+    return rb, 1.0 / rb
+
+
+@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (64, 64, 64, False), (256, 64, 32, True)])
+def test_anelastic_burgers_operators_vs_oracle(T, nx, ny, nz, stretch):
+    """OPR_Burgers_X/Y/Z with rhoinv active: generic kernels at (32, 40, 16), the fast derivative kernels at the other sizes."""
+    import torch
+    from oracle import tlab_oracle as O
+    from tlab_amd.lib import load, check
+    x, y, z = grids(nx, ny, nz, stretch)
+    rb, ri = background(y)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 11)
+    dp = __import__("ctypes").POINTER(__import__("ctypes").c_double)
+    check(load().tlab_opr_burgers_set_anelastic(ny, rb.ctypes.data_as(dp), ri.ctypes.data_as(dp)), "set_anelastic")
+    try:
+        s_, v_ = torch.from_numpy(s0[0]).cuda(), torch.from_numpy(q0[1]).cuda()
+        res, tmp = torch.empty_like(s_), torch.empty_like(s_)
+        for d, (nodes, per, uni) in {1: (x, True, True), 2: (y, False, not stretch), 3: (z, True, True)}.items():
+            gp, go = T.FdmPlan(nodes, per, uni, hyper_bc1_ext=REF_HYPER), O.FdmPlan(nodes, per, uni)
+            burg = (T.OPR_Burgers_X, T.OPR_Burgers_Y, T.OPR_Burgers_Z)[d - 1]
+            burg(T.OPR_B_U_IN, 1.0 / 300.0, nx, ny, nz, 0, gp, s_, v_, res, tmp)
+            ref = O.opr_burgers(d, nx, ny, nz, 0, go, 1.0 / 300.0, s0[0], q0[1], anelastic=(rb, ri))[0]
+            assert rel_err(res.cpu().numpy(), ref) <= 1e-12, d
+            plain = O.opr_burgers(d, nx, ny, nz, 0, go, 1.0 / 300.0, s0[0], q0[1])[0]
+            assert rel_err(ref, plain) > 1e-3          # (the weights do something)
+    finally:
+        check(load().tlab_opr_burgers_set_anelastic(0, None, None), "set_anelastic off")
+    with pytest.raises(T.TlabError):                   # ribackground must be the reciprocal profile
+        check(load().tlab_opr_burgers_set_anelastic(ny, rb.ctypes.data_as(dp), rb.ctypes.data_as(dp)), "set_anelastic")
+
+
+@pytest.mark.parametrize("bcs", ["noslip", "freeslip"])
+@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (128, 64, 64, True)])
+def test_anelastic_substep_vs_oracle(T, nx, ny, nz, stretch, bcs):
+    import torch
+    from tlab_amd.dns import Dns, velocity_bcs
+    from oracle.tlab_oracle_rhs import DnsOracle
+    x, y, z = grids(nx, ny, nz, stretch)
+    rb, ri = background(y)
+    visc, sc = 1.0 / 800.0, (0.7,)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 5)
+    d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=REF_HYPER)
+    d.set_anelastic(rb)
+    try:
+        if bcs == "freeslip":
+            d.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+        for i in range(3):
+            d.q[i].copy_(torch.from_numpy(q0[i]))
+        d.s[0].copy_(torch.from_numpy(s0[0]))
+        dtime = 2e-3
+        sched = [(dtime * d.kdt[k], d.kco[k], True) for k in range(2)]
+
+        def make_oracle():
+            o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, anelastic=(rb, ri))
+            if bcs == "freeslip":
+                o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
+            return o
+        B, S = oracle_substeps(("anel", nx, ny, nz, stretch, bcs), make_oracle, q0, s0, sched, nsamples=2)
+        for k, (dte, kco, scale) in enumerate(sched):
+            d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
+            check_state(d, B, S, k, tag="anelastic " + bcs)
+        # and it is not the incompressible result
+        o0 = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch)
+        for i in range(3):
+            o0.q[i] = q0[i].copy()
+        o0.s[0] = s0[0].copy()
+        o0.time_substep(*sched[0])
+        assert rel_err(B[0]["q"][1], o0.q[1]) > 1e-6
+    finally:
+        d.set_anelastic(None)

@@ -58,6 +58,14 @@ int guarded(F &&f) {
     }
 }
 
+// result of a nested C-ABI call inside a guarded body: pass the failure on with its class
+void ok_or_throw(int rc) {
+    if (rc == TLAB_OK) return;
+    if (rc == TLAB_EHIP) throw HipError(g_err);
+    if (rc == TLAB_EUNSUPPORTED) throw Unsupported(g_err);
+    throw Invalid(g_err);
+}
+
 double *workspace(size_t n) {
     if (!g_ws) g_ws = new DeviceArray();
     if (g_ws->n < n) {
@@ -983,6 +991,29 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
     });
 }
 
+// nse_eqns == DNS_EQNS_ANELASTIC: the state OPR_Burgers_Initialize keeps in module variables (rhoinv(1), rhoinv(3), the modified U factors of
+// fdmDiffusion(2); physics/opr_burgers.f90:128-183)
+static std::unique_ptr<DeviceArray> g_anelastic_ri;
+static int g_anelastic_ny = 0;
+int tlab_opr_burgers_set_anelastic(int ny, const double *rbackground, const double *ribackground) {
+    return guarded([&] {
+        if (ny <= 0 || !rbackground || !ribackground) {      // back to the incompressible operator
+            g_anelastic_ri.reset();
+            g_anelastic_ny = 0;
+            return;
+        }
+        if (g_device < 0) throw HipError("tlab_init has not been called (no CPU fallback exists)");
+        // along y the reference scales U's inverse diagonal by ribackground(j) and its superdiagonal by rbackground(j+1): x'(j) = x(j) ribackground(j)
+        // provided rbackground * ribackground = 1, which is what the profiles of Thermo_Anelastic are; anything else is not the anelastic operator
+        for (int j = 0; j < ny; ++j)
+            if (std::fabs(rbackground[j] * ribackground[j] - 1.0) > 1e-14) throw Invalid("ribackground must be 1 / rbackground");
+        g_anelastic_ri = std::make_unique<DeviceArray>();
+        g_anelastic_ri->upload(std::vector<double>(ribackground, ribackground + ny));
+        g_anelastic_ny = ny;
+    });
+}
+bool tlab_internal_anelastic() { return g_anelastic_ny > 0; }
+
 int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int nz, int ibc, double nu, const double *s,
                      const double *u, double *result, double *tmp1, int write_transposed) {
     return guarded([&] {
@@ -1003,7 +1034,11 @@ int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int n
         int path = choose_path(dir, geom.n, g);
         if (path == PATH_XLINE && (corr || g->t.der2.direct)) path = PATH_GENERIC;
         g_last_path = path;
-        if (path == PATH_XLINE) {
+        if (g_anelastic_ny > 0) {      // OPR_Burgers_1D with rhoinv (opr_burgers.f90:504-507): the two derivatives unfused, then the weighted sum
+            if (g_anelastic_ny != ny) throw Invalid("anelastic profiles were given for another ny");
+            ok_or_throw(tlab_opr_partial(dir, g, TLAB_OPR_P2_P1, nx, ny, nz, ibc, s, result, d1));
+            hip_check(launch_burgers_epilogue_anelastic(result, vel, d1, nu, g_anelastic_ri->p, nx, ny, ntot, g_stream), "burgers epilogue (anelastic)");
+        } else if (path == PATH_XLINE) {
             run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu);
         } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {
             run_htile(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu);                  // fully fused: s and vel read once

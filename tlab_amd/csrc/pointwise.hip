@@ -263,6 +263,35 @@ hipError_t launch_pencil_repack(double *a, double *buf, int nxh, int ny, int kma
                        kmax, dir);
     return CHECK_LAUNCH();
 }
+// Thermo_Anelastic_WEIGHT_{INPLACE,OUTPLACE,SUBTRACT} (thermodynamics/thermo_anelastic.f90:377-448): a(i,j,k) weighted by a profile of y
+//   mode 0: out = in * w(j)      mode 1: out = out - in * w(j)
+__global__ void __launch_bounds__(256) k_weight_y(double *__restrict__ out, const double *__restrict__ in, const double *__restrict__ w, int nx,
+                                                  int ny, long long n, int mode) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double wj = w[(i / nx) % ny];
+        out[i] = mode ? out[i] - in[i] * wj : in[i] * wj;
+    }
+}
+hipError_t launch_weight_y(double *out, const double *in, const double *w, int nx, int ny, long long n, int mode, hipStream_t st) {
+    ProfScope ps("k_weight_y", st, (double)n * (mode ? 24.0 : 16.0));
+    hipLaunchKernelGGL(k_weight_y, dim3(pw_grid(n)), dim3(256), 0, st, out, in, w, nx, ny, n, mode);
+    return CHECK_LAUNCH();
+}
+// OPR_Burgers_1D with rhoinv%active (physics/opr_burgers.f90:504-507): out = (nu d2) * ribackground(j) - vel * d1
+__global__ void __launch_bounds__(256) k_burgers_epilogue_anelastic(double *__restrict__ out, const double *__restrict__ vel,
+                                                                    const double *__restrict__ d1, double nu, const double *__restrict__ ri,
+                                                                    int nx, int ny, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (nu * out[i]) * ri[(i / nx) % ny] - vel[i] * d1[i];
+}
+hipError_t launch_burgers_epilogue_anelastic(double *out, const double *vel, const double *d1, double nu, const double *ri, int nx, int ny,
+                                             long long n, hipStream_t st) {
+    ProfScope ps("k_burgers_epilogue_anelastic", st, (double)n * 32.0);
+    hipLaunchKernelGGL(k_burgers_epilogue_anelastic, dim3(pw_grid(n)), dim3(256), 0, st, out, vel, d1, nu, ri, nx, ny, n);
+    return CHECK_LAUNCH();
+}
 hipError_t launch_scale(double *a, double alpha, long long n, hipStream_t st) {
     hipLaunchKernelGGL(k_scale, dim3(pw_grid(n)), dim3(256), 0, st, a, alpha, n);
     return CHECK_LAUNCH();

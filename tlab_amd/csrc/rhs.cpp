@@ -51,12 +51,17 @@ struct tlab_dns {
     double *part = nullptr;                        // [2][NPART] partial (min, max) of the reductions
     double dx2i = 0.0, schmidtfactor = 0.0;
     int koffset = 0, nz_total = 0;                 // z-slab: first global plane and global nz (one_ov_ds1 of z is indexed globally)
+    // nse_eqns == DNS_EQNS_ANELASTIC: rbackground, ribackground (ny values each) on the device; the wall values of rbackground on the host
+    double *rb = nullptr, *rib = nullptr;
+    double rb_wall[2] = {1.0, 1.0};
     ~tlab_dns() {
         if (bcs_hb) (void)hipFree(bcs_hb);
         if (bcs_ht) (void)hipFree(bcs_ht);
         for (int i = 0; i < 3; ++i)
             if (od[i]) (void)hipFree(od[i]);
         if (part) (void)hipFree(part);
+        if (rb) (void)hipFree(rb);
+        if (rib) (void)hipFree(rib);
     }
 };
 
@@ -130,7 +135,7 @@ int tlab_dns_destroy(tlab_dns_t d) {
 static void burgers_into(tlab_dns_t d, int dir, double nu, const double *s, const double *vel, bool self, double *dst, double *tmp,
                          double *scratch, bool &pending_add, double **pend, int &npend) {
     const int nx = d->nx, ny = d->ny, nz = d->nz;
-    if (d->fuse && tlab_internal_burgers_acc(dir, d->g[dir - 1], nx, ny, nz, 0, nu, s, vel, dst)) return;
+    if (d->fuse && !d->rb && tlab_internal_burgers_acc(dir, d->g[dir - 1], nx, ny, nz, 0, nu, s, vel, dst)) return;
     ok(tlab_opr_burgers(dir, d->g[dir - 1], self ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, nx, ny, nz, 0, nu, s, vel, tmp, scratch, 0), "OPR_Burgers");
     pend[npend++] = tmp;
     pending_add = true;
@@ -158,7 +163,8 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     double *tmps[3] = {tmp1, tmp7, tmp8};
     // Fused path: one launch per direction serves all equations (they share the advecting velocity of that direction), four fields per
     // launch.  The terms of an equation are then added in the order x, y, z instead of the reference's {1,2,3},{2,1,3},{3,1,2}: rounding only.
-    const bool batched = d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
+    const bool anel = d->rb != nullptr;            // every fused form below assumes the incompressible operators: anelastic runs take the literal sequence
+    const bool batched = !anel && d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
                          tlab_internal_burgers_fusable(3, gz, nx, ny, nz);
     const bool fresh = d->fresh;       // TIME_RUNGEKUTTA zeroes hq, hs at the start of a step (time.f90:212-216): the first launch overwrites instead
     d->fresh = false;
@@ -215,7 +221,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         }
     }
     // ---- pressure (:177-260, remove_divergence branch): forcing = div(hq + q/dte) ----
-    bool fused_div = d->fuse && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) &&
+    bool fused_div = !anel && d->fuse && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) &&
                      tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
     if (div_in_burgers) {     // tmp1 holds the x term already
         const bool oky = tlab_internal_partial_p1_fused(2, gy, nx, ny, nz, B0, hq[1], v, idte, tmp1, true);
@@ -232,6 +238,11 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     }
     if (!fused_div) {
         hk(launch_axpy3(tmp2, tmp3, tmp4, hq[1], hq[0], hq[2], v, u, w, idte, n, st), "axpy3");
+        if (anel) {      // Thermo_Anelastic_WEIGHT_INPLACE(.., rbackground, tmp2 | tmp3 | tmp4)  (:211-214)
+            hk(launch_weight_y(tmp2, tmp2, d->rb, nx, ny, n, 0, st), "weight");
+            hk(launch_weight_y(tmp3, tmp3, d->rb, nx, ny, n, 0, st), "weight");
+            hk(launch_weight_y(tmp4, tmp4, d->rb, nx, ny, n, 0, st), "weight");
+        }
         ok(tlab_opr_partial(2, gy, TLAB_OPR_P1, nx, ny, nz, B0, tmp2, tmp1, nullptr), "OPR_Partial_Y");
         ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp3, tmp2, nullptr), "OPR_Partial_X");
         ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp4, tmp3, nullptr), "OPR_Partial_Z");
@@ -239,12 +250,16 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     }
     // Neumann BCs in d/dy(p) s.t. v = 0 (:263-281)
     hk(launch_get_wall_planes(hq[1], d->bcs_hb, d->bcs_ht, nx, ny, nz, st), "wall planes");
+    if (anel) {          // BcsFlowJmin%ref(:,:,2) = p_bcs(:,1,:) * rbackground(1), Jmax likewise (:275-277)
+        hk(launch_scale(d->bcs_hb, d->rb_wall[0], (long long)nx * nz, st), "scale");
+        hk(launch_scale(d->bcs_ht, d->rb_wall[1], (long long)nx * nz, st), "scale");
+    }
     // pressure in tmp1, Oy derivative in tmp3 (:284)
     ok(tlab_opr_poisson(d->poisson, nx, ny, nz, TLAB_BCS_NN, tmp1, tmp2, tmp4, d->bcs_hb, d->bcs_ht, tmp3), "OPR_Poisson");
     // ---- pressure gradient (:319-320).  With Dirichlet walls and the RK update folded in (tail_update), the x- and z-gradient kernels
     // finish u and w themselves: hq -= dp/dx; wall planes; q += dte hq; hq *= kco (no gradient array is written or re-read) ----
     bool grad_final = false;
-    if (tail_update && d->fuse && nz > 1) {
+    if (tail_update && d->fuse && nz > 1 && !anel) {
         bool dirichlet = true;
         for (int iq = 0; iq < 3; ++iq) dirichlet = dirichlet && d->flow_jmin[iq] == TLAB_DNS_BCS_DIRICHLET && d->flow_jmax[iq] == TLAB_DNS_BCS_DIRICHLET;
         if (dirichlet && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz)) {
@@ -272,10 +287,16 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         if (ibc & 2) pt = d->bcs_ht;
     };
     const double *pb, *pt;
+    if (anel) {          // Thermo_Anelastic_WEIGHT_SUBTRACT(.., ribackground, tmp2 | tmp3 | tmp4, hq(:,1) | hq(:,2) | hq(:,3))  (:326-329)
+        hk(launch_weight_y(hq[0], tmp2, d->rib, nx, ny, n, 1, st), "weight");
+        hk(launch_weight_y(hq[1], tmp3, d->rib, nx, ny, n, 1, st), "weight");
+        hk(launch_weight_y(hq[2], tmp4, d->rib, nx, ny, n, 1, st), "weight");
+    }
     if (tail_update) {
         // hq -= grad p (:348-352), wall planes (:373-375), q += dte hq (time.f90:645-664), hq *= kco (:272-297) in one pass per field
         double *gp[3] = {tmp2, tmp3, tmp4};
-        if (any_q) {   // the Neumann planes need the finished tendency first
+        if (anel) gp[0] = gp[1] = gp[2] = nullptr;      // subtracted above, with the density weight
+        if (any_q && !anel) {   // the Neumann planes need the finished tendency first
             hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
             gp[0] = gp[1] = gp[2] = nullptr;
         }
@@ -289,7 +310,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             hk(launch_final_update(s[is], hs[is], nullptr, pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
     } else {
-        hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
+        if (!anel) hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
         for (int iq = 0; iq < 3; ++iq) {
             planes(ibc_q[iq], hq[iq], pb, pt);
             hk(launch_set_wall_planes(hq[iq], pb, pt, nx, ny, nz, st), "wall planes");
@@ -361,6 +382,35 @@ static void minmax_impl(tlab_dns_t d, const double *a, const double *v, const do
     hk(hipStreamSynchronize(st), "sync");
     *mn = *std::min_element(h.begin(), h.begin() + nb);
     *mx = *std::max_element(h.begin() + nb, h.end());
+}
+
+// nse_eqns == DNS_EQNS_ANELASTIC (tools/dns/rhs_global_incompressible_1.f90:211-214, 275-277, 326-329; physics/opr_burgers.f90:128-183) with the
+// background profiles the host's thermodynamics made: rbackground(1:ny), ribackground(1:ny) = 1 / rbackground (HOST pointers; NULL: incompressible)
+int tlab_dns_set_anelastic(tlab_dns_t d, const double *rbackground, const double *ribackground) {
+    if (!d) return TLAB_EINVAL;
+    try {
+        if (d->rb) { (void)hipFree(d->rb); d->rb = nullptr; }
+        if (d->rib) { (void)hipFree(d->rib); d->rib = nullptr; }
+        if (!rbackground || !ribackground) {
+            ok(tlab_opr_burgers_set_anelastic(0, nullptr, nullptr), "tlab_opr_burgers_set_anelastic");
+            return TLAB_OK;
+        }
+        ok(tlab_opr_burgers_set_anelastic(d->ny, rbackground, ribackground), "tlab_opr_burgers_set_anelastic");
+        const size_t bytes = (size_t)d->ny * sizeof(double);
+        hk(hipMalloc((void **)&d->rb, bytes), "hipMalloc");
+        hk(hipMalloc((void **)&d->rib, bytes), "hipMalloc");
+        hk(hipMemcpy(d->rb, rbackground, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+        hk(hipMemcpy(d->rib, ribackground, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+        d->rb_wall[0] = rbackground[0];
+        d->rb_wall[1] = rbackground[d->ny - 1];
+        return TLAB_OK;
+    } catch (const Fail &e) {
+        tlab_set_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    }
 }
 
 int tlab_dns_set_slab(tlab_dns_t d, int koffset) {

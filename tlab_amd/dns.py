@@ -92,6 +92,19 @@ class Dns:
         fj0, fj1, sj0, sj1 = _bcs_arrays(self.nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax)
         check(load().tlab_dns_set_bcs(self._h, fj0, fj1, sj0, sj1), "tlab_dns_set_bcs")
 
+    def set_anelastic(self, rbackground=None, ribackground=None):
+        """nse_eqns = anelastic with the background density profile rbackground(ny) (ribackground defaults to 1 / rbackground); None: incompressible.
+        Module state of the Burgers operator, like the reference's rhoinv: it applies to every plan of the process until switched off."""
+        dp = ctypes.POINTER(ctypes.c_double)
+        if rbackground is None:
+            check(load().tlab_dns_set_anelastic(self._h, None, None), "tlab_dns_set_anelastic")
+            return
+        rb = np.ascontiguousarray(rbackground, dtype=np.float64)
+        ri = np.ascontiguousarray(1.0 / rb if ribackground is None else ribackground, dtype=np.float64)
+        if rb.shape != (self.ny,) or ri.shape != (self.ny,):
+            raise TlabError("anelastic profiles: ny values each")
+        check(load().tlab_dns_set_anelastic(self._h, rb.ctypes.data_as(dp), ri.ctypes.data_as(dp)), "tlab_dns_set_anelastic")
+
     def set_fusion(self, on):
         """on (default): pointwise sums folded into the operator kernels; off: the reference's literal sequence."""
         check(load().tlab_dns_set_fusion(self._h, int(bool(on))), "tlab_dns_set_fusion")

@@ -32,6 +32,7 @@ module TLAB_AMD_BURGERS_MODULE
     public :: OPR_Burgers_Y
     public :: OPR_Burgers_Z
     public :: OPR_Burgers_SetPlans
+    public :: OPR_Burgers_AMD_Anelastic      ! (rbackground, ribackground): what OPR_Burgers_Initialize does for nse_eqns == DNS_EQNS_ANELASTIC (:128-183)
 
     integer, parameter, public :: OPR_B_SELF = 0
     integer, parameter, public :: OPR_B_U_IN = 1
@@ -84,6 +85,20 @@ contains
         type(fdm_dt), intent(in), target :: g(3)
         gp => g
     end subroutine OPR_Burgers_SetPlans
+
+    ! Anelastic density correction of the diffusion term (physics/opr_burgers.f90:128-183): rhoinv(1), rhoinv(3) and the scaled U factors of
+    ! fdmDiffusion(2) all amount to the factor ribackground(j), which the device applies in the epilogue of the operator.  A complete host calls this
+    ! from where the reference has the block, with the profiles of module Thermo_Anelastic; size 0 switches back.
+    subroutine OPR_Burgers_AMD_Anelastic(rbackground, ribackground)
+        real(wp), intent(in), target :: rbackground(:), ribackground(:)
+        integer(c_int) rc
+        if (size(rbackground) == 0) then
+            rc = tlab_opr_burgers_set_anelastic(0_c_int, c_null_ptr, c_null_ptr)
+        else
+            rc = tlab_opr_burgers_set_anelastic(int(size(rbackground), c_int), c_loc(rbackground), c_loc(ribackground))
+        end if
+        call TLab_AMD_Check(rc, 'tlab_opr_burgers_set_anelastic')
+    end subroutine OPR_Burgers_AMD_Anelastic
 
     subroutine burgers_any(idir, ivel, is, nx, ny, nz, bcs, s, u, result, tmp1)
         integer, intent(in) :: idir, ivel, is

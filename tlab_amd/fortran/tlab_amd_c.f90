@@ -73,6 +73,15 @@ module TLab_AMD_C
             real(c_double), value :: nu
             type(c_ptr), value :: plan, s, u, res, tmp1
         end function
+        integer(c_int) function tlab_opr_burgers_set_anelastic(ny, rbackground, ribackground) bind(C, name='tlab_opr_burgers_set_anelastic')
+            import :: c_int, c_ptr
+            integer(c_int), value :: ny
+            type(c_ptr), value :: rbackground, ribackground      ! host arrays of ny doubles (c_null_ptr: incompressible)
+        end function
+        integer(c_int) function tlab_dns_set_anelastic(dns, rbackground, ribackground) bind(C, name='tlab_dns_set_anelastic')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: dns, rbackground, ribackground
+        end function
         integer(c_int) function tlab_poisson_plan_create(plan, gx, gy, gz, nx, ny, nz) bind(C, name='tlab_poisson_plan_create')
             import :: c_int, c_ptr
             type(c_ptr), intent(out) :: plan
