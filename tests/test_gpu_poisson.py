@@ -209,7 +209,8 @@ def test_projection_forcing_within_the_oracles_own_scatter(T):
                                               (32, 512, 8, True), (16, 256, 8, False)])
 def test_poisson_dirichlet_vs_oracle(T, nx, ny, nz, stretch):
     """ibc = BCS_DD of the factorized solver (OPR_ODE2_Factorize_DD / _DD_Sing per mode, opr_elliptic.f90:322-329): bcs_hb, bcs_ht are the
-    wall VALUES of p.  Chunked plans (ny % 8 == 0) and marching plans (ny = 33) take the same marching route for this boundary type."""
+    wall VALUES of p.  Chunked plans (ny % 8 == 0) take k_ode_nn<DD> with the singular and the lowest modes marched beside it, the marching plan
+    (ny = 33) the marching kernels for every mode; test_poisson_dirichlet_marching_route_on_chunked_plans keeps the old route of chunked plans covered."""
     import torch
     from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
     x, y, z = setup(nx, ny, nz, stretch)
@@ -240,6 +241,31 @@ def test_poisson_dirichlet_vs_oracle(T, nx, ny, nz, stretch):
             T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN, q, t1, t2, dev(hb), dev(ht), dpdy)
             qn, _ = OP.opr_poisson_fxz(plan_o, f, hb.reshape(nz, nx), ht.reshape(nz, nx))
             assert rel_err(q.cpu().numpy(), qn) <= TOL
+
+
+def test_poisson_dirichlet_marching_route_on_chunked_plans(T):
+    """TLAB_ODE_DD_CHUNKED=0: a chunked plan marches every mode for BCS_DD (the route before k_ode_nn<DD>); both routes of the same plan agree
+    with each other far inside the oracle's scatter."""
+    import os
+    import torch
+    nx, ny, nz = 32, 64, 16
+    x, y, z = setup(nx, ny, nz, True)
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, False), T.FdmPlan(z, True, True)]
+    plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+    rng = np.random.default_rng(5)
+    f, hb, ht = rng.uniform(-1, 1, nx * ny * nz), rng.uniform(-1, 1, nx * nz), rng.uniform(-1, 1, nx * nz)
+    t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.empty_like(t1)
+    out = {}
+    try:
+        for route in ("1", "0"):
+            os.environ["TLAB_ODE_DD_CHUNKED"] = route
+            p, dpdy = dev(f), torch.empty(nx * ny * nz, dtype=torch.float64, device="cuda")
+            T.OPR_Poisson(plan, nx, ny, nz, T.BCS_DD, p, t1, t2, dev(hb), dev(ht), dpdy)
+            out[route] = (p.cpu().numpy(), dpdy.cpu().numpy())
+    finally:
+        os.environ.pop("TLAB_ODE_DD_CHUNKED", None)
+    assert rel_err(out["1"][0], out["0"][0]) <= 1e-12 and rel_err(out["1"][1], out["0"][1]) <= 1e-12
+    assert not np.array_equal(out["1"][0], out["0"][0])          # (two different kernels did run)
 
 
 @pytest.mark.parametrize("nx,ny,nz,stretch,ibc,alphas", [

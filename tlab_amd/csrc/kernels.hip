@@ -915,8 +915,10 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
         static const int tpb = [] { const char *e = getenv("TLAB_XLINE_TPB"); return e ? atoi(e) : 0; }();
         const bool one = (mode == MODE_P1 || mode == MODE_P2);
         if (tpb == 256) return one ? launch_xline_m<8, 1, 4, 1, 256>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 256>(mode, a, st);
-        if (tpb == 1024) return one ? launch_xline_m<8, 1, 4, 1, 1024>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 1024>(mode, a, st);
-        return one ? launch_xline_m<8, 1, 4, 1, 512>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 512>(mode, a, st);
+        if (tpb == 512) return one ? launch_xline_m<8, 1, 4, 1, 512>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 512>(mode, a, st);
+        // two systems: 256 VGPRs + 70-110 AGPRs at 256 threads; on 512 threads the kernel spills (1.2 TB/s), and with chunk 0's rows read from LDS
+        // instead of scalar loads (no spills) both forms run at 2.2 TB/s against 2.46 (measured): 256 threads, scalar loads
+        return one ? launch_xline_m<8, 1, 4, 1, 512>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 256>(mode, a, st);
     }
     if (chunks != 64) return hipErrorInvalidValue;
     switch (n) {

@@ -1013,7 +1013,9 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
 #undef FAC
 }
 
-template <int NM>
+// DD: OPR_ODE2_Factorize_DD (opr_odes.f90:391-478) instead of _NN: the same two solves with the top value of u GIVEN (bcs(:,2)), two constants
+// instead of three (a.cst = [5][nm]: aa, bb, 1 / (aa sp(1) - bb u1(1)), sp(1), u1(1) from k_dd_constants), no e^(+) term in the superposition.
+template <int NM, bool DD = false>
 __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     extern __shared__ double lds[];
     const int C = a.C, n = a.n;
@@ -1072,12 +1074,23 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     }
     if (c == C - 1) { s_sc[6 * NM + m] = vh[OM][0]; s_sc[7 * NM + m] = vh[OM][1]; }     // v0(n)
     // ---- u0' - lambda u0 = v0, u0(n) = 0 ; the "opposite boundary value" is v0(1) = 0 (res(1) = f(1), fdm_integral.f90:243) ----
+    if (DD) { u_n[0] = bt[0]; u_n[1] = bt[1]; }      // u(:, nx) = bcs(:, 2)  (:440)
     ode_solve<2, NM>(a.T2, -lam, a.chk2, nm, t, c, C, m, vh, v_1, u_n, u, ext, s_w, s_k, s_fac);
     // ---- u0(1), v0(n), du0(n) -> the three constants (opr_odes.f90:350-356 with the LU of k_nn_constants) ----
     if (c == 0) { s_sc[4 * NM + m] = u[0][0]; s_sc[5 * NM + m] = u[0][1]; }
     if (c == C - 1) { s_sc[8 * NM + m] = ext[0]; s_sc[9 * NM + m] = ext[1]; }
     __syncthreads();
-    {
+    if (DD) {      // :452-456
+        const double aa = a.cst[(unsigned)(0 * nm + t)], bc = a.cst[(unsigned)(1 * nm + t)], dummy = a.cst[(unsigned)(2 * nm + t)];
+        const double sp1 = a.cst[(unsigned)(3 * nm + t)], u11 = a.cst[(unsigned)(4 * nm + t)];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const double u0_1 = s_sc[(4 + l) * NM + m], v0_n = s_sc[(6 + l) * NM + m], du0n = s_sc[(8 + l) * NM + m];
+            const double w = lam * bt[l] - du0n + v0_n;
+            v_1[l] = (aa * (bb[l] - u0_1) - u11 * w) * dummy;
+            fn[l] = (sp1 * w - bc * (bb[l] - u0_1)) * dummy;
+        }
+    } else {
         const double a11 = a.cst[(unsigned)(0 * nm + t)], a21 = a.cst[(unsigned)(1 * nm + t)], a31 = a.cst[(unsigned)(2 * nm + t)];
         const double a12 = a.cst[(unsigned)(3 * nm + t)], a22 = a.cst[(unsigned)(4 * nm + t)], a32 = a.cst[(unsigned)(5 * nm + t)];
         const double a13 = a.cst[(unsigned)(6 * nm + t)], a23 = a.cst[(unsigned)(7 * nm + t)], a33 = a.cst[(unsigned)(8 * nm + t)];
@@ -1103,12 +1116,20 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
         const int j = j0 + p;
         const unsigned h = (unsigned)(((t / NM) * 5 * n + j) * NM + m), hs = (unsigned)(n * NM);       // hom_blocked[blk][5][n][NM]
         double hv1 = 0.0, hem = 0.0, hu1 = 0.0, hsp = 0.0, hep = 0.0;
-        if (need) { hv1 = a.hom[h]; hem = a.hom[h + hs]; hu1 = a.hom[h + 2 * hs]; hsp = a.hom[h + 3 * hs]; hep = a.hom[h + 4 * hs]; }
+        if (need) { hv1 = a.hom[h]; hem = a.hom[h + hs]; hu1 = a.hom[h + 2 * hs]; hsp = a.hom[h + 3 * hs]; if (!DD) hep = a.hom[h + 4 * hs]; }
         double uu[2], vv[2];
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
             const double u0 = u[p][l], v0 = vh[p + 1][l];
-            if (j == n - 1) {
+            if (DD) {           // :459-465: rows nx .. 2 by the general formula (u0(nx) = bcs(:,2), u1(nx) = sp(nx) = 0), row 1 = the bottom value
+                if (j == 0) {
+                    uu[l] = bb[l];
+                    vv[l] = v_1[l] + lam * uu[l];
+                } else {
+                    uu[l] = u0 + fn[l] * hu1 + v_1[l] * hsp;
+                    vv[l] = v0 + fn[l] * hv1 + v_1[l] * hem + lam * uu[l];
+                }
+            } else if (j == n - 1) {
                 uu[l] = u_n[l];
                 vv[l] = v0 + fn[l] * hv1 + v_1[l] * hem + lam * uu[l];
             } else if (j == 0) {
@@ -1356,6 +1377,28 @@ struct DDCombineArgs {
     long long nm;
 };
 
+// constants of OPR_ODE2_Factorize_DD that depend on the mode only (opr_odes.f90:452-454), for the chunked kernel: cst[5][nm]
+__global__ void __launch_bounds__(256) k_dd_constants(const double *__restrict__ hom, int hom_nm_block, const double *__restrict__ der,
+                                                      double *__restrict__ cst, int n, long long nm) {
+#pragma clang fp contract(off)
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nm) return;
+    auto H = [&](int c, int j) {
+        if (hom_nm_block > 0) {
+            const int NM = hom_nm_block;
+            return hom[(((t / NM) * 5 + c) * n + j) * NM + (t % NM)];
+        }
+        return hom[((long long)c * n + j) * nm + t];
+    };
+    const double aa = der[0 * nm + t] - H(0, n - 1);
+    const double bb = der[1 * nm + t] - H(1, n - 1);
+    cst[0 * nm + t] = aa;
+    cst[1 * nm + t] = bb;
+    cst[2 * nm + t] = 1.0 / (aa * H(3, 0) - bb * H(2, 0));
+    cst[3 * nm + t] = H(3, 0);
+    cst[4 * nm + t] = H(2, 0);
+}
+
 __global__ void __launch_bounds__(256) k_dd_combine(DDCombineArgs a) {
 #pragma clang fp contract(off)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1552,6 +1595,7 @@ struct tlab_poisson_plan {
     DBuf s_lam, s_f, s_unit, s_bct, s_v0, s_v1, s_u0, s_u1, s_du0, s_du1, s_scr;
     DBuf dd_v1, dd_u1, dd_du1, dd_sp, dd_ones, dd_bcb;      // BCS_DD: homogeneous solutions of the singular modes (built on first use)
     bool dd_ready = false;
+    DBuf cst_dd;                                // [5][nm] constants of the chunked BCS_DD solver (k_dd_constants), built on first use
     FftPlan fx_r2c, fx_c2r, fz_f, fz_b;
     FftPlan f2_fwd, f2_bwd;           // optional fused 2-D (x,z) transforms, batch over y
     std::unique_ptr<FftzPlan> fz_own;  // own strided z-transform (fftz.hip) where its lengths apply; rocFFT's fz_f / fz_b otherwise
@@ -1654,22 +1698,22 @@ int ode_modes_per_wg(int C) {
 }
 size_t ode_lds_bytes(int C, int NM) { return ((size_t)(64 + 4 * C + 10 + OK_SIZE) * NM + (size_t)(3 * OM + 1) * NM * C) * sizeof(double); }
 
-template <int NM>
+template <int NM, bool DD>
 void launch_ode_nm(const OdeArgs &a, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ode_nn<NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ode_nn<NM, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         (void)hipGetLastError();
         attr_done = true;
     }
     const unsigned grid = (unsigned)((a.nm + NM - 1) / NM);
-    hipLaunchKernelGGL((k_ode_nn<NM>), dim3(grid), dim3(NM * a.C), lds, st, a);
+    hipLaunchKernelGGL((k_ode_nn<NM, DD>), dim3(grid), dim3(NM * a.C), lds, st, a);
 }
 
-void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
+void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st, bool dd = false) {
     OdeArgs a{};
     a.T1 = P.sys(0); a.T2 = P.sys(1);
-    a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = P.cst.p; a.hom = P.homb.p; a.band = P.d_hom_band;
+    a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = dd ? P.cst_dd.p : P.cst.p; a.hom = P.homb.p; a.band = P.d_hom_band;
     a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
     a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.nm = P.nm;
     const int NM = P.ode_nm_per_wg;
@@ -1679,13 +1723,23 @@ void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_h
         a.pair_xcd = pair;
     }
     const size_t lds = ode_lds_bytes(a.C, NM);
-    ProfScope ps("k_ode_nn", st, (double)P.nm * P.ny * 48.0);      // algorithmic bytes: f^ in, p^ and dp^/dy out (its own tables -- checkpoints 12 B, the band of the homogeneous solutions -- come on top)
-    switch (NM) {
-    case 4: launch_ode_nm<4>(a, lds, st); break;
-    case 8: launch_ode_nm<8>(a, lds, st); break;
-    case 16: launch_ode_nm<16>(a, lds, st); break;
-    case 32: launch_ode_nm<32>(a, lds, st); break;
-    default: launch_ode_nm<64>(a, lds, st); break;
+    ProfScope ps(dd ? "k_ode_nn<DD>" : "k_ode_nn", st, (double)P.nm * P.ny * 48.0);      // algorithmic bytes: f^ in, p^ and dp^/dy out (its own tables -- checkpoints 12 B, the band of the homogeneous solutions -- come on top)
+    if (dd) {
+        switch (NM) {
+        case 4: launch_ode_nm<4, true>(a, lds, st); break;
+        case 8: launch_ode_nm<8, true>(a, lds, st); break;
+        case 16: launch_ode_nm<16, true>(a, lds, st); break;
+        case 32: launch_ode_nm<32, true>(a, lds, st); break;
+        default: launch_ode_nm<64, true>(a, lds, st); break;
+        }
+    } else {
+        switch (NM) {
+        case 4: launch_ode_nm<4, false>(a, lds, st); break;
+        case 8: launch_ode_nm<8, false>(a, lds, st); break;
+        case 16: launch_ode_nm<16, false>(a, lds, st); break;
+        case 32: launch_ode_nm<32, false>(a, lds, st); break;
+        default: launch_ode_nm<64, false>(a, lds, st); break;
+        }
     }
     hipc(hipGetLastError(), "k_ode_nn");
 }
@@ -2175,12 +2229,26 @@ static void poisson_direct_stage(tlab_poisson_plan_t P, int ibc, double *f_hat, 
     hipc(hipGetLastError(), "k_int2");
 }
 
-// ibc = BCS_DD on a factorized plan (opr_elliptic.f90:322-329): marching kernels for every mode
+// ibc = BCS_DD on a factorized plan (opr_elliptic.f90:322-329).  Chunked plans: the regular modes in k_ode_nn<DD> (the BCS_NN kernel with the
+// top value given and the two constants of OPR_ODE2_Factorize_DD), the <= 4 singular modes (_DD_Sing) and the lowest-lambda modes (marching
+// sub-plan) beside it on the side stream, as for BCS_NN; other plans: marching kernels for every mode.  TLAB_ODE_DD_CHUNKED=0 keeps the marching route.
 static void poisson_dd_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
     const long long nm = P->nm;
     const int n = P->ny, nxh = P->nxh, ny = P->ny;
     const int ns = (int)P->sing_modes.size();
-    if (P->scratch.n == 0) {     // a chunked plan released the work arrays of the marching kernels: BCS_DD brings them back
+    const char *dd_env = getenv("TLAB_ODE_DD_CHUNKED");      // read per call: the tests switch between the two routes of one plan
+    const bool chunked = P->use_chunked && !(dd_env && atoi(dd_env) == 0);
+    hipStream_t main_st = st;
+    if (chunked) {
+        if (P->cst_dd.n == 0) {
+            P->cst_dd.alloc((size_t)5 * nm);
+            hipLaunchKernelGGL(k_dd_constants, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, P->homb.p, P->ode_nm_per_wg, P->der.p, P->cst_dd.p, n, nm);
+            hipc(hipGetLastError(), "k_dd_constants");
+        }
+        hipc(hipEventRecord(P->ev_fork, st), "event record");
+        hipc(hipStreamWaitEvent(P->side, P->ev_fork, 0), "stream wait");
+        st = P->side;            // the singular and the low modes run beside k_ode_nn<DD>, which leaves their columns alone
+    } else if (P->scratch.n == 0) {     // a chunked plan released the work arrays of the marching kernels: they come back
         P->scratch.alloc((size_t)6 * n * nm); P->v0.alloc((size_t)2 * n * nm); P->u0.alloc((size_t)2 * n * nm);
     }
     // ---- singular modes first (they read f^ before the regular combine may overwrite it when p_hat aliases f_hat) ----
@@ -2208,6 +2276,28 @@ static void poisson_dd_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat
         Int1Args s2 = base_args(*P, 1, P->s_lam.p, ns, P->s_scr.p);        // u' = v, u(n) = bcs_t
         s2.fsrc = P->s_v0.p; s2.nlf = 2; s2.zero_bsave = 0; s2.bv_ptr = P->s_bct.p; s2.dst = P->s_u0.p; s2.du = P->s_du0.p;
         launch_int1<2, 2, FS_LINEAR>(s2, st);
+    }
+    if (chunked) {
+        if (ns > 0) {
+            dim3 g(ns, (n + 63) / 64), blk(64);
+            hipLaunchKernelGGL(k_sing_combine_dd, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->dd_u1.p, P->dd_v1.p, P->dd_sp.p, P->s_du0.p, P->dd_du1.p,
+                               P->dd_bcb.p, P->d_sing, ns, n, nxh, ny, p_hat, dp_hat);
+        }
+        if (P->low) {            // the lowest-lambda modes through the marching sub-plan (poisson_ode_stage does the same for BCS_NN)
+            const int nl = P->n_low;
+            const dim3 g((nl + 63) / 64, n), blk(64);
+            hipLaunchKernelGGL(k_modes_gather, g, blk, 0, st, reinterpret_cast<const double2 *>(f_hat), P->d_low_modes, nl, n, nxh, ny,
+                               reinterpret_cast<double2 *>(P->low_f.p));
+            poisson_dd_stage(P->low.get(), P->low_f.p, P->low_p.p, P->low_dp.p, st);
+            hipLaunchKernelGGL(k_modes_scatter, g, blk, 0, st, reinterpret_cast<const double2 *>(P->low_p.p),
+                               reinterpret_cast<const double2 *>(P->low_dp.p), P->d_low_modes, nl, n, nxh, ny, reinterpret_cast<double2 *>(p_hat),
+                               reinterpret_cast<double2 *>(dp_hat));
+        }
+        launch_ode(*P, f_hat, p_hat, dp_hat, main_st, true);
+        hipc(hipEventRecord(P->ev_join, st), "event record");
+        hipc(hipStreamWaitEvent(main_st, P->ev_join, 0), "stream wait");
+        hipc(hipGetLastError(), "BCS_DD kernels");
+        return;
     }
     // ---- regular modes ----
     Int1Args a = base_args(*P, 0, P->lam.p, nm, P->scratch.p);             // v' + l v = f, v(1) = 0
