@@ -8,8 +8,11 @@ RHS hot path (OPR_Burgers x (12+3 ns), OPR_Partial x 5, OPR_Poisson, pointwise a
 
 A "step" is one explicit RK substep (TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT, tools/dns/time.f90:559) on synthetic fields
 already resident in HBM.  Prints ONE JSON line on rank 0.  The `roofline` object is measured live with HIP events placed
-by the library around every kernel launch on its own stream; `cpu_baseline` times the numpy oracle (a port of the
-reference's CPU path, oracle/) on a bounded sample of the same workload on the host cores of this box.
+by the library around every kernel launch on its own stream; `targets` = OPR_Partial_{X,Y,Z}(OPR_P1) standalone (the north-star's own
+kernel); `substep_traffic` = the substep on the HBM bytes it really moves (PMC counters, profiles/traffic.json); `cpu_baseline` times the
+C / OpenMP restatement of the reference's CPU path (oracle/tlab_cpu.c, kind "port") on bounded samples of the same workload on the host
+cores of this box, best of several thread counts.  `--gpus N` without a launcher starts torch.distributed.run itself.  Diagnostics:
+`--loopback P` (P z-slab ranks on one GPU), `--decomp IxK` (x/z pencils), `--grid NX NY NZ`, `--nscal`.
 """
 import argparse
 import json
