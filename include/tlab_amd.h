@@ -129,9 +129,27 @@ int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int n
 /* The anelastic branch of OPR_Burgers_1D (physics/opr_burgers.f90:504-507) with the module state OPR_Burgers_Initialize sets up for
  * nse_eqns == DNS_EQNS_ANELASTIC (:128-183): the diffusion term is multiplied by ribackground(j) -- rhoinv(1), rhoinv(3) along x and z, the
  * scaled U factors of fdmDiffusion(2) along y (the same product, rounding aside).  HOST pointers, ny values each; ny = 0 or NULL: off.
- * While it is on, tlab_opr_burgers runs the two derivatives unfused and a weighted epilogue.  The dealiasing branch (:478-500, OPR_FILTER_1D) is
- * not built: TLAB_EUNSUPPORTED is the answer of the Fortran shim when [Dealiasing] selects a filter. */
+ * While it is on, tlab_opr_burgers runs the two derivatives unfused and a weighted epilogue. */
 int tlab_opr_burgers_set_anelastic(int ny, const double *rbackground, const double *ribackground);
+
+/* ---- 1-D filters: OPR_FILTER_1D (operators/opr_filter.f90:393-460) and the dealiasing branch of OPR_Burgers_1D ----------------------
+ * type(filter_dt) as OPR_FILTER_INITIALIZE leaves it (opr_filter.f90:28-41, 236-275): type = DNS_FILTER_COMPACT 1 | _6E 2 | _4E 3 |
+ * _COMPACT_CUTOFF 9 (:56-65; tophat 8 and the 3-D spectral / Helmholtz types: TLAB_EUNSUPPORTED), BcsMin / BcsMax = DNS_FILTER_BCS_* of
+ * filters/flt_base.f90:5-11, coeffs = f%coeffs(size, inb_filter), HOST pointer, column-major (NULL for explicit6; the generators
+ * FLT_C4_RHS_COEFFS / FLT_E4_COEFFS and the LU of the compact forms stay the host's). */
+typedef struct tlab_filter *tlab_filter_t;
+#define TLAB_FILTER_COMPACT 1
+#define TLAB_FILTER_6E 2
+#define TLAB_FILTER_4E 3
+#define TLAB_FILTER_COMPACT_CUTOFF 9
+int tlab_filter_create(tlab_filter_t *out, int type, int size, int periodic, int bcsmin, int bcsmax, int inb_filter, const double *coeffs);
+int tlab_filter_destroy(tlab_filter_t f);
+/* result = filter(u) along direction dir of a field (nx, ny, nz), out of place: FLT_C4_RHS + TRIDSS / TRIDPSS, FLT_C4[P]_CUTOFF_RHS + PENTADSS2 /
+ * PENTADPSS, FLT_E6, FLT_E4 (src/filters/flt_compact.f90, flt_explitic.f90) -- one line per thread, the reference's operation order. */
+int tlab_opr_filter_1d(int dir, tlab_filter_t f, int nx, int ny, int nz, const double *u, double *result);
+/* [Dealiasing] Dealiasing(dir) of OPR_Burgers (physics/opr_burgers.f90:33, 71, 118-125): while a filter is set for a direction, tlab_opr_burgers
+ * along it computes nu d2s - filter(u) filter(ds/dx) (:478-500), unfused; NULL: none.  The filter is not owned. */
+int tlab_opr_burgers_set_dealiasing(int dir, tlab_filter_t f);
 
 /* ---- Poisson solver --------------------------------------------------------------------------- */
 /* OPR_Elliptic_Initialize (operators/opr_elliptic.f90:86-250, TYPE_FACTORIZE) + OPR_Fourier_Initialize

@@ -36,6 +36,8 @@ def lib():
         L.ref_partial.argtypes = [c_int] * 6 + [_P, _P, _P]
         L.ref_transpose.argtypes = [_P, c_int, c_int, _P]
         L.ref_burgers.argtypes = [c_int] * 5 + [c_dbl, _P, _P, _P, _P]
+        L.ref_filter_init.argtypes = [c_int] * 5 + [c_dbl, _P, c_dbl, _P, c_int, _P]
+        L.ref_filter_1d.argtypes = [c_int] * 7 + [_P, _P, _P]
         _lib = L
     return _lib
 
@@ -236,3 +238,32 @@ def io_read_fields(name, nx, ny, nz, nt, nfield, nparams):
     L.ref_io_read_fields.argtypes = [ctypes.c_char_p] + [c_int] * 5 + [_P, c_int, _P]
     L.ref_io_read_fields(name.encode(), nx, ny, nz, nt, nfield, a, nparams, p)
     return [a[i] for i in range(nfield)], p[:nparams]
+
+
+# 1-D filters (src/filters/*.f90 through oracle/ref_driver_filter.f90): DNS_FILTER_COMPACT = 1, _6E = 2, _4E = 3, _COMPACT_CUTOFF = 9
+FILTER_NCOLS = {1: 10, 2: 0, 3: 5, 9: 7}        # inb_filter (opr_filter.f90:121-139)
+
+
+def filter_init(itype, nodes, jac, periodic, bcsmin=1, bcsmax=1, alpha=0.49, scale=None):
+    """OPR_FILTER_INITIALIZE (opr_filter.f90:236-275) -> coeffs as [row, column] (n, inb_filter)."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    jac = np.ascontiguousarray(jac, dtype=np.float64)
+    n, nc = nodes.shape[0], max(FILTER_NCOLS[itype], 1)
+    if scale is None:
+        scale = (nodes[-1] - nodes[0]) * (n / (n - 1.0) if periodic else 1.0)
+    buf = np.zeros(n * nc)
+    lib().ref_filter_init(itype, n, int(periodic), bcsmin, bcsmax, float(alpha), jac, float(scale), nodes, nc, buf)
+    return buf.reshape(nc, n).T.copy()[:, :FILTER_NCOLS[itype]]
+
+
+def filter_1d(itype, periodic, bcsmin, bcsmax, coeffs, u):
+    """OPR_FILTER_1D (opr_filter.f90:393-460).  u: (n, nlines) C-ordered == Fortran (nlines, n)."""
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    n = u.shape[0]
+    nc = max(FILTER_NCOLS[itype], 1)
+    c = np.zeros((nc, n))
+    if FILTER_NCOLS[itype]:
+        c[:, :] = np.asarray(coeffs, dtype=np.float64).T
+    r = np.empty_like(u)
+    lib().ref_filter_1d(itype, n, u.shape[1], int(periodic), bcsmin, bcsmax, nc, np.ascontiguousarray(c.reshape(-1)), u, r)
+    return r

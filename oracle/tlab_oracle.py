@@ -1061,13 +1061,15 @@ def opr_partial(idir, itype, nx, ny, nz, ibc, g, u):
     raise NotImplementedError
 
 
-def opr_burgers(idir, nx, ny, nz, ibc, g, nu, s, vel, anelastic=None):
+def opr_burgers(idir, nx, ny, nz, ibc, g, nu, s, vel, anelastic=None, dealiasing=None):
     """physics/opr_burgers.f90:190-273 (X), :277-355 (Y), :359-431 (Z) + OPR_Burgers_1D :439-521
     (serial, no dealiasing): result = nu d2s - vel ds along idir.
     anelastic = (rbackground, ribackground) (ny values each; nse_eqns == DNS_EQNS_ANELASTIC, opr_burgers.f90:128-183): along x and z the
     diffusion term is multiplied by rhoinv%values(line) = ribackground(y index of the line) (:134-151, :164-181, :504-507); along y the
     correction sits in the LU factors of the diffusion system (:153-160): U's inverse diagonal times ribackground, its superdiagonal times
     rbackground(2:).
+    dealiasing = a tlab_oracle_filter.Filter of this direction ([Dealiasing], :478-500): the velocity and ds/dx are filtered along the line
+    (OPR_FILTER_1D) before their product.
     Returns (result, s_transposed) with s_transposed the flat (lines-fastest) operand the reference leaves in tmp1."""
     n = (nx, ny, nz)[idir - 1]
     if n == 1:
@@ -1081,6 +1083,9 @@ def opr_burgers(idir, nx, ny, nz, ibc, g, nu, s, vel, anelastic=None):
         lu[:, 1] = lu[:, 1] * ri
         lu[:n - 1, 2] = lu[:n - 1, 2] * rb[1:]
     r = der2_solve(g.der2, lu, sl, dsdx)
+    if dealiasing is not None:
+        from .tlab_oracle_filter import opr_filter_1d
+        vl, dsdx = opr_filter_1d(dealiasing, vl), opr_filter_1d(dealiasing, dsdx)      # uf, dsf (:479-482)
     if anelastic is not None and idir != 2:
         ri = np.asarray(anelastic[1], dtype=np.float64)
         nl = sl.shape[1]

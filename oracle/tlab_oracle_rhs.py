@@ -14,11 +14,12 @@ from . import tlab_oracle_poisson as OP
 
 class DnsOracle:
     def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None, gy_elliptic=None, hyper_bc1_ext=None,
-                 anelastic=None):
+                 anelastic=None, dealiasing=None):
         """anelastic = (rbackground, ribackground): nse_eqns == DNS_EQNS_ANELASTIC with those background profiles (ny values each): the density
         weights of rhs_global_incompressible_1.f90:211-214, :275-277, :326-329 and of OPR_Burgers (opr_burgers.f90:128-183).  The buoyancy and
         the thermodynamics that PRODUCE the profiles are outside the path."""
         self.anelastic = None if anelastic is None else tuple(np.asarray(a, dtype=np.float64) for a in anelastic)
+        self.dealiasing = [None, None, None] if dealiasing is None else list(dealiasing)      # Dealiasing(1:3) of opr_burgers.f90:33 (None: DNS_FILTER_NONE)
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
         h = hyper_bc1_ext                      # None: O.HYPER_BC1_EXT = the flang-built reference's wall closure (DESIGN.md section 2, defect 1)
@@ -39,7 +40,7 @@ class DnsOracle:
         self.scal_jmin, self.scal_jmax = [3] * nscal, [3] * nscal
 
     def burgers(self, d, nu, s, vel):
-        return O.opr_burgers(d, self.nx, self.ny, self.nz, 0, self.g[d - 1], nu, s, vel, anelastic=self.anelastic)[0]
+        return O.opr_burgers(d, self.nx, self.ny, self.nz, 0, self.g[d - 1], nu, s, vel, anelastic=self.anelastic, dealiasing=self.dealiasing[d - 1])[0]
 
     def weight(self, w, a):
         """Thermo_Anelastic_WEIGHT_* (thermodynamics/thermo_anelastic.f90:377-448): a(i, j, k) * w(j)"""

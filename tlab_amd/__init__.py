@@ -11,6 +11,6 @@ from .operators import (  # noqa: F401
     BCS_DD, BCS_ND, BCS_DN, BCS_NN,
     FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN_PENTA, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER, FDM_COM6_DIRECT, FDM_COM4_DIRECT,
     OPR_Partial_X, OPR_Partial_Y, OPR_Partial_Z,
-    OPR_Burgers_X, OPR_Burgers_Y, OPR_Burgers_Z,
+    OPR_Burgers_X, OPR_Burgers_Y, OPR_Burgers_Z, Filter, OPR_FILTER_1D, set_dealiasing,
     TLab_Transpose, PoissonPlan, OPR_Poisson, OPR_Helmholtz, poisson_set_exact, BOUNDARY_BCS_NEUMANN_Y,
 )

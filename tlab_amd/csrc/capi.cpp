@@ -79,6 +79,8 @@ double *workspace(size_t n) {
 
 }  // namespace
 
+void tlab_internal_filter_1d(int dir, tlab_filter_t f, int nx, int ny, int nz, const double *u, double *result, hipStream_t st);      // filter.hip
+
 // hooks for the other translation units (poisson.hip, rhs.hip)
 hipStream_t tlab_current_stream() { return g_stream; }
 void tlab_set_error(const std::string &s) { g_err = s; }
@@ -1014,6 +1016,27 @@ int tlab_opr_burgers_set_anelastic(int ny, const double *rbackground, const doub
 }
 bool tlab_internal_anelastic() { return g_anelastic_ny > 0; }
 
+// [Dealiasing] (physics/opr_burgers.f90:33, 71, 118-125): Dealiasing(1:3), one filter per direction (NULL = DNS_FILTER_NONE); NOT owned
+static tlab_filter_t g_dealias[3] = {nullptr, nullptr, nullptr};
+static DeviceArray *g_wsd[2] = {nullptr, nullptr};      // wrkdea(:, 1:2) (:34, :124): filtered velocity and filtered ds/dx
+int tlab_opr_burgers_set_dealiasing(int dir, tlab_filter_t f) {
+    return guarded([&] {
+        if (dir < 1 || dir > 3) throw Invalid("dir must be 1, 2 or 3");
+        g_dealias[dir - 1] = f;
+    });
+}
+bool tlab_internal_dealiasing() { return g_dealias[0] || g_dealias[1] || g_dealias[2]; }
+static double *dealias_ws(int k, size_t n) {
+    if (!g_wsd[k]) g_wsd[k] = new DeviceArray();
+    if (g_wsd[k]->n < n) {
+        if (g_wsd[k]->p) hip_check(hipFree(g_wsd[k]->p), "hipFree");
+        g_wsd[k]->p = nullptr;
+        hip_check(hipMalloc((void **)&g_wsd[k]->p, n * sizeof(double)), "hipMalloc(wrkdea)");
+        g_wsd[k]->n = n;
+    }
+    return g_wsd[k]->p;
+}
+
 int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int nz, int ibc, double nu, const double *s,
                      const double *u, double *result, double *tmp1, int write_transposed) {
     return guarded([&] {
@@ -1034,10 +1057,21 @@ int tlab_opr_burgers(int dir, tlab_fdm_plan_t g, int ivel, int nx, int ny, int n
         int path = choose_path(dir, geom.n, g);
         if (path == PATH_XLINE && (corr || g->t.der2.direct)) path = PATH_GENERIC;
         g_last_path = path;
-        if (g_anelastic_ny > 0) {      // OPR_Burgers_1D with rhoinv (opr_burgers.f90:504-507): the two derivatives unfused, then the weighted sum
-            if (g_anelastic_ny != ny) throw Invalid("anelastic profiles were given for another ny");
+        if (g_anelastic_ny > 0 || g_dealias[dir - 1]) {      // OPR_Burgers_1D with rhoinv (opr_burgers.f90:504-507) and / or dealiasing (:478-500):
+            // the two derivatives unfused, then filter(u) and filter(ds/dx) if asked for, then the (weighted) sum
+            if (g_anelastic_ny > 0 && g_anelastic_ny != ny) throw Invalid("anelastic profiles were given for another ny");
             ok_or_throw(tlab_opr_partial(dir, g, TLAB_OPR_P2_P1, nx, ny, nz, ibc, s, result, d1));
-            hip_check(launch_burgers_epilogue_anelastic(result, vel, d1, nu, g_anelastic_ri->p, nx, ny, ntot, g_stream), "burgers epilogue (anelastic)");
+            const double *uf = vel, *dsf = d1;
+            if (g_dealias[dir - 1]) {
+                double *w1 = dealias_ws(0, (size_t)ntot), *w2 = dealias_ws(1, (size_t)ntot);
+                tlab_internal_filter_1d(dir, g_dealias[dir - 1], nx, ny, nz, vel, w1, g_stream);
+                tlab_internal_filter_1d(dir, g_dealias[dir - 1], nx, ny, nz, d1, w2, g_stream);
+                uf = w1; dsf = w2;
+            }
+            if (g_anelastic_ny > 0)
+                hip_check(launch_burgers_epilogue_anelastic(result, uf, dsf, nu, g_anelastic_ri->p, nx, ny, ntot, g_stream), "burgers epilogue (anelastic)");
+            else
+                hip_check(launch_burgers_epilogue(result, uf, dsf, nu, ntot, g_stream), "burgers epilogue");
         } else if (path == PATH_XLINE) {
             run_xline(g, geom, MODE_BURGERS, ibc, s, vel, result, nullptr, nu);
         } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {

@@ -29,6 +29,7 @@ bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int n
 bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
                                   double kco, int scale);
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
+extern "C" bool tlab_internal_dealiasing();      // capi.cpp (defined inside its extern "C" block)
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale,
@@ -135,7 +136,7 @@ int tlab_dns_destroy(tlab_dns_t d) {
 static void burgers_into(tlab_dns_t d, int dir, double nu, const double *s, const double *vel, bool self, double *dst, double *tmp,
                          double *scratch, bool &pending_add, double **pend, int &npend) {
     const int nx = d->nx, ny = d->ny, nz = d->nz;
-    if (d->fuse && !d->rb && tlab_internal_burgers_acc(dir, d->g[dir - 1], nx, ny, nz, 0, nu, s, vel, dst)) return;
+    if (d->fuse && !d->rb && !tlab_internal_dealiasing() && tlab_internal_burgers_acc(dir, d->g[dir - 1], nx, ny, nz, 0, nu, s, vel, dst)) return;
     ok(tlab_opr_burgers(dir, d->g[dir - 1], self ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, nx, ny, nz, 0, nu, s, vel, tmp, scratch, 0), "OPR_Burgers");
     pend[npend++] = tmp;
     pending_add = true;
@@ -163,8 +164,10 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     double *tmps[3] = {tmp1, tmp7, tmp8};
     // Fused path: one launch per direction serves all equations (they share the advecting velocity of that direction), four fields per
     // launch.  The terms of an equation are then added in the order x, y, z instead of the reference's {1,2,3},{2,1,3},{3,1,2}: rounding only.
-    const bool anel = d->rb != nullptr;            // every fused form below assumes the incompressible operators: anelastic runs take the literal sequence
-    const bool batched = !anel && d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
+    // every fused form below assumes the plain operators: anelastic runs and runs with [Dealiasing] take the literal sequence
+    const bool anel = d->rb != nullptr;
+    const bool literal = anel || tlab_internal_dealiasing();
+    const bool batched = !literal && d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
                          tlab_internal_burgers_fusable(3, gz, nx, ny, nz);
     const bool fresh = d->fresh;       // TIME_RUNGEKUTTA zeroes hq, hs at the start of a step (time.f90:212-216): the first launch overwrites instead
     d->fresh = false;
@@ -221,7 +224,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         }
     }
     // ---- pressure (:177-260, remove_divergence branch): forcing = div(hq + q/dte) ----
-    bool fused_div = !anel && d->fuse && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) &&
+    bool fused_div = !literal && d->fuse && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) &&
                      tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
     if (div_in_burgers) {     // tmp1 holds the x term already
         const bool oky = tlab_internal_partial_p1_fused(2, gy, nx, ny, nz, B0, hq[1], v, idte, tmp1, true);
@@ -259,7 +262,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // ---- pressure gradient (:319-320).  With Dirichlet walls and the RK update folded in (tail_update), the x- and z-gradient kernels
     // finish u and w themselves: hq -= dp/dx; wall planes; q += dte hq; hq *= kco (no gradient array is written or re-read) ----
     bool grad_final = false;
-    if (tail_update && d->fuse && nz > 1 && !anel) {
+    if (tail_update && d->fuse && nz > 1 && !literal) {
         bool dirichlet = true;
         for (int iq = 0; iq < 3; ++iq) dirichlet = dirichlet && d->flow_jmin[iq] == TLAB_DNS_BCS_DIRICHLET && d->flow_jmax[iq] == TLAB_DNS_BCS_DIRICHLET;
         if (dirichlet && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz)) {

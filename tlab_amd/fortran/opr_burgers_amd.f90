@@ -33,6 +33,7 @@ module TLAB_AMD_BURGERS_MODULE
     public :: OPR_Burgers_Z
     public :: OPR_Burgers_SetPlans
     public :: OPR_Burgers_AMD_Anelastic      ! (rbackground, ribackground): what OPR_Burgers_Initialize does for nse_eqns == DNS_EQNS_ANELASTIC (:128-183)
+    public :: OPR_Burgers_AMD_Dealiasing     ! (idir, type, periodic, bcsmin, bcsmax, coeffs): Dealiasing(idir) after OPR_FILTER_INITIALIZE (:118-121)
 
     integer, parameter, public :: OPR_B_SELF = 0
     integer, parameter, public :: OPR_B_U_IN = 1
@@ -64,11 +65,27 @@ contains
         integer ig
         integer, parameter :: DNS_ERROR_OPTION = 85, DNS_ERROR_UNDEVELOP = 104      ! include/dns_error.h
         bakfile = trim(adjustl(inifile))//'.bak'
+#ifdef TLAB_AMD_HAVE_OPR_FILTER
+        ! a complete host (module OPR_Filter present; operators/opr_filter.f90 needs OPR_Fourier / FFTW and is therefore not part of the test build
+        ! of this repository): the reference's own block (opr_burgers.f90:71, 118-125), plus the hand-over of every active filter to the device
+        block
+            use OPR_Filter, only: filter_dt, FILTER_READBLOCK, OPR_FILTER_INITIALIZE, DNS_FILTER_NONE
+            type(filter_dt), save :: Dealiasing(3)
+            call FILTER_READBLOCK(bakfile, inifile, 'Dealiasing', Dealiasing)
+            do ig = 1, 3
+                if (Dealiasing(ig)%type == DNS_FILTER_NONE) cycle
+                call OPR_FILTER_INITIALIZE(g(ig), Dealiasing(ig))
+                call OPR_Burgers_AMD_Dealiasing(ig, Dealiasing(ig)%type, Dealiasing(ig)%periodic, Dealiasing(ig)%BcsMin, Dealiasing(ig)%BcsMax, &
+                                                Dealiasing(ig)%coeffs)      ! tophat: TLAB_EUNSUPPORTED -> TLab_Stop through TLab_AMD_Check
+            end do
+        end block
+#else
         call ScanFile_Char(bakfile, inifile, 'Dealiasing', 'Type', 'none', sRes)    ! FILTER_READBLOCK(.., 'Dealiasing', ..), opr_burgers.f90:71
         if (trim(adjustl(sRes)) /= 'none') then
-            call TLab_Write_ASCII(efile, __FILE__//'. Dealiasing inside OPR_Burgers is not built on the device path.')
+            call TLab_Write_ASCII(efile, __FILE__//'. [Dealiasing] needs module OPR_Filter of the host: build with -DTLAB_AMD_HAVE_OPR_FILTER.')
             call TLab_Stop(DNS_ERROR_UNDEVELOP)
         end if
+#endif
         do ig = 1, 3                                                               ! :75-83
             if (g(ig)%size == 1) cycle
             if (g(ig)%der2%nb_diag(1) /= 3) then
@@ -99,6 +116,33 @@ contains
         end if
         call TLab_AMD_Check(rc, 'tlab_opr_burgers_set_anelastic')
     end subroutine OPR_Burgers_AMD_Anelastic
+
+    ! Dealiasing(idir) (physics/opr_burgers.f90:33, 118-121): the host's filter_dt after OPR_FILTER_INITIALIZE; the table f%coeffs goes to the device.
+    ! type = 0 (DNS_FILTER_NONE) switches the direction off.
+    subroutine OPR_Burgers_AMD_Dealiasing(idir, ftype, periodic, bcsmin, bcsmax, coeffs)
+        integer, intent(in) :: idir, ftype, bcsmin, bcsmax
+        logical, intent(in) :: periodic
+        real(wp), intent(in), target, contiguous :: coeffs(:, :)
+        type(c_ptr), save :: handle(3) = c_null_ptr
+        integer(c_int) rc, per
+        if (c_associated(handle(idir))) then
+            rc = tlab_opr_burgers_set_dealiasing(int(idir, c_int), c_null_ptr)
+            rc = tlab_filter_destroy(handle(idir))
+            handle(idir) = c_null_ptr
+        end if
+        if (ftype == 0) return
+        per = 0_c_int; if (periodic) per = 1_c_int
+        if (size(coeffs) > 0) then
+            rc = tlab_filter_create(handle(idir), int(ftype, c_int), int(size(coeffs, 1), c_int), per, int(bcsmin, c_int), int(bcsmax, c_int), &
+                                    int(size(coeffs, 2), c_int), c_loc(coeffs))
+        else
+            rc = tlab_filter_create(handle(idir), int(ftype, c_int), int(gp(idir)%size, c_int), per, int(bcsmin, c_int), int(bcsmax, c_int), &
+                                    0_c_int, c_null_ptr)
+        end if
+        call TLab_AMD_Check(rc, 'tlab_filter_create')
+        rc = tlab_opr_burgers_set_dealiasing(int(idir, c_int), handle(idir))
+        call TLab_AMD_Check(rc, 'tlab_opr_burgers_set_dealiasing')
+    end subroutine OPR_Burgers_AMD_Dealiasing
 
     subroutine burgers_any(idir, ivel, is, nx, ny, nz, bcs, s, u, result, tmp1)
         integer, intent(in) :: idir, ivel, is

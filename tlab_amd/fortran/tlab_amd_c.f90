@@ -78,6 +78,26 @@ module TLab_AMD_C
             integer(c_int), value :: ny
             type(c_ptr), value :: rbackground, ribackground      ! host arrays of ny doubles (c_null_ptr: incompressible)
         end function
+        integer(c_int) function tlab_filter_create(f, itype, n, periodic, bcsmin, bcsmax, inb_filter, coeffs) bind(C, name='tlab_filter_create')
+            import :: c_int, c_ptr
+            type(c_ptr), intent(out) :: f
+            integer(c_int), value :: itype, n, periodic, bcsmin, bcsmax, inb_filter
+            type(c_ptr), value :: coeffs                          ! host array f%coeffs(n, inb_filter)
+        end function
+        integer(c_int) function tlab_filter_destroy(f) bind(C, name='tlab_filter_destroy')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: f
+        end function
+        integer(c_int) function tlab_opr_filter_1d(dir, f, nx, ny, nz, u, res) bind(C, name='tlab_opr_filter_1d')
+            import :: c_int, c_ptr
+            integer(c_int), value :: dir, nx, ny, nz
+            type(c_ptr), value :: f, u, res
+        end function
+        integer(c_int) function tlab_opr_burgers_set_dealiasing(dir, f) bind(C, name='tlab_opr_burgers_set_dealiasing')
+            import :: c_int, c_ptr
+            integer(c_int), value :: dir
+            type(c_ptr), value :: f
+        end function
         integer(c_int) function tlab_dns_set_anelastic(dns, rbackground, ribackground) bind(C, name='tlab_dns_set_anelastic')
             import :: c_int, c_ptr
             type(c_ptr), value :: dns, rbackground, ribackground

@@ -204,6 +204,43 @@ def OPR_Burgers_Z(ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, u_t=None, wr
     _burgers(3, ivel, nu, nx, ny, nz, bcs, g, s, u, result, tmp1, write_transposed)
 
 
+class Filter:
+    """type(filter_dt) of operators/opr_filter.f90:28-41 with the coefficient table OPR_FILTER_INITIALIZE made on the host: ftype = 1 compact,
+    2 explicit6, 3 explicit4, 9 compactcutoff; coeffs: numpy [row, column] (n, inb_filter) or None (explicit6); bcsmin / bcsmax: DNS_FILTER_BCS_*
+    (filters/flt_base.f90: 1 biased, 2 free, 6 zero ...)."""
+
+    def __init__(self, ftype, n, periodic, coeffs=None, bcsmin=1, bcsmax=1):
+        self.type, self.size, self.periodic = int(ftype), int(n), bool(periodic)
+        self._h = c_vp(0)
+        dp = ctypes.POINTER(ctypes.c_double)
+        if coeffs is None:
+            nc, ptr = 0, None
+        else:
+            self._c = np.asfortranarray(coeffs, dtype=np.float64)
+            nc, ptr = self._c.shape[1], self._c.ctypes.data_as(dp)
+        check(load().tlab_filter_create(ctypes.byref(self._h), self.type, self.size, int(self.periodic), 0 if periodic else int(bcsmin),
+                                        0 if periodic else int(bcsmax), nc, ptr), "tlab_filter_create")
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().tlab_filter_destroy(self._h)
+        except Exception:
+            pass
+
+
+def OPR_FILTER_1D(idir, f, nx, ny, nz, u, result):
+    """OPR_FILTER_1D (opr_filter.f90:393-460) along direction idir of a field, out of place."""
+    _use_torch_stream()
+    check(load().tlab_opr_filter_1d(int(idir), f._h, nx, ny, nz, _ptr(u), _ptr(result)), "tlab_opr_filter_1d")
+
+
+def set_dealiasing(idir, f):
+    """Dealiasing(idir) of OPR_Burgers ([Dealiasing], opr_burgers.f90:33, 71): a Filter, or None for DNS_FILTER_NONE.  Module state of the
+    operator, as in the reference; the caller keeps the Filter alive while it is set."""
+    check(load().tlab_opr_burgers_set_dealiasing(int(idir), f._h if f is not None else None), "tlab_opr_burgers_set_dealiasing")
+
+
 class PoissonPlan:
     """Module state of OPR_Elliptic (operators/opr_elliptic.f90:64-81) + OPR_Fourier plans, built by
     OPR_Elliptic_Initialize / OPR_Fourier_Initialize in the reference; here one object owned by the library."""
