@@ -210,6 +210,14 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     const bool stored = a.fac != nullptr;
     for (int jb = 1; jb <= nmax; jb += U) {
         double fqb[U][NL], fab[U][2];         // f[jb+2 .. jb+U+1]; stored forward factors of rows jb .. jb+U-1
+        double Rb[U][2];                      // right-hand-side coefficients of the rows of the block: requested with the rest, BEFORE the first store
+        //                                       of the block (the output arrays may alias the tables as far as the compiler knows: left inside the row loop,
+        //                                       every row waited for its own scalar load -- 7 us per block of 8 rows with few modes in flight)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jc = (jb + u <= nmax) ? jb + u : nmax;
+            Rb[u][0] = a.T.R[jc * 3 + 0]; Rb[u][1] = a.T.R[jc * 3 + 1];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jr = jb + u + 2;
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
                 else if (j == 2) rhs[l] = res0[l] * rb[2][0] + fm[l] * rb[2][1] + fc[l] * rb[2][2] + fp[l] * rb[2][3];
                 else if (j == n - 3) rhs[l] = fm[l] * rt[0][0] + fc[l] * rt[0][1] + fp[l] * rt[0][2] + resN[l] * rt[0][3];
                 else if (j == n - 2) rhs[l] = fm[l] * rt[1][0] + fc[l] * rt[1][1] + resN[l] * rt[1][2];
-                else rhs[l] = fm[l] * a.T.R[j * 3 + 0] + fc[l] * a.T.R[j * 3 + 1] + fp[l];
+                else rhs[l] = fm[l] * Rb[u][0] + fc[l] * Rb[u][1] + fp[l];
             }
             if (j == n - 2) {
 #pragma unroll
@@ -1284,7 +1292,10 @@ __global__ void __launch_bounds__(256) k_nn_combine(CombineArgs a) {
         v_1[l] = v_1[l] - a12 * u_n[l] - a13 * fn[l];
     }
     double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
-    for (int j = 0; j < n; ++j) {
+    // rows [jlo, jhi) of this thread: gridDim.y row blocks (few modes: the rows are the parallelism; many modes: one block does them all)
+    const int rows = (n + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int jlo = (int)blockIdx.y * rows, jhi = (jlo + rows < n) ? jlo + rows : n;
+    for (int j = jlo; j < jhi; ++j) {
         const double hv1 = a.hom[((long long)0 * n + j) * nm + t], hem = a.hom[((long long)1 * n + j) * nm + t];
         const double hu1 = a.hom[((long long)2 * n + j) * nm + t], hsp = a.hom[((long long)3 * n + j) * nm + t];
         const double hep = a.hom[((long long)4 * n + j) * nm + t];
@@ -1432,7 +1443,9 @@ __global__ void __launch_bounds__(256) k_dd_combine(DDCombineArgs a) {
         bb_[l] = bcb;
     }
     double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
-    for (int j = n - 1; j >= 1; --j) {
+    const int rows = (n + (int)gridDim.y - 1) / (int)gridDim.y;      // row blocks as in k_nn_combine
+    const int jlo = (int)blockIdx.y * rows, jhi = (jlo + rows < n) ? jlo + rows : n;
+    for (int j = jhi - 1; j >= (jlo > 1 ? jlo : 1); --j) {
         const double hv1 = H(0, j), hem = H(1, j), hu1 = H(2, j), hsp = H(3, j);
         double u[2], v[2];
 #pragma unroll
@@ -1443,8 +1456,10 @@ __global__ void __launch_bounds__(256) k_dd_combine(DDCombineArgs a) {
         P[fidx0 + (long long)j * a.nxh] = make_double2(u[0], u[1]);
         D[fidx0 + (long long)j * a.nxh] = make_double2(v[0], v[1]);
     }
-    P[fidx0] = make_double2(bb_[0], bb_[1]);
-    D[fidx0] = make_double2(q1[0] + lam * bb_[0], q1[1] + lam * bb_[1]);
+    if (jlo == 0) {
+        P[fidx0] = make_double2(bb_[0], bb_[1]);
+        D[fidx0] = make_double2(q1[0] + lam * bb_[0], q1[1] + lam * bb_[1]);
+    }
 }
 
 // singular modes: f^ * norm into SoA [(l*n + j)*ns + s] (all rows), bottom / top values into bcb / bct [l*ns + s]
@@ -2312,7 +2327,7 @@ static void poisson_dd_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat
     c.hom_nm_block = P->use_chunked ? P->ode_nm_per_wg : 0;
     c.sing = P->d_sing; c.ns = ns;
     c.p_hat = p_hat; c.dp_hat = dp_hat; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
-    hipLaunchKernelGGL(k_dd_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_dd_combine, dim3((unsigned)((nm + 255) / 256), nm <= 4096 ? (unsigned)((n + 15) / 16) : 1u), dim3(256), 0, st, c);
     if (ns > 0) {
         dim3 g(ns, (n + 63) / 64), blk(64);
         hipLaunchKernelGGL(k_sing_combine_dd, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->dd_u1.p, P->dd_v1.p, P->dd_sp.p, P->s_du0.p, P->dd_du1.p,
@@ -2371,7 +2386,7 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
         c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.hom = P->hom.p; c.cst = P->cst.p; c.lam = P->lam.p;
         c.skip = P->d_skip; c.p_hat = p_hat; c.dp_hat = dp_hat; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
         ProfScope ps("k_nn_combine", st, (double)nm * n * (9 + 4) * 8.0);
-        hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c);
+        hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256), nm <= 4096 ? (unsigned)((n + 15) / 16) : 1u), dim3(256), 0, st, c);
     } else {
         launch_ode(*P, f_hat, p_hat, dp_hat, st);      // both solves, the constants and the final pass in one kernel
     }
