@@ -8,7 +8,7 @@ from oracle import tlab_oracle as O
 from oracle import tlab_oracle_poisson as OP
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-13     # p: the device repeats the reference's operations bit for bit; what is left is rocFFT against numpy.fft (~1e-15)
+TOL = 1e-13     # p with the MARCHING kernel (k_int2): it repeats the reference's operations bit for bit; what is left is rocFFT against numpy.fft (~1e-15)
 
 
 @pytest.fixture(scope="module")
@@ -70,6 +70,31 @@ def test_poisson_direct_matches_oracle(T, nx, ny, nz, ibc):
     # dp/dy = OPR_Partial_Y(p): differentiating the 1e-15 FFT noise of p on the stretched grid (h_min ~ 1/(4 ny)) costs ~ny digits -- on the oracle
     # too: the bound is max(1e-12, 2 x the oracle's own scatter under one ulp of input noise) (tests/scatter.py)
     assert rel_err(dpdy.cpu().numpy(), dp_ref) <= bound(sc_dp), (rel_err(dpdy.cpu().numpy(), dp_ref), sc_dp)
+
+
+@pytest.mark.parametrize("ibc", [0, 1, 2, 3])
+def test_marching_and_chunked_direct_solvers_agree(T, ibc):
+    """k_int2c (8-row chunks, parallel scan) is the default where ny is a multiple of 8; TLAB_INT2_CHUNKED=0 (read per call) selects the marching
+    k_int2, which repeats the reference's operation order.  Same plan, both routes: they differ by the association of the substitution sums only."""
+    import os
+    import torch
+    nx, ny, nz = 32, 128, 8
+    (ogx, ogy, ogz), (gx, gy, gz), f, hb, ht = _setup(T, nx, ny, nz, 40 + ibc)
+    plan = T.PoissonPlan(gx, gy, gz, nx, ny, nz, gy_elliptic=gy)
+    tmp1 = torch.zeros(plan.isize_txc_field, dtype=torch.float64, device="cuda"); tmp2 = torch.zeros_like(tmp1)
+    out = {}
+    try:
+        for route in ("1", "0"):
+            os.environ["TLAB_INT2_CHUNKED"] = route
+            p = torch.from_numpy(f.copy()).cuda(); dpdy = torch.zeros_like(p)
+            T.OPR_Poisson(plan, nx, ny, nz, ibc, p, tmp1, tmp2, torch.from_numpy(hb.ravel().copy()).cuda(), torch.from_numpy(ht.ravel().copy()).cuda(), dpdy)
+            out[route] = p.cpu().numpy()
+    finally:
+        os.environ.pop("TLAB_INT2_CHUNKED", None)
+    oplan = OP.PoissonDirectPlan(ogx, ogy, ogz, nx, ny, nz)
+    p_ref, _ = OP.opr_poisson_fxz_direct(oplan, f, hb, ht, ibc)
+    assert rel_err(out["0"], p_ref) <= TOL and rel_err(out["1"], p_ref) <= 1e-12
+    assert not np.array_equal(out["0"], out["1"])         # (two different kernels did run)
 
 
 @pytest.mark.parametrize("nx,ny,nz,ibc,alpha", [(16, 24, 8, 0, -12.5), (16, 64, 8, 3, -400.0), (32, 128, 8, 1, -3.0), (16, 64, 1, 2, -50.0), (64, 512, 16, 0, -1.0e4)])

@@ -1154,6 +1154,219 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     }
 }
 
+// ================================================================================================
+// k_int2c : FDM_Int2_Solve (the DIRECT elliptic solver, k_int2 above) on the chunked scheme of k_ode_nn: ONE pentadiagonal system per mode,
+// thread (mode m, chunk c) owns 8 rows, the PENTADFS pivots of its rows regenerated from a checkpoint of the serial recurrence, forward and
+// backward substitution as particular end values + 2 x 2 transfer matrix, parallel scan over the chunks (ode_chain), repeat with the inflow.
+// Rows and right-hand sides are built exactly as k_int2 builds them (same operations, no contraction); what differs from the marching kernel is
+// the association of the substitution sums.  No scratch: f^ 16 B in, p^ 16 B out, checkpoints 6 B per mode and row.
+// ================================================================================================
+struct Int2cArgs {
+    Int2Dev T;
+    const double *lam;
+    double alpha;
+    long long nm, skip;
+    const double *chk;          // [blk][C][6][NM] PENTADFS state before the first row of each chunk
+    const double *fsrc;
+    double *dst;
+    double fscale;
+    int nxh, ny, C, neumann_b, neumann_t;
+};
+
+__device__ __forceinline__ void int2_row(const Int2Dev &T, int j, double lam, const double (&l1)[3], const double (&lN)[3], int nb_on, int nt_on,
+                                         double (&r)[5]) {
+#pragma clang fp contract(off)
+    const int n = T.n;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = T.Bt[(unsigned)(j * 5 + k)] - lam * T.A5[(unsigned)(j * 5 + k)];      // fdm_integral.f90:412-432
+    if (nb_on && (j == 1 || j == 2)) {       // :462-464
+        const int k0 = 3 - j;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r[k0 + q] = r[k0 + q] - T.nb[j - 1] * l1[q];
+    }
+    if (nt_on && (j == n - 2 || j == n - 3)) {   // :501-503
+        const int ir = n - 1 - j;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r[ir - 1 + q] = r[ir - 1 + q] - T.nt[ir - 1] * lN[q];
+    }
+    const double sj = T.s[j];                    // :518-540
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = r[k] * sj;
+}
+
+// checkpoints of the factor recurrence of every mode: state before rows 8, 16, ...
+__global__ void __launch_bounds__(256) k_int2_checkpoint(Int2Dev T, const double *__restrict__ lamv, double alpha, int nb_on, int nt_on,
+                                                         double *__restrict__ chk, long long nm, int NM, int C) {
+#pragma clang fp contract(off)
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nm) return;
+    const int n = T.n;
+    const double lam = lamv[t] - alpha;
+    double l1[3] = {T.c1[0], T.c1[1], T.c1[2]}, lN[3] = {T.cn[0], T.cn[1], T.cn[2]};
+    l1[0] = l1[0] + lam * T.e1;
+    lN[2] = lN[2] + lam * T.en;
+    double st[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 1; j <= n - 2; ++j) {
+        if ((j % OM) == 0) {
+            const int c = j / OM;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) chk[(((t / NM) * C + c) * 6 + q) * NM + (t % NM)] = st[q];
+        }
+        double r[5], am, bm, cinv, nd, ne;
+        int2_row(T, j, lam, l1, lN, nb_on, nt_on, r);
+        ode_factor_step(j, r, st, am, bm, cinv, nd, ne);
+    }
+}
+
+template <int NM>
+__global__ void __launch_bounds__(512) k_int2c(Int2cArgs a) {
+    extern __shared__ double lds[];
+    const int C = a.C, n = a.T.n;
+    const int m = threadIdx.x % NM, c = threadIdx.x / NM;
+    double *s_w = lds, *s_fac = lds + 8 * 8 * NM;
+    const int nm = (int)a.nm;
+    int t = (int)blockIdx.x * NM + m;
+    const bool live = t < nm;
+    if (!live) t = nm - 1;
+    const bool store = live && ((long long)t != a.skip);
+    const double lam = a.lam[t] - a.alpha;
+    const unsigned fidx0 = (unsigned)((t % a.nxh) + a.nxh * a.ny * (t / a.nxh));
+    const int j0 = c * OM;
+    const bool lo = (c == 0), hi = (c == C - 1);
+    const double2 *F = reinterpret_cast<const double2 *>(a.fsrc);
+    double fl[OM + 2][2];        // f rows j0-1 .. j0+8 (normalised)
+#pragma unroll
+    for (int p = 0; p < OM + 2; ++p) {
+        const int j = j0 - 1 + p;
+        double2 w = make_double2(0.0, 0.0);
+        if (j >= 0 && j <= n - 1) w = F[fidx0 + (unsigned)(j * a.nxh)];
+        fl[p][0] = w.x * a.fscale; fl[p][1] = w.y * a.fscale;
+    }
+    const double res0[2] = {fl[1][0], fl[1][1]}, resN[2] = {fl[OM][0], fl[OM][1]};      // rows 0 / n-1: meaningful in the first / last chunk only
+    double l1[3] = {a.T.c1[0], a.T.c1[1], a.T.c1[2]}, lN[3] = {a.T.cn[0], a.T.cn[1], a.T.cn[2]};
+    l1[0] = nf_madd(l1[0], lam, a.T.e1);
+    lN[2] = nf_madd(lN[2], lam, a.T.en);
+    double bcs_b[2] = {0, 0}, bcs_t[2] = {0, 0};
+    // ---- factors of my rows from the checkpoint, right-hand side ----
+    double st[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) st[q] = (c == 0) ? 0.0 : a.chk[(unsigned)((((t / NM) * C + c) * 6 + q) * NM + m)];
+    double am[OM], bm[OM], x[OM][2];
+    double *my_fac = s_fac + threadIdx.x * (3 * OM + 1);
+#define FAC(p, q) my_fac[(p) * 3 + (q)]
+#pragma unroll
+    for (int p = 0; p < OM; ++p) {
+        const int j = j0 + p;
+        const bool off = (p == 0 && lo) || (p == OM - 1 && hi);
+        double r[5];
+        int2_row(a.T, j, lam, l1, lN, a.neumann_b, a.neumann_t, r);
+        double a_m = 0.0, b_m = 0.0, cm = r[2], dm = r[3];
+        const double em = r[4];
+        if (p >= 3 || !lo) {
+            a_m = r[0] / st[3];
+            b_m = nf_msub(r[1], a_m, st[4]) / st[0];
+            cm = nf_msub(nf_msub(r[2], b_m, st[1]), a_m, st[5]);
+            dm = nf_msub(r[3], b_m, st[2]);
+        } else if (p == 2) {
+            b_m = r[1] / st[0];
+            cm = nf_msub(r[2], b_m, st[1]);
+            dm = nf_msub(r[3], b_m, st[2]);
+        }
+        if (off) { a_m = 0.0; b_m = 0.0; }
+        am[p] = a_m; bm[p] = b_m;
+        FAC(p, 0) = off ? 1.0 : 1.0 / cm; FAC(p, 1) = off ? 0.0 : -dm; FAC(p, 2) = off ? 0.0 : -em;
+        if (!off) {
+            st[3] = st[0]; st[4] = st[1]; st[5] = st[2];
+            st[0] = cm; st[1] = dm; st[2] = em;
+        }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+#pragma clang fp contract(off)
+            const double fm = fl[p][l], fc = fl[p + 1][l], fp = fl[p + 2][l];
+            double v = fm * a.T.R[(unsigned)(j * 3 + 0)] + fc * a.T.R[(unsigned)(j * 3 + 1)] + fp;      // MatMul_3d interior row
+            if (p == 1 && lo) v = res0[l] * a.T.rb[1][1] + fc * a.T.rb[1][2] + fp * a.T.rb[1][3];
+            if (p == 2 && lo) v = res0[l] * a.T.rb[2][0] + fm * a.T.rb[2][1] + fc * a.T.rb[2][2] + fp * a.T.rb[2][3];
+            if (p == OM - 3 && hi) v = fm * a.T.rt[0][0] + fc * a.T.rt[0][1] + fp * a.T.rt[0][2] + resN[l] * a.T.rt[0][3];
+            if (p == OM - 2 && hi) v = fm * a.T.rt[1][0] + fc * a.T.rt[1][1] + resN[l] * a.T.rt[1][2];
+            x[p][l] = off ? 0.0 : v;
+            if (p == 1 && lo) bcs_b[l] = res0[l] * a.T.rb[0][2] + fc * a.T.rb[0][3] + fp * a.T.rb[0][1];
+            if (p == OM - 2 && hi) bcs_t[l] = fm * a.T.rt[2][2] + fc * a.T.rt[2][0] + resN[l] * a.T.rt[2][1];
+        }
+        if (p & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- forward substitution ----
+    double inflow[2][2];
+    {
+        double y1[2] = {0, 0}, y2[2] = {0, 0};
+        double h1a = 1.0, h2a = 0.0, h1b = 0.0, h2b = 1.0;
+#pragma unroll
+        for (int p = 0; p < OM; ++p) {
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double y = x[p][l] - y1[l] * bm[p] - y2[l] * am[p];
+                y2[l] = y1[l]; y1[l] = y;
+            }
+            const double ha = -h1a * bm[p] - h2a * am[p]; h2a = h1a; h1a = ha;
+            const double hb = -h1b * bm[p] - h2b * am[p]; h2b = h1b; h1b = hb;
+        }
+        double phi[4] = {h1a, h1b, h2a, h2b}, ee[2][2] = {{y1[0], y2[0]}, {y1[1], y2[1]}};
+        ode_chain<NM, +1>(phi, ee, c, C, m, s_w, inflow);
+    }
+    {
+        double y1[2] = {inflow[0][0], inflow[1][0]}, y2[2] = {inflow[0][1], inflow[1][1]};
+#pragma unroll
+        for (int p = 0; p < OM; ++p)
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double v = x[p][l] - y1[l] * bm[p] - y2[l] * am[p];
+                x[p][l] = v; y2[l] = y1[l]; y1[l] = v;
+            }
+    }
+    __syncthreads();
+    // ---- backward substitution ----
+    {
+        double x1[2] = {0, 0}, x2[2] = {0, 0};
+        double h1a = 1.0, h2a = 0.0, h1b = 0.0, h2b = 1.0;
+#pragma unroll
+        for (int p = OM - 1; p >= 0; --p) {
+            const double cinv_p = FAC(p, 0), nd_p = FAC(p, 1), ne_p = FAC(p, 2);
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double v = (x[p][l] + x1[l] * nd_p + x2[l] * ne_p) * cinv_p;
+                x2[l] = x1[l]; x1[l] = v;
+            }
+            const double ha = (h1a * nd_p + h2a * ne_p) * cinv_p; h2a = h1a; h1a = ha;
+            const double hb = (h1b * nd_p + h2b * ne_p) * cinv_p; h2b = h1b; h1b = hb;
+        }
+        double phi[4] = {h1a, h1b, h2a, h2b}, ee[2][2] = {{x1[0], x2[0]}, {x1[1], x2[1]}};
+        ode_chain<NM, -1>(phi, ee, c, C, m, s_w, inflow);
+    }
+    {
+        double x1[2] = {inflow[0][0], inflow[1][0]}, x2[2] = {inflow[0][1], inflow[1][1]};
+#pragma unroll
+        for (int p = OM - 1; p >= 0; --p) {
+            const double cinv_p = FAC(p, 0), nd_p = FAC(p, 1), ne_p = FAC(p, 2);
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const double v = (x[p][l] + x1[l] * nd_p + x2[l] * ne_p) * cinv_p;
+                x[p][l] = v; x2[l] = x1[l]; x1[l] = v;
+            }
+        }
+    }
+#undef FAC
+    // ---- end values: given (Dirichlet) or from the biased first-derivative formula (Neumann), fdm_integral.f90:659-668 ----
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma clang fp contract(off)
+        if (lo) x[0][l] = a.neumann_b ? bcs_b[l] + l1[0] * x[1][l] + l1[1] * x[2][l] + l1[2] * x[3][l] : res0[l];
+        if (hi) x[OM - 1][l] = a.neumann_t ? bcs_t[l] + lN[2] * x[OM - 2][l] + lN[1] * x[OM - 3][l] + lN[0] * x[OM - 4][l] : resN[l];
+    }
+    if (!store) return;
+    double2 *D = reinterpret_cast<double2 *>(a.dst);
+#pragma unroll
+    for (int p = 0; p < OM; ++p) D[fidx0 + (unsigned)((j0 + p) * a.nxh)] = make_double2(x[p][0], x[p][1]);
+}
+
 // The <= 4 singular modes (lambda = 0): OPR_ODE2_Factorize_NN_Sing -> _DN_Sing (opr_odes.f90:165-183, 37-96) with the same chunked
 // solves, one workgroup: v0' = f (f(1) = 0), v0(n) = bcs_t ; u0' = v0, u0(1) = 0 ; u = u0 + c u1, v = v0 + c v1 with
 // c = (v0(1) - du0(1)) / (du1(1) - v1(1)); u1, v1, du1 depend on the mode only (plan creation).
@@ -1619,6 +1832,7 @@ struct tlab_poisson_plan {
     hipStream_t side = nullptr;       // the <= 4 singular modes are solved beside the regular ones
     // DIRECT elliptic solver (EllipticOrder = CompactDirect6): one second-order integral operator per boundary type, built on first use
     bool direct = false;
+    bool exact_mode = false;                  // tlab_poisson_set_exact(1) at creation: marching kernels only (k_int2 instead of k_int2c)
     tlab_fdm_plan_t gy_der = nullptr;         // y plan of the derivatives (dp/dy = OPR_Partial_Y(p), opr_elliptic.f90:447-449); not owned
     // factorized Helmholtz (opr_elliptic.f90:466-557): the per-mode tables depend on alpha, so every alpha in use is a sub-plan of its own
     // (tables only; transforms and work field are the parent's).  The implicit RK cycles through a few alphas: the last 4 are kept.
@@ -1627,7 +1841,7 @@ struct tlab_poisson_plan {
     std::vector<std::pair<double, std::unique_ptr<tlab_poisson_plan>>> helm;
     DerTables ell_der2;                       // second derivative of the elliptic y plan (fdm_loc%der2)
     std::vector<double> ell_nodes;
-    struct Int2Set { Int2Tables host; DBuf Bt, A5, s, R; };
+    struct Int2Set { Int2Tables host; DBuf Bt, A5, s, R, chk; double chk_alpha = 0.0; bool chk_ok = false; };      // chk: checkpoints of k_int2c for one alpha
     std::unique_ptr<Int2Set> int2[4];
     long long sing_direct = -1;               // local index of the mode (1,1), or -1 when another rank owns it
     Int2Dev dev2(int ibc) {
@@ -1757,6 +1971,17 @@ void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_h
         }
     }
     hipc(hipGetLastError(), "k_ode_nn");
+}
+
+template <int NM>
+static void launch_int2c(const Int2cArgs &k, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_int2c<NM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_int2c<NM>), dim3((unsigned)((k.nm + NM - 1) / NM)), dim3(NM * k.C), lds, st, k);
 }
 
 void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
@@ -2048,6 +2273,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
         P->norm = 1.0 / ((double)nx * (double)nzt);                     // opr_elliptic.f90:130
         if (gy_ell) {   // TYPE_DIRECT (opr_elliptic.f90:152-163, 228-245)
             P->direct = true;
+            P->exact_mode = g_poisson_exact;
             P->gy_der = gy;
             P->ell_der2 = gy_ell->t.der2;
             P->ell_nodes = gy_ell->t.nodes;
@@ -2231,7 +2457,34 @@ static void poisson_direct_stage(tlab_poisson_plan_t P, int ibc, double *f_hat, 
     a.neumann_b = (ibc == TLAB_BCS_ND || ibc == TLAB_BCS_NN) ? 1 : 0;
     a.neumann_t = (ibc == TLAB_BCS_DN || ibc == TLAB_BCS_NN) ? 1 : 0;
     a.scratch = P->scratch.p;
-    {
+    // chunked kernel (k_int2c) where the line splits into 8-row chunks and 32-bit indices suffice; TLAB_INT2_CHUNKED=0 (read per call) or
+    // tlab_poisson_set_exact(1) keep the marching kernel, which repeats the reference's operation order
+    const int C = P->ny / OM, NM = (P->ny % OM == 0 && P->ny >= 2 * OM) ? ode_modes_per_wg(C) : 0;
+    const char *ce = getenv("TLAB_INT2_CHUNKED");
+    const bool chunked = NM > 0 && !(ce && atoi(ce) == 0) && !P->exact_mode && (double)P->nm * P->ny * 2.0 < 2.0e9;
+    if (chunked) {
+        auto &E = *P->int2[ibc];
+        const long long nblk = (P->nm + NM - 1) / NM;
+        if (!E.chk_ok || E.chk_alpha != a.alpha) {
+            if (E.chk.n != (size_t)C * 6 * nblk * NM) E.chk.alloc((size_t)C * 6 * nblk * NM);
+            hipLaunchKernelGGL(k_int2_checkpoint, dim3((unsigned)((P->nm + 255) / 256)), dim3(256), 0, st, a.T, P->lam.p, a.alpha, a.neumann_b, a.neumann_t,
+                               E.chk.p, P->nm, NM, C);
+            hipc(hipGetLastError(), "k_int2_checkpoint");
+            E.chk_alpha = a.alpha; E.chk_ok = true;
+        }
+        Int2cArgs k{};
+        k.T = a.T; k.lam = a.lam; k.alpha = a.alpha; k.nm = P->nm; k.skip = a.skip; k.chk = E.chk.p; k.fsrc = f_hat; k.dst = p_hat; k.fscale = a.fscale;
+        k.nxh = a.nxh; k.ny = a.ny; k.C = C; k.neumann_b = a.neumann_b; k.neumann_t = a.neumann_t;
+        const size_t lds = ((size_t)64 * NM + (size_t)(3 * OM + 1) * NM * C) * sizeof(double);
+        ProfScope ps("k_int2c", st, (double)P->nm * P->ny * 32.0);
+        switch (NM) {
+        case 4: launch_int2c<4>(k, lds, st); break;
+        case 8: launch_int2c<8>(k, lds, st); break;
+        case 16: launch_int2c<16>(k, lds, st); break;
+        case 32: launch_int2c<32>(k, lds, st); break;
+        default: launch_int2c<64>(k, lds, st); break;
+        }
+    } else {
         ProfScope ps("k_int2", st, (double)P->nm * P->ny * 32.0);
         hipLaunchKernelGGL((k_int2<4>), dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, st, a);
     }
