@@ -304,6 +304,13 @@ int tlab_dns_begin_step(tlab_dns_t d);
 #define TLAB_DNS_BCS_DIRICHLET 3
 #define TLAB_DNS_BCS_NEUMANN 4
 int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
+/* Dynamic surface model of the scalars: BcsScalJmin/Jmax%SfcType (0 = DNS_SFC_STATIC, 1 = DNS_SFC_LINEAR) and %cpl per scalar
+ * ([BoundaryConditions] Scalar<i>SfcTypeJmin/Jmax, Scalar<i>CouplingJmin/Jmax; tools/dns/boundary_bcs.f90:29-31, 76-87).  With a linear surface the
+ * wall plane of the scalar's tendency is its old value plus cpl times the anomaly of the diffusive surface flux: the tendency planes kept at the
+ * start of the RHS (rhs_global_incompressible_1.f90:77-87) and BOUNDARY_BCS_SURFACE_Y (boundary_bcs.f90:478-546: d/dy of the scalar, AVG1V2D of its
+ * plane j = 1 -- at both ends, as the reference has it) in the boundary section (:393-396).  Single-domain driver (the plane average is an
+ * all-reduce in a decomposed run: the slab / pencil drivers do not take it). */
+int tlab_dns_set_surface_bcs(tlab_dns_t d, const int *sfc_jmin, const int *sfc_jmax, const double *cpl_jmin, const double *cpl_jmax);
 /* nse_eqns == DNS_EQNS_ANELASTIC: the density weights of the RHS (Thermo_Anelastic_WEIGHT_INPLACE / _SUBTRACT with rbackground / ribackground,
  * tools/dns/rhs_global_incompressible_1.f90:211-214, :326-329; the Neumann data of the pressure times rbackground at the walls, :275-277) and of
  * OPR_Burgers (below).  rbackground, ribackground: HOST pointers, ny values each, ribackground = 1 / rbackground -- the profiles the host's

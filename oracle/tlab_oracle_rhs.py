@@ -38,6 +38,9 @@ class DnsOracle:
         # BcsFlowJmin/Jmax%type, BcsScalJmin/Jmax%type (boundary_bcs.f90:18-27): 3 = DNS_BCS_DIRICHLET, 4 = DNS_BCS_NEUMANN
         self.flow_jmin, self.flow_jmax = [3, 3, 3], [3, 3, 3]
         self.scal_jmin, self.scal_jmax = [3] * nscal, [3] * nscal
+        # BcsScalJmin/Jmax%SfcType (0 = DNS_SFC_STATIC, 1 = DNS_SFC_LINEAR) and %cpl (boundary_bcs.f90:29-31, 49-50, 76-87): dynamic surface model
+        self.sfc_jmin, self.sfc_jmax = [0] * nscal, [0] * nscal
+        self.cpl_jmin, self.cpl_jmax = [0.0] * nscal, [0.0] * nscal
 
     def burgers(self, d, nu, s, vel):
         return O.opr_burgers(d, self.nx, self.ny, self.nz, 0, self.g[d - 1], nu, s, vel, anelastic=self.anelastic, dealiasing=self.dealiasing[d - 1])[0]
@@ -54,6 +57,9 @@ class DnsOracle:
         u, v, w = self.q
         hq, hs = self.hq, self.hs
         nu = self.visc
+        # the old tendency of the scalar at the boundary for the dynamic surface BCs (:77-87); zero otherwise
+        sref_b = [hs[i].reshape(nz, ny, nx)[:, 0, :].copy() if self.sfc_jmin[i] == 1 else np.zeros((nz, nx)) for i in range(self.nscal)]
+        sref_t = [hs[i].reshape(nz, ny, nx)[:, ny - 1, :].copy() if self.sfc_jmax[i] == 1 else np.zeros((nz, nx)) for i in range(self.nscal)]
         tmp1 = self.burgers(1, nu, u, u); tmp2 = self.burgers(2, nu, v, v); tmp3 = self.burgers(3, nu, w, w)      # :98-100
         tmp7 = self.burgers(2, nu, u, v); tmp8 = self.burgers(3, nu, u, w)                                          # :103-104
         hq[0] = hq[0] + tmp1 + tmp7 + tmp8
@@ -89,8 +95,10 @@ class DnsOracle:
         else:
             hq[0] = hq[0] - tmp2; hq[1] = hq[1] - dpdy; hq[2] = hq[2] - tmp4                                        # :349-351
         types = list(zip(self.flow_jmin, self.flow_jmax)) + list(zip(self.scal_jmin, self.scal_jmax))
-        for a, (tmin, tmax) in zip(hq + hs, types):                                                                 # :363-375, :379-396
+        for ia, (a, (tmin, tmax)) in enumerate(zip(hq + hs, types)):                                                # :363-375, :379-396
             ref_b = np.zeros((nz, nx)); ref_t = np.zeros((nz, nx))
+            if ia >= 3:
+                ref_b, ref_t = sref_b[ia - 3], sref_t[ia - 3]
             ibc = (1 if tmin == 4 else 0) + (2 if tmax == 4 else 0)
             if ibc > 0:
                 nb, nt = O.boundary_bcs_neumann_y(ibc, nx, ny, nz, self.g[1], a)
@@ -98,9 +106,29 @@ class DnsOracle:
                     ref_b = nb
                 if ibc & 2:
                     ref_t = nt
+            if ia >= 3 and (self.sfc_jmin[ia - 3] == 1 or self.sfc_jmax[ia - 3] == 1):                              # BOUNDARY_BCS_SURFACE_Y (boundary_bcs.f90:478-546)
+                i = ia - 3
+                diff = self.visc / self.schmidt[i]
+                t1 = self.p1(2, self.s[i]).reshape(nz, ny, nx)                                                      # :508
+                avg1 = self._avg1v2d(t1, 0)                                                                         # AVG1V2D(.., 1, 1, tmp1): j = 1 at BOTH ends (:520, :535)
+                if self.sfc_jmin[i] == 1:
+                    hfx = diff * t1[:, 0, :]
+                    ref_b = ref_b + self.cpl_jmin[i] * (hfx - diff * avg1)
+                if self.sfc_jmax[i] == 1:
+                    hfx = -diff * t1[:, ny - 1, :]
+                    ref_t = ref_t + self.cpl_jmax[i] * (hfx - diff * avg1)
             b = a.reshape(nz, ny, nx)
             b[:, 0, :] = ref_b
             b[:, ny - 1, :] = ref_t
+
+    @staticmethod
+    def _avg1v2d(a3, j):
+        """utils/averages.f90:114-137 AVG1V2D (imom = 1): serial sum over i fastest, then k, of the plane j, / (nx nz)"""
+        acc = 0.0
+        for row in a3[:, j, :]:
+            for v in row:
+                acc = acc + v
+        return acc / float(a3.shape[0] * a3.shape[2])
 
     def time_courant(self, cfla, cfld):
         """tools/dns/time.f90:365-548 (incompressible) with the constants of TIME_INITIALIZE :138-176."""

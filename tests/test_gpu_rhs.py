@@ -492,3 +492,37 @@ def test_anelastic_substep_vs_oracle(T, nx, ny, nz, stretch, bcs):
         assert rel_err(B[0]["q"][1], o0.q[1]) > 1e-6
     finally:
         d.set_anelastic(None)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("sides", ["bottom", "both"])
+def test_dynamic_surface_bcs_vs_oracle(T, sides, fuse):
+    """Scalar1SfcTypeJmin = linear (examples/Case88): BOUNDARY_BCS_SURFACE_Y on the device against the oracle, three substeps (the kept tendency
+    plane of one substep feeds the next)."""
+    import torch
+    from tlab_amd.dns import Dns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 64, 48, 32
+    x, y, z = grids(nx, ny, nz, True)
+    visc, sc = 1.0 / 800.0, (0.7,)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 13)
+    d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    d.set_fusion(fuse)
+    jmax = "linear" if sides == "both" else "static"
+    d.set_surface_bcs(["linear"], [jmax], [0.35], [-0.2])
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i]))
+    d.s[0].copy_(torch.from_numpy(s0[0]))
+    dtime = 2e-3
+    sched = [(dtime * d.kdt[k], d.kco[k] if k < 2 else 1.0, k < 2) for k in range(3)]      # one full RK3 step (time.f90:220-298)
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        o.sfc_jmin, o.cpl_jmin = [1], [0.35]
+        o.sfc_jmax, o.cpl_jmax = [1 if sides == "both" else 0], [-0.2]
+        return o
+    B, S = oracle_substeps(("sfc", sides), make_oracle, q0, s0, sched, nsamples=2)
+    for k, (dte, kco, scale) in enumerate(sched):
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
+        check_state(d, B, S, k, tag="surface " + sides)
+    assert np.abs(B[2]["hs"][0].reshape(nz, ny, nx)[:, 0, :]).max() > 1e-3          # (the bottom plane of the tendency is alive)

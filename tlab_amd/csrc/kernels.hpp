@@ -110,6 +110,8 @@ hipError_t launch_minmax_partial(const double *a, const double *v, const double 
                                  int mode, int nx, int ny, int nz, int koff, int zon, double *part, int nblocks, hipStream_t st);
 hipError_t launch_negate(double *a, long long n, hipStream_t st);
 hipError_t launch_scale(double *a, double alpha, long long n, hipStream_t st);
+hipError_t launch_surface_flux(double *ref, const double *t, int j, int javg, double sign, double diff, double cpl, double *avg_scratch, int nx, int ny,
+                               int nz, hipStream_t st);
 hipError_t launch_weight_y(double *out, const double *in, const double *w, int nx, int ny, long long n, int mode, hipStream_t st);
 hipError_t launch_burgers_epilogue_anelastic(double *out, const double *vel, const double *d1, double nu, const double *ri, int nx, int ny,
                                              long long n, hipStream_t st);

@@ -292,6 +292,36 @@ hipError_t launch_burgers_epilogue_anelastic(double *out, const double *vel, con
     hipLaunchKernelGGL(k_burgers_epilogue_anelastic, dim3(pw_grid(n)), dim3(256), 0, st, out, vel, d1, nu, ri, nx, ny, n);
     return CHECK_LAUNCH();
 }
+// BOUNDARY_BCS_SURFACE_Y (tools/dns/boundary_bcs.f90:478-546): ref(i,k) += cpl (sign diff t(i,j,k) - diff avg), avg = AVG1V2D of plane javg of t
+// (utils/averages.f90:114-137).  One workgroup sums the plane (deterministic order, not the reference's serial one), a second kernel adds.
+__global__ void __launch_bounds__(1024) k_plane_sum(const double *__restrict__ t, int j, int nx, int ny, int nz, double *__restrict__ out) {
+    __shared__ double part[1024];
+    double acc = 0.0;
+    const long long np = (long long)nx * nz;
+    for (long long q = threadIdx.x; q < np; q += blockDim.x) acc += t[(q % nx) + (long long)nx * (j + (long long)ny * (q / nx))];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] / (double)np;
+}
+__global__ void __launch_bounds__(256) k_surface_flux(double *__restrict__ ref, const double *__restrict__ t, int j, double sign, double diff, double cpl,
+                                                      const double *__restrict__ avg, int nx, int ny, int nz) {
+#pragma clang fp contract(off)
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)nx * nz) return;
+    const double hfx = sign * diff * t[(q % nx) + (long long)nx * (j + (long long)ny * (q / nx))];
+    const double hfx_avg = diff * avg[0];
+    ref[q] = ref[q] + cpl * (hfx - hfx_avg);
+}
+hipError_t launch_surface_flux(double *ref, const double *t, int j, int javg, double sign, double diff, double cpl, double *avg_scratch, int nx, int ny,
+                               int nz, hipStream_t st) {
+    hipLaunchKernelGGL(k_plane_sum, dim3(1), dim3(1024), 0, st, t, javg, nx, ny, nz, avg_scratch);
+    hipLaunchKernelGGL(k_surface_flux, dim3(pw_grid((long long)nx * nz)), dim3(256), 0, st, ref, t, j, sign, diff, cpl, avg_scratch, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
 hipError_t launch_scale(double *a, double alpha, long long n, hipStream_t st) {
     hipLaunchKernelGGL(k_scale, dim3(pw_grid(n)), dim3(256), 0, st, a, alpha, n);
     return CHECK_LAUNCH();

@@ -47,6 +47,11 @@ struct tlab_dns {
     int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};   // BcsFlowJmin%type
     int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
     std::vector<int> scal_jmin, scal_jmax;         // BcsScalJmin%type, BcsScalJmax%type
+    // dynamic surface model of the scalars (BcsScalJmin/Jmax%SfcType = DNS_SFC_LINEAR, %cpl; boundary_bcs.f90:29-31, 49-50, 478-546)
+    std::vector<int> sfc_jmin, sfc_jmax;
+    std::vector<double> cpl_jmin, cpl_jmax;
+    std::vector<double *> sref_b, sref_t;          // BcsScalJmin%ref(:,:,is), BcsScalJmax%ref(:,:,is) of the scalars with a surface model
+    double *sfc_avg = nullptr;                     // one double: plane average
     // TIME_COURANT (tools/dns/time.f90:138-176): ds(ig)%one_ov_ds1 = 1/jac(:,1) on the device, dx2i, schmidtfactor
     double *od[3] = {nullptr, nullptr, nullptr};
     double *part = nullptr;                        // [2][NPART] partial (min, max) of the reductions
@@ -61,6 +66,9 @@ struct tlab_dns {
         for (int i = 0; i < 3; ++i)
             if (od[i]) (void)hipFree(od[i]);
         if (part) (void)hipFree(part);
+        for (double *p : sref_b) if (p) (void)hipFree(p);
+        for (double *p : sref_t) if (p) (void)hipFree(p);
+        if (sfc_avg) (void)hipFree(sfc_avg);
         if (rb) (void)hipFree(rb);
         if (rib) (void)hipFree(rib);
     }
@@ -155,6 +163,15 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // ---- diffusion and advection (:98-136), scalars (:149-162).  Reference: every OPR_Burgers result goes to a tmp array and
     // hq = hq + tmp_a + tmp_b + tmp_c afterwards; here each kernel adds its result to hq directly (same summation order)
     // when the fused kernels apply, and falls back to tmp + k_add3 per equation otherwise. ----
+    auto surface = [&](int is) { return !d->sfc_jmin.empty() && (d->sfc_jmin[is] == 1 || d->sfc_jmax[is] == 1); };
+    bool any_surface = false;
+    for (int is = 0; is < d->nscal; ++is) {      // keep the old tendency of the scalar at the boundary for the dynamic BCs (:77-87); zero otherwise
+        if (!surface(is)) continue;
+        any_surface = true;
+        hk(launch_get_wall_planes(hs[is], d->sref_b[is], d->sref_t[is], nx, ny, nz, st), "wall planes");
+        if (d->sfc_jmin[is] != 1) hk(hipMemsetAsync(d->sref_b[is], 0, (size_t)nx * nz * sizeof(double), st), "memset");
+        if (d->sfc_jmax[is] != 1) hk(hipMemsetAsync(d->sref_t[is], 0, (size_t)nx * nz * sizeof(double), st), "memset");
+    }
     struct Eq { double *dst; const double *fld; double nu; int order[3]; };   // order = directions in the reference's summation order
     std::vector<Eq> eqs = {{hq[0], u, nu, {1, 2, 3}},      // hq1 + tmp1(X) + tmp7(Y) + tmp8(Z)   (:110)
                            {hq[1], v, nu, {2, 1, 3}},      // hq2 + tmp2(Y) + tmp7(X) + tmp8(Z)   (:122)
@@ -181,6 +198,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     bool finish_scal = !finish_off && batched && tail_update && d->nscal > 0 && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
     for (int is = 0; is < d->nscal; ++is)
         finish_scal = finish_scal && d->scal_jmin[is] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[is] == TLAB_DNS_BCS_DIRICHLET;
+    finish_scal = finish_scal && !any_surface;      // the wall planes of a scalar with a surface model are not zero
     // Likewise the x term of the pressure forcing, d/dx (hq1 + u/dte) (:197-230): when the x Burgers launch runs last it holds the finished
     // tendency of u in registers, line by line, and differentiates it on the spot instead of a separate launch re-reading hq1 and u.
     const double idte = 1.0 / dte;
@@ -290,6 +308,21 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         if (ibc & 2) pt = d->bcs_ht;
     };
     const double *pb, *pt;
+    // planes of a scalar: Neumann values where selected, then the dynamic surface model (BOUNDARY_BCS_SURFACE_Y, :393-396), zeros (null) elsewhere
+    auto scal_planes = [&](int is, const double *&qb, const double *&qt) {
+        const int ibc = ibc_of(d->scal_jmin[is], d->scal_jmax[is]);
+        planes(ibc, hs[is], qb, qt);
+        if (!surface(is)) return;
+        const size_t pbytes = (size_t)nx * nz * sizeof(double);
+        if (qb) hk(hipMemcpyAsync(d->sref_b[is], qb, pbytes, hipMemcpyDeviceToDevice, st), "memcpy");      // the Neumann value replaces the kept tendency
+        if (qt) hk(hipMemcpyAsync(d->sref_t[is], qt, pbytes, hipMemcpyDeviceToDevice, st), "memcpy");
+        const double diff = d->visc / d->schmidt[is];
+        ok(tlab_opr_partial(2, gy, TLAB_OPR_P1, nx, ny, nz, B0, s[is], tmp1, nullptr), "OPR_Partial_Y (surface flux)");      // boundary_bcs.f90:508
+        // AVG1V2D(imax, jmax, kmax, 1, 1, tmp1) at BOTH ends (:520, :535): the plane j = 1
+        if (d->sfc_jmin[is] == 1) hk(launch_surface_flux(d->sref_b[is], tmp1, 0, 0, 1.0, diff, d->cpl_jmin[is], d->sfc_avg, nx, ny, nz, st), "surface flux");
+        if (d->sfc_jmax[is] == 1) hk(launch_surface_flux(d->sref_t[is], tmp1, ny - 1, 0, -1.0, diff, d->cpl_jmax[is], d->sfc_avg, nx, ny, nz, st), "surface flux");
+        qb = d->sref_b[is]; qt = d->sref_t[is];
+    };
     if (anel) {          // Thermo_Anelastic_WEIGHT_SUBTRACT(.., ribackground, tmp2 | tmp3 | tmp4, hq(:,1) | hq(:,2) | hq(:,3))  (:326-329)
         hk(launch_weight_y(hq[0], tmp2, d->rib, nx, ny, n, 1, st), "weight");
         hk(launch_weight_y(hq[1], tmp3, d->rib, nx, ny, n, 1, st), "weight");
@@ -309,7 +342,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             hk(launch_final_update(q[iq], hq[iq], gp[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
         for (int is = 0; is < d->nscal && !finish_scal; ++is) {      // (finish_scal: done in the epilogue of the x Burgers launch)
-            planes(ibc_of(d->scal_jmin[is], d->scal_jmax[is]), hs[is], pb, pt);
+            scal_planes(is, pb, pt);
             hk(launch_final_update(s[is], hs[is], nullptr, pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
     } else {
@@ -319,7 +352,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             hk(launch_set_wall_planes(hq[iq], pb, pt, nx, ny, nz, st), "wall planes");
         }
         for (int is = 0; is < d->nscal; ++is) {
-            planes(ibc_of(d->scal_jmin[is], d->scal_jmax[is]), hs[is], pb, pt);
+            scal_planes(is, pb, pt);
             hk(launch_set_wall_planes(hs[is], pb, pt, nx, ny, nz, st), "wall planes");
         }
     }
@@ -385,6 +418,34 @@ static void minmax_impl(tlab_dns_t d, const double *a, const double *v, const do
     hk(hipStreamSynchronize(st), "sync");
     *mn = *std::min_element(h.begin(), h.begin() + nb);
     *mx = *std::max_element(h.begin() + nb, h.end());
+}
+
+// BcsScalJmin/Jmax%SfcType and %cpl of the scalars ([BoundaryConditions] Scalar<i>SfcTypeJmin/Jmax = static | linear, Scalar<i>CouplingJmin/Jmax;
+// boundary_bcs.f90:76-87): 0 = DNS_SFC_STATIC, 1 = DNS_SFC_LINEAR.  Single-domain driver only (the plane average is an all-reduce in a decomposed run).
+int tlab_dns_set_surface_bcs(tlab_dns_t d, const int *sfc_jmin, const int *sfc_jmax, const double *cpl_jmin, const double *cpl_jmax) {
+    if (!d || (d->nscal > 0 && (!sfc_jmin || !sfc_jmax || !cpl_jmin || !cpl_jmax))) {
+        tlab_set_error("tlab_dns_set_surface_bcs: bad arguments");
+        return TLAB_EINVAL;
+    }
+    try {
+        for (int i = 0; i < d->nscal; ++i)
+            if ((sfc_jmin[i] != 0 && sfc_jmin[i] != 1) || (sfc_jmax[i] != 0 && sfc_jmax[i] != 1)) throw Fail(TLAB_EINVAL, "SfcType: 0 static or 1 linear");
+        d->sfc_jmin.assign(sfc_jmin, sfc_jmin + d->nscal); d->sfc_jmax.assign(sfc_jmax, sfc_jmax + d->nscal);
+        d->cpl_jmin.assign(cpl_jmin, cpl_jmin + d->nscal); d->cpl_jmax.assign(cpl_jmax, cpl_jmax + d->nscal);
+        d->sref_b.resize(d->nscal, nullptr); d->sref_t.resize(d->nscal, nullptr);
+        const size_t pbytes = (size_t)d->nx * d->nz * sizeof(double);
+        for (int i = 0; i < d->nscal; ++i) {
+            if ((sfc_jmin[i] == 1 || sfc_jmax[i] == 1) && !d->sref_b[i]) {
+                hk(hipMalloc((void **)&d->sref_b[i], pbytes), "hipMalloc");
+                hk(hipMalloc((void **)&d->sref_t[i], pbytes), "hipMalloc");
+            }
+        }
+        if (!d->sfc_avg) hk(hipMalloc((void **)&d->sfc_avg, sizeof(double)), "hipMalloc");
+        return TLAB_OK;
+    } catch (const Fail &e) {
+        tlab_set_error(e.what());
+        return e.code;
+    }
 }
 
 // nse_eqns == DNS_EQNS_ANELASTIC (tools/dns/rhs_global_incompressible_1.f90:211-214, 275-277, 326-329; physics/opr_burgers.f90:128-183) with the

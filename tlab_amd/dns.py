@@ -92,6 +92,15 @@ class Dns:
         fj0, fj1, sj0, sj1 = _bcs_arrays(self.nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax)
         check(load().tlab_dns_set_bcs(self._h, fj0, fj1, sj0, sj1), "tlab_dns_set_bcs")
 
+    def set_surface_bcs(self, sfc_jmin=None, sfc_jmax=None, coupling_jmin=None, coupling_jmax=None):
+        """[BoundaryConditions] Scalar<i>SfcTypeJmin/Jmax = "static" | "linear" and Scalar<i>CouplingJmin/Jmax per scalar (boundary_bcs.f90:76-87)."""
+        ns = max(self.nscal, 1)
+        code = lambda v: [1 if str(t).lower() == "linear" else 0 for t in (v or ["static"] * ns)]      # noqa: E731
+        s0, s1 = (ctypes.c_int * ns)(*code(sfc_jmin)[:ns]), (ctypes.c_int * ns)(*code(sfc_jmax)[:ns])
+        c0 = (ctypes.c_double * ns)(*[float(v) for v in (coupling_jmin or [0.0] * ns)][:ns])
+        c1 = (ctypes.c_double * ns)(*[float(v) for v in (coupling_jmax or [0.0] * ns)][:ns])
+        check(load().tlab_dns_set_surface_bcs(self._h, s0, s1, c0, c1), "tlab_dns_set_surface_bcs")
+
     def set_anelastic(self, rbackground=None, ribackground=None):
         """nse_eqns = anelastic with the background density profile rbackground(ny) (ribackground defaults to 1 / rbackground); None: incompressible.
         Module state of the Burgers operator, like the reference's rhoinv: it applies to every plan of the process until switched off."""

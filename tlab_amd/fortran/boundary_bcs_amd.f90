@@ -63,11 +63,13 @@ contains
             call ScanFile_Char(bakfile, inifile, 'BoundaryConditions', trim(adjustl(lstr))//'SfcType'//trim(adjustl(tag)), 'static', sRes)
             if (trim(adjustl(sRes)) == 'static') then
                 var%SfcType(is) = DNS_SFC_STATIC
-            else                                             ! BOUNDARY_BCS_SURFACE_Y (non-static surfaces) is not on the device path
-                call TLab_Write_ASCII(efile, __FILE__//'. BoundaryConditions.'//trim(adjustl(lstr))//'SfcType'//trim(adjustl(tag))//': only static.')
-                call TLab_Stop(DNS_ERROR_UNDEVELOP)
+            else if (trim(adjustl(sRes)) == 'linear') then   ! dynamic surface model: BOUNDARY_BCS_SURFACE_Y runs inside tlab_rhs_global_incompressible_1
+                var%SfcType(is) = DNS_SFC_LINEAR
+            else
+                call TLab_Write_ASCII(efile, __FILE__//'. BoundaryConditions.'//trim(adjustl(lstr))//'SfcType'//trim(adjustl(tag)))
+                call TLab_Stop(DNS_ERROR_JBC)
             end if
-            var%cpl(is) = 0.0_wp
+            call ScanFile_Real(bakfile, inifile, 'BoundaryConditions', trim(adjustl(lstr))//'Coupling'//trim(adjustl(tag)), '0.0', var%cpl(is))
         end do
     end subroutine BOUNDARY_BCS_SCAL_READBLOCK
 

@@ -149,6 +149,12 @@ module TLab_AMD_C
             type(c_ptr), value :: dns
             integer(c_int), intent(in) :: flow_jmin(3), flow_jmax(3), scal_jmin(*), scal_jmax(*)
         end function
+        integer(c_int) function tlab_dns_set_surface_bcs(dns, sfc_jmin, sfc_jmax, cpl_jmin, cpl_jmax) bind(C, name='tlab_dns_set_surface_bcs')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: dns
+            integer(c_int), intent(in) :: sfc_jmin(*), sfc_jmax(*)
+            real(c_double), intent(in) :: cpl_jmin(*), cpl_jmax(*)
+        end function
         integer(c_int) function tlab_dns_begin_step(dns) bind(C, name='tlab_dns_begin_step')
             import :: c_int, c_ptr
             type(c_ptr), value :: dns

@@ -34,6 +34,7 @@ contains
         use OPR_Elliptic, only: OPR_Elliptic_AMD_Plan
         type(c_ptr) :: h
         integer(c_int) :: rc, fj0(3), fj1(3), sj0(16), sj1(16)
+        real(c_double) :: cp0(16), cp1(16)
         real(c_double) :: sc(16)
         integer ns
         if (.not. c_associated(dns)) then
@@ -49,6 +50,15 @@ contains
             sj0(1:inb_scal) = BcsScalJmin%type(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%type(1:inb_scal)
             rc = tlab_dns_set_bcs(dns, fj0, fj1, sj0, sj1)
             call TLab_AMD_Check(rc, 'tlab_dns_set_bcs')
+            if (inb_scal > 0) then          ! dynamic surface model of the scalars (BcsScalJmin%SfcType, %cpl)
+                sj0 = 0; sj1 = 0; cp0 = 0.0_c_double; cp1 = 0.0_c_double
+                sj0(1:inb_scal) = BcsScalJmin%SfcType(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%SfcType(1:inb_scal)
+                cp0(1:inb_scal) = BcsScalJmin%cpl(1:inb_scal); cp1(1:inb_scal) = BcsScalJmax%cpl(1:inb_scal)
+                if (any(sj0(1:inb_scal) /= 0) .or. any(sj1(1:inb_scal) /= 0)) then
+                    rc = tlab_dns_set_surface_bcs(dns, sj0, sj1, cp0, cp1)
+                    call TLab_AMD_Check(rc, 'tlab_dns_set_surface_bcs')
+                end if
+            end if
         end if
         h = dns
     end function TLab_AMD_DNS_Handle
