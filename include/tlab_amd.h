@@ -304,6 +304,9 @@ int tlab_dns_begin_step(tlab_dns_t d);
 #define TLAB_DNS_BCS_DIRICHLET 3
 #define TLAB_DNS_BCS_NEUMANN 4
 int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
+/* remove_divergence of dns.ini (tools/dns/dns_read_local.f90): on (default): the pressure forcing is div(hq + q/dte), which removes the residual
+ * divergence of q (rhs_global_incompressible_1.f90:177-232); off: div(hq) (:234-250). */
+int tlab_dns_set_remove_divergence(tlab_dns_t d, int on);
 /* Dynamic surface model of the scalars: BcsScalJmin/Jmax%SfcType (0 = DNS_SFC_STATIC, 1 = DNS_SFC_LINEAR) and %cpl per scalar
  * ([BoundaryConditions] Scalar<i>SfcTypeJmin/Jmax, Scalar<i>CouplingJmin/Jmax; tools/dns/boundary_bcs.f90:29-31, 76-87).  With a linear surface the
  * wall plane of the scalar's tendency is its old value plus cpl times the anomaly of the diffusive surface flux: the tendency planes kept at the

@@ -39,6 +39,7 @@ class DnsOracle:
         self.flow_jmin, self.flow_jmax = [3, 3, 3], [3, 3, 3]
         self.scal_jmin, self.scal_jmax = [3] * nscal, [3] * nscal
         # BcsScalJmin/Jmax%SfcType (0 = DNS_SFC_STATIC, 1 = DNS_SFC_LINEAR) and %cpl (boundary_bcs.f90:29-31, 49-50, 76-87): dynamic surface model
+        self.remove_divergence = True                  # dns.ini; False: the else-branch of :234-250 (forcing = div(hq))
         self.sfc_jmin, self.sfc_jmax = [0] * nscal, [0] * nscal
         self.cpl_jmin, self.cpl_jmax = [0.0] * nscal, [0.0] * nscal
 
@@ -71,10 +72,13 @@ class DnsOracle:
             kap = self.visc / self.schmidt[i]
             t1 = self.burgers(1, kap, self.s[i], u); t2 = self.burgers(2, kap, self.s[i], v); t3 = self.burgers(3, kap, self.s[i], w)
             hs[i] = hs[i] + t1 + t2 + t3
-        dummy = 1.0 / dte                                                                                           # :188-201
-        tmp2 = hq[1] + v * dummy
-        tmp3 = hq[0] + u * dummy
-        tmp4 = hq[2] + w * dummy
+        if self.remove_divergence:
+            dummy = 1.0 / dte                                                                                       # :188-201
+            tmp2 = hq[1] + v * dummy
+            tmp3 = hq[0] + u * dummy
+            tmp4 = hq[2] + w * dummy
+        else:                                                                                                       # :234-250
+            tmp2, tmp3, tmp4 = hq[1].copy(), hq[0].copy(), hq[2].copy()
         if self.anelastic is not None:                                                                              # :211-214
             rb, ri = self.anelastic
             tmp2, tmp3, tmp4 = self.weight(rb, tmp2), self.weight(rb, tmp3), self.weight(rb, tmp4)

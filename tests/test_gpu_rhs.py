@@ -526,3 +526,31 @@ def test_dynamic_surface_bcs_vs_oracle(T, sides, fuse):
         d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
         check_state(d, B, S, k, tag="surface " + sides)
     assert np.abs(B[2]["hs"][0].reshape(nz, ny, nx)[:, 0, :]).max() > 1e-3          # (the bottom plane of the tendency is alive)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_without_remove_divergence_vs_oracle(T, fuse):
+    """dns.ini remove_divergence = none: the forcing of the pressure is div(hq) alone (rhs_global_incompressible_1.f90:234-250)."""
+    import torch
+    from tlab_amd.dns import Dns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 64, 40, 32
+    x, y, z = grids(nx, ny, nz, True)
+    visc, sc = 1.0 / 800.0, (0.7,)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 17)
+    d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    d.set_fusion(fuse)
+    d.set_remove_divergence(False)
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i]))
+    d.s[0].copy_(torch.from_numpy(s0[0]))
+    sched = [(2e-3 * d.kdt[k], d.kco[k], True) for k in range(2)]
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        o.remove_divergence = False
+        return o
+    B, S = oracle_substeps(("nodiv",), make_oracle, q0, s0, sched, nsamples=2)
+    for k, (dte, kco, scale) in enumerate(sched):
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
+        check_state(d, B, S, k, tag="remove_divergence off")

@@ -43,6 +43,7 @@ struct tlab_dns {
     std::vector<double> schmidt;
     double *bcs_hb = nullptr, *bcs_ht = nullptr;   // BcsFlowJmin%ref(:,:,2), BcsFlowJmax%ref(:,:,2)
     bool fuse = true;                              // fold the pointwise sums into the operator kernels where the fast kernels apply
+    bool remove_divergence = true;                 // [Main] ... forcing = div(hq + q/dte) (rhs_global_incompressible_1.f90:177-232); false: div(hq) (:234-250)
     bool fresh = false;                            // one-shot: hq, hs count as zero on entry of the next substep (tlab_dns_begin_step)
     int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};   // BcsFlowJmin%type
     int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
@@ -201,7 +202,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     finish_scal = finish_scal && !any_surface;      // the wall planes of a scalar with a surface model are not zero
     // Likewise the x term of the pressure forcing, d/dx (hq1 + u/dte) (:197-230): when the x Burgers launch runs last it holds the finished
     // tendency of u in registers, line by line, and differentiates it on the spot instead of a separate launch re-reading hq1 and u.
-    const double idte = 1.0 / dte;
+    const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (:234-250)
     const bool x_last = !finish_off && batched && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
     const bool div_in_burgers = x_last && d->fuse && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
     if (batched) {
@@ -475,6 +476,12 @@ int tlab_dns_set_anelastic(tlab_dns_t d, const double *rbackground, const double
         tlab_set_error(e.what());
         return TLAB_EINVAL;
     }
+}
+
+int tlab_dns_set_remove_divergence(tlab_dns_t d, int on) {
+    if (!d) return TLAB_EINVAL;
+    d->remove_divergence = on != 0;
+    return TLAB_OK;
 }
 
 int tlab_dns_set_slab(tlab_dns_t d, int koffset) {

@@ -92,6 +92,10 @@ class Dns:
         fj0, fj1, sj0, sj1 = _bcs_arrays(self.nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax)
         check(load().tlab_dns_set_bcs(self._h, fj0, fj1, sj0, sj1), "tlab_dns_set_bcs")
 
+    def set_remove_divergence(self, on):
+        """dns.ini remove_divergence (default on): forcing = div(hq + q/dte); off: div(hq)."""
+        check(load().tlab_dns_set_remove_divergence(self._h, int(bool(on))), "tlab_dns_set_remove_divergence")
+
     def set_surface_bcs(self, sfc_jmin=None, sfc_jmax=None, coupling_jmin=None, coupling_jmax=None):
         """[BoundaryConditions] Scalar<i>SfcTypeJmin/Jmax = "static" | "linear" and Scalar<i>CouplingJmin/Jmax per scalar (boundary_bcs.f90:76-87)."""
         ns = max(self.nscal, 1)

@@ -69,6 +69,7 @@ SIGNATURES = {
     "tlab_dns_begin_step": (c_int, [c_vp]),
     "tlab_dns_set_slab": (c_int, [c_vp, c_int]),
     "tlab_dns_set_anelastic": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
+    "tlab_dns_set_remove_divergence": (c_int, [c_vp, c_int]),
     "tlab_dns_set_surface_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
     "tlab_opr_burgers_set_anelastic": (c_int, [c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
     "tlab_filter_create": (c_int, [ctypes.POINTER(c_vp), c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_dbl)]),
