@@ -147,6 +147,9 @@ int tlab_filter_destroy(tlab_filter_t f);
 /* result = filter(u) along direction dir of a field (nx, ny, nz), out of place: FLT_C4_RHS + TRIDSS / TRIDPSS, FLT_C4[P]_CUTOFF_RHS + PENTADSS2 /
  * PENTADPSS, FLT_E6, FLT_E4 (src/filters/flt_compact.f90, flt_explitic.f90) -- one line per thread, the reference's operation order. */
 int tlab_opr_filter_1d(int dir, tlab_filter_t f, int nx, int ny, int nz, const double *u, double *result);
+/* OPR_FILTER(nx, ny, nz, f, u, txc) (opr_filter.f90:283-392), directional branch: the x, y, z filters in that order (NULL = none), each repeat[d]
+ * times (NULL = once), in place; tmp: one field of scratch. */
+int tlab_opr_filter(int nx, int ny, int nz, tlab_filter_t fx, tlab_filter_t fy, tlab_filter_t fz, const int *repeat, double *u, double *tmp);
 /* [Dealiasing] Dealiasing(dir) of OPR_Burgers (physics/opr_burgers.f90:33, 71, 118-125): while a filter is set for a direction, tlab_opr_burgers
  * along it computes nu d2s - filter(u) filter(ds/dx) (:478-500), unfused; NULL: none.  The filter is not owned. */
 int tlab_opr_burgers_set_dealiasing(int dir, tlab_filter_t f);
@@ -304,6 +307,9 @@ int tlab_dns_begin_step(tlab_dns_t d);
 #define TLAB_DNS_BCS_DIRICHLET 3
 #define TLAB_DNS_BCS_NEUMANN 4
 int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
+/* [PressureFilter] of dns.ini: p and dp/dy pass OPR_FILTER after the Poisson solve (rhs_global_incompressible_1.f90:286-290; examples/Case92-93:
+ * compact filter in y with zero ends).  Filters not owned; NULL = none. */
+int tlab_dns_set_pressure_filter(tlab_dns_t d, tlab_filter_t fx, tlab_filter_t fy, tlab_filter_t fz, const int *repeat);
 /* remove_divergence of dns.ini (tools/dns/dns_read_local.f90): on (default): the pressure forcing is div(hq + q/dte), which removes the residual
  * divergence of q (rhs_global_incompressible_1.f90:177-232); off: div(hq) (:234-250). */
 int tlab_dns_set_remove_divergence(tlab_dns_t d, int on);

@@ -163,3 +163,16 @@ def opr_filter_1d(f, u):
     if f.type == DNS_FILTER_4E:
         return flt_e4(f.periodic, c, u)
     raise NotImplementedError("oracle: filter type %d" % f.type)
+
+
+def opr_filter(nx, ny, nz, f, u):
+    """operators/opr_filter.f90:283-392 OPR_FILTER, directional branch (:368-389): the x, then the y, then the z filter, each f[d].repeat times
+    (None = DNS_FILTER_NONE).  u: flat field -> filtered flat field."""
+    u = np.array(u, dtype=np.float64)
+    for d in (1, 2, 3):
+        fd = f[d - 1]
+        if fd is None:
+            continue
+        for _ in range(getattr(fd, "repeat", 1)):
+            u = O._from_lines(opr_filter_1d(fd, O._to_lines(u, nx, ny, nz, d)), nx, ny, nz, d)
+    return u

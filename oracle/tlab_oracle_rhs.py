@@ -39,6 +39,7 @@ class DnsOracle:
         self.flow_jmin, self.flow_jmax = [3, 3, 3], [3, 3, 3]
         self.scal_jmin, self.scal_jmax = [3] * nscal, [3] * nscal
         # BcsScalJmin/Jmax%SfcType (0 = DNS_SFC_STATIC, 1 = DNS_SFC_LINEAR) and %cpl (boundary_bcs.f90:29-31, 49-50, 76-87): dynamic surface model
+        self.pressure_filter = [None, None, None]      # PressureFilter(1:3) (opr_filter.f90:46; rhs_global_incompressible_1.f90:286-290): tlab_oracle_filter.Filter or None
         self.remove_divergence = True                  # dns.ini; False: the else-branch of :234-250 (forcing = div(hq))
         self.sfc_jmin, self.sfc_jmax = [0] * nscal, [0] * nscal
         self.cpl_jmin, self.cpl_jmax = [0.0] * nscal, [0.0] * nscal
@@ -92,6 +93,10 @@ class DnsOracle:
             p, dpdy = OP.opr_poisson_fxz_direct(self.poisson, tmp1, hb, ht, gy_der=self.g[1])
         else:
             p, dpdy = OP.opr_poisson_fxz(self.poisson, tmp1, hb, ht)                                                # :284
+        if any(f is not None for f in self.pressure_filter):                                                       # :286-290
+            from .tlab_oracle_filter import opr_filter
+            p = opr_filter(nx, ny, nz, self.pressure_filter, p)
+            dpdy = opr_filter(nx, ny, nz, self.pressure_filter, dpdy)
         self.p = p
         tmp2 = self.p1(1, p); tmp4 = self.p1(3, p)                                                                  # :319-320
         if self.anelastic is not None:                                                                              # :326-329

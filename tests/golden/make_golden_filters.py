@@ -29,7 +29,7 @@ if __name__ == "__main__":
         u = rng.uniform(-1, 1, (n, 6))
         out["n%d_u" % n] = u
         for t in (1, 2, 3, 9):
-            for per, nodes, jac, bcs in ((True, x, jx, [(0, 0)]), (False, y, jy, [(1, 1), (2, 6), (6, 2)])):
+            for per, nodes, jac, bcs in ((True, x, jx, [(0, 0)]), (False, y, jy, [(1, 1), (2, 6), (6, 2), (6, 6)])):
                 for b0, b1 in bcs:
                     key = "n%d_t%d_p%d_b%d%d" % (n, t, int(per), b0, b1)
                     c = R.filter_init(t, nodes, jac, per, b0, b1)

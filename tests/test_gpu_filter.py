@@ -106,3 +106,43 @@ def test_dealiased_burgers_and_substep_vs_oracle(T):
     finally:
         for d in (1, 2, 3):
             T.set_dealiasing(d, None)
+
+
+def test_pressure_filter_substeps_vs_oracle(T):
+    """[PressureFilter] Type = compact, ActiveY only, BcsJmin = BcsJmax = zero (examples/Case92-93): p and dp/dy pass OPR_FILTER after the Poisson
+    solve (rhs_global_incompressible_1.f90:286-290)."""
+    import torch
+    from oracle.tlab_oracle_rhs import DnsOracle
+    from tlab_amd.dns import Dns
+    from test_gpu_rhs import grids, init_fields
+    nx, ny, nz = 64, 64, 32
+    x, y, z = grids(nx, ny, nz, True)
+    assert np.array_equal(y, G["n64_y"])
+    fdev, _ = device_filter(T, "n64_t1_p0_b66")
+    forc, _ = filter_of("n64_t1_p0_b66")
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 21)
+    visc, sc = 1.0 / 500.0, (0.7,)
+    dn = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    dn.set_pressure_filter(None, fdev, None)
+    for i in range(3):
+        dn.q[i].copy_(torch.from_numpy(q0[i]))
+    dn.s[0].copy_(torch.from_numpy(s0[0]))
+    sched = [(2e-3 * dn.kdt[k], dn.kco[k], True) for k in range(2)]
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        o.pressure_filter = [None, forc, None]
+        return o
+    B, S = substep_scatter(make_oracle, q0, s0, sched, nsamples=2)
+    for k, (dte, kco, scale) in enumerate(sched):
+        dn.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
+        for name in ("q", "hq", "s", "hs"):
+            for i, (b, scat) in enumerate(zip(B[k][name], S[k][name])):
+                e = rel_err(getattr(dn, name)[i].cpu().numpy(), b)
+                assert e <= bound(scat), (k, name, i, e, scat)
+    plain = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+    for i in range(3):
+        plain.q[i] = q0[i].copy()
+    plain.s[0] = s0[0].copy()
+    plain.time_substep(*sched[0])
+    assert rel_err(B[0]["q"][1], plain.q[1]) > 1e-9

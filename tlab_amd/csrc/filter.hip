@@ -240,4 +240,23 @@ int tlab_opr_filter_1d(int dir, tlab_filter_t f, int nx, int ny, int nz, const d
     });
 }
 
+// OPR_FILTER (operators/opr_filter.f90:283-392), directional branch: x, y, z in that order, each `repeat` times, in place through tmp
+int tlab_opr_filter(int nx, int ny, int nz, tlab_filter_t fx, tlab_filter_t fy, tlab_filter_t fz, const int *repeat, double *u, double *tmp) {
+    return guarded([&] {
+        if (!u || !tmp || u == tmp || nx < 1 || ny < 1 || nz < 1) throw std::invalid_argument("tlab_opr_filter: bad arguments");
+        tlab_filter_t f[3] = {fx, fy, fz};
+        hipStream_t st = tlab_current_stream();
+        const size_t bytes = (size_t)nx * ny * nz * sizeof(double);
+        for (int d = 0; d < 3; ++d) {
+            if (!f[d]) continue;
+            const int rep = repeat ? repeat[d] : 1;
+            if (rep < 1) throw std::invalid_argument("tlab_opr_filter: Filter.Repeat must be positive (opr_filter.f90:198-204)");
+            for (int r = 0; r < rep; ++r) {
+                tlab_internal_filter_1d(d + 1, f[d], nx, ny, nz, u, tmp, st);
+                if (hipMemcpyAsync(u, tmp, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) throw std::runtime_error("hipMemcpyAsync");
+            }
+        }
+    });
+}
+
 }  // extern "C"

@@ -43,6 +43,8 @@ struct tlab_dns {
     std::vector<double> schmidt;
     double *bcs_hb = nullptr, *bcs_ht = nullptr;   // BcsFlowJmin%ref(:,:,2), BcsFlowJmax%ref(:,:,2)
     bool fuse = true;                              // fold the pointwise sums into the operator kernels where the fast kernels apply
+    tlab_filter_t pfilter[3] = {nullptr, nullptr, nullptr};      // PressureFilter(1:3) (not owned) and its repeat counts
+    int pfilter_rep[3] = {1, 1, 1};
     bool remove_divergence = true;                 // [Main] ... forcing = div(hq + q/dte) (rhs_global_incompressible_1.f90:177-232); false: div(hq) (:234-250)
     bool fresh = false;                            // one-shot: hq, hs count as zero on entry of the next substep (tlab_dns_begin_step)
     int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};   // BcsFlowJmin%type
@@ -278,6 +280,10 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     }
     // pressure in tmp1, Oy derivative in tmp3 (:284)
     ok(tlab_opr_poisson(d->poisson, nx, ny, nz, TLAB_BCS_NN, tmp1, tmp2, tmp4, d->bcs_hb, d->bcs_ht, tmp3), "OPR_Poisson");
+    if (d->pfilter[0] || d->pfilter[1] || d->pfilter[2]) {      // filter pressure p and its vertical gradient dpdy (:286-290)
+        ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp1, tmp4), "OPR_FILTER(p)");
+        ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp3, tmp4), "OPR_FILTER(dpdy)");
+    }
     // ---- pressure gradient (:319-320).  With Dirichlet walls and the RK update folded in (tail_update), the x- and z-gradient kernels
     // finish u and w themselves: hq -= dp/dx; wall planes; q += dte hq; hq *= kco (no gradient array is written or re-read) ----
     bool grad_final = false;
@@ -476,6 +482,15 @@ int tlab_dns_set_anelastic(tlab_dns_t d, const double *rbackground, const double
         tlab_set_error(e.what());
         return TLAB_EINVAL;
     }
+}
+
+// [PressureFilter] (operators/opr_filter.f90:46, 78; rhs_global_incompressible_1.f90:286-290): directional 1-D filters applied to p and dp/dy after
+// the Poisson solve; NULL = DNS_FILTER_NONE in that direction; repeat may be NULL (1 each).  The filters are not owned.
+int tlab_dns_set_pressure_filter(tlab_dns_t d, tlab_filter_t fx, tlab_filter_t fy, tlab_filter_t fz, const int *repeat) {
+    if (!d) return TLAB_EINVAL;
+    d->pfilter[0] = fx; d->pfilter[1] = fy; d->pfilter[2] = fz;
+    for (int i = 0; i < 3; ++i) d->pfilter_rep[i] = repeat ? repeat[i] : 1;
+    return TLAB_OK;
 }
 
 int tlab_dns_set_remove_divergence(tlab_dns_t d, int on) {

@@ -92,6 +92,13 @@ class Dns:
         fj0, fj1, sj0, sj1 = _bcs_arrays(self.nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax)
         check(load().tlab_dns_set_bcs(self._h, fj0, fj1, sj0, sj1), "tlab_dns_set_bcs")
 
+    def set_pressure_filter(self, fx=None, fy=None, fz=None, repeat=None):
+        """[PressureFilter]: tlab_amd.Filter objects per direction (None = no filter); the caller keeps them alive."""
+        self._pfilters = (fx, fy, fz)
+        rp = (ctypes.c_int * 3)(*(repeat or (1, 1, 1)))
+        h = [f._h if f is not None else None for f in (fx, fy, fz)]
+        check(load().tlab_dns_set_pressure_filter(self._h, h[0], h[1], h[2], rp), "tlab_dns_set_pressure_filter")
+
     def set_remove_divergence(self, on):
         """dns.ini remove_divergence (default on): forcing = div(hq + q/dte); off: div(hq)."""
         check(load().tlab_dns_set_remove_divergence(self._h, int(bool(on))), "tlab_dns_set_remove_divergence")

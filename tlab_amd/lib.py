@@ -76,6 +76,8 @@ SIGNATURES = {
     "tlab_filter_destroy": (c_int, [c_vp]),
     "tlab_opr_filter_1d": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tlab_opr_burgers_set_dealiasing": (c_int, [c_int, c_vp]),
+    "tlab_opr_filter": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.POINTER(c_int), c_vp, c_vp]),
+    "tlab_dns_set_pressure_filter": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_int)]),
     "tlab_time_courant": (c_int, [c_vp, ctypes.POINTER(c_vp), c_dbl, c_dbl, _dp, _dp]),
     "tlab_fi_invariant_p": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tlab_minmax": (c_int, [c_vp, c_vp, c_int, c_int, c_int, _dp, _dp]),
