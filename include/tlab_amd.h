@@ -40,6 +40,10 @@ extern "C" {
 #define TLAB_OPR_P1 1
 #define TLAB_OPR_P2 2
 #define TLAB_OPR_P2_P1 3
+#define TLAB_OPR_P1_INT_VP 5   /* interpolatory first derivative velocity -> pressure grid (staggering; periodic x, z) */
+#define TLAB_OPR_P1_INT_PV 6
+#define TLAB_OPR_P0_INT_VP 7   /* interpolation velocity -> pressure grid */
+#define TLAB_OPR_P0_INT_PV 8
 /* physics/opr_burgers.f90:29-30 */
 #define TLAB_OPR_B_SELF 0
 #define TLAB_OPR_B_U_IN 1
@@ -97,14 +101,20 @@ int tlab_fdm_plan_set_aux(tlab_fdm_plan_t plan, const double *mwn1, const double
  * FDM_C1N4_Direct / FDM_C1N6_Direct: 3 / 5 per-row RHS diagonals, MatMul_3d / MatMul_5d with the Neumann-reduced rows of FDM_Bcs_Neumann)
  * in non-periodic directions (periodic ones fall back to the Jacobian schemes, fdm.f90:155-158). */
 int tlab_fdm_plan_set_scheme(tlab_fdm_plan_t plan, int mode1, int mode2);
+/* [Staggering] StaggerHorizontalPressure = yes (TLab_WorkFlow::stagger_on): FDM_CreatePlan then gives a periodic direction the interpolation
+ * tables g%intl (FDM_Interpol_Initialize, fdm/fdm_interpolate.f90:33-96) and replaces g%der1%mwn by the interpolatory modified wavenumbers
+ * (fdm.f90:236-248).  mode 1: both (plans of tlab_fdm_plan_create); 2: tables only (host-built plans whose mwn1 already is the host's); 0: off.
+ * With it tlab_opr_partial takes the types TLAB_OPR_P0/P1_INT_VP/PV along x and z, a Poisson plan built on such x / z plans has the one singular
+ * mode (1,1) (opr_elliptic.f90:144-146) and the RHS driver takes the staggered branch (rhs_global_incompressible_1.f90:216-226, 266-273, 307-317). */
+int tlab_fdm_plan_set_stagger(tlab_fdm_plan_t plan, int mode);
 int tlab_fdm_plan_destroy(tlab_fdm_plan_t p);
 
 /* read back plan tables (HOST buffer, column-major like the reference) for parity tests. which:
  *  1 der1%lhs(n,5) 2 der1%rhs(n,7) 3 der1%lu(n,5|20) 4 der1%rhs_b(4,0:7) 5 der1%rhs_t(0:4,7) 6 der1%mwn(n)
- *  7 der2%lhs(n,5) 8 der2%rhs(n,12) 9 der2%lu(n,5|3) 10 der2%mwn(n) 11 jac(n,3)
+ *  7 der2%lhs(n,5) 8 der2%rhs(n,12) 9 der2%lu(n,5|3) 10 der2%mwn(n) 11 jac(n,3) 12 intl%lu0i(n,5) 13 intl%lu1i(n,5)
  * returns the number of doubles written (or <0). */
 int tlab_fdm_plan_get(tlab_fdm_plan_t p, int which, double *buf, int nbuf);
-int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what); /* 0 n, 1 ndl1, 2 ndr1, 3 ndl2, 4 ndr2, 5 need_1der, 6 periodic */
+int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what); /* 0 n, 1 ndl1, 2 ndr1, 3 ndl2, 4 ndr2, 5 need_1der, 6 periodic, 7 staggered */
 
 /* ---- operators ----------------------------------------------------------------------------- */
 /* OPR_Partial_X/Y/Z(type, nx, ny, nz, bcs, g, u, result, tmp1)   operators/opr_partial.f90:31,266,154

@@ -77,3 +77,29 @@ subroutine ref_filter_1d(itype, n, nlines, periodic, bcsmin, bcsmax, ncols, coef
         call FLT_E4(n, nlines, per, coeffs, u, res)
     end select
 end subroutine ref_filter_1d
+
+!########################################################################
+! horizontal staggering of the pressure ([Staggering] StaggerHorizontalPressure = yes): the reference keeps it in the module variable
+! TLab_WorkFlow::stagger_on, read by FDM_CreatePlan (fdm/fdm.f90:236-248: g%intl, and g%der1%mwn becomes the interpolatory one)
+subroutine ref_set_stagger(on) bind(C, name='ref_set_stagger')
+    use iso_c_binding
+    use TLab_WorkFlow, only: stagger_on
+    implicit none
+    integer(c_int), value :: on
+    stagger_on = on /= 0
+end subroutine ref_set_stagger
+
+! which = 0: g%intl%lu0i(n, 5), 1: g%intl%lu1i(n, 5)   (fdm/fdm_interpolate.f90:14-21)
+subroutine ref_intl_get(idir, which, n, buf) bind(C, name='ref_intl_get')
+    use iso_c_binding
+    use TLab_Constants, only: wp
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, which, n
+    real(c_double), intent(out) :: buf(n*5)
+    if (which == 0) then
+        buf = reshape(gp(idir)%intl%lu0i, [n*5])
+    else
+        buf = reshape(gp(idir)%intl%lu1i, [n*5])
+    end if
+end subroutine ref_intl_get

@@ -38,6 +38,8 @@ def lib():
         L.ref_burgers.argtypes = [c_int] * 5 + [c_dbl, _P, _P, _P, _P]
         L.ref_filter_init.argtypes = [c_int] * 5 + [c_dbl, _P, c_dbl, _P, c_int, _P]
         L.ref_filter_1d.argtypes = [c_int] * 7 + [_P, _P, _P]
+        L.ref_set_stagger.argtypes = [c_int]
+        L.ref_intl_get.argtypes = [c_int, c_int, c_int, _P]
         _lib = L
     return _lib
 
@@ -267,3 +269,18 @@ def filter_1d(itype, periodic, bcsmin, bcsmax, coeffs, u):
     r = np.empty_like(u)
     lib().ref_filter_1d(itype, n, u.shape[1], int(periodic), bcsmin, bcsmax, nc, np.ascontiguousarray(c.reshape(-1)), u, r)
     return r
+
+
+def set_stagger(on):
+    """TLab_WorkFlow::stagger_on for the plans created afterwards (fdm.f90:236-248)."""
+    lib().ref_set_stagger(int(bool(on)))
+
+
+def intl_arrays(idir, n):
+    """g%intl%lu0i, g%intl%lu1i as [row, column] (n, 5)"""
+    out = []
+    for which in (0, 1):
+        buf = np.zeros(n * 5)
+        lib().ref_intl_get(idir, which, n, buf)
+        out.append(buf.reshape(5, n).T.copy())
+    return out

@@ -35,6 +35,7 @@ FDM_COM4_DIRECT = 17
 
 # operators/opr_partial.f90:19-21 ; physics/opr_burgers.f90:29-30
 OPR_P1, OPR_P2, OPR_P2_P1 = 1, 2, 3
+OPR_P1_INT_VP, OPR_P1_INT_PV, OPR_P0_INT_VP, OPR_P0_INT_PV = 5, 6, 7, 8      # interpolatory operators of the staggered pressure grid (:22-25)
 OPR_B_SELF, OPR_B_U_IN = 0, 1
 
 # value the flang-built reference picks up for the out-of-bounds coef_bc1(7) of the C2N6-Hyper wall closure
@@ -927,8 +928,10 @@ def der2_solve(g, lu, u, du):
 class FdmPlan:
     """fdm/fdm.f90:14-29 type fdm_dt."""
 
-    def __init__(self, nodes, periodic, uniform, mode1=FDM_COM6_JACOBIAN, mode2=FDM_COM6_JACOBIAN_HYPER, hyper_bc1_ext=None):
-        """fdm/fdm.f90:143-252 FDM_CreatePlan.  hyper_bc1_ext: None = the module's HYPER_BC1_EXT (what the flang-built reference reads)."""
+    def __init__(self, nodes, periodic, uniform, mode1=FDM_COM6_JACOBIAN, mode2=FDM_COM6_JACOBIAN_HYPER, hyper_bc1_ext=None, stagger=False):
+        """fdm/fdm.f90:143-252 FDM_CreatePlan.  hyper_bc1_ext: None = the module's HYPER_BC1_EXT (what the flang-built reference reads).
+        stagger: TLab_WorkFlow::stagger_on (horizontal pressure staggering): periodic directions get g%intl and the interpolatory der1%mwn (:236-248)."""
+        self.stagger = bool(stagger)
         global HYPER_BC1_EXT
         saved = HYPER_BC1_EXT
         if hyper_bc1_ext is not None:
@@ -980,6 +983,9 @@ class FdmPlan:
         der2_initialize(self.der2, self.jac[:, 1:3].copy(), periodic, uniform)
         if self.der2.periodic:
             self.der2.mwn = self.der2.mwn / (self.jac[0, 0] ** 2)
+        if getattr(self, "stagger", False) and periodic:                          # :236-248
+            self.intl = Interpol()
+            self.der1.mwn = interpol_initialize(nodes, self.jac[:, 0], self.intl)
 
     @classmethod
     def from_tables(cls, tab, periodic=False, mode1=FDM_COM6_JACOBIAN, mode2=FDM_COM6_DIRECT):
@@ -1041,6 +1047,83 @@ def _from_lines(r, nx, ny, nz, idir):
     return np.ascontiguousarray(r).ravel()
 
 
+# ######################################################################################
+# fdm/fdm_interpolate.f90 + fdm/fdm_com0_jacobian.f90 -- interpolation between the velocity and the staggered pressure grid (periodic directions)
+# ######################################################################################
+class Interpol:
+    """type(fdm_interpol_dt), fdm_interpolate.f90:14-21"""
+    lu0i = lu1i = None
+
+
+def fdm_c0int6p_lhs(n):
+    """fdm_com0_jacobian.f90:29-44"""
+    return np.full(n, 2.0 / 5.0), np.full(n, 4.0 / 3.0), np.full(n, 2.0 / 5.0)
+
+
+def fdm_c1int6p_lhs(dx):
+    """fdm_com0_jacobian.f90:287-320 (with the Jacobian multiplication)"""
+    n = dx.shape[0]
+    a, b, c = np.full(n, 9.0 / 63.0), np.full(n, 62.0 / 63.0), np.full(n, 9.0 / 63.0)
+    c[n - 1] = c[n - 1] * dx[0]; b[0] = b[0] * dx[0]; a[1] = a[1] * dx[0]
+    for i in range(1, n - 1):
+        c[i - 1] = c[i - 1] * dx[i]; b[i] = b[i] * dx[i]; a[i + 1] = a[i + 1] * dx[i]
+    c[n - 2] = c[n - 2] * dx[n - 1]; b[n - 1] = b[n - 1] * dx[n - 1]; a[0] = a[0] * dx[n - 1]
+    return a, b, c
+
+
+def _cyc(u, k):
+    """u[(i + k) mod n] for every row i (the mod(...) index arithmetic of the periodic right-hand sides)"""
+    return np.roll(u, -k, axis=0)
+
+
+def fdm_c0intvp6p_rhs(u):
+    """:50-76"""
+    return _cyc(u, 1) + u + (1.0 / 15.0) * (_cyc(u, 2) + _cyc(u, -1))
+
+
+def fdm_c0intpv6p_rhs(u):
+    """:82-108"""
+    return u + _cyc(u, -1) + (1.0 / 15.0) * (_cyc(u, 1) + _cyc(u, -2))
+
+
+def fdm_c1intvp6p_rhs(u):
+    """:326-353"""
+    return (_cyc(u, 1) - u) + (17.0 / 189.0) * (_cyc(u, 2) - _cyc(u, -1))
+
+
+def fdm_c1intpv6p_rhs(u):
+    """:359-386"""
+    return (u - _cyc(u, -1)) + (17.0 / 189.0) * (_cyc(u, 1) - _cyc(u, -2))
+
+
+def interpol_initialize(x, dx, var):
+    """fdm_interpolate.f90:33-96 FDM_Interpol_Initialize: LU of the two periodic tridiagonal systems; returns the interpolatory modified wavenumbers"""
+    nx = x.shape[0]
+    for name, (a, b, c) in (("lu0i", fdm_c0int6p_lhs(nx)), ("lu1i", fdm_c1int6p_lhs(np.asarray(dx, dtype=np.float64)))):
+        lu = np.zeros((nx, 5))
+        lu[:, 0], lu[:, 1], lu[:, 2] = a, b, c
+        cols = [lu[:, k].copy() for k in range(5)]
+        tridpfs(*cols)
+        setattr(var, name, np.stack(cols, axis=1))
+    wn = _wavenumbers(nx)
+    c1, c3, c4 = 9.0 / 62.0, 63.0 / 62.0, 17.0 / 62.0
+    wn = 2.0 * (c3 * np.sin(1.0 / 2.0 * wn) + c4 / 3.0 * np.sin(3.0 / 2.0 * wn)) / (1.0 + 2.0 * c1 * np.cos(wn))
+    return wn / dx[0]
+
+
+def fdm_interpol(direction, g, u, der):
+    """FDM_Interpol (der = False) / FDM_Interpol_Der1 (der = True), fdm_interpolate.f90:98-160; direction 0: velocity -> pressure grid, 1: back"""
+    if der:
+        r = fdm_c1intvp6p_rhs(u) if direction == 0 else fdm_c1intpv6p_rhs(u)
+        lu = g.lu1i
+    else:
+        r = fdm_c0intvp6p_rhs(u) if direction == 0 else fdm_c0intpv6p_rhs(u)
+        lu = g.lu0i
+    r = np.ascontiguousarray(r)
+    tridpss(lu[:, 0], lu[:, 1], lu[:, 2], lu[:, 3], lu[:, 4], r)
+    return r
+
+
 def opr_partial(idir, itype, nx, ny, nz, ibc, g, u):
     """operators/opr_partial.f90:31-150 (X), :266-377 (Y), :154-262 (Z), serial branch.
     Returns (result, tmp1) with tmp1 = first derivative for OPR_P2_P1 (else None)."""
@@ -1058,6 +1141,9 @@ def opr_partial(idir, itype, nx, ny, nz, ibc, g, u):
         du = der1_solve(g.der1, ibc, ul)
         r = der2_solve(g.der2, g.der2.lu, ul, du)
         return _from_lines(r, nx, ny, nz, idir), _from_lines(du, nx, ny, nz, idir)
+    if itype in (OPR_P0_INT_VP, OPR_P0_INT_PV, OPR_P1_INT_VP, OPR_P1_INT_PV) and idir in (1, 3):      # opr_partial.f90:110-120, :228-238
+        r = fdm_interpol(0 if itype in (OPR_P0_INT_VP, OPR_P1_INT_VP) else 1, g.intl, ul, itype in (OPR_P1_INT_VP, OPR_P1_INT_PV))
+        return _from_lines(r, nx, ny, nz, idir), None
     raise NotImplementedError
 
 

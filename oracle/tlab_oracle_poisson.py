@@ -417,7 +417,7 @@ class PoissonPlan:
     """operators/opr_elliptic.f90:86-250 OPR_Elliptic_Initialize (TYPE_FACTORIZE, serial): lambda(k,i), singular modes,
     norm; the integral plans are rebuilt per call in this oracle (they are cheap here)."""
 
-    def __init__(self, gx, gy, gz, nx, ny, nz):
+    def __init__(self, gx, gy, gz, nx, ny, nz, stagger=False):
         self.nx, self.ny, self.nz = nx, ny, nz
         self.gy = gy
         self.nxh = nx // 2 + 1
@@ -430,6 +430,8 @@ class PoissonPlan:
         self.norm = 1.0 / float(nx * nz)
         self.i_sing = (0, nx // 2)                                       # 0-based (1, nx/2+1)
         self.k_sing = (0, nz // 2) if nz > 1 else (0, 0)
+        if stagger:                                                      # only one singular mode + other modified wavenumbers (:144-146)
+            self.i_sing, self.k_sing = (0, 0), (0, 0)
         sing = np.zeros((max(nz, 1), self.nxh), dtype=bool)
         for i in set(self.i_sing):
             for k in set(self.k_sing):

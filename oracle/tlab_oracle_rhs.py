@@ -14,7 +14,7 @@ from . import tlab_oracle_poisson as OP
 
 class DnsOracle:
     def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, plans=None, gy_elliptic=None, hyper_bc1_ext=None,
-                 anelastic=None, dealiasing=None):
+                 anelastic=None, dealiasing=None, stagger=False):
         """anelastic = (rbackground, ribackground): nse_eqns == DNS_EQNS_ANELASTIC with those background profiles (ny values each): the density
         weights of rhs_global_incompressible_1.f90:211-214, :275-277, :326-329 and of OPR_Burgers (opr_burgers.f90:128-183).  The buoyancy and
         the thermodynamics that PRODUCE the profiles are outside the path."""
@@ -23,13 +23,14 @@ class DnsOracle:
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
         h = hyper_bc1_ext                      # None: O.HYPER_BC1_EXT = the flang-built reference's wall closure (defect 1)
-        self.g = list(plans) if plans is not None else [O.FdmPlan(x, True, True, hyper_bc1_ext=h), O.FdmPlan(y, False, yuniform, hyper_bc1_ext=h),
-                                                        O.FdmPlan(z, True, True, hyper_bc1_ext=h)]
+        self.stagger = bool(stagger)                # [Staggering] StaggerHorizontalPressure = yes (TLab_WorkFlow::stagger_on)
+        self.g = list(plans) if plans is not None else [O.FdmPlan(x, True, True, hyper_bc1_ext=h, stagger=stagger), O.FdmPlan(y, False, yuniform, hyper_bc1_ext=h),
+                                                        O.FdmPlan(z, True, True, hyper_bc1_ext=h, stagger=stagger)]
         self.direct = gy_elliptic is not None         # EllipticOrder = CompactDirect6: OPR_Poisson => OPR_Poisson_FourierXZ_Direct (opr_elliptic.f90:153)
         if self.direct:
             self.poisson = OP.PoissonDirectPlan(self.g[0], gy_elliptic, self.g[2], self.nx, self.ny, self.nz)
         else:
-            self.poisson = OP.PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz)
+            self.poisson = OP.PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz, stagger=self.stagger)
         self.nscal, self.visc, self.schmidt = nscal, visc, list(schmidt)
         self.q = [np.zeros(self.n) for _ in range(3)]
         self.s = [np.zeros(self.n) for _ in range(nscal)]
@@ -53,6 +54,10 @@ class DnsOracle:
 
     def p1(self, d, u):
         return O.opr_partial(d, O.OPR_P1, self.nx, self.ny, self.nz, 0, self.g[d - 1], u)[0]
+
+    def pint(self, d, itype, u):
+        """OPR_Partial_X / _Z with an interpolatory type (OPR_P0_INT_VP ...), opr_partial.f90:110-120, :228-238"""
+        return O.opr_partial(d, itype, self.nx, self.ny, self.nz, 0, self.g[d - 1], u)[0]
 
     def rhs_global_incompressible_1(self, dte):
         nx, ny, nz = self.nx, self.ny, self.nz
@@ -83,9 +88,15 @@ class DnsOracle:
         if self.anelastic is not None:                                                                              # :211-214
             rb, ri = self.anelastic
             tmp2, tmp3, tmp4 = self.weight(rb, tmp2), self.weight(rb, tmp3), self.weight(rb, tmp4)
-        tmp1 = self.p1(2, tmp2); tmp2 = self.p1(1, tmp3); tmp3 = self.p1(3, tmp4)                                   # :228-230
+        VP0, VP1, PV0, PV1 = O.OPR_P0_INT_VP, O.OPR_P1_INT_VP, O.OPR_P0_INT_PV, O.OPR_P1_INT_PV
+        if self.stagger:                                                                                            # :216-226: derivatives onto the pressure nodes
+            tmp1 = self.pint(3, VP0, self.p1(2, self.pint(1, VP0, tmp2)))
+            tmp2 = self.pint(3, VP0, self.pint(1, VP1, tmp3))
+            tmp3 = self.pint(3, VP1, self.pint(1, VP0, tmp4))
+        else:
+            tmp1 = self.p1(2, tmp2); tmp2 = self.p1(1, tmp3); tmp3 = self.p1(3, tmp4)                               # :228-230
         tmp1 = tmp1 + tmp2 + tmp3                                                                                   # :258
-        h2 = hq[1].reshape(nz, ny, nx)
+        h2 = (self.pint(3, VP0, self.pint(1, VP0, hq[1])) if self.stagger else hq[1]).reshape(nz, ny, nx)           # :266-273
         hb, ht = h2[:, 0, :].copy(), h2[:, ny - 1, :].copy()                                                        # :279-280
         if self.anelastic is not None:                                                                              # :275-277
             hb, ht = hb * rb[0], ht * rb[ny - 1]
@@ -98,7 +109,12 @@ class DnsOracle:
             p = opr_filter(nx, ny, nz, self.pressure_filter, p)
             dpdy = opr_filter(nx, ny, nz, self.pressure_filter, dpdy)
         self.p = p
-        tmp2 = self.p1(1, p); tmp4 = self.p1(3, p)                                                                  # :319-320
+        if self.stagger:                                                                                            # :307-317: back onto the velocity nodes
+            dpdy = self.pint(1, PV0, self.pint(3, PV0, dpdy))
+            tmp4 = self.pint(1, PV0, self.pint(3, PV1, p))
+            tmp2 = self.pint(1, PV1, self.pint(3, PV0, p))
+        else:
+            tmp2 = self.p1(1, p); tmp4 = self.p1(3, p)                                                              # :319-320
         if self.anelastic is not None:                                                                              # :326-329
             hq[0] = hq[0] - self.weight(ri, tmp2); hq[1] = hq[1] - self.weight(ri, dpdy); hq[2] = hq[2] - self.weight(ri, tmp4)
         else:

@@ -167,3 +167,42 @@ def test_fortran_rk_driver_direct_schemes_from_the_ini_file(tmp_path):
     for i in range(3):
         assert rel_err(q1[i], B[2]["q"][i]) <= bound(S[2]["q"][i]), ("q", i, rel_err(q1[i], B[2]["q"][i]), S[2]["q"][i])
     assert rel_err(s1[0], B[2]["s"][0]) <= bound(S[2]["s"][0])
+
+
+@pytest.mark.parametrize("divergence", ["remove", "none"])
+def test_fortran_rk_driver_staggered_pressure(tmp_path, divergence):
+    """[Staggering] StaggerHorizontalPressure = yes (examples/Case92-93) and [Main] TermDivergence read from tlab.ini: the reference's own
+    FDM_Initialize builds g%intl and the interpolatory wavenumbers, the drop-in OPR_Partial_AMD_Plan hands them on (tlab_fdm_plan_set_stagger),
+    and the device RHS takes the staggered branch -- against the oracle's restatement of rhs_global_incompressible_1.f90."""
+    import numpy as np
+    from conftest import rel_err
+    from scatter import substep_scatter, bound
+    from oracle.tlab_oracle_rhs import DnsOracle
+    _need_rk()
+    nx, ny, nz = 64, 40, 32
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(92)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * Y)
+    q0 = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3)]
+    s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    re, sc, dt = 800.0, 0.7, 2e-3
+    bcs = ["VelocityJmin=noslip", "VelocityJmax=noslip", "Scalar1Jmin=dirichlet", "Scalar1Jmax=dirichlet"]
+    ini = INI.replace("{elliptic}", "TermDivergence=%s\n{elliptic}" % divergence) + "\n[Staggering]\nStaggerHorizontalPressure=yes\n"
+    q1, s1, _ = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 1, bcs, ini=ini)
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=1.0 / re, schmidt=(sc,), yuniform=False, stagger=True)
+        o.remove_divergence = divergence == "remove"
+        return o
+    kdt, kco = [1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0], [-5.0 / 9.0, -153.0 / 128.0]
+    sched = [(dt * kdt[k], kco[k] if k < 2 else 1.0, k < 2) for k in range(3)]
+    B, S = substep_scatter(make_oracle, q0, s0, sched, nsamples=1)
+    for i in range(3):
+        assert rel_err(q1[i], B[2]["q"][i]) <= bound(S[2]["q"][i]), ("q", i, rel_err(q1[i], B[2]["q"][i]), S[2]["q"][i])
+    assert rel_err(s1[0], B[2]["s"][0]) <= bound(S[2]["s"][0])
+    # and the staggered run is not the collocated one
+    C, _ = substep_scatter(lambda: DnsOracle(x, y, z, nscal=1, visc=1.0 / re, schmidt=(sc,), yuniform=False), q0, s0, sched, nsamples=0)
+    assert rel_err(q1[0], C[2]["q"][0]) > 1e-9

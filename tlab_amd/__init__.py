@@ -7,7 +7,7 @@ operator raises TlabError unless tlab_init() found an MI355X.
 from .lib import TlabError, load, lib_path  # noqa: F401
 from .operators import (  # noqa: F401
     FdmPlan, init, sync,
-    OPR_P1, OPR_P2, OPR_P2_P1, OPR_B_SELF, OPR_B_U_IN,
+    OPR_P1, OPR_P2, OPR_P2_P1, OPR_B_SELF, OPR_B_U_IN, OPR_P1_INT_VP, OPR_P1_INT_PV, OPR_P0_INT_VP, OPR_P0_INT_PV,
     BCS_DD, BCS_ND, BCS_DN, BCS_NN,
     FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN_PENTA, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER, FDM_COM6_DIRECT, FDM_COM4_DIRECT,
     OPR_Partial_X, OPR_Partial_Y, OPR_Partial_Z,

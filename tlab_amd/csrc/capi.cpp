@@ -489,7 +489,23 @@ int tlab_fdm_plan_set_scheme(tlab_fdm_plan_t p, int mode1, int mode2) {
     });
 }
 
+// [Staggering] StaggerHorizontalPressure (TLab_WorkFlow::stagger_on): what FDM_CreatePlan adds for a periodic direction (fdm.f90:236-248)
+int tlab_fdm_plan_set_stagger(tlab_fdm_plan_t p, int mode) {
+    return guarded([&] {
+        if (!p) throw Invalid("tlab_fdm_plan_set_stagger: null plan");
+        if (mode < 0 || mode > 2) throw Invalid("tlab_fdm_plan_set_stagger: mode 0 off, 1 tables + interpolatory wavenumbers, 2 tables only");
+        for (auto &f : p->interp)
+            if (f) { tlab_filter_destroy(f); f = nullptr; }
+        if (mode == 0) { p->t.stagger = false; return; }
+        if (p->t.jac.size() < (size_t)p->t.n) throw Invalid("tlab_fdm_plan_set_stagger: the plan has no Jacobian (tlab_fdm_plan_set_aux)");
+        try { interpol_initialize(p->t, mode == 1); } catch (const std::runtime_error &e) { throw Unsupported(e.what()); }
+    });
+}
+
 int tlab_fdm_plan_destroy(tlab_fdm_plan_t p) {
+    if (p)
+        for (auto &f : p->interp)
+            if (f) tlab_filter_destroy(f);
     delete p;
     return TLAB_OK;
 }
@@ -504,6 +520,7 @@ int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what) {
     case 4: return p->t.der2.ndr;
     case 5: return p->t.der2.need_1der ? 1 : 0;
     case 6: return p->t.periodic ? 1 : 0;
+    case 7: return p->t.stagger ? 1 : 0;
     }
     return TLAB_EINVAL;
 }
@@ -525,6 +542,8 @@ int tlab_fdm_plan_get(tlab_fdm_plan_t p, int which, double *buf, int nbuf) {
     case 9: src = t.der2.lu.data(); m = t.der2.lu.size(); break;
     case 10: src = t.der2.mwn.data(); m = t.der2.mwn.size(); break;
     case 11: src = t.jac.data(); m = t.jac.size(); break;
+    case 12: src = t.lu0i.data(); m = t.lu0i.size(); break;
+    case 13: src = t.lu1i.data(); m = t.lu1i.size(); break;
     default: return TLAB_EINVAL;
     }
     if ((size_t)nbuf < m) return TLAB_EINVAL;
@@ -947,9 +966,35 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
                      double *result, double *tmp1) {
     return guarded([&] {
         check_common(dir, g, nx, ny, nz, ibc);
-        if (type != TLAB_OPR_P1 && type != TLAB_OPR_P2 && type != TLAB_OPR_P2_P1)
-            throw Unsupported("OPR_Partial type not built on the device (interpolation / IBM variants stay on the CPU path)");
         if (!u || !result || u == result || (tmp1 && (tmp1 == u || tmp1 == result))) throw Invalid("u, result, tmp1 must be distinct");
+        if (type >= TLAB_OPR_P1_INT_VP && type <= TLAB_OPR_P0_INT_PV) {
+            // interpolatory operators of the staggered pressure grid (opr_partial.f90:110-120, :228-238 -> FDM_Interpol / FDM_Interpol_Der1,
+            // fdm_interpolate.f90:98-160): a 4-point right-hand side and the periodic tridiagonal LU of g%intl -- the same shape as the periodic
+            // compact FILTER (5-point per-row right-hand side + TRIDPSS), so they run as four such filter objects per plan (k_filter1d)
+            if (dir == 2) throw Unsupported("interpolatory operators along y are not built (the RHS staggers x and z only)");
+            if (!g->t.stagger) throw Invalid("the plan has no interpolation tables: tlab_fdm_plan_set_stagger");
+            if ((dir == 1 ? nx : nz) == 1) throw Invalid("interpolatory operator along a direction of one point");
+            const int k = type - TLAB_OPR_P1_INT_VP;      // 0 P1 VP, 1 P1 PV, 2 P0 VP, 3 P0 PV
+            if (!g->interp[k]) {
+                const int n = g->t.n;
+                const double c0 = 1.0 / 15.0, c1 = 17.0 / 189.0;      // fdm_com0_jacobian.f90:61, :338
+                const double st[4][5] = {{0.0, -c1, -1.0, 1.0, c1},       // (u(i+1) - u(i)) + c (u(i+2) - u(i-1))      :347
+                                         {-c1, -1.0, 1.0, c1, 0.0},       // (u(i) - u(i-1)) + c (u(i+1) - u(i-2))      :380
+                                         {0.0, c0, 1.0, 1.0, c0},         // u(i+1) + u(i) + c (u(i+2) + u(i-1))        :70
+                                         {c0, 1.0, 1.0, c0, 0.0}};        // u(i) + u(i-1) + c (u(i+1) + u(i-2))        :102
+                std::vector<double> tab((size_t)10 * n);
+                for (int q = 0; q < 5; ++q)
+                    for (int i = 0; i < n; ++i) tab[(size_t)q * n + i] = st[k][q];
+                const std::vector<double> &lu = (k < 2) ? g->t.lu1i : g->t.lu0i;
+                std::copy(lu.begin(), lu.end(), tab.begin() + (size_t)5 * n);
+                ok_or_throw(tlab_filter_create(&g->interp[k], TLAB_FILTER_COMPACT, n, 1, 0, 0, 10, tab.data()));
+            }
+            tlab_internal_filter_1d(dir, g->interp[k], nx, ny, nz, u, result, g_stream);
+            g_last_path = PATH_GENERIC;
+            return;
+        }
+        if (type != TLAB_OPR_P1 && type != TLAB_OPR_P2 && type != TLAB_OPR_P2_P1)
+            throw Unsupported("OPR_Partial type not built on the device (the IBM variants stay on the CPU path)");
         const long long ntot = (long long)nx * ny * nz;
         const LineGeom geom = make_geom(dir, nx, ny, nz);
         if (geom.n == 1) {  // 2-D guard (opr_partial.f90:175-177, :287-289)

@@ -522,6 +522,35 @@ void der2_matmul1(const DerTables &g, int ibc, const double *u, double *f) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fdm/fdm_interpolate.f90:33-96 FDM_Interpol_Initialize
+// ------------------------------------------------------------------------------------------------
+void interpol_initialize(FdmTables &g, bool replace_mwn) {
+    const int nx = g.n;
+    if (!g.periodic || nx < 8) throw std::runtime_error("staggered grid only along periodic directions (fdm.f90:239-246)");
+    const double *dx = g.jac.data();       // jac(:, 1)
+    g.lu0i.assign((size_t)5 * nx, 0.0);
+    g.lu1i.assign((size_t)5 * nx, 0.0);
+    double *a = g.lu0i.data(), *b = a + nx, *c = b + nx;
+    for (int i = 0; i < nx; ++i) { a[i] = 2.0 / 5.0; b[i] = 4.0 / 3.0; c[i] = 2.0 / 5.0; }      // FDM_C0INT6P_LHS
+    tridpfs(nx, a, b, c, c + nx, c + 2 * nx);
+    a = g.lu1i.data(); b = a + nx; c = b + nx;
+    for (int i = 0; i < nx; ++i) { a[i] = 9.0 / 63.0; b[i] = 62.0 / 63.0; c[i] = 9.0 / 63.0; }  // FDM_C1INT6P_LHS
+    c[nx - 1] = c[nx - 1] * dx[0]; b[0] = b[0] * dx[0]; a[1] = a[1] * dx[0];                     // Jacobian multiplication (:305-317)
+    for (int i = 1; i < nx - 1; ++i) { c[i - 1] = c[i - 1] * dx[i]; b[i] = b[i] * dx[i]; a[i + 1] = a[i + 1] * dx[i]; }
+    c[nx - 2] = c[nx - 2] * dx[nx - 1]; b[nx - 1] = b[nx - 1] * dx[nx - 1]; a[0] = a[0] * dx[nx - 1];
+    tridpfs(nx, a, b, c, c + nx, c + 2 * nx);
+    g.stagger = true;
+    if (replace_mwn) {
+        std::vector<double> wn;
+        wavenumbers(nx, wn);
+        const double c1 = 9.0 / 62.0, c3 = 63.0 / 62.0, c4 = 17.0 / 62.0;
+        g.der1.mwn.resize(nx);
+        for (int i = 0; i < nx; ++i)
+            g.der1.mwn[i] = 2.0 * (c3 * std::sin(1.0 / 2.0 * wn[i]) + c4 / 3.0 * std::sin(3.0 / 2.0 * wn[i])) / (1.0 + 2.0 * c1 * std::cos(wn[i])) / dx[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fdm/fdm.f90:143-252 FDM_CreatePlan
 // ------------------------------------------------------------------------------------------------
 void fdm_create_plan(FdmTables &g, int nx, const double *nodes, bool periodic, bool uniform, int mode1, int mode2,

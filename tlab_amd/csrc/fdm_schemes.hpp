@@ -37,7 +37,14 @@ struct FdmTables {
     std::vector<double> nodes;         // (n)
     std::vector<double> jac;           // (n,3)
     DerTables der1, der2;
+    // horizontal pressure staggering (TLab_WorkFlow::stagger_on; fdm.f90:236-248, fdm_interpolate.f90): g%intl of a periodic direction
+    bool stagger = false;
+    std::vector<double> lu0i, lu1i;    // (n,5) LU of the interpolation / interpolatory first-derivative systems (TRIDPFS)
 };
+
+// FDM_Interpol_Initialize (fdm/fdm_interpolate.f90:33-96): lu0i, lu1i from FDM_C0INT6P_LHS / FDM_C1INT6P_LHS (fdm_com0_jacobian.f90:29-44, 287-320);
+// replace_mwn: der1.mwn becomes the interpolatory modified wavenumber (:74-93), as FDM_CreatePlan does with stagger_on
+void interpol_initialize(FdmTables &g, bool replace_mwn);
 
 // utils/linear3.f90:29-51, :269-316
 void tridfs(int nmax, double *a, double *b, double *c);

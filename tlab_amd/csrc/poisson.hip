@@ -2313,7 +2313,10 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                 }
                 lam[(size_t)i + (size_t)P->nxh * k] = std::sqrt(l2);
             }
-        const int isg[2] = {0, nx / 2}, ksg[2] = {0, nzt > 1 ? nzt / 2 : 0};   // i_sing, k_sing (:148-149), 0-based, global
+        // i_sing, k_sing (:148-149), 0-based, global; with the staggered pressure grid only (1, 1) is singular: the interpolatory modified
+        // wavenumbers do not vanish at the Nyquist modes (:144-146)
+        const bool stag = gx->t.stagger || (nzt > 1 && gz->t.stagger);
+        const int isg[2] = {0, stag ? 0 : nx / 2}, ksg[2] = {0, (nzt > 1 && !stag) ? nzt / 2 : 0};
         for (int a = 0; a < 2 && !helmholtz; ++a)                           // Helmholtz: every mode is a regular one (:512-531)
             for (int b = 0; b < 2; ++b) {
                 const int kl = ksg[b] - koff;                               // task-local index (:177-178)

@@ -45,6 +45,7 @@ struct tlab_dns {
     bool fuse = true;                              // fold the pointwise sums into the operator kernels where the fast kernels apply
     tlab_filter_t pfilter[3] = {nullptr, nullptr, nullptr};      // PressureFilter(1:3) (not owned) and its repeat counts
     int pfilter_rep[3] = {1, 1, 1};
+    bool stagger = false;                          // [Staggering] StaggerHorizontalPressure: taken from the x / z plans at creation (tlab_fdm_plan_set_stagger)
     bool remove_divergence = true;                 // [Main] ... forcing = div(hq + q/dte) (rhs_global_incompressible_1.f90:177-232); false: div(hq) (:234-250)
     bool fresh = false;                            // one-shot: hq, hs count as zero on entry of the next substep (tlab_dns_begin_step)
     int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};   // BcsFlowJmin%type
@@ -102,6 +103,9 @@ int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tla
         d->g[0] = gx; d->g[1] = gy; d->g[2] = gz;
         d->poisson = poisson;
         d->nx = nx; d->ny = ny; d->nz = nz; d->nscal = nscal; d->visc = visc;
+        d->stagger = tlab_fdm_plan_info(gx, 7) == 1 || (nz > 1 && tlab_fdm_plan_info(gz, 7) == 1);
+        if (d->stagger && (tlab_fdm_plan_info(gx, 7) != 1 || (nz > 1 && tlab_fdm_plan_info(gz, 7) != 1)))
+            throw Fail(TLAB_EINVAL, "staggering: both the x and the z plan need their interpolation tables (tlab_fdm_plan_set_stagger)");
         d->schmidt.assign(schmidt, schmidt + nscal);
         d->scal_jmin.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
         d->scal_jmax.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
@@ -186,7 +190,9 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // launch.  The terms of an equation are then added in the order x, y, z instead of the reference's {1,2,3},{2,1,3},{3,1,2}: rounding only.
     // every fused form below assumes the plain operators: anelastic runs and runs with [Dealiasing] take the literal sequence
     const bool anel = d->rb != nullptr;
-    const bool literal = anel || tlab_internal_dealiasing();
+    const bool stag = d->stagger;                 // staggered pressure grid (rhs_global_incompressible_1.f90:216-226, 266-273, 307-317)
+    const bool literal = anel || stag || tlab_internal_dealiasing();
+    double *tmp5 = txc[4];
     const bool batched = !literal && d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
                          tlab_internal_burgers_fusable(3, gz, nx, ny, nz);
     const bool fresh = d->fresh;       // TIME_RUNGEKUTTA zeroes hq, hs at the start of a step (time.f90:212-216): the first launch overwrites instead
@@ -267,13 +273,27 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             hk(launch_weight_y(tmp3, tmp3, d->rb, nx, ny, n, 0, st), "weight");
             hk(launch_weight_y(tmp4, tmp4, d->rb, nx, ny, n, 0, st), "weight");
         }
-        ok(tlab_opr_partial(2, gy, TLAB_OPR_P1, nx, ny, nz, B0, tmp2, tmp1, nullptr), "OPR_Partial_Y");
-        ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp3, tmp2, nullptr), "OPR_Partial_X");
-        ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp4, tmp3, nullptr), "OPR_Partial_Z");
+        if (stag) {      // the three terms on the horizontal pressure nodes (:216-226)
+            ok(tlab_opr_partial(1, gx, TLAB_OPR_P0_INT_VP, nx, ny, nz, B0, tmp2, tmp5, nullptr), "OPR_Partial_X(P0_INT_VP)");      // Oy derivative
+            ok(tlab_opr_partial(2, gy, TLAB_OPR_P1, nx, ny, nz, B0, tmp5, tmp2, nullptr), "OPR_Partial_Y");
+            ok(tlab_opr_partial(3, gz, TLAB_OPR_P0_INT_VP, nx, ny, nz, B0, tmp2, tmp1, nullptr), "OPR_Partial_Z(P0_INT_VP)");
+            ok(tlab_opr_partial(1, gx, TLAB_OPR_P1_INT_VP, nx, ny, nz, B0, tmp3, tmp5, nullptr), "OPR_Partial_X(P1_INT_VP)");      // Ox derivative
+            ok(tlab_opr_partial(3, gz, TLAB_OPR_P0_INT_VP, nx, ny, nz, B0, tmp5, tmp2, nullptr), "OPR_Partial_Z(P0_INT_VP)");
+            ok(tlab_opr_partial(1, gx, TLAB_OPR_P0_INT_VP, nx, ny, nz, B0, tmp4, tmp5, nullptr), "OPR_Partial_X(P0_INT_VP)");      // Oz derivative
+            ok(tlab_opr_partial(3, gz, TLAB_OPR_P1_INT_VP, nx, ny, nz, B0, tmp5, tmp3, nullptr), "OPR_Partial_Z(P1_INT_VP)");
+        } else {
+            ok(tlab_opr_partial(2, gy, TLAB_OPR_P1, nx, ny, nz, B0, tmp2, tmp1, nullptr), "OPR_Partial_Y");
+            ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp3, tmp2, nullptr), "OPR_Partial_X");
+            ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp4, tmp3, nullptr), "OPR_Partial_Z");
+        }
         hk(launch_sum3(tmp1, tmp2, tmp3, n, st), "sum3");
     }
-    // Neumann BCs in d/dy(p) s.t. v = 0 (:263-281)
-    hk(launch_get_wall_planes(hq[1], d->bcs_hb, d->bcs_ht, nx, ny, nz, st), "wall planes");
+    // Neumann BCs in d/dy(p) s.t. v = 0 (:263-281); staggered: the planes of hq2 interpolated onto the pressure nodes (:266-269)
+    if (stag) {
+        ok(tlab_opr_partial(1, gx, TLAB_OPR_P0_INT_VP, nx, ny, nz, B0, hq[1], tmp5, nullptr), "OPR_Partial_X(P0_INT_VP)");
+        ok(tlab_opr_partial(3, gz, TLAB_OPR_P0_INT_VP, nx, ny, nz, B0, tmp5, tmp4, nullptr), "OPR_Partial_Z(P0_INT_VP)");
+    }
+    hk(launch_get_wall_planes(stag ? tmp4 : hq[1], d->bcs_hb, d->bcs_ht, nx, ny, nz, st), "wall planes");
     if (anel) {          // BcsFlowJmin%ref(:,:,2) = p_bcs(:,1,:) * rbackground(1), Jmax likewise (:275-277)
         hk(launch_scale(d->bcs_hb, d->rb_wall[0], (long long)nx * nz, st), "scale");
         hk(launch_scale(d->bcs_ht, d->rb_wall[1], (long long)nx * nz, st), "scale");
@@ -297,7 +317,14 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             grad_final = okx;
         }
     }
-    if (!grad_final) {
+    if (stag) {          // back onto the horizontal velocity nodes (:307-317)
+        ok(tlab_opr_partial(3, gz, TLAB_OPR_P0_INT_PV, nx, ny, nz, B0, tmp3, tmp5, nullptr), "OPR_Partial_Z(P0_INT_PV)");       // dp/dy
+        ok(tlab_opr_partial(1, gx, TLAB_OPR_P0_INT_PV, nx, ny, nz, B0, tmp5, tmp3, nullptr), "OPR_Partial_X(P0_INT_PV)");
+        ok(tlab_opr_partial(3, gz, TLAB_OPR_P1_INT_PV, nx, ny, nz, B0, tmp1, tmp5, nullptr), "OPR_Partial_Z(P1_INT_PV)");       // dp/dz
+        ok(tlab_opr_partial(1, gx, TLAB_OPR_P0_INT_PV, nx, ny, nz, B0, tmp5, tmp4, nullptr), "OPR_Partial_X(P0_INT_PV)");
+        ok(tlab_opr_partial(3, gz, TLAB_OPR_P0_INT_PV, nx, ny, nz, B0, tmp1, tmp5, nullptr), "OPR_Partial_Z(P0_INT_PV)");       // dp/dx
+        ok(tlab_opr_partial(1, gx, TLAB_OPR_P1_INT_PV, nx, ny, nz, B0, tmp5, tmp2, nullptr), "OPR_Partial_X(P1_INT_PV)");
+    } else if (!grad_final) {
         ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
         ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
     }

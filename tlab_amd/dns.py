@@ -58,7 +58,7 @@ class Dns:
     """imax, jmax, kmax, inb_scal, visc, schmidt + the allocated arrays of TLab_Initialize_Memory (tlab_memory.f90:164-216)."""
 
     def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
-                 hyper_bc1_ext=0.0, device="cuda", plans=None, gy_elliptic=None):
+                 hyper_bc1_ext=0.0, device="cuda", plans=None, gy_elliptic=None, stagger=False):
         import torch
         self.nx, self.ny, self.nz = len(x), len(y), len(z)
         self.n = self.nx * self.ny * self.nz
@@ -67,8 +67,9 @@ class Dns:
         self.schmidt = np.ascontiguousarray(schmidt, dtype=np.float64)[: self.nscal]
         # plans: optional (gx, gy, gz) built elsewhere, e.g. FdmPlan.from_tables with a host's CompactDirect6 tables in y
         self.g = list(plans) if plans is not None else [
-            FdmPlan(x, True, True, hyper_bc1_ext=hyper_bc1_ext), FdmPlan(y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext),
-            FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
+            FdmPlan(x, True, True, hyper_bc1_ext=hyper_bc1_ext, stagger=stagger), FdmPlan(y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext),
+            FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext, stagger=stagger)]
+        # stagger: [Staggering] StaggerHorizontalPressure -- the driver reads it off the x plan (tlab_fdm_plan_info 7)
         # gy_elliptic: the y plan of EllipticOrder = CompactDirect6 (fdm_loc, opr_elliptic.f90:107-124) -> OPR_Poisson_FourierXZ_Direct
         self.poisson = PoissonPlan(self.g[0], self.g[1], self.g[2], self.nx, self.ny, self.nz, gy_elliptic=gy_elliptic)
         self.isize_txc_field = self.poisson.isize_txc_field

@@ -39,6 +39,7 @@ module TLAB_AMD_PARTIAL_MODULE
 contains
     ! ###################################################################
     function OPR_Partial_AMD_Plan(idir, g) result(p)
+        use TLab_WorkFlow, only: stagger_on
         integer, intent(in) :: idir
         type(fdm_dt), intent(in), target :: g
         type(c_ptr) :: p, pm1, pm2
@@ -56,6 +57,10 @@ contains
             call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_aux')
             rc = tlab_fdm_plan_set_scheme(plans(idir), int(g%der1%mode_fdm, c_int), int(g%der2%mode_fdm, c_int))     ! CompactDirect6: per-row rhs
             call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_scheme')
+            if (stagger_on .and. g%periodic) then                 ! fdm.f90:236-248; g%der1%mwn above is already the interpolatory one
+                rc = tlab_fdm_plan_set_stagger(plans(idir), 2_c_int)
+                call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_stagger')
+            end if
         end if
         p = plans(idir)
     end function OPR_Partial_AMD_Plan

@@ -12,6 +12,11 @@ module NavierStokes
     integer :: nse_eqns = DNS_EQNS_INCOMPRESSIBLE, nse_advection = EQNS_CONVECTIVE
 end module NavierStokes
 
+module DNS_LOCAL
+    implicit none
+    logical :: remove_divergence = .true.                           ! Remove residual divergence every time step (tools/dns/dns_local.f90:36)
+end module DNS_LOCAL
+
 module DNS_ARRAYS
     use TLab_Constants, only: wp
     implicit none

@@ -165,7 +165,8 @@ end module TIME
 ! ###################################################################
 program test_rk_driver
     use TLab_Constants, only: wp, wi, ifile, gfile, lfile, tag_flow, tag_scal
-    use TLab_WorkFlow, only: TLab_Start, TLab_Stop, TLab_Write_ASCII, fourier_on, flow_on, scal_on
+    use TLab_WorkFlow, only: TLab_Start, TLab_Stop, TLab_Write_ASCII, fourier_on, flow_on, scal_on, stagger_on
+    use DNS_LOCAL, only: remove_divergence
     use TLab_Memory, only: imax, jmax, kmax, isize_field, inb_flow, inb_flow_array, inb_scal, inb_scal_array, inb_txc, inb_wrk1d, inb_wrk2d
     use TLab_Memory, only: TLab_Initialize_Memory, TLab_Allocate_Real
     use TLab_Arrays
@@ -217,6 +218,11 @@ program test_rk_driver
     inb_txc = 9                                                                ! tools/dns/dns_read_local.f90:711
     inb_wrk1d = 20; inb_wrk2d = 6
     io_fileformat = IO_MPIIO; io_datatype = IO_TYPE_DOUBLE
+
+    call ScanFile_Char(bakfile, ifile, 'Staggering', 'StaggerHorizontalPressure', 'no', sRes)     ! tlab_initialize_parameters.f90:114-116
+    stagger_on = (trim(adjustl(sRes)) == 'yes')
+    call ScanFile_Char(bakfile, ifile, 'Main', 'TermDivergence', 'remove', sRes)                  ! dns_read_local.f90:79-81
+    remove_divergence = (trim(adjustl(sRes)) /= 'none')
 
     call TLab_Grid_Read(gfile, x, y, z)                                        ! :75
     call FDM_Initialize(ifile)                                                 ! :76  (the reference's own: tables of g(1:3) stay the host's)

@@ -57,6 +57,11 @@ module TLab_AMD_C
             type(c_ptr), value :: plan
             integer(c_int), value :: mode1, mode2
         end function
+        integer(c_int) function tlab_fdm_plan_set_stagger(plan, mode) bind(C, name='tlab_fdm_plan_set_stagger')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: mode
+        end function
         integer(c_int) function tlab_fdm_plan_destroy(plan) bind(C, name='tlab_fdm_plan_destroy')
             import :: c_int, c_ptr
             type(c_ptr), value :: plan
@@ -148,6 +153,11 @@ module TLab_AMD_C
             import :: c_int, c_ptr
             type(c_ptr), value :: dns
             integer(c_int), intent(in) :: flow_jmin(3), flow_jmax(3), scal_jmin(*), scal_jmax(*)
+        end function
+        integer(c_int) function tlab_dns_set_remove_divergence(dns, on) bind(C, name='tlab_dns_set_remove_divergence')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: dns
+            integer(c_int), value :: on
         end function
         integer(c_int) function tlab_dns_set_surface_bcs(dns, sfc_jmin, sfc_jmax, cpl_jmin, cpl_jmax) bind(C, name='tlab_dns_set_surface_bcs')
             import :: c_int, c_ptr, c_double

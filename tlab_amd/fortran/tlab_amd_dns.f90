@@ -32,6 +32,7 @@ contains
         use BOUNDARY_BCS, only: BcsFlowJmin, BcsFlowJmax, BcsScalJmin, BcsScalJmax
         use OPR_Partial, only: OPR_Partial_AMD_Plan
         use OPR_Elliptic, only: OPR_Elliptic_AMD_Plan
+        use DNS_LOCAL, only: remove_divergence
         type(c_ptr) :: h
         integer(c_int) :: rc, fj0(3), fj1(3), sj0(16), sj1(16)
         real(c_double) :: cp0(16), cp1(16)
@@ -50,6 +51,8 @@ contains
             sj0(1:inb_scal) = BcsScalJmin%type(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%type(1:inb_scal)
             rc = tlab_dns_set_bcs(dns, fj0, fj1, sj0, sj1)
             call TLab_AMD_Check(rc, 'tlab_dns_set_bcs')
+            rc = tlab_dns_set_remove_divergence(dns, merge(1_c_int, 0_c_int, remove_divergence))      ! dns.ini [Main] TermDivergence
+            call TLab_AMD_Check(rc, 'tlab_dns_set_remove_divergence')
             if (inb_scal > 0) then          ! dynamic surface model of the scalars (BcsScalJmin%SfcType, %cpl)
                 sj0 = 0; sj1 = 0; cp0 = 0.0_c_double; cp1 = 0.0_c_double
                 sj0(1:inb_scal) = BcsScalJmin%SfcType(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%SfcType(1:inb_scal)

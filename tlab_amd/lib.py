@@ -32,6 +32,7 @@ SIGNATURES = {
     "tlab_fdm_plan_create_from_arrays": (c_int, [ctypes.POINTER(c_vp), c_int, c_int, c_int, c_int, c_int, _dp, _dp, c_int, c_int, _dp, _dp]),
     "tlab_fdm_plan_set_aux": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tlab_fdm_plan_set_scheme": (c_int, [c_vp, c_int, c_int]),
+    "tlab_fdm_plan_set_stagger": (c_int, [c_vp, c_int]),
     "tlab_fdm_plan_destroy": (c_int, [c_vp]),
     "tlab_fdm_plan_get": (c_int, [c_vp, c_int, _dp, c_int]),
     "tlab_fdm_plan_info": (c_int, [c_vp, c_int]),

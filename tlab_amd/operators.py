@@ -15,6 +15,7 @@ from .lib import load, check, TlabError, c_vp
 
 # operators/opr_partial.f90:19-21, physics/opr_burgers.f90:29-30, base/tlab_constants.f90:63-66, fdm_derivative.f90:51-54
 OPR_P1, OPR_P2, OPR_P2_P1 = 1, 2, 3
+OPR_P1_INT_VP, OPR_P1_INT_PV, OPR_P0_INT_VP, OPR_P0_INT_PV = 5, 6, 7, 8      # interpolatory operators of the staggered pressure grid
 OPR_B_SELF, OPR_B_U_IN = 0, 1
 BCS_DD, BCS_ND, BCS_DN, BCS_NN = 0, 1, 2, 3
 FDM_COM4_JACOBIAN, FDM_COM6_JACOBIAN_PENTA, FDM_COM6_JACOBIAN, FDM_COM6_JACOBIAN_HYPER = 4, 5, 6, 7
@@ -58,10 +59,12 @@ class FdmPlan:
     hyper_bc1_ext: see include/tlab_amd.h (0.1 reproduces the flang-built reference)."""
 
     _KEYS = {"lhs1": (1, 5), "rhs1": (2, 7), "lu1": (3, None), "rhs_b1": (4, None), "rhs_t1": (5, None), "mwn1": (6, 1),
-             "lhs2": (7, 5), "rhs2": (8, 12), "lu2": (9, None), "mwn2": (10, 1), "jac": (11, 3)}
+             "lhs2": (7, 5), "rhs2": (8, 12), "lu2": (9, None), "mwn2": (10, 1), "jac": (11, 3), "lu0i": (12, 5), "lu1i": (13, 5)}
 
     def __init__(self, nodes, periodic, uniform, scheme1=FDM_COM6_JACOBIAN, scheme2=FDM_COM6_JACOBIAN_HYPER,
-                 hyper_bc1_ext=0.1):
+                 hyper_bc1_ext=0.1, stagger=False):
+        """stagger: [Staggering] StaggerHorizontalPressure (a periodic direction gets the interpolation tables and the interpolatory der1%mwn,
+        fdm.f90:236-248); non-periodic directions ignore it, as the reference does."""
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
         self.size = int(nodes.shape[0])
         self.periodic = bool(periodic)
@@ -71,6 +74,12 @@ class FdmPlan:
                                           nodes.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(self.periodic),
                                           int(self.uniform), int(scheme1), int(scheme2), float(hyper_bc1_ext)),
               "tlab_fdm_plan_create")
+        if stagger and self.periodic:
+            self.set_stagger(1)
+
+    def set_stagger(self, mode):
+        """tlab_fdm_plan_set_stagger: 1 tables + interpolatory wavenumbers, 2 tables only (host-built plans), 0 off"""
+        check(load().tlab_fdm_plan_set_stagger(self._h, int(mode)), "tlab_fdm_plan_set_stagger")
 
     @classmethod
     def from_arrays(cls, n, periodic, need_1der, lhs1, rhs1, lhs2, rhs2, ndl1=3):
