@@ -117,6 +117,42 @@ def test_own_z_fft_matches_numpy(T, nz):
     check(L.tlab_poisson_plan_destroy(h), "destroy")
 
 
+@pytest.mark.parametrize("nx", [64, 128, 256, 512, 1024, 2048])
+def test_x_fft_matches_numpy(T, nx):
+    """OPR_Fourier_X_Forward / _Backward through the C ABI against numpy.fft.rfft: the one-pass k_fftx_r2c (fftz.hip; nx/2 = 8^a * {1,2,4} from 128
+    points on) and rocFFT for the other lengths (64 here) and for the inverse; 11 lines (a 2-D box) leave the last workgroup partly empty."""
+    import torch
+    from tlab_amd.lib import load, check
+    ny, nz = 11, 1
+    x, y, z = np.arange(nx) / nx, np.arange(ny) / (ny - 1.0), np.zeros(1)
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, True), T.FdmPlan(z, True, True)]
+    plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+    rng = np.random.default_rng(nx)
+    a = rng.uniform(-1, 1, (nz, ny, nx))
+    da = torch.from_numpy(a.reshape(-1)).cuda()
+    db = torch.full((nz * ny * (nx // 2 + 1) * 2 + 8,), np.nan, dtype=torch.float64, device="cuda")
+    L = load()
+    check(L.tlab_poisson_fft_x(plan._h, 1, da.data_ptr(), db.data_ptr()), "fft_x")
+    out = db.cpu().numpy()
+    assert np.isnan(out[-8:]).all()            # nothing written past the last line
+    fwd = out[:-8].view(np.complex128).reshape(nz, ny, nx // 2 + 1)
+    ref = np.fft.rfft(a, axis=2)
+    assert np.abs(fwd - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(fwd[..., 0].imag).max() == 0.0 and np.abs(fwd[..., -1].imag).max() == 0.0      # the two real modes, like FFTW's r2c
+    dc = torch.empty_like(da)
+    check(L.tlab_poisson_fft_x(plan._h, -1, db.data_ptr(), dc.data_ptr()), "fft_x")
+    assert np.abs(dc.cpu().numpy().reshape(a.shape) - nx * a).max() <= 1e-13 * nx
+    if nx >= 128:      # the library's own inverse (k_fftx_c2r: the kernel that finishes the v equation inside OPR_Poisson), on a spectrum of its own
+        spec = rng.uniform(-1, 1, (nz, ny, nx // 2 + 1)) + 1j * rng.uniform(-1, 1, (nz, ny, nx // 2 + 1))
+        dsp = torch.from_numpy(np.ascontiguousarray(spec).view(np.float64).reshape(-1)).cuda()
+        dd = torch.full((nz * ny * nx + 8,), np.nan, dtype=torch.float64, device="cuda")
+        check(L.tlab_poisson_fft_x(plan._h, -2, dsp.data_ptr(), dd.data_ptr()), "fft_x own inverse")
+        got = dd.cpu().numpy()
+        assert np.isnan(got[-8:]).all()
+        ref = np.fft.irfft(spec, n=nx, axis=2) * nx           # imaginary parts of the two real modes ignored, like FFTW's c2r
+        assert np.abs(got[:-8].reshape(ref.shape) - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("n", [256])
 def test_poisson_full_size_identity(T, n):
     """256^3: div(grad p) = f with the device operators (vpoisson.f90 / SURVEY 4.4 construction), dpdy = d/dy of phi."""

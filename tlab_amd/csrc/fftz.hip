@@ -199,6 +199,225 @@ __global__ void __launch_bounds__(1024) k_fftz(FftzArgs a) {
     }
 }
 
+// ================================================================================================
+// k_fftx_r2c : real-to-complex FFT of contiguous lines (OPR_Fourier_X_Forward: dfftw_plan_many_dft_r2c, opr_fourier.f90:163-166), in ONE pass
+// over the data.  rocFFT does this transform as a half-length complex FFT + a separate even/odd post-processing kernel (0.34 + 0.38 ms at
+// 512^3, two reads and two writes of the field); here the n reals of a line are read as m = n/2 complex numbers z_j = x_2j + i x_2j+1, the
+// m-point Stockham transform runs through LDS exactly like k_fftz (radix-8 passes + one radix-4 / radix-2 pass, m/8 threads per line), and the
+// same threads then form X_k = E_k + w^k O_k, X_(m-k) = conj(E_k - w^k O_k) with E = (Z_k + conj Z_(m-k))/2, O = -i (Z_k - conj Z_(m-k))/2
+// from the LDS copy and write the n/2+1 outputs of the line.  Unnormalised, exp(-i ...), like FFTW.
+// ================================================================================================
+struct FftxArgs {
+    const double *in;
+    double2 *out;
+    const double2 *tw;      // exp(-2 pi i k / n), k < n
+    long long nlines;
+    int n, m;               // real length, m = n/2
+    int npass;
+    int radix[8];
+    int tl, lines;          // threads per line (m/8), lines per workgroup
+};
+
+template <int R>
+__device__ __forceinline__ void fftx_pass(const FftxArgs &a, const double2 *__restrict__ zin, bool ok, cd *lds, int jt, int Ns, bool first) {
+    constexpr int Q = 8 / R;                 // items of this pass per thread
+    const int M = a.m, m = M / R;
+    cd v[Q][R];
+    int j0s[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int j = jt + q * a.tl;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (first) {
+                double2 w = make_double2(0.0, 0.0);
+                if (ok) w = zin[j + r * m];
+                v[q][r] = {w.x, w.y};
+            } else {
+                v[q][r] = lds[j + r * m];
+            }
+        }
+        const int k0 = (j % Ns) * (M / (Ns * R));
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            const double2 w = a.tw[2 * ((k0 * r) % M)];      // exp(-2 pi i (k0 r) / m) from the table of n = 2 m
+            v[q][r] = cmul(v[q][r], cd{w.x, w.y});
+        }
+        if (R == 8) dft8<-1>(reinterpret_cast<cd(&)[8]>(v[q]));
+        else if (R == 4) dft4<-1>(v[q][0], v[q][1 % R], v[q][2 % R], v[q][3 % R]);
+        else dft2<-1>(v[q][0], v[q][1 % R]);
+        j0s[q] = (j / Ns) * Ns * R + (j % Ns);
+    }
+    if (!first) __syncthreads();          // every item of this pass has read its inputs from the buffer
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds[j0s[q] + r * Ns] = v[q][r];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_fftx_r2c(FftxArgs a) {
+    extern __shared__ double2 fx_lds[];
+    const int jt = threadIdx.x % a.tl, ll = threadIdx.x / a.tl;
+    const long long line = (long long)blockIdx.x * a.lines + ll;
+    const bool ok = line < a.nlines;
+    cd *lds = reinterpret_cast<cd *>(fx_lds) + (size_t)ll * a.m;
+    const double2 *zin = reinterpret_cast<const double2 *>(a.in + (ok ? line : 0) * a.n);
+    int Ns = 1;
+    for (int p = 0; p < a.npass; ++p) {
+        const int R = a.radix[p];
+        if (R == 8) fftx_pass<8>(a, zin, ok, lds, jt, Ns, p == 0);
+        else if (R == 4) fftx_pass<4>(a, zin, ok, lds, jt, Ns, p == 0);
+        else fftx_pass<2>(a, zin, ok, lds, jt, Ns, p == 0);
+        Ns *= R;
+    }
+    if (!ok) return;
+    double2 *out = a.out + line * (a.m + 1);
+    const int M = a.m;
+    for (int k = jt; k <= M / 2; k += a.tl) {
+        const cd A = lds[k], Zc = lds[(M - k) % M];
+        const cd B = {Zc.x, -Zc.y};
+        const cd E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
+        const cd D = A - B;
+        const cd O = {0.5 * D.y, -0.5 * D.x};
+        const double2 w = a.tw[k];
+        const cd T = cmul(cd{w.x, w.y}, O);
+        out[k] = make_double2(E.x + T.x, E.y + T.y);
+        if (k != M - k) out[M - k] = make_double2(E.x - T.x, -(E.y - T.y));
+    }
+}
+
+// k_fftx_c2r : the inverse (dfftw_plan_many_dft_c2r, opr_fourier.f90:167-170; unnormalised), same structure backwards: the threads of a line form
+// Z_k = (X_k + conj X_(m-k)) + i (X_k - conj X_(m-k)) conj(w^k) in LDS (the imaginary parts of X_0 and X_m are ignored, like FFTW), run the m-point
+// transform with exp(+i ...), and x_2j + i x_2j+1 = z_j goes out as the line of n reals.
+// FINAL: the line is not written; it is the pressure-gradient component g of k_final_update (pointwise.hip), whose arithmetic follows in the same
+// registers -- h = h - g, zero on the wall rows, q += dte h, h *= kco -- so that dp/dy is never stored (rhs.cpp: the v equation after OPR_Poisson).
+struct FftxFinal {
+    double *q, *h;
+    double dte, kco;
+    int scale, ny;
+};
+
+template <int R>
+__device__ __forceinline__ void fftx_pass_inv(const FftxArgs &a, cd *lds, int jt, int Ns) {
+    constexpr int Q = 8 / R;
+    const int M = a.m, m = M / R;
+    cd v[Q][R];
+    int j0s[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int j = jt + q * a.tl;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[q][r] = lds[j + r * m];
+        const int k0 = (j % Ns) * (M / (Ns * R));
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            const double2 w = a.tw[2 * ((k0 * r) % M)];
+            v[q][r] = cmul(v[q][r], cd{w.x, -w.y});
+        }
+        if (R == 8) dft8<+1>(reinterpret_cast<cd(&)[8]>(v[q]));
+        else if (R == 4) dft4<+1>(v[q][0], v[q][1 % R], v[q][2 % R], v[q][3 % R]);
+        else dft2<+1>(v[q][0], v[q][1 % R]);
+        j0s[q] = (j / Ns) * Ns * R + (j % Ns);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds[j0s[q] + r * Ns] = v[q][r];
+    __syncthreads();
+}
+
+template <bool FINAL>
+__global__ void __launch_bounds__(256) k_fftx_c2r(FftxArgs a, FftxFinal fin) {
+    extern __shared__ double2 fx_lds[];
+    const int jt = threadIdx.x % a.tl, ll = threadIdx.x / a.tl;
+    const long long line = (long long)blockIdx.x * a.lines + ll;
+    const bool ok = line < a.nlines;
+    cd *lds = reinterpret_cast<cd *>(fx_lds) + (size_t)ll * a.m;
+    const int M = a.m;
+    if (ok) {
+        const double2 *X = reinterpret_cast<const double2 *>(a.in) + line * (M + 1);
+        for (int k = jt; k <= M / 2; k += a.tl) {
+            double2 xa = X[k], xb = X[M - k];
+            if (k == 0) { xa.y = 0.0; xb.y = 0.0; }
+            const cd E = {xa.x + xb.x, xa.y - xb.y};                 // X_k + conj X_(m-k)
+            const cd D = {xa.x - xb.x, xa.y + xb.y};                 // X_k - conj X_(m-k)
+            const double2 w = a.tw[k];
+            const cd O = cmul(D, cd{w.x, -w.y});
+            if (k < M) lds[k % M] = {E.x - O.y, E.y + O.x};          // E + i O
+            if (k != 0 && k != M - k) lds[M - k] = {E.x + O.y, -E.y + O.x};      // conj(E) + i conj(O)
+        }
+    }
+    __syncthreads();
+    int Ns = 1;
+    for (int p = 0; p < a.npass; ++p) {
+        const int R = a.radix[p];
+        if (R == 8) fftx_pass_inv<8>(a, lds, jt, Ns);
+        else if (R == 4) fftx_pass_inv<4>(a, lds, jt, Ns);
+        else fftx_pass_inv<2>(a, lds, jt, Ns);
+        Ns *= R;
+    }
+    if (!ok) return;
+    if (!FINAL) {
+        double2 *out = a.out + line * M;
+        for (int j = jt; j < M; j += a.tl) out[j] = make_double2(lds[j].x, lds[j].y);
+    } else {
+        const int jy = (int)(line % fin.ny);
+        const bool wall = jy == 0 || jy == fin.ny - 1;
+        double2 *q2 = reinterpret_cast<double2 *>(fin.q) + line * M, *h2 = reinterpret_cast<double2 *>(fin.h) + line * M;
+        for (int j = jt; j < M; j += a.tl) {
+            const double2 hv0 = h2[j], qv = q2[j];
+            double hx = hv0.x - lds[j].x, hy = hv0.y - lds[j].y;
+            if (wall) { hx = 0.0; hy = 0.0; }
+            q2[j] = make_double2(qv.x + fin.dte * hx, qv.y + fin.dte * hy);
+            h2[j] = fin.scale ? make_double2(fin.kco * hx, fin.kco * hy) : make_double2(hx, hy);
+        }
+    }
+}
+
+bool FftxPlan::supported(int n) {
+    if (n % 2 || n < 128 || n > 2048) return false;
+    int m = n / 2;
+    while (m % 8 == 0) m /= 8;
+    return m == 1 || m == 2 || m == 4;
+}
+
+FftxPlan::FftxPlan(int n_, long long nlines_) : n(n_), nlines(nlines_) {
+    if (!supported(n)) throw std::runtime_error("FftxPlan: unsupported length");
+    int m = n / 2;
+    while (m % 8 == 0) { radix.push_back(8); m /= 8; }
+    if (m > 1) radix.push_back(m);
+    std::vector<double> tw((size_t)2 * n);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < n; ++k) {
+        tw[2 * k] = (double)cosl(two_pi * k / n);
+        tw[2 * k + 1] = (double)(-sinl(two_pi * k / n));
+    }
+    if (hipMalloc((void **)&d_tw, tw.size() * sizeof(double)) != hipSuccess) throw std::runtime_error("FftxPlan: hipMalloc");
+    if (hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("FftxPlan: hipMemcpy");
+}
+
+FftxPlan::~FftxPlan() {
+    if (d_tw) (void)hipFree(d_tw);
+}
+
+void FftxPlan::exec(const double *in, double *out, hipStream_t st) const {
+    FftxArgs a{};
+    a.in = in;
+    a.out = reinterpret_cast<double2 *>(out);
+    a.tw = reinterpret_cast<const double2 *>(d_tw);
+    a.nlines = nlines; a.n = n; a.m = n / 2; a.npass = (int)radix.size();
+    for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
+    a.tl = a.m / 8;
+    a.lines = a.tl >= 256 ? 1 : 256 / a.tl;
+    const unsigned grid = (unsigned)((nlines + a.lines - 1) / a.lines);
+    const size_t lds = (size_t)a.lines * a.m * sizeof(double2);
+    ProfScope ps("k_fftx_r2c", st, (double)nlines * (n * 8.0 + (a.m + 1) * 16.0));
+    hipLaunchKernelGGL(k_fftx_r2c, dim3(grid), dim3((unsigned)(a.tl * a.lines)), lds, st, a);
+    if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftx_r2c launch failed");
+}
+
 bool FftzPlan::supported(int n) {
     if (n < 16 || n > 2048) return false;
     int m = n;
@@ -252,6 +471,29 @@ void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) cons
     if (n <= 1024) fftz_launch<8>(dir, a, st);       // 8 neighbouring lines per workgroup (128-B rows), n * 8 * 16 B of LDS
     else fftz_launch<4>(dir, a, st);                 // n = 2048: 4 lines (64-B rows) to stay within 1024 threads / 128 KB
     if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftz launch failed");
+}
+
+void FftxPlan::launch_inverse(const double *in, double *out, const double *q, const double *h, double dte, double kco, int scale, int ny,
+                              hipStream_t st) const {
+    FftxArgs a{};
+    a.in = in;
+    a.out = reinterpret_cast<double2 *>(out);
+    a.tw = reinterpret_cast<const double2 *>(d_tw);
+    a.nlines = nlines; a.n = n; a.m = n / 2; a.npass = (int)radix.size();
+    for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
+    a.tl = a.m / 8;
+    a.lines = a.tl >= 256 ? 1 : 256 / a.tl;
+    const unsigned grid = (unsigned)((nlines + a.lines - 1) / a.lines);
+    const size_t lds = (size_t)a.lines * a.m * sizeof(double2);
+    FftxFinal f{const_cast<double *>(q), const_cast<double *>(h), dte, kco, scale, ny};
+    if (q) {
+        ProfScope ps("k_fftx_c2r<final>", st, (double)nlines * ((a.m + 1) * 16.0 + n * 32.0));
+        hipLaunchKernelGGL(k_fftx_c2r<true>, dim3(grid), dim3((unsigned)(a.tl * a.lines)), lds, st, a, f);
+    } else {
+        ProfScope ps("k_fftx_c2r", st, (double)nlines * ((a.m + 1) * 16.0 + n * 8.0));
+        hipLaunchKernelGGL(k_fftx_c2r<false>, dim3(grid), dim3((unsigned)(a.tl * a.lines)), lds, st, a, f);
+    }
+    if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftx_c2r launch failed");
 }
 
 }  // namespace tlab

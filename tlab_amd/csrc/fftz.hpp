@@ -22,4 +22,29 @@ private:
     double *d_tw = nullptr;
 };
 
+// real -> complex FFT of contiguous lines in one pass (fftz.hip: k_fftx_r2c); out-of-place, line l: n reals at in + l n -> n/2+1 complex at out + l (n/2+1)
+class FftxPlan {
+public:
+    static bool supported(int n);                       // n/2 = 8^a * {1, 2, 4}, 128 <= n <= 2048
+    FftxPlan(int n, long long nlines);
+    ~FftxPlan();
+    FftxPlan(const FftxPlan &) = delete;
+    FftxPlan &operator=(const FftxPlan &) = delete;
+    void exec(const double *in, double *out, hipStream_t st) const;
+    // the inverse (n/2+1 complex -> n reals per line, unnormalised)
+    void exec_inverse(const double *in, double *out, hipStream_t st) const { launch_inverse(in, out, nullptr, nullptr, 0.0, 0.0, 0, 0, st); }
+    // the inverse as the pressure-gradient operand g of the final update of one velocity component (pointwise.hip: k_final_update with zero wall
+    // planes): h = h - g, h = 0 on the rows j = 0, ny-1 of every x-y plane, q += dte h, h *= kco (if scale); g itself is not stored
+    void exec_inverse_final(const double *in, double *q, double *h, double dte, double kco, int scale, int ny, hipStream_t st) const {
+        launch_inverse(in, nullptr, q, h, dte, kco, scale, ny, st);
+    }
+
+private:
+    void launch_inverse(const double *in, double *out, const double *q, const double *h, double dte, double kco, int scale, int ny, hipStream_t st) const;
+    int n;
+    long long nlines;
+    std::vector<int> radix;
+    double *d_tw = nullptr;
+};
+
 }  // namespace tlab

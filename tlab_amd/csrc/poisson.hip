@@ -1827,6 +1827,22 @@ struct tlab_poisson_plan {
     FftPlan fx_r2c, fx_c2r, fz_f, fz_b;
     FftPlan f2_fwd, f2_bwd;           // optional fused 2-D (x,z) transforms, batch over y
     std::unique_ptr<FftzPlan> fz_own;  // own strided z-transform (fftz.hip) where its lengths apply; rocFFT's fz_f / fz_b otherwise
+    std::unique_ptr<FftxPlan> fx_own;  // own one-pass real-to-complex x-transform (fftz.hip: k_fftx_r2c); rocFFT's two-kernel fx_r2c otherwise
+    // one-shot request of the RHS driver (tlab_internal_poisson_arm_v_final): the inverse x-transform of dp^/dy finishes the v equation
+    // (FftxPlan::exec_inverse_final) instead of writing dp/dy
+    struct VFinal { double *q = nullptr, *h = nullptr; double dte = 0.0, kco = 0.0; int scale = 0; bool armed = false; } vfinal;
+    void x_backward_dpdy(void *in, double *dpdy, hipStream_t st) {
+        if (vfinal.armed && fx_own) {
+            fx_own->exec_inverse_final(static_cast<const double *>(in), vfinal.q, vfinal.h, vfinal.dte, vfinal.kco, vfinal.scale, ny, st);
+            vfinal.armed = false;
+        } else {
+            fx_c2r.exec(in, dpdy, st);
+        }
+    }
+    void x_forward(void *in, void *out, hipStream_t st) {
+        if (fx_own) fx_own->exec(static_cast<const double *>(in), static_cast<double *>(out), st);
+        else fx_r2c.exec(in, out, st);
+    }
     bool use_2d = false;
     bool fz_inplace = false;          // z-transform plans built in place (kx-pencil plans: rocFFT then picks its column kernel, ~3x faster)
     hipStream_t side = nullptr;       // the <= 4 singular modes are solved beside the regular ones
@@ -2078,6 +2094,8 @@ void build_fft(tlab_poisson_plan &P) {
                                 1, len, ny * nz, d), "plan r2c");
         rocfft_plan_description_destroy(d);
         P.fx_r2c.finish();
+        const char *e = getenv("TLAB_FFTX");              // TLAB_FFTX=0 keeps rocFFT for the forward x-transform
+        if (!(e && atoi(e) == 0) && FftxPlan::supported((int)nx) && nxh == nx / 2 + 1) P.fx_own = std::make_unique<FftxPlan>((int)nx, (long long)(ny * nz));
     }
     {   // x: complex -> real (dfftw_plan_many_dft_c2r, :167-170)
         rocfft_plan_description d = nullptr;
@@ -2688,11 +2706,11 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
         hipStream_t st = tlab_current_stream();
         hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, p, bcs_hb, bcs_ht, nx, ny, nz);
         if (nz > 1) {
-            P->fx_r2c.exec(p, tmp2, st);
+            P->x_forward(p, tmp2, st);
             if (P->fz_own) P->fz_own->exec(1, tmp2, tmp1, st);
             else P->fz_f.exec(tmp2, tmp1, st);
         } else {
-            P->fx_r2c.exec(p, tmp1, st);
+            P->x_forward(p, tmp1, st);
         }
         poisson_direct_stage(P, ibc, tmp1, tmp1, st);
         if (nz > 1) {
@@ -2715,11 +2733,11 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
     if (P->use_2d) {
         P->f2_fwd.exec(p, tmp1, st);
     } else if (nz > 1) {
-        P->fx_r2c.exec(p, tmp2, st);
+        P->x_forward(p, tmp2, st);
         if (P->fz_own) P->fz_own->exec(1, tmp2, tmp1, st);
         else P->fz_f.exec(tmp2, tmp1, st);
     } else {
-        P->fx_r2c.exec(p, tmp1, st);
+        P->x_forward(p, tmp1, st);
     }
     if (ibc == TLAB_BCS_DD) poisson_dd_stage(P, tmp1, tmp1, tmp2, st);
     else poisson_ode_stage(P, tmp1, tmp1, tmp2, st);      // p^ -> tmp1 (over f^), dp^/dy -> tmp2
@@ -2734,12 +2752,13 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
         if (dpdy) {
             if (P->fz_own) P->fz_own->exec(-1, tmp2, P->cwork.p, st);
             else P->fz_b.exec(tmp2, P->cwork.p, st);
-            P->fx_c2r.exec(P->cwork.p, dpdy, st);
+            P->x_backward_dpdy(P->cwork.p, dpdy, st);
         }
     } else {
         P->fx_c2r.exec(tmp1, p, st);
-        if (dpdy) P->fx_c2r.exec(tmp2, dpdy, st);
+        if (dpdy) P->x_backward_dpdy(tmp2, dpdy, st);
     }
+    P->vfinal.armed = false;
     POISSON_GUARD_END
 }
 
@@ -2752,11 +2771,15 @@ int tlab_poisson_set_wall_planes(tlab_poisson_plan_t P, double *p, const double 
     POISSON_GUARD_END
 }
 // dir = +1: real (nx,ny,kmax) -> complex (nx/2+1,ny,kmax)  [OPR_Fourier_X_Forward]; dir = -1: the inverse [OPR_Fourier_X_Backward]
+// dir = -2: the inverse by the library's own kernel (k_fftx_c2r; the solver itself uses rocFFT's, which already runs at the copy rate) -- tests
 int tlab_poisson_fft_x(tlab_poisson_plan_t P, int dir, double *in, double *out) {
     POISSON_GUARD_BEGIN
     if (!P || !in || !out || in == out) throw std::invalid_argument("tlab_poisson_fft_x: bad arguments");
-    if (dir > 0) P->fx_r2c.exec(in, out, tlab_current_stream());
-    else P->fx_c2r.exec(in, out, tlab_current_stream());
+    if (dir > 0) P->x_forward(in, out, tlab_current_stream());
+    else if (dir == -2) {
+        if (!P->fx_own) throw std::invalid_argument("tlab_poisson_fft_x: no own transform for this length");
+        P->fx_own->exec_inverse(in, out, tlab_current_stream());
+    } else P->fx_c2r.exec(in, out, tlab_current_stream());
     POISSON_GUARD_END
 }
 // complex (nlines, nz_total) lines-fastest (the K-transposed layout; nlines = (nx/2+1)*ny/nproc_k), out of place
@@ -2822,11 +2845,11 @@ int tlab_opr_helmholtz(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, d
     if (P->use_2d) {
         P->f2_fwd.exec(a, tmp1, st);
     } else if (nz > 1) {
-        P->fx_r2c.exec(a, tmp2, st);
+        P->x_forward(a, tmp2, st);
         if (P->fz_own) P->fz_own->exec(1, tmp2, tmp1, st);
         else P->fz_f.exec(tmp2, tmp1, st);
     } else {
-        P->fx_r2c.exec(a, tmp1, st);
+        P->x_forward(a, tmp1, st);
     }
     if (P->direct) poisson_direct_stage(P, ibc, tmp1, tmp1, st, true, alpha);
     else if (ibc == TLAB_BCS_DD) poisson_dd_stage(H, tmp1, tmp1, tmp2, st);      // u over f^; v = u' + sqrt(lambda - alpha) u (not returned) in tmp2
@@ -2854,3 +2877,14 @@ int tlab_poisson_direct_ode(tlab_poisson_plan_t P, int ibc, double *f_hat, doubl
 }
 
 }  // extern "C"
+
+// ---- hooks of the RHS driver (rhs.cpp) ----
+// The v equation needs dp/dy only as the operand of its final update: when the plan has the own x-transform and takes the 1-D transform route, the
+// driver arms the NEXT tlab_opr_poisson call with (q, h, dte, kco, scale) and that call's last inverse transform finishes v instead of storing dp/dy.
+bool tlab_internal_poisson_can_v_final(tlab_poisson_plan_t P) {
+    static const bool on = [] { const char *e = getenv("TLAB_V_FINAL"); return !(e && atoi(e) == 0); }();
+    return on && P && P->fx_own && !P->use_2d && !P->direct && !P->helmholtz && P->nproc == 1;
+}
+void tlab_internal_poisson_arm_v_final(tlab_poisson_plan_t P, double *q, double *h, double dte, double kco, int scale) {
+    P->vfinal.q = q; P->vfinal.h = h; P->vfinal.dte = dte; P->vfinal.kco = kco; P->vfinal.scale = scale; P->vfinal.armed = true;
+}

@@ -30,6 +30,8 @@ bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, in
                                   double kco, int scale);
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 extern "C" bool tlab_internal_dealiasing();      // capi.cpp (defined inside its extern "C" block)
+bool tlab_internal_poisson_can_v_final(tlab_poisson_plan_t P);                                                      // poisson.hip
+void tlab_internal_poisson_arm_v_final(tlab_poisson_plan_t P, double *q, double *h, double dte, double kco, int scale);
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale,
@@ -298,7 +300,16 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         hk(launch_scale(d->bcs_hb, d->rb_wall[0], (long long)nx * nz, st), "scale");
         hk(launch_scale(d->bcs_ht, d->rb_wall[1], (long long)nx * nz, st), "scale");
     }
-    // pressure in tmp1, Oy derivative in tmp3 (:284)
+    // pressure in tmp1, Oy derivative in tmp3 (:284).  With Dirichlet walls for v and the RK update folded in, the last inverse transform of the
+    // solver finishes the v equation itself (hq2 -= dp/dy; wall planes; v += dte hq2; hq2 *= kco) and tmp3 is not written
+    bool v_final = false;
+    bool walls_dirichlet = true;      // (a Neumann wall of any component sends all three through the unfused subtraction below)
+    for (int iq = 0; iq < 3; ++iq) walls_dirichlet = walls_dirichlet && d->flow_jmin[iq] == TLAB_DNS_BCS_DIRICHLET && d->flow_jmax[iq] == TLAB_DNS_BCS_DIRICHLET;
+    if (tail_update && d->fuse && !literal && !d->pfilter[0] && !d->pfilter[1] && !d->pfilter[2] && walls_dirichlet &&
+        tlab_internal_poisson_can_v_final(d->poisson)) {
+        tlab_internal_poisson_arm_v_final(d->poisson, q[1], hq[1], dte, kco, scale_tendencies);
+        v_final = true;
+    }
     ok(tlab_opr_poisson(d->poisson, nx, ny, nz, TLAB_BCS_NN, tmp1, tmp2, tmp4, d->bcs_hb, d->bcs_ht, tmp3), "OPR_Poisson");
     if (d->pfilter[0] || d->pfilter[1] || d->pfilter[2]) {      // filter pressure p and its vertical gradient dpdy (:286-290)
         ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp1, tmp4), "OPR_FILTER(p)");
@@ -372,6 +383,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         }
         for (int iq = 0; iq < 3; ++iq) {
             if (grad_final && iq != 1) continue;          // u and w are finished already
+            if (v_final && iq == 1) continue;             // v too (inside OPR_Poisson)
             planes(ibc_q[iq], hq[iq], pb, pt);
             hk(launch_final_update(q[iq], hq[iq], gp[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
