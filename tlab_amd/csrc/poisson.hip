@@ -1831,13 +1831,9 @@ struct tlab_poisson_plan {
     // one-shot request of the RHS driver (tlab_internal_poisson_arm_v_final): the inverse x-transform of dp^/dy finishes the v equation
     // (FftxPlan::exec_inverse_final) instead of writing dp/dy
     struct VFinal { double *q = nullptr, *h = nullptr; double dte = 0.0, kco = 0.0; int scale = 0; bool armed = false; } vfinal;
-    void x_backward_dpdy(void *in, double *dpdy, hipStream_t st) {
-        if (vfinal.armed && fx_own) {
-            fx_own->exec_inverse_final(static_cast<const double *>(in), vfinal.q, vfinal.h, vfinal.dte, vfinal.kco, vfinal.scale, ny, st);
-            vfinal.armed = false;
-        } else {
-            fx_c2r.exec(in, dpdy, st);
-        }
+    void x_backward_dpdy(void *in, double *dpdy, hipStream_t st, const VFinal &f) {
+        if (f.armed && fx_own) fx_own->exec_inverse_final(static_cast<const double *>(in), f.q, f.h, f.dte, f.kco, f.scale, ny, st);
+        else fx_c2r.exec(in, dpdy, st);
     }
     void x_forward(void *in, void *out, hipStream_t st) {
         if (fx_own) fx_own->exec(static_cast<const double *>(in), static_cast<double *>(out), st);
@@ -2248,6 +2244,8 @@ void build_low_modes(tlab_poisson_plan &P, const std::vector<double> &nodes, con
 extern hipStream_t tlab_current_stream();
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
+
+bool tlab_internal_poisson_can_v_final(tlab_poisson_plan_t P);
 
 extern "C" {
 
@@ -2693,6 +2691,9 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
                      const double *bcs_hb, const double *bcs_ht, double *dpdy) {
     POISSON_GUARD_BEGIN
     if (!P || !p || !tmp1 || !tmp2 || !bcs_hb || !bcs_ht) throw std::invalid_argument("tlab_opr_poisson: null argument");
+    const tlab_poisson_plan::VFinal vf = P->vfinal;      // the request holds for THIS call only, whatever its outcome
+    P->vfinal.armed = false;
+    if (vf.armed && (!dpdy || !tlab_internal_poisson_can_v_final(P))) throw std::invalid_argument("tlab_opr_poisson: internal: the fused v update was requested from a plan that cannot do it");
     if (nx != P->nx || ny != P->ny || nz != P->nz) throw std::invalid_argument("tlab_opr_poisson: sizes do not match the plan");
     if (P->nproc != 1 || P->nxh != P->fx_nxh || P->fx_nz != P->nz)
         throw std::invalid_argument("tlab_opr_poisson: plan is a z-slab / kx-pencil plan; drive its stages with the transposes in between");
@@ -2752,13 +2753,12 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
         if (dpdy) {
             if (P->fz_own) P->fz_own->exec(-1, tmp2, P->cwork.p, st);
             else P->fz_b.exec(tmp2, P->cwork.p, st);
-            P->x_backward_dpdy(P->cwork.p, dpdy, st);
+            P->x_backward_dpdy(P->cwork.p, dpdy, st, vf);
         }
     } else {
         P->fx_c2r.exec(tmp1, p, st);
-        if (dpdy) P->x_backward_dpdy(tmp2, dpdy, st);
+        if (dpdy) P->x_backward_dpdy(tmp2, dpdy, st, vf);
     }
-    P->vfinal.armed = false;
     POISSON_GUARD_END
 }
 
