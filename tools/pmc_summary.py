@@ -29,6 +29,8 @@ def tag(name):
     m = re.match(r"k_int1<(\d+), (\d+), (\d+)", name)
     if m:
         return "k_int1<%s>" % {"0": "field", "1": "linear", "2": "unit"}[m.group(3)]
+    if name.startswith("k_fftx_c2r<true>"):
+        return "k_fftx_c2r<final>"
     m = re.match(r"(k_[a-z0-9_]+)", name)
     return m.group(1) if m else name[:60]
 
