@@ -587,6 +587,7 @@ struct OpExtra {
     int ffin[4] = {0, 0, 0, 0};
     double *fdiv = nullptr;
     double fidte = 0.0;
+    unsigned fresh_mask = 0;        // k_htile MODE_BURGERS: fields that overwrite their tendency in an accumulating launch
 };
 const OpExtra kNoExtra{};
 
@@ -669,7 +670,7 @@ void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, co
 void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *in1,
                const double *in2, double *out, double nu, const OpExtra &ex = kNoExtra) {
     const int P = geom.n / rtile_chunk(geom.n);
-    RTileArgs a;
+    RTileArgs a{};
     a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.out1 = nullptr; a.g = geom; a.nu = nu;
     a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
     a.nf = 0;
@@ -689,7 +690,7 @@ bool htile_ok(int n, int mode) { return g_htile_policy != 1 && htile_chunk(n, mo
 void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *vel, double *out0,
                double *out1, double nu, const OpExtra &ex = kNoExtra) {
     const int C = geom.n / htile_chunk(geom.n, mode);
-    RTileArgs a;
+    RTileArgs a{};
     a.in0 = in0; a.in1 = nullptr; a.in2 = vel; a.out0 = out0; a.out1 = out1; a.g = geom; a.nu = nu;
     a.in0b = nullptr; a.in0b_scale = 0.0; a.acc = ex.acc ? 1 : 0;
     a.fq = nullptr; a.fdte = 0.0; a.fkco = 1.0; a.fscale = 0; a.fnx = 1; a.fny = 1;
@@ -700,6 +701,7 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.y1 = g->system(1, ibc, C).dev();
     a.y2 = g->system(2, 0, C).dev();
     a.jc = (mode != MODE_P1) ? g->jaccorr() : JacCorrDev{nullptr};
+    a.fresh_mask = ex.fresh_mask; a.fdiv = ex.fdiv; a.fidte = ex.fidte;
     hip_check(launch_htile(mode, a, g_stream), "k_htile");
 }
 
@@ -816,15 +818,25 @@ bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny
 
 // finish (may be NULL): per field, != 0 -> this launch is the last term of that field's tendency and also does its Runge-Kutta update
 // (s += dte h, h = scale ? kco h : h, h = 0 on the wall planes); only where tlab_internal_burgers_can_finish says so
+// the y / z tile kernel can add its direction's term of the pressure forcing in the epilogue of a one-field launch (RTileArgs::fdiv)
+bool tlab_internal_burgers_can_div(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz) {
+    if (!g || dir < 2 || dir > 3) return false;
+    static const bool on = [] { const char *e = getenv("TLAB_DIV_IN_BURGERS"); return !(e && atoi(e) == 0); }();
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (!on || geom.n == 1 || choose_path(dir, geom.n, g) != PATH_RTILE || !htile_ok(geom.n, MODE_BURGERS)) return false;
+    return htile_chunk(geom.n, MODE_BURGERS) == 32 && geom.n / 32 <= 16 && !g->t.der1.direct && !htile_narrow();
+}
+
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco,
-                                 int scale, double *divx, double idte) {
+                                 int scale, double *divx, double idte, unsigned fresh_mask) {
     check_common(dir, g, nx, ny, nz, ibc);
     if (nf < 1 || nf > 4) throw Invalid("1 to 4 fields per call");
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
     OpExtra ex;
     ex.acc = !overwrite;        // overwrite: the tendency is known to be zero (start of a Runge-Kutta step): neither zero-filled nor read
+    ex.fresh_mask = fresh_mask; // ... or only that of some fields
     ex.nf = nf;
     for (int f = 0; f < nf; ++f) { ex.fs[f] = s[f]; ex.fo[f] = result[f]; ex.fnu[f] = nu[f]; }
     if (finish) {
@@ -832,15 +844,19 @@ bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int
         for (int f = 0; f < nf; ++f) ex.ffin[f] = finish[f];
         ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fny = ny;
     }
-    if (divx) {      // divx: the launch also writes d/dx (h + idte vel) of the field that is the velocity itself (x term of the pressure forcing)
-        if (!tlab_internal_burgers_can_finish(dir, g, nx, ny, nz)) throw Invalid("internal: this Burgers launch cannot write the forcing term");
+    if (divx) {      // divx: the launch also writes (x) / adds (y, z) d/dx (h + idte vel) of the field that is the velocity itself (a term of the pressure forcing)
+        if (!(dir == 1 ? tlab_internal_burgers_can_finish(dir, g, nx, ny, nz) : tlab_internal_burgers_can_div(dir, g, nx, ny, nz)))
+            throw Invalid("internal: this Burgers launch cannot write the forcing term");
         ex.fdiv = divx; ex.fidte = idte;
     }
     const bool corr = g->t.der2.need_1der || g->t.der2.direct;
     const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE && !corr) {
+        if (fresh_mask) throw Invalid("internal: per-field overwrite is a feature of the y / z tile kernel");
         run_xline(g, geom, MODE_BURGERS, ibc, s[0], vel, result[0], nullptr, nu[0], ex);
     } else if (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS)) {
+        if (divx && (nf != 1 || s[0] != vel || !tlab_internal_burgers_can_div(dir, g, nx, ny, nz)))
+            throw Invalid("internal: the forcing term rides on a one-field launch of the velocity component of that direction");
         run_htile(g, geom, MODE_BURGERS, ibc, s[0], vel, result[0], nullptr, nu[0], ex);
     } else {
         return false;
@@ -886,7 +902,7 @@ int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, i
         if (nf < 1 || nf > 4 || !nu || !s || !vel || !result) throw Invalid("tlab_opr_burgers_add_n: bad arguments (1 to 4 fields)");
         for (int f = 0; f < nf; ++f)
             if (!s[f] || !result[f] || result[f] == s[f] || result[f] == vel) throw Invalid("tlab_opr_burgers_add_n: null or aliased arrays");
-        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result, overwrite != 0, nullptr, 0.0, 1.0, 0, nullptr, 0.0)) return;
+        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result, overwrite != 0, nullptr, 0.0, 1.0, 0, nullptr, 0.0, 0u)) return;
         for (int f = 0; f < nf; ++f) {
             if (overwrite) hip_check(hipMemsetAsync(result[f], 0, (size_t)nx * ny * nz * sizeof(double), g_stream), "memset");
             const int rc = tlab_opr_burgers_add(dir, g, nx, ny, nz, ibc, nu[f], s[f], vel, result[f], tmp1, tmp2);

@@ -66,11 +66,14 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
 
 // L = lines per tile: 32 (a wave holds two chunks) or 16 (four chunks; half the tile, so that TWO workgroups fit a CU and one can
 // load or store while the other solves)
-template <int M, int MODE, int MAXT, int L>
+// DIV (MODE_BURGERS, one field = the advecting velocity, at most 16 chunks): RTileArgs::fdiv, the forcing term of this direction from the finished
+// tendency while the lines are still in registers.
+template <int M, int MODE, int MAXT, int L, bool DIV = false>
 __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_htile(RTileArgs a) {
     __shared__ double s_yl[32 * L];
     __shared__ double s_r[32 * L];
     __shared__ double s_e[2 * 32 * L];   // first-derivative edge values of every chunk (Jacobian correction)
+    __shared__ double s_h[DIV ? 6 * 16 * L : 1];      // DIV: first and last three rows of every chunk's forcing operand
     extern __shared__ double s_tab[];     // coefficient rows of both systems, separator inverses, Jacobian-correction diagonals
     constexpr bool NEED1 = (MODE == MODE_P1 || MODE == MODE_P2_P1 || MODE == MODE_BURGERS);
     constexpr bool NEED2 = (MODE != MODE_P1);
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
         for (int p = 0; p < M; ++p) x2[p] = nu * x2[p] - vl[p] * x1[p];
         // the old tendency is read once and the new one is not read again before 4 GB of other traffic have passed: non-temporal accesses keep
         // them out of the way of the operand rows in L2 (3 % of the launch, measured A/B in one binary)
-        if (a.acc) {   // accumulate into the tendency: all loads first (the compiler cannot move them across the stores itself)
+        if (a.acc && !((a.fresh_mask >> fi) & 1u)) {   // accumulate into the tendency: all loads first (the compiler cannot move them across the stores itself)
 #pragma unroll
             for (int p = 0; p < M; ++p) x1[p] = __builtin_nontemporal_load(&out0[base + (long long)(row0 + p) * rs]);
 #pragma unroll
@@ -244,10 +247,54 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
         for (int p = 0; p < M; ++p) __builtin_nontemporal_store(x2[p], &out0[base + (long long)(row0 + p) * rs]);
     }
     }   // valid
+    if constexpr (DIV && MODE == MODE_BURGERS) {
+        // x2 = the finished tendency h of the velocity component of this direction, vl = that component: forcing term d/dy (h + fidte v), the same
+        // operand, stencil and system as the separate fused launch (k_rtile MODE_P1 with in0b), added to fdiv
+        double tt[M + 6];
+#pragma unroll
+        for (int p = 0; p < M; ++p) tt[p + 3] = valid ? x2[p] + vl[p] * a.fidte : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s_h[(c * 6 + k) * L + l32] = tt[3 + k];
+            s_h[(c * 6 + 3 + k) * L + l32] = tt[M + k];
+        }
+        __syncthreads();
+        {
+            const int cl = (c + C - 1) % C, cr = (c + 1) % C;
+            const bool okl = per || c > 0, okr = per || c < C - 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                tt[k] = okl ? s_h[(cl * 6 + 3 + k) * L + l32] : 0.0;
+                tt[M + 3 + k] = okr ? s_h[(cr * 6 + k) * L + l32] : 0.0;
+            }
+        }
+        double gg[M];
+#pragma unroll
+        for (int p = 0; p < M; ++p) gg[p] = h_stencil<false>(a.s1, tt[p], tt[p + 1], tt[p + 2], tt[p + 3], tt[p + 4], tt[p + 5], tt[p + 6]);
+        if (!per) {
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gg[r] = h_dense6(a.s1.bb[r], tt[3], tt[4], tt[5], tt[6], tt[7], tt[8]);
+            }
+            if (c == C - 1) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gg[M - 3 + r] = h_dense6(a.s1.bt[r], tt[M - 3], tt[M - 2], tt[M - 1], tt[M], tt[M + 1], tt[M + 2]);
+            }
+        }
+        h_solve<M, L>(gg, t1, gi1, n, row0, c, C, l32, s_yl, s_r);
+        if (valid) {
+            double fo[M];
+#pragma unroll
+            for (int p = 0; p < M; ++p) fo[p] = a.fdiv[base + (long long)(row0 + p) * rs];
+#pragma unroll
+            for (int p = 0; p < M; ++p) a.fdiv[base + (long long)(row0 + p) * rs] = fo[p] + gg[p];
+        }
+    }
 }
 
 static int g_htile_lines = [] { const char *e = getenv("TLAB_HTILE_LINES"); return (e && atoi(e) == 16) ? 16 : 32; }();
 void htile_set_lines(int lines) { g_htile_lines = lines; }
+bool htile_narrow() { return g_htile_lines == 16; }
 
 // chunk length of the half-wave-tile kernel for a line length n and a mode (0 = unsupported)
 int htile_chunk(int n, int mode) {
@@ -271,19 +318,32 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
     const dim3 grid((unsigned)nwg), block(L * C);
     const size_t lds = ((size_t)(a.s2.rowc ? 15 : 13) * a.g.n + (size_t)2 * C * C) * sizeof(double);     // 10n tables + max(3n correction, 5n per-row RHS)
     const double pts = (double)a.g.nlines * a.g.n;
-    const char *name = mode == MODE_P1 ? "k_htile<P1>" : mode == MODE_P2 ? "k_htile<P2>" : mode == MODE_P2_P1 ? "k_htile<P2_P1>" : "k_htile<BURGERS>";
+    const char *name = mode == MODE_P1 ? "k_htile<P1>" : mode == MODE_P2 ? "k_htile<P2>" : mode == MODE_P2_P1 ? "k_htile<P2_P1>" :
+                       a.fdiv ? "k_htile<BURGERS+div>" : "k_htile<BURGERS>";
     const double bpp = (mode == MODE_P1 || mode == MODE_P2) ? 16 : 24;
     double bytes = pts * (bpp + (a.acc ? 8 : 0));
     if (mode == MODE_BURGERS) {   // velocity once (re-reads are L2 hits by construction) + per field: operand unless it is the velocity, result, old result
         bytes = pts * 8;
-        for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in2 ? 0 : 8) + 8 + (a.acc ? 8 : 0));
+        for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in2 ? 0 : 8) + 8 + ((a.acc && !((a.fresh_mask >> f) & 1u)) ? 8 : 0));
+        if (a.fdiv) bytes += pts * 16;      // forcing term: read + write
     }
     ProfScope ps(name, st, bytes);
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT, L>), grid, block, lds, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_htile<M, MODE_P2, MAXT, L>), grid, block, lds, st, a); break;
     case MODE_P2_P1: hipLaunchKernelGGL((k_htile<M, MODE_P2_P1, MAXT, L>), grid, block, lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a); break;
+    case MODE_BURGERS:
+        if (a.fdiv) {
+            if constexpr (M == 32 && MAXT == 512 && L == 32) {
+                if (a.nf != 1 || a.fs[0] != a.in2 || C > 16 || a.s1.rowc != nullptr) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true>), grid, block, lds, st, a);
+            } else {
+                return hipErrorInvalidValue;
+            }
+        } else {
+            hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a);
+        }
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

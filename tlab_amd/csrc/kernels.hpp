@@ -63,6 +63,14 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     double *fq;
     double fdte, fkco;
     int fscale, fnx, fny;
+    // k_htile MODE_BURGERS: bit f of fresh_mask set = field f OVERWRITES its tendency although acc is set (a field whose first term this launch
+    // adds, in a launch that accumulates for the others)
+    unsigned fresh_mask;
+    // k_htile MODE_BURGERS with ONE field that is the advecting velocity itself (v along y, w along z), in the LAST launch that adds to its
+    // tendency h: fdiv != NULL also ADDS this direction's term of the pressure forcing, d/dy (h + fidte v) (rhs_global_incompressible_1.f90:197-230),
+    // to fdiv -- a third solve on the lines the workgroup holds anyway, instead of a separate pass that re-reads h and v
+    double *fdiv;
+    double fidte;
 };
 
 struct GenericArgs {        // k_generic: any n
@@ -96,6 +104,7 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
 hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st);
 int htile_chunk(int n, int mode);
 void htile_set_lines(int lines);   // tuning: 16 = narrow Burgers tiles (two workgroups per CU)
+bool htile_narrow();
 hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st);
 hipError_t launch_generic(bool sym, const GenericArgs &a, hipStream_t st);
 hipError_t launch_burgers_epilogue(double *out, const double *vel, const double *d1, double nu, long long ntot, hipStream_t st);

@@ -35,7 +35,8 @@ void tlab_internal_poisson_arm_v_final(tlab_poisson_plan_t P, double *q, double 
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale,
-                                 double *divx, double idte);
+                                 double *divx, double idte, unsigned fresh_mask = 0);
+bool tlab_internal_burgers_can_div(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 
 struct tlab_dns {
     tlab_fdm_plan_t g[3];
@@ -215,7 +216,42 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (:234-250)
     const bool x_last = !finish_off && batched && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
     const bool div_in_burgers = x_last && d->fuse && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
-    if (batched) {
+    // ... and the y and z terms, d/dy (hq2 + v/dte) and d/dz (hq3 + w/dte): each component gets the term of its OWN direction last, in a launch of
+    // its own whose workgroups hold the finished tendency line by line and differentiate it on the spot (k_htile<BURGERS+div>).  Order of the
+    // launches: z (all but w), y (all but v), x (all: finishes u, the scalars, writes the x term), y (v: adds the y term), z (w: adds the z term).
+    // Against the three four-field launches + two forcing passes this saves the re-read of hq2, v, hq3, w (four passes of the eight).
+    const bool div_all = div_in_burgers && nz > 1 && tlab_internal_burgers_can_div(2, gy, nx, ny, nz) && tlab_internal_burgers_can_div(3, gz, nx, ny, nz);
+    if (batched && div_all) {
+        struct Launch { int dir; std::vector<int> eq; bool last_x; int divf; };      // divf: equation whose forcing term rides on the launch (-1: none)
+        std::vector<int> all_but_w, all_but_v, all;
+        for (int e = 0; e < (int)eqs.size(); ++e) { all.push_back(e); if (e != 2) all_but_w.push_back(e); if (e != 1) all_but_v.push_back(e); }
+        const Launch plan[5] = {{3, all_but_w, false, -1}, {2, all_but_v, false, -1}, {1, all, true, 0}, {2, {1}, false, 1}, {3, {2}, false, 2}};
+        bool touched[16] = {false};
+        for (const Launch &L : plan) {
+            for (size_t e0 = 0; e0 < L.eq.size(); e0 += 4) {
+                const int nf = (int)std::min<size_t>(4, L.eq.size() - e0);
+                const double *sp[4]; double *rp[4]; double nup[4];
+                int fin[4] = {0, 0, 0, 0};
+                unsigned fresh_mask = 0;
+                bool all_fresh = fresh, any_fresh = false;
+                for (int f = 0; f < nf; ++f) {
+                    const int e = L.eq[e0 + f];
+                    sp[f] = eqs[e].fld; rp[f] = eqs[e].dst; nup[f] = eqs[e].nu;
+                    fin[f] = (finish_scal && L.last_x && e >= 3) ? 1 : 0;        // equations 3.. are the scalars
+                    const bool fr = fresh && !touched[e];
+                    if (fr) { fresh_mask |= 1u << f; any_fresh = true; } else all_fresh = false;
+                    touched[e] = true;
+                }
+                const bool any_fin = fin[0] || fin[1] || fin[2] || fin[3];
+                const bool over = all_fresh && any_fresh;                   // every field of the launch starts its tendency here
+                double *divp = nullptr;
+                if (L.divf >= 0 && (L.dir != 1 || e0 == 0)) divp = tmp1;  // x: batch 0 holds u; y, z: the one-field launches
+                if (!tlab_internal_burgers_acc_n(L.dir, d->g[L.dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[L.dir - 1], rp, over,
+                                                 any_fin ? fin : nullptr, dte, kco, scale_tendencies ? 1 : 0, divp, idte, over ? 0u : fresh_mask))
+                    throw Fail(TLAB_EINVAL, "internal: inconsistent fused Burgers path");
+            }
+        }
+    } else if (batched) {
         const int order_xyz[3] = {1, 2, 3}, order_zyx[3] = {3, 2, 1};
         const int *order = x_last ? order_zyx : order_xyz;
         for (int k = 0; k < 3; ++k) {
@@ -255,7 +291,9 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // ---- pressure (:177-260, remove_divergence branch): forcing = div(hq + q/dte) ----
     bool fused_div = !literal && d->fuse && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) &&
                      tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
-    if (div_in_burgers) {     // tmp1 holds the x term already
+    if (batched && div_all) {
+        fused_div = true;     // tmp1 holds the three terms
+    } else if (div_in_burgers) {     // tmp1 holds the x term already
         const bool oky = tlab_internal_partial_p1_fused(2, gy, nx, ny, nz, B0, hq[1], v, idte, tmp1, true);
         const bool okz = oky && tlab_internal_partial_p1_fused(3, gz, nx, ny, nz, B0, hq[2], w, idte, tmp1, true);
         if (!oky || !okz) throw Fail(TLAB_EINVAL, "internal: inconsistent fused divergence path");
