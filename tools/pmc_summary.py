@@ -20,6 +20,9 @@ MODES = {1: "P1", 2: "P2", 3: "P2_P1", 4: "BURGERS", 5: "P2_D1IN", 6: "BURGERS_D
 def tag(name):
     """rocprof kernel name -> the tag the library's own profiler (and bench.py) uses."""
     name = re.sub(r"^void\s+", "", name).replace("tlab::", "")
+    m = re.match(r"k_htile<(\d+), 4, (\d+), (\d+), true>", name)
+    if m:
+        return "k_htile<BURGERS+div>"
     m = re.match(r"k_(xline|rtile|htile)<(\d+), (\d+)", name)
     if m:
         return "k_%s<%s>" % (m.group(1), MODES.get(int(m.group(3)), m.group(3)))
