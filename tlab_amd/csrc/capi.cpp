@@ -824,7 +824,7 @@ bool tlab_internal_burgers_can_div(int dir, tlab_fdm_plan_t g, int nx, int ny, i
     static const bool on = [] { const char *e = getenv("TLAB_DIV_IN_BURGERS"); return !(e && atoi(e) == 0); }();
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (!on || geom.n == 1 || choose_path(dir, geom.n, g) != PATH_RTILE || !htile_ok(geom.n, MODE_BURGERS)) return false;
-    return htile_chunk(geom.n, MODE_BURGERS) == 32 && geom.n / 32 <= 16 && !g->t.der1.direct && !htile_narrow();
+    return htile_chunk(geom.n, MODE_BURGERS) == 32 && geom.n / 32 <= 32 && !g->t.der1.direct && !htile_narrow();      // 32 chunks: 1024-point lines on 16-line tiles
 }
 
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     __shared__ double s_yl[32 * L];
     __shared__ double s_r[32 * L];
     __shared__ double s_e[2 * 32 * L];   // first-derivative edge values of every chunk (Jacobian correction)
-    __shared__ double s_h[DIV ? 6 * 16 * L : 1];      // DIV: first and last three rows of every chunk's forcing operand
+    __shared__ double s_h[DIV ? 6 * MAXT : 1];        // DIV: first and last three rows of every chunk's forcing operand (C * L = MAXT threads at most)
     extern __shared__ double s_tab[];     // coefficient rows of both systems, separator inverses, Jacobian-correction diagonals
     constexpr bool NEED1 = (MODE == MODE_P1 || MODE == MODE_P2_P1 || MODE == MODE_BURGERS);
     constexpr bool NEED2 = (MODE != MODE_P1);
@@ -334,8 +334,8 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
     case MODE_P2_P1: hipLaunchKernelGGL((k_htile<M, MODE_P2_P1, MAXT, L>), grid, block, lds, st, a); break;
     case MODE_BURGERS:
         if (a.fdiv) {
-            if constexpr (M == 32 && MAXT == 512 && L == 32) {
-                if (a.nf != 1 || a.fs[0] != a.in2 || C > 16 || a.s1.rowc != nullptr) return hipErrorInvalidValue;
+            if constexpr (M == 32 && MAXT == 512) {      // L = 32 with up to 16 chunks, or the 16-line tiles of 1024-point lines (32 chunks)
+                if (a.nf != 1 || a.fs[0] != a.in2 || C * L > MAXT || a.s1.rowc != nullptr) return hipErrorInvalidValue;
                 hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true>), grid, block, lds, st, a);
             } else {
                 return hipErrorInvalidValue;
