@@ -291,6 +291,50 @@ def test_full_rk_step_with_begin_step(T, fuse, nx):
     assert rel_err(d.s[0].cpu().numpy(), o.s[0]) <= 1e-12
 
 
+def test_forcing_terms_inside_the_burgers_launches(T):
+    """256 x 64 x 64, two scalars, stretched y: every velocity component gets the Burgers term of its own direction last and the one-field launches of
+    v along y and w along z add their term of the pressure forcing themselves (k_htile<BURGERS+div>; launch order z, y, x, y, z).  A full Runge-Kutta
+    step from NaN-poisoned tendencies: the first launch of each field overwrites (per-field flags: the y launch of u, w, s starts w and continues the
+    others), the later substeps accumulate.  Against the oracle at 1e-12, and the launch itself is looked up in the library's own kernel table."""
+    import ctypes
+    import torch
+    from tlab_amd.dns import Dns
+    from tlab_amd.lib import load
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz, nscal = 256, 64, 64, 2
+    x, y, z = grids(nx, ny, nz, True)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 29)
+    sc = (0.7, 2.0)
+    ss = [s0[0], s0[0] * 0.5 + 0.2]
+    d = Dns(x, y, z, nscal=nscal, visc=1.0 / 800.0, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    o = DnsOracle(x, y, z, nscal=nscal, visc=1.0 / 800.0, schmidt=sc, yuniform=False)
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i])); o.q[i] = q0[i].copy()
+    for i in range(nscal):
+        d.s[i].copy_(torch.from_numpy(ss[i])); o.s[i] = ss[i].copy()
+    for t in d.hq + d.hs:
+        t.fill_(float("nan"))
+    L = load()
+    L.tlab_profile_reset(); L.tlab_profile_enable(1)
+    dtime = 2e-3
+    d.TIME_RUNGEKUTTA(dtime)
+    torch.cuda.synchronize()
+    L.tlab_profile_enable(0)
+    buf = ctypes.create_string_buffer(16384); L.tlab_profile_report(buf, 16384)
+    rows = {r.split("\t")[0]: int(r.split("\t")[1]) for r in buf.value.decode().splitlines() if "\t" in r}
+    assert rows.get("k_htile<BURGERS+div>") == 6, rows          # v along y and w along z, three substeps
+    assert "k_rtile<P1>" not in rows or rows["k_rtile<P1>"] == 3, rows      # only the gradient-final launches of w are left of that kernel
+    for a in o.hq + o.hs:
+        a[:] = 0.0
+    for k in range(3):
+        last = k == 2
+        o.time_substep(dtime * d.kdt[k], 1.0 if last else d.kco[k], not last)
+    for i in range(3):
+        assert rel_err(d.q[i].cpu().numpy(), o.q[i]) <= 1e-12, i
+    for i in range(nscal):
+        assert rel_err(d.s[i].cpu().numpy(), o.s[i]) <= 1e-12, i
+
+
 def test_time_courant_and_dilatation_vs_oracle(T):
     """TIME_COURANT (time.f90:365) and the dilatation monitor (FI_INVARIANT_P + MINMAX, dns_local.f90:157-187)."""
     import torch
