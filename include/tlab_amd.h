@@ -246,7 +246,10 @@ int tlab_pencil_repack(double *slab, double *buffer, int nxh, int ny, int kmax, 
  * ahead of all second halves, so that the solves of one half run while the other half is on the wire (tlab_amd/parallel.py). */
 int tlab_pencil_repack_blocks(double *slab, double *buffer, int nxh, int ny, int kmax, int nblocks, const int *start, const long long *base, int dir);
 int tlab_poisson_set_wall_planes(tlab_poisson_plan_t plan, double *p, const double *bcs_hb, const double *bcs_ht);
-int tlab_poisson_fft_x(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* OPR_Fourier_X_Forward/Backward, opr_fourier.f90:219,277 */
+/* OPR_Fourier_X_Forward (dir = +1) / _Backward (dir = -1), opr_fourier.f90:219,277; out of place, unnormalised like FFTW.  The forward transform is
+ * the library's one-pass kernel where its lengths apply (nx/2 = 8^a * {1,2,4}, 128 <= nx <= 2048), rocFFT otherwise; the backward one is rocFFT's.
+ * dir = -2: the library's own inverse kernel (the one that finishes the v equation inside tlab_opr_poisson when the RHS driver asks for it), for tests. */
+int tlab_poisson_fft_x(tlab_poisson_plan_t plan, int dir, double *in, double *out);
 int tlab_poisson_fft_z(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* the FFT inside OPR_Fourier_Z_*, :355,422 */
 int tlab_poisson_ode(tlab_poisson_plan_t plan, double *f_hat, double *p_hat, double *dp_hat); /* mode loop of opr_elliptic.f90:308-333 */
 
