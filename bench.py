@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--n", "--box", dest="n", type=int, default=512, help="box size n^3 (BASELINE: 512), split into z-slabs over the GPUs; under torch.distributed.run spell it --box (its parser rejects --n as ambiguous)")
     ap.add_argument("--grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"), help="non-cubic box (diagnostics; e.g. 1024 512 1024 = BASELINE configs[3])")
     ap.add_argument("--nscal", type=int, default=1)
+    ap.add_argument("--walls", default="noslip", choices=["noslip", "freeslip"], help="diagnostic (single GPU): freeslip = the reference's default velocity walls "
+                    "with Neumann scalars (BOUNDARY_BCS_NEUMANN_Y in the tail of the substep); the headline is noslip / Dirichlet")
     ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
                     "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
     ap.add_argument("--decomp", default="", metavar="IxK", help="diagnostic: x/z pencil decomposition npro_i x npro_k (tlab_amd/pencil.py), e.g. 2x4: with "
@@ -205,6 +207,8 @@ def main():
         # one GPU owns the whole box: the C++ driver (tlab_amd/csrc/rhs.cpp) runs the substep
         d = Dns(x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3,
                 hyper_bc1_ext=HYPER_BC1_EXT)
+        if args.walls == "freeslip":
+            d.set_bcs("freeslip", "freeslip", "neumann", "neumann")
         synthetic_fields(d.q + d.s, nx, ny, nz, 0, nz, rank)
         state_fields = d.q + d.s
 

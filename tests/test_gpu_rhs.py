@@ -297,8 +297,9 @@ def test_forcing_terms_inside_the_burgers_launches(T, walls):
     v along y and w along z add their term of the pressure forcing themselves (k_htile<BURGERS+div>; launch order z, y, x, y, z).  A full Runge-Kutta
     step from NaN-poisoned tendencies: the first launch of each field overwrites (per-field flags: the y launch of u, w, s starts w and continues the
     others), the later substeps accumulate.  Against the oracle at 1e-12, and the launch itself is looked up in the library's own kernel table.
-    walls = freeslip (and Neumann scalars): the forcing terms still ride on the Burgers launches, while the tail of the substep takes the unfused
-    route (subtraction of the gradient, BOUNDARY_BCS_NEUMANN_Y planes, final update) and the scalars are not finished in the x launch."""
+    walls = freeslip (and Neumann scalars), the reference's default walls: the forcing terms still ride on the Burgers launches, v is finished by the
+    solver, and every field with a Neumann wall takes one launch along y that forms the wall tendencies of BOUNDARY_BCS_NEUMANN_Y from the finished
+    tendency and does the final update (after the gradient was subtracted by the x / z derivative launch itself)."""
     import ctypes
     import torch
     from tlab_amd.dns import Dns, velocity_bcs, scalar_bcs
@@ -332,6 +333,8 @@ def test_forcing_terms_inside_the_burgers_launches(T, walls):
     assert rows.get("k_htile<BURGERS+div>") == 6, rows          # v along y and w along z, three substeps
     if walls == "noslip":
         assert "k_rtile<P1>" not in rows or rows["k_rtile<P1>"] == 3, rows      # only the gradient-final launches of w are left of that kernel
+    else:       # u, w and the two scalars: BOUNDARY_BCS_NEUMANN_Y + final update in one launch each, three substeps; no separate update pass is left
+        assert rows.get("k_rtile<P1+neumann final>") == 12 and "k_final_update" not in rows and "k_sub3" not in rows, rows
     for a in o.hq + o.hs:
         a[:] = 0.0
     for k in range(3):

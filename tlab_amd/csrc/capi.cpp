@@ -588,6 +588,9 @@ struct OpExtra {
     double *fdiv = nullptr;
     double fidte = 0.0;
     unsigned fresh_mask = 0;        // k_htile MODE_BURGERS: fields that overwrite their tendency in an accumulating launch
+    bool sub = false;               // MODE_P1: out0 -= value
+    int fneu = 0;                   // k_rtile MODE_P1: Neumann-final epilogue (RTileArgs::fneu)
+    double fcb[4] = {0, 0, 0, 0}, fct[4] = {0, 0, 0, 0};
 };
 const OpExtra kNoExtra{};
 
@@ -672,9 +675,11 @@ void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     const int P = geom.n / rtile_chunk(geom.n);
     RTileArgs a{};
     a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.out1 = nullptr; a.g = geom; a.nu = nu;
-    a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
+    a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.sub ? 2 : (ex.acc ? 1 : 0);
     a.nf = 0;
     a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny;
+    a.fneu = ex.fneu;
+    for (int q = 0; q < 4; ++q) { a.fcb[q] = ex.fcb[q]; a.fct[q] = ex.fct[q]; }
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     a.y1 = g->system(1, ibc, P).dev();
@@ -709,7 +714,7 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
                double *out0, double *out1, double nu, const OpExtra &ex = kNoExtra) {
     XLineArgs a;
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1; a.nlines = geom.nlines; a.nu = nu;
-    a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.acc ? 1 : 0;
+    a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.sub ? 2 : (ex.acc ? 1 : 0);
     a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny;
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; a.ffin[f] = ex.ffin[f]; }
@@ -763,6 +768,66 @@ bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, 
         return false;
     }
     g_last_path = path;
+    return true;
+}
+// coefficients of BOUNDARY_BCS_NEUMANN_Y (boundary_bcs.f90:368-473): wall value = (u(2) cb0 + u(3) cb1) + u(4) cb2 + cb3 du(2), likewise at the top
+void neumann_y_coefficients(tlab_fdm_plan_t g, int ibc, int ny, double (&cb)[4], double (&ct)[4]) {
+    const DerTables &d = g->t.der1;
+    if (d.ndl != 3 || (d.ndr != 3 && d.ndr != 5)) throw Unsupported("BOUNDARY_BCS_NEUMANN_Y: tridiagonal first-derivative schemes only");
+    if (ny < 8) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: ny too small");
+    std::vector<double> lhs(d.lhs.begin(), d.lhs.begin() + (size_t)3 * ny);
+    double rb[4 * 8] = {0}, rt[5 * 7] = {0};
+    fdm_bcs_neumann(ibc, ny, 3, lhs.data(), d.ndr, d.rhs.data(), rb, rt);
+    for (int q = 0; q < 4; ++q) cb[q] = ct[q] = 0.0;
+#define RB(j, c) rb[((j)-1) + 4 * (c)]
+#define RT(rr, c) rt[(rr) + 5 * ((c)-1)]
+    if (d.ndr == 5) {   // MatMul_5d_antisym, fdm_matmul.f90:384,410
+        cb[0] = RB(1, 4); cb[1] = RB(1, 5); cb[2] = RB(1, 1);
+        ct[0] = RT(3, 5); ct[1] = RT(3, 1); ct[2] = RT(3, 2);
+    } else {            // MatMul_3d_antisym, fdm_matmul.f90:179,203
+        cb[0] = RB(1, 3); cb[1] = RB(1, 1);
+        ct[1] = RT(2, 3); ct[2] = RT(2, 1);
+    }
+#undef RB
+#undef RT
+    cb[3] = lhs[0 + (size_t)ny * 2];          // lu(1, ip+idl+1): first row of the reduced LHS is not touched by TRIDFS
+    ct[3] = lhs[(ny - 1) + (size_t)ny * 0];   // lu(ny, ip+idl-1)
+}
+// result -= d/dx_dir u  (fused kernels only; the caller falls back to OPR_Partial + a subtraction otherwise)
+bool tlab_internal_partial_p1_sub(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *u, double *result) {
+    check_common(dir, g, nx, ny, nz, 0);
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (geom.n == 1) return false;
+    OpExtra ex;
+    ex.sub = true;
+    const int path = choose_path(dir, geom.n, g);
+    if (path == PATH_XLINE) run_xline(g, geom, MODE_P1, 0, u, nullptr, result, nullptr, 0.0, ex);
+    else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_rtile(g, geom, MODE_P1, 0, u, nullptr, nullptr, result, 0.0, ex);
+    else return false;
+    g_last_path = path;
+    return true;
+}
+// The last pass over a field with Neumann walls (ibc: 1 jmin, 2 jmax, 3 both; the other side Dirichlet): BOUNDARY_BCS_NEUMANN_Y on the finished
+// tendency h, its wall planes, q += dte h, h *= kco -- one launch along y instead of OPR_Partial_Y + k_neumann_planes + k_final_update.
+bool tlab_internal_neumann_final_ok(tlab_fdm_plan_t g, int nx, int ny, int nz) {
+    static const bool on = [] { const char *e = getenv("TLAB_NEUMANN_FINAL"); return !(e && atoi(e) == 0); }();
+    if (!on || !g || g->t.periodic || g->t.der1.direct || ny < 8) return false;
+    const DerTables &d = g->t.der1;
+    if (d.ndl != 3 || (d.ndr != 3 && d.ndr != 5)) return false;
+    const LineGeom geom = make_geom(2, nx, ny, nz);
+    const int M = rtile_chunk(geom.n);
+    return choose_path(2, geom.n, g) == PATH_RTILE && M >= 8 && M % 8 == 0;
+}
+bool tlab_internal_neumann_final(tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double *h, double *q, double dte, double kco, int scale) {
+    check_common(2, g, nx, ny, nz, ibc);
+    if (ibc < 1 || ibc > 3 || !tlab_internal_neumann_final_ok(g, nx, ny, nz)) return false;
+    const LineGeom geom = make_geom(2, nx, ny, nz);
+    OpExtra ex;
+    ex.fq = q; ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fnx = nx; ex.fny = ny;
+    ex.fneu = ibc;
+    neumann_y_coefficients(g, ibc, ny, ex.fcb, ex.fct);
+    run_rtile(g, geom, MODE_P1, ibc, h, nullptr, nullptr, h, 0.0, ex);
+    g_last_path = PATH_RTILE;
     return true;
 }
 // h -= d/dx_dir p ; walls ; q += dte h ; h *= kco : the last pass over a velocity component folded into the gradient of the pressure.
@@ -952,26 +1017,8 @@ int tlab_boundary_bcs_neumann_y(tlab_fdm_plan_t g, int ibc, int nx, int ny, int 
         if (ibc != BCS_ND && ibc != BCS_DN && ibc != BCS_NN) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: ibc must be 1 (jmin), 2 (jmax) or 3 (both)");
         if (g->t.periodic) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: periodic direction");
         if (!u || !tmp1 || u == tmp1 || !bcs_hb || !bcs_ht) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: null or aliased arrays");
-        const DerTables &d = g->t.der1;
-        if (d.ndl != 3 || (d.ndr != 3 && d.ndr != 5)) throw Unsupported("BOUNDARY_BCS_NEUMANN_Y: tridiagonal first-derivative schemes only");
-        if (ny < 8) throw Invalid("BOUNDARY_BCS_NEUMANN_Y: ny too small");
-        std::vector<double> lhs(d.lhs.begin(), d.lhs.begin() + (size_t)3 * ny);
-        double rb[4 * 8] = {0}, rt[5 * 7] = {0};
-        fdm_bcs_neumann(ibc, ny, 3, lhs.data(), d.ndr, d.rhs.data(), rb, rt);
-        double cb[4] = {0, 0, 0, 0}, ct[4] = {0, 0, 0, 0};
-#define RB(j, c) rb[((j)-1) + 4 * (c)]
-#define RT(rr, c) rt[(rr) + 5 * ((c)-1)]
-        if (d.ndr == 5) {   // MatMul_5d_antisym, fdm_matmul.f90:384,410
-            cb[0] = RB(1, 4); cb[1] = RB(1, 5); cb[2] = RB(1, 1);
-            ct[0] = RT(3, 5); ct[1] = RT(3, 1); ct[2] = RT(3, 2);
-        } else {            // MatMul_3d_antisym, fdm_matmul.f90:179,203
-            cb[0] = RB(1, 3); cb[1] = RB(1, 1);
-            ct[1] = RT(2, 3); ct[2] = RT(2, 1);
-        }
-#undef RB
-#undef RT
-        cb[3] = lhs[0 + (size_t)ny * 2];          // lu(1, ip+idl+1): first row of the reduced LHS is not touched by TRIDFS
-        ct[3] = lhs[(ny - 1) + (size_t)ny * 0];   // lu(ny, ip+idl-1)
+        double cb[4], ct[4];
+        neumann_y_coefficients(g, ibc, ny, cb, ct);
         const int rc = tlab_opr_partial(2, g, TLAB_OPR_P1, nx, ny, nz, ibc, u, tmp1, nullptr);
         if (rc != TLAB_OK) throw Invalid(std::string("BOUNDARY_BCS_NEUMANN_Y: ") + tlab_last_error());
         hip_check(launch_neumann_planes(u, tmp1, cb, ct, (ibc & 1), (ibc & 2), bcs_hb, bcs_ht, nx, ny, nz, g_stream), "k_neumann_planes");

@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
                 } else {
                     if (a.acc) {
 #pragma unroll
-                        for (int p = 0; p < M; ++p) x1[p] = h[p] + x1[p];
+                        for (int p = 0; p < M; ++p) x1[p] = (a.acc == 2) ? h[p] - x1[p] : h[p] + x1[p];
                     }
                     xstore<M>(a.out0 + off, x1);
                 }
@@ -620,6 +620,35 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
             const long long idx = base + (long long)(row0 + p) * rs;
             if (valid) a.out0[idx] = a.nu * f[p] - a.in2[idx] * a.in1[idx];
         }
+    } else if (MODE == MODE_P1 && a.fneu != 0) {
+        // Neumann-final epilogue (y-direction lines, operand = the finished tendency h, f = its derivative by the Neumann variant of the system):
+        // wall tendencies as k_neumann_planes forms them, then k_final_update's arithmetic.  h is read again (the operand registers are gone).
+        if (valid) {
+#pragma unroll
+            for (int p0 = 0; p0 < M; p0 += 8) {
+                double h[8], qv[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    h[p] = a.in0[base + (long long)(row0 + p0 + p) * rs];
+                    qv[p] = a.fq[base + (long long)(row0 + p0 + p) * rs];
+                }
+                if (p0 == 0 && w == 0)           // row 0: BOUNDARY_BCS_NEUMANN_Y's bottom value, or zero on a Dirichlet side
+                    h[0] = (a.fneu & 1) ? ((h[1] * a.fcb[0] + h[2] * a.fcb[1]) + h[3] * a.fcb[2]) + a.fcb[3] * f[1] : 0.0;
+                if (p0 == M - 8 && w == P - 1)   // row n-1
+                    h[7] = (a.fneu & 2) ? ((h[4] * a.fct[0] + h[5] * a.fct[1]) + h[6] * a.fct[2]) + a.fct[3] * f[M - 2] : 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const double hv = h[p];
+                    qv[p] = qv[p] + a.fdte * hv;
+                    h[p] = a.fscale ? a.fkco * hv : hv;
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    a.fq[base + (long long)(row0 + p0 + p) * rs] = qv[p];
+                    a.out0[base + (long long)(row0 + p0 + p) * rs] = h[p];
+                }
+            }
+        }
     } else if (MODE == MODE_P1 && a.fq != nullptr) {
         // final-update epilogue (z-direction lines: lane = (ix, j) inside the plane, rows = k)
         if (valid) {
@@ -653,7 +682,7 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
 #pragma unroll
             for (int p = 0; p < M; ++p) o[p] = a.out0[base + (long long)(row0 + p) * rs];
 #pragma unroll
-            for (int p = 0; p < M; ++p) f[p] = o[p] + f[p];
+            for (int p = 0; p < M; ++p) f[p] = (a.acc == 2) ? o[p] - f[p] : o[p] + f[p];
         }
 #pragma unroll
         for (int p = 0; p < M; ++p)
@@ -954,7 +983,7 @@ static hipError_t launch_rtile_m(int mode, int P, long long tiles, const RTileAr
     const double pts = (double)a.g.nlines * a.g.n;
     const char *name = mode == MODE_P1 ? "k_rtile<P1>" : mode == MODE_P2 ? "k_rtile<P2>" : mode == MODE_P2_D1IN ? "k_rtile<P2_D1IN>" : "k_rtile<BURGERS_D1IN>";
     const double bpp = mode == MODE_P1 || mode == MODE_P2 ? 16 : mode == MODE_P2_D1IN ? 24 : 32;   // operand reads + writes of this launch
-    ProfScope ps(name, st, pts * (bpp + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0) + (a.fq ? 24 : 0)));
+    ProfScope ps(a.fneu ? "k_rtile<P1+neumann final>" : name, st, pts * (bpp + (a.acc ? 8 : 0) + (a.in0b ? 8 : 0) + (a.fq ? 24 : 0)));
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_rtile<M, MODE_P1, MAXT>), grid, block, 0, st, a); break;
     case MODE_P2: hipLaunchKernelGGL((k_rtile<M, MODE_P2, MAXT>), grid, block, 0, st, a); break;

@@ -12,7 +12,7 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     double *out0, *out1;
     const double *in0b;     // optional: operand = in0 + in0b_scale * in0b   (tmp = hq + q/dte fused into the divergence, P1 only)
     double in0b_scale;
-    int acc;                // 1: out0 += value instead of out0 = value (MODE_P1, MODE_BURGERS)
+    int acc;                // 1: out0 += value instead of out0 = value (MODE_P1, MODE_BURGERS); 2: out0 -= value (MODE_P1)
     long long nlines;
     StencilDev s1, s2;      // first / second derivative RHS operators
     SystemDev y1, y2;       // first / second derivative chunked systems (P = 64)
@@ -47,7 +47,7 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     double *out1;           // first derivative (MODE_P2_P1 of k_htile)
     const double *in0b;     // optional second operand term: operand = in0 + in0b_scale * in0b (k_rtile MODE_P1)
     double in0b_scale;
-    int acc;                // 1: out0 += value (k_rtile MODE_P1, k_htile MODE_BURGERS)
+    int acc;                // 1: out0 += value (k_rtile MODE_P1, k_htile MODE_BURGERS); 2: out0 -= value (MODE_P1)
     LineGeom g;
     StencilDev s1, s2;
     SystemDev y1, y2;       // chunked with P = n / rtile_chunk(n)  (k_htile: n / htile_chunk(n, mode))
@@ -71,6 +71,12 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     // to fdiv -- a third solve on the lines the workgroup holds anyway, instead of a separate pass that re-reads h and v
     double *fdiv;
     double fidte;
+    // k_rtile MODE_P1 along y on the FINISHED tendency h (= in0) of a field with Neumann walls (fneu: bit 0 = jmin, bit 1 = jmax): the derivative of
+    // the Neumann variant is not stored; its rows 1 / n-2 give the wall tendencies of BOUNDARY_BCS_NEUMANN_Y (boundary_bcs.f90:368-473; fcb / fct =
+    // the three stencil coefficients and the LHS coefficient, as k_neumann_planes takes them), a Dirichlet side gets zero, and the final update of
+    // k_final_update follows in the same launch: q (= fq) += fdte h, h = fscale ? fkco h : h.
+    int fneu;
+    double fcb[4], fct[4];
 };
 
 struct GenericArgs {        // k_generic: any n

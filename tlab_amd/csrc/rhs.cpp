@@ -37,6 +37,9 @@ bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale,
                                  double *divx, double idte, unsigned fresh_mask = 0);
 bool tlab_internal_burgers_can_div(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
+bool tlab_internal_partial_p1_sub(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *u, double *result);
+bool tlab_internal_neumann_final_ok(tlab_fdm_plan_t g, int nx, int ny, int nz);
+bool tlab_internal_neumann_final(tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double *h, double *q, double dte, double kco, int scale);
 
 struct tlab_dns {
     tlab_fdm_plan_t g[3];
@@ -343,7 +346,16 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     bool v_final = false;
     bool walls_dirichlet = true;      // (a Neumann wall of any component sends all three through the unfused subtraction below)
     for (int iq = 0; iq < 3; ++iq) walls_dirichlet = walls_dirichlet && d->flow_jmin[iq] == TLAB_DNS_BCS_DIRICHLET && d->flow_jmax[iq] == TLAB_DNS_BCS_DIRICHLET;
-    if (tail_update && d->fuse && !literal && !d->pfilter[0] && !d->pfilter[1] && !d->pfilter[2] && walls_dirichlet &&
+    // Neumann walls somewhere (free-slip u, w; Neumann scalars): the tail below then runs per field -- gradient subtracted in its own launch,
+    // BOUNDARY_BCS_NEUMANN_Y + final update in ONE launch along y (tlab_internal_neumann_final) -- and v, always Dirichlet, is finished by the solver
+    auto ibc_y = [](int tmin, int tmax) { return (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0); };
+    bool any_neumann = false;
+    for (int iq = 0; iq < 3; ++iq) any_neumann = any_neumann || ibc_y(d->flow_jmin[iq], d->flow_jmax[iq]) != 0;
+    for (int is = 0; is < d->nscal; ++is) any_neumann = any_neumann || ibc_y(d->scal_jmin[is], d->scal_jmax[is]) != 0;
+    const bool neu_fast = any_neumann && tail_update && d->fuse && !literal && nz > 1 && !d->pfilter[0] && !d->pfilter[1] && !d->pfilter[2] && !any_surface &&
+                          tlab_internal_poisson_can_v_final(d->poisson) && tlab_internal_neumann_final_ok(gy, nx, ny, nz) &&
+                          tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
+    if (tail_update && d->fuse && !literal && !d->pfilter[0] && !d->pfilter[1] && !d->pfilter[2] && (walls_dirichlet || neu_fast) &&
         tlab_internal_poisson_can_v_final(d->poisson)) {
         tlab_internal_poisson_arm_v_final(d->poisson, q[1], hq[1], dte, kco, scale_tendencies);
         v_final = true;
@@ -352,6 +364,25 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     if (d->pfilter[0] || d->pfilter[1] || d->pfilter[2]) {      // filter pressure p and its vertical gradient dpdy (:286-290)
         ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp1, tmp4), "OPR_FILTER(p)");
         ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp3, tmp4), "OPR_FILTER(dpdy)");
+    }
+    if (neu_fast) {
+        for (int iq = 0; iq < 3; iq += 2) {      // u along x, w along z
+            const int dir = iq == 0 ? 1 : 3;
+            tlab_fdm_plan_t gd = iq == 0 ? gx : gz;
+            const int ibc = ibc_y(d->flow_jmin[iq], d->flow_jmax[iq]);
+            bool done;
+            if (ibc == 0) done = tlab_internal_gradient_final(dir, gd, nx, ny, nz, tmp1, q[iq], hq[iq], dte, kco, scale_tendencies);
+            else done = tlab_internal_partial_p1_sub(dir, gd, nx, ny, nz, tmp1, hq[iq]) &&
+                        tlab_internal_neumann_final(gy, nx, ny, nz, ibc, hq[iq], q[iq], dte, kco, scale_tendencies);
+            if (!done) throw Fail(TLAB_EINVAL, "internal: inconsistent fused Neumann tail");
+        }
+        for (int is = 0; is < d->nscal && !finish_scal; ++is) {
+            const int ibc = ibc_y(d->scal_jmin[is], d->scal_jmax[is]);
+            if (ibc == 0) hk(launch_final_update(s[is], hs[is], nullptr, nullptr, nullptr, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+            else if (!tlab_internal_neumann_final(gy, nx, ny, nz, ibc, hs[is], s[is], dte, kco, scale_tendencies))
+                throw Fail(TLAB_EINVAL, "internal: inconsistent fused Neumann tail");
+        }
+        return;
     }
     // ---- pressure gradient (:319-320).  With Dirichlet walls and the RK update folded in (tail_update), the x- and z-gradient kernels
     // finish u and w themselves: hq -= dp/dx; wall planes; q += dte hq; hq *= kco (no gradient array is written or re-read) ----
