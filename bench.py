@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--n", "--box", dest="n", type=int, default=512, help="box size n^3 (BASELINE: 512), split into z-slabs over the GPUs; under torch.distributed.run spell it --box (its parser rejects --n as ambiguous)")
     ap.add_argument("--grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"), help="non-cubic box (diagnostics; e.g. 1024 512 1024 = BASELINE configs[3])")
     ap.add_argument("--nscal", type=int, default=1)
+    ap.add_argument("--ystretch", action="store_true", help="diagnostic (single GPU): tanh-stretched y nodes (SURVEY 8d: y_j = (1 + tanh(2(2(j-1)/(ny-1) - 1))/tanh 2)/2, "
+                    "the grid of BASELINE configs[4]) instead of the uniform ones of the headline: the second derivative then carries its Jacobian correction")
     ap.add_argument("--walls", default="noslip", choices=["noslip", "freeslip"], help="diagnostic (single GPU): freeslip = the reference's default velocity walls "
                     "with Neumann scalars (BOUNDARY_BCS_NEUMANN_Y in the tail of the substep); the headline is noslip / Dirichlet")
     ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
@@ -167,8 +169,10 @@ def main():
     nx, ny, nz = (args.grid if args.grid else (n, n, n))
     x = np.arange(nx) / nx
     y = np.arange(ny) / (ny - 1.0)
+    if args.ystretch:
+        y = 0.5 * (1.0 + np.tanh(2.0 * (2.0 * y - 1.0)) / np.tanh(2.0))
     z = np.arange(nz) / nz
-    dtime = 1e-3
+    dtime = 2e-5 if args.ystretch else 1e-3      # (the stretched grid's wall spacing is 1/7 of the uniform one: advective and diffusive limits of the explicit scheme)
     # wall closure of the hyper-diffusive second derivative: the consistent one.  The parity tests use 0.1, the value the flang-built reference reads
     # past the end of a coefficient array (defect 1) -- same kernels and bytes, but that scheme is unstable over many steps.
     HYPER_BC1_EXT = 0.0
@@ -205,7 +209,7 @@ def main():
             d.substep_of_cycle(k, dtime)
     elif world == 1:
         # one GPU owns the whole box: the C++ driver (tlab_amd/csrc/rhs.cpp) runs the substep
-        d = Dns(x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3,
+        d = Dns(x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=not args.ystretch, rkm_mode=RKM_EXP3,
                 hyper_bc1_ext=HYPER_BC1_EXT)
         if args.walls == "freeslip":
             d.set_bcs("freeslip", "freeslip", "neumann", "neumann")
