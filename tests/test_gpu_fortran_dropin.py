@@ -55,7 +55,10 @@ End={steps}
 """
 
 
-def run_rk_driver(tmp_path, x, y, z, q0, s0, reynolds, schmidt, dtime, steps, bcs_lines, elliptic="", ini=None):
+RK_EXE_FUSED = os.path.join(ROOT, "tlab_amd", "fortran", "_build_rk_fused", "test_rk_driver")
+
+
+def run_rk_driver(tmp_path, x, y, z, q0, s0, reynolds, schmidt, dtime, steps, bcs_lines, elliptic="", ini=None, exe=None):
     """Writes tlab.ini, grid, flow.0.*, scal.0.* in the reference's formats, runs the Fortran mini-driver there, reads flow.<steps>.*, scal.<steps>.*"""
     import numpy as np
     from tlab_amd import io as tio
@@ -66,7 +69,7 @@ def run_rk_driver(tmp_path, x, y, z, q0, s0, reynolds, schmidt, dtime, steps, bc
     tio.grid_write(os.path.join(tmp_path, "grid"), x, y, z, scales=[x[-1] - x[0] + (x[1] - x[0]), y[-1] - y[0], z[-1] - z[0] + (z[1] - z[0])])
     tio.io_write_fields(os.path.join(tmp_path, "flow.0"), nx, ny, nz, 0, q0, params=(0.0, 1.0 / reynolds))
     tio.io_write_fields(os.path.join(tmp_path, "scal.0"), nx, ny, nz, 0, s0, params=(0.0,))
-    r = subprocess.run([RK_EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe or RK_EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     log = ""
     for name in ("tlab.err", "tlab.log"):
         p = os.path.join(tmp_path, name)
@@ -87,8 +90,9 @@ def _need_rk():
         pytest.skip("tlab_amd/fortran/_build_rk/test_rk_driver not built (needs oracle/_ref, i.e. the build container)")
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("case", ["noslip", "freeslip"])
-def test_fortran_rk_driver_against_golden_step(case, tmp_path):
+def test_fortran_rk_driver_against_golden_step(case, fused, tmp_path):
     """The unchanged-host sequence TLab_Start, TLab_Grid_Read, FDM_Initialize (all three the reference's own code), TLab_Initialize_Memory (hook),
     OPR_Burgers_Initialize(ifile), OPR_Elliptic_Initialize(ifile), OPR_Fourier_Initialize(), IO_Read_Fields, TIME_RUNGEKUTTA x 2 with the external
     RHS_GLOBAL_INCOMPRESSIBLE_1 and DAXPY / DSCAL on device arrays, IO_Write_Fields -- against the committed oracle fixture of the same two steps
@@ -97,15 +101,20 @@ def test_fortran_rk_driver_against_golden_step(case, tmp_path):
     from conftest import rel_err
     _need_rk()
     g = np.load(os.path.join(ROOT, "tests", "golden", "rk_step_%s.npz" % case))
+    # fused: the same driver built with -DTLAB_AMD_FUSED_SUBSTEP -- the six-line patch of time.f90 that hands RHS + update loops + tendency scaling
+    # of a substep to tlab_time_substep_incompressible_explicit in one call (TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD)
+    if fused and not os.path.exists(RK_EXE_FUSED):
+        pytest.skip("tlab_amd/fortran/_build_rk_fused/test_rk_driver not built")
     q1, s1, log = run_rk_driver(str(tmp_path), g["x"], g["y"], g["z"], list(g["q0"]), list(g["s0"]), float(g["reynolds"]), float(g["schmidt"]),
-                                float(g["dtime"]), int(g["steps"]), [str(v) for v in g["ini"]])
+                                float(g["dtime"]), int(g["steps"]), [str(v) for v in g["ini"]], exe=RK_EXE_FUSED if fused else None)
     assert "HBM (tlab_malloc)" in log                         # the allocation hook was the allocator
     for i in range(3):
         assert rel_err(q1[i], g["q1"][i]) <= 1e-12, (case, "q", i, rel_err(q1[i], g["q1"][i]))
     assert rel_err(s1[0], g["s1"][0]) <= 1e-12, (case, "s")
 
 
-def test_fortran_rk_driver_fast_kernels(tmp_path):
+@pytest.mark.parametrize("fused", [False, True])
+def test_fortran_rk_driver_fast_kernels(tmp_path, fused):
     """The same driver at a size that takes the fused kernels (256-point x lines, 64-point y lines), against the numpy oracle run here; the log
     carries the transposition round trip of the same-named TLabMPI_Trp_Exec* procedures (one rank, RCCL communicator)."""
     import numpy as np
@@ -124,7 +133,9 @@ def test_fortran_rk_driver_fast_kernels(tmp_path):
     s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
     re, sc, dt = 1000.0, 0.7, 1e-3
     bcs = ["VelocityJmin=noslip", "VelocityJmax=noslip", "Scalar1Jmin=dirichlet", "Scalar1Jmax=dirichlet"]
-    q1, s1, log = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 1, bcs)
+    if fused and not os.path.exists(RK_EXE_FUSED):
+        pytest.skip("tlab_amd/fortran/_build_rk_fused/test_rk_driver not built")
+    q1, s1, log = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 1, bcs, exe=RK_EXE_FUSED if fused else None)
     assert "Checking transposition round trip: residual  0.000E+00" in log, log[-1500:]
     kdt, kco = [1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0], [-5.0 / 9.0, -153.0 / 128.0]
     sched = [(dt * kdt[k], kco[k] if k < 2 else 1.0, k < 2) for k in range(3)]

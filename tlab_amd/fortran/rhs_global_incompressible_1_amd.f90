@@ -34,3 +34,42 @@ subroutine RHS_GLOBAL_INCOMPRESSIBLE_1()
     call TLab_AMD_Check(rc, 'tlab_rhs_global_incompressible_1')
 
 end subroutine RHS_GLOBAL_INCOMPRESSIBLE_1
+
+!########################################################################
+! The whole of TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT (tools/dns/time.f90:559-664) AND the tendency scaling that follows it in TIME_RUNGEKUTTA
+! (:272-297) in the fused device driver: RHS, q += dte hq, s += dte hs, hq *= kco, hs *= kco (the last only if scale).  For a host that accepts a
+! six-line patch of time.f90 (test_rk_driver.f90, -DTLAB_AMD_FUSED_SUBSTEP) instead of the link-time RHS alone: the update loops then ride on the
+! last kernels that touch each field (18.7 instead of ~24 ms per substep at 512^3 on an MI355X).
+!########################################################################
+subroutine TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(kco_loc, scale_loc)
+    use, intrinsic :: iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use TLab_Memory, only: inb_flow, inb_scal, inb_txc
+    use TLab_Arrays
+    use DNS_ARRAYS
+    use TIME, only: dte
+    use TLab_AMD_C
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle
+    implicit none
+    real(wp), intent(in) :: kco_loc
+    logical, intent(in) :: scale_loc
+
+    type(c_ptr) :: pq(3), ps(16), phq(3), phs(16), ptxc(16)
+    integer is
+    integer(c_int) rc
+
+    do is = 1, 3
+        pq(is) = c_loc(q(1, is)); phq(is) = c_loc(hq(1, is))
+    end do
+    ps = c_null_ptr; phs = c_null_ptr
+    do is = 1, inb_scal
+        ps(is) = c_loc(s(1, is)); phs(is) = c_loc(hs(1, is))
+    end do
+    do is = 1, min(int(inb_txc), 16)
+        ptxc(is) = c_loc(txc(1, is))
+    end do
+    rc = tlab_time_substep_incompressible_explicit(TLab_AMD_DNS_Handle(), real(dte, c_double), real(kco_loc, c_double), &
+                                                   merge(1_c_int, 0_c_int, scale_loc), pq, ps, phq, phs, ptxc)
+    call TLab_AMD_Check(rc, 'tlab_time_substep_incompressible_explicit')
+
+end subroutine TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD

@@ -20,7 +20,7 @@ module TIME
     use TLab_Memory, only: imax, jmax, kmax, isize_field
     use TLab_Memory, only: inb_flow, inb_scal
     use NavierStokes
-    use TLab_AMD_DNS, only: TLab_AMD_Zero
+    use TLab_AMD_DNS, only: TLab_AMD_Zero, TLab_AMD_DNS_Begin_Step
     implicit none
     private
 
@@ -84,8 +84,12 @@ contains
         ! Initialize arrays to zero for the explcit low-storage algorithm
         ! -------------------------------------------------------------------
         if (rkm_mode == RKM_EXP3 .or. rkm_mode == RKM_EXP4) then
+#ifdef TLAB_AMD_FUSED_SUBSTEP
+            call TLab_AMD_DNS_Begin_Step()                                      ! hq = hs = 0 as a flag: the first launch of each field overwrites
+#else
             if (flow_on) call TLab_AMD_Zero(hq, isize_field*inb_flow)           ! hq = 0.0_wp   (time.f90:213; no BLAS branch: the one patched line)
             if (scal_on) call TLab_AMD_Zero(hs, isize_field*inb_scal)           ! hs = 0.0_wp   (time.f90:214)
+#endif
         end if
         !########################################################################
         ! Loop over the sub-stages
@@ -108,8 +112,12 @@ contains
             ! -------------------------------------------------------------------
             ! Update RHS hq and hs in the explicit low-storage algorithm
             ! -------------------------------------------------------------------
+#ifdef TLAB_AMD_FUSED_SUBSTEP
+            if (.false.) then                   ! (the scaling rides on the substep: TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD)
+#else
             if ((rkm_mode == RKM_EXP3 .or. rkm_mode == RKM_EXP4) .and. &
                 rkm_substep < rkm_endstep) then
+#endif
 
                 alpha = kco(rkm_substep)
 
@@ -138,6 +146,17 @@ contains
 
         integer ij_len
         external RHS_GLOBAL_INCOMPRESSIBLE_1
+#ifdef TLAB_AMD_FUSED_SUBSTEP
+        external TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD
+
+        ! the patch: RHS, the two update loops below and the DSCAL loops of TIME_RUNGEKUTTA in one call of the fused device driver
+        if (rkm_substep < rkm_endstep) then
+            call TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(kco(rkm_substep), .true.)
+        else
+            call TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(1.0_wp, .false.)
+        end if
+        return
+#endif
 
         ij_len = isize_field
 
