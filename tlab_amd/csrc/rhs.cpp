@@ -386,7 +386,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     }
     // ---- pressure gradient (:319-320).  With Dirichlet walls and the RK update folded in (tail_update), the x- and z-gradient kernels
     // finish u and w themselves: hq -= dp/dx; wall planes; q += dte hq; hq *= kco (no gradient array is written or re-read) ----
-    bool grad_final = false;
+    bool grad_final = false, grad_sub = false;
     if (tail_update && d->fuse && nz > 1 && !literal) {
         bool dirichlet = true;
         for (int iq = 0; iq < 3; ++iq) dirichlet = dirichlet && d->flow_jmin[iq] == TLAB_DNS_BCS_DIRICHLET && d->flow_jmax[iq] == TLAB_DNS_BCS_DIRICHLET;
@@ -405,8 +405,18 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         ok(tlab_opr_partial(3, gz, TLAB_OPR_P0_INT_PV, nx, ny, nz, B0, tmp1, tmp5, nullptr), "OPR_Partial_Z(P0_INT_PV)");       // dp/dx
         ok(tlab_opr_partial(1, gx, TLAB_OPR_P1_INT_PV, nx, ny, nz, B0, tmp5, tmp2, nullptr), "OPR_Partial_X(P1_INT_PV)");
     } else if (!grad_final) {
-        ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
-        ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
+        // the gradient launches subtract themselves from the tendencies where the fused kernels apply (hq -= dp/dx: the same difference k_sub3 forms
+        // from a stored gradient, two passes per component less); this is the tail of the RHS-only entry, i.e. of an unpatched Fortran host
+        if (d->fuse && !literal && nz > 1 && tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz)) {
+            const bool okx = tlab_internal_partial_p1_sub(1, gx, nx, ny, nz, tmp1, hq[0]);
+            const bool okz = okx && tlab_internal_partial_p1_sub(3, gz, nx, ny, nz, tmp1, hq[2]);
+            if (!okx || !okz) throw Fail(TLAB_EINVAL, "internal: inconsistent fused gradient path");
+            if (!v_final) hk(launch_axpy1(hq[1], hq[1], tmp3, -1.0, n, st), "axpy1");      // hq2 - dp/dy
+            grad_sub = true;
+        } else {
+            ok(tlab_opr_partial(1, gx, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp2, nullptr), "OPR_Partial_X(p)");
+            ok(tlab_opr_partial(3, gz, TLAB_OPR_P1, nx, ny, nz, B0, tmp1, tmp4, nullptr), "OPR_Partial_Z(p)");
+        }
     }
     // ---- boundary conditions (:360-398): Dirichlet -> the tendency vanishes on the wall plane; Neumann -> the wall tendency
     // keeps d/dy = 0 there (BOUNDARY_BCS_NEUMANN_Y on the finished tendency; tmp1 is its work array as in the reference) ----
@@ -445,8 +455,8 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     if (tail_update) {
         // hq -= grad p (:348-352), wall planes (:373-375), q += dte hq (time.f90:645-664), hq *= kco (:272-297) in one pass per field
         double *gp[3] = {tmp2, tmp3, tmp4};
-        if (anel) gp[0] = gp[1] = gp[2] = nullptr;      // subtracted above, with the density weight
-        if (any_q && !anel) {   // the Neumann planes need the finished tendency first
+        if (anel || grad_sub) gp[0] = gp[1] = gp[2] = nullptr;      // subtracted above (anelastic: with the density weight)
+        if (any_q && !anel && !grad_sub) {   // the Neumann planes need the finished tendency first
             hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
             gp[0] = gp[1] = gp[2] = nullptr;
         }
@@ -461,7 +471,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             hk(launch_final_update(s[is], hs[is], nullptr, pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
         }
     } else {
-        if (!anel) hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
+        if (!anel && !grad_sub) hk(launch_sub3(hq[0], hq[1], hq[2], tmp2, tmp3, tmp4, n, st), "sub3");
         for (int iq = 0; iq < 3; ++iq) {
             planes(ibc_q[iq], hq[iq], pb, pt);
             hk(launch_set_wall_planes(hq[iq], pb, pt, nx, ny, nz, st), "wall planes");
