@@ -509,7 +509,7 @@ def test_anelastic_burgers_operators_vs_oracle(T, nx, ny, nz, stretch):
 
 
 @pytest.mark.parametrize("bcs", ["noslip", "freeslip"])
-@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (128, 64, 64, True)])
+@pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (128, 64, 64, True), (256, 64, 64, True)])      # the last: the fused Burgers launches
 def test_anelastic_substep_vs_oracle(T, nx, ny, nz, stretch, bcs):
     import torch
     from tlab_amd.dns import Dns, velocity_bcs

@@ -588,6 +588,8 @@ struct OpExtra {
     double *fdiv = nullptr;
     double fidte = 0.0;
     unsigned fresh_mask = 0;        // k_htile MODE_BURGERS: fields that overwrite their tendency in an accumulating launch
+    const double *ari = nullptr;    // MODE_BURGERS, anelastic: ribackground [ny] on the diffusion term
+    int ari_mode = 0, ari_nx = 1, ari_ny = 1;
     bool sub = false;               // MODE_P1: out0 -= value
     int fneu = 0;                   // k_rtile MODE_P1: Neumann-final epilogue (RTileArgs::fneu)
     double fcb[4] = {0, 0, 0, 0}, fct[4] = {0, 0, 0, 0};
@@ -707,6 +709,7 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.y2 = g->system(2, 0, C).dev();
     a.jc = (mode != MODE_P1) ? g->jaccorr() : JacCorrDev{nullptr};
     a.fresh_mask = ex.fresh_mask; a.fdiv = ex.fdiv; a.fidte = ex.fidte;
+    a.ari = ex.ari; a.ari_mode = ex.ari_mode; a.ari_nx = ex.ari_nx; a.ari_ny = ex.ari_ny;
     hip_check(launch_htile(mode, a, g_stream), "k_htile");
 }
 
@@ -719,6 +722,7 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; a.ffin[f] = ex.ffin[f]; }
     a.fdiv = ex.fdiv; a.fidte = ex.fidte;
+    a.ari = ex.ari; a.ari_ny = ex.ari_ny;
     a.s1 = g->stencil(1, ibc);
     a.s2 = g->stencil(2, 0);
     const int P = xline_chunks(geom.n, g);
@@ -847,10 +851,13 @@ bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, in
     g_last_path = path;
     return true;
 }
+extern "C" bool tlab_internal_anelastic();      // (defined inside the extern "C" block below)
+extern "C" bool tlab_internal_dealiasing();
 // result += nu d2s - vel ds   (only when the fully fused Burgers kernels apply)
 bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
                                double *result) {
     check_common(dir, g, nx, ny, nz, ibc);
+    if (tlab_internal_anelastic() || tlab_internal_dealiasing()) return false;      // those branches of OPR_Burgers_1D: the caller's unfused sequence
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
     OpExtra ex;
@@ -874,6 +881,14 @@ bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, i
     const int path = choose_path(dir, geom.n, g);
     return (path == PATH_XLINE && !g->t.der2.need_1der && !g->t.der2.direct) || (path == PATH_RTILE && htile_ok(geom.n, MODE_BURGERS));
 }
+// ... with the anelastic diffusion weight (tlab_internal_burgers_acc_n's ari): it exists in the wave-per-line kernel and in the 32-line tile form of k_htile
+bool tlab_internal_burgers_fusable_anelastic(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz) {
+    static const bool on = [] { const char *e = getenv("TLAB_ANELASTIC_FUSED"); return !(e && atoi(e) == 0); }();
+    if (!on || !tlab_internal_burgers_fusable(dir, g, nx, ny, nz)) return false;
+    const LineGeom geom = make_geom(dir, nx, ny, nz);
+    if (choose_path(dir, geom.n, g) == PATH_XLINE) return true;
+    return htile_chunk(geom.n, MODE_BURGERS) == 32 && geom.n / 32 <= 16 && !htile_narrow() && (dir == 2 || nx % 32 == 0);
+}
 // several transported fields, one advecting velocity: result[f] += nu[f] d2 s[f] - vel d s[f]
 // x lines of at most 512 points on the wave-per-line kernel: the launch can finish the substep of a transported field in its epilogue
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz) {
@@ -894,7 +909,7 @@ bool tlab_internal_burgers_can_div(int dir, tlab_fdm_plan_t g, int nx, int ny, i
 
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco,
-                                 int scale, double *divx, double idte, unsigned fresh_mask) {
+                                 int scale, double *divx, double idte, unsigned fresh_mask, const double *ari) {
     check_common(dir, g, nx, ny, nz, ibc);
     if (nf < 1 || nf > 4) throw Invalid("1 to 4 fields per call");
     const LineGeom geom = make_geom(dir, nx, ny, nz);
@@ -902,6 +917,11 @@ bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int
     OpExtra ex;
     ex.acc = !overwrite;        // overwrite: the tendency is known to be zero (start of a Runge-Kutta step): neither zero-filled nor read
     ex.fresh_mask = fresh_mask; // ... or only that of some fields
+    if (tlab_internal_dealiasing()) return false;
+    if (ari) {      // anelastic: ribackground [ny] (device) on the diffusion term; the epilogues are forms of the incompressible driver
+        if (finish || divx || !tlab_internal_burgers_fusable_anelastic(dir, g, nx, ny, nz)) return false;
+        ex.ari = ari; ex.ari_mode = dir == 2 ? 1 : 2; ex.ari_nx = nx; ex.ari_ny = ny;
+    }
     ex.nf = nf;
     for (int f = 0; f < nf; ++f) { ex.fs[f] = s[f]; ex.fo[f] = result[f]; ex.fnu[f] = nu[f]; }
     if (finish) {
@@ -967,7 +987,8 @@ int tlab_opr_burgers_add_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, i
         if (nf < 1 || nf > 4 || !nu || !s || !vel || !result) throw Invalid("tlab_opr_burgers_add_n: bad arguments (1 to 4 fields)");
         for (int f = 0; f < nf; ++f)
             if (!s[f] || !result[f] || result[f] == s[f] || result[f] == vel) throw Invalid("tlab_opr_burgers_add_n: null or aliased arrays");
-        if (tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result, overwrite != 0, nullptr, 0.0, 1.0, 0, nullptr, 0.0, 0u)) return;
+        if (!tlab_internal_anelastic() &&
+            tlab_internal_burgers_acc_n(dir, g, nx, ny, nz, ibc, nf, nu, s, vel, result, overwrite != 0, nullptr, 0.0, 1.0, 0, nullptr, 0.0, 0u, nullptr)) return;
         for (int f = 0; f < nf; ++f) {
             if (overwrite) hip_check(hipMemsetAsync(result[f], 0, (size_t)nx * ny * nz * sizeof(double), g_stream), "memset");
             const int rc = tlab_opr_burgers_add(dir, g, nx, ny, nz, ibc, nu[f], s[f], vel, result[f], tmp1, tmp2);

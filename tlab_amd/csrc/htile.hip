@@ -68,7 +68,9 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
 // load or store while the other solves)
 // DIV (MODE_BURGERS, one field = the advecting velocity, at most 16 chunks): RTileArgs::fdiv, the forcing term of this direction from the finished
 // tendency while the lines are still in registers.
-template <int M, int MODE, int MAXT, int L, bool DIV = false>
+// ANEL (MODE_BURGERS): 1 / 2 = anelastic diffusion weight along y / z lines (RTileArgs::ari); a template parameter because the register allocation
+// of the incompressible kernel sits at 256 and must not see the extra path
+template <int M, int MODE, int MAXT, int L, bool DIV = false, int ANEL = 0>
 __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_htile(RTileArgs a) {
     __shared__ double s_yl[32 * L];
     __shared__ double s_r[32 * L];
@@ -105,7 +107,8 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     const int row0 = c * M;
     const double *__restrict__ in0 = (MODE == MODE_BURGERS) ? a.fs[fi] : a.in0;
     double *__restrict__ out0 = (MODE == MODE_BURGERS) ? a.fo[fi] : a.out0;
-    const double nu = (MODE == MODE_BURGERS) ? a.fnu[fi] : a.nu;
+    double nu = (MODE == MODE_BURGERS) ? a.fnu[fi] : a.nu;
+    if (ANEL == 2) nu = nu * a.ari[(l0 / a.ari_nx) % a.ari_ny];      // z lines: ribackground of the tile's y row
 
     // ---- operand rows + 3-row halos: requested BEFORE the tables are staged, so that the two latencies overlap ----
     double e[M + 6];
@@ -233,8 +236,13 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
             a.out1[base + (long long)(row0 + p) * rs] = x1[p];
         }
     } else {  // MODE_BURGERS: result = nu d2 - vel d1 (opr_burgers.f90:513)
+        if (ANEL == 1) {      // y lines: ribackground(j) of every row on the diffusion term (opr_burgers.f90:128-183)
 #pragma unroll
-        for (int p = 0; p < M; ++p) x2[p] = nu * x2[p] - vl[p] * x1[p];
+            for (int p = 0; p < M; ++p) x2[p] = (nu * a.ari[row0 + p]) * x2[p] - vl[p] * x1[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < M; ++p) x2[p] = nu * x2[p] - vl[p] * x1[p];
+        }
         // the old tendency is read once and the new one is not read again before 4 GB of other traffic have passed: non-temporal accesses keep
         // them out of the way of the operand rows in L2 (3 % of the launch, measured A/B in one binary)
         if (a.acc && !((a.fresh_mask >> fi) & 1u)) {   // accumulate into the tendency: all loads first (the compiler cannot move them across the stores itself)
@@ -335,8 +343,16 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
     case MODE_BURGERS:
         if (a.fdiv) {
             if constexpr (M == 32 && MAXT == 512) {      // L = 32 with up to 16 chunks, or the 16-line tiles of 1024-point lines (32 chunks)
-                if (a.nf != 1 || a.fs[0] != a.in2 || C * L > MAXT || a.s1.rowc != nullptr) return hipErrorInvalidValue;
+                if (a.nf != 1 || a.fs[0] != a.in2 || C * L > MAXT || a.s1.rowc != nullptr || a.ari) return hipErrorInvalidValue;
                 hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true>), grid, block, lds, st, a);
+            } else {
+                return hipErrorInvalidValue;
+            }
+        } else if (a.ari) {
+            if constexpr (M == 32 && MAXT == 512 && L == 32) {
+                if (a.ari_mode == 1) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, false, 1>), grid, block, lds, st, a);
+                else if (a.ari_mode == 2 && a.ari_nx % L == 0) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, false, 2>), grid, block, lds, st, a);
+                else return hipErrorInvalidValue;
             } else {
                 return hipErrorInvalidValue;
             }

@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
             for (int f = 0; f < a.nf; ++f) {
                 const double *src = a.fs[f];
                 double *dst = a.fo[f];
-                const double nuf = a.fnu[f];
+                const double nuf = a.ari ? a.fnu[f] * a.ari[line % a.ari_ny] : a.fnu[f];      // anelastic: ribackground(j) of this line on the diffusion term
                 if constexpr (LV == 2 || (LV == 1 && M >= 16)) asm volatile("" : "+v"(y1.lds));      // ... and per field
                 if constexpr (LV2 == 2 || (LV2 == 1 && M >= 16)) asm volatile("" : "+v"(y2.lds));
                 double u[M];

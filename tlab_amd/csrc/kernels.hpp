@@ -37,6 +37,10 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     // pressure forcing, d/dx (h + fidte u) with the finished tendency h (rhs_global_incompressible_1.f90:197-230), into fdiv
     double *fdiv;
     double fidte;
+    // MODE_BURGERS, anelastic (opr_burgers.f90:128-183, :504-507): the diffusion term of a line carries ribackground(j), j = line % ari_ny (x lines
+    // run over (j, k)); ari == NULL: incompressible
+    const double *ari;
+    int ari_ny;
 };
 
 struct RTileArgs {          // k_rtile: derivative along a strided index
@@ -77,6 +81,10 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     // k_final_update follows in the same launch: q (= fq) += fdte h, h = fscale ? fkco h : h.
     int fneu;
     double fcb[4], fct[4];
+    // k_htile MODE_BURGERS, anelastic: ribackground [ari_ny] on the diffusion term -- ari_mode 1: lines along y, the factor of row j; 2: lines along z,
+    // the factor of the tile's y row, j = (first line / ari_nx) % ari_ny (32-line tiles inside one row: ari_nx % 32 == 0)
+    const double *ari;
+    int ari_mode, ari_nx, ari_ny;
 };
 
 struct GenericArgs {        // k_generic: any n

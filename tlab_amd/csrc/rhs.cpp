@@ -35,7 +35,8 @@ void tlab_internal_poisson_arm_v_final(tlab_poisson_plan_t P, double *q, double 
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, int nf, const double *nu, const double *const *s,
                                  const double *vel, double *const *result, bool overwrite, const int *finish, double dte, double kco, int scale,
-                                 double *divx, double idte, unsigned fresh_mask = 0);
+                                 double *divx, double idte, unsigned fresh_mask = 0, const double *ari = nullptr);
+bool tlab_internal_burgers_fusable_anelastic(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_burgers_can_div(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 bool tlab_internal_partial_p1_sub(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *u, double *result);
 bool tlab_internal_neumann_final_ok(tlab_fdm_plan_t g, int nx, int ny, int nz);
@@ -149,6 +150,7 @@ int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tla
 }
 
 int tlab_dns_destroy(tlab_dns_t d) {
+    if (d && d->rb) (void)tlab_opr_burgers_set_anelastic(0, nullptr, nullptr);      // the operator state this driver set (tlab_dns_set_anelastic) goes with it
     delete d;
     return TLAB_OK;
 }
@@ -199,8 +201,12 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     const bool stag = d->stagger;                 // staggered pressure grid (rhs_global_incompressible_1.f90:216-226, 266-273, 307-317)
     const bool literal = anel || stag || tlab_internal_dealiasing();
     double *tmp5 = txc[4];
-    const bool batched = !literal && d->fuse && tlab_internal_burgers_fusable(1, gx, nx, ny, nz) && tlab_internal_burgers_fusable(2, gy, nx, ny, nz) &&
-                         tlab_internal_burgers_fusable(3, gz, nx, ny, nz);
+    // (the Burgers launches themselves only care about [Dealiasing]: the anelastic diffusion weight is inside the fused kernels where
+    // tlab_internal_burgers_fusable says so, and the staggered pressure grid does not touch them; the epilogues below are incompressible forms)
+    auto burgers_ok = [&](int dir, tlab_fdm_plan_t g) {
+        return anel ? tlab_internal_burgers_fusable_anelastic(dir, g, nx, ny, nz) : tlab_internal_burgers_fusable(dir, g, nx, ny, nz);
+    };
+    const bool batched = !tlab_internal_dealiasing() && d->fuse && burgers_ok(1, gx) && burgers_ok(2, gy) && burgers_ok(3, gz);
     const bool fresh = d->fresh;       // TIME_RUNGEKUTTA zeroes hq, hs at the start of a step (time.f90:212-216): the first launch overwrites instead
     d->fresh = false;
     if (fresh && !batched) {
@@ -210,14 +216,14 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // ride on the LAST Burgers launch that adds to hs, if that launch is the x one (the wave-per-line kernel has the registers for it; the
     // y/z tile kernels do not, measured).  The directions then run z, y, x instead of x, y, z: the terms are summed in another order, rounding only.
     static const bool finish_off = [] { const char *e = getenv("TLAB_SCALAR_FINISH"); return e && atoi(e) == 0; }();
-    bool finish_scal = !finish_off && batched && tail_update && d->nscal > 0 && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
+    bool finish_scal = !finish_off && batched && !literal && tail_update && d->nscal > 0 && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
     for (int is = 0; is < d->nscal; ++is)
         finish_scal = finish_scal && d->scal_jmin[is] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[is] == TLAB_DNS_BCS_DIRICHLET;
     finish_scal = finish_scal && !any_surface;      // the wall planes of a scalar with a surface model are not zero
     // Likewise the x term of the pressure forcing, d/dx (hq1 + u/dte) (:197-230): when the x Burgers launch runs last it holds the finished
     // tendency of u in registers, line by line, and differentiates it on the spot instead of a separate launch re-reading hq1 and u.
     const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (:234-250)
-    const bool x_last = !finish_off && batched && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
+    const bool x_last = !finish_off && batched && !literal && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
     const bool div_in_burgers = x_last && d->fuse && tlab_internal_partial_p1_fusable(2, gy, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);
     // ... and the y and z terms, d/dy (hq2 + v/dte) and d/dz (hq3 + w/dte): each component gets the term of its OWN direction last, in a launch of
     // its own whose workgroups hold the finished tendency line by line and differentiate it on the spot (k_htile<BURGERS+div>).  Order of the
@@ -270,7 +276,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
                 const bool any_fin = fin[0] || fin[1] || fin[2] || fin[3];
                 double *divx = (div_in_burgers && dir == 1 && e0 == 0) ? tmp1 : nullptr;       // batch 0 holds u
                 if (!tlab_internal_burgers_acc_n(dir, d->g[dir - 1], nx, ny, nz, 0, nf, nup, sp, vel[dir - 1], rp, fresh && k == 0,
-                                                 any_fin ? fin : nullptr, dte, kco, scale_tendencies ? 1 : 0, divx, idte))
+                                                 any_fin ? fin : nullptr, dte, kco, scale_tendencies ? 1 : 0, divx, idte, 0u, anel ? d->rib : nullptr))
                     throw Fail(TLAB_EINVAL, "internal: inconsistent fused Burgers path");
             }
         }
