@@ -129,6 +129,8 @@ hipError_t launch_transpose(const double *a, double *b, int nra, int nca, hipStr
 hipError_t launch_add3(double *h, const double *a, const double *b, const double *c, long long n, hipStream_t st);
 hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1,
                         const double *q2, const double *q3, double s, long long n, hipStream_t st);
+hipError_t launch_axpy3w(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1,
+                         const double *q2, const double *q3, double s, const double *w, int nx, int ny, long long n, hipStream_t st);
 hipError_t launch_minmax_partial(const double *a, const double *v, const double *w, const double *odx, const double *ody, const double *odz,
                                  int mode, int nx, int ny, int nz, int koff, int zon, double *part, int nblocks, hipStream_t st);
 hipError_t launch_negate(double *a, long long n, hipStream_t st);
@@ -148,7 +150,7 @@ hipError_t launch_rk_update(double *q, double *h, double dte, double kco, int sc
 hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz, hipStream_t st);
 hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int ny, int nz, hipStream_t st);
 hipError_t launch_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
-                               int nx, int ny, int nz, hipStream_t st);
+                               int nx, int ny, int nz, hipStream_t st, const double *gw = nullptr);
 hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz, hipStream_t st);
 hipError_t launch_neumann_planes(const double *u, const double *du, const double *cb, const double *ct, int do_b, int do_t, double *hb,
                                  double *ht, int nx, int ny, int nz, hipStream_t st);

@@ -40,6 +40,20 @@ __global__ void __launch_bounds__(256) k_axpy3(double *__restrict__ o1, double *
         o3[i] = h3[i] + q3[i] * s;
     }
 }
+// ... and the anelastic density weight on top, o = (h + q s) * w(j)  (Thermo_Anelastic_WEIGHT_INPLACE with rbackground, :211-214): k_axpy3 + 3 x k_weight_y in one pass
+__global__ void __launch_bounds__(256) k_axpy3w(double *__restrict__ o1, double *__restrict__ o2, double *__restrict__ o3,
+                                                const double *__restrict__ h1, const double *__restrict__ h2, const double *__restrict__ h3,
+                                                const double *__restrict__ q1, const double *__restrict__ q2, const double *__restrict__ q3,
+                                                double s, const double *__restrict__ w, int nx, int ny, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double wj = w[(i / nx) % ny];
+        const double t1 = h1[i] + q1[i] * s, t2 = h2[i] + q2[i] * s, t3 = h3[i] + q3[i] * s;
+        o1[i] = t1 * wj;
+        o2[i] = t2 * wj;
+        o3[i] = t3 * wj;
+    }
+}
 
 // a = a + b + c             (tmp1 = tmp1 + tmp2 + tmp3, :257-259)
 __global__ void __launch_bounds__(256) k_sum3(double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, long long n) {
@@ -139,13 +153,14 @@ __global__ void __launch_bounds__(256) k_neumann_planes(const double *__restrict
 
 // fused tail of the substep for one velocity component (rhs_global_incompressible_1.f90:348-352, :373-375; time.f90:645-664, :272-297):
 //   h = h - g (pressure gradient); h = 0 on the wall planes j = 1, ny; q = q + dte*h; h = kco*h (if scale)
+// gw != NULL: h = h - g gw(j), the anelastic form (Thermo_Anelastic_WEIGHT_SUBTRACT with ribackground, :326-329)
 __global__ void __launch_bounds__(256) k_final_update(double *__restrict__ q, double *__restrict__ h, const double *__restrict__ g,
                                                       const double *__restrict__ pb, const double *__restrict__ pt, double dte,
-                                                      double kco, int scale, int nx, int ny, long long n) {
+                                                      double kco, int scale, int nx, int ny, long long n, const double *__restrict__ gw) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int j = (int)((i / nx) % ny);
-        double hv = g ? h[i] - g[i] : h[i];
+        double hv = g ? (gw ? h[i] - g[i] * gw[j] : h[i] - g[i]) : h[i];
         if (j == 0) hv = pb ? pb[(i % nx) + (long long)nx * (i / ((long long)nx * ny))] : 0.0;
         else if (j == ny - 1) hv = pt ? pt[(i % nx) + (long long)nx * (i / ((long long)nx * ny))] : 0.0;
         q[i] = q[i] + dte * hv;
@@ -343,10 +358,10 @@ hipError_t launch_axpy1(double *o, const double *a, const double *b, double s, l
 }
 
 hipError_t launch_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
-                               int nx, int ny, int nz, hipStream_t st) {
+                               int nx, int ny, int nz, hipStream_t st, const double *gw) {
     const long long n = (long long)nx * ny * nz;
     ProfScope ps("k_final_update", st, (double)n * (g ? 40 : 32));
-    hipLaunchKernelGGL(k_final_update, dim3(pw_grid(n)), dim3(256), 0, st, q, h, g, pb, pt, dte, kco, scale, nx, ny, n);
+    hipLaunchKernelGGL(k_final_update, dim3(pw_grid(n)), dim3(256), 0, st, q, h, g, pb, pt, dte, kco, scale, nx, ny, n, gw);
     return CHECK_LAUNCH();
 }
 
@@ -359,6 +374,12 @@ hipError_t launch_axpy3(double *o1, double *o2, double *o3, const double *h1, co
                         const double *q2, const double *q3, double s, long long n, hipStream_t st) {
     ProfScope ps("k_axpy3", st, (double)n * 72);
     hipLaunchKernelGGL(k_axpy3, dim3(pw_grid(n)), dim3(256), 0, st, o1, o2, o3, h1, h2, h3, q1, q2, q3, s, n);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_axpy3w(double *o1, double *o2, double *o3, const double *h1, const double *h2, const double *h3, const double *q1,
+                         const double *q2, const double *q3, double s, const double *w, int nx, int ny, long long n, hipStream_t st) {
+    ProfScope ps("k_axpy3w", st, (double)n * 72);
+    hipLaunchKernelGGL(k_axpy3w, dim3(pw_grid(n)), dim3(256), 0, st, o1, o2, o3, h1, h2, h3, q1, q2, q3, s, w, nx, ny, n);
     return CHECK_LAUNCH();
 }
 hipError_t launch_sum3(double *a, const double *b, const double *c, long long n, hipStream_t st) {

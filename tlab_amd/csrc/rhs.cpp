@@ -316,11 +316,15 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         }
     }
     if (!fused_div) {
-        hk(launch_axpy3(tmp2, tmp3, tmp4, hq[1], hq[0], hq[2], v, u, w, idte, n, st), "axpy3");
-        if (anel) {      // Thermo_Anelastic_WEIGHT_INPLACE(.., rbackground, tmp2 | tmp3 | tmp4)  (:211-214)
-            hk(launch_weight_y(tmp2, tmp2, d->rb, nx, ny, n, 0, st), "weight");
-            hk(launch_weight_y(tmp3, tmp3, d->rb, nx, ny, n, 0, st), "weight");
-            hk(launch_weight_y(tmp4, tmp4, d->rb, nx, ny, n, 0, st), "weight");
+        if (anel && d->fuse) {      // ... with Thermo_Anelastic_WEIGHT_INPLACE(.., rbackground, tmp2 | tmp3 | tmp4) (:211-214) in the same pass
+            hk(launch_axpy3w(tmp2, tmp3, tmp4, hq[1], hq[0], hq[2], v, u, w, idte, d->rb, nx, ny, n, st), "axpy3w");
+        } else {
+            hk(launch_axpy3(tmp2, tmp3, tmp4, hq[1], hq[0], hq[2], v, u, w, idte, n, st), "axpy3");
+            if (anel) {      // Thermo_Anelastic_WEIGHT_INPLACE(.., rbackground, tmp2 | tmp3 | tmp4)  (:211-214)
+                hk(launch_weight_y(tmp2, tmp2, d->rb, nx, ny, n, 0, st), "weight");
+                hk(launch_weight_y(tmp3, tmp3, d->rb, nx, ny, n, 0, st), "weight");
+                hk(launch_weight_y(tmp4, tmp4, d->rb, nx, ny, n, 0, st), "weight");
+            }
         }
         if (stag) {      // the three terms on the horizontal pressure nodes (:216-226)
             ok(tlab_opr_partial(1, gx, TLAB_OPR_P0_INT_VP, nx, ny, nz, B0, tmp2, tmp5, nullptr), "OPR_Partial_X(P0_INT_VP)");      // Oy derivative
@@ -453,10 +457,15 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         if (d->sfc_jmax[is] == 1) hk(launch_surface_flux(d->sref_t[is], tmp1, ny - 1, 0, -1.0, diff, d->cpl_jmax[is], d->sfc_avg, nx, ny, nz, st), "surface flux");
         qb = d->sref_b[is]; qt = d->sref_t[is];
     };
-    if (anel) {          // Thermo_Anelastic_WEIGHT_SUBTRACT(.., ribackground, tmp2 | tmp3 | tmp4, hq(:,1) | hq(:,2) | hq(:,3))  (:326-329)
-        hk(launch_weight_y(hq[0], tmp2, d->rib, nx, ny, n, 1, st), "weight");
-        hk(launch_weight_y(hq[1], tmp3, d->rib, nx, ny, n, 1, st), "weight");
-        hk(launch_weight_y(hq[2], tmp4, d->rib, nx, ny, n, 1, st), "weight");
+    // Thermo_Anelastic_WEIGHT_SUBTRACT(.., ribackground, tmp2 | tmp3 | tmp4, hq(:,1) | hq(:,2) | hq(:,3))  (:326-329): a pass of its own, or -- for a
+    // component with Dirichlet walls whose Runge-Kutta update follows -- the operand of that update (k_final_update with gw)
+    bool gw_defer[3] = {false, false, false};
+    if (anel) {
+        double *gt[3] = {tmp2, tmp3, tmp4};
+        for (int iq = 0; iq < 3; ++iq) {
+            gw_defer[iq] = tail_update && d->fuse && ibc_q[iq] == 0;
+            if (!gw_defer[iq]) hk(launch_weight_y(hq[iq], gt[iq], d->rib, nx, ny, n, 1, st), "weight");
+        }
     }
     if (tail_update) {
         // hq -= grad p (:348-352), wall planes (:373-375), q += dte hq (time.f90:645-664), hq *= kco (:272-297) in one pass per field
@@ -470,7 +479,12 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             if (grad_final && iq != 1) continue;          // u and w are finished already
             if (v_final && iq == 1) continue;             // v too (inside OPR_Poisson)
             planes(ibc_q[iq], hq[iq], pb, pt);
-            hk(launch_final_update(q[iq], hq[iq], gp[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+            if (gw_defer[iq]) {
+                double *gt[3] = {tmp2, tmp3, tmp4};
+                hk(launch_final_update(q[iq], hq[iq], gt[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st, d->rib), "final update");
+            } else {
+                hk(launch_final_update(q[iq], hq[iq], gp[iq], pb, pt, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
+            }
         }
         for (int is = 0; is < d->nscal && !finish_scal; ++is) {      // (finish_scal: done in the epilogue of the x Burgers launch)
             scal_planes(is, pb, pt);
