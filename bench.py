@@ -123,6 +123,9 @@ def main():
                     "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
     ap.add_argument("--decomp", default="", metavar="IxK", help="diagnostic: x/z pencil decomposition npro_i x npro_k (tlab_amd/pencil.py), e.g. 2x4: with "
                     "--gpus N = I*K one block per GPU, otherwise all I*K ranks inside this one process/GPU (loopback); the default multi-GPU run is 1 x N z-slabs")
+    ap.add_argument("--slab-driver", default="native", choices=["native", "python"], help="z-slab runs (--gpus N > 1, --loopback P): native = the C++ driver behind "
+                    "tlab_slab_dns_* (tlab_amd/csrc/slab.cpp; RCCL transport of libtlab_amd_comm.so), the code a Fortran / MPI host runs; python = its "
+                    "cross-check tlab_amd/parallel.py::SlabDns over torch.distributed (diagnostic)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="n of the n^3 CPU-baseline sample (0 disables)")
     ap.add_argument("--cpu-sample-large", type=int, default=512, help="second, larger CPU-baseline sample, run only on hosts with at least --cpu-large-min-cores CPUs (0 disables)")
     ap.add_argument("--cpu-large-min-cores", type=int, default=48)
@@ -197,8 +200,9 @@ def main():
             d.substep_of_cycle(k, dtime)
     elif world == 1 and args.loopback > 1:
         from tlab_amd.parallel import SlabDns, LoopbackComm
-        d = SlabDns(LoopbackComm(args.loopback), x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True,
-                    rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
+        from tlab_amd.slab import NativeSlabDns
+        kw = dict(nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
+        d = NativeSlabDns("loopback", x, y, z, size=args.loopback, **kw) if args.slab_driver == "native" else SlabDns(LoopbackComm(args.loopback), x, y, z, **kw)
         state_fields = []
         for r in range(args.loopback):
             S = d.st[r]
@@ -223,10 +227,12 @@ def main():
             last = s == d.rkm_endstep - 1
             d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * d.kdt[s], 1.0 if last else d.kco[s], not last)
     else:
-        # STRONG scaling of the same n^3 box: z-slabs (1 x N pencils), K-transposes by RCCL all-to-all (tlab_amd/parallel.py)
+        # STRONG scaling of the same n^3 box over z-slabs (1 x N): the native driver (tlab_amd/csrc/slab.cpp) with its exchanges as grouped
+        # ncclSend / ncclRecv on the communication stream of libtlab_amd_comm.so -- the same calls a Fortran / MPI host makes
         from tlab_amd.parallel import SlabDns, DistComm
-        d = SlabDns(DistComm(), x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3,
-                    hyper_bc1_ext=HYPER_BC1_EXT)
+        from tlab_amd.slab import NativeSlabDns
+        kw = dict(nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
+        d = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, **kw) if args.slab_driver == "native" else SlabDns(DistComm(), x, y, z, **kw)
         S = d.st[rank]
         synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
         state_fields = S["q"] + S["s"]
@@ -300,8 +306,8 @@ def main():
                                    % (nx, ny, nz, args.nscal),
                        "grid": [nx, ny, nz], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper (consistent wall closure)", "reynolds": 5000,
                        "parallelism": ("DIAGNOSTIC: x/z pencils %s (%s), I-/K-transpositions per x/z operator, Poisson on kx-pencils" % (args.decomp, "one block per GPU" if world > 1 else "all ranks back to back on one GPU, exchanges = copies")) if args.decomp else
-                                      ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode) executed back to back on one GPU, no communication" % (args.loopback, d.zmode)) if world == 1 else
-                       ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep), %s" % (world, "RCCL" if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
+                                      ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode, %s driver) executed back to back on one GPU, no communication" % (args.loopback, d.zmode, args.slab_driver)) if world == 1 else
+                       ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep in two pipelined halves), %s driver, %s" % (world, args.slab_driver, "RCCL" if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
                        "fields_finite": finite},
             "roofline": None if dom is None else {
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

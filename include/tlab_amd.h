@@ -373,6 +373,67 @@ int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double k
                                               double *const *q, double *const *s, double *const *hq, double *const *hs,
                                               double *const *txc);
 
+/* ---- the decomposed substep: RHS_GLOBAL_INCOMPRESSIBLE_1 / TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT with ims_npro_k > 1 ----------------
+ * z-slabs (ims_npro_i x ims_npro_k = 1 x P, base/tlab_mpi_procs.f90:76-94): x- and y-operators are local.  What the reference does with a
+ * K-transposition around every z-operator and z-FFT (operators/opr_partial.f90:185-195, 248-253; physics/opr_burgers.f90:386-426;
+ * operators/opr_fourier.f90:343-428; base/tlab_mpi_transpose.f90:343-553) is done here without transposing a field for a derivative: the compact
+ * z-systems are partitioned at the slab boundaries (tlab_zslab_* above: 3 halo planes of the operand + one value per line and system from each ring
+ * neighbour), and the Poisson solver goes z-slab -> kx-pencil with ONE all-to-all after the x-FFT and one per output field on the way back, pipelined
+ * in two kx halves against the per-mode solves (tlab_amd/csrc/slab.cpp).  The exchanges go through a transport the caller hands in:
+ *   - tlab_comm_slab_transport (libtlab_amd_comm.so): RCCL grouped ncclSend / ncclRecv on the library's communication stream, so that the x / y
+ *     operators on the compute stream (tlab_set_stream) run while halo planes, interface values and pencil blocks travel over xGMI;
+ *   - tlab_slab_transport_loopback: all P ranks inside one process on one device (exchanges = device copies): the complete decomposed algorithm
+ *     against the single-domain result on a single GPU;
+ *   - any other struct of these five entry points: a Fortran host's GPU-aware MPI (MPI_Isend / MPI_Irecv / MPI_Alltoallv on device pointers), or the
+ *     host-staged gloo processes of the tests.
+ * All counts are doubles, all buffers DEVICE pointers; `stream` is the caller's compute stream (hipStream_t).  An exchange must not start before the
+ * work enqueued on `stream` up to the call has finished, and must be complete for the work enqueued on `stream` after `wait` of its ticket. */
+typedef struct tlab_slab_transport {
+    void *ctx;
+    int nranks;           /* ims_npro_k                                                                                              */
+    int nlocal;           /* ranks this process executes: 1, or nranks for the single-process loopback                                */
+    int first;            /* ims_pro_k of the first (or only) local rank                                                              */
+    /* Periodic ring in z.  For the local rank l < nlocal and the message i < nmsg (count[i] doubles): to_left[l*nmsg + i] arrives in from_right[..]
+     * of rank - 1, to_right[l*nmsg + i] in from_left[..] of rank + 1.  With two ranks both neighbours are the same peer: sends are posted left then
+     * right, receives from the right then from the left.  Returns a ticket >= 0, or a negative TLAB_E* code. */
+    int (*ring_start)(void *ctx, void *stream, int nmsg, const long long *count, double *const *to_left, double *const *to_right,
+                      double *const *from_right, double *const *from_left);
+    /* MPI_Alltoallv among the nranks: send[l] holds the blocks for rank 0, 1, .. back to back, scount[l*nranks + p] doubles each; recv[l] / rcount
+     * likewise by source.  Returns a ticket. */
+    int (*alltoallv_start)(void *ctx, void *stream, double *const *send, const long long *scount, double *const *recv, const long long *rcount);
+    int (*wait)(void *ctx, void *stream, int ticket);
+    /* MPI_ALLREDUCE of n HOST doubles per local rank (values[l*n + i]), in place; op 0 = MPI_MAX, 1 = MPI_MIN (tools/dns/time.f90:522) */
+    int (*allreduce)(void *ctx, double *values, int n, int op);
+    void (*destroy)(void *ctx);     /* may be NULL */
+} tlab_slab_transport;
+int tlab_slab_transport_loopback(tlab_slab_transport *out, int nranks);
+
+typedef struct tlab_slab_dns *tlab_slab_dns_t;
+/* gx, gy: the local plans; gz: the plan of the GLOBAL z direction (nz_total nodes).  kmax = nz_total / nranks planes per rank; returns
+ * TLAB_EUNSUPPORTED when the slabs are too thin for the partitioned z-systems (kmax <~ 50: tlab_zslab_plan_create) -- such runs keep the
+ * reference's K-transposition scheme.  gy_elliptic: NULL, or the y plan of EllipticOrder = CompactDirect6 (tlab_poisson_plan_create_direct).
+ * The plans are not owned; the transport struct is copied (its destroy, if any, runs in tlab_slab_dns_destroy). */
+int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *transport, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                         int nx, int ny, int nz_total, int nscal, double visc, const double *schmidt, tlab_fdm_plan_t gy_elliptic);
+int tlab_slab_dns_destroy(tlab_slab_dns_t d);
+/* The module arrays of local rank l (0 for a one-rank process): q[3], s[nscal], hq[3], hs[nscal], txc[9] as tlab_rhs_global_incompressible_1
+ * (HOST arrays of DEVICE pointers; txc of (nx+2)*ny*kmax doubles each).  Every array must have tlab_slab_dns_info(d, 3) doubles of room BEFORE its
+ * first element and AFTER its nx*ny*kmax-th one: the neighbours' halo planes land there (the allocation hook of the Fortran host adds that room when
+ * ims_npro_k > 1).  The pointers are kept: call again if the host moves its arrays. */
+int tlab_slab_dns_bind(tlab_slab_dns_t d, int l, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc);
+/* what: 0 kmax, 1 nranks, 2 nlocal, 3 halo room in doubles (3 planes), 4 pipeline stages of the pencil exchange, 5 first local rank */
+long long tlab_slab_dns_info(tlab_slab_dns_t d, int what);
+int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
+int tlab_slab_dns_begin_step(tlab_slab_dns_t d);                 /* as tlab_dns_begin_step */
+/* RHS_GLOBAL_INCOMPRESSIBLE_1 on the bound arrays of all local ranks (tools/dns/rhs_global_incompressible_1.f90:98-398) */
+int tlab_slab_dns_rhs(tlab_slab_dns_t d, double dte);
+/* TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT (tools/dns/time.f90:559-664 + :261-298): RHS with the RK update folded into its last passes */
+int tlab_slab_dns_substep(tlab_slab_dns_t d, double dte, double kco, int scale_tendencies);
+/* TIME_COURANT with the MPI_MAX of time.f90:522: pmax[2] and dtime (may be NULL) are the same on every rank */
+int tlab_slab_dns_time_courant(tlab_slab_dns_t d, double cfla, double cfld, double *pmax, double *dtime);
+/* DNS_BOUNDS_CONTROL (tools/dns/dns_local.f90:157-187): extremes of div(q) over the whole box; destroys txc[0], txc[1] */
+int tlab_slab_dns_dilatation_bounds(tlab_slab_dns_t d, double *dil_min, double *dil_max);
+
 /* The pointwise loops of the RHS / RK update as separate calls (rhs_global_incompressible_1.f90:106-112, :197-201, :257-259,
  * :348-352, :279-280, :373-375; time.f90:645-664 + :272-297), for drivers that interleave communication. */
 int tlab_pw_add3(double *h, const double *a, const double *b, const double *c, long long n);             /* h += a + b + c   */

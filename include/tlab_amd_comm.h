@@ -18,6 +18,8 @@
 
 #include <stddef.h>
 
+#include "tlab_amd.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -37,6 +39,11 @@ int tlab_comm_destroy(tlab_comm_t comm);
 int tlab_comm_info(tlab_comm_t comm, int what);   /* 0 ims_pro, 1 ims_npro, 2 ims_pro_i, 3 ims_npro_i, 4 ims_pro_k, 5 ims_npro_k */
 /* MPI_ALLREDUCE(.., MPI_MAX, ..) of TIME_COURANT (tools/dns/time.f90:522) on n device doubles, in place, on the current stream */
 int tlab_comm_allreduce_max(tlab_comm_t comm, double *dev_values, int n);
+
+/* The exchanges of the native z-slab driver (tlab_slab_dns_create, include/tlab_amd.h) over this communicator's z direction: ring neighbours and
+ * all-to-all-v as grouped ncclSend / ncclRecv on the library's communication stream, MPI_MAX / MPI_MIN as ncclAllReduce.  Needs npro_i = 1.
+ * The struct refers to comm, which must outlive the driver made from it. */
+int tlab_comm_slab_transport(tlab_comm_t comm, tlab_slab_transport *out);
 
 /* TLabMPI_Trp_PlanI (dir = 1) / TLabMPI_Trp_PlanK (dir = 3)   base/tlab_mpi_transpose.f90:205-286, 290-339
  *   dir = 1: nmax = imax, npage = jmax*kmax:  local a(imax, npage)  <->  b(imax*npro_i, nlines), nlines = npage / npro_i

@@ -26,6 +26,39 @@ def test_multiprocess_slabs(world, zmode, nz, bcs):
     assert "DIST_CHECK" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
 
 
+@pytest.mark.parametrize("world,nz,bcs", [(2, 128, "noslip"), (3, 192, "freeslip")])
+def test_multiprocess_native_slab_driver(world, nz, bcs):
+    """The C++ slab driver (tlab_slab_dns_*), one rank per PROCESS, with the five transport entry points supplied by the caller (ctypes callbacks over
+    gloo with host-staged payloads, tlab_amd/slab.py::dist_transport): rank-local plans, ring pairing with 2 and 3 ranks, uneven kx-pencils in two
+    halves, monitors -- against the single-domain step each rank computes redundantly."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, TLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29570 + world), os.path.join(ROOT, "tools", "dist_check.py"), "--driver", "native", "--nz", str(nz), "--bcs", bcs,
+           "--nx", "32" if world != 3 else "48"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "DIST_CHECK driver=native" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_native_slab_driver_over_rccl_world_size_one():
+    """The product transport (grouped ncclSend / ncclRecv on the communication stream of libtlab_amd_comm.so, events against the compute stream,
+    ncclAllReduce of the monitors) under the C++ slab driver.  One GPU here, so one rank that is its own ring neighbour and all-to-all peer: every
+    call, the ticket / event logic and the stream ordering are exercised, traffic between different GPUs is not."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TLAB_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(ROOT, "tools", "dist_check.py"), "--driver", "native", "--nz", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "DIST_CHECK driver=native world=1" in out.stdout and "backend=nccl" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
+
+
 def test_rccl_operations_of_the_slab_driver():
     """DistComm on the RCCL backend with device buffers (what `bench.py --gpus N` uses).  The test box has one GPU, so one rank:
     every peer is the rank itself, but the calls, the grouped send/recv and the stream ordering are RCCL's.  Followed by the

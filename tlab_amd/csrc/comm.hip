@@ -63,6 +63,11 @@ struct tlab_comm {
     ncclComm_t world = nullptr, cx = nullptr, cz = nullptr;
     int nranks = 1, rank = 0, npro_i = 1, npro_k = 1, pro_i = 0, pro_k = 0;
     hipStream_t stream = nullptr;      // the library's communication stream
+    // slab transport (tlab_comm_slab_transport): events of the exchanges in flight, device scratch of the all-reduce
+    static constexpr int NEV = 64;
+    hipEvent_t ev_start[NEV] = {}, ev_done[NEV] = {};
+    int next_ticket = 0;
+    double *red = nullptr;
 };
 
 struct tlab_trp_plan {
@@ -99,7 +104,118 @@ int guard(const Fail &f) {
 
 }  // namespace
 
+// ---- tlab_slab_transport over RCCL (include/tlab_amd.h: the exchanges of the z-slab driver, csrc/slab.cpp) ----------------------------------
+// Every exchange is one grouped ncclSend / ncclRecv on the communication stream: it starts after the work enqueued on the caller's stream so far
+// (event), and the caller's stream takes it up again at `wait` (event) -- in between the x / y operators run beside it.  Exchanges are issued in
+// program order on every rank, so the in-order communication stream matches them up.
+namespace {
+
+ncclComm_t zcomm(tlab_comm *c) { return c->cz ? c->cz : c->world; }
+
+int slab_begin(tlab_comm *c, hipStream_t cur) {
+    const int t = c->next_ticket;
+    c->next_ticket = (t + 1) % tlab_comm::NEV;
+    if (!c->ev_start[t]) {
+        hipc(hipEventCreateWithFlags(&c->ev_start[t], hipEventDisableTiming), "hipEventCreate");
+        hipc(hipEventCreateWithFlags(&c->ev_done[t], hipEventDisableTiming), "hipEventCreate");
+    }
+    hipc(hipEventRecord(c->ev_start[t], cur), "hipEventRecord");
+    hipc(hipStreamWaitEvent(c->stream, c->ev_start[t], 0), "hipStreamWaitEvent");
+    return t;
+}
+
+int slab_ring_start(void *ctx, void *stream, int nmsg, const long long *count, double *const *to_left, double *const *to_right, double *const *from_right,
+                    double *const *from_left) {
+    try {
+        tlab_comm *c = static_cast<tlab_comm *>(ctx);
+        const int P = c->npro_k, me = c->pro_k, left = (me + P - 1) % P, right = (me + 1) % P;
+        const int t = slab_begin(c, (hipStream_t)stream);
+        ncclComm_t nc = zcomm(c);
+        ncc(ncclGroupStart(), "ncclGroupStart");
+        for (int i = 0; i < nmsg; ++i) ncc(ncclSend(to_left[i], (size_t)count[i], ncclDouble, left, nc, c->stream), "ncclSend");
+        for (int i = 0; i < nmsg; ++i) ncc(ncclSend(to_right[i], (size_t)count[i], ncclDouble, right, nc, c->stream), "ncclSend");
+        for (int i = 0; i < nmsg; ++i) ncc(ncclRecv(from_right[i], (size_t)count[i], ncclDouble, right, nc, c->stream), "ncclRecv");
+        for (int i = 0; i < nmsg; ++i) ncc(ncclRecv(from_left[i], (size_t)count[i], ncclDouble, left, nc, c->stream), "ncclRecv");
+        ncc(ncclGroupEnd(), "ncclGroupEnd");
+        hipc(hipEventRecord(c->ev_done[t], c->stream), "hipEventRecord");
+        return t;
+    } catch (const Fail &f) {
+        tlab_set_error(f.msg);
+        return f.code;
+    }
+}
+
+int slab_alltoallv_start(void *ctx, void *stream, double *const *send, const long long *scount, double *const *recv, const long long *rcount) {
+    try {
+        tlab_comm *c = static_cast<tlab_comm *>(ctx);
+        const int P = c->npro_k, me = c->pro_k;
+        const int t = slab_begin(c, (hipStream_t)stream);
+        ncclComm_t nc = zcomm(c);
+        long long so = 0, ro = 0, my_so = 0, my_ro = 0;
+        ncc(ncclGroupStart(), "ncclGroupStart");
+        for (int q = 0; q < P; ++q) {
+            if (q == me) { my_so = so; my_ro = ro; }
+            else {
+                if (scount[q] > 0) ncc(ncclSend(send[0] + so, (size_t)scount[q], ncclDouble, q, nc, c->stream), "ncclSend");
+                if (rcount[q] > 0) ncc(ncclRecv(recv[0] + ro, (size_t)rcount[q], ncclDouble, q, nc, c->stream), "ncclRecv");
+            }
+            so += scount[q];
+            ro += rcount[q];
+        }
+        ncc(ncclGroupEnd(), "ncclGroupEnd");
+        if (scount[me] != rcount[me]) throw Fail{TLAB_EINVAL, "slab transport: own block sizes differ"};
+        if (scount[me] > 0)
+            hipc(hipMemcpyAsync(recv[0] + my_ro, send[0] + my_so, (size_t)scount[me] * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync (own block)");
+        hipc(hipEventRecord(c->ev_done[t], c->stream), "hipEventRecord");
+        return t;
+    } catch (const Fail &f) {
+        tlab_set_error(f.msg);
+        return f.code;
+    }
+}
+
+int slab_wait(void *ctx, void *stream, int ticket) {
+    try {
+        tlab_comm *c = static_cast<tlab_comm *>(ctx);
+        if (ticket < 0 || ticket >= tlab_comm::NEV || !c->ev_done[ticket]) throw Fail{TLAB_EINVAL, "slab transport: unknown ticket"};
+        hipc(hipStreamWaitEvent((hipStream_t)stream, c->ev_done[ticket], 0), "hipStreamWaitEvent");
+        return TLAB_OK;
+    } catch (const Fail &f) {
+        tlab_set_error(f.msg);
+        return f.code;
+    }
+}
+
+int slab_allreduce(void *ctx, double *values, int n, int op) {
+    try {
+        tlab_comm *c = static_cast<tlab_comm *>(ctx);
+        if (n < 1 || n > 64) throw Fail{TLAB_EINVAL, "slab transport: all-reduce of 1..64 values"};
+        if (!c->red) hipc(hipMalloc((void **)&c->red, 64 * sizeof(double)), "hipMalloc");
+        hipStream_t st = tlab_current_stream();
+        hipc(hipMemcpyAsync(c->red, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+        ncc(ncclAllReduce(c->red, c->red, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclMin, zcomm(c), st), "ncclAllReduce");
+        hipc(hipMemcpyAsync(values, c->red, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+        hipc(hipStreamSynchronize(st), "hipStreamSynchronize");
+        return TLAB_OK;
+    } catch (const Fail &f) {
+        tlab_set_error(f.msg);
+        return f.code;
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
+int tlab_comm_slab_transport(tlab_comm_t c, tlab_slab_transport *out) {
+    if (!c || !out) { tlab_set_error("tlab_comm_slab_transport: null argument"); return TLAB_EINVAL; }
+    if (c->npro_i != 1) { tlab_set_error("tlab_comm_slab_transport: the slab driver is the 1 x npro_k decomposition (ims_npro_i = 1)"); return TLAB_EUNSUPPORTED; }
+    out->ctx = c;
+    out->nranks = c->npro_k; out->nlocal = 1; out->first = c->pro_k;
+    out->ring_start = slab_ring_start; out->alltoallv_start = slab_alltoallv_start; out->wait = slab_wait; out->allreduce = slab_allreduce;
+    out->destroy = nullptr;       // the communicator stays the caller's (tlab_comm_destroy)
+    return TLAB_OK;
+}
 
 int tlab_comm_get_unique_id(void *id_bytes) {
     try {
@@ -137,6 +253,11 @@ int tlab_comm_init(tlab_comm_t *out, const void *id_bytes, int nranks, int rank,
 int tlab_comm_destroy(tlab_comm_t c) {
     if (!c) return TLAB_OK;
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (int i = 0; i < tlab_comm::NEV; ++i) {
+        if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+    }
+    if (c->red) (void)hipFree(c->red);
     if (c->cx) (void)ncclCommDestroy(c->cx);
     if (c->cz) (void)ncclCommDestroy(c->cz);
     if (c->world) (void)ncclCommDestroy(c->world);

@@ -1,0 +1,669 @@
+// RHS_GLOBAL_INCOMPRESSIBLE_1 / TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT on z-slabs (ims_npro_i x ims_npro_k = 1 x P), native driver.
+//
+// Reference: the same operator list as rhs.cpp (tools/dns/rhs_global_incompressible_1.f90:98-398) with the MPI branches of the z-operators --
+// OPR_Partial_Z (operators/opr_partial.f90:185-195, 248-253), OPR_Burgers_Z (physics/opr_burgers.f90:386-426), OPR_Fourier_Z_Forward / _Backward
+// (operators/opr_fourier.f90:343-428), each of which wraps its 1-D work in TLabMPI_Trp_ExecK_Forward / _Backward (base/tlab_mpi_transpose.f90:343-458).
+// Here no field is transposed for a derivative:
+//   * z-derivatives: the compact systems are partitioned at the slab boundaries (zslab.hip).  An operator needs 3 halo planes of its operand and,
+//     per line and implicit system, one value from each ring neighbour ("head" to the left, "tail" to the right).  The z-terms come last in every
+//     equation, so that those messages travel on the transport's stream while the x / y operators run on the compute stream.
+//   * OPR_Poisson: z-slab -> kx-pencil with ONE all-to-all after the x-FFT (z-FFT, per-mode solves and inverse z-FFT are local on the pencil) and one
+//     per output field on the way back; every rank's kx range is cut in two halves with a plan each, and the six half-size all-to-alls queue up as
+//     fwd A, fwd B, back p A, back dp A, back p B, back dp B: the solves of A run under fwd B, those of B under the returns of A.
+// The exchanges go through a tlab_slab_transport (include/tlab_amd.h): RCCL (comm.hip), the single-process loopback below, or the caller's own.
+// This file holds host logic only; every kernel is reached through the C ABI of the operator library, as a Fortran host would reach it.
+#include "../../include/tlab_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+extern hipStream_t tlab_current_stream();
+extern void tlab_set_error(const std::string &s);
+extern bool tlab_device_ready();
+
+namespace {
+
+struct Fail : std::runtime_error {
+    int code;
+    Fail(int c, const std::string &s) : std::runtime_error(s), code(c) {}
+};
+void ok(int rc, const char *what) {
+    if (rc != TLAB_OK) throw Fail(rc, std::string(what) + ": " + tlab_last_error());
+}
+void hk(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Fail(TLAB_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+double *dalloc(size_t ndoubles) {
+    double *p = nullptr;
+    hk(hipMalloc((void **)&p, std::max<size_t>(ndoubles, 1) * sizeof(double)), "hipMalloc");
+    hk(hipMemset(p, 0, std::max<size_t>(ndoubles, 1) * sizeof(double)), "hipMemset");
+    return p;
+}
+
+constexpr int HALO = 3;      // planes each side: the 7-diagonal right-hand side of the second derivative reaches 3 rows
+
+// ---- single-process loopback transport: every exchange is a set of device copies on the caller's stream ----
+struct Loopback {
+    int P;
+};
+int lb_ring(void *ctx, void *stream, int nmsg, const long long *count, double *const *to_left, double *const *to_right, double *const *from_right,
+            double *const *from_left) {
+    const int P = static_cast<Loopback *>(ctx)->P;
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < P; ++r) {
+        const int left = (r + P - 1) % P, right = (r + 1) % P;
+        for (int i = 0; i < nmsg; ++i) {
+            const size_t bytes = (size_t)count[i] * sizeof(double);
+            if (hipMemcpyAsync(from_right[left * nmsg + i], to_left[r * nmsg + i], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return TLAB_EHIP;
+            if (hipMemcpyAsync(from_left[right * nmsg + i], to_right[r * nmsg + i], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return TLAB_EHIP;
+        }
+    }
+    return 0;
+}
+int lb_a2a(void *ctx, void *stream, double *const *send, const long long *scount, double *const *recv, const long long *rcount) {
+    const int P = static_cast<Loopback *>(ctx)->P;
+    hipStream_t st = (hipStream_t)stream;
+    for (int dst = 0; dst < P; ++dst) {
+        long long ro = 0;
+        for (int src = 0; src < P; ++src) {
+            long long so = 0;
+            for (int p = 0; p < dst; ++p) so += scount[src * P + p];
+            const long long cnt = scount[src * P + dst];
+            if (cnt != rcount[dst * P + src]) return TLAB_EINVAL;
+            if (cnt > 0 && hipMemcpyAsync(recv[dst] + ro, send[src] + so, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return TLAB_EHIP;
+            ro += cnt;
+        }
+    }
+    return 0;
+}
+int lb_wait(void *, void *, int) { return TLAB_OK; }
+int lb_allreduce(void *ctx, double *v, int n, int op) {
+    const int P = static_cast<Loopback *>(ctx)->P;
+    for (int i = 0; i < n; ++i) {
+        double a = v[i];
+        for (int r = 1; r < P; ++r) a = op == 0 ? std::max(a, v[r * n + i]) : std::min(a, v[r * n + i]);
+        for (int r = 0; r < P; ++r) v[r * n + i] = a;
+    }
+    return TLAB_OK;
+}
+void lb_destroy(void *ctx) { delete static_cast<Loopback *>(ctx); }
+
+// one local rank
+struct Rank {
+    int r = 0;                                   // ims_pro_k
+    tlab_zslab_plan_t zplan = nullptr;
+    tlab_poisson_plan_t poisson = nullptr, poisson_b = nullptr;
+    tlab_dns_t dns = nullptr;                    // monitors (TIME_COURANT, MINMAX), made on first use
+    double *hb = nullptr, *ht = nullptr;         // BcsFlowJmin/Jmax%ref(:,:,2): Neumann data of the pressure, wall planes of the Neumann fields
+    double *head = nullptr, *tail = nullptr, *head_right = nullptr, *tail_left = nullptr;   // interface values, [2 (3 + ns)][nx*ny]
+    double *pen[3] = {nullptr, nullptr, nullptr};   // complex kx-pencils (nxl, ny, nz_total)
+    double *pack[2] = {nullptr, nullptr};           // complex slabs blocked by peer
+    std::vector<double *> q, s, hq, hs, txc;     // bound module arrays
+    bool bound = false;
+};
+
+}  // namespace
+
+struct tlab_slab_dns {
+    tlab_slab_transport tr{};
+    tlab_fdm_plan_t g[3] = {nullptr, nullptr, nullptr}, gy_elliptic = nullptr;
+    int P = 1, nx = 0, ny = 0, nzt = 0, kmax = 0, nxh = 0, nscal = 0, stages = 1;
+    long long npage = 0, n = 0;
+    double visc = 0.0;
+    std::vector<double> schmidt;
+    std::vector<int> nxl, ioff, nxa;
+    std::vector<int> st_start;                   // two-stage block map (tlab_pencil_repack_blocks)
+    std::vector<long long> st_base;
+    long long st_split = 0;                      // doubles of the A part of a pack buffer
+    int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
+    int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
+    std::vector<int> scal_jmin, scal_jmax;
+    bool fresh = false;
+    std::vector<Rank> rk;
+    ~tlab_slab_dns() {
+        for (Rank &R : rk) {
+            if (R.dns) (void)tlab_dns_destroy(R.dns);
+            if (R.poisson) (void)tlab_poisson_plan_destroy(R.poisson);
+            if (R.poisson_b) (void)tlab_poisson_plan_destroy(R.poisson_b);
+            if (R.zplan) (void)tlab_zslab_plan_destroy(R.zplan);
+            for (double *p : {R.hb, R.ht, R.head, R.tail, R.head_right, R.tail_left, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1]})
+                if (p) (void)hipFree(p);
+        }
+        if (tr.destroy) tr.destroy(tr.ctx);
+    }
+};
+
+namespace {
+
+using D = tlab_slab_dns;
+
+void need_bound(D *d) {
+    for (const Rank &R : d->rk)
+        if (!R.bound) throw Fail(TLAB_EINVAL, "tlab_slab_dns: the arrays of every local rank must be bound first (tlab_slab_dns_bind)");
+}
+void tck(int rc, const char *what) {
+    if (rc < 0) throw Fail(rc, std::string("slab transport: ") + what + " failed");
+}
+void twait(D *d, int ticket) { tck(d->tr.wait(d->tr.ctx, (void *)tlab_current_stream(), ticket), "wait"); }
+
+// One ring exchange of nmsg messages per local rank; the four pointer tables are filled by `fill(R, l, to_left, to_right, from_right, from_left)`.
+template <class F>
+int ring(D *d, int nmsg, const std::vector<long long> &count, F fill) {
+    const int L = (int)d->rk.size();
+    std::vector<double *> tl((size_t)L * nmsg), trr((size_t)L * nmsg), fr((size_t)L * nmsg), fl((size_t)L * nmsg);
+    for (int l = 0; l < L; ++l) fill(d->rk[l], &tl[(size_t)l * nmsg], &trr[(size_t)l * nmsg], &fr[(size_t)l * nmsg], &fl[(size_t)l * nmsg]);
+    const int t = d->tr.ring_start(d->tr.ctx, (void *)tlab_current_stream(), nmsg, count.data(), tl.data(), trr.data(), fr.data(), fl.data());
+    tck(t, "ring_start");
+    return t;
+}
+
+// Halo planes of `nf` fields (picked by `field(R, i)`): my last planes go to the right neighbour's planes -H..-1, my first planes to the left
+// neighbour's planes kmax..kmax+H-1 (periodic in z).  Zero-copy: the planes are contiguous in memory on both sides.
+template <class F>
+int halo_start(D *d, int nf, F field) {
+    const long long Hn = HALO * d->npage, n = d->n;
+    std::vector<long long> count((size_t)nf, Hn);
+    return ring(d, nf, count, [&](Rank &R, double **tl, double **tr, double **fr, double **fl) {
+        for (int i = 0; i < nf; ++i) {
+            double *f = field(R, i);
+            tl[i] = f;
+            tr[i] = f + n - Hn;
+            fr[i] = f + n;         // planes kmax .. kmax+H-1
+            fl[i] = f - Hn;        // planes -H .. -1
+        }
+    });
+}
+
+// head -> left neighbour (its head_right), tail -> right neighbour (its tail_left); nrows line-sets of nx*ny
+int msg_start(D *d, int nrows) {
+    std::vector<long long> count(1, (long long)nrows * d->npage);
+    return ring(d, 1, count, [&](Rank &R, double **tl, double **tr, double **fr, double **fl) {
+        tl[0] = R.head; tr[0] = R.tail; fr[0] = R.head_right; fl[0] = R.tail_left;
+    });
+}
+
+struct Eq {
+    double *f, *h;
+    double nu;
+};
+std::vector<Eq> eqs(D *d, Rank &R) {
+    std::vector<Eq> E;
+    for (int i = 0; i < 3; ++i) E.push_back({R.q[i], R.hq[i], d->visc});
+    for (int i = 0; i < d->nscal; ++i) E.push_back({R.s[i], R.hs[i], d->visc / d->schmidt[i]});
+    return E;
+}
+
+// hq, hs += Burgers_dir of every transported field, four per launch (they share the advecting velocity q_dir)
+void badd_all(D *d, Rank &R, int dir, bool overwrite) {
+    const std::vector<Eq> E = eqs(d, R);
+    for (size_t e0 = 0; e0 < E.size(); e0 += 4) {
+        const int nf = (int)std::min<size_t>(4, E.size() - e0);
+        double nus[4];
+        const double *sp[4];
+        double *rp[4];
+        for (int f = 0; f < nf; ++f) { nus[f] = E[e0 + f].nu; sp[f] = E[e0 + f].f; rp[f] = E[e0 + f].h; }
+        ok(tlab_opr_burgers_add_n(dir, d->g[dir - 1], d->nx, d->ny, d->kmax, 0, nf, nus, sp, R.q[dir - 1], rp, R.txc[6], R.txc[7], overwrite ? 1 : 0),
+           "tlab_opr_burgers_add_n");
+    }
+}
+void zburgers_all(D *d, Rank &R, int phase) {
+    const std::vector<Eq> E = eqs(d, R);
+    for (size_t e0 = 0; e0 < E.size(); e0 += 4) {
+        const int nf = (int)std::min<size_t>(4, E.size() - e0);
+        double nus[4];
+        const double *sp[4];
+        double *rp[4];
+        for (int f = 0; f < nf; ++f) { nus[f] = E[e0 + f].nu; sp[f] = E[e0 + f].f; rp[f] = E[e0 + f].h; }
+        const long long o = 2 * (long long)e0 * d->npage;
+        ok(tlab_zslab_burgers_z_n(R.zplan, phase, d->nx, d->ny, nf, nus, sp, phase == 2 ? R.q[2] : nullptr, R.head + o, R.tail + o, R.tail_left + o,
+                                  R.head_right + o, phase == 2 ? rp : nullptr, 1),
+           "tlab_zslab_burgers_z_n");
+    }
+}
+void padd(D *d, Rank &R, int dir, const double *u, const double *ub, double scale, double *res, int acc) {
+    ok(tlab_opr_partial_add(dir, d->g[dir - 1], d->nx, d->ny, d->kmax, 0, u, ub, scale, res, acc, R.txc[6], R.txc[7]), "tlab_opr_partial_add");
+}
+void zpartial(D *d, Rank &R, int phase, const double *u, const double *ub, double scale, double *res, int acc) {
+    ok(tlab_zslab_partial_z(R.zplan, phase, d->nx, d->ny, u, ub, scale, R.head, R.tail, R.tail_left, R.head_right, res, acc), "tlab_zslab_partial_z");
+}
+
+// ---- OPR_Poisson on kx-pencils: forcing in tmp1, Neumann data in hb / ht; p -> tmp1, dp/dy -> tmp3 ----
+int a2a(D *d, const std::vector<double *> &send, const std::vector<long long> &scnt, const std::vector<double *> &recv, const std::vector<long long> &rcnt) {
+    const int t = d->tr.alltoallv_start(d->tr.ctx, (void *)tlab_current_stream(), send.data(), scnt.data(), recv.data(), rcnt.data());
+    tck(t, "alltoallv_start");
+    return t;
+}
+
+void repack(D *d, double *slab, double *buf, int dir) {
+    const int P = d->P;
+    if (P <= 8) {
+        ok(tlab_pencil_repack(slab, buf, d->nxh, d->ny, d->kmax, P, d->ioff.data(), dir), "tlab_pencil_repack");
+    } else {    // up to 16 peers through the block form
+        std::vector<long long> base((size_t)P);
+        long long off = 0;
+        for (int p = 0; p < P; ++p) { base[p] = off; off += (long long)d->nxl[p] * d->ny * d->kmax; }
+        ok(tlab_pencil_repack_blocks(slab, buf, d->nxh, d->ny, d->kmax, P, d->ioff.data(), base.data(), dir), "tlab_pencil_repack_blocks");
+    }
+}
+
+// slab <-> pencil exchange of one complex field: slab side = pack buffer blocked by peer, pencil side = (nxl_r, ny, nz_total)
+int pencil_exchange(D *d, int i_pen, int i_pack, bool forward) {
+    const int P = d->P, L = (int)d->rk.size();
+    std::vector<double *> send(L), recv(L);
+    std::vector<long long> scnt((size_t)L * P), rcnt((size_t)L * P);
+    for (int l = 0; l < L; ++l) {
+        Rank &R = d->rk[l];
+        for (int p = 0; p < P; ++p) {
+            const long long slab_cnt = 2LL * d->nxl[p] * d->ny * d->kmax, pen_cnt = 2LL * d->nxl[R.r] * d->ny * d->kmax;
+            scnt[(size_t)l * P + p] = forward ? slab_cnt : pen_cnt;
+            rcnt[(size_t)l * P + p] = forward ? pen_cnt : slab_cnt;
+        }
+        send[l] = forward ? R.pack[i_pack] : R.pen[i_pen];
+        recv[l] = forward ? R.pen[i_pen] : R.pack[i_pack];
+    }
+    return a2a(d, send, scnt, recv, rcnt);
+}
+
+void poisson_pencil_single(D *d) {
+    const bool direct = d->gy_elliptic != nullptr;
+    for (Rank &R : d->rk) {
+        ok(tlab_poisson_set_wall_planes(R.poisson, R.txc[0], R.hb, R.ht), "tlab_poisson_set_wall_planes");
+        ok(tlab_poisson_fft_x(R.poisson, 1, R.txc[0], R.txc[1]), "tlab_poisson_fft_x");              // p -> tmp2 (complex slab)
+        repack(d, R.txc[1], R.pack[0], 1);
+    }
+    twait(d, pencil_exchange(d, 0, 0, true));
+    for (Rank &R : d->rk) {
+        ok(tlab_poisson_fft_z(R.poisson, 1, R.pen[0], R.pen[1]), "tlab_poisson_fft_z");
+        if (direct) ok(tlab_poisson_direct_ode(R.poisson, TLAB_BCS_NN, R.pen[1], R.pen[1]), "tlab_poisson_direct_ode");   // p^ over f^
+        else ok(tlab_poisson_ode(R.poisson, R.pen[1], R.pen[1], R.pen[2]), "tlab_poisson_ode");                           // p^ over f^, dp^ in pen[2]
+        ok(tlab_poisson_fft_z(R.poisson, -1, R.pen[1], R.pen[0]), "tlab_poisson_fft_z");
+    }
+    const int w0 = pencil_exchange(d, 0, 0, false);                                                   // p travels ...
+    if (direct) {    // one field on the way back; dp/dy = OPR_Partial_Y(p) on the slab (opr_elliptic.f90:447-449)
+        twait(d, w0);
+        for (Rank &R : d->rk) {
+            repack(d, R.txc[1], R.pack[0], -1);
+            ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[1], R.txc[0]), "tlab_poisson_fft_x");
+            ok(tlab_opr_partial(2, d->g[1], TLAB_OPR_P1, d->nx, d->ny, d->kmax, 0, R.txc[0], R.txc[2], nullptr), "tlab_opr_partial");
+        }
+        return;
+    }
+    for (Rank &R : d->rk) ok(tlab_poisson_fft_z(R.poisson, -1, R.pen[2], R.pen[1]), "tlab_poisson_fft_z");   // ... while dp/dy is transformed
+    const int w1 = pencil_exchange(d, 1, 1, false);
+    twait(d, w0);
+    for (Rank &R : d->rk) {
+        repack(d, R.txc[1], R.pack[0], -1);
+        ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[1], R.txc[0]), "tlab_poisson_fft_x");             // p -> tmp1
+    }
+    twait(d, w1);
+    for (Rank &R : d->rk) {
+        repack(d, R.txc[3], R.pack[1], -1);
+        ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[3], R.txc[2]), "tlab_poisson_fft_x");             // dp/dy -> tmp3
+    }
+}
+
+// The same solve with every rank's kx range cut in two halves A, B (plans poisson, poisson_b).  The pack buffer holds all A blocks ahead of all B
+// blocks, so each half is one all-to-all of its own.  Same kernels on the same modes: the result is that of the one-piece exchange to the bit.
+void poisson_pencil_staged(D *d) {
+    const int P = d->P, L = (int)d->rk.size(), ny = d->ny, kmax = d->kmax, nzt = d->nzt;
+    std::vector<int> nxb((size_t)P);
+    for (int p = 0; p < P; ++p) nxb[p] = d->nxl[p] - d->nxa[p];
+    auto pen = [&](Rank &R, int i, int h) { return h == 0 ? R.pen[i] : R.pen[i] + 2LL * d->nxa[R.r] * ny * nzt; };
+    auto pack = [&](Rank &R, int i, int h) { return h == 0 ? R.pack[i] : R.pack[i] + d->st_split; };
+    auto exchange = [&](int i_pen, int i_pack, int h, bool forward) {
+        const std::vector<int> &w = h == 0 ? d->nxa : nxb;
+        std::vector<double *> send(L), recv(L);
+        std::vector<long long> scnt((size_t)L * P), rcnt((size_t)L * P);
+        for (int l = 0; l < L; ++l) {
+            Rank &R = d->rk[l];
+            for (int p = 0; p < P; ++p) {
+                const long long slab_cnt = 2LL * w[p] * ny * kmax, pen_cnt = 2LL * w[R.r] * ny * kmax;
+                scnt[(size_t)l * P + p] = forward ? slab_cnt : pen_cnt;
+                rcnt[(size_t)l * P + p] = forward ? pen_cnt : slab_cnt;
+            }
+            send[l] = forward ? pack(R, i_pack, h) : pen(R, i_pen, h);
+            recv[l] = forward ? pen(R, i_pen, h) : pack(R, i_pack, h);
+        }
+        return a2a(d, send, scnt, recv, rcnt);
+    };
+    for (Rank &R : d->rk) {
+        ok(tlab_poisson_set_wall_planes(R.poisson, R.txc[0], R.hb, R.ht), "tlab_poisson_set_wall_planes");
+        ok(tlab_poisson_fft_x(R.poisson, 1, R.txc[0], R.txc[1]), "tlab_poisson_fft_x");
+        ok(tlab_pencil_repack_blocks(R.txc[1], R.pack[0], d->nxh, ny, kmax, 2 * P, d->st_start.data(), d->st_base.data(), 1), "tlab_pencil_repack_blocks");
+    }
+    int fwd[2], back[2][2];
+    for (int h = 0; h < 2; ++h) fwd[h] = exchange(0, 0, h, true);
+    for (int h = 0; h < 2; ++h) {
+        twait(d, fwd[h]);
+        for (Rank &R : d->rk) {
+            tlab_poisson_plan_t pl = h == 0 ? R.poisson : R.poisson_b;
+            double *b0 = pen(R, 0, h), *b1 = pen(R, 1, h), *b2 = pen(R, 2, h);
+            ok(tlab_poisson_fft_z(pl, 1, b0, b1), "tlab_poisson_fft_z");
+            ok(tlab_poisson_ode(pl, b1, b1, b2), "tlab_poisson_ode");
+            ok(tlab_poisson_fft_z(pl, -1, b1, b0), "tlab_poisson_fft_z");
+        }
+        back[h][0] = exchange(0, 0, h, false);          // p^ of this half travels (its forward block of pack[0] has been consumed) ...
+        for (Rank &R : d->rk)
+            ok(tlab_poisson_fft_z(h == 0 ? R.poisson : R.poisson_b, -1, pen(R, 2, h), pen(R, 1, h)), "tlab_poisson_fft_z");   // ... while dp^/dy is transformed
+        back[h][1] = exchange(1, 1, h, false);
+    }
+    const int slab_of[2] = {1, 3}, out_of[2] = {0, 2};  // p -> tmp1, dp/dy -> tmp3
+    for (int i = 0; i < 2; ++i) {
+        twait(d, back[0][i]);
+        twait(d, back[1][i]);
+        for (Rank &R : d->rk) {
+            ok(tlab_pencil_repack_blocks(R.txc[slab_of[i]], R.pack[i], d->nxh, ny, kmax, 2 * P, d->st_start.data(), d->st_base.data(), -1),
+               "tlab_pencil_repack_blocks");
+            ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[slab_of[i]], R.txc[out_of[i]]), "tlab_poisson_fft_x");
+        }
+    }
+}
+
+void poisson_pencil(D *d) {
+    if (d->stages == 2) poisson_pencil_staged(d);
+    else poisson_pencil_single(d);
+}
+
+// Same terms as rhs.cpp / rhs_global_incompressible_1.f90:98-398; the z-terms are added last in every equation (the reference's order differs in
+// the third equation: rounding only).  tail: fold the RK update into the last pass of every field (TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT).
+void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
+    need_bound(d);
+    const int nx = d->nx, ny = d->ny, kmax = d->kmax, ns = d->nscal;
+    const long long n = d->n;
+    // ---- diffusion + advection (:98-162) ----
+    int w = halo_start(d, 3 + ns, [&](Rank &R, int i) { return i < 3 ? R.q[i] : R.s[i - 3]; });
+    const bool fresh = d->fresh;       // start of a Runge-Kutta step: hq = hs = 0 (time.f90:212-216) -> the x-terms overwrite
+    d->fresh = false;
+    for (Rank &R : d->rk) badd_all(d, R, 1, fresh);
+    twait(d, w);
+    for (Rank &R : d->rk) zburgers_all(d, R, 1);
+    w = msg_start(d, 2 * (3 + ns));
+    for (Rank &R : d->rk) badd_all(d, R, 2, false);
+    twait(d, w);
+    for (Rank &R : d->rk) zburgers_all(d, R, 2);
+    // ---- pressure forcing: div(hq + q/dte) (:188-260) ----
+    const double idte = 1.0 / dte;
+    w = halo_start(d, 1, [&](Rank &R, int) { return R.hq[2]; });                       // w's halo planes are still valid
+    for (Rank &R : d->rk) padd(d, R, 2, R.hq[1], R.q[1], idte, R.txc[0], 0);
+    for (Rank &R : d->rk) padd(d, R, 1, R.hq[0], R.q[0], idte, R.txc[0], 1);
+    twait(d, w);
+    for (Rank &R : d->rk) zpartial(d, R, 1, R.hq[2], R.q[2], idte, nullptr, 0);
+    w = msg_start(d, 1);
+    for (Rank &R : d->rk) ok(tlab_pw_get_wall_planes(R.hq[1], R.hb, R.ht, nx, ny, kmax), "tlab_pw_get_wall_planes");
+    twait(d, w);
+    for (Rank &R : d->rk) zpartial(d, R, 2, R.hq[2], R.q[2], idte, R.txc[0], 1);
+    // ---- pressure (:284) and its gradient (:319-320) ----
+    poisson_pencil(d);
+    auto dirichlet = [](int t) { return t == TLAB_DNS_BCS_DIRICHLET; };
+    bool vel_dirichlet = true, scal_dirichlet = true;
+    for (int i = 0; i < 3; ++i) vel_dirichlet = vel_dirichlet && dirichlet(d->flow_jmin[i]) && dirichlet(d->flow_jmax[i]);
+    for (int i = 0; i < ns; ++i) scal_dirichlet = scal_dirichlet && dirichlet(d->scal_jmin[i]) && dirichlet(d->scal_jmax[i]);
+    const bool grad_final = tail && vel_dirichlet;
+    // ---- hq -= grad p, boundary conditions (:348-398) [+ RK update] ----
+    auto finish = [&](Rank &R) {
+        struct Fd {
+            double *q, *h, *g;
+            int tmin, tmax;
+        };
+        std::vector<Fd> F;
+        for (int i = 0; i < 3; ++i) F.push_back({R.q[i], R.hq[i], R.txc[1 + i], d->flow_jmin[i], d->flow_jmax[i]});
+        for (int i = 0; i < ns; ++i) F.push_back({R.s[i], R.hs[i], nullptr, d->scal_jmin[i], d->scal_jmax[i]});
+        if (grad_final) F.erase(F.begin() + 2), F.erase(F.begin());          // v and the scalars; u, w are done
+        if (!grad_final && (!vel_dirichlet || !tail)) {
+            ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
+            for (Fd &f : F) f.g = nullptr;
+        }
+        for (const Fd &f : F) {
+            const int ibc = (f.tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (f.tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0);
+            if (ibc)       // needs the finished tendency (g is null here)
+                ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, f.h, R.hb, R.ht, R.txc[0]), "tlab_boundary_bcs_neumann_y");
+            const double *pb = (ibc & 1) ? R.hb : nullptr, *pt = (ibc & 2) ? R.ht : nullptr;
+            if (!tail) ok(tlab_pw_set_wall_planes(f.h, pb, pt, nx, ny, kmax), "tlab_pw_set_wall_planes");
+            else ok(tlab_pw_final_update(f.q, f.h, f.g, pb, pt, tdte, kco, scale, nx, ny, kmax), "tlab_pw_final_update");
+        }
+    };
+    w = halo_start(d, 1, [&](Rank &R, int) { return R.txc[0]; });
+    if (grad_final) {   // u and w are finished by the gradient kernels themselves (no gradient array)
+        for (Rank &R : d->rk)
+            ok(tlab_opr_gradient_final(1, d->g[0], nx, ny, kmax, R.txc[0], R.q[0], R.hq[0], tdte, kco, scale, R.txc[1]), "tlab_opr_gradient_final");
+    } else {
+        for (Rank &R : d->rk) padd(d, R, 1, R.txc[0], nullptr, 0.0, R.txc[1], 0);
+    }
+    twait(d, w);
+    for (Rank &R : d->rk) zpartial(d, R, 1, R.txc[0], nullptr, 0.0, nullptr, 0);
+    w = msg_start(d, 1);
+    // v and the scalars do not wait for dp/dz: their update runs while the interface values travel (not with Neumann scalars, whose boundary
+    // routine takes tmp1 = p as scratch)
+    const bool early_finish = grad_final && scal_dirichlet;
+    if (early_finish)
+        for (Rank &R : d->rk) finish(R);
+    twait(d, w);
+    if (grad_final) {
+        for (Rank &R : d->rk)
+            ok(tlab_zslab_gradient_final_z(R.zplan, nx, ny, R.txc[0], R.tail_left, R.head_right, R.q[2], R.hq[2], tdte, kco, scale), "tlab_zslab_gradient_final_z");
+    } else {
+        for (Rank &R : d->rk) zpartial(d, R, 2, R.txc[0], nullptr, 0.0, R.txc[3], 0);
+    }
+    if (!early_finish)
+        for (Rank &R : d->rk) finish(R);
+}
+
+tlab_dns_t dns_handle(D *d, Rank &R) {
+    if (!R.dns) {
+        const double one = 1.0;
+        ok(tlab_dns_create(&R.dns, d->g[0], d->g[1], d->g[2], R.poisson, d->nx, d->ny, d->kmax, d->nscal, d->visc, d->nscal ? d->schmidt.data() : &one),
+           "tlab_dns_create");
+        ok(tlab_dns_set_slab(R.dns, R.r * d->kmax), "tlab_dns_set_slab");
+    }
+    return R.dns;
+}
+
+template <class F>
+int guarded(F f) {
+    try {
+        if (!tlab_device_ready()) throw Fail(TLAB_EHIP, "tlab_init has not been called (no CPU fallback exists)");
+        f();
+        return TLAB_OK;
+    } catch (const Fail &e) {
+        tlab_set_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tlab_slab_transport_loopback(tlab_slab_transport *out, int nranks) {
+    if (!out || nranks < 1) { tlab_set_error("tlab_slab_transport_loopback: bad arguments"); return TLAB_EINVAL; }
+    out->ctx = new Loopback{nranks};
+    out->nranks = nranks; out->nlocal = nranks; out->first = 0;
+    out->ring_start = lb_ring; out->alltoallv_start = lb_a2a; out->wait = lb_wait; out->allreduce = lb_allreduce; out->destroy = lb_destroy;
+    return TLAB_OK;
+}
+
+int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *tr, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx, int ny,
+                         int nz_total, int nscal, double visc, const double *schmidt, tlab_fdm_plan_t gy_elliptic) {
+    return guarded([&] {
+        if (!out || !tr || !gx || !gy || !gz || nscal < 0 || (nscal > 0 && !schmidt) || visc <= 0.0) throw Fail(TLAB_EINVAL, "tlab_slab_dns_create: bad arguments");
+        if (!tr->ring_start || !tr->alltoallv_start || !tr->wait || !tr->allreduce) throw Fail(TLAB_EINVAL, "tlab_slab_dns_create: incomplete transport");
+        const int P = tr->nranks;
+        if (P < 1) throw Fail(TLAB_EINVAL, "tlab_slab_dns_create: nranks < 1");       // (one rank: its own ring neighbour; tests of a transport on one GPU)
+        if (tr->nlocal < 1 || tr->first < 0 || tr->first + tr->nlocal > P) throw Fail(TLAB_EINVAL, "tlab_slab_dns_create: local ranks outside [0, nranks)");
+        if (nz_total % P) throw Fail(TLAB_EINVAL, "nz must be divisible by the number of z slabs");
+        auto d = std::make_unique<tlab_slab_dns>();
+        d->g[0] = gx; d->g[1] = gy; d->g[2] = gz; d->gy_elliptic = gy_elliptic;
+        d->P = P; d->nx = nx; d->ny = ny; d->nzt = nz_total; d->kmax = nz_total / P; d->nxh = nx / 2 + 1; d->nscal = nscal; d->visc = visc;
+        d->npage = (long long)nx * ny; d->n = d->npage * d->kmax;
+        if (nscal) d->schmidt.assign(schmidt, schmidt + nscal);
+        d->scal_jmin.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
+        d->scal_jmax.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
+        // kx ranges of the pencils: [ioff[r], ioff[r] + nxl[r])
+        const int base = d->nxh / P, rem = d->nxh % P;
+        for (int r = 0; r < P; ++r) {
+            d->nxl.push_back(base + (r < rem ? 1 : 0));
+            d->ioff.push_back(r * base + std::min(r, rem));
+            d->nxa.push_back((d->nxl[r] + 1) / 2);
+        }
+        if (base < 1) throw Fail(TLAB_EINVAL, "fewer kx modes than ranks");
+        if (P > 16) throw Fail(TLAB_EUNSUPPORTED, "tlab_slab_dns_create: at most 16 z slabs (one node)");
+        const char *env = std::getenv("TLAB_PENCIL_STAGES");
+        d->stages = (!gy_elliptic && base >= 2 && 2 * P <= 16 && !(env && std::strcmp(env, "1") == 0)) ? 2 : 1;
+        if (d->stages == 2) {   // block 2p / 2p+1 = half A / B of rank p: all A blocks (by rank) ahead of all B blocks
+            long long offa = 0, offb = 0;
+            for (int p = 0; p < P; ++p) offb += (long long)d->nxa[p] * ny * d->kmax;
+            d->st_split = 2 * offb;
+            for (int p = 0; p < P; ++p) {
+                d->st_start.push_back(d->ioff[p]);
+                d->st_start.push_back(d->ioff[p] + d->nxa[p]);
+                d->st_base.push_back(offa);
+                d->st_base.push_back(offb);
+                offa += (long long)d->nxa[p] * ny * d->kmax;
+                offb += (long long)(d->nxl[p] - d->nxa[p]) * ny * d->kmax;
+            }
+        }
+        d->rk.resize(tr->nlocal);
+        const int nmsg = 2 * (3 + nscal);
+        for (int l = 0; l < tr->nlocal; ++l) {
+            Rank &R = d->rk[l];
+            R.r = tr->first + l;
+            ok(tlab_zslab_plan_create(&R.zplan, gz, d->kmax, R.r * d->kmax, 0), "tlab_zslab_plan_create");
+            if (gy_elliptic)
+                ok(tlab_poisson_plan_create_direct_decomposed(&R.poisson, gx, gy, gz, nx, ny, d->kmax, nz_total, 1, d->ioff[R.r], d->nxl[R.r], gy_elliptic),
+                   "tlab_poisson_plan_create_direct_decomposed");
+            else if (d->stages == 2) {
+                ok(tlab_poisson_plan_create_pencil(&R.poisson, gx, gy, gz, nx, ny, d->kmax, nz_total, d->ioff[R.r], d->nxa[R.r]), "tlab_poisson_plan_create_pencil");
+                ok(tlab_poisson_plan_create_pencil(&R.poisson_b, gx, gy, gz, nx, ny, d->kmax, nz_total, d->ioff[R.r] + d->nxa[R.r], d->nxl[R.r] - d->nxa[R.r]),
+                   "tlab_poisson_plan_create_pencil");
+            } else
+                ok(tlab_poisson_plan_create_pencil(&R.poisson, gx, gy, gz, nx, ny, d->kmax, nz_total, d->ioff[R.r], d->nxl[R.r]), "tlab_poisson_plan_create_pencil");
+            R.hb = dalloc((size_t)nx * d->kmax);
+            R.ht = dalloc((size_t)nx * d->kmax);
+            for (double **p : {&R.head, &R.tail, &R.head_right, &R.tail_left}) *p = dalloc((size_t)nmsg * d->npage);
+            for (int i = 0; i < 3; ++i) R.pen[i] = dalloc((size_t)2 * d->nxl[R.r] * ny * nz_total);
+            for (int i = 0; i < 2; ++i) R.pack[i] = dalloc((size_t)2 * d->nxh * ny * d->kmax);
+        }
+        d->tr = *tr;         // from here on the driver owns the transport's context
+        *out = d.release();
+    });
+}
+
+int tlab_slab_dns_destroy(tlab_slab_dns_t d) {
+    delete d;
+    return TLAB_OK;
+}
+
+int tlab_slab_dns_bind(tlab_slab_dns_t d, int l, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc) {
+    return guarded([&] {
+        if (!d || l < 0 || l >= (int)d->rk.size() || !q || !hq || !txc || (d->nscal > 0 && (!s || !hs))) throw Fail(TLAB_EINVAL, "tlab_slab_dns_bind: bad arguments");
+        Rank &R = d->rk[l];
+        R.q.assign(q, q + 3); R.hq.assign(hq, hq + 3); R.txc.assign(txc, txc + 9);
+        R.s.assign(s, s + d->nscal); R.hs.assign(hs, hs + d->nscal);
+        for (const std::vector<double *> *v : {&R.q, &R.s, &R.hq, &R.hs, &R.txc})
+            for (double *p : *v)
+                if (!p) throw Fail(TLAB_EINVAL, "tlab_slab_dns_bind: null array");
+        R.bound = true;
+    });
+}
+
+long long tlab_slab_dns_info(tlab_slab_dns_t d, int what) {
+    if (!d) return TLAB_EINVAL;
+    switch (what) {
+        case 0: return d->kmax;
+        case 1: return d->P;
+        case 2: return (long long)d->rk.size();
+        case 3: return HALO * d->npage;
+        case 4: return d->stages;
+        case 5: return d->rk.empty() ? 0 : d->rk[0].r;
+    }
+    return TLAB_EINVAL;
+}
+
+int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax) {
+    return guarded([&] {
+        if (!d || !flow_jmin || !flow_jmax || (d->nscal > 0 && (!scal_jmin || !scal_jmax))) throw Fail(TLAB_EINVAL, "tlab_slab_dns_set_bcs: bad arguments");
+        auto valid = [](int t) { return t == TLAB_DNS_BCS_DIRICHLET || t == TLAB_DNS_BCS_NEUMANN; };
+        for (int i = 0; i < 3; ++i)
+            if (!valid(flow_jmin[i]) || !valid(flow_jmax[i])) throw Fail(TLAB_EINVAL, "tlab_slab_dns_set_bcs: type must be DNS_BCS_DIRICHLET or DNS_BCS_NEUMANN");
+        for (int i = 0; i < d->nscal; ++i)
+            if (!valid(scal_jmin[i]) || !valid(scal_jmax[i])) throw Fail(TLAB_EINVAL, "tlab_slab_dns_set_bcs: type must be DNS_BCS_DIRICHLET or DNS_BCS_NEUMANN");
+        if (flow_jmin[1] != TLAB_DNS_BCS_DIRICHLET || flow_jmax[1] != TLAB_DNS_BCS_DIRICHLET)
+            throw Fail(TLAB_EUNSUPPORTED, "tlab_slab_dns_set_bcs: the wall-normal velocity must be Dirichlet (impermeable walls; the pressure BCs assume v = 0)");
+        for (int i = 0; i < 3; ++i) { d->flow_jmin[i] = flow_jmin[i]; d->flow_jmax[i] = flow_jmax[i]; }
+        for (int i = 0; i < d->nscal; ++i) { d->scal_jmin[i] = scal_jmin[i]; d->scal_jmax[i] = scal_jmax[i]; }
+    });
+}
+
+int tlab_slab_dns_begin_step(tlab_slab_dns_t d) {
+    if (!d) return TLAB_EINVAL;
+    d->fresh = true;
+    return TLAB_OK;
+}
+
+int tlab_slab_dns_rhs(tlab_slab_dns_t d, double dte) {
+    return guarded([&] {
+        if (!d || !(dte > 0.0)) throw Fail(TLAB_EINVAL, "tlab_slab_dns_rhs: bad arguments");
+        rhs_halo(d, dte, false, 0.0, 1.0, 0);
+    });
+}
+
+int tlab_slab_dns_substep(tlab_slab_dns_t d, double dte, double kco, int scale_tendencies) {
+    return guarded([&] {
+        if (!d || !(dte > 0.0)) throw Fail(TLAB_EINVAL, "tlab_slab_dns_substep: bad arguments");
+        rhs_halo(d, dte, true, dte, kco, scale_tendencies);
+    });
+}
+
+int tlab_slab_dns_time_courant(tlab_slab_dns_t d, double cfla, double cfld, double *pmax, double *dtime) {
+    return guarded([&] {
+        if (!d || !pmax) throw Fail(TLAB_EINVAL, "tlab_slab_dns_time_courant: bad arguments");
+        need_bound(d);
+        const int L = (int)d->rk.size();
+        std::vector<double> v((size_t)2 * L);
+        for (int l = 0; l < L; ++l) ok(tlab_time_courant(dns_handle(d, d->rk[l]), d->rk[l].q.data(), cfla, cfld, &v[(size_t)2 * l], nullptr), "tlab_time_courant");
+        tck(d->tr.allreduce(d->tr.ctx, v.data(), 2, 0), "allreduce");            // MPI_MAX, time.f90:522
+        pmax[0] = v[0]; pmax[1] = v[1];
+        if (dtime) {
+            const double dtc = pmax[0] > 0.0 ? cfla / pmax[0] : 1.0e300, dtd = pmax[1] > 0.0 ? cfld / pmax[1] : 1.0e300;
+            *dtime = cfla > 0.0 ? std::min(dtc, dtd) : 0.0;
+        }
+    });
+}
+
+int tlab_slab_dns_dilatation_bounds(tlab_slab_dns_t d, double *dil_min, double *dil_max) {
+    return guarded([&] {
+        if (!d || !dil_min || !dil_max) throw Fail(TLAB_EINVAL, "tlab_slab_dns_dilatation_bounds: bad arguments");
+        need_bound(d);
+        const int nx = d->nx, ny = d->ny, kmax = d->kmax, L = (int)d->rk.size();
+        // div(q) with the z-derivative by the slab route of the RHS (FI_INVARIANT_P = -div, fi_vectorcalculus.f90:111-141)
+        int w = halo_start(d, 1, [&](Rank &R, int) { return R.q[2]; });
+        for (Rank &R : d->rk) {
+            ok(tlab_opr_partial(1, d->g[0], TLAB_OPR_P1, nx, ny, kmax, 0, R.q[0], R.txc[0], nullptr), "tlab_opr_partial");
+            padd(d, R, 2, R.q[1], nullptr, 0.0, R.txc[0], 1);
+        }
+        twait(d, w);
+        for (Rank &R : d->rk) zpartial(d, R, 1, R.q[2], nullptr, 0.0, nullptr, 0);
+        w = msg_start(d, 1);
+        twait(d, w);
+        for (Rank &R : d->rk) zpartial(d, R, 2, R.q[2], nullptr, 0.0, R.txc[0], 1);
+        std::vector<double> mn((size_t)L), mx((size_t)L);
+        for (int l = 0; l < L; ++l) ok(tlab_minmax(dns_handle(d, d->rk[l]), d->rk[l].txc[0], nx, ny, kmax, &mn[l], &mx[l]), "tlab_minmax");
+        tck(d->tr.allreduce(d->tr.ctx, mn.data(), 1, 1), "allreduce");
+        tck(d->tr.allreduce(d->tr.ctx, mx.data(), 1, 0), "allreduce");
+        *dil_min = mn[0];
+        *dil_max = mx[0];
+    });
+}
+
+}  // extern "C"

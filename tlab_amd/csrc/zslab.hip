@@ -395,7 +395,6 @@ int tlab_zslab_plan_create(tlab_zslab_plan_t *out, tlab_fdm_plan_t gz, int kmax,
         const int nz = gz->t.n;
         if (!gz->t.periodic) throw Fail(TLAB_EUNSUPPORTED, "z-slab operators: the decomposed direction must be periodic");
         if (kmax <= 0 || nz % kmax || koffset < 0 || koffset % kmax || koffset >= nz) throw Fail(TLAB_EINVAL, "tlab_zslab_plan_create: bad slab");
-        if (nz / kmax < 2) throw Fail(TLAB_EINVAL, "tlab_zslab_plan_create: needs at least 2 slabs");
         auto P = std::make_unique<tlab_zslab_plan>();
         P->nz = nz; P->kmax = kmax; P->k0 = koffset;
         int M = chunk;

@@ -97,6 +97,17 @@ SIGNATURES = {
     "tlab_pw_set_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int]),
     "tlab_rhs_global_incompressible_1": (c_int, [c_vp, c_dbl, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
     "tlab_time_substep_incompressible_explicit": (c_int, [c_vp, c_dbl, c_dbl, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
+    "tlab_slab_transport_loopback": (c_int, [c_vp, c_int]),
+    "tlab_slab_dns_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, _dp, c_vp]),
+    "tlab_slab_dns_destroy": (c_int, [c_vp]),
+    "tlab_slab_dns_bind": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
+    "tlab_slab_dns_info": (ctypes.c_longlong, [c_vp, c_int]),
+    "tlab_slab_dns_set_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "tlab_slab_dns_begin_step": (c_int, [c_vp]),
+    "tlab_slab_dns_rhs": (c_int, [c_vp, c_dbl]),
+    "tlab_slab_dns_substep": (c_int, [c_vp, c_dbl, c_dbl, c_int]),
+    "tlab_slab_dns_time_courant": (c_int, [c_vp, c_dbl, c_dbl, _dp, _dp]),
+    "tlab_slab_dns_dilatation_bounds": (c_int, [c_vp, _dp, _dp]),
     "tlab_transpose": (c_int, [c_vp, c_int, c_int, c_vp]),
     "tlab_last_kernel_path": (c_int, []),
     "tlab_force_kernel_path": (c_int, [c_int]),

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--nz", type=int, default=128)
     ap.add_argument("--zmode", default="auto")
     ap.add_argument("--bcs", default="noslip")
+    ap.add_argument("--driver", default="python", choices=["python", "native"], help="python: tlab_amd/parallel.py::SlabDns over torch.distributed; "
+                    "native: the C++ driver (tlab_slab_dns_*) with the RCCL transport of libtlab_amd_comm.so (backend nccl) or, on gloo, with the "
+                    "host-staged callback transport (several ranks on one GPU)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -48,7 +51,11 @@ def main():
     wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
     fields = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
     one = Dns(x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, hyper_bc1_ext=REF_HYPER)
-    slab = SlabDns(DistComm(), x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, zmode=args.zmode, hyper_bc1_ext=REF_HYPER)
+    if args.driver == "native":
+        from tlab_amd.slab import NativeSlabDns
+        slab = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, hyper_bc1_ext=REF_HYPER)
+    else:
+        slab = SlabDns(DistComm(), x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, zmode=args.zmode, hyper_bc1_ext=REF_HYPER)
     if args.bcs == "freeslip":
         one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
         slab.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
@@ -84,7 +91,7 @@ def main():
         tt = tt.cuda()
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print("DIST_CHECK world=%d zmode=%s backend=%s worst_rel_err=%.3e %s" % (world, slab.zmode, backend, float(tt.item()),
+        print("DIST_CHECK driver=%s world=%d zmode=%s backend=%s worst_rel_err=%.3e %s" % (args.driver, world, slab.zmode, backend, float(tt.item()),
                                                                                  "OK" if float(tt.item()) <= 1e-11 else "FAIL"))
     dist.barrier()
     dist.destroy_process_group()
