@@ -14,6 +14,8 @@
 // the reference recomputes on every call (opr_odes.f90:308-324) depend only on the mode and are computed once at plan
 // creation.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
@@ -117,7 +119,7 @@ __device__ __forceinline__ void load_f(const Int1Args &a, int j, long long t, lo
 }
 
 // One FDM_Int1_Solve per thread (mode).  BC = 1: value given at the bottom (BCS_MIN), BC = 2: at the top (BCS_MAX).
-template <int BC, int NL, int FS, int U>
+template <int BC, int NL, int FS, int U, bool STORED>
 __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma clang fp contract(off)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     const int nmax = n - 2;
     // U = rows per block: the loads of a block are issued together so that only one memory latency is exposed per U rows.  Large U
     // pays on small slabs (few modes -> few waves -> latency-bound), small U keeps the registers down when the grid fills the chip.
-    const bool stored = a.fac != nullptr;
+    constexpr bool stored = STORED;          // a.fac != nullptr (launch_int1): the factors of every row are read instead of regenerated
     for (int jb = 1; jb <= nmax; jb += U) {
         double fqb[U][NL], fab[U][2];         // f[jb+2 .. jb+U+1]; stored forward factors of rows jb .. jb+U-1
         double Rb[U][2];                      // right-hand-side coefficients of the rows of the block: requested with the rest, BEFORE the first store
@@ -233,29 +235,33 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
                 fab[u][1] = a.fac[((long long)1 * n + jf) * nm + t];
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+        // A block without one of the boundary rows 1, 2, n-3, n-2 (all but the first and the last one or two) takes the plain form of every
+        // expression: with few modes in flight (the low-mode sub-plan: 2 waves) the kernel is bound by the instructions per row, and the
+        // row-number selects of the general form are most of them.
+        const bool edge_blk = jb < 3 || jb + U - 1 > n - 4;
+        auto fwd_row = [&](auto edge_c, int u) {
+            constexpr bool EDGE = decltype(edge_c)::value;
             const int j = jb + u;
-            if (j > nmax) break;
+            if (EDGE && j > nmax) return;
             double r[5] = {0.0, 0.0, 1.0, 0.0, 0.0};
             if (!stored) {
-                if (j == 1) { for (int k = 0; k < 5; ++k) r[k] = l1[k]; }
-                else if (j == 2) { for (int k = 0; k < 5; ++k) r[k] = l2[k]; }
-                else if (j == n - 3) { for (int k = 0; k < 5; ++k) r[k] = lN2[k]; }
-                else if (j == n - 2) { for (int k = 0; k < 5; ++k) r[k] = lN1[k]; }
+                if (EDGE && j == 1) { for (int k = 0; k < 5; ++k) r[k] = l1[k]; }
+                else if (EDGE && j == 2) { for (int k = 0; k < 5; ++k) r[k] = l2[k]; }
+                else if (EDGE && j == n - 3) { for (int k = 0; k < 5; ++k) r[k] = lN2[k]; }
+                else if (EDGE && j == n - 2) { for (int k = 0; k < 5; ++k) r[k] = lN1[k]; }
                 else lhs_row(a.T, j, lam, r);
             }
             // right-hand side of row j
             double rhs[NL];
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
-                if (j == 1) rhs[l] = res0[l] * rb[1][1] + fc[l] * rb[1][2] + fp[l] * rb[1][3];
-                else if (j == 2) rhs[l] = res0[l] * rb[2][0] + fm[l] * rb[2][1] + fc[l] * rb[2][2] + fp[l] * rb[2][3];
-                else if (j == n - 3) rhs[l] = fm[l] * rt[0][0] + fc[l] * rt[0][1] + fp[l] * rt[0][2] + resN[l] * rt[0][3];
-                else if (j == n - 2) rhs[l] = fm[l] * rt[1][0] + fc[l] * rt[1][1] + resN[l] * rt[1][2];
+                if (EDGE && j == 1) rhs[l] = res0[l] * rb[1][1] + fc[l] * rb[1][2] + fp[l] * rb[1][3];
+                else if (EDGE && j == 2) rhs[l] = res0[l] * rb[2][0] + fm[l] * rb[2][1] + fc[l] * rb[2][2] + fp[l] * rb[2][3];
+                else if (EDGE && j == n - 3) rhs[l] = fm[l] * rt[0][0] + fc[l] * rt[0][1] + fp[l] * rt[0][2] + resN[l] * rt[0][3];
+                else if (EDGE && j == n - 2) rhs[l] = fm[l] * rt[1][0] + fc[l] * rt[1][1] + resN[l] * rt[1][2];
                 else rhs[l] = fm[l] * Rb[u][0] + fc[l] * Rb[u][1] + fp[l];
             }
-            if (j == n - 2) {
+            if (EDGE && j == n - 2) {
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     fn2[l] = fc[l];
@@ -267,11 +273,11 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
             if (stored) {
                 am = fab[u][0]; bm = fab[u][1];
             } else {
-                if (j == 2) {
+                if (EDGE && j == 2) {
                     bm = r[1] / c1;
                     cm = nf_msub(r[2], bm, d1);
                     dm = nf_msub(r[3], bm, e1);
-                } else if (j >= 3) {
+                } else if (!EDGE || j >= 3) {
                     am = r[0] / c2;
                     bm = nf_msub(r[1], am, d2) / c1;
                     cm = nf_msub(nf_msub(r[2], bm, d1), am, e2);
@@ -301,6 +307,13 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
             c1 = cm; d1 = dm; e1 = em;
 #pragma unroll
             for (int l = 0; l < NL; ++l) { fm[l] = fc[l]; fc[l] = fp[l]; fp[l] = fqb[u][l]; }
+        };
+        if (edge_blk) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) fwd_row(std::true_type{}, u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) fwd_row(std::false_type{}, u);
         }
     }
 
@@ -323,23 +336,33 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) yb[u][l] = a.scratch[((long long)l * n + jr) * nm + t];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+        const bool edge_blk = jb > n - 5 || jb - U + 1 < 4;       // holds one of the rows 1, 2, 3, n-4, n-3, n-2 (kept for the boundary formulas), or runs past row 1
+        auto bwd_row = [&](auto edge_c, int u) {
+            constexpr bool EDGE = decltype(edge_c)::value;
             const int j = jb - u;
-            if (j < 1) break;
+            if (EDGE && j < 1) return;
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const double x = (yb[u][l] + x1[l] * db[u] + x2[l] * eb[u]) * cb[u];
                 a.dst[((long long)l * n + j) * nm + t] = x;
                 x2[l] = x1[l];
                 x1[l] = x;
-                if (j == 1) xs1[l] = x;
-                if (j == 2) xs2[l] = x;
-                if (j == 3) xs3[l] = x;
-                if (j == n - 2) xe2[l] = x;
-                if (j == n - 3) xe3[l] = x;
-                if (j == n - 4) xe4[l] = x;
+                if (EDGE) {
+                    if (j == 1) xs1[l] = x;
+                    if (j == 2) xs2[l] = x;
+                    if (j == 3) xs3[l] = x;
+                    if (j == n - 2) xe2[l] = x;
+                    if (j == n - 3) xe3[l] = x;
+                    if (j == n - 4) xe4[l] = x;
+                }
             }
+        };
+        if (edge_blk) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) bwd_row(std::true_type{}, u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) bwd_row(std::false_type{}, u);
         }
     }
 
@@ -1907,8 +1930,13 @@ void launch_int1(const Int1Args &a, hipStream_t st) {
     const bool few = a.nm <= 8;   // the <= 4 singular modes, solved beside the regular ones on the side stream
     ProfScope ps(few ? "k_int1<singular modes>" : (FS == FS_FIELD ? "k_int1<field>" : (FS == FS_LINEAR ? "k_int1<linear>" : "k_int1<unit>")), st,
                  (double)a.nm * a.T.n * 16.0 * NL);
-    if (a.nm < 65536) hipLaunchKernelGGL((k_int1<BC, NL, FS, 8>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_int1<BC, NL, FS, 2>), dim3(grid), dim3(256), 0, st, a);
+    if (a.fac) {
+        if (a.nm < 65536) hipLaunchKernelGGL((k_int1<BC, NL, FS, 8, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_int1<BC, NL, FS, 2, true>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (a.nm < 65536) hipLaunchKernelGGL((k_int1<BC, NL, FS, 8, false>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_int1<BC, NL, FS, 2, false>), dim3(grid), dim3(256), 0, st, a);
+    }
     hipc(hipGetLastError(), "k_int1");
 }
 
