@@ -380,7 +380,7 @@ int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double k
  * z-systems are partitioned at the slab boundaries (tlab_zslab_* above: 3 halo planes of the operand + one value per line and system from each ring
  * neighbour), and the Poisson solver goes z-slab -> kx-pencil with ONE all-to-all after the x-FFT and one per output field on the way back, pipelined
  * in two kx halves against the per-mode solves (tlab_amd/csrc/slab.cpp).  The exchanges go through a transport the caller hands in:
- *   - tlab_comm_slab_transport (libtlab_amd_comm.so): RCCL grouped ncclSend / ncclRecv on the library's communication stream, so that the x / y
+ *   - tlab_comm_slab_transport, in libtlab_amd_comm.so: RCCL grouped ncclSend / ncclRecv on the library's communication stream, so that the x / y
  *     operators on the compute stream (tlab_set_stream) run while halo planes, interface values and pencil blocks travel over xGMI;
  *   - tlab_slab_transport_loopback: all P ranks inside one process on one device (exchanges = device copies): the complete decomposed algorithm
  *     against the single-domain result on a single GPU;

@@ -31,3 +31,44 @@ def rel_err(a, b):
 def has_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+PARITY_ROUND = "r03"
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Composed-path parity, auditable: every comparison of a device (or CPU-port) error against a scatter-derived bound made in this session goes
+    to profiles/<round>/parity_table.json -- per test the measured error, the oracle's own one-ulp scatter, the bound used and what set it.  Written
+    on GPU sessions only (the -m "not gpu" suite holds two such comparisons); a copy under gpurun_out/ travels back from the GPU box."""
+    try:
+        import json
+        import subprocess
+        import torch
+        from scatter import PARITY_RECORDS
+        if not PARITY_RECORDS or not torch.cuda.is_available():
+            return
+        rows = {}
+        for r in PARITY_RECORDS:          # worst comparison per (test, bound): a test checks many fields against one scatter list
+            key = (r["test"], r["bound_set_by"])
+            k = rows.setdefault(key, dict(r, comparisons=0, max_err=0.0, max_err_over_bound=0.0, max_oracle_scatter=0.0, max_bound=0.0))
+            k["comparisons"] += 1
+            k["max_err"] = max(k["max_err"], r["err"])
+            k["max_err_over_bound"] = max(k["max_err_over_bound"], r["err"] / r["bound"])
+            k["max_oracle_scatter"] = max(k["max_oracle_scatter"], r["oracle_scatter"])
+            k["max_bound"] = max(k["max_bound"], r["bound"])
+            k["ok"] = k["ok"] and r["ok"]
+        table = [{"test": t, "bound_set_by": by, "comparisons": k["comparisons"], "max_err": k["max_err"], "max_oracle_scatter": k["max_oracle_scatter"],
+                  "max_bound": k["max_bound"], "max_err_over_bound": k["max_err_over_bound"], "all_within": k["ok"]} for (t, by), k in sorted(rows.items())]
+        try:
+            head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+        except Exception:       # noqa: BLE001
+            head = None
+        doc = {"what": "device error vs oracle scatter vs bound for every composed-path comparison of this pytest session (tests/scatter.py::Bound)",
+               "bound": "max(1e-12, factor x oracle one-ulp scatter)", "commit": head, "exitstatus": int(exitstatus),
+               "rows_above_floor": sum(1 for r in table if r["max_bound"] > 1e-12), "rows": table}
+        for d in (os.path.join(ROOT, "profiles", PARITY_ROUND), os.path.join(ROOT, "gpurun_out", PARITY_ROUND)):
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "parity_table.json"), "w") as f:
+                json.dump(doc, f, indent=1)
+    except Exception as e:       # noqa: BLE001  (bookkeeping must never fail a test session)
+        print("parity table not written:", e)

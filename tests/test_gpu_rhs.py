@@ -8,12 +8,12 @@ from scatter import substep_scatter, bound
 REF_HYPER = 0.1      # wall closure of the flang-built reference (defect 1); the driver classes default to the consistent 0.0
 
 
-def check_state(d, B, S, k, names=("q", "hq", "s", "hs"), tag=""):
-    """Device state after substep k against the oracle's, each field within max(1e-12, 2 x the oracle's own one-ulp scatter) (tests/scatter.py)."""
+def check_state(d, B, S, k, names=("q", "hq", "s", "hs"), tag="", factor=2.0):
+    """Device state after substep k against the oracle's, each field within max(1e-12, factor x the oracle's own one-ulp scatter) (tests/scatter.py)."""
     for name in names:
         for i, (b, sc) in enumerate(zip(B[k][name], S[k][name])):
             e = rel_err(getattr(d, name)[i].cpu().numpy(), b)
-            assert e <= bound(sc), (tag, k, name, i, "err %.2e" % e, "oracle scatter %.2e" % sc)
+            assert e <= bound(sc, factor), (tag, k, name, i, "err %.2e" % e, "oracle scatter %.2e" % sc)
 
 pytestmark = pytest.mark.gpu
 
@@ -232,7 +232,9 @@ def test_line_lengths_of_the_large_configs(T, nx, ny, nz, nscal, stretch, exact)
     that the numpy oracle finishes in seconds: every kernel selection that depends on n is exercised at its real n.
     The first substep projects a field that is not solenoidal: the pressure forcing div(q)/dte is 1e4-1e5 for a pressure of 1e2, and the
     solve amplifies rounding accordingly.  The bound is therefore MEASURED: the oracle is run a second time from fields moved by one ulp of
-    white noise, and the device must stay within max(1e-12, 2 x that scatter) of the oracle (tests/scatter.py), in either mode of the solver."""
+    white noise, and the device must stay within max(1e-12, 2 x that scatter) of the oracle (tests/scatter.py); with the exact mode of the solver
+    (tlab_poisson_set_exact(1): the reference's operations one by one, transforms still rocFFT's) within 1.6 x that scatter (measured on the
+    bare solve: 1.5 x, tests/test_gpu_poisson.py::test_projection_forcing_within_the_oracles_own_scatter)."""
     import torch
     from tlab_amd.dns import Dns
     from oracle.tlab_oracle_rhs import DnsOracle
@@ -253,12 +255,12 @@ def test_line_lengths_of_the_large_configs(T, nx, ny, nz, nscal, stretch, exact)
     dt = 1e-3
     sched = [(dt * d.kdt[k], d.kco[k], True) for k in range(2)]
     B, S = oracle_substeps(("lines", nx, ny, nz), lambda: DnsOracle(x, y, z, nscal=nscal, visc=visc, schmidt=sc, yuniform=not stretch), q0, ss, sched,
-                           nsamples=1)
+                           nsamples=3)
     for k, (dte, kco, scale) in enumerate(sched):
         d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
     errs = [rel_err(d.q[i].cpu().numpy(), B[1]["q"][i]) for i in range(3)]
     print("exact" if exact else "fast ", (nx, ny, nz), "err", ["%.1e" % e for e in errs], "oracle one-ulp scatter", ["%.1e" % e for e in S[1]["q"]])
-    check_state(d, B, S, 1, names=("q", "s"), tag="exact" if exact else "fast")
+    check_state(d, B, S, 1, names=("q", "s"), tag="exact" if exact else "fast", factor=1.6 if exact else 2.0)
 
 
 @pytest.mark.parametrize("fuse,nx", [(True, 256), (False, 256), (True, 48)])
@@ -508,18 +510,28 @@ def test_anelastic_burgers_operators_vs_oracle(T, nx, ny, nz, stretch):
         check(load().tlab_opr_burgers_set_anelastic(ny, rb.ctypes.data_as(dp), rb.ctypes.data_as(dp)), "set_anelastic")
 
 
-@pytest.mark.parametrize("bcs", ["noslip", "freeslip"])
+@pytest.mark.parametrize("bcs", ["noslip", "freeslip", "noslip, set through the operators"])
 @pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (128, 64, 64, True), (256, 64, 64, True)])      # the last: the fused Burgers launches
 def test_anelastic_substep_vs_oracle(T, nx, ny, nz, stretch, bcs):
+    """"set through the operators": only tlab_opr_burgers_set_anelastic is called (what the Fortran shim OPR_Burgers_AMD_Anelastic does) -- the RHS
+    driver follows the operator state, so the Burgers terms and the density weights of the pressure step cannot disagree about the equations."""
+    import ctypes
     import torch
     from tlab_amd.dns import Dns, velocity_bcs
+    from tlab_amd.lib import load, check
     from oracle.tlab_oracle_rhs import DnsOracle
     x, y, z = grids(nx, ny, nz, stretch)
     rb, ri = background(y)
     visc, sc = 1.0 / 800.0, (0.7,)
     q0, s0 = init_fields(nx, ny, nz, x, y, z, 5)
     d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=REF_HYPER)
-    d.set_anelastic(rb)
+    if bcs.endswith("operators"):
+        dp = ctypes.POINTER(ctypes.c_double)
+        rbc, ric = np.ascontiguousarray(rb), np.ascontiguousarray(ri)
+        check(load().tlab_opr_burgers_set_anelastic(ny, rbc.ctypes.data_as(dp), ric.ctypes.data_as(dp)), "tlab_opr_burgers_set_anelastic")
+        bcs = "noslip"
+    else:
+        d.set_anelastic(rb)
     try:
         if bcs == "freeslip":
             d.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
@@ -535,6 +547,8 @@ def test_anelastic_substep_vs_oracle(T, nx, ny, nz, stretch, bcs):
                 o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
             return o
         B, S = oracle_substeps(("anel", nx, ny, nz, stretch, bcs), make_oracle, q0, s0, sched, nsamples=2)
+        other = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=REF_HYPER)
+        del other                      # destroying a driver that did not switch the state on must leave it on
         for k, (dte, kco, scale) in enumerate(sched):
             d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
             check_state(d, B, S, k, tag="anelastic " + bcs)
@@ -581,6 +595,41 @@ def test_dynamic_surface_bcs_vs_oracle(T, sides, fuse):
         d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
         check_state(d, B, S, k, tag="surface " + sides)
     assert np.abs(B[2]["hs"][0].reshape(nz, ny, nx)[:, 0, :]).max() > 1e-3          # (the bottom plane of the tendency is alive)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_dynamic_surface_bcs_over_two_runge_kutta_steps(T, fuse):
+    """The kept tendency planes of the surface model across a step boundary: the device driver is TOLD that hq, hs are zero at the start of a step
+    (begin_step instead of the fill of time.f90:212-216), so the planes it keeps in the first substep of the SECOND step must be zero too, not
+    what hs still holds from the step before (BcsScal%ref = 0 there in the reference)."""
+    import torch
+    from tlab_amd.dns import Dns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 64, 48, 32
+    x, y, z = grids(nx, ny, nz, True)
+    visc, sc = 1.0 / 800.0, (0.7,)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 13)
+    d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    d.set_fusion(fuse)
+    d.set_surface_bcs(["linear"], ["linear"], [0.35], [-0.2])
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i]))
+    d.s[0].copy_(torch.from_numpy(s0[0]))
+    dtime = 2e-3
+    sched = [(dtime * d.kdt[k % 3], d.kco[k % 3] if k % 3 < 2 else 1.0, k % 3 < 2, k % 3 == 0) for k in range(6)]
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        o.sfc_jmin, o.cpl_jmin, o.sfc_jmax, o.cpl_jmax = [1], [0.35], [1], [-0.2]
+        return o
+    B, S = oracle_substeps(("sfc two steps",), make_oracle, q0, s0, sched, nsamples=2)
+    for k, (dte, kco, scale, new_step) in enumerate(sched):
+        if new_step:
+            d.begin_step()
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
+        check_state(d, B, S, k, tag="surface, two steps")
+    # the planes the second step would wrongly keep are not small: the unscaled last-substep tendency of step 1
+    assert np.abs(B[2]["hs"][0].reshape(nz, ny, nx)[:, 0, :]).max() > 1e-3
 
 
 @pytest.mark.parametrize("fuse", [True, False])

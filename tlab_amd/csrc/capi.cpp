@@ -912,6 +912,7 @@ bool tlab_internal_burgers_acc_n(int dir, tlab_fdm_plan_t g, int nx, int ny, int
                                  int scale, double *divx, double idte, unsigned fresh_mask, const double *ari) {
     check_common(dir, g, nx, ny, nz, ibc);
     if (nf < 1 || nf > 4) throw Invalid("1 to 4 fields per call");
+    if (tlab_internal_anelastic() && !ari) return false;      // the operator state says anelastic: the plain fused kernels would drop the density weight
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
     OpExtra ex;
@@ -1126,11 +1127,16 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
 // fdmDiffusion(2); physics/opr_burgers.f90:128-183)
 static std::unique_ptr<DeviceArray> g_anelastic_ri;
 static int g_anelastic_ny = 0;
+// the host copies and a change counter: the RHS drivers (rhs.cpp) follow this state instead of keeping one of their own that could disagree with it
+static std::vector<double> g_anelastic_rb_host, g_anelastic_ri_host;
+static unsigned long g_anelastic_version = 0;
 int tlab_opr_burgers_set_anelastic(int ny, const double *rbackground, const double *ribackground) {
     return guarded([&] {
         if (ny <= 0 || !rbackground || !ribackground) {      // back to the incompressible operator
             g_anelastic_ri.reset();
             g_anelastic_ny = 0;
+            g_anelastic_rb_host.clear(); g_anelastic_ri_host.clear();
+            ++g_anelastic_version;
             return;
         }
         if (g_device < 0) throw HipError("tlab_init has not been called (no CPU fallback exists)");
@@ -1141,9 +1147,17 @@ int tlab_opr_burgers_set_anelastic(int ny, const double *rbackground, const doub
         g_anelastic_ri = std::make_unique<DeviceArray>();
         g_anelastic_ri->upload(std::vector<double>(ribackground, ribackground + ny));
         g_anelastic_ny = ny;
+        g_anelastic_rb_host.assign(rbackground, rbackground + ny);
+        g_anelastic_ri_host.assign(ribackground, ribackground + ny);
+        ++g_anelastic_version;
     });
 }
 bool tlab_internal_anelastic() { return g_anelastic_ny > 0; }
+// ny of the profiles (0: incompressible), the host copies and the change counter
+int tlab_internal_anelastic_state(const double **rb, const double **rib, unsigned long *version) {
+    *rb = g_anelastic_rb_host.data(); *rib = g_anelastic_ri_host.data(); *version = g_anelastic_version;
+    return g_anelastic_ny;
+}
 
 // [Dealiasing] (physics/opr_burgers.f90:33, 71, 118-125): Dealiasing(1:3), one filter per direction (NULL = DNS_FILTER_NONE); NOT owned
 static tlab_filter_t g_dealias[3] = {nullptr, nullptr, nullptr};
@@ -1155,6 +1169,11 @@ int tlab_opr_burgers_set_dealiasing(int dir, tlab_filter_t f) {
     });
 }
 bool tlab_internal_dealiasing() { return g_dealias[0] || g_dealias[1] || g_dealias[2]; }
+// a filter that is being destroyed while still set as Dealiasing(dir) is taken out (tlab_filter_destroy): no dangling pointer in the Burgers operators
+void tlab_internal_dealiasing_forget(tlab_filter_t f) {
+    for (int i = 0; i < 3; ++i)
+        if (g_dealias[i] == f) g_dealias[i] = nullptr;
+}
 static double *dealias_ws(int k, size_t n) {
     if (!g_wsd[k]) g_wsd[k] = new DeviceArray();
     if (g_wsd[k]->n < n) {

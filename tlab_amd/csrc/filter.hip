@@ -17,6 +17,7 @@
 #include "plan.hpp"
 #include "profile.hpp"
 
+extern "C" void tlab_internal_dealiasing_forget(tlab_filter_t f);      // capi.cpp
 extern hipStream_t tlab_current_stream();
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
@@ -228,6 +229,7 @@ int tlab_filter_create(tlab_filter_t *out, int type, int size, int periodic, int
 }
 
 int tlab_filter_destroy(tlab_filter_t f) {
+    if (f) tlab_internal_dealiasing_forget(f);      // (a [PressureFilter] of a live tlab_dns must be taken out by its owner first: tlab_dns_set_pressure_filter)
     delete f;
     return TLAB_OK;
 }

@@ -30,6 +30,7 @@ bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, in
                                   double kco, int scale);
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 extern "C" bool tlab_internal_dealiasing();      // capi.cpp (defined inside its extern "C" block)
+extern "C" int tlab_internal_anelastic_state(const double **rb, const double **rib, unsigned long *version);
 bool tlab_internal_poisson_can_v_final(tlab_poisson_plan_t P);                                                      // poisson.hip
 void tlab_internal_poisson_arm_v_final(tlab_poisson_plan_t P, double *q, double *h, double dte, double kco, int scale);
 bool tlab_internal_burgers_can_finish(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
@@ -71,6 +72,8 @@ struct tlab_dns {
     // nse_eqns == DNS_EQNS_ANELASTIC: rbackground, ribackground (ny values each) on the device; the wall values of rbackground on the host
     double *rb = nullptr, *rib = nullptr;
     double rb_wall[2] = {1.0, 1.0};
+    unsigned long anel_version = 0;                // change counter of the operator state these mirror (follow_anelastic)
+    bool anel_owner = false;                       // this driver switched the operator state on (tlab_dns_set_anelastic): it goes with the driver
     ~tlab_dns() {
         if (bcs_hb) (void)hipFree(bcs_hb);
         if (bcs_ht) (void)hipFree(bcs_ht);
@@ -150,9 +153,40 @@ int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tla
 }
 
 int tlab_dns_destroy(tlab_dns_t d) {
-    if (d && d->rb) (void)tlab_opr_burgers_set_anelastic(0, nullptr, nullptr);      // the operator state this driver set (tlab_dns_set_anelastic) goes with it
+    // the operator state THIS driver switched on goes with it; one set through tlab_opr_burgers_set_anelastic (OPR_Burgers_AMD_Anelastic) or by
+    // another driver since is not this driver's to clear
+    if (d && d->anel_owner && d->rb) {
+        const double *rb, *rib;
+        unsigned long ver;
+        (void)tlab_internal_anelastic_state(&rb, &rib, &ver);
+        if (ver == d->anel_version) (void)tlab_opr_burgers_set_anelastic(0, nullptr, nullptr);
+    }
     delete d;
     return TLAB_OK;
+}
+
+// The anelastic state lives with the operators (tlab_opr_burgers_set_anelastic = the module variables of OPR_Burgers_Initialize); the driver's density
+// weights follow it, whichever entry point set it (tlab_dns_set_anelastic, tlab_opr_burgers_set_anelastic, Fortran OPR_Burgers_AMD_Anelastic), so the
+// Burgers operators and the pressure step can never disagree about the equations being solved.
+static void follow_anelastic(tlab_dns_t d) {
+    const double *rb, *rib;
+    unsigned long ver;
+    const int ny = tlab_internal_anelastic_state(&rb, &rib, &ver);
+    if (ver == d->anel_version) return;
+    if (d->rb) { (void)hipFree(d->rb); d->rb = nullptr; }
+    if (d->rib) { (void)hipFree(d->rib); d->rib = nullptr; }
+    d->rb_wall[0] = d->rb_wall[1] = 1.0;
+    if (ny > 0) {
+        if (ny != d->ny) throw Fail(TLAB_EINVAL, "the anelastic profiles of the operators (tlab_opr_burgers_set_anelastic) have another ny than this driver");
+        const size_t bytes = (size_t)ny * sizeof(double);
+        hk(hipMalloc((void **)&d->rb, bytes), "hipMalloc");
+        hk(hipMalloc((void **)&d->rib, bytes), "hipMalloc");
+        hk(hipMemcpy(d->rb, rb, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+        hk(hipMemcpy(d->rib, rib, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+        d->rb_wall[0] = rb[0];
+        d->rb_wall[1] = rb[ny - 1];
+    }
+    d->anel_version = ver;
 }
 
 // dst += Burgers_dir(s; vel): fused accumulation when the fast kernels apply, otherwise the reference's temp + add path
@@ -170,6 +204,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     const int nx = d->nx, ny = d->ny, nz = d->nz;
     const long long n = (long long)nx * ny * nz;
     hipStream_t st = tlab_current_stream();
+    follow_anelastic(d);
     double *u = q[0], *v = q[1], *w = q[2];
     double *tmp1 = txc[0], *tmp2 = txc[1], *tmp3 = txc[2], *tmp4 = txc[3], *tmp7 = txc[6], *tmp8 = txc[7], *tmp9 = txc[8];
     tlab_fdm_plan_t gx = d->g[0], gy = d->g[1], gz = d->g[2];
@@ -183,6 +218,13 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     for (int is = 0; is < d->nscal; ++is) {      // keep the old tendency of the scalar at the boundary for the dynamic BCs (:77-87); zero otherwise
         if (!surface(is)) continue;
         any_surface = true;
+        // at the start of a Runge-Kutta step the tendencies COUNT as zero (tlab_dns_begin_step instead of the fill of time.f90:212-216): whatever
+        // hs still holds from the last step must not become BcsScal%ref
+        if (d->fresh) {
+            hk(hipMemsetAsync(d->sref_b[is], 0, (size_t)nx * nz * sizeof(double), st), "memset");
+            hk(hipMemsetAsync(d->sref_t[is], 0, (size_t)nx * nz * sizeof(double), st), "memset");
+            continue;
+        }
         hk(launch_get_wall_planes(hs[is], d->sref_b[is], d->sref_t[is], nx, ny, nz, st), "wall planes");
         if (d->sfc_jmin[is] != 1) hk(hipMemsetAsync(d->sref_b[is], 0, (size_t)nx * nz * sizeof(double), st), "memset");
         if (d->sfc_jmax[is] != 1) hk(hipMemsetAsync(d->sref_t[is], 0, (size_t)nx * nz * sizeof(double), st), "memset");
@@ -598,20 +640,10 @@ int tlab_dns_set_surface_bcs(tlab_dns_t d, const int *sfc_jmin, const int *sfc_j
 int tlab_dns_set_anelastic(tlab_dns_t d, const double *rbackground, const double *ribackground) {
     if (!d) return TLAB_EINVAL;
     try {
-        if (d->rb) { (void)hipFree(d->rb); d->rb = nullptr; }
-        if (d->rib) { (void)hipFree(d->rib); d->rib = nullptr; }
-        if (!rbackground || !ribackground) {
-            ok(tlab_opr_burgers_set_anelastic(0, nullptr, nullptr), "tlab_opr_burgers_set_anelastic");
-            return TLAB_OK;
-        }
-        ok(tlab_opr_burgers_set_anelastic(d->ny, rbackground, ribackground), "tlab_opr_burgers_set_anelastic");
-        const size_t bytes = (size_t)d->ny * sizeof(double);
-        hk(hipMalloc((void **)&d->rb, bytes), "hipMalloc");
-        hk(hipMalloc((void **)&d->rib, bytes), "hipMalloc");
-        hk(hipMemcpy(d->rb, rbackground, bytes, hipMemcpyHostToDevice), "hipMemcpy");
-        hk(hipMemcpy(d->rib, ribackground, bytes, hipMemcpyHostToDevice), "hipMemcpy");
-        d->rb_wall[0] = rbackground[0];
-        d->rb_wall[1] = rbackground[d->ny - 1];
+        if (!rbackground || !ribackground) ok(tlab_opr_burgers_set_anelastic(0, nullptr, nullptr), "tlab_opr_burgers_set_anelastic");
+        else ok(tlab_opr_burgers_set_anelastic(d->ny, rbackground, ribackground), "tlab_opr_burgers_set_anelastic");
+        follow_anelastic(d);
+        d->anel_owner = d->rb != nullptr;
         return TLAB_OK;
     } catch (const Fail &e) {
         tlab_set_error(e.what());
