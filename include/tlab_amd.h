@@ -60,6 +60,7 @@ extern "C" {
 
 /* ---- runtime ------------------------------------------------------------------------------ */
 int tlab_init(int device);                 /* hipSetDevice + library state; idempotent            */
+int tlab_device_count(void);               /* visible GPUs (hipGetDeviceCount; 0 if none): a multi-rank host selects mod(local rank, count) */
 int tlab_finalize(void);
 const char *tlab_last_error(void);
 int tlab_set_stream(void *hip_stream);     /* hipStream_t; NULL = default stream                  */
@@ -417,11 +418,11 @@ int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *transp
                          int nx, int ny, int nz_total, int nscal, double visc, const double *schmidt, tlab_fdm_plan_t gy_elliptic);
 int tlab_slab_dns_destroy(tlab_slab_dns_t d);
 /* The module arrays of local rank l (0 for a one-rank process): q[3], s[nscal], hq[3], hs[nscal], txc[9] as tlab_rhs_global_incompressible_1
- * (HOST arrays of DEVICE pointers; txc of (nx+2)*ny*kmax doubles each).  Every array must have tlab_slab_dns_info(d, 3) doubles of room BEFORE its
- * first element and AFTER its nx*ny*kmax-th one: the neighbours' halo planes land there (the allocation hook of the Fortran host adds that room when
- * ims_npro_k > 1).  The pointers are kept: call again if the host moves its arrays. */
+ * (HOST arrays of DEVICE pointers; txc of (nx+2)*ny*kmax doubles each).  Plain arrays: the neighbours' halo planes land in buffers of the driver
+ * (the columns of a Fortran host's q(isize_field, 3) lie back to back: there is no room around a field).  The pointers are kept: call again if
+ * the host moves its arrays. */
 int tlab_slab_dns_bind(tlab_slab_dns_t d, int l, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc);
-/* what: 0 kmax, 1 nranks, 2 nlocal, 3 halo room in doubles (3 planes), 4 pipeline stages of the pencil exchange, 5 first local rank */
+/* what: 0 kmax, 1 nranks, 2 nlocal, 3 doubles of one halo (3 planes), 4 pipeline stages of the pencil exchange, 5 first local rank */
 long long tlab_slab_dns_info(tlab_slab_dns_t d, int what);
 int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d);                 /* as tlab_dns_begin_step */

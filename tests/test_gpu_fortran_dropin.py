@@ -58,7 +58,7 @@ End={steps}
 RK_EXE_FUSED = os.path.join(ROOT, "tlab_amd", "fortran", "_build_rk_fused", "test_rk_driver")
 
 
-def run_rk_driver(tmp_path, x, y, z, q0, s0, reynolds, schmidt, dtime, steps, bcs_lines, elliptic="", ini=None, exe=None):
+def run_rk_driver(tmp_path, x, y, z, q0, s0, reynolds, schmidt, dtime, steps, bcs_lines, elliptic="", ini=None, exe=None, env=None):
     """Writes tlab.ini, grid, flow.0.*, scal.0.* in the reference's formats, runs the Fortran mini-driver there, reads flow.<steps>.*, scal.<steps>.*"""
     import numpy as np
     from tlab_amd import io as tio
@@ -69,7 +69,7 @@ def run_rk_driver(tmp_path, x, y, z, q0, s0, reynolds, schmidt, dtime, steps, bc
     tio.grid_write(os.path.join(tmp_path, "grid"), x, y, z, scales=[x[-1] - x[0] + (x[1] - x[0]), y[-1] - y[0], z[-1] - z[0] + (z[1] - z[0])])
     tio.io_write_fields(os.path.join(tmp_path, "flow.0"), nx, ny, nz, 0, q0, params=(0.0, 1.0 / reynolds))
     tio.io_write_fields(os.path.join(tmp_path, "scal.0"), nx, ny, nz, 0, s0, params=(0.0,))
-    r = subprocess.run([exe or RK_EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe or RK_EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     log = ""
     for name in ("tlab.err", "tlab.log"):
         p = os.path.join(tmp_path, name)
@@ -143,6 +143,50 @@ def test_fortran_rk_driver_fast_kernels(tmp_path, fused):
     for i in range(3):
         assert rel_err(q1[i], B[2]["q"][i]) <= bound(S[2]["q"][i]), ("q", i, rel_err(q1[i], B[2]["q"][i]), S[2]["q"][i])
     assert rel_err(s1[0], B[2]["s"][0]) <= bound(S[2]["s"][0])
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused):
+    """The decomposed route of the Fortran host: RHS_GLOBAL_INCOMPRESSIBLE_1 (and TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD) hand the substep to the
+    native z-slab driver -- tlab_slab_dns_create over the RCCL communicator of module TLabMPI_Transpose, the module arrays q(:, 1:3), s, hq, hs,
+    txc bound as they are (columns back to back: the halo planes live in the driver's buffers).  One GPU here, so TLAB_AMD_FORCE_SLAB=1 takes that
+    route with ims_npro_k = 1: the rank is its own ring neighbour and all-to-all peer, through ncclSend / ncclRecv.  Against the oracle."""
+    import numpy as np
+    from conftest import rel_err
+    from scatter import substep_scatter, bound
+    from oracle.tlab_oracle_rhs import DnsOracle
+    _need_rk()
+    if fused and not os.path.exists(RK_EXE_FUSED):
+        pytest.skip("tlab_amd/fortran/_build_rk_fused/test_rk_driver not built")
+    nx, ny, nz = 64, 32, 64
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(64)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * Y)
+    q0 = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3)]
+    s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    re, sc, dt = 1000.0, 0.7, 1e-3
+    bcs = ["VelocityJmin=freeslip", "VelocityJmax=freeslip", "Scalar1Jmin=neumann", "Scalar1Jmax=dirichlet"]
+    q1, s1, log = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 2, bcs, exe=RK_EXE_FUSED if fused else None, env={"TLAB_AMD_FORCE_SLAB": "1"})
+    kdt, kco = [1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0], [-5.0 / 9.0, -153.0 / 128.0]
+    sched = [(dt * kdt[k % 3], kco[k % 3] if k % 3 < 2 else 1.0, k % 3 < 2, k % 3 == 0) for k in range(6)]
+
+    def make_oracle():
+        from tlab_amd.dns import velocity_bcs
+        o = DnsOracle(x, y, z, nscal=1, visc=1.0 / re, schmidt=(sc,), yuniform=False)
+        o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
+        return o
+    B, S = substep_scatter(make_oracle, q0, s0, sched, nsamples=1)
+    for i in range(3):
+        assert rel_err(q1[i], B[5]["q"][i]) <= bound(S[5]["q"][i]), ("q", i, rel_err(q1[i], B[5]["q"][i]), S[5]["q"][i])
+    assert rel_err(s1[0], B[5]["s"][0]) <= bound(S[5]["s"][0])
+    # and it did take the slab route: the single-domain driver state was never created (its Poisson plan logs nothing; the slab one is silent too),
+    # so ask the run itself: a second run without the switch differs in the last bits (another operator order), not in substance
+    q2, _, _ = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 2, bcs, exe=RK_EXE_FUSED if fused else None)
+    d = max(rel_err(q1[i], q2[i]) for i in range(3))
+    assert 0.0 < d <= 1e-10, d
 
 
 def test_fortran_rk_driver_direct_schemes_from_the_ini_file(tmp_path):

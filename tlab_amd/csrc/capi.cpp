@@ -383,6 +383,12 @@ int tlab_finalize(void) {
     });
 }
 
+int tlab_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 int tlab_set_stream(void *s) {
     g_stream = (hipStream_t)s;
     return TLAB_OK;

@@ -27,6 +27,15 @@
 extern hipStream_t tlab_current_stream();
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
+// zslab.hip: the z-slab operators with the neighbours' halo planes of every operand in buffers of their own ({lo, hi}, 3 planes each)
+int tlab_internal_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny, const double *u, const double *const *u_halo, const double *ub,
+                                  const double *const *ub_halo, double scale, double *head, double *tail, const double *tail_left,
+                                  const double *head_right, double *result, int acc);
+int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s,
+                                    const double *const *s_lo, const double *const *s_hi, const double *vel, double *head, double *tail,
+                                    const double *tail_left, const double *head_right, double *const *result, int acc);
+int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *const *p_halo, const double *tail_left,
+                                         const double *head_right, double *q, double *h, double dte, double kco, int scale);
 
 namespace {
 
@@ -106,6 +115,10 @@ struct Rank {
     double *head = nullptr, *tail = nullptr, *head_right = nullptr, *tail_left = nullptr;   // interface values, [2 (3 + ns)][nx*ny]
     double *pen[3] = {nullptr, nullptr, nullptr};   // complex kx-pencils (nxl, ny, nz_total)
     double *pack[2] = {nullptr, nullptr};           // complex slabs blocked by peer
+    // The neighbours' halo planes (3 before = lo, 3 after = hi) of the fields a z-operator reads: q(1:3), s(1:ns), hq(3), tmp1.  Buffers of the
+    // driver's own: the module arrays of a Fortran host (q(isize_field, 3): columns back to back) have no room around a field.
+    double *halo = nullptr;                         // one allocation: [3 + ns + 2][2][3 planes]
+    std::vector<const double *> lo, hi;             // per field slot: 0..2 q, 3..2+ns s, 3+ns hq(3), 4+ns tmp1
     std::vector<double *> q, s, hq, hs, txc;     // bound module arrays
     bool bound = false;
 };
@@ -134,7 +147,7 @@ struct tlab_slab_dns {
             if (R.poisson) (void)tlab_poisson_plan_destroy(R.poisson);
             if (R.poisson_b) (void)tlab_poisson_plan_destroy(R.poisson_b);
             if (R.zplan) (void)tlab_zslab_plan_destroy(R.zplan);
-            for (double *p : {R.hb, R.ht, R.head, R.tail, R.head_right, R.tail_left, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1]})
+            for (double *p : {R.hb, R.ht, R.head, R.tail, R.head_right, R.tail_left, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1], R.halo})
                 if (p) (void)hipFree(p);
         }
         if (tr.destroy) tr.destroy(tr.ctx);
@@ -165,19 +178,23 @@ int ring(D *d, int nmsg, const std::vector<long long> &count, F fill) {
     return t;
 }
 
-// Halo planes of `nf` fields (picked by `field(R, i)`): my last planes go to the right neighbour's planes -H..-1, my first planes to the left
-// neighbour's planes kmax..kmax+H-1 (periodic in z).  Zero-copy: the planes are contiguous in memory on both sides.
+// Halo planes of `nf` fields (picked by `field(R, i)` -> (array, halo slot)): my last planes go to the right neighbour's planes -H..-1 (its lo
+// buffer), my first planes to the left neighbour's planes kmax..kmax+H-1 (its hi buffer); periodic in z.  The send side is the field itself.
+struct Slot {
+    double *f;
+    int slot;
+};
 template <class F>
 int halo_start(D *d, int nf, F field) {
     const long long Hn = HALO * d->npage, n = d->n;
     std::vector<long long> count((size_t)nf, Hn);
     return ring(d, nf, count, [&](Rank &R, double **tl, double **tr, double **fr, double **fl) {
         for (int i = 0; i < nf; ++i) {
-            double *f = field(R, i);
-            tl[i] = f;
-            tr[i] = f + n - Hn;
-            fr[i] = f + n;         // planes kmax .. kmax+H-1
-            fl[i] = f - Hn;        // planes -H .. -1
+            const Slot sl = field(R, i);
+            tl[i] = sl.f;
+            tr[i] = sl.f + n - Hn;
+            fr[i] = const_cast<double *>(R.hi[sl.slot]);       // planes kmax .. kmax+H-1
+            fl[i] = const_cast<double *>(R.lo[sl.slot]);       // planes -H .. -1
         }
     });
 }
@@ -223,16 +240,19 @@ void zburgers_all(D *d, Rank &R, int phase) {
         double *rp[4];
         for (int f = 0; f < nf; ++f) { nus[f] = E[e0 + f].nu; sp[f] = E[e0 + f].f; rp[f] = E[e0 + f].h; }
         const long long o = 2 * (long long)e0 * d->npage;
-        ok(tlab_zslab_burgers_z_n(R.zplan, phase, d->nx, d->ny, nf, nus, sp, phase == 2 ? R.q[2] : nullptr, R.head + o, R.tail + o, R.tail_left + o,
-                                  R.head_right + o, phase == 2 ? rp : nullptr, 1),
+        ok(tlab_internal_zslab_burgers_z_n(R.zplan, phase, d->nx, d->ny, nf, nus, sp, &R.lo[e0], &R.hi[e0], phase == 2 ? R.q[2] : nullptr, R.head + o,
+                                           R.tail + o, R.tail_left + o, R.head_right + o, phase == 2 ? rp : nullptr, 1),
            "tlab_zslab_burgers_z_n");
     }
 }
 void padd(D *d, Rank &R, int dir, const double *u, const double *ub, double scale, double *res, int acc) {
     ok(tlab_opr_partial_add(dir, d->g[dir - 1], d->nx, d->ny, d->kmax, 0, u, ub, scale, res, acc, R.txc[6], R.txc[7]), "tlab_opr_partial_add");
 }
-void zpartial(D *d, Rank &R, int phase, const double *u, const double *ub, double scale, double *res, int acc) {
-    ok(tlab_zslab_partial_z(R.zplan, phase, d->nx, d->ny, u, ub, scale, R.head, R.tail, R.tail_left, R.head_right, res, acc), "tlab_zslab_partial_z");
+// us, ubs: halo slots of the operands (ubs ignored without ub)
+void zpartial(D *d, Rank &R, int phase, const double *u, int us, const double *ub, int ubs, double scale, double *res, int acc) {
+    const double *uh[2] = {R.lo[us], R.hi[us]}, *ubh[2] = {R.lo[ub ? ubs : us], R.hi[ub ? ubs : us]};
+    ok(tlab_internal_zslab_partial_z(R.zplan, phase, d->nx, d->ny, u, uh, ub, ubh, scale, R.head, R.tail, R.tail_left, R.head_right, res, acc),
+       "tlab_zslab_partial_z");
 }
 
 // ---- OPR_Poisson on kx-pencils: forcing in tmp1, Neumann data in hb / ht; p -> tmp1, dp/dy -> tmp3 ----
@@ -379,7 +399,8 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     const int nx = d->nx, ny = d->ny, kmax = d->kmax, ns = d->nscal;
     const long long n = d->n;
     // ---- diffusion + advection (:98-162) ----
-    int w = halo_start(d, 3 + ns, [&](Rank &R, int i) { return i < 3 ? R.q[i] : R.s[i - 3]; });
+    const int S_HQ3 = 3 + ns, S_P = 4 + ns;            // halo slots (Rank::lo, hi): 0..2 q, 3..2+ns s, then hq(3) and tmp1
+    int w = halo_start(d, 3 + ns, [&](Rank &R, int i) { return Slot{i < 3 ? R.q[i] : R.s[i - 3], i}; });
     const bool fresh = d->fresh;       // start of a Runge-Kutta step: hq = hs = 0 (time.f90:212-216) -> the x-terms overwrite
     d->fresh = false;
     for (Rank &R : d->rk) badd_all(d, R, 1, fresh);
@@ -391,15 +412,15 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     for (Rank &R : d->rk) zburgers_all(d, R, 2);
     // ---- pressure forcing: div(hq + q/dte) (:188-260) ----
     const double idte = 1.0 / dte;
-    w = halo_start(d, 1, [&](Rank &R, int) { return R.hq[2]; });                       // w's halo planes are still valid
+    w = halo_start(d, 1, [&](Rank &R, int) { return Slot{R.hq[2], S_HQ3}; });          // w's halo planes are still valid
     for (Rank &R : d->rk) padd(d, R, 2, R.hq[1], R.q[1], idte, R.txc[0], 0);
     for (Rank &R : d->rk) padd(d, R, 1, R.hq[0], R.q[0], idte, R.txc[0], 1);
     twait(d, w);
-    for (Rank &R : d->rk) zpartial(d, R, 1, R.hq[2], R.q[2], idte, nullptr, 0);
+    for (Rank &R : d->rk) zpartial(d, R, 1, R.hq[2], S_HQ3, R.q[2], 2, idte, nullptr, 0);
     w = msg_start(d, 1);
     for (Rank &R : d->rk) ok(tlab_pw_get_wall_planes(R.hq[1], R.hb, R.ht, nx, ny, kmax), "tlab_pw_get_wall_planes");
     twait(d, w);
-    for (Rank &R : d->rk) zpartial(d, R, 2, R.hq[2], R.q[2], idte, R.txc[0], 1);
+    for (Rank &R : d->rk) zpartial(d, R, 2, R.hq[2], S_HQ3, R.q[2], 2, idte, R.txc[0], 1);
     // ---- pressure (:284) and its gradient (:319-320) ----
     poisson_pencil(d);
     auto dirichlet = [](int t) { return t == TLAB_DNS_BCS_DIRICHLET; };
@@ -430,7 +451,7 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
             else ok(tlab_pw_final_update(f.q, f.h, f.g, pb, pt, tdte, kco, scale, nx, ny, kmax), "tlab_pw_final_update");
         }
     };
-    w = halo_start(d, 1, [&](Rank &R, int) { return R.txc[0]; });
+    w = halo_start(d, 1, [&](Rank &R, int) { return Slot{R.txc[0], S_P}; });
     if (grad_final) {   // u and w are finished by the gradient kernels themselves (no gradient array)
         for (Rank &R : d->rk)
             ok(tlab_opr_gradient_final(1, d->g[0], nx, ny, kmax, R.txc[0], R.q[0], R.hq[0], tdte, kco, scale, R.txc[1]), "tlab_opr_gradient_final");
@@ -438,7 +459,7 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
         for (Rank &R : d->rk) padd(d, R, 1, R.txc[0], nullptr, 0.0, R.txc[1], 0);
     }
     twait(d, w);
-    for (Rank &R : d->rk) zpartial(d, R, 1, R.txc[0], nullptr, 0.0, nullptr, 0);
+    for (Rank &R : d->rk) zpartial(d, R, 1, R.txc[0], S_P, nullptr, 0, 0.0, nullptr, 0);
     w = msg_start(d, 1);
     // v and the scalars do not wait for dp/dz: their update runs while the interface values travel (not with Neumann scalars, whose boundary
     // routine takes tmp1 = p as scratch)
@@ -447,10 +468,13 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
         for (Rank &R : d->rk) finish(R);
     twait(d, w);
     if (grad_final) {
-        for (Rank &R : d->rk)
-            ok(tlab_zslab_gradient_final_z(R.zplan, nx, ny, R.txc[0], R.tail_left, R.head_right, R.q[2], R.hq[2], tdte, kco, scale), "tlab_zslab_gradient_final_z");
+        for (Rank &R : d->rk) {
+            const double *ph[2] = {R.lo[S_P], R.hi[S_P]};
+            ok(tlab_internal_zslab_gradient_final_z(R.zplan, nx, ny, R.txc[0], ph, R.tail_left, R.head_right, R.q[2], R.hq[2], tdte, kco, scale),
+               "tlab_zslab_gradient_final_z");
+        }
     } else {
-        for (Rank &R : d->rk) zpartial(d, R, 2, R.txc[0], nullptr, 0.0, R.txc[3], 0);
+        for (Rank &R : d->rk) zpartial(d, R, 2, R.txc[0], S_P, nullptr, 0, 0.0, R.txc[3], 0);
     }
     if (!early_finish)
         for (Rank &R : d->rk) finish(R);
@@ -553,6 +577,10 @@ int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *tr, tl
             for (double **p : {&R.head, &R.tail, &R.head_right, &R.tail_left}) *p = dalloc((size_t)nmsg * d->npage);
             for (int i = 0; i < 3; ++i) R.pen[i] = dalloc((size_t)2 * d->nxl[R.r] * ny * nz_total);
             for (int i = 0; i < 2; ++i) R.pack[i] = dalloc((size_t)2 * d->nxh * ny * d->kmax);
+            const int nslots = 3 + nscal + 2;
+            const size_t Hn = (size_t)HALO * d->npage;
+            R.halo = dalloc((size_t)nslots * 2 * Hn);
+            for (int i = 0; i < nslots; ++i) { R.lo.push_back(R.halo + (size_t)(2 * i) * Hn); R.hi.push_back(R.halo + (size_t)(2 * i + 1) * Hn); }
         }
         d->tr = *tr;         // from here on the driver owns the transport's context
         *out = d.release();
@@ -647,16 +675,16 @@ int tlab_slab_dns_dilatation_bounds(tlab_slab_dns_t d, double *dil_min, double *
         need_bound(d);
         const int nx = d->nx, ny = d->ny, kmax = d->kmax, L = (int)d->rk.size();
         // div(q) with the z-derivative by the slab route of the RHS (FI_INVARIANT_P = -div, fi_vectorcalculus.f90:111-141)
-        int w = halo_start(d, 1, [&](Rank &R, int) { return R.q[2]; });
+        int w = halo_start(d, 1, [&](Rank &R, int) { return Slot{R.q[2], 2}; });
         for (Rank &R : d->rk) {
             ok(tlab_opr_partial(1, d->g[0], TLAB_OPR_P1, nx, ny, kmax, 0, R.q[0], R.txc[0], nullptr), "tlab_opr_partial");
             padd(d, R, 2, R.q[1], nullptr, 0.0, R.txc[0], 1);
         }
         twait(d, w);
-        for (Rank &R : d->rk) zpartial(d, R, 1, R.q[2], nullptr, 0.0, nullptr, 0);
+        for (Rank &R : d->rk) zpartial(d, R, 1, R.q[2], 2, nullptr, 0, 0.0, nullptr, 0);
         w = msg_start(d, 1);
         twait(d, w);
-        for (Rank &R : d->rk) zpartial(d, R, 2, R.q[2], nullptr, 0.0, R.txc[0], 1);
+        for (Rank &R : d->rk) zpartial(d, R, 2, R.q[2], 2, nullptr, 0, 0.0, R.txc[0], 1);
         std::vector<double> mn((size_t)L), mx((size_t)L);
         for (int l = 0; l < L; ++l) ok(tlab_minmax(dns_handle(d, d->rk[l]), d->rk[l].txc[0], nx, ny, kmax, &mn[l], &mx[l]), "tlab_minmax");
         tck(d->tr.allreduce(d->tr.ctx, mn.data(), 1, 1), "allreduce");

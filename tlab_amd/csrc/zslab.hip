@@ -52,8 +52,12 @@ struct ZSysDev {
 };
 
 struct ZSlabArgs {
-    const double *in0;      // operand (first plane of the slab; planes -3..-1 and kmax..kmax+2 are valid halos)
-    const double *in0b;     // optional: operand = in0 + scale * in0b (same halo rule)
+    const double *in0;      // operand (first plane of the slab)
+    const double *in0b;     // optional: operand = in0 + scale * in0b
+    // the neighbours' 3 planes before (lo) and after (hi) the slab of every operand: in place (lo = in - 3 planes, hi = in + kmax planes: the
+    // caller's arrays carry the room) or in buffers of their own (the native slab driver: a Fortran host's module arrays have no room)
+    const double *lo0, *hi0, *lo0b, *hi0b;
+    const double *flo[4], *fhi[4];
     double scale;
     const double *vel;      // advecting velocity (Burgers), no halo needed
     double *out0;
@@ -161,14 +165,19 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
     const double nu = (MODE == MODE_BURGERS) ? a.fnu[fi] : a.nu;
     const int msg0 = (MODE == MODE_BURGERS) ? 2 * fi : 0;       // first message row of this field
 
-    // operand rows + 3-row halos; no wrap: the rows before / after the slab are the neighbours' planes
+    // operand rows + 3-row halos; no wrap: the rows before / after the slab are the neighbours' planes (wave-uniform choice of the base pointer)
+    const double *__restrict__ lo = (MODE == MODE_BURGERS) ? a.flo[fi] : a.lo0;
+    const double *__restrict__ hi = (MODE == MODE_BURGERS) ? a.fhi[fi] : a.hi0;
+    auto row_of = [&](const double *in, const double *l, const double *h, int r) -> const double * {
+        return r < 0 ? l + (long long)(r + 3) * rs : (r >= a.kmax ? h + (long long)(r - a.kmax) * rs : in + (long long)r * rs);
+    };
     double e[M + 6];
 #pragma unroll
-    for (int p = 0; p < M + 6; ++p) e[p] = valid ? in0[base + (long long)(row0 - 3 + p) * rs] : 0.0;
+    for (int p = 0; p < M + 6; ++p) e[p] = valid ? row_of(in0, lo, hi, row0 - 3 + p)[base] : 0.0;
     if (MODE == MODE_P1 && a.in0b != nullptr) {
         double eb[M + 6];
 #pragma unroll
-        for (int p = 0; p < M + 6; ++p) eb[p] = valid ? a.in0b[base + (long long)(row0 - 3 + p) * rs] : 0.0;
+        for (int p = 0; p < M + 6; ++p) eb[p] = valid ? row_of(a.in0b, a.lo0b, a.hi0b, row0 - 3 + p)[base] : 0.0;
 #pragma unroll
         for (int p = 0; p < M + 6; ++p) e[p] = e[p] + eb[p] * a.scale;
     }
@@ -352,7 +361,13 @@ void launch_m(int phase, int C, const ZSlabArgs &a, hipStream_t st) {
     else hipLaunchKernelGGL((k_zslab<M, MODE, 2>), grid, block, 0, st, a);
 }
 
-void launch(const tlab_zslab_plan &P, int mode, int phase, const ZSlabArgs &a, hipStream_t st) {
+void launch(const tlab_zslab_plan &P, int mode, int phase, const ZSlabArgs &a_in, hipStream_t st) {
+    ZSlabArgs a = a_in;
+    const long long rs3 = 3 * a.nlines, rsk = (long long)a.kmax * a.nlines;       // halos in place where the caller gave none
+    if (a.in0 && !a.lo0) { a.lo0 = a.in0 - rs3; a.hi0 = a.in0 + rsk; }
+    if (a.in0b && !a.lo0b) { a.lo0b = a.in0b - rs3; a.hi0b = a.in0b + rsk; }
+    for (int f = 0; f < 4; ++f)
+        if (a.fs[f] && !a.flo[f]) { a.flo[f] = a.fs[f] - rs3; a.fhi[f] = a.fs[f] + rsk; }
     const double pts = (double)a.nlines * a.kmax;
     const char *name = mode == MODE_P1 ? (phase == 1 ? "k_zslab<P1,A>" : "k_zslab<P1,B>") : (phase == 1 ? "k_zslab<BURGERS,A>" : "k_zslab<BURGERS,B>");
     double bpp = 8.0 * ((a.in0b && mode == MODE_P1) ? 2 : 1);
@@ -387,6 +402,15 @@ ZSlabArgs base_args(const tlab_zslab_plan &P, int nx, int ny) {
 
 }  // namespace
 
+int tlab_internal_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny, const double *u, const double *const *u_halo, const double *ub,
+                                  const double *const *ub_halo, double scale, double *head, double *tail, const double *tail_left,
+                                  const double *head_right, double *result, int acc);
+int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s,
+                                    const double *const *s_lo, const double *const *s_hi, const double *vel, double *head, double *tail,
+                                    const double *tail_left, const double *head_right, double *const *result, int acc);
+int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *const *p_halo, const double *tail_left,
+                                         const double *head_right, double *q, double *h, double dte, double kco, int scale);
+
 extern "C" {
 
 int tlab_zslab_plan_create(tlab_zslab_plan_t *out, tlab_fdm_plan_t gz, int kmax, int koffset, int chunk) {
@@ -418,10 +442,20 @@ int tlab_zslab_plan_destroy(tlab_zslab_plan_t p) {
 
 int tlab_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny, const double *u, const double *ub, double scale, double *head,
                          double *tail, const double *tail_left, const double *head_right, double *result, int acc) {
+    return tlab_internal_zslab_partial_z(P, phase, nx, ny, u, nullptr, ub, nullptr, scale, head, tail, tail_left, head_right, result, acc);
+}
+}  // extern "C"
+
+// the same with the halo planes of the operands in buffers of their own: halos = {lo, hi} of 3 planes each (nullptr: in place)
+int tlab_internal_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny, const double *u, const double *const *u_halo, const double *ub,
+                                  const double *const *ub_halo, double scale, double *head, double *tail, const double *tail_left,
+                                  const double *head_right, double *result, int acc) {
     return guard([&] {
         if (!P || !u || nx < 1 || ny < 1 || (phase != 1 && phase != 2)) throw Fail(TLAB_EINVAL, "tlab_zslab_partial_z: bad arguments");
         ZSlabArgs a = base_args(*P, nx, ny);
         a.in0 = u; a.in0b = ub; a.scale = scale;
+        if (u_halo) { a.lo0 = u_halo[0]; a.hi0 = u_halo[1]; }
+        if (ub && ub_halo) { a.lo0b = ub_halo[0]; a.hi0b = ub_halo[1]; }
         if (phase == 1) {
             if (!head || !tail) throw Fail(TLAB_EINVAL, "tlab_zslab_partial_z: phase A needs head and tail");
             a.head = head; a.tail = tail;
@@ -432,6 +466,8 @@ int tlab_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny, const d
         launch(*P, MODE_P1, phase, a, tlab_current_stream());
     });
 }
+
+extern "C" {
 
 int tlab_zslab_burgers_z(tlab_zslab_plan_t P, int phase, int nx, int ny, double nu, const double *s, const double *vel, double *head,
                          double *tail, const double *tail_left, const double *head_right, double *result, int acc) {
@@ -453,6 +489,13 @@ int tlab_zslab_burgers_z(tlab_zslab_plan_t P, int phase, int nx, int ny, double 
 
 int tlab_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s, const double *vel,
                            double *head, double *tail, const double *tail_left, const double *head_right, double *const *result, int acc) {
+    return tlab_internal_zslab_burgers_z_n(P, phase, nx, ny, nf, nu, s, nullptr, nullptr, vel, head, tail, tail_left, head_right, result, acc);
+}
+}  // extern "C"
+
+int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s,
+                                    const double *const *s_lo, const double *const *s_hi, const double *vel, double *head, double *tail,
+                                    const double *tail_left, const double *head_right, double *const *result, int acc) {
     return guard([&] {
         if (!P || !s || !nu || nf < 1 || nf > 4 || nx < 1 || ny < 1 || (phase != 1 && phase != 2)) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: bad arguments");
         ZSlabArgs a = base_args(*P, nx, ny);
@@ -460,6 +503,7 @@ int tlab_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int n
         for (int f = 0; f < nf; ++f) {
             if (!s[f]) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: null operand");
             a.fs[f] = s[f]; a.fnu[f] = nu[f]; a.fo[f] = nullptr;
+            if (s_lo && s_hi) { a.flo[f] = s_lo[f]; a.fhi[f] = s_hi[f]; }
         }
         if (phase == 1) {
             if (!head || !tail) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: phase A needs head and tail");
@@ -476,16 +520,23 @@ int tlab_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int n
     });
 }
 
+extern "C" {
+
 // phase 2 of d/dz p with the final update of w as its epilogue: h -= dp/dz; wall planes (Dirichlet); q += dte h; h *= kco
 int tlab_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *tail_left, const double *head_right, double *q,
                                 double *h, double dte, double kco, int scale) {
+    return tlab_internal_zslab_gradient_final_z(P, nx, ny, p, nullptr, tail_left, head_right, q, h, dte, kco, scale);
+}
+}  // extern "C"
+
+int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *const *p_halo, const double *tail_left,
+                                         const double *head_right, double *q, double *h, double dte, double kco, int scale) {
     return guard([&] {
         if (!P || !p || !tail_left || !head_right || !q || !h || q == h) throw Fail(TLAB_EINVAL, "tlab_zslab_gradient_final_z: bad arguments");
         ZSlabArgs a = base_args(*P, nx, ny);
         a.in0 = p; a.tail_left = tail_left; a.head_right = head_right; a.out0 = h;
+        if (p_halo) { a.lo0 = p_halo[0]; a.hi0 = p_halo[1]; }
         a.fq = q; a.fdte = dte; a.fkco = kco; a.fscale = scale; a.fnx = nx; a.fny = ny;
         launch(*P, MODE_P1, 2, a, tlab_current_stream());
     });
 }
-
-}  // extern "C"

@@ -1,8 +1,13 @@
+#include "dns_error.h"
 !########################################################################
-! Drop-in replacement of the incompressible part of module BOUNDARY_BCS (tools/dns/boundary_bcs.f90): the wall-boundary-condition
-! types the RHS reads (BcsFlowJmin%type(1:3), ..., :14-27), their readers for the [BoundaryConditions] block of tlab.ini (:54-121) and
-! BOUNDARY_BCS_NEUMANN_Y (:368-473), which marshals to the C ABI.  The reference planes %ref are host arrays in the reference; the
-! device RHS keeps its wall planes itself, so BOUNDARY_BCS_INITIALIZE only sizes them.
+! Drop-in replacement of the incompressible part of module BOUNDARY_BCS (tools/dns/boundary_bcs.f90).  Only the delta lives here:
+!   BOUNDARY_BCS_NEUMANN_Y (:368-473)   marshals to the C ABI (the walls' Neumann-reduced first-derivative system runs on the device);
+!   BOUNDARY_BCS_INITIALIZE (:125-364)  only sizes the reference planes %ref: the device RHS keeps its wall planes itself, and the reference's
+!                                       routine drags in the thermodynamics, buffer zones and background profiles that are outside the path.
+! The declarations (type bcs_dt, Bcs{Flow,Scal}{I,J,K}{min,max}, DNS_BCS_*, DNS_SFC_*; :15-50) and the two readers of the [BoundaryConditions] block
+! of tlab.ini (BOUNDARY_BCS_SCAL_READBLOCK / _FLOW_READBLOCK, :55-124) ARE the reference's: the build extracts them from
+! $(REF)/src/tools/dns/boundary_bcs.f90 where it lies into two include files (tlab_amd/fortran/Makefile: sed ranges) -- nothing of them is kept here.
+! BOUNDARY_BCS_SURFACE_Y has no counterpart on the host: the dynamic surface model runs inside tlab_rhs_global_incompressible_1.
 !########################################################################
 module BOUNDARY_BCS
     use, intrinsic :: iso_c_binding
@@ -15,93 +20,11 @@ module BOUNDARY_BCS
     save
     private
 
-    type bcs_dt                                              ! boundary_bcs.f90:14-21
-        sequence
-        integer type(MAX_VARS)                              ! dirichlet, neumann for incompressible
-        integer SfcType(MAX_VARS)                           ! Type of Surface Model
-        real(wp) cpl(MAX_VARS)                              ! Coupling parameter for surface model
-        real(wp) cinf, cout, ctan                           ! characteristic formulation for compressible
-        real(wp), allocatable, dimension(:, :, :) :: ref    ! reference fields
-    end type bcs_dt
-
-    type(bcs_dt), public :: BcsFlowImin, BcsFlowImax, BcsFlowJmin, BcsFlowJmax, BcsFlowKmin, BcsFlowKmax
-    type(bcs_dt), public :: BcsScalImin, BcsScalImax, BcsScalJmin, BcsScalJmax, BcsScalKmin, BcsScalKmax
-
-    public :: BOUNDARY_BCS_NEUMANN_Y
-    public :: BOUNDARY_BCS_SCAL_READBLOCK, BOUNDARY_BCS_FLOW_READBLOCK
-    public :: BOUNDARY_BCS_INITIALIZE
-
-    integer, parameter, public :: DNS_BCS_NONE = 0           ! :41-46
-    integer, parameter, public :: DNS_BCS_NR = 1
-    integer, parameter, public :: DNS_BCS_INFLOW = 2
-    integer, parameter, public :: DNS_BCS_DIRICHLET = 3
-    integer, parameter, public :: DNS_BCS_NEUMANN = 4
-    integer, parameter, public :: DNS_SFC_STATIC = 0
-    integer, parameter, public :: DNS_SFC_LINEAR = 1
-
-    integer, parameter :: DNS_ERROR_IBC = 20, DNS_ERROR_JBC = 21, DNS_ERROR_UNDEVELOP = 104      ! include/dns_error.h
+#include "boundary_bcs_ref_decls.inc"
 
 contains
-    ! BOUNDARY_BCS_SCAL_READBLOCK   boundary_bcs.f90:54-93
-    subroutine BOUNDARY_BCS_SCAL_READBLOCK(bakfile, inifile, tag, var)
-        use TLab_Memory, only: inb_scal
-        character(len=*), intent(in) :: bakfile, inifile, tag
-        type(bcs_dt), intent(out) :: var
-        character(len=512) sRes
-        character(len=20) lstr
-        integer is
-        do is = 1, inb_scal
-            write (lstr, *) is; lstr = 'Scalar'//trim(adjustl(lstr))
-            call ScanFile_Char(bakfile, inifile, 'BoundaryConditions', trim(adjustl(lstr))//trim(adjustl(tag)), 'void', sRes)
-            if (trim(adjustl(sRes)) == 'none') then; var%type(is) = DNS_BCS_NONE
-            else if (trim(adjustl(sRes)) == 'dirichlet') then; var%type(is) = DNS_BCS_DIRICHLET
-            else if (trim(adjustl(sRes)) == 'neumann') then; var%type(is) = DNS_BCS_NEUMANN
-            else
-                call TLab_Write_ASCII(efile, __FILE__//'. BoundaryConditions.'//trim(adjustl(lstr)))
-                call TLab_Stop(DNS_ERROR_JBC)
-            end if
-            call ScanFile_Char(bakfile, inifile, 'BoundaryConditions', trim(adjustl(lstr))//'SfcType'//trim(adjustl(tag)), 'static', sRes)
-            if (trim(adjustl(sRes)) == 'static') then
-                var%SfcType(is) = DNS_SFC_STATIC
-            else if (trim(adjustl(sRes)) == 'linear') then   ! dynamic surface model: BOUNDARY_BCS_SURFACE_Y runs inside tlab_rhs_global_incompressible_1
-                var%SfcType(is) = DNS_SFC_LINEAR
-            else
-                call TLab_Write_ASCII(efile, __FILE__//'. BoundaryConditions.'//trim(adjustl(lstr))//'SfcType'//trim(adjustl(tag)))
-                call TLab_Stop(DNS_ERROR_JBC)
-            end if
-            call ScanFile_Real(bakfile, inifile, 'BoundaryConditions', trim(adjustl(lstr))//'Coupling'//trim(adjustl(tag)), '0.0', var%cpl(is))
-        end do
-    end subroutine BOUNDARY_BCS_SCAL_READBLOCK
+#include "boundary_bcs_ref_readblocks.inc"
 
-    ! BOUNDARY_BCS_FLOW_READBLOCK   boundary_bcs.f90:97-121
-    subroutine BOUNDARY_BCS_FLOW_READBLOCK(bakfile, inifile, tag, var)
-        character(len=*), intent(in) :: bakfile, inifile, tag
-        type(bcs_dt), intent(out) :: var
-        character(len=512) sRes
-        integer inormal, itangential(2)
-        select case (trim(adjustl(tag)))
-        case ('Imin', 'Imax')
-            inormal = 1
-            itangential = [2, 3]
-        case ('Jmin', 'Jmax')
-            inormal = 2
-            itangential = [1, 3]
-        case ('Kmin', 'Kmax')
-            inormal = 3
-            itangential = [1, 2]
-        end select
-        call ScanFile_Char(bakfile, inifile, 'BoundaryConditions', 'Velocity'//trim(adjustl(tag)), 'freeslip', sRes)
-        if (trim(adjustl(sRes)) == 'none') then; var%type(1:3) = DNS_BCS_NONE
-        else if (trim(adjustl(sRes)) == 'noslip') then; var%type(1:3) = DNS_BCS_DIRICHLET
-        else if (trim(adjustl(sRes)) == 'freeslip') then; var%type(inormal) = DNS_BCS_DIRICHLET
-            var%type(itangential) = DNS_BCS_NEUMANN
-        else
-            call TLab_Write_ASCII(efile, __FILE__//'. BoundaryConditions.Velocity'//trim(adjustl(tag)))
-            call TLab_Stop(DNS_ERROR_IBC)
-        end if
-    end subroutine BOUNDARY_BCS_FLOW_READBLOCK
-
-    ! BOUNDARY_BCS_INITIALIZE   boundary_bcs.f90:125-364: reference planes of the incompressible mode
     subroutine BOUNDARY_BCS_INITIALIZE()
         use TLab_Memory, only: imax, kmax, inb_flow_array, inb_scal_array
         if (.not. allocated(BcsFlowJmin%ref)) allocate (BcsFlowJmin%ref(imax, kmax, inb_flow_array + 1))
@@ -111,7 +34,7 @@ contains
         BcsFlowJmin%ref = 0.0_wp; BcsFlowJmax%ref = 0.0_wp; BcsScalJmin%ref = 0.0_wp; BcsScalJmax%ref = 0.0_wp
     end subroutine BOUNDARY_BCS_INITIALIZE
 
-    ! BOUNDARY_BCS_NEUMANN_Y(ibc, nx, ny, nz, g, u, bcs_hb, bcs_ht, tmp1)   boundary_bcs.f90:368-473; all arrays on the device
+    ! all arrays on the device
     subroutine BOUNDARY_BCS_NEUMANN_Y(ibc, nx, ny, nz, g, u, bcs_hb, bcs_ht, tmp1)
         integer(wi), intent(in) :: ibc
         integer(wi) nx, ny, nz

@@ -13,17 +13,24 @@ subroutine RHS_GLOBAL_INCOMPRESSIBLE_1()
     use DNS_ARRAYS
     use TIME, only: dte
     use TLab_AMD_C
-    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle, TLab_AMD_Slab_Active, TLab_AMD_Slab_Handle
     implicit none
 
     type(c_ptr) :: pq(3), ps(16), phq(3), phs(16), ptxc(16)
     integer is
     integer(c_int) rc
 
+    ! ims_npro_k > 1: the z-slab driver (tlab_amd/csrc/slab.cpp) on the module arrays it was bound to -- the MPI branches of OPR_Partial_Z,
+    ! OPR_Burgers_Z and OPR_Fourier_Z_* (opr_partial.f90:185-195, opr_burgers.f90:386-426, opr_fourier.f90:343-428) without a transposition per operator
+    if (TLab_AMD_Slab_Active()) then
+        call TLab_AMD_Check(tlab_slab_dns_rhs(TLab_AMD_Slab_Handle(), real(dte, c_double)), 'tlab_slab_dns_rhs')
+        return
+    end if
+    if (inb_scal > 16 .or. inb_txc < 9) call TLab_AMD_Check(-1_c_int, 'RHS_GLOBAL_INCOMPRESSIBLE_1: needs inb_scal <= 16 and inb_txc >= 9')
     do is = 1, 3
         pq(is) = c_loc(q(1, is)); phq(is) = c_loc(hq(1, is))
     end do
-    ps = c_null_ptr; phs = c_null_ptr
+    ps = c_null_ptr; phs = c_null_ptr; ptxc = c_null_ptr
     do is = 1, inb_scal
         ps(is) = c_loc(s(1, is)); phs(is) = c_loc(hs(1, is))
     end do
@@ -49,7 +56,7 @@ subroutine TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(kco_loc, scale_loc)
     use DNS_ARRAYS
     use TIME, only: dte
     use TLab_AMD_C
-    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle, TLab_AMD_Slab_Active, TLab_AMD_Slab_Handle
     implicit none
     real(wp), intent(in) :: kco_loc
     logical, intent(in) :: scale_loc
@@ -58,10 +65,16 @@ subroutine TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(kco_loc, scale_loc)
     integer is
     integer(c_int) rc
 
+    if (TLab_AMD_Slab_Active()) then
+        call TLab_AMD_Check(tlab_slab_dns_substep(TLab_AMD_Slab_Handle(), real(dte, c_double), real(kco_loc, c_double), &
+                                                  merge(1_c_int, 0_c_int, scale_loc)), 'tlab_slab_dns_substep')
+        return
+    end if
+    if (inb_scal > 16 .or. inb_txc < 9) call TLab_AMD_Check(-1_c_int, 'TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD: needs inb_scal <= 16 and inb_txc >= 9')
     do is = 1, 3
         pq(is) = c_loc(q(1, is)); phq(is) = c_loc(hq(1, is))
     end do
-    ps = c_null_ptr; phs = c_null_ptr
+    ps = c_null_ptr; phs = c_null_ptr; ptxc = c_null_ptr
     do is = 1, inb_scal
         ps(is) = c_loc(s(1, is)); phs(is) = c_loc(hs(1, is))
     end do

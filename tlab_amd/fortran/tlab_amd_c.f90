@@ -7,8 +7,20 @@ module TLab_AMD_C
     implicit none
     public
 
+    ! struct tlab_slab_transport (include/tlab_amd.h): filled by tlab_comm_slab_transport / tlab_slab_transport_loopback, or by the host with the
+    ! five entry points of its own (GPU-aware MPI)
+    type, bind(C) :: tlab_slab_transport
+        type(c_ptr) :: ctx = c_null_ptr
+        integer(c_int) :: nranks = 1, nlocal = 1, first = 0
+        type(c_funptr) :: ring_start = c_null_funptr, alltoallv_start = c_null_funptr, wait = c_null_funptr, allreduce = c_null_funptr, &
+                          destroy = c_null_funptr
+    end type tlab_slab_transport
+
     interface
         integer(c_int) function tlab_finalize() bind(C, name='tlab_finalize')
+            import :: c_int
+        end function
+        integer(c_int) function tlab_device_count() bind(C, name='tlab_device_count')
             import :: c_int
         end function
         integer(c_int) function tlab_init(device) bind(C, name='tlab_init')
@@ -208,6 +220,67 @@ module TLab_AMD_C
             type(c_ptr), value :: a
             real(c_double), value :: alpha
             integer(c_long_long), value :: n
+        end function
+        ! ---- the decomposed substep (ims_npro_k > 1): tlab_slab_dns_* of include/tlab_amd.h ----
+        integer(c_int) function tlab_slab_transport_loopback(tr, nranks) bind(C, name='tlab_slab_transport_loopback')
+            import :: c_int, tlab_slab_transport
+            type(tlab_slab_transport), intent(out) :: tr
+            integer(c_int), value :: nranks
+        end function
+        integer(c_int) function tlab_slab_dns_create(d, tr, gx, gy, gz, nx, ny, nz_total, nscal, visc, schmidt, gy_elliptic) bind(C, name='tlab_slab_dns_create')
+            import :: c_int, c_ptr, c_double, tlab_slab_transport
+            type(c_ptr), intent(out) :: d
+            type(tlab_slab_transport), intent(in) :: tr
+            type(c_ptr), value :: gx, gy, gz, gy_elliptic
+            integer(c_int), value :: nx, ny, nz_total, nscal
+            real(c_double), value :: visc
+            real(c_double), intent(in) :: schmidt(*)
+        end function
+        integer(c_int) function tlab_slab_dns_destroy(d) bind(C, name='tlab_slab_dns_destroy')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+        end function
+        integer(c_int) function tlab_slab_dns_bind(d, l, q, s, hq, hs, txc) bind(C, name='tlab_slab_dns_bind')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+            integer(c_int), value :: l
+            type(c_ptr), intent(in) :: q(*), s(*), hq(*), hs(*), txc(*)
+        end function
+        integer(c_long_long) function tlab_slab_dns_info(d, what) bind(C, name='tlab_slab_dns_info')
+            import :: c_int, c_ptr, c_long_long
+            type(c_ptr), value :: d
+            integer(c_int), value :: what
+        end function
+        integer(c_int) function tlab_slab_dns_set_bcs(d, flow_jmin, flow_jmax, scal_jmin, scal_jmax) bind(C, name='tlab_slab_dns_set_bcs')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+            integer(c_int), intent(in) :: flow_jmin(*), flow_jmax(*), scal_jmin(*), scal_jmax(*)
+        end function
+        integer(c_int) function tlab_slab_dns_begin_step(d) bind(C, name='tlab_slab_dns_begin_step')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+        end function
+        integer(c_int) function tlab_slab_dns_rhs(d, dte) bind(C, name='tlab_slab_dns_rhs')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: d
+            real(c_double), value :: dte
+        end function
+        integer(c_int) function tlab_slab_dns_substep(d, dte, kco, scale_tendencies) bind(C, name='tlab_slab_dns_substep')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: d
+            real(c_double), value :: dte, kco
+            integer(c_int), value :: scale_tendencies
+        end function
+        integer(c_int) function tlab_slab_dns_time_courant(d, cfla, cfld, pmax, dtime) bind(C, name='tlab_slab_dns_time_courant')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: d
+            real(c_double), value :: cfla, cfld
+            real(c_double), intent(out) :: pmax(2), dtime
+        end function
+        integer(c_int) function tlab_slab_dns_dilatation_bounds(d, dil_min, dil_max) bind(C, name='tlab_slab_dns_dilatation_bounds')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: d
+            real(c_double), intent(out) :: dil_min, dil_max
         end function
         integer(c_int) function tlab_boundary_bcs_neumann_y(plan, ibc, nx, ny, nz, u, bcs_hb, bcs_ht, tmp1) bind(C, name='tlab_boundary_bcs_neumann_y')
             import :: c_int, c_ptr

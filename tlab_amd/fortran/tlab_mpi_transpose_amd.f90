@@ -15,7 +15,7 @@ module TLabMPI_Transpose
     use TLab_Memory, only: imax, jmax, kmax
     use TLab_WorkFlow, only: TLab_Write_ASCII, TLab_Stop
     use TLabMPI_VARS, only: ims_pro, ims_npro, ims_npro_i, ims_npro_k
-    use TLab_AMD_C, only: TLab_AMD_Check
+    use TLab_AMD_C, only: TLab_AMD_Check, tlab_slab_transport
     implicit none
     private
 
@@ -24,6 +24,7 @@ module TLabMPI_Transpose
     public :: TLabMPI_Trp_ExecK_Forward, TLabMPI_Trp_ExecK_Backward
     public :: TLabMPI_Trp_ExecI_Forward, TLabMPI_Trp_ExecI_Backward
     public :: TLabMPI_Trp_AMD_Comm, TLabMPI_Trp_AMD_Finalize
+    public :: TLabMPI_Trp_AMD_Slab_Transport        ! the exchanges of the z-slab driver over the same communicator (tlab_comm_slab_transport)
 
     type, public :: tmpi_transpose_dt
         integer(wi) :: nlines                                       ! as in the reference (tlab_mpi_transpose.f90:19-25)
@@ -48,6 +49,11 @@ module TLabMPI_Transpose
             type(c_ptr), intent(out) :: comm
             character(kind=c_char), intent(in) :: id(128)
             integer(c_int), value :: nranks, rank, npro_i, npro_k
+        end function
+        integer(c_int) function tlab_comm_slab_transport(comm, tr) bind(C, name='tlab_comm_slab_transport')
+            import :: c_int, c_ptr, tlab_slab_transport
+            type(c_ptr), value :: comm
+            type(tlab_slab_transport), intent(out) :: tr
         end function
         integer(c_int) function tlab_comm_destroy(comm) bind(C, name='tlab_comm_destroy')
             import :: c_int, c_ptr
@@ -92,6 +98,12 @@ contains
         call TLab_AMD_Check(tlab_comm_init(comm, id, int(ims_npro, c_int), int(ims_pro, c_int), int(ims_npro_i, c_int), int(ims_npro_k, c_int)), &
                             'tlab_comm_init')
     end subroutine TLabMPI_Trp_AMD_Comm
+
+    subroutine TLabMPI_Trp_AMD_Slab_Transport(tr)
+        type(tlab_slab_transport), intent(out) :: tr
+        if (.not. c_associated(comm)) call TLab_AMD_Check(-1_c_int, 'TLabMPI_Transpose: no communicator yet (call TLabMPI_Trp_AMD_Comm first)')
+        call TLab_AMD_Check(tlab_comm_slab_transport(comm, tr), 'tlab_comm_slab_transport')
+    end subroutine TLabMPI_Trp_AMD_Slab_Transport
 
     subroutine TLabMPI_Trp_AMD_Finalize()
         integer(c_int) rc
@@ -155,6 +167,9 @@ contains
             end if
         end do
         if (ncache == size(cache)) call TLab_AMD_Check(-1_c_int, 'TLabMPI_Transpose: more than 32 distinct transposition plans')
+        ! without a communicator the device plan is a one-rank plan: with a decomposed direction that would be a local copy instead of an exchange
+        if (.not. c_associated(comm) .and. ((trp_plan%dir == 1 .and. ims_npro_i > 1) .or. (trp_plan%dir == 3 .and. ims_npro_k > 1))) &
+            call TLab_AMD_Check(-1_c_int, 'TLabMPI_Transpose: decomposed direction but no RCCL communicator (call TLabMPI_Trp_AMD_Comm after TLabMPI_Initialize)')
         call TLab_AMD_Check(tlab_trp_plan_create(h, comm, int(trp_plan%dir, c_int), int(trp_plan%nmax, c_int), int(trp_plan%npage, c_int), &
                                                  int(e, c_int), 0_c_int, 1_c_int), 'tlab_trp_plan_create')
         ncache = ncache + 1

@@ -20,6 +20,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 # name -> (restype, argtypes); must list every entry point of include/tlab_amd.h (tests/test_capi_symbols.py checks)
 SIGNATURES = {
     "tlab_init": (c_int, [c_int]),
+    "tlab_device_count": (c_int, []),
     "tlab_finalize": (c_int, []),
     "tlab_last_error": (ctypes.c_char_p, []),
     "tlab_set_stream": (c_int, [c_vp]),

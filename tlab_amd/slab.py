@@ -1,8 +1,8 @@
 """Host-side mirror of the NATIVE z-slab driver (tlab_amd/csrc/slab.cpp behind tlab_slab_dns_* of include/tlab_amd.h): the decomposed
 RHS_GLOBAL_INCOMPRESSIBLE_1 / TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT a Fortran / MPI host calls when ims_npro_k > 1, and what `bench.py --gpus N` runs.
 
-Python only allocates the module arrays (torch tensors with the 3 halo planes of room the driver asks for), picks the transport and forwards the
-calls; the operator sequence, the exchanges and their overlap are in C++.  Transports (tlab_slab_transport, include/tlab_amd.h):
+Python only allocates the module arrays (plain torch tensors: the neighbours' halo planes live in buffers of the driver), picks the transport and
+forwards the calls; the operator sequence, the exchanges and their overlap are in C++.  Transports (tlab_slab_transport, include/tlab_amd.h):
 
     "loopback"  all P ranks inside this process on one device, exchanges = device copies (verification on one GPU; tests/test_gpu_slab.py)
     "rccl"      one rank per process, grouped ncclSend / ncclRecv on the communication stream of libtlab_amd_comm.so (the product path)
@@ -161,18 +161,13 @@ class NativeSlabDns:
         check(rc, "tlab_slab_dns_create")
         self.kmax = int(L.tlab_slab_dns_info(self._h, 0))
         self.stages = int(L.tlab_slab_dns_info(self._h, 4))
-        room = int(L.tlab_slab_dns_info(self._h, 3))
         self.npage = self.nx * self.ny
         self.n = self.npage * self.kmax
         self.isize_txc = (self.nx + 2) * self.ny * self.kmax
         self.st = {}
-        self._ext = []
         for l, r in enumerate(self.local_ranks):
             def field(m):
-                """m doubles with the halo room on both sides: the slab's first plane is at ext[room]"""
-                ext = torch.zeros(m + 2 * room, dtype=torch.float64, device=device)
-                self._ext.append(ext)
-                return ext[room:room + m]
+                return torch.zeros(m, dtype=torch.float64, device=device)
             S = {name: [field(m) for _ in range(cnt)] for name, cnt, m in
                  (("q", 3, self.n), ("s", self.nscal, self.n), ("hq", 3, self.n), ("hs", self.nscal, self.n), ("txc", 9, self.isize_txc))}
             arr = lambda ts: (c_vp * max(len(ts), 1))(*[t.data_ptr() for t in ts])       # noqa: E731
