@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--slab-driver", default="native", choices=["native", "python"], help="z-slab runs (--gpus N > 1, --loopback P): native = the C++ driver behind "
                     "tlab_slab_dns_* (tlab_amd/csrc/slab.cpp; RCCL transport of libtlab_amd_comm.so), the code a Fortran / MPI host runs; python = its "
                     "cross-check tlab_amd/parallel.py::SlabDns over torch.distributed (diagnostic)")
+    ap.add_argument("--no-freeslip-leg", action="store_true", help="skip the extra `walls_freeslip` timing of the default single-GPU line")
     ap.add_argument("--cpu-sample", type=int, default=256, help="n of the n^3 CPU-baseline sample (0 disables)")
     ap.add_argument("--cpu-sample-large", type=int, default=512, help="second, larger CPU-baseline sample, run only on hosts with at least --cpu-large-min-cores CPUs (0 disables)")
     ap.add_argument("--cpu-large-min-cores", type=int, default=48)
@@ -279,11 +280,16 @@ def main():
         # dominant kernel = largest summed time among the full-field kernels (the <= 4 singular Poisson modes run beside the
         # main stream and rocFFT carries no byte count)
         dom = next((k for k in kernels if k["alg_bytes_per_launch"] > 1e6), None)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if collected (profiles/README.md)
+        # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC passes of the SAME binaries (profiles/traffic.json is
+        # regenerated by tools/profile_round.sh together with the rocprofv3 CSV and stamped with the commit and the kernel list of that session;
+        # a kernel the file does not know gets null, never another kernel's or an older build's figure)
+        traffic, traffic_meta = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if dom and os.path.exists(tpath) and world == 1 and args.loopback <= 1 and not args.decomp and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:      # measured for this workload only
             try:
-                traffic = json.load(open(tpath)).get(dom["kernel"])
+                tj0 = json.load(open(tpath))
+                traffic_meta = tj0.get("_meta")
+                traffic = tj0.get(dom["kernel"])
             except Exception:
                 traffic = None
         npts = float(nx) * ny * nz      # strong scaling: the same box on 1/2/4/8 GPUs (BASELINE.json metric)
@@ -311,7 +317,7 @@ def main():
                        "fields_finite": finite},
             "roofline": None if dom is None else {
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "launches": dom["calls"],
+                "frac": dom["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_meta, "avg_launch_ms": dom["avg_ms"], "launches": dom["calls"],
                 "share_of_step": dom["total_ms"] / (ms_per_step * args.steps)},
             "substep_alg_GBps": (736.0 + 152.0 * args.nscal) * npts / (ms_per_step * 1e-3) / 1e9,
             "kernels": [{k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in k.items()} for k in kernels],
@@ -360,6 +366,7 @@ def main():
                     tj = None
             if tj:
                 moved, missing = 0.0, []
+                tj = {k2: v for k2, v in tj.items() if not k2.startswith("_")}
                 for k in kernels:
                     per = tj.get(k["kernel"])
                     if per is None and k["kernel"] == "rocfft":
@@ -371,6 +378,35 @@ def main():
                 out["substep_traffic"] = {"hbm_bytes_per_step": moved, "GBps": moved / (ms_per_step * 1e-3) / 1e9,
                                           "frac_of_peak": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels_without_counter_data": missing,
                                           "what": "sum over the kernels of a step of the HBM bytes per launch measured with rocprofv3 PMC counters (profiles/traffic.json)"}
+        if single and args.walls == "noslip" and not args.no_freeslip_leg:
+            # the same workload with the reference's DEFAULT walls (VelocityJmin/Jmax = freeslip, Neumann scalars: BOUNDARY_BCS_NEUMANN_Y in the tail
+            # of the substep), timed the same way right after the headline: the headline keeps no-slip / Dirichlet walls, this key says what the default costs
+            del d
+            torch.cuda.empty_cache()
+            d2 = Dns(x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=not args.ystretch, rkm_mode=RKM_EXP3,
+                     hyper_bc1_ext=HYPER_BC1_EXT)
+            d2.set_bcs("freeslip", "freeslip", "neumann", "neumann")
+            synthetic_fields(d2.q + d2.s, nx, ny, nz, 0, nz, rank)
+
+            def substep2(k):
+                s_ = k % d2.rkm_endstep
+                if s_ == 0:
+                    d2.begin_step()
+                last = s_ == d2.rkm_endstep - 1
+                d2.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * d2.kdt[s_], 1.0 if last else d2.kco[s_], not last)
+            for k in range(args.warmup):
+                substep2(k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                substep2(args.warmup + k)
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+            out["walls_freeslip"] = {"ms_per_step": el2 / args.steps * 1e3, "value": npts * args.steps / el2, "unit": "grid-point-updates/s",
+                                     "steps": args.steps, "warmup": args.warmup, "fields_finite": all(bool(torch.isfinite(t).all()) for t in d2.q + d2.s),
+                                     "what": "same box and steps with VelocityJmin/Jmax = freeslip and Neumann scalars (the reference's default walls)"}
+            del d2
+            torch.cuda.empty_cache()
         if args.cpu_sample > 0 and world == 1 and args.loopback <= 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.nscal)
             if args.cpu_sample_large > args.cpu_sample and (os.cpu_count() or 1) >= args.cpu_large_min_cores:

@@ -142,7 +142,8 @@ def int1_create(lam, ibc, factorize=True):
     _poisson_sigs().ref_int1_create(float(lam), int(ibc), int(factorize))
 
 
-def int1_tables(n, ibc):
+def int1_tables(n, ibc, nd_lhs=5, nd_rhs=3):
+    """nd_lhs / nd_rhs: diagonals of the integral system / of its right-hand side = RHS / LHS diagonals of the derivative it inverts."""
     L = _poisson_sigs()
 
     def get(which, rows, cols):
@@ -150,7 +151,7 @@ def int1_tables(n, ibc):
         L.ref_int1_get(int(ibc), which, buf, buf.shape[0])
         return buf.reshape(cols, rows).T.copy()
 
-    return {"lhs": get(1, n, 5), "rhs": get(2, n, 3), "rhs_b": get(3, 5, 8), "rhs_t": get(4, 5, 8)}
+    return {"lhs": get(1, n, nd_lhs), "rhs": get(2, n, nd_rhs), "rhs_b": get(3, 5, 8), "rhs_t": get(4, 5, 8)}
 
 
 def int1_solve(ibc, f, res):

@@ -54,6 +54,83 @@ def pentadss(a, b, c, d, e, f):
 
 
 # ######################################################################################
+# utils/linear3.f90, utils/linear7.f90: the band solvers of the 3- and 7-diagonal integral systems (fdm_integral.f90:75-83, 255-263)
+# ######################################################################################
+def tridfs_m(a, b, c):
+    """utils/linear3.f90:29-51 TRIDFS, in place; arrays (nmax, M)."""
+    nmax = a.shape[0]
+    for n in range(1, nmax):
+        a[n] = a[n] / b[n - 1]
+        b[n] = b[n] - a[n] * c[n - 1]
+    a[:] = -a
+    b[:] = 1.0 / b
+    c[:] = -c
+
+
+def tridss_m(a, b, c, f):
+    """utils/linear3.f90:56-150 TRIDSS; coefficients (nmax, M), f (nmax, nlines, M) in place."""
+    nmax = a.shape[0]
+    for n in range(1, nmax):
+        f[n] = f[n] + a[n] * f[n - 1]
+    f[nmax - 1] = f[nmax - 1] * b[nmax - 1]
+    for n in range(nmax - 2, -1, -1):
+        f[n] = (f[n] + c[n] * f[n + 1]) * b[n]
+
+
+def heptadfs(a, b, c, d, e, f, g):
+    """utils/linear7.f90:30-93 HEPTADFS, in place; arrays (nmax, M) (0-based rows)."""
+    nmax = a.shape[0]
+    g[0] = g[0] / d[0]
+    f[0] = f[0] / d[0]
+    e[0] = e[0] / d[0]
+    c[0] = 1.0 / d[0]
+    d[0] = 1.0
+    c[1] = c[1] / d[0]
+    d[1] = d[1] - c[1] * e[0]
+    e[1] = e[1] - c[1] * f[0]
+    f[1] = f[1] - c[1] * g[0]
+    b[2] = b[2] / d[0]
+    c[2] = (c[2] - b[2] * e[0]) / d[1]
+    d[2] = d[2] - c[2] * e[1] - b[2] * f[0]
+    e[2] = e[2] - c[2] * f[1] - b[2] * g[0]
+    f[2] = f[2] - c[2] * g[1]
+    for n in range(3, nmax - 2):
+        a[n] = a[n] / d[n - 3]
+        b[n] = (b[n] - a[n] * e[n - 3]) / d[n - 2]
+        c[n] = (c[n] - b[n] * e[n - 2] - a[n] * f[n - 3]) / d[n - 1]
+        d[n] = d[n] - c[n] * e[n - 1] - b[n] * f[n - 2] - a[n] * g[n - 3]
+        e[n] = e[n] - c[n] * f[n - 1] - b[n] * g[n - 2]
+        f[n] = f[n] - c[n] * g[n - 1]
+    n = nmax - 2
+    a[n] = a[n] / d[n - 3]
+    b[n] = (b[n] - a[n] * e[n - 3]) / d[n - 2]
+    c[n] = (c[n] - b[n] * e[n - 2] - a[n] * f[n - 3]) / d[n - 1]
+    d[n] = d[n] - c[n] * e[n - 1] - b[n] * f[n - 2] - a[n] * g[n - 3]
+    e[n] = e[n] - c[n] * f[n - 1] - b[n] * g[n - 2]
+    n = nmax - 1
+    a[n] = a[n] / d[n - 3]
+    b[n] = (b[n] - a[n] * e[n - 3]) / d[n - 2]
+    c[n] = (c[n] - b[n] * e[n - 2] - a[n] * f[n - 3]) / d[n - 1]
+    d[n] = d[n] - c[n] * e[n - 1] - b[n] * f[n - 2] - a[n] * g[n - 3]
+
+
+def heptadss(a, b, c, d, e, f, g, frc):
+    """utils/linear7.f90:98-142 HEPTADSS; coefficients (nmax, M), frc (nmax, nlines, M) in place."""
+    nmax = a.shape[0]
+    frc[0] = frc[0] * c[0]
+    frc[1] = frc[1] - frc[0] * c[1]
+    frc[2] = frc[2] - frc[1] * c[2] - frc[0] * b[2]
+    for n in range(3, nmax):
+        frc[n] = frc[n] - frc[n - 1] * c[n] - frc[n - 2] * b[n] - frc[n - 3] * a[n]
+    n = nmax - 1
+    frc[n] = frc[n] / d[n]
+    frc[n - 1] = (frc[n - 1] - frc[n] * e[n - 1]) / d[n - 1]
+    frc[n - 2] = (frc[n - 2] - frc[n - 1] * e[n - 2] - frc[n] * f[n - 2]) / d[n - 2]
+    for n in range(nmax - 4, -1, -1):
+        frc[n] = (frc[n] - frc[n + 1] * e[n] - frc[n + 2] * f[n] - frc[n + 3] * g[n]) / d[n]
+
+
+# ######################################################################################
 # fdm/fdm_base.f90:304-391 FDM_Bcs_Reduce
 # lhs (nx, ndl[, M]) modified in place; rhs (nx, ndr[, M]); rhs_b (>=4, 8[, M]) [row-1, col]; rhs_t (5, 8[, M]) [row, col-1]
 # ######################################################################################
@@ -180,12 +257,13 @@ def int1_create_system(g, lam, ibc):
 
 
 def int1_initialize(g, lam, ibc):
-    """fdm/fdm_integral.f90:58-87 FDM_Int1_Initialize (pentadiagonal case: C1N6 -> 5 LHS diagonals)."""
+    """fdm/fdm_integral.f90:58-87 FDM_Int1_Initialize: TRIDFS / PENTADFS / HEPTADFS by the number of diagonals of the integral system
+    (= RHS diagonals of the derivative: 3 for CompactJacobian4 / CompactDirect4, 5 for CompactJacobian6, 7 for CompactJacobian6Penta)."""
     p = int1_create_system(g, lam, ibc)
-    assert p.lhs.shape[1] == 5, "oracle: only the pentadiagonal integral (C1N6) is restated"
-    cols = [p.lhs[1:p.nx - 1, k, :].copy() for k in range(5)]
-    pentadfs(*cols)
-    for k in range(5):
+    nd = p.lhs.shape[1]
+    cols = [p.lhs[1:p.nx - 1, k, :].copy() for k in range(nd)]
+    {3: tridfs_m, 5: pentadfs, 7: heptadfs}[nd](*cols)
+    for k in range(nd):
         p.lhs[1:p.nx - 1, k, :] = cols[k]
     p.factorized = True
     return p
@@ -210,6 +288,26 @@ def _matmul_3d_both(rhs, f, res, rhs_b, rhs_t):
     return bcs_b, bcs_t
 
 
+def _matmul_5d_both(rhs, f, res, rhs_b, rhs_t):
+    """fdm/fdm_matmul.f90:267-320 MatMul_5d with ibc = BCS_BOTH, as called at fdm_integral.f90:251-253: rhs_b = fdmi%rhs_b(1:4, 0:5),
+    rhs_t = fdmi%rhs_t(0:3, 1:6).  res[0], res[nx-1] carry the boundary values.  Returns (bcs_b, bcs_t)."""
+    nx = rhs.shape[0]
+    r1, r2, r3, r5 = rhs[:, 0], rhs[:, 1], rhs[:, 2], rhs[:, 4]
+    rb = lambda j, c: rhs_b[j - 1, c]          # noqa: E731  rhs_b(j, c)
+    rt = lambda r, c: rhs_t[r, c - 1]          # noqa: E731  rhs_t(r, c)
+    bcs_b = res[0] * rb(1, 3) + f[1] * rb(1, 4) + f[2] * rb(1, 5) + f[3] * rb(1, 1)
+    res[1] = res[0] * rb(2, 2) + f[1] * rb(2, 3) + f[2] * rb(2, 4) + f[3] * rb(2, 5)
+    res[2] = res[0] * rb(3, 1) + f[1] * rb(3, 2) + f[2] * rb(3, 3) + f[3] * rb(3, 4) + f[4] * rb(3, 5)
+    res[3] = res[0] * rb(4, 0) + f[1] * rb(4, 1) + f[2] * rb(4, 2) + f[3] * rb(4, 3) + f[4] * rb(4, 4) + f[5] * rb(4, 5)
+    for n in range(4, nx - 4):
+        res[n] = f[n - 2] * r1[n] + f[n - 1] * r2[n] + f[n] * r3[n] + f[n + 1] + f[n + 2] * r5[n]
+    res[nx - 4] = f[nx - 6] * rt(0, 1) + f[nx - 5] * rt(0, 2) + f[nx - 4] * rt(0, 3) + f[nx - 3] * rt(0, 4) + f[nx - 2] * rt(0, 5) + res[nx - 1] * rt(0, 6)
+    res[nx - 3] = f[nx - 5] * rt(1, 1) + f[nx - 4] * rt(1, 2) + f[nx - 3] * rt(1, 3) + f[nx - 2] * rt(1, 4) + res[nx - 1] * rt(1, 5)
+    res[nx - 2] = f[nx - 4] * rt(2, 1) + f[nx - 3] * rt(2, 2) + f[nx - 2] * rt(2, 3) + res[nx - 1] * rt(2, 4)
+    bcs_t = f[nx - 4] * rt(3, 5) + f[nx - 3] * rt(3, 1) + f[nx - 2] * rt(3, 2) + res[nx - 1] * rt(3, 3)
+    return bcs_b, bcs_t
+
+
 def int1_solve(p, rhsi, f, res, want_du=False):
     """fdm/fdm_integral.f90:219-314 FDM_Int1_Solve.  f, res: (n, nlines, M); res carries the boundary value
     (res[0] for BCS_MIN, res[nx-1] for BCS_MAX) and is overwritten with the solution.  Returns du_boundary or None."""
@@ -219,11 +317,12 @@ def int1_solve(p, rhsi, f, res, want_du=False):
         res[nx - 1] = f[nx - 1]
     else:
         res[0] = f[0]
-    bcs_b, bcs_t = _matmul_3d_both(rhsi, f, res, p.rhs_b, p.rhs_t)
+    ndl, ndr = lhs.shape[1], rhsi.shape[1]            # diagonals of the integral system / of its right-hand side (fdm_integral.f90:236-239)
+    idl, idr = ndl // 2 + 1, ndr // 2 + 1
+    bcs_b, bcs_t = (_matmul_3d_both if ndr == 3 else _matmul_5d_both)(rhsi, f, res, p.rhs_b, p.rhs_t)
     sub = res[1:nx - 1]
-    pentadss(lhs[1:nx - 1, 0], lhs[1:nx - 1, 1], lhs[1:nx - 1, 2], lhs[1:nx - 1, 3], lhs[1:nx - 1, 4], sub)
+    {3: tridss_m, 5: pentadss, 7: heptadss}[ndl](*([lhs[1:nx - 1, k] for k in range(ndl)] + [sub]))
     du = None
-    idl, ndl, idr = 3, 5, 2
     if p.bc == BCS_MAX:
         res[0] = bcs_b
         for ic in range(1, idl):

@@ -11,20 +11,23 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from oracle import ref_lib as R  # noqa: E402
 
 
-def case(name, n, stretch):
+def case(name, n, stretch, mode1=6):
+    """mode1: SpaceOrder1 of the y plan the integral operators invert (fdm_derivative.f90:52-58): 6 CompactJacobian6 (3 / 5 diagonals: pentadiagonal
+    integral systems, PENTADFS), 5 CompactJacobian6Penta (5 / 7: HEPTADFS), 4 CompactJacobian4 (3 / 3: TRIDFS) -- fdm_integral.f90:75-83."""
     y = 0.5 * (1 + np.tanh(2 * (2 * np.arange(n) / (n - 1) - 1)) / np.tanh(2)) if stretch else np.arange(n) / (n - 1.0) * 2.0
     R.init(4, n, 4)
-    R.fdm_create(2, y, False, not stretch)
+    R.fdm_create(2, y, False, not stretch, mode1=mode1)
+    ndl, ndr = {6: (3, 5), 5: (5, 7), 4: (3, 3)}[mode1]
     rng = np.random.default_rng(20250509 + n)
     lams = np.array([0.0, 1.2246467991473532e-16, 0.5, 6.283185307179586, 97.0, 1500.0])
-    out = {"y": y, "uniform": int(not stretch), "lams": lams}
+    out = {"y": y, "uniform": int(not stretch), "lams": lams, "mode1": mode1}
     for il, lam in enumerate(lams):
         for ibc, sgn in ((1, 1.0), (2, -1.0)):
             R.int1_create(sgn * lam, ibc, False)
-            for k, v in R.int1_tables(n, ibc).items():
+            for k, v in R.int1_tables(n, ibc, ndr, ndl).items():
                 out["sys_l%d_bc%d_%s" % (il, ibc, k)] = v
             R.int1_create(sgn * lam, ibc, True)
-            out["lu_l%d_bc%d_lhs" % (il, ibc)] = R.int1_tables(n, ibc)["lhs"]
+            out["lu_l%d_bc%d_lhs" % (il, ibc)] = R.int1_tables(n, ibc, ndr, ndl)["lhs"]
             f = rng.uniform(-1, 1, (n, 3))
             res = np.zeros((n, 3))
             res[0 if ibc == 1 else n - 1] = rng.uniform(-1, 1, 3)
@@ -59,8 +62,12 @@ def case(name, n, stretch):
 
 
 def main():
-    case("poisson_modes_stretched_40", 40, True)
-    case("poisson_modes_uniform_32", 32, False)
+    import sys as _sys
+    if "--all" in _sys.argv:              # the two fixtures of round 1 (regenerating them reproduces the committed files bit for bit)
+        case("poisson_modes_stretched_40", 40, True)
+        case("poisson_modes_uniform_32", 32, False)
+    case("poisson_modes_penta_stretched_40", 40, True, mode1=5)          # 7-diagonal integral systems (HEPTADFS / HEPTADSS, MatMul_5d)
+    case("poisson_modes_jacobian4_stretched_36", 36, True, mode1=4)      # 3-diagonal ones (TRIDFS / TRIDSS, MatMul_3d)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,9 @@ TOL = 1e-13
 def test_int1_and_ode2_match_golden(path):
     g = np.load(path)
     y = g["y"]; n = y.shape[0]
-    gy = O.FdmPlan(y, False, bool(g["uniform"]))
+    # mode1: the first-derivative scheme whose integral operators these are (absent in the round-1 fixtures: CompactJacobian6); 5 = CompactJacobian6Penta
+    # -> 7-diagonal systems (HEPTADFS / HEPTADSS, MatMul_5d), 4 = CompactJacobian4 -> tridiagonal ones (fdm_integral.f90:75-83, 249-263)
+    gy = O.FdmPlan(y, False, bool(g["uniform"]), mode1=int(g["mode1"]) if "mode1" in g.files else O.FDM_COM6_JACOBIAN)
     for il, lam in enumerate(g["lams"]):
         for ibc, sgn in ((1, 1.0), (2, -1.0)):
             p = OP.int1_create_system(gy.der1, sgn * lam, ibc)

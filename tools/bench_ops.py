@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--rtile-m", type=int, default=0)
     ap.add_argument("--dirs", default="123")
+    ap.add_argument("--types", default="P1,P2,P2_P1,BURGERS", help="which operators to time (P1 alone: the north-star's own kernels, one template each under rocprofv3)")
     args = ap.parse_args()
     n = args.n
     T.init(0)
@@ -57,10 +58,13 @@ def main():
             g = plans[key]
             tag = "XYZ"[d - 1] + ("(uniform)" if key == "2u" else "")
             for name, typ, bpp in (("P1", T.OPR_P1, 16), ("P2", T.OPR_P2, 16), ("P2_P1", T.OPR_P2_P1, 24)):
+                if name not in args.types.split(","):
+                    continue
                 med, best = timeit(lambda: part[d](typ, n, n, n, 0, g, u, r, t), args.iters)
                 rows.append(("OPR_Partial_%s %s" % (tag, name), med, best, bpp))
-            med, best = timeit(lambda: burg[d](T.OPR_B_U_IN, 1e-3, n, n, n, 0, g, u, v, r, t), args.iters)
-            rows.append(("OPR_Burgers_%s U_IN" % tag, med, best, 24))
+            if "BURGERS" in args.types.split(","):
+                med, best = timeit(lambda: burg[d](T.OPR_B_U_IN, 1e-3, n, n, n, 0, g, u, v, r, t), args.iters)
+                rows.append(("OPR_Burgers_%s U_IN" % tag, med, best, 24))
     for name, med, best, bpp in rows:
         print("%-28s %8.3f ms (best %7.3f)  %9.3e pts/s  %7.1f GB/s alg (%d B/pt)  %5.1f %% of 8 TB/s" %
               (name, med, best, N / med * 1e3, bpp * N / med / 1e6, bpp, bpp * N / med / 1e6 / 80.0))

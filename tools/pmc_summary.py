@@ -2,7 +2,7 @@
 """Turns rocprofv3 outputs into the summaries kept under profiles/:
 
     python tools/pmc_summary.py stats  <dir of `rocprofv3 --kernel-trace --stats --output-format csv`>  > profiles/rNN/rocprofv3_kernel_stats_*.csv
-    python tools/pmc_summary.py pmc    <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [traffic.json to update]
+    python tools/pmc_summary.py pmc    <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [traffic.json to write [commit]]
 
 HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE KiB (gfx950: FETCH_SIZE counts half of the bytes of wide coalesced reads,
 MI355X_MICROARCH.md section HBM; calibrated on a 4-array streaming kernel, profiles/README.md)."""
@@ -20,7 +20,7 @@ MODES = {1: "P1", 2: "P2", 3: "P2_P1", 4: "BURGERS", 5: "P2_D1IN", 6: "BURGERS_D
 def tag(name):
     """rocprof kernel name -> the tag the library's own profiler (and bench.py) uses."""
     name = re.sub(r"^void\s+", "", name).replace("tlab::", "")
-    m = re.match(r"k_htile<(\d+), 4, (\d+), (\d+), true>", name)
+    m = re.match(r"k_htile<(\d+), 4, (\d+), (\d+), true\b", name)
     if m:
         return "k_htile<BURGERS+div>"
     m = re.match(r"k_(xline|rtile|htile)<(\d+), (\d+)", name)
@@ -67,7 +67,7 @@ def counters(d, cname):
     return acc
 
 
-def pmc(dfetch, dwrite, tjson=None):
+def pmc(dfetch, dwrite, tjson=None, commit=None):
     fe, wr = counters(dfetch, "FETCH_SIZE"), counters(dwrite, "WRITE_SIZE")
     out = {}
     print("%-44s %-22s %8s %20s %20s  HBM bytes/launch = (2*FETCH+WRITE) KiB" % ("kernel (rocprof name)", "bench tag", "launches", "FETCH_SIZE[KiB]/launch", "WRITE_SIZE[KiB]/launch"))
@@ -83,13 +83,18 @@ def pmc(dfetch, dwrite, tjson=None):
         if t not in out or fe[k][1] > out[t][1]:
             out[t] = (b, fe[k][1])
     if tjson:
-        json.dump({k: v[0] for k, v in out.items()}, open(tjson, "w"), indent=1)
+        import datetime
+        doc = {"_meta": {"commit": commit, "session": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "kernels": len(out),
+                         "what": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB from two separate rocprofv3 --pmc passes of `bench.py` on the "
+                                 "binaries of that commit (tools/profile_round.sh); regenerated with the rocprofv3 kernel-stats CSV of the same session"}}
+        doc.update({k: v[0] for k, v in out.items()})
+        json.dump(doc, open(tjson, "w"), indent=1)
 
 
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == "pmc":
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, sys.argv[5] if len(sys.argv) > 5 else None)
     else:
         sys.exit(__doc__)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# One profiling session on the GPU box (from the repo root): everything profiles/<round>/ and profiles/traffic.json are made from, out of the SAME
+# binaries in ONE session.
+#     gpurun --timeout 1500 -- "bash tools/profile_round.sh r03 $(git rev-parse --short HEAD)"
+# then copy gpurun_out/<round>/{*.csv,*.txt,*.json} to profiles/<round>/ and gpurun_out/<round>/traffic.json to profiles/traffic.json.
+# rocprofv3 rules of this pool: the program itself after `--` (no env / bash -c hops), --pmc passes separate from --stats, counters one per pass.
+set -u
+R=${1:-r03}
+COMMIT=${2:-unknown}
+ROOT=$(pwd)
+O=$ROOT/gpurun_out/$R
+mkdir -p "$O"
+export TMPDIR=/tmp
+cd /tmp
+B="$ROOT/bench.py"
+# 1. the default bench line (what the driver runs) and the same command under the kernel trace
+python3 "$B" > "$O/bench_default.json" 2> "$O/bench_default.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/raw_stats" -- python3 "$B" --steps 6 --warmup 2 --cpu-sample 0 --no-freeslip-leg > "$O/bench_under_rocprof.json" 2> "$O/rocprof_stats.err"
+python3 "$ROOT/tools/pmc_summary.py" stats "$O/raw_stats" > "$O/rocprofv3_kernel_stats_bench_steps6.csv"
+# 2. HBM traffic: two separate counter passes, kernel trace only
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/raw_fetch" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/raw_write" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_write.err"
+python3 "$ROOT/tools/pmc_summary.py" pmc "$O/raw_fetch" "$O/raw_write" "$O/traffic.json" "$COMMIT" > "$O/pmc_hbm_traffic_summary.txt"
+# 3. the north-star's own kernels stand-alone: OPR_Partial_{X,Y,Z}(OPR_P1) at 512^3, kernel trace + the same two counter passes
+OPS="$ROOT/tools/bench_ops.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/raw_ops_stats" -- python3 "$OPS" --types P1 --iters 20 > "$O/ops_p1_under_rocprof.txt" 2> "$O/rocprof_ops.err"
+python3 "$ROOT/tools/pmc_summary.py" stats "$O/raw_ops_stats" > "$O/rocprofv3_kernel_stats_opr_partial_p1.csv"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/raw_ops_fetch" -- python3 "$OPS" --types P1 --iters 5 > /dev/null 2>> "$O/rocprof_ops.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/raw_ops_write" -- python3 "$OPS" --types P1 --iters 5 > /dev/null 2>> "$O/rocprof_ops.err"
+python3 "$ROOT/tools/pmc_summary.py" pmc "$O/raw_ops_fetch" "$O/raw_ops_write" > "$O/pmc_hbm_traffic_opr_partial_p1.txt"
+python3 "$OPS" --types P1,BURGERS --iters 20 > "$O/ops_standalone.txt" 2>&1
+# the raw rocprofv3 trees are large: only the summaries travel back
+rm -rf "$O"/raw_*
+ls -la "$O"
