@@ -475,6 +475,16 @@ int tlab_profile_report(char *buf, int nbuf);
  * which = 1 (first derivative, variant ibc) or 2 (second derivative); chunks = number of chunks;
  * f (HOST, n doubles): right-hand side in, solution out. */
 int tlab_debug_host_chunked_solve(tlab_fdm_plan_t p, int which, int ibc, int chunks, double *f);
+/* Debug aid, never on an operator path: the HOST-factorized tables of the 3- / 7-diagonal first-order integral operators (FDM_Int1_Initialize for
+ * SpaceOrder1 = CompactJacobian4 | CompactDirect4 | CompactJacobian6Penta, tlab_amd/csrc/int1_generic.cpp) of the y plan gy for the nm constants
+ * lam (ibc: 1 BCS_MIN, 2 BCS_MAX; the sign convention is the caller's), so that they can be checked against the oracle without a GPU.  HOST buffers:
+ * fac [nd][n][nm] (nd = RHS diagonals of the derivative), rb, rt [40][nm] (rhs_b(1:5, 0:7), rhs_t(0:4, 1:8)), R [n][LHS diagonals] row-major. */
+int tlab_debug_int1_tables(tlab_fdm_plan_t gy, int ibc, int nm, const double *lam, double *fac, double *rb, double *rt, double *R);
+/* ... and one FDM_Int1_Solve with them on the DEVICE (k_int1g), two lines per mode.  HOST buffers: f, res [2][n][nm] (res: the solution, boundary
+ * values included), bv [2][nm] (the value given at the bottom, ibc = 1, or at the top, 2; the opposite end takes f's entry), du [2][nm].
+ * variant (the kernel instantiations the plan builders use): 0 as described; 1: unit forcing (line 0: f = delta at the row opposite to the given
+ * end, value 0; line 1: f = 0, value 1; f and bv ignored); 2: ibc = 2 with three lines (f's two and a zero one; values 0, 0, 1), res / du = lines 1, 2. */
+int tlab_debug_int1_solve(tlab_fdm_plan_t gy, int ibc, int variant, int nm, const double *lam, const double *f, const double *bv, double *res, double *du);
 
 #ifdef __cplusplus
 }

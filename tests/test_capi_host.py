@@ -130,3 +130,32 @@ def test_no_cpu_fallback_without_gpu():
     p = T.FdmPlan(np.arange(64) / 64.0, True, True)
     rc = L.load().tlab_opr_partial(1, p._h, 1, 64, 1, 1, 0, L.c_vp(8), L.c_vp(16), L.c_vp(0))
     assert rc != 0       # refused: tlab_init never succeeded
+
+
+def test_host_factorized_int1_tables_equal_the_oracle_bitwise():
+    """FDM_Int1 with 3 and 7 diagonals (SpaceOrder1 = CompactJacobian4 / CompactJacobian6Penta under the factorized Poisson solver): the library builds
+    and factorizes these systems on the HOST (tlab_amd/csrc/int1_generic.cpp: FDM_Int1_CreateSystem, FDM_Bcs_Reduce, TRIDFS / HEPTADFS); its tables
+    equal the oracle's to the bit, and the oracle's equal the reference's (tests/test_oracle_poisson.py on the _ref-generated fixtures)."""
+    import ctypes
+    import numpy as np
+    import tlab_amd as T
+    from tlab_amd.lib import load, check
+    from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
+    L = load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    for n, stretch in ((40, True), (33, False)):
+        y = 0.5 * (1 + np.tanh(2 * (2 * np.arange(n) / (n - 1) - 1)) / np.tanh(2)) if stretch else np.arange(n) / (n - 1.0) * 2.0
+        for mode1 in (5, 4):
+            gp, op = T.FdmPlan(y, False, not stretch, mode1, 7), O.FdmPlan(y, False, not stretch, mode1, 7)
+            ndl, ndr = op.der1.nb_diag
+            lam = np.array([0.0, 1.2246467991473532e-16, 0.5, 6.283185307179586, 97.0, 1500.0])
+            nm = len(lam)
+            for ibc, sgn in ((1, 1.0), (2, -1.0)):
+                fac, rb, rt, R = np.zeros((ndr, n, nm)), np.zeros((40, nm)), np.zeros((40, nm)), np.zeros((n, ndl))
+                ls = np.ascontiguousarray(sgn * lam)
+                check(L.tlab_debug_int1_tables(gp._h, ibc, nm, ls.ctypes.data_as(dp), fac.ctypes.data_as(dp), rb.ctypes.data_as(dp),
+                                               rt.ctypes.data_as(dp), R.ctypes.data_as(dp)), "tlab_debug_int1_tables")
+                p = OP.int1_initialize(op.der1, ls, ibc)
+                assert np.array_equal(fac.transpose(1, 0, 2), p.lhs), (n, mode1, ibc, "factors")
+                assert np.array_equal(rb, p.rhs_b.transpose(1, 0, 2).reshape(40, nm)) and np.array_equal(rt, p.rhs_t.transpose(1, 0, 2).reshape(40, nm))
+                assert np.array_equal(R, p.rhs)

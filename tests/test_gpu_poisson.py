@@ -281,6 +281,85 @@ def test_poisson_dirichlet_vs_oracle(T, nx, ny, nz, stretch):
             assert rel_err(q.cpu().numpy(), qn) <= TOL
 
 
+@pytest.mark.parametrize("n", [40, 129])
+@pytest.mark.parametrize("scheme1", [5, 4])
+def test_device_int1_solve_with_3_and_7_diagonals_is_bitwise_the_oracle(T, scheme1, n):
+    """One FDM_Int1_Solve per mode on the device (k_int1g: MatMul_3d / MatMul_5d, TRIDSS / HEPTADSS on host-made factors, free-end value and
+    derivative at the given end) against the oracle, which is bitwise the reference for these widths: equal to the last bit, 305 constants."""
+    import ctypes
+    from tlab_amd.lib import load, check
+    from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
+    L = load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    y = 0.5 * (1 + np.tanh(2 * (2 * np.arange(n) / (n - 1) - 1)) / np.tanh(2))
+    gp, op = T.FdmPlan(y, False, False, scheme1, 7), O.FdmPlan(y, False, False, scheme1, 7)
+    lam = np.concatenate([[0.0, 1.2246467991473532e-16, 0.5, 6.28, 97.0, 1500.0], np.linspace(0.1, 900, 299)])
+    nm = len(lam)
+    rng = np.random.default_rng(n + scheme1)
+    def solve(ibc, variant, ls, f, bv):
+        res, du = np.zeros((2, n, nm)), np.zeros((2, nm))
+        check(L.tlab_debug_int1_solve(gp._h, ibc, variant, nm, ls.ctypes.data_as(dp), f.ctypes.data_as(dp), bv.ctypes.data_as(dp),
+                                      res.ctypes.data_as(dp), du.ctypes.data_as(dp)), "tlab_debug_int1_solve")
+        return res.transpose(1, 0, 2), du
+
+    for ibc, sgn in ((1, 1.0), (2, -1.0)):
+        ls = np.ascontiguousarray(sgn * lam)
+        p = OP.int1_initialize(op.der1, ls, ibc)
+        # variant 0: two given lines with given boundary values
+        f, bv = rng.uniform(-1, 1, (2, n, nm)), rng.uniform(-1, 1, (2, nm))
+        res, du = solve(ibc, 0, ls, f, bv)
+        ro = np.zeros((n, 2, nm))
+        ro[0 if ibc == 1 else n - 1] = bv
+        duo = OP.int1_solve(p, p.rhs, f.transpose(1, 0, 2).copy(), ro, want_du=True)
+        assert np.array_equal(res, ro) and np.array_equal(du, duo), (scheme1, n, ibc, "given lines")
+        # variant 1: the unit forcings of the homogeneous solutions (opr_odes.f90:308-318)
+        res, du = solve(ibc, 1, ls, f, bv)
+        fo, ro = np.zeros((n, 2, nm)), np.zeros((n, 2, nm))
+        fo[n - 1 if ibc == 1 else 0, 0] = 1.0
+        ro[0 if ibc == 1 else n - 1, 1] = 1.0
+        duo = OP.int1_solve(p, p.rhs, fo, ro, want_du=True)
+        assert np.array_equal(res, ro) and np.array_equal(du, duo), (scheme1, n, ibc, "unit forcing")
+        if ibc == 2:      # variant 2: three lines (u1, s+, e+ of OPR_ODE2_Factorize_NN: two forced lines and the free one with value 1 at the top)
+            res, du = solve(2, 2, ls, f, bv)
+            fo, ro = np.zeros((n, 3, nm)), np.zeros((n, 3, nm))
+            fo[:, 0:2] = f.transpose(1, 0, 2)
+            ro[n - 1, 2] = 1.0
+            duo = OP.int1_solve(p, p.rhs, fo, ro, want_du=True)
+            assert np.array_equal(res, ro[:, 1:3]) and np.array_equal(du, duo[1:3]), (scheme1, n, "three lines")
+
+
+@pytest.mark.parametrize("ibc", ["NN", "DD"])
+@pytest.mark.parametrize("scheme1,nx,ny,nz", [(5, 32, 40, 16), (5, 16, 128, 8), (4, 32, 36, 16), (4, 16, 24, 1)])
+def test_poisson_with_3_and_7_diagonal_integral_systems(T, scheme1, nx, ny, nz, ibc):
+    """The factorized solver on a y plan whose first derivative is CompactJacobian6Penta (5: heptadiagonal integral systems, HEPTADFS / HEPTADSS,
+    MatMul_5d) or CompactJacobian4 (4: tridiagonal ones, TRIDFS / TRIDSS) -- fdm_integral.f90:75-83, 249-263.  The systems are factorized on the
+    host (tlab_amd/csrc/int1_generic.cpp; bitwise equal to the oracle's, tests/test_capi_host.py), k_int1g substitutes; against the oracle, whose
+    FDM_Int1 for these widths is bitwise equal to the reference's (tests/golden/poisson_modes_penta_*, _jacobian4_*)."""
+    import torch
+    from oracle import tlab_oracle as O, tlab_oracle_poisson as OP
+    x, y, z = setup(nx, ny, nz, True)
+    go = [O.FdmPlan(x, True, True), O.FdmPlan(y, False, False, scheme1, 7), O.FdmPlan(z, True, True)]
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, False, scheme1, 7), T.FdmPlan(z, True, True)]
+    rng = np.random.default_rng(nx + ny + nz + scheme1)
+    N = nx * ny * nz
+    i = np.arange(N)
+    f = np.sin(0.3 * (i % nx)) * np.cos(0.07 * (i // nx)) + 0.2 * rng.uniform(-1, 1, N)
+    hb, ht = rng.uniform(-1, 1, nx * nz), rng.uniform(-1, 1, nx * nz)
+    code = O.BCS_NN if ibc == "NN" else O.BCS_DD
+    plan_o = OP.PoissonPlan(go[0], go[1], go[2], nx, ny, nz)
+    (p_ref, d_ref), (sc_p, sc_d) = scatter_of(lambda f_, hb_, ht_: OP.opr_poisson_fxz(plan_o, f_, hb_, ht_, ibc=code),
+                                              [f, hb.reshape(nz, nx), ht.reshape(nz, nx)], nsamples=2)
+    plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+    t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda")
+    t2 = torch.empty_like(t1)
+    for rep in range(2):
+        p = dev(f)
+        dpdy = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
+        T.OPR_Poisson(plan, nx, ny, nz, T.BCS_NN if ibc == "NN" else T.BCS_DD, p, t1, t2, dev(hb), dev(ht), dpdy)
+        ep, ed = rel_err(p.cpu().numpy(), p_ref), rel_err(dpdy.cpu().numpy(), d_ref)
+        assert ep <= bound(sc_p) and ed <= bound(sc_d), (scheme1, ibc, ep, sc_p, ed, sc_d)
+
+
 def test_poisson_dirichlet_marching_route_on_chunked_plans(T):
     """TLAB_ODE_DD_CHUNKED=0: a chunked plan marches every mode for BCS_DD (the route before k_ode_nn<DD>); both routes of the same plan agree
     with each other far inside the oracle's scatter."""

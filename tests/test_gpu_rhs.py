@@ -597,6 +597,35 @@ def test_dynamic_surface_bcs_vs_oracle(T, sides, fuse):
     assert np.abs(B[2]["hs"][0].reshape(nz, ny, nx)[:, 0, :]).max() > 1e-3          # (the bottom plane of the tendency is alive)
 
 
+@pytest.mark.parametrize("scheme1,nx,ny,nz", [(5, 64, 40, 32), (5, 256, 64, 64), (4, 64, 36, 32)])
+def test_substep_with_other_first_derivatives_and_the_default_elliptic_solver(T, scheme1, nx, ny, nz):
+    """SpaceOrder1 = CompactJacobian6Penta (5) / CompactJacobian4 (4) with the DEFAULT EllipticOrder: the factorized Poisson solver then inverts a
+    first derivative with (5, 7) / (3, 3) diagonals, i.e. 7- / 3-diagonal integral systems (FDM_Int1 with HEPTADFS / TRIDFS, fdm_integral.f90:75-83)
+    -- the last piece of SURVEY 8f n3.  Two substeps against the oracle within the scatter bound."""
+    import torch
+    from tlab_amd.dns import Dns
+    from oracle import tlab_oracle as O
+    from oracle.tlab_oracle_rhs import DnsOracle
+    x, y, z = grids(nx, ny, nz, True)
+    visc, sc = 1.0 / 800.0, (0.7,)
+    q0, s0 = init_fields(nx, ny, nz, x, y, z, 31)
+    gp = [T.FdmPlan(x, True, True, scheme1, 7, hyper_bc1_ext=REF_HYPER), T.FdmPlan(y, False, False, scheme1, 7, hyper_bc1_ext=REF_HYPER),
+          T.FdmPlan(z, True, True, scheme1, 7, hyper_bc1_ext=REF_HYPER)]
+    d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, plans=gp, hyper_bc1_ext=REF_HYPER)
+    for i in range(3):
+        d.q[i].copy_(torch.from_numpy(q0[i]))
+    d.s[0].copy_(torch.from_numpy(s0[0]))
+    sched = [(2e-3 * d.kdt[k], d.kco[k], True) for k in range(2)]
+
+    def make_oracle():
+        go = [O.FdmPlan(x, True, True, scheme1, 7), O.FdmPlan(y, False, False, scheme1, 7), O.FdmPlan(z, True, True, scheme1, 7)]
+        return DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, plans=go)
+    B, S = oracle_substeps(("scheme1", scheme1, nx, ny, nz), make_oracle, q0, s0, sched, nsamples=2)
+    for k, (dte, kco, scale) in enumerate(sched):
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
+        check_state(d, B, S, k, tag="scheme1 = %d" % scheme1)
+
+
 @pytest.mark.parametrize("fuse", [True, False])
 def test_dynamic_surface_bcs_over_two_runge_kutta_steps(T, fuse):
     """The kept tendency planes of the surface model across a step boundary: the device driver is TOLD that hq, hs are zero at the start of a step

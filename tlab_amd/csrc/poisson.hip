@@ -31,6 +31,7 @@
 #include "plan.hpp"
 #include "fftz.hpp"
 #include "poisson_host.hpp"
+#include "int1_generic.hpp"
 #include "profile.hpp"
 
 namespace tlab {
@@ -71,6 +72,11 @@ struct Int1Args {
     // (its per-call solves: the chain of dependent divisions is what a handful of marching threads spends its time on)
     double *fac_out;
     const double *fac;
+    // 3- / 7-diagonal integral systems (int1_generic.cpp): everything factorized on the host, per mode -- g_fac [ndi][n][nm] (rows 2..n-1: the factors
+    // of TRIDFS / HEPTADFS; rows 1, n: the reduced boundary rows), g_rb / g_rt [40][nm] (rhs_b(1:5, 0:7), rhs_t(0:4, 1:8)), g_R [n][nri].  g_fac != NULL
+    // sends launch_int1 to k_int1g.
+    const double *g_fac, *g_rb, *g_rt, *g_R;
+    int g_ndi, g_nri;
 };
 
 // Non-fused arithmetic for everything that builds or factorizes the per-mode matrices: the reference's CPU build rounds every product and
@@ -379,6 +385,146 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
             a.dst[((long long)l * n + (n - 1)) * nm + t] = rN;
             a.dst[((long long)l * n + 0) * nm + t] = res0[l];
             if (a.du) a.du[(long long)l * nm + t] = l0[2] * res0[l] + l0[3] * xs1[l] + l0[4] * xs2[l] + l0[0] * xs3[l] + a.T.R[0 * 3 + 2] * f1[l];
+        }
+    }
+}
+
+// ================================================================================================
+// k_int1g : FDM_Int1_Solve (fdm/fdm_integral.f90:219-314) for the 3- and 7-diagonal integral systems of SpaceOrder1 = CompactJacobian4 /
+// CompactDirect4 / CompactJacobian6Penta, factorized on the host (int1_generic.cpp).  One thread per mode, the reference's operations in the
+// reference's order, no fused multiply-adds: right-hand side (MatMul_3d / MatMul_5d with BCS_BOTH, fdm_matmul.f90:70-121 / :267-320), substitution
+// (TRIDSS utils/linear3.f90:56-150 / HEPTADSS utils/linear7.f90:98-142), value at the free end and derivative at the given one (:265-311).
+// Nobody selects these schemes with the factorized solver: correctness first, every operand re-read where it is used.
+// optnone: at -O3 hipcc 7.2 miscompiles some instantiations of this kernel (the first version gave O(1) errors in the 7-diagonal substitution that
+// vanished when a printf was added; after a restructuring the FS_UNIT / NDI = 7 instantiations were still wrong while FS_LINEAR was bitwise right).
+// Unoptimised, every instantiation in use is bitwise equal to the oracle (tests/test_gpu_poisson.py, tlab_debug_int1_solve variants 0-2); nobody
+// selects these schemes with the factorized solver, so the kernel stays simple and slow rather than clever.
+template <int BC, int NL, int FS, int NDI>
+__global__ void __launch_bounds__(256) __attribute__((optnone)) k_int1g(Int1Args a) {
+#pragma clang fp contract(off)
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nm) return;
+    constexpr int ndi = NDI, nri = NDI == 3 ? 3 : 5, idl = ndi / 2 + 1, idr = nri / 2 + 1;      // (3, 3): CompactJacobian4 / Direct4; (7, 5): CompactJacobian6Penta
+    const int n = a.T.n;
+    const long long nm = a.nm;
+    const long long fidx0 = (FS == FS_FIELD) ? (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh) : 0;
+    auto F = [&](int k, int j) { return a.g_fac[((long long)k * n + j) * nm + t]; };                 // diagonal k (0-based) of row j (0-based)
+    auto RB = [&](int j1, int c) { return a.g_rb[(long long)((j1 - 1) + 5 * c) * nm + t]; };          // rhs_b(j1, c)
+    auto RT = [&](int r, int c1) { return a.g_rt[(long long)(r + 5 * (c1 - 1)) * nm + t]; };          // rhs_t(r, c1)
+    auto Rr = [&](int j, int k1) { return a.g_R[j * nri + (k1 - 1)]; };                               // rhs(j+1, k1)
+    auto fv = [&](int j, int l) -> double {                                                            // f(l, j+1): one value, no private array
+        if (FS == FS_FIELD) return reinterpret_cast<const double *>(a.fsrc)[2 * (fidx0 + (long long)j * a.nxh) + l] * a.fscale;
+        if (FS == FS_LINEAR) return (l < a.nlf) ? a.fsrc[((long long)l * n + j) * nm + t] : 0.0;
+        return (l == 0 && j == a.unit_row) ? 1.0 : 0.0;
+    };
+    double res0[NL], resN[NL];
+    {
+        double fb0[NL], fbN[NL];
+        load_f<NL, FS>(a, 0, t, fidx0, fb0);
+        load_f<NL, FS>(a, n - 1, t, fidx0, fbN);
+        if (FS == FS_FIELD && a.bcs_save != nullptr) {
+            a.bcs_save[0 * nm + t] = fb0[0]; a.bcs_save[1 * nm + t] = fb0[NL > 1 ? 1 : 0];
+            a.bcs_save[2 * nm + t] = fbN[0]; a.bcs_save[3 * nm + t] = fbN[NL > 1 ? 1 : 0];
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const double given = a.bv_ptr ? a.bv_ptr[(long long)l * nm + t] : a.bv[l];
+            if (BC == 1) { res0[l] = given; resN[l] = a.zero_bsave ? 0.0 : fbN[l]; }
+            else { resN[l] = given; res0[l] = a.zero_bsave ? 0.0 : fb0[l]; }
+        }
+    }
+    const int nmax = n - 2;                       // the systems are those of rows 2 .. n-1; sub-row m <-> row j = m + 1 (0-based)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        // ---- right-hand side of row j (0-based) ----
+        auto rhs_row = [&](int j) -> double {
+            if (nri == 3) {
+                if (j == 1) return res0[l] * RB(2, 1) + fv(1, l) * RB(2, 2) + fv(2, l) * RB(2, 3);
+                if (j == 2) return res0[l] * RB(3, 0) + fv(1, l) * RB(3, 1) + fv(2, l) * RB(3, 2) + fv(3, l) * RB(3, 3);
+                if (j == n - 3) return fv(n - 4, l) * RT(0, 1) + fv(n - 3, l) * RT(0, 2) + fv(n - 2, l) * RT(0, 3) + resN[l] * RT(0, 4);
+                if (j == n - 2) return fv(n - 3, l) * RT(1, 1) + fv(n - 2, l) * RT(1, 2) + resN[l] * RT(1, 3);
+                return fv(j - 1, l) * Rr(j, 1) + fv(j, l) * Rr(j, 2) + fv(j + 1, l);
+            }
+            if (j == 1) return res0[l] * RB(2, 2) + fv(1, l) * RB(2, 3) + fv(2, l) * RB(2, 4) + fv(3, l) * RB(2, 5);
+            if (j == 2) return res0[l] * RB(3, 1) + fv(1, l) * RB(3, 2) + fv(2, l) * RB(3, 3) + fv(3, l) * RB(3, 4) + fv(4, l) * RB(3, 5);
+            if (j == 3) return res0[l] * RB(4, 0) + fv(1, l) * RB(4, 1) + fv(2, l) * RB(4, 2) + fv(3, l) * RB(4, 3) + fv(4, l) * RB(4, 4) + fv(5, l) * RB(4, 5);
+            if (j == n - 4)
+                return fv(n - 6, l) * RT(0, 1) + fv(n - 5, l) * RT(0, 2) + fv(n - 4, l) * RT(0, 3) + fv(n - 3, l) * RT(0, 4) + fv(n - 2, l) * RT(0, 5) +
+                       resN[l] * RT(0, 6);
+            if (j == n - 3) return fv(n - 5, l) * RT(1, 1) + fv(n - 4, l) * RT(1, 2) + fv(n - 3, l) * RT(1, 3) + fv(n - 2, l) * RT(1, 4) + resN[l] * RT(1, 5);
+            if (j == n - 2) return fv(n - 4, l) * RT(2, 1) + fv(n - 3, l) * RT(2, 2) + fv(n - 2, l) * RT(2, 3) + resN[l] * RT(2, 4);
+            return fv(j - 2, l) * Rr(j, 1) + fv(j - 1, l) * Rr(j, 2) + fv(j, l) * Rr(j, 3) + fv(j + 1, l) + fv(j + 2, l) * Rr(j, 5);
+        };
+        double bcs_b, bcs_t;
+        if (nri == 3) {
+            bcs_b = res0[l] * RB(1, 2) + fv(1, l) * RB(1, 3) + fv(2, l) * RB(1, 1);
+            bcs_t = fv(n - 3, l) * RT(2, 3) + fv(n - 2, l) * RT(2, 1) + resN[l] * RT(2, 2);
+        } else {
+            bcs_b = res0[l] * RB(1, 3) + fv(1, l) * RB(1, 4) + fv(2, l) * RB(1, 5) + fv(3, l) * RB(1, 1);
+            bcs_t = fv(n - 4, l) * RT(3, 5) + fv(n - 3, l) * RT(3, 1) + fv(n - 2, l) * RT(3, 2) + resN[l] * RT(3, 3);
+        }
+        double *y = a.scratch + (long long)l * n * nm + t;                   // y(j) at y[j * nm]
+        double *x = a.dst + (long long)l * n * nm + t;
+        // ---- forward substitution (the rows before come back from memory: same thread, program order) ----
+        auto Y = [&](int j) { return y[(long long)j * nm]; };
+        for (int m = 0; m < nmax; ++m) {
+            const int j = m + 1;
+            const double r = rhs_row(j);
+            double v;
+            if constexpr (NDI == 3) {
+                v = m == 0 ? r : r + F(0, j) * Y(j - 1);                      // f(n) = f(n) + a(n) f(n-1)
+            } else {
+                if (m == 0) v = r * F(2, j);                                  // normalise the first equation (c(1) = 1 / d(1), HEPTADFS)
+                else if (m == 1) v = r - Y(j - 1) * F(2, j);
+                else if (m == 2) v = r - Y(j - 1) * F(2, j) - Y(j - 2) * F(1, j);
+                else v = r - Y(j - 1) * F(2, j) - Y(j - 2) * F(1, j) - Y(j - 3) * F(0, j);
+            }
+            y[(long long)j * nm] = v;
+        }
+        // ---- backward substitution ----
+        auto XX = [&](int j) { return x[(long long)j * nm]; };
+        for (int m = nmax - 1; m >= 0; --m) {
+            const int j = m + 1;
+            const double yv = Y(j);
+            double v;
+            if constexpr (NDI == 3) {
+                v = m == nmax - 1 ? yv * F(1, j) : (yv + F(2, j) * XX(j + 1)) * F(1, j);
+            } else {
+                if (m == nmax - 1) v = yv / F(3, j);
+                else if (m == nmax - 2) v = (yv - XX(j + 1) * F(4, j)) / F(3, j);
+                else if (m == nmax - 3) v = (yv - XX(j + 1) * F(4, j) - XX(j + 2) * F(5, j)) / F(3, j);
+                else v = (yv - XX(j + 1) * F(4, j) - XX(j + 2) * F(5, j) - XX(j + 3) * F(6, j)) / F(3, j);
+            }
+            x[(long long)j * nm] = v;
+        }
+        // ---- value at the free end, derivative at the given end (fdm_integral.f90:265-311); idl: centre of the integral system ----
+        auto X = [&](int j) { return x[(long long)j * nm]; };
+        if (BC == 2) {
+            double r0 = bcs_b;
+            for (int ic = 1; ic <= idl - 1; ++ic) r0 = r0 + F(idl + ic - 1, 0) * X(ic);
+            r0 = r0 + F(0, 0) * X(idl);
+            x[0] = r0;
+            x[(long long)(n - 1) * nm] = resN[l];
+            if (a.du) {
+                double du = F(idl - 1, n - 1) * resN[l];
+                for (int ic = 1; ic <= idl - 1; ++ic) du = du + F(idl - ic - 1, n - 1) * X(n - 1 - ic);
+                du = du + F(ndi - 1, n - 1) * X(n - 1 - idl);
+                for (int ic = 1; ic <= idr - 1; ++ic) du = du + Rr(n - 1, idr - ic) * fv(n - 1 - ic, l);
+                a.du[(long long)l * nm + t] = du;
+            }
+        } else {
+            double rN = bcs_t;
+            for (int ic = 1; ic <= idl - 1; ++ic) rN = rN + F(idl - ic - 1, n - 1) * X(n - 1 - ic);
+            rN = rN + F(ndi - 1, n - 1) * X(n - 1 - idl);
+            x[(long long)(n - 1) * nm] = rN;
+            x[0] = res0[l];
+            if (a.du) {
+                double du = F(idl - 1, 0) * res0[l];
+                for (int ic = 1; ic <= idl - 1; ++ic) du = du + F(idl + ic - 1, 0) * X(ic);
+                du = du + F(0, 0) * X(idl);
+                for (int ic = 1; ic <= idr - 1; ++ic) du = du + Rr(0, idr + ic) * fv(ic, l);
+                a.du[(long long)l * nm + t] = du;
+            }
         }
     }
 }
@@ -1824,6 +1970,25 @@ struct tlab_poisson_plan {
     long long nm = 0;                 // local modes = nxh * nz
     double norm = 1.0;
     Int1Tables tmin, tmax;            // host copies
+    // SpaceOrder1 with (3, 3) or (5, 7) diagonals: integral systems factorized on the host (int1_generic.cpp), one table set per system and
+    // lambda array in use (all modes; the singular modes' zeros), built the first time base_args meets it
+    bool generic = false;
+    DerTables gder;
+    struct GenSet { int which; const double *lam; long long nm; DBuf fac, rb, rt, R; int ndi = 0, nri = 0; };
+    mutable std::vector<std::unique_ptr<GenSet>> gen;
+    const GenSet &gen_set(int which, const double *lam_dev, long long nm_) const {
+        for (const auto &e : gen)
+            if (e->which == which && e->lam == lam_dev && e->nm == nm_) return *e;
+        std::vector<double> hl((size_t)nm_);
+        if (hipMemcpy(hl.data(), lam_dev, (size_t)nm_ * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy (lambda)");
+        Int1Gen G;
+        int1_generic_build(gder, which == 0 ? 1 : 2, hl.data(), nm_, which == 0 ? 1.0 : -1.0, G);
+        auto e = std::make_unique<GenSet>();
+        e->which = which; e->lam = lam_dev; e->nm = nm_; e->ndi = G.ndi; e->nri = G.nri;
+        e->fac.upload(G.fac); e->rb.upload(G.rb); e->rt.upload(G.rt); e->R.upload(G.R);
+        gen.push_back(std::move(e));
+        return *gen.back();
+    }
     DBuf d_L0[2], d_L1[2], d_R[2];    // [0] BCS_MIN tables, [1] BCS_MAX tables
     DBuf lam;                         // [nm]  sqrt(kx'^2 + kz'^2)
     DBuf hom, der, cst;               // homogeneous solutions [5][ny][nm], their boundary derivatives [3][nm], 3x3 LU [9][nm]
@@ -1914,6 +2079,11 @@ struct tlab_poisson_plan {
     Int1Dev dev(int which) const {
         const Int1Tables &T = which == 0 ? tmin : tmax;
         Int1Dev d;
+        if (generic) {      // k_int1g reads its own tables (Int1Args::g_*)
+            d = Int1Dev{};
+            d.n = ny;
+            return d;
+        }
         d.L0 = d_L0[which].p; d.L1 = d_L1[which].p; d.R = d_R[which].p; d.n = ny;
         for (int j = 0; j < 3; ++j)
             for (int c = 0; c < 4; ++c) { d.rb[j][c] = T.rb[j][c]; d.rt[j][c] = T.rt[j][c]; }
@@ -1930,7 +2100,10 @@ void launch_int1(const Int1Args &a, hipStream_t st) {
     const bool few = a.nm <= 8;   // the <= 4 singular modes, solved beside the regular ones on the side stream
     ProfScope ps(few ? "k_int1<singular modes>" : (FS == FS_FIELD ? "k_int1<field>" : (FS == FS_LINEAR ? "k_int1<linear>" : "k_int1<unit>")), st,
                  (double)a.nm * a.T.n * 16.0 * NL);
-    if (a.fac) {
+    if (a.g_fac) {
+        if (a.g_ndi == 3) hipLaunchKernelGGL((k_int1g<BC, NL, FS, 3>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_int1g<BC, NL, FS, 7>), dim3(grid), dim3(256), 0, st, a);
+    } else if (a.fac) {
         if (a.nm < 65536) hipLaunchKernelGGL((k_int1<BC, NL, FS, 8, true>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_int1<BC, NL, FS, 2, true>), dim3(grid), dim3(256), 0, st, a);
     } else {
@@ -1950,6 +2123,10 @@ Int1Args base_args(const tlab_poisson_plan &P, int which, const double *lam, lon
     a.nxh = P.nxh;
     a.ny = P.ny;
     a.scratch = scratch;
+    if (P.generic) {
+        const tlab_poisson_plan::GenSet &G = P.gen_set(which, lam, nm);
+        a.g_fac = G.fac.p; a.g_rb = G.rb.p; a.g_rt = G.rt.p; a.g_R = G.R.p; a.g_ndi = G.ndi; a.g_nri = G.nri;
+    }
     return a;
 }
 
@@ -2339,10 +2516,16 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
             *out = P.release();
             return TLAB_OK;
         }
-        int1_build_tables(gy->t.der1, 1, P->tmin);
-        int1_build_tables(gy->t.der1, 2, P->tmax);
-        P->d_L0[0].upload(P->tmin.L0); P->d_L1[0].upload(P->tmin.L1); P->d_R[0].upload(P->tmin.R);
-        P->d_L0[1].upload(P->tmax.L0); P->d_L1[1].upload(P->tmax.L1); P->d_R[1].upload(P->tmax.R);
+        if (int1_generic_applies(gy->t.der1)) {      // (3, 3) / (5, 7) diagonals: TRIDFS / HEPTADFS systems, factorized on the host (int1_generic.cpp)
+            if (gy->t.periodic) throw std::invalid_argument("Poisson: the wall-normal direction must not be periodic");
+            P->generic = true;
+            P->gder = gy->t.der1;
+        } else {
+            int1_build_tables(gy->t.der1, 1, P->tmin);
+            int1_build_tables(gy->t.der1, 2, P->tmax);
+            P->d_L0[0].upload(P->tmin.L0); P->d_L1[0].upload(P->tmin.L1); P->d_R[0].upload(P->tmin.R);
+            P->d_L0[1].upload(P->tmax.L0); P->d_L1[1].upload(P->tmax.L1); P->d_R[1].upload(P->tmax.R);
+        }
         // lambda(k,i) = mwn_x(i)^2 + mwn_z(k)^2 (opr_elliptic.f90:199-203), stored as sqrt (:205-209)
         const long long nm = P->nm;
         std::vector<double> lam((size_t)nm);
@@ -2413,7 +2596,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
             const char *e = g_poisson_exact ? "0" : getenv("TLAB_ODE_CHUNKED");
             const int C = ny / OM;
             const long long big = std::max<long long>((long long)5 * ny * (nm + 64), std::max<long long>(9 * nm, (long long)P->nxh * ny * nz));
-            if (!(e && atoi(e) == 0) && ny % OM == 0 && C >= 2 && ode_modes_per_wg(C) > 0 && big < (1LL << 31) &&
+            if (!P->generic && !(e && atoi(e) == 0) && ny % OM == 0 && C >= 2 && ode_modes_per_wg(C) > 0 && big < (1LL << 31) &&
                 ode_lds_bytes(C, ode_modes_per_wg(C)) <= (size_t)160 * 1024) {
                 P->ode_nm_per_wg = ode_modes_per_wg(C);
                 build_checkpoints(*P, st);
@@ -2902,6 +3085,52 @@ int tlab_poisson_direct_ode(tlab_poisson_plan_t P, int ibc, double *f_hat, doubl
     if (ibc < TLAB_BCS_DD || ibc > TLAB_BCS_NN) throw std::invalid_argument("tlab_poisson_direct_ode: bad ibc");
     poisson_direct_stage(P, ibc, f_hat, p_hat, tlab_current_stream());
     POISSON_GUARD_END
+}
+
+
+// include/tlab_amd.h: debug aid -- one FDM_Int1_Solve of the 3- / 7-diagonal path on the device (k_int1g), two lines per mode, for tests
+int tlab_debug_int1_solve(tlab_fdm_plan_t gy, int ibc, int variant, int nm, const double *lam, const double *f, const double *bv, double *res, double *du) {
+    try {
+        if (!gy || !lam || !f || !bv || !res || !du || nm < 1 || (ibc != 1 && ibc != 2)) throw std::invalid_argument("tlab_debug_int1_solve: bad arguments");
+        if (!tlab_device_ready()) throw std::runtime_error("tlab_init has not been called");
+        const int n = gy->t.n;
+        Int1Gen G;
+        int1_generic_build(gy->t.der1, ibc, lam, nm, 1.0, G);
+        DBuf fac, rb, rt, R, df, dbv, dres, ddu, scr;
+        fac.upload(G.fac); rb.upload(G.rb); rt.upload(G.rt); R.upload(G.R);
+        df.upload(std::vector<double>(f, f + (size_t)2 * n * nm));
+        dbv.upload(std::vector<double>(bv, bv + (size_t)2 * nm));
+        dres.alloc((size_t)2 * n * nm); ddu.alloc((size_t)2 * nm); scr.alloc((size_t)5 * n * nm);
+        Int1Args a{};
+        a.T.n = n; a.nm = nm; a.fscale = 1.0; a.fsrc = df.p; a.nlf = 2; a.bv_ptr = dbv.p; a.dst = dres.p; a.du = ddu.p; a.scratch = scr.p;
+        a.g_fac = fac.p; a.g_rb = rb.p; a.g_rt = rt.p; a.g_R = R.p; a.g_ndi = G.ndi; a.g_nri = G.nri;
+        hipStream_t st = tlab_current_stream();
+        if (variant == 1) {                 // FS_UNIT variants of build_homogeneous / build_singular_homogeneous
+            a.bv_ptr = nullptr; a.bv[0] = 0.0; a.bv[1] = 1.0; a.bv[2] = 0.0;
+            if (ibc == 1) { a.unit_row = n - 1; launch_int1<1, 2, FS_UNIT>(a, st); }
+            else { a.unit_row = 0; launch_int1<2, 2, FS_UNIT>(a, st); }
+        } else if (variant == 2) {          // three lines, two stored (build_homogeneous, u-solve); ibc = 2
+            DBuf d3, u3;
+            d3.alloc((size_t)3 * n * nm); u3.alloc((size_t)3 * nm);
+            a.bv_ptr = nullptr; a.bv[0] = 0.0; a.bv[1] = 0.0; a.bv[2] = 1.0;
+            a.dst = d3.p; a.du = u3.p;
+            launch_int1<2, 3, FS_LINEAR>(a, st);
+            hipc(hipStreamSynchronize(st), "sync");
+            hipc(hipMemcpy(dres.p, d3.p + (size_t)n * nm, (size_t)2 * n * nm * sizeof(double), hipMemcpyDeviceToDevice), "copy");      // lines 1, 2
+            hipc(hipMemcpy(ddu.p, u3.p + (size_t)nm, (size_t)2 * nm * sizeof(double), hipMemcpyDeviceToDevice), "copy");
+        } else if (ibc == 1) launch_int1<1, 2, FS_LINEAR>(a, st);
+        else launch_int1<2, 2, FS_LINEAR>(a, st);
+        hipc(hipStreamSynchronize(st), "sync");
+        hipc(hipMemcpy(res, dres.p, (size_t)2 * n * nm * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+        hipc(hipMemcpy(du, ddu.p, (size_t)2 * nm * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+        return TLAB_OK;
+    } catch (const std::invalid_argument &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EHIP;
+    }
 }
 
 }  // extern "C"

@@ -352,3 +352,24 @@ void int2_build_tables(const DerTables &g, const std::vector<double> &x, int ibc
 }
 
 }  // namespace tlab
+
+// include/tlab_amd.h: debug aid (host only)
+#include "../../include/tlab_amd.h"
+#include "int1_generic.hpp"
+#include "plan.hpp"
+extern void tlab_set_error(const std::string &s);
+extern "C" int tlab_debug_int1_tables(tlab_fdm_plan_t gy, int ibc, int nm, const double *lam, double *fac, double *rb, double *rt, double *R) {
+    try {
+        if (!gy || !lam || !fac || !rb || !rt || !R || nm < 1 || (ibc != 1 && ibc != 2)) throw std::runtime_error("tlab_debug_int1_tables: bad arguments");
+        tlab::Int1Gen G;
+        tlab::int1_generic_build(gy->t.der1, ibc, lam, nm, 1.0, G);
+        std::copy(G.fac.begin(), G.fac.end(), fac);
+        std::copy(G.rb.begin(), G.rb.end(), rb);
+        std::copy(G.rt.begin(), G.rt.end(), rt);
+        std::copy(G.R.begin(), G.R.end(), R);
+        return TLAB_OK;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    }
+}
