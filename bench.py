@@ -107,6 +107,91 @@ def cpu_baseline(n, nscal, budget_s=25.0):
                       "%d threads on '%s' (%d logical CPUs), %.1f s timed after %.1f s of plan construction" % (nsub, n, nscal, threads, model, ncpu, dt, t_init)}
 
 
+def _cpu_instance_worker(idx, cores, threads, n, nscal, nsub, q_ready, ev_go, q_out):
+    """One independent instance of the C / OpenMP port on its own cores (spawned process: environment and affinity are set before the port loads)."""
+    try:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        os.environ["OMP_PROC_BIND"] = "close"
+        try:
+            os.sched_setaffinity(0, cores)
+        except Exception:      # noqa: BLE001  (no affinity control: the instance still runs)
+            pass
+        from oracle import tlab_cpu as C
+        C.load()
+        x = np.arange(n) / n
+        y = np.arange(n) / (n - 1.0)
+        rng = np.random.default_rng(20250509 + idx)
+        c = C.CpuDnsDriver(x, y, x.copy(), nscal=nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * nscal, yuniform=True, hyper_bc1_ext=0.0)
+        for i in range(3):
+            c.q[i][:] = rng.uniform(-1, 1, n ** 3) * 0.1
+        for i in range(nscal):
+            c.s[i][:] = rng.uniform(-1, 1, n ** 3)
+        c.time_substep(1e-3, 1.0, False)
+        c.time_substep(1e-3, 1.0, False)
+        q_ready.put(idx)
+        ev_go.wait()
+        t0 = time.time()
+        for _ in range(nsub):
+            c.time_substep(1e-3, 1.0, False)
+        q_out.put((idx, t0, time.time(), None))
+    except Exception as e:      # noqa: BLE001
+        q_ready.put(idx)
+        q_out.put((idx, 0.0, 0.0, repr(e)))
+
+
+def cpu_baseline_instances(n, nscal, threads, nsub=6):
+    """The host the way the reference uses it: the reference's production mode is one MPI rank per core, each rank on its own part of the problem,
+    so a many-socket host is timed as P independent instances of the port (threads cores each, pinned to disjoint contiguous core ranges, NUMA-local
+    by first touch), all stepping an n^3 box at the same time; value = P x n^3 x substeps / wall time.  An upper bound of what a decomposed CPU run
+    of the same box reaches on these cores (no exchange between the instances is counted)."""
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except Exception:      # noqa: BLE001
+        avail = list(range(ncpu))
+    phys = avail[: max(1, len(avail) // 2)] if len(avail) >= 64 else avail      # first half: one hardware thread per core on an SMT-2 host
+    P = max(1, min(len(phys) // threads, 16))
+    if P < 2:
+        return None
+    try:
+        import psutil
+        if psutil.virtual_memory().available < P * 40 * 8 * n ** 3:
+            return None
+    except Exception:      # noqa: BLE001
+        pass
+    ctx = mp.get_context("spawn")
+    q_ready, q_out, ev_go = ctx.Queue(), ctx.Queue(), ctx.Event()
+    procs = [ctx.Process(target=_cpu_instance_worker, args=(i, set(phys[i * threads:(i + 1) * threads]), threads, n, nscal, nsub, q_ready, ev_go, q_out))
+             for i in range(P)]
+    t_launch = time.time()
+    for p in procs:
+        p.start()
+    for _ in range(P):
+        q_ready.get(timeout=600)
+    t_init = time.time() - t_launch
+    ev_go.set()
+    res = [q_out.get(timeout=600) for _ in range(P)]
+    for p in procs:
+        p.join(timeout=60)
+    bad = [r for r in res if r[3]]
+    if bad:
+        return {"error": bad[0][3]}
+    wall = max(r[2] for r in res) - min(r[1] for r in res)
+    model = ""
+    try:
+        from oracle import tlab_cpu as C
+        model, _ = C.host_description()
+    except Exception:      # noqa: BLE001
+        pass
+    return {"value": P * nsub * n ** 3 / wall, "unit": "grid-point-updates/s per RK substep", "cores": P * threads, "kind": "port", "cpu_model": model,
+            "host_cpus": ncpu, "instances": P, "threads_per_instance": threads, "seconds_per_substep_per_instance": wall / nsub,
+            "sample": "%d independent instances of the C/OpenMP restatement of the reference's CPU path (oracle/tlab_cpu.c), %d threads each on disjoint "
+                      "pinned core ranges (%d of the %d logical CPUs of '%s'), every instance stepping its own %d^3 box, %d scalar(s): %d substeps each in "
+                      "%.1f s of wall time after %.1f s of start-up; aggregate = instances x points x substeps / wall time (the reference's rank-per-core "
+                      "mode without its exchanges: an upper bound for a decomposed CPU run of one box)" % (P, threads, P * threads, ncpu, model, n, nscal, nsub, wall, t_init)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,6 +494,17 @@ def main():
             torch.cuda.empty_cache()
         if args.cpu_sample > 0 and world == 1 and args.loopback <= 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.nscal)
+            # ... and the host used the way the reference uses it (one rank per core): independent instances on disjoint core ranges.  The larger of
+            # the two is `cpu_baseline`; the other one stays in the record.
+            try:
+                multi = cpu_baseline_instances(args.cpu_sample, args.nscal, int(out["cpu_baseline"].get("cores", 16)))
+            except Exception as e:       # noqa: BLE001
+                multi = {"error": repr(e)}
+            if multi and "value" in multi and multi["value"] > out["cpu_baseline"]["value"]:
+                out["cpu_baseline_single_instance"] = out["cpu_baseline"]
+                out["cpu_baseline"] = multi
+            elif multi:
+                out["cpu_baseline_instances"] = multi
             if args.cpu_sample_large > args.cpu_sample and (os.cpu_count() or 1) >= args.cpu_large_min_cores:
                 # the benchmark's own size on the host cores, when the host is big enough to finish it in about a minute
                 out["cpu_baseline_large"] = cpu_baseline(args.cpu_sample_large, args.nscal)

@@ -39,11 +39,17 @@ subroutine ref_init(nx, ny, nz) bind(C, name='ref_init')
     use TLab_Constants, only: wp, wi
     use TLab_Arrays, only: wrk1d, wrk2d, wrk3d
     use TLab_OpenMP, only: TLab_OMP_numThreads
+#ifdef USE_OPENMP
+    use OMP_LIB
+#endif
     implicit none
     integer(c_int), value :: nx, ny, nz
     integer(wi) n2d, n1d
 
     TLab_OMP_numThreads = 1
+#ifdef USE_OPENMP
+    TLab_OMP_numThreads = omp_get_max_threads()      ! what TLab_Start does (base/tlab_workflow.f90:90); the timing build of `make -C oracle omp` only
+#endif
     if (allocated(wrk1d)) deallocate (wrk1d)
     if (allocated(wrk2d)) deallocate (wrk2d)
     if (allocated(wrk3d)) deallocate (wrk3d)
