@@ -83,7 +83,8 @@ def cpu_baseline(n, nscal, budget_s=25.0):
     # a many-socket host (transposes, NUMA), so the best of a few counts is what gets reported
     L = C.load()
     tmax = L.tlabcpu_num_threads()
-    cand = sorted({t for t in (8, 16, 32, 64, 128, 256, tmax) if t <= tmax})
+    quota = cpu_quota()[0]
+    cand = sorted({t for t in (8, 16, 32, 64, 128, 256, tmax, quota) if t <= tmax and t <= 2 * quota})      # beyond the granted CPUs threads only queue up
     best, trials = None, {}
     for t in cand:
         L.tlabcpu_set_num_threads(t)
@@ -103,8 +104,33 @@ def cpu_baseline(n, nscal, budget_s=25.0):
     threads = best
     return {"value": nsub * n ** 3 / dt, "unit": "grid-point-updates/s per RK substep", "cores": threads, "kind": "port",
             "cpu_model": model, "host_cpus": ncpu, "seconds_per_substep_by_threads": {str(k): round(v, 3) for k, v in trials.items()},
+            "cpu_quota": cpu_quota()[0], "cpu_quota_source": cpu_quota()[1],
             "sample": "%d RK substeps of the C/OpenMP restatement of the reference's CPU path (oracle/tlab_cpu.c) on a %d^3 box, %d scalar(s), "
-                      "%d threads on '%s' (%d logical CPUs), %.1f s timed after %.1f s of plan construction" % (nsub, n, nscal, threads, model, ncpu, dt, t_init)}
+                      "%d threads on '%s' (%d logical CPUs visible, %d granted to this job: %s), %.1f s timed after %.1f s of plan construction"
+                      % (nsub, n, nscal, threads, model, ncpu, cpu_quota()[0], cpu_quota()[1], dt, t_init)}
+
+
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup's CPU bandwidth quota (cpu.max = quota period; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us) if
+    there is one, else the affinity mask.  On the GPU boxes of this pool 256 logical CPUs are visible and 16 are granted."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:      # noqa: BLE001
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return min(n, max(1, int(round(int(q) / int(per))))), "cgroup cpu.max = %s %s" % (q, per)
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return min(n, max(1, int(round(q / per)))), "cgroup cpu.cfs_quota_us / cpu.cfs_period_us = %d / %d" % (q, per)
+    except Exception:      # noqa: BLE001
+        pass
+    return n, "no CPU quota (affinity mask)"
 
 
 def _cpu_instance_worker(idx, cores, threads, n, nscal, nsub, q_ready, ev_go, q_out):
@@ -151,7 +177,7 @@ def cpu_baseline_instances(n, nscal, threads, nsub=6):
     except Exception:      # noqa: BLE001
         avail = list(range(ncpu))
     phys = avail[: max(1, len(avail) // 2)] if len(avail) >= 64 else avail      # first half: one hardware thread per core on an SMT-2 host
-    P = max(1, min(len(phys) // threads, 16))
+    P = max(1, min(len(phys) // threads, cpu_quota()[0] // threads, 16))
     if P < 2:
         return None
     try:
@@ -288,7 +314,14 @@ def main():
         from tlab_amd.parallel import SlabDns, LoopbackComm
         from tlab_amd.slab import NativeSlabDns
         kw = dict(nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
-        d = NativeSlabDns("loopback", x, y, z, size=args.loopback, **kw) if args.slab_driver == "native" else SlabDns(LoopbackComm(args.loopback), x, y, z, **kw)
+        if args.slab_driver == "native":
+            try:
+                d = NativeSlabDns("loopback", x, y, z, size=args.loopback, **kw)
+            except T.TlabError as e:       # slabs too thin for the partitioned z-systems: the reference's K-transposition scheme (Python driver)
+                print("bench.py: native slab driver refused (%s); falling back to the transposition scheme of tlab_amd/parallel.py" % e, file=sys.stderr)
+                args.slab_driver = "python"
+        if args.slab_driver != "native":
+            d = SlabDns(LoopbackComm(args.loopback), x, y, z, **kw)
         state_fields = []
         for r in range(args.loopback):
             S = d.st[r]
@@ -318,6 +351,11 @@ def main():
         from tlab_amd.parallel import SlabDns, DistComm
         from tlab_amd.slab import NativeSlabDns
         kw = dict(nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
+        if args.slab_driver == "native" and nz // world < 56:      # decided from the sizes alone, so that every rank takes the same branch
+            if rank == 0:
+                print("bench.py: %d planes per rank are too few for the partitioned z-systems of the native slab driver; using the K-transposition "
+                      "scheme of tlab_amd/parallel.py" % (nz // world), file=sys.stderr)
+            args.slab_driver = "python"
         d = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, **kw) if args.slab_driver == "native" else SlabDns(DistComm(), x, y, z, **kw)
         S = d.st[rank]
         synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
@@ -496,8 +534,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.nscal)
             # ... and the host used the way the reference uses it (one rank per core): independent instances on disjoint core ranges.  The larger of
             # the two is `cpu_baseline`; the other one stays in the record.
-            try:
-                multi = cpu_baseline_instances(args.cpu_sample, args.nscal, int(out["cpu_baseline"].get("cores", 16)))
+            multi = None
+            try:      # only where the job is granted more CPUs than one instance uses (on this pool it is not: 16 granted, 16 used)
+                if cpu_quota()[0] >= 2 * int(out["cpu_baseline"].get("cores", 16)):
+                    multi = cpu_baseline_instances(args.cpu_sample, args.nscal, int(out["cpu_baseline"].get("cores", 16)))
             except Exception as e:       # noqa: BLE001
                 multi = {"error": repr(e)}
             if multi and "value" in multi and multi["value"] > out["cpu_baseline"]["value"]:

@@ -72,6 +72,7 @@ struct Int1Args {
     // (its per-call solves: the chain of dependent divisions is what a handful of marching threads spends its time on)
     double *fac_out;
     const double *fac;
+    int fpart;              // SPLIT launches of k_int1 (one line per thread): which component of the complex FS_FIELD source this thread takes
     // 3- / 7-diagonal integral systems (int1_generic.cpp): everything factorized on the host, per mode -- g_fac [ndi][n][nm] (rows 2..n-1: the factors
     // of TRIDFS / HEPTADFS; rows 1, n: the reduced boundary rows), g_rb / g_rt [40][nm] (rhs_b(1:5, 0:7), rhs_t(0:4, 1:8)), g_R [n][nri].  g_fac != NULL
     // sends launch_int1 to k_int1g.
@@ -112,6 +113,10 @@ __device__ __forceinline__ void lhs_row_t(const TT &T, int j, double lam, double
 template <int NL, int FS>
 __device__ __forceinline__ void load_f(const Int1Args &a, int j, long long t, long long fidx0, double (&f)[NL]) {
     if (FS == FS_FIELD) {
+        if (NL == 1 && a.fpart) {       // (SPLIT launch: the imaginary part alone)
+            f[0] = reinterpret_cast<const double *>(a.fsrc)[2 * (fidx0 + (long long)j * a.nxh) + 1] * a.fscale;
+            return;
+        }
         const double2 v = reinterpret_cast<const double2 *>(a.fsrc)[fidx0 + (long long)j * a.nxh];
         f[0] = v.x * a.fscale;
         if (NL > 1) f[1] = v.y * a.fscale;
@@ -125,13 +130,27 @@ __device__ __forceinline__ void load_f(const Int1Args &a, int j, long long t, lo
 }
 
 // One FDM_Int1_Solve per thread (mode).  BC = 1: value given at the bottom (BCS_MIN), BC = 2: at the top (BCS_MAX).
-template <int BC, int NL, int FS, int U, bool STORED>
+// SPLIT (with NL = 1): the two lines of a mode (real and imaginary part) on two threads, thread gid -> (mode gid % nm, line gid / nm).  The few
+// modes of the low-mode sub-plan are a latency chain of n dependent rows bound by the instructions per row: half of them per thread.
+template <int BC, int NL, int FS, int U, bool STORED, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma clang fp contract(off)
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.nm) return;
+    static_assert(!SPLIT || (NL == 1 && STORED), "SPLIT: one line per thread, stored factors");
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (SPLIT ? 2 : 1) * a.nm) return;
+    const long long t = SPLIT ? gid % a.nm : gid;
+    const int part = SPLIT ? (int)(gid / a.nm) : 0;
     const int n = a.T.n;
     const long long nm = a.nm;
+    if (SPLIT && part) {      // line 1 of every array becomes this thread's line 0
+        a.scratch += (long long)n * nm;
+        a.dst += (long long)n * nm;
+        if (a.du) a.du += nm;
+        if (a.bv_ptr) a.bv_ptr += nm;
+        a.bv[0] = a.bv[1];
+        if (FS == FS_LINEAR) { a.fsrc += (long long)n * nm; a.nlf -= 1; }
+        a.fpart = 1;
+    }
     const double lam = a.lam_sign * a.lam[t];
     const long long fidx0 = (FS == FS_FIELD) ? (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh) : 0;
 
@@ -186,8 +205,13 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     load_f<NL, FS>(a, 0, t, fidx0, fb0);
     load_f<NL, FS>(a, n - 1, t, fidx0, fbN);
     if (FS == FS_FIELD && a.bcs_save != nullptr) {  // Neumann data travel in the forcing planes (opr_elliptic.f90:285-286,310-311)
-        a.bcs_save[0 * nm + t] = fb0[0]; a.bcs_save[1 * nm + t] = fb0[NL > 1 ? 1 : 0];
-        a.bcs_save[2 * nm + t] = fbN[0]; a.bcs_save[3 * nm + t] = fbN[NL > 1 ? 1 : 0];
+        if (SPLIT) {
+            a.bcs_save[(long long)part * nm + t] = fb0[0];
+            a.bcs_save[(long long)(2 + part) * nm + t] = fbN[0];
+        } else {
+            a.bcs_save[0 * nm + t] = fb0[0]; a.bcs_save[1 * nm + t] = fb0[NL > 1 ? 1 : 0];
+            a.bcs_save[2 * nm + t] = fbN[0]; a.bcs_save[3 * nm + t] = fbN[NL > 1 ? 1 : 0];
+        }
     }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -2103,6 +2127,8 @@ void launch_int1(const Int1Args &a, hipStream_t st) {
     if (a.g_fac) {
         if (a.g_ndi == 3) hipLaunchKernelGGL((k_int1g<BC, NL, FS, 3>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_int1g<BC, NL, FS, 7>), dim3(grid), dim3(256), 0, st, a);
+    } else if (a.fac && NL == 2 && a.nm <= 2048) {      // the low-mode sub-plan: one line per thread
+        hipLaunchKernelGGL((k_int1<BC, 1, FS, 8, true, true>), dim3((unsigned)((2 * a.nm + 127) / 128)), dim3(128), 0, st, a);
     } else if (a.fac) {
         if (a.nm < 65536) hipLaunchKernelGGL((k_int1<BC, NL, FS, 8, true>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_int1<BC, NL, FS, 2, true>), dim3(grid), dim3(256), 0, st, a);
