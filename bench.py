@@ -504,7 +504,7 @@ def main():
         if single and args.walls == "noslip" and not args.no_freeslip_leg:
             # the same workload with the reference's DEFAULT walls (VelocityJmin/Jmax = freeslip, Neumann scalars: BOUNDARY_BCS_NEUMANN_Y in the tail
             # of the substep), timed the same way right after the headline: the headline keeps no-slip / Dirichlet walls, this key says what the default costs
-            del d
+            d = None
             torch.cuda.empty_cache()
             d2 = Dns(x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=not args.ystretch, rkm_mode=RKM_EXP3,
                      hyper_bc1_ext=HYPER_BC1_EXT)
@@ -549,6 +549,13 @@ def main():
                 # the benchmark's own size on the host cores, when the host is big enough to finish it in about a minute
                 out["cpu_baseline_large"] = cpu_baseline(args.cpu_sample_large, args.nscal)
         print(json.dumps(out))
+    # the native slab driver owns an RCCL communicator of its own: release it while every rank is still here, not during interpreter teardown
+    try:
+        if hasattr(d, "close"):
+            torch.cuda.synchronize()
+            d.close()
+    except Exception as e:       # noqa: BLE001  (the measurement is already printed)
+        print("bench.py: closing the slab driver: %r" % (e,), file=sys.stderr)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

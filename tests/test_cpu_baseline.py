@@ -1,6 +1,13 @@
 """CPU tests of oracle/tlab_cpu.c, the C + OpenMP restatement that bench.py times as `cpu_baseline`: against the golden vectors generated from
 the reference's own Fortran (tests/golden/) and against the numpy oracle, <= 1e-14 (the two differ at most by the last bit of a different
-summation order inside the FFTs; everything else is the same operation sequence)."""
+summation order inside the FFTs; everything else is the same operation sequence).
+
+SECOND CHECKER of the transcribed routines.  OPR_Burgers_* (physics/opr_burgers.f90), OPR_Poisson_FourierXZ_Factorize (operators/opr_elliptic.f90)
+and the RHS cannot be compiled from the reference in this image (opr_fourier.f90 needs fftw3.f03), so the numpy oracle's versions of them are pinned
+through their compiled parts plus a reading of their data flow (oracle/ref_driver*.f90).  tlab_cpu.c is an independent second reading of the same
+Fortran -- another language, its own transposes, sweeps, Stockham FFT and per-mode loop -- so test_operators_match_golden (OPR_Burgers against the
+fixtures the reference's own solvers made), test_poisson_matches_numpy_oracle and test_substeps_match_numpy_oracle below check one transcription
+against the other: a misreading of opr_burgers.f90 / opr_elliptic.f90 / rhs_global_incompressible_1.f90 would have to be made twice to pass."""
 import os
 
 import numpy as np
