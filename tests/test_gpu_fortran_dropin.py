@@ -189,6 +189,64 @@ def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused):
     assert 0.0 < d <= 1e-10, d
 
 
+def test_case01_own_tlab_ini_through_the_fortran_driver(tmp_path):
+    """BASELINE configs[0] = examples/Case01 on ITS OWN tlab.ini (tests/golden/case01/tlab.ini: the example's input file as the reference ships it,
+    a data fixture; only `End=10` is shortened to 2 iterations): 512 x 256 x 1, SpaceOrder = CompactJacobian6 (the backwards-compatible key, read by
+    the reference's own FDM_Initialize), TimeOrder = RungeKuttaExplicit4, TimeCFL = 1.2 with TimeStep < 0 (the step comes from TIME_COURANT every
+    iteration), free-slip walls, Neumann scalar -- all read by the Fortran mini-driver through the reference's key names.  The case's initial fields come
+    from the reference's initialisation tools (out of scope), so synthetic shear-layer fields of the case's shape are written in the reference's restart
+    format.  Against the oracle stepping the same way (time_courant + 5 RK4 substeps per iteration)."""
+    import numpy as np
+    from conftest import rel_err
+    from tlab_amd import io as tio
+    from tlab_amd.dns import rk_coefficients, RKM_EXP4, velocity_bcs
+    from oracle.tlab_oracle_rhs import DnsOracle
+    _need_rk()
+    ini = open(os.path.join(ROOT, "tests", "golden", "case01", "tlab.ini")).read()
+    assert "Imax=512" in ini and "TimeOrder=RungeKuttaExplicit4" in ini and "TimeCFL=1.20000" in ini and "VelocityJmin=freeslip" in ini
+    iters = 2
+    ini = ini.replace("End=10", "End=%d" % iters)
+    nx, ny, nz = 512, 256, 1
+    x = np.arange(nx) / nx * 2.0                 # [IniGridOx]: 513 points on 2.0, periodic -> 512 nodes
+    y = np.arange(ny) / (ny - 1.0)               # [IniGridOy]: 256 points on 1.0
+    z = np.zeros(1)
+    rng = np.random.default_rng(101)
+    Y, X = np.meshgrid(y, x, indexing="ij")
+    thick = 0.005859375 * 8
+    u0 = 0.5 * np.tanh((Y - 0.5) / (2 * thick)) + 0.02 * rng.uniform(-1, 1, X.shape) * np.exp(-((Y - 0.5) / 0.1) ** 2)
+    v0 = 0.02 * rng.uniform(-1, 1, X.shape) * np.exp(-((Y - 0.5) / 0.1) ** 2) * np.sin(np.pi * Y)
+    s0 = 0.5 - 0.5 * np.tanh((Y - 0.5) / (2 * thick))
+    q0, sc0 = [u0.ravel(), v0.ravel(), np.zeros(nx * ny)], [s0.ravel()]
+    tmp = str(tmp_path)
+    open(os.path.join(tmp, "tlab.ini"), "w").write(ini)
+    tio.grid_write(os.path.join(tmp, "grid"), x, y, z, scales=[2.0, 1.0, 1.0])
+    tio.io_write_fields(os.path.join(tmp, "flow.0"), nx, ny, nz, 0, q0, params=(0.0, 1.0 / 5000.0))
+    tio.io_write_fields(os.path.join(tmp, "scal.0"), nx, ny, nz, 0, sc0, params=(0.0,))
+    r = subprocess.run([RK_EXE], cwd=tmp, capture_output=True, text=True, timeout=600)
+    log = "".join(open(os.path.join(tmp, f)).read()[-3000:] for f in ("tlab.err", "tlab.log") if os.path.exists(os.path.join(tmp, f)))
+    assert r.returncode == 0 and not os.path.exists(os.path.join(tmp, "tlab.err")), r.stdout + r.stderr + log
+    q1, _, _ = tio.io_read_fields(os.path.join(tmp, "flow.%d" % iters), nx, ny, nz, 3)
+    s1, _, _ = tio.io_read_fields(os.path.join(tmp, "scal.%d" % iters), nx, ny, nz, 1)
+    o = DnsOracle(x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True)
+    o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin = o.scal_jmax = [4]
+    for i in range(3):
+        o.q[i] = q0[i].copy()
+    o.s[0] = sc0[0].copy()
+    kdt, kco = rk_coefficients(RKM_EXP4)
+    steps = []
+    for it in range(iters):
+        _, dt = o.time_courant(1.2, 0.3)         # TimeDiffusiveCFL defaults to 0.25 TimeCFL (dns_read_local.f90:72-73)
+        steps.append(dt)
+        o.hq = [np.zeros_like(a) for a in o.hq]; o.hs = [np.zeros_like(a) for a in o.hs]
+        for k in range(5):
+            o.time_substep(dt * kdt[k], 1.0 if k == 4 else kco[k], k < 4)
+    logged = [float(line.split("=")[1]) for line in log.splitlines() if "TIME_COURANT: dtime" in line]
+    assert len(logged) == iters and all(abs(a - b) <= 1e-13 * b for a, b in zip(logged, steps)), (logged, steps)
+    for i in range(2):
+        assert rel_err(q1[i], o.q[i]) <= 1e-12, ("q", i, rel_err(q1[i], o.q[i]))
+    assert np.abs(q1[2]).max() == 0.0 and rel_err(s1[0], o.s[0]) <= 1e-12
+
+
 def test_fortran_rk_driver_direct_schemes_from_the_ini_file(tmp_path):
     """[Main] SpaceOrder2 = CompactDirect6, EllipticOrder = CompactDirect6 (the scheme set of examples/Case81-93) read by the reference's own
     FDM_Initialize and by the drop-in OPR_Elliptic_Initialize(inifile), which builds fdm_loc with the reference's FDM_CreatePlan

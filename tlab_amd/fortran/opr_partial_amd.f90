@@ -44,6 +44,15 @@ contains
         type(fdm_dt), intent(in), target :: g
         type(c_ptr) :: p, pm1, pm2
         integer(c_int) rc
+        real(c_double) :: one_node(1)
+        if (.not. c_associated(plans(idir)) .and. g%size == 1) then
+            ! a direction of one point (the z direction of a 2-D case, examples/Case01): FDM_CreatePlan leaves no tables (fdm.f90:185-189) and
+            ! the operators return zeros (opr_partial.f90:175-177) -- the library's own one-point plan does the same
+            one_node = 0.0_c_double
+            rc = tlab_fdm_plan_create(plans(idir), 1_c_int, one_node, merge(1_c_int, 0_c_int, g%periodic), 1_c_int, &
+                                      int(g%der1%mode_fdm, c_int), int(g%der2%mode_fdm, c_int), 0.0_c_double)
+            call TLab_AMD_Check(rc, 'tlab_fdm_plan_create')
+        end if
         if (.not. c_associated(plans(idir))) then
             rc = tlab_fdm_plan_create_from_arrays(plans(idir), int(g%size, c_int), merge(1_c_int, 0_c_int, g%periodic), &
                                                   merge(1_c_int, 0_c_int, g%der2%need_1der), &

@@ -200,10 +200,10 @@ program test_rk_driver
     use BOUNDARY_BCS
     use DNS_ARRAYS
     use TIME
-    use TLab_AMD_DNS, only: TLab_AMD_DNS_Finalize
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Finalize, TLab_AMD_DNS_Handle
     use TLabMPI_VARS
     use TLabMPI_Transpose
-    use TLab_AMD_C, only: tlab_sync, tlab_memcpy_d2h, TLab_AMD_Check
+    use TLab_AMD_C, only: tlab_sync, tlab_memcpy_d2h, TLab_AMD_Check, tlab_time_courant
     use, intrinsic :: iso_c_binding
     implicit none
 
@@ -221,7 +221,10 @@ program test_rk_driver
     character(len=32) fname, bakfile
     character(len=512) sRes
     integer(wi) nitera_first, nitera_last, itime
-    real(wp) params(2), reynolds
+    real(wp) params(2), reynolds, cfla, cfld
+    real(c_double) pmax(2), dt_c
+    type(c_ptr) pq(3)
+    logical step_from_cfl
 
     ! ###################################################################
     call TLab_Start()                                                          ! dns_main.f90:62
@@ -251,12 +254,26 @@ program test_rk_driver
     schmidt = 1.0_wp
     call ScanFile_Real(bakfile, ifile, 'Parameters', 'Schmidt', '1.0', schmidt(1))
 
-    call ScanFile_Char(bakfile, ifile, 'Time', 'Scheme', 'RungeKuttaExplicit3', sRes)    ! DNS_READ_LOCAL, dns_read_local.f90:100-116
+    ! Time marching: the reference's keys ([Main] TimeOrder, TimeStep, TimeCFL: dns_read_local.f90:100-141; [Iteration] Start, End: :170-175), so that
+    ! an example's own tlab.ini runs as it is (examples/Case01); the [Time] block of the earlier fixtures of this driver is still read first
+    call ScanFile_Char(bakfile, ifile, 'Time', 'Scheme', 'void', sRes)
+    if (trim(adjustl(sRes)) == 'void') call ScanFile_Char(bakfile, ifile, 'Main', 'TimeOrder', 'RungeKuttaExplicit3', sRes)
     if (trim(adjustl(sRes)) == 'rungekuttaexplicit4') then; rkm_mode = RKM_EXP4
     else; rkm_mode = RKM_EXP3; end if
-    call ScanFile_Real(bakfile, ifile, 'Time', 'TimeStep', '0.001', dtime)
-    call ScanFile_Int(bakfile, ifile, 'Time', 'Start', '0', nitera_first)
-    call ScanFile_Int(bakfile, ifile, 'Time', 'End', '1', nitera_last)
+    call ScanFile_Real(bakfile, ifile, 'Time', 'TimeStep', '0.0', dtime)
+    if (dtime /= 0.0_wp) then                   ! the earlier fixtures of this driver: a fixed step
+        cfla = -1.0_wp; cfld = -1.0_wp
+    else                                        ! dns_read_local.f90:60-76: the CFL numbers rule whenever TimeCFL > 0, TimeStep otherwise
+        if (rkm_mode == RKM_EXP4) then; sRes = '1.2'; else; sRes = '0.6'; end if
+        call ScanFile_Real(bakfile, ifile, 'Main', 'TimeCFL', trim(adjustl(sRes)), cfla)
+        write (sRes, *) 0.25_wp*cfla
+        call ScanFile_Real(bakfile, ifile, 'Main', 'TimeDiffusiveCFL', trim(adjustl(sRes)), cfld)
+        call ScanFile_Real(bakfile, ifile, 'Main', 'TimeStep', '0.05', dtime)
+    end if
+    call ScanFile_Int(bakfile, ifile, 'Time', 'Start', '-1', nitera_first)
+    if (nitera_first < 0) call ScanFile_Int(bakfile, ifile, 'Iteration', 'Start', '0', nitera_first)
+    call ScanFile_Int(bakfile, ifile, 'Time', 'End', '-1', nitera_last)
+    if (nitera_last < 0) call ScanFile_Int(bakfile, ifile, 'Iteration', 'End', '1', nitera_last)
     call BOUNDARY_BCS_SCAL_READBLOCK(bakfile, ifile, 'Jmin', BcsScalJmin)      ! dns_read_local.f90:242-243, :257-258
     call BOUNDARY_BCS_SCAL_READBLOCK(bakfile, ifile, 'Jmax', BcsScalJmax)
     call BOUNDARY_BCS_FLOW_READBLOCK(bakfile, ifile, 'Jmin', BcsFlowJmin)
@@ -321,7 +338,15 @@ program test_rk_driver
     ! ###################################################################
     ! Do simulation: Integrate equations
     ! ###################################################################
+    step_from_cfl = cfla > 0.0_wp               ! time.f90:530: the step follows the Courant numbers whenever TimeCFL > 0
     do while (itime < nitera_last)                                             ! :246-250
+        if (step_from_cfl) then                                                ! TIME_COURANT() at the start of the iteration (dns_main.f90:243, time.f90:365-548)
+            pq = [c_loc(q(1, 1)), c_loc(q(1, 2)), c_loc(q(1, 3))]
+            call TLab_AMD_Check(tlab_time_courant(TLab_AMD_DNS_Handle(), pq, real(cfla, c_double), real(cfld, c_double), pmax, dt_c), 'tlab_time_courant')
+            dtime = dt_c
+            write (line, '(a,es23.16)') 'TIME_COURANT: dtime = ', dtime
+            call TLab_Write_ASCII(lfile, line)
+        end if
         call TIME_RUNGEKUTTA()
         itime = itime + 1
         rtime = rtime + dtime

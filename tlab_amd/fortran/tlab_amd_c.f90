@@ -20,6 +20,13 @@ module TLab_AMD_C
         integer(c_int) function tlab_finalize() bind(C, name='tlab_finalize')
             import :: c_int
         end function
+        integer(c_int) function tlab_fdm_plan_create(plan, n, nodes, periodic, uniform, scheme1, scheme2, hyper_bc1_ext) bind(C, name='tlab_fdm_plan_create')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), intent(out) :: plan
+            integer(c_int), value :: n, periodic, uniform, scheme1, scheme2
+            real(c_double), intent(in) :: nodes(*)
+            real(c_double), value :: hyper_bc1_ext
+        end function
         integer(c_int) function tlab_device_count() bind(C, name='tlab_device_count')
             import :: c_int
         end function
