@@ -251,6 +251,14 @@ int tlab_poisson_set_wall_planes(tlab_poisson_plan_t plan, double *p, const doub
  * the library's one-pass kernel where its lengths apply (nx/2 = 8^a * {1,2,4}, 128 <= nx <= 2048), rocFFT otherwise; the backward one is rocFFT's.
  * dir = -2: the library's own inverse kernel (the one that finishes the v equation inside tlab_opr_poisson when the RHS driver asks for it), for tests. */
 int tlab_poisson_fft_x(tlab_poisson_plan_t plan, int dir, double *in, double *out);
+/* The same transforms with the complex side directly in the pack layout of tlab_pencil_repack_blocks (same nblocks / start / base), i.e. the
+ * repack pass folded into the library's own x-transform kernels: dir = +1 real in -> pack buffer out, dir = -1 pack buffer in -> real out.
+ * _final: the inverse of dp^/dy finishes the v equation in its epilogue (h = h - dp/dy, wall planes of h zeroed, q += dte h, h *= kco when
+ * scale; rhs_global_incompressible_1.f90:236-241,258-261 + time.f90 RK update) instead of writing dp/dy.  TLAB_EUNSUPPORTED where the own
+ * kernels do not apply (see above); the inverse differs from rocFFT's by rounding.  Used by the native slab driver (tlab_slab_dns_*). */
+int tlab_poisson_fft_x_packed(tlab_poisson_plan_t plan, int dir, double *in, double *out, int nblocks, const int *start, const long long *base);
+int tlab_poisson_fft_x_packed_final(tlab_poisson_plan_t plan, double *in, double *q, double *h, double dte, double kco, int scale, int nblocks,
+                                    const int *start, const long long *base);
 int tlab_poisson_fft_z(tlab_poisson_plan_t plan, int dir, double *in, double *out);   /* the FFT inside OPR_Fourier_Z_*, :355,422 */
 int tlab_poisson_ode(tlab_poisson_plan_t plan, double *f_hat, double *p_hat, double *dp_hat); /* mode loop of opr_elliptic.f90:308-333 */
 
@@ -422,7 +430,9 @@ int tlab_slab_dns_destroy(tlab_slab_dns_t d);
  * (the columns of a Fortran host's q(isize_field, 3) lie back to back: there is no room around a field).  The pointers are kept: call again if
  * the host moves its arrays. */
 int tlab_slab_dns_bind(tlab_slab_dns_t d, int l, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc);
-/* what: 0 kmax, 1 nranks, 2 nlocal, 3 doubles of one halo (3 planes), 4 pipeline stages of the pencil exchange, 5 first local rank */
+/* what: 0 kmax, 1 nranks, 2 nlocal, 3 doubles of one halo (3 planes), 4 pipeline stages of the pencil exchange, 5 first local rank,
+ * 6 whether the repack passes are folded into the x-transforms (default where the library's own x kernels apply; TLAB_SLAB_FUSED_X=0 at creation
+ * keeps the separate passes and rocFFT's inverse, whose results equal the Python driver's to the bit) */
 long long tlab_slab_dns_info(tlab_slab_dns_t d, int what);
 int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d);                 /* as tlab_dns_begin_step */

@@ -26,21 +26,23 @@ def test_multiprocess_slabs(world, zmode, nz, bcs):
     assert "DIST_CHECK" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("world,nz,bcs", [(2, 128, "noslip"), (3, 192, "freeslip")])
-def test_multiprocess_native_slab_driver(world, nz, bcs):
+@pytest.mark.parametrize("world,nz,bcs,nx", [(2, 128, "noslip", 32), (3, 192, "freeslip", 48), (2, 128, "noslip", 128), (3, 192, "freeslip", 128)])
+def test_multiprocess_native_slab_driver(world, nz, bcs, nx):
     """The C++ slab driver (tlab_slab_dns_*), one rank per PROCESS, with the five transport entry points supplied by the caller (ctypes callbacks over
     gloo with host-staged payloads, tlab_amd/slab.py::dist_transport): rank-local plans, ring pairing with 2 and 3 ranks, uneven kx-pencils in two
-    halves, monitors -- against the single-domain step each rank computes redundantly."""
+    halves, monitors -- against the single-domain step each rank computes redundantly.  nx = 128: the repack passes are folded into the
+    library's own x-transforms and (no-slip) v is finished by the inverse transform of dp^/dy."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, TLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29570 + world), os.path.join(ROOT, "tools", "dist_check.py"), "--driver", "native", "--nz", str(nz), "--bcs", bcs,
-           "--nx", "32" if world != 3 else "48"]
+           "--master-port", str(29570 + world + (10 if nx == 128 else 0)), os.path.join(ROOT, "tools", "dist_check.py"), "--driver", "native",
+           "--nz", str(nz), "--bcs", bcs, "--nx", str(nx)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "DIST_CHECK driver=native" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
+    assert ("fused_x=1" if nx == 128 else "fused_x=0") in out.stdout, out.stdout[-2000:]
 
 
 def test_native_slab_driver_over_rccl_world_size_one():

@@ -47,8 +47,8 @@ def test_native_driver_is_bit_identical_to_the_python_driver(T, P, nx, ny, nz, b
     f = _fields(x, y, z, P + ns)
     kw = dict(nscal=ns, visc=1.0 / 600.0, schmidt=(0.8, 1.3)[:ns], yuniform=False, hyper_bc1_ext=REF_HYPER)
     py = SlabDns(LoopbackComm(P), x, y, z, zmode="halo", **kw)
-    nat = NativeSlabDns("loopback", x, y, z, size=P, **kw)
-    assert py.stages == nat.stages == int(stages) and nat.kmax == py.kmax
+    nat = NativeSlabDns("loopback", x, y, z, size=P, fused_x=False, **kw)     # separate repack passes + rocFFT's inverse, like the Python driver
+    assert py.stages == nat.stages == int(stages) and nat.kmax == py.kmax and not nat.fused_x
     walls = {"noslip": (), "freeslip": ("freeslip", "freeslip", "neumann", "dirichlet"), "neumann-scalars": ("noslip", "freeslip", "neumann", "neumann")}[bcs]
     if walls:
         py.set_bcs(*walls); nat.set_bcs(*walls)
@@ -77,19 +77,24 @@ def test_native_driver_is_bit_identical_to_the_python_driver(T, P, nx, ny, nz, b
     assert py.dilatation_bounds() == nat.dilatation_bounds()
 
 
-def test_native_driver_equals_single_domain_and_oracle(T):
+@pytest.mark.parametrize("bcs,fused,stages", [("freeslip", True, "2"), ("noslip", True, "2"), ("noslip", True, "1"), ("noslip", False, "2")])
+def test_native_driver_equals_single_domain_and_oracle(T, bcs, fused, stages, monkeypatch):
+    """fused: the repack passes folded into the own x-transforms, v finished by the inverse transform of dp^/dy (no-slip walls)."""
     import torch
+    monkeypatch.setenv("TLAB_PENCIL_STAGES", stages)
     from tlab_amd.dns import Dns, velocity_bcs
     from tlab_amd.slab import NativeSlabDns
     from oracle.tlab_oracle_rhs import DnsOracle
-    P, nx, ny, nz = 4, 64, 24, 256
+    P, nx, ny, nz = 4, 128, 24, 256          # nx >= 128: the library's own x-transforms apply
     x, y, z = _grid(nx, ny, nz)
     f = _fields(x, y, z, 11)
     visc, sc = 1.0 / 600.0, (0.8,)
     one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
-    nat = NativeSlabDns("loopback", x, y, z, size=P, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
-    one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
-    nat.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+    nat = NativeSlabDns("loopback", x, y, z, size=P, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER, fused_x=fused)
+    assert nat.fused_x == fused and nat.stages == int(stages)
+    walls = ("freeslip", "freeslip", "neumann", "dirichlet") if bcs == "freeslip" else ("noslip", "noslip", "dirichlet", "dirichlet")
+    one.set_bcs(*walls)
+    nat.set_bcs(*walls)
     for i in range(3):
         t = torch.from_numpy(f[i]).cuda()
         one.q[i].copy_(t); nat.scatter("q", i, t)
@@ -102,7 +107,9 @@ def test_native_driver_equals_single_domain_and_oracle(T):
 
     def make_oracle():
         o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
-        o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
+        o.flow_jmin = o.flow_jmax = velocity_bcs(bcs)
+        if bcs == "freeslip":
+            o.scal_jmin, o.scal_jmax = [4], [3]
         return o
     B, S = substep_scatter(make_oracle, f[:3], f[3:4], [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=3)
     for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
@@ -130,7 +137,7 @@ def test_native_driver_with_the_direct_schemes_is_bit_identical(T):
     g1, g2 = mk(), mk()
     kw = dict(nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, hyper_bc1_ext=REF_HYPER)
     py = SlabDns(LoopbackComm(P), x, y, z, zmode="halo", plans=g1, gy_elliptic=g1[1], **kw)
-    nat = NativeSlabDns("loopback", x, y, z, size=P, plans=g2, gy_elliptic=g2[1], **kw)
+    nat = NativeSlabDns("loopback", x, y, z, size=P, plans=g2, gy_elliptic=g2[1], fused_x=False, **kw)
     f = _fields(x, y, z, 5)
     for d in (py, nat):
         for i in range(4):
@@ -189,9 +196,10 @@ def test_full_size_eight_native_slabs(T):
     del one
     torch.cuda.empty_cache()
     out = {}
-    for which in ("python", "native"):
-        d = SlabDns(LoopbackComm(P), x, y, x.copy(), **kw) if which == "python" else NativeSlabDns("loopback", x, y, x.copy(), size=P, **kw)
-        assert d.zmode == "halo" and d.stages == 2
+    for which in ("python", "native", "native-fused"):
+        d = SlabDns(LoopbackComm(P), x, y, x.copy(), **kw) if which == "python" else \
+            NativeSlabDns("loopback", x, y, x.copy(), size=P, fused_x=which == "native-fused", **kw)
+        assert d.zmode == "halo" and d.stages == 2 and (which == "python" or d.fused_x == (which == "native-fused"))
         for i in range(3):
             d.scatter("q", i, fields[i])
         d.scatter("s", 0, fields[3])
@@ -203,5 +211,6 @@ def test_full_size_eight_native_slabs(T):
         torch.cuda.empty_cache()
     for i, rf in enumerate(ref):
         assert torch.equal(out["python"][i], out["native"][i]), i
-        err = float((out["native"][i] - rf).abs().max() / rf.abs().max())
-        assert err <= bound(scat[i]), (i, err, scat[i])
+        for which in ("native", "native-fused"):
+            err = float((out[which][i] - rf).abs().max() / rf.abs().max())
+            assert err <= bound(scat[i]), (which, i, err, scat[i])

@@ -191,11 +191,15 @@ int slab_allreduce(void *ctx, double *values, int n, int op) {
         tlab_comm *c = static_cast<tlab_comm *>(ctx);
         if (n < 1 || n > 64) throw Fail{TLAB_EINVAL, "slab transport: all-reduce of 1..64 values"};
         if (!c->red) hipc(hipMalloc((void **)&c->red, 64 * sizeof(double)), "hipMalloc");
-        hipStream_t st = tlab_current_stream();
-        hipc(hipMemcpyAsync(c->red, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st), "hipMemcpyAsync");
-        ncc(ncclAllReduce(c->red, c->red, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclMin, zcomm(c), st), "ncclAllReduce");
-        hipc(hipMemcpyAsync(values, c->red, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
-        hipc(hipStreamSynchronize(st), "hipStreamSynchronize");
+        // on the communication stream like every other operation of this communicator (one stream per communicator: no ordering left to RCCL),
+        // behind the work enqueued on the caller's stream so far
+        hipStream_t cur = tlab_current_stream(), cs = c->stream;
+        const int t = slab_begin(c, cur);
+        hipc(hipMemcpyAsync(c->red, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, cs), "hipMemcpyAsync");
+        ncc(ncclAllReduce(c->red, c->red, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclMin, zcomm(c), cs), "ncclAllReduce");
+        hipc(hipMemcpyAsync(values, c->red, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, cs), "hipMemcpyAsync");
+        hipc(hipEventRecord(c->ev_done[t], cs), "hipEventRecord");
+        hipc(hipStreamSynchronize(cs), "hipStreamSynchronize");
         return TLAB_OK;
     } catch (const Fail &f) {
         tlab_set_error(f.msg);

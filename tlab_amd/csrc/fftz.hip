@@ -216,6 +216,10 @@ struct FftxArgs {
     int npass;
     int radix[8];
     int tl, lines;          // threads per line (m/8), lines per workgroup
+    // the complex side in the slab <-> kx-pencil PACK layout instead of (m+1) contiguous values per line (tlab_pencil_repack_blocks folded into the
+    // transform): element (line, kx) at kxoff[kx] + line * kxw[kx] complex values; NULL: contiguous
+    const long long *kxoff;
+    const int *kxw;
 };
 
 template <int R>
@@ -274,6 +278,20 @@ __global__ void __launch_bounds__(256) k_fftx_r2c(FftxArgs a) {
     if (!ok) return;
     double2 *out = a.out + line * (a.m + 1);
     const int M = a.m;
+    if (a.kxw != nullptr) {      // same values, scattered into the pack buffer
+        for (int k = jt; k <= M / 2; k += a.tl) {
+            const cd A = lds[k], Zc = lds[(M - k) % M];
+            const cd B = {Zc.x, -Zc.y};
+            const cd E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
+            const cd D = A - B;
+            const cd O = {0.5 * D.y, -0.5 * D.x};
+            const double2 w = a.tw[k];
+            const cd T = cmul(cd{w.x, w.y}, O);
+            a.out[a.kxoff[k] + line * a.kxw[k]] = make_double2(E.x + T.x, E.y + T.y);
+            if (k != M - k) a.out[a.kxoff[M - k] + line * a.kxw[M - k]] = make_double2(E.x - T.x, -(E.y - T.y));
+        }
+        return;
+    }
     for (int k = jt; k <= M / 2; k += a.tl) {
         const cd A = lds[k], Zc = lds[(M - k) % M];
         const cd B = {Zc.x, -Zc.y};
@@ -338,8 +356,11 @@ __global__ void __launch_bounds__(256) k_fftx_c2r(FftxArgs a, FftxFinal fin) {
     const int M = a.m;
     if (ok) {
         const double2 *X = reinterpret_cast<const double2 *>(a.in) + line * (M + 1);
+        const double2 *XP = reinterpret_cast<const double2 *>(a.in);
         for (int k = jt; k <= M / 2; k += a.tl) {
-            double2 xa = X[k], xb = X[M - k];
+            double2 xa, xb;
+            if (a.kxw != nullptr) { xa = XP[a.kxoff[k] + line * a.kxw[k]]; xb = XP[a.kxoff[M - k] + line * a.kxw[M - k]]; }
+            else { xa = X[k]; xb = X[M - k]; }
             if (k == 0) { xa.y = 0.0; xb.y = 0.0; }
             const cd E = {xa.x + xb.x, xa.y - xb.y};                 // X_k + conj X_(m-k)
             const cd D = {xa.x - xb.x, xa.y + xb.y};                 // X_k - conj X_(m-k)
@@ -402,8 +423,9 @@ FftxPlan::~FftxPlan() {
     if (d_tw) (void)hipFree(d_tw);
 }
 
-void FftxPlan::exec(const double *in, double *out, hipStream_t st) const {
+void FftxPlan::exec(const double *in, double *out, hipStream_t st, const long long *kxoff, const int *kxw) const {
     FftxArgs a{};
+    a.kxoff = kxoff; a.kxw = kxw;
     a.in = in;
     a.out = reinterpret_cast<double2 *>(out);
     a.tw = reinterpret_cast<const double2 *>(d_tw);
@@ -474,8 +496,9 @@ void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) cons
 }
 
 void FftxPlan::launch_inverse(const double *in, double *out, const double *q, const double *h, double dte, double kco, int scale, int ny,
-                              hipStream_t st) const {
+                              hipStream_t st, const long long *kxoff, const int *kxw) const {
     FftxArgs a{};
+    a.kxoff = kxoff; a.kxw = kxw;
     a.in = in;
     a.out = reinterpret_cast<double2 *>(out);
     a.tw = reinterpret_cast<const double2 *>(d_tw);

@@ -2051,6 +2051,29 @@ struct tlab_poisson_plan {
         if (fx_own) fx_own->exec(static_cast<const double *>(in), static_cast<double *>(out), st);
         else fx_r2c.exec(in, out, st);
     }
+    // pack-layout maps of the own x-transforms (tlab_poisson_fft_x_packed), one per distinct block map; a slab driver uses one or two
+    struct KxMap { std::vector<long long> key; long long *off = nullptr; int *w = nullptr; };
+    std::vector<KxMap> kxmaps;
+    const KxMap &kx_map(int nblocks, const int *start, const long long *base) {
+        std::vector<long long> key;
+        key.reserve((size_t)2 * nblocks);
+        for (int b = 0; b < nblocks; ++b) { key.push_back(start[b]); key.push_back(base[b]); }
+        for (const KxMap &m : kxmaps) if (m.key == key) return m;
+        std::vector<long long> off((size_t)fx_nxh);
+        std::vector<int> w((size_t)fx_nxh);
+        for (int b = 0; b < nblocks; ++b) {
+            const int e = b + 1 < nblocks ? start[b + 1] : fx_nxh;
+            for (int i = start[b]; i < e; ++i) { off[i] = base[b] + (i - start[b]); w[i] = e - start[b]; }
+        }
+        KxMap m;
+        m.key = key;
+        hipc(hipMalloc((void **)&m.off, off.size() * sizeof(long long)), "hipMalloc");
+        hipc(hipMalloc((void **)&m.w, w.size() * sizeof(int)), "hipMalloc");
+        hipc(hipMemcpy(m.off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice), "hipMemcpy");
+        hipc(hipMemcpy(m.w, w.data(), w.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
+        kxmaps.push_back(m);
+        return kxmaps.back();
+    }
     bool use_2d = false;
     bool fz_inplace = false;          // z-transform plans built in place (kx-pencil plans: rocFFT then picks its column kernel, ~3x faster)
     hipStream_t side = nullptr;       // the <= 4 singular modes are solved beside the regular ones
@@ -2094,6 +2117,7 @@ struct tlab_poisson_plan {
         if (side) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        for (KxMap &m : kxmaps) { (void)hipFree(m.off); (void)hipFree(m.w); }
     }
     OdeSys sys(int which) const {
         OdeSys d;
@@ -2476,6 +2500,7 @@ extern hipStream_t tlab_current_stream();
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
 
+bool tlab_internal_poisson_has_own_x(tlab_poisson_plan_t P) { return P && P->fx_own; }
 bool tlab_internal_poisson_can_v_final(tlab_poisson_plan_t P);
 
 extern "C" {
@@ -3017,6 +3042,35 @@ int tlab_poisson_fft_x(tlab_poisson_plan_t P, int dir, double *in, double *out) 
         if (!P->fx_own) throw std::invalid_argument("tlab_poisson_fft_x: no own transform for this length");
         P->fx_own->exec_inverse(in, out, tlab_current_stream());
     } else P->fx_c2r.exec(in, out, tlab_current_stream());
+    POISSON_GUARD_END
+}
+// The x-transforms with the complex side in the pack layout of tlab_pencil_repack_blocks (the repack pass folded into the transform):
+// dir = +1: real in (nx,ny,kmax) -> pack buffer out; dir = -1: pack buffer in -> real out.  Own kernels only.
+static void packed_check(tlab_poisson_plan_t P, const void *a, const void *b, int nblocks, const int *start, const long long *base, const char *who) {
+    if (!P || !a || !b || !start || !base || nblocks < 1 || nblocks > 16 || start[0] != 0) throw std::invalid_argument(std::string(who) + ": bad arguments");
+    for (int p = 0; p + 1 < nblocks; ++p)
+        if (start[p + 1] < start[p] || start[p + 1] > P->fx_nxh) throw std::invalid_argument(std::string(who) + ": block starts must increase within [0, nx/2+1]");
+}
+#define PACKED_NEEDS_OWN(P, who) if ((P) && !(P)->fx_own) { tlab_set_error(who ": no own transform for this length"); return TLAB_EUNSUPPORTED; }
+int tlab_poisson_fft_x_packed(tlab_poisson_plan_t P, int dir, double *in, double *out, int nblocks, const int *start, const long long *base) {
+    PACKED_NEEDS_OWN(P, "tlab_poisson_fft_x_packed")
+    POISSON_GUARD_BEGIN
+    packed_check(P, in, out, nblocks, start, base, "tlab_poisson_fft_x_packed");
+    if (in == out) throw std::invalid_argument("tlab_poisson_fft_x_packed: out of place only");
+    const auto &m = P->kx_map(nblocks, start, base);
+    if (dir > 0) P->fx_own->exec(in, out, tlab_current_stream(), m.off, m.w);
+    else P->fx_own->exec_inverse(in, out, tlab_current_stream(), m.off, m.w);
+    POISSON_GUARD_END
+}
+// ... and the inverse of dp^/dy finishing the v equation (h = h - dp/dy, wall planes zeroed, q += dte h, h *= kco when scale) in its epilogue
+int tlab_poisson_fft_x_packed_final(tlab_poisson_plan_t P, double *in, double *q, double *h, double dte, double kco, int scale, int nblocks,
+                                    const int *start, const long long *base) {
+    PACKED_NEEDS_OWN(P, "tlab_poisson_fft_x_packed_final")
+    POISSON_GUARD_BEGIN
+    packed_check(P, in, q, nblocks, start, base, "tlab_poisson_fft_x_packed_final");
+    if (!h) throw std::invalid_argument("tlab_poisson_fft_x_packed_final: bad arguments");
+    const auto &m = P->kx_map(nblocks, start, base);
+    P->fx_own->exec_inverse_final(in, q, h, dte, kco, scale, (int)P->ny, tlab_current_stream(), m.off, m.w);
     POISSON_GUARD_END
 }
 // complex (nlines, nz_total) lines-fastest (the K-transposed layout; nlines = (nx/2+1)*ny/nproc_k), out of place

@@ -28,6 +28,7 @@ extern hipStream_t tlab_current_stream();
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
 // zslab.hip: the z-slab operators with the neighbours' halo planes of every operand in buffers of their own ({lo, hi}, 3 planes each)
+bool tlab_internal_poisson_has_own_x(tlab_poisson_plan_t P);      // poisson.hip
 int tlab_internal_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny, const double *u, const double *const *u_halo, const double *ub,
                                   const double *const *ub_halo, double scale, double *head, double *tail, const double *tail_left,
                                   const double *head_right, double *result, int acc);
@@ -133,6 +134,12 @@ struct tlab_slab_dns {
     double visc = 0.0;
     std::vector<double> schmidt;
     std::vector<int> nxl, ioff, nxa;
+    // the slab <-> pencil repack folded into the library's own x-transforms (tlab_poisson_fft_x_packed), and v finished by the inverse transform of
+    // dp^/dy; TLAB_SLAB_FUSED_X=0 keeps the separate passes (then the results equal the Python driver's to the bit: rocFFT's inverse)
+    bool fused_x = false;
+    struct VFinal { bool armed = false; double dte = 0.0, kco = 0.0; int scale = 0; } vf;
+    std::vector<int> sg_start;                   // one-piece block map
+    std::vector<long long> sg_base;
     std::vector<int> st_start;                   // two-stage block map (tlab_pencil_repack_blocks)
     std::vector<long long> st_base;
     long long st_split = 0;                      // doubles of the A part of a pack buffer
@@ -274,6 +281,22 @@ void repack(D *d, double *slab, double *buf, int dir) {
     }
 }
 
+// the x-transforms of the fused route: real slab <-> pack buffer; the one of dp^/dy finishes v when the RHS armed it
+void x_to_pack(D *d, Rank &R, double *real, double *pack) {
+    const bool st = d->stages == 2;
+    ok(tlab_poisson_fft_x_packed(R.poisson, 1, real, pack, st ? 2 * d->P : d->P, st ? d->st_start.data() : d->sg_start.data(),
+                                 st ? d->st_base.data() : d->sg_base.data()), "tlab_poisson_fft_x_packed");
+}
+void x_from_pack(D *d, Rank &R, double *pack, double *real, bool dpdy) {
+    const bool st = d->stages == 2;
+    const int nb = st ? 2 * d->P : d->P;
+    const int *start = st ? d->st_start.data() : d->sg_start.data();
+    const long long *base = st ? d->st_base.data() : d->sg_base.data();
+    if (dpdy && d->vf.armed)
+        ok(tlab_poisson_fft_x_packed_final(R.poisson, pack, R.q[1], R.hq[1], d->vf.dte, d->vf.kco, d->vf.scale, nb, start, base), "tlab_poisson_fft_x_packed_final");
+    else ok(tlab_poisson_fft_x_packed(R.poisson, -1, pack, real, nb, start, base), "tlab_poisson_fft_x_packed");
+}
+
 // slab <-> pencil exchange of one complex field: slab side = pack buffer blocked by peer, pencil side = (nxl_r, ny, nz_total)
 int pencil_exchange(D *d, int i_pen, int i_pack, bool forward) {
     const int P = d->P, L = (int)d->rk.size();
@@ -296,6 +319,7 @@ void poisson_pencil_single(D *d) {
     const bool direct = d->gy_elliptic != nullptr;
     for (Rank &R : d->rk) {
         ok(tlab_poisson_set_wall_planes(R.poisson, R.txc[0], R.hb, R.ht), "tlab_poisson_set_wall_planes");
+        if (d->fused_x) { x_to_pack(d, R, R.txc[0], R.pack[0]); continue; }
         ok(tlab_poisson_fft_x(R.poisson, 1, R.txc[0], R.txc[1]), "tlab_poisson_fft_x");              // p -> tmp2 (complex slab)
         repack(d, R.txc[1], R.pack[0], 1);
     }
@@ -310,8 +334,11 @@ void poisson_pencil_single(D *d) {
     if (direct) {    // one field on the way back; dp/dy = OPR_Partial_Y(p) on the slab (opr_elliptic.f90:447-449)
         twait(d, w0);
         for (Rank &R : d->rk) {
-            repack(d, R.txc[1], R.pack[0], -1);
-            ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[1], R.txc[0]), "tlab_poisson_fft_x");
+            if (d->fused_x) x_from_pack(d, R, R.pack[0], R.txc[0], false);
+            else {
+                repack(d, R.txc[1], R.pack[0], -1);
+                ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[1], R.txc[0]), "tlab_poisson_fft_x");
+            }
             ok(tlab_opr_partial(2, d->g[1], TLAB_OPR_P1, d->nx, d->ny, d->kmax, 0, R.txc[0], R.txc[2], nullptr), "tlab_opr_partial");
         }
         return;
@@ -320,11 +347,13 @@ void poisson_pencil_single(D *d) {
     const int w1 = pencil_exchange(d, 1, 1, false);
     twait(d, w0);
     for (Rank &R : d->rk) {
+        if (d->fused_x) { x_from_pack(d, R, R.pack[0], R.txc[0], false); continue; }
         repack(d, R.txc[1], R.pack[0], -1);
         ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[1], R.txc[0]), "tlab_poisson_fft_x");             // p -> tmp1
     }
     twait(d, w1);
     for (Rank &R : d->rk) {
+        if (d->fused_x) { x_from_pack(d, R, R.pack[1], R.txc[2], true); continue; }
         repack(d, R.txc[3], R.pack[1], -1);
         ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[3], R.txc[2]), "tlab_poisson_fft_x");             // dp/dy -> tmp3
     }
@@ -356,6 +385,7 @@ void poisson_pencil_staged(D *d) {
     };
     for (Rank &R : d->rk) {
         ok(tlab_poisson_set_wall_planes(R.poisson, R.txc[0], R.hb, R.ht), "tlab_poisson_set_wall_planes");
+        if (d->fused_x) { x_to_pack(d, R, R.txc[0], R.pack[0]); continue; }
         ok(tlab_poisson_fft_x(R.poisson, 1, R.txc[0], R.txc[1]), "tlab_poisson_fft_x");
         ok(tlab_pencil_repack_blocks(R.txc[1], R.pack[0], d->nxh, ny, kmax, 2 * P, d->st_start.data(), d->st_base.data(), 1), "tlab_pencil_repack_blocks");
     }
@@ -380,6 +410,7 @@ void poisson_pencil_staged(D *d) {
         twait(d, back[0][i]);
         twait(d, back[1][i]);
         for (Rank &R : d->rk) {
+            if (d->fused_x) { x_from_pack(d, R, R.pack[i], R.txc[out_of[i]], i == 1); continue; }
             ok(tlab_pencil_repack_blocks(R.txc[slab_of[i]], R.pack[i], d->nxh, ny, kmax, 2 * P, d->st_start.data(), d->st_base.data(), -1),
                "tlab_pencil_repack_blocks");
             ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[slab_of[i]], R.txc[out_of[i]]), "tlab_poisson_fft_x");
@@ -422,12 +453,15 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     twait(d, w);
     for (Rank &R : d->rk) zpartial(d, R, 2, R.hq[2], S_HQ3, R.q[2], 2, idte, R.txc[0], 1);
     // ---- pressure (:284) and its gradient (:319-320) ----
-    poisson_pencil(d);
     auto dirichlet = [](int t) { return t == TLAB_DNS_BCS_DIRICHLET; };
     bool vel_dirichlet = true, scal_dirichlet = true;
     for (int i = 0; i < 3; ++i) vel_dirichlet = vel_dirichlet && dirichlet(d->flow_jmin[i]) && dirichlet(d->flow_jmax[i]);
     for (int i = 0; i < ns; ++i) scal_dirichlet = scal_dirichlet && dirichlet(d->scal_jmin[i]) && dirichlet(d->scal_jmax[i]);
     const bool grad_final = tail && vel_dirichlet;
+    const bool v_final = grad_final && d->fused_x && !d->gy_elliptic;      // v is finished by the inverse x-transform of dp^/dy
+    d->vf.armed = v_final; d->vf.dte = tdte; d->vf.kco = kco; d->vf.scale = scale;
+    poisson_pencil(d);
+    d->vf.armed = false;
     // ---- hq -= grad p, boundary conditions (:348-398) [+ RK update] ----
     auto finish = [&](Rank &R) {
         struct Fd {
@@ -438,6 +472,7 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
         for (int i = 0; i < 3; ++i) F.push_back({R.q[i], R.hq[i], R.txc[1 + i], d->flow_jmin[i], d->flow_jmax[i]});
         for (int i = 0; i < ns; ++i) F.push_back({R.s[i], R.hs[i], nullptr, d->scal_jmin[i], d->scal_jmax[i]});
         if (grad_final) F.erase(F.begin() + 2), F.erase(F.begin());          // v and the scalars; u, w are done
+        if (v_final) F.erase(F.begin());                                     // the scalars
         if (!grad_final && (!vel_dirichlet || !tail)) {
             ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
             for (Fd &f : F) f.g = nullptr;
@@ -557,6 +592,10 @@ int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *tr, tl
                 offb += (long long)(d->nxl[p] - d->nxa[p]) * ny * d->kmax;
             }
         }
+        {
+            long long off = 0;
+            for (int p = 0; p < P; ++p) { d->sg_start.push_back(d->ioff[p]); d->sg_base.push_back(off); off += (long long)d->nxl[p] * ny * d->kmax; }
+        }
         d->rk.resize(tr->nlocal);
         const int nmsg = 2 * (3 + nscal);
         for (int l = 0; l < tr->nlocal; ++l) {
@@ -582,6 +621,9 @@ int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *tr, tl
             R.halo = dalloc((size_t)nslots * 2 * Hn);
             for (int i = 0; i < nslots; ++i) { R.lo.push_back(R.halo + (size_t)(2 * i) * Hn); R.hi.push_back(R.halo + (size_t)(2 * i + 1) * Hn); }
         }
+        const char *fx = std::getenv("TLAB_SLAB_FUSED_X");
+        d->fused_x = !(fx && std::strcmp(fx, "0") == 0);
+        for (Rank &R : d->rk) d->fused_x = d->fused_x && tlab_internal_poisson_has_own_x(R.poisson);
         d->tr = *tr;         // from here on the driver owns the transport's context
         *out = d.release();
     });
@@ -614,6 +656,7 @@ long long tlab_slab_dns_info(tlab_slab_dns_t d, int what) {
         case 3: return HALO * d->npage;
         case 4: return d->stages;
         case 5: return d->rk.empty() ? 0 : d->rk[0].r;
+        case 6: return d->fused_x ? 1 : 0;
     }
     return TLAB_EINVAL;
 }

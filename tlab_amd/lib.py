@@ -48,6 +48,8 @@ SIGNATURES = {
     "tlab_pencil_repack_blocks": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong), c_int]),
     "tlab_poisson_set_wall_planes": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "tlab_poisson_fft_x": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "tlab_poisson_fft_x_packed": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tlab_poisson_fft_x_packed_final": (c_int, [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_vp, c_vp]),
     "tlab_poisson_fft_z": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tlab_poisson_ode": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "tlab_poisson_plan_create_direct": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

@@ -128,8 +128,11 @@ class NativeSlabDns:
     zmode = "halo"
 
     def __init__(self, transport, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=0.0,
-                 device="cuda", plans=None, gy_elliptic=None, size=None, group=None):
-        """transport: "loopback" (size = number of ranks), "rccl" or "dist" (torch.distributed initialised; one rank per process)."""
+                 device="cuda", plans=None, gy_elliptic=None, size=None, group=None, fused_x=None):
+        """transport: "loopback" (size = number of ranks), "rccl" or "dist" (torch.distributed initialised; one rank per process).
+        fused_x: None = the library's default (TLAB_SLAB_FUSED_X); False keeps the separate repack passes and rocFFT's inverse x-transform,
+        whose results equal tlab_amd.parallel.SlabDns to the bit."""
+        import os
         import torch
         L = load()
         if transport == "loopback":
@@ -155,10 +158,21 @@ class NativeSlabDns:
         self.rkm_endstep = len(self.kdt)
         sc = np.ascontiguousarray(self.schmidt if self.nscal else [1.0], dtype=np.float64)
         self._h = c_vp(0)
-        rc = L.tlab_slab_dns_create(ctypes.byref(self._h), ctypes.byref(self._tr), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny, self.nzt,
-                                    self.nscal, self.visc, sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                    gy_elliptic._h if gy_elliptic is not None else None)
+        saved = os.environ.get("TLAB_SLAB_FUSED_X")
+        if fused_x is not None:
+            os.environ["TLAB_SLAB_FUSED_X"] = "1" if fused_x else "0"
+        try:
+            rc = L.tlab_slab_dns_create(ctypes.byref(self._h), ctypes.byref(self._tr), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny,
+                                        self.nzt, self.nscal, self.visc, sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                        gy_elliptic._h if gy_elliptic is not None else None)
+        finally:
+            if fused_x is not None:
+                if saved is None:
+                    os.environ.pop("TLAB_SLAB_FUSED_X", None)
+                else:
+                    os.environ["TLAB_SLAB_FUSED_X"] = saved
         check(rc, "tlab_slab_dns_create")
+        self.fused_x = bool(L.tlab_slab_dns_info(self._h, 6))
         self.kmax = int(L.tlab_slab_dns_info(self._h, 0))
         self.stages = int(L.tlab_slab_dns_info(self._h, 4))
         self.npage = self.nx * self.ny

@@ -91,8 +91,8 @@ def main():
         tt = tt.cuda()
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print("DIST_CHECK driver=%s world=%d zmode=%s backend=%s worst_rel_err=%.3e %s" % (args.driver, world, slab.zmode, backend, float(tt.item()),
-                                                                                 "OK" if float(tt.item()) <= 1e-11 else "FAIL"))
+        print("DIST_CHECK driver=%s world=%d zmode=%s backend=%s fused_x=%d worst_rel_err=%.3e %s" % (
+            args.driver, world, slab.zmode, backend, int(getattr(slab, "fused_x", False)), float(tt.item()), "OK" if float(tt.item()) <= 1e-11 else "FAIL"))
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if float(tt.item()) <= 1e-11 else 1)
