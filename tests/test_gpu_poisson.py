@@ -91,6 +91,33 @@ def test_chunked_and_marching_ode_kernels_agree(T, monkeypatch):
     assert rel_err(outs[0][1], outs[1][1]) <= 1e-13
 
 
+@pytest.mark.parametrize("nx,ny,nz", [(128, 128, 64), (32, 64, 8), (48, 512, 12), (16, 24, 16)])
+def test_mirror_pair_and_single_mode_ode_kernels_agree(T, nx, ny, nz, monkeypatch):
+    """k_ode_nn carries the modes (kx, kz) and (kx, nz - kz) -- same lambda to the bit, hence same pivots, constants and homogeneous solutions --
+    through one thread (default); TLAB_ODE_PAIR=0 at plan creation keeps one mode per thread.  Same operations per line, so the two agree to the
+    last bits (the compiler may contract the two instantiations differently); BCS_NN and BCS_DD; kz = 0 and nz/2 are their own mirrors."""
+    import torch
+    x, y, z = setup(nx, ny, nz, True)
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, False), T.FdmPlan(z, True, True)]
+    rng = np.random.default_rng(nx + nz)
+    N = nx * ny * nz
+    f, hb, ht = rng.uniform(-1, 1, N), rng.uniform(-1, 1, nx * nz), rng.uniform(-1, 1, nx * nz)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TLAB_ODE_PAIR", flag)
+        plan = T.PoissonPlan(gp[0], gp[1], gp[2], nx, ny, nz)
+        t1 = torch.empty(plan.isize_txc_field, dtype=torch.float64, device="cuda"); t2 = torch.empty_like(t1)
+        for ibc in (T.BCS_NN, T.BCS_DD):
+            p = dev(f)
+            dpdy = torch.empty(N, dtype=torch.float64, device="cuda")
+            T.OPR_Poisson(plan, nx, ny, nz, ibc, p, t1, t2, dev(hb), dev(ht), dpdy)
+            outs[flag, ibc] = (p.cpu().numpy(), dpdy.cpu().numpy())
+    for ibc in (T.BCS_NN, T.BCS_DD):
+        for k in range(2):
+            assert np.isfinite(outs["1", ibc][k]).all() and np.abs(outs["1", ibc][k]).max() > 0.0
+            assert rel_err(outs["1", ibc][k], outs["0", ibc][k]) <= 1e-14, (ibc, k)
+
+
 @pytest.mark.parametrize("nz", [16, 32, 64, 128, 256, 512, 1024, 2048])
 def test_own_z_fft_matches_numpy(T, nz):
     """k_fftz (strided Stockham, fftz.hip) against numpy on the kx-pencil layout (nxl, ny, nz); lengths 8^a * {1,2,4}."""

@@ -901,7 +901,7 @@ template <int BC>
 // Layout of everything k_ode_nn reads per mode: blocked by the NM modes of a workgroup, [block][...][NM], so that a workgroup's reads are
 // one contiguous stream (mode-minor [..][nm] rows would be 64-B pieces of 128-B lines at NM = 8: measured 2x over-fetch).
 __global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *__restrict__ lamv, double lam_sign, double *__restrict__ chk,
-                                                        long long nm, int NM, int C) {
+                                                        long long nm, int NM, int C, int om) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nm) return;
     const int n = T.n;
@@ -910,8 +910,8 @@ __global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *
     ode_boundary_rows<BC>(T, lam, k);
     double st[6] = {0, 0, 0, 0, 0, 0};
     for (int j = 1; j <= n - 2; ++j) {
-        if ((j % OM) == 0) {
-            const int c = j / OM;
+        if ((j % om) == 0) {
+            const int c = j / om;
 #pragma unroll
             for (int q = 0; q < 6; ++q) chk[(((t / NM) * C + c) * 6 + q) * NM + (t % NM)] = st[q];
         }
@@ -924,26 +924,27 @@ __global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *
 // Inflow of every chunk from the chunks before it (DIR = +1: c-1, c-2, ... ; DIR = -1: c+1, c+2, ...), i.e. the exclusive prefix of the
 // affine maps in -> Phi in + e of the chunks, composed in the direction of the sweep.  Lanes hold (mode m, chunk c) with m fastest, so a
 // wave owns 64/NM consecutive chunks of NM modes: Hillis-Steele with lane shuffles inside the wave, the wave totals through LDS.
-//   phi = {p00, p01, p10, p11}, e[l] = {e1, e2} per line; returns in[l] = {in1, in2}.     s_w: [nwaves][8][NM] doubles
-template <int NM, int DIR>
-__device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[2][2], int c, int C, int m, double *s_w, double (&in)[2][2]) {
+//   phi = {p00, p01, p10, p11}, e[l] = {e1, e2} per line; returns in[l] = {in1, in2}.     s_w: [nwaves][4 + 2 NL][NM] doubles
+template <int NM, int DIR, int NL = 2>
+__device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[NL][2], int c, int C, int m, double *s_w, double (&in)[NL][2]) {
+    constexpr int SW = 4 + 2 * NL;                     // doubles per wave total: phi, then (e1, e2) of every line
     constexpr int CPW = 64 / NM;                       // chunks per wave
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int cw = lane / NM;                          // chunk index inside the wave
     // position along the sweep inside the wave: DIR = +1 -> cw, DIR = -1 -> reversed
 #pragma unroll
     for (int d = 1; d < CPW; d <<= 1) {
-        double q[4], f[2][2];
+        double q[4], f[NL][2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = (DIR > 0) ? __shfl_up(phi[k], d * NM) : __shfl_down(phi[k], d * NM);
 #pragma unroll
-        for (int l = 0; l < 2; ++l)
+        for (int l = 0; l < NL; ++l)
 #pragma unroll
             for (int k = 0; k < 2; ++k) f[l][k] = (DIR > 0) ? __shfl_up(e[l][k], d * NM) : __shfl_down(e[l][k], d * NM);
         const bool has = (DIR > 0) ? (cw >= d) : (cw + d < CPW && c + d < C);
         if (has) {      // (phi, e) <- (phi * q, phi * f + e): the partner's chunks come first in the sweep
 #pragma unroll
-            for (int l = 0; l < 2; ++l) {
+            for (int l = 0; l < NL; ++l) {
                 const double n1 = phi[0] * f[l][0] + phi[1] * f[l][1] + e[l][0];
                 const double n2 = phi[2] * f[l][0] + phi[3] * f[l][1] + e[l][1];
                 e[l][0] = n1; e[l][1] = n2;
@@ -957,38 +958,40 @@ __device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[2][2], i
     const bool last_in_wave = (DIR > 0) ? (cw == CPW - 1 || c == C - 1) : (cw == 0);
     if (last_in_wave) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_w[(w * 8 + k) * NM + m] = phi[k];
-        s_w[(w * 8 + 4) * NM + m] = e[0][0]; s_w[(w * 8 + 5) * NM + m] = e[0][1];
-        s_w[(w * 8 + 6) * NM + m] = e[1][0]; s_w[(w * 8 + 7) * NM + m] = e[1][1];
+        for (int k = 0; k < 4; ++k) s_w[(w * SW + k) * NM + m] = phi[k];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { s_w[(w * SW + 4 + 2 * l) * NM + m] = e[l][0]; s_w[(w * SW + 5 + 2 * l) * NM + m] = e[l][1]; }
     }
     __syncthreads();
     // what enters my wave: the waves before it along the sweep, composed in order
     const int nw = (blockDim.x + 63) >> 6;
-    double pe[2][2] = {{0, 0}, {0, 0}};
+    double pe[NL][2];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) pe[l][0] = pe[l][1] = 0.0;
     if (DIR > 0) {
         for (int v = 0; v < w; ++v) {
-            const double a0 = s_w[(v * 8 + 0) * NM + m], a1 = s_w[(v * 8 + 1) * NM + m], a2 = s_w[(v * 8 + 2) * NM + m], a3 = s_w[(v * 8 + 3) * NM + m];
+            const double a0 = s_w[(v * SW + 0) * NM + m], a1 = s_w[(v * SW + 1) * NM + m], a2 = s_w[(v * SW + 2) * NM + m], a3 = s_w[(v * SW + 3) * NM + m];
 #pragma unroll
-            for (int l = 0; l < 2; ++l) {
-                const double n1 = a0 * pe[l][0] + a1 * pe[l][1] + s_w[(v * 8 + 4 + 2 * l) * NM + m];
-                const double n2 = a2 * pe[l][0] + a3 * pe[l][1] + s_w[(v * 8 + 5 + 2 * l) * NM + m];
+            for (int l = 0; l < NL; ++l) {
+                const double n1 = a0 * pe[l][0] + a1 * pe[l][1] + s_w[(v * SW + 4 + 2 * l) * NM + m];
+                const double n2 = a2 * pe[l][0] + a3 * pe[l][1] + s_w[(v * SW + 5 + 2 * l) * NM + m];
                 pe[l][0] = n1; pe[l][1] = n2;
             }
         }
     } else {
         for (int v = nw - 1; v > w; --v) {
-            const double a0 = s_w[(v * 8 + 0) * NM + m], a1 = s_w[(v * 8 + 1) * NM + m], a2 = s_w[(v * 8 + 2) * NM + m], a3 = s_w[(v * 8 + 3) * NM + m];
+            const double a0 = s_w[(v * SW + 0) * NM + m], a1 = s_w[(v * SW + 1) * NM + m], a2 = s_w[(v * SW + 2) * NM + m], a3 = s_w[(v * SW + 3) * NM + m];
 #pragma unroll
-            for (int l = 0; l < 2; ++l) {
-                const double n1 = a0 * pe[l][0] + a1 * pe[l][1] + s_w[(v * 8 + 4 + 2 * l) * NM + m];
-                const double n2 = a2 * pe[l][0] + a3 * pe[l][1] + s_w[(v * 8 + 5 + 2 * l) * NM + m];
+            for (int l = 0; l < NL; ++l) {
+                const double n1 = a0 * pe[l][0] + a1 * pe[l][1] + s_w[(v * SW + 4 + 2 * l) * NM + m];
+                const double n2 = a2 * pe[l][0] + a3 * pe[l][1] + s_w[(v * SW + 5 + 2 * l) * NM + m];
                 pe[l][0] = n1; pe[l][1] = n2;
             }
         }
     }
     // inclusive value of my chunk over the whole line, then the previous chunk's along the sweep = my inflow
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
         const double f1 = phi[0] * pe[l][0] + phi[1] * pe[l][1] + e[l][0];
         const double f2 = phi[2] * pe[l][0] + phi[3] * pe[l][1] + e[l][1];
         const double g1 = (DIR > 0) ? __shfl_up(f1, NM) : __shfl_down(f1, NM);
@@ -1036,11 +1039,14 @@ __global__ void __launch_bounds__(256) k_ode_block_layout(const double *__restri
 //   res0 / resN: the boundary values as MatMul_3d sees them (fdm_integral.f90:240-245)
 //   x[p][l]: solution rows j0..j0+7 (boundary rows included after the reconstruction)
 //   ext[l]: derivative at the given end: BC == 1 at the bottom (valid in chunk 0), BC == 2 at the top (valid in the last chunk)
-// LDS: s_w [nwaves][8][NM] (scan), s_k [OK_SIZE][NM] (boundary rows), s_fac [threads][25] (backward factors)
-template <int BC, int NM>
+// LDS: s_w [nwaves][4 + 2 NL][NM] (scan), s_k [OK_SIZE][NM] (boundary rows), s_fac [threads][3 OM + 1] (backward factors)
+// OM rows per thread (8, or 4 with the line cut into twice as many chunks), NL lines sharing the factors (2 = Re, Im of one mode; 4 = of two
+// modes with the same lambda)
+template <int BC, int NM, int OM = 8, int NL = 2>
 __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const double *__restrict__ chk, int nm, int t, int c, int C, int m,
-                                          const double (&fl)[OM + 2][2], const double (&res0)[2], const double (&resN)[2],
-                                          double (&x)[OM][2], double (&ext)[2], double *s_w, double *s_k, double *s_fac) {
+                                          const double (&fl)[OM + 2][NL], const double (&res0)[NL], const double (&resN)[NL],
+                                          double (&x)[OM][NL], double (&ext)[NL], double *s_w, double *s_k, double *s_fac) {
+    static_assert(OM == 4 || OM == 8, "rows per thread");
     const int n = T.n, j0 = c * OM;
     if (c == 1) {              // C >= 2; chunk 1 never touches a boundary row itself
         OdeRows k;
@@ -1058,10 +1064,14 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
     double am[OM], bm[OM];             // forward multipliers in registers; the backward factors (1/c, -d, -e) wait in LDS
     double *my_fac = s_fac + threadIdx.x * (3 * OM + 1);      // thread-major with an odd stride: constant offsets, no bank conflicts
 #define FAC(p, q) my_fac[(p) * 3 + (q)]
-    double (&rhs)[OM][2] = x;          // right-hand side -> y -> x in place
-    const double fn2[2] = {fl[OM - 1][0], fl[OM - 1][1]};      // f(n-2) of the last chunk, for du (the only use of fl after the rhs)
-    const double f1s[2] = {fl[2][0], fl[2][1]};                  // f(1) of the first chunk, for du of the BCS_MIN system
-    double bcs_b[2] = {0, 0}, bcs_t[2] = {0, 0};
+    double (&rhs)[OM][NL] = x;          // right-hand side -> y -> x in place
+    double fn2[NL], f1s[NL], bcs_b[NL], bcs_t[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        fn2[l] = fl[OM - 1][l];          // f(n-2) of the last chunk, for du (the only use of fl after the rhs)
+        f1s[l] = fl[2][l];               // f(1) of the first chunk, for du of the BCS_MIN system
+        bcs_b[l] = bcs_t[l] = 0.0;
+    }
     // The special rows sit at fixed positions of the first and the last chunk (requires n = 8 C): row 0 / n-1 are not part of the
     // system, rows 1, 2 / n-3, n-2 carry the reduced boundary closures.  Conditions are written on the unrolled p so that they fold away
     // everywhere else, and the special cases are selections of coefficients, not branches.
@@ -1114,7 +1124,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
             st[0] = cm; st[1] = dm; st[2] = em;
         }
 #pragma unroll
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < NL; ++l) {
             const double fm = fl[p][l], fc = fl[p + 1][l], fp = fl[p + 2][l];
             double v = fm * c0 + fc * c1 + fp * c2;
             if ((p == 1 || p == 2) && lo) v = res0[l] * cb + v;          // (order of the reference: boundary term first, fdm_matmul.f90:93-94)
@@ -1126,14 +1136,16 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
         if (p & 1) __builtin_amdgcn_sched_barrier(0);      // table loads of two rows in flight, not of all eight (96 doubles)
     }
     // ---- forward substitution: particular end values + transfer matrix, scan, repeat with the inflow ----
-    double inflow[2][2];
+    double inflow[NL][2];
     {
-        double y1[2] = {0, 0}, y2[2] = {0, 0};
+        double y1[NL], y2[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) y1[l] = y2[l] = 0.0;
         double h1a = 1.0, h2a = 0.0, h1b = 0.0, h2b = 1.0;     // responses to unit inflows (y[j0-1], y[j0-2]) = (1,0), (0,1)
 #pragma unroll
         for (int p = 0; p < OM; ++p) {
 #pragma unroll
-            for (int l = 0; l < 2; ++l) {
+            for (int l = 0; l < NL; ++l) {
                 const double y = rhs[p][l] - y1[l] * bm[p] - y2[l] * am[p];
                 y2[l] = y1[l]; y1[l] = y;
             }
@@ -1141,16 +1153,20 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
             const double hb = -h1b * bm[p] - h2b * am[p]; h2b = h1b; h1b = hb;
         }
         // out = (y[j0+7], y[j0+6]) = Phi (in1, in2) + end
-        double phi[4] = {h1a, h1b, h2a, h2b}, ee[2][2] = {{y1[0], y2[0]}, {y1[1], y2[1]}};
-        ode_chain<NM, +1>(phi, ee, c, C, m, s_w, inflow);
+        double phi[4] = {h1a, h1b, h2a, h2b}, ee[NL][2];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { ee[l][0] = y1[l]; ee[l][1] = y2[l]; }
+        ode_chain<NM, +1, NL>(phi, ee, c, C, m, s_w, inflow);
     }
-    double (&y)[OM][2] = x;
+    double (&y)[OM][NL] = x;
     {
-        double y1[2] = {inflow[0][0], inflow[1][0]}, y2[2] = {inflow[0][1], inflow[1][1]};
+        double y1[NL], y2[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { y1[l] = inflow[l][0]; y2[l] = inflow[l][1]; }
 #pragma unroll
         for (int p = 0; p < OM; ++p)
 #pragma unroll
-            for (int l = 0; l < 2; ++l) {
+            for (int l = 0; l < NL; ++l) {
                 const double v = rhs[p][l] - y1[l] * bm[p] - y2[l] * am[p];
                 y[p][l] = v; y2[l] = y1[l]; y1[l] = v;
             }
@@ -1158,29 +1174,35 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
     __syncthreads();
     // ---- backward substitution, same scheme downwards: in = (x[j0+8], x[j0+9]), out = (x[j0], x[j0+1]) ----
     {
-        double x1[2] = {0, 0}, x2[2] = {0, 0};
+        double x1[NL], x2[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) x1[l] = x2[l] = 0.0;
         double h1a = 1.0, h2a = 0.0, h1b = 0.0, h2b = 1.0;
 #pragma unroll
         for (int p = OM - 1; p >= 0; --p) {
             const double cinv_p = FAC(p, 0), nd_p = FAC(p, 1), ne_p = FAC(p, 2);
 #pragma unroll
-            for (int l = 0; l < 2; ++l) {
+            for (int l = 0; l < NL; ++l) {
                 const double v = (y[p][l] + x1[l] * nd_p + x2[l] * ne_p) * cinv_p;
                 x2[l] = x1[l]; x1[l] = v;
             }
             const double ha = (h1a * nd_p + h2a * ne_p) * cinv_p; h2a = h1a; h1a = ha;
             const double hb = (h1b * nd_p + h2b * ne_p) * cinv_p; h2b = h1b; h1b = hb;
         }
-        double phi[4] = {h1a, h1b, h2a, h2b}, ee[2][2] = {{x1[0], x2[0]}, {x1[1], x2[1]}};
-        ode_chain<NM, -1>(phi, ee, c, C, m, s_w, inflow);
+        double phi[4] = {h1a, h1b, h2a, h2b}, ee[NL][2];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { ee[l][0] = x1[l]; ee[l][1] = x2[l]; }
+        ode_chain<NM, -1, NL>(phi, ee, c, C, m, s_w, inflow);
     }
     {
-        double x1[2] = {inflow[0][0], inflow[1][0]}, x2[2] = {inflow[0][1], inflow[1][1]};
+        double x1[NL], x2[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { x1[l] = inflow[l][0]; x2[l] = inflow[l][1]; }
 #pragma unroll
         for (int p = OM - 1; p >= 0; --p) {
             const double cinv_p = FAC(p, 0), nd_p = FAC(p, 1), ne_p = FAC(p, 2);
 #pragma unroll
-            for (int l = 0; l < 2; ++l) {
+            for (int l = 0; l < NL; ++l) {
                 const double v = (y[p][l] + x1[l] * nd_p + x2[l] * ne_p) * cinv_p;
                 x[p][l] = v; x2[l] = x1[l]; x1[l] = v;
             }
@@ -1188,9 +1210,9 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
     }
     __syncthreads();
     // ---- boundary value at the free end, derivative at the given end (fdm_integral.f90:265-311) ----
-    ext[0] = ext[1] = 0.0;
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
+        ext[l] = 0.0;
         if (BC == 2) {
             if (c == 0) x[0][l] = bcs_b[l] + KK(OK_L0, 3) * x[1][l] + KK(OK_L0, 4) * x[2][l] + KK(OK_L0, 0) * x[3][l];
             if (c == C - 1) {
@@ -1216,15 +1238,22 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
 
 // DD: OPR_ODE2_Factorize_DD (opr_odes.f90:391-478) instead of _NN: the same two solves with the top value of u GIVEN (bcs(:,2)), two constants
 // instead of three (a.cst = [5][nm]: aa, bb, 1 / (aa sp(1) - bb u1(1)), sp(1), u1(1) from k_dd_constants), no e^(+) term in the superposition.
-template <int NM, bool DD = false>
+// NL = 4: MIRROR PAIRS.  lambda(kx, kz) = lambda(kx, nz - kz) to the bit (the modified wavenumbers of +-omega, fdm_derivative.f90:198-204), so the
+// pivots, the checkpoints, the constants and the homogeneous solutions of the two modes are the same numbers: one thread carries the four lines
+// (Re, Im of both modes) through one regeneration of the factors and one read of the tables.  Workgroup = NM values of kx x one kz <= nz/2 (and its
+// mirror plane); kz = 0 and nz/2 are their own partners (the second store is dropped).  The plan checks the symmetry of lambda and of the skip
+// flags on the host before it picks this form.  OMR = 4 rows per thread there: the same 16 values per thread as 8 rows x 2 lines.
+template <int NM, bool DD = false, int OMR = 8, int NL = 2>
 __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
+    constexpr int NQ = NL / 2;                                                                    // modes per thread
     extern __shared__ double lds[];
     const int C = a.C, n = a.n;
     const int m = threadIdx.x % NM, c = threadIdx.x / NM;
-    double *s_w = lds, *s_x = lds + 8 * 8 * NM;                                                  // s_w: [8 waves][8][NM]; s_x: [C][2 lines][2][NM]
-    double *s_sc = s_x + (size_t)C * 4 * NM;                                                     // [10][NM]
-    double *s_k = s_sc + 10 * NM;                                                                // [OK_SIZE][NM]
-    double *s_fac = s_k + OK_SIZE * NM;                                                          // [OM][3][threads]
+    double *s_w = lds, *s_x = lds + 8 * (4 + 2 * NL) * NM;                                       // s_w: [8 waves][4 + 2 NL][NM]; s_x: [C][NL lines][2][NM]
+    double *s_sc = s_x + (size_t)C * 2 * NL * NM;                                                // [5][NL][NM]
+    double *s_k = s_sc + 5 * NL * NM;                                                            // [OK_SIZE][NM]
+    double *s_fac = s_k + OK_SIZE * NM;                                                          // [threads][3 OMR + 1]
+#define SC(q, l) s_sc[((q) * NL + (l)) * NM + m]
     // 32-bit index arithmetic throughout (the host checks that every array has < 2^31 elements): 64-bit address pairs for the ~50
     // distinct rows this thread touches would otherwise be precomputed and kept in registers
     const int nm = (int)a.nm;
@@ -1233,60 +1262,86 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // 6.7 algorithmic).  Pair them: of every 16 consecutive workgroups, XCD x gets the adjacent blocks 2x and 2x + 1.
     unsigned blk = blockIdx.x;
     if (NM == 4 && a.pair_xcd && (blk | 15u) < gridDim.x) blk = (blk & ~15u) + 2u * (blk & 7u) + ((blk >> 3) & 1u);
-    int t = (int)blk * NM + m;
-    const bool live = t < nm;
-    if (!live) t = nm - 1;
-    const bool store = live && !a.skip[t];
+    int t = (int)blk * NM + m;                        // the mode whose tables are read (NL = 4: kz <= nz/2, so the pair index is the mode index)
+    const int nlive = (NL == 4) ? a.nxh * (nm / a.nxh / 2 + 1) : nm;
+    const bool live = t < nlive;
+    if (!live) t = nlive - 1;
     const double lam = a.lam[t];
-    const unsigned fidx0 = (unsigned)((t % a.nxh) + a.nxh * a.ny * (t / a.nxh));
-    const int j0 = c * OM;
+    unsigned fidx0[NQ];
+    bool store[NQ];                                   // modes solved elsewhere (singular, low) are left alone, each of a pair on its own
+    fidx0[0] = (unsigned)((t % a.nxh) + a.nxh * a.ny * (t / a.nxh));
+    store[0] = live && !a.skip[t];
+    if (NL == 4) {
+        const int nz = nm / a.nxh, kz = t / a.nxh, kz2 = (nz - kz) % nz;
+        fidx0[NQ - 1] = (unsigned)((t % a.nxh) + a.nxh * a.ny * kz2);
+        store[NQ - 1] = live && kz2 != kz && !a.skip[(t % a.nxh) + a.nxh * kz2];      // kz = 0, nz/2: their own mirror, stored once
+    }
+    const int j0 = c * OMR;
     const double2 *F = reinterpret_cast<const double2 *>(a.f_hat);
     double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
 
-    double u[OM][2], ext[2];
-    double v_1[2] = {0, 0}, u_n[2] = {0, 0}, fn[2] = {0, 0}, bb[2], bt[2];
-    double vh[OM + 2][2];        // rows j0-1 .. j0+8 of the u-solve's right-hand side v; vh[1..8] is where the v-solve puts v
-    {
-        // ---- f rows j0-1 .. j0+8 (normalised).  f(n) itself is never read by the solves: the callers' f(n) = 0 enters as resN (opr_odes.f90:303)
-        double fl[OM + 2][2];
+    double u[OMR][NL], ext[NL];
+    double v_1[NL], u_n[NL], fn[NL], bb[NL], bt[NL];
 #pragma unroll
-        for (int p = 0; p < OM + 2; ++p) {
+    for (int l = 0; l < NL; ++l) v_1[l] = u_n[l] = fn[l] = 0.0;
+    double vh[OMR + 2][NL];      // rows j0-1 .. j0+OMR of the u-solve's right-hand side v; vh[1..OMR] is where the v-solve puts v
+    {
+        // ---- f rows j0-1 .. j0+OMR (normalised).  f(n) itself is never read by the solves: the callers' f(n) = 0 enters as resN (opr_odes.f90:303)
+        double fl[OMR + 2][NL];
+#pragma unroll
+        for (int p = 0; p < OMR + 2; ++p) {
             const int j = j0 - 1 + p;
-            double2 w = make_double2(0.0, 0.0);
-            if (j >= 0 && j <= n - 1) w = F[fidx0 + (unsigned)(j * a.nxh)];
-            fl[p][0] = w.x * a.fscale; fl[p][1] = w.y * a.fscale;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                double2 w = make_double2(0.0, 0.0);
+                if (j >= 0 && j <= n - 1) w = F[fidx0[q] + (unsigned)(j * a.nxh)];
+                fl[p][2 * q] = w.x * a.fscale; fl[p][2 * q + 1] = w.y * a.fscale;
+            }
         }
         // Neumann data travel in the boundary rows of the forcing (opr_elliptic.f90:310-311)
-        if (c == 0) { s_sc[0 * NM + m] = fl[1][0]; s_sc[1 * NM + m] = fl[1][1]; }
-        if (c == C - 1) { s_sc[2 * NM + m] = fl[OM][0]; s_sc[3 * NM + m] = fl[OM][1]; }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (c == 0) SC(0, l) = fl[1][l];
+            if (c == C - 1) SC(1, l) = fl[OMR][l];
+        }
         __syncthreads();
-        bb[0] = s_sc[0 * NM + m]; bb[1] = s_sc[1 * NM + m]; bt[0] = s_sc[2 * NM + m]; bt[1] = s_sc[3 * NM + m];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { bb[l] = SC(0, l); bt[l] = SC(1, l); }
         // ---- v0' + lambda v0 = f, v0(1) = 0 ; f(n) = 0 ----
-        ode_solve<1, NM>(a.T1, lam, a.chk1, nm, t, c, C, m, fl, v_1, fn, reinterpret_cast<double (&)[OM][2]>(vh[1]), ext, s_w, s_k, s_fac);
+        ode_solve<1, NM, OMR, NL>(a.T1, lam, a.chk1, nm, t, c, C, m, fl, v_1, fn, reinterpret_cast<double (&)[OMR][NL]>(vh[1]), ext, s_w, s_k, s_fac);
     }
     // halo rows of v0 for the right-hand side of the u-solve
 #pragma unroll
-    for (int l = 0; l < 2; ++l) { s_x[((c * 2 + l) * 2 + 0) * NM + m] = vh[1][l]; s_x[((c * 2 + l) * 2 + 1) * NM + m] = vh[OM][l]; }
+    for (int l = 0; l < NL; ++l) { s_x[((c * NL + l) * 2 + 0) * NM + m] = vh[1][l]; s_x[((c * NL + l) * 2 + 1) * NM + m] = vh[OMR][l]; }
     __syncthreads();
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        vh[0][l] = (c > 0) ? s_x[(((c - 1) * 2 + l) * 2 + 1) * NM + m] : 0.0;
-        vh[OM + 1][l] = (c < C - 1) ? s_x[(((c + 1) * 2 + l) * 2 + 0) * NM + m] : 0.0;
+    for (int l = 0; l < NL; ++l) {
+        vh[0][l] = (c > 0) ? s_x[(((c - 1) * NL + l) * 2 + 1) * NM + m] : 0.0;
+        vh[OMR + 1][l] = (c < C - 1) ? s_x[(((c + 1) * NL + l) * 2 + 0) * NM + m] : 0.0;
     }
-    if (c == C - 1) { s_sc[6 * NM + m] = vh[OM][0]; s_sc[7 * NM + m] = vh[OM][1]; }     // v0(n)
+    if (c == C - 1) {     // v0(n)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) SC(3, l) = vh[OMR][l];
+    }
     // ---- u0' - lambda u0 = v0, u0(n) = 0 ; the "opposite boundary value" is v0(1) = 0 (res(1) = f(1), fdm_integral.f90:243) ----
-    if (DD) { u_n[0] = bt[0]; u_n[1] = bt[1]; }      // u(:, nx) = bcs(:, 2)  (:440)
-    ode_solve<2, NM>(a.T2, -lam, a.chk2, nm, t, c, C, m, vh, v_1, u_n, u, ext, s_w, s_k, s_fac);
+    if (DD) {      // u(:, nx) = bcs(:, 2)  (:440)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) u_n[l] = bt[l];
+    }
+    ode_solve<2, NM, OMR, NL>(a.T2, -lam, a.chk2, nm, t, c, C, m, vh, v_1, u_n, u, ext, s_w, s_k, s_fac);
     // ---- u0(1), v0(n), du0(n) -> the three constants (opr_odes.f90:350-356 with the LU of k_nn_constants) ----
-    if (c == 0) { s_sc[4 * NM + m] = u[0][0]; s_sc[5 * NM + m] = u[0][1]; }
-    if (c == C - 1) { s_sc[8 * NM + m] = ext[0]; s_sc[9 * NM + m] = ext[1]; }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (c == 0) SC(2, l) = u[0][l];
+        if (c == C - 1) SC(4, l) = ext[l];
+    }
     __syncthreads();
     if (DD) {      // :452-456
         const double aa = a.cst[(unsigned)(0 * nm + t)], bc = a.cst[(unsigned)(1 * nm + t)], dummy = a.cst[(unsigned)(2 * nm + t)];
         const double sp1 = a.cst[(unsigned)(3 * nm + t)], u11 = a.cst[(unsigned)(4 * nm + t)];
 #pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            const double u0_1 = s_sc[(4 + l) * NM + m], v0_n = s_sc[(6 + l) * NM + m], du0n = s_sc[(8 + l) * NM + m];
+        for (int l = 0; l < NL; ++l) {
+            const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l);
             const double w = lam * bt[l] - du0n + v0_n;
             v_1[l] = (aa * (bb[l] - u0_1) - u11 * w) * dummy;
             fn[l] = (sp1 * w - bc * (bb[l] - u0_1)) * dummy;
@@ -1296,8 +1351,8 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
         const double a12 = a.cst[(unsigned)(3 * nm + t)], a22 = a.cst[(unsigned)(4 * nm + t)], a32 = a.cst[(unsigned)(5 * nm + t)];
         const double a13 = a.cst[(unsigned)(6 * nm + t)], a23 = a.cst[(unsigned)(7 * nm + t)], a33 = a.cst[(unsigned)(8 * nm + t)];
 #pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            const double u0_1 = s_sc[(4 + l) * NM + m], v0_n = s_sc[(6 + l) * NM + m], du0n = s_sc[(8 + l) * NM + m];
+        for (int l = 0; l < NL; ++l) {
+            const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l);
             v_1[l] = (bb[l] - lam * u0_1) / a11;
             u_n[l] = (bt[l] - v0_n - a21 * v_1[l]) / a22;
             fn[l] = (bt[l] - du0n - a31 * v_1[l] - a32 * u_n[l]) / a33;
@@ -1305,22 +1360,23 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
             v_1[l] = v_1[l] - a12 * u_n[l] - a13 * fn[l];
         }
     }
+#undef SC
     // ---- superposition with the stored homogeneous solutions (opr_odes.f90:358-367); p^ = u, dp^/dy = v ----
-    if (!store) return;
+    if (!store[0] && !store[NQ - 1]) return;
     // The homogeneous solutions decay like exp(-sqrt(lambda) distance from their wall): for all but the lowest modes they are below 1e-40 of
     // their maximum a few tens of rows away from the walls, where adding them changes no bit of the sum.  The plan records that band per
     // mode (k_ode_hom_band); chunks inside it skip the five loads (40 of the 100 B per mode and row this kernel would otherwise move).
     bool need = true;
-    if (a.band != nullptr) need = (j0 <= a.band[t]) || (j0 + OM - 1 >= a.band[nm + t]);
+    if (a.band != nullptr) need = (j0 <= a.band[t]) || (j0 + OMR - 1 >= a.band[nm + t]);
 #pragma unroll
-    for (int p = 0; p < OM; ++p) {
+    for (int p = 0; p < OMR; ++p) {
         const int j = j0 + p;
         const unsigned h = (unsigned)(((t / NM) * 5 * n + j) * NM + m), hs = (unsigned)(n * NM);       // hom_blocked[blk][5][n][NM]
         double hv1 = 0.0, hem = 0.0, hu1 = 0.0, hsp = 0.0, hep = 0.0;
         if (need) { hv1 = a.hom[h]; hem = a.hom[h + hs]; hu1 = a.hom[h + 2 * hs]; hsp = a.hom[h + 3 * hs]; if (!DD) hep = a.hom[h + 4 * hs]; }
-        double uu[2], vv[2];
+        double uu[NL], vv[NL];
 #pragma unroll
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < NL; ++l) {
             const double u0 = u[p][l], v0 = vh[p + 1][l];
             if (DD) {           // :459-465: rows nx .. 2 by the general formula (u0(nx) = bcs(:,2), u1(nx) = sp(nx) = 0), row 1 = the bottom value
                 if (j == 0) {
@@ -1341,9 +1397,13 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
                 vv[l] = v0 + fn[l] * hv1 + v_1[l] * hem + lam * uu[l];
             }
         }
-        const unsigned idx = fidx0 + (unsigned)(j * a.nxh);
-        P[idx] = make_double2(uu[0], uu[1]);
-        D[idx] = make_double2(vv[0], vv[1]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (!store[q]) continue;
+            const unsigned idx = fidx0[q] + (unsigned)(j * a.nxh);
+            P[idx] = make_double2(uu[2 * q], uu[2 * q + 1]);
+            D[idx] = make_double2(vv[2 * q], vv[2 * q + 1]);
+        }
     }
 }
 
@@ -2022,6 +2082,8 @@ struct tlab_poisson_plan {
                                       // homogeneous solutions re-laid out as [blk][5][ny][NM]
     bool use_chunked = false;
     int ode_nm_per_wg = 0;
+    int ode_om = OM;                  // rows per thread of k_ode_nn
+    bool ode_pair = false;            // k_ode_nn on mirror pairs (kx, kz), (kx, nz - kz): lambda symmetric to the bit, checked at creation
     // The lowest-lambda modes of a chunked plan go through a marching sub-plan on the side stream (see build_low_modes)
     std::unique_ptr<tlab_poisson_plan> low;
     DBuf fac[2];                      // sub-plan only: stored LU factors of its two systems (Int1Args::fac)
@@ -2109,6 +2171,8 @@ struct tlab_poisson_plan {
         return d;
     }
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side_low = nullptr;   // the low-mode sub-plan runs beside the singular modes, not behind them
+    hipEvent_t ev_join_low = nullptr;
     ~tlab_poisson_plan() {
         if (d_sing) (void)hipFree(d_sing);
         if (d_skip) (void)hipFree(d_skip);
@@ -2117,6 +2181,8 @@ struct tlab_poisson_plan {
         if (side) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side_low) (void)hipStreamDestroy(side_low);
+        if (ev_join_low) (void)hipEventDestroy(ev_join_low);
         for (KxMap &m : kxmaps) { (void)hipFree(m.off); (void)hipFree(m.w); }
     }
     OdeSys sys(int which) const {
@@ -2192,35 +2258,55 @@ int ode_modes_per_wg(int C) {
     }
     return (nmw * C <= 512) ? nmw : 0;
 }
-size_t ode_lds_bytes(int C, int NM) { return ((size_t)(64 + 4 * C + 10 + OK_SIZE) * NM + (size_t)(3 * OM + 1) * NM * C) * sizeof(double); }
+size_t ode_lds_bytes(int C, int NM, int om = OM, int NL = 2) {
+    return ((size_t)(8 * (4 + 2 * NL) + 2 * NL * C + 5 * NL + OK_SIZE) * NM + (size_t)(3 * om + 1) * NM * C) * sizeof(double);
+}
 
-template <int NM, bool DD>
+template <int NM, bool DD, int OMR = OM, int NL = 2>
 void launch_ode_nm(const OdeArgs &a, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ode_nn<NM, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ode_nn<NM, DD, OMR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         (void)hipGetLastError();
         attr_done = true;
     }
-    const unsigned grid = (unsigned)((a.nm + NM - 1) / NM);
-    hipLaunchKernelGGL((k_ode_nn<NM, DD>), dim3(grid), dim3(NM * a.C), lds, st, a);
+    const long long nlive = NL == 4 ? (long long)a.nxh * (a.nm / a.nxh / 2 + 1) : a.nm;
+    const unsigned grid = (unsigned)((nlive + NM - 1) / NM);
+    hipLaunchKernelGGL((k_ode_nn<NM, DD, OMR, NL>), dim3(grid), dim3(NM * a.C), lds, st, a);
 }
+template <bool DD>
+void launch_ode_pair(const OdeArgs &a, int NM, int om, size_t lds, hipStream_t st) {
+    // 8 rows x 4 lines per thread (256 VGPRs, ~20 of them spilled) beats 4 rows x 4 lines in twice as many chunks (217 VGPRs, but 512-thread
+    // workgroups that do not share a CU and a scan twice as long): 1.86 against 2.83 ms at 512^3, one mode per thread 2.30 (profiles/r03)
+    if (om != OM) throw std::logic_error("k_ode_nn: no pair form for this geometry");
+    switch (NM) {
+    case 4: launch_ode_nm<4, DD, OM, 4>(a, lds, st); break;
+    case 8: launch_ode_nm<8, DD, OM, 4>(a, lds, st); break;
+    case 16: launch_ode_nm<16, DD, OM, 4>(a, lds, st); break;
+    case 32: launch_ode_nm<32, DD, OM, 4>(a, lds, st); break;
+    default: launch_ode_nm<64, DD, OM, 4>(a, lds, st); break;
+    }
+}
+bool ode_pair_geometry(int NM, int om) { return om == OM; }
 
 void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st, bool dd = false) {
     OdeArgs a{};
     a.T1 = P.sys(0); a.T2 = P.sys(1);
     a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = dd ? P.cst_dd.p : P.cst.p; a.hom = P.homb.p; a.band = P.d_hom_band;
     a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
-    a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / OM; a.nm = P.nm;
+    a.n = P.ny; a.nxh = P.nxh; a.ny = P.ny; a.C = P.ny / P.ode_om; a.nm = P.nm;
     const int NM = P.ode_nm_per_wg;
     {
         static int pair = -1;
         if (pair < 0) { const char *e = getenv("TLAB_ODE_PAIR_XCD"); pair = e ? atoi(e) : 1; }
         a.pair_xcd = pair;
     }
-    const size_t lds = ode_lds_bytes(a.C, NM);
+    const size_t lds = ode_lds_bytes(a.C, NM, P.ode_om, P.ode_pair ? 4 : 2);
     ProfScope ps(dd ? "k_ode_nn<DD>" : "k_ode_nn", st, (double)P.nm * P.ny * 48.0);      // algorithmic bytes: f^ in, p^ and dp^/dy out (its own tables -- checkpoints 12 B, the band of the homogeneous solutions -- come on top)
-    if (dd) {
+    if (P.ode_pair) {
+        if (dd) launch_ode_pair<true>(a, NM, P.ode_om, lds, st);
+        else launch_ode_pair<false>(a, NM, P.ode_om, lds, st);
+    } else if (dd) {
         switch (NM) {
         case 4: launch_ode_nm<4, true>(a, lds, st); break;
         case 8: launch_ode_nm<8, true>(a, lds, st); break;
@@ -2252,7 +2338,7 @@ static void launch_int2c(const Int2cArgs &k, size_t lds, hipStream_t st) {
 }
 
 void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
-    const int C = P.ny / OM, NM = P.ode_nm_per_wg;
+    const int C = P.ny / P.ode_om, NM = P.ode_nm_per_wg;
     const long long nblk = (P.nm + NM - 1) / NM;
     for (int w = 0; w < 2; ++w) {
         const Int1Tables &T = w == 0 ? P.tmin : P.tmax;
@@ -2263,8 +2349,8 @@ void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
         P.chk[w].alloc((size_t)C * 6 * nblk * NM);
     }
     const int grid = (int)((P.nm + 255) / 256);
-    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(grid), dim3(256), 0, st, P.sys(0), P.lam.p, 1.0, P.chk[0].p, P.nm, NM, C);
-    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(grid), dim3(256), 0, st, P.sys(1), P.lam.p, -1.0, P.chk[1].p, P.nm, NM, C);
+    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(grid), dim3(256), 0, st, P.sys(0), P.lam.p, 1.0, P.chk[0].p, P.nm, NM, C, P.ode_om);
+    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(grid), dim3(256), 0, st, P.sys(1), P.lam.p, -1.0, P.chk[1].p, P.nm, NM, C, P.ode_om);
     hipc(hipGetLastError(), "k_ode_checkpoint");
     P.homb.alloc((size_t)5 * P.ny * nblk * NM);
     const long long tot = (long long)5 * P.ny * P.nm;
@@ -2291,15 +2377,23 @@ void build_singular_homogeneous(tlab_poisson_plan &P, hipStream_t st) {
 }
 
 // lanes per chunk of the singular-mode kernel: 8 (<= 4 modes in use), 4 when the line has more than 64 chunks (512 threads at most)
-inline int ode_sing_nm(int C) { return C > 64 ? 4 : 8; }
+// 256 threads from 512 rows on: the one workgroup then fits the slot any retiring workgroup of k_ode_nn (256 threads, ~250 VGPRs: two per CU)
+// leaves; with 512 threads it needs a whole CU and waited for the tail of k_ode_nn (measured: 1.84 ms in the queue beside the pair form)
+inline int ode_sing_nm(int C) { return C >= 64 ? 4 : 8; }
+// the streams of the singular / low modes: highest priority, so that their few workgroups are dispatched ahead of the 30000 of k_ode_nn
+static void create_side_stream(hipStream_t *s) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) hipc(hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi), "stream");
+    else { (void)hipGetLastError(); hipc(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "stream"); }
+}
 
 void build_singular_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
     const int ns = (int)P.sing_modes.size();
     if (ns == 0) return;
     const int C = P.ny / OM, NM = ode_sing_nm(C);
     for (int w = 0; w < 2; ++w) P.chk_s[w].alloc((size_t)C * 6 * NM);
-    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(1), dim3(256), 0, st, P.sys(0), P.s_lam.p, 1.0, P.chk_s[0].p, (long long)ns, NM, C);
-    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(1), dim3(256), 0, st, P.sys(1), P.s_lam.p, -1.0, P.chk_s[1].p, (long long)ns, NM, C);
+    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(1), dim3(256), 0, st, P.sys(0), P.s_lam.p, 1.0, P.chk_s[0].p, (long long)ns, NM, C, OM);
+    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(1), dim3(256), 0, st, P.sys(1), P.s_lam.p, -1.0, P.chk_s[1].p, (long long)ns, NM, C, OM);
     hipc(hipGetLastError(), "k_ode_checkpoint (singular)");
 }
 
@@ -2473,7 +2567,7 @@ void build_low_modes(tlab_poisson_plan &P, const std::vector<double> &nodes, con
     L->hom.alloc(5 * n * ns); L->der.alloc(3 * (size_t)ns); L->cst.alloc(9 * (size_t)ns);
     L->scratch.alloc(6 * n * ns);
     L->v0.alloc(2 * n * ns); L->u0.alloc(2 * n * ns); L->du0.alloc(2 * (size_t)ns); L->bcs.alloc(4 * (size_t)ns);
-    hipc(hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking), "stream");
+    create_side_stream(&L->side);
     hipc(hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming), "event");
     hipc(hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming), "event");
     build_homogeneous(*L, st);
@@ -2492,6 +2586,8 @@ void build_low_modes(tlab_poisson_plan &P, const std::vector<double> &nodes, con
     P.n_low = ns;
     P.low_f.alloc(2 * n * ns); P.low_p.alloc(2 * n * ns); P.low_dp.alloc(2 * n * ns);
     P.low = std::move(L);
+    create_side_stream(&P.side_low);
+    hipc(hipEventCreateWithFlags(&P.ev_join_low, hipEventDisableTiming), "event");
 }
 
 }  // namespace
@@ -2636,7 +2732,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                 }
             }
         }
-        hipc(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking), "stream");
+        create_side_stream(&P->side);
         hipc(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming), "event");
         hipc(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), "event");
         hipStream_t st = tlab_current_stream();
@@ -2650,6 +2746,18 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
             if (!P->generic && !(e && atoi(e) == 0) && ny % OM == 0 && C >= 2 && ode_modes_per_wg(C) > 0 && big < (1LL << 31) &&
                 ode_lds_bytes(C, ode_modes_per_wg(C)) <= (size_t)160 * 1024) {
                 P->ode_nm_per_wg = ode_modes_per_wg(C);
+                {   // mirror pairs (see k_ode_nn): TLAB_ODE_PAIR=0 keeps one mode per thread
+                    const char *pe = getenv("TLAB_ODE_PAIR");
+                    const int om = OM;
+                    const int nzm = (int)(nm / P->nxh);
+                    bool sym = !(pe && atoi(pe) == 0) && nzm >= 4 && (om == 4 || om == 8) && ny % om == 0;
+                    for (int kz = 1; sym && kz < nzm; ++kz)
+                        for (long long i = 0; i < P->nxh; ++i) sym = sym && lam[i + P->nxh * kz] == lam[i + P->nxh * (nzm - kz)];
+                    const int Cp = ny / om, NMp = sym ? ode_modes_per_wg(Cp) : 0;
+                    if (sym && NMp > 0 && ode_pair_geometry(NMp, om) && ode_lds_bytes(Cp, NMp, om, 4) <= (size_t)160 * 1024) {
+                        P->ode_pair = true; P->ode_om = om; P->ode_nm_per_wg = NMp;
+                    }
+                }
                 build_checkpoints(*P, st);
                 P->use_chunked = true;
                 if (ode_sing_nm(C) * C <= 512 && (int)P->sing_modes.size() <= ode_sing_nm(C) && ode_lds_bytes(C, ode_sing_nm(C)) <= (size_t)160 * 1024)
@@ -2896,12 +3004,15 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
     if (P->use_chunked && P->low) {                         // the lowest-lambda modes: marching sub-plan, also beside the regular ones
         const int nl = P->n_low;
         const dim3 g((nl + 63) / 64, n), blk(64);
-        hipLaunchKernelGGL(k_modes_gather, g, blk, 0, ss, reinterpret_cast<const double2 *>(f_hat), P->d_low_modes, nl, n, nxh, ny,
+        hipStream_t ls = P->side_low;
+        hipc(hipStreamWaitEvent(ls, P->ev_fork, 0), "stream wait");
+        hipLaunchKernelGGL(k_modes_gather, g, blk, 0, ls, reinterpret_cast<const double2 *>(f_hat), P->d_low_modes, nl, n, nxh, ny,
                            reinterpret_cast<double2 *>(P->low_f.p));
-        poisson_ode_stage(P->low.get(), P->low_f.p, P->low_p.p, P->low_dp.p, ss);
-        hipLaunchKernelGGL(k_modes_scatter, g, blk, 0, ss, reinterpret_cast<const double2 *>(P->low_p.p),
+        poisson_ode_stage(P->low.get(), P->low_f.p, P->low_p.p, P->low_dp.p, ls);
+        hipLaunchKernelGGL(k_modes_scatter, g, blk, 0, ls, reinterpret_cast<const double2 *>(P->low_p.p),
                            reinterpret_cast<const double2 *>(P->low_dp.p), P->d_low_modes, nl, n, nxh, ny, reinterpret_cast<double2 *>(p_hat),
                            reinterpret_cast<double2 *>(dp_hat));
+        hipc(hipEventRecord(P->ev_join_low, ls), "event record");
     }
     if (ns > 0 && P->use_chunked) {
     } else if (ns > 0) {
@@ -2928,6 +3039,7 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
     // v-solve first when p_hat aliases it: order the scatter after it through the main stream
     hipc(hipEventRecord(P->ev_join, ss), "event record");
     hipc(hipStreamWaitEvent(st, P->ev_join, 0), "stream wait");
+    if (P->use_chunked && P->low) hipc(hipStreamWaitEvent(st, P->ev_join_low, 0), "stream wait");
     if (ns > 0 && !P->use_chunked) {
         dim3 g(ns, (n + 63) / 64), blk(64);
         hipLaunchKernelGGL(k_sing_combine, g, blk, 0, st, P->s_u0.p, P->s_v0.p, P->s_u1.p, P->s_v1.p, P->s_du0.p, P->s_du1.p,
