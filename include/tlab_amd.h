@@ -115,7 +115,10 @@ int tlab_fdm_plan_destroy(tlab_fdm_plan_t p);
  *  7 der2%lhs(n,5) 8 der2%rhs(n,12) 9 der2%lu(n,5|3) 10 der2%mwn(n) 11 jac(n,3) 12 intl%lu0i(n,5) 13 intl%lu1i(n,5)
  * returns the number of doubles written (or <0). */
 int tlab_fdm_plan_get(tlab_fdm_plan_t p, int which, double *buf, int nbuf);
-int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what); /* 0 n, 1 ndl1, 2 ndr1, 3 ndl2, 4 ndr2, 5 need_1der, 6 periodic, 7 staggered */
+int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what); /* 0 n, 1 ndl1, 2 ndr1, 3 ndl2, 4 ndr2, 5 need_1der, 6 periodic, 7 staggered; after tlab_init:
+                                                        * 8 chunks per x line of the wave-per-line kernel (64 one wave, 128 / 256 two / four waves
+                                                        * per line, 0 another kernel), 9 whether all those chunks share one set of tables (1: an
+                                                        * exactly uniform grid, scalar loads; 0: per-chunk tables staged in LDS) */
 
 /* ---- operators ----------------------------------------------------------------------------- */
 /* OPR_Partial_X/Y/Z(type, nx, ny, nz, bcs, g, u, result, tmp1)   operators/opr_partial.f90:31,266,154

@@ -343,6 +343,56 @@ def test_x_lines_of_2048_take_the_wave_per_line_kernel(T):
     assert rel_err(r.cpu().numpy(), O.opr_partial(1, 1, nx, ny, nz, 0, ogs, u)[0]) <= 1e-12
 
 
+@pytest.mark.parametrize("nx", [1024, 2048])
+@pytest.mark.parametrize("wander", [False, True])
+def test_x_lines_on_several_waves_both_table_forms(T, nx, wander):
+    """x lines of 1024 / 2048 points on 2 / 4 waves (8 rows per lane); the two-system forms keep the per-lane constants of the separator reduction
+    in LDS.  wander = False: tables whose rows are all the same (2048 points, two systems: scalar loads of chunk 0's rows, no table in LDS);
+    True: rows that differ by ~1e-13 like the reference's own tables of a "uniform" grid (per-chunk tables in LDS: doubles, or chunk 0 + float
+    differences).  All operator types and the 4-field Burgers launch against the oracle working from the same tables."""
+    import ctypes
+    import torch
+    from oracle import tlab_oracle as O
+    from tlab_amd.lib import load, check, c_vp
+    L = load()
+    ny, nz = 6, 5
+    x = np.arange(nx) / nx * 2.0
+    og = O.FdmPlan(x, True, True)
+    rng = np.random.default_rng(nx)
+    w = 1.0 + 1e-13 * rng.uniform(-1, 1, nx) if wander else np.ones(nx)
+    mid = nx // 2           # every row = the middle row (exactly uniform), times what a per-row Jacobian does to the tables
+    for dp, ww in ((og.der1, w), (og.der2, w * w)):
+        dp.lhs = np.tile(dp.lhs[mid], (nx, 1)) * ww[:, None]
+        dp.rhs = np.tile(dp.rhs[mid], (nx, 1)) * ww[:, None]
+        ndl = dp.nb_diag[0]
+        cols = [dp.lhs[:, k].copy() if k < ndl else np.zeros(nx) for k in range(ndl + 2)]
+        O.tridpfs(*cols)
+        dp.lu = np.stack(cols, axis=1)
+    g = T.FdmPlan.from_arrays(nx, True, 0, og.der1.lhs, og.der1.rhs[:, :og.der1.nb_diag[1]], og.der2.lhs, og.der2.rhs[:, :og.der2.nb_diag[1] + 3])
+    assert L.tlab_fdm_plan_info(g._h, 8) == nx // 8 and L.tlab_fdm_plan_info(g._h, 9) == (0 if wander else 1)
+    rng = np.random.default_rng(nx + 1)
+    N = nx * ny * nz
+    f = [rng.uniform(-1, 1, N) for _ in range(4)]
+    d = [torch.from_numpy(a).cuda() for a in f]
+    r = torch.zeros(N, dtype=torch.float64, device="cuda"); t = torch.zeros_like(r)
+    for typ in (1, 2, 3):
+        T.OPR_Partial_X(typ, nx, ny, nz, 0, g, d[0], r, t)
+        assert L.tlab_last_kernel_path() == 2
+        ro, to = O.opr_partial(1, typ, nx, ny, nz, 0, og, f[0])
+        assert rel_err(r.cpu().numpy(), ro) <= 1e-12, typ
+        if typ == 3:
+            assert rel_err(t.cpu().numpy(), to) <= 1e-12
+    h = [torch.from_numpy(rng.uniform(-1, 1, N)).cuda() for _ in range(4)]
+    h0 = [a.cpu().numpy().copy() for a in h]
+    nu = (ctypes.c_double * 4)(2e-4, 3e-4, 4e-4, 5e-4)
+    sp = (c_vp * 4)(*[a.data_ptr() for a in d])
+    hp = (c_vp * 4)(*[a.data_ptr() for a in h])
+    check(L.tlab_opr_burgers_add_n(1, g._h, nx, ny, nz, 0, 4, nu, sp, d[0].data_ptr(), hp, r.data_ptr(), t.data_ptr(), 0), "burgers_add_n")
+    for i in range(4):
+        ref = h0[i] + O.opr_burgers(1, nx, ny, nz, 0, og, nu[i], f[i], f[0])[0]
+        assert rel_err(h[i].cpu().numpy(), ref) <= 1e-12, i
+
+
 @pytest.mark.parametrize("d", [2, 3])
 def test_lines_of_1024_points_fused_on_16_line_tiles(T, d):
     """BASELINE configs[3]/[4]: y / z lines of 1024 points.  OPR_P2_P1 and OPR_Burgers keep two line-sets in registers on 16-line tiles

@@ -334,9 +334,8 @@ SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
             for (int j = 1; j < 64; ++j)
                 if (!close(red[(size_t)q * 64 + j], red[(size_t)q * 64])) { inv = false; break; }
         e->red.upload(red);
-    } else if (P == 128 || P == 256) {      // several waves per line: two-level reduction tables [21][P] (chunked.hpp); per-lane by construction
-        if (h.tl_waves * 64 != P) throw std::runtime_error("two-level separator tables unavailable for this system");
-        inv = false;
+    } else if (P == 128 || P == 256) {      // several waves per line: two-level reduction tables [21][P] (chunked.hpp), per-lane by construction
+        if (h.tl_waves * 64 != P) throw std::runtime_error("two-level separator tables unavailable for this system");      // (inv: the row tables only)
         e->red.upload(h.tl);
     } else {
         e->red.upload(h.ginv);
@@ -516,8 +515,19 @@ int tlab_fdm_plan_destroy(tlab_fdm_plan_t p) {
     return TLAB_OK;
 }
 
+namespace { int xline_chunks(int n, tlab_fdm_plan_t g); }
 int tlab_fdm_plan_info(tlab_fdm_plan_t p, int what) {
     if (!p) return TLAB_EINVAL;
+    if (what == 8 || what == 9) {      // the x-line kernel's view of the plan (builds the chunked tables on first use: needs tlab_init)
+        try {
+            const int P = xline_chunks(p->t.n, p);
+            if (what == 8 || P == 0) return P;
+            return (p->system(1, 0, P).lane_invariant && p->system(2, 0, P).lane_invariant) ? 1 : 0;
+        } catch (const std::exception &e) {
+            tlab_set_error(e.what());
+            return TLAB_EINVAL;
+        }
+    }
     switch (what) {
     case 0: return p->t.n;
     case 1: return p->t.der1.ndl;

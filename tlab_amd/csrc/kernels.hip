@@ -102,74 +102,84 @@ __device__ __forceinline__ void xhalo(XCtx<WPL> &c, const double (&u)[M], double
     }
 }
 
-template <int WPL>
+// CL: the 23 per-lane constants below live in LDS ([XRED][64 WPL], staged once per workgroup and shared by its lines) instead of 46 VGPRs per
+// system: the several-waves-per-line forms then fit two waves per SIMD
+constexpr int XRED = 23;         // rows: 0-5 k1, 6-11 k2, 12 dinv, 13-20 vs ws wL vF dn wLp vFm dp, 21 a_s, 22 c_s
+template <int WPL, bool CL = false>
 struct XSys {                    // per-lane view of one chunked system
     const double *rowtab;        // global [5][n]
     const double *lds;           // LV: [5][M][64 WPL] in LDS
-    double k1[6], k2[6], dinv;   // PCR coefficients of this lane (WPL = 1: cyclic over the 64 chunks; WPL > 1: of the wave's isolated block)
+    double k1[CL ? 1 : 6], k2[CL ? 1 : 6], dinv;   // PCR coefficients of this lane (WPL = 1: cyclic over the 64 chunks; WPL > 1: of the wave's isolated block)
     double a_s, c_s;             // separator-row couplings of this lane
     double vs, ws, wL, vF, dn, wLp, vFm, dp;      // WPL > 1: two-level reduction (chunked.hpp)
+    const double *red;           // CL: this lane's column of the constants in LDS (stride 64 WPL)
 };
 
 // LV = 0: every chunk has the same tables (scalar loads of chunk 0); 1: lane-variant tables [5][M][P] doubles in LDS; 2: lane-variant tables
 // kept as chunk 0's value (scalar load) + a float difference in LDS -- where two systems of doubles do not fit (n >= 1024 with both systems).
 // The reconstruction is exact when the chunks differ by less than 2^-29 relative (the 1e-13 wander of a "uniform" reference grid): the plan
 // checks every entry on the host (xline_wide_ok, capi.cpp) and takes another kernel otherwise.
-template <int M, int LV, int WPL>
-__device__ __forceinline__ double xcoef(const XSys<WPL> &y, int tab, int p, int gl, int n) {
+template <int M, int LV, int WPL, bool CL>
+__device__ __forceinline__ double xcoef(const XSys<WPL, CL> &y, int tab, int p, int gl, int n) {
     constexpr int P = 64 * WPL;
     if (LV == 1) return y.lds[(tab * M + p) * P + gl];
     if (LV == 2) return y.rowtab[tab * n + p] + (double)reinterpret_cast<const float *>(y.lds)[(tab * M + p) * P + gl];
     return y.rowtab[tab * n + p];  // lane-invariant: chunk 0's row p, wave-uniform address -> scalar load
 }
 
-template <int M, int LV, int WPL>
-__device__ __forceinline__ void xsys_init(XSys<WPL> &y, const SystemDev &sd, const double *lds, int gl, int n) {
+template <int M, int LV, int WPL, bool CL>
+__device__ __forceinline__ void xsys_init(XSys<WPL, CL> &y, const SystemDev &sd, const double *lds, const double *red_lds, int gl, int n) {
     constexpr int P = 64 * WPL;
     y.rowtab = sd.rowtab;
     y.lds = lds;
-    const int src = (LV || WPL > 1) ? gl : 0;
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        y.k1[s] = sd.red[s * P + src];
-        y.k2[s] = sd.red[(6 + s) * P + src];
+    y.red = red_lds + gl;
+    if constexpr (!CL) {
+        const int src = (LV || WPL > 1) ? gl : 0;
+    #pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            y.k1[s] = sd.red[s * P + src];
+            y.k2[s] = sd.red[(6 + s) * P + src];
+        }
+        y.dinv = sd.red[12 * P + src];
+        if constexpr (WPL > 1) {
+            y.vs = sd.red[13 * P + src]; y.ws = sd.red[14 * P + src];
+            y.wL = sd.red[15 * P + src]; y.vF = sd.red[16 * P + src]; y.dn = sd.red[17 * P + src];
+            y.wLp = sd.red[18 * P + src]; y.vFm = sd.red[19 * P + src]; y.dp = sd.red[20 * P + src];
+        }
+        y.a_s = sd.rowtab[0 * n + (LV ? gl * M : 0)];
+        y.c_s = sd.rowtab[2 * n + (LV ? gl * M : 0)];
+    
     }
-    y.dinv = sd.red[12 * P + src];
-    if constexpr (WPL > 1) {
-        y.vs = sd.red[13 * P + src]; y.ws = sd.red[14 * P + src];
-        y.wL = sd.red[15 * P + src]; y.vF = sd.red[16 * P + src]; y.dn = sd.red[17 * P + src];
-        y.wLp = sd.red[18 * P + src]; y.vFm = sd.red[19 * P + src]; y.dp = sd.red[20 * P + src];
-    }
-    y.a_s = sd.rowtab[0 * n + (LV ? gl * M : 0)];
-    y.c_s = sd.rowtab[2 * n + (LV ? gl * M : 0)];
 }
 
 // f[0..M-1] (this lane's chunk of the right-hand side) -> solution, in place
-template <int M, int LV, int WPL>
-__device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL> &y, XCtx<WPL> &c, int n) {
+template <int M, int LV, int WPL, bool CL>
+__device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL, CL> &y, XCtx<WPL> &c, int n) {
+    constexpr int P = 64 * WPL;
     const int gl = c.gl, lane = c.lane;
+#define XR(row) y.red[(row) * P]
     double g = 0.0;
 #pragma unroll
     for (int p = 1; p < M; ++p) {
-        g = f[p] + xcoef<M, LV, WPL>(y, 0, p, gl, n) * g;
+        g = f[p] + xcoef<M, LV, WPL, CL>(y, 0, p, gl, n) * g;
         f[p] = g;
     }
     double yn = 0.0;
 #pragma unroll
     for (int p = M - 1; p >= 1; --p) {
-        yn = f[p] * xcoef<M, LV, WPL>(y, 1, p, gl, n) + xcoef<M, LV, WPL>(y, 2, p, gl, n) * yn;
+        yn = f[p] * xcoef<M, LV, WPL, CL>(y, 1, p, gl, n) + xcoef<M, LV, WPL, CL>(y, 2, p, gl, n) * yn;
         f[p] = yn;
     }
     const double yLprev = xprev<WPL>(c, f[M - 1]);
-    double r = f[0] - y.a_s * yLprev - y.c_s * f[1];
+    double r = f[0] - (CL ? XR(21) : y.a_s) * yLprev - (CL ? XR(22) : y.c_s) * f[1];
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const int d = 1 << s;
         const double rl = shfl_d(r, (lane - d) & 63);
         const double rr = shfl_d(r, (lane + d) & 63);
-        r = r - y.k1[s] * rl - y.k2[s] * rr;       // WPL > 1: the coefficients of neighbours outside the wave's block are zero
+        r = r - (CL ? XR(s) : y.k1[CL ? 0 : s]) * rl - (CL ? XR(6 + s) : y.k2[CL ? 0 : s]) * rr;       // WPL > 1: the coefficients of neighbours outside the wave's block are zero
     }
-    double X = r * y.dinv, Xr;
+    double X = r * (CL ? XR(12) : y.dinv), Xr;
     if constexpr (WPL == 1) {
         Xr = shfl_d(X, (lane + 1) & 63);
     } else {
@@ -180,16 +190,17 @@ __device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL> &y, XCtx<
         const double YpL = b[((c.wl + WPL - 1) & (WPL - 1)) * 4 + 2], YnF = b[((c.wl + 1) & (WPL - 1)) * 4 + 1];
         const double myF = b[c.wl * 4 + 1], myL = b[c.wl * 4 + 2];
         c.par ^= 1;
-        const double XL = (myL - y.wL * YnF) * y.dn;          // last unknown of this wave and first one of the next: 2 x 2 interface system
-        const double XnF = YnF - y.vF * XL;
-        const double XpL = (YpL - y.wLp * myF) * y.dp;        // last unknown of the previous wave (its interface with this one)
-        X = X - y.vs * XpL - y.ws * XnF;
+        const double XL = (myL - (CL ? XR(15) : y.wL) * YnF) * (CL ? XR(17) : y.dn);          // last unknown of this wave and first one of the next: 2 x 2 interface system
+        const double XnF = YnF - (CL ? XR(16) : y.vF) * XL;
+        const double XpL = (YpL - (CL ? XR(18) : y.wLp) * myF) * (CL ? XR(20) : y.dp);        // last unknown of the previous wave (its interface with this one)
+        X = X - (CL ? XR(13) : y.vs) * XpL - (CL ? XR(14) : y.ws) * XnF;
         Xr = shfl_d(X, (lane + 1) & 63);
         if (lane == 63) Xr = XnF;
     }
     f[0] = X;
 #pragma unroll
-    for (int p = 1; p < M; ++p) f[p] = f[p] + xcoef<M, LV, WPL>(y, 3, p, gl, n) * X + xcoef<M, LV, WPL>(y, 4, p, gl, n) * Xr;
+    for (int p = 1; p < M; ++p) f[p] = f[p] + xcoef<M, LV, WPL, CL>(y, 3, p, gl, n) * X + xcoef<M, LV, WPL, CL>(y, 4, p, gl, n) * Xr;
+#undef XR
 }
 
 // f = B u for this lane's chunk; um/up are the 3-point halos from the neighbouring lanes
@@ -254,8 +265,9 @@ __device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)
 }
 
 // LV / LV2: table form of the first- / second-derivative system (see xcoef)
-template <int M, int MODE, int LV, int WPL, int LV2 = LV, int TPB = 256>
+template <int M, int MODE, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false>
 __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
+    static_assert(!CL || WPL > 1, "constants in LDS: several waves per line only");
     extern __shared__ double xlds[];
     constexpr bool NEED1 = (MODE != MODE_P2);
     constexpr bool NEED2 = (MODE != MODE_P1);
@@ -290,14 +302,26 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
     if (NEED2) stage(a.y2.rowtab, lds2, LV2);
     XCtx<WPL> cx;
     cx.lane = lane; cx.gl = gl; cx.wl = wl; cx.par = 0; cx.eb = nullptr; cx.hb = nullptr;
+    constexpr size_t REDW = CL ? (size_t)XRED * P : 0;        // per-lane constants of one system
+    double *red1 = xlds + ((NEED1 ? TABW1 : 0) + (NEED2 ? TABW2 : 0)), *red2 = red1 + (NEED1 ? REDW : 0);
+    if constexpr (CL) {
+        auto stage_red = [&](const SystemDev &sd, double *d, int lv) {
+            for (int idx = threadIdx.x; idx < XRED * P; idx += blockDim.x) {
+                const int l = idx % P, k = idx / P;
+                d[idx] = k < 21 ? sd.red[k * P + l] : sd.rowtab[(k == 21 ? 0 : 2) * n + (lv ? l * M : 0)];
+            }
+        };
+        if (NEED1) stage_red(a.y1, red1, LV);
+        if (NEED2) stage_red(a.y2, red2, LV2);
+    }
     if constexpr (WPL > 1) {
-        double *ex = xlds + ((NEED1 ? TABW1 : 0) + (NEED2 ? TABW2 : 0)) + (size_t)lib * (14 * WPL);
+        double *ex = xlds + ((NEED1 ? TABW1 : 0) + (NEED2 ? TABW2 : 0)) + (NEED1 ? REDW : 0) + (NEED2 ? REDW : 0) + (size_t)lib * (14 * WPL);
         cx.eb = ex; cx.hb = ex + 8 * WPL;
     }
     if (LV != 0 || LV2 != 0 || WPL > 1) __syncthreads();
-    XSys<WPL> y1, y2;
-    if (NEED1) xsys_init<M, LV, WPL>(y1, a.y1, lds1, gl, n);
-    if (NEED2) xsys_init<M, LV2, WPL>(y2, a.y2, lds2, gl, n);
+    XSys<WPL, CL> y1, y2;
+    if (NEED1) xsys_init<M, LV, WPL, CL>(y1, a.y1, lds1, red1, gl, n);
+    if (NEED2) xsys_init<M, LV2, WPL, CL>(y2, a.y2, lds2, red2, gl, n);
 
     const long long stride = (long long)gridDim.x * LPB;
     // software pipeline over the lines of this workgroup: the operand of the NEXT line is requested before the solves of this one (with few
@@ -362,9 +386,9 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
                 xhalo<M, WPL>(cx, u, um, up);
                 double x1[M], x2[M];
                 xsten<M, false, WPL>(x1, u, um, up, a.s1, lane);
-                xsolve<M, LV, WPL>(x1, y1, cx, n);
+                xsolve<M, LV, WPL, CL>(x1, y1, cx, n);
                 xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
-                xsolve<M, LV2, WPL>(x2, y2, cx, n);
+                xsolve<M, LV2, WPL, CL>(x2, y2, cx, n);
 #pragma unroll
                 for (int p = 0; p < M; ++p) x2[p] = nuf * x2[p] - v[p] * x1[p];      // opr_burgers.f90:513
                 if (a.acc) {
@@ -379,7 +403,7 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
                         for (int p = 0; p < M; ++p) wq[p] = x2[p] + v[p] * a.fidte;
                         xhalo<M, WPL>(cx, wq, um, up);
                         xsten<M, false, WPL>(x1, wq, um, up, a.s1, lane);
-                        xsolve<M, LV, WPL>(x1, y1, cx, n);
+                        xsolve<M, LV, WPL, CL>(x1, y1, cx, n);
                         if (live) xstore<M>(a.fdiv + off, x1);
                     }
                     if (a.ffin[f]) {          // the tendency of this field is complete: wall planes, Runge-Kutta update, scaling (k_final_update's arithmetic)
@@ -438,11 +462,11 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
             double x1[M], x2[M];
             if (NEED1) {
                 xsten<M, false, WPL>(x1, u, um, up, a.s1, lane);
-                xsolve<M, LV, WPL>(x1, y1, cx, n);
+                xsolve<M, LV, WPL, CL>(x1, y1, cx, n);
             }
             if (NEED2) {
                 xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
-                xsolve<M, LV2, WPL>(x2, y2, cx, n);
+                xsolve<M, LV2, WPL, CL>(x2, y2, cx, n);
             }
             if (!live) continue;                     // (WPL > 1: after the last barrier of this line)
             if constexpr (MODE == MODE_P1) {
@@ -887,14 +911,16 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a,
 // ============================================================================================
 static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
 
-template <int M, int LV, int WPL, int LV2 = LV, int TPB = 256>
+template <int M, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false>
 static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     constexpr int P = 64 * WPL, LPB = TPB / 64 / WPL;
     const long long blocks_needed = (a.nlines + LPB - 1) / LPB;
     const int grid = imin(blocks_needed, 256 * 8 * 256 / TPB);
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
     auto tabbytes = [](int lv) { return lv == 1 ? (size_t)5 * M * P * sizeof(double) : lv == 2 ? (size_t)5 * M * P * sizeof(float) : (size_t)0; };
-    const size_t lds = (mode != MODE_P2 ? tabbytes(LV) : 0) + (mode != MODE_P1 ? tabbytes(LV2) : 0) + (WPL > 1 ? (size_t)LPB * 14 * WPL * sizeof(double) : 0);
+    const size_t redbytes = CL ? (size_t)XRED * P * sizeof(double) : 0;
+    const size_t lds = (mode != MODE_P2 ? tabbytes(LV) + redbytes : 0) + (mode != MODE_P1 ? tabbytes(LV2) + redbytes : 0) +
+                       (WPL > 1 ? (size_t)LPB * 14 * WPL * sizeof(double) : 0);
     const double pts = (double)a.nlines * P * M;
     static const char *names[5] = {"", "k_xline<P1>", "k_xline<P2>", "k_xline<P2_P1>", "k_xline<BURGERS>"};
     const double bpp[5] = {0, 16, 16, 24, 24};
@@ -906,18 +932,18 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     ProfScope ps(names[mode], st, bytes);
     switch (mode) {
-    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
     }
     return hipGetLastError();
 }
@@ -937,11 +963,23 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
     // table forms on several waves per line: doubles in LDS where they fit (1024 points: both systems, 80 KB; 2048 points: one system, 80 KB),
     // the second-derivative system of the two-system modes at 2048 points as float differences (40 KB) -- the reconstruction costs a scalar
     // load, a conversion and an add per coefficient, which is why doubles are preferred
-    if (chunks == 128 && n == 1024) return launch_xline_m<8, 1, 2, 1>(mode, a, st);
+    // Two-system modes keep the per-lane constants of the separator reduction in LDS (CL) where the tables leave room: 254 -> ~245 VGPRs without
+    // the 60-110 AGPRs, i.e. two waves per SIMD, on 512 threads (4 lines share the tables): fused 4-field Burgers at 1024 points 3.09 -> 3.41 TB/s.
+    // Per-chunk tables in LDS beat scalar loads of chunk 0's rows even where every chunk has the same rows (measured with exactly uniform
+    // tables: 512 points 4.55 against 3.87 TB/s, 1024 points 3.41 against 3.05), so only the 2048-point two-system forms -- whose per-chunk
+    // tables (120 KB) leave no room for the constants -- take the scalar-load form when the tables allow it (3.12 against 2.46 TB/s).
+    // Tables made by FDM_CreatePlan never do: its numerically derived "uniform" spacing wanders by ~1e-13 (see tlab_fdm_plan::system).
+    static const int tpb = [] { const char *e = getenv("TLAB_XLINE_TPB"); return e ? atoi(e) : 0; }();
+    const bool one_sys = (mode == MODE_P1 || mode == MODE_P2);       // ~150 VGPRs with the constants in registers: three waves per SIMD anyway
+    if (chunks == 128 && n == 1024) {
+        if (one_sys) return launch_xline_m<8, 1, 2, 1>(mode, a, st);
+        return tpb == 256 ? launch_xline_m<8, 1, 2, 1, 256, true>(mode, a, st) : launch_xline_m<8, 1, 2, 1, 512, true>(mode, a, st);
+    }
+    if (chunks == 256 && n == 2048 && !lane_variant && !one_sys)
+        return tpb == 256 ? launch_xline_m<8, 0, 4, 0, 256, true>(mode, a, st) : launch_xline_m<8, 0, 4, 0, 512, true>(mode, a, st);
     if (chunks == 256 && n == 2048)
         // one system (80 KB of tables): two lines per 512-thread workgroup share them, i.e. 8 waves per CU instead of 4
     {
-        static const int tpb = [] { const char *e = getenv("TLAB_XLINE_TPB"); return e ? atoi(e) : 0; }();
         const bool one = (mode == MODE_P1 || mode == MODE_P2);
         if (tpb == 256) return one ? launch_xline_m<8, 1, 4, 1, 256>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 256>(mode, a, st);
         if (tpb == 512) return one ? launch_xline_m<8, 1, 4, 1, 512>(mode, a, st) : launch_xline_m<8, 1, 4, 2, 512>(mode, a, st);
@@ -952,7 +990,7 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
     if (chunks != 64) return hipErrorInvalidValue;
     switch (n) {
     case 256: return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);
-    case 512: return lane_variant ? launch_xline_m<8, 1, 1>(mode, a, st) : launch_xline_m<8, 0, 1>(mode, a, st);
+    case 512: return launch_xline_m<8, 1, 1>(mode, a, st);         // (scalar loads of common rows are slower: see above)
     case 1024: return lane_variant ? launch_xline_m<16, 1, 1>(mode, a, st) : launch_xline_m<16, 0, 1>(mode, a, st);
     case 2048: return lane_variant ? launch_xline_m<32, 2, 1>(mode, a, st) : launch_xline_m<32, 0, 1>(mode, a, st);     // the caller checked xline_wide_ok
     }

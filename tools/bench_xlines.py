@@ -32,6 +32,8 @@ def timeit(fn, iters=12, warmup=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grids", default="512x512x512,1024x512x128,2048x1024x64")
+    ap.add_argument("--exact-uniform", action="store_true", help="A/B: a plan whose table rows are all the middle row of the generated ones (every "
+                    "chunk then has the same tables: scalar loads instead of per-lane tables in LDS)")
     args = ap.parse_args()
     T.init(0)
     L = load()
@@ -40,12 +42,15 @@ def main():
         nx, ny, nz = (int(v) for v in spec.split("x"))
         N = nx * ny * nz
         g = T.FdmPlan(np.arange(nx) / nx * 2.0, True, True)
+        if args.exact_uniform:
+            tabs = [np.tile(g.table(k)[nx // 2], (nx, 1)) for k in ("lhs1", "rhs1", "lhs2", "rhs2")]
+            g = T.FdmPlan.from_arrays(nx, True, 0, tabs[0], tabs[1][:, :g.info(2)], tabs[2], tabs[3][:, :g.info(4) + 3])
         gen = torch.Generator(device="cuda"); gen.manual_seed(nx)
         f = [torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) for _ in range(4)]
         h = [torch.zeros(N, dtype=torch.float64, device="cuda") for _ in range(4)]
         tmp = torch.empty(N, dtype=torch.float64, device="cuda")
         tmp2 = torch.empty(N, dtype=torch.float64, device="cuda")
-        rec = {"grid": [nx, ny, nz], "wide": os.environ.get("TLAB_XLINE_WIDE", "1")}
+        rec = {"grid": [nx, ny, nz], "wide": os.environ.get("TLAB_XLINE_WIDE", "1"), "chunks": g.info(8), "same_tables_in_every_chunk": g.info(9)}
         ms = timeit(lambda: T.OPR_Partial_X(T.OPR_P1, nx, ny, nz, 0, g, f[0], h[0], tmp))
         rec["P1"] = {"ms": ms, "GBps": 16.0 * N / ms / 1e6}
         ms = timeit(lambda: T.OPR_Partial_X(T.OPR_P2_P1, nx, ny, nz, 0, g, f[0], h[0], tmp))
