@@ -2380,10 +2380,13 @@ void build_singular_homogeneous(tlab_poisson_plan &P, hipStream_t st) {
 // 256 threads from 512 rows on: the one workgroup then fits the slot any retiring workgroup of k_ode_nn (256 threads, ~250 VGPRs: two per CU)
 // leaves; with 512 threads it needs a whole CU and waited for the tail of k_ode_nn (measured: 1.84 ms in the queue beside the pair form)
 inline int ode_sing_nm(int C) { return C >= 64 ? 4 : 8; }
-// the streams of the singular / low modes: highest priority, so that their few workgroups are dispatched ahead of the 30000 of k_ode_nn
+// the streams of the singular / low modes.  NOT high-priority ones: the presence of a high-priority stream in the process slowed every kernel of
+// the normal streams on this stack (measured A/B on one box: substep 17.7 -> 21.9 ms, k_fftz 0.53 -> 0.66 ms; 8 loopback slabs 30.6 -> 62.9 ms);
+// TLAB_SIDE_PRIORITY=1 brings it back for experiments
 static void create_side_stream(hipStream_t *s) {
     int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) hipc(hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi), "stream");
+    static const bool prio = [] { const char *e = getenv("TLAB_SIDE_PRIORITY"); return e && atoi(e) != 0; }();
+    if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) hipc(hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi), "stream");
     else { (void)hipGetLastError(); hipc(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "stream"); }
 }
 

@@ -34,7 +34,8 @@ int tlab_internal_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny
                                   const double *head_right, double *result, int acc);
 int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s,
                                     const double *const *s_lo, const double *const *s_hi, const double *vel, double *head, double *tail,
-                                    const double *tail_left, const double *head_right, double *const *result, int acc);
+                                    const double *tail_left, const double *head_right, double *const *result, int acc, const int *fin, double dte,
+                                    double kco, int scale);
 int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *const *p_halo, const double *tail_left,
                                          const double *head_right, double *q, double *h, double dte, double kco, int scale);
 
@@ -238,17 +239,23 @@ void badd_all(D *d, Rank &R, int dir, bool overwrite) {
            "tlab_opr_burgers_add_n");
     }
 }
-void zburgers_all(D *d, Rank &R, int phase) {
+// fin (phase 2): equations whose tendency is complete with the z term and whose walls are Dirichlet (the scalars on the last pass of a substep)
+// take their Runge-Kutta update in the epilogue of the kernel
+void zburgers_all(D *d, Rank &R, int phase, const std::vector<int> *fin = nullptr, double dte = 0.0, double kco = 1.0, int scale = 0) {
     const std::vector<Eq> E = eqs(d, R);
     for (size_t e0 = 0; e0 < E.size(); e0 += 4) {
         const int nf = (int)std::min<size_t>(4, E.size() - e0);
         double nus[4];
         const double *sp[4];
         double *rp[4];
-        for (int f = 0; f < nf; ++f) { nus[f] = E[e0 + f].nu; sp[f] = E[e0 + f].f; rp[f] = E[e0 + f].h; }
+        int fl[4] = {0, 0, 0, 0};
+        for (int f = 0; f < nf; ++f) {
+            nus[f] = E[e0 + f].nu; sp[f] = E[e0 + f].f; rp[f] = E[e0 + f].h;
+            if (fin && phase == 2) fl[f] = (*fin)[e0 + f];
+        }
         const long long o = 2 * (long long)e0 * d->npage;
         ok(tlab_internal_zslab_burgers_z_n(R.zplan, phase, d->nx, d->ny, nf, nus, sp, &R.lo[e0], &R.hi[e0], phase == 2 ? R.q[2] : nullptr, R.head + o,
-                                           R.tail + o, R.tail_left + o, R.head_right + o, phase == 2 ? rp : nullptr, 1),
+                                           R.tail + o, R.tail_left + o, R.head_right + o, phase == 2 ? rp : nullptr, 1, fl, dte, kco, scale),
            "tlab_zslab_burgers_z_n");
     }
 }
@@ -440,7 +447,11 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     w = msg_start(d, 2 * (3 + ns));
     for (Rank &R : d->rk) badd_all(d, R, 2, false);
     twait(d, w);
-    for (Rank &R : d->rk) zburgers_all(d, R, 2);
+    // scalars with Dirichlet walls are finished by the z pass itself (TLAB_SLAB_FUSED_X=0: separate update, the Python driver's sequence)
+    std::vector<int> zfin((size_t)(3 + ns), 0);
+    for (int i = 0; i < ns; ++i)
+        zfin[3 + i] = tail && d->fused_x && d->scal_jmin[i] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[i] == TLAB_DNS_BCS_DIRICHLET;
+    for (Rank &R : d->rk) zburgers_all(d, R, 2, &zfin, tdte, kco, scale);
     // ---- pressure forcing: div(hq + q/dte) (:188-260) ----
     const double idte = 1.0 / dte;
     w = halo_start(d, 1, [&](Rank &R, int) { return Slot{R.hq[2], S_HQ3}; });          // w's halo planes are still valid
@@ -470,7 +481,8 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
         };
         std::vector<Fd> F;
         for (int i = 0; i < 3; ++i) F.push_back({R.q[i], R.hq[i], R.txc[1 + i], d->flow_jmin[i], d->flow_jmax[i]});
-        for (int i = 0; i < ns; ++i) F.push_back({R.s[i], R.hs[i], nullptr, d->scal_jmin[i], d->scal_jmax[i]});
+        for (int i = 0; i < ns; ++i)
+            if (!zfin[3 + i]) F.push_back({R.s[i], R.hs[i], nullptr, d->scal_jmin[i], d->scal_jmax[i]});
         if (grad_final) F.erase(F.begin() + 2), F.erase(F.begin());          // v and the scalars; u, w are done
         if (v_final) F.erase(F.begin());                                     // the scalars
         if (!grad_final && (!vel_dirichlet || !tail)) {

@@ -75,6 +75,9 @@ struct ZSlabArgs {
     const double *fs[4];
     double *fo[4];
     double fnu[4];
+    // Burgers phase B: ffin[f] != 0: the tendency of field f is complete with this term -> wall planes, Runge-Kutta update of the operand in
+    // place, scaling (k_final_update's arithmetic with Dirichlet walls; the scalars of the slab driver, whose z term comes last)
+    int ffin[4];
     // MODE_P1 phase B "final update" epilogue (fq != NULL), as in k_xline / k_rtile: out0 = tendency h, hv = h - d/dz, walls, q += dte hv
     double *fq;
     double fdte, fkco;
@@ -234,6 +237,17 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
                 for (int p = 0; p < M; ++p) o[p] = __builtin_nontemporal_load(&out0[base + (long long)(row0 + p) * rs]);
 #pragma unroll
                 for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
+            }
+            if (a.ffin[fi]) {
+                const int j = (int)((line / a.fnx) % a.fny);
+                const bool wall = (j == 0) || (j == a.fny - 1);
+                double *qo = const_cast<double *>(in0);
+#pragma unroll
+                for (int p = 0; p < M; ++p) {
+                    const double hv = wall ? 0.0 : x1[p];
+                    qo[base + (long long)(row0 + p) * rs] = e[p + 3] + a.fdte * hv;
+                    x1[p] = a.fscale ? a.fkco * hv : hv;
+                }
             }
 #pragma unroll
             for (int p = 0; p < M; ++p) __builtin_nontemporal_store(x1[p], &out0[base + (long long)(row0 + p) * rs]);
@@ -407,7 +421,8 @@ int tlab_internal_zslab_partial_z(tlab_zslab_plan_t P, int phase, int nx, int ny
                                   const double *head_right, double *result, int acc);
 int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s,
                                     const double *const *s_lo, const double *const *s_hi, const double *vel, double *head, double *tail,
-                                    const double *tail_left, const double *head_right, double *const *result, int acc);
+                                    const double *tail_left, const double *head_right, double *const *result, int acc, const int *fin, double dte,
+                                    double kco, int scale);
 int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *const *p_halo, const double *tail_left,
                                          const double *head_right, double *q, double *h, double dte, double kco, int scale);
 
@@ -489,13 +504,15 @@ int tlab_zslab_burgers_z(tlab_zslab_plan_t P, int phase, int nx, int ny, double 
 
 int tlab_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s, const double *vel,
                            double *head, double *tail, const double *tail_left, const double *head_right, double *const *result, int acc) {
-    return tlab_internal_zslab_burgers_z_n(P, phase, nx, ny, nf, nu, s, nullptr, nullptr, vel, head, tail, tail_left, head_right, result, acc);
+    return tlab_internal_zslab_burgers_z_n(P, phase, nx, ny, nf, nu, s, nullptr, nullptr, vel, head, tail, tail_left, head_right, result, acc, nullptr,
+                                           0.0, 1.0, 0);
 }
 }  // extern "C"
 
 int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int ny, int nf, const double *nu, const double *const *s,
                                     const double *const *s_lo, const double *const *s_hi, const double *vel, double *head, double *tail,
-                                    const double *tail_left, const double *head_right, double *const *result, int acc) {
+                                    const double *tail_left, const double *head_right, double *const *result, int acc, const int *fin, double dte,
+                                    double kco, int scale) {
     return guard([&] {
         if (!P || !s || !nu || nf < 1 || nf > 4 || nx < 1 || ny < 1 || (phase != 1 && phase != 2)) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: bad arguments");
         ZSlabArgs a = base_args(*P, nx, ny);
@@ -515,6 +532,11 @@ int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int 
                 a.fo[f] = result[f];
             }
             a.vel = vel; a.tail_left = tail_left; a.head_right = head_right; a.acc = acc;
+            for (int f = 0; f < nf; ++f) {
+                a.ffin[f] = fin ? fin[f] : 0;
+                if (a.ffin[f] && s[f] == vel) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: the advecting velocity cannot be updated in place");
+            }
+            a.fdte = dte; a.fkco = kco; a.fscale = scale; a.fnx = nx; a.fny = ny;
         }
         launch(*P, MODE_BURGERS, phase, a, tlab_current_stream());
     });
