@@ -850,7 +850,7 @@ __device__ __forceinline__ void ode_row(const OdeSys &T, const OdeRows &k, int j
 // The boundary rows depend on the mode only: one thread per mode computes them into LDS (54 doubles per mode), the two chunks that
 // touch a boundary read what they need from there, and no thread keeps them in registers.  Layout: [field][NM], fields:
 //   0-4 l0, 5-9 l1, 10-14 l2, 15-19 lN, 20-24 lN1, 25-29 lN2, 30-41 rb[3][4], 42-53 rt[3][4]
-constexpr int OK_L0 = 0, OK_L1 = 5, OK_L2 = 10, OK_LN = 15, OK_LN1 = 20, OK_LN2 = 25, OK_RB = 30, OK_RT = 42, OK_SIZE = 54;
+constexpr int OK_L0 = 0, OK_L1 = 5, OK_L2 = 10, OK_LN = 15, OK_LN1 = 20, OK_LN2 = 25, OK_RB = 30, OK_RT = 42, OK_FS = 54, OK_SIZE = 58;      // OK_FS: one f row per line, parked by the chunk that needs it after the solve
 template <int NM>
 __device__ __forceinline__ void ode_rows_to_lds(const OdeRows &k, double *s_k, int m) {
 #pragma unroll
@@ -1065,11 +1065,14 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
     double *my_fac = s_fac + threadIdx.x * (3 * OM + 1);      // thread-major with an odd stride: constant offsets, no bank conflicts
 #define FAC(p, q) my_fac[(p) * 3 + (q)]
     double (&rhs)[OM][NL] = x;          // right-hand side -> y -> x in place
-    double fn2[NL], f1s[NL], bcs_b[NL], bcs_t[NL];
+    double bcs_b[NL], bcs_t[NL];
+    static_assert(NL <= OK_SIZE - OK_FS, "parking rows");
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        fn2[l] = fl[OM - 1][l];          // f(n-2) of the last chunk, for du (the only use of fl after the rhs)
-        f1s[l] = fl[2][l];               // f(1) of the first chunk, for du of the BCS_MIN system
+        // the only use of fl after the right-hand side: f(n-2) of the last chunk (BCS_MAX) / f(1) of the first one (BCS_MIN), for du -- parked in
+        // LDS by the thread that reads it back (8 VGPRs less through both sweeps)
+        if (BC == 2 && c == C - 1) s_k[(OK_FS + l) * NM + m] = fl[OM - 1][l];
+        if (BC == 1 && c == 0) s_k[(OK_FS + l) * NM + m] = fl[2][l];
         bcs_b[l] = bcs_t[l] = 0.0;
     }
     // The special rows sit at fixed positions of the first and the last chunk (requires n = 8 C): row 0 / n-1 are not part of the
@@ -1219,13 +1222,13 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
                 x[OM - 1][l] = resN[l];
                 // rows n-2, n-3, n-4 = p 6, 5, 4 ; f[n-2] = fl[7]
                 ext[l] = KK(OK_LN, 2) * resN[l] + KK(OK_LN, 1) * x[OM - 2][l] + KK(OK_LN, 0) * x[OM - 3][l] + KK(OK_LN, 4) * x[OM - 4][l] +
-                         T.R[(n - 1) * 3 + 0] * fn2[l];
+                         T.R[(n - 1) * 3 + 0] * s_k[(OK_FS + l) * NM + m];
             }
         } else {
             if (c == C - 1) x[OM - 1][l] = bcs_t[l] + KK(OK_LN, 1) * x[OM - 2][l] + KK(OK_LN, 0) * x[OM - 3][l] + KK(OK_LN, 4) * x[OM - 4][l];
             if (c == 0) {
                 x[0][l] = res0[l];
-                ext[l] = KK(OK_L0, 2) * res0[l] + KK(OK_L0, 3) * x[1][l] + KK(OK_L0, 4) * x[2][l] + KK(OK_L0, 0) * x[3][l] + T.R[0 * 3 + 2] * f1s[l];
+                ext[l] = KK(OK_L0, 2) * res0[l] + KK(OK_L0, 3) * x[1][l] + KK(OK_L0, 4) * x[2][l] + KK(OK_L0, 0) * x[3][l] + T.R[0 * 3 + 2] * s_k[(OK_FS + l) * NM + m];
             }
         }
     }
@@ -1281,7 +1284,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
 
     double u[OMR][NL], ext[NL];
-    double v_1[NL], u_n[NL], fn[NL], bb[NL], bt[NL];
+    double v_1[NL], u_n[NL], fn[NL];      // (the Neumann data bb = SC(0, l), bt = SC(1, l) stay in LDS until the constants are formed)
 #pragma unroll
     for (int l = 0; l < NL; ++l) v_1[l] = u_n[l] = fn[l] = 0.0;
     double vh[OMR + 2][NL];      // rows j0-1 .. j0+OMR of the u-solve's right-hand side v; vh[1..OMR] is where the v-solve puts v
@@ -1304,9 +1307,6 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
             if (c == 0) SC(0, l) = fl[1][l];
             if (c == C - 1) SC(1, l) = fl[OMR][l];
         }
-        __syncthreads();
-#pragma unroll
-        for (int l = 0; l < NL; ++l) { bb[l] = SC(0, l); bt[l] = SC(1, l); }
         // ---- v0' + lambda v0 = f, v0(1) = 0 ; f(n) = 0 ----
         ode_solve<1, NM, OMR, NL>(a.T1, lam, a.chk1, nm, t, c, C, m, fl, v_1, fn, reinterpret_cast<double (&)[OMR][NL]>(vh[1]), ext, s_w, s_k, s_fac);
     }
@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // ---- u0' - lambda u0 = v0, u0(n) = 0 ; the "opposite boundary value" is v0(1) = 0 (res(1) = f(1), fdm_integral.f90:243) ----
     if (DD) {      // u(:, nx) = bcs(:, 2)  (:440)
 #pragma unroll
-        for (int l = 0; l < NL; ++l) u_n[l] = bt[l];
+        for (int l = 0; l < NL; ++l) u_n[l] = SC(1, l);
     }
     ode_solve<2, NM, OMR, NL>(a.T2, -lam, a.chk2, nm, t, c, C, m, vh, v_1, u_n, u, ext, s_w, s_k, s_fac);
     // ---- u0(1), v0(n), du0(n) -> the three constants (opr_odes.f90:350-356 with the LU of k_nn_constants) ----
@@ -1341,10 +1341,10 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
         const double sp1 = a.cst[(unsigned)(3 * nm + t)], u11 = a.cst[(unsigned)(4 * nm + t)];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l);
-            const double w = lam * bt[l] - du0n + v0_n;
-            v_1[l] = (aa * (bb[l] - u0_1) - u11 * w) * dummy;
-            fn[l] = (sp1 * w - bc * (bb[l] - u0_1)) * dummy;
+            const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l), bbl = SC(0, l), btl = SC(1, l);
+            const double w = lam * btl - du0n + v0_n;
+            v_1[l] = (aa * (bbl - u0_1) - u11 * w) * dummy;
+            fn[l] = (sp1 * w - bc * (bbl - u0_1)) * dummy;
         }
     } else {
         const double a11 = a.cst[(unsigned)(0 * nm + t)], a21 = a.cst[(unsigned)(1 * nm + t)], a31 = a.cst[(unsigned)(2 * nm + t)];
@@ -1352,15 +1352,14 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
         const double a13 = a.cst[(unsigned)(6 * nm + t)], a23 = a.cst[(unsigned)(7 * nm + t)], a33 = a.cst[(unsigned)(8 * nm + t)];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l);
-            v_1[l] = (bb[l] - lam * u0_1) / a11;
-            u_n[l] = (bt[l] - v0_n - a21 * v_1[l]) / a22;
-            fn[l] = (bt[l] - du0n - a31 * v_1[l] - a32 * u_n[l]) / a33;
+            const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l), bbl = SC(0, l), btl = SC(1, l);
+            v_1[l] = (bbl - lam * u0_1) / a11;
+            u_n[l] = (btl - v0_n - a21 * v_1[l]) / a22;
+            fn[l] = (btl - du0n - a31 * v_1[l] - a32 * u_n[l]) / a33;
             u_n[l] = u_n[l] - a23 * fn[l];
             v_1[l] = v_1[l] - a12 * u_n[l] - a13 * fn[l];
         }
     }
-#undef SC
     // ---- superposition with the stored homogeneous solutions (opr_odes.f90:358-367); p^ = u, dp^/dy = v ----
     if (!store[0] && !store[NQ - 1]) return;
     // The homogeneous solutions decay like exp(-sqrt(lambda) distance from their wall): for all but the lowest modes they are below 1e-40 of
@@ -1380,7 +1379,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
             const double u0 = u[p][l], v0 = vh[p + 1][l];
             if (DD) {           // :459-465: rows nx .. 2 by the general formula (u0(nx) = bcs(:,2), u1(nx) = sp(nx) = 0), row 1 = the bottom value
                 if (j == 0) {
-                    uu[l] = bb[l];
+                    uu[l] = SC(0, l);
                     vv[l] = v_1[l] + lam * uu[l];
                 } else {
                     uu[l] = u0 + fn[l] * hu1 + v_1[l] * hsp;
@@ -1405,6 +1404,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
             D[idx] = make_double2(vv[2 * q], vv[2 * q + 1]);
         }
     }
+#undef SC
 }
 
 // ================================================================================================
