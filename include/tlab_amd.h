@@ -497,6 +497,9 @@ int tlab_debug_int1_tables(tlab_fdm_plan_t gy, int ibc, int nm, const double *la
  * values included), bv [2][nm] (the value given at the bottom, ibc = 1, or at the top, 2; the opposite end takes f's entry), du [2][nm].
  * variant (the kernel instantiations the plan builders use): 0 as described; 1: unit forcing (line 0: f = delta at the row opposite to the given
  * end, value 0; line 1: f = 0, value 1; f and bv ignored); 2: ibc = 2 with three lines (f's two and a zero one; values 0, 0, 1), res / du = lines 1, 2. */
+/* Debug aid: the pack-layout map tlab_poisson_fft_x_packed works with (host arithmetic, no GPU): element (line, kx) of the complex slab sits at
+ * off[kx] + line * width[kx] complex values of the pack buffer -- the layout tlab_pencil_repack_blocks writes for the same nblocks / start / base. */
+int tlab_debug_pack_map(int nxh, int nblocks, const int *start, const long long *base, long long *off, int *width);
 int tlab_debug_int1_solve(tlab_fdm_plan_t gy, int ibc, int variant, int nm, const double *lam, const double *f, const double *bv, double *res, double *du);
 
 #ifdef __cplusplus

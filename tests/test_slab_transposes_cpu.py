@@ -244,6 +244,79 @@ def test_staged_pencil_exchange_two_processes_gloo():
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
 
 
+def _packed_by_map(P, r, ioff, nxl, g, ny, kmax):
+    """What the packed x-transform of the native slab driver writes (tlab_poisson_fft_x_packed: element (line, kx) -> off[kx] + line * width[kx],
+    the map computed by the library on the host), for the staged block map of rank r's slab."""
+    import ctypes
+    from tlab_amd.lib import load, check
+    start, base, split, nxa, nxb = pencil_stage_layout(ioff, nxl, ny, kmax)
+    nxh = g.shape[2]
+    st = (ctypes.c_int * len(start))(*start)
+    bs = (ctypes.c_longlong * len(base))(*base)
+    off = (ctypes.c_longlong * nxh)()
+    wid = (ctypes.c_int * nxh)()
+    check(load().tlab_debug_pack_map(nxh, len(start), st, bs, off, wid), "tlab_debug_pack_map")
+    a = g[r * kmax:(r + 1) * kmax].reshape(kmax * ny, nxh)          # lines = (k, j), kx fastest
+    buf = torch.full((a.numel(),), -1.0, dtype=torch.float64)
+    for kx in range(nxh):
+        buf[off[kx] + torch.arange(kmax * ny) * wid[kx]] = a[:, kx]
+    return buf
+
+
+@pytest.mark.parametrize("P,nxh,ny,kmax", [(2, 9, 3, 2), (3, 17, 2, 2), (8, 33, 2, 1), (1, 5, 2, 3)])
+def test_packed_transform_layout_is_the_repack_layout(P, nxh, ny, kmax):
+    """The repack pass folded into the x-transforms: writing element (line, kx) at off[kx] + line * width[kx] fills the pack buffer exactly as
+    tlab_pencil_repack_blocks does (no gaps, no overlaps), for even and uneven kx ranges and both halves of the staged exchange."""
+    nxl, ioff, g = _pencil_case(P, nxh, ny, kmax)
+    for r in range(P):
+        ref, split, nxa, nxb = _staged_pack(P, r, ioff, nxl, g, ny, kmax)
+        got = _packed_by_map(P, r, ioff, nxl, g, ny, kmax)
+        assert torch.equal(got, ref), r
+
+
+def _worker_packed(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nxh, ny, kmax = 9, 3, 2
+        nxl, ioff, g = _pencil_case(world, nxh, ny, kmax)
+        start, base, split, nxa, nxb = pencil_stage_layout(ioff, nxl, ny, kmax)
+        pack = _packed_by_map(world, rank, ioff, nxl, g, ny, kmax)
+        comm = DistComm()
+        pens = (torch.zeros(kmax * world * ny * nxa[rank], dtype=torch.float64), torch.zeros(kmax * world * ny * nxb[rank], dtype=torch.float64))
+        works = []
+        for h, w in ((0, nxa), (1, nxb)):
+            works.append(comm.all_to_all_v({rank: pack[:split] if h == 0 else pack[split:]}, {rank: [w[p] * ny * kmax for p in range(world)]},
+                                           {rank: pens[h]}, {rank: [w[rank] * ny * kmax] * world}))
+        for wk in works:
+            wk.wait()
+        ok = torch.equal(pens[0].view(kmax * world, ny, nxa[rank]), g[:, :, ioff[rank]:ioff[rank] + nxa[rank]]) and \
+            torch.equal(pens[1].view(kmax * world, ny, nxb[rank]), g[:, :, ioff[rank] + nxa[rank]:ioff[rank] + nxl[rank]])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_transform_layout_two_processes_gloo():
+    """World size 2 over gloo: pack buffers filled through the library's map travel as the two halves of the staged exchange and arrive as the
+    kx-pencils (nz, ny, half width) with no unpacking."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # I-transposes (x pencils): TLabMPI_Trp_ExecI_*, tlab_mpi_transpose.f90:205-286
 # ---------------------------------------------------------------------------------------------------------------------------------

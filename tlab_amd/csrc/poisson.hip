@@ -2123,10 +2123,7 @@ struct tlab_poisson_plan {
         for (const KxMap &m : kxmaps) if (m.key == key) return m;
         std::vector<long long> off((size_t)fx_nxh);
         std::vector<int> w((size_t)fx_nxh);
-        for (int b = 0; b < nblocks; ++b) {
-            const int e = b + 1 < nblocks ? start[b + 1] : fx_nxh;
-            for (int i = start[b]; i < e; ++i) { off[i] = base[b] + (i - start[b]); w[i] = e - start[b]; }
-        }
+        if (tlab_debug_pack_map(fx_nxh, nblocks, start, base, off.data(), w.data()) != TLAB_OK) throw std::invalid_argument("pack map: bad block map");
         KxMap m;
         m.key = key;
         hipc(hipMalloc((void **)&m.off, off.size() * sizeof(long long)), "hipMalloc");

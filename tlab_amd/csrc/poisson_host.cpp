@@ -373,3 +373,16 @@ extern "C" int tlab_debug_int1_tables(tlab_fdm_plan_t gy, int ibc, int nm, const
         return TLAB_EINVAL;
     }
 }
+
+// The pack-layout map of the x-transforms (tlab_poisson_fft_x_packed): element (line, kx) of the complex slab at off[kx] + line * width[kx] complex
+// values of the pack buffer, i.e. what tlab_pencil_repack_blocks writes for the same block map.  Host arithmetic only.
+extern "C" int tlab_debug_pack_map(int nxh, int nblocks, const int *start, const long long *base, long long *off, int *width) {
+    if (nxh < 1 || nblocks < 1 || nblocks > 16 || !start || !base || !off || !width || start[0] != 0) { tlab_set_error("tlab_debug_pack_map: bad arguments"); return TLAB_EINVAL; }
+    for (int b = 0; b + 1 < nblocks; ++b)
+        if (start[b + 1] < start[b] || start[b + 1] > nxh) { tlab_set_error("tlab_debug_pack_map: block starts must increase within [0, nx/2+1]"); return TLAB_EINVAL; }
+    for (int b = 0; b < nblocks; ++b) {
+        const int e = b + 1 < nblocks ? start[b + 1] : nxh;
+        for (int i = start[b]; i < e; ++i) { off[i] = base[b] + (i - start[b]); width[i] = e - start[b]; }
+    }
+    return TLAB_OK;
+}

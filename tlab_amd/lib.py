@@ -119,6 +119,7 @@ SIGNATURES = {
     "tlab_profile_reset": (c_int, []),
     "tlab_profile_report": (c_int, [ctypes.c_char_p, c_int]),
     "tlab_debug_host_chunked_solve": (c_int, [c_vp, c_int, c_int, c_int, _dp]),
+    "tlab_debug_pack_map": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "tlab_debug_int1_tables": (c_int, [c_vp, c_int, c_int, _dp, _dp, _dp, _dp, _dp]),
     "tlab_debug_int1_solve": (c_int, [c_vp, c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp]),
 }
