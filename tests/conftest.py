@@ -61,6 +61,7 @@ def pytest_sessionfinish(session, exitstatus):
                   "max_bound": k["max_bound"], "max_err_over_bound": k["max_err_over_bound"], "all_within": k["ok"]} for (t, by), k in sorted(rows.items())]
         try:
             head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+            head = head or os.environ.get("TLAB_COMMIT") or None        # the GPU box has no .git: the caller may pass the commit
         except Exception:       # noqa: BLE001
             head = None
         doc = {"what": "device error vs oracle scatter vs bound for every composed-path comparison of this pytest session (tests/scatter.py::Bound)",
