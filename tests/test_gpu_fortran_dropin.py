@@ -146,11 +146,14 @@ def test_fortran_rk_driver_fast_kernels(tmp_path, fused):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused):
+@pytest.mark.parametrize("nx,walls", [(64, "freeslip"), (128, "noslip")])
+def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused, nx, walls):
     """The decomposed route of the Fortran host: RHS_GLOBAL_INCOMPRESSIBLE_1 (and TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD) hand the substep to the
     native z-slab driver -- tlab_slab_dns_create over the RCCL communicator of module TLabMPI_Transpose, the module arrays q(:, 1:3), s, hq, hs,
     txc bound as they are (columns back to back: the halo planes live in the driver's buffers).  One GPU here, so TLAB_AMD_FORCE_SLAB=1 takes that
-    route with ims_npro_k = 1: the rank is its own ring neighbour and all-to-all peer, through ncclSend / ncclRecv.  Against the oracle."""
+    route with ims_npro_k = 1: the rank is its own ring neighbour and all-to-all peer, through ncclSend / ncclRecv.  Against the oracle.
+    nx = 128, no-slip walls: the library's own x-transforms apply, so the driver folds the repack into them and finishes v and the scalar in the
+    kernels that complete their tendencies (its default route)."""
     import numpy as np
     from conftest import rel_err
     from scatter import substep_scatter, bound
@@ -158,7 +161,7 @@ def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused):
     _need_rk()
     if fused and not os.path.exists(RK_EXE_FUSED):
         pytest.skip("tlab_amd/fortran/_build_rk_fused/test_rk_driver not built")
-    nx, ny, nz = 64, 32, 64
+    ny, nz = 32, 64
     x = np.arange(nx) / nx * 2.0
     z = np.arange(nz) / nz
     y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
@@ -168,7 +171,8 @@ def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused):
     q0 = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3)]
     s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
     re, sc, dt = 1000.0, 0.7, 1e-3
-    bcs = ["VelocityJmin=freeslip", "VelocityJmax=freeslip", "Scalar1Jmin=neumann", "Scalar1Jmax=dirichlet"]
+    bcs = ["VelocityJmin=freeslip", "VelocityJmax=freeslip", "Scalar1Jmin=neumann", "Scalar1Jmax=dirichlet"] if walls == "freeslip" else \
+        ["VelocityJmin=noslip", "VelocityJmax=noslip", "Scalar1Jmin=dirichlet", "Scalar1Jmax=dirichlet"]
     q1, s1, log = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 2, bcs, exe=RK_EXE_FUSED if fused else None, env={"TLAB_AMD_FORCE_SLAB": "1"})
     kdt, kco = [1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0], [-5.0 / 9.0, -153.0 / 128.0]
     sched = [(dt * kdt[k % 3], kco[k % 3] if k % 3 < 2 else 1.0, k % 3 < 2, k % 3 == 0) for k in range(6)]
@@ -176,7 +180,9 @@ def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused):
     def make_oracle():
         from tlab_amd.dns import velocity_bcs
         o = DnsOracle(x, y, z, nscal=1, visc=1.0 / re, schmidt=(sc,), yuniform=False)
-        o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
+        o.flow_jmin = o.flow_jmax = velocity_bcs(walls)
+        if walls == "freeslip":
+            o.scal_jmin, o.scal_jmax = [4], [3]
         return o
     B, S = substep_scatter(make_oracle, q0, s0, sched, nsamples=1)
     for i in range(3):
