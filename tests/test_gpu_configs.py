@@ -89,9 +89,14 @@ def test_configs1_burgers_and_partial_at_256_cubed_vs_oracle(T):
 def test_configs4_rank_share_fused_vs_literal_and_divergence(T):
     """configs[4]: 2048 x 1024 x 2048 with 3 scalars on a stretched y mesh over 8 GPUs -> one rank's share, 2048 x 1024 x 256 (5.4e8 points,
     ~125 GB of the 288), one full RK3 step: x lines of 2048 (32 rows per lane), stretched y lines of 1024 (16-line tiles, Jacobian correction),
-    two Burgers launches per direction (4 + 2 fields), Poisson with 1025 x 256 modes of 1024 rows."""
+    two Burgers launches per direction (4 + 2 fields), Poisson with 1025 x 256 modes of 1024 rows.  Then the same box as FOUR z-slabs of 64 planes
+    through the native slab driver (all ranks on this GPU, exchanges as device copies): the composition of that shape -- 2048-point x lines and 1024-point
+    y lines inside slabs, six transported fields in two launches per direction and phase, kx-pencils of 256-257 modes in two halves, packed x-transforms,
+    v and the three scalars finished by their last kernels -- against the single domain within the scatter bound (the full 2048-plane box of the config
+    would need 8 x this memory)."""
     import torch
     from tlab_amd.dns import Dns
+    from tlab_amd.slab import NativeSlabDns
     nx, ny, nz, ns = 2048, 1024, 256, 3
     x = np.arange(nx) / nx * 2.0
     z = np.arange(nz) / nz * 0.25
@@ -123,6 +128,29 @@ def test_configs4_rank_share_fused_vs_literal_and_divergence(T):
     print("configs[4] share: one-ulp scatter", ["%.1e" % v for v in results["fused+ulp"]], "fused vs literal", ["%.1e" % v for v in results["literal"]])
     for i, (err, sc) in enumerate(zip(results["literal"], results["fused+ulp"])):
         assert err <= bound(sc), (i, err, sc)
+    # ---- four z-slabs ----
+    P = 4
+    d = NativeSlabDns("loopback", x, y, z, size=P, **kw)
+    assert d.kmax == nz // P and d.stages == 2 and d.fused_x
+    fields = device_fields(nx, ny, nz, 3 + ns, 2048, y)
+    for i in range(3 + ns):
+        d.scatter("q" if i < 3 else "s", i if i < 3 else i - 3, fields[i])
+        fields[i] = None
+    del fields
+    torch.cuda.empty_cache()
+    for k in range(3):
+        d.substep_of_cycle(k, 2e-4)
+    torch.cuda.synchronize()
+    errs = []
+    for i, rf in enumerate(results["fused"]):
+        name, ix = ("q", i) if i < 3 else ("s", i - 3)
+        scale = float(rf.abs().max())
+        err = max(float((d.st[r][name][ix] - rf[r * d.n:(r + 1) * d.n]).abs().max()) for r in range(P)) / scale
+        errs.append(err)
+    print("configs[4] share as 4 slabs vs single domain", ["%.1e" % v for v in errs])
+    d.close()
+    for i, (err, sc) in enumerate(zip(errs, results["fused+ulp"])):
+        assert err <= bound(sc), ("4 slabs", i, err, sc)
 
 
 def test_configs3_eight_loopback_ranks_equal_single_domain(T):
