@@ -77,3 +77,25 @@ def test_rccl_operations_of_the_slab_driver():
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
         assert mark in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
         assert "backend=nccl" in out.stdout or script == "rccl_check.py"
+
+
+@pytest.mark.parametrize("world,n", [(2, 128)])
+def test_bench_contract_with_two_ranks(world, n):
+    """`bench.py --gpus N` exactly as the driver launches it for N > 1 -- torch.distributed.run, one rank per process, barrier + MAX over ranks,
+    ONE JSON line from rank 0 -- here with the ranks sharing the one GPU of the test box (TLAB_DIST_BACKEND=gloo: the native slab driver over the
+    caller-supplied transport; with RCCL the same code path needs one GPU per rank)."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, TLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29593", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--box", str(n)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "strong" and rec["higher_is_better"] is True
+    assert rec["value"] > 0 and abs(rec["value"] - n ** 3 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]
+    assert rec["config"]["fields_finite"] is True and "z-slabs 1x%d" % world in rec["config"]["parallelism"]
