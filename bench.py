@@ -356,7 +356,36 @@ def main():
                 print("bench.py: %d planes per rank are too few for the partitioned z-systems of the native slab driver; using the K-transposition "
                       "scheme of tlab_amd/parallel.py" % (nz // world), file=sys.stderr)
             args.slab_driver = "python"
-        d = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, **kw) if args.slab_driver == "native" else SlabDns(DistComm(), x, y, z, **kw)
+        def all_ranks_ok(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        d = None
+        if args.slab_driver == "native":
+            # The native driver's RCCL transport has only ever run with one rank per communicator (one GPU per test box): should its start-up or its
+            # first substep fail on ANY rank, every rank falls back to the Python driver over torch.distributed (same algorithm, same kernels) and
+            # the line says so -- a number from the slower driver beats no number.
+            err = None
+            try:
+                d = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, **kw)
+                S = d.st[rank]
+                synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
+                d.substep_of_cycle(0, dtime)
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                err = e
+            if not all_ranks_ok(err is None):
+                print("bench.py rank %d: native slab driver failed (%s); falling back to the Python driver" % (rank, err if err else "on another rank"), file=sys.stderr)
+                try:
+                    if d is not None:
+                        d.close()
+                except Exception:       # noqa: BLE001
+                    pass
+                d = None
+                args.slab_driver = "python (native driver failed at start-up)"
+        if d is None:
+            d = SlabDns(DistComm(), x, y, z, **kw)
         S = d.st[rank]
         synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
         state_fields = S["q"] + S["s"]
