@@ -102,9 +102,11 @@ __device__ __forceinline__ void xhalo(XCtx<WPL> &c, const double (&u)[M], double
     }
 }
 
-// CL: the 23 per-lane constants below live in LDS ([XRED][64 WPL], staged once per workgroup and shared by its lines) instead of 46 VGPRs per
-// system: the several-waves-per-line forms then fit two waves per SIMD
-constexpr int XRED = 23;         // rows: 0-5 k1, 6-11 k2, 12 dinv, 13-20 vs ws wL vF dn wLp vFm dp, 21 a_s, 22 c_s
+// CL: the 23 constants below live in LDS (staged once per workgroup and shared by its lines) instead of 46 VGPRs per system: the
+// several-waves-per-line forms then fit two waves per SIMD
+// LDS layout of the constants of one system: 17 rows per lane [XRL][64 WPL] -- 0-5 k1, 6-11 k2, 12 dinv, 13 vs, 14 ws, 15 a_s, 16 c_s -- followed by the six
+// constants of the 2 x 2 interface systems, which are the same for all lanes of a wave: [6][WPL] -- wL, vF, dn, wLp, vFm, dp (chunked.cpp)
+constexpr int XRL = 17;
 template <int WPL, bool CL = false>
 struct XSys {                    // per-lane view of one chunked system
     const double *rowtab;        // global [5][n]
@@ -119,20 +121,19 @@ struct XSys {                    // per-lane view of one chunked system
 // kept as chunk 0's value (scalar load) + a float difference in LDS -- where two systems of doubles do not fit (n >= 1024 with both systems).
 // The reconstruction is exact when the chunks differ by less than 2^-29 relative (the 1e-13 wander of a "uniform" reference grid): the plan
 // checks every entry on the host (xline_wide_ok, capi.cpp) and takes another kernel otherwise.
-template <int M, int LV, int WPL, bool CL>
-__device__ __forceinline__ double xcoef(const XSys<WPL, CL> &y, int tab, int p, int gl, int n) {
+template <int M, int LV, int WPL>
+__device__ __forceinline__ double xcoef(const double *rowtab, const double *lds, int tab, int p, int gl, int n) {
     constexpr int P = 64 * WPL;
-    if (LV == 1) return y.lds[(tab * M + p) * P + gl];
-    if (LV == 2) return y.rowtab[tab * n + p] + (double)reinterpret_cast<const float *>(y.lds)[(tab * M + p) * P + gl];
-    return y.rowtab[tab * n + p];  // lane-invariant: chunk 0's row p, wave-uniform address -> scalar load
+    if (LV == 1) return lds[(tab * M + p) * P + gl];
+    if (LV == 2) return rowtab[tab * n + p] + (double)reinterpret_cast<const float *>(lds)[(tab * M + p) * P + gl];
+    return rowtab[tab * n + p];  // lane-invariant: chunk 0's row p, wave-uniform address -> scalar load
 }
-
 template <int M, int LV, int WPL, bool CL>
 __device__ __forceinline__ void xsys_init(XSys<WPL, CL> &y, const SystemDev &sd, const double *lds, const double *red_lds, int gl, int n) {
     constexpr int P = 64 * WPL;
     y.rowtab = sd.rowtab;
     y.lds = lds;
-    y.red = red_lds + gl;
+    y.red = red_lds;
     if constexpr (!CL) {
         const int src = (LV || WPL > 1) ? gl : 0;
     #pragma unroll
@@ -157,21 +158,23 @@ template <int M, int LV, int WPL, bool CL>
 __device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL, CL> &y, XCtx<WPL> &c, int n) {
     constexpr int P = 64 * WPL;
     const int gl = c.gl, lane = c.lane;
-#define XR(row) y.red[(row) * P]
+#define XR(row) y.red[(row) * P + gl]
+#define XW(q) y.red[XRL * P + (q) * WPL + c.wl]
+    const double *tl = y.lds;
     double g = 0.0;
 #pragma unroll
     for (int p = 1; p < M; ++p) {
-        g = f[p] + xcoef<M, LV, WPL, CL>(y, 0, p, gl, n) * g;
+        g = f[p] + xcoef<M, LV, WPL>(y.rowtab, tl, 0, p, gl, n) * g;
         f[p] = g;
     }
     double yn = 0.0;
 #pragma unroll
     for (int p = M - 1; p >= 1; --p) {
-        yn = f[p] * xcoef<M, LV, WPL, CL>(y, 1, p, gl, n) + xcoef<M, LV, WPL, CL>(y, 2, p, gl, n) * yn;
+        yn = f[p] * xcoef<M, LV, WPL>(y.rowtab, tl, 1, p, gl, n) + xcoef<M, LV, WPL>(y.rowtab, tl, 2, p, gl, n) * yn;
         f[p] = yn;
     }
     const double yLprev = xprev<WPL>(c, f[M - 1]);
-    double r = f[0] - (CL ? XR(21) : y.a_s) * yLprev - (CL ? XR(22) : y.c_s) * f[1];
+    double r = f[0] - (CL ? XR(15) : y.a_s) * yLprev - (CL ? XR(16) : y.c_s) * f[1];
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const int d = 1 << s;
@@ -190,17 +193,20 @@ __device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL, CL> &y, X
         const double YpL = b[((c.wl + WPL - 1) & (WPL - 1)) * 4 + 2], YnF = b[((c.wl + 1) & (WPL - 1)) * 4 + 1];
         const double myF = b[c.wl * 4 + 1], myL = b[c.wl * 4 + 2];
         c.par ^= 1;
-        const double XL = (myL - (CL ? XR(15) : y.wL) * YnF) * (CL ? XR(17) : y.dn);          // last unknown of this wave and first one of the next: 2 x 2 interface system
-        const double XnF = YnF - (CL ? XR(16) : y.vF) * XL;
-        const double XpL = (YpL - (CL ? XR(18) : y.wLp) * myF) * (CL ? XR(20) : y.dp);        // last unknown of the previous wave (its interface with this one)
+        const double XL = (myL - (CL ? XW(0) : y.wL) * YnF) * (CL ? XW(2) : y.dn);          // last unknown of this wave and first one of the next: 2 x 2 interface system
+        const double XnF = YnF - (CL ? XW(1) : y.vF) * XL;
+        const double XpL = (YpL - (CL ? XW(3) : y.wLp) * myF) * (CL ? XW(5) : y.dp);        // last unknown of the previous wave (its interface with this one)
         X = X - (CL ? XR(13) : y.vs) * XpL - (CL ? XR(14) : y.ws) * XnF;
         Xr = shfl_d(X, (lane + 1) & 63);
         if (lane == 63) Xr = XnF;
     }
     f[0] = X;
 #pragma unroll
-    for (int p = 1; p < M; ++p) f[p] = f[p] + xcoef<M, LV, WPL, CL>(y, 3, p, gl, n) * X + xcoef<M, LV, WPL, CL>(y, 4, p, gl, n) * Xr;
+    for (int p = 1; p < M; ++p) {
+        f[p] = f[p] + xcoef<M, LV, WPL>(y.rowtab, tl, 3, p, gl, n) * X + xcoef<M, LV, WPL>(y.rowtab, tl, 4, p, gl, n) * Xr;
+    }
 #undef XR
+#undef XW
 }
 
 // f = B u for this lane's chunk; um/up are the 3-point halos from the neighbouring lanes
@@ -302,14 +308,15 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
     if (NEED2) stage(a.y2.rowtab, lds2, LV2);
     XCtx<WPL> cx;
     cx.lane = lane; cx.gl = gl; cx.wl = wl; cx.par = 0; cx.eb = nullptr; cx.hb = nullptr;
-    constexpr size_t REDW = CL ? (size_t)XRED * P : 0;        // per-lane constants of one system
+    constexpr size_t REDW = CL ? (size_t)XRL * P + 6 * WPL : 0;        // constants of one system
     double *red1 = xlds + ((NEED1 ? TABW1 : 0) + (NEED2 ? TABW2 : 0)), *red2 = red1 + (NEED1 ? REDW : 0);
     if constexpr (CL) {
         auto stage_red = [&](const SystemDev &sd, double *d, int lv) {
-            for (int idx = threadIdx.x; idx < XRED * P; idx += blockDim.x) {
+            for (int idx = threadIdx.x; idx < XRL * P; idx += blockDim.x) {
                 const int l = idx % P, k = idx / P;
-                d[idx] = k < 21 ? sd.red[k * P + l] : sd.rowtab[(k == 21 ? 0 : 2) * n + (lv ? l * M : 0)];
+                d[idx] = k < 15 ? sd.red[k * P + l] : sd.rowtab[(k == 15 ? 0 : 2) * n + (lv ? l * M : 0)];
             }
+            for (int idx = threadIdx.x; idx < 6 * WPL; idx += blockDim.x) d[XRL * P + idx] = sd.red[(15 + idx / WPL) * P + (idx % WPL) * 64];
         };
         if (NEED1) stage_red(a.y1, red1, LV);
         if (NEED2) stage_red(a.y2, red2, LV2);
@@ -918,7 +925,7 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     const int grid = imin(blocks_needed, 256 * 8 * 256 / TPB);
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
     auto tabbytes = [](int lv) { return lv == 1 ? (size_t)5 * M * P * sizeof(double) : lv == 2 ? (size_t)5 * M * P * sizeof(float) : (size_t)0; };
-    const size_t redbytes = CL ? (size_t)XRED * P * sizeof(double) : 0;
+    const size_t redbytes = CL ? ((size_t)XRL * P + 6 * WPL) * sizeof(double) : 0;
     const size_t lds = (mode != MODE_P2 ? tabbytes(LV) + redbytes : 0) + (mode != MODE_P1 ? tabbytes(LV2) + redbytes : 0) +
                        (WPL > 1 ? (size_t)LPB * 14 * WPL * sizeof(double) : 0);
     const double pts = (double)a.nlines * P * M;
