@@ -101,6 +101,12 @@ void DeviceArray::upload(const std::vector<double> &h) {
     hip_check(hipMalloc((void **)&p, n * sizeof(double)), "hipMalloc(table)");
     hip_check(hipMemcpy(p, h.data(), n * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(table)");
 }
+void DeviceArray::alloc(size_t count) {
+    if (p) hip_check(hipFree(p), "hipFree");
+    p = nullptr;
+    n = count;
+    if (n) hip_check(hipMalloc((void **)&p, n * sizeof(double)), "hipMalloc(scratch)");
+}
 }  // namespace tlab
 
 // ------------------------------------------------------------------------------------------------
@@ -677,6 +683,21 @@ void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, co
         a.periodic = d.periodic ? 1 : 0; a.ibc = d.periodic ? 0 : ibc;
         std::copy(d.rhs_b, d.rhs_b + 32, a.rb);
         std::copy(d.rhs_t, d.rhs_t + 35, a.rt);
+        if (geom.row_stride == 1 && geom.nlines >= 64) {
+            // x lines: one thread per line strides through contiguous memory (64 cache lines per wave access; 243 GB/s at 256^3, measured).  Like the
+            // reference (OPR_Partial_X: TLab_Transpose, solve, transpose back, opr_partial.f90:185-195) the lines are made the fastest index first:
+            // two transposes at the copy rate + the coalesced solve (the y-direction speed) -- same operations per line, same results
+            const size_t N = (size_t)geom.n * geom.nlines;
+            if (!g->penta_ws) g->penta_ws = std::make_unique<DeviceArray>();
+            if (g->penta_ws->n < 2 * N) g->penta_ws->alloc(2 * N);
+            double *t1 = g->penta_ws->p, *t2 = t1 + N;
+            hip_check(launch_transpose(in0, t1, geom.n, (int)geom.nlines, g_stream), "transpose");
+            a.in0 = t1; a.out0 = t2;
+            a.g.row_stride = geom.nlines; a.g.lines_inner = (int)geom.nlines; a.g.outer_stride = 0;
+            hip_check(launch_penta1(a, g_stream), "k_penta1");
+            hip_check(launch_transpose(t2, out, (int)geom.nlines, geom.n, g_stream), "transpose");
+            return;
+        }
         hip_check(launch_penta1(a, g_stream), "k_penta1");
         return;
     }

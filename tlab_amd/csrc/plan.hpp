@@ -23,6 +23,7 @@ struct DeviceArray {
     DeviceArray &operator=(const DeviceArray &) = delete;
     ~DeviceArray();
     void upload(const std::vector<double> &h);
+    void alloc(size_t count);       // uninitialised scratch of count doubles (grows or shrinks to exactly that)
 };
 
 struct SystemEntry {
@@ -42,6 +43,7 @@ struct tlab_fdm_plan {
     std::unique_ptr<tlab::DeviceArray> jc;   // [3][n] Jacobian-correction diagonals (non-uniform grids)
     std::unique_ptr<tlab::DeviceArray> rowc2;  // [n][5] per-row RHS of a direct second-derivative scheme
     std::unique_ptr<tlab::DeviceArray> rowc1[4];   // the same for a direct first derivative, one per Neumann variant (rows 4 and n-3 differ)
+    std::unique_ptr<tlab::DeviceArray> penta_ws;              // ... and two transposed copies of a field for its x direction
     std::unique_ptr<tlab::DeviceArray> penta_rhs, penta_lu;   // CompactJacobian6Penta first derivative: g%der1%rhs (n,7) and g%der1%lu on the device
     tlab_filter_t interp[4] = {nullptr, nullptr, nullptr, nullptr};      // interpolatory operators P1 VP, P1 PV, P0 VP, P0 PV as periodic compact-filter objects (capi.cpp)
     int wide_ok[3] = {-1, -1, -1};             // x lines on 64 / 128 / 256 chunks: float-difference tables exact? (-1 = not checked yet; capi.cpp xline_wide_ok)
