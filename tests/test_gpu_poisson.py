@@ -180,6 +180,66 @@ def test_x_fft_matches_numpy(T, nx):
         assert np.abs(got[:-8].reshape(ref.shape) - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("nx,P", [(128, 2), (256, 3), (512, 8)])
+def test_packed_x_transforms_equal_transform_plus_repack(T, nx, P):
+    """tlab_poisson_fft_x_packed / _packed_final (the repack of the slab <-> kx-pencil exchange folded into the own x-transforms, the native slab
+    driver's default route) through the C ABI: the forward transform into the pack buffer is BIT-identical to tlab_poisson_fft_x followed by
+    tlab_pencil_repack_blocks (same kernel arithmetic, other store addresses); the inverse from the pack buffer is bit-identical to the own inverse
+    (dir = -2) of the unpacked spectrum; the final form equals k_final_update's arithmetic on that inverse.  Two halves per rank, uneven kx ranges."""
+    import ctypes
+    import torch
+    from tlab_amd.lib import load, check
+    from tlab_amd.parallel import pencil_stage_layout
+    ny, kmax = 9, 4
+    nzt = kmax * P
+    nxh = nx // 2 + 1
+    x, y, z = np.arange(nx) / nx, np.arange(ny) / (ny - 1.0), np.arange(nzt) / nzt
+    gp = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, True), T.FdmPlan(z, True, True)]
+    L = load()
+    h = ctypes.c_void_p(0)
+    base_, rem = nxh // P, nxh % P
+    nxl = [base_ + (1 if r < rem else 0) for r in range(P)]
+    ioff = [r * base_ + min(r, rem) for r in range(P)]
+    check(L.tlab_poisson_plan_create_pencil(ctypes.byref(h), gp[0]._h, gp[1]._h, gp[2]._h, nx, ny, kmax, nzt, ioff[0], nxl[0]), "pencil plan")
+    start, base, split, nxa, nxb = pencil_stage_layout(ioff, nxl, ny, kmax)
+    nb = len(start)
+    st = (ctypes.c_int * nb)(*start)
+    bs = (ctypes.c_longlong * nb)(*base)
+    rng = np.random.default_rng(nx + P)
+    a = torch.from_numpy(rng.uniform(-1, 1, kmax * ny * nx)).cuda()
+    nc = 2 * nxh * ny * kmax
+    spec = torch.full((nc,), np.nan, dtype=torch.float64, device="cuda")
+    pack_ref = torch.full((nc,), np.nan, dtype=torch.float64, device="cuda")
+    pack = torch.full((nc + 8,), np.nan, dtype=torch.float64, device="cuda")
+    check(L.tlab_poisson_fft_x(h, 1, a.data_ptr(), spec.data_ptr()), "fft_x")
+    check(L.tlab_pencil_repack_blocks(spec.data_ptr(), pack_ref.data_ptr(), nxh, ny, kmax, nb, st, bs, 1), "repack")
+    check(L.tlab_poisson_fft_x_packed(h, 1, a.data_ptr(), pack.data_ptr(), nb, st, bs), "fft_x_packed")
+    assert bool(torch.isnan(pack[-8:]).all()) and torch.equal(pack[:-8], pack_ref) and not bool(torch.isnan(pack_ref).any())
+    # inverse: a spectrum of its own in the pack layout
+    sp = torch.from_numpy(rng.uniform(-1, 1, nc)).cuda()
+    unp = torch.empty_like(sp)
+    check(L.tlab_pencil_repack_blocks(unp.data_ptr(), sp.data_ptr(), nxh, ny, kmax, nb, st, bs, -1), "repack back")
+    r_ref = torch.empty(kmax * ny * nx, dtype=torch.float64, device="cuda")
+    r_got = torch.full((kmax * ny * nx + 8,), np.nan, dtype=torch.float64, device="cuda")
+    check(L.tlab_poisson_fft_x(h, -2, unp.data_ptr(), r_ref.data_ptr()), "own inverse")
+    check(L.tlab_poisson_fft_x_packed(h, -1, sp.data_ptr(), r_got.data_ptr(), nb, st, bs), "packed inverse")
+    assert bool(torch.isnan(r_got[-8:]).all()) and torch.equal(r_got[:-8], r_ref)
+    # final form: h = h - g, wall planes zero, q += dte h, h *= kco
+    q = torch.from_numpy(rng.uniform(-1, 1, kmax * ny * nx)).cuda()
+    hh = torch.from_numpy(rng.uniform(-1, 1, kmax * ny * nx)).cuda()
+    q2, h2 = q.clone(), hh.clone()
+    dte, kco = 3e-3, -0.6
+    check(L.tlab_pw_final_update(q2.data_ptr(), h2.data_ptr(), r_ref.data_ptr(), None, None, dte, kco, 1, nx, ny, kmax), "final_update")
+    check(L.tlab_poisson_fft_x_packed_final(h, sp.data_ptr(), q.data_ptr(), hh.data_ptr(), dte, kco, 1, nb, st, bs), "packed final")
+    assert float((q - q2).abs().max()) <= 1e-15 * float(q2.abs().max()) and float((hh - h2).abs().max()) <= 1e-15 * float(h2.abs().max())
+    assert float(hh.view(kmax, ny, nx)[:, 0].abs().max()) == 0.0 and float(hh.view(kmax, ny, nx)[:, -1].abs().max()) == 0.0
+    # refusals: a block map that does not start at kx = 0, in place
+    bad = (ctypes.c_int * nb)(*([1] + list(start[1:])))
+    assert L.tlab_poisson_fft_x_packed(h, 1, a.data_ptr(), pack.data_ptr(), nb, bad, bs) != 0
+    assert L.tlab_poisson_fft_x_packed(h, 1, a.data_ptr(), a.data_ptr(), nb, st, bs) != 0
+    check(L.tlab_poisson_plan_destroy(h), "destroy")
+
+
 @pytest.mark.parametrize("n", [256])
 def test_poisson_full_size_identity(T, n):
     """256^3: div(grad p) = f with the device operators (vpoisson.f90 / SURVEY 4.4 construction), dpdy = d/dy of phi."""
