@@ -1,3 +1,5 @@
+"""OPR_Partial_{X,Y,Z}(OPR_P1) at 256^3 with the tridiagonal (CompactJacobian6) and the pentadiagonal (CompactJacobian6Penta) first derivative:
+ms, algorithmic GB/s and the kernel path taken (1 generic / k_penta1, 2 wave-per-line, 3 register tile).  DESIGN.md section 8."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import tlab_amd as T
