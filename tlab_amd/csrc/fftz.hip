@@ -59,6 +59,9 @@ __device__ __forceinline__ void dft8(cd (&v)[8]) {
     v[3] = e3 + o3; v[7] = e3 - o3;
 }
 
+// lengths, radices and their running products are powers of two: shifts and masks instead of integer division (the compiler cannot know)
+__device__ __forceinline__ int ilog2(int v) { return 31 - __builtin_clz(v); }
+
 struct FftzArgs {
     const double2 *in;
     double2 *out;
@@ -86,16 +89,17 @@ __device__ __forceinline__ void fftz_pass(const FftzArgs &a, int t, int j, int N
         for (int r = 0; r < R; ++r) v[r] = lds[(j + r * m) * T + t];
     }
     // twiddles exp(SGN 2 pi i (j % Ns) r / (Ns R))
-    const int k0 = (j % Ns) * (n / (Ns * R));
+    const int lNs = ilog2(Ns), lR = ilog2(R), ln = ilog2(n);
+    const int k0 = (j & (Ns - 1)) << (ln - lNs - lR);
 #pragma unroll
     for (int r = 1; r < R; ++r) {
-        const double2 w = a.tw[(k0 * r) % n];
+        const double2 w = a.tw[(k0 * r) & (n - 1)];
         v[r] = cmul(v[r], cd{w.x, SGN > 0 ? -w.y : w.y});
     }
     if (R == 8) dft8<SGN>(reinterpret_cast<cd(&)[8]>(v));
     else if (R == 4) dft4<SGN>(v[0], v[1 % R], v[2 % R], v[3 % R]);
     else dft2<SGN>(v[0], v[1 % R]);
-    const int j0 = (j / Ns) * Ns * R + (j % Ns);
+    const int j0 = ((j >> lNs) << (lNs + lR)) + (j & (Ns - 1));
     if (!first) __syncthreads();          // every item of this pass has read its inputs from the buffer
     if (last) {
         if (colok) {
@@ -144,13 +148,13 @@ __global__ void __launch_bounds__(1024) k_fftz(FftzArgs a) {
                             keep[q][r] = lds[(j + r * m) * T + t];
                         }
                     }
-                    const int k0 = (j % Ns) * (a.n / (Ns * 4));
+                    const int k0 = (j & (Ns - 1)) * (a.n >> (ilog2(Ns) + 2));
                     for (int r = 1; r < 4; ++r) {
-                        const double2 w = a.tw[(k0 * r) % a.n];
+                        const double2 w = a.tw[(k0 * r) & (a.n - 1)];
                         keep[q][r] = cmul(keep[q][r], cd{w.x, SGN > 0 ? -w.y : w.y});
                     }
                     dft4<SGN>(keep[q][0], keep[q][1], keep[q][2], keep[q][3]);
-                    j0s[q] = (j / Ns) * Ns * 4 + (j % Ns);
+                    j0s[q] = ((j >> ilog2(Ns)) << (ilog2(Ns) + 2)) + (j & (Ns - 1));
                 }
                 if (!first) __syncthreads();
                 for (int q = 0; q < 2; ++q)
@@ -176,11 +180,11 @@ __global__ void __launch_bounds__(1024) k_fftz(FftzArgs a) {
                             keep[q][r] = lds[(j + r * m) * T + t];
                         }
                     }
-                    const int k0 = (j % Ns) * (a.n / (Ns * 2));
-                    const double2 w = a.tw[k0 % a.n];
+                    const int k0 = (j & (Ns - 1)) * (a.n >> (ilog2(Ns) + 1));
+                    const double2 w = a.tw[k0 & (a.n - 1)];
                     keep[q][1] = cmul(keep[q][1], cd{w.x, SGN > 0 ? -w.y : w.y});
                     dft2<SGN>(keep[q][0], keep[q][1]);
-                    j0s[q] = (j / Ns) * Ns * 2 + (j % Ns);
+                    j0s[q] = ((j >> ilog2(Ns)) << (ilog2(Ns) + 1)) + (j & (Ns - 1));
                 }
                 if (!first) __syncthreads();
                 for (int q = 0; q < 4; ++q)
@@ -241,16 +245,16 @@ __device__ __forceinline__ void fftx_pass(const FftxArgs &a, const double2 *__re
                 v[q][r] = lds[j + r * m];
             }
         }
-        const int k0 = (j % Ns) * (M / (Ns * R));
+        const int k0 = (j & (Ns - 1)) << (ilog2(M) - ilog2(Ns) - ilog2(R));
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-            const double2 w = a.tw[2 * ((k0 * r) % M)];      // exp(-2 pi i (k0 r) / m) from the table of n = 2 m
+            const double2 w = a.tw[2 * ((k0 * r) & (M - 1))];      // exp(-2 pi i (k0 r) / m) from the table of n = 2 m
             v[q][r] = cmul(v[q][r], cd{w.x, w.y});
         }
         if (R == 8) dft8<-1>(reinterpret_cast<cd(&)[8]>(v[q]));
         else if (R == 4) dft4<-1>(v[q][0], v[q][1 % R], v[q][2 % R], v[q][3 % R]);
         else dft2<-1>(v[q][0], v[q][1 % R]);
-        j0s[q] = (j / Ns) * Ns * R + (j % Ns);
+        j0s[q] = ((j >> ilog2(Ns)) << (ilog2(Ns) + ilog2(R))) + (j & (Ns - 1));
     }
     if (!first) __syncthreads();          // every item of this pass has read its inputs from the buffer
 #pragma unroll
@@ -262,7 +266,7 @@ __device__ __forceinline__ void fftx_pass(const FftxArgs &a, const double2 *__re
 
 __global__ void __launch_bounds__(256) k_fftx_r2c(FftxArgs a) {
     extern __shared__ double2 fx_lds[];
-    const int jt = threadIdx.x % a.tl, ll = threadIdx.x / a.tl;
+    const int jt = threadIdx.x & (a.tl - 1), ll = threadIdx.x >> ilog2(a.tl);      // tl = m/8: a power of two
     const long long line = (long long)blockIdx.x * a.lines + ll;
     const bool ok = line < a.nlines;
     cd *lds = reinterpret_cast<cd *>(fx_lds) + (size_t)ll * a.m;
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(256) k_fftx_r2c(FftxArgs a) {
     const int M = a.m;
     if (a.kxw != nullptr) {      // same values, scattered into the pack buffer
         for (int k = jt; k <= M / 2; k += a.tl) {
-            const cd A = lds[k], Zc = lds[(M - k) % M];
+            const cd A = lds[k], Zc = lds[(M - k) & (M - 1)];
             const cd B = {Zc.x, -Zc.y};
             const cd E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
             const cd D = A - B;
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(256) k_fftx_r2c(FftxArgs a) {
         return;
     }
     for (int k = jt; k <= M / 2; k += a.tl) {
-        const cd A = lds[k], Zc = lds[(M - k) % M];
+        const cd A = lds[k], Zc = lds[(M - k) & (M - 1)];
         const cd B = {Zc.x, -Zc.y};
         const cd E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
         const cd D = A - B;
@@ -327,16 +331,16 @@ __device__ __forceinline__ void fftx_pass_inv(const FftxArgs &a, cd *lds, int jt
         const int j = jt + q * a.tl;
 #pragma unroll
         for (int r = 0; r < R; ++r) v[q][r] = lds[j + r * m];
-        const int k0 = (j % Ns) * (M / (Ns * R));
+        const int k0 = (j & (Ns - 1)) << (ilog2(M) - ilog2(Ns) - ilog2(R));
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-            const double2 w = a.tw[2 * ((k0 * r) % M)];
+            const double2 w = a.tw[2 * ((k0 * r) & (M - 1))];
             v[q][r] = cmul(v[q][r], cd{w.x, -w.y});
         }
         if (R == 8) dft8<+1>(reinterpret_cast<cd(&)[8]>(v[q]));
         else if (R == 4) dft4<+1>(v[q][0], v[q][1 % R], v[q][2 % R], v[q][3 % R]);
         else dft2<+1>(v[q][0], v[q][1 % R]);
-        j0s[q] = (j / Ns) * Ns * R + (j % Ns);
+        j0s[q] = ((j >> ilog2(Ns)) << (ilog2(Ns) + ilog2(R))) + (j & (Ns - 1));
     }
     __syncthreads();
 #pragma unroll
@@ -349,7 +353,7 @@ __device__ __forceinline__ void fftx_pass_inv(const FftxArgs &a, cd *lds, int jt
 template <bool FINAL>
 __global__ void __launch_bounds__(256) k_fftx_c2r(FftxArgs a, FftxFinal fin) {
     extern __shared__ double2 fx_lds[];
-    const int jt = threadIdx.x % a.tl, ll = threadIdx.x / a.tl;
+    const int jt = threadIdx.x & (a.tl - 1), ll = threadIdx.x >> ilog2(a.tl);      // tl = m/8: a power of two
     const long long line = (long long)blockIdx.x * a.lines + ll;
     const bool ok = line < a.nlines;
     cd *lds = reinterpret_cast<cd *>(fx_lds) + (size_t)ll * a.m;
