@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256) k_fftx_c2r(FftxArgs a, FftxFinal fin) {
         double2 *out = a.out + line * M;
         for (int j = jt; j < M; j += a.tl) out[j] = make_double2(lds[j].x, lds[j].y);
     } else {
-        const int jy = (int)(line % fin.ny);
+        const int jy = a.nlines < (1LL << 31) ? (int)((unsigned)line % (unsigned)fin.ny) : (int)(line % fin.ny);      // (32-bit where it fits: cheaper)
         const bool wall = jy == 0 || jy == fin.ny - 1;
         double2 *q2 = reinterpret_cast<double2 *>(fin.q) + line * M, *h2 = reinterpret_cast<double2 *>(fin.h) + line * M;
         for (int j = jt; j < M; j += a.tl) {
