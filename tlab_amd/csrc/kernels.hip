@@ -249,9 +249,11 @@ __device__ __forceinline__ void xstencil_periodic(double (&f)[M], const double (
 #pragma unroll
     for (int p = 0; p < M; ++p) f[p] = stencil_interior<SYM>(s, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
 }
-template <int M, bool SYM, int WPL>
+// PER: the line is periodic (known on the host): no wall closures in the code -- their 2 x 36 coefficients are kernel arguments, and with them in
+// play the one-wave forms spill scalar registers (a quarter of the instructions of the fused Burgers loop were v_readlane / v_accvgpr moves)
+template <int M, bool SYM, int WPL, bool PER>
 __device__ __forceinline__ void xsten(double (&f)[M], const double (&u)[M], const double (&um)[3], const double (&up)[3], const StencilDev &s, int lane) {
-    if constexpr (WPL == 1) xstencil<M, SYM>(f, u, um, up, s, lane);
+    if constexpr (WPL == 1 && !PER) xstencil<M, SYM>(f, u, um, up, s, lane);
     else xstencil_periodic<M, SYM>(f, u, um, up, s);
 }
 
@@ -271,7 +273,7 @@ __device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)
 }
 
 // LV / LV2: table form of the first- / second-derivative system (see xcoef)
-template <int M, int MODE, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false>
+template <int M, int MODE, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false, bool PER = false>
 __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
     static_assert(!CL || WPL > 1, "constants in LDS: several waves per line only");
     extern __shared__ double xlds[];
@@ -392,9 +394,9 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
                 double um[3], up[3];
                 xhalo<M, WPL>(cx, u, um, up);
                 double x1[M], x2[M];
-                xsten<M, false, WPL>(x1, u, um, up, a.s1, lane);
+                xsten<M, false, WPL, PER>(x1, u, um, up, a.s1, lane);
                 xsolve<M, LV, WPL, CL>(x1, y1, cx, n);
-                xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
+                xsten<M, true, WPL, PER>(x2, u, um, up, a.s2, lane);
                 xsolve<M, LV2, WPL, CL>(x2, y2, cx, n);
 #pragma unroll
                 for (int p = 0; p < M; ++p) x2[p] = nuf * x2[p] - v[p] * x1[p];      // opr_burgers.f90:513
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
 #pragma unroll
                         for (int p = 0; p < M; ++p) wq[p] = x2[p] + v[p] * a.fidte;
                         xhalo<M, WPL>(cx, wq, um, up);
-                        xsten<M, false, WPL>(x1, wq, um, up, a.s1, lane);
+                        xsten<M, false, WPL, PER>(x1, wq, um, up, a.s1, lane);
                         xsolve<M, LV, WPL, CL>(x1, y1, cx, n);
                         if (live) xstore<M>(a.fdiv + off, x1);
                     }
@@ -468,11 +470,11 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
             xhalo<M, WPL>(cx, u, um, up);
             double x1[M], x2[M];
             if (NEED1) {
-                xsten<M, false, WPL>(x1, u, um, up, a.s1, lane);
+                xsten<M, false, WPL, PER>(x1, u, um, up, a.s1, lane);
                 xsolve<M, LV, WPL, CL>(x1, y1, cx, n);
             }
             if (NEED2) {
-                xsten<M, true, WPL>(x2, u, um, up, a.s2, lane);
+                xsten<M, true, WPL, PER>(x2, u, um, up, a.s2, lane);
                 xsolve<M, LV2, WPL, CL>(x2, y2, cx, n);
             }
             if (!live) continue;                     // (WPL > 1: after the last barrier of this line)
@@ -918,7 +920,7 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a,
 // ============================================================================================
 static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
 
-template <int M, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false>
+template <int M, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false, bool PER = false>
 static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     constexpr int P = 64 * WPL, LPB = TPB / 64 / WPL;
     const long long blocks_needed = (a.nlines + LPB - 1) / LPB;
@@ -939,18 +941,18 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a, hipStream_t st) {
     }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     ProfScope ps(names[mode], st, bytes);
     switch (mode) {
-    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
     }
     return hipGetLastError();
 }
@@ -996,8 +998,11 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
     }
     if (chunks != 64) return hipErrorInvalidValue;
     switch (n) {
-    case 256: return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);
-    case 512: return launch_xline_m<8, 1, 1>(mode, a, st);         // (scalar loads of common rows are slower: see above)
+    case 256:
+        if (a.s1.periodic && lane_variant) return launch_xline_m<4, 1, 1, 1, 256, false, true>(mode, a, st);
+        return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);
+    case 512:         // (scalar loads of common rows are slower: see above)
+        return a.s1.periodic ? launch_xline_m<8, 1, 1, 1, 256, false, true>(mode, a, st) : launch_xline_m<8, 1, 1>(mode, a, st);
     case 1024: return lane_variant ? launch_xline_m<16, 1, 1>(mode, a, st) : launch_xline_m<16, 0, 1>(mode, a, st);
     case 2048: return lane_variant ? launch_xline_m<32, 2, 1>(mode, a, st) : launch_xline_m<32, 0, 1>(mode, a, st);     // the caller checked xline_wide_ok
     }
