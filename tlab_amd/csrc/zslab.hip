@@ -171,16 +171,27 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
     // operand rows + 3-row halos; no wrap: the rows before / after the slab are the neighbours' planes (wave-uniform choice of the base pointer)
     const double *__restrict__ lo = (MODE == MODE_BURGERS) ? a.flo[fi] : a.lo0;
     const double *__restrict__ hi = (MODE == MODE_BURGERS) ? a.fhi[fi] : a.hi0;
-    auto row_of = [&](const double *in, const double *l, const double *h, int r) -> const double * {
-        return r < 0 ? l + (long long)(r + 3) * rs : (r >= a.kmax ? h + (long long)(r - a.kmax) * rs : in + (long long)r * rs);
+    // Row addresses: one pointer per array, advanced by the plane stride from row to row (every (row0 + p) * rs as a product of its own was a
+    // third of the instructions of this kernel and put it into 275 spilled SGPRs); only the three rows before the first chunk and after the last
+    // one can lie in the neighbours' planes.
+    const bool first_chunk = row0 == 0, last_chunk = row0 + M == a.kmax;
+    auto load_rows = [&](const double *in, const double *l, const double *h, double (&v)[M + 6]) {
+        // (wave-uniform row pointers, the lane's line as the index: scalar base + vector offset addressing)
+        const double *pin = in + (long long)row0 * rs;                   // row row0
+        const double *pl = first_chunk ? l : pin - 3 * rs;               // row row0 - 3
+        const double *ph = last_chunk ? h : pin + (long long)M * rs;     // row row0 + M
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v[k] = valid ? pl[base] : 0.0; pl += rs; }
+#pragma unroll
+        for (int p = 0; p < M; ++p) { v[p + 3] = valid ? pin[base] : 0.0; pin += rs; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v[M + 3 + k] = valid ? ph[base] : 0.0; ph += rs; }
     };
     double e[M + 6];
-#pragma unroll
-    for (int p = 0; p < M + 6; ++p) e[p] = valid ? row_of(in0, lo, hi, row0 - 3 + p)[base] : 0.0;
+    load_rows(in0, lo, hi, e);
     if (MODE == MODE_P1 && a.in0b != nullptr) {
         double eb[M + 6];
-#pragma unroll
-        for (int p = 0; p < M + 6; ++p) eb[p] = valid ? row_of(a.in0b, a.lo0b, a.hi0b, row0 - 3 + p)[base] : 0.0;
+        load_rows(a.in0b, a.lo0b, a.hi0b, eb);
 #pragma unroll
         for (int p = 0; p < M + 6; ++p) e[p] = e[p] + eb[p] * a.scale;
     }
@@ -195,8 +206,9 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
     z_solve<M, PHASE>(x1, a.y1, a.kmax, w, C, lane, valid, line, a.nlines, msg0, a, s_yl, s_r, s_x);
     double vl[(MODE == MODE_BURGERS && PHASE == 2) ? M : 1];
     if constexpr (MODE == MODE_BURGERS && PHASE == 2) {   // issued before the second solve: its latency hides behind it
+        const double *pv = a.vel + (long long)row0 * rs;
 #pragma unroll
-        for (int p = 0; p < M; ++p) vl[p] = valid ? a.vel[base + (long long)(row0 + p) * rs] : 0.0;
+        for (int p = 0; p < M; ++p) { vl[p] = valid ? pv[base] : 0.0; pv += rs; }
     }
     if constexpr (MODE == MODE_BURGERS) z_solve<M, PHASE>(x2, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, msg0 + 1, a, s_yl, s_r, s_x);
     if constexpr (PHASE == 2) {
@@ -231,10 +243,12 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
             return;
         }
         if (MODE == MODE_BURGERS) {     // tendencies: read once, written once -> non-temporal (as in k_htile; 2 % of the launch)
+            double *const po0 = out0 + (long long)row0 * rs;
             if (a.acc) {
                 double o[M];
+                const double *po = po0;
 #pragma unroll
-                for (int p = 0; p < M; ++p) o[p] = __builtin_nontemporal_load(&out0[base + (long long)(row0 + p) * rs]);
+                for (int p = 0; p < M; ++p) { o[p] = __builtin_nontemporal_load(po + base); po += rs; }
 #pragma unroll
                 for (int p = 0; p < M; ++p) x1[p] = o[p] + x1[p];
             }
@@ -243,22 +257,26 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
                 const bool wall = (j == 0) || (j == a.fny - 1);
                 // (the operand rows are read again here, 8 at a time: keeping e[] alive through both solves costs the kernel its occupancy --
                 // measured 0.54 against 0.38 ms per launch at 512 x 512 x 64)
-                double *qo = const_cast<double *>(in0);
+                double *qo = const_cast<double *>(in0) + (long long)row0 * rs;
 #pragma unroll
                 for (int p0 = 0; p0 < M; p0 += 8) {
                     double qv[8];
+                    double *qr = qo;
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) qv[p] = qo[base + (long long)(row0 + p0 + p) * rs];
+                    for (int p = 0; p < 8; ++p) { qv[p] = qr[base]; qr += rs; }
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
                         const double hv = wall ? 0.0 : x1[p0 + p];
-                        qo[base + (long long)(row0 + p0 + p) * rs] = qv[p] + a.fdte * hv;
+                        qo[base] = qv[p] + a.fdte * hv; qo += rs;
                         x1[p0 + p] = a.fscale ? a.fkco * hv : hv;
                     }
                 }
             }
+            {
+                double *po = po0;
 #pragma unroll
-            for (int p = 0; p < M; ++p) __builtin_nontemporal_store(x1[p], &out0[base + (long long)(row0 + p) * rs]);
+                for (int p = 0; p < M; ++p) { __builtin_nontemporal_store(x1[p], po + base); po += rs; }
+            }
             return;
         }
         if (a.acc) {
