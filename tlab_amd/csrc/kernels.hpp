@@ -152,6 +152,7 @@ hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int 
 hipError_t launch_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
                                int nx, int ny, int nz, hipStream_t st, const double *gw = nullptr);
 hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // n device copies, batched launches
 hipError_t launch_neumann_planes(const double *u, const double *du, const double *cb, const double *ct, int do_b, int do_t, double *hb,
                                  double *ht, int nx, int ny, int nz, hipStream_t st);
 

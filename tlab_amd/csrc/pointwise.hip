@@ -410,6 +410,40 @@ hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt,
     hipLaunchKernelGGL(k_set_wall_planes_opt, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, f, pb, pt, nx, ny, nz);
     return CHECK_LAUNCH();
 }
+// up to 48 device-to-device copies in ONE launch (the single-process loopback transport of the slab driver: P x P blocks per all-to-all, the
+// ring messages of all ranks): one kernel instead of dozens of hipMemcpyAsync calls, whose host cost made that diagnostic host-bound
+struct CopyBlocks { int n; const double *src[48]; double *dst[48]; long long cnt[48]; };
+__global__ void __launch_bounds__(256) k_copy_blocks(CopyBlocks c) {
+    const int b = blockIdx.y;
+    const double *__restrict__ s = c.src[b];
+    double *__restrict__ d = c.dst[b];
+    const long long n = c.cnt[b], stride = (long long)gridDim.x * blockDim.x;
+    if ((((size_t)s | (size_t)d) & 15) == 0) {
+        const double2 *s2 = reinterpret_cast<const double2 *>(s);
+        double2 *d2 = reinterpret_cast<double2 *>(d);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += stride) d2[i] = s2[i];
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) d[n - 1] = s[n - 1];
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s[i];
+    }
+}
+hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st) {
+    for (int b0 = 0; b0 < n; b0 += 48) {
+        CopyBlocks c;
+        c.n = std::min(48, n - b0);
+        long long mx = 0;
+        for (int b = 0; b < 48; ++b) {
+            const bool in = b < c.n;
+            c.src[b] = in ? src[b0 + b] : nullptr; c.dst[b] = in ? dst[b0 + b] : nullptr; c.cnt[b] = in ? cnt[b0 + b] : 0;
+            mx = std::max(mx, c.cnt[b]);
+        }
+        if (mx == 0) continue;
+        const unsigned gx = (unsigned)std::min<long long>((mx / 2 + 255) / 256 + 1, 2048 / c.n + 1);
+        hipLaunchKernelGGL(k_copy_blocks, dim3(gx, (unsigned)c.n), dim3(256), 0, st, c);
+        if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    }
+    return hipSuccess;
+}
 hipError_t launch_neumann_planes(const double *u, const double *du, const double *cb, const double *ct, int do_b, int do_t, double *hb,
                                  double *ht, int nx, int ny, int nz, hipStream_t st) {
     NeumannCoef c;

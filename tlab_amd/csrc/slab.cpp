@@ -39,6 +39,10 @@ int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int 
 int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *const *p_halo, const double *tail_left,
                                          const double *head_right, double *q, double *h, double dte, double kco, int scale);
 
+namespace tlab {
+hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // pointwise.hip
+}
+
 namespace {
 
 struct Fail : std::runtime_error {
@@ -64,23 +68,29 @@ constexpr int HALO = 3;      // planes each side: the 7-diagonal right-hand side
 struct Loopback {
     int P;
 };
+// (the copies of one exchange go out as a few batched launches: dozens of hipMemcpyAsync calls per exchange made the diagnostic host-bound)
 int lb_ring(void *ctx, void *stream, int nmsg, const long long *count, double *const *to_left, double *const *to_right, double *const *from_right,
             double *const *from_left) {
     const int P = static_cast<Loopback *>(ctx)->P;
     hipStream_t st = (hipStream_t)stream;
+    std::vector<const double *> src;
+    std::vector<double *> dst;
+    std::vector<long long> cnt;
     for (int r = 0; r < P; ++r) {
         const int left = (r + P - 1) % P, right = (r + 1) % P;
         for (int i = 0; i < nmsg; ++i) {
-            const size_t bytes = (size_t)count[i] * sizeof(double);
-            if (hipMemcpyAsync(from_right[left * nmsg + i], to_left[r * nmsg + i], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return TLAB_EHIP;
-            if (hipMemcpyAsync(from_left[right * nmsg + i], to_right[r * nmsg + i], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return TLAB_EHIP;
+            src.push_back(to_left[r * nmsg + i]); dst.push_back(from_right[left * nmsg + i]); cnt.push_back(count[i]);
+            src.push_back(to_right[r * nmsg + i]); dst.push_back(from_left[right * nmsg + i]); cnt.push_back(count[i]);
         }
     }
-    return 0;
+    return tlab::launch_copy_blocks((int)src.size(), src.data(), dst.data(), cnt.data(), st) == hipSuccess ? 0 : TLAB_EHIP;
 }
 int lb_a2a(void *ctx, void *stream, double *const *send, const long long *scount, double *const *recv, const long long *rcount) {
     const int P = static_cast<Loopback *>(ctx)->P;
     hipStream_t st = (hipStream_t)stream;
+    std::vector<const double *> sp;
+    std::vector<double *> dp;
+    std::vector<long long> cn;
     for (int dst = 0; dst < P; ++dst) {
         long long ro = 0;
         for (int src = 0; src < P; ++src) {
@@ -88,12 +98,11 @@ int lb_a2a(void *ctx, void *stream, double *const *send, const long long *scount
             for (int p = 0; p < dst; ++p) so += scount[src * P + p];
             const long long cnt = scount[src * P + dst];
             if (cnt != rcount[dst * P + src]) return TLAB_EINVAL;
-            if (cnt > 0 && hipMemcpyAsync(recv[dst] + ro, send[src] + so, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
-                return TLAB_EHIP;
+            if (cnt > 0) { sp.push_back(send[src] + so); dp.push_back(recv[dst] + ro); cn.push_back(cnt); }
             ro += cnt;
         }
     }
-    return 0;
+    return tlab::launch_copy_blocks((int)sp.size(), sp.data(), dp.data(), cn.data(), st) == hipSuccess ? 0 : TLAB_EHIP;
 }
 int lb_wait(void *, void *, int) { return TLAB_OK; }
 int lb_allreduce(void *ctx, double *v, int n, int op) {
