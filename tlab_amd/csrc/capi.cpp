@@ -606,6 +606,7 @@ struct OpExtra {
     double *fq = nullptr;
     double fdte = 0.0, fkco = 1.0;
     int fscale = 0, fnx = 1, fny = 1;
+    const double *fpb = nullptr, *fpt = nullptr;      // ... with given wall tendencies (Neumann walls) instead of zero
     int ffin[4] = {0, 0, 0, 0};
     double *fdiv = nullptr;
     double fidte = 0.0;
@@ -716,7 +717,7 @@ void run_rtile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.in0 = in0; a.in1 = in1; a.in2 = in2; a.out0 = out; a.out1 = nullptr; a.g = geom; a.nu = nu;
     a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.sub ? 2 : (ex.acc ? 1 : 0);
     a.nf = 0;
-    a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny;
+    a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny; a.fpb = ex.fpb; a.fpt = ex.fpt;
     a.fneu = ex.fneu;
     for (int q = 0; q < 4; ++q) { a.fcb[q] = ex.fcb[q]; a.fct[q] = ex.fct[q]; }
     a.s1 = g->stencil(1, ibc);
@@ -737,7 +738,7 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     RTileArgs a{};
     a.in0 = in0; a.in1 = nullptr; a.in2 = vel; a.out0 = out0; a.out1 = out1; a.g = geom; a.nu = nu;
     a.in0b = nullptr; a.in0b_scale = 0.0; a.acc = ex.acc ? 1 : 0;
-    a.fq = nullptr; a.fdte = 0.0; a.fkco = 1.0; a.fscale = 0; a.fnx = 1; a.fny = 1;
+    a.fq = nullptr; a.fdte = 0.0; a.fkco = 1.0; a.fscale = 0; a.fnx = 1; a.fny = 1; a.fpb = nullptr; a.fpt = nullptr;
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; }
     a.s1 = g->stencil(1, ibc);
@@ -755,7 +756,7 @@ void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     XLineArgs a;
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1; a.nlines = geom.nlines; a.nu = nu;
     a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.sub ? 2 : (ex.acc ? 1 : 0);
-    a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny;
+    a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny; a.fpb = ex.fpb; a.fpt = ex.fpt;
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; a.ffin[f] = ex.ffin[f]; }
     a.fdiv = ex.fdiv; a.fidte = ex.fidte;
@@ -873,14 +874,15 @@ bool tlab_internal_neumann_final(tlab_fdm_plan_t g, int nx, int ny, int nz, int 
 }
 // h -= d/dx_dir p ; walls ; q += dte h ; h *= kco : the last pass over a velocity component folded into the gradient of the pressure.
 // Dirichlet walls only (the tendency is zero on the wall planes); dir = 1 or 3.
+// pb, pt (device, [nx][nz]; NULL: zero): the tendencies of the wall planes j = 0 / ny-1 (BOUNDARY_BCS_NEUMANN_Y's values for a Neumann wall)
 bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
-                                  double kco, int scale) {
+                                  double kco, int scale, const double *pb, const double *pt) {
     check_common(dir, g, nx, ny, nz, 0);
     if (dir == 2) return false;
     const LineGeom geom = make_geom(dir, nx, ny, nz);
     if (geom.n == 1) return false;
     OpExtra ex;
-    ex.fq = q; ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fnx = nx; ex.fny = ny;
+    ex.fq = q; ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fnx = nx; ex.fny = ny; ex.fpb = pb; ex.fpt = pt;
     const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE) run_xline(g, geom, MODE_P1, 0, p, nullptr, h, nullptr, 0.0, ex);
     else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_rtile(g, geom, MODE_P1, 0, p, nullptr, nullptr, h, 0.0, ex);
@@ -1040,7 +1042,7 @@ int tlab_opr_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, 
     return guarded([&] {
         check_common(dir, g, nx, ny, nz, 0);
         if (!p || !q || !h || q == h || p == q || p == h) throw Invalid("tlab_opr_gradient_final: null or aliased arrays");
-        if (tlab_internal_gradient_final(dir, g, nx, ny, nz, p, q, h, dte, kco, scale)) return;
+        if (tlab_internal_gradient_final(dir, g, nx, ny, nz, p, q, h, dte, kco, scale, nullptr, nullptr)) return;
         if (!tmp1 || tmp1 == p || tmp1 == q || tmp1 == h) throw Invalid("tlab_opr_gradient_final: the unfused path needs tmp1");
         const int rc = tlab_opr_partial(dir, g, TLAB_OPR_P1, nx, ny, nz, 0, p, tmp1, nullptr);
         if (rc != TLAB_OK) throw Invalid(std::string("tlab_opr_gradient_final: ") + g_err);

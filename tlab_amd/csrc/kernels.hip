@@ -482,9 +482,11 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
                 if (a.fq != nullptr) {          // final-update epilogue: the line is (j, k) = (line % ny, line / ny)
                     const int j = (int)(line % a.fny);
                     const bool wall = (j == 0) || (j == a.fny - 1);
+                    const double *wp = wall ? (j == 0 ? a.fpb : a.fpt) : nullptr;      // given wall tendencies (Neumann walls), or zero
+                    if (wp != nullptr) wp += (line / a.fny) * n + gl * M;
 #pragma unroll
                     for (int p = 0; p < M; ++p) {
-                        const double hv = wall ? 0.0 : h[p] - x1[p];
+                        const double hv = wall ? (wp ? wp[p] : 0.0) : h[p] - x1[p];
                         qv[p] = qv[p] + a.fdte * hv;
                         h[p] = a.fscale ? a.fkco * hv : hv;
                     }
@@ -687,6 +689,8 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
         if (valid) {
             const int j = ((l0 + lane) / a.fnx) % a.fny;
             const bool wall = (j == 0) || (j == a.fny - 1);
+            const double *wp = wall ? (j == 0 ? a.fpb : a.fpt) : nullptr;      // given wall tendencies (Neumann walls), or zero
+            if (wp != nullptr) wp += (l0 + lane) % a.fnx;
             // 8 rows at a time: 16 loads in flight, then their stores (f[M] + h[M] + q[M] would not fit the 128 VGPRs of the 1024-thread launch)
 #pragma unroll
             for (int p0 = 0; p0 < M; p0 += 8) {
@@ -698,7 +702,7 @@ __global__ void __launch_bounds__(MAXT) k_rtile(RTileArgs a) {
                 }
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
-                    const double hv = wall ? 0.0 : h[p] - f[p0 + p];
+                    const double hv = wall ? (wp ? wp[(long long)(row0 + p0 + p) * a.fnx] : 0.0) : h[p] - f[p0 + p];
                     qv[p] = qv[p] + a.fdte * hv;
                     h[p] = a.fscale ? a.fkco * hv : hv;
                 }

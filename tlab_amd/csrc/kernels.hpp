@@ -29,6 +29,7 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     double *fq;
     double fdte, fkco;
     int fscale, fnx, fny;
+    const double *fpb, *fpt;      // final-update epilogue: wall tendencies of the planes j = 0 / fny-1, [fnx][nz] each (NULL: zero, Dirichlet walls)
     // MODE_BURGERS, 8 rows per lane at most: ffin[f] != 0 finishes the substep of transported field f (a scalar: no pressure term) in the epilogue
     // of this launch, which must be the LAST one that adds to its tendency:  h = fo[f] (+ this term) ; h = 0 on the wall planes ;
     // fs[f] += fdte h ; fo[f] = fscale ? fkco h : h     (time.f90:645-664, :272-297; Dirichlet walls)
@@ -67,6 +68,7 @@ struct RTileArgs {          // k_rtile: derivative along a strided index
     double *fq;
     double fdte, fkco;
     int fscale, fnx, fny;
+    const double *fpb, *fpt;      // final-update epilogue: wall tendencies of the planes j = 0 / fny-1, [fnx][nz] each (NULL: zero, Dirichlet walls)
     // k_htile MODE_BURGERS: bit f of fresh_mask set = field f OVERWRITES its tendency although acc is set (a field whose first term this launch
     // adds, in a launch that accumulates for the others)
     unsigned fresh_mask;
@@ -152,6 +154,9 @@ hipError_t launch_fill_wall_planes(double *f, double vb, double vt, int nx, int 
 hipError_t launch_final_update(double *q, double *h, const double *g, const double *pb, const double *pt, double dte, double kco, int scale,
                                int nx, int ny, int nz, hipStream_t st, const double *gw = nullptr);
 hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_wall_weighted(const double *a1, const double *a2, const double *wb, const double *wt, int K, double *ob1, double *ot1, double *ob2,
+                                double *ot2, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_sub2(double *o, const double *a, const double *b, long long n, hipStream_t st);
 hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // n device copies, batched launches
 hipError_t launch_neumann_planes(const double *u, const double *du, const double *cb, const double *ct, int do_b, int do_t, double *hb,
                                  double *ht, int nx, int ny, int nz, hipStream_t st);

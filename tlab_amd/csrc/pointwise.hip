@@ -410,6 +410,44 @@ hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt,
     hipLaunchKernelGGL(k_set_wall_planes_opt, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, f, pb, pt, nx, ny, nz);
     return CHECK_LAUNCH();
 }
+// Weighted sums over the K rows next to each wall: ob[ix, k] = sum_{j < K} wb[j] a[ix, j, k], ot[ix, k] = sum_{j < K} wt[j] a[ix, ny-1-j, k], for one or
+// two fields at once (a2 / ob2 / ot2 may be NULL).  With wb, wt = the row of the Neumann operator that BOUNDARY_BCS_NEUMANN_Y applies to a finished
+// tendency (its wall value is a linear functional of the line whose weights decay like 0.38^j), this is that wall value without the y-derivative
+// pass over the whole field.
+__global__ void __launch_bounds__(256) k_wall_weighted(const double *__restrict__ a1, const double *__restrict__ a2, const double *__restrict__ wb,
+                                                       const double *__restrict__ wt, int K, double *__restrict__ ob1, double *__restrict__ ot1,
+                                                       double *__restrict__ ob2, double *__restrict__ ot2, int nx, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * nz) return;
+    const int ix = (int)((unsigned long long)i % (unsigned)nx);
+    const long long k = i / nx;
+    const long long base = ix + (long long)nx * ny * k;
+    double sb1 = 0.0, st1 = 0.0, sb2 = 0.0, st2 = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const double cb = wb ? wb[j] : 0.0, ct = wt ? wt[j] : 0.0;
+        const long long lo = base + (long long)nx * j, hi = base + (long long)nx * (ny - 1 - j);
+        sb1 += cb * a1[lo]; st1 += ct * a1[hi];
+        if (a2) { sb2 += cb * a2[lo]; st2 += ct * a2[hi]; }
+    }
+    ob1[i] = sb1; ot1[i] = st1;
+    if (a2) { ob2[i] = sb2; ot2[i] = st2; }
+}
+hipError_t launch_wall_weighted(const double *a1, const double *a2, const double *wb, const double *wt, int K, double *ob1, double *ot1, double *ob2,
+                                double *ot2, int nx, int ny, int nz, hipStream_t st) {
+    ProfScope ps("k_wall_weighted", st, (double)nx * nz * K * (a2 ? 32.0 : 16.0));
+    hipLaunchKernelGGL(k_wall_weighted, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, a1, a2, wb, wt, K, ob1, ot1, ob2, ot2, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
+// o = a - b (planes)
+__global__ void __launch_bounds__(256) k_sub2(double *__restrict__ o, const double *__restrict__ a, const double *__restrict__ b, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] - b[i];
+}
+hipError_t launch_sub2(double *o, const double *a, const double *b, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_sub2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, o, a, b, n);
+    return CHECK_LAUNCH();
+}
+
 // up to 48 device-to-device copies in ONE launch (the single-process loopback transport of the slab driver: P x P blocks per all-to-all, the
 // ring messages of all ranks): one kernel instead of dozens of hipMemcpyAsync calls, whose host cost made that diagnostic host-bound
 struct CopyBlocks { int n; const double *src[48]; double *dst[48]; long long cnt[48]; };

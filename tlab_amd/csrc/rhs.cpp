@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <memory>
 #include <stdexcept>
@@ -27,7 +28,7 @@ bool tlab_internal_partial_p1_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny
 bool tlab_internal_burgers_acc(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, double nu, const double *s, const double *vel,
                                double *result);
 bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, const double *p, double *q, double *h, double dte,
-                                  double kco, int scale);
+                                  double kco, int scale, const double *pb = nullptr, const double *pt = nullptr);
 bool tlab_internal_burgers_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
 extern "C" bool tlab_internal_dealiasing();      // capi.cpp (defined inside its extern "C" block)
 extern "C" int tlab_internal_anelastic_state(const double **rb, const double **rib, unsigned long *version);
@@ -71,6 +72,10 @@ struct tlab_dns {
     int koffset = 0, nz_total = 0;                 // z-slab: first global plane and global nz (one_ov_ds1 of z is indexed globally)
     // nse_eqns == DNS_EQNS_ANELASTIC: rbackground, ribackground (ny values each) on the device; the wall values of rbackground on the host
     double *rb = nullptr, *rib = nullptr;
+    // BOUNDARY_BCS_NEUMANN_Y as a weighted sum over the rows next to the wall (neumann_weights below): per variant ibc = 1..3 the device weights
+    // [2][K] (bottom, top), K, and six scratch planes
+    struct NeuW { double *w = nullptr; int K = 0; bool tried = false; } neuw[4];
+    double *wall_planes = nullptr;
     double rb_wall[2] = {1.0, 1.0};
     unsigned long anel_version = 0;                // change counter of the operator state these mirror (follow_anelastic)
     bool anel_owner = false;                       // this driver switched the operator state on (tlab_dns_set_anelastic): it goes with the driver
@@ -85,6 +90,8 @@ struct tlab_dns {
         if (sfc_avg) (void)hipFree(sfc_avg);
         if (rb) (void)hipFree(rb);
         if (rib) (void)hipFree(rib);
+        for (NeuW &n : neuw) if (n.w) (void)hipFree(n.w);
+        if (wall_planes) (void)hipFree(wall_planes);
     }
 };
 
@@ -98,6 +105,59 @@ void ok(int rc, const char *what) {
 }
 void hk(hipError_t e, const char *what) {
     if (e != hipSuccess) throw Fail(TLAB_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// The wall value BOUNDARY_BCS_NEUMANN_Y (boundary_bcs.f90:368-473) gives a finished tendency h is a LINEAR functional of the y line:
+// c0 h(2) + c1 h(3) + c2 h(4) + c3 (D_N h)(2) with D_N the first derivative under the Neumann variant of the system.  Its weights are found once per
+// plan and variant by sending the unit vectors through the library's own routine (an ny x ny x 1 box holding the identity), and they decay like the
+// coupling of the compact system (0.38^j): K = the rows beyond which they are below 1e-22 of the largest.  The wall planes of a field then cost a
+// weighted sum over 2 K rows instead of a derivative pass over the field; and for u (w), whose finished tendency is hq - dp/dx (dp/dz), the sum
+// commutes with the x (z) derivative: wall value = sum_j w_j hq(j) - d/dx [sum_j w_j p(j)] -- one derivative of a PLANE.
+// (K <= ny always: on short lines the two sums overlap, which is as exact as the full line.)  Returns false where the weights are not finite.
+bool neumann_weights(tlab_dns *d, int ibc) {
+    tlab_dns::NeuW &W = d->neuw[ibc];
+    if (W.tried) return W.w != nullptr;
+    W.tried = true;
+    const int ny = d->ny;
+    const size_t N = (size_t)ny * ny;
+    double *h = nullptr, *tmp = nullptr, *hb = nullptr, *ht = nullptr;
+    auto release = [&] { for (double *p : {h, tmp, hb, ht}) if (p) (void)hipFree(p); };
+    try {
+        hk(hipMalloc((void **)&h, N * sizeof(double)), "hipMalloc");
+        hk(hipMalloc((void **)&tmp, (N + 2 * (size_t)ny) * sizeof(double)), "hipMalloc");
+        hk(hipMalloc((void **)&hb, (size_t)ny * sizeof(double)), "hipMalloc");
+        hk(hipMalloc((void **)&ht, (size_t)ny * sizeof(double)), "hipMalloc");
+        std::vector<double> id(N, 0.0);
+        for (int j = 0; j < ny; ++j) id[(size_t)j * ny + j] = 1.0;       // column ix = j carries the unit vector e_j along y: h(ix, j) = delta
+        hk(hipMemcpy(h, id.data(), N * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+        hk(hipMemset(hb, 0, (size_t)ny * sizeof(double)), "hipMemset");
+        hk(hipMemset(ht, 0, (size_t)ny * sizeof(double)), "hipMemset");
+        ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, ny, ny, 1, h, hb, ht, tmp), "BOUNDARY_BCS_NEUMANN_Y (weights)");
+        hk(hipStreamSynchronize(tlab_current_stream()), "sync");
+        std::vector<double> wb(ny), wt(ny);
+        hk(hipMemcpy(wb.data(), hb, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+        hk(hipMemcpy(wt.data(), ht, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+        release();
+        h = tmp = hb = ht = nullptr;
+        double mb = 0.0, mt = 0.0;
+        for (int j = 0; j < ny; ++j) { mb = std::max(mb, std::fabs(wb[j])); mt = std::max(mt, std::fabs(wt[j])); }
+        int K = 1;
+        for (int j = 0; j < ny; ++j) {
+            if ((ibc & 1) && std::fabs(wb[j]) > 1.0e-22 * mb) K = std::max(K, j + 1);
+            if ((ibc & 2) && std::fabs(wt[ny - 1 - j]) > 1.0e-22 * mt) K = std::max(K, j + 1);
+        }
+        for (int j = 0; j < ny; ++j)
+            if (!std::isfinite(wb[j]) || !std::isfinite(wt[j])) return false;
+        std::vector<double> w((size_t)2 * K, 0.0);
+        for (int j = 0; j < K; ++j) { w[j] = (ibc & 1) ? wb[j] : 0.0; w[K + j] = (ibc & 2) ? wt[ny - 1 - j] : 0.0; }
+        hk(hipMalloc((void **)&W.w, w.size() * sizeof(double)), "hipMalloc");
+        hk(hipMemcpy(W.w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+        W.K = K;
+        return true;
+    } catch (...) {
+        release();
+        throw;
+    }
 }
 }  // namespace
 
@@ -418,14 +478,30 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp3, tmp4), "OPR_FILTER(dpdy)");
     }
     if (neu_fast) {
+        const char *npe = getenv("TLAB_NEUMANN_PLANES");      // (read per substep: A/B in one process)
+        const bool neu_planes = !(npe && atoi(npe) == 0);
         for (int iq = 0; iq < 3; iq += 2) {      // u along x, w along z
             const int dir = iq == 0 ? 1 : 3;
             tlab_fdm_plan_t gd = iq == 0 ? gx : gz;
             const int ibc = ibc_y(d->flow_jmin[iq], d->flow_jmax[iq]);
             bool done;
             if (ibc == 0) done = tlab_internal_gradient_final(dir, gd, nx, ny, nz, tmp1, q[iq], hq[iq], dte, kco, scale_tendencies);
-            else done = tlab_internal_partial_p1_sub(dir, gd, nx, ny, nz, tmp1, hq[iq]) &&
-                        tlab_internal_neumann_final(gy, nx, ny, nz, ibc, hq[iq], q[iq], dte, kco, scale_tendencies);
+            else if (neu_planes && neumann_weights(d, ibc)) {
+                // wall tendencies from weighted sums over the rows next to the walls (of hq and of p; the derivative of the p planes commutes
+                // with the sum), then the gradient kernel finishes the field as it does with Dirichlet walls -- one pass over hq instead of two
+                const tlab_dns::NeuW &W = d->neuw[ibc];
+                const size_t np = (size_t)nx * nz;
+                if (!d->wall_planes) hk(hipMalloc((void **)&d->wall_planes, 6 * np * sizeof(double)), "hipMalloc");
+                double *Hb = d->wall_planes, *Ht = Hb + np, *Pb = Ht + np, *Pt = Pb + np, *Db = Pt + np, *Dt = Db + np;
+                hk(launch_wall_weighted(hq[iq], tmp1, W.w, W.w + W.K, W.K, Hb, Ht, Pb, Pt, nx, ny, nz, st), "wall planes");
+                ok(tlab_opr_partial(dir, gd, TLAB_OPR_P1, nx, 1, nz, 0, Pb, Db, nullptr), "OPR_Partial (wall plane)");
+                ok(tlab_opr_partial(dir, gd, TLAB_OPR_P1, nx, 1, nz, 0, Pt, Dt, nullptr), "OPR_Partial (wall plane)");
+                hk(launch_sub2(Hb, Hb, Db, (long long)np, st), "wall planes");
+                hk(launch_sub2(Ht, Ht, Dt, (long long)np, st), "wall planes");
+                done = tlab_internal_gradient_final(dir, gd, nx, ny, nz, tmp1, q[iq], hq[iq], dte, kco, scale_tendencies, (ibc & 1) ? Hb : nullptr,
+                                                    (ibc & 2) ? Ht : nullptr);
+            } else done = tlab_internal_partial_p1_sub(dir, gd, nx, ny, nz, tmp1, hq[iq]) &&
+                          tlab_internal_neumann_final(gy, nx, ny, nz, ibc, hq[iq], q[iq], dte, kco, scale_tendencies);
             if (!done) throw Fail(TLAB_EINVAL, "internal: inconsistent fused Neumann tail");
         }
         for (int is = 0; is < d->nscal && !finish_scal; ++is) {
