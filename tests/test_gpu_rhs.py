@@ -392,8 +392,10 @@ def test_forcing_terms_inside_the_burgers_launches(T, walls):
     assert rows.get("k_htile<BURGERS+div>") == 6, rows          # v along y and w along z, three substeps
     if walls == "noslip":
         assert "k_rtile<P1>" not in rows or rows["k_rtile<P1>"] == 3, rows      # only the gradient-final launches of w are left of that kernel
-    else:       # u, w and the two scalars: BOUNDARY_BCS_NEUMANN_Y + final update in one launch each, three substeps; no separate update pass is left
-        assert rows.get("k_rtile<P1+neumann final>") == 12 and "k_final_update" not in rows and "k_sub3" not in rows, rows
+    else:       # the two scalars: BOUNDARY_BCS_NEUMANN_Y + final update in one launch each, three substeps; u and w: their wall planes from weighted
+        # sums (one launch each per substep) and the gradient kernels finish them; no separate update pass is left
+        assert rows.get("k_rtile<P1+neumann final>") == 6 and rows.get("k_wall_weighted") == 6, rows
+        assert "k_final_update" not in rows and "k_sub3" not in rows, rows
     for a in o.hq + o.hs:
         a[:] = 0.0
     for k in range(3):
