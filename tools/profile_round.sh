@@ -29,6 +29,17 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/raw_ops_fet
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/raw_ops_write" -- python3 "$OPS" --types P1 --iters 5 > /dev/null 2>> "$O/rocprof_ops.err"
 python3 "$ROOT/tools/pmc_summary.py" pmc "$O/raw_ops_fetch" "$O/raw_ops_write" > "$O/pmc_hbm_traffic_opr_partial_p1.txt"
 python3 "$OPS" --types P1,BURGERS --iters 20 > "$O/ops_standalone.txt" 2>&1
+# 4. the other lines profiles/README.md quotes, same binaries, same session (outside the profiler)
+Q="--cpu-sample 0 --no-freeslip-leg"
+python3 "$B" --loopback 8 --steps 20 --warmup 5 $Q > "$O/bench_loopback8_native.json" 2> /dev/null
+TLAB_SLAB_FUSED_X=0 python3 "$B" --loopback 8 --steps 20 --warmup 5 $Q > "$O/bench_loopback8_native_unfused.json" 2> /dev/null
+python3 "$B" --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_freeslip.json" 2> /dev/null
+TLAB_NEUMANN_PLANES=0 python3 "$B" --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_freeslip_derivative_pass.json" 2> /dev/null
+python3 "$B" --grid 2048 1024 256 --nscal 3 --steps 6 --warmup 2 $Q > "$O/bench_configs4_rank_share.json" 2> /dev/null
+python3 "$B" --grid 1024 512 1024 --steps 6 --warmup 2 $Q > "$O/bench_configs3_one_device.json" 2> /dev/null
+TLAB_PROFILE_REPORT=1 python3 "$ROOT/tools/bench_poisson.py" > "$O/poisson_standalone.txt" 2>&1
+python3 "$ROOT/tools/bench_xlines.py" 2> /dev/null | grep grid > "$O/xlines.jsonl"
+python3 "$ROOT/tools/bench_xlines.py" --exact-uniform --grids 2048x1024x64 2> /dev/null | grep grid > "$O/xlines_equal_rows_2048.jsonl"
 # the raw rocprofv3 trees are large: only the summaries travel back
 rm -rf "$O"/raw_*
 ls -la "$O"
