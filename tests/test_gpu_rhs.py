@@ -165,7 +165,7 @@ def test_neumann_wall_planes_route(T, vel, scal, monkeypatch):
         L.tlab_profile_report(buf, len(buf))
         rep = buf.value.decode()
         assert ("k_wall_weighted" in rep) == (planes == "1"), rep              # the route taken
-        assert "k_rtile<P1+neumann final>" in rep or planes == "1"
+        assert ("k_rtile<P1+neumann final>" in rep) == (planes == "0"), rep   # ... for the Neumann scalar as well (its interior rides on the x Burgers launch)
         out[planes] = [t.cpu().numpy().copy() for t in d.q + d.s + d.hq + d.hs]
         if planes == "1":
             def make_oracle():
@@ -393,8 +393,9 @@ def test_forcing_terms_inside_the_burgers_launches(T, walls):
     if walls == "noslip":
         assert "k_rtile<P1>" not in rows or rows["k_rtile<P1>"] == 3, rows      # only the gradient-final launches of w are left of that kernel
     else:       # the two scalars: BOUNDARY_BCS_NEUMANN_Y + final update in one launch each, three substeps; u and w: their wall planes from weighted
-        # sums (one launch each per substep) and the gradient kernels finish them; no separate update pass is left
-        assert rows.get("k_rtile<P1+neumann final>") == 6 and rows.get("k_wall_weighted") == 6, rows
+        # sums (one launch each per substep; the scalars' interior rides on the x Burgers launch) and the gradient kernels finish u and w; no
+        # derivative pass along y and no separate update pass is left
+        assert "k_rtile<P1+neumann final>" not in rows and rows.get("k_wall_weighted") == 12, rows
         assert "k_final_update" not in rows and "k_sub3" not in rows, rows
     for a in o.hq + o.hs:
         a[:] = 0.0

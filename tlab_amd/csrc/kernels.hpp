@@ -156,6 +156,8 @@ hipError_t launch_final_update(double *q, double *h, const double *g, const doub
 hipError_t launch_set_wall_planes(double *f, const double *pb, const double *pt, int nx, int ny, int nz, hipStream_t st);
 hipError_t launch_wall_weighted(const double *a1, const double *a2, const double *wb, const double *wt, int K, double *ob1, double *ot1, double *ob2,
                                 double *ot2, int nx, int ny, int nz, hipStream_t st);
+hipError_t launch_wall_fix(double *q, double *h, const double *sb, const double *st, double dte, double kco, int scale, int nx, int ny, int nz,
+                           hipStream_t stream);
 hipError_t launch_sub2(double *o, const double *a, const double *b, long long n, hipStream_t st);
 hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // n device copies, batched launches
 hipError_t launch_neumann_planes(const double *u, const double *du, const double *cb, const double *ct, int do_b, int do_t, double *hb,

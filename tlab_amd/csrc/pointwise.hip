@@ -438,6 +438,24 @@ hipError_t launch_wall_weighted(const double *a1, const double *a2, const double
     hipLaunchKernelGGL(k_wall_weighted, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, a1, a2, wb, wt, K, ob1, ot1, ob2, ot2, nx, ny, nz);
     return CHECK_LAUNCH();
 }
+// Wall planes of a field whose interior was finished with zero wall tendencies (the Burgers epilogue's Dirichlet treatment) although its walls are
+// Neumann ones: sb / st = the weighted sums of k_wall_weighted over the STORED tendencies, i.e. kco times the wall tendency when the tendencies were
+// scaled (the functional is linear) -- h(wall) = s, q(wall) += dte s / kco (or dte s unscaled)
+__global__ void __launch_bounds__(256) k_wall_fix(double *__restrict__ q, double *__restrict__ h, const double *__restrict__ sb,
+                                                  const double *__restrict__ st, double dte, double kco, int scale, int nx, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * nz) return;
+    const int ix = (int)((unsigned long long)i % (unsigned)nx);
+    const long long k = i / nx;
+    const long long lo = ix + (long long)nx * ny * k, hi = lo + (long long)nx * (ny - 1);
+    if (sb) { const double s = sb[i]; h[lo] = s; q[lo] = q[lo] + dte * (scale ? s / kco : s); }
+    if (st) { const double s = st[i]; h[hi] = s; q[hi] = q[hi] + dte * (scale ? s / kco : s); }
+}
+hipError_t launch_wall_fix(double *q, double *h, const double *sb, const double *st, double dte, double kco, int scale, int nx, int ny, int nz,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(k_wall_fix, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, stream, q, h, sb, st, dte, kco, scale, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
 // o = a - b (planes)
 __global__ void __launch_bounds__(256) k_sub2(double *__restrict__ o, const double *__restrict__ a, const double *__restrict__ b, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

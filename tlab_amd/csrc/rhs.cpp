@@ -319,7 +319,29 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
     // y/z tile kernels do not, measured).  The directions then run z, y, x instead of x, y, z: the terms are summed in another order, rounding only.
     static const bool finish_off = [] { const char *e = getenv("TLAB_SCALAR_FINISH"); return e && atoi(e) == 0; }();
     bool finish_scal = !finish_off && batched && !literal && tail_update && d->nscal > 0 && tlab_internal_burgers_can_finish(1, gx, nx, ny, nz);
-    for (int is = 0; is < d->nscal; ++is)
+    // Neumann scalars can ride too where the fused Neumann tail below applies: the epilogue finishes their interior with zero wall tendencies, and the
+    // wall planes follow from weighted sums over the stored tendencies next to the walls (neumann_weights; k_wall_fix) instead of a derivative pass
+    // over the field (TLAB_NEUMANN_PLANES=0: that pass, k_rtile<P1+neumann final>)
+    bool scal_neumann_planes = false;
+    {
+        auto ibc_of = [](int tmin, int tmax) { return (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0); };
+        bool any_neu = false, scal_neu = false;
+        for (int iq = 0; iq < 3; ++iq) any_neu = any_neu || ibc_of(d->flow_jmin[iq], d->flow_jmax[iq]) != 0;
+        for (int is = 0; is < d->nscal; ++is) scal_neu = scal_neu || ibc_of(d->scal_jmin[is], d->scal_jmax[is]) != 0;
+        any_neu = any_neu || scal_neu;
+        const char *npe = getenv("TLAB_NEUMANN_PLANES");
+        const bool tail_fast = any_neu && tail_update && d->fuse && !literal && nz > 1 && !d->pfilter[0] && !d->pfilter[1] && !d->pfilter[2] && !any_surface &&
+                               tlab_internal_poisson_can_v_final(d->poisson) && tlab_internal_neumann_final_ok(gy, nx, ny, nz) &&
+                               tlab_internal_partial_p1_fusable(1, gx, nx, ny, nz) && tlab_internal_partial_p1_fusable(3, gz, nx, ny, nz);      // = neu_fast below
+        if (finish_scal && scal_neu && tail_fast && !(npe && atoi(npe) == 0)) {
+            scal_neumann_planes = true;
+            for (int is = 0; is < d->nscal; ++is) {
+                const int ibc = ibc_of(d->scal_jmin[is], d->scal_jmax[is]);
+                if (ibc != 0 && !neumann_weights(d, ibc)) scal_neumann_planes = false;
+            }
+        }
+    }
+    for (int is = 0; is < d->nscal && !scal_neumann_planes; ++is)
         finish_scal = finish_scal && d->scal_jmin[is] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[is] == TLAB_DNS_BCS_DIRICHLET;
     finish_scal = finish_scal && !any_surface;      // the wall planes of a scalar with a surface model are not zero
     // Likewise the x term of the pressure forcing, d/dx (hq1 + u/dte) (:197-230): when the x Burgers launch runs last it holds the finished
@@ -477,6 +499,7 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
         ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp1, tmp4), "OPR_FILTER(p)");
         ok(tlab_opr_filter(nx, ny, nz, d->pfilter[0], d->pfilter[1], d->pfilter[2], d->pfilter_rep, tmp3, tmp4), "OPR_FILTER(dpdy)");
     }
+    if (scal_neumann_planes && !neu_fast) throw Fail(TLAB_EINVAL, "internal: Neumann scalars were finished without their wall planes");
     if (neu_fast) {
         const char *npe = getenv("TLAB_NEUMANN_PLANES");      // (read per substep: A/B in one process)
         const bool neu_planes = !(npe && atoi(npe) == 0);
@@ -509,6 +532,16 @@ static void rhs_impl(tlab_dns_t d, double dte, double *const *q, double *const *
             if (ibc == 0) hk(launch_final_update(s[is], hs[is], nullptr, nullptr, nullptr, dte, kco, scale_tendencies, nx, ny, nz, st), "final update");
             else if (!tlab_internal_neumann_final(gy, nx, ny, nz, ibc, hs[is], s[is], dte, kco, scale_tendencies))
                 throw Fail(TLAB_EINVAL, "internal: inconsistent fused Neumann tail");
+        }
+        for (int is = 0; is < d->nscal && finish_scal && scal_neumann_planes; ++is) {      // finished by the x Burgers launch but for their wall planes
+            const int ibc = ibc_y(d->scal_jmin[is], d->scal_jmax[is]);
+            if (ibc == 0) continue;
+            const tlab_dns::NeuW &W = d->neuw[ibc];
+            const size_t np = (size_t)nx * nz;
+            if (!d->wall_planes) hk(hipMalloc((void **)&d->wall_planes, 6 * np * sizeof(double)), "hipMalloc");
+            double *Sb = d->wall_planes, *St = Sb + np;
+            hk(launch_wall_weighted(hs[is], nullptr, W.w, W.w + W.K, W.K, Sb, St, nullptr, nullptr, nx, ny, nz, st), "wall planes");
+            hk(launch_wall_fix(s[is], hs[is], (ibc & 1) ? Sb : nullptr, (ibc & 2) ? St : nullptr, dte, kco, scale_tendencies, nx, ny, nz, st), "wall planes");
         }
         return;
     }
