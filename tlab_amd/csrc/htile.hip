@@ -18,6 +18,26 @@
 
 namespace tlab {
 
+typedef __attribute__((address_space(1))) char gchar;        // global address space kept through the integer round trip below (else: flat_load)
+typedef __attribute__((address_space(1))) double gdouble;
+// a wave-uniform pointer pinned into a scalar register pair and made opaque to the optimiser
+__device__ __forceinline__ gchar *sgpr_ptr(const void *p) {
+    unsigned long long v = (unsigned long long)p;
+    asm("" : "+s"(v));
+    return (gchar *)v;
+}
+
+__device__ __forceinline__ gchar *sgpr_ptr(gchar *p) {
+    unsigned long long v = (unsigned long long)p;
+    asm("" : "+s"(v));
+    return (gchar *)v;
+}
+
+__device__ __forceinline__ unsigned vgpr_u32(unsigned v) {
+    asm("" : "+v"(v));
+    return v;
+}
+
 template <bool SYM>
 __device__ __forceinline__ double h_stencil(const StencilDev &s, double um3, double um2, double um1, double u0, double up1, double up2,
                                             double up3) {
@@ -64,13 +84,64 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
     for (int p = 1; p < M; ++p) f[p] = f[p] + Vt[p] * X + Wt[p] * Xr;
 }
 
+// Both systems of OPR_Burgers / OPR_P2_P1 at once (uniform grids: the second right-hand side does not need the first solution): two independent
+// recurrences per lane hide the latency of the dependent fp64 multiply-adds (two waves per SIMD do not), and the two separator systems share their
+// two barriers.  Same operations per system, in the same order, as h_solve.
+template <int M, int L>
+__device__ __forceinline__ void h_solve2(double (&f)[M], double (&h)[M], const double *tf, const double *th, const double *gif, const double *gih, int n,
+                                         int row0, int c, int C, int l32, double *s_ylf, double *s_rf, double *s_ylh, double *s_rh) {
+    const double *Lf = tf + row0, *Df = tf + n + row0, *Cf = tf + 2 * n + row0, *Vf = tf + 3 * n + row0, *Wf = tf + 4 * n + row0;
+    const double *Lh = th + row0, *Dh = th + n + row0, *Ch = th + 2 * n + row0, *Vh = th + 3 * n + row0, *Wh = th + 4 * n + row0;
+    double gf = 0.0, gh = 0.0;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        gf = f[p] + Lf[p] * gf;
+        gh = h[p] + Lh[p] * gh;
+        f[p] = gf;
+        h[p] = gh;
+    }
+    double yf = 0.0, yh = 0.0;
+#pragma unroll
+    for (int p = M - 1; p >= 1; --p) {
+        yf = f[p] * Df[p] + Cf[p] * yf;
+        yh = h[p] * Dh[p] + Ch[p] * yh;
+        f[p] = yf;
+        h[p] = yh;
+    }
+    s_ylf[c * L + l32] = f[M - 1];
+    s_ylh[c * L + l32] = h[M - 1];
+    __syncthreads();
+    const int cm = (c + C - 1) % C, cp = (c + 1) % C;
+    s_rf[c * L + l32] = f[0] - Lf[0] * s_ylf[cm * L + l32] - Cf[0] * f[1];
+    s_rh[c * L + l32] = h[0] - Lh[0] * s_ylh[cm * L + l32] - Ch[0] * h[1];
+    __syncthreads();
+    double Xf = 0.0, Xrf = 0.0, Xh = 0.0, Xrh = 0.0;
+    const double *g0f = gif + c * C, *g1f = gif + cp * C, *g0h = gih + c * C, *g1h = gih + cp * C;
+    for (int q = 0; q < C; ++q) {
+        const double rf = s_rf[q * L + l32], rh = s_rh[q * L + l32];
+        Xf += g0f[q] * rf;
+        Xrf += g1f[q] * rf;
+        Xh += g0h[q] * rh;
+        Xrh += g1h[q] * rh;
+    }
+    f[0] = Xf;
+    h[0] = Xh;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        f[p] = f[p] + Vf[p] * Xf + Wf[p] * Xrf;
+        h[p] = h[p] + Vh[p] * Xh + Wh[p] * Xrh;
+    }
+}
+
 // L = lines per tile: 32 (a wave holds two chunks) or 16 (four chunks; half the tile, so that TWO workgroups fit a CU and one can
 // load or store while the other solves)
 // DIV (MODE_BURGERS, one field = the advecting velocity, at most 16 chunks): RTileArgs::fdiv, the forcing term of this direction from the finished
 // tendency while the lines are still in registers.
 // ANEL (MODE_BURGERS): 1 / 2 = anelastic diffusion weight along y / z lines (RTileArgs::ari); a template parameter because the register allocation
 // of the incompressible kernel sits at 256 and must not see the extra path
-template <int M, int MODE, int MAXT, int L, bool DIV = false, int ANEL = 0>
+// UNI (two systems): uniform grid and Jacobian schemes only -- no Jacobian correction, no per-row right-hand-side coefficients -- so that both systems are
+// solved in one pass (h_solve2); its own instantiation because the allocation of the general kernel sits at 256 registers
+template <int M, int MODE, int MAXT, int L, bool DIV = false, int ANEL = 0, bool UNI = false>
 __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_htile(RTileArgs a) {
     __shared__ double s_yl[32 * L];
     __shared__ double s_r[32 * L];
@@ -79,13 +150,19 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     extern __shared__ double s_tab[];     // coefficient rows of both systems, separator inverses, Jacobian-correction diagonals
     constexpr bool NEED1 = (MODE == MODE_P1 || MODE == MODE_P2_P1 || MODE == MODE_BURGERS);
     constexpr bool NEED2 = (MODE != MODE_P1);
+    // A wave holds 64 / L chunks: its first chunk cw is wave-uniform (readfirstlane makes that visible to the compiler), the lane adds csub.  Addresses are
+    // then   field + [tile + cw M rs + p rs]  (64-bit, SCALAR registers and scalar adds)  +  [l32 + csub M rs] (one 32-bit byte offset per lane, the same
+    // for every row p and every field): the loads and stores take the SGPR-base + VGPR-offset form and no 64-bit vector multiply-add per access is left
+    // (they were a third of the kernel's vector instructions).  launch_htile refuses row strides for which the lane part leaves 32 bits.
     const int l32 = threadIdx.x & (L - 1);
-    const int c = threadIdx.x / L;
+    const int cw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 / L);
+    const int csub = (threadIdx.x & 63) / L;
+    const int c = cw + csub;
     const int C = blockDim.x / L;
     const int n = a.g.n;
     const long long rs = a.g.row_stride;
     const bool per = a.s1.periodic != 0;
-    const bool corr = a.jc.j != nullptr;        // non-uniform grid: second derivative needs the first one
+    const bool corr = !UNI && a.jc.j != nullptr;        // non-uniform grid: second derivative needs the first one
 
     // MODE_BURGERS: one launch serves every transported field that shares the advecting velocity.  Workgroup ids are dealt round-robin
     // to the 8 XCDs (each with its own L2), so the nf workgroups of a tile get ids with the same residue mod 8 and follow each other
@@ -103,8 +180,17 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     const long long outer = tile / tiles_inner;
     const int l0 = (int)(tile % tiles_inner) * L;
     const bool valid = (l0 + l32) < a.g.lines_inner;
-    const long long base = outer * a.g.outer_stride + l0 + l32;
+    const int lv = valid ? l32 : 0;       // lanes beyond the last line of a partial tile LOAD line l0 of the tile (finite values, never stored): no branch per load
+    const long long base = outer * a.g.outer_stride + l0 + lv;
     const int row0 = c * M;
+    const long long ub = outer * a.g.outer_stride + l0 + (long long)cw * M * rs;      // wave-uniform element offset of row cw M, line l0
+    const unsigned vb = (unsigned)((lv + (long long)csub * M * rs) * 8);              // the lane's byte offset from there
+    const long long rs8 = rs * 8;
+    // (the row pointers go through an empty asm with an SGPR constraint: left visible, the compiler re-associates field + ub + vb first and adds p rs
+    // to that 64-bit VECTOR address again; they are advanced by scalar adds, row after row)
+#define H_ROW0(f) sgpr_ptr((f) + ub)
+#define H_NEXT(r) r = sgpr_ptr(r + rs8)
+#define H_AT(r) (reinterpret_cast<gdouble *>(r + vgpr_u32(vb)))
     const double *__restrict__ in0 = (MODE == MODE_BURGERS) ? a.fs[fi] : a.in0;
     double *__restrict__ out0 = (MODE == MODE_BURGERS) ? a.fo[fi] : a.out0;
     double nu = (MODE == MODE_BURGERS) ? a.fnu[fi] : a.nu;
@@ -112,16 +198,19 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
 
     // ---- operand rows + 3-row halos: requested BEFORE the tables are staged, so that the two latencies overlap ----
     double e[M + 6];
+    {
+        gchar *r = H_ROW0(in0);
 #pragma unroll
-    for (int p = 0; p < M; ++p) e[p + 3] = valid ? in0[base + (long long)(row0 + p) * rs] : 0.0;
+        for (int p = 0; p < M; ++p) { e[p + 3] = *H_AT(r); H_NEXT(r); }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int rl = row0 - 3 + k, rr = row0 + M + k;
         const bool okl = per || rl >= 0, okr = per || rr < n;
         if (rl < 0) rl += n;
         if (rr >= n) rr -= n;
-        e[k] = (valid && okl) ? in0[base + (long long)rl * rs] : 0.0;
-        e[M + 3 + k] = (valid && okr) ? in0[base + (long long)rr * rs] : 0.0;
+        e[k] = okl ? in0[base + (long long)rl * rs] : 0.0;
+        e[M + 3 + k] = okr ? in0[base + (long long)rr * rs] : 0.0;
     }
 
 
@@ -140,7 +229,7 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
         }
         if (NEED2 && corr)
             for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) tj[i] = a.jc.j[i];
-        if (NEED2 && a.s2.rowc != nullptr)      // direct second derivative: per-row RHS coefficients (never together with the correction)
+        if (!UNI && NEED2 && a.s2.rowc != nullptr)      // direct second derivative: per-row RHS coefficients (never together with the correction)
             for (int i = threadIdx.x; i < 5 * n; i += blockDim.x) tj[i] = a.s2.rowc[i];
     }
     // (the first __syncthreads inside h_solve would be too late for the coefficient reads of the local sweeps)
@@ -151,7 +240,7 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     if (NEED1 || (NEED2 && corr)) {
 #pragma unroll
         for (int p = 0; p < M; ++p) x1[p] = h_stencil<false>(a.s1, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
-        if (a.s1.rowc != nullptr) {   // direct first derivative (MatMul_3d / MatMul_5d): per-row coefficients, read where they lie (rare scheme)
+        if (!UNI && a.s1.rowc != nullptr) {   // direct first derivative (MatMul_3d / MatMul_5d): per-row coefficients, read where they lie (rare scheme)
             const double *rc = a.s1.rowc + row0 * 5;
 #pragma unroll
             for (int p = 0; p < M; ++p)
@@ -171,7 +260,7 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     if constexpr (NEED2) {
 #pragma unroll
         for (int p = 0; p < M; ++p) x2[p] = h_stencil<true>(a.s2, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
-        if (a.s2.rowc != nullptr) {   // MatMul_5d interior (fdm_matmul.f90:303-305) with the per-row coefficients staged in LDS
+        if (!UNI && a.s2.rowc != nullptr) {   // MatMul_5d interior (fdm_matmul.f90:303-305) with the per-row coefficients staged in LDS
             const double *rc = tj + row0 * 5;
 #pragma unroll
             for (int p = 0; p < M; ++p)
@@ -192,10 +281,14 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     // advecting velocity: issued now (the operand registers are dead) so that its latency hides behind the two solves
     double vl[MODE == MODE_BURGERS ? M : 1];
     if constexpr (MODE == MODE_BURGERS) {
+        gchar *r = H_ROW0(a.in2);
 #pragma unroll
-        for (int p = 0; p < M; ++p) vl[p] = valid ? a.in2[base + (long long)(row0 + p) * rs] : 0.0;
+        for (int p = 0; p < M; ++p) { vl[p] = *H_AT(r); H_NEXT(r); }
     }
 
+    if constexpr (UNI && NEED1 && NEED2) {      // both systems in one pass: the second right-hand side is complete (no Jacobian correction)
+        h_solve2<M, L>(x1, x2, t1, t2, gi1, gi2, n, row0, c, C, l32, s_yl, s_r, s_e, s_e + 32 * L);
+    } else {
     // ---- first derivative ----
     if (NEED1 || (NEED2 && corr)) h_solve<M, L>(x1, t1, gi1, n, row0, c, C, l32, s_yl, s_r);
 
@@ -220,20 +313,24 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
         }
         h_solve<M, L>(x2, t2, gi2, n, row0, c, C, l32, s_yl, s_r);
     }
+    }
 
     // ---- epilogue ----
     if (valid) {
+    gchar *ro = H_ROW0(out0);
     if constexpr (MODE == MODE_P1) {
 #pragma unroll
-        for (int p = 0; p < M; ++p) out0[base + (long long)(row0 + p) * rs] = x1[p];
+        for (int p = 0; p < M; ++p) { *H_AT(ro) = x1[p]; H_NEXT(ro); }
     } else if constexpr (MODE == MODE_P2) {
 #pragma unroll
-        for (int p = 0; p < M; ++p) out0[base + (long long)(row0 + p) * rs] = x2[p];
+        for (int p = 0; p < M; ++p) { *H_AT(ro) = x2[p]; H_NEXT(ro); }
     } else if constexpr (MODE == MODE_P2_P1) {
+        gchar *r1 = H_ROW0(a.out1);
 #pragma unroll
         for (int p = 0; p < M; ++p) {
-            out0[base + (long long)(row0 + p) * rs] = x2[p];
-            a.out1[base + (long long)(row0 + p) * rs] = x1[p];
+            *H_AT(ro) = x2[p];
+            *H_AT(r1) = x1[p];
+            H_NEXT(ro); H_NEXT(r1);
         }
     } else {  // MODE_BURGERS: result = nu d2 - vel d1 (opr_burgers.f90:513)
         if (ANEL == 1) {      // y lines: ribackground(j) of every row on the diffusion term (opr_burgers.f90:128-183)
@@ -247,12 +344,13 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
         // them out of the way of the operand rows in L2 (3 % of the launch, measured A/B in one binary)
         if (a.acc && !((a.fresh_mask >> fi) & 1u)) {   // accumulate into the tendency: all loads first (the compiler cannot move them across the stores itself)
 #pragma unroll
-            for (int p = 0; p < M; ++p) x1[p] = __builtin_nontemporal_load(&out0[base + (long long)(row0 + p) * rs]);
+            for (int p = 0; p < M; ++p) { x1[p] = __builtin_nontemporal_load(H_AT(ro)); H_NEXT(ro); }
+            ro = H_ROW0(out0);
 #pragma unroll
             for (int p = 0; p < M; ++p) x2[p] = x1[p] + x2[p];
         }
 #pragma unroll
-        for (int p = 0; p < M; ++p) __builtin_nontemporal_store(x2[p], &out0[base + (long long)(row0 + p) * rs]);
+        for (int p = 0; p < M; ++p) { __builtin_nontemporal_store(x2[p], H_AT(ro)); H_NEXT(ro); }
     }
     }   // valid
     if constexpr (DIV && MODE == MODE_BURGERS) {
@@ -292,14 +390,20 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
         h_solve<M, L>(gg, t1, gi1, n, row0, c, C, l32, s_yl, s_r);
         if (valid) {
             double fo[M];
+            gchar *r = H_ROW0(a.fdiv);
 #pragma unroll
-            for (int p = 0; p < M; ++p) fo[p] = a.fdiv[base + (long long)(row0 + p) * rs];
+            for (int p = 0; p < M; ++p) { fo[p] = *H_AT(r); H_NEXT(r); }
+            r = H_ROW0(a.fdiv);
 #pragma unroll
-            for (int p = 0; p < M; ++p) a.fdiv[base + (long long)(row0 + p) * rs] = fo[p] + gg[p];
+            for (int p = 0; p < M; ++p) { *H_AT(r) = fo[p] + gg[p]; H_NEXT(r); }
         }
     }
+#undef H_AT
+#undef H_NEXT
+#undef H_ROW0
 }
 
+static int g_htile_uni = [] { const char *e = getenv("TLAB_HTILE_UNI"); return (e && atoi(e) == 0) ? 0 : 1; }();      // 0: general kernel on uniform grids too (A/B)
 static int g_htile_lines = [] { const char *e = getenv("TLAB_HTILE_LINES"); return (e && atoi(e) == 16) ? 16 : 32; }();
 void htile_set_lines(int lines) { g_htile_lines = lines; }
 bool htile_narrow() { return g_htile_lines == 16; }
@@ -335,6 +439,7 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
         for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in2 ? 0 : 8) + 8 + ((a.acc && !((a.fresh_mask >> f) & 1u)) ? 8 : 0));
         if (a.fdiv) bytes += pts * 16;      // forcing term: read + write
     }
+    const bool uni = g_htile_uni && a.jc.j == nullptr && a.s1.rowc == nullptr && a.s2.rowc == nullptr;      // uniform grid, Jacobian schemes
     ProfScope ps(name, st, bytes);
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT, L>), grid, block, lds, st, a); break;
@@ -344,7 +449,8 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
         if (a.fdiv) {
             if constexpr (M == 32 && MAXT == 512) {      // L = 32 with up to 16 chunks, or the 16-line tiles of 1024-point lines (32 chunks)
                 if (a.nf != 1 || a.fs[0] != a.in2 || C * L > MAXT || a.s1.rowc != nullptr || a.ari) return hipErrorInvalidValue;
-                hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true>), grid, block, lds, st, a);
+                if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true, 0, true>), grid, block, lds, st, a);
+                else hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true>), grid, block, lds, st, a);
             } else {
                 return hipErrorInvalidValue;
             }
@@ -357,7 +463,12 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
                 return hipErrorInvalidValue;
             }
         } else {
-            hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a);
+            if constexpr (M == 32 && MAXT == 512) {
+                if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, false, 0, true>), grid, block, lds, st, a);
+                else hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a);
+            } else {
+                hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a);
+            }
         }
         break;
     default: return hipErrorInvalidValue;
@@ -371,6 +482,8 @@ hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st) {
     if (M == 0) return hipErrorInvalidValue;
     const int C = n / M;
     if (C & 1) return hipErrorInvalidValue;      // two chunks per wave
+    // the lane part of an address, (line in tile + chunk-in-wave x M rows) x 8 B, is a 32-bit byte offset in the kernel
+    if ((double)(64 / 16 - 1) * M * (double)a.g.row_stride * 8.0 + 512.0 >= 4294967296.0) return hipErrorInvalidValue;
     const bool two = (mode == MODE_P2_P1 || mode == MODE_BURGERS);
     const bool narrow = (g_htile_lines == 16) && mode == MODE_BURGERS && M == 32 && C <= 16;
     const bool long16 = two && M == 32 && C == 32;     // lines of 1024 points with two line-sets in registers: 16-line tiles, 4 chunks per wave
