@@ -437,11 +437,21 @@ def main():
         # a kernel the file does not know gets null, never another kernel's or an older build's figure)
         traffic, traffic_meta = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        # the counter data is quoted only when it was measured on THESE kernel sources (sha256 over tlab_amd/csrc, stamped by tools/pmc_summary.py)
+        traffic_valid = False
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_summary import source_hash
+            traffic_valid = os.path.exists(tpath) and json.load(open(tpath)).get("_meta", {}).get("source_hash") == source_hash()
+        except Exception:       # noqa: BLE001
+            traffic_valid = False
         if dom and os.path.exists(tpath) and world == 1 and args.loopback <= 1 and not args.decomp and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:      # measured for this workload only
             try:
                 tj0 = json.load(open(tpath))
                 traffic_meta = tj0.get("_meta")
-                traffic = tj0.get(dom["kernel"])
+                traffic = tj0.get(dom["kernel"]) if traffic_valid else None
+                if not traffic_valid:
+                    traffic_meta = dict(traffic_meta or {}, stale="profiles/traffic.json was measured on other kernel sources (source_hash differs): traffic is null")
             except Exception:
                 traffic = None
         npts = float(nx) * ny * nz      # strong scaling: the same box on 1/2/4/8 GPUs (BASELINE.json metric)
@@ -490,6 +500,23 @@ def main():
             out["copy_ceiling"] = {"GBps": copy_gbs, "what": "device copy of one %d-point fp64 field, read + write bytes, 10 repetitions" % src.numel()}
             if out["roofline"] is not None:
                 out["roofline"]["frac_of_copy"] = out["roofline"]["achieved"] / copy_gbs
+            # ... and hand-written streaming kernels on the same box (tools/yardstick.hip, a child process: 16-B-per-lane copy and triad, and the access
+            # pattern of the tile kernels -- 32 lines x 512 rows per workgroup, operand + velocity + old tendency in, new tendency out -- WITHOUT arithmetic)
+            ybin = os.path.join(ROOT, "tools", "yardstick")
+            if os.path.exists(ybin) and (nx, ny, nz) == (512, 512, 512):
+                try:
+                    import subprocess
+                    yl = [json.loads(l) for l in subprocess.run([ybin, "512"], capture_output=True, text=True, timeout=120).stdout.splitlines() if l.startswith("{")]
+                    yd = {r["kernel"]: r["GBps"] for r in yl}
+                    pat = max((v for k2, v in yd.items() if k2.startswith("tile L=32")), default=None)
+                    out["copy_ceiling_own"] = {"copy16_GBps": max((v for k2, v in yd.items() if k2.startswith("copy16")), default=None),
+                                               "triad16_GBps": yd.get("triad16 grid=8192"), "tile_pattern_GBps": pat, "all": yd,
+                                               "what": "tools/yardstick.hip on this box after the timed region: global_load/store_dwordx4 copy and 3-read / 1-write triad, "
+                                                       "and the Burgers tile kernels' own access pattern without arithmetic (best of y / z lines, phased, non-temporal)"}
+                    if out["roofline"] is not None and pat:
+                        out["roofline"]["frac_of_own_pattern"] = out["roofline"]["achieved"] / pat
+                except Exception as e:       # noqa: BLE001
+                    out["copy_ceiling_own"] = {"error": repr(e)}
         if single:
             # the north-star's own target kernel, standalone on this box: OPR_Partial_{X,Y,Z}(OPR_P1) at the benchmark's grid, 16 B per point
             # (SURVEY.md 8d), >= 40 % of the 8 TB/s HBM peak asked for OPR_Partial_X at 512^3
@@ -511,7 +538,7 @@ def main():
             # the substep against the bytes it really moves: PMC-measured HBM traffic per launch (profiles/traffic.json, this workload only) x
             # the launches of one step; rocFFT's transforms are counted at their algorithmic 2 x 8 B per point of the complex field
             tj = None
-            if os.path.exists(tpath) and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:
+            if traffic_valid and (nx, ny, nz) == (512, 512, 512) and args.nscal == 1:
                 try:
                     tj = json.load(open(tpath))
                 except Exception:
@@ -576,7 +603,12 @@ def main():
                 out["cpu_baseline_instances"] = multi
             if args.cpu_sample_large > args.cpu_sample and (os.cpu_count() or 1) >= args.cpu_large_min_cores:
                 # the benchmark's own size on the host cores, when the host is big enough to finish it in about a minute
-                out["cpu_baseline_large"] = cpu_baseline(args.cpu_sample_large, args.nscal)
+                large = cpu_baseline(args.cpu_sample_large, args.nscal)
+                if isinstance(large, dict) and large.get("value"):      # like for like: the benchmark's own size is the headline baseline when it ran
+                    out["cpu_baseline_small_sample"] = out["cpu_baseline"]
+                    out["cpu_baseline"] = large
+                else:
+                    out["cpu_baseline_large"] = large
         print(json.dumps(out))
     # the native slab driver owns an RCCL communicator of its own: release it while every rank is still here, not during interpreter teardown
     try:

@@ -424,7 +424,12 @@ typedef struct tlab_slab_dns *tlab_slab_dns_t;
 /* gx, gy: the local plans; gz: the plan of the GLOBAL z direction (nz_total nodes).  kmax = nz_total / nranks planes per rank; returns
  * TLAB_EUNSUPPORTED when the slabs are too thin for the partitioned z-systems (kmax <~ 50: tlab_zslab_plan_create) -- such runs keep the
  * reference's K-transposition scheme.  gy_elliptic: NULL, or the y plan of EllipticOrder = CompactDirect6 (tlab_poisson_plan_create_direct).
- * The plans are not owned; the transport struct is copied (its destroy, if any, runs in tlab_slab_dns_destroy). */
+ * The plans are not owned; the transport struct is copied (its destroy, if any, runs in tlab_slab_dns_destroy).
+ * OWNERSHIP of transport->ctx passes to the driver only when the call returns TLAB_OK; on any refusal the caller still owns it and must run
+ * transport->destroy(ctx) itself.
+ * SUPPORTED SUBSET (everything else is refused with TLAB_EUNSUPPORTED, never silently dropped): convective form, RhsMode = combined, Dirichlet or
+ * Neumann walls with an impermeable wall-normal velocity, static scalar surfaces, factorized or CompactDirect6 elliptic solver, remove_divergence on
+ * or off; NOT the anelastic formulation, dealiasing filters or the dynamic surface model (single-domain driver tlab_dns_* only). */
 int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *transport, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                          int nx, int ny, int nz_total, int nscal, double visc, const double *schmidt, tlab_fdm_plan_t gy_elliptic);
 int tlab_slab_dns_destroy(tlab_slab_dns_t d);
@@ -439,6 +444,7 @@ int tlab_slab_dns_bind(tlab_slab_dns_t d, int l, double *const *q, double *const
 long long tlab_slab_dns_info(tlab_slab_dns_t d, int what);
 int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d);                 /* as tlab_dns_begin_step */
+int tlab_slab_dns_set_remove_divergence(tlab_slab_dns_t d, int on);      /* as tlab_dns_set_remove_divergence ([Main] TermDivergence) */
 /* RHS_GLOBAL_INCOMPRESSIBLE_1 on the bound arrays of all local ranks (tools/dns/rhs_global_incompressible_1.f90:98-398) */
 int tlab_slab_dns_rhs(tlab_slab_dns_t d, double dte);
 /* TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT (tools/dns/time.f90:559-664 + :261-298): RHS with the RK update folded into its last passes */

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "_ref", "libtlab_ref.so")
+_PATH = os.environ.get("TLAB_REF_LIB") or os.path.join(_HERE, "_ref", "libtlab_ref.so")      # TLAB_REF_LIB: another build of the same sources (_ref_omp, _ref_fma)
 
 c_int, c_dbl = ctypes.c_int, ctypes.c_double
 _P = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

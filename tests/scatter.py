@@ -44,16 +44,17 @@ class Bound(float):
     (the right operand is an instance of a subclass of float that overrides the reflected method), so every use of a scatter-derived bound is logged
     with the error it was compared against -- pytest -q prints none of them, the table keeps all of them."""
 
-    def __new__(cls, scatter, factor):
+    def __new__(cls, scatter, factor, source="oracle one-ulp scatter"):
         b = super().__new__(cls, max(FLOOR, factor * scatter))
-        b.scatter, b.factor = float(scatter), float(factor)
+        b.scatter, b.factor, b.source = float(scatter), float(factor), source
         return b
 
     def _log(self, err):
         import os
-        PARITY_RECORDS.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "err": float(err), "oracle_scatter": self.scatter,
-                               "factor": self.factor, "bound": float(self), "ok": bool(float(err) <= float(self)),
-                               "bound_set_by": "north-star floor 1e-12" if float(self) <= FLOOR else "%g x oracle one-ulp scatter" % self.factor})
+        PARITY_RECORDS.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "err": float(err), "yardstick": self.source,
+                               "yardstick_value": self.scatter, "factor": self.factor, "bound": float(self), "ok": bool(float(err) <= float(self)),
+                               "within_1e-12": bool(float(err) <= FLOOR),
+                               "bound_set_by": "north-star floor 1e-12" if float(self) <= FLOOR else "%g x %s" % (self.factor, self.source)})
 
     def __ge__(self, err):
         self._log(err)
@@ -68,6 +69,25 @@ class Bound(float):
 
 def bound(scatter, factor=2.0):
     return Bound(scatter, factor)
+
+
+_REF_FMA = None
+
+
+def ref_build_diff(key):
+    """By how much two legitimate builds of the REFERENCE (amdflang -O2 with and without fused multiply-adds, oracle/Makefile targets `all` and `fma`)
+    differ on the case `key` of tests/golden/ref_fma_scatter.npz (made by tests/golden/make_golden_fma_scatter.py from oracle/_ref and oracle/_ref_fma)."""
+    global _REF_FMA
+    if _REF_FMA is None:
+        import os
+        _REF_FMA = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fma_scatter.npz"))
+    return float(_REF_FMA["diff_" + key])
+
+
+def ref_build_bound(key, factor=1.0):
+    """max(1e-12, factor x the difference between two builds of the reference itself): the device may differ from the oracle by what the reference
+    differs from itself when its compiler fuses multiply-adds -- a yardstick that does not come from this repository's oracle."""
+    return Bound(ref_build_diff(key), factor, "difference between the reference's own FMA / non-FMA builds (%s)" % key)
 
 
 def substep_scatter(make_oracle, q0, s0, schedule, nsamples=1, seed=77):

@@ -150,6 +150,79 @@ def test_native_driver_with_the_direct_schemes_is_bit_identical(T):
                 assert float(b.abs().max()) > 0.0 and torch.equal(a, b), (name, r)
 
 
+def test_native_driver_refuses_what_it_does_not_build(T):
+    """A decomposed run must integrate the same equations as the same tlab.ini on one rank, or stop: with the anelastic operator state
+    on, the z-slab driver refuses to be created and refuses to run -- TLAB_EUNSUPPORTED with a message, nothing silently dropped."""
+    import ctypes
+    import torch
+    from tlab_amd.lib import load
+    from tlab_amd.slab import NativeSlabDns
+    L = load()
+    nx, ny, nz = 32, 16, 128
+    x, y, z = _grid(nx, ny, nz)
+    rb = np.linspace(1.0, 0.8, ny)
+    ri = 1.0 / rb
+    dp = ctypes.POINTER(ctypes.c_double)
+    nat = NativeSlabDns("loopback", x, y, z, size=2, hyper_bc1_ext=REF_HYPER)
+    f = _fields(x, y, z, 3)
+    for i in range(4):
+        nat.scatter("q" if i < 3 else "s", i if i < 3 else 0, torch.from_numpy(f[i]).cuda())
+    nat.substep_of_cycle(0, 1e-3)                       # fine while the state is incompressible
+    assert L.tlab_opr_burgers_set_anelastic(ny, rb.ctypes.data_as(dp), ri.ctypes.data_as(dp)) == 0
+    try:
+        with pytest.raises(T.TlabError, match="anelastic"):
+            nat.substep_of_cycle(1, 1e-3)
+        with pytest.raises(T.TlabError, match="anelastic"):
+            NativeSlabDns("loopback", x, y, z, size=2, hyper_bc1_ext=REF_HYPER)
+    finally:
+        assert L.tlab_opr_burgers_set_anelastic(0, None, None) == 0
+    nat.substep_of_cycle(1, 1e-3)                       # and fine again
+    nat.close()
+
+
+def test_native_driver_without_remove_divergence_equals_the_single_domain(T):
+    """dns.ini [Main] TermDivergence = no (rhs_global_incompressible_1.f90:234-250: forcing div(hq) alone) is forwarded to the z-slab driver
+    (tlab_slab_dns_set_remove_divergence), not ignored: slabs = single domain within the composed-path bound, and the switch changes the result."""
+    import torch
+    from tlab_amd.dns import Dns
+    from tlab_amd.slab import NativeSlabDns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    P, nx, ny, nz = 2, 64, 24, 128
+    x, y, z = _grid(nx, ny, nz)
+    f = _fields(x, y, z, 17)
+    visc, sc = 1.0 / 600.0, (0.8,)
+    one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    nat = NativeSlabDns("loopback", x, y, z, size=P, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    on = NativeSlabDns("loopback", x, y, z, size=P, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    one.set_remove_divergence(False)
+    nat.set_remove_divergence(False)
+    for i in range(4):
+        t = torch.from_numpy(f[i]).cuda()
+        (one.q[i] if i < 3 else one.s[0]).copy_(t)
+        for d in (nat, on):
+            d.scatter("q" if i < 3 else "s", i if i < 3 else 0, t)
+    dtime = 2e-3
+    for k in range(2):
+        one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * one.kdt[k], one.kco[k], True)
+        nat.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * one.kdt[k], one.kco[k], True)
+        on.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * one.kdt[k], one.kco[k], True)
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        o.remove_divergence = False
+        return o
+    B, S = substep_scatter(make_oracle, f[:3], f[3:4], [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=2)
+    for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s)):
+        for i, rf in enumerate(ref):
+            got = torch.cat([nat.st[r][name][i] for r in range(P)])
+            tol = bound(S[1][name][i])
+            assert float((got - rf).abs().max() / rf.abs().max()) <= tol, ("slabs vs single domain without remove_divergence", name, i)
+            ob = torch.from_numpy(B[1][name][i]).cuda()
+            assert float((got - ob).abs().max() / ob.abs().max()) <= tol, ("slabs vs oracle without remove_divergence", name, i)
+    diff = float((torch.cat([on.st[r]["q"][1] for r in range(P)]) - torch.cat([nat.st[r]["q"][1] for r in range(P)])).abs().max())
+    assert diff > 1e-8, "the switch must change the wall-normal velocity"
+
+
 def test_native_driver_refuses_thin_slabs_and_unbound_arrays(T):
     import ctypes
     from tlab_amd.lib import load, c_vp

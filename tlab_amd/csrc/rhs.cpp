@@ -132,6 +132,8 @@ bool neumann_weights(tlab_dns *d, int ibc) {
         hk(hipMemcpy(h, id.data(), N * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
         hk(hipMemset(hb, 0, (size_t)ny * sizeof(double)), "hipMemset");
         hk(hipMemset(ht, 0, (size_t)ny * sizeof(double)), "hipMemset");
+        // the copies above ran on the NULL stream, the routine below runs on the caller's stream (tlab_set_stream), which may be non-blocking: order them
+        hk(hipDeviceSynchronize(), "hipDeviceSynchronize");
         ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, ny, ny, 1, h, hb, ht, tmp), "BOUNDARY_BCS_NEUMANN_Y (weights)");
         hk(hipStreamSynchronize(tlab_current_stream()), "sync");
         std::vector<double> wb(ny), wt(ny);
@@ -148,6 +150,7 @@ bool neumann_weights(tlab_dns *d, int ibc) {
         }
         for (int j = 0; j < ny; ++j)
             if (!std::isfinite(wb[j]) || !std::isfinite(wt[j])) return false;
+        if (((ibc & 1) && mb == 0.0) || ((ibc & 2) && mt == 0.0)) return false;       // weights that are all zero are never cached (the derivative pass serves then)
         std::vector<double> w((size_t)2 * K, 0.0);
         for (int j = 0; j < K; ++j) { w[j] = (ibc & 1) ? wb[j] : 0.0; w[K + j] = (ibc & 2) ? wt[ny - 1 - j] : 0.0; }
         hk(hipMalloc((void **)&W.w, w.size() * sizeof(double)), "hipMalloc");
@@ -700,6 +703,20 @@ int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, c
     }
     for (int i = 0; i < 3; ++i) { d->flow_jmin[i] = flow_jmin[i]; d->flow_jmax[i] = flow_jmax[i]; }
     for (int i = 0; i < d->nscal; ++i) { d->scal_jmin[i] = scal_jmin[i]; d->scal_jmax[i] = scal_jmax[i]; }
+    // the wall-plane weights of the Neumann variants in use are built HERE (allocations, a synchronisation), not in the middle of the first substep
+    try {
+        auto variant = [](int jmin, int jmax) { return (jmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (jmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0); };
+        for (int i = 0; i < 3; ++i)
+            if (variant(flow_jmin[i], flow_jmax[i])) (void)neumann_weights(d, variant(flow_jmin[i], flow_jmax[i]));
+        for (int i = 0; i < d->nscal; ++i)
+            if (variant(scal_jmin[i], scal_jmax[i])) (void)neumann_weights(d, variant(scal_jmin[i], scal_jmax[i]));
+    } catch (const Fail &e) {
+        tlab_set_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EHIP;
+    }
     return TLAB_OK;
 }
 

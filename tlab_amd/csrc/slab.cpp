@@ -39,6 +39,9 @@ int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int 
 int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, const double *p, const double *const *p_halo, const double *tail_left,
                                          const double *head_right, double *q, double *h, double dte, double kco, int scale);
 
+extern "C" bool tlab_internal_anelastic();       // capi.cpp: the operator state set by tlab_opr_burgers_set_anelastic / _set_dealiasing
+extern "C" bool tlab_internal_dealiasing();
+
 namespace tlab {
 hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // pointwise.hip
 }
@@ -157,6 +160,7 @@ struct tlab_slab_dns {
     int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
     std::vector<int> scal_jmin, scal_jmax;
     bool fresh = false;
+    bool remove_divergence = true;     // [Main] TermDivergence: forcing div(hq + q/dte) (rhs_global_incompressible_1.f90:177-232); false: div(hq) (:234-250)
     std::vector<Rank> rk;
     ~tlab_slab_dns() {
         for (Rank &R : rk) {
@@ -434,6 +438,16 @@ void poisson_pencil_staged(D *d) {
     }
 }
 
+// The z-slab kernels and the pencil pressure step know neither the anelastic density weights nor the dealiasing filters of the operator state
+// (tlab_opr_burgers_set_anelastic / _set_dealiasing act on the single-domain operators only): a decomposed run with either would integrate other
+// equations than the same tlab.ini on one rank -- refused, at creation and again at every right-hand side (the state may be set later).
+void refuse_unsupported_state(const char *who) {
+    if (tlab_internal_anelastic())
+        throw Fail(TLAB_EUNSUPPORTED, std::string(who) + ": the anelastic formulation is not built into the z-slab driver (single-domain driver only)");
+    if (tlab_internal_dealiasing())
+        throw Fail(TLAB_EUNSUPPORTED, std::string(who) + ": dealiasing filters are not built into the z-slab driver (single-domain driver only)");
+}
+
 void poisson_pencil(D *d) {
     if (d->stages == 2) poisson_pencil_staged(d);
     else poisson_pencil_single(d);
@@ -443,6 +457,7 @@ void poisson_pencil(D *d) {
 // the third equation: rounding only).  tail: fold the RK update into the last pass of every field (TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT).
 void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     need_bound(d);
+    refuse_unsupported_state("tlab_slab_dns_rhs");
     const int nx = d->nx, ny = d->ny, kmax = d->kmax, ns = d->nscal;
     const long long n = d->n;
     // ---- diffusion + advection (:98-162) ----
@@ -462,7 +477,7 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
         zfin[3 + i] = tail && d->fused_x && d->scal_jmin[i] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[i] == TLAB_DNS_BCS_DIRICHLET;
     for (Rank &R : d->rk) zburgers_all(d, R, 2, &zfin, tdte, kco, scale);
     // ---- pressure forcing: div(hq + q/dte) (:188-260) ----
-    const double idte = 1.0 / dte;
+    const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (as rhs.cpp)
     w = halo_start(d, 1, [&](Rank &R, int) { return Slot{R.hq[2], S_HQ3}; });          // w's halo planes are still valid
     for (Rank &R : d->rk) padd(d, R, 2, R.hq[1], R.q[1], idte, R.txc[0], 0);
     for (Rank &R : d->rk) padd(d, R, 1, R.hq[0], R.q[0], idte, R.txc[0], 1);
@@ -582,6 +597,10 @@ int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *tr, tl
         if (P < 1) throw Fail(TLAB_EINVAL, "tlab_slab_dns_create: nranks < 1");       // (one rank: its own ring neighbour; tests of a transport on one GPU)
         if (tr->nlocal < 1 || tr->first < 0 || tr->first + tr->nlocal > P) throw Fail(TLAB_EINVAL, "tlab_slab_dns_create: local ranks outside [0, nranks)");
         if (nz_total % P) throw Fail(TLAB_EINVAL, "nz must be divisible by the number of z slabs");
+        // every cheap refusal BEFORE anything is allocated (on failure the caller keeps ownership of transport->ctx: see include/tlab_amd.h)
+        if (P > 16) throw Fail(TLAB_EUNSUPPORTED, "tlab_slab_dns_create: at most 16 z slabs (one node)");
+        if ((nx / 2 + 1) / P < 1) throw Fail(TLAB_EINVAL, "fewer kx modes than ranks");
+        refuse_unsupported_state("tlab_slab_dns_create");
         auto d = std::make_unique<tlab_slab_dns>();
         d->g[0] = gx; d->g[1] = gy; d->g[2] = gz; d->gy_elliptic = gy_elliptic;
         d->P = P; d->nx = nx; d->ny = ny; d->nzt = nz_total; d->kmax = nz_total / P; d->nxh = nx / 2 + 1; d->nscal = nscal; d->visc = visc;
@@ -596,8 +615,6 @@ int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *tr, tl
             d->ioff.push_back(r * base + std::min(r, rem));
             d->nxa.push_back((d->nxl[r] + 1) / 2);
         }
-        if (base < 1) throw Fail(TLAB_EINVAL, "fewer kx modes than ranks");
-        if (P > 16) throw Fail(TLAB_EUNSUPPORTED, "tlab_slab_dns_create: at most 16 z slabs (one node)");
         const char *env = std::getenv("TLAB_PENCIL_STAGES");
         d->stages = (!gy_elliptic && base >= 2 && 2 * P <= 16 && !(env && std::strcmp(env, "1") == 0)) ? 2 : 1;
         if (d->stages == 2) {   // block 2p / 2p+1 = half A / B of rank p: all A blocks (by rank) ahead of all B blocks
@@ -695,6 +712,12 @@ int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *fl
         for (int i = 0; i < 3; ++i) { d->flow_jmin[i] = flow_jmin[i]; d->flow_jmax[i] = flow_jmax[i]; }
         for (int i = 0; i < d->nscal; ++i) { d->scal_jmin[i] = scal_jmin[i]; d->scal_jmax[i] = scal_jmax[i]; }
     });
+}
+
+int tlab_slab_dns_set_remove_divergence(tlab_slab_dns_t d, int on) {
+    if (!d) return TLAB_EINVAL;
+    d->remove_divergence = on != 0;
+    return TLAB_OK;
 }
 
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d) {

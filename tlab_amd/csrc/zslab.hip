@@ -561,6 +561,12 @@ int tlab_internal_zslab_burgers_z_n(tlab_zslab_plan_t P, int phase, int nx, int 
             for (int f = 0; f < nf; ++f) {
                 a.ffin[f] = fin ? fin[f] : 0;
                 if (a.ffin[f] && s[f] == vel) throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: the advecting velocity cannot be updated in place");
+                // the in-place update of operand f is only ordered against the kernel's own reads of THAT field (the barriers of z_solve): it must not be
+                // any other launch operand or result
+                if (a.ffin[f])
+                    for (int g2 = 0; g2 < nf; ++g2)
+                        if ((g2 != f && s[g2] == s[f]) || result[g2] == s[f])
+                            throw Fail(TLAB_EINVAL, "tlab_zslab_burgers_z_n: a field finished in place appears twice among the operands / results");
             }
             a.fdte = dte; a.fkco = kco; a.fscale = scale; a.fnx = nx; a.fny = ny;
         }

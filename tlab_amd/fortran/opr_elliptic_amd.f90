@@ -26,6 +26,7 @@ module TLAB_AMD_ELLIPTIC_MODULE
     public :: OPR_Elliptic_Initialize           ! (inifile): operators/opr_elliptic.f90:86, in a complete host (modules TLab_Memory, TLab_Grid present)
 #endif
     public :: OPR_Elliptic_AMD_Plan             ! the device plan (for the RHS driver, tlab_dns_create)
+    public :: OPR_Elliptic_AMD_PlanY            ! the y plan of EllipticOrder = CompactDirect6 (fdm_loc), c_null_ptr for the factorized solver: tlab_slab_dns_create
     public :: OPR_Poisson
     public :: OPR_Helmholtz                     ! _FourierXZ_Direct (:562-628) or _FourierXZ_Factorize (:466-557), by the plan's type
 
@@ -66,6 +67,11 @@ contains
         type(c_ptr) :: p
         p = plan
     end function OPR_Elliptic_AMD_Plan
+
+    function OPR_Elliptic_AMD_PlanY() result(p)
+        type(c_ptr) :: p
+        p = plan_elliptic_y
+    end function OPR_Elliptic_AMD_PlanY
 
 #ifdef TLAB_AMD_FULL_HOST
     ! OPR_Elliptic_Initialize(inifile)   operators/opr_elliptic.f90:86-250: [Main] EllipticOrder selects the factorized (default: the scheme of

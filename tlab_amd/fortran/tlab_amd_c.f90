@@ -267,6 +267,11 @@ module TLab_AMD_C
             import :: c_int, c_ptr
             type(c_ptr), value :: d
         end function
+        integer(c_int) function tlab_slab_dns_set_remove_divergence(d, on) bind(C, name='tlab_slab_dns_set_remove_divergence')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+            integer(c_int), value :: on
+        end function
         integer(c_int) function tlab_slab_dns_rhs(d, dte) bind(C, name='tlab_slab_dns_rhs')
             import :: c_int, c_ptr, c_double
             type(c_ptr), value :: d

@@ -49,6 +49,8 @@ contains
         use NavierStokes, only: visc, schmidt
         use BOUNDARY_BCS, only: BcsFlowJmin, BcsFlowJmax, BcsScalJmin, BcsScalJmax
         use OPR_Partial, only: OPR_Partial_AMD_Plan
+        use OPR_Elliptic, only: OPR_Elliptic_AMD_PlanY
+        use DNS_LOCAL, only: remove_divergence
         use TLabMPI_VARS, only: ims_npro_k
         use TLabMPI_Transpose, only: TLabMPI_Trp_AMD_Slab_Transport
         type(c_ptr) :: h
@@ -59,13 +61,21 @@ contains
         integer is
         if (.not. c_associated(slab)) then
             if (inb_scal > 16 .or. inb_txc < 9) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Slab_Handle: needs inb_scal <= 16 and inb_txc >= 9')
+            ! what the z-slab driver does not build is REFUSED here, not dropped: the same tlab.ini must integrate the same equations on 1 and on N ranks
+            ! (the anelastic formulation and dealiasing filters are refused inside tlab_slab_dns_create / _rhs from the operator state)
+            if (inb_scal > 0) then
+                if (any(BcsScalJmin%SfcType(1:inb_scal) /= 0) .or. any(BcsScalJmax%SfcType(1:inb_scal) /= 0)) &
+                    call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Slab_Handle: the dynamic surface model (BcsScal%SfcType) runs on one rank only (ims_npro_k = 1)')
+            end if
             call TLabMPI_Trp_AMD_Slab_Transport(tr)
             sc = 1.0_c_double
             sc(1:inb_scal) = schmidt(1:inb_scal)
             rc = tlab_slab_dns_create(slab, tr, OPR_Partial_AMD_Plan(1, g(1)), OPR_Partial_AMD_Plan(2, g(2)), OPR_Partial_AMD_Plan(3, g(3)), &
                                       int(imax, c_int), int(jmax, c_int), int(kmax*max(ims_npro_k, 1), c_int), int(inb_scal, c_int), &
-                                      real(visc, c_double), sc, c_null_ptr)
+                                      real(visc, c_double), sc, OPR_Elliptic_AMD_PlanY())      ! the host's elliptic choice: factorized, or CompactDirect6
             call TLab_AMD_Check(rc, 'tlab_slab_dns_create')
+            call TLab_AMD_Check(tlab_slab_dns_set_remove_divergence(slab, merge(1_c_int, 0_c_int, remove_divergence)), &     ! dns.ini [Main] TermDivergence
+                                'tlab_slab_dns_set_remove_divergence')
             fj0 = BcsFlowJmin%type(1:3); fj1 = BcsFlowJmax%type(1:3)
             sj0 = 3; sj1 = 3
             sj0(1:inb_scal) = BcsScalJmin%type(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%type(1:inb_scal)

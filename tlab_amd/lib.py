@@ -107,6 +107,7 @@ SIGNATURES = {
     "tlab_slab_dns_info": (ctypes.c_longlong, [c_vp, c_int]),
     "tlab_slab_dns_set_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "tlab_slab_dns_begin_step": (c_int, [c_vp]),
+    "tlab_slab_dns_set_remove_divergence": (c_int, [c_vp, c_int]),
     "tlab_slab_dns_rhs": (c_int, [c_vp, c_dbl]),
     "tlab_slab_dns_substep": (c_int, [c_vp, c_dbl, c_dbl, c_int]),
     "tlab_slab_dns_time_courant": (c_int, [c_vp, c_dbl, c_dbl, _dp, _dp]),

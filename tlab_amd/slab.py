@@ -171,6 +171,16 @@ class NativeSlabDns:
                     os.environ.pop("TLAB_SLAB_FUSED_X", None)
                 else:
                     os.environ["TLAB_SLAB_FUSED_X"] = saved
+        if rc != 0:
+            # a refused configuration leaves the transport context with the caller (include/tlab_amd.h): release it before raising
+            try:
+                if self._tr.destroy:
+                    self._tr.destroy(self._tr.ctx)
+            finally:
+                if self.transport == "rccl" and self._keep is not None:
+                    self._keep.close()
+                self._keep = None
+                self._h = c_vp(0)
         check(rc, "tlab_slab_dns_create")
         self.fused_x = bool(L.tlab_slab_dns_info(self._h, 6))
         self.kmax = int(L.tlab_slab_dns_info(self._h, 0))
@@ -196,6 +206,10 @@ class NativeSlabDns:
 
     def begin_step(self):
         check(load().tlab_slab_dns_begin_step(self._h), "tlab_slab_dns_begin_step")
+
+    def set_remove_divergence(self, on):
+        """dns.ini [Main] TermDivergence (as Dns.set_remove_divergence): off = the forcing of the pressure equation is div(hq) alone."""
+        check(load().tlab_slab_dns_set_remove_divergence(self._h, int(bool(on))), "tlab_slab_dns_set_remove_divergence")
 
     def RHS_GLOBAL_INCOMPRESSIBLE_1(self, dte):
         _use_torch_stream()

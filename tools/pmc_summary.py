@@ -67,6 +67,18 @@ def counters(d, cname):
     return acc
 
 
+def source_hash():
+    """sha256 over the kernel sources the library is built from (tlab_amd/csrc/*.{hip,cpp,hpp}, sorted by name): the stamp bench.py recomputes before it
+    quotes profiles/traffic.json -- counter data measured on other sources is nulled, whatever the commit says."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tlab_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.cpp")) + glob.glob(os.path.join(root, "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc(dfetch, dwrite, tjson=None, commit=None):
     fe, wr = counters(dfetch, "FETCH_SIZE"), counters(dwrite, "WRITE_SIZE")
     out = {}
@@ -84,7 +96,7 @@ def pmc(dfetch, dwrite, tjson=None, commit=None):
             out[t] = (b, fe[k][1])
     if tjson:
         import datetime
-        doc = {"_meta": {"commit": commit, "session": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "kernels": len(out),
+        doc = {"_meta": {"commit": commit, "source_hash": source_hash(), "session": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "kernels": len(out),
                          "what": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB from two separate rocprofv3 --pmc passes of `bench.py` on the "
                                  "binaries of that commit (tools/profile_round.sh); regenerated with the rocprofv3 kernel-stats CSV of the same session"}}
         doc.update({k: v[0] for k, v in out.items()})
