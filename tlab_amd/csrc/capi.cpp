@@ -347,6 +347,24 @@ SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
         e->red.upload(h.ginv);
     }
     e->lane_invariant = inv;
+    {   // interior chunks equal to chunk 1 to the bit (the first and the last chunk carry the wall rows of a non-periodic system)
+        bool ci = P >= 3;
+        long long worst = 0;
+        for (int tab = 0; tab < 5; ++tab)
+            for (int j = 2; j < P - 1; ++j)
+                for (int p = 0; p < m; ++p) {
+                    const double u = rowtab[(size_t)tab * n + j * m + p], v = rowtab[(size_t)tab * n + m + p];
+                    if (u != v) {
+                        ci = false;
+                        long long iu, iv;
+                        std::memcpy(&iu, &u, 8);
+                        std::memcpy(&iv, &v, 8);
+                        worst = std::max(worst, std::llabs(iu - iv));
+                    }
+                }
+        e->chunk_invariant = ci;
+        if (getenv("TLAB_DEBUG_TABLES")) fprintf(stderr, "system n=%d P=%d periodic=%d: lane_invariant %d chunk_invariant %d (largest interior difference %lld ulp)\n", n, P, (int)h.periodic, (int)inv, (int)ci, worst);
+    }
     SystemEntry &ref = *e;
     systems[key] = std::move(e);
     return ref;

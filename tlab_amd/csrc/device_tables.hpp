@@ -25,6 +25,7 @@ struct SystemDev {
     const double *rowtab;   // [5][n]: Lm, Dinv, Cm, V, W
     const double *red;      // wave-per-line kernel: [13][64] = k1[6][64], k2[6][64], dinv[64]; register-tile kernel: ginv[P][P]
     int lane_invariant;     // 1: every chunk has the same tables (circulant, uniform grid) -> scalar loads of chunk 0
+    int chunk_invariant;    // 1: every INTERIOR chunk (1 .. P-2) has the tables of chunk 1 to the bit (uniform grid; walls only touch the first / last chunk)
 };
 
 // Jacobian correction of the second derivative on non-uniform grids: f += A2 dx2 du (MatMul_3d_add, fdm_matmul.f90:126-153)

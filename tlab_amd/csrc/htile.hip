@@ -90,6 +90,7 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
 template <int M, int L>
 __device__ __forceinline__ void h_solve2(double (&f)[M], double (&h)[M], const double *tf, const double *th, const double *gif, const double *gih, int n,
                                          int row0, int c, int C, int l32, double *s_ylf, double *s_rf, double *s_ylh, double *s_rh) {
+    // (n = distance between the five arrays of a table, row0 = first row of the chunk in them: (n, c M) for the full tables, (M, 0) for a chunk's own copy)
     const double *Lf = tf + row0, *Df = tf + n + row0, *Cf = tf + 2 * n + row0, *Vf = tf + 3 * n + row0, *Wf = tf + 4 * n + row0;
     const double *Lh = th + row0, *Dh = th + n + row0, *Ch = th + 2 * n + row0, *Vh = th + 3 * n + row0, *Wh = th + 4 * n + row0;
     double gf = 0.0, gh = 0.0;
@@ -403,6 +404,239 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
 #undef H_ROW0
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// k_ptile: OPR_Burgers along y / z on uniform grids with PERSISTENT workgroups whose operand tiles arrive by LDS-DMA.
+//
+// k_htile is one workgroup per CU (256 registers x 512 threads) whose waves load, solve and store in lockstep: the knock-out timings of round 4
+// (profiles/r04/htile_knockout.txt) say the memory phases of a launch take 1.8 ms and the two solves plus the staging of the tables another 0.5 ms
+// that nothing hides.  Here a workgroup walks over its work items (tile, field): while it computes item k, `global_load_lds_dwordx4` instructions
+// (no destination registers) bring the operand tile of item k + 1 into LDS -- 32 lines x n rows x 8 B = 128 KiB at n = 512 -- so that the operand
+// trip from HBM runs beside the stencils, the velocity load and the solves.  The halo rows of a chunk are rows of the same LDS tile (no second read
+// of the operand through L2), and the tables are staged once per workgroup, not once per tile.  To fit beside the tile the tables are kept in their
+// chunk-invariant form (first / interior / last chunk: 3 x 10 x M doubles): uniform grids only, checked on the host (launch_htile).
+// LDS: tile 128 KiB + separator values of both systems 16 KiB + tables 7.5 KiB + separator inverses 4 KiB = 155.5 of 160 KiB.
+// The DMA is inline assembly (the compiler drains its own `__builtin_amdgcn_global_load_lds` with vmcnt(0) at the next ordinary load or barrier): loads
+// return in order, so the wait for the velocity / old tendency of item k, which are issued AFTER the DMA of item k + 1, retires that DMA as well; an
+// explicit vmcnt(0) before the stores states it.
+// DIV: the one-field launch of the velocity component of this direction with the forcing term of the pressure equation as a third solve (k_htile's DIV);
+// the operand IS the advecting velocity then, which is taken from the LDS tile instead of a second load.
+template <int M, int L, int C, bool DIV = false>
+__global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitems) {
+    constexpr int N = M * C;                 // points per line
+    __shared__ double s_sep[4 * C * L];      // s_yl, s_r of both systems
+    __shared__ double s_t[2 * 3 * 5 * M];    // [system][first / interior / last chunk][Lm, Dinv, Cm, V, W][M]
+    __shared__ double s_gi[2 * C * C];
+    extern __shared__ double s_op[];         // operand tile [N][L]
+    const int l32 = threadIdx.x & (L - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cw = wv * (64 / L);
+    const int csub = (threadIdx.x & 63) / L;
+    const int c = cw + csub;
+    const long long rs = a.g.row_stride;
+    const long long rs8 = rs * 8;
+    const bool per = a.s1.periodic != 0;
+    const int tiles_inner = a.g.lines_inner / L;
+    const long long ntiles = (long long)tiles_inner * (a.g.nlines / a.g.lines_inner);
+
+    // tables: once per workgroup
+    for (int i = threadIdx.x; i < 2 * 3 * 5 * M; i += blockDim.x) {
+        const int sys = i / (15 * M), v = (i / (5 * M)) % 3, arr = (i / M) % 5, p = i % M;
+        const int chunk = v == 0 ? 0 : (v == 1 ? 1 : C - 1);
+        s_t[i] = (sys == 0 ? a.y1.rowtab : a.y2.rowtab)[arr * N + chunk * M + p];
+    }
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        s_gi[i] = a.y1.red[i];
+        s_gi[C * C + i] = a.y2.red[i];
+    }
+    const int var = (c == 0) ? 0 : (c == C - 1 ? 2 : 1);
+    const double *t1 = s_t + var * 5 * M, *t2 = s_t + (3 + var) * 5 * M;
+
+    // item -> (tile, field): as k_htile (the fields of a tile on one XCD at the same time: their velocity reads share its L2)
+    auto decode = [&](long long it, long long &tile, int &fi) {
+        const long long q = it >> 3;
+        fi = (int)(q % a.nf);
+        tile = (it & 7) + 8 * (q / a.nf);
+    };
+    // LDS-DMA of the operand tile of an item: wave w brings rows [64 w, 64 w + 64), 4 rows (1 KiB) per instruction, lane = (row in the four, 16-B piece)
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned dma_voff = (unsigned)(((long long)(lane >> 4) * rs + (lane & 15) * 2) * 8);
+    const unsigned lds_base = (unsigned)(unsigned long long)s_op;
+    auto prefetch = [&](long long it) {
+        long long tile;
+        int fi;
+        decode(it, tile, fi);
+        if (tile >= ntiles) return;
+        const long long outer = tile / tiles_inner;
+        const int l0 = (int)(tile % tiles_inner) * L;
+        gchar *src = sgpr_ptr(a.fs[fi] + outer * a.g.outer_stride + l0 + (long long)(64 * wv) * rs);
+        unsigned dst = lds_base + (unsigned)(64 * wv) * (L * 8);
+        const long long step = 4 * rs8;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(dma_voff), "s"(src), "s"(dst)
+                         : "memory");
+            src = sgpr_ptr(src + step);
+            dst += 4 * L * 8;
+        }
+    };
+
+    long long item = blockIdx.x;
+    prefetch(item);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();      // tables and the first tile are in LDS
+    for (; item < nitems; item += gridDim.x) {
+        long long tile;
+        int fi;
+        decode(item, tile, fi);
+        if (tile >= ntiles) continue;         // padding of the item range: the whole workgroup skips (its prefetch skipped it as well)
+        const long long outer = tile / tiles_inner;
+        const int l0 = (int)(tile % tiles_inner) * L;
+        const int row0 = c * M;
+        const long long ub = outer * a.g.outer_stride + l0 + (long long)cw * M * rs;
+        const unsigned vb = (unsigned)((l32 + (long long)csub * M * rs) * 8);
+        double *__restrict__ out0 = a.fo[fi];
+        const double nu = a.fnu[fi];
+
+        // ---- operand rows + halos from the LDS tile ----
+        double e[M + 6];
+        {
+            const double *col = s_op + l32 + row0 * L;
+#pragma unroll
+            for (int p = 0; p < M; ++p) e[p + 3] = col[p * L];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int rl = row0 - 3 + k, rr = row0 + M + k;
+                const bool okl = per || rl >= 0, okr = per || rr < N;
+                if (rl < 0) rl += N;
+                if (rr >= N) rr -= N;
+                e[k] = okl ? s_op[l32 + rl * L] : 0.0;
+                e[M + 3 + k] = okr ? s_op[l32 + rr * L] : 0.0;
+            }
+        }
+        __syncthreads();      // every wave has read its rows: the tile may be overwritten
+        if (item + gridDim.x < nitems) prefetch(item + gridDim.x);
+
+        // ---- right-hand sides of both systems ----
+        double x1[M], x2[M];
+#pragma unroll
+        for (int p = 0; p < M; ++p) x1[p] = h_stencil<false>(a.s1, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+#pragma unroll
+        for (int p = 0; p < M; ++p) x2[p] = h_stencil<true>(a.s2, e[p], e[p + 1], e[p + 2], e[p + 3], e[p + 4], e[p + 5], e[p + 6]);
+        if (!per) {
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    x1[r] = h_dense6(a.s1.bb[r], e[3], e[4], e[5], e[6], e[7], e[8]);
+                    x2[r] = h_dense6(a.s2.bb[r], e[3], e[4], e[5], e[6], e[7], e[8]);
+                }
+            }
+            if (c == C - 1) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    x1[M - 3 + r] = h_dense6(a.s1.bt[r], e[M - 3], e[M - 2], e[M - 1], e[M], e[M + 1], e[M + 2]);
+                    x2[M - 3 + r] = h_dense6(a.s2.bt[r], e[M - 3], e[M - 2], e[M - 1], e[M], e[M + 1], e[M + 2]);
+                }
+            }
+        }
+#define H_ROW0(f) sgpr_ptr((f) + ub)
+#define H_NEXT(r) r = sgpr_ptr(r + rs8)
+#define H_AT(r) (reinterpret_cast<gdouble *>(r + vgpr_u32(vb)))
+        double vl[M];
+        if constexpr (DIV) {
+#pragma unroll
+            for (int p = 0; p < M; ++p) vl[p] = e[p + 3];
+        } else {
+            gchar *r = H_ROW0(a.in2);
+#pragma unroll
+            for (int p = 0; p < M; ++p) { vl[p] = *H_AT(r); H_NEXT(r); }
+        }
+        h_solve2<M, L>(x1, x2, t1, t2, s_gi, s_gi + C * C, M, 0, c, C, l32, s_sep, s_sep + C * L, s_sep + 2 * C * L, s_sep + 3 * C * L);
+
+        // ---- epilogue: result = nu d2 - vel d1 (opr_burgers.f90:513), accumulated into the tendency ----
+#pragma unroll
+        for (int p = 0; p < M; ++p) x2[p] = nu * x2[p] - vl[p] * x1[p];
+        gchar *ro = H_ROW0(out0);
+        if (a.acc && !((a.fresh_mask >> fi) & 1u)) {
+#pragma unroll
+            for (int p = 0; p < M; ++p) { x1[p] = __builtin_nontemporal_load(H_AT(ro)); H_NEXT(ro); }
+            ro = H_ROW0(out0);
+#pragma unroll
+            for (int p = 0; p < M; ++p) x2[p] = x1[p] + x2[p];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every load of this wave has landed, the DMA of the next tile included
+#pragma unroll
+        for (int p = 0; p < M; ++p) { __builtin_nontemporal_store(x2[p], H_AT(ro)); H_NEXT(ro); }
+        if constexpr (DIV) {
+            // x2 = the finished tendency h of this velocity component, vl = the component: forcing term d/dz (h + fidte w) (rhs_global_incompressible_1.f90:
+            // 197-230), same stencil and system as the first derivative above, added to fdiv.  The three rows a chunk needs from each neighbour travel
+            // through the separator buffer in two rounds (first rows to the left neighbour, last rows to the right one).
+            double tt[M + 6];
+#pragma unroll
+            for (int p = 0; p < M; ++p) tt[p + 3] = x2[p] + vl[p] * a.fidte;
+            const int cl = (c + C - 1) % C, cr = (c + 1) % C;
+            const bool okl = per || c > 0, okr = per || c < C - 1;
+            __syncthreads();      // the separator values of the dual solve have been read by everyone
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_sep[(c * 3 + k) * L + l32] = tt[3 + k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tt[M + 3 + k] = okr ? s_sep[(cr * 3 + k) * L + l32] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_sep[(c * 3 + k) * L + l32] = tt[M + k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tt[k] = okl ? s_sep[(cl * 3 + k) * L + l32] : 0.0;
+            __syncthreads();      // ... before h_solve writes its separator values there
+            double gg[M];
+#pragma unroll
+            for (int p = 0; p < M; ++p) gg[p] = h_stencil<false>(a.s1, tt[p], tt[p + 1], tt[p + 2], tt[p + 3], tt[p + 4], tt[p + 5], tt[p + 6]);
+            if (!per) {
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) gg[r] = h_dense6(a.s1.bb[r], tt[3], tt[4], tt[5], tt[6], tt[7], tt[8]);
+                }
+                if (c == C - 1) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) gg[M - 3 + r] = h_dense6(a.s1.bt[r], tt[M - 3], tt[M - 2], tt[M - 1], tt[M], tt[M + 1], tt[M + 2]);
+                }
+            }
+            h_solve<M, L>(gg, t1, s_gi, M, 0, c, C, l32, s_sep, s_sep + C * L);
+            double fo[M];
+            gchar *r = H_ROW0(a.fdiv);
+#pragma unroll
+            for (int p = 0; p < M; ++p) { fo[p] = *H_AT(r); H_NEXT(r); }
+            r = H_ROW0(a.fdiv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < M; ++p) { *H_AT(r) = fo[p] + gg[p]; H_NEXT(r); }
+        }
+#undef H_AT
+#undef H_NEXT
+#undef H_ROW0
+        __syncthreads();      // the next tile is in LDS for every wave (and the separator values of this item are no longer read)
+    }
+}
+
+static int g_htile_persist = [] { const char *e = getenv("TLAB_HTILE_PERSIST"); return (e && atoi(e) == 0) ? 0 : 1; }();      // 0: k_htile<UNI> instead of k_ptile (A/B)
+static int g_ncu = 0;
+static long long ptile_cus() {
+    if (!g_ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) g_ncu = pr.multiProcessorCount;
+        if (g_ncu <= 0) g_ncu = 256;
+    }
+    return g_ncu;
+}
+// the persistent kernel takes 512-point lines in 32-line tiles whose tables are the same for every interior chunk (periodic z of a uniform grid)
+static bool ptile_ok(const RTileArgs &a, int L, int C) {
+    return g_htile_persist && L == 32 && C == 16 && a.g.n == 512 && a.g.lines_inner % 32 == 0 && a.y1.chunk_invariant && a.y2.chunk_invariant;
+}
 static int g_htile_uni = [] { const char *e = getenv("TLAB_HTILE_UNI"); return (e && atoi(e) == 0) ? 0 : 1; }();      // 0: general kernel on uniform grids too (A/B)
 static int g_htile_lines = [] { const char *e = getenv("TLAB_HTILE_LINES"); return (e && atoi(e) == 16) ? 16 : 32; }();
 void htile_set_lines(int lines) { g_htile_lines = lines; }
@@ -440,6 +674,9 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
         if (a.fdiv) bytes += pts * 16;      // forcing term: read + write
     }
     const bool uni = g_htile_uni && a.jc.j == nullptr && a.s1.rowc == nullptr && a.s2.rowc == nullptr;      // uniform grid, Jacobian schemes
+    if constexpr (M == 32 && MAXT == 512)
+        if (mode == MODE_BURGERS && uni && !a.ari && ptile_ok(a, L, C) && (!a.fdiv || (a.nf == 1 && a.fs[0] == a.in2)))
+            name = a.fdiv ? "k_ptile<BURGERS+div>" : "k_ptile<BURGERS>";
     ProfScope ps(name, st, bytes);
     switch (mode) {
     case MODE_P1: hipLaunchKernelGGL((k_htile<M, MODE_P1, MAXT, L>), grid, block, lds, st, a); break;
@@ -449,7 +686,10 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
         if (a.fdiv) {
             if constexpr (M == 32 && MAXT == 512) {      // L = 32 with up to 16 chunks, or the 16-line tiles of 1024-point lines (32 chunks)
                 if (a.nf != 1 || a.fs[0] != a.in2 || C * L > MAXT || a.s1.rowc != nullptr || a.ari) return hipErrorInvalidValue;
-                if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true, 0, true>), grid, block, lds, st, a);
+                if (uni && ptile_ok(a, L, C)) {
+                    const unsigned pg = (unsigned)(nwg < ptile_cus() ? nwg : ptile_cus());
+                    hipLaunchKernelGGL((k_ptile<32, 32, 16, true>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                } else if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true, 0, true>), grid, block, lds, st, a);
                 else hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true>), grid, block, lds, st, a);
             } else {
                 return hipErrorInvalidValue;
@@ -464,7 +704,10 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
             }
         } else {
             if constexpr (M == 32 && MAXT == 512) {
-                if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, false, 0, true>), grid, block, lds, st, a);
+                if (uni && ptile_ok(a, L, C)) {
+                    const unsigned pg = (unsigned)(nwg < ptile_cus() ? nwg : ptile_cus());      // items = the (padded) workgroup ids of k_htile
+                    hipLaunchKernelGGL((k_ptile<32, 32, 16>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                } else if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, false, 0, true>), grid, block, lds, st, a);
                 else hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a);
             } else {
                 hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a);

@@ -30,7 +30,8 @@ struct SystemEntry {
     ChunkedTables host;
     DeviceArray rowtab, red;
     bool lane_invariant = false;
-    SystemDev dev() const { return SystemDev{rowtab.p, red.p, lane_invariant ? 1 : 0}; }
+    bool chunk_invariant = false;      // interior chunks 1 .. P-2 bitwise equal (k_ptile's compact tables)
+    SystemDev dev() const { return SystemDev{rowtab.p, red.p, lane_invariant ? 1 : 0, chunk_invariant ? 1 : 0}; }
 };
 
 }  // namespace tlab

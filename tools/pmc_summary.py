@@ -23,6 +23,9 @@ def tag(name):
     m = re.match(r"k_htile<(\d+), 4, (\d+), (\d+), true\b", name)
     if m:
         return "k_htile<BURGERS+div>"
+    m = re.match(r"k_ptile<(\d+), (\d+), (\d+), (true|false)", name)
+    if m:
+        return "k_ptile<BURGERS+div>" if m.group(4) == "true" else "k_ptile<BURGERS>"
     m = re.match(r"k_(xline|rtile|htile)<(\d+), (\d+)", name)
     if m:
         return "k_%s<%s>" % (m.group(1), MODES.get(int(m.group(3)), m.group(3)))
