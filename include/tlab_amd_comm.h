@@ -54,7 +54,13 @@ int tlab_comm_slab_transport(tlab_comm_t comm, tlab_slab_transport *out);
  * with a communicator rank_dir / npro_dir are taken from it and the arguments are ignored. */
 int tlab_trp_plan_create(tlab_trp_plan_t *out, tlab_comm_t comm, int dir, int nmax, int npage, int elem_doubles, int rank_dir, int npro_dir);
 int tlab_trp_plan_destroy(tlab_trp_plan_t plan);
-int tlab_trp_plan_info(tlab_trp_plan_t plan, int what);   /* 0 nlines, 1 npro, 2 rank, 3 doubles per peer block, 4 local doubles */
+int tlab_trp_plan_info(tlab_trp_plan_t plan, int what);   /* 0 nlines, 1 npro, 2 rank, 3 reals per peer block, 4 local reals, 5 bytes per real on the wire */
+/* [Parallel] TransposeTypeI / TransposeTypeK = single (tlab_mpi_transpose.f90:106-122; applied in the real Exec routines :362-371, :473-482): the
+ * data of a REAL plan travel as fp32 -- the pack pass converts, the unpack pass converts back, the result is the transposition of the field rounded
+ * to single precision (every block, the own one included, exactly as the reference, which converts the whole array first): half the bytes over
+ * xGMI.  Complex plans always travel in double precision (:386-399): TLAB_EUNSUPPORTED.  With single the wire format of tlab_trp_pack /
+ * tlab_trp_unpack is npro blocks of floats (the buffers are still passed as double pointers; half of their bytes are used). */
+int tlab_trp_plan_set_wire(tlab_trp_plan_t plan, int single);
 
 /* TLabMPI_Trp_Exec{I,K}_Forward (forward != 0) / _Backward (forward == 0): a -> b (forward) resp. b -> a, bit-exact index work.
  * exec = start + wait.  start: pack (if this direction's send side is strided) on the current stream, then the grouped exchange on the

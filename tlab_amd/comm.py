@@ -20,6 +20,7 @@ SIGNATURES = {
     "tlab_trp_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
     "tlab_trp_plan_destroy": (c_int, [c_vp]),
     "tlab_trp_plan_info": (c_int, [c_vp, c_int]),
+    "tlab_trp_plan_set_wire": (c_int, [c_vp, c_int]),
     "tlab_trp_exec": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tlab_trp_start": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tlab_trp_wait": (c_int, [c_vp]),
@@ -89,6 +90,10 @@ class TrpPlan:
 
     def info(self, what):
         return load().tlab_trp_plan_info(self._h, what)
+
+    def set_wire(self, single):
+        """[Parallel] TransposeTypeI / TransposeTypeK = single: fp32 on the wire (real plans only)."""
+        check(load().tlab_trp_plan_set_wire(self._h, int(bool(single))), "tlab_trp_plan_set_wire")
 
     def exec(self, forward, src, dst):
         check(load().tlab_trp_exec(self._h, int(forward), c_vp(src), c_vp(dst)), "tlab_trp_exec")

@@ -57,6 +57,26 @@ __global__ void __launch_bounds__(256) k_trp_copy(double *__restrict__ S, double
     }
 }
 
+// TransposeType{I,K} = single (tlab_mpi_transpose.f90:106-122, :362-371, :473-482): the data travel as fp32.  The same index pattern with a float wire;
+// strided = 0: S is read / written in wire order (the side that is blocked by peer as it stands).  to_wire: W[i] = (float) S[..]; else S[..] = (double) W[i].
+template <int VEC>
+__global__ void __launch_bounds__(256) k_trp_copy_f32(double *__restrict__ S, float *__restrict__ W, long long m, int P, long long c, int to_wire, int strided) {
+    const long long mv = m / VEC, total = mv * c * P, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long r = i % mv, o = (i / mv) % c, q = i / (mv * c);
+        const long long s = strided ? (q * mv + r) + (mv * P) * o : i;
+        if (VEC == 2) {
+            double2 *S2 = reinterpret_cast<double2 *>(S);
+            float2 *W2 = reinterpret_cast<float2 *>(W);
+            if (to_wire) { const double2 v = S2[s]; W2[i] = make_float2((float)v.x, (float)v.y); }
+            else { const float2 v = W2[i]; S2[s] = make_double2((double)v.x, (double)v.y); }
+        } else {
+            if (to_wire) W[i] = (float)S[s];
+            else S[s] = (double)W[i];
+        }
+    }
+}
+
 }  // namespace
 
 struct tlab_comm {
@@ -76,6 +96,7 @@ struct tlab_trp_plan {
     int dir = 0, P = 1, rank = 0, e = 1;
     long long m = 0, c = 0, blk = 0, local = 0, nlines = 0;
     double *stage = nullptr;
+    bool single = false;               // fp32 on the wire (real plans only): stage = send floats | receive floats
     hipStream_t stream = nullptr;      // comm->stream, or an own one for plans without a communicator
     bool own_stream = false;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
@@ -96,6 +117,15 @@ void copy_strided(const tlab_trp_plan *p, double *S, double *W, int to_wire, hip
     hipc(hipGetLastError(), "k_trp_copy");
 }
 bool strided_on_send(const tlab_trp_plan *p, int forward) { return (p->dir == 1 && !forward) || (p->dir == 3 && forward); }
+void copy_f32(const tlab_trp_plan *p, double *S, float *W, int to_wire, int strided, hipStream_t st) {
+    const long long total = p->m * p->c * p->P;
+    const bool vec = (p->m % 2 == 0) && (reinterpret_cast<uintptr_t>(S) % 16 == 0) && (reinterpret_cast<uintptr_t>(W) % 8 == 0);
+    const long long work = vec ? total / 2 : total;
+    const int grid = (int)std::min<long long>(4096, std::max<long long>(1, (work + 255) / 256));
+    if (vec) hipLaunchKernelGGL(k_trp_copy_f32<2>, dim3(grid), dim3(256), 0, st, S, W, p->m, p->P, p->c, to_wire, strided);
+    else hipLaunchKernelGGL(k_trp_copy_f32<1>, dim3(grid), dim3(256), 0, st, S, W, p->m, p->P, p->c, to_wire, strided);
+    hipc(hipGetLastError(), "k_trp_copy_f32");
+}
 
 int guard(const Fail &f) {
     tlab_set_error(f.msg);
@@ -132,11 +162,14 @@ int slab_ring_start(void *ctx, void *stream, int nmsg, const long long *count, d
         const int t = slab_begin(c, (hipStream_t)stream);
         ncclComm_t nc = zcomm(c);
         ncc(ncclGroupStart(), "ncclGroupStart");
-        for (int i = 0; i < nmsg; ++i) ncc(ncclSend(to_left[i], (size_t)count[i], ncclDouble, left, nc, c->stream), "ncclSend");
-        for (int i = 0; i < nmsg; ++i) ncc(ncclSend(to_right[i], (size_t)count[i], ncclDouble, right, nc, c->stream), "ncclSend");
-        for (int i = 0; i < nmsg; ++i) ncc(ncclRecv(from_right[i], (size_t)count[i], ncclDouble, right, nc, c->stream), "ncclRecv");
-        for (int i = 0; i < nmsg; ++i) ncc(ncclRecv(from_left[i], (size_t)count[i], ncclDouble, left, nc, c->stream), "ncclRecv");
-        ncc(ncclGroupEnd(), "ncclGroupEnd");
+        ncclResult_t r = ncclSuccess;      // a failing call must not leave the group open: it is closed first, the error raised afterwards
+        for (int i = 0; i < nmsg && r == ncclSuccess; ++i) r = ncclSend(to_left[i], (size_t)count[i], ncclDouble, left, nc, c->stream);
+        for (int i = 0; i < nmsg && r == ncclSuccess; ++i) r = ncclSend(to_right[i], (size_t)count[i], ncclDouble, right, nc, c->stream);
+        for (int i = 0; i < nmsg && r == ncclSuccess; ++i) r = ncclRecv(from_right[i], (size_t)count[i], ncclDouble, right, nc, c->stream);
+        for (int i = 0; i < nmsg && r == ncclSuccess; ++i) r = ncclRecv(from_left[i], (size_t)count[i], ncclDouble, left, nc, c->stream);
+        const ncclResult_t e = ncclGroupEnd();
+        ncc(r, "ncclSend / ncclRecv (ring)");
+        ncc(e, "ncclGroupEnd");
         hipc(hipEventRecord(c->ev_done[t], c->stream), "hipEventRecord");
         return t;
     } catch (const Fail &f) {
@@ -153,16 +186,19 @@ int slab_alltoallv_start(void *ctx, void *stream, double *const *send, const lon
         ncclComm_t nc = zcomm(c);
         long long so = 0, ro = 0, my_so = 0, my_ro = 0;
         ncc(ncclGroupStart(), "ncclGroupStart");
+        ncclResult_t r = ncclSuccess;
         for (int q = 0; q < P; ++q) {
             if (q == me) { my_so = so; my_ro = ro; }
-            else {
-                if (scount[q] > 0) ncc(ncclSend(send[0] + so, (size_t)scount[q], ncclDouble, q, nc, c->stream), "ncclSend");
-                if (rcount[q] > 0) ncc(ncclRecv(recv[0] + ro, (size_t)rcount[q], ncclDouble, q, nc, c->stream), "ncclRecv");
+            else if (r == ncclSuccess) {
+                if (scount[q] > 0) r = ncclSend(send[0] + so, (size_t)scount[q], ncclDouble, q, nc, c->stream);
+                if (r == ncclSuccess && rcount[q] > 0) r = ncclRecv(recv[0] + ro, (size_t)rcount[q], ncclDouble, q, nc, c->stream);
             }
             so += scount[q];
             ro += rcount[q];
         }
-        ncc(ncclGroupEnd(), "ncclGroupEnd");
+        const ncclResult_t e = ncclGroupEnd();
+        ncc(r, "ncclSend / ncclRecv (all-to-all)");
+        ncc(e, "ncclGroupEnd");
         if (scount[me] != rcount[me]) throw Fail{TLAB_EINVAL, "slab transport: own block sizes differ"};
         if (scount[me] > 0)
             hipc(hipMemcpyAsync(recv[0] + my_ro, send[0] + my_so, (size_t)scount[me] * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync (own block)");
@@ -337,6 +373,16 @@ int tlab_trp_plan_destroy(tlab_trp_plan_t p) {
     return TLAB_OK;
 }
 
+int tlab_trp_plan_set_wire(tlab_trp_plan_t p, int single) {
+    try {
+        if (!p) throw Fail{TLAB_EINVAL, "tlab_trp_plan_set_wire: null plan"};
+        if (p->pending) throw Fail{TLAB_EINVAL, "tlab_trp_plan_set_wire: a transposition of this plan is in flight"};
+        if (single && p->e != 1) throw Fail{TLAB_EUNSUPPORTED, "tlab_trp_plan_set_wire: complex plans always travel in double precision (tlab_mpi_transpose.f90:386-399)"};
+        p->single = single != 0;
+        return TLAB_OK;
+    } catch (const Fail &f) { return guard(f); }
+}
+
 int tlab_trp_plan_info(tlab_trp_plan_t p, int what) {
     if (!p) return TLAB_EINVAL;
     switch (what) {
@@ -345,6 +391,7 @@ int tlab_trp_plan_info(tlab_trp_plan_t p, int what) {
         case 2: return p->rank;
         case 3: return (int)p->blk;
         case 4: return (int)p->local;
+        case 5: return p->single ? 4 : 8;      // bytes per real on the wire
     }
     return TLAB_EINVAL;
 }
@@ -353,7 +400,8 @@ int tlab_trp_pack(tlab_trp_plan_t p, int forward, const double *in, double *send
     try {
         if (!p || !in || !sendbuf || in == sendbuf) throw Fail{TLAB_EINVAL, "tlab_trp_pack: bad arguments"};
         hipStream_t st = tlab_current_stream();
-        if (strided_on_send(p, forward)) copy_strided(p, const_cast<double *>(in), sendbuf, 1, st);
+        if (p->single) copy_f32(p, const_cast<double *>(in), reinterpret_cast<float *>(sendbuf), 1, strided_on_send(p, forward) ? 1 : 0, st);
+        else if (strided_on_send(p, forward)) copy_strided(p, const_cast<double *>(in), sendbuf, 1, st);
         else hipc(hipMemcpyAsync(sendbuf, in, (size_t)p->local * sizeof(double), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
         return TLAB_OK;
     } catch (const Fail &f) { return guard(f); }
@@ -363,7 +411,8 @@ int tlab_trp_unpack(tlab_trp_plan_t p, int forward, const double *recvbuf, doubl
     try {
         if (!p || !recvbuf || !out || recvbuf == out) throw Fail{TLAB_EINVAL, "tlab_trp_unpack: bad arguments"};
         hipStream_t st = tlab_current_stream();
-        if (!strided_on_send(p, forward)) copy_strided(p, out, const_cast<double *>(recvbuf), 0, st);
+        if (p->single) copy_f32(p, out, reinterpret_cast<float *>(const_cast<double *>(recvbuf)), 0, strided_on_send(p, forward) ? 0 : 1, st);
+        else if (!strided_on_send(p, forward)) copy_strided(p, out, const_cast<double *>(recvbuf), 0, st);
         else hipc(hipMemcpyAsync(out, recvbuf, (size_t)p->local * sizeof(double), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
         return TLAB_OK;
     } catch (const Fail &f) { return guard(f); }
@@ -376,6 +425,32 @@ int tlab_trp_start(tlab_trp_plan_t p, int forward, const double *in, double *out
         if (p->P > 1 && !p->nc) throw Fail{TLAB_EINVAL, "tlab_trp_start: the plan has no communicator (use tlab_trp_pack / tlab_trp_unpack)"};
         hipStream_t cur = tlab_current_stream(), cs = p->stream;
         const bool pack = strided_on_send(p, forward);
+        if (p->single) {
+            // fp32 wire: BOTH sides go through the staging buffer (send floats in its first half, received floats in its second), the conversions
+            // ride on the pack / unpack passes.  Every block -- the own one included -- is rounded to fp32, as in the reference, which converts the
+            // whole array before the exchange (tlab_mpi_transpose.f90:362-371).
+            float *sf = reinterpret_cast<float *>(p->stage), *rf = sf + p->local;
+            copy_f32(p, const_cast<double *>(in), sf, 1, pack ? 1 : 0, cur);
+            hipc(hipEventRecord(p->ev_ready, cur), "hipEventRecord");
+            hipc(hipStreamWaitEvent(cs, p->ev_ready, 0), "hipStreamWaitEvent");
+            hipc(hipMemcpyAsync(rf + (size_t)p->rank * p->blk, sf + (size_t)p->rank * p->blk, (size_t)p->blk * sizeof(float), hipMemcpyDeviceToDevice, cs),
+                 "hipMemcpyAsync (own block)");
+            if (p->P > 1) {
+                ncc(ncclGroupStart(), "ncclGroupStart");
+                ncclResult_t r = ncclSuccess;
+                for (int q = 0; q < p->P && r == ncclSuccess; ++q) {
+                    if (q == p->rank) continue;
+                    r = ncclSend(sf + (size_t)q * p->blk, (size_t)p->blk, ncclFloat, q, p->nc, cs);
+                    if (r == ncclSuccess) r = ncclRecv(rf + (size_t)q * p->blk, (size_t)p->blk, ncclFloat, q, p->nc, cs);
+                }
+                const ncclResult_t e = ncclGroupEnd();      // (always closed, also when a call inside the group failed)
+                ncc(r, "ncclSend / ncclRecv");
+                ncc(e, "ncclGroupEnd");
+            }
+            hipc(hipEventRecord(p->ev_done, cs), "hipEventRecord");
+            p->pending = true; p->pending_unpack = !pack; p->pending_out = out;
+            return TLAB_OK;
+        }
         const double *src = in;       // blocked by peer
         double *dst = out;            // blocked by peer
         if (pack) { copy_strided(p, const_cast<double *>(in), p->stage, 1, cur); src = p->stage; }
@@ -386,12 +461,15 @@ int tlab_trp_start(tlab_trp_plan_t p, int forward, const double *in, double *out
         hipc(hipMemcpyAsync(dst + (size_t)p->rank * p->blk, src + (size_t)p->rank * p->blk, bytes, hipMemcpyDeviceToDevice, cs), "hipMemcpyAsync (own block)");
         if (p->P > 1) {
             ncc(ncclGroupStart(), "ncclGroupStart");
-            for (int q = 0; q < p->P; ++q) {
+            ncclResult_t r = ncclSuccess;
+            for (int q = 0; q < p->P && r == ncclSuccess; ++q) {
                 if (q == p->rank) continue;
-                ncc(ncclSend(src + (size_t)q * p->blk, (size_t)p->blk, ncclDouble, q, p->nc, cs), "ncclSend");
-                ncc(ncclRecv(dst + (size_t)q * p->blk, (size_t)p->blk, ncclDouble, q, p->nc, cs), "ncclRecv");
+                r = ncclSend(src + (size_t)q * p->blk, (size_t)p->blk, ncclDouble, q, p->nc, cs);
+                if (r == ncclSuccess) r = ncclRecv(dst + (size_t)q * p->blk, (size_t)p->blk, ncclDouble, q, p->nc, cs);
             }
-            ncc(ncclGroupEnd(), "ncclGroupEnd");
+            const ncclResult_t e = ncclGroupEnd();      // (always closed, also when a call inside the group failed: no open group is left behind)
+            ncc(r, "ncclSend / ncclRecv");
+            ncc(e, "ncclGroupEnd");
         }
         hipc(hipEventRecord(p->ev_done, cs), "hipEventRecord");
         p->pending = true; p->pending_unpack = !pack; p->pending_out = out;
@@ -405,7 +483,8 @@ int tlab_trp_wait(tlab_trp_plan_t p) {
         if (!p->pending) return TLAB_OK;
         hipStream_t cur = tlab_current_stream();
         hipc(hipStreamWaitEvent(cur, p->ev_done, 0), "hipStreamWaitEvent");
-        if (p->pending_unpack) copy_strided(p, p->pending_out, p->stage, 0, cur);
+        if (p->single) copy_f32(p, p->pending_out, reinterpret_cast<float *>(p->stage) + p->local, 0, p->pending_unpack ? 1 : 0, cur);
+        else if (p->pending_unpack) copy_strided(p, p->pending_out, p->stage, 0, cur);
         p->pending = false;
         return TLAB_OK;
     } catch (const Fail &f) { return guard(f); }

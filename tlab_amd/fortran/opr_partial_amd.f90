@@ -34,7 +34,11 @@ module TLAB_AMD_PARTIAL_MODULE
     integer, parameter, public :: OPR_P0_INT_PV = 8
     integer, parameter, public :: OPR_P0_IBM = 9
 
-    type(c_ptr), save :: plans(3) = [c_null_ptr, c_null_ptr, c_null_ptr]
+    ! device plans, keyed by direction AND by the host plan object they mirror (the address of the fdm_dt): a caller that passes another fdm_dt for
+    ! the same direction -- fdm_loc of OPR_Elliptic (opr_elliptic.f90:107-124), a pressure grid -- gets a plan of its own, not the first one made
+    integer, parameter :: NSLOT = 4
+    type(c_ptr), save :: plans(NSLOT, 3) = c_null_ptr
+    type(c_ptr), save :: keys(NSLOT, 3) = c_null_ptr
 
 contains
     ! ###################################################################
@@ -42,19 +46,38 @@ contains
         use TLab_WorkFlow, only: stagger_on
         integer, intent(in) :: idir
         type(fdm_dt), intent(in), target :: g
+        type(c_ptr) :: p, pm1, pm2, key
+        integer(c_int) rc
+        integer is
+        real(c_double) :: one_node(1)
+        key = c_loc(g%size)                                      ! the address of the host object
+        is = 0
+        do is = 1, NSLOT
+            if (.not. c_associated(keys(is, idir))) exit          ! first free slot: a new plan
+            if (c_associated(keys(is, idir), key)) exit           ! known object
+        end do
+        if (is > NSLOT) call TLab_AMD_Check(-1_c_int, 'OPR_Partial_AMD_Plan: more than 4 different fdm_dt objects for one direction')
+        keys(is, idir) = key
+        p = partial_plan_slot(plans(is, idir), g)
+    end function OPR_Partial_AMD_Plan
+
+    function partial_plan_slot(slot, g) result(p)
+        use TLab_WorkFlow, only: stagger_on
+        type(c_ptr), intent(inout) :: slot
+        type(fdm_dt), intent(in), target :: g
         type(c_ptr) :: p, pm1, pm2
         integer(c_int) rc
         real(c_double) :: one_node(1)
-        if (.not. c_associated(plans(idir)) .and. g%size == 1) then
+        if (.not. c_associated(slot) .and. g%size == 1) then
             ! a direction of one point (the z direction of a 2-D case, examples/Case01): FDM_CreatePlan leaves no tables (fdm.f90:185-189) and
             ! the operators return zeros (opr_partial.f90:175-177) -- the library's own one-point plan does the same
             one_node = 0.0_c_double
-            rc = tlab_fdm_plan_create(plans(idir), 1_c_int, one_node, merge(1_c_int, 0_c_int, g%periodic), 1_c_int, &
+            rc = tlab_fdm_plan_create(slot, 1_c_int, one_node, merge(1_c_int, 0_c_int, g%periodic), 1_c_int, &
                                       int(g%der1%mode_fdm, c_int), int(g%der2%mode_fdm, c_int), 0.0_c_double)
             call TLab_AMD_Check(rc, 'tlab_fdm_plan_create')
         end if
-        if (.not. c_associated(plans(idir))) then
-            rc = tlab_fdm_plan_create_from_arrays(plans(idir), int(g%size, c_int), merge(1_c_int, 0_c_int, g%periodic), &
+        if (.not. c_associated(slot)) then
+            rc = tlab_fdm_plan_create_from_arrays(slot, int(g%size, c_int), merge(1_c_int, 0_c_int, g%periodic), &
                                                   merge(1_c_int, 0_c_int, g%der2%need_1der), &
                                                   int(g%der1%nb_diag(1), c_int), int(g%der1%nb_diag(2), c_int), g%der1%lhs, g%der1%rhs, &
                                                   int(g%der2%nb_diag(1), c_int), int(g%der2%nb_diag(2), c_int), g%der2%lhs, g%der2%rhs)
@@ -62,17 +85,17 @@ contains
             pm1 = c_null_ptr; pm2 = c_null_ptr                    ! modified wavenumbers exist in periodic directions only
             if (allocated(g%der1%mwn)) pm1 = c_loc(g%der1%mwn)
             if (allocated(g%der2%mwn)) pm2 = c_loc(g%der2%mwn)
-            rc = tlab_fdm_plan_set_aux(plans(idir), pm1, pm2, c_loc(g%jac), c_null_ptr)
+            rc = tlab_fdm_plan_set_aux(slot, pm1, pm2, c_loc(g%jac), c_null_ptr)
             call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_aux')
-            rc = tlab_fdm_plan_set_scheme(plans(idir), int(g%der1%mode_fdm, c_int), int(g%der2%mode_fdm, c_int))     ! CompactDirect6: per-row rhs
+            rc = tlab_fdm_plan_set_scheme(slot, int(g%der1%mode_fdm, c_int), int(g%der2%mode_fdm, c_int))     ! CompactDirect6: per-row rhs
             call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_scheme')
             if (stagger_on .and. g%periodic) then                 ! fdm.f90:236-248; g%der1%mwn above is already the interpolatory one
-                rc = tlab_fdm_plan_set_stagger(plans(idir), 2_c_int)
+                rc = tlab_fdm_plan_set_stagger(slot, 2_c_int)
                 call TLab_AMD_Check(rc, 'tlab_fdm_plan_set_stagger')
             end if
         end if
-        p = plans(idir)
-    end function OPR_Partial_AMD_Plan
+        p = slot
+    end function partial_plan_slot
 
     ! ###################################################################
     subroutine partial_any(idir, type, nx, ny, nz, bcs, g, u, result, tmp1)

@@ -35,6 +35,9 @@ module TLabMPI_Transpose
     type(tmpi_transpose_dt), public :: tmpi_plan_dz
 
     type(c_ptr), save :: comm = c_null_ptr
+    ! the [Parallel] options of TLabMPI_Trp_Initialize (tlab_mpi_transpose.f90:29-47)
+    integer, public, save :: trp_mode_i = 1, trp_mode_k = 1               ! TLAB_MPI_TRP_ASYNCHRONOUS: validated and kept, no effect on the device path
+    logical, public, save :: trp_single_i = .false., trp_single_k = .false.   ! TransposeTypeI / TransposeTypeK = single: fp32 on the wire (real plans)
 
     type :: cache_dt                                                ! device plans (tlab_trp_plan_t) by (dir, nmax, npage, element size)
         integer :: dir = 0, nmax = 0, npage = 0, e = 0
@@ -68,6 +71,11 @@ module TLabMPI_Transpose
         integer(c_int) function tlab_trp_plan_destroy(plan) bind(C, name='tlab_trp_plan_destroy')
             import :: c_int, c_ptr
             type(c_ptr), value :: plan
+        end function
+        integer(c_int) function tlab_trp_plan_set_wire(plan, single) bind(C, name='tlab_trp_plan_set_wire')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: single
         end function
         integer(c_int) function tlab_trp_exec(plan, forward, a, b) bind(C, name='tlab_trp_exec')
             import :: c_int, c_ptr
@@ -116,13 +124,55 @@ contains
         comm = c_null_ptr
     end subroutine TLabMPI_Trp_AMD_Finalize
 
-    ! TLabMPI_Trp_Initialize(inifile)   tlab_mpi_transpose.f90:66-201 (the [Parallel] transposition modes of the reference select among MPI
-    ! strategies and have no meaning here; the plans of the derivatives are the same)
+    ! TLabMPI_Trp_Initialize(inifile)   tlab_mpi_transpose.f90:66-201.  The [Parallel] block is read as the reference reads it (:82-122):
+    !   TransposeModeI / TransposeModeK (fallback [Main] ComModeITranspose / ComModeKTranspose) = none | asynchronous | sendrecv | alltoall select among
+    !     MPI strategies; here every transposition is one grouped ncclSend / ncclRecv, so the value is validated (same error as the reference) and kept;
+    !   TransposeTypeI / TransposeTypeK = double | single: the wire precision of the REAL transpositions (tlab_trp_plan_set_wire; complex ones always
+    !     travel in double precision, :386-399).
     subroutine TLabMPI_Trp_Initialize(inifile)
         character(len=*), intent(in) :: inifile
+        character(len=32) bakfile
+        character(len=512) sRes
+        integer, parameter :: DNS_ERROR_OPTION = 15, DNS_ERROR_UNDEVELOP = 104
+        bakfile = trim(adjustl(inifile))//'.bak'
+        call ScanFile_Char(bakfile, inifile, 'Parallel', 'TransposeModeI', 'void', sRes)
+        if (trim(adjustl(sRes)) == 'void') call ScanFile_Char(bakfile, inifile, 'Main', 'ComModeITranspose', 'asynchronous', sRes)
+        trp_mode_i = mode_code(sRes, 'TransposeModeI')
+        call ScanFile_Char(bakfile, inifile, 'Parallel', 'TransposeModeK', 'void', sRes)
+        if (trim(adjustl(sRes)) == 'void') call ScanFile_Char(bakfile, inifile, 'Main', 'ComModeKTranspose', 'asynchronous', sRes)
+        trp_mode_k = mode_code(sRes, 'TransposeModeK')
+        call ScanFile_Char(bakfile, inifile, 'Parallel', 'TransposeTypeK', 'Double', sRes)
+        if (trim(adjustl(sRes)) == 'double') then; trp_single_k = .false.
+        elseif (trim(adjustl(sRes)) == 'single') then; trp_single_k = .true.
+        else
+            call TLab_Write_ASCII(efile, __FILE__//'. Wrong TransposeTypeK.')
+            call TLab_Stop(DNS_ERROR_UNDEVELOP)
+        end if
+        call ScanFile_Char(bakfile, inifile, 'Parallel', 'TransposeTypeI', 'Double', sRes)
+        if (trim(adjustl(sRes)) == 'double') then; trp_single_i = .false.
+        elseif (trim(adjustl(sRes)) == 'single') then; trp_single_i = .true.
+        else
+            call TLab_Write_ASCII(efile, __FILE__//'. Wrong TransposeTypeI.')
+            call TLab_Stop(DNS_ERROR_UNDEVELOP)
+        end if
         if (ims_npro_i > 1) tmpi_plan_dx = TLabMPI_Trp_PlanI(imax, kmax*jmax, message='Ox derivatives.')     ! :189-192
         if (ims_npro_k > 1) tmpi_plan_dz = TLabMPI_Trp_PlanK(kmax, imax*jmax, message='Oz derivatives.')     ! :194-197
     end subroutine TLabMPI_Trp_Initialize
+
+    integer function mode_code(sRes, key) result(m)      ! TLAB_MPI_TRP_NONE .. _ALLTOALL (tlab_mpi_transpose.f90:29-33)
+        character(len=*), intent(in) :: sRes, key
+        integer, parameter :: DNS_ERROR_OPTION = 15
+        select case (trim(adjustl(sRes)))
+        case ('none'); m = 0
+        case ('asynchronous'); m = 1
+        case ('sendrecv'); m = 2
+        case ('alltoall'); m = 3
+        case default
+            m = -1
+            call TLab_Write_ASCII(efile, __FILE__//'. Wrong '//key//' option.')
+            call TLab_Stop(DNS_ERROR_OPTION)
+        end select
+    end function mode_code
 
     ! TLabMPI_Trp_PlanI(nmax, npage, ...)   tlab_mpi_transpose.f90:205-286
     function TLabMPI_Trp_PlanI(nmax, npage, message) result(trp_plan)
@@ -172,6 +222,8 @@ contains
             call TLab_AMD_Check(-1_c_int, 'TLabMPI_Transpose: decomposed direction but no RCCL communicator (call TLabMPI_Trp_AMD_Comm after TLabMPI_Initialize)')
         call TLab_AMD_Check(tlab_trp_plan_create(h, comm, int(trp_plan%dir, c_int), int(trp_plan%nmax, c_int), int(trp_plan%npage, c_int), &
                                                  int(e, c_int), 0_c_int, 1_c_int), 'tlab_trp_plan_create')
+        if (e == 1 .and. ((trp_plan%dir == 1 .and. trp_single_i) .or. (trp_plan%dir == 3 .and. trp_single_k))) &      ! [Parallel] TransposeType = single
+            call TLab_AMD_Check(tlab_trp_plan_set_wire(h, 1_c_int), 'tlab_trp_plan_set_wire')
         ncache = ncache + 1
         cache(ncache)%dir = trp_plan%dir; cache(ncache)%nmax = trp_plan%nmax; cache(ncache)%npage = trp_plan%npage; cache(ncache)%e = e
         cache(ncache)%h = h

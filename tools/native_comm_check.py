@@ -63,13 +63,40 @@ def local_b(G, dir, nlines, r):
     return G[r * nlines:(r + 1) * nlines, :, :] if dir == 1 else G[:, r * nlines:(r + 1) * nlines, :]
 
 
-def loopback(dir, nmax, npage, P, e):
+def f32(a):
+    """what TransposeType = single leaves of a field: every value rounded to single precision (tlab_mpi_transpose.f90:362-371)"""
+    return np.asarray(a, dtype=np.float64).astype(np.float32).astype(np.float64)
+
+
+def loopback(dir, nmax, npage, P, e, single=False):
     G = global_array(dir, nmax, npage, P, e, 7 * dir + P + e + nmax)
     nl = npage // P
     plans = [C.TrpPlan(None, dir, nmax, npage, e, r, P) for r in range(P)]
     n = plans[0].info(4)
     blk = plans[0].info(3)
     assert n == nmax * npage * e and blk * P == n and plans[0].info(0) == nl
+    if single:      # fp32 wire: the buffers hold npro blocks of floats; result = the transposition of the fp32-rounded field, bit for bit
+        for p in plans:
+            p.set_wire(True)
+            assert p.info(5) == 4
+        src, snd, rcv, dst = ([Dev(n) for _ in range(P)] for _ in range(4))
+        for fwd in (1, 0):
+            for r in range(P):
+                src[r].put(local_a(G, dir, nmax, r) if fwd else local_b(G, dir, nl, r))
+                plans[r].pack(fwd, src[r].ptr, snd[r].ptr)
+            wire = [snd[r].get().view(np.float32)[:n].reshape(P, blk) for r in range(P)]
+            for r in range(P):
+                w = np.zeros(n, dtype=np.float64)
+                w.view(np.float32)[:n] = np.stack([wire[q][r] for q in range(P)]).reshape(-1)
+                rcv[r].put(w)
+                plans[r].unpack(fwd, rcv[r].ptr, dst[r].ptr)
+                want = f32(local_b(G, dir, nl, r) if fwd else local_a(G, dir, nmax, r))
+                assert np.array_equal(dst[r].get(), np.ascontiguousarray(want).reshape(-1)), ("loopback fp32 wire", dir, nmax, npage, P, fwd, r)
+        for d in src + snd + rcv + dst:
+            d.free()
+        for p in plans:
+            p.close()
+        return
     src, snd, rcv, dst = ([Dev(n) for _ in range(P)] for _ in range(4))
     for fwd in (1, 0):
         for r in range(P):
@@ -132,6 +159,21 @@ def rccl(args):
             plan.wait()
             L.tlab_sync()
             assert np.array_equal(a2.get(), np.ascontiguousarray(local_a(G, dir, nmax, r)).reshape(-1)), ("rccl backward", dir, e, rank)
+            if e == 1:      # the same through the fp32 wire: forward = T(fp32(a)); backward of that result returns it unchanged (already fp32 values)
+                plan.set_wire(True)
+                plan.exec(1, a.ptr, b.ptr)
+                L.tlab_sync()
+                assert np.array_equal(b.get(), np.ascontiguousarray(f32(local_b(G, dir, nl, r))).reshape(-1)), ("rccl fp32 forward", dir, rank)
+                plan.start(0, b.ptr, a2.ptr)
+                plan.wait()
+                L.tlab_sync()
+                assert np.array_equal(a2.get(), np.ascontiguousarray(f32(local_a(G, dir, nmax, r))).reshape(-1)), ("rccl fp32 backward", dir, rank)
+            else:
+                try:
+                    plan.set_wire(True)
+                    raise AssertionError("complex plans must refuse the fp32 wire")
+                except C.TlabError:
+                    pass
             plan.close()
             for d in (a, b, a2):
                 d.free()
@@ -157,6 +199,8 @@ def main():
                     loopback(dir, nmax, npage, P, e)
         loopback(3, 8, 8 * 64, 8, 2)
         loopback(1, 64, 8 * 16, 8, 1)
+        for dir, nmax, npage, P in ((1, 24, 60, 3), (1, 17, 24, 2), (3, 10, 120, 4), (3, 7, 24, 1), (3, 8, 8 * 64, 8), (1, 64, 8 * 16, 8)):
+            loopback(dir, nmax, npage, P, 1, single=True)
     rccl(args)
     print("native comm ok (rank %d of %d)" % (args.rank, args.nranks))
 
