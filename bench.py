@@ -266,15 +266,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    backend = os.environ.get("TLAB_DIST_BACKEND", "nccl")      # gloo: functional runs with several ranks on one GPU (host-staged)
+    # Start-up of N > 1 ranks.  The product path moves its data through the RCCL inside libtlab_amd_comm.so (linked against /opt/rocm's librccl); torch
+    # bundles an RCCL of its own.  To keep ONE RCCL user in the process the torch.distributed group is a gloo (CPU) group by default: it carries the
+    # ncclUniqueId of the native communicator, the barriers and the max-over-ranks of the timing -- no payload.  TLAB_DIST_BOOTSTRAP=nccl restores the
+    # torch NCCL group (the Python fall-back driver needs one); TLAB_DIST_BACKEND=gloo is the functional mode with host-staged payloads (several ranks
+    # on one GPU), never a measurement.
+    backend = os.environ.get("TLAB_DIST_BACKEND", "nccl")      # transport of the payload: nccl (= RCCL) | gloo (functional, host-staged)
+    bootstrap = os.environ.get("TLAB_DIST_BOOTSTRAP", "gloo" if (args.slab_driver == "native" and not args.decomp) else "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+        bootstrap = backend
     torch.cuda.set_device(local_rank)
+    nccl_group = [None]
+
+    def torch_nccl_group():
+        """the torch NCCL group, made on first use (Python fall-back driver, pencil decomposition)"""
+        if bootstrap == "nccl":
+            return None      # the default group is it
+        if nccl_group[0] is None:
+            nccl_group[0] = dist.new_group(backend="nccl")
+        return nccl_group[0]
     if world > 1:
-        if backend == "nccl":
+        if bootstrap == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(bootstrap)
+    reduce_dev = "cuda" if (world > 1 and bootstrap == "nccl") else "cpu"      # where the small control reductions live
 
     import tlab_amd as T
     from tlab_amd.dns import Dns, RKM_EXP3
@@ -357,7 +374,7 @@ def main():
                       "scheme of tlab_amd/parallel.py" % (nz // world), file=sys.stderr)
             args.slab_driver = "python"
         def all_ranks_ok(flag):
-            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=reduce_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
 
@@ -366,16 +383,35 @@ def main():
             # The native driver's RCCL transport has only ever run with one rank per communicator (one GPU per test box): should its start-up or its
             # first substep fail on ANY rank, every rank falls back to the Python driver over torch.distributed (same algorithm, same kernels) and
             # the line says so -- a number from the slower driver beats no number.
+            # Two agreements, each BEFORE the step that could leave a peer blocked inside a grouped exchange: (1) every rank has built its driver and
+            # bound its arrays (no exchange has been enqueued yet); (2) the trial substep, which runs under a watchdog -- a rank whose peers never
+            # arrive (an ncclSend / ncclRecv error on one side only) would otherwise wait for ever instead of falling back: after 120 s the process
+            # exits non-zero, which takes the whole launch down instead of hanging it.
             err = None
             try:
                 d = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, **kw)
                 S = d.st[rank]
                 synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
-                d.substep_of_cycle(0, dtime)
-                torch.cuda.synchronize()
             except Exception as e:      # noqa: BLE001
                 err = e
-            if not all_ranks_ok(err is None):
+            built = all_ranks_ok(err is None)
+            if built:
+                import threading
+                done = threading.Event()
+
+                def watchdog():
+                    if not done.wait(120.0):
+                        print("bench.py rank %d: the trial substep of the native slab driver did not finish in 120 s (a peer failed inside an exchange?)" % rank,
+                              file=sys.stderr, flush=True)
+                        os._exit(3)
+                threading.Thread(target=watchdog, daemon=True).start()
+                try:
+                    d.substep_of_cycle(0, dtime)
+                    torch.cuda.synchronize()
+                except Exception as e:      # noqa: BLE001
+                    err = e
+                done.set()
+            if not built or not all_ranks_ok(err is None):
                 print("bench.py rank %d: native slab driver failed (%s); falling back to the Python driver" % (rank, err if err else "on another rank"), file=sys.stderr)
                 try:
                     if d is not None:
@@ -385,7 +421,7 @@ def main():
                 d = None
                 args.slab_driver = "python (native driver failed at start-up)"
         if d is None:
-            d = SlabDns(DistComm(), x, y, z, **kw)
+            d = SlabDns(DistComm(torch_nccl_group() if backend == "nccl" else None), x, y, z, **kw)
         S = d.st[rank]
         synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
         state_fields = S["q"] + S["s"]
@@ -410,7 +446,7 @@ def main():
     elapsed = time.perf_counter() - t0
     L.tlab_profile_enable(0)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = all(bool(torch.isfinite(t).all()) for t in state_fields)
@@ -475,7 +511,7 @@ def main():
                        "grid": [nx, ny, nz], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper (consistent wall closure)", "reynolds": 5000,
                        "parallelism": ("DIAGNOSTIC: x/z pencils %s (%s), I-/K-transpositions per x/z operator, Poisson on kx-pencils" % (args.decomp, "one block per GPU" if world > 1 else "all ranks back to back on one GPU, exchanges = copies")) if args.decomp else
                                       ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode, %s driver) executed back to back on one GPU, no communication" % (args.loopback, d.zmode, args.slab_driver)) if world == 1 else
-                       ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep in two pipelined halves), %s driver, %s" % (world, args.slab_driver, "RCCL" if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
+                       ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep in two pipelined halves), %s driver, %s" % (world, args.slab_driver, ("RCCL of libtlab_amd_comm.so (start-up over a %s group)" % bootstrap) if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
                        "fields_finite": finite},
             "roofline": None if dom is None else {
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

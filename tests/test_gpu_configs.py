@@ -154,8 +154,9 @@ def test_configs4_rank_share_fused_vs_literal_and_divergence(T):
 
 
 def test_configs3_eight_loopback_ranks_equal_single_domain(T):
-    """configs[3]: 1024 x 512 x 1024 over 8 ranks (z-slabs of 128 planes), every rank's work executed on this one GPU (LoopbackComm: only the
-    exchanges are copies), against the single-domain driver after one RK3 step; interior divergence of the slab result."""
+    """configs[3]: 1024 x 512 x 1024 over 8 ranks (z-slabs of 128 planes) through the native C++ slab driver, every rank's work executed on this one
+    GPU (loopback transport: only the exchanges are copies), against the single-domain driver after one RK3 step; interior divergence of the slab
+    result.  (The Python statement of the driver runs the same case bit-identically at smaller sizes: tests/test_gpu_slab_native.py.)"""
     import torch
     from tlab_amd.dns import Dns
     from tlab_amd.parallel import SlabDns, LoopbackComm
@@ -180,8 +181,10 @@ def test_configs3_eight_loopback_ranks_equal_single_domain(T):
     scat = [float((t - r).abs().max() / r.abs().max()) for t, r in zip(one.q + one.s, ref)]
     del one
     torch.cuda.empty_cache()
-    slab = SlabDns(LoopbackComm(P), x, y, z, **kw)
-    assert slab.zmode == "halo" and slab.kmax == 128
+    # the NATIVE driver (tlab_slab_dns_*, csrc/slab.cpp: the code a Fortran / MPI host runs) at the size of configs[3]
+    from tlab_amd.slab import NativeSlabDns
+    slab = NativeSlabDns("loopback", x, y, z, size=P, **kw)
+    assert slab.zmode == "halo" and slab.kmax == 128 and slab.stages == 2
     for i in range(3):
         slab.scatter("q", i, fields[i])
     slab.scatter("s", 0, fields[3])
@@ -196,7 +199,8 @@ def test_configs3_eight_loopback_ranks_equal_single_domain(T):
         assert bool(torch.isfinite(got).all())
         errs.append(float((got - rf).abs().max() / rf.abs().max()))
         del got
-    print("configs[3] loopback-8: one-ulp scatter", ["%.1e" % v for v in scat], "slabs vs single domain", ["%.1e" % v for v in errs])
+    slab.close()
+    print("configs[3] loopback-8 (native driver): one-ulp scatter", ["%.1e" % v for v in scat], "slabs vs single domain", ["%.1e" % v for v in errs])
     for i, (e, sc) in enumerate(zip(errs, scat)):
         assert e <= bound(sc), (i, e, sc)
     # the same box "x/z-decomposed" as BASELINE configs[3] words it: 2 x 4 blocks of 512 x 512 x 256 (tlab_amd/pencil.py: I-transpositions in

@@ -61,6 +61,21 @@ def test_native_slab_driver_over_rccl_world_size_one():
     assert "DIST_CHECK driver=native world=1" in out.stdout and "backend=nccl" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
 
 
+def test_native_slab_driver_over_rccl_with_a_gloo_start_up():
+    """bench.py's default start-up for N > 1: the torch.distributed group is gloo -- it carries the ncclUniqueId and the control
+    reductions -- so that the RCCL inside libtlab_amd_comm.so is the only RCCL in the process (torch's bundled copy is never initialised)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TLAB_DIST_BOOTSTRAP="gloo")
+    env.pop("TLAB_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29563", os.path.join(ROOT, "tools", "dist_check.py"), "--driver", "native", "--nz", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "DIST_CHECK driver=native world=1" in out.stdout and "backend=nccl bootstrap=gloo" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
+
+
 def test_rccl_operations_of_the_slab_driver():
     """DistComm on the RCCL backend with device buffers (what `bench.py --gpus N` uses).  The test box has one GPU, so one rank:
     every peer is the rank itself, but the calls, the grouped send/recv and the stream ordering are RCCL's.  Followed by the

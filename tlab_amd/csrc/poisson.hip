@@ -419,12 +419,15 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 // reference's order, no fused multiply-adds: right-hand side (MatMul_3d / MatMul_5d with BCS_BOTH, fdm_matmul.f90:70-121 / :267-320), substitution
 // (TRIDSS utils/linear3.f90:56-150 / HEPTADSS utils/linear7.f90:98-142), value at the free end and derivative at the given one (:265-311).
 // Nobody selects these schemes with the factorized solver: correctness first, every operand re-read where it is used.
-// optnone: at -O3 hipcc 7.2 miscompiles some instantiations of this kernel (the first version gave O(1) errors in the 7-diagonal substitution that
-// vanished when a printf was added; after a restructuring the FS_UNIT / NDI = 7 instantiations were still wrong while FS_LINEAR was bitwise right).
-// Unoptimised, every instantiation in use is bitwise equal to the oracle (tests/test_gpu_poisson.py, tlab_debug_int1_solve variants 0-2); nobody
-// selects these schemes with the factorized solver, so the kernel stays simple and slow rather than clever.
+// Compiled at -O3 like everything else since round 4.  Rounds 2-3 carried __attribute__((optnone)) here because "-O3 gave O(1) errors that vanished when a
+// printf was added".  Root cause (tools/repro/int1g_O3.hip, a stand-alone reduction: the same function body on host and device): hipcc 7.2's loop
+// unroller mis-transforms the two substitution loops below -- loops whose first three / last three iterations take other branches and whose
+// iterations communicate through memory -- at -O2 and -O3; -O1, -O0 and -fno-unroll-loops give the host's bits, the host replay is clean under
+// AddressSanitizer and UBSan (no undefined behaviour in the source), fences and volatile accesses change nothing.  `#pragma clang loop
+// unroll(disable)` on those two loops is the whole work-around; every instantiation in use is bitwise equal to the oracle at -O3
+// (tests/test_gpu_poisson.py, tlab_debug_int1_solve variants 0-2).
 template <int BC, int NL, int FS, int NDI>
-__global__ void __launch_bounds__(256) __attribute__((optnone)) k_int1g(Int1Args a) {
+__global__ void __launch_bounds__(256) k_int1g(Int1Args a) {
 #pragma clang fp contract(off)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.nm) return;
@@ -491,6 +494,7 @@ __global__ void __launch_bounds__(256) __attribute__((optnone)) k_int1g(Int1Args
         double *x = a.dst + (long long)l * n * nm + t;
         // ---- forward substitution (the rows before come back from memory: same thread, program order) ----
         auto Y = [&](int j) { return y[(long long)j * nm]; };
+#pragma clang loop unroll(disable)      // hipcc 7.2 miscompiles these two loops when its loop unroller peels them: tools/repro/int1g_O3.hip
         for (int m = 0; m < nmax; ++m) {
             const int j = m + 1;
             const double r = rhs_row(j);
@@ -507,6 +511,7 @@ __global__ void __launch_bounds__(256) __attribute__((optnone)) k_int1g(Int1Args
         }
         // ---- backward substitution ----
         auto XX = [&](int j) { return x[(long long)j * nm]; };
+#pragma clang loop unroll(disable)
         for (int m = nmax - 1; m >= 0; --m) {
             const int j = m + 1;
             const double yv = Y(j);

@@ -34,10 +34,11 @@ def main():
     backend = os.environ.get("TLAB_DIST_BACKEND", "nccl")
     dev = local % torch.cuda.device_count()
     torch.cuda.set_device(dev)
-    if backend == "nccl":
+    bootstrap = os.environ.get("TLAB_DIST_BOOTSTRAP", backend)      # gloo with backend nccl: torch.distributed carries the ncclUniqueId and the control
+    if bootstrap == "nccl":                                          # reductions only, the RCCL of libtlab_amd_comm.so is the only RCCL user (bench.py's default)
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(bootstrap)
     import tlab_amd as T
     from tlab_amd.dns import Dns
     from tlab_amd.parallel import SlabDns, DistComm
@@ -87,12 +88,12 @@ def main():
     smin, smax = slab.dilatation_bounds()
     worst = max(worst, abs(dmin - smin) / a1, abs(dmax - smax) / a1)      # a1 = max(|u_i|/h_i): the size of the terms of div(q)
     tt = torch.tensor([worst], dtype=torch.float64)
-    if backend == "nccl":
+    if bootstrap == "nccl":
         tt = tt.cuda()
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print("DIST_CHECK driver=%s world=%d zmode=%s backend=%s fused_x=%d worst_rel_err=%.3e %s" % (
-            args.driver, world, slab.zmode, backend, int(getattr(slab, "fused_x", False)), float(tt.item()), "OK" if float(tt.item()) <= 1e-11 else "FAIL"))
+        print("DIST_CHECK driver=%s world=%d zmode=%s backend=%s bootstrap=%s fused_x=%d worst_rel_err=%.3e %s" % (
+            args.driver, world, slab.zmode, backend, bootstrap, int(getattr(slab, "fused_x", False)), float(tt.item()), "OK" if float(tt.item()) <= 1e-11 else "FAIL"))
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if float(tt.item()) <= 1e-11 else 1)
