@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--nscal", type=int, default=1)
     ap.add_argument("--ystretch", action="store_true", help="diagnostic (single GPU): tanh-stretched y nodes (SURVEY 8d: y_j = (1 + tanh(2(2(j-1)/(ny-1) - 1))/tanh 2)/2, "
                     "the grid of BASELINE configs[4]) instead of the uniform ones of the headline: the second derivative then carries its Jacobian correction")
-    ap.add_argument("--walls", default="noslip", choices=["noslip", "freeslip"], help="diagnostic (single GPU): freeslip = the reference's default velocity walls "
+    ap.add_argument("--walls", default="noslip", choices=["noslip", "freeslip"], help="diagnostic (single GPU, or --loopback P): freeslip = the reference's default velocity walls "
                     "with Neumann scalars (BOUNDARY_BCS_NEUMANN_Y in the tail of the substep); the headline is noslip / Dirichlet")
     ap.add_argument("--loopback", type=int, default=0, help="diagnostic: run the z-slab algorithm of P ranks inside this one process/GPU "
                     "(no communication, ranks execute one after the other); reports the time of ALL ranks' work")
@@ -339,6 +339,8 @@ def main():
                 args.slab_driver = "python"
         if args.slab_driver != "native":
             d = SlabDns(LoopbackComm(args.loopback), x, y, z, **kw)
+        if args.walls == "freeslip":
+            d.set_bcs("freeslip", "freeslip", "neumann", "neumann")
         state_fields = []
         for r in range(args.loopback):
             S = d.st[r]

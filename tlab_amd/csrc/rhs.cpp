@@ -166,6 +166,18 @@ bool neumann_weights(tlab_dns *d, int ibc) {
 
 extern "C" {
 
+// the wall-plane weights of a Neumann variant for the other drivers of the library (slab.cpp): 1 and (w = [2][K] device weights, K) when available
+int tlab_internal_dns_neumann_weights(tlab_dns_t d, int ibc, const double **w, int *K) {
+    try {
+        if (!d || ibc < 1 || ibc > 3 || !neumann_weights(d, ibc)) return 0;
+        *w = d->neuw[ibc].w;
+        *K = d->neuw[ibc].K;
+        return 1;
+    } catch (...) {
+        return 0;
+    }
+}
+
 int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, tlab_poisson_plan_t poisson,
                     int nx, int ny, int nz, int nscal, double visc, const double *schmidt) {
     try {

@@ -42,7 +42,13 @@ int tlab_internal_zslab_gradient_final_z(tlab_zslab_plan_t P, int nx, int ny, co
 extern "C" bool tlab_internal_anelastic();       // capi.cpp: the operator state set by tlab_opr_burgers_set_anelastic / _set_dealiasing
 extern "C" bool tlab_internal_dealiasing();
 
+extern "C" int tlab_internal_dns_neumann_weights(tlab_dns_t d, int ibc, const double **w, int *K);      // rhs.cpp
+
 namespace tlab {
+hipError_t launch_wall_weighted(const double *a1, const double *a2, const double *wb, const double *wt, int K, double *ob1, double *ot1, double *ob2,
+                                double *ot2, int nx, int ny, int nz, hipStream_t st);                                      // pointwise.hip
+hipError_t launch_wall_fix(double *q, double *h, const double *sb, const double *st, double dte, double kco, int scale, int nx, int ny, int nz,
+                           hipStream_t stream);
 hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // pointwise.hip
 }
 
@@ -448,6 +454,8 @@ void refuse_unsupported_state(const char *who) {
         throw Fail(TLAB_EUNSUPPORTED, std::string(who) + ": dealiasing filters are not built into the z-slab driver (single-domain driver only)");
 }
 
+tlab_dns_t dns_handle(D *d, Rank &R);
+
 void poisson_pencil(D *d) {
     if (d->stages == 2) poisson_pencil_staged(d);
     else poisson_pencil_single(d);
@@ -471,10 +479,38 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     w = msg_start(d, 2 * (3 + ns));
     for (Rank &R : d->rk) badd_all(d, R, 2, false);
     twait(d, w);
-    // scalars with Dirichlet walls are finished by the z pass itself (TLAB_SLAB_FUSED_X=0: separate update, the Python driver's sequence)
+    // The reference's DEFAULT walls (free-slip u, w; Neumann scalars: boundary_bcs.f90:102-190) without a derivative pass per Neumann field, as in the
+    // single-domain driver (rhs.cpp): the wall tendency of BOUNDARY_BCS_NEUMANN_Y is a linear functional of the y line with weights that decay
+    // like the coupling of the compact system, so a field is finished with zero wall tendencies by the kernel that holds its last term (Dirichlet
+    // treatment), the weighted sums over the STORED tendencies next to the walls give the wall planes (k_wall_weighted) and k_wall_fix sets them.  All of
+    // it is local in y: no exchange.  TLAB_NEUMANN_PLANES=0 / TLAB_SLAB_FUSED_X=0 keep the derivative pass (the Python driver's sequence).
+    auto ibc_of = [](int tmin, int tmax) { return (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0); };
+    const char *npe = std::getenv("TLAB_NEUMANN_PLANES");
+    bool planes_route = tail && d->fused_x && !(npe && std::atoi(npe) == 0);
+    auto weights_of = [&](Rank &R, int ibc, const double *&w, int &K) { return tlab_internal_dns_neumann_weights(dns_handle(d, R), ibc, &w, &K) == 1; };
+    if (planes_route) {      // every Neumann variant in use needs its weights on every local rank
+        for (Rank &R : d->rk) {
+            const double *w;
+            int K;
+            for (int i = 0; i < 3; i += 2)
+                if (int ibc = ibc_of(d->flow_jmin[i], d->flow_jmax[i])) planes_route = planes_route && weights_of(R, ibc, w, K);
+            for (int i = 0; i < ns; ++i)
+                if (int ibc = ibc_of(d->scal_jmin[i], d->scal_jmax[i])) planes_route = planes_route && weights_of(R, ibc, w, K);
+        }
+    }
+    // wall planes of a field that was finished with zero wall tendencies
+    auto wall_fix = [&](Rank &R, double *q, double *h, int ibc) {
+        const double *w;
+        int K;
+        if (!weights_of(R, ibc, w, K)) throw Fail(TLAB_EINVAL, "internal: wall-plane weights vanished");
+        hk(tlab::launch_wall_weighted(h, nullptr, w, w + K, K, R.hb, R.ht, nullptr, nullptr, nx, ny, kmax, tlab_current_stream()), "k_wall_weighted");
+        hk(tlab::launch_wall_fix(q, h, (ibc & 1) ? R.hb : nullptr, (ibc & 2) ? R.ht : nullptr, tdte, kco, scale, nx, ny, kmax, tlab_current_stream()), "k_wall_fix");
+    };
+    // scalars are finished by the z pass itself: Dirichlet walls, or Neumann ones on the wall-plane route (TLAB_SLAB_FUSED_X=0: separate update, the
+    // Python driver's sequence)
     std::vector<int> zfin((size_t)(3 + ns), 0);
     for (int i = 0; i < ns; ++i)
-        zfin[3 + i] = tail && d->fused_x && d->scal_jmin[i] == TLAB_DNS_BCS_DIRICHLET && d->scal_jmax[i] == TLAB_DNS_BCS_DIRICHLET;
+        zfin[3 + i] = tail && d->fused_x && (ibc_of(d->scal_jmin[i], d->scal_jmax[i]) == 0 || planes_route);
     for (Rank &R : d->rk) zburgers_all(d, R, 2, &zfin, tdte, kco, scale);
     // ---- pressure forcing: div(hq + q/dte) (:188-260) ----
     const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (as rhs.cpp)
@@ -492,7 +528,7 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     bool vel_dirichlet = true, scal_dirichlet = true;
     for (int i = 0; i < 3; ++i) vel_dirichlet = vel_dirichlet && dirichlet(d->flow_jmin[i]) && dirichlet(d->flow_jmax[i]);
     for (int i = 0; i < ns; ++i) scal_dirichlet = scal_dirichlet && dirichlet(d->scal_jmin[i]) && dirichlet(d->scal_jmax[i]);
-    const bool grad_final = tail && vel_dirichlet;
+    const bool grad_final = tail && (vel_dirichlet || planes_route);      // (v is always Dirichlet: tlab_slab_dns_set_bcs)
     const bool v_final = grad_final && d->fused_x && !d->gy_elliptic;      // v is finished by the inverse x-transform of dp^/dy
     d->vf.armed = v_final; d->vf.dte = tdte; d->vf.kco = kco; d->vf.scale = scale;
     poisson_pencil(d);
@@ -507,7 +543,7 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
         for (int i = 0; i < 3; ++i) F.push_back({R.q[i], R.hq[i], R.txc[1 + i], d->flow_jmin[i], d->flow_jmax[i]});
         for (int i = 0; i < ns; ++i)
             if (!zfin[3 + i]) F.push_back({R.s[i], R.hs[i], nullptr, d->scal_jmin[i], d->scal_jmax[i]});
-        if (grad_final) F.erase(F.begin() + 2), F.erase(F.begin());          // v and the scalars; u, w are done
+        if (grad_final) F.erase(F.begin() + 2), F.erase(F.begin());          // v and the scalars; u, w are done (+ their wall planes below)
         if (v_final) F.erase(F.begin());                                     // the scalars
         if (!grad_final && (!vel_dirichlet || !tail)) {
             ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
@@ -524,8 +560,10 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     };
     w = halo_start(d, 1, [&](Rank &R, int) { return Slot{R.txc[0], S_P}; });
     if (grad_final) {   // u and w are finished by the gradient kernels themselves (no gradient array)
-        for (Rank &R : d->rk)
+        for (Rank &R : d->rk) {
             ok(tlab_opr_gradient_final(1, d->g[0], nx, ny, kmax, R.txc[0], R.q[0], R.hq[0], tdte, kco, scale, R.txc[1]), "tlab_opr_gradient_final");
+            if (int ibc = ibc_of(d->flow_jmin[0], d->flow_jmax[0])) wall_fix(R, R.q[0], R.hq[0], ibc);
+        }
     } else {
         for (Rank &R : d->rk) padd(d, R, 1, R.txc[0], nullptr, 0.0, R.txc[1], 0);
     }
@@ -534,7 +572,9 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     w = msg_start(d, 1);
     // v and the scalars do not wait for dp/dz: their update runs while the interface values travel (not with Neumann scalars, whose boundary
     // routine takes tmp1 = p as scratch)
-    const bool early_finish = grad_final && scal_dirichlet;
+    bool needs_bcs_routine = false;      // a field left for `finish` with a Neumann wall: BOUNDARY_BCS_NEUMANN_Y, which takes tmp1 = p as scratch
+    for (int i = 0; i < ns; ++i) needs_bcs_routine = needs_bcs_routine || (!zfin[3 + i] && ibc_of(d->scal_jmin[i], d->scal_jmax[i]) != 0);
+    const bool early_finish = grad_final && (scal_dirichlet || !needs_bcs_routine);
     if (early_finish)
         for (Rank &R : d->rk) finish(R);
     twait(d, w);
@@ -543,12 +583,18 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
             const double *ph[2] = {R.lo[S_P], R.hi[S_P]};
             ok(tlab_internal_zslab_gradient_final_z(R.zplan, nx, ny, R.txc[0], ph, R.tail_left, R.head_right, R.q[2], R.hq[2], tdte, kco, scale),
                "tlab_zslab_gradient_final_z");
+            if (int ibc = ibc_of(d->flow_jmin[2], d->flow_jmax[2])) wall_fix(R, R.q[2], R.hq[2], ibc);
         }
     } else {
         for (Rank &R : d->rk) zpartial(d, R, 2, R.txc[0], S_P, nullptr, 0, 0.0, R.txc[3], 0);
     }
     if (!early_finish)
         for (Rank &R : d->rk) finish(R);
+    // Neumann scalars the z pass finished: their wall planes
+    for (int i = 0; i < ns; ++i)
+        if (zfin[3 + i])
+            if (int ibc = ibc_of(d->scal_jmin[i], d->scal_jmax[i]))
+                for (Rank &R : d->rk) wall_fix(R, R.s[i], R.hs[i], ibc);
 }
 
 tlab_dns_t dns_handle(D *d, Rank &R) {
