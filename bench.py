@@ -272,7 +272,7 @@ def main():
     # torch NCCL group (the Python fall-back driver needs one); TLAB_DIST_BACKEND=gloo is the functional mode with host-staged payloads (several ranks
     # on one GPU), never a measurement.
     backend = os.environ.get("TLAB_DIST_BACKEND", "nccl")      # transport of the payload: nccl (= RCCL) | gloo (functional, host-staged)
-    bootstrap = os.environ.get("TLAB_DIST_BOOTSTRAP", "gloo" if (args.slab_driver == "native" and not args.decomp) else "nccl")
+    bootstrap = os.environ.get("TLAB_DIST_BOOTSTRAP", "gloo" if args.slab_driver == "native" else "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
         bootstrap = backend
@@ -310,19 +310,24 @@ def main():
     HYPER_BC1_EXT = 0.0
     L = load()
     if args.decomp:
-        from tlab_amd.pencil import PencilDns, loopback_comms, dist_comms
+        from tlab_amd.pencil import PencilDns, NativePencilDns, loopback_comms, dist_comms
         npi, npk = (int(v) for v in args.decomp.lower().split("x"))
         if world > 1 and world != npi * npk:
             raise SystemExit("--decomp IxK needs --gpus I*K (or one process for the loopback)")
-        d = PencilDns(dist_comms(npi, npk) if world > 1 else loopback_comms(npi, npk), npi, npk, x, y, z, nscal=args.nscal, visc=1.0 / 5000.0,
-                      schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
+        pkw = dict(nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=True, rkm_mode=RKM_EXP3, hyper_bc1_ext=HYPER_BC1_EXT)
+        if args.slab_driver == "native":      # the C++ driver behind tlab_pencil_dns_* (csrc/pencil.cpp)
+            d = NativePencilDns("rccl" if world > 1 else "loopback", npi, npk, x, y, z, **pkw)
+            pranks = d.local_ranks
+        else:
+            d = PencilDns(dist_comms(npi, npk) if world > 1 else loopback_comms(npi, npk), npi, npk, x, y, z, **pkw)
+            pranks = d.world.local_ranks
         state_fields = []
         full = [torch.empty(nx * ny * nz, dtype=torch.float64, device="cuda") for _ in range(3 + args.nscal)]
         synthetic_fields(full, nx, ny, nz, 0, nz, 0)
         for i, f in enumerate(full):
             d.scatter("q" if i < 3 else "s", i if i < 3 else i - 3, f)
         del full
-        for r in d.world.local_ranks:
+        for r in pranks:
             state_fields += d.st[r]["q"] + d.st[r]["s"]
 
         def substep(k):
@@ -511,7 +516,7 @@ def main():
             "config": {"workload": "%dx%dx%d incompressible box, %d scalar, full RHS (12+3ns OPR_Burgers, 5 OPR_Partial, OPR_Poisson FourierXZ) + RK3 update per substep"
                                    % (nx, ny, nz, args.nscal),
                        "grid": [nx, ny, nz], "n_scalars": args.nscal, "schemes": "CompactJacobian6 / CompactJacobian6Hyper (consistent wall closure)", "reynolds": 5000,
-                       "parallelism": ("DIAGNOSTIC: x/z pencils %s (%s), I-/K-transpositions per x/z operator, Poisson on kx-pencils" % (args.decomp, "one block per GPU" if world > 1 else "all ranks back to back on one GPU, exchanges = copies")) if args.decomp else
+                       "parallelism": ("DIAGNOSTIC: x/z pencils %s (%s, %s driver), I-/K-transpositions per x/z operator, Poisson on kx-pencils" % (args.decomp, "one block per GPU" if world > 1 else "all ranks back to back on one GPU, exchanges = copies", args.slab_driver)) if args.decomp else
                                       ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode, %s driver) executed back to back on one GPU, no communication" % (args.loopback, d.zmode, args.slab_driver)) if world == 1 else
                        ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep in two pipelined halves), %s driver, %s" % (world, args.slab_driver, ("RCCL of libtlab_amd_comm.so (start-up over a %s group)" % bootstrap) if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
                        "fields_finite": finite},

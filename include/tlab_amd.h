@@ -420,6 +420,43 @@ typedef struct tlab_slab_transport {
 } tlab_slab_transport;
 int tlab_slab_transport_loopback(tlab_slab_transport *out, int nranks);
 
+/* ---- x/z pencils: ims_npro_i x ims_npro_k blocks (base/tlab_mpi_procs.f90:76-94), the reference's own scheme ---------------------------------
+ * Every x operator through an I-transposition inside ims_comm_x (operators/opr_partial.f90:66-147, physics/opr_burgers.f90:216-262), every z operator
+ * through a K-transposition inside ims_comm_z (opr_partial.f90:185-253, opr_burgers.f90:386-426), the operator sequence of
+ * tools/dns/rhs_global_incompressible_1.f90:98-398 with its transposed-velocity reuse, the Poisson solver on kx-pencils over all ranks.
+ * Exchanges = MPI_Alltoallv inside one of three communicators, supplied by the caller like tlab_slab_transport:
+ *   which = 0: all ranks (world order); 1: ims_comm_x of the local rank (members by ims_pro_i); 2: ims_comm_z (members by ims_pro_k).
+ *   send[l] holds the blocks for the members back to back, scount[l*size + j] doubles each; recv[l] / rcount likewise by source.
+ * Implementations: tlab_pencil_transport_loopback (all ranks in this process, exchanges = device copies), tlab_comm_pencil_transport
+ * (libtlab_amd_comm.so: grouped ncclSend / ncclRecv inside the RCCL communicators of tlab_comm_init), or the host's GPU-aware MPI. */
+typedef struct tlab_pencil_transport {
+    void *ctx;
+    int npro_i, npro_k;   /* ims_npro_i, ims_npro_k                                                 */
+    int nlocal, first;    /* world ranks this process executes: [first, first + nlocal)             */
+    int (*alltoallv_start)(void *ctx, void *stream, int which, double *const *send, const long long *scount, double *const *recv,
+                           const long long *rcount);                                                /* returns a ticket >= 0 or a TLAB_E* code */
+    int (*wait)(void *ctx, void *stream, int ticket);
+    int (*allreduce)(void *ctx, double *values, int n, int op);                                     /* as tlab_slab_transport                  */
+    void (*destroy)(void *ctx);                                                                     /* may be NULL                             */
+} tlab_pencil_transport;
+int tlab_pencil_transport_loopback(tlab_pencil_transport *out, int npro_i, int npro_k);
+
+typedef struct tlab_pencil_dns *tlab_pencil_dns_t;
+/* gx, gz: the plans of the GLOBAL x and z directions (nx, nz_total nodes), gy the y plan.  Conditions of the reference's decomposition: nx, nz
+ * divisible by npro_i, npro_k; imax even; npro_i divides kmax; imax*jmax divisible by npro_k; at least one kx mode per rank.  The transport context
+ * passes to the driver on success only.  Same supported subset as tlab_slab_dns_create (anelastic / dealiasing refused); the driver ADDS to the
+ * tendencies like the reference: call tlab_pencil_dns_begin_step (hq = hs = 0) at the start of every Runge-Kutta step. */
+int tlab_pencil_dns_create(tlab_pencil_dns_t *out, const tlab_pencil_transport *transport, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
+                           int nx, int ny, int nz_total, int nscal, double visc, const double *schmidt);
+int tlab_pencil_dns_destroy(tlab_pencil_dns_t d);
+/* q[3], s[nscal], hq[3], hs[nscal] of imax*jmax*kmax doubles, txc[9] of tlab_pencil_dns_info(d, 3) doubles each, for local rank l */
+int tlab_pencil_dns_bind(tlab_pencil_dns_t d, int l, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc);
+long long tlab_pencil_dns_info(tlab_pencil_dns_t d, int what);   /* 0 imax, 1 kmax, 2 kmax / npro_i, 3 doubles of a txc array, 4 nlocal, 5 first local rank */
+int tlab_pencil_dns_set_bcs(tlab_pencil_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
+int tlab_pencil_dns_begin_step(tlab_pencil_dns_t d);
+int tlab_pencil_dns_rhs(tlab_pencil_dns_t d, double dte);                                    /* RHS_GLOBAL_INCOMPRESSIBLE_1 */
+int tlab_pencil_dns_substep(tlab_pencil_dns_t d, double dte, double kco, int scale_tendencies);   /* + the update loops of time.f90:645-664, :272-297 */
+
 typedef struct tlab_slab_dns *tlab_slab_dns_t;
 /* gx, gy: the local plans; gz: the plan of the GLOBAL z direction (nz_total nodes).  kmax = nz_total / nranks planes per rank; returns
  * TLAB_EUNSUPPORTED when the slabs are too thin for the partitioned z-systems (kmax <~ 50: tlab_zslab_plan_create) -- such runs keep the

@@ -44,6 +44,8 @@ int tlab_comm_allreduce_max(tlab_comm_t comm, double *dev_values, int n);
  * all-to-all-v as grouped ncclSend / ncclRecv on the library's communication stream, MPI_MAX / MPI_MIN as ncclAllReduce.  Needs npro_i = 1.
  * The struct refers to comm, which must outlive the driver made from it. */
 int tlab_comm_slab_transport(tlab_comm_t comm, tlab_slab_transport *out);
+/* ... and of the native x/z pencil driver (tlab_pencil_dns_create): MPI_Alltoallv inside the world / ims_comm_x / ims_comm_z communicators. */
+int tlab_comm_pencil_transport(tlab_comm_t comm, tlab_pencil_transport *out);
 
 /* TLabMPI_Trp_PlanI (dir = 1) / TLabMPI_Trp_PlanK (dir = 3)   base/tlab_mpi_transpose.f90:205-286, 290-339
  *   dir = 1: nmax = imax, npage = jmax*kmax:  local a(imax, npage)  <->  b(imax*npro_i, nlines), nlines = npage / npro_i

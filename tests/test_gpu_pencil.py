@@ -88,3 +88,59 @@ def test_pencil_layout_is_refused_where_the_reference_refuses(T):
     x, y, z = grids(32, 16, 12)
     with pytest.raises(T.TlabError):
         PencilDns(loopback_comms(4, 2), 4, 2, x, y, z)          # kmax = 6 is not a multiple of npro_i = 4
+
+
+@pytest.mark.parametrize("npi,npk,nx,ny,nz,bcs,ns", [(2, 2, 32, 24, 16, "noslip", 1), (2, 4, 32, 16, 32, "freeslip", 2), (4, 2, 64, 16, 16, "noslip", 1),
+                                                      (8, 1, 64, 8, 16, "noslip", 0), (1, 4, 32, 16, 16, "freeslip", 1), (4, 4, 64, 16, 32, "noslip", 1)])
+def test_native_pencil_driver_is_bit_identical_to_the_python_driver(T, npi, npk, nx, ny, nz, bcs, ns):
+    """tlab_pencil_dns_* (tlab_amd/csrc/pencil.cpp: what a Fortran / MPI host calls) against tlab_amd/pencil.py::PencilDns, both on loopback ranks:
+    the same library calls on the same numbers in the same order, the transpositions and the three all-to-alls as native index work -> every field
+    of every rank equal to the bit after a full Runge-Kutta step (three substeps incl. the tendency scaling and the step-start zeroing)."""
+    import torch
+    from tlab_amd.pencil import PencilDns, NativePencilDns, loopback_comms
+    x, y, z = grids(nx, ny, nz)
+    rng = np.random.default_rng(100 * npi + npk)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    fields = [((np.sin(X + k) * np.cos(2 * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3 + ns)]
+    kw = dict(nscal=ns, visc=1.0 / 300.0, schmidt=(0.7, 1.3)[:ns], yuniform=False, hyper_bc1_ext=REF_HYPER)
+    py = PencilDns(loopback_comms(npi, npk), npi, npk, x, y, z, **kw)
+    nat = NativePencilDns("loopback", npi, npk, x, y, z, **kw)
+    assert (nat.imax, nat.kmax, nat.kmax2, nat.isize_txc) == (py.imax, py.kmax, py.kmax2, py.isize_txc)
+    if bcs == "freeslip":
+        py.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+        nat.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
+    for d in (py, nat):
+        for i in range(3 + ns):
+            d.scatter("q" if i < 3 else "s", i if i < 3 else i - 3, torch.from_numpy(fields[i]).cuda())
+    for k in range(4):
+        py.substep_of_cycle(k, 2e-3)
+        nat.substep_of_cycle(k, 2e-3)
+    torch.cuda.synchronize()
+    for name in ("q", "s", "hq", "hs"):
+        for r in range(npi * npk):
+            for a, b in zip(py.st[r][name], nat.st[r][name]):
+                assert float(b.abs().max()) > 0.0 and torch.equal(a, b), (name, r)
+    nat.close()
+
+
+def test_native_pencil_driver_refusals(T):
+    from tlab_amd.pencil import NativePencilDns
+    x, y, z = grids(32, 16, 12)
+    with pytest.raises(T.TlabError, match="npro_i must divide kmax"):
+        NativePencilDns("loopback", 4, 2, x, y, z)
+    x, y, z = grids(32, 16, 16)
+    nat = NativePencilDns("loopback", 2, 2, x, y, z)
+    nat.close()
+    import ctypes
+    from tlab_amd.lib import load, c_vp
+    from tlab_amd.pencil import PencilTransport
+    L = load()
+    g = [T.FdmPlan(x, True, True), T.FdmPlan(y, False, False), T.FdmPlan(z, True, True)]
+    tr = PencilTransport()
+    assert L.tlab_pencil_transport_loopback(ctypes.byref(tr), 2, 2) == 0
+    h = c_vp(0)
+    one = (ctypes.c_double * 1)(1.0)
+    assert L.tlab_pencil_dns_create(ctypes.byref(h), ctypes.byref(tr), g[0]._h, g[1]._h, g[2]._h, 32, 16, 16, 1, 1e-3, one) == 0
+    assert L.tlab_pencil_dns_substep(h, 1e-3, 1.0, 0) != 0 and b"bound" in L.tlab_last_error()
+    assert L.tlab_pencil_dns_destroy(h) == 0

@@ -150,6 +150,70 @@ def test_native_driver_with_the_direct_schemes_is_bit_identical(T):
                 assert float(b.abs().max()) > 0.0 and torch.equal(a, b), (name, r)
 
 
+@pytest.mark.parametrize("walls", [("freeslip", "freeslip", "neumann", "dirichlet"), ("freeslip", "noslip", "neumann", "neumann")])
+def test_native_driver_default_walls_on_the_wall_plane_route(T, walls, monkeypatch):
+    """The reference's default walls (free-slip u, w; Neumann scalars) in the slab driver WITHOUT a derivative pass per Neumann field: the fields are
+    finished with zero wall tendencies by the kernels that hold their last term and k_wall_weighted + k_wall_fix set the wall planes (local in y, no
+    exchange).  Against the derivative-pass route (TLAB_NEUMANN_PLANES=0) and the single domain, within the composed-path bound; the route must
+    actually have been taken (k_wall_weighted launches in the library's profile)."""
+    import ctypes
+    import torch
+    from tlab_amd.dns import Dns
+    from tlab_amd.lib import load
+    from tlab_amd.slab import NativeSlabDns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    from tlab_amd.dns import velocity_bcs
+    L = load()
+    P, nx, ny, nz = 2, 128, 64, 128
+    x, y, z = _grid(nx, ny, nz)
+    f = _fields(x, y, z, 29)
+    visc, sc = 1.0 / 600.0, (0.8,)
+    kw = dict(nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    one = Dns(x, y, z, **kw)
+    one.set_bcs(*walls)
+    runs = {}
+    for tag, env in (("planes", None), ("derivative", "0")):
+        if env is None:
+            monkeypatch.delenv("TLAB_NEUMANN_PLANES", raising=False)
+        else:
+            monkeypatch.setenv("TLAB_NEUMANN_PLANES", env)
+        nat = NativeSlabDns("loopback", x, y, z, size=P, fused_x=True, **kw)
+        nat.set_bcs(*walls)
+        for i in range(4):
+            nat.scatter("q" if i < 3 else "s", i if i < 3 else 0, torch.from_numpy(f[i]).cuda())
+        L.tlab_profile_reset(); L.tlab_profile_enable(1)
+        for k in range(2):
+            nat.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(2e-3 * one.kdt[k], one.kco[k], True)
+        torch.cuda.synchronize()
+        L.tlab_profile_enable(0)
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.tlab_profile_report(buf, len(buf))
+        took = b"k_wall_weighted" in buf.value
+        assert took == (tag == "planes"), (tag, buf.value.decode()[:400])
+        runs[tag] = {name: [torch.cat([nat.st[r][name][i] for r in range(P)]) for i in range(len(nat.st[0][name]))] for name in ("q", "hq", "s", "hs")}
+        nat.close()
+    monkeypatch.delenv("TLAB_NEUMANN_PLANES", raising=False)
+    for i in range(4):
+        (one.q[i] if i < 3 else one.s[0]).copy_(torch.from_numpy(f[i]).cuda())
+    for k in range(2):
+        one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(2e-3 * one.kdt[k], one.kco[k], True)
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        o.flow_jmin, o.flow_jmax = velocity_bcs(walls[0]), velocity_bcs(walls[1])
+        o.scal_jmin, o.scal_jmax = [4 if walls[2] == "neumann" else 3], [4 if walls[3] == "neumann" else 3]
+        return o
+    B, S = substep_scatter(make_oracle, f[:3], f[3:4], [(2e-3 * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=2)
+    for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
+        for i, rf in enumerate(ref):
+            tol = bound(S[1][name][i])
+            ob = torch.from_numpy(B[1][name][i]).cuda()
+            for tag in ("planes", "derivative"):
+                got = runs[tag][name][i]
+                assert float((got - rf).abs().max() / rf.abs().max()) <= tol, (tag, "vs single domain", name, i)
+                assert float((got - ob).abs().max() / ob.abs().max()) <= tol, (tag, "vs oracle", name, i)
+
+
 def test_native_driver_refuses_what_it_does_not_build(T):
     """A decomposed run must integrate the same equations as the same tlab.ini on one rank, or stop: with the anelastic operator state
     on, the z-slab driver refuses to be created and refuses to run -- TLAB_EUNSUPPORTED with a message, nothing silently dropped."""

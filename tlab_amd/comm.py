@@ -17,6 +17,7 @@ SIGNATURES = {
     "tlab_comm_info": (c_int, [c_vp, c_int]),
     "tlab_comm_allreduce_max": (c_int, [c_vp, c_vp, c_int]),
     "tlab_comm_slab_transport": (c_int, [c_vp, c_vp]),
+    "tlab_comm_pencil_transport": (c_int, [c_vp, c_vp]),
     "tlab_trp_plan_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
     "tlab_trp_plan_destroy": (c_int, [c_vp]),
     "tlab_trp_plan_info": (c_int, [c_vp, c_int]),

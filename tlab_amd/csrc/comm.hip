@@ -257,6 +257,57 @@ int tlab_comm_slab_transport(tlab_comm_t c, tlab_slab_transport *out) {
     return TLAB_OK;
 }
 
+// ---- tlab_pencil_transport over RCCL (include/tlab_amd.h: the exchanges of the native x/z pencil driver, csrc/pencil.cpp) ------------------------------
+// MPI_Alltoallv inside the world, ims_comm_x or ims_comm_z communicator as one grouped ncclSend / ncclRecv on the communication stream, ordered against
+// the caller's stream by events like the slab transport (same tickets, same wait).
+namespace {
+int pencil_alltoallv_start(void *ctx, void *stream, int which, double *const *send, const long long *scount, double *const *recv, const long long *rcount) {
+    try {
+        tlab_comm *c = static_cast<tlab_comm *>(ctx);
+        ncclComm_t nc = which == 0 ? c->world : (which == 1 ? c->cx : c->cz);
+        const int S = which == 0 ? c->nranks : (which == 1 ? c->npro_i : c->npro_k);
+        const int me = which == 0 ? c->rank : (which == 1 ? c->pro_i : c->pro_k);
+        if (which < 0 || which > 2) throw Fail{TLAB_EINVAL, "pencil transport: communicator 0 (world), 1 (x) or 2 (z)"};
+        const int t = slab_begin(c, (hipStream_t)stream);
+        long long so = 0, ro = 0, my_so = 0, my_ro = 0;
+        ncclResult_t r = ncclSuccess, e = ncclSuccess;
+        if (S > 1) {
+            if (!nc) throw Fail{TLAB_EINVAL, "pencil transport: no communicator for this direction"};
+            ncc(ncclGroupStart(), "ncclGroupStart");
+        }
+        for (int q = 0; q < S; ++q) {
+            if (q == me) { my_so = so; my_ro = ro; }
+            else if (r == ncclSuccess) {
+                if (scount[q] > 0) r = ncclSend(send[0] + so, (size_t)scount[q], ncclDouble, q, nc, c->stream);
+                if (r == ncclSuccess && rcount[q] > 0) r = ncclRecv(recv[0] + ro, (size_t)rcount[q], ncclDouble, q, nc, c->stream);
+            }
+            so += scount[q];
+            ro += rcount[q];
+        }
+        if (S > 1) e = ncclGroupEnd();
+        ncc(r, "ncclSend / ncclRecv (pencil all-to-all)");
+        ncc(e, "ncclGroupEnd");
+        if (scount[me] != rcount[me]) throw Fail{TLAB_EINVAL, "pencil transport: own block sizes differ"};
+        if (scount[me] > 0)
+            hipc(hipMemcpyAsync(recv[0] + my_ro, send[0] + my_so, (size_t)scount[me] * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync (own block)");
+        hipc(hipEventRecord(c->ev_done[t], c->stream), "hipEventRecord");
+        return t;
+    } catch (const Fail &f) {
+        tlab_set_error(f.msg);
+        return f.code;
+    }
+}
+}  // namespace
+
+int tlab_comm_pencil_transport(tlab_comm_t c, tlab_pencil_transport *out) {
+    if (!c || !out) { tlab_set_error("tlab_comm_pencil_transport: null argument"); return TLAB_EINVAL; }
+    out->ctx = c;
+    out->npro_i = c->npro_i; out->npro_k = c->npro_k; out->nlocal = 1; out->first = c->rank;
+    out->alltoallv_start = pencil_alltoallv_start; out->wait = slab_wait; out->allreduce = slab_allreduce;
+    out->destroy = nullptr;       // the communicator stays the caller's (tlab_comm_destroy)
+    return TLAB_OK;
+}
+
 int tlab_comm_get_unique_id(void *id_bytes) {
     try {
         if (!id_bytes) throw Fail{TLAB_EINVAL, "tlab_comm_get_unique_id: null buffer"};

@@ -1,0 +1,514 @@
+// tlab_pencil_dns_* : RHS_GLOBAL_INCOMPRESSIBLE_1 + TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT on ims_npro_i x ims_npro_k blocks (x/z pencils), behind the C ABI.
+//
+// The reference's own scheme for a 2-D decomposition (base/tlab_mpi_procs.f90:76-94): every x operator goes through an I-transposition inside
+// ims_comm_x (operators/opr_partial.f90:66-86, :133-147; physics/opr_burgers.f90:216-262), every z operator through a K-transposition inside
+// ims_comm_z (opr_partial.f90:185-253; opr_burgers.f90:386-426), y is never split; the operator sequence and the reuse of the transposed velocities
+// are those of tools/dns/rhs_global_incompressible_1.f90:98-375.  The Poisson solver works on the 1 x (npro_i npro_k) z-slabs the I-transposition
+// leaves and on kx-pencils over ALL ranks (one all-to-all after the x transform, one back per output; operators/opr_fourier.f90:232-262 does the
+// same through its own transpositions).
+//
+// This is the C++ port of tlab_amd/pencil.py::PencilDns (the Python statement stays as the cross-check: the two are bit-identical on loopback
+// ranks, tests/test_gpu_pencil.py) so that a Fortran / MPI host can call it: host cost per rank and substep < 1 ms instead of ~7 ms.
+// Exchanges go through a transport struct of four entry points (tlab_pencil_transport): RCCL (libtlab_amd_comm.so: tlab_comm_pencil_transport), the
+// single-process loopback (every rank on one device, exchanges = device copies), or the caller's GPU-aware MPI_Alltoallv.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tlab_amd.h"
+
+extern hipStream_t tlab_current_stream();
+extern void tlab_set_error(const std::string &s);
+extern bool tlab_device_ready();
+extern "C" bool tlab_internal_anelastic();
+extern "C" bool tlab_internal_dealiasing();
+
+namespace tlab {
+hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // pointwise.hip
+hipError_t launch_trp_copy(double *S, double *W, long long m, int P, long long c, int to_wire, hipStream_t st);
+}
+
+namespace {
+
+struct Fail : std::runtime_error {
+    int code;
+    Fail(int c, const std::string &s) : std::runtime_error(s), code(c) {}
+};
+void ok(int rc, const char *what) {
+    if (rc != TLAB_OK) throw Fail(rc, std::string(what) + ": " + tlab_last_error());
+}
+void hk(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Fail(TLAB_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+double *dalloc(size_t n) {
+    double *p = nullptr;
+    hk(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(double)), "hipMalloc");
+    hk(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(double), tlab_current_stream()), "hipMemset");
+    return p;
+}
+
+// ---- loopback transport: all npro_i x npro_k ranks in this process ----------------------------------------------------------------------------
+struct Loopback {
+    int npi, npk;
+};
+// members of communicator `which` of world rank r, in member order (tlab_mpi_procs.f90:76-94: ims_pro_i = mod(ims_pro, npro_i), ims_pro_k = ims_pro / npro_i)
+void members(int npi, int npk, int which, int r, std::vector<int> &m) {
+    m.clear();
+    const int pi = r % npi, pk = r / npi;
+    if (which == 0) for (int q = 0; q < npi * npk; ++q) m.push_back(q);
+    else if (which == 1) for (int q = 0; q < npi; ++q) m.push_back(pk * npi + q);
+    else for (int q = 0; q < npk; ++q) m.push_back(q * npi + pi);
+}
+int lb_a2a(void *ctx, void *stream, int which, double *const *send, const long long *scount, double *const *recv, const long long *rcount) {
+    const Loopback *L = static_cast<Loopback *>(ctx);
+    const int P = L->npi * L->npk;
+    std::vector<const double *> sp;
+    std::vector<double *> dp;
+    std::vector<long long> cn;
+    std::vector<int> mem, mem2;
+    for (int dst = 0; dst < P; ++dst) {
+        members(L->npi, L->npk, which, dst, mem);
+        const int S = (int)mem.size();
+        int me = 0;
+        for (int j = 0; j < S; ++j) if (mem[j] == dst) me = j;
+        long long ro = 0;
+        for (int j = 0; j < S; ++j) {      // block j of dst's receive buffer comes from member j: its block for member `me`
+            const int src = mem[j];
+            long long so = 0;
+            for (int p = 0; p < me; ++p) so += scount[(size_t)src * S + p];
+            const long long cnt = scount[(size_t)src * S + me];
+            if (cnt != rcount[(size_t)dst * S + j]) return TLAB_EINVAL;
+            if (cnt > 0) { sp.push_back(send[src] + so); dp.push_back(recv[dst] + ro); cn.push_back(cnt); }
+            ro += cnt;
+        }
+    }
+    return tlab::launch_copy_blocks((int)sp.size(), sp.data(), dp.data(), cn.data(), (hipStream_t)stream) == hipSuccess ? 0 : TLAB_EHIP;
+}
+int lb_wait(void *, void *, int) { return TLAB_OK; }
+int lb_allreduce(void *ctx, double *v, int n, int op) {
+    const Loopback *L = static_cast<Loopback *>(ctx);
+    const int P = L->npi * L->npk;
+    for (int i = 0; i < n; ++i) {
+        double a = v[i];
+        for (int r = 1; r < P; ++r) a = op == 0 ? std::max(a, v[r * n + i]) : std::min(a, v[r * n + i]);
+        for (int r = 0; r < P; ++r) v[r * n + i] = a;
+    }
+    return TLAB_OK;
+}
+void lb_destroy(void *ctx) { delete static_cast<Loopback *>(ctx); }
+
+struct Rank {
+    int r = 0, pi = 0, pk = 0;
+    tlab_poisson_plan_t poisson = nullptr;
+    double *hb = nullptr, *ht = nullptr, *rt = nullptr, *u_t = nullptr, *w_t = nullptr, *ta = nullptr, *tb = nullptr, *wire = nullptr;
+    double *pen[3] = {nullptr, nullptr, nullptr}, *pack[2] = {nullptr, nullptr};
+    std::vector<double *> q, s, hq, hs, txc;
+    bool bound = false;
+};
+
+}  // namespace
+
+struct tlab_pencil_dns {
+    tlab_pencil_transport tr{};
+    tlab_fdm_plan_t g[3] = {nullptr, nullptr, nullptr};
+    int npi = 1, npk = 1, P = 1, nx = 0, ny = 0, nzt = 0, imax = 0, kmax = 0, kmax2 = 0, nxh = 0, nscal = 0;
+    long long n = 0, npage_i = 0, nlx = 0, npage_k = 0, nlz = 0, isize_txc = 0;
+    double visc = 0.0;
+    std::vector<double> schmidt;
+    std::vector<int> nxl, ioff;
+    int flow_jmin[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
+    int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
+    std::vector<int> scal_jmin, scal_jmax;
+    bool fresh = false;
+    std::vector<Rank> rk;
+    ~tlab_pencil_dns() {
+        for (Rank &R : rk) {
+            if (R.poisson) (void)tlab_poisson_plan_destroy(R.poisson);
+            for (double *p : {R.hb, R.ht, R.rt, R.u_t, R.w_t, R.ta, R.tb, R.wire, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1]})
+                if (p) (void)hipFree(p);
+        }
+        if (tr.destroy && tr.ctx) tr.destroy(tr.ctx);
+    }
+};
+
+namespace {
+using D = tlab_pencil_dns;
+
+void tck(int t, const char *what) {
+    if (t < 0) throw Fail(t, std::string("pencil transport: ") + what + " failed");
+}
+
+// equal-block all-to-all inside communicator `which` (1: x, 2: z): buffer sel(R) of every local rank, blk doubles per member
+template <class FS, class FR>
+void a2a_equal(D *d, int which, long long blk, FS send_of, FR recv_of) {
+    const int S = which == 1 ? d->npi : d->npk;
+    std::vector<double *> send, recv;
+    std::vector<long long> cnt((size_t)d->rk.size() * S, blk);
+    for (Rank &R : d->rk) { send.push_back(send_of(R)); recv.push_back(recv_of(R)); }
+    const int t = d->tr.alltoallv_start(d->tr.ctx, (void *)tlab_current_stream(), which, send.data(), cnt.data(), recv.data(), cnt.data());
+    tck(t, "alltoallv_start");
+    tck(d->tr.wait(d->tr.ctx, (void *)tlab_current_stream(), t), "wait");
+}
+void trp_copy(double *S, double *W, long long m, int P, long long c, int to_wire) {
+    hk(tlab::launch_trp_copy(S, W, m, P, c, to_wire, tlab_current_stream()), "k_trp_copy");
+}
+// TLabMPI_Trp_ExecI_Forward (tlab_mpi_transpose.f90:232-256): a(imax, npage) -> b(imax npro_i, nlines); src / dst: per-rank selectors
+template <class FA, class FB>
+void trp_i_forward(D *d, FA a_of, FB b_of) {
+    const long long blk = d->nlx * d->imax;
+    a2a_equal(d, 1, blk, a_of, [](Rank &R) { return R.wire; });                                    // a is blocked by peer as it stands
+    for (Rank &R : d->rk) trp_copy(b_of(R), R.wire, d->imax, d->npi, d->nlx, 0);                   // b[line][src][x] = wire[src][line][x]
+}
+template <class FB, class FA>
+void trp_i_backward(D *d, FB b_of, FA a_of) {
+    const long long blk = d->nlx * d->imax;
+    for (Rank &R : d->rk) trp_copy(b_of(R), R.wire, d->imax, d->npi, d->nlx, 1);
+    a2a_equal(d, 1, blk, [](Rank &R) { return R.wire; }, a_of);
+}
+// TLabMPI_Trp_ExecK_Forward (:301-325): a(npage, kmax) -> b(nlines, kmax npro_k)
+template <class FA, class FB>
+void trp_k_forward(D *d, FA a_of, FB b_of) {
+    const long long blk = d->nlz * d->kmax;
+    for (Rank &R : d->rk) trp_copy(a_of(R), R.wire, d->nlz, d->npk, d->kmax, 1);                    // wire[peer][k][line] = a[k][peer nl + line]
+    a2a_equal(d, 2, blk, [](Rank &R) { return R.wire; }, b_of);
+}
+template <class FB, class FA>
+void trp_k_backward(D *d, FB b_of, FA a_of) {
+    const long long blk = d->nlz * d->kmax;
+    a2a_equal(d, 2, blk, b_of, [](Rank &R) { return R.wire; });
+    for (Rank &R : d->rk) trp_copy(a_of(R), R.wire, d->nlz, d->npk, d->kmax, 0);
+}
+
+void burgers(D *d, int dir, int ivel, int nx, int ny, int nz, double nu, const double *s, const double *u, double *res, double *tmp) {
+    ok(tlab_opr_burgers(dir, d->g[dir - 1], ivel, nx, ny, nz, 0, nu, s, u, res, tmp, 0), "tlab_opr_burgers");
+}
+void partial(D *d, int dir, int nx, int ny, int nz, const double *u, double *res) {
+    ok(tlab_opr_partial(dir, d->g[dir - 1], TLAB_OPR_P1, nx, ny, nz, 0, u, res, nullptr), "tlab_opr_partial");
+}
+
+// OPR_Burgers_X (dir = 1) / OPR_Burgers_Z (dir = 3) through the I- / K-transposition; self_vel: the operand is the advecting velocity, whose
+// transposed copy is kept for the later calls (rhs_global_incompressible_1.f90:98-104: tmp4 / tmp6)
+template <class FS>
+void burgers_t(D *d, int dir, double nu, FS s_of, int res_idx, bool self_vel) {
+    const int csize = dir == 1 ? d->npi : d->npk;
+    if (csize == 1) {       // not decomposed in this direction
+        for (Rank &R : d->rk) burgers(d, dir, self_vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, d->imax, d->ny, d->kmax, nu, s_of(R), R.q[dir - 1], R.txc[res_idx], R.txc[8]);
+        return;
+    }
+    auto vel = [&](Rank &R) -> double *& { return dir == 1 ? R.u_t : R.w_t; };
+    if (dir == 1) trp_i_forward(d, s_of, [&](Rank &R) { return self_vel ? R.u_t : R.ta; });
+    else trp_k_forward(d, s_of, [&](Rank &R) { return self_vel ? R.w_t : R.ta; });
+    for (Rank &R : d->rk) {
+        const double *st = self_vel ? vel(R) : R.ta;
+        if (dir == 1) burgers(d, 1, self_vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, d->nx, (int)d->nlx, 1, nu, st, vel(R), R.rt, R.txc[8]);
+        else burgers(d, 3, self_vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, (int)d->nlz, 1, d->nzt, nu, st, vel(R), R.rt, R.txc[8]);
+    }
+    if (dir == 1) trp_i_backward(d, [](Rank &R) { return R.rt; }, [&](Rank &R) { return R.txc[res_idx]; });
+    else trp_k_backward(d, [](Rank &R) { return R.rt; }, [&](Rank &R) { return R.txc[res_idx]; });
+}
+// OPR_Partial_X / _Z (OPR_P1) through the transposition (opr_partial.f90:117-136, :185-195)
+void partial_t(D *d, int dir, int src_idx, int dst_idx) {
+    const int csize = dir == 1 ? d->npi : d->npk;
+    if (csize == 1) {
+        for (Rank &R : d->rk) partial(d, dir, d->imax, d->ny, d->kmax, R.txc[src_idx], R.txc[dst_idx]);
+        return;
+    }
+    if (dir == 1) trp_i_forward(d, [&](Rank &R) { return R.txc[src_idx]; }, [](Rank &R) { return R.ta; });
+    else trp_k_forward(d, [&](Rank &R) { return R.txc[src_idx]; }, [](Rank &R) { return R.ta; });
+    for (Rank &R : d->rk) {
+        if (dir == 1) partial(d, 1, d->nx, (int)d->nlx, 1, R.ta, R.rt);
+        else partial(d, 3, (int)d->nlz, 1, d->nzt, R.ta, R.rt);
+    }
+    if (dir == 1) trp_i_backward(d, [](Rank &R) { return R.rt; }, [&](Rank &R) { return R.txc[dst_idx]; });
+    else trp_k_backward(d, [](Rank &R) { return R.rt; }, [&](Rank &R) { return R.txc[dst_idx]; });
+}
+
+// block txc[idx] (imax, ny, kmax) <-> z-slab (nx, ny, kmax2) of the rank, in place of txc[idx]
+void to_slab(D *d, int idx) {
+    if (d->npi == 1) return;
+    trp_i_forward(d, [&](Rank &R) { return R.txc[idx]; }, [](Rank &R) { return R.tb; });
+    for (Rank &R : d->rk) hk(hipMemcpyAsync(R.txc[idx], R.tb, (size_t)d->n * sizeof(double), hipMemcpyDeviceToDevice, tlab_current_stream()), "copy");
+}
+void to_block(D *d, int idx) {
+    if (d->npi == 1) return;
+    trp_i_backward(d, [&](Rank &R) { return R.txc[idx]; }, [](Rank &R) { return R.tb; });
+    for (Rank &R : d->rk) hk(hipMemcpyAsync(R.txc[idx], R.tb, (size_t)d->n * sizeof(double), hipMemcpyDeviceToDevice, tlab_current_stream()), "copy");
+}
+void pencil_exchange(D *d, bool forward, int pen_idx, int pack_idx) {
+    const int P = d->P;
+    std::vector<double *> send, recv;
+    std::vector<long long> scnt((size_t)d->rk.size() * P), rcnt((size_t)d->rk.size() * P);
+    for (size_t l = 0; l < d->rk.size(); ++l) {
+        Rank &R = d->rk[l];
+        for (int p = 0; p < P; ++p) {
+            const long long mine = 2LL * d->nxl[R.r] * d->ny * d->kmax2, peer = 2LL * d->nxl[p] * d->ny * d->kmax2;
+            scnt[l * P + p] = forward ? peer : mine;
+            rcnt[l * P + p] = forward ? mine : peer;
+        }
+        send.push_back(forward ? R.pack[pack_idx] : R.pen[pen_idx]);
+        recv.push_back(forward ? R.pen[pen_idx] : R.pack[pack_idx]);
+    }
+    const int t = d->tr.alltoallv_start(d->tr.ctx, (void *)tlab_current_stream(), 0, send.data(), scnt.data(), recv.data(), rcnt.data());
+    tck(t, "alltoallv_start");
+    tck(d->tr.wait(d->tr.ctx, (void *)tlab_current_stream(), t), "wait");
+}
+void repack(D *d, Rank &R, double *slab, int pack_idx, int dir) {
+    const int P = d->P;
+    if (P <= 8) {
+        ok(tlab_pencil_repack(slab, R.pack[pack_idx], d->nxh, d->ny, d->kmax2, P, d->ioff.data(), dir), "tlab_pencil_repack");
+        return;
+    }
+    std::vector<long long> base((size_t)P);
+    long long off = 0;
+    for (int p = 0; p < P; ++p) { base[p] = off; off += (long long)d->nxl[p] * d->ny * d->kmax2; }
+    ok(tlab_pencil_repack_blocks(slab, R.pack[pack_idx], d->nxh, d->ny, d->kmax2, P, d->ioff.data(), base.data(), dir), "tlab_pencil_repack_blocks");
+}
+
+// OPR_Poisson(.., BCS_NN, ..): forcing in tmp1 (txc[0]), Neumann data in hb / ht; p -> tmp1, dp/dy -> tmp3 (txc[2])
+void poisson(D *d) {
+    for (Rank &R : d->rk)      // the Neumann data travel in the wall rows of the forcing (opr_elliptic.f90:310-311)
+        ok(tlab_pw_set_wall_planes(R.txc[0], R.hb, R.ht, d->imax, d->ny, d->kmax), "tlab_pw_set_wall_planes");
+    to_slab(d, 0);
+    for (Rank &R : d->rk) {
+        ok(tlab_poisson_fft_x(R.poisson, 1, R.txc[0], R.txc[1]), "tlab_poisson_fft_x");
+        repack(d, R, R.txc[1], 0, 1);
+    }
+    pencil_exchange(d, true, 0, 0);
+    for (Rank &R : d->rk) {
+        ok(tlab_poisson_fft_z(R.poisson, 1, R.pen[0], R.pen[1]), "tlab_poisson_fft_z");
+        ok(tlab_poisson_ode(R.poisson, R.pen[1], R.pen[1], R.pen[2]), "tlab_poisson_ode");
+        ok(tlab_poisson_fft_z(R.poisson, -1, R.pen[1], R.pen[0]), "tlab_poisson_fft_z");
+        ok(tlab_poisson_fft_z(R.poisson, -1, R.pen[2], R.pen[1]), "tlab_poisson_fft_z");
+    }
+    const int dst_of[2] = {0, 2};
+    for (int i = 0; i < 2; ++i) {
+        pencil_exchange(d, false, i, 0);
+        for (Rank &R : d->rk) {
+            repack(d, R, R.txc[1], 0, -1);
+            ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[1], R.txc[dst_of[i]]), "tlab_poisson_fft_x");
+        }
+        to_block(d, dst_of[i]);
+    }
+}
+
+void need_bound(D *d) {
+    for (Rank &R : d->rk)
+        if (!R.bound) throw Fail(TLAB_EINVAL, "tlab_pencil_dns: the arrays of every local rank must be bound first (tlab_pencil_dns_bind)");
+}
+
+// tools/dns/rhs_global_incompressible_1.f90:98-398
+void rhs(D *d, double dte) {
+    need_bound(d);
+    if (tlab_internal_anelastic() || tlab_internal_dealiasing())
+        throw Fail(TLAB_EUNSUPPORTED, "tlab_pencil_dns_rhs: the anelastic formulation / dealiasing filters are not built into the decomposed drivers");
+    const int nx = d->imax, ny = d->ny, kmax = d->kmax, ns = d->nscal;
+    const long long n = d->n;
+    const double nu = d->visc;
+    d->fresh = false;      // (this driver follows the reference literally: the tendencies are added to arrays the caller zeroed, time.f90:212-216)
+    auto U = [](int i) { return [i](Rank &R) { return R.q[i]; }; };
+    auto burgers_y = [&](int ivel, double nu_, auto s_of, int res_idx) {
+        for (Rank &R : d->rk) burgers(d, 2, ivel, nx, ny, kmax, nu_, s_of(R), R.q[1], R.txc[res_idx], R.txc[8]);
+    };
+    auto add3 = [&](auto h_of, int a, int b, int c) {
+        for (Rank &R : d->rk) ok(tlab_pw_add3(h_of(R), R.txc[a], R.txc[b], R.txc[c], n), "tlab_pw_add3");
+    };
+    burgers_t(d, 1, nu, U(0), 0, true);                    // :98   tmp1, u transposed kept
+    burgers_y(TLAB_OPR_B_SELF, nu, U(1), 1);               // :99
+    burgers_t(d, 3, nu, U(2), 2, true);                    // :100  tmp3, w transposed kept
+    burgers_y(TLAB_OPR_B_U_IN, nu, U(0), 6);               // :103
+    burgers_t(d, 3, nu, U(0), 7, false);                   // :104
+    add3([](Rank &R) { return R.hq[0]; }, 0, 6, 7);
+    burgers_t(d, 1, nu, U(1), 6, false);                   // :115
+    burgers_t(d, 3, nu, U(1), 7, false);                   // :116
+    add3([](Rank &R) { return R.hq[1]; }, 1, 6, 7);
+    burgers_t(d, 1, nu, U(2), 6, false);                   // :127
+    burgers_y(TLAB_OPR_B_U_IN, nu, U(2), 7);               // :128
+    add3([](Rank &R) { return R.hq[2]; }, 2, 6, 7);
+    for (int i = 0; i < ns; ++i) {                         // :149-162
+        const double kap = d->visc / d->schmidt[i];
+        auto sc = [i](Rank &R) { return R.s[i]; };
+        burgers_t(d, 1, kap, sc, 0, false);
+        burgers_y(TLAB_OPR_B_U_IN, kap, sc, 1);
+        burgers_t(d, 3, kap, sc, 2, false);
+        add3([i](Rank &R) { return R.hs[i]; }, 0, 1, 2);
+    }
+    // pressure (:188-260)
+    for (Rank &R : d->rk)
+        ok(tlab_pw_axpy3(R.txc[1], R.txc[2], R.txc[3], R.hq[1], R.hq[0], R.hq[2], R.q[1], R.q[0], R.q[2], 1.0 / dte, n), "tlab_pw_axpy3");
+    for (Rank &R : d->rk) partial(d, 2, nx, ny, kmax, R.txc[1], R.txc[0]);      // :228
+    partial_t(d, 1, 2, 1);                                                        // :229
+    partial_t(d, 3, 3, 2);                                                        // :230
+    for (Rank &R : d->rk) ok(tlab_pw_sum3(R.txc[0], R.txc[1], R.txc[2], n), "tlab_pw_sum3");
+    for (Rank &R : d->rk) ok(tlab_pw_get_wall_planes(R.hq[1], R.hb, R.ht, nx, ny, kmax), "tlab_pw_get_wall_planes");
+    poisson(d);                                                                   // :284
+    partial_t(d, 1, 0, 1);                                                        // :319
+    partial_t(d, 3, 0, 3);                                                        // :320
+    for (Rank &R : d->rk) ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
+    // boundary conditions (:360-398); y is never split, BOUNDARY_BCS_NEUMANN_Y needs no communication
+    for (Rank &R : d->rk) {
+        auto walls = [&](double *h, int tmin, int tmax) {
+            const int ibc = (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0);
+            if (ibc) ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, h, R.hb, R.ht, R.txc[0]), "tlab_boundary_bcs_neumann_y");
+            ok(tlab_pw_set_wall_planes(h, (ibc & 1) ? R.hb : nullptr, (ibc & 2) ? R.ht : nullptr, nx, ny, kmax), "tlab_pw_set_wall_planes");
+        };
+        for (int i = 0; i < 3; ++i) walls(R.hq[i], d->flow_jmin[i], d->flow_jmax[i]);
+        for (int i = 0; i < ns; ++i) walls(R.hs[i], d->scal_jmin[i], d->scal_jmax[i]);
+    }
+}
+
+template <class F>
+int guarded(F f) {
+    try {
+        if (!tlab_device_ready()) throw Fail(TLAB_EHIP, "tlab_init has not been called (no CPU fallback exists)");
+        f();
+        return TLAB_OK;
+    } catch (const Fail &e) {
+        tlab_set_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tlab_pencil_transport_loopback(tlab_pencil_transport *out, int npro_i, int npro_k) {
+    if (!out || npro_i < 1 || npro_k < 1) { tlab_set_error("tlab_pencil_transport_loopback: bad arguments"); return TLAB_EINVAL; }
+    out->ctx = new Loopback{npro_i, npro_k};
+    out->npro_i = npro_i; out->npro_k = npro_k; out->nlocal = npro_i * npro_k; out->first = 0;
+    out->alltoallv_start = lb_a2a; out->wait = lb_wait; out->allreduce = lb_allreduce; out->destroy = lb_destroy;
+    return TLAB_OK;
+}
+
+int tlab_pencil_dns_create(tlab_pencil_dns_t *out, const tlab_pencil_transport *tr, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz, int nx,
+                           int ny, int nz_total, int nscal, double visc, const double *schmidt) {
+    return guarded([&] {
+        if (!out || !tr || !gx || !gy || !gz || nscal < 0 || (nscal > 0 && !schmidt) || visc <= 0.0) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_create: bad arguments");
+        if (!tr->alltoallv_start || !tr->wait || !tr->allreduce) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_create: incomplete transport");
+        const int npi = tr->npro_i, npk = tr->npro_k, P = npi * npk;
+        if (npi < 1 || npk < 1 || tr->nlocal < 1 || tr->first < 0 || tr->first + tr->nlocal > P) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_create: rank layout");
+        // the conditions of the reference's decomposition, checked before anything is allocated
+        if (nx % npi || nz_total % npk) throw Fail(TLAB_EINVAL, "nx, nz must be divisible by npro_i, npro_k");
+        const int imax = nx / npi, kmax = nz_total / npk;
+        if (imax % 2) throw Fail(TLAB_EINVAL, "imax must be even (opr_fourier.f90:73-76)");
+        if (kmax % npi) throw Fail(TLAB_EINVAL, "npro_i must divide kmax: the x lines of a rank after the I-transposition form whole z planes");
+        if (((long long)imax * ny) % npk) throw Fail(TLAB_EINVAL, "imax*jmax must be divisible by npro_k (tlab_mpi_transpose.f90:292)");
+        if ((nx / 2 + 1) / P < 1) throw Fail(TLAB_EINVAL, "fewer kx modes than ranks");
+        if (P > 16) throw Fail(TLAB_EUNSUPPORTED, "tlab_pencil_dns_create: at most 16 ranks (one node)");
+        if (tlab_internal_anelastic() || tlab_internal_dealiasing())
+            throw Fail(TLAB_EUNSUPPORTED, "tlab_pencil_dns_create: the anelastic formulation / dealiasing filters are not built into the decomposed drivers");
+        auto d = std::make_unique<tlab_pencil_dns>();
+        d->g[0] = gx; d->g[1] = gy; d->g[2] = gz;
+        d->npi = npi; d->npk = npk; d->P = P; d->nx = nx; d->ny = ny; d->nzt = nz_total; d->imax = imax; d->kmax = kmax; d->kmax2 = kmax / npi;
+        d->nxh = nx / 2 + 1; d->nscal = nscal; d->visc = visc;
+        d->n = (long long)imax * ny * kmax;
+        d->npage_i = (long long)ny * kmax; d->nlx = (long long)ny * d->kmax2;
+        d->npage_k = (long long)imax * ny; d->nlz = d->npage_k / npk;
+        d->isize_txc = (long long)(nx + 2) * ny * d->kmax2;
+        if (nscal) d->schmidt.assign(schmidt, schmidt + nscal);
+        d->scal_jmin.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
+        d->scal_jmax.assign(nscal, TLAB_DNS_BCS_DIRICHLET);
+        const int base = d->nxh / P, rem = d->nxh % P;
+        for (int r = 0; r < P; ++r) { d->nxl.push_back(base + (r < rem ? 1 : 0)); d->ioff.push_back(r * base + std::min(r, rem)); }
+        d->rk.resize(tr->nlocal);
+        for (int l = 0; l < tr->nlocal; ++l) {
+            Rank &R = d->rk[l];
+            R.r = tr->first + l; R.pi = R.r % npi; R.pk = R.r / npi;
+            ok(tlab_poisson_plan_create_pencil(&R.poisson, gx, gy, gz, nx, ny, d->kmax2, nz_total, d->ioff[R.r], d->nxl[R.r]), "tlab_poisson_plan_create_pencil");
+            R.hb = dalloc((size_t)imax * kmax); R.ht = dalloc((size_t)imax * kmax);
+            for (double **p : {&R.rt, &R.u_t, &R.w_t, &R.ta, &R.tb, &R.wire}) *p = dalloc((size_t)d->n);
+            for (int i = 0; i < 3; ++i) R.pen[i] = dalloc((size_t)2 * d->nxl[R.r] * ny * nz_total);
+            for (int i = 0; i < 2; ++i) R.pack[i] = dalloc((size_t)2 * d->nxh * ny * d->kmax2);
+        }
+        d->tr = *tr;      // ownership of the transport context passes here, on success only
+        *out = d.release();
+    });
+}
+
+int tlab_pencil_dns_destroy(tlab_pencil_dns_t d) {
+    if (d) (void)hipDeviceSynchronize();
+    delete d;
+    return TLAB_OK;
+}
+
+int tlab_pencil_dns_bind(tlab_pencil_dns_t d, int l, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc) {
+    return guarded([&] {
+        if (!d || l < 0 || l >= (int)d->rk.size() || !q || !hq || !txc || (d->nscal > 0 && (!s || !hs))) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_bind: bad arguments");
+        Rank &R = d->rk[l];
+        R.q.assign(q, q + 3); R.hq.assign(hq, hq + 3); R.txc.assign(txc, txc + 9);
+        R.s.assign(s, s + d->nscal); R.hs.assign(hs, hs + d->nscal);
+        for (double *p : R.q) if (!p) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_bind: null array");
+        for (double *p : R.hq) if (!p) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_bind: null array");
+        for (double *p : R.txc) if (!p) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_bind: null array");
+        R.bound = true;
+    });
+}
+
+long long tlab_pencil_dns_info(tlab_pencil_dns_t d, int what) {
+    if (!d) return TLAB_EINVAL;
+    switch (what) {
+    case 0: return d->imax;
+    case 1: return d->kmax;
+    case 2: return d->kmax2;
+    case 3: return d->isize_txc;
+    case 4: return (long long)d->rk.size();
+    case 5: return d->rk.empty() ? 0 : d->rk[0].r;
+    }
+    return TLAB_EINVAL;
+}
+
+int tlab_pencil_dns_set_bcs(tlab_pencil_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax) {
+    return guarded([&] {
+        if (!d || !flow_jmin || !flow_jmax || (d->nscal > 0 && (!scal_jmin || !scal_jmax))) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_set_bcs: bad arguments");
+        auto valid = [](int t) { return t == TLAB_DNS_BCS_DIRICHLET || t == TLAB_DNS_BCS_NEUMANN; };
+        for (int i = 0; i < 3; ++i)
+            if (!valid(flow_jmin[i]) || !valid(flow_jmax[i])) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_set_bcs: type must be DNS_BCS_DIRICHLET or DNS_BCS_NEUMANN");
+        for (int i = 0; i < d->nscal; ++i)
+            if (!valid(scal_jmin[i]) || !valid(scal_jmax[i])) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_set_bcs: type must be DNS_BCS_DIRICHLET or DNS_BCS_NEUMANN");
+        if (flow_jmin[1] != TLAB_DNS_BCS_DIRICHLET || flow_jmax[1] != TLAB_DNS_BCS_DIRICHLET)
+            throw Fail(TLAB_EUNSUPPORTED, "tlab_pencil_dns_set_bcs: the wall-normal velocity must be Dirichlet (impermeable walls; the pressure BCs assume v = 0)");
+        for (int i = 0; i < 3; ++i) { d->flow_jmin[i] = flow_jmin[i]; d->flow_jmax[i] = flow_jmax[i]; }
+        for (int i = 0; i < d->nscal; ++i) { d->scal_jmin[i] = scal_jmin[i]; d->scal_jmax[i] = scal_jmax[i]; }
+    });
+}
+
+// hq = hs = 0 of TIME_RUNGEKUTTA (time.f90:212-216): this driver adds to the tendencies like the reference, so the start of a step zeroes them
+int tlab_pencil_dns_begin_step(tlab_pencil_dns_t d) {
+    return guarded([&] {
+        if (!d) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_begin_step: null handle");
+        need_bound(d);
+        for (Rank &R : d->rk) {
+            for (double *h : R.hq) ok(tlab_pw_fill(h, 0.0, d->n), "tlab_pw_fill");
+            for (double *h : R.hs) ok(tlab_pw_fill(h, 0.0, d->n), "tlab_pw_fill");
+        }
+    });
+}
+
+int tlab_pencil_dns_rhs(tlab_pencil_dns_t d, double dte) {
+    return guarded([&] {
+        if (!d || !(dte > 0.0)) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_rhs: bad arguments");
+        rhs(d, dte);
+    });
+}
+
+int tlab_pencil_dns_substep(tlab_pencil_dns_t d, double dte, double kco, int scale_tendencies) {
+    return guarded([&] {
+        if (!d || !(dte > 0.0)) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_substep: bad arguments");
+        rhs(d, dte);
+        for (Rank &R : d->rk) {      // time.f90:645-664, :272-297
+            for (int i = 0; i < 3; ++i) ok(tlab_pw_rk_update(R.q[i], R.hq[i], dte, kco, scale_tendencies, d->n), "tlab_pw_rk_update");
+            for (int i = 0; i < d->nscal; ++i) ok(tlab_pw_rk_update(R.s[i], R.hs[i], dte, kco, scale_tendencies, d->n), "tlab_pw_rk_update");
+        }
+    });
+}
+
+}  // extern "C"

@@ -3,6 +3,8 @@
 // All are streaming kernels with 16-B accesses per lane, grid-strided over at most 2048 workgroups.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "profile.hpp"
 
@@ -463,6 +465,36 @@ __global__ void __launch_bounds__(256) k_sub2(double *__restrict__ o, const doub
 }
 hipError_t launch_sub2(double *o, const double *a, const double *b, long long n, hipStream_t st) {
     hipLaunchKernelGGL(k_sub2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, o, a, b, n);
+    return CHECK_LAUNCH();
+}
+
+// The one strided copy of an I- / K-transposition (TLabMPI_Trp_Exec*, base/tlab_mpi_transpose.f90:232-256, :301-325): strided array S and wire format W
+//     S[(q m + r) + (m P) o]   <->   W[q (m c) + r + m o]        q = peer < P, r < m, o < c          (to_wire: W = S, else S = W)
+// (the same kernel as k_trp_copy of comm.hip, here for the native pencil driver of the operator library: bit-exact index work)
+template <int VEC>
+__global__ void __launch_bounds__(256) k_trp_copy_core(double *__restrict__ S, double *__restrict__ W, long long m, int P, long long c, int to_wire) {
+    const long long mv = m / VEC, total = mv * c * P, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long r = i % mv, o = (i / mv) % c, q = i / (mv * c);
+        const long long s = (q * mv + r) + (mv * P) * o;
+        if (VEC == 2) {
+            double2 *S2 = reinterpret_cast<double2 *>(S), *W2 = reinterpret_cast<double2 *>(W);
+            if (to_wire) W2[i] = S2[s];
+            else S2[s] = W2[i];
+        } else {
+            if (to_wire) W[i] = S[s];
+            else S[s] = W[i];
+        }
+    }
+}
+hipError_t launch_trp_copy(double *S, double *W, long long m, int P, long long c, int to_wire, hipStream_t st) {
+    const long long total = m * c * P;
+    const bool vec = (m % 2 == 0) && ((((size_t)S) | ((size_t)W)) % 16 == 0);
+    const long long work = vec ? total / 2 : total;
+    const int grid = (int)std::min<long long>(4096, std::max<long long>(1, (work + 255) / 256));
+    ProfScope ps("k_trp_copy", st, (double)total * 16.0);
+    if (vec) hipLaunchKernelGGL(k_trp_copy_core<2>, dim3(grid), dim3(256), 0, st, S, W, m, P, c, to_wire);
+    else hipLaunchKernelGGL(k_trp_copy_core<1>, dim3(grid), dim3(256), 0, st, S, W, m, P, c, to_wire);
     return CHECK_LAUNCH();
 }
 

@@ -367,3 +367,127 @@ class PencilDns:
                 load().tlab_poisson_plan_destroy(S["poisson"])
         except Exception:
             pass
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------
+# The NATIVE driver (tlab_pencil_dns_*, tlab_amd/csrc/pencil.cpp): the C++ port of PencilDns behind the C ABI -- what a Fortran / MPI host calls.
+# ---------------------------------------------------------------------------------------------------------------------------------------------------
+_PA2A_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, ctypes.c_int, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(c_vp),
+                            ctypes.POINTER(ctypes.c_longlong))
+_PWAIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, ctypes.c_int)
+_PRED_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int)
+_PDESTROY_FN = ctypes.CFUNCTYPE(None, c_vp)
+
+
+class PencilTransport(ctypes.Structure):
+    """struct tlab_pencil_transport"""
+    _fields_ = [("ctx", c_vp), ("npro_i", ctypes.c_int), ("npro_k", ctypes.c_int), ("nlocal", ctypes.c_int), ("first", ctypes.c_int),
+                ("alltoallv_start", _PA2A_FN), ("wait", _PWAIT_FN), ("allreduce", _PRED_FN), ("destroy", _PDESTROY_FN)]
+
+
+class NativePencilDns:
+    """tlab_pencil_dns_* with the interface of PencilDns (st[rank][name][i] tensors, scatter, gather_local, substep_of_cycle).
+    transport: "loopback" (all npro_i x npro_k ranks in this process) or "rccl" (torch.distributed initialised, one rank per process: the
+    ncclUniqueId of the library's own communicators travels through the group's object broadcast)."""
+
+    def __init__(self, transport, npro_i, npro_k, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, rkm_mode=RKM_EXP3,
+                 hyper_bc1_ext=0.0, device="cuda", group=None):
+        import torch
+        L = load()
+        self.npi, self.npk = int(npro_i), int(npro_k)
+        self._tr = PencilTransport()
+        self._keep = None
+        if transport == "loopback":
+            check(L.tlab_pencil_transport_loopback(ctypes.byref(self._tr), self.npi, self.npk), "tlab_pencil_transport_loopback")
+        elif transport == "rccl":
+            import torch.distributed as dist
+            from . import comm as C
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [C.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            self._keep = C.NativeComm(box[0], world, rank, self.npi, self.npk)
+            C.check(C.load().tlab_comm_pencil_transport(self._keep._h, ctypes.byref(self._tr)), "tlab_comm_pencil_transport")
+        else:
+            raise TlabError("transport: loopback or rccl")
+        self.transport = transport
+        self.nx, self.ny, self.nzt = len(x), len(y), len(z)
+        self.nscal, self.visc = int(nscal), float(visc)
+        self.schmidt = [float(v) for v in schmidt][: self.nscal]
+        self.g = [FdmPlan(x, True, True, hyper_bc1_ext=hyper_bc1_ext), FdmPlan(y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext),
+                  FdmPlan(z, True, True, hyper_bc1_ext=hyper_bc1_ext)]
+        self.kdt, self.kco = rk_coefficients(rkm_mode)
+        self.rkm_endstep = len(self.kdt)
+        sc = np.ascontiguousarray(self.schmidt if self.nscal else [1.0], dtype=np.float64)
+        self._h = c_vp(0)
+        rc = L.tlab_pencil_dns_create(ctypes.byref(self._h), ctypes.byref(self._tr), self.g[0]._h, self.g[1]._h, self.g[2]._h, self.nx, self.ny, self.nzt,
+                                      self.nscal, self.visc, sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        if rc != 0:          # a refused configuration leaves the transport context with the caller (include/tlab_amd.h)
+            if self._tr.destroy:
+                self._tr.destroy(self._tr.ctx)
+            if self._keep is not None:
+                self._keep.close()
+                self._keep = None
+        check(rc, "tlab_pencil_dns_create")
+        self.imax, self.kmax, self.kmax2 = (int(L.tlab_pencil_dns_info(self._h, w)) for w in (0, 1, 2))
+        self.isize_txc = int(L.tlab_pencil_dns_info(self._h, 3))
+        self.n = self.imax * self.ny * self.kmax
+        first, nlocal = int(L.tlab_pencil_dns_info(self._h, 5)), int(L.tlab_pencil_dns_info(self._h, 4))
+        self.local_ranks = list(range(first, first + nlocal))
+        self.st = {}
+        for l, r in enumerate(self.local_ranks):
+            S = {name: [torch.zeros(m, dtype=torch.float64, device=device) for _ in range(cnt)] for name, cnt, m in
+                 (("q", 3, self.n), ("s", self.nscal, self.n), ("hq", 3, self.n), ("hs", self.nscal, self.n), ("txc", 9, self.isize_txc))}
+            arr = lambda ts: (c_vp * max(len(ts), 1))(*[t.data_ptr() for t in ts])       # noqa: E731
+            check(L.tlab_pencil_dns_bind(self._h, l, arr(S["q"]), arr(S["s"]), arr(S["hq"]), arr(S["hs"]), arr(S["txc"])), "tlab_pencil_dns_bind")
+            self.st[r] = S
+
+    def pro(self, r):
+        return r % self.npi, r // self.npi
+
+    def set_bcs(self, velocity_jmin="noslip", velocity_jmax="noslip", scalar_jmin="dirichlet", scalar_jmax="dirichlet"):
+        fj0, fj1, sj0, sj1 = _bcs_arrays(self.nscal, velocity_jmin, velocity_jmax, scalar_jmin, scalar_jmax)
+        ia = lambda v, m: (ctypes.c_int * max(m, 1))(*list(v)[:m])       # noqa: E731
+        check(load().tlab_pencil_dns_set_bcs(self._h, ia(fj0, 3), ia(fj1, 3), ia(sj0, self.nscal), ia(sj1, self.nscal)), "tlab_pencil_dns_set_bcs")
+
+    def RHS_GLOBAL_INCOMPRESSIBLE_1(self, dte):
+        _use_torch_stream()
+        check(load().tlab_pencil_dns_rhs(self._h, float(dte)), "tlab_pencil_dns_rhs")
+
+    def TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(self, dte, kco=1.0, scale_tendencies=False):
+        _use_torch_stream()
+        check(load().tlab_pencil_dns_substep(self._h, float(dte), float(kco), int(scale_tendencies)), "tlab_pencil_dns_substep")
+
+    def substep_of_cycle(self, k, dtime):
+        s = k % self.rkm_endstep
+        if s == 0:
+            _use_torch_stream()
+            check(load().tlab_pencil_dns_begin_step(self._h), "tlab_pencil_dns_begin_step")
+        last = s == self.rkm_endstep - 1
+        self.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dtime * self.kdt[s], 1.0 if last else self.kco[s], not last)
+
+    def block_of(self, r, global_field):
+        pi, pk = self.pro(r)
+        g = global_field.view(self.nzt, self.ny, self.nx)
+        return g[pk * self.kmax:(pk + 1) * self.kmax, :, pi * self.imax:(pi + 1) * self.imax]
+
+    def scatter(self, name, idx, global_field):
+        for r in self.local_ranks:
+            self.st[r][name][idx].view(self.kmax, self.ny, self.imax).copy_(self.block_of(r, global_field))
+
+    def gather_local(self, name, idx):
+        return {r: self.st[r][name][idx] for r in self.local_ranks}
+
+    def close(self):
+        if self._h:
+            load().tlab_pencil_dns_destroy(self._h)
+            self._h = c_vp(0)
+        if self._keep is not None:
+            self._keep.close()
+            self._keep = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
