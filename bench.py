@@ -456,6 +456,13 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # the host's own cost of issuing a substep: `enqueue` above is throttled by the device once the launch queue is full (the host runs ahead of the GPU
+    # until hipLaunchKernel blocks), so one more substep is issued into an EMPTY queue and timed on the host alone
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    substep(args.warmup + args.steps)
+    issue_empty = time.perf_counter() - t0
+    torch.cuda.synchronize()
     finite = all(bool(torch.isfinite(t).all()) for t in state_fields)
 
     if rank == 0:
@@ -508,6 +515,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "host_issue_ms_per_step": enqueue / args.steps * 1e3,
+            "host_issue_empty_queue_ms": issue_empty * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

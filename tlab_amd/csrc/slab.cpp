@@ -468,17 +468,10 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     refuse_unsupported_state("tlab_slab_dns_rhs");
     const int nx = d->nx, ny = d->ny, kmax = d->kmax, ns = d->nscal;
     const long long n = d->n;
-    // ---- diffusion + advection (:98-162) ----
     const int S_HQ3 = 3 + ns, S_P = 4 + ns;            // halo slots (Rank::lo, hi): 0..2 q, 3..2+ns s, then hq(3) and tmp1
-    int w = halo_start(d, 3 + ns, [&](Rank &R, int i) { return Slot{i < 3 ? R.q[i] : R.s[i - 3], i}; });
-    const bool fresh = d->fresh;       // start of a Runge-Kutta step: hq = hs = 0 (time.f90:212-216) -> the x-terms overwrite
+    const bool fresh = d->fresh;       // start of a Runge-Kutta step: hq = hs = 0 (time.f90:212-216) -> the first term of every equation overwrites
     d->fresh = false;
-    for (Rank &R : d->rk) badd_all(d, R, 1, fresh);
-    twait(d, w);
-    for (Rank &R : d->rk) zburgers_all(d, R, 1);
-    w = msg_start(d, 2 * (3 + ns));
-    for (Rank &R : d->rk) badd_all(d, R, 2, false);
-    twait(d, w);
+    const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (as rhs.cpp)
     // The reference's DEFAULT walls (free-slip u, w; Neumann scalars: boundary_bcs.f90:102-190) without a derivative pass per Neumann field, as in the
     // single-domain driver (rhs.cpp): the wall tendency of BOUNDARY_BCS_NEUMANN_Y is a linear functional of the y line with weights that decay
     // like the coupling of the compact system, so a field is finished with zero wall tendencies by the kernel that holds its last term (Dirichlet
@@ -511,9 +504,18 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     std::vector<int> zfin((size_t)(3 + ns), 0);
     for (int i = 0; i < ns; ++i)
         zfin[3 + i] = tail && d->fused_x && (ibc_of(d->scal_jmin[i], d->scal_jmax[i]) == 0 || planes_route);
+    // ---- diffusion + advection (:98-162) and the pressure forcing div(hq + q/dte) (:188-260) ----
+    // (Measured in round 4 and dropped: the x and y terms of the forcing inside the Burgers launches that add the last term of u resp. v, as rhs.cpp
+    // does on one device.  It needs u to end with its x term and v with its y term, i.e. the x and y launches split in two; on slabs of 64 planes the
+    // extra velocity reads and the smaller launches cost what the two saved passes return: 28.17 against 28.04 ms for 8 loopback ranks at 512^3.)
+    int w = halo_start(d, 3 + ns, [&](Rank &R, int i) { return Slot{i < 3 ? R.q[i] : R.s[i - 3], i}; });
+    for (Rank &R : d->rk) badd_all(d, R, 1, fresh);
+    twait(d, w);
+    for (Rank &R : d->rk) zburgers_all(d, R, 1);
+    w = msg_start(d, 2 * (3 + ns));
+    for (Rank &R : d->rk) badd_all(d, R, 2, false);
+    twait(d, w);
     for (Rank &R : d->rk) zburgers_all(d, R, 2, &zfin, tdte, kco, scale);
-    // ---- pressure forcing: div(hq + q/dte) (:188-260) ----
-    const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (as rhs.cpp)
     w = halo_start(d, 1, [&](Rank &R, int) { return Slot{R.hq[2], S_HQ3}; });          // w's halo planes are still valid
     for (Rank &R : d->rk) padd(d, R, 2, R.hq[1], R.q[1], idte, R.txc[0], 0);
     for (Rank &R : d->rk) padd(d, R, 1, R.hq[0], R.q[0], idte, R.txc[0], 1);

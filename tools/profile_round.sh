@@ -5,7 +5,7 @@
 # then copy gpurun_out/<round>/{*.csv,*.txt,*.json} to profiles/<round>/ and gpurun_out/<round>/traffic.json to profiles/traffic.json.
 # rocprofv3 rules of this pool: the program itself after `--` (no env / bash -c hops), --pmc passes separate from --stats, counters one per pass.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 COMMIT=${2:-unknown}
 ROOT=$(pwd)
 O=$ROOT/gpurun_out/$R
@@ -33,6 +33,13 @@ python3 "$OPS" --types P1,BURGERS --iters 20 > "$O/ops_standalone.txt" 2>&1
 Q="--cpu-sample 0 --no-freeslip-leg"
 python3 "$B" --loopback 8 --steps 20 --warmup 5 $Q > "$O/bench_loopback8_native.json" 2> /dev/null
 TLAB_SLAB_FUSED_X=0 python3 "$B" --loopback 8 --steps 20 --warmup 5 $Q > "$O/bench_loopback8_native_unfused.json" 2> /dev/null
+python3 "$B" --loopback 8 --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_loopback8_native_freeslip.json" 2> /dev/null
+TLAB_NEUMANN_PLANES=0 python3 "$B" --loopback 8 --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_loopback8_native_freeslip_derivative_pass.json" 2> /dev/null
+python3 "$B" --decomp 2x4 --slab-driver native --steps 6 --warmup 2 $Q > "$O/bench_decomp2x4_native.json" 2> /dev/null
+python3 "$B" --decomp 2x4 --slab-driver python --steps 6 --warmup 2 $Q > "$O/bench_decomp2x4_python.json" 2> /dev/null
+"$ROOT/tools/yardstick" 512 > "$O/yardstick.jsonl" 2> /dev/null
+TLAB_HTILE_PERSIST=0 python3 "$B" --steps 20 --warmup 5 $Q > "$O/bench_no_ptile.json" 2> /dev/null
+TLAB_HTILE_PERSIST=0 TLAB_HTILE_UNI=0 python3 "$B" --steps 20 --warmup 5 $Q > "$O/bench_no_ptile_no_dual_solve.json" 2> /dev/null
 python3 "$B" --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_freeslip.json" 2> /dev/null
 TLAB_NEUMANN_PLANES=0 python3 "$B" --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_freeslip_derivative_pass.json" 2> /dev/null
 python3 "$B" --grid 2048 1024 256 --nscal 3 --steps 6 --warmup 2 $Q > "$O/bench_configs4_rank_share.json" 2> /dev/null
