@@ -195,6 +195,49 @@ def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused, nx, walls):
     assert 0.0 < d <= 1e-10, d
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_fortran_rk_driver_through_the_pencil_driver(tmp_path, fused):
+    """The x/z pencil route of the Fortran host (ims_npro_i > 1): RHS_GLOBAL_INCOMPRESSIBLE_1 / TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD hand the substep
+    to tlab_pencil_dns_* with the module arrays bound as they are.  One GPU here: TLAB_AMD_FORCE_PENCIL=1 takes that route on 1 x 1 ranks (loopback
+    transport: the marshalling, the binding of q / s / hq / hs / txc and the step-start zeroing are what is exercised; the transpositions themselves are
+    covered on 2 x 2 .. 4 x 4 ranks in tests/test_gpu_pencil.py).  Two Runge-Kutta steps against the oracle."""
+    import numpy as np
+    from conftest import rel_err
+    from scatter import substep_scatter, bound
+    from oracle.tlab_oracle_rhs import DnsOracle
+    _need_rk()
+    if fused and not os.path.exists(RK_EXE_FUSED):
+        pytest.skip("tlab_amd/fortran/_build_rk_fused/test_rk_driver not built")
+    nx, ny, nz = 64, 32, 32
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(65)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * Y)
+    q0 = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3)]
+    s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    re, sc, dt = 1000.0, 0.7, 1e-3
+    bcs = ["VelocityJmin=freeslip", "VelocityJmax=freeslip", "Scalar1Jmin=neumann", "Scalar1Jmax=dirichlet"]
+    q1, s1, log = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 2, bcs, exe=RK_EXE_FUSED if fused else None, env={"TLAB_AMD_FORCE_PENCIL": "1"})
+    kdt, kco = [1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0], [-5.0 / 9.0, -153.0 / 128.0]
+    sched = [(dt * kdt[k % 3], kco[k % 3] if k % 3 < 2 else 1.0, k % 3 < 2, k % 3 == 0) for k in range(6)]
+
+    def make_oracle():
+        from tlab_amd.dns import velocity_bcs
+        o = DnsOracle(x, y, z, nscal=1, visc=1.0 / re, schmidt=(sc,), yuniform=False)
+        o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip")
+        o.scal_jmin, o.scal_jmax = [4], [3]
+        return o
+    B, S = substep_scatter(make_oracle, q0, s0, sched, nsamples=1)
+    for i in range(3):
+        assert rel_err(q1[i], B[5]["q"][i]) <= bound(S[5]["q"][i]), ("q", i, rel_err(q1[i], B[5]["q"][i]), S[5]["q"][i])
+    assert rel_err(s1[0], B[5]["s"][0]) <= bound(S[5]["s"][0])
+    q2, _, _ = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 2, bcs, exe=RK_EXE_FUSED if fused else None)
+    d = max(rel_err(q1[i], q2[i]) for i in range(3))
+    assert 0.0 < d <= 1e-10, d       # another operator order than the single-domain driver, not another result
+
+
 def test_case01_own_tlab_ini_through_the_fortran_driver(tmp_path):
     """BASELINE configs[0] = examples/Case01 on ITS OWN tlab.ini (tests/golden/case01/tlab.ini: the example's input file as the reference ships it,
     a data fixture; only `End=10` is shortened to 2 iterations): 512 x 256 x 1, SpaceOrder = CompactJacobian6 (the backwards-compatible key, read by

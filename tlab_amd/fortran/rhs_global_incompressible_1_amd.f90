@@ -13,13 +13,19 @@ subroutine RHS_GLOBAL_INCOMPRESSIBLE_1()
     use DNS_ARRAYS
     use TIME, only: dte
     use TLab_AMD_C
-    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle, TLab_AMD_Slab_Active, TLab_AMD_Slab_Handle
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle, TLab_AMD_Slab_Active, TLab_AMD_Slab_Handle, TLab_AMD_Pencil_Active, TLab_AMD_Pencil_Handle
     implicit none
 
     type(c_ptr) :: pq(3), ps(16), phq(3), phs(16), ptxc(16)
     integer is
     integer(c_int) rc
 
+    ! ims_npro_i > 1: the x/z pencil driver (tlab_amd/csrc/pencil.cpp): I- / K-transpositions around the x / z operators, exactly the MPI branches of
+    ! OPR_Partial_X/Z and OPR_Burgers_X/Z (opr_partial.f90:66-147, :185-253; opr_burgers.f90:216-262, :386-426)
+    if (TLab_AMD_Pencil_Active()) then
+        call TLab_AMD_Check(tlab_pencil_dns_rhs(TLab_AMD_Pencil_Handle(), real(dte, c_double)), 'tlab_pencil_dns_rhs')
+        return
+    end if
     ! ims_npro_k > 1: the z-slab driver (tlab_amd/csrc/slab.cpp) on the module arrays it was bound to -- the MPI branches of OPR_Partial_Z,
     ! OPR_Burgers_Z and OPR_Fourier_Z_* (opr_partial.f90:185-195, opr_burgers.f90:386-426, opr_fourier.f90:343-428) without a transposition per operator
     if (TLab_AMD_Slab_Active()) then
@@ -56,7 +62,7 @@ subroutine TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(kco_loc, scale_loc)
     use DNS_ARRAYS
     use TIME, only: dte
     use TLab_AMD_C
-    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle, TLab_AMD_Slab_Active, TLab_AMD_Slab_Handle
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Handle, TLab_AMD_Slab_Active, TLab_AMD_Slab_Handle, TLab_AMD_Pencil_Active, TLab_AMD_Pencil_Handle
     implicit none
     real(wp), intent(in) :: kco_loc
     logical, intent(in) :: scale_loc
@@ -65,6 +71,11 @@ subroutine TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(kco_loc, scale_loc)
     integer is
     integer(c_int) rc
 
+    if (TLab_AMD_Pencil_Active()) then
+        call TLab_AMD_Check(tlab_pencil_dns_substep(TLab_AMD_Pencil_Handle(), real(dte, c_double), real(kco_loc, c_double), &
+                                                    merge(1_c_int, 0_c_int, scale_loc)), 'tlab_pencil_dns_substep')
+        return
+    end if
     if (TLab_AMD_Slab_Active()) then
         call TLab_AMD_Check(tlab_slab_dns_substep(TLab_AMD_Slab_Handle(), real(dte, c_double), real(kco_loc, c_double), &
                                                   merge(1_c_int, 0_c_int, scale_loc)), 'tlab_slab_dns_substep')

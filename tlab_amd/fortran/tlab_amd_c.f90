@@ -16,6 +16,13 @@ module TLab_AMD_C
                           destroy = c_null_funptr
     end type tlab_slab_transport
 
+    ! struct tlab_pencil_transport: MPI_Alltoallv inside the world / ims_comm_x / ims_comm_z communicators for the x/z pencil driver (tlab_pencil_dns_*)
+    type, bind(C) :: tlab_pencil_transport
+        type(c_ptr) :: ctx = c_null_ptr
+        integer(c_int) :: npro_i = 1, npro_k = 1, nlocal = 1, first = 0
+        type(c_funptr) :: alltoallv_start = c_null_funptr, wait = c_null_funptr, allreduce = c_null_funptr, destroy = c_null_funptr
+    end type tlab_pencil_transport
+
     interface
         integer(c_int) function tlab_finalize() bind(C, name='tlab_finalize')
             import :: c_int
@@ -227,6 +234,56 @@ module TLab_AMD_C
             type(c_ptr), value :: a
             real(c_double), value :: alpha
             integer(c_long_long), value :: n
+        end function
+        ! ---- x/z pencils (ims_npro_i > 1): tlab_pencil_dns_* of include/tlab_amd.h ----
+        integer(c_int) function tlab_pencil_transport_loopback(tr, npro_i, npro_k) bind(C, name='tlab_pencil_transport_loopback')
+            import :: c_int, tlab_pencil_transport
+            type(tlab_pencil_transport), intent(out) :: tr
+            integer(c_int), value :: npro_i, npro_k
+        end function
+        integer(c_int) function tlab_pencil_dns_create(d, tr, gx, gy, gz, nx, ny, nz_total, nscal, visc, schmidt) bind(C, name='tlab_pencil_dns_create')
+            import :: c_int, c_ptr, c_double, tlab_pencil_transport
+            type(c_ptr), intent(out) :: d
+            type(tlab_pencil_transport), intent(in) :: tr
+            type(c_ptr), value :: gx, gy, gz
+            integer(c_int), value :: nx, ny, nz_total, nscal
+            real(c_double), value :: visc
+            real(c_double), intent(in) :: schmidt(*)
+        end function
+        integer(c_int) function tlab_pencil_dns_destroy(d) bind(C, name='tlab_pencil_dns_destroy')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+        end function
+        integer(c_int) function tlab_pencil_dns_bind(d, l, q, s, hq, hs, txc) bind(C, name='tlab_pencil_dns_bind')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+            integer(c_int), value :: l
+            type(c_ptr), intent(in) :: q(*), s(*), hq(*), hs(*), txc(*)
+        end function
+        integer(c_long_long) function tlab_pencil_dns_info(d, what) bind(C, name='tlab_pencil_dns_info')
+            import :: c_int, c_ptr, c_long_long
+            type(c_ptr), value :: d
+            integer(c_int), value :: what
+        end function
+        integer(c_int) function tlab_pencil_dns_set_bcs(d, flow_jmin, flow_jmax, scal_jmin, scal_jmax) bind(C, name='tlab_pencil_dns_set_bcs')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+            integer(c_int), intent(in) :: flow_jmin(*), flow_jmax(*), scal_jmin(*), scal_jmax(*)
+        end function
+        integer(c_int) function tlab_pencil_dns_begin_step(d) bind(C, name='tlab_pencil_dns_begin_step')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: d
+        end function
+        integer(c_int) function tlab_pencil_dns_rhs(d, dte) bind(C, name='tlab_pencil_dns_rhs')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: d
+            real(c_double), value :: dte
+        end function
+        integer(c_int) function tlab_pencil_dns_substep(d, dte, kco, scale) bind(C, name='tlab_pencil_dns_substep')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: d
+            real(c_double), value :: dte, kco
+            integer(c_int), value :: scale
         end function
         ! ---- the decomposed substep (ims_npro_k > 1): tlab_slab_dns_* of include/tlab_amd.h ----
         integer(c_int) function tlab_slab_transport_loopback(tr, nranks) bind(C, name='tlab_slab_transport_loopback')

@@ -20,12 +20,15 @@ module TLab_AMD_DNS
     public :: TLab_AMD_DNS_Handle          ! type(c_ptr): creates the device driver state on first use
     public :: TLab_AMD_Slab_Active         ! ims_npro_k > 1 (or TLAB_AMD_FORCE_SLAB=1, one rank as its own neighbour: tests): the z-slab driver runs the RHS
     public :: TLab_AMD_Slab_Handle         ! type(c_ptr): tlab_slab_dns_create over the communicator of TLabMPI_Transpose, module arrays bound
+    public :: TLab_AMD_Pencil_Active       ! ims_npro_i > 1 (or TLAB_AMD_FORCE_PENCIL=1): the RHS goes to the native x/z pencil driver (tlab_pencil_dns_*)
+    public :: TLab_AMD_Pencil_Handle
     public :: TLab_AMD_DNS_Begin_Step      ! optional: tells the device RHS that hq, hs are zero (no fill, no read of the old tendencies)
     public :: TLab_AMD_Zero
     public :: TLab_AMD_DNS_Finalize
 
     type(c_ptr), save :: dns = c_null_ptr
     type(c_ptr), save :: slab = c_null_ptr
+    type(c_ptr), save :: pencil = c_null_ptr
 
 contains
     logical function TLab_AMD_Slab_Active()
@@ -38,6 +41,74 @@ contains
             TLab_AMD_Slab_Active = (stat == 0 .and. trim(val) == '1')
         end if
     end function TLab_AMD_Slab_Active
+
+    logical function TLab_AMD_Pencil_Active()
+        use TLabMPI_VARS, only: ims_npro_i
+        character(len=8) val
+        integer stat
+        TLab_AMD_Pencil_Active = ims_npro_i > 1
+        if (.not. TLab_AMD_Pencil_Active) then
+            call get_environment_variable('TLAB_AMD_FORCE_PENCIL', val, status=stat)
+            TLab_AMD_Pencil_Active = (stat == 0 .and. trim(val) == '1')
+        end if
+    end function TLab_AMD_Pencil_Active
+
+    ! The x/z pencil driver (include/tlab_amd.h: tlab_pencil_dns_*): imax, kmax are the LOCAL sizes, g(1) and g(3) the plans of the GLOBAL x and z
+    ! directions, as FDM_Initialize leaves them in an MPI run.  Without a communicator (one rank: tests) the loopback transport serves.
+    function TLab_AMD_Pencil_Handle() result(h)
+        use FDM, only: g
+        use TLab_Memory, only: imax, jmax, kmax, inb_scal, inb_txc
+        use TLab_Arrays, only: q, s, txc
+        use DNS_ARRAYS, only: hq, hs
+        use NavierStokes, only: visc, schmidt
+        use BOUNDARY_BCS, only: BcsFlowJmin, BcsFlowJmax, BcsScalJmin, BcsScalJmax
+        use OPR_Partial, only: OPR_Partial_AMD_Plan
+        use DNS_LOCAL, only: remove_divergence
+        use TLabMPI_VARS, only: ims_npro_i, ims_npro_k
+        use TLabMPI_Transpose, only: TLabMPI_Trp_AMD_Pencil_Transport
+        type(c_ptr) :: h
+        type(tlab_pencil_transport) :: tr
+        type(c_ptr) :: pq(3), ps(16), phq(3), phs(16), ptxc(16)
+        integer(c_int) :: rc, fj0(3), fj1(3), sj0(16), sj1(16)
+        real(c_double) :: sc(16)
+        integer is
+        if (.not. c_associated(pencil)) then
+            if (inb_scal > 16 .or. inb_txc < 9) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Pencil_Handle: needs inb_scal <= 16 and inb_txc >= 9')
+            ! the supported subset, refused rather than dropped (as TLab_AMD_Slab_Handle)
+            if (.not. remove_divergence) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Pencil_Handle: TermDivergence = none is not built into the pencil driver')
+            if (inb_scal > 0) then
+                if (any(BcsScalJmin%SfcType(1:inb_scal) /= 0) .or. any(BcsScalJmax%SfcType(1:inb_scal) /= 0)) &
+                    call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Pencil_Handle: the dynamic surface model (BcsScal%SfcType) runs on one rank only')
+            end if
+            if (max(ims_npro_i, 1)*max(ims_npro_k, 1) > 1) then
+                call TLabMPI_Trp_AMD_Pencil_Transport(tr)
+            else
+                call TLab_AMD_Check(tlab_pencil_transport_loopback(tr, 1_c_int, 1_c_int), 'tlab_pencil_transport_loopback')
+            end if
+            sc = 1.0_c_double
+            sc(1:inb_scal) = schmidt(1:inb_scal)
+            rc = tlab_pencil_dns_create(pencil, tr, OPR_Partial_AMD_Plan(1, g(1)), OPR_Partial_AMD_Plan(2, g(2)), OPR_Partial_AMD_Plan(3, g(3)), &
+                                        int(imax*max(ims_npro_i, 1), c_int), int(jmax, c_int), int(kmax*max(ims_npro_k, 1), c_int), int(inb_scal, c_int), &
+                                        real(visc, c_double), sc)
+            call TLab_AMD_Check(rc, 'tlab_pencil_dns_create')
+            fj0 = BcsFlowJmin%type(1:3); fj1 = BcsFlowJmax%type(1:3)
+            sj0 = 3; sj1 = 3
+            sj0(1:inb_scal) = BcsScalJmin%type(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%type(1:inb_scal)
+            call TLab_AMD_Check(tlab_pencil_dns_set_bcs(pencil, fj0, fj1, sj0, sj1), 'tlab_pencil_dns_set_bcs')
+            ps = c_null_ptr; phs = c_null_ptr; ptxc = c_null_ptr
+            do is = 1, 3
+                pq(is) = c_loc(q(1, is)); phq(is) = c_loc(hq(1, is))
+            end do
+            do is = 1, inb_scal
+                ps(is) = c_loc(s(1, is)); phs(is) = c_loc(hs(1, is))
+            end do
+            do is = 1, 9
+                ptxc(is) = c_loc(txc(1, is))
+            end do
+            call TLab_AMD_Check(tlab_pencil_dns_bind(pencil, 0_c_int, pq, ps, phq, phs, ptxc), 'tlab_pencil_dns_bind')
+        end if
+        h = pencil
+    end function TLab_AMD_Pencil_Handle
 
     ! The decomposed driver (include/tlab_amd.h: tlab_slab_dns_*): kmax is the LOCAL number of planes, g(3) the plan of the GLOBAL z direction, as
     ! FDM_Initialize leaves it in an MPI run (g(3)%size = kmax*ims_npro_k).  The module arrays are bound once; they never move.
@@ -138,7 +209,10 @@ contains
     end function TLab_AMD_DNS_Handle
 
     subroutine TLab_AMD_DNS_Begin_Step()
-        if (TLab_AMD_Slab_Active()) then
+        if (TLab_AMD_Pencil_Active()) then
+            ! the pencil driver ADDS to the tendencies like the reference: the start of a step zeroes them (hq = hs = 0, time.f90:212-216)
+            call TLab_AMD_Check(tlab_pencil_dns_begin_step(TLab_AMD_Pencil_Handle()), 'tlab_pencil_dns_begin_step')
+        else if (TLab_AMD_Slab_Active()) then
             call TLab_AMD_Check(tlab_slab_dns_begin_step(TLab_AMD_Slab_Handle()), 'tlab_slab_dns_begin_step')
         else
             call TLab_AMD_Check(tlab_dns_begin_step(TLab_AMD_DNS_Handle()), 'tlab_dns_begin_step')
@@ -156,6 +230,8 @@ contains
         integer(c_int) rc
         if (c_associated(slab)) rc = tlab_slab_dns_destroy(slab)
         slab = c_null_ptr
+        if (c_associated(pencil)) rc = tlab_pencil_dns_destroy(pencil)
+        pencil = c_null_ptr
         if (c_associated(dns)) rc = tlab_dns_destroy(dns)
         dns = c_null_ptr
         rc = tlab_sync()

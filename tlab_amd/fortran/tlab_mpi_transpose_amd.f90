@@ -15,7 +15,7 @@ module TLabMPI_Transpose
     use TLab_Memory, only: imax, jmax, kmax
     use TLab_WorkFlow, only: TLab_Write_ASCII, TLab_Stop
     use TLabMPI_VARS, only: ims_pro, ims_npro, ims_npro_i, ims_npro_k
-    use TLab_AMD_C, only: TLab_AMD_Check, tlab_slab_transport
+    use TLab_AMD_C, only: TLab_AMD_Check, tlab_slab_transport, tlab_pencil_transport
     implicit none
     private
 
@@ -25,6 +25,7 @@ module TLabMPI_Transpose
     public :: TLabMPI_Trp_ExecI_Forward, TLabMPI_Trp_ExecI_Backward
     public :: TLabMPI_Trp_AMD_Comm, TLabMPI_Trp_AMD_Finalize
     public :: TLabMPI_Trp_AMD_Slab_Transport        ! the exchanges of the z-slab driver over the same communicator (tlab_comm_slab_transport)
+    public :: TLabMPI_Trp_AMD_Pencil_Transport      ! ... and of the x/z pencil driver (tlab_comm_pencil_transport)
 
     type, public :: tmpi_transpose_dt
         integer(wi) :: nlines                                       ! as in the reference (tlab_mpi_transpose.f90:19-25)
@@ -57,6 +58,11 @@ module TLabMPI_Transpose
             import :: c_int, c_ptr, tlab_slab_transport
             type(c_ptr), value :: comm
             type(tlab_slab_transport), intent(out) :: tr
+        end function
+        integer(c_int) function tlab_comm_pencil_transport(comm, tr) bind(C, name='tlab_comm_pencil_transport')
+            import :: c_int, c_ptr, tlab_pencil_transport
+            type(c_ptr), value :: comm
+            type(tlab_pencil_transport), intent(out) :: tr
         end function
         integer(c_int) function tlab_comm_destroy(comm) bind(C, name='tlab_comm_destroy')
             import :: c_int, c_ptr
@@ -112,6 +118,12 @@ contains
         if (.not. c_associated(comm)) call TLab_AMD_Check(-1_c_int, 'TLabMPI_Transpose: no communicator yet (call TLabMPI_Trp_AMD_Comm first)')
         call TLab_AMD_Check(tlab_comm_slab_transport(comm, tr), 'tlab_comm_slab_transport')
     end subroutine TLabMPI_Trp_AMD_Slab_Transport
+
+    subroutine TLabMPI_Trp_AMD_Pencil_Transport(tr)
+        type(tlab_pencil_transport), intent(out) :: tr
+        if (.not. c_associated(comm)) call TLab_AMD_Check(-1_c_int, 'TLabMPI_Transpose: no communicator yet (call TLabMPI_Trp_AMD_Comm first)')
+        call TLab_AMD_Check(tlab_comm_pencil_transport(comm, tr), 'tlab_comm_pencil_transport')
+    end subroutine TLabMPI_Trp_AMD_Pencil_Transport
 
     subroutine TLabMPI_Trp_AMD_Finalize()
         integer(c_int) rc
