@@ -414,7 +414,8 @@ typedef struct tlab_slab_transport {
      * likewise by source.  Returns a ticket. */
     int (*alltoallv_start)(void *ctx, void *stream, double *const *send, const long long *scount, double *const *recv, const long long *rcount);
     int (*wait)(void *ctx, void *stream, int ticket);
-    /* MPI_ALLREDUCE of n HOST doubles per local rank (values[l*n + i]), in place; op 0 = MPI_MAX, 1 = MPI_MIN (tools/dns/time.f90:522) */
+    /* MPI_ALLREDUCE of n HOST doubles per local rank (values[l*n + i]), in place; op 0 = MPI_MAX, 1 = MPI_MIN (tools/dns/time.f90:522),
+     * 2 = MPI_SUM (the plane average of the dynamic surface model, boundary_bcs.f90:520) */
     int (*allreduce)(void *ctx, double *values, int n, int op);
     void (*destroy)(void *ctx);     /* may be NULL */
 } tlab_slab_transport;
@@ -465,8 +466,8 @@ typedef struct tlab_slab_dns *tlab_slab_dns_t;
  * OWNERSHIP of transport->ctx passes to the driver only when the call returns TLAB_OK; on any refusal the caller still owns it and must run
  * transport->destroy(ctx) itself.
  * SUPPORTED SUBSET (everything else is refused with TLAB_EUNSUPPORTED, never silently dropped): convective form, RhsMode = combined, Dirichlet or
- * Neumann walls with an impermeable wall-normal velocity, static scalar surfaces, factorized or CompactDirect6 elliptic solver, remove_divergence on
- * or off; NOT the anelastic formulation, dealiasing filters or the dynamic surface model (single-domain driver tlab_dns_* only). */
+ * Neumann walls with an impermeable wall-normal velocity, static or dynamic (linear) scalar surfaces, factorized or CompactDirect6 elliptic solver,
+ * remove_divergence on or off; NOT the anelastic formulation or dealiasing filters (single-domain driver tlab_dns_* only). */
 int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *transport, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tlab_fdm_plan_t gz,
                          int nx, int ny, int nz_total, int nscal, double visc, const double *schmidt, tlab_fdm_plan_t gy_elliptic);
 int tlab_slab_dns_destroy(tlab_slab_dns_t d);
@@ -481,7 +482,10 @@ int tlab_slab_dns_bind(tlab_slab_dns_t d, int l, double *const *q, double *const
 long long tlab_slab_dns_info(tlab_slab_dns_t d, int what);
 int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d);                 /* as tlab_dns_begin_step */
-int tlab_slab_dns_set_remove_divergence(tlab_slab_dns_t d, int on);      /* as tlab_dns_set_remove_divergence ([Main] TermDivergence) */
+int tlab_slab_dns_set_remove_divergence(tlab_slab_dns_t d, int on);
+/* as tlab_dns_set_surface_bcs: the dynamic surface model of the scalars on z-slabs.  The plane average of BOUNDARY_BCS_SURFACE_Y (AVG1V2D,
+ * boundary_bcs.f90:520,535) is an all-reduce: the transport's allreduce is called with op = 2 (MPI_SUM) on the ranks' plane averages. */
+int tlab_slab_dns_set_surface_bcs(tlab_slab_dns_t d, const int *sfc_jmin, const int *sfc_jmax, const double *cpl_jmin, const double *cpl_jmax);      /* as tlab_dns_set_remove_divergence ([Main] TermDivergence) */
 /* RHS_GLOBAL_INCOMPRESSIBLE_1 on the bound arrays of all local ranks (tools/dns/rhs_global_incompressible_1.f90:98-398) */
 int tlab_slab_dns_rhs(tlab_slab_dns_t d, double dte);
 /* TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT (tools/dns/time.f90:559-664 + :261-298): RHS with the RK update folded into its last passes */

@@ -214,6 +214,58 @@ def test_native_driver_default_walls_on_the_wall_plane_route(T, walls, monkeypat
                 assert float((got - ob).abs().max() / ob.abs().max()) <= tol, (tag, "vs oracle", name, i)
 
 
+@pytest.mark.parametrize("P,sides,walls", [(2, "bottom", "noslip"), (4, "both", "freeslip")])
+def test_native_driver_dynamic_surface_model_on_slabs(T, P, sides, walls):
+    """Scalar1SfcTypeJmin/Jmax = linear (examples/Case88) on z-slabs: BOUNDARY_BCS_SURFACE_Y needs the plane average of d s / dy over ALL ranks (AVG1V2D,
+    boundary_bcs.f90:520) -- the transport's all-reduce with MPI_SUM.  Four substeps across a step boundary (the kept tendency plane of one substep feeds
+    the next; zeroed at a step start) against the single domain and the oracle."""
+    import torch
+    from tlab_amd.dns import Dns, velocity_bcs
+    from tlab_amd.slab import NativeSlabDns
+    from oracle.tlab_oracle_rhs import DnsOracle
+    nx, ny, nz = 128, 48, 64 * P
+    x, y, z = _grid(nx, ny, nz)
+    f = _fields(x, y, z, 31)
+    visc, sc = 1.0 / 600.0, (0.7,)
+    kw = dict(nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
+    one = Dns(x, y, z, **kw)
+    nat = NativeSlabDns("loopback", x, y, z, size=P, **kw)
+    jmax = "linear" if sides == "both" else "static"
+    bc = (walls, walls, "dirichlet", "dirichlet")
+    for d in (one, nat):
+        d.set_bcs(*bc)
+        d.set_surface_bcs(["linear"], [jmax], [0.35], [-0.2])
+    for i in range(4):
+        t = torch.from_numpy(f[i]).cuda()
+        (one.q[i] if i < 3 else one.s[0]).copy_(t)
+        nat.scatter("q" if i < 3 else "s", i if i < 3 else 0, t)
+    dtime = 2e-3
+    sched = [(dtime * one.kdt[k % 3], one.kco[k % 3] if k % 3 < 2 else 1.0, k % 3 < 2, k % 3 == 0) for k in range(4)]
+    one.begin_step()
+    for k in range(4):
+        if k == 3:
+            one.begin_step()
+        one.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(*sched[k][:3])
+        nat.substep_of_cycle(k, dtime)
+
+    def make_oracle():
+        o = DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False)
+        o.flow_jmin = o.flow_jmax = velocity_bcs(walls)
+        o.sfc_jmin, o.cpl_jmin = [1], [0.35]
+        o.sfc_jmax, o.cpl_jmax = [1 if sides == "both" else 0], [-0.2]
+        return o
+    B, S = substep_scatter(make_oracle, f[:3], f[3:4], sched, nsamples=1)
+    for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
+        for i, rf in enumerate(ref):
+            got = torch.cat([nat.st[r][name][i] for r in range(P)])
+            tol = bound(S[3][name][i])
+            assert float((got - rf).abs().max() / rf.abs().max()) <= tol, ("slabs vs single domain", name, i)
+            ob = torch.from_numpy(B[3][name][i]).cuda()
+            assert float((got - ob).abs().max() / ob.abs().max()) <= tol, ("slabs vs oracle", name, i)
+    assert np.abs(B[3]["hs"][0].reshape(nz, ny, nx)[:, 0, :]).max() > 1e-3          # (the bottom plane of the tendency is alive)
+    nat.close()
+
+
 def test_native_driver_refuses_what_it_does_not_build(T):
     """A decomposed run must integrate the same equations as the same tlab.ini on one rank, or stop: with the anelastic operator state
     on, the z-slab driver refuses to be created and refuses to run -- TLAB_EUNSUPPORTED with a message, nothing silently dropped."""

@@ -232,7 +232,7 @@ int slab_allreduce(void *ctx, double *values, int n, int op) {
         hipStream_t cur = tlab_current_stream(), cs = c->stream;
         const int t = slab_begin(c, cur);
         hipc(hipMemcpyAsync(c->red, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, cs), "hipMemcpyAsync");
-        ncc(ncclAllReduce(c->red, c->red, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclMin, zcomm(c), cs), "ncclAllReduce");
+        ncc(ncclAllReduce(c->red, c->red, (size_t)n, ncclDouble, op == 0 ? ncclMax : (op == 1 ? ncclMin : ncclSum), zcomm(c), cs), "ncclAllReduce");
         hipc(hipMemcpyAsync(values, c->red, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, cs), "hipMemcpyAsync");
         hipc(hipEventRecord(c->ev_done[t], cs), "hipEventRecord");
         hipc(hipStreamSynchronize(cs), "hipStreamSynchronize");

@@ -339,6 +339,16 @@ hipError_t launch_surface_flux(double *ref, const double *t, int j, int javg, do
     hipLaunchKernelGGL(k_surface_flux, dim3(pw_grid((long long)nx * nz)), dim3(256), 0, st, ref, t, j, sign, diff, cpl, avg_scratch, nx, ny, nz);
     return CHECK_LAUNCH();
 }
+// the two halves on their own (z-slab driver: the plane average is an all-reduce over the ranks between them)
+hipError_t launch_plane_avg(const double *t, int j, int nx, int ny, int nz, double *avg, hipStream_t st) {
+    hipLaunchKernelGGL(k_plane_sum, dim3(1), dim3(1024), 0, st, t, j, nx, ny, nz, avg);
+    return CHECK_LAUNCH();
+}
+hipError_t launch_surface_flux_avg(double *ref, const double *t, int j, double sign, double diff, double cpl, const double *avg, int nx, int ny, int nz,
+                                   hipStream_t st) {
+    hipLaunchKernelGGL(k_surface_flux, dim3(pw_grid((long long)nx * nz)), dim3(256), 0, st, ref, t, j, sign, diff, cpl, avg, nx, ny, nz);
+    return CHECK_LAUNCH();
+}
 hipError_t launch_scale(double *a, double alpha, long long n, hipStream_t st) {
     hipLaunchKernelGGL(k_scale, dim3(pw_grid(n)), dim3(256), 0, st, a, alpha, n);
     return CHECK_LAUNCH();

@@ -50,6 +50,10 @@ hipError_t launch_wall_weighted(const double *a1, const double *a2, const double
 hipError_t launch_wall_fix(double *q, double *h, const double *sb, const double *st, double dte, double kco, int scale, int nx, int ny, int nz,
                            hipStream_t stream);
 hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // pointwise.hip
+hipError_t launch_plane_avg(const double *t, int j, int nx, int ny, int nz, double *avg, hipStream_t st);
+hipError_t launch_surface_flux_avg(double *ref, const double *t, int j, double sign, double diff, double cpl, const double *avg, int nx, int ny, int nz,
+                                   hipStream_t st);
+hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz, hipStream_t st);
 }
 
 namespace {
@@ -118,7 +122,7 @@ int lb_allreduce(void *ctx, double *v, int n, int op) {
     const int P = static_cast<Loopback *>(ctx)->P;
     for (int i = 0; i < n; ++i) {
         double a = v[i];
-        for (int r = 1; r < P; ++r) a = op == 0 ? std::max(a, v[r * n + i]) : std::min(a, v[r * n + i]);
+        for (int r = 1; r < P; ++r) a = op == 0 ? std::max(a, v[r * n + i]) : (op == 1 ? std::min(a, v[r * n + i]) : a + v[r * n + i]);
         for (int r = 0; r < P; ++r) v[r * n + i] = a;
     }
     return TLAB_OK;
@@ -131,6 +135,8 @@ struct Rank {
     tlab_zslab_plan_t zplan = nullptr;
     tlab_poisson_plan_t poisson = nullptr, poisson_b = nullptr;
     tlab_dns_t dns = nullptr;                    // monitors (TIME_COURANT, MINMAX), made on first use
+    std::vector<double *> sref_b, sref_t;        // BcsScalJmin / Jmax%ref(:,:,is) of the scalars with a dynamic surface (boundary_bcs.f90:76-87)
+    double *sfc_avg = nullptr;                   // one double: plane average
     double *hb = nullptr, *ht = nullptr;         // BcsFlowJmin/Jmax%ref(:,:,2): Neumann data of the pressure, wall planes of the Neumann fields
     double *head = nullptr, *tail = nullptr, *head_right = nullptr, *tail_left = nullptr;   // interface values, [2 (3 + ns)][nx*ny]
     double *pen[3] = {nullptr, nullptr, nullptr};   // complex kx-pencils (nxl, ny, nz_total)
@@ -166,6 +172,8 @@ struct tlab_slab_dns {
     int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
     std::vector<int> scal_jmin, scal_jmax;
     bool fresh = false;
+    std::vector<int> sfc_jmin, sfc_jmax;          // BcsScalJmin / Jmax%SfcType (0 static, 1 linear) and %cpl per scalar
+    std::vector<double> cpl_jmin, cpl_jmax;
     bool remove_divergence = true;     // [Main] TermDivergence: forcing div(hq + q/dte) (rhs_global_incompressible_1.f90:177-232); false: div(hq) (:234-250)
     std::vector<Rank> rk;
     ~tlab_slab_dns() {
@@ -174,8 +182,10 @@ struct tlab_slab_dns {
             if (R.poisson) (void)tlab_poisson_plan_destroy(R.poisson);
             if (R.poisson_b) (void)tlab_poisson_plan_destroy(R.poisson_b);
             if (R.zplan) (void)tlab_zslab_plan_destroy(R.zplan);
-            for (double *p : {R.hb, R.ht, R.head, R.tail, R.head_right, R.tail_left, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1], R.halo})
+            for (double *p : {R.hb, R.ht, R.head, R.tail, R.head_right, R.tail_left, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1], R.halo, R.sfc_avg})
                 if (p) (void)hipFree(p);
+            for (double *p : R.sref_b) if (p) (void)hipFree(p);
+            for (double *p : R.sref_t) if (p) (void)hipFree(p);
         }
         if (tr.destroy) tr.destroy(tr.ctx);
     }
@@ -471,6 +481,18 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     const int S_HQ3 = 3 + ns, S_P = 4 + ns;            // halo slots (Rank::lo, hi): 0..2 q, 3..2+ns s, then hq(3) and tmp1
     const bool fresh = d->fresh;       // start of a Runge-Kutta step: hq = hs = 0 (time.f90:212-216) -> the first term of every equation overwrites
     d->fresh = false;
+    // dynamic surface model: keep the old tendency of the scalar at the boundary (rhs_global_incompressible_1.f90:77-87); zero at the start of a step,
+    // when the tendencies COUNT as zero, and on the sides without a surface model (as rhs.cpp)
+    auto surface = [&](int is) { return !d->sfc_jmin.empty() && (d->sfc_jmin[is] == 1 || d->sfc_jmax[is] == 1); };
+    for (int is = 0; is < ns; ++is) {
+        if (!surface(is)) continue;
+        const size_t pbytes = (size_t)nx * kmax * sizeof(double);
+        for (Rank &R : d->rk) {
+            if (!fresh) hk(tlab::launch_get_wall_planes(R.hs[is], R.sref_b[is], R.sref_t[is], nx, ny, kmax, tlab_current_stream()), "k_get_wall_planes");
+            if (fresh || d->sfc_jmin[is] != 1) hk(hipMemsetAsync(R.sref_b[is], 0, pbytes, tlab_current_stream()), "hipMemsetAsync");
+            if (fresh || d->sfc_jmax[is] != 1) hk(hipMemsetAsync(R.sref_t[is], 0, pbytes, tlab_current_stream()), "hipMemsetAsync");
+        }
+    }
     const double idte = d->remove_divergence ? 1.0 / dte : 0.0;      // hq + 0 q is hq bit for bit: the same kernels serve the else-branch (as rhs.cpp)
     // The reference's DEFAULT walls (free-slip u, w; Neumann scalars: boundary_bcs.f90:102-190) without a derivative pass per Neumann field, as in the
     // single-domain driver (rhs.cpp): the wall tendency of BOUNDARY_BCS_NEUMANN_Y is a linear functional of the y line with weights that decay
@@ -503,7 +525,7 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     // Python driver's sequence)
     std::vector<int> zfin((size_t)(3 + ns), 0);
     for (int i = 0; i < ns; ++i)
-        zfin[3 + i] = tail && d->fused_x && (ibc_of(d->scal_jmin[i], d->scal_jmax[i]) == 0 || planes_route);
+        zfin[3 + i] = tail && d->fused_x && !surface(i) && (ibc_of(d->scal_jmin[i], d->scal_jmax[i]) == 0 || planes_route);
     // ---- diffusion + advection (:98-162) and the pressure forcing div(hq + q/dte) (:188-260) ----
     // (Measured in round 4 and dropped: the x and y terms of the forcing inside the Burgers launches that add the last term of u resp. v, as rhs.cpp
     // does on one device.  It needs u to end with its x term and v with its y term, i.e. the x and y launches split in two; on slabs of 64 planes the
@@ -535,16 +557,50 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     d->vf.armed = v_final; d->vf.dte = tdte; d->vf.kco = kco; d->vf.scale = scale;
     poisson_pencil(d);
     d->vf.armed = false;
+    // BOUNDARY_BCS_SURFACE_Y (boundary_bcs.f90:478-546) on slabs: d/dy of the scalar is local; AVG1V2D of its plane j = 1 (at BOTH ends, as the reference
+    // has it) is the average over all ranks -- local averages to the host, one all-reduce (sum) over the z communicator, the global average back to the
+    // device; the flux anomaly then goes into BcsScal%ref rank by rank.  A synchronising step: the model is a correctness feature of examples/Case88.
+    std::vector<double> sfc_avg_host;      // [scalar]: the global plane average of d s / dy, computed once per substep for every surface scalar
+    auto surface_averages = [&]() {
+        sfc_avg_host.assign((size_t)ns, 0.0);
+        bool any = false;
+        for (int is = 0; is < ns; ++is) any = any || surface(is);
+        if (!any) return;
+        const int L = (int)d->rk.size();
+        std::vector<double> v((size_t)L * ns, 0.0);
+        for (int is = 0; is < ns; ++is) {
+            if (!surface(is)) continue;
+            for (int l = 0; l < L; ++l) {
+                Rank &R = d->rk[l];
+                ok(tlab_opr_partial(2, d->g[1], TLAB_OPR_P1, nx, ny, kmax, 0, R.s[is], R.txc[4], nullptr), "OPR_Partial_Y (surface flux)");      // boundary_bcs.f90:508
+                hk(tlab::launch_plane_avg(R.txc[4], 0, nx, ny, kmax, R.sfc_avg, tlab_current_stream()), "k_plane_sum");
+                hk(hipMemcpyAsync(&v[(size_t)l * ns + is], R.sfc_avg, sizeof(double), hipMemcpyDeviceToHost, tlab_current_stream()), "hipMemcpyAsync");
+            }
+        }
+        hk(hipStreamSynchronize(tlab_current_stream()), "hipStreamSynchronize");
+        tck(d->tr.allreduce(d->tr.ctx, v.data(), ns, 2), "allreduce (sum)");            // sum of the ranks' plane averages
+        for (int is = 0; is < ns; ++is) sfc_avg_host[is] = v[is] / (double)d->P;
+    };
+    auto surface_flux_local = [&](Rank &R, int is) {
+        const double diff = d->visc / d->schmidt[is];
+        ok(tlab_opr_partial(2, d->g[1], TLAB_OPR_P1, nx, ny, kmax, 0, R.s[is], R.txc[4], nullptr), "OPR_Partial_Y (surface flux)");
+        hk(hipMemcpyAsync(R.sfc_avg, &sfc_avg_host[is], sizeof(double), hipMemcpyHostToDevice, tlab_current_stream()), "hipMemcpyAsync");
+        if (d->sfc_jmin[is] == 1)
+            hk(tlab::launch_surface_flux_avg(R.sref_b[is], R.txc[4], 0, 1.0, diff, d->cpl_jmin[is], R.sfc_avg, nx, ny, kmax, tlab_current_stream()), "k_surface_flux");
+        if (d->sfc_jmax[is] == 1)
+            hk(tlab::launch_surface_flux_avg(R.sref_t[is], R.txc[4], ny - 1, -1.0, diff, d->cpl_jmax[is], R.sfc_avg, nx, ny, kmax, tlab_current_stream()), "k_surface_flux");
+    };
+    surface_averages();
     // ---- hq -= grad p, boundary conditions (:348-398) [+ RK update] ----
     auto finish = [&](Rank &R) {
         struct Fd {
             double *q, *h, *g;
-            int tmin, tmax;
+            int tmin, tmax, is;
         };
         std::vector<Fd> F;
-        for (int i = 0; i < 3; ++i) F.push_back({R.q[i], R.hq[i], R.txc[1 + i], d->flow_jmin[i], d->flow_jmax[i]});
+        for (int i = 0; i < 3; ++i) F.push_back({R.q[i], R.hq[i], R.txc[1 + i], d->flow_jmin[i], d->flow_jmax[i], -1});
         for (int i = 0; i < ns; ++i)
-            if (!zfin[3 + i]) F.push_back({R.s[i], R.hs[i], nullptr, d->scal_jmin[i], d->scal_jmax[i]});
+            if (!zfin[3 + i]) F.push_back({R.s[i], R.hs[i], nullptr, d->scal_jmin[i], d->scal_jmax[i], i});
         if (grad_final) F.erase(F.begin() + 2), F.erase(F.begin());          // v and the scalars; u, w are done (+ their wall planes below)
         if (v_final) F.erase(F.begin());                                     // the scalars
         if (!grad_final && (!vel_dirichlet || !tail)) {
@@ -556,6 +612,13 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
             if (ibc)       // needs the finished tendency (g is null here)
                 ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, f.h, R.hb, R.ht, R.txc[0]), "tlab_boundary_bcs_neumann_y");
             const double *pb = (ibc & 1) ? R.hb : nullptr, *pt = (ibc & 2) ? R.ht : nullptr;
+            if (f.is >= 0 && surface(f.is)) {      // BcsScal%ref: the Neumann value replaces the kept tendency, the flux anomaly was added by surface_fluxes
+                const size_t pbytes = (size_t)nx * kmax * sizeof(double);
+                if (pb) hk(hipMemcpyAsync(R.sref_b[f.is], pb, pbytes, hipMemcpyDeviceToDevice, tlab_current_stream()), "hipMemcpyAsync");
+                if (pt) hk(hipMemcpyAsync(R.sref_t[f.is], pt, pbytes, hipMemcpyDeviceToDevice, tlab_current_stream()), "hipMemcpyAsync");
+                surface_flux_local(R, f.is);
+                pb = R.sref_b[f.is]; pt = R.sref_t[f.is];
+            }
             if (!tail) ok(tlab_pw_set_wall_planes(f.h, pb, pt, nx, ny, kmax), "tlab_pw_set_wall_planes");
             else ok(tlab_pw_final_update(f.q, f.h, f.g, pb, pt, tdte, kco, scale, nx, ny, kmax), "tlab_pw_final_update");
         }
@@ -766,6 +829,27 @@ int tlab_slab_dns_set_remove_divergence(tlab_slab_dns_t d, int on) {
     if (!d) return TLAB_EINVAL;
     d->remove_divergence = on != 0;
     return TLAB_OK;
+}
+
+int tlab_slab_dns_set_surface_bcs(tlab_slab_dns_t d, const int *sfc_jmin, const int *sfc_jmax, const double *cpl_jmin, const double *cpl_jmax) {
+    return guarded([&] {
+        if (!d || (d->nscal > 0 && (!sfc_jmin || !sfc_jmax || !cpl_jmin || !cpl_jmax))) throw Fail(TLAB_EINVAL, "tlab_slab_dns_set_surface_bcs: bad arguments");
+        for (int i = 0; i < d->nscal; ++i)
+            if ((sfc_jmin[i] != 0 && sfc_jmin[i] != 1) || (sfc_jmax[i] != 0 && sfc_jmax[i] != 1)) throw Fail(TLAB_EINVAL, "SfcType: 0 static or 1 linear");
+        d->sfc_jmin.assign(sfc_jmin, sfc_jmin + d->nscal); d->sfc_jmax.assign(sfc_jmax, sfc_jmax + d->nscal);
+        d->cpl_jmin.assign(cpl_jmin, cpl_jmin + d->nscal); d->cpl_jmax.assign(cpl_jmax, cpl_jmax + d->nscal);
+        for (Rank &R : d->rk) {
+            R.sref_b.resize(d->nscal, nullptr); R.sref_t.resize(d->nscal, nullptr);
+            for (int i = 0; i < d->nscal; ++i)
+                if ((sfc_jmin[i] == 1 || sfc_jmax[i] == 1) && !R.sref_b[i]) {
+                    R.sref_b[i] = dalloc((size_t)d->nx * d->kmax);
+                    R.sref_t[i] = dalloc((size_t)d->nx * d->kmax);
+                    hk(hipMemsetAsync(R.sref_b[i], 0, (size_t)d->nx * d->kmax * sizeof(double), tlab_current_stream()), "hipMemsetAsync");
+                    hk(hipMemsetAsync(R.sref_t[i], 0, (size_t)d->nx * d->kmax * sizeof(double), tlab_current_stream()), "hipMemsetAsync");
+                }
+            if (!R.sfc_avg) R.sfc_avg = dalloc(1);
+        }
+    });
 }
 
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d) {

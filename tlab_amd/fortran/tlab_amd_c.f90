@@ -324,6 +324,12 @@ module TLab_AMD_C
             import :: c_int, c_ptr
             type(c_ptr), value :: d
         end function
+        integer(c_int) function tlab_slab_dns_set_surface_bcs(d, sfc_jmin, sfc_jmax, cpl_jmin, cpl_jmax) bind(C, name='tlab_slab_dns_set_surface_bcs')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: d
+            integer(c_int), intent(in) :: sfc_jmin(*), sfc_jmax(*)
+            real(c_double), intent(in) :: cpl_jmin(*), cpl_jmax(*)
+        end function
         integer(c_int) function tlab_slab_dns_set_remove_divergence(d, on) bind(C, name='tlab_slab_dns_set_remove_divergence')
             import :: c_int, c_ptr
             type(c_ptr), value :: d

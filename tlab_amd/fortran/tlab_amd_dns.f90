@@ -128,16 +128,12 @@ contains
         type(tlab_slab_transport) :: tr
         type(c_ptr) :: pq(3), ps(16), phq(3), phs(16), ptxc(16)
         integer(c_int) :: rc, fj0(3), fj1(3), sj0(16), sj1(16)
-        real(c_double) :: sc(16)
+        real(c_double) :: sc(16), cp0(16), cp1(16)
         integer is
         if (.not. c_associated(slab)) then
             if (inb_scal > 16 .or. inb_txc < 9) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Slab_Handle: needs inb_scal <= 16 and inb_txc >= 9')
             ! what the z-slab driver does not build is REFUSED here, not dropped: the same tlab.ini must integrate the same equations on 1 and on N ranks
             ! (the anelastic formulation and dealiasing filters are refused inside tlab_slab_dns_create / _rhs from the operator state)
-            if (inb_scal > 0) then
-                if (any(BcsScalJmin%SfcType(1:inb_scal) /= 0) .or. any(BcsScalJmax%SfcType(1:inb_scal) /= 0)) &
-                    call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Slab_Handle: the dynamic surface model (BcsScal%SfcType) runs on one rank only (ims_npro_k = 1)')
-            end if
             call TLabMPI_Trp_AMD_Slab_Transport(tr)
             sc = 1.0_c_double
             sc(1:inb_scal) = schmidt(1:inb_scal)
@@ -147,6 +143,13 @@ contains
             call TLab_AMD_Check(rc, 'tlab_slab_dns_create')
             call TLab_AMD_Check(tlab_slab_dns_set_remove_divergence(slab, merge(1_c_int, 0_c_int, remove_divergence)), &     ! dns.ini [Main] TermDivergence
                                 'tlab_slab_dns_set_remove_divergence')
+            if (inb_scal > 0) then          ! dynamic surface model of the scalars (BcsScalJmin%SfcType, %cpl): its plane average is an all-reduce
+                sj0 = 0; sj1 = 0; cp0 = 0.0_c_double; cp1 = 0.0_c_double
+                sj0(1:inb_scal) = BcsScalJmin%SfcType(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%SfcType(1:inb_scal)
+                cp0(1:inb_scal) = BcsScalJmin%cpl(1:inb_scal); cp1(1:inb_scal) = BcsScalJmax%cpl(1:inb_scal)
+                if (any(sj0(1:inb_scal) /= 0) .or. any(sj1(1:inb_scal) /= 0)) &
+                    call TLab_AMD_Check(tlab_slab_dns_set_surface_bcs(slab, sj0, sj1, cp0, cp1), 'tlab_slab_dns_set_surface_bcs')
+            end if
             fj0 = BcsFlowJmin%type(1:3); fj1 = BcsFlowJmax%type(1:3)
             sj0 = 3; sj1 = 3
             sj0(1:inb_scal) = BcsScalJmin%type(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%type(1:inb_scal)

@@ -108,6 +108,7 @@ SIGNATURES = {
     "tlab_slab_dns_set_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "tlab_slab_dns_begin_step": (c_int, [c_vp]),
     "tlab_slab_dns_set_remove_divergence": (c_int, [c_vp, c_int]),
+    "tlab_slab_dns_set_surface_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
     "tlab_pencil_transport_loopback": (c_int, [c_vp, c_int, c_int]),
     "tlab_pencil_dns_create": (c_int, [ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, ctypes.POINTER(c_dbl)]),
     "tlab_pencil_dns_destroy": (c_int, [c_vp]),

@@ -109,7 +109,7 @@ def dist_transport(group=None):
     def red(ctx, values, n, op):
         try:
             t = torch.tensor([values[i] for i in range(n)], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 0 else dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 0 else (dist.ReduceOp.MIN if op == 1 else dist.ReduceOp.SUM), group=group)
             for i in range(n):
                 values[i] = float(t[i])
             return 0
@@ -206,6 +206,15 @@ class NativeSlabDns:
 
     def begin_step(self):
         check(load().tlab_slab_dns_begin_step(self._h), "tlab_slab_dns_begin_step")
+
+    def set_surface_bcs(self, sfc_jmin=None, sfc_jmax=None, coupling_jmin=None, coupling_jmax=None):
+        """As Dns.set_surface_bcs: Scalar<i>SfcTypeJmin/Jmax = "static" | "linear", Scalar<i>CouplingJmin/Jmax (boundary_bcs.f90:76-87)."""
+        ns = max(self.nscal, 1)
+        code = lambda v: [1 if str(t).lower() == "linear" else 0 for t in (v or ["static"] * ns)]      # noqa: E731
+        s0, s1 = (c_int * ns)(*code(sfc_jmin)[:ns]), (c_int * ns)(*code(sfc_jmax)[:ns])
+        c0 = (ctypes.c_double * ns)(*[float(v) for v in (coupling_jmin or [0.0] * ns)][:ns])
+        c1 = (ctypes.c_double * ns)(*[float(v) for v in (coupling_jmax or [0.0] * ns)][:ns])
+        check(load().tlab_slab_dns_set_surface_bcs(self._h, s0, s1, c0, c1), "tlab_slab_dns_set_surface_bcs")
 
     def set_remove_divergence(self, on):
         """dns.ini [Main] TermDivergence (as Dns.set_remove_divergence): off = the forcing of the pressure equation is div(hq) alone."""
