@@ -107,14 +107,17 @@ __device__ __forceinline__ void xhalo(XCtx<WPL> &c, const double (&u)[M], double
 // LDS layout of the constants of one system: 17 rows per lane [XRL][64 WPL] -- 0-5 k1, 6-11 k2, 12 dinv, 13 vs, 14 ws, 15 a_s, 16 c_s -- followed by the six
 // constants of the 2 x 2 interface systems, which are the same for all lanes of a wave: [6][WPL] -- wL, vF, dn, wLp, vFm, dp (chunked.cpp)
 constexpr int XRL = 17;
+// LDS pointers carry their address space in the type: the opaque copies below (asm) would otherwise degrade the generic pointers to flat loads
+typedef __attribute__((address_space(3))) const double ldsd_t;
+typedef __attribute__((address_space(3))) const float ldsf_t;
 template <int WPL, bool CL = false>
 struct XSys {                    // per-lane view of one chunked system
     const double *rowtab;        // global [5][n]
-    const double *lds;           // LV: [5][M][64 WPL] in LDS
+    ldsd_t *lds;                 // LV: [5][M][64 WPL] in LDS
     double k1[CL ? 1 : 6], k2[CL ? 1 : 6], dinv;   // PCR coefficients of this lane (WPL = 1: cyclic over the 64 chunks; WPL > 1: of the wave's isolated block)
     double a_s, c_s;             // separator-row couplings of this lane
     double vs, ws, wL, vF, dn, wLp, vFm, dp;      // WPL > 1: two-level reduction (chunked.hpp)
-    const double *red;           // CL: this lane's column of the constants in LDS (stride 64 WPL)
+    ldsd_t *red, *redw;          // CL: the constants in LDS, [XRL][64 WPL] per lane and [6][WPL] per wave (xsys_init)
 };
 
 // LV = 0: every chunk has the same tables (scalar loads of chunk 0); 1: lane-variant tables [5][M][P] doubles in LDS; 2: lane-variant tables
@@ -122,18 +125,26 @@ struct XSys {                    // per-lane view of one chunked system
 // The reconstruction is exact when the chunks differ by less than 2^-29 relative (the 1e-13 wander of a "uniform" reference grid): the plan
 // checks every entry on the host (xline_wide_ok, capi.cpp) and takes another kernel otherwise.
 template <int M, int LV, int WPL>
-__device__ __forceinline__ double xcoef(const double *rowtab, const double *lds, int tab, int p, int gl, int n) {
+__device__ __forceinline__ double xcoef(const double *rowtab, ldsd_t *lds, int tab, int p, int gl, int n) {
     constexpr int P = 64 * WPL;
     if (LV == 1) return lds[(tab * M + p) * P + gl];
-    if (LV == 2) return rowtab[tab * n + p] + (double)reinterpret_cast<const float *>(lds)[(tab * M + p) * P + gl];
+    if (LV == 2) return rowtab[tab * n + p] + (double)((ldsf_t *)lds)[(tab * M + p) * P];
     return rowtab[tab * n + p];  // lane-invariant: chunk 0's row p, wave-uniform address -> scalar load
 }
 template <int M, int LV, int WPL, bool CL>
 __device__ __forceinline__ void xsys_init(XSys<WPL, CL> &y, const SystemDev &sd, const double *lds, const double *red_lds, int gl, int n) {
     constexpr int P = 64 * WPL;
     y.rowtab = sd.rowtab;
-    y.lds = lds;
-    y.red = red_lds;
+    // float differences: per-lane pointers, opaque to the compiler -- behind 64 KB of tables every row of the constants would otherwise get an
+    // address register of its own (148 spilled VGPRs in the two-system form); with doubles (1024 points) its own addressing is 3 % faster
+    y.lds = LV == 2 ? (ldsd_t *)((ldsf_t *)lds + gl) : (ldsd_t *)lds;
+    y.red = (ldsd_t *)red_lds;
+    y.redw = (ldsd_t *)red_lds + XRL * P;
+    if constexpr (CL && LV == 2) {
+        y.red = (ldsd_t *)red_lds + gl;
+        y.redw = (ldsd_t *)red_lds + XRL * P + (gl >> 6);
+        asm volatile("" : "+v"(y.red), "+v"(y.redw));
+    }
     if constexpr (!CL) {
         const int src = (LV || WPL > 1) ? gl : 0;
     #pragma unroll
@@ -158,9 +169,9 @@ template <int M, int LV, int WPL, bool CL>
 __device__ __forceinline__ void xsolve(double (&f)[M], const XSys<WPL, CL> &y, XCtx<WPL> &c, int n) {
     constexpr int P = 64 * WPL;
     const int gl = c.gl, lane = c.lane;
-#define XR(row) y.red[(row) * P + gl]
-#define XW(q) y.red[XRL * P + (q) * WPL + c.wl]
-    const double *tl = y.lds;
+#define XR(row) y.red[(row) * P + (LV == 2 ? 0 : gl)]
+#define XW(q) y.redw[(q) * WPL + (LV == 2 ? 0 : c.wl)]
+    ldsd_t *tl = y.lds;
     double g = 0.0;
 #pragma unroll
     for (int p = 1; p < M; ++p) {
@@ -385,7 +396,7 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
                 } else {
                     xload<M>(u, src + off);
                 }
-                constexpr bool PIPE = (M <= 16);     // 32 rows per lane: the extra line-sets would spill
+                constexpr bool PIPE = (M <= 16) && !(CL && LV == 2 && LV2 == 2);     // 32 rows per lane: the extra line-sets would spill
                 double o[M];
                 if (PIPE && a.acc) xload<M>(o, dst + off);
                 have_next = PIPE && (f + 1 < a.nf) && (a.fs[f + 1] != a.in1);
@@ -990,6 +1001,11 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
     }
     if (chunks == 256 && n == 2048 && !lane_variant && !one_sys)
         return tpb == 256 ? launch_xline_m<8, 0, 4, 0, 256, true>(mode, a, st) : launch_xline_m<8, 0, 4, 0, 512, true>(mode, a, st);
+    // 2048 points, two systems, lane-variant tables: both as float differences (2 x 40 KB) + the constants in LDS (70 KB): 234 VGPRs, two lines per
+    // 512-thread workgroup, two waves per SIMD -- 2.79 TB/s against 2.67 for doubles + floats with the constants in registers (one wave per SIMD);
+    // TLAB_XLINE_FF=0 keeps that form
+    static const int ff = [] { const char *e = getenv("TLAB_XLINE_FF"); return e ? atoi(e) : 1; }();
+    if (chunks == 256 && n == 2048 && !one_sys && ff) return launch_xline_m<8, 2, 4, 2, 512, true>(mode, a, st);
     if (chunks == 256 && n == 2048)
         // one system (80 KB of tables): two lines per 512-thread workgroup share them, i.e. 8 waves per CU instead of 4
     {

@@ -765,6 +765,11 @@ __global__ void __launch_bounds__(256) k_int2(Int2Args a) {
 //     bound by dependent fp64 latency at 8 waves per CU, not by HBM, and the second pass doubled its time.)
 // HBM traffic per mode and row: f^ 16 B, p^ + dp^/dy 32 B, homogeneous solutions 40 B, checkpoints 12 B; no scratch.
 // ================================================================================================
+#ifndef ODE_KO
+#define ODE_KO 0
+#endif
+#define ODE_SYNC() do { if (!(ODE_KO & 1)) __syncthreads(); } while (0)
+#define ODE_DIV(x, y) ((ODE_KO & 4) ? (x) * (y) : (x) / (y))
 constexpr int OM = 8;   // rows per thread
 
 struct OdeSys {                  // Int1Dev without the by-value boundary constants (they would sit in ~100 SGPRs)
@@ -938,7 +943,7 @@ __device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[NL][2], 
     const int cw = lane / NM;                          // chunk index inside the wave
     // position along the sweep inside the wave: DIR = +1 -> cw, DIR = -1 -> reversed
 #pragma unroll
-    for (int d = 1; d < CPW; d <<= 1) {
+    for (int d = 1; d < ((ODE_KO & 2) ? 1 : CPW); d <<= 1) {
         double q[4], f[NL][2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = (DIR > 0) ? __shfl_up(phi[k], d * NM) : __shfl_down(phi[k], d * NM);
@@ -967,7 +972,7 @@ __device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[NL][2], 
 #pragma unroll
         for (int l = 0; l < NL; ++l) { s_w[(w * SW + 4 + 2 * l) * NM + m] = e[l][0]; s_w[(w * SW + 5 + 2 * l) * NM + m] = e[l][1]; }
     }
-    __syncthreads();
+    ODE_SYNC();
     // what enters my wave: the waves before it along the sweep, composed in order
     const int nw = (blockDim.x + 63) >> 6;
     double pe[NL][2];
@@ -1005,7 +1010,7 @@ __device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[NL][2], 
         in[l][0] = first_in_wave ? pe[l][0] : g1;
         in[l][1] = first_in_wave ? pe[l][1] : g2;
     }
-    __syncthreads();      // s_w is reused by the next scan
+    ODE_SYNC();      // s_w is reused by the next scan
 }
 
 // Per mode: the rows between which all five homogeneous solutions are below 1e-40 of their own maximum, found from the middle of the line
@@ -1058,7 +1063,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
         ode_boundary_rows<BC>(T, lam, k);
         ode_rows_to_lds<NM>(k, s_k, m);
     }
-    __syncthreads();
+    ODE_SYNC();
 #define KK(field, q) s_k[((field) + (q)) * NM + m]
 #define KRB(j, cc) s_k[(OK_RB + (j) * 4 + (cc)) * NM + m]
 #define KRT(j, cc) s_k[(OK_RT + (j) * 4 + (cc)) * NM + m]
@@ -1089,8 +1094,9 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
         const int j = j0 + p;
         const bool off = (p == 0 && lo) || (p == OM - 1 && hi);         // boundary rows
         double r[5];
+        if (ODE_KO & 16) { r[0] = 0.01 * lam; r[1] = 0.3; r[2] = 1.0 + lam; r[3] = 0.3; r[4] = 0.01; } else
         lhs_row_t(T, j, lam, r);
-        double c0 = T.R[(unsigned)(j * 3 + 0)], c1 = T.R[(unsigned)(j * 3 + 1)], c2 = 1.0, cb = 0.0, ct = 0.0;     // rhs = c0 f(j-1) + c1 f(j) + c2 f(j+1) + cb res0 + ct resN
+        double c0 = (ODE_KO & 16) ? 0.5 : T.R[(unsigned)(j * 3 + 0)], c1 = (ODE_KO & 16) ? 0.25 : T.R[(unsigned)(j * 3 + 1)], c2 = 1.0, cb = 0.0, ct = 0.0;     // rhs = c0 f(j-1) + c1 f(j) + c2 f(j+1) + cb res0 + ct resN
         if (p == 1 && lo) {
 #pragma unroll
             for (int q = 0; q < 5; ++q) r[q] = KK(OK_L1, q);
@@ -1115,18 +1121,18 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
         double a_m = 0.0, b_m = 0.0, cm = r[2], dm = r[3];
         const double em = r[4];
         if (p >= 3 || !lo) {
-            a_m = r[0] / st[3];
-            b_m = nf_msub(r[1], a_m, st[4]) / st[0];
+            a_m = ODE_DIV(r[0], st[3]);
+            b_m = ODE_DIV(nf_msub(r[1], a_m, st[4]), st[0]);
             cm = nf_msub(nf_msub(r[2], b_m, st[1]), a_m, st[5]);
             dm = nf_msub(r[3], b_m, st[2]);
         } else if (p == 2) {
-            b_m = r[1] / st[0];
+            b_m = ODE_DIV(r[1], st[0]);
             cm = nf_msub(r[2], b_m, st[1]);
             dm = nf_msub(r[3], b_m, st[2]);
         }
         if (off) { a_m = 0.0; b_m = 0.0; }
         am[p] = a_m; bm[p] = b_m;
-        FAC(p, 0) = off ? 1.0 : 1.0 / cm; FAC(p, 1) = off ? 0.0 : -dm; FAC(p, 2) = off ? 0.0 : -em;
+        FAC(p, 0) = off ? 1.0 : ODE_DIV(1.0, cm); FAC(p, 1) = off ? 0.0 : -dm; FAC(p, 2) = off ? 0.0 : -em;
         if (!off) {
             st[3] = st[0]; st[4] = st[1]; st[5] = st[2];
             st[0] = cm; st[1] = dm; st[2] = em;
@@ -1179,7 +1185,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
                 y[p][l] = v; y2[l] = y1[l]; y1[l] = v;
             }
     }
-    __syncthreads();
+    ODE_SYNC();
     // ---- backward substitution, same scheme downwards: in = (x[j0+8], x[j0+9]), out = (x[j0], x[j0+1]) ----
     {
         double x1[NL], x2[NL];
@@ -1216,7 +1222,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
             }
         }
     }
-    __syncthreads();
+    ODE_SYNC();
     // ---- boundary value at the free end, derivative at the given end (fdm_integral.f90:265-311) ----
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -1237,7 +1243,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
             }
         }
     }
-    __syncthreads();       // s_k is rewritten by the next solve
+    ODE_SYNC();       // s_k is rewritten by the next solve
 #undef KK
 #undef KRB
 #undef KRT
@@ -1318,7 +1324,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // halo rows of v0 for the right-hand side of the u-solve
 #pragma unroll
     for (int l = 0; l < NL; ++l) { s_x[((c * NL + l) * 2 + 0) * NM + m] = vh[1][l]; s_x[((c * NL + l) * 2 + 1) * NM + m] = vh[OMR][l]; }
-    __syncthreads();
+    ODE_SYNC();
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         vh[0][l] = (c > 0) ? s_x[(((c - 1) * NL + l) * 2 + 1) * NM + m] : 0.0;
@@ -1340,7 +1346,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
         if (c == 0) SC(2, l) = u[0][l];
         if (c == C - 1) SC(4, l) = ext[l];
     }
-    __syncthreads();
+    ODE_SYNC();
     if (DD) {      // :452-456
         const double aa = a.cst[(unsigned)(0 * nm + t)], bc = a.cst[(unsigned)(1 * nm + t)], dummy = a.cst[(unsigned)(2 * nm + t)];
         const double sp1 = a.cst[(unsigned)(3 * nm + t)], u11 = a.cst[(unsigned)(4 * nm + t)];
@@ -1371,7 +1377,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // their maximum a few tens of rows away from the walls, where adding them changes no bit of the sum.  The plan records that band per
     // mode (k_ode_hom_band); chunks inside it skip the five loads (40 of the 100 B per mode and row this kernel would otherwise move).
     bool need = true;
-    if (a.band != nullptr) need = (j0 <= a.band[t]) || (j0 + OMR - 1 >= a.band[nm + t]);
+    if (ODE_KO & 8) need = false; else if (a.band != nullptr) need = (j0 <= a.band[t]) || (j0 + OMR - 1 >= a.band[nm + t]);
 #pragma unroll
     for (int p = 0; p < OMR; ++p) {
         const int j = j0 + p;
@@ -2113,6 +2119,13 @@ struct tlab_poisson_plan {
     void x_backward_dpdy(void *in, double *dpdy, hipStream_t st, const VFinal &f) {
         if (f.armed && fx_own) fx_own->exec_inverse_final(static_cast<const double *>(in), f.q, f.h, f.dte, f.kco, f.scale, ny, st);
         else fx_c2r.exec(in, dpdy, st);
+    }
+    // inverse x-transform of p^: rocFFT's c2r runs at the copy rate at 512 points but at 2.1 TB/s from 1024 on (4.06 ms per call on one rank's share of
+    // BASELINE configs[4], where the own kernel moves the same bytes at 5.9 TB/s); TLAB_FFTX_C2R_OWN = 0 / 1 forces the choice
+    void x_backward_p(void *in, double *p, hipStream_t st) {
+        static const int own = [] { const char *e = getenv("TLAB_FFTX_C2R_OWN"); return e ? atoi(e) : -1; }();
+        if (fx_own && (own == 1 || (own < 0 && nx >= 1024))) fx_own->exec_inverse(static_cast<const double *>(in), p, st);
+        else fx_c2r.exec(in, p, st);
     }
     void x_forward(void *in, void *out, hipStream_t st) {
         if (fx_own) fx_own->exec(static_cast<const double *>(in), static_cast<double *>(out), st);
@@ -3096,9 +3109,9 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
         if (nz > 1) {
             if (P->fz_own) P->fz_own->exec(-1, tmp1, P->cwork.p, st);
             else P->fz_b.exec(tmp1, P->cwork.p, st);
-            P->fx_c2r.exec(P->cwork.p, p, st);
+            P->x_backward_p(P->cwork.p, p, st);
         } else {
-            P->fx_c2r.exec(tmp1, p, st);
+            P->x_backward_p(tmp1, p, st);
         }
         if (dpdy) {     // :447-449, with the y plan of the derivatives
             const int rc = tlab_opr_partial(2, P->gy_der, TLAB_OPR_P1, nx, ny, nz, 0, p, dpdy, tmp1);
@@ -3128,14 +3141,14 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
     } else if (nz > 1) {
         if (P->fz_own) P->fz_own->exec(-1, tmp1, P->cwork.p, st);
         else P->fz_b.exec(tmp1, P->cwork.p, st);
-        P->fx_c2r.exec(P->cwork.p, p, st);
+        P->x_backward_p(P->cwork.p, p, st);
         if (dpdy) {
             if (P->fz_own) P->fz_own->exec(-1, tmp2, P->cwork.p, st);
             else P->fz_b.exec(tmp2, P->cwork.p, st);
             P->x_backward_dpdy(P->cwork.p, dpdy, st, vf);
         }
     } else {
-        P->fx_c2r.exec(tmp1, p, st);
+        P->x_backward_p(tmp1, p, st);
         if (dpdy) P->x_backward_dpdy(tmp2, dpdy, st, vf);
     }
     POISSON_GUARD_END
@@ -3267,9 +3280,9 @@ int tlab_opr_helmholtz(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, d
     } else if (nz > 1) {
         if (P->fz_own) P->fz_own->exec(-1, tmp1, P->cwork.p, st);
         else P->fz_b.exec(tmp1, P->cwork.p, st);
-        P->fx_c2r.exec(P->cwork.p, a, st);
+        P->x_backward_p(P->cwork.p, a, st);
     } else {
-        P->fx_c2r.exec(tmp1, a, st);
+        P->x_backward_p(tmp1, a, st);
     }
     POISSON_GUARD_END
 }
