@@ -283,7 +283,8 @@ def test_other_scalar_counts(T, nscal):
 @pytest.mark.parametrize("nx,ny,nz,nscal,stretch", [
     (1024, 512, 16, 1, False),      # configs[3]: x lines of 1024, y lines of 512 (z lines of 1024: test_gpu_slab.py)
     (2048, 1024, 8, 3, True),       # configs[4]: x lines of 2048, stretched y lines of 1024, 3 scalars
-    (16, 32, 2048, 1, False)])      # z lines of 2048 on one device (own z-FFT of length 2048, 64-row tiles)
+    (16, 32, 2048, 1, False),       # z lines of 2048 on one device (own z-FFT of length 2048, 64-row tiles)
+    (32, 16, 1024, 1, False)])      # z lines of 1024 on one device: the first derivatives with their fused epilogues on k_htile's 32-line tiles
 def test_line_lengths_of_the_large_configs(T, nx, ny, nz, nscal, stretch, exact):
     """Full substeps against the oracle with the LINE LENGTHS of configs[3] and configs[4] (BASELINE.json) and the other extents reduced so
     that the numpy oracle finishes in seconds: every kernel selection that depends on n is exercised at its real n.

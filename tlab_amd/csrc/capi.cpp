@@ -757,6 +757,10 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.in0 = in0; a.in1 = nullptr; a.in2 = vel; a.out0 = out0; a.out1 = out1; a.g = geom; a.nu = nu;
     a.in0b = nullptr; a.in0b_scale = 0.0; a.acc = ex.acc ? 1 : 0;
     a.fq = nullptr; a.fdte = 0.0; a.fkco = 1.0; a.fscale = 0; a.fnx = 1; a.fny = 1; a.fpb = nullptr; a.fpt = nullptr;
+    if (mode == MODE_P1) {      // the epilogues of k_rtile<P1> (run_p1_tile)
+        a.in0b = ex.in0b; a.in0b_scale = ex.scale; a.acc = ex.sub ? 2 : (ex.acc ? 1 : 0);
+        a.fq = ex.fq; a.fdte = ex.fdte; a.fkco = ex.fkco; a.fscale = ex.fscale; a.fnx = ex.fnx; a.fny = ex.fny; a.fpb = ex.fpb; a.fpt = ex.fpt;
+    }
     a.nf = ex.nf > 0 ? ex.nf : 1;
     for (int f = 0; f < 4; ++f) { a.fs[f] = ex.nf > 0 ? ex.fs[f] : in0; a.fo[f] = ex.nf > 0 ? ex.fo[f] : out0; a.fnu[f] = ex.nf > 0 ? ex.fnu[f] : nu; }
     a.s1 = g->stencil(1, ibc);
@@ -767,6 +771,20 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
     a.fresh_mask = ex.fresh_mask; a.fdiv = ex.fdiv; a.fidte = ex.fidte;
     a.ari = ex.ari; a.ari_mode = ex.ari_mode; a.ari_nx = ex.ari_nx; a.ari_ny = ex.ari_ny;
     hip_check(launch_htile(mode, a, g_stream), "k_htile");
+}
+
+// One line-set (first derivative, with or without the fused epilogues) along y or z.  k_rtile's 64-line tiles are the best form while a chunk of
+// the line fits the 128 VGPRs of its 1024-thread launch (32 rows, lines up to 512 points); at 1024 points its chunks are 64 rows and it spills
+// 431 VGPRs (3.0 TB/s for the final z gradient of BASELINE configs[3]) -- those lines take k_htile's 32-line tiles (32 chunks of 32 rows, 126 VGPRs),
+// which carries the same epilogues except the Neumann-final one (y lines only).
+void run_p1_tile(tlab_fdm_plan_t g, const LineGeom &geom, int ibc, const double *u, double *result, const OpExtra &ex = kNoExtra) {
+    static const bool off = [] { const char *e = getenv("TLAB_P1_HTILE"); return e && atoi(e) == 0; }();
+    const int mr = rtile_chunk(geom.n);
+    const bool rtile_spills = mr == 64 && geom.n / 64 > 8;
+    if (!off && rtile_spills && ex.fneu == 0 && htile_chunk(geom.n, MODE_P1) == 32 && g_htile_policy != 1)
+        run_htile(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0, ex);
+    else
+        run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0, ex);
 }
 
 void run_xline(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const double *in0, const double *in1,
@@ -823,7 +841,7 @@ bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, 
     if (path == PATH_XLINE) {
         run_xline(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0, ex);
     } else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) {
-        run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0, ex);
+        run_p1_tile(g, geom, ibc, u, result, ex);
     } else {
         return false;
     }
@@ -862,7 +880,7 @@ bool tlab_internal_partial_p1_sub(int dir, tlab_fdm_plan_t g, int nx, int ny, in
     ex.sub = true;
     const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE) run_xline(g, geom, MODE_P1, 0, u, nullptr, result, nullptr, 0.0, ex);
-    else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_rtile(g, geom, MODE_P1, 0, u, nullptr, nullptr, result, 0.0, ex);
+    else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_p1_tile(g, geom, 0, u, result, ex);
     else return false;
     g_last_path = path;
     return true;
@@ -903,7 +921,7 @@ bool tlab_internal_gradient_final(int dir, tlab_fdm_plan_t g, int nx, int ny, in
     ex.fq = q; ex.fdte = dte; ex.fkco = kco; ex.fscale = scale; ex.fnx = nx; ex.fny = ny; ex.fpb = pb; ex.fpt = pt;
     const int path = choose_path(dir, geom.n, g);
     if (path == PATH_XLINE) run_xline(g, geom, MODE_P1, 0, p, nullptr, h, nullptr, 0.0, ex);
-    else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_rtile(g, geom, MODE_P1, 0, p, nullptr, nullptr, h, 0.0, ex);
+    else if (path == PATH_RTILE && rtile_chunk(geom.n) > 0) run_p1_tile(g, geom, 0, p, h, ex);
     else return false;
     g_last_path = path;
     return true;
@@ -1156,7 +1174,7 @@ int tlab_opr_partial(int dir, tlab_fdm_plan_t g, int type, int nx, int ny, int n
         } else if (path == PATH_RTILE) {
             const bool r64 = rtile_chunk(geom.n) > 0 && g_htile_policy != 2;     // 64-line tiles: best for one line-set
             if (type == TLAB_OPR_P1) {
-                if (r64) run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0);
+                if (r64) run_p1_tile(g, geom, ibc, u, result);
                 else run_htile(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0);
             } else if (type == TLAB_OPR_P2_P1 && htile_ok(geom.n, MODE_P2_P1)) {
                 run_htile(g, geom, MODE_P2_P1, ibc, u, nullptr, result, tmp1, 0.0);              // fused, one load of u

@@ -213,6 +213,29 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
         e[k] = okl ? in0[base + (long long)rl * rs] : 0.0;
         e[M + 3 + k] = okr ? in0[base + (long long)rr * rs] : 0.0;
     }
+    if constexpr (MODE == MODE_P1) {
+        if (a.in0b != nullptr) {   // operand = in0 + s * in0b (same rows, same halos), as in k_rtile
+            gchar *r = H_ROW0(a.in0b);
+#pragma unroll
+            for (int p0 = 0; p0 < M; p0 += 8) {      // 8 rows in flight: the operand rows are all live here (128 VGPRs on 1024 threads)
+                double t[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { t[p] = *H_AT(r); H_NEXT(r); }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) e[p0 + p + 3] = e[p0 + p + 3] + t[p] * a.in0b_scale;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int rl = row0 - 3 + k, rr = row0 + M + k;
+                const bool okl = per || rl >= 0, okr = per || rr < n;
+                if (rl < 0) rl += n;
+                if (rr >= n) rr -= n;
+                if (okl) e[k] = e[k] + a.in0b[base + (long long)rl * rs] * a.in0b_scale;
+                if (okr) e[M + 3 + k] = e[M + 3 + k] + a.in0b[base + (long long)rr * rs] * a.in0b_scale;
+            }
+        }
+    }
 
 
     // stage the tables once per workgroup: the two halves of a wave work on different rows, so the coefficient rows are not
@@ -320,8 +343,44 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
     if (valid) {
     gchar *ro = H_ROW0(out0);
     if constexpr (MODE == MODE_P1) {
+        if (a.fq != nullptr) {
+            // final-update epilogue of k_rtile (z-direction lines: lane = (ix, j) inside the plane, rows = k): h -= dp/dz, wall planes, q += dte h, h *= kco;
+            // 8 rows at a time (the 1024-thread launch has 128 VGPRs)
+            const int li = l0 + l32;
+            const int j = (li / a.fnx) % a.fny;
+            const bool wall = (j == 0) || (j == a.fny - 1);
+            const double *wp = wall ? (j == 0 ? a.fpb : a.fpt) : nullptr;      // given wall tendencies (Neumann walls), or zero
+            if (wp != nullptr) wp += li % a.fnx;
+            gchar *rq = H_ROW0(a.fq);
 #pragma unroll
-        for (int p = 0; p < M; ++p) { *H_AT(ro) = x1[p]; H_NEXT(ro); }
+            for (int p0 = 0; p0 < M; p0 += 8) {
+                double h[8], qv[8];
+                gchar *rh2 = ro, *rq2 = rq;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { h[p] = *H_AT(rh2); qv[p] = *H_AT(rq2); H_NEXT(rh2); H_NEXT(rq2); }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const double hv = wall ? (wp ? wp[(long long)(row0 + p0 + p) * a.fnx] : 0.0) : h[p] - x1[p0 + p];
+                    qv[p] = qv[p] + a.fdte * hv;
+                    h[p] = a.fscale ? a.fkco * hv : hv;
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { *H_AT(rq) = qv[p]; *H_AT(ro) = h[p]; H_NEXT(rq); H_NEXT(ro); }
+            }
+        } else if (a.acc) {      // result = old +- derivative: loads first, 8 rows at a time
+#pragma unroll
+            for (int p0 = 0; p0 < M; p0 += 8) {
+                double o[8];
+                gchar *r2 = ro;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { o[p] = *H_AT(r2); H_NEXT(r2); }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { *H_AT(ro) = (a.acc == 2) ? o[p] - x1[p0 + p] : o[p] + x1[p0 + p]; H_NEXT(ro); }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < M; ++p) { *H_AT(ro) = x1[p]; H_NEXT(ro); }
+        }
     } else if constexpr (MODE == MODE_P2) {
 #pragma unroll
         for (int p = 0; p < M; ++p) { *H_AT(ro) = x2[p]; H_NEXT(ro); }
@@ -668,6 +727,7 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
                        a.fdiv ? "k_htile<BURGERS+div>" : "k_htile<BURGERS>";
     const double bpp = (mode == MODE_P1 || mode == MODE_P2) ? 16 : 24;
     double bytes = pts * (bpp + (a.acc ? 8 : 0));
+    if (mode == MODE_P1) bytes += pts * ((a.in0b ? 8 : 0) + (a.fq ? 24 : 0));
     if (mode == MODE_BURGERS) {   // velocity once (re-reads are L2 hits by construction) + per field: operand unless it is the velocity, result, old result
         bytes = pts * 8;
         for (int f = 0; f < a.nf; ++f) bytes += pts * ((a.fs[f] == a.in2 ? 0 : 8) + 8 + ((a.acc && !((a.fresh_mask >> f) & 1u)) ? 8 : 0));
