@@ -363,7 +363,24 @@ SystemEntry &tlab_fdm_plan::system(int which, int ibc, int P) {
                     }
                 }
         e->chunk_invariant = ci;
-        if (getenv("TLAB_DEBUG_TABLES")) fprintf(stderr, "system n=%d P=%d periodic=%d: lane_invariant %d chunk_invariant %d (largest interior difference %lld ulp)\n", n, P, (int)h.periodic, (int)inv, (int)ci, worst);
+        bool band = P >= 8 && P <= 32 && (P & (P - 1)) == 0 && h.ginv.size() == (size_t)P * P;
+        if (band) {
+            double dmax = 0.0, omax = 0.0;
+            std::vector<double> gb((size_t)P * 5, 0.0);
+            for (int c = 0; c < P; ++c)
+                for (int q = 0; q < P; ++q) {
+                    int d = q - c;
+                    if (d > P / 2) d -= P;
+                    if (d < -P / 2) d += P;
+                    const double v = h.ginv[(size_t)c * P + q];
+                    if (d >= -2 && d <= 2) { gb[(size_t)c * 5 + d + 2] = v; if (d == 0) dmax = std::max(dmax, std::fabs(v)); }
+                    else omax = std::max(omax, std::fabs(v));
+                }
+            band = omax <= 1e-30 * dmax;
+            if (band) e->band.upload(gb);
+        }
+        e->band_ok = band;
+        if (getenv("TLAB_DEBUG_TABLES")) fprintf(stderr, "system n=%d P=%d periodic=%d: lane_invariant %d chunk_invariant %d (largest interior difference %lld ulp) banded inverse %d\n", n, P, (int)h.periodic, (int)inv, (int)ci, worst, (int)band);
     }
     SystemEntry &ref = *e;
     systems[key] = std::move(e);

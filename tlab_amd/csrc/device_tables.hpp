@@ -26,6 +26,9 @@ struct SystemDev {
     const double *red;      // wave-per-line kernel: [13][64] = k1[6][64], k2[6][64], dinv[64]; register-tile kernel: ginv[P][P]
     int lane_invariant;     // 1: every chunk has the same tables (circulant, uniform grid) -> scalar loads of chunk 0
     int chunk_invariant;    // 1: every INTERIOR chunk (1 .. P-2) has the tables of chunk 1 to the bit (uniform grid; walls only touch the first / last chunk)
+    const double *band;     // register-tile kernels, P <= 32: ginv[c][(c + d) mod P], d = -2 .. 2, as [P][5] -- or NULL when the entries further from the
+                            // diagonal are not negligible (they fall off like 0.38^(rows per chunk) per chunk for the compact schemes: 1e-27 at distance 2
+                            // with 32-row chunks).  k_ptile keeps this form where the full matrices do not fit beside its tile.
 };
 
 // Jacobian correction of the second derivative on non-uniform grids: f += A2 dx2 du (MatMul_3d_add, fdm_matmul.f90:126-153)

@@ -49,7 +49,8 @@ __device__ __forceinline__ double h_dense6(const double (&c)[6], double a0, doub
 }
 
 // local Thomas solve of one chunk + separator system through LDS.  f: right-hand side in, solution out.
-template <int M, int L>
+// BAND: ginv holds the five central cyclic diagonals [C][5] of the inverse (SystemDev::band; C a power of two), the rest being negligible
+template <int M, int L, bool BAND = false>
 __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, const double *ginv, int n, int row0, int c, int C, int l32,
                                         double *s_yl, double *s_r) {
     const double *Lm = rowtab + row0, *Di = rowtab + n + row0, *Cm = rowtab + 2 * n + row0;
@@ -73,11 +74,19 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
     s_r[c * L + l32] = f[0] - Lm[0] * yLprev - Cm[0] * f[1];
     __syncthreads();
     double X = 0.0, Xr = 0.0;
-    const double *g0 = ginv + c * C, *g1 = ginv + cp * C;
-    for (int q = 0; q < C; ++q) {
-        const double rq = s_r[q * L + l32];
-        X += g0[q] * rq;
-        Xr += g1[q] * rq;
+    if constexpr (BAND) {
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            X += ginv[c * 5 + d] * s_r[((c + d - 2) & (C - 1)) * L + l32];
+            Xr += ginv[cp * 5 + d] * s_r[((cp + d - 2) & (C - 1)) * L + l32];
+        }
+    } else {
+        const double *g0 = ginv + c * C, *g1 = ginv + cp * C;
+        for (int q = 0; q < C; ++q) {
+            const double rq = s_r[q * L + l32];
+            X += g0[q] * rq;
+            Xr += g1[q] * rq;
+        }
     }
     f[0] = X;
 #pragma unroll
@@ -87,7 +96,7 @@ __device__ __forceinline__ void h_solve(double (&f)[M], const double *rowtab, co
 // Both systems of OPR_Burgers / OPR_P2_P1 at once (uniform grids: the second right-hand side does not need the first solution): two independent
 // recurrences per lane hide the latency of the dependent fp64 multiply-adds (two waves per SIMD do not), and the two separator systems share their
 // two barriers.  Same operations per system, in the same order, as h_solve.
-template <int M, int L>
+template <int M, int L, bool BAND = false>
 __device__ __forceinline__ void h_solve2(double (&f)[M], double (&h)[M], const double *tf, const double *th, const double *gif, const double *gih, int n,
                                          int row0, int c, int C, int l32, double *s_ylf, double *s_rf, double *s_ylh, double *s_rh) {
     // (n = distance between the five arrays of a table, row0 = first row of the chunk in them: (n, c M) for the full tables, (M, 0) for a chunk's own copy)
@@ -117,13 +126,24 @@ __device__ __forceinline__ void h_solve2(double (&f)[M], double (&h)[M], const d
     s_rh[c * L + l32] = h[0] - Lh[0] * s_ylh[cm * L + l32] - Ch[0] * h[1];
     __syncthreads();
     double Xf = 0.0, Xrf = 0.0, Xh = 0.0, Xrh = 0.0;
-    const double *g0f = gif + c * C, *g1f = gif + cp * C, *g0h = gih + c * C, *g1h = gih + cp * C;
-    for (int q = 0; q < C; ++q) {
-        const double rf = s_rf[q * L + l32], rh = s_rh[q * L + l32];
-        Xf += g0f[q] * rf;
-        Xrf += g1f[q] * rf;
-        Xh += g0h[q] * rh;
-        Xrh += g1h[q] * rh;
+    if constexpr (BAND) {
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            const int q0 = ((c + d - 2) & (C - 1)) * L + l32, q1 = ((cp + d - 2) & (C - 1)) * L + l32;
+            Xf += gif[c * 5 + d] * s_rf[q0];
+            Xrf += gif[cp * 5 + d] * s_rf[q1];
+            Xh += gih[c * 5 + d] * s_rh[q0];
+            Xrh += gih[cp * 5 + d] * s_rh[q1];
+        }
+    } else {
+        const double *g0f = gif + c * C, *g1f = gif + cp * C, *g0h = gih + c * C, *g1h = gih + cp * C;
+        for (int q = 0; q < C; ++q) {
+            const double rf = s_rf[q * L + l32], rh = s_rh[q * L + l32];
+            Xf += g0f[q] * rf;
+            Xrf += g1f[q] * rf;
+            Xh += g0h[q] * rh;
+            Xrh += g1h[q] * rh;
+        }
     }
     f[0] = Xf;
     h[0] = Xh;
@@ -480,12 +500,15 @@ __global__ void __launch_bounds__(MAXT, ((L == 16 && MAXT == 256) ? 2 : 1)) k_ht
 // explicit vmcnt(0) before the stores states it.
 // DIV: the one-field launch of the velocity component of this direction with the forcing term of the pressure equation as a third solve (k_htile's DIV);
 // the operand IS the advecting velocity then, which is taken from the LDS tile instead of a second load.
-template <int M, int L, int C, bool DIV = false>
+// <32, 16, 32, ., BAND>: lines of 1024 points in 16-line tiles (the same 128 KiB); the separator inverses (2 x 32 x 32 doubles) no longer fit beside the
+// tile and are kept as their five central diagonals (SystemDev::band: what lies further out is below 1e-30 of the diagonal, checked per plan).
+template <int M, int L, int C, bool DIV = false, bool BAND = false>
 __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitems) {
     constexpr int N = M * C;                 // points per line
+    constexpr int GI = BAND ? 5 * C : C * C; // separator inverse of one system
     __shared__ double s_sep[4 * C * L];      // s_yl, s_r of both systems
     __shared__ double s_t[2 * 3 * 5 * M];    // [system][first / interior / last chunk][Lm, Dinv, Cm, V, W][M]
-    __shared__ double s_gi[2 * C * C];
+    __shared__ double s_gi[2 * GI];
     extern __shared__ double s_op[];         // operand tile [N][L]
     const int l32 = threadIdx.x & (L - 1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -504,9 +527,9 @@ __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitem
         const int chunk = v == 0 ? 0 : (v == 1 ? 1 : C - 1);
         s_t[i] = (sys == 0 ? a.y1.rowtab : a.y2.rowtab)[arr * N + chunk * M + p];
     }
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
-        s_gi[i] = a.y1.red[i];
-        s_gi[C * C + i] = a.y2.red[i];
+    for (int i = threadIdx.x; i < GI; i += blockDim.x) {
+        s_gi[i] = BAND ? a.y1.band[i] : a.y1.red[i];
+        s_gi[GI + i] = BAND ? a.y2.band[i] : a.y2.red[i];
     }
     const int var = (c == 0) ? 0 : (c == C - 1 ? 2 : 1);
     const double *t1 = s_t + var * 5 * M, *t2 = s_t + (3 + var) * 5 * M;
@@ -517,9 +540,11 @@ __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitem
         fi = (int)(q % a.nf);
         tile = (it & 7) + 8 * (q / a.nf);
     };
-    // LDS-DMA of the operand tile of an item: wave w brings rows [64 w, 64 w + 64), 4 rows (1 KiB) per instruction, lane = (row in the four, 16-B piece)
+    // LDS-DMA of the operand tile of an item: wave w brings rows [RW w, RW w + RW), 1 KiB (RI rows of L doubles) per instruction, lane = (row of the
+    // instruction, 16-B piece of the row)
+    constexpr int PR = L / 2, RI = 64 / PR, RW = N / (L * C / 64), NI = RW / RI;      // pieces per row, rows per instruction, rows per wave, instructions
     const unsigned lane = threadIdx.x & 63;
-    const unsigned dma_voff = (unsigned)(((long long)(lane >> 4) * rs + (lane & 15) * 2) * 8);
+    const unsigned dma_voff = (unsigned)(((long long)(lane / PR) * rs + (lane % PR) * 2) * 8);
     const unsigned lds_base = (unsigned)(unsigned long long)s_op;
     auto prefetch = [&](long long it) {
         long long tile;
@@ -528,18 +553,18 @@ __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitem
         if (tile >= ntiles) return;
         const long long outer = tile / tiles_inner;
         const int l0 = (int)(tile % tiles_inner) * L;
-        gchar *src = sgpr_ptr(a.fs[fi] + outer * a.g.outer_stride + l0 + (long long)(64 * wv) * rs);
-        unsigned dst = lds_base + (unsigned)(64 * wv) * (L * 8);
-        const long long step = 4 * rs8;
+        gchar *src = sgpr_ptr(a.fs[fi] + outer * a.g.outer_stride + l0 + (long long)(RW * wv) * rs);
+        unsigned dst = lds_base + (unsigned)(RW * wv) * (L * 8);
+        const long long step = RI * rs8;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NI; ++j) {
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
                          : "v"(dma_voff), "s"(src), "s"(dst)
                          : "memory");
             src = sgpr_ptr(src + step);
-            dst += 4 * L * 8;
+            dst += RI * L * 8;
         }
     };
 
@@ -613,7 +638,7 @@ __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitem
 #pragma unroll
             for (int p = 0; p < M; ++p) { vl[p] = *H_AT(r); H_NEXT(r); }
         }
-        h_solve2<M, L>(x1, x2, t1, t2, s_gi, s_gi + C * C, M, 0, c, C, l32, s_sep, s_sep + C * L, s_sep + 2 * C * L, s_sep + 3 * C * L);
+        h_solve2<M, L, BAND>(x1, x2, t1, t2, s_gi, s_gi + GI, M, 0, c, C, l32, s_sep, s_sep + C * L, s_sep + 2 * C * L, s_sep + 3 * C * L);
 
         // ---- epilogue: result = nu d2 - vel d1 (opr_burgers.f90:513), accumulated into the tendency ----
 #pragma unroll
@@ -664,7 +689,7 @@ __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitem
                     for (int r = 0; r < 3; ++r) gg[M - 3 + r] = h_dense6(a.s1.bt[r], tt[M - 3], tt[M - 2], tt[M - 1], tt[M], tt[M + 1], tt[M + 2]);
                 }
             }
-            h_solve<M, L>(gg, t1, s_gi, M, 0, c, C, l32, s_sep, s_sep + C * L);
+            h_solve<M, L, BAND>(gg, t1, s_gi, M, 0, c, C, l32, s_sep, s_sep + C * L);
             double fo[M];
             gchar *r = H_ROW0(a.fdiv);
 #pragma unroll
@@ -682,6 +707,9 @@ __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitem
 }
 
 static int g_htile_persist = [] { const char *e = getenv("TLAB_HTILE_PERSIST"); return (e && atoi(e) == 0) ? 0 : 1; }();      // 0: k_htile<UNI> instead of k_ptile (A/B)
+// 512-point lines: the banded separator inverses as well -- 2.07 -> 2.00 ms for the three-field launch, 1.05 -> 1.10 ms for the one with the forcing term
+// (A/B on one box): 1 = the first only (default), 2 = both, 0 = neither
+static int g_ptile_band = [] { const char *e = getenv("TLAB_PTILE_BAND"); return e ? atoi(e) : 1; }();
 static int g_ncu = 0;
 static long long ptile_cus() {
     if (!g_ncu) {
@@ -693,8 +721,12 @@ static long long ptile_cus() {
     return g_ncu;
 }
 // the persistent kernel takes 512-point lines in 32-line tiles whose tables are the same for every interior chunk (periodic z of a uniform grid)
+// ... or 1024-point lines in 16-line tiles whose separator inverses are banded (five diagonals of them in LDS)
 static bool ptile_ok(const RTileArgs &a, int L, int C) {
-    return g_htile_persist && L == 32 && C == 16 && a.g.n == 512 && a.g.lines_inner % 32 == 0 && a.y1.chunk_invariant && a.y2.chunk_invariant;
+    if (!g_htile_persist || a.g.lines_inner % L != 0 || !a.y1.chunk_invariant || !a.y2.chunk_invariant) return false;
+    if (L == 32 && C == 16 && a.g.n == 512) return true;
+    static const bool long_ok = [] { const char *e = getenv("TLAB_PTILE_1024"); return !(e && atoi(e) == 0); }();
+    return long_ok && L == 16 && C == 32 && a.g.n == 1024 && a.y1.band != nullptr && a.y2.band != nullptr;
 }
 static int g_htile_uni = [] { const char *e = getenv("TLAB_HTILE_UNI"); return (e && atoi(e) == 0) ? 0 : 1; }();      // 0: general kernel on uniform grids too (A/B)
 static int g_htile_lines = [] { const char *e = getenv("TLAB_HTILE_LINES"); return (e && atoi(e) == 16) ? 16 : 32; }();
@@ -748,7 +780,11 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
                 if (a.nf != 1 || a.fs[0] != a.in2 || C * L > MAXT || a.s1.rowc != nullptr || a.ari) return hipErrorInvalidValue;
                 if (uni && ptile_ok(a, L, C)) {
                     const unsigned pg = (unsigned)(nwg < ptile_cus() ? nwg : ptile_cus());
-                    hipLaunchKernelGGL((k_ptile<32, 32, 16, true>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                    if constexpr (L == 32) {
+                        if (g_ptile_band == 2 && a.y1.band && a.y2.band) hipLaunchKernelGGL((k_ptile<32, 32, 16, true, true>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                        else hipLaunchKernelGGL((k_ptile<32, 32, 16, true>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                    }
+                    else hipLaunchKernelGGL((k_ptile<32, 16, 32, true, true>), dim3(pg), dim3(512), (size_t)a.g.n * 16 * sizeof(double), st, a, nwg);
                 } else if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true, 0, true>), grid, block, lds, st, a);
                 else hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, true>), grid, block, lds, st, a);
             } else {
@@ -766,7 +802,11 @@ static hipError_t launch_htile_m(int mode, int C, long long tiles, const RTileAr
             if constexpr (M == 32 && MAXT == 512) {
                 if (uni && ptile_ok(a, L, C)) {
                     const unsigned pg = (unsigned)(nwg < ptile_cus() ? nwg : ptile_cus());      // items = the (padded) workgroup ids of k_htile
-                    hipLaunchKernelGGL((k_ptile<32, 32, 16>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                    if constexpr (L == 32) {
+                        if (g_ptile_band && a.y1.band && a.y2.band) hipLaunchKernelGGL((k_ptile<32, 32, 16, false, true>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                        else hipLaunchKernelGGL((k_ptile<32, 32, 16>), dim3(pg), dim3(512), (size_t)a.g.n * 32 * sizeof(double), st, a, nwg);
+                    }
+                    else hipLaunchKernelGGL((k_ptile<32, 16, 32, false, true>), dim3(pg), dim3(512), (size_t)a.g.n * 16 * sizeof(double), st, a, nwg);
                 } else if (uni) hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L, false, 0, true>), grid, block, lds, st, a);
                 else hipLaunchKernelGGL((k_htile<M, MODE_BURGERS, MAXT, L>), grid, block, lds, st, a);
             } else {

@@ -31,7 +31,9 @@ struct SystemEntry {
     DeviceArray rowtab, red;
     bool lane_invariant = false;
     bool chunk_invariant = false;      // interior chunks 1 .. P-2 bitwise equal (k_ptile's compact tables)
-    SystemDev dev() const { return SystemDev{rowtab.p, red.p, lane_invariant ? 1 : 0, chunk_invariant ? 1 : 0}; }
+    DeviceArray band;                  // the five central (cyclic) diagonals of the dense separator inverse, when the rest is negligible (SystemDev::band)
+    bool band_ok = false;
+    SystemDev dev() const { return SystemDev{rowtab.p, red.p, lane_invariant ? 1 : 0, chunk_invariant ? 1 : 0, band_ok ? band.p : nullptr}; }
 };
 
 }  // namespace tlab
