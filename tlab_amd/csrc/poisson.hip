@@ -1015,14 +1015,14 @@ __device__ __forceinline__ void ode_chain(double (&phi)[4], double (&e)[NL][2], 
 
 // Per mode: the rows between which all five homogeneous solutions are below 1e-40 of their own maximum, found from the middle of the line
 // outwards (band[t] = last significant row of the lower half, band[nm + t] = first one of the upper half).  hom: [5][n][nm].
-__global__ void __launch_bounds__(256) k_ode_hom_band(const double *__restrict__ hom, int n, long long nm, int *__restrict__ band) {
+__global__ void __launch_bounds__(256) k_ode_hom_band(const double *__restrict__ hom, int n, long long nm, int *__restrict__ band, double rel) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nm) return;
     double thr[5];
     for (int a = 0; a < 5; ++a) {
         double mx = 0.0;
         for (int j = 0; j < n; ++j) mx = fmax(mx, fabs(hom[((size_t)a * n + j) * nm + t]));
-        thr[a] = mx * 1.0e-40;
+        thr[a] = mx * rel;
     }
     const int mid = n / 2;
     int jb = -1, jt = n;
@@ -2374,7 +2374,8 @@ void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
     static const bool band_on = [] { const char *e = getenv("TLAB_ODE_HOM_BAND"); return !(e && atoi(e) == 0); }();
     if (band_on) {
         hipc(hipMalloc((void **)&P.d_hom_band, (size_t)2 * P.nm * sizeof(int)), "hipMalloc");
-        hipLaunchKernelGGL(k_ode_hom_band, dim3(grid), dim3(256), 0, st, P.hom.p, P.ny, P.nm, P.d_hom_band);
+        static const double rel = [] { const char *e = getenv("TLAB_ODE_HOM_THR"); return e ? atof(e) : 1.0e-40; }();
+        hipLaunchKernelGGL(k_ode_hom_band, dim3(grid), dim3(256), 0, st, P.hom.p, P.ny, P.nm, P.d_hom_band, rel);
         hipc(hipGetLastError(), "k_ode_hom_band");
     }
 }
