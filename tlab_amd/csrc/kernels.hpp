@@ -42,6 +42,7 @@ struct XLineArgs {          // k_xline: derivative along the contiguous index, n
     // run over (j, k)); ari == NULL: incompressible
     const double *ari;
     int ari_ny;
+    int line_barriers;      // several waves per line and several lines per workgroup: the waves of a line meet at an LDS counter (xline_barrier); 0: workgroup barriers
 };
 
 struct RTileArgs {          // k_rtile: derivative along a strided index
