@@ -798,7 +798,8 @@ void run_p1_tile(tlab_fdm_plan_t g, const LineGeom &geom, int ibc, const double 
     static const bool off = [] { const char *e = getenv("TLAB_P1_HTILE"); return e && atoi(e) == 0; }();
     const int mr = rtile_chunk(geom.n);
     const bool rtile_spills = mr == 64 && geom.n / 64 > 8;
-    if (!off && rtile_spills && ex.fneu == 0 && htile_chunk(geom.n, MODE_P1) == 32 && g_htile_policy != 1)
+    const bool lane_offsets_fit = 3.0 * 32.0 * (double)geom.row_stride * 8.0 + 512.0 < 4294967296.0;      // launch_htile's 32-bit lane part of an address
+    if (!off && rtile_spills && ex.fneu == 0 && htile_chunk(geom.n, MODE_P1) == 32 && g_htile_policy != 1 && lane_offsets_fit)
         run_htile(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0, ex);
     else
         run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0, ex);

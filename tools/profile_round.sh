@@ -44,6 +44,11 @@ python3 "$B" --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_freeslip.json
 TLAB_NEUMANN_PLANES=0 python3 "$B" --walls freeslip --steps 20 --warmup 5 $Q > "$O/bench_freeslip_derivative_pass.json" 2> /dev/null
 python3 "$B" --grid 2048 1024 256 --nscal 3 --steps 6 --warmup 2 $Q > "$O/bench_configs4_rank_share.json" 2> /dev/null
 python3 "$B" --grid 1024 512 1024 --steps 6 --warmup 2 $Q > "$O/bench_configs3_one_device.json" 2> /dev/null
+# the same two with this round's routes for long lines switched off (line barriers, float-difference tables, own c2r of p, k_htile<P1> epilogues, k_ptile at 1024)
+OFF="TLAB_XLINE_LINE_BARRIERS=0 TLAB_XLINE_FF=0 TLAB_FFTX_C2R_OWN=0 TLAB_P1_HTILE=0 TLAB_PTILE_1024=0"
+env $OFF python3 "$B" --grid 2048 1024 256 --nscal 3 --steps 6 --warmup 2 $Q > "$O/bench_configs4_rank_share_long_line_routes_off.json" 2> /dev/null
+env $OFF python3 "$B" --grid 1024 512 1024 --steps 6 --warmup 2 $Q > "$O/bench_configs3_one_device_long_line_routes_off.json" 2> /dev/null
+TLAB_XLINE_LINE_BARRIERS=0 python3 "$ROOT/tools/bench_xlines.py" 2> /dev/null | grep grid > "$O/xlines_workgroup_barriers.jsonl"
 TLAB_PROFILE_REPORT=1 python3 "$ROOT/tools/bench_poisson.py" > "$O/poisson_standalone.txt" 2>&1
 python3 "$ROOT/tools/bench_xlines.py" 2> /dev/null | grep grid > "$O/xlines.jsonl"
 python3 "$ROOT/tools/bench_xlines.py" --exact-uniform --grids 2048x1024x64 2> /dev/null | grep grid > "$O/xlines_equal_rows_2048.jsonl"
