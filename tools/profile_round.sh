@@ -21,6 +21,8 @@ python3 "$ROOT/tools/pmc_summary.py" stats "$O/raw_stats" > "$O/rocprofv3_kernel
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/raw_fetch" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/raw_write" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_write.err"
 python3 "$ROOT/tools/pmc_summary.py" pmc "$O/raw_fetch" "$O/raw_write" "$O/traffic.json" "$COMMIT" > "$O/pmc_hbm_traffic_summary.txt"
+# (third argument "quick": the bench line, its kernel trace and the traffic file only -- after a change that leaves the other lines as they are)
+if [ "${3:-}" = "quick" ]; then rm -rf "$O"/raw_*; ls -la "$O"; exit 0; fi
 # 3. the north-star's own kernels stand-alone: OPR_Partial_{X,Y,Z}(OPR_P1) at 512^3, kernel trace + the same two counter passes
 OPS="$ROOT/tools/bench_ops.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/raw_ops_stats" -- python3 "$OPS" --types P1 --iters 20 > "$O/ops_p1_under_rocprof.txt" 2> "$O/rocprof_ops.err"
