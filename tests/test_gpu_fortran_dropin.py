@@ -195,9 +195,13 @@ def test_fortran_rk_driver_through_the_slab_driver(tmp_path, fused, nx, walls):
     assert 0.0 < d <= 1e-10, d
 
 
+@pytest.mark.parametrize("route", ["TLAB_AMD_FORCE_PENCIL", "TLAB_AMD_FORCE_SLAB"])
 @pytest.mark.parametrize("fused", [False, True])
-def test_fortran_rk_driver_through_the_pencil_driver(tmp_path, fused):
-    """The x/z pencil route of the Fortran host (ims_npro_i > 1): RHS_GLOBAL_INCOMPRESSIBLE_1 / TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD hand the substep
+def test_fortran_rk_driver_through_the_pencil_driver(tmp_path, fused, route):
+    """TLAB_AMD_FORCE_SLAB on this box of 32 planes: the z-slab route with slabs too THIN for the partitioned z systems (tlab_zslab_plan_create refuses
+    them) -- the Fortran host then takes the reference's own scheme, K-transpositions around the z operators, through the pencil driver with npro_i = 1
+    instead of stopping.
+    The x/z pencil route of the Fortran host (ims_npro_i > 1): RHS_GLOBAL_INCOMPRESSIBLE_1 / TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD hand the substep
     to tlab_pencil_dns_* with the module arrays bound as they are.  One GPU here: TLAB_AMD_FORCE_PENCIL=1 takes that route on 1 x 1 ranks (loopback
     transport: the marshalling, the binding of q / s / hq / hs / txc and the step-start zeroing are what is exercised; the transpositions themselves are
     covered on 2 x 2 .. 4 x 4 ranks in tests/test_gpu_pencil.py).  Two Runge-Kutta steps against the oracle."""
@@ -219,7 +223,7 @@ def test_fortran_rk_driver_through_the_pencil_driver(tmp_path, fused):
     s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
     re, sc, dt = 1000.0, 0.7, 1e-3
     bcs = ["VelocityJmin=freeslip", "VelocityJmax=freeslip", "Scalar1Jmin=neumann", "Scalar1Jmax=dirichlet"]
-    q1, s1, log = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 2, bcs, exe=RK_EXE_FUSED if fused else None, env={"TLAB_AMD_FORCE_PENCIL": "1"})
+    q1, s1, log = run_rk_driver(str(tmp_path), x, y, z, q0, s0, re, sc, dt, 2, bcs, exe=RK_EXE_FUSED if fused else None, env={route: "1"})
     kdt, kco = [1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0], [-5.0 / 9.0, -153.0 / 128.0]
     sched = [(dt * kdt[k % 3], kco[k % 3] if k % 3 < 2 else 1.0, k % 3 < 2, k % 3 == 0) for k in range(6)]
 

@@ -241,6 +241,17 @@ module TLab_AMD_C
             type(tlab_pencil_transport), intent(out) :: tr
             integer(c_int), value :: npro_i, npro_k
         end function
+        ! the partitioned z systems of a slab (include/tlab_amd.h): used here as the test whether slabs of kmax planes are thick enough (TLAB_EUNSUPPORTED: no)
+        integer(c_int) function tlab_zslab_plan_create(plan, gz, kmax, koffset, chunk) bind(C, name='tlab_zslab_plan_create')
+            import :: c_int, c_ptr
+            type(c_ptr), intent(out) :: plan
+            type(c_ptr), value :: gz
+            integer(c_int), value :: kmax, koffset, chunk
+        end function
+        integer(c_int) function tlab_zslab_plan_destroy(plan) bind(C, name='tlab_zslab_plan_destroy')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+        end function
         integer(c_int) function tlab_pencil_dns_create(d, tr, gx, gy, gz, nx, ny, nz_total, nscal, visc, schmidt) bind(C, name='tlab_pencil_dns_create')
             import :: c_int, c_ptr, c_double, tlab_pencil_transport
             type(c_ptr), intent(out) :: d

@@ -51,7 +51,27 @@ contains
             call get_environment_variable('TLAB_AMD_FORCE_PENCIL', val, status=stat)
             TLab_AMD_Pencil_Active = (stat == 0 .and. trim(val) == '1')
         end if
+        ! z-slabs too thin for the partitioned z systems (tlab_zslab_plan_create refuses them: the coupling between slab separators is not negligible
+        ! below ~50 planes): the reference's own scheme -- K-transpositions around the z operators -- through the pencil driver with npro_i = 1
+        if (.not. TLab_AMD_Pencil_Active) TLab_AMD_Pencil_Active = TLab_AMD_Slab_Active() .and. thin_slabs()
     end function TLab_AMD_Pencil_Active
+
+    logical function thin_slabs()
+        use FDM, only: g
+        use TLab_Memory, only: kmax
+        use OPR_Partial, only: OPR_Partial_AMD_Plan
+        logical, save :: known = .false., thin = .false.
+        type(c_ptr) :: zp
+        integer(c_int) :: rc
+        if (.not. known) then
+            zp = c_null_ptr
+            rc = tlab_zslab_plan_create(zp, OPR_Partial_AMD_Plan(3, g(3)), int(kmax, c_int), 0_c_int, 0_c_int)
+            thin = (rc == -2_c_int)      ! TLAB_EUNSUPPORTED (include/tlab_amd.h)
+            if (rc == 0_c_int) rc = tlab_zslab_plan_destroy(zp)
+            known = .true.
+        end if
+        thin_slabs = thin
+    end function thin_slabs
 
     ! The x/z pencil driver (include/tlab_amd.h: tlab_pencil_dns_*): imax, kmax are the LOCAL sizes, g(1) and g(3) the plans of the GLOBAL x and z
     ! directions, as FDM_Initialize leaves them in an MPI run.  Without a communicator (one rank: tests) the loopback transport serves.
@@ -64,6 +84,7 @@ contains
         use BOUNDARY_BCS, only: BcsFlowJmin, BcsFlowJmax, BcsScalJmin, BcsScalJmax
         use OPR_Partial, only: OPR_Partial_AMD_Plan
         use DNS_LOCAL, only: remove_divergence
+        use OPR_Elliptic, only: OPR_Elliptic_AMD_PlanY
         use TLabMPI_VARS, only: ims_npro_i, ims_npro_k
         use TLabMPI_Transpose, only: TLabMPI_Trp_AMD_Pencil_Transport
         type(c_ptr) :: h
@@ -76,6 +97,8 @@ contains
             if (inb_scal > 16 .or. inb_txc < 9) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Pencil_Handle: needs inb_scal <= 16 and inb_txc >= 9')
             ! the supported subset, refused rather than dropped (as TLab_AMD_Slab_Handle)
             if (.not. remove_divergence) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Pencil_Handle: TermDivergence = none is not built into the pencil driver')
+            if (c_associated(OPR_Elliptic_AMD_PlanY())) &
+                call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Pencil_Handle: EllipticOrder = CompactDirect* is not built into the pencil driver (factorized solver only)')
             if (inb_scal > 0) then
                 if (any(BcsScalJmin%SfcType(1:inb_scal) /= 0) .or. any(BcsScalJmax%SfcType(1:inb_scal) /= 0)) &
                     call TLab_AMD_Check(-1_c_int, 'TLab_AMD_Pencil_Handle: the dynamic surface model (BcsScal%SfcType) runs on one rank only')
