@@ -796,10 +796,13 @@ void run_htile(tlab_fdm_plan_t g, const LineGeom &geom, int mode, int ibc, const
 // which carries the same epilogues except the Neumann-final one (y lines only).
 void run_p1_tile(tlab_fdm_plan_t g, const LineGeom &geom, int ibc, const double *u, double *result, const OpExtra &ex = kNoExtra) {
     static const bool off = [] { const char *e = getenv("TLAB_P1_HTILE"); return e && atoi(e) == 0; }();
+    // ... and the final-update epilogue (five passes: p, h, q in; h, q out) at every length: k_rtile's 1024-thread launch spills 43 VGPRs with it,
+    // k_htile<32, P1, 512> none -- final z gradient at 512^3 1.24 -> 1.15 ms (A/B on one box); TLAB_P1_HTILE=2: k_htile for every epilogue form
+    static const bool always = [] { const char *e = getenv("TLAB_P1_HTILE"); return e && atoi(e) == 2; }();
     const int mr = rtile_chunk(geom.n);
     const bool rtile_spills = mr == 64 && geom.n / 64 > 8;
     const bool lane_offsets_fit = 3.0 * 32.0 * (double)geom.row_stride * 8.0 + 512.0 < 4294967296.0;      // launch_htile's 32-bit lane part of an address
-    if (!off && rtile_spills && ex.fneu == 0 && htile_chunk(geom.n, MODE_P1) == 32 && g_htile_policy != 1 && lane_offsets_fit)
+    if (!off && (rtile_spills || always || ex.fq != nullptr) && ex.fneu == 0 && htile_chunk(geom.n, MODE_P1) == 32 && g_htile_policy != 1 && lane_offsets_fit)
         run_htile(g, geom, MODE_P1, ibc, u, nullptr, result, nullptr, 0.0, ex);
     else
         run_rtile(g, geom, MODE_P1, ibc, u, nullptr, nullptr, result, 0.0, ex);
