@@ -463,7 +463,14 @@ int tlab_zslab_plan_create(tlab_zslab_plan_t *out, tlab_fdm_plan_t gz, int kmax,
         auto P = std::make_unique<tlab_zslab_plan>();
         P->nz = nz; P->kmax = kmax; P->k0 = koffset;
         int M = chunk;
-        if (M == 0) M = (kmax % 32 == 0 && kmax / 32 <= 8) ? 32 : 16;
+        if (M == 0) {
+            static const int forced = [] { const char *e = getenv("TLAB_ZSLAB_M"); return e ? atoi(e) : 0; }();      // 16 / 32: experiments
+            M = (kmax % 32 == 0 && kmax / 32 <= 8) ? 32 : 16;
+            // two sub-chunks of 32 rows are two waves per workgroup at 256 registers (20 spilled in the Burgers phase B): slabs of 64 planes -- the
+            // 512^3 box on 8 ranks -- take four of 16 rows (phase B 0.452 -> 0.407 ms per rank, phase A 0.157 -> 0.175); at 128 planes 32 rows win
+            if (M == 32 && kmax / 32 <= 2 && kmax % 16 == 0) M = 16;
+            if ((forced == 16 || forced == 32) && kmax % forced == 0 && kmax / forced <= 8) M = forced;
+        }
         if ((M != 16 && M != 32) || kmax % M || kmax / M > 8 || kmax / M < 1)
             throw Fail(TLAB_EUNSUPPORTED, "z-slab operators: kmax must be a multiple of 16 or 32 with at most 8 sub-chunks");
         P->M = M; P->C = kmax / M;
