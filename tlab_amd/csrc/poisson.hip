@@ -765,6 +765,8 @@ __global__ void __launch_bounds__(256) k_int2(Int2Args a) {
 //     bound by dependent fp64 latency at 8 waves per CU, not by HBM, and the second pass doubled its time.)
 // HBM traffic per mode and row: f^ 16 B, p^ + dp^/dy 32 B, homogeneous solutions 40 B, checkpoints 12 B; no scratch.
 // ================================================================================================
+// Knock-out builds (-DODE_KO=<bits>: 1 no workgroup barriers, 2 no scan steps, 4 divisions as multiplications, 8 no homogeneous-solution loads, 16 no
+// table loads): wrong results, right timings -- what DESIGN.md section 4 quotes for the parts of k_ode_nn (profiles/r04/ode_knockout.txt).  0: the product.
 #ifndef ODE_KO
 #define ODE_KO 0
 #endif
@@ -774,6 +776,8 @@ constexpr int OM = 8;   // rows per thread
 
 struct OdeSys {                  // Int1Dev without the by-value boundary constants (they would sit in ~100 SGPRs)
     const double *L0, *L1, *R;   // row-major [n][5], [n][5], [n][3]
+    const double *pk;            // the same numbers packed per row, [n][16] = L0[5], L1[5], row scale, R[0], R[1], 0, 0, 0: one 128-B line and seven 16-B loads
+                                 // per row where the separate arrays take 13 loads from four lines (k_ode_nn's per-row loads were a fifth of its time)
     const double *bt;            // [3][4]: rhs_b of the BCS_MIN system / rhs_t of the BCS_MAX system
     int n;
 };
@@ -860,7 +864,7 @@ __device__ __forceinline__ void ode_row(const OdeSys &T, const OdeRows &k, int j
 // The boundary rows depend on the mode only: one thread per mode computes them into LDS (54 doubles per mode), the two chunks that
 // touch a boundary read what they need from there, and no thread keeps them in registers.  Layout: [field][NM], fields:
 //   0-4 l0, 5-9 l1, 10-14 l2, 15-19 lN, 20-24 lN1, 25-29 lN2, 30-41 rb[3][4], 42-53 rt[3][4]
-constexpr int OK_L0 = 0, OK_L1 = 5, OK_L2 = 10, OK_LN = 15, OK_LN1 = 20, OK_LN2 = 25, OK_RB = 30, OK_RT = 42, OK_FS = 54, OK_SIZE = 58;      // OK_FS: one f row per line, parked by the chunk that needs it after the solve
+constexpr int OK_L0 = 0, OK_L1 = 5, OK_L2 = 10, OK_LN = 15, OK_LN1 = 20, OK_LN2 = 25, OK_RB = 30, OK_RT = 42, OK_FS = 54, OK_CST = 58, OK_BAND = 67, OK_SIZE = 70;      // OK_FS: one f row per line, parked by the chunk that needs it after the solve; OK_CST, OK_BAND: the mode's constants and band (k_ode_nn: fetched at the start)
 template <int NM>
 __device__ __forceinline__ void ode_rows_to_lds(const OdeRows &k, double *s_k, int m) {
 #pragma unroll
@@ -1037,6 +1041,7 @@ __global__ void __launch_bounds__(256) k_ode_hom_band(const double *__restrict__
 }
 
 // src[a][j][nm] -> dst[blk][a][j][NM]
+// (the five solutions of a mode and row side by side, [blk][j][NM][6] with three 16-B loads per row in k_ode_nn, was measured: 3 % slower)
 __global__ void __launch_bounds__(256) k_ode_block_layout(const double *__restrict__ src, double *__restrict__ dst, int A, int n, long long nm, int NM) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)A * n * nm) return;
@@ -1093,10 +1098,16 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
     for (int p = 0; p < OM; ++p) {
         const int j = j0 + p;
         const bool off = (p == 0 && lo) || (p == OM - 1 && hi);         // boundary rows
-        double r[5];
-        if (ODE_KO & 16) { r[0] = 0.01 * lam; r[1] = 0.3; r[2] = 1.0 + lam; r[3] = 0.3; r[4] = 0.01; } else
-        lhs_row_t(T, j, lam, r);
-        double c0 = (ODE_KO & 16) ? 0.5 : T.R[(unsigned)(j * 3 + 0)], c1 = (ODE_KO & 16) ? 0.25 : T.R[(unsigned)(j * 3 + 1)], c2 = 1.0, cb = 0.0, ct = 0.0;     // rhs = c0 f(j-1) + c1 f(j) + c2 f(j+1) + cb res0 + ct resN
+        double r[5], c0, c1, c2 = 1.0, cb = 0.0, ct = 0.0;     // rhs = c0 f(j-1) + c1 f(j) + c2 f(j+1) + cb res0 + ct resN
+        if (ODE_KO & 16) { r[0] = 0.01 * lam; r[1] = 0.3; r[2] = 1.0 + lam; r[3] = 0.3; r[4] = 0.01; c0 = 0.5; c1 = 0.25; } else
+        {   // lhs_row_t and R(j, 1:2) from the packed row (same numbers, same operations)
+            const double2 *pk = reinterpret_cast<const double2 *>(T.pk) + (unsigned)(j * 8);
+            const double2 q0 = pk[0], q1 = pk[1], q2 = pk[2], q3 = pk[3], q4 = pk[4], q5 = pk[5], q6 = pk[6];
+            const double sj = q5.x;
+            r[0] = nf_madd(q0.x, lam, q2.y) * sj; r[1] = nf_madd(q0.y, lam, q3.x) * sj; r[2] = nf_madd(q1.x, lam, q3.y) * sj;
+            r[3] = nf_madd(q1.y, lam, q4.x) * sj; r[4] = nf_madd(q2.x, lam, q4.y) * sj;
+            c0 = q5.y; c1 = q6.x;
+        }
         if (p == 1 && lo) {
 #pragma unroll
             for (int q = 0; q < 5; ++q) r[q] = KK(OK_L1, q);
@@ -1293,6 +1304,14 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     const int j0 = c * OMR;
     const double2 *F = reinterpret_cast<const double2 *>(a.f_hat);
     double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
+    // the constants of the mode and its band of negligible homogeneous solutions are needed after the two solves, by every chunk: one thread per mode
+    // fetches them now (their trip to HBM was exposed in front of the epilogue, and 64 chunks issued the same nine loads)
+    if (c == (C > 2 ? 2 : 0)) {
+#pragma unroll
+        for (int k = 0; k < (DD ? 5 : 9); ++k) s_k[(OK_CST + k) * NM + m] = a.cst[(unsigned)(k * nm + t)];
+        s_k[(OK_BAND + 0) * NM + m] = a.band != nullptr ? (double)a.band[t] : (double)n;
+        s_k[(OK_BAND + 1) * NM + m] = a.band != nullptr ? (double)a.band[nm + t] : 0.0;
+    }
 
     double u[OMR][NL], ext[NL];
     double v_1[NL], u_n[NL], fn[NL];      // (the Neumann data bb = SC(0, l), bt = SC(1, l) stay in LDS until the constants are formed)
@@ -1348,8 +1367,8 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     }
     ODE_SYNC();
     if (DD) {      // :452-456
-        const double aa = a.cst[(unsigned)(0 * nm + t)], bc = a.cst[(unsigned)(1 * nm + t)], dummy = a.cst[(unsigned)(2 * nm + t)];
-        const double sp1 = a.cst[(unsigned)(3 * nm + t)], u11 = a.cst[(unsigned)(4 * nm + t)];
+        const double aa = s_k[(OK_CST + 0) * NM + m], bc = s_k[(OK_CST + 1) * NM + m], dummy = s_k[(OK_CST + 2) * NM + m];
+        const double sp1 = s_k[(OK_CST + 3) * NM + m], u11 = s_k[(OK_CST + 4) * NM + m];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l), bbl = SC(0, l), btl = SC(1, l);
@@ -1358,9 +1377,9 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
             fn[l] = (sp1 * w - bc * (bbl - u0_1)) * dummy;
         }
     } else {
-        const double a11 = a.cst[(unsigned)(0 * nm + t)], a21 = a.cst[(unsigned)(1 * nm + t)], a31 = a.cst[(unsigned)(2 * nm + t)];
-        const double a12 = a.cst[(unsigned)(3 * nm + t)], a22 = a.cst[(unsigned)(4 * nm + t)], a32 = a.cst[(unsigned)(5 * nm + t)];
-        const double a13 = a.cst[(unsigned)(6 * nm + t)], a23 = a.cst[(unsigned)(7 * nm + t)], a33 = a.cst[(unsigned)(8 * nm + t)];
+        const double a11 = s_k[(OK_CST + 0) * NM + m], a21 = s_k[(OK_CST + 1) * NM + m], a31 = s_k[(OK_CST + 2) * NM + m];
+        const double a12 = s_k[(OK_CST + 3) * NM + m], a22 = s_k[(OK_CST + 4) * NM + m], a32 = s_k[(OK_CST + 5) * NM + m];
+        const double a13 = s_k[(OK_CST + 6) * NM + m], a23 = s_k[(OK_CST + 7) * NM + m], a33 = s_k[(OK_CST + 8) * NM + m];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const double u0_1 = SC(2, l), v0_n = SC(3, l), du0n = SC(4, l), bbl = SC(0, l), btl = SC(1, l);
@@ -1377,7 +1396,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // their maximum a few tens of rows away from the walls, where adding them changes no bit of the sum.  The plan records that band per
     // mode (k_ode_hom_band); chunks inside it skip the five loads (40 of the 100 B per mode and row this kernel would otherwise move).
     bool need = true;
-    if (ODE_KO & 8) need = false; else if (a.band != nullptr) need = (j0 <= a.band[t]) || (j0 + OMR - 1 >= a.band[nm + t]);
+    if (ODE_KO & 8) need = false; else need = (j0 <= (int)s_k[(OK_BAND + 0) * NM + m]) || (j0 + OMR - 1 >= (int)s_k[(OK_BAND + 1) * NM + m]);
 #pragma unroll
     for (int p = 0; p < OMR; ++p) {
         const int j = j0 + p;
@@ -2085,6 +2104,7 @@ struct tlab_poisson_plan {
         return *gen.back();
     }
     DBuf d_L0[2], d_L1[2], d_R[2];    // [0] BCS_MIN tables, [1] BCS_MAX tables
+    DBuf d_pk[2];                     // OdeSys::pk
     DBuf lam;                         // [nm]  sqrt(kx'^2 + kz'^2)
     DBuf hom, der, cst;               // homogeneous solutions [5][ny][nm], their boundary derivatives [3][nm], 3x3 LU [9][nm]
     DBuf scratch, v0, u0, du0, bcs;   // per-call work: [5][ny][nm], [2][ny][nm] x2, [2][nm], [4][nm]
@@ -2203,6 +2223,7 @@ struct tlab_poisson_plan {
     OdeSys sys(int which) const {
         OdeSys d;
         d.L0 = d_L0[which].p; d.L1 = d_L1[which].p; d.R = d_R[which].p; d.bt = d_bt[which].p; d.n = ny;
+        d.pk = d_pk[which].p;
         return d;
     }
     Int1Dev dev(int which) const {
@@ -2691,6 +2712,18 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
             int1_build_tables(gy->t.der1, 2, P->tmax);
             P->d_L0[0].upload(P->tmin.L0); P->d_L1[0].upload(P->tmin.L1); P->d_R[0].upload(P->tmin.R);
             P->d_L0[1].upload(P->tmax.L0); P->d_L1[1].upload(P->tmax.L1); P->d_R[1].upload(P->tmax.R);
+            for (int w = 0; w < 2; ++w) {
+                const Int1Tables &T = w == 0 ? P->tmin : P->tmax;
+                if (T.L0.size() < (size_t)6 * ny || T.L1.size() < (size_t)5 * ny || T.R.size() < (size_t)3 * ny) continue;      // (generic tables: k_int1g)
+                std::vector<double> pk((size_t)16 * ny, 0.0);
+                for (int j = 0; j < ny; ++j) {
+                    for (int k = 0; k < 5; ++k) { pk[(size_t)16 * j + k] = T.L0[(size_t)5 * j + k]; pk[(size_t)16 * j + 5 + k] = T.L1[(size_t)5 * j + k]; }
+                    pk[(size_t)16 * j + 10] = T.L0[(size_t)5 * ny + j];
+                    pk[(size_t)16 * j + 11] = T.R[(size_t)3 * j + 0];
+                    pk[(size_t)16 * j + 12] = T.R[(size_t)3 * j + 1];
+                }
+                P->d_pk[w].upload(pk);
+            }
         }
         // lambda(k,i) = mwn_x(i)^2 + mwn_z(k)^2 (opr_elliptic.f90:199-203), stored as sqrt (:205-209)
         const long long nm = P->nm;
