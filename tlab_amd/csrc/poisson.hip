@@ -776,7 +776,7 @@ constexpr int OM = 8;   // rows per thread
 
 struct OdeSys {                  // Int1Dev without the by-value boundary constants (they would sit in ~100 SGPRs)
     const double *L0, *L1, *R;   // row-major [n][5], [n][5], [n][3]
-    const double *pk;            // the same numbers packed per row, [n][16] = L0[5], L1[5], row scale, R[0], R[1], 0, 0, 0: one 128-B line and seven 16-B loads
+    const double *pk;            // the same numbers packed per row, [n][16] = L0[5], L1[5], row scale, R[3], 0, 0: one 128-B line and seven 16-B loads
                                  // per row where the separate arrays take 13 loads from four lines (k_ode_nn's per-row loads were a fifth of its time)
     const double *bt;            // [3][4]: rhs_b of the BCS_MIN system / rhs_t of the BCS_MAX system
     int n;
@@ -803,11 +803,23 @@ struct OdeRows {
     double l0[5], l1[5], l2[5], lN[5], lN1[5], lN2[5], rb[3][4], rt[3][4];
 };
 
+// lhs_row_t and R(j, 1:3) of row j from the packed table (OdeSys::pk): the same numbers by the same operations
+__device__ __forceinline__ void ode_row_pk(const OdeSys &T, int j, double lam, double (&r)[5], double (&R)[3]) {
+    const double2 *pk = reinterpret_cast<const double2 *>(T.pk) + (unsigned)(j * 8);
+    const double2 q0 = pk[0], q1 = pk[1], q2 = pk[2], q3 = pk[3], q4 = pk[4], q5 = pk[5], q6 = pk[6];
+    const double sj = q5.x;
+    r[0] = nf_madd(q0.x, lam, q2.y) * sj; r[1] = nf_madd(q0.y, lam, q3.x) * sj; r[2] = nf_madd(q1.x, lam, q3.y) * sj;
+    r[3] = nf_madd(q1.y, lam, q4.x) * sj; r[4] = nf_madd(q2.x, lam, q4.y) * sj;
+    R[0] = q5.y; R[1] = q6.x; R[2] = q6.y;
+}
+
+// (the two ends are independent of each other: a caller that stores one end only -- ode_solve -- pays for that end only)
 template <int BC>
 __device__ __forceinline__ void ode_boundary_rows(const OdeSys &T, double lam, OdeRows &k) {
     const int n = T.n;
-    lhs_row_t(T, 0, lam, k.l0); lhs_row_t(T, 1, lam, k.l1); lhs_row_t(T, 2, lam, k.l2);
-    lhs_row_t(T, n - 1, lam, k.lN); lhs_row_t(T, n - 2, lam, k.lN1); lhs_row_t(T, n - 3, lam, k.lN2);
+    double R0[3], R1[3], R2[3], RN[3], RN1[3], RN2[3];
+    ode_row_pk(T, 0, lam, k.l0, R0); ode_row_pk(T, 1, lam, k.l1, R1); ode_row_pk(T, 2, lam, k.l2, R2);
+    ode_row_pk(T, n - 1, lam, k.lN, RN); ode_row_pk(T, n - 2, lam, k.lN1, RN1); ode_row_pk(T, n - 3, lam, k.lN2, RN2);
     if (BC == 1) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -821,9 +833,9 @@ __device__ __forceinline__ void ode_boundary_rows(const OdeSys &T, double lam, O
         k.lN2[1] = nf_madd(k.lN2[1], k.lN2[4], k.lN[4]); k.lN2[2] = nf_madd(k.lN2[2], k.lN2[4], k.lN[0]); k.lN2[3] = nf_madd(k.lN2[3], k.lN2[4], k.lN[1]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            k.rt[2][c] = T.R[(n - 1) * 3 + c] * d;
-            k.rt[1][c] = T.R[(n - 2) * 3 + c];
-            k.rt[0][c] = T.R[(n - 3) * 3 + c];
+            k.rt[2][c] = RN[c] * d;
+            k.rt[1][c] = RN1[c];
+            k.rt[0][c] = RN2[c];
         }
         k.rt[0][3] = k.rt[1][3] = k.rt[2][3] = 0.0;
         k.rt[1][0] = nf_msub(k.rt[1][0], k.lN1[3], k.rt[2][2]); k.rt[1][1] = nf_msub(k.rt[1][1], k.lN1[3], k.rt[2][0]); k.rt[1][2] = nf_msub(k.rt[1][2], k.lN1[3], k.rt[2][1]);
@@ -841,9 +853,9 @@ __device__ __forceinline__ void ode_boundary_rows(const OdeSys &T, double lam, O
         k.l2[1] = nf_madd(k.l2[1], k.l2[0], k.l0[3]); k.l2[2] = nf_madd(k.l2[2], k.l2[0], k.l0[4]); k.l2[3] = nf_madd(k.l2[3], k.l2[0], k.l0[0]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            k.rb[0][c + 1] = T.R[0 * 3 + c] * d;
-            k.rb[1][c + 1] = T.R[1 * 3 + c];
-            k.rb[2][c + 1] = T.R[2 * 3 + c];
+            k.rb[0][c + 1] = R0[c] * d;
+            k.rb[1][c + 1] = R1[c];
+            k.rb[2][c + 1] = R2[c];
         }
         k.rb[0][0] = k.rb[1][0] = k.rb[2][0] = 0.0;
         k.rb[1][1] = nf_msub(k.rb[1][1], k.l1[1], k.rb[0][2]); k.rb[1][2] = nf_msub(k.rb[1][2], k.l1[1], k.rb[0][3]); k.rb[1][3] = nf_msub(k.rb[1][3], k.l1[1], k.rb[0][1]);
@@ -865,17 +877,20 @@ __device__ __forceinline__ void ode_row(const OdeSys &T, const OdeRows &k, int j
 // touch a boundary read what they need from there, and no thread keeps them in registers.  Layout: [field][NM], fields:
 //   0-4 l0, 5-9 l1, 10-14 l2, 15-19 lN, 20-24 lN1, 25-29 lN2, 30-41 rb[3][4], 42-53 rt[3][4]
 constexpr int OK_L0 = 0, OK_L1 = 5, OK_L2 = 10, OK_LN = 15, OK_LN1 = 20, OK_LN2 = 25, OK_RB = 30, OK_RT = 42, OK_FS = 54, OK_CST = 58, OK_BAND = 67, OK_SIZE = 70;      // OK_FS: one f row per line, parked by the chunk that needs it after the solve; OK_CST, OK_BAND: the mode's constants and band (k_ode_nn: fetched at the start)
-template <int NM>
+template <int NM, int END = 0>      // END = 1 / 2: the rows of the bottom / the top only
 __device__ __forceinline__ void ode_rows_to_lds(const OdeRows &k, double *s_k, int m) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-        s_k[(OK_L0 + q) * NM + m] = k.l0[q]; s_k[(OK_L1 + q) * NM + m] = k.l1[q]; s_k[(OK_L2 + q) * NM + m] = k.l2[q];
-        s_k[(OK_LN + q) * NM + m] = k.lN[q]; s_k[(OK_LN1 + q) * NM + m] = k.lN1[q]; s_k[(OK_LN2 + q) * NM + m] = k.lN2[q];
+        if (END != 2) { s_k[(OK_L0 + q) * NM + m] = k.l0[q]; s_k[(OK_L1 + q) * NM + m] = k.l1[q]; s_k[(OK_L2 + q) * NM + m] = k.l2[q]; }
+        if (END != 1) { s_k[(OK_LN + q) * NM + m] = k.lN[q]; s_k[(OK_LN1 + q) * NM + m] = k.lN1[q]; s_k[(OK_LN2 + q) * NM + m] = k.lN2[q]; }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s_k[(OK_RB + j * 4 + c) * NM + m] = k.rb[j][c]; s_k[(OK_RT + j * 4 + c) * NM + m] = k.rt[j][c]; }
+        for (int c = 0; c < 4; ++c) {
+            if (END != 2) s_k[(OK_RB + j * 4 + c) * NM + m] = k.rb[j][c];
+            if (END != 1) s_k[(OK_RT + j * 4 + c) * NM + m] = k.rt[j][c];
+        }
 }
 template <int NM>
 __device__ __forceinline__ void ode_row_lds(const OdeSys &T, const double *s_k, int m, int j, double lam, double (&r)[5]) {
@@ -1063,7 +1078,20 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
                                           double (&x)[OM][NL], double (&ext)[NL], double *s_w, double *s_k, double *s_fac) {
     static_assert(OM == 4 || OM == 8, "rows per thread");
     const int n = T.n, j0 = c * OM;
-    if (c == 1) {              // C >= 2; chunk 1 never touches a boundary row itself
+    // the boundary rows of the mode: the bottom ones by the thread of chunk 1, the top ones by that of chunk 2 (every other thread of the workgroup waits
+    // for them at the barrier below: two threads side by side halve that wait; what a thread does not store is not computed)
+    if (C >= 3) {
+        if (c == 1) {
+            OdeRows k;
+            ode_boundary_rows<BC>(T, lam, k);
+            ode_rows_to_lds<NM, 1>(k, s_k, m);
+        }
+        if (c == 2) {
+            OdeRows k;
+            ode_boundary_rows<BC>(T, lam, k);
+            ode_rows_to_lds<NM, 2>(k, s_k, m);
+        }
+    } else if (c == 1) {       // C >= 2; chunk 1 never touches a boundary row itself
         OdeRows k;
         ode_boundary_rows<BC>(T, lam, k);
         ode_rows_to_lds<NM>(k, s_k, m);
@@ -1306,7 +1334,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     double2 *P = reinterpret_cast<double2 *>(a.p_hat), *D = reinterpret_cast<double2 *>(a.dp_hat);
     // the constants of the mode and its band of negligible homogeneous solutions are needed after the two solves, by every chunk: one thread per mode
     // fetches them now (their trip to HBM was exposed in front of the epilogue, and 64 chunks issued the same nine loads)
-    if (c == (C > 2 ? 2 : 0)) {
+    if (c == (C > 3 ? 3 : 0)) {
 #pragma unroll
         for (int k = 0; k < (DD ? 5 : 9); ++k) s_k[(OK_CST + k) * NM + m] = a.cst[(unsigned)(k * nm + t)];
         s_k[(OK_BAND + 0) * NM + m] = a.band != nullptr ? (double)a.band[t] : (double)n;
@@ -2721,6 +2749,7 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                     pk[(size_t)16 * j + 10] = T.L0[(size_t)5 * ny + j];
                     pk[(size_t)16 * j + 11] = T.R[(size_t)3 * j + 0];
                     pk[(size_t)16 * j + 12] = T.R[(size_t)3 * j + 1];
+                    pk[(size_t)16 * j + 13] = T.R[(size_t)3 * j + 2];
                 }
                 P->d_pk[w].upload(pk);
             }
