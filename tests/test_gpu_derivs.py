@@ -91,9 +91,10 @@ def test_golden_vectors(T, path):
         run_all_ops(T, O, d, gp, op, nx, ny, nz, (0, 1, 2, 3) if d == 2 else (0,), g["u"], g["v"], float(g["visc"]), expect=g, tag=path)
 
 
-@pytest.mark.parametrize("nx,ny,nz", [(96, 64, 40), (256, 130, 12)])
+@pytest.mark.parametrize("nx,ny,nz", [(96, 64, 40), (256, 130, 12), (512, 128, 64)])
 def test_penta_first_derivative(T, nx, ny, nz):
-    """SpaceOrder1 = CompactJacobian6Penta (fdm_com1_jacobian.f90:136-192; k_penta1, one line per thread) in the three directions, all
+    """SpaceOrder1 = CompactJacobian6Penta (fdm_com1_jacobian.f90:136-192; k_pentatile on lines of 64 .. 512 points in 32-row chunks -- 96, 64, 256, 512,
+    128 here --, k_penta1, one line per thread, on the others) in the three directions, all
     operator types and the Burgers operator, against the oracle (itself bitwise equal to the reference for this scheme, tests/golden/
     derivs_penta_*.npz); the plan also built from the host's tables (tlab_fdm_plan_create_from_arrays, ndl1 = 5)."""
     from oracle import tlab_oracle as O

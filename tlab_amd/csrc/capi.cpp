@@ -719,6 +719,23 @@ void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, co
         a.periodic = d.periodic ? 1 : 0; a.ibc = d.periodic ? 0 : ibc;
         std::copy(d.rhs_b, d.rhs_b + 32, a.rb);
         std::copy(d.rhs_t, d.rhs_t + 35, a.rt);
+        auto tile = [&](const LineGeom &tg, const double *src, double *dst) {      // k_pentatile where the line length allows (32-row chunks, at most 16)
+            const int key = d.periodic ? 0 : ibc;
+            auto &slot = g->penta_tile[key];
+            if (!slot) {
+                std::vector<double> rows, blocks, smw;
+                pentatile_build(tg.n, tg.n / 32, d.periodic, key, d.lu.data(), rows, blocks, smw);
+                slot = std::make_unique<tlab_fdm_plan::PentaTile>();
+                slot->rows.upload(rows); slot->blocks.upload(blocks); slot->smw.upload(smw);
+            }
+            PentaTileArgs t;
+            t.in0 = src; t.out0 = dst; t.g = tg; t.rhs = g->penta_rhs->p; t.rows = slot->rows.p; t.blocks = slot->blocks.p; t.smw = slot->smw.p;
+            t.r6 = d.rhs[4 + (size_t)tg.n * 5]; t.r7 = d.rhs[4 + (size_t)tg.n * 6];      // rhs(5, 6), rhs(5, 7)
+            t.periodic = a.periodic; t.ibc = a.ibc;
+            std::copy(d.rhs_b, d.rhs_b + 32, t.rb);
+            std::copy(d.rhs_t, d.rhs_t + 35, t.rt);
+            hip_check(launch_pentatile(t, g_stream), "k_pentatile");
+        };
         if (geom.row_stride == 1 && geom.nlines >= 64) {
             // x lines: one thread per line strides through contiguous memory (64 cache lines per wave access; 243 GB/s at 256^3, measured).  Like the
             // reference (OPR_Partial_X: TLab_Transpose, solve, transpose back, opr_partial.f90:185-195) the lines are made the fastest index first:
@@ -730,11 +747,13 @@ void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, co
             hip_check(launch_transpose(in0, t1, geom.n, (int)geom.nlines, g_stream), "transpose");
             a.in0 = t1; a.out0 = t2;
             a.g.row_stride = geom.nlines; a.g.lines_inner = (int)geom.nlines; a.g.outer_stride = 0;
-            hip_check(launch_penta1(a, g_stream), "k_penta1");
+            if (pentatile_ok(a.g)) tile(a.g, t1, t2);
+            else hip_check(launch_penta1(a, g_stream), "k_penta1");
             hip_check(launch_transpose(t2, out, (int)geom.nlines, geom.n, g_stream), "transpose");
             return;
         }
-        hip_check(launch_penta1(a, g_stream), "k_penta1");
+        if (pentatile_ok(geom)) tile(geom, in0, out);
+        else hip_check(launch_penta1(a, g_stream), "k_penta1");
         return;
     }
     GenericArgs a;

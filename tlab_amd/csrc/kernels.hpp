@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "device_tables.hpp"
 
 namespace tlab {
@@ -113,6 +115,24 @@ struct PentaArgs {
     double rt[5 * 7];       // rhs_t(0:4,7): [r + 5 (c-1)]
 };
 hipError_t launch_penta1(const PentaArgs &a, hipStream_t st);
+
+// k_pentatile (pentatile.hip): the same operator on register tiles; rows / blocks / smw: device copies of what pentatile_build makes
+struct PentaTileArgs {
+    const double *in0;
+    double *out0;
+    LineGeom g;
+    const double *rhs;      // as PentaArgs
+    const double *rows;     // [9][n]
+    const double *blocks;   // [2][C][C][4]
+    const double *smw;      // [2][n] + 8 (periodic lines)
+    double r6, r7;          // interior coefficients rhs(5, 6), rhs(5, 7)
+    int periodic, ibc;
+    double rb[4 * 8];
+    double rt[5 * 7];
+};
+bool pentatile_ok(const LineGeom &g);
+void pentatile_build(int n, int C, bool periodic, int ibc, const double *lu, std::vector<double> &rows, std::vector<double> &blocks, std::vector<double> &smw);
+hipError_t launch_pentatile(const PentaTileArgs &a, hipStream_t st);
 
 bool xline_supported(int n);
 int rtile_chunk(int n);

@@ -48,6 +48,8 @@ struct tlab_fdm_plan {
     std::unique_ptr<tlab::DeviceArray> rowc1[4];   // the same for a direct first derivative, one per Neumann variant (rows 4 and n-3 differ)
     std::unique_ptr<tlab::DeviceArray> penta_ws;              // ... and two transposed copies of a field for its x direction
     std::unique_ptr<tlab::DeviceArray> penta_rhs, penta_lu;   // CompactJacobian6Penta first derivative: g%der1%rhs (n,7) and g%der1%lu on the device
+    struct PentaTile { tlab::DeviceArray rows, blocks, smw; };
+    std::map<int, std::unique_ptr<PentaTile>> penta_tile;     // ... and the tables of k_pentatile per Neumann variant (pentatile_build)
     tlab_filter_t interp[4] = {nullptr, nullptr, nullptr, nullptr};      // interpolatory operators P1 VP, P1 PV, P0 VP, P0 PV as periodic compact-filter objects (capi.cpp)
     int wide_ok[3] = {-1, -1, -1};             // x lines on 64 / 128 / 256 chunks: float-difference tables exact? (-1 = not checked yet; capi.cpp xline_wide_ok)
 
