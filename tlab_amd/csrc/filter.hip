@@ -27,6 +27,7 @@ using namespace tlab;
 struct tlab_filter {
     int type, n, periodic, bcsmin, bcsmax, ncols;
     DeviceArray coeffs;      // [ncols][n], column-major like f%coeffs
+    DeviceArray ws;          // two transposed copies of a field: x lines are filtered with the lines made the fastest index (tlab_internal_filter_1d)
 };
 
 namespace {
@@ -204,6 +205,23 @@ void tlab_internal_filter_1d(int dir, tlab_filter_t f, int nx, int ny, int nz, c
     if (g.n != f->n) throw std::invalid_argument("filter size does not match the field size along dir");
     FilterArgs a;
     a.in = u; a.out = result; a.g = g; a.type = f->type; a.periodic = f->periodic; a.bcsmin = f->bcsmin; a.bcsmax = f->bcsmax; a.c = f->coeffs.p;
+    if (dir == 1 && g.nlines >= 64) {
+        // x lines: one thread per line would stride through contiguous memory (64 cache lines per wave access).  Like the reference (OPR_FILTER_X:
+        // TLab_Transpose, filter, transpose back) the lines are made the fastest index first: two transposes at the copy rate + the coalesced filter
+        const size_t N = (size_t)g.n * g.nlines;
+        if (f->ws.n < 2 * N) f->ws.alloc(2 * N);
+        double *t1 = f->ws.p, *t2 = t1 + N;
+        if (launch_transpose(u, t1, g.n, (int)g.nlines, st) != hipSuccess) throw std::runtime_error("transpose");
+        a.in = t1; a.out = t2;
+        a.g.row_stride = g.nlines; a.g.lines_inner = (int)g.nlines; a.g.outer_stride = 0;
+        {
+            ProfScope ps("k_filter1d", st, (double)g.nlines * g.n * 16.0);
+            hipLaunchKernelGGL(k_filter1d, dim3((unsigned)((g.nlines + 255) / 256)), dim3(256), 0, st, a);
+        }
+        if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_filter1d launch failed");
+        if (launch_transpose(t2, result, (int)g.nlines, g.n, st) != hipSuccess) throw std::runtime_error("transpose");
+        return;
+    }
     ProfScope ps("k_filter1d", st, (double)g.nlines * g.n * 16.0);
     hipLaunchKernelGGL(k_filter1d, dim3((unsigned)((g.nlines + 255) / 256)), dim3(256), 0, st, a);
     if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_filter1d launch failed");
