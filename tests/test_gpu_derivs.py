@@ -416,3 +416,43 @@ def test_lines_of_1024_points_fused_on_16_line_tiles(T, d):
     assert rel_err(r.cpu().numpy(), ro) <= 1e-12 and rel_err(t.cpu().numpy(), to) <= 1e-12
     burg(T.OPR_B_U_IN, 3e-4, nx, ny, nz, 0, g, du, dv, r, t)
     assert rel_err(r.cpu().numpy(), O.opr_burgers(d, nx, ny, nz, 0, og, 3e-4, u, v)[0]) <= 1e-12
+
+
+@pytest.mark.parametrize("grid", [0, 5, 3, 13])
+def test_persistent_z_burgers_with_padding_items_and_any_grid(T, grid):
+    """k_ptile (persistent workgroups, operand tile of the next item by LDS-DMA): 96 x 3 lines of 512 points = 9 tiles, three fields -> 48 items of
+    which every (item & 7) >= tile count of its octet is padding.  With a grid that is not a multiple of 8 (partitioned parts: 38 / 228 CUs) a
+    workgroup meets a padding item and then a valid one: the skip path must still bring the next operand tile in.  The grid is
+    forced through tlab_set_tuning(4, n); 0 = the default (CUs rounded down to a multiple of 8)."""
+    import ctypes
+    import torch
+    from oracle import tlab_oracle as O
+    from tlab_amd.lib import load, check
+    L = load()
+    c_vp = ctypes.c_void_p
+    nx, ny, nz = 96, 3, 512
+    z = np.arange(nz) / nz
+    g, og = T.FdmPlan(z, True, True), O.FdmPlan(z, True, True)
+    rng = np.random.default_rng(40 + grid)
+    N = nx * ny * nz
+    f = [rng.uniform(-1, 1, N) for _ in range(3)]
+    d = [torch.from_numpy(a).cuda() for a in f]
+    h0 = [rng.uniform(-1, 1, N) for _ in range(3)]
+    h = [torch.from_numpy(a).cuda() for a in h0]
+    r = torch.zeros(N, dtype=torch.float64, device="cuda"); t = torch.zeros_like(r)
+    nu = (ctypes.c_double * 3)(2e-4, 3e-4, 4e-4)
+    sp = (c_vp * 3)(*[a.data_ptr() for a in d])
+    hp = (c_vp * 3)(*[a.data_ptr() for a in h])
+    check(L.tlab_set_tuning(4, grid), "set_tuning")
+    try:
+        L.tlab_profile_reset(); L.tlab_profile_enable(1)
+        check(L.tlab_opr_burgers_add_n(3, g._h, nx, ny, nz, 0, 3, nu, sp, d[2].data_ptr(), hp, r.data_ptr(), t.data_ptr(), 0), "burgers_add_n")
+        torch.cuda.synchronize()
+        L.tlab_profile_enable(0)
+        buf = ctypes.create_string_buffer(1 << 14); L.tlab_profile_report(buf, len(buf))
+        assert "k_ptile<BURGERS>" in buf.value.decode(), buf.value.decode()
+    finally:
+        L.tlab_set_tuning(4, 0)
+    for i in range(3):
+        ref = h0[i] + O.opr_burgers(3, nx, ny, nz, 0, og, nu[i], f[i], f[2])[0]
+        assert rel_err(h[i].cpu().numpy(), ref) <= 1e-12, (grid, i)

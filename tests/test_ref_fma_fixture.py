@@ -16,7 +16,7 @@ FIX = os.path.join(ROOT, "tests", "golden", "ref_fma_scatter.npz")
 def test_fixture_is_complete_and_sane():
     f = np.load(FIX)
     meta = json.loads(str(f["_meta"]))
-    assert "haswell" in meta["fma"] and "amdflang" in meta["compiler"].lower() or "flang" in meta["compiler"].lower()
+    assert "haswell" in meta["fma"] and ("amdflang" in meta["compiler"].lower() or "flang" in meta["compiler"].lower())
     for n in meta["line_lengths"]:
         for kind in ("periodic", "uniform", "stretched"):
             for d in ("der1", "der2"):

@@ -1080,6 +1080,7 @@ int tlab_set_tuning(int key, int value) {
     if (key == 1) { rtile_force_chunk(value); return TLAB_OK; }
     if (key == 2) { g_htile_policy = value; return TLAB_OK; }
     if (key == 3 && (value == 16 || value == 32)) { htile_set_lines(value); return TLAB_OK; }
+    if (key == 4 && value >= 0) { ptile_set_grid(value); return TLAB_OK; }      // persistent workgroups of k_ptile (0 = one per CU, rounded to a multiple of 8)
     g_err = "tlab_set_tuning: unknown key";
     return TLAB_EINVAL;
 }

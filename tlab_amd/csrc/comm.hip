@@ -264,10 +264,10 @@ namespace {
 int pencil_alltoallv_start(void *ctx, void *stream, int which, double *const *send, const long long *scount, double *const *recv, const long long *rcount) {
     try {
         tlab_comm *c = static_cast<tlab_comm *>(ctx);
+        if (which < 0 || which > 2) throw Fail{TLAB_EINVAL, "pencil transport: communicator 0 (world), 1 (x) or 2 (z)"};
         ncclComm_t nc = which == 0 ? c->world : (which == 1 ? c->cx : c->cz);
         const int S = which == 0 ? c->nranks : (which == 1 ? c->npro_i : c->npro_k);
         const int me = which == 0 ? c->rank : (which == 1 ? c->pro_i : c->pro_k);
-        if (which < 0 || which > 2) throw Fail{TLAB_EINVAL, "pencil transport: communicator 0 (world), 1 (x) or 2 (z)"};
         const int t = slab_begin(c, (hipStream_t)stream);
         long long so = 0, ro = 0, my_so = 0, my_ro = 0;
         ncclResult_t r = ncclSuccess, e = ncclSuccess;

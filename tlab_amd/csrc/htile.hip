@@ -576,7 +576,13 @@ __global__ void __launch_bounds__(L * C, 1) k_ptile(RTileArgs a, long long nitem
         long long tile;
         int fi;
         decode(item, tile, fi);
-        if (tile >= ntiles) continue;         // padding of the item range: the whole workgroup skips (its prefetch skipped it as well)
+        if (tile >= ntiles) {                 // padding of the item range: nothing to compute (its own prefetch was skipped as well), but the operand
+            // tile of the workgroup's NEXT item must still be brought in -- that item is padding too only when gridDim.x is a multiple of 8
+            if (item + gridDim.x < nitems) prefetch(item + gridDim.x);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            continue;
+        }
         const long long outer = tile / tiles_inner;
         const int l0 = (int)(tile % tiles_inner) * L;
         const int row0 = c * M;
@@ -711,12 +717,18 @@ static int g_htile_persist = [] { const char *e = getenv("TLAB_HTILE_PERSIST"); 
 // (A/B on one box): 1 = the first only (default), 2 = both, 0 = neither
 static int g_ptile_band = [] { const char *e = getenv("TLAB_PTILE_BAND"); return e ? atoi(e) : 1; }();
 static int g_ncu = 0;
+static int g_ptile_grid = 0;       // > 0: forced number of persistent workgroups (tests: a count that is not a multiple of 8)
+void ptile_set_grid(int n) { g_ptile_grid = n > 0 ? n : 0; }
 static long long ptile_cus() {
+    if (g_ptile_grid) return g_ptile_grid;
     if (!g_ncu) {
         int dev = 0;
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) g_ncu = pr.multiProcessorCount;
         if (g_ncu <= 0) g_ncu = 256;
+        // items of one tile-octet sit on the 8 XCDs (item & 7): a grid that is a multiple of 8 keeps (item & 7) fixed per workgroup, so that a workgroup whose
+        // first item is padding only ever sees padding (partitioned parts report 38 / 228 CUs; the kernel is correct without this, only slower)
+        g_ncu = g_ncu >= 8 ? (g_ncu / 8) * 8 : 8;
     }
     return g_ncu;
 }

@@ -140,6 +140,7 @@ void rtile_force_chunk(int m);
 hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XLineArgs &a, hipStream_t st);
 hipError_t launch_rtile(int mode, const RTileArgs &a, hipStream_t st);
 int htile_chunk(int n, int mode);
+void ptile_set_grid(int n);       // tests: forced grid of the persistent kernel (0 = default)
 void htile_set_lines(int lines);   // tuning: 16 = narrow Burgers tiles (two workgroups per CU)
 bool htile_narrow();
 hipError_t launch_htile(int mode, const RTileArgs &a, hipStream_t st);

@@ -94,9 +94,10 @@ int lb_wait(void *, void *, int) { return TLAB_OK; }
 int lb_allreduce(void *ctx, double *v, int n, int op) {
     const Loopback *L = static_cast<Loopback *>(ctx);
     const int P = L->npi * L->npk;
+    if (op < 0 || op > 2) return TLAB_EINVAL;      // 0 = max, 1 = min, 2 = sum (as tlab_slab_transport, include/tlab_amd.h)
     for (int i = 0; i < n; ++i) {
         double a = v[i];
-        for (int r = 1; r < P; ++r) a = op == 0 ? std::max(a, v[r * n + i]) : std::min(a, v[r * n + i]);
+        for (int r = 1; r < P; ++r) a = op == 0 ? std::max(a, v[r * n + i]) : (op == 1 ? std::min(a, v[r * n + i]) : a + v[r * n + i]);
         for (int r = 0; r < P; ++r) v[r * n + i] = a;
     }
     return TLAB_OK;

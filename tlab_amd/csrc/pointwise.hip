@@ -333,6 +333,16 @@ __global__ void __launch_bounds__(256) k_surface_flux(double *__restrict__ ref, 
     const double hfx_avg = diff * avg[0];
     ref[q] = ref[q] + cpl * (hfx - hfx_avg);
 }
+// the same with the plane average as a kernel argument (z-slab driver: the all-reduced value lives on the host)
+__global__ void __launch_bounds__(256) k_surface_flux_v(double *__restrict__ ref, const double *__restrict__ t, int j, double sign, double diff, double cpl,
+                                                        double avg, int nx, int ny, int nz) {
+#pragma clang fp contract(off)
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)nx * nz) return;
+    const double hfx = sign * diff * t[(q % nx) + (long long)nx * (j + (long long)ny * (q / nx))];
+    const double hfx_avg = diff * avg;
+    ref[q] = ref[q] + cpl * (hfx - hfx_avg);
+}
 hipError_t launch_surface_flux(double *ref, const double *t, int j, int javg, double sign, double diff, double cpl, double *avg_scratch, int nx, int ny,
                                int nz, hipStream_t st) {
     hipLaunchKernelGGL(k_plane_sum, dim3(1), dim3(1024), 0, st, t, javg, nx, ny, nz, avg_scratch);
@@ -344,9 +354,9 @@ hipError_t launch_plane_avg(const double *t, int j, int nx, int ny, int nz, doub
     hipLaunchKernelGGL(k_plane_sum, dim3(1), dim3(1024), 0, st, t, j, nx, ny, nz, avg);
     return CHECK_LAUNCH();
 }
-hipError_t launch_surface_flux_avg(double *ref, const double *t, int j, double sign, double diff, double cpl, const double *avg, int nx, int ny, int nz,
+hipError_t launch_surface_flux_avg(double *ref, const double *t, int j, double sign, double diff, double cpl, double avg, int nx, int ny, int nz,
                                    hipStream_t st) {
-    hipLaunchKernelGGL(k_surface_flux, dim3(pw_grid((long long)nx * nz)), dim3(256), 0, st, ref, t, j, sign, diff, cpl, avg, nx, ny, nz);
+    hipLaunchKernelGGL(k_surface_flux_v, dim3(pw_grid((long long)nx * nz)), dim3(256), 0, st, ref, t, j, sign, diff, cpl, avg, nx, ny, nz);
     return CHECK_LAUNCH();
 }
 hipError_t launch_scale(double *a, double alpha, long long n, hipStream_t st) {

@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
 #define FAC(p, q) my_fac[(p) * 3 + (q)]
     double (&rhs)[OM][NL] = x;          // right-hand side -> y -> x in place
     double bcs_b[NL], bcs_t[NL];
-    static_assert(NL <= OK_SIZE - OK_FS, "parking rows");
+    static_assert(NL <= OK_CST - OK_FS, "parking rows (the mode constants start at OK_CST)");
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         // the only use of fl after the right-hand side: f(n-2) of the last chunk (BCS_MAX) / f(1) of the first one (BCS_MIN), for du -- parked in

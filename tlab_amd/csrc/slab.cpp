@@ -51,7 +51,7 @@ hipError_t launch_wall_fix(double *q, double *h, const double *sb, const double 
                            hipStream_t stream);
 hipError_t launch_copy_blocks(int n, const double *const *src, double *const *dst, const long long *cnt, hipStream_t st);      // pointwise.hip
 hipError_t launch_plane_avg(const double *t, int j, int nx, int ny, int nz, double *avg, hipStream_t st);
-hipError_t launch_surface_flux_avg(double *ref, const double *t, int j, double sign, double diff, double cpl, const double *avg, int nx, int ny, int nz,
+hipError_t launch_surface_flux_avg(double *ref, const double *t, int j, double sign, double diff, double cpl, double avg, int nx, int ny, int nz,
                                    hipStream_t st);
 hipError_t launch_get_wall_planes(const double *f, double *hb, double *ht, int nx, int ny, int nz, hipStream_t st);
 }
@@ -584,11 +584,10 @@ void rhs_halo(D *d, double dte, bool tail, double tdte, double kco, int scale) {
     auto surface_flux_local = [&](Rank &R, int is) {
         const double diff = d->visc / d->schmidt[is];
         ok(tlab_opr_partial(2, d->g[1], TLAB_OPR_P1, nx, ny, kmax, 0, R.s[is], R.txc[4], nullptr), "OPR_Partial_Y (surface flux)");
-        hk(hipMemcpyAsync(R.sfc_avg, &sfc_avg_host[is], sizeof(double), hipMemcpyHostToDevice, tlab_current_stream()), "hipMemcpyAsync");
         if (d->sfc_jmin[is] == 1)
-            hk(tlab::launch_surface_flux_avg(R.sref_b[is], R.txc[4], 0, 1.0, diff, d->cpl_jmin[is], R.sfc_avg, nx, ny, kmax, tlab_current_stream()), "k_surface_flux");
+            hk(tlab::launch_surface_flux_avg(R.sref_b[is], R.txc[4], 0, 1.0, diff, d->cpl_jmin[is], sfc_avg_host[is], nx, ny, kmax, tlab_current_stream()), "k_surface_flux");
         if (d->sfc_jmax[is] == 1)
-            hk(tlab::launch_surface_flux_avg(R.sref_t[is], R.txc[4], ny - 1, -1.0, diff, d->cpl_jmax[is], R.sfc_avg, nx, ny, kmax, tlab_current_stream()), "k_surface_flux");
+            hk(tlab::launch_surface_flux_avg(R.sref_t[is], R.txc[4], ny - 1, -1.0, diff, d->cpl_jmax[is], sfc_avg_host[is], nx, ny, kmax, tlab_current_stream()), "k_surface_flux");
     };
     surface_averages();
     // ---- hq -= grad p, boundary conditions (:348-398) [+ RK update] ----
