@@ -464,6 +464,19 @@ def main():
     issue_empty = time.perf_counter() - t0
     torch.cuda.synchronize()
     finite = all(bool(torch.isfinite(t).all()) for t in state_fields)
+    # what RCCL itself saw (ncclCommCount / ncclCommCuDevice of the communicator inside libtlab_amd_comm.so), not what this script passed in: the first
+    # multi-GPU run must be diagnosable from its one JSON line.  None: no RCCL communicator in this run (single GPU, loopback, gloo functional mode,
+    # or the Python fall-back driver over torch's own NCCL group).
+    rccl_ranks = rccl_device = None
+    nc = getattr(d, "_keep", None)
+    if nc is not None and hasattr(nc, "info"):
+        try:
+            rccl_ranks, rccl_device = int(nc.info(6)), int(nc.info(8))
+        except Exception:       # noqa: BLE001
+            rccl_ranks = rccl_device = None
+    driver_name = ("tlab_pencil_dns (csrc/pencil.cpp)" if args.slab_driver == "native" else "tlab_amd/pencil.py") if args.decomp else \
+                  ("tlab_dns (csrc/rhs.cpp)" if (world == 1 and args.loopback <= 1) else
+                   "tlab_slab_dns (csrc/slab.cpp)" if args.slab_driver == "native" else "tlab_amd/parallel.py::SlabDns (%s)" % args.slab_driver)
 
     if rank == 0:
         import ctypes
@@ -527,6 +540,9 @@ def main():
                        "parallelism": ("DIAGNOSTIC: x/z pencils %s (%s, %s driver), I-/K-transpositions per x/z operator, Poisson on kx-pencils" % (args.decomp, "one block per GPU" if world > 1 else "all ranks back to back on one GPU, exchanges = copies", args.slab_driver)) if args.decomp else
                                       ("single GPU" if args.loopback <= 1 else "DIAGNOSTIC: %d z-slab ranks (%s mode, %s driver) executed back to back on one GPU, no communication" % (args.loopback, d.zmode, args.slab_driver)) if world == 1 else
                        ("z-slabs 1x%d, halo planes + interface values between neighbours for d/dz, kx-pencil Poisson (3 all-to-alls per substep in two pipelined halves), %s driver, %s" % (world, args.slab_driver, ("RCCL of libtlab_amd_comm.so (start-up over a %s group)" % bootstrap) if backend == "nccl" else backend + " (functional run, host-staged)") if d.zmode == "halo" else "z-slabs 1x%d, K-transposes = RCCL all_to_all_single per z-operator / z-FFT" % world),
+                       "driver": driver_name, "rccl_ranks": rccl_ranks, "rccl_device_of_rank0": rccl_device, "world_size": world,
+                       "transport": ("none (one domain)" if (world == 1 and args.loopback <= 1 and not args.decomp) else "loopback copies" if world == 1 else
+                                     ("RCCL (libtlab_amd_comm.so)" if rccl_ranks is not None else "torch.distributed %s" % (backend if backend != "nccl" else "nccl group"))),
                        "fields_finite": finite},
             "roofline": None if dom is None else {
                 "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -36,7 +36,8 @@ int tlab_comm_get_unique_id(void *id_bytes);
  * (ncclCommSplit).  The calling process must already have selected its GPU (tlab_init). */
 int tlab_comm_init(tlab_comm_t *out, const void *id_bytes, int nranks, int rank, int npro_i, int npro_k);
 int tlab_comm_destroy(tlab_comm_t comm);
-int tlab_comm_info(tlab_comm_t comm, int what);   /* 0 ims_pro, 1 ims_npro, 2 ims_pro_i, 3 ims_npro_i, 4 ims_pro_k, 5 ims_npro_k */
+int tlab_comm_info(tlab_comm_t comm, int what);   /* 0 ims_pro, 1 ims_npro, 2 ims_pro_i, 3 ims_npro_i, 4 ims_pro_k, 5 ims_npro_k;
+                                                    * from RCCL itself: 6 ncclCommCount, 7 ncclCommUserRank, 8 ncclCommCuDevice of the world communicator */
 /* MPI_ALLREDUCE(.., MPI_MAX, ..) of TIME_COURANT (tools/dns/time.f90:522) on n device doubles, in place, on the current stream */
 int tlab_comm_allreduce_max(tlab_comm_t comm, double *dev_values, int n);
 

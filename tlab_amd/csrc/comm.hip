@@ -365,6 +365,10 @@ int tlab_comm_info(tlab_comm_t c, int what) {
         case 3: return c->npro_i;
         case 4: return c->pro_k;
         case 5: return c->npro_k;
+        // what RCCL itself reports for the world communicator (not what the caller passed to tlab_comm_init): ranks, this rank, its device
+        case 6: { int v = -1; return (c->world && ncclCommCount(c->world, &v) == ncclSuccess) ? v : TLAB_EHIP; }
+        case 7: { int v = -1; return (c->world && ncclCommUserRank(c->world, &v) == ncclSuccess) ? v : TLAB_EHIP; }
+        case 8: { int v = -1; return (c->world && ncclCommCuDevice(c->world, &v) == ncclSuccess) ? v : TLAB_EHIP; }
     }
     return TLAB_EINVAL;
 }
