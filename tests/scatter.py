@@ -67,8 +67,61 @@ class Bound(float):
     __hash__ = float.__hash__
 
 
-def bound(scatter, factor=2.0):
-    return Bound(scatter, factor)
+def bound(scatter, factor=2.0, source="oracle one-ulp scatter"):
+    return Bound(scatter, factor, source)
+
+
+CPU_PORT_SOURCE = "one-ulp scatter of the C/OpenMP port (oracle/tlab_cpu.c)"
+
+
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup's CPU bandwidth quota if there is one, else the affinity mask (the GPU boxes show 256 logical CPUs and
+    grant 16: an OpenMP team of 256 threads would only queue up)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:      # noqa: BLE001
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return min(n, max(1, int(round(int(q) / int(per)))))
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return min(n, max(1, int(round(q / per))))
+    except Exception:      # noqa: BLE001
+        pass
+    return n
+
+
+_CPU_PORTS = {}
+
+
+def cpu_port_factory(x, y, z, nscal, visc, schmidt, yuniform, hyper_bc1_ext=None):
+    """make_oracle() for substep_scatter on the C + OpenMP restatement of the reference's CPU path (oracle/tlab_cpu.c through oracle/tlab_cpu.py) instead of the
+    single-threaded numpy oracle: the checker for the cases with 1e7 points and more (the numpy oracle took 420 of the GPU suite's 735 s on
+    four of them).  The port is held to the golden vectors of the reference and to the numpy oracle on the CPU (tests/test_cpu_baseline.py: operators
+    <= 1e-14, substeps within the scatter bound); it restates no-slip walls / Dirichlet scalars with the default schemes only.  ONE driver per grid is
+    built and handed out again with zeroed tendencies (its plan construction is numpy work of several seconds)."""
+    from oracle import tlab_cpu as C
+    key = (len(x), len(y), len(z), float(x[1] - x[0]), float(y[1] - y[0]), float(y[-1]), int(nscal), float(visc), tuple(float(v) for v in schmidt), bool(yuniform),
+           hyper_bc1_ext)
+
+    def make():
+        L = C.load()
+        L.tlabcpu_set_num_threads(max(1, min(cpu_quota(), L.tlabcpu_num_threads())))
+        if key not in _CPU_PORTS:
+            _CPU_PORTS.clear()                 # one grid at a time: a driver of 2048 x 1024 x 8 points with three scalars holds 3.5 GB
+            _CPU_PORTS[key] = C.CpuDnsDriver(x, y, z, nscal=nscal, visc=visc, schmidt=tuple(schmidt), yuniform=yuniform, hyper_bc1_ext=hyper_bc1_ext)
+        c = _CPU_PORTS[key]
+        c.hq = [np.zeros(c.n) for _ in range(3)]
+        c.hs = [np.zeros(c.n) for _ in range(nscal)]
+        return c
+    return make
 
 
 _REF_FMA = None

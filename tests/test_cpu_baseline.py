@@ -99,3 +99,29 @@ def test_substeps_match_numpy_oracle(nx, ny, nz, stretch, nscal):
             for i, (a, b) in enumerate(zip(getattr(c, name), B[k][name])):
                 assert rel_err(a, b) <= bound(S[k][name][i]), (k, name, i, rel_err(a, b), S[k][name][i])
     assert C.load().tlabcpu_num_threads() >= 1
+
+
+def test_port_as_the_checker_of_the_large_gpu_cases():
+    """tests/scatter.py::cpu_port_factory -- what the GPU suite uses instead of the numpy oracle from 4e6 points on -- driven exactly as there (one driver
+    per grid, handed out again with zeroed tendencies, new_step flags) and held to the numpy oracle through the same substep_scatter interface."""
+    from oracle.tlab_oracle_rhs import DnsOracle
+    from scatter import substep_scatter, bound, cpu_port_factory
+    nx, ny, nz, nscal = 32, 40, 16, 2
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    sc = (0.7, 1.3)
+    rng = np.random.default_rng(11)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    f = [((np.sin(np.pi * X + i) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for i in range(5)]
+    sched = [(2e-3 / 3, -5.0 / 9.0, True, True), (2e-3 * 15 / 16, -153.0 / 128.0, True, False), (2e-3 * 8 / 15, 1.0, False, False), (2e-3 / 3, -5.0 / 9.0, True, True)]
+    make = cpu_port_factory(x, y, z, nscal, 1.0 / 800.0, sc, False)
+    Bc, Sc = substep_scatter(make, f[:3], f[3:], sched, nsamples=1)
+    Bc2, _ = substep_scatter(make, f[:3], f[3:], sched, nsamples=1)          # the re-used driver starts from the same state
+    Bn, Sn = substep_scatter(lambda: DnsOracle(x, y, z, nscal=nscal, visc=1.0 / 800.0, schmidt=sc, yuniform=False), f[:3], f[3:], sched, nsamples=2)
+    for k in range(len(sched)):
+        for name in ("q", "hq", "s", "hs"):
+            for i, (a, b) in enumerate(zip(Bc[k][name], Bn[k][name])):
+                assert np.array_equal(a, Bc2[k][name][i])
+                assert rel_err(a, b) <= bound(Sn[k][name][i]), (k, name, i, rel_err(a, b), Sn[k][name][i])

@@ -11,38 +11,42 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,zmode,nz,bcs", [(2, "halo", 128, "noslip"), (3, "halo", 192, "freeslip"), (2, "transpose", 64, "noslip")])
-def test_multiprocess_slabs(world, zmode, nz, bcs):
+def _launch(world, port, script_args, env, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+# (driver, zmode, nz, bcs, nx) per world size -- ONE torch.distributed.run launch per world size (round 4 started one per case: twelve interpreter
+# start-ups of 4-9 s each inside the driver's time limit); every case prints its own DIST_CHECK line and all of them are asserted
+GLOO_CASES = {
+    2: [("python", "halo", 128, "noslip", 32), ("python", "transpose", 64, "noslip", 32), ("native", "auto", 128, "noslip", 32), ("native", "auto", 128, "noslip", 128)],
+    3: [("python", "halo", 192, "freeslip", 48), ("native", "auto", 192, "freeslip", 48), ("native", "auto", 192, "freeslip", 128)],
+}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multiprocess_slab_drivers(world):
+    """P processes share the one GPU (gloo, host-staged payloads).  Python driver (tlab_amd/parallel.py::SlabDns): halo and transposition schemes.  Native
+    C++ driver (tlab_slab_dns_*) with the five transport entry points supplied by the caller (ctypes callbacks over gloo, tlab_amd/slab.py::dist_transport):
+    rank-local plans, ring pairing with 2 and 3 ranks, uneven kx-pencils in two halves, monitors -- against the single-domain step each rank computes
+    redundantly.  nx = 128: the repack passes are folded into the library's own x-transforms and (no-slip) v is finished by the inverse transform of dp^/dy."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, TLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29540 + world + (7 if zmode == "halo" else 0)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_check.py"), "--zmode", zmode, "--nz", str(nz), "--bcs", bcs,
-           "--nx", "32" if world != 3 else "48"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "DIST_CHECK" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
-
-
-@pytest.mark.parametrize("world,nz,bcs,nx", [(2, 128, "noslip", 32), (3, 192, "freeslip", 48), (2, 128, "noslip", 128), (3, 192, "freeslip", 128)])
-def test_multiprocess_native_slab_driver(world, nz, bcs, nx):
-    """The C++ slab driver (tlab_slab_dns_*), one rank per PROCESS, with the five transport entry points supplied by the caller (ctypes callbacks over
-    gloo with host-staged payloads, tlab_amd/slab.py::dist_transport): rank-local plans, ring pairing with 2 and 3 ranks, uneven kx-pencils in two
-    halves, monitors -- against the single-domain step each rank computes redundantly.  nx = 128: the repack passes are folded into the
-    library's own x-transforms and (no-slip) v is finished by the inverse transform of dp^/dy."""
-    import torch
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    env = dict(os.environ, TLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29570 + world + (10 if nx == 128 else 0)), os.path.join(ROOT, "tools", "dist_check.py"), "--driver", "native",
-           "--nz", str(nz), "--bcs", bcs, "--nx", str(nx)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "DIST_CHECK driver=native" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
-    assert ("fused_x=1" if nx == 128 else "fused_x=0") in out.stdout, out.stdout[-2000:]
+    cases = GLOO_CASES[world]
+    spec = ";".join("%s:%s:%d:%s:%d" % c for c in cases)
+    out = _launch(world, 29540 + world, [os.path.join(ROOT, "tools", "dist_check.py"), "--cases", spec], env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("DIST_CHECK")]
+    assert len(lines) == len(cases), out.stdout[-3000:]
+    for (drv, zm, nz, bcs, nx), ln in zip(cases, lines):
+        assert ("driver=%s world=%d" % (drv, world)) in ln and ("nx=%d nz=%d bcs=%s" % (nx, nz, bcs)) in ln and ln.endswith(" OK"), ln
+        if drv == "python":
+            assert "zmode=%s" % zm in ln, ln
+        else:
+            assert ("fused_x=1" if nx == 128 else "fused_x=0") in ln, ln
 
 
 def test_native_slab_driver_over_rccl_world_size_one():
@@ -55,10 +59,14 @@ def test_native_slab_driver_over_rccl_world_size_one():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("TLAB_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29561", os.path.join(ROOT, "tools", "dist_check.py"), "--driver", "native", "--nz", "64"]
+           "--master-port", "29561", os.path.join(ROOT, "tools", "dist_check.py"), "--cases", "native:auto:64:noslip:32;python:transpose:128:noslip:32"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "DIST_CHECK driver=native world=1" in out.stdout and "backend=nccl" in out.stdout and " OK" in out.stdout, out.stdout[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("DIST_CHECK")]
+    assert len(lines) == 2, out.stdout[-2000:]
+    assert "driver=native world=1" in lines[0] and "backend=nccl" in lines[0] and "rccl_ranks=1" in lines[0] and lines[0].endswith(" OK"), lines[0]
+    # ... and the Python driver's DistComm on torch's NCCL group with device buffers (the fall-back of bench.py --gpus N), transposition scheme
+    assert "driver=python world=1 zmode=transpose backend=nccl" in lines[1] and lines[1].endswith(" OK"), lines[1]
 
 
 def test_native_slab_driver_over_rccl_with_a_gloo_start_up():
@@ -85,7 +93,7 @@ def test_rccl_operations_of_the_slab_driver():
         pytest.skip("no GPU")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("TLAB_DIST_BACKEND", None)
-    for script, mark, extra in (("rccl_check.py", "RCCL_CHECK", []), ("dist_check.py", "DIST_CHECK", ["--zmode", "transpose"])):
+    for script, mark, extra in (("rccl_check.py", "RCCL_CHECK", []),):      # (its slab substep on that backend: second case of the test above)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", "29557", os.path.join(ROOT, "tools", script)] + extra
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

@@ -335,6 +335,7 @@ def test_fortran_rk_driver_direct_schemes_from_the_ini_file(tmp_path):
     assert rel_err(s1[0], B[2]["s"][0]) <= bound(S[2]["s"][0])
 
 
+@pytest.mark.gpu_extra
 @pytest.mark.parametrize("divergence", ["remove", "none"])
 def test_fortran_rk_driver_staggered_pressure(tmp_path, divergence):
     """[Staggering] StaggerHorizontalPressure = yes (examples/Case92-93) and [Main] TermDivergence read from tlab.ini: the reference's own

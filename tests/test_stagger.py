@@ -80,6 +80,7 @@ def dev():
     return T
 
 
+@pytest.mark.gpu_extra
 @pytest.mark.gpu
 @pytest.mark.parametrize("d", [1, 3])
 @pytest.mark.parametrize("t", TYPES)
@@ -92,6 +93,7 @@ def test_device_interpolatory_operators_vs_fixture(dev, d, t):
     assert rel_err(r.cpu().numpy().reshape(nz, ny, nx), G["d%d_t%d" % (d, t)]) <= 1e-13, (d, t)
 
 
+@pytest.mark.gpu_extra
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [256, 1024])
 def test_device_interpolatory_operators_long_lines(dev, n):
@@ -108,6 +110,7 @@ def test_device_interpolatory_operators_long_lines(dev, n):
             assert rel_err(r.cpu().numpy().reshape(shape), np.asarray(e).reshape(shape)) <= 1e-12, (d, t)
 
 
+@pytest.mark.gpu_extra
 @pytest.mark.gpu
 def test_interpolatory_type_without_tables_is_refused(dev):
     import torch
@@ -117,6 +120,7 @@ def test_interpolatory_type_without_tables_is_refused(dev):
         device_partial(1, T.OPR_P0_INT_VP, g, n, 2, 2, torch.zeros(n * 4, dtype=torch.float64, device="cuda"))
 
 
+@pytest.mark.gpu_extra
 @pytest.mark.gpu
 @pytest.mark.parametrize("fuse", [True, False])
 def test_staggered_substeps_vs_oracle(dev, fuse):

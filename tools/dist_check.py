@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--driver", default="python", choices=["python", "native"], help="python: tlab_amd/parallel.py::SlabDns over torch.distributed; "
                     "native: the C++ driver (tlab_slab_dns_*) with the RCCL transport of libtlab_amd_comm.so (backend nccl) or, on gloo, with the "
                     "host-staged callback transport (several ranks on one GPU)")
+    ap.add_argument("--cases", default="", help='several cases in one launch: "driver:zmode:nz:bcs:nx;..." (overrides the single-case options)')
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -43,7 +44,24 @@ def main():
     from tlab_amd.dns import Dns
     from tlab_amd.parallel import SlabDns, DistComm
     T.init(dev)
-    nx, ny, nz = args.nx, args.ny, args.nz
+    # --cases "driver:zmode:nz:bcs:nx;..." : several checks in ONE launch (one interpreter start-up and one process group per world size instead of one
+    # per case: tests/test_gpu_dist.py); without it the single case of the other options
+    cases = [(args.driver, args.zmode, args.nz, args.bcs, args.nx)]
+    if args.cases:
+        cases = []
+        for c in args.cases.split(";"):
+            drv, zm, nz_, bcs_, nx_ = c.split(":")
+            cases.append((drv, zm, int(nz_), bcs_, int(nx_)))
+    overall = 0.0
+    for drv, zm, nz, bcs, nx in cases:
+        worst = one_case(args, T, Dns, SlabDns, DistComm, torch, dist, rank, world, backend, bootstrap, drv, zm, nx, args.ny, nz, bcs)
+        overall = max(overall, worst)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if overall <= 1e-11 else 1)
+
+
+def one_case(args, T, Dns, SlabDns, DistComm, torch, dist, rank, world, backend, bootstrap, driver, zmode, nx, ny, nz, bcs):
     x = np.arange(nx) / nx * 2.0
     z = np.arange(nz) / nz
     y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
@@ -52,12 +70,12 @@ def main():
     wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
     fields = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
     one = Dns(x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, hyper_bc1_ext=REF_HYPER)
-    if args.driver == "native":
+    if driver == "native":
         from tlab_amd.slab import NativeSlabDns
         slab = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, hyper_bc1_ext=REF_HYPER)
     else:
-        slab = SlabDns(DistComm(), x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, zmode=args.zmode, hyper_bc1_ext=REF_HYPER)
-    if args.bcs == "freeslip":
+        slab = SlabDns(DistComm(), x, y, z, nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, zmode=zmode, hyper_bc1_ext=REF_HYPER)
+    if bcs == "freeslip":
         one.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
         slab.set_bcs("freeslip", "freeslip", "neumann", "dirichlet")
     for i in range(3):
@@ -91,12 +109,19 @@ def main():
     if bootstrap == "nccl":
         tt = tt.cuda()
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    rccl_ranks = None
+    nc = getattr(slab, "_keep", None)
+    if driver == "native" and backend == "nccl" and nc is not None and hasattr(nc, "info"):
+        rccl_ranks = nc.info(6)            # ncclCommCount of the communicator inside libtlab_amd_comm.so
     if rank == 0:
-        print("DIST_CHECK driver=%s world=%d zmode=%s backend=%s bootstrap=%s fused_x=%d worst_rel_err=%.3e %s" % (
-            args.driver, world, slab.zmode, backend, bootstrap, int(getattr(slab, "fused_x", False)), float(tt.item()), "OK" if float(tt.item()) <= 1e-11 else "FAIL"))
+        print("DIST_CHECK driver=%s world=%d zmode=%s backend=%s bootstrap=%s fused_x=%d nx=%d nz=%d bcs=%s rccl_ranks=%s worst_rel_err=%.3e %s" % (
+            driver, world, slab.zmode, backend, bootstrap, int(getattr(slab, "fused_x", False)), nx, nz, bcs, rccl_ranks, float(tt.item()),
+            "OK" if float(tt.item()) <= 1e-11 else "FAIL"), flush=True)
+    torch.cuda.synchronize()
+    if hasattr(slab, "close"):
+        slab.close()
     dist.barrier()
-    dist.destroy_process_group()
-    sys.exit(0 if float(tt.item()) <= 1e-11 else 1)
+    return float(tt.item())
 
 
 if __name__ == "__main__":
