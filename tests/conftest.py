@@ -64,7 +64,7 @@ def has_gpu():
     return torch.cuda.is_available()
 
 
-PARITY_ROUND = "r04"
+PARITY_ROUND = "r05"
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -93,7 +93,10 @@ def pytest_sessionfinish(session, exitstatus):
                   "within_1e-12": bool(k["max_err"] <= 1e-12)} for (t, by), k in sorted(rows.items())]
         try:
             head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
-            head = head or os.environ.get("TLAB_COMMIT") or None        # the GPU box has no .git: the caller may pass the commit
+            head = head or os.environ.get("TLAB_COMMIT") or None        # the GPU box has no .git: the caller may pass the commit ...
+            stamp = os.path.join(ROOT, "tlab_amd", "BUILD_COMMIT")       # ... or build() left it beside the libraries it built (__graft_entry__.py)
+            if head is None and os.path.exists(stamp):
+                head = open(stamp).read().strip() or None
         except Exception:       # noqa: BLE001
             head = None
         doc = {"what": "device error vs yardstick vs bound for every composed-path comparison of this pytest session (tests/scatter.py::Bound); yardstick = "
