@@ -55,6 +55,14 @@ class DnsOracle:
     def p1(self, d, u):
         return O.opr_partial(d, O.OPR_P1, self.nx, self.ny, self.nz, 0, self.g[d - 1], u)[0]
 
+    def solve_poisson(self, f, hb, ht):
+        """OPR_Poisson (factorized); a subclass may put the reference's compiled per-mode routines here (oracle/tlab_ref_rhs.py)"""
+        return OP.opr_poisson_fxz(self.poisson, f, hb, ht)
+
+    def neumann_y(self, ibc, a):
+        """BOUNDARY_BCS_NEUMANN_Y -> (bcs_hb, bcs_ht)"""
+        return O.boundary_bcs_neumann_y(ibc, self.nx, self.ny, self.nz, self.g[1], a)
+
     def pint(self, d, itype, u):
         """OPR_Partial_X / _Z with an interpolatory type (OPR_P0_INT_VP ...), opr_partial.f90:110-120, :228-238"""
         return O.opr_partial(d, itype, self.nx, self.ny, self.nz, 0, self.g[d - 1], u)[0]
@@ -103,7 +111,7 @@ class DnsOracle:
         if self.direct:
             p, dpdy = OP.opr_poisson_fxz_direct(self.poisson, tmp1, hb, ht, gy_der=self.g[1])
         else:
-            p, dpdy = OP.opr_poisson_fxz(self.poisson, tmp1, hb, ht)                                                # :284
+            p, dpdy = self.solve_poisson(tmp1, hb, ht)                                                              # :284
         if any(f is not None for f in self.pressure_filter):                                                       # :286-290
             from .tlab_oracle_filter import opr_filter
             p = opr_filter(nx, ny, nz, self.pressure_filter, p)
@@ -126,7 +134,7 @@ class DnsOracle:
                 ref_b, ref_t = sref_b[ia - 3], sref_t[ia - 3]
             ibc = (1 if tmin == 4 else 0) + (2 if tmax == 4 else 0)
             if ibc > 0:
-                nb, nt = O.boundary_bcs_neumann_y(ibc, nx, ny, nz, self.g[1], a)
+                nb, nt = self.neumann_y(ibc, a)
                 if ibc & 1:
                     ref_b = nb
                 if ibc & 2:

@@ -44,9 +44,11 @@ class Bound(float):
     (the right operand is an instance of a subclass of float that overrides the reflected method), so every use of a scatter-derived bound is logged
     with the error it was compared against -- pytest -q prints none of them, the table keeps all of them."""
 
-    def __new__(cls, scatter, factor, source="oracle one-ulp scatter"):
+    def __new__(cls, scatter, factor, source="oracle one-ulp scatter", ref=None):
         b = super().__new__(cls, max(FLOOR, factor * scatter))
         b.scatter, b.factor, b.source = float(scatter), float(factor), source
+        b.ref = ref          # (value, case[, one-ulp scatter of the reference's own routines]): by how much two builds of the REFERENCE differ on this very case
+        # and field, and how far its own routines move under one ulp of input noise (tests/golden/yardsticks.json), or None
         return b
 
     def _log(self, err):
@@ -54,6 +56,8 @@ class Bound(float):
         PARITY_RECORDS.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "err": float(err), "yardstick": self.source,
                                "yardstick_value": self.scatter, "factor": self.factor, "bound": float(self), "ok": bool(float(err) <= float(self)),
                                "within_1e-12": bool(float(err) <= FLOOR),
+                               "ref_build_diff": None if self.ref is None else float(self.ref[0]), "ref_build_case": None if self.ref is None else self.ref[1],
+                               "ref_one_ulp_scatter": None if (self.ref is None or len(self.ref) < 3 or self.ref[2] is None) else float(self.ref[2]),
                                "bound_set_by": "north-star floor 1e-12" if float(self) <= FLOOR else "%g x %s" % (self.factor, self.source)})
 
     def __ge__(self, err):
@@ -67,8 +71,34 @@ class Bound(float):
     __hash__ = float.__hash__
 
 
-def bound(scatter, factor=2.0, source="oracle one-ulp scatter"):
-    return Bound(scatter, factor, source)
+def bound(scatter, factor=2.0, source="oracle one-ulp scatter", ref=None):
+    return Bound(scatter, factor, source, ref)
+
+
+_YARD = None
+
+
+def ref_yardstick(key):
+    """tests/golden/yardsticks.json (made by tests/golden/make_golden_yardsticks.py in the build container): for the composed-path case `key` the
+    relative difference between two builds of the REFERENCE'S OWN ROUTINES (amdflang -O2 with / without fused multiply-adds) composed into the same
+    substeps on the same inputs (oracle/tlab_ref_rhs.py), per substep and field: {"q": [[..3..] per substep], "hq": ..., "s": ..., "hs": ...}; None
+    when the table has no such case."""
+    global _YARD
+    if _YARD is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yardsticks.json")
+        _YARD = json.load(open(path))["cases"] if os.path.exists(path) else {}
+    return _YARD.get(key)
+
+
+def ref_of(key, k, name, i):
+    """(value, case) for Bound(ref=...) or None"""
+    y = ref_yardstick(key) if key else None
+    if y is None or name not in y["diff"] or k >= len(y["diff"][name]) or i >= len(y["diff"][name][k]):
+        return None
+    u = y.get("ref_one_ulp_scatter")
+    return (y["diff"][name][k][i], key, None if u is None else u[name][k][i])
 
 
 CPU_PORT_SOURCE = "one-ulp scatter of the C/OpenMP port (oracle/tlab_cpu.c)"

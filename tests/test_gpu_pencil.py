@@ -4,7 +4,8 @@ transposed-velocity reuse, the Poisson solver on the 1 x (npro_i npro_k) slabs t
 for real; only the transport of the blocks is replaced by copies."""
 import numpy as np
 import pytest
-from scatter import bound, substep_scatter
+from scatter import bound, substep_scatter, ref_of
+import cases as C
 
 pytestmark = pytest.mark.gpu
 REF_HYPER = 0.1
@@ -43,12 +44,9 @@ def test_pencil_substeps_match_single_domain(T, npi, npk, nx, ny, nz, bcs):
     from tlab_amd.dns import Dns, velocity_bcs
     from tlab_amd.pencil import PencilDns, loopback_comms
     from oracle.tlab_oracle_rhs import DnsOracle
-    x, y, z = grids(nx, ny, nz)
-    rng = np.random.default_rng(10 * npi + npk)
-    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
-    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
-    fields = [((np.sin(X + k) * np.cos(2 * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
-    visc, sc = 1.0 / 300.0, (0.7,)
+    case = C.pencil(npi, npk, nx, ny, nz, bcs)
+    x, y, z, visc, sc = (case[k] for k in ("x", "y", "z", "visc", "sc"))
+    fields = case["q0"] + case["s0"]
     one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
     D = PencilDns(loopback_comms(npi, npk), npi, npk, x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
     if bcs == "freeslip":
@@ -71,11 +69,12 @@ def test_pencil_substeps_match_single_domain(T, npi, npk, nx, ny, nz, bcs):
         if bcs == "freeslip":
             o.flow_jmin = o.flow_jmax = velocity_bcs("freeslip"); o.scal_jmin, o.scal_jmax = [4], [3]
         return o
-    B, S = substep_scatter(make_oracle, fields[:3], fields[3:], [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=2)
+    assert [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)] == case["sched"]
+    B, S = substep_scatter(make_oracle, fields[:3], fields[3:], case["sched"], nsamples=2)
     for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
         for i, rf in enumerate(ref):
             got = gather(D, name, i, nx, ny, nz)
-            tol = bound(S[1][name][i])
+            tol = bound(S[1][name][i], ref=ref_of(case["key"], 1, name, i))
             rf = rf.cpu().numpy()
             err = float(np.abs(got - rf).max() / np.abs(rf).max())
             assert err <= tol, ("pencils vs single domain", name, i, err, tol)

@@ -3,17 +3,20 @@ and of the invariant the projection must satisfy (interior divergence of the new
 import numpy as np
 import pytest
 from conftest import rel_err
-from scatter import substep_scatter, bound, FLOOR, cpu_port_factory, CPU_PORT_SOURCE
+from scatter import substep_scatter, bound, FLOOR, cpu_port_factory, CPU_PORT_SOURCE, ref_of
+import cases as C
+from cases import grids, init_fields      # noqa: F401  (the inputs of the composed-path cases live in tests/cases.py: the yardstick generator uses them too)
 
 REF_HYPER = 0.1      # wall closure of the flang-built reference (defect 1); the driver classes default to the consistent 0.0
 
 
-def check_state(d, B, S, k, names=("q", "hq", "s", "hs"), tag="", factor=2.0, source=None):
-    """Device state after substep k against the oracle's, each field within max(1e-12, factor x the oracle's own one-ulp scatter) (tests/scatter.py)."""
+def check_state(d, B, S, k, names=("q", "hq", "s", "hs"), tag="", factor=2.0, source=None, key=None):
+    """Device state after substep k against the oracle's, each field within max(1e-12, factor x the oracle's own one-ulp scatter) (tests/scatter.py).
+    key: the case of tests/cases.py -- the difference between two builds of the reference on it is recorded next to the error (tests/golden/yardsticks.json)."""
     for name in names:
         for i, (b, sc) in enumerate(zip(B[k][name], S[k][name])):
             e = rel_err(getattr(d, name)[i].cpu().numpy(), b)
-            bd = bound(sc, factor, source) if source else bound(sc, factor)
+            bd = bound(sc, factor, source or "oracle one-ulp scatter", ref=ref_of(key, k, name, i))
             assert e <= bd, (tag, k, name, i, "err %.2e" % e, "oracle scatter %.2e" % sc)
 
 
@@ -41,24 +44,6 @@ def T():
     return T
 
 
-def grids(nx, ny, nz, stretch):
-    x = np.arange(nx) / nx * 2.0
-    z = np.arange(nz) / nz * 1.0
-    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5)) if stretch else np.arange(ny) / (ny - 1.0)
-    return x, y, z
-
-
-def init_fields(nx, ny, nz, x, y, z, seed, noise=0.1):
-    rng = np.random.default_rng(seed)
-    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
-    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))                  # vanishes on the walls (no-slip)
-    u = (np.sin(np.pi * X) * np.cos(2 * np.pi * Z) + noise * rng.uniform(-1, 1, X.shape)) * wall
-    v = (np.cos(np.pi * X) * np.sin(2 * np.pi * Z) + noise * rng.uniform(-1, 1, X.shape)) * wall ** 2
-    w = (np.sin(2 * np.pi * X + 1) * np.sin(2 * np.pi * Z) + noise * rng.uniform(-1, 1, X.shape)) * wall
-    s = np.cos(np.pi * X) * Y + noise * rng.uniform(-1, 1, X.shape)
-    return [a.ravel() for a in (u, v, w)], [s.ravel()]
-
-
 _ORACLE_CACHE = {}
 
 
@@ -76,22 +61,20 @@ def test_substep_vs_oracle(T, nx, ny, nz, stretch, hyper, fuse):
     import torch
     from tlab_amd.dns import Dns
     from oracle.tlab_oracle_rhs import DnsOracle
-    x, y, z = grids(nx, ny, nz, stretch)
-    visc, sc = 1.0 / 800.0, (0.7,)
-    q0, s0 = init_fields(nx, ny, nz, x, y, z, 3)
+    case = C.rhs_substep(nx, ny, nz, stretch)
+    x, y, z, visc, sc, q0, s0, sched = (case[k] for k in ("x", "y", "z", "visc", "sc", "q0", "s0", "sched"))
     d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=hyper)
     d.set_fusion(fuse)
     for i in range(3):
         d.q[i].copy_(torch.from_numpy(q0[i]))
     d.s[0].copy_(torch.from_numpy(s0[0]))
-    dtime = 2e-3
+    assert [s_[0] for s_ in sched] == [2e-3 * d.kdt[k] for k in range(2)] and [s_[1] for s_ in sched] == [d.kco[k] for k in range(2)]
     # two RK3 substeps incl. the tendency scaling in between (time.f90:220-298)
-    sched = [(dtime * d.kdt[k], d.kco[k], True) for k in range(2)]
     B, S = oracle_substeps(("sub", nx, ny, nz, stretch, hyper), lambda: DnsOracle(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=hyper),
                            q0, s0, sched, nsamples=2)
     for k, (dte, kco, scale) in enumerate(sched):
         d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
-        check_state(d, B, S, k)
+        check_state(d, B, S, k, key=case["key"] if hyper == REF_HYPER else None)      # (the reference as compiled reads 0.1: its builds say nothing about the closure 0.0)
 
 
 @pytest.mark.parametrize("fuse", [True, False])
@@ -102,16 +85,9 @@ def test_substep_with_neumann_walls_vs_oracle(T, vel, scal, fuse):
     import torch
     from tlab_amd.dns import Dns, velocity_bcs, scalar_bcs
     from oracle.tlab_oracle_rhs import DnsOracle
+    case = C.rhs_neumann(vel, scal)
     nx, ny, nz, stretch = 64, 64, 32, True
-    x, y, z = grids(nx, ny, nz, stretch)
-    visc, sc = 1.0 / 800.0, (0.7,)
-    rng = np.random.default_rng(11)
-    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
-    wall = np.sin(np.pi * Y)
-    q0 = [(np.sin(np.pi * X) * np.cos(2 * np.pi * Z) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel(),
-          ((np.cos(np.pi * X) * np.sin(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel(),
-          (np.sin(2 * np.pi * X + 1) * np.sin(2 * np.pi * Z) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
-    s0 = [(np.cos(np.pi * X) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    x, y, z, visc, sc, q0, s0 = (case[k] for k in ("x", "y", "z", "visc", "sc", "q0", "s0"))
     d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=REF_HYPER)
     d.set_fusion(fuse)
     d.set_bcs(vel[0], vel[1], scal[0], scal[1])
@@ -126,10 +102,11 @@ def test_substep_with_neumann_walls_vs_oracle(T, vel, scal, fuse):
     d.s[0].copy_(torch.from_numpy(s0[0]))
     dtime = 2e-3
     sched = [(dtime * d.kdt[k], d.kco[k], True) for k in range(2)]
+    assert sched == case["sched"]
     B, S = oracle_substeps(("neumann", vel, scal), make_oracle, q0, s0, sched, nsamples=2)
     for k, (dte, kco, scale) in enumerate(sched):
         d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
-        check_state(d, B, S, k)
+        check_state(d, B, S, k, key=case["key"])
     # the wall tendencies are not zero where Neumann was asked for, and the RHS entry point agrees with the fused substep
     hq0 = B[1]["hq"][0].reshape(nz, ny, nx)
     assert np.abs(hq0[:, -1, :]).max() > 0
@@ -148,16 +125,9 @@ def test_neumann_wall_planes_route(T, vel, scal, monkeypatch):
     from tlab_amd.dns import Dns, velocity_bcs, scalar_bcs
     from tlab_amd.lib import load
     from oracle.tlab_oracle_rhs import DnsOracle
+    case = C.rhs_neumann(vel, scal, nx=256, seed=21)
     nx, ny, nz, stretch = 256, 64, 64, True
-    x, y, z = grids(nx, ny, nz, stretch)
-    visc, sc = 1.0 / 800.0, (0.7,)
-    rng = np.random.default_rng(21)
-    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
-    wall = np.sin(np.pi * Y)
-    q0 = [(np.sin(np.pi * X) * np.cos(2 * np.pi * Z) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel(),
-          ((np.cos(np.pi * X) * np.sin(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel(),
-          (np.sin(2 * np.pi * X + 1) * np.sin(2 * np.pi * Z) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
-    s0 = [(np.cos(np.pi * X) * np.cos(np.pi * Y) + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    x, y, z, visc, sc, q0, s0 = (case[k] for k in ("x", "y", "z", "visc", "sc", "q0", "s0"))
     L = load()
     out = {}
     for planes in ("1", "0"):
@@ -186,8 +156,9 @@ def test_neumann_wall_planes_route(T, vel, scal, monkeypatch):
                 o.flow_jmin, o.flow_jmax = velocity_bcs(vel[0]), velocity_bcs(vel[1])
                 o.scal_jmin, o.scal_jmax = [scalar_bcs(scal[0])], [scalar_bcs(scal[1])]
                 return o
+            assert sched == case["sched"]
             B, S = oracle_substeps(("neumann planes", vel, scal), make_oracle, q0, s0, sched, nsamples=2)
-            check_state(d, B, S, 1)
+            check_state(d, B, S, 1, key=case["key"])
     for a, b in zip(out["1"], out["0"]):
         assert rel_err(a, b) <= 1e-12      # (two substeps; the sums and the sweeps round differently: measured 1.6e-13 on the tendencies)
     hq0 = out["1"][4].reshape(nz, ny, nx)
@@ -309,29 +280,27 @@ def test_line_lengths_of_the_large_configs(T, nx, ny, nz, nscal, stretch, exact)
     import torch
     from tlab_amd.dns import Dns
     from oracle.tlab_oracle_rhs import DnsOracle
-    x, y, z = grids(nx, ny, nz, stretch)
-    sc = (0.7, 1.0, 2.5)[:nscal]
-    q0, s0 = init_fields(nx, ny, nz, x, y, z, 23, noise=1e-3)
-    visc = 1.0 / 5000.0
+    case = C.rhs_lines(nx, ny, nz, nscal, stretch)
+    x, y, z, visc, sc, q0, ss = (case[k] for k in ("x", "y", "z", "visc", "sc", "q0", "s0"))
     T.poisson_set_exact(exact)
     try:
         d = Dns(x, y, z, nscal=nscal, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=REF_HYPER)
     finally:
         T.poisson_set_exact(False)
-    ss = [s0[0] * (1.0 + 0.3 * i) + 0.1 * i for i in range(nscal)]
     for i in range(3):
         d.q[i].copy_(torch.from_numpy(q0[i]))
     for i in range(nscal):
         d.s[i].copy_(torch.from_numpy(ss[i]))
     dt = 1e-3
     sched = [(dt * d.kdt[k], d.kco[k], True) for k in range(2)]
+    assert sched == case["sched"]
     make, source = oracle_factory(x, y, z, nscal, visc, sc, stretch)
     B, S = oracle_substeps(("lines", nx, ny, nz), make, q0, ss, sched, nsamples=3 if source is None else 2)
     for k, (dte, kco, scale) in enumerate(sched):
         d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
     errs = [rel_err(d.q[i].cpu().numpy(), B[1]["q"][i]) for i in range(3)]
     print("exact" if exact else "fast ", (nx, ny, nz), "err", ["%.1e" % e for e in errs], "oracle one-ulp scatter", ["%.1e" % e for e in S[1]["q"]])
-    check_state(d, B, S, 1, names=("q", "s"), tag="exact" if exact else "fast", factor=1.6 if exact else 2.0, source=source)
+    check_state(d, B, S, 1, names=("q", "s"), tag="exact" if exact else "fast", factor=1.6 if exact else 2.0, source=source, key=case["key"])
 
 
 @pytest.mark.parametrize("nx,ny,nz,nscal,stretch", [

@@ -4,7 +4,8 @@ transposed layout, Poisson with its own kz range and singular-mode ownership), a
 substep to round-off.  Only the collective itself is replaced by direct copies."""
 import numpy as np
 import pytest
-from scatter import substep_scatter, one_ulp_noise, bound
+from scatter import substep_scatter, one_ulp_noise, bound, ref_of
+import cases as C
 
 REF_HYPER = 0.1      # wall closure of the flang-built reference (DESIGN.md section 2, defect 1); the driver classes default to the consistent 0.0
 
@@ -33,14 +34,9 @@ def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs, zmode, zchunk)
     import torch
     from tlab_amd.dns import Dns
     from tlab_amd.parallel import SlabDns, LoopbackComm
-    x = np.arange(nx) / nx * 2.0
-    z = np.arange(nz) / nz
-    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
-    rng = np.random.default_rng(P)
-    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
-    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
-    fields = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
-    visc, sc = 1.0 / 600.0, (0.8,)
+    case = C.slab(P, nx, ny, nz, bcs)            # (the inputs live in tests/cases.py: the reference-made yardstick of the case is made from the same)
+    x, y, z, visc, sc = (case[k] for k in ("x", "y", "z", "visc", "sc"))
+    fields = case["q0"] + case["s0"]
     one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
     slab = SlabDns(LoopbackComm(P), x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, zmode=zmode, zchunk=zchunk, hyper_bc1_ext=REF_HYPER)
     assert slab.zmode == ("transpose" if nz // P < 56 else zmode if zmode != "auto" else "halo")
@@ -68,12 +64,13 @@ def test_slab_substep_equals_single_domain(T, P, nx, ny, nz, bcs, zmode, zchunk)
         return o
     key = (nx, ny, nz, bcs, P)
     if key not in _ORACLE:
-        _ORACLE[key] = substep_scatter(make_oracle, fields[:3], fields[3:], [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=3)
+        assert [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)] == case["sched"]
+        _ORACLE[key] = substep_scatter(make_oracle, fields[:3], fields[3:], case["sched"], nsamples=3)
     B, S = _ORACLE[key]
     for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
         for i, rf in enumerate(ref):
             got = torch.cat([slab.st[r][name][i] for r in range(P)])
-            tol = bound(S[1][name][i])
+            tol = bound(S[1][name][i], ref=ref_of(case["key"], 1, name, i))
             err = float((got - rf).abs().max() / rf.abs().max())
             assert err <= tol, ("slab vs single domain", name, i, err, tol)
             ob = torch.from_numpy(B[1][name][i]).cuda()

@@ -4,7 +4,8 @@ all npro_k ranks inside this process through the loopback transport.  It must re
 arguments, same order per rank -- and, independently, the single-domain substep and the oracle within the scatter bound."""
 import numpy as np
 import pytest
-from scatter import substep_scatter, bound
+from scatter import substep_scatter, bound, ref_of
+import cases as C
 
 REF_HYPER = 0.1      # wall closure of the flang-built reference (DESIGN.md section 2, defect 1)
 
@@ -19,6 +20,9 @@ def T():
     import tlab_amd as T
     T.init(0)
     return T
+
+
+_ORACLE = {}
 
 
 def _fields(x, y, z, seed):
@@ -86,9 +90,9 @@ def test_native_driver_equals_single_domain_and_oracle(T, bcs, fused, stages, mo
     from tlab_amd.slab import NativeSlabDns
     from oracle.tlab_oracle_rhs import DnsOracle
     P, nx, ny, nz = 4, 128, 24, 256          # nx >= 128: the library's own x-transforms apply
-    x, y, z = _grid(nx, ny, nz)
-    f = _fields(x, y, z, 11)
-    visc, sc = 1.0 / 600.0, (0.8,)
+    case = C.slab_native(bcs)
+    x, y, z, visc, sc = (case[k] for k in ("x", "y", "z", "visc", "sc"))
+    f = case["q0"] + case["s0"]
     one = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER)
     nat = NativeSlabDns("loopback", x, y, z, size=P, nscal=1, visc=visc, schmidt=sc, yuniform=False, hyper_bc1_ext=REF_HYPER, fused_x=fused)
     assert nat.fused_x == fused and nat.stages == int(stages)
@@ -111,11 +115,14 @@ def test_native_driver_equals_single_domain_and_oracle(T, bcs, fused, stages, mo
         if bcs == "freeslip":
             o.scal_jmin, o.scal_jmax = [4], [3]
         return o
-    B, S = substep_scatter(make_oracle, f[:3], f[3:4], [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)], nsamples=3)
+    assert [(dtime * one.kdt[k], one.kco[k], True) for k in range(2)] == case["sched"]
+    if ("native", bcs) not in _ORACLE:          # (the fused / stages parametrizations share one oracle run)
+        _ORACLE[("native", bcs)] = substep_scatter(make_oracle, f[:3], f[3:4], case["sched"], nsamples=3)
+    B, S = _ORACLE[("native", bcs)]
     for name, ref in (("q", one.q), ("hq", one.hq), ("s", one.s), ("hs", one.hs)):
         for i, rf in enumerate(ref):
             got = torch.cat([nat.st[r][name][i] for r in range(P)])
-            tol = bound(S[1][name][i])
+            tol = bound(S[1][name][i], ref=ref_of(case["key"], 1, name, i))
             err = float((got - rf).abs().max() / rf.abs().max())
             assert err <= tol, ("native slabs vs single domain", name, i, err, tol)
             ob = torch.from_numpy(B[1][name][i]).cuda()
