@@ -67,10 +67,6 @@ struct FftzArgs {
     double2 *out;
     const double2 *tw;      // exp(-2 pi i k / n), k < n  (conjugated for the backward transform)
     long long nlines;       // = stride between consecutive points of a line
-    long long batch_stride; // blockIdx.y-th batch of nlines lines starts at y * batch_stride (0 with one batch): the kx-blocks of the blocked spectral layout
-    // a kx sub-range of a (nxh, ny) plane (kx-batched Poisson stage): the lines handled are kx in [sub_k0, sub_k0 + sub_w) of every row of the plane, a row
-    // nxh lines long; sub_w = 0: all lines.  Workgroup x covers T consecutive kx of row x / ceil(sub_w / T)
-    int sub_k0, sub_w, sub_row;
     int n;
     int npass;
     int radix[8];
@@ -126,14 +122,8 @@ __global__ void __launch_bounds__(1024) k_fftz(FftzArgs a) {
     cd *lds = reinterpret_cast<cd *>(fz_lds);
     const int t = threadIdx.x % T;
     const int jt = threadIdx.x / T;              // 0 .. n/8 - 1
-    long long col0 = (long long)blockIdx.x * T + t;
-    bool colok = col0 < a.nlines;
-    if (a.sub_w > 0) {
-        const int per = (a.sub_w + T - 1) / T, row = (int)blockIdx.x / per, kx = ((int)blockIdx.x - row * per) * T + t;
-        colok = kx < a.sub_w;
-        col0 = (long long)row * a.sub_row + a.sub_k0 + kx;
-    }
-    const long long col = col0 + (long long)blockIdx.y * a.batch_stride;
+    const long long col = (long long)blockIdx.x * T + t;
+    const bool colok = col < a.nlines;
     int Ns = 1;
     for (int p = 0; p < a.npass; ++p) {
         const int R = a.radix[p];
@@ -234,8 +224,6 @@ struct FftxArgs {
     // transform): element (line, kx) at kxoff[kx] + line * kxw[kx] complex values; NULL: contiguous
     const long long *kxoff;
     const int *kxw;
-    int zfix_ny;            // > 0 (blocked spectral layout, poisson.hip SpecLayout): lines come in planes of zfix_ny, and the planes are (m + 1) zfix_ny values apart
-                            // whatever the width of a kx-block: element (line, kx) at kxoff[kx] + line * kxw[kx] + (line / zfix_ny) * (m + 1 - kxw[kx]) * zfix_ny
 };
 
 template <int R>
@@ -295,8 +283,6 @@ __global__ void __launch_bounds__(256) k_fftx_r2c(FftxArgs a) {
     double2 *out = a.out + line * (a.m + 1);
     const int M = a.m;
     if (a.kxw != nullptr) {      // same values, scattered into the pack buffer
-        const long long zq = a.zfix_ny > 0 ? (line / a.zfix_ny) * a.zfix_ny : 0;      // first line of this line's plane
-        auto at = [&](int k) { const int w = a.kxw[k]; return a.kxoff[k] + line * w + zq * (M + 1 - w); };
         for (int k = jt; k <= M / 2; k += a.tl) {
             const cd A = lds[k], Zc = lds[(M - k) & (M - 1)];
             const cd B = {Zc.x, -Zc.y};
@@ -305,8 +291,8 @@ __global__ void __launch_bounds__(256) k_fftx_r2c(FftxArgs a) {
             const cd O = {0.5 * D.y, -0.5 * D.x};
             const double2 w = a.tw[k];
             const cd T = cmul(cd{w.x, w.y}, O);
-            a.out[at(k)] = make_double2(E.x + T.x, E.y + T.y);
-            if (k != M - k) a.out[at(M - k)] = make_double2(E.x - T.x, -(E.y - T.y));
+            a.out[a.kxoff[k] + line * a.kxw[k]] = make_double2(E.x + T.x, E.y + T.y);
+            if (k != M - k) a.out[a.kxoff[M - k] + line * a.kxw[M - k]] = make_double2(E.x - T.x, -(E.y - T.y));
         }
         return;
     }
@@ -375,11 +361,9 @@ __global__ void __launch_bounds__(256) k_fftx_c2r(FftxArgs a, FftxFinal fin) {
     if (ok) {
         const double2 *X = reinterpret_cast<const double2 *>(a.in) + line * (M + 1);
         const double2 *XP = reinterpret_cast<const double2 *>(a.in);
-        const long long zq = a.zfix_ny > 0 ? (line / a.zfix_ny) * a.zfix_ny : 0;
-        auto at = [&](int k) { const int w = a.kxw[k]; return a.kxoff[k] + line * w + zq * (M + 1 - w); };
         for (int k = jt; k <= M / 2; k += a.tl) {
             double2 xa, xb;
-            if (a.kxw != nullptr) { xa = XP[at(k)]; xb = XP[at(M - k)]; }
+            if (a.kxw != nullptr) { xa = XP[a.kxoff[k] + line * a.kxw[k]]; xb = XP[a.kxoff[M - k] + line * a.kxw[M - k]]; }
             else { xa = X[k]; xb = X[M - k]; }
             if (k == 0) { xa.y = 0.0; xb.y = 0.0; }
             const cd E = {xa.x + xb.x, xa.y - xb.y};                 // X_k + conj X_(m-k)
@@ -443,9 +427,9 @@ FftxPlan::~FftxPlan() {
     if (d_tw) (void)hipFree(d_tw);
 }
 
-void FftxPlan::exec(const double *in, double *out, hipStream_t st, const long long *kxoff, const int *kxw, int zfix_ny) const {
+void FftxPlan::exec(const double *in, double *out, hipStream_t st, const long long *kxoff, const int *kxw) const {
     FftxArgs a{};
-    a.kxoff = kxoff; a.kxw = kxw; a.zfix_ny = zfix_ny;
+    a.kxoff = kxoff; a.kxw = kxw;
     a.in = in;
     a.out = reinterpret_cast<double2 *>(out);
     a.tw = reinterpret_cast<const double2 *>(d_tw);
@@ -487,9 +471,8 @@ FftzPlan::~FftzPlan() {
 }
 
 template <int T>
-static void fftz_launch(int dir, const FftzArgs &a, hipStream_t st, unsigned nbatch = 1) {
-    dim3 grid((unsigned)((a.nlines + T - 1) / T), nbatch);
-    if (a.sub_w > 0) grid.x = (unsigned)(((a.sub_w + T - 1) / T) * (a.nlines / a.sub_row));
+static void fftz_launch(int dir, const FftzArgs &a, hipStream_t st) {
+    const unsigned grid = (unsigned)((a.nlines + T - 1) / T);
     const unsigned block = (unsigned)(T * a.n / 8);
     const size_t lds = (size_t)a.n * T * sizeof(double2);
     static bool attr_done = false;
@@ -499,38 +482,8 @@ static void fftz_launch(int dir, const FftzArgs &a, hipStream_t st, unsigned nba
         (void)hipGetLastError();
         attr_done = true;
     }
-    if (dir > 0) hipLaunchKernelGGL((k_fftz<-1, T>), grid, dim3(block), lds, st, a);      // forward: exp(-i ...)
-    else hipLaunchKernelGGL((k_fftz<+1, T>), grid, dim3(block), lds, st, a);
-}
-
-// nbatch boxes of `lines` lines each, box b at in + b * batch_stride (complex values), point k of a line `lines` values after point k - 1: the z transform
-// of the blocked spectral layout (poisson.hip: SpecLayout), in == out allowed (a workgroup reads its lines whole before it writes them)
-// the lines kx in [k0, k0 + w) of every row (row = nxh lines) of the plan's planes
-void FftzPlan::exec_sub(int dir, const double *in, double *out, int nxh, int k0, int w, hipStream_t st) const {
-    FftzArgs a{};
-    a.in = reinterpret_cast<const double2 *>(in);
-    a.out = reinterpret_cast<double2 *>(out);
-    a.tw = reinterpret_cast<const double2 *>(d_tw);
-    a.nlines = nlines; a.n = n; a.npass = (int)radix.size();
-    a.sub_k0 = k0; a.sub_w = w; a.sub_row = nxh;
-    for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
-    ProfScope ps("k_fftz<sub>", st, (double)(nlines / nxh) * w * n * 32.0);
-    if (n <= 1024) fftz_launch<8>(dir, a, st);
-    else fftz_launch<4>(dir, a, st);
-    if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftz launch failed");
-}
-
-void FftzPlan::exec_batched(int dir, const double *in, double *out, long long lines, int nbatch, long long batch_stride, hipStream_t st) const {
-    FftzArgs a{};
-    a.in = reinterpret_cast<const double2 *>(in);
-    a.out = reinterpret_cast<double2 *>(out);
-    a.tw = reinterpret_cast<const double2 *>(d_tw);
-    a.nlines = lines; a.batch_stride = batch_stride; a.n = n; a.npass = (int)radix.size();
-    for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
-    ProfScope ps("k_fftz", st, (double)lines * nbatch * n * 32.0);
-    if (n <= 1024) fftz_launch<8>(dir, a, st, (unsigned)nbatch);
-    else fftz_launch<4>(dir, a, st, (unsigned)nbatch);
-    if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftz launch failed");
+    if (dir > 0) hipLaunchKernelGGL((k_fftz<-1, T>), dim3(grid), dim3(block), lds, st, a);      // forward: exp(-i ...)
+    else hipLaunchKernelGGL((k_fftz<+1, T>), dim3(grid), dim3(block), lds, st, a);
 }
 
 void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) const {
@@ -547,9 +500,9 @@ void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) cons
 }
 
 void FftxPlan::launch_inverse(const double *in, double *out, const double *q, const double *h, double dte, double kco, int scale, int ny,
-                              hipStream_t st, const long long *kxoff, const int *kxw, int zfix_ny) const {
+                              hipStream_t st, const long long *kxoff, const int *kxw) const {
     FftxArgs a{};
-    a.kxoff = kxoff; a.kxw = kxw; a.zfix_ny = zfix_ny;
+    a.kxoff = kxoff; a.kxw = kxw;
     a.in = in;
     a.out = reinterpret_cast<double2 *>(out);
     a.tw = reinterpret_cast<const double2 *>(d_tw);

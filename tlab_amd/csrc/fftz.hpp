@@ -14,9 +14,6 @@ public:
     FftzPlan(const FftzPlan &) = delete;
     FftzPlan &operator=(const FftzPlan &) = delete;
     void exec(int dir, const double *in, double *out, hipStream_t st) const;      // dir > 0 forward (exp(-i)), else backward; in == out allowed
-    // the same transform on nbatch boxes of `lines` lines (box b at + b * batch_stride complex values; inside a box the points of a line are `lines` apart)
-    void exec_sub(int dir, const double *in, double *out, int nxh, int k0, int w, hipStream_t st) const;      // kx in [k0, k0 + w) of every (nxh-long) row only
-    void exec_batched(int dir, const double *in, double *out, long long lines, int nbatch, long long batch_stride, hipStream_t st) const;
 
 private:
     int n;
@@ -35,21 +32,21 @@ public:
     FftxPlan &operator=(const FftxPlan &) = delete;
     // kxoff, kxw (device, n/2+1 entries each; both NULL: contiguous lines): the complex side lives in the slab <-> kx-pencil pack layout, element
     // (line, kx) at kxoff[kx] + line * kxw[kx] complex values (tlab_pencil_repack_blocks folded into the transform)
-    void exec(const double *in, double *out, hipStream_t st, const long long *kxoff = nullptr, const int *kxw = nullptr, int zfix_ny = 0) const;
+    void exec(const double *in, double *out, hipStream_t st, const long long *kxoff = nullptr, const int *kxw = nullptr) const;
     // the inverse (n/2+1 complex -> n reals per line, unnormalised)
-    void exec_inverse(const double *in, double *out, hipStream_t st, const long long *kxoff = nullptr, const int *kxw = nullptr, int zfix_ny = 0) const {
-        launch_inverse(in, out, nullptr, nullptr, 0.0, 0.0, 0, 0, st, kxoff, kxw, zfix_ny);
+    void exec_inverse(const double *in, double *out, hipStream_t st, const long long *kxoff = nullptr, const int *kxw = nullptr) const {
+        launch_inverse(in, out, nullptr, nullptr, 0.0, 0.0, 0, 0, st, kxoff, kxw);
     }
     // the inverse as the pressure-gradient operand g of the final update of one velocity component (pointwise.hip: k_final_update with zero wall
     // planes): h = h - g, h = 0 on the rows j = 0, ny-1 of every x-y plane, q += dte h, h *= kco (if scale); g itself is not stored
     void exec_inverse_final(const double *in, double *q, double *h, double dte, double kco, int scale, int ny, hipStream_t st,
-                            const long long *kxoff = nullptr, const int *kxw = nullptr, int zfix_ny = 0) const {
-        launch_inverse(in, nullptr, q, h, dte, kco, scale, ny, st, kxoff, kxw, zfix_ny);
+                            const long long *kxoff = nullptr, const int *kxw = nullptr) const {
+        launch_inverse(in, nullptr, q, h, dte, kco, scale, ny, st, kxoff, kxw);
     }
 
 private:
     void launch_inverse(const double *in, double *out, const double *q, const double *h, double dte, double kco, int scale, int ny, hipStream_t st,
-                        const long long *kxoff, const int *kxw, int zfix_ny = 0) const;
+                        const long long *kxoff, const int *kxw) const;
     int n;
     long long nlines;
     std::vector<int> radix;

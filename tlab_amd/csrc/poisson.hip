@@ -774,38 +774,6 @@ __global__ void __launch_bounds__(256) k_int2(Int2Args a) {
 #define ODE_DIV(x, y) ((ODE_KO & 4) ? (x) * (y) : (x) / (y))
 constexpr int OM = 8;   // rows per thread
 
-// ---- spectral layouts ------------------------------------------------------------------------------------------------------------------
-// STANDARD: element (kx, j, kz) of a spectral field at kx + nxh (j + ny kz) -- the reference's (nx/2+1, ny, nz) complex array.
-// BLOCKED (single-device chunked plans, between the own transforms only; never seen by a caller): inside every kz plane the (kx, j) array is re-tiled into
-// kx-blocks of nb = NM values, block b a contiguous [j][kxi] box of width w = min(nb, nxh - b nb):  kz nxh ny + b nb ny + j w + kxi.  What k_ode_nn reads
-// and writes per workgroup (NM modes of one kz, all rows) is then ONE contiguous 16 NM ny-byte box instead of ny pieces of 16 NM bytes 16 nxh bytes
-// apart (at 512^3: 512 pieces of 64 B in 512 different 4-KiB pages, per array).  The z transform does not notice (a plane is still nxh ny values, its
-// lines still contiguous across the batch, the stride between planes still 16 nxh ny bytes -- NOT a power of two: a first version with the kx-blocks
-// outermost had every workgroup of a launch start on the same HBM channel, 2^24 bytes apart); the x transforms reach the layout through their
-// (offset, width) maps per kx (FftxArgs::kxoff, kxw: the pack layout of the slab drivers) plus a per-plane term (FftxArgs::zfix_ny).
-struct SpecLayout {
-    int nxh, ny, nz, nb;         // nb = 0: standard
-};
-__device__ __forceinline__ unsigned spec_index(const SpecLayout &L, int kx, int j, int kz) {
-    if (L.nb == 0) return (unsigned)(kx + L.nxh * (j + L.ny * kz));
-    const int b = kx / L.nb, w = (L.nxh - b * L.nb < L.nb) ? L.nxh - b * L.nb : L.nb;
-    return (unsigned)(kz * (L.nxh * L.ny) + b * L.nb * L.ny + j * w + (kx - b * L.nb));
-}
-__device__ __forceinline__ unsigned spec_row_stride(const SpecLayout &L, int kx) {      // from row j to j + 1 of one mode
-    if (L.nb == 0) return (unsigned)L.nxh;
-    const int b = kx / L.nb;
-    return (unsigned)((L.nxh - b * L.nb < L.nb) ? L.nxh - b * L.nb : L.nb);
-}
-// slot of mode t = kx + nxh kz in the tables that are blocked by the NM modes of a workgroup of k_ode_nn ([slot / NM][...][slot % NM]: checkpoints,
-// homogeneous solutions).  nkb = 0: workgroups take NM consecutive t (slot = t); nkb = ceil(nxh / NM): a workgroup = block kxb of one kz -- the
-// blocks do not straddle kz rows, the last one of a row is partly empty
-__device__ __forceinline__ long long ode_slot(long long t, int nxh, int nkb, int NM) {
-    if (nkb == 0) return t;
-    const int kx = (int)(t % nxh);
-    const long long kz = t / nxh;
-    return (kz * nkb + kx / NM) * NM + kx % NM;
-}
-
 struct OdeSys {                  // Int1Dev without the by-value boundary constants (they would sit in ~100 SGPRs)
     const double *L0, *L1, *R;   // row-major [n][5], [n][5], [n][3]
     const double *pk;            // the same numbers packed per row, [n][16] = L0[5], L1[5], row scale, R[3], 0, 0: one 128-B line and seven 16-B loads
@@ -823,9 +791,6 @@ struct OdeArgs {
     const double *hom;           // [5][n][nm] homogeneous solutions v1, em, u1, sp, ep (build_homogeneous)
     const int *band;             // [2][nm] (may be NULL): rows (jb, jt) exclusive where all five homogeneous solutions of the mode are negligible
     int pair_xcd;                // see k_ode_nn
-    int nkb;                     // > 0: a workgroup = kx-block (NM wide) of one kz (ode_slot); the blocked tables are laid out accordingly
-    int kxb0, nkb_sub;           // nkb_sub > 0: only the kx-blocks [kxb0, kxb0 + nkb_sub) (kx-batched stage)
-    SpecLayout lay;              // where f^, p^, dp^ live
     const double *f_hat;
     double *p_hat, *dp_hat;
     double fscale;
@@ -965,12 +930,11 @@ template <int BC>
 // Layout of everything k_ode_nn reads per mode: blocked by the NM modes of a workgroup, [block][...][NM], so that a workgroup's reads are
 // one contiguous stream (mode-minor [..][nm] rows would be 64-B pieces of 128-B lines at NM = 8: measured 2x over-fetch).
 __global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *__restrict__ lamv, double lam_sign, double *__restrict__ chk,
-                                                        long long nm, int NM, int C, int om, int nxh = 1, int nkb = 0) {
+                                                        long long nm, int NM, int C, int om) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nm) return;
     const int n = T.n;
     const double lam = lam_sign * lamv[t];
-    const long long sl = ode_slot(t, nxh, nkb, NM);
     OdeRows k;
     ode_boundary_rows<BC>(T, lam, k);
     double st[6] = {0, 0, 0, 0, 0, 0};
@@ -978,7 +942,7 @@ __global__ void __launch_bounds__(256) k_ode_checkpoint(OdeSys T, const double *
         if ((j % om) == 0) {
             const int c = j / om;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) chk[(((sl / NM) * C + c) * 6 + q) * NM + (sl % NM)] = st[q];
+            for (int q = 0; q < 6; ++q) chk[(((t / NM) * C + c) * 6 + q) * NM + (t % NM)] = st[q];
         }
         double r[5], am, bm, cinv, nd, ne;
         ode_row(T, k, j, lam, r);
@@ -1093,13 +1057,11 @@ __global__ void __launch_bounds__(256) k_ode_hom_band(const double *__restrict__
 
 // src[a][j][nm] -> dst[blk][a][j][NM]
 // (the five solutions of a mode and row side by side, [blk][j][NM][6] with three 16-B loads per row in k_ode_nn, was measured: 3 % slower)
-__global__ void __launch_bounds__(256) k_ode_block_layout(const double *__restrict__ src, double *__restrict__ dst, int A, int n, long long nm, int NM,
-                                                          int nxh = 1, int nkb = 0) {
+__global__ void __launch_bounds__(256) k_ode_block_layout(const double *__restrict__ src, double *__restrict__ dst, int A, int n, long long nm, int NM) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)A * n * nm) return;
     const long long t = i % nm, aj = i / nm;          // aj = a * n + j
-    const long long sl = ode_slot(t, nxh, nkb, NM);
-    dst[((sl / NM) * A * n + aj) * NM + (sl % NM)] = src[i];
+    dst[((t / NM) * A * n + aj) * NM + (t % NM)] = src[i];
 }
 
 // One FDM_Int1_Solve of BOTH lines (Re, Im) for the rows of this thread.
@@ -1141,7 +1103,7 @@ __device__ __forceinline__ void ode_solve(const OdeSys &T, double lam, const dou
     // ---- factors of my rows, from the checkpoint ----
     double st[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) st[q] = (c == 0) ? 0.0 : chk[(unsigned)((((t / NM) * C + c) * 6 + q) * NM + (t % NM))];      // t = the SLOT of the mode in the blocked tables (ode_slot); 32-bit indices: checked on the host
+    for (int q = 0; q < 6; ++q) st[q] = (c == 0) ? 0.0 : chk[(unsigned)((((t / NM) * C + c) * 6 + q) * NM + m)];      // 32-bit indices: checked on the host
     double am[OM], bm[OM];             // forward multipliers in registers; the backward factors (1/c, -d, -e) wait in LDS
     double *my_fac = s_fac + threadIdx.x * (3 * OM + 1);      // thread-major with an odd stride: constant offsets, no bank conflicts
 #define FAC(p, q) my_fac[(p) * 3 + (q)]
@@ -1352,34 +1314,20 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // the neighbour that owns the other half would sit on another XCD and the line would cross the fabric twice (PMC: 9.3 GB per launch, 8.3 with the pairing, against
     // 6.7 algorithmic).  Pair them: of every 16 consecutive workgroups, XCD x gets the adjacent blocks 2x and 2x + 1.
     unsigned blk = blockIdx.x;
-    if (NM == 4 && a.lay.nb == 0 && a.pair_xcd && (blk | 15u) < gridDim.x) blk = (blk & ~15u) + 2u * (blk & 7u) + ((blk >> 3) & 1u);
-    int t;                                            // the mode whose tables are read (NL = 4: kz <= nz/2, so the pair index is the mode index)
-    bool live;
-    if (a.nkb > 0) {                                  // workgroup = kx-block kxb of one kz: the blocks do not straddle kz rows (the last one of a row is partly empty)
-        const int per = a.nkb_sub > 0 ? a.nkb_sub : a.nkb;
-        const int kzb = (int)blk / per, kxb = a.kxb0 + (int)blk - kzb * per;
-        int kx = kxb * NM + m;
-        live = kx < a.nxh;
-        if (!live) kx = a.nxh - 1;
-        t = kx + a.nxh * kzb;
-    } else {
-        t = (int)blk * NM + m;
-        const int nlive = (NL == 4) ? a.nxh * (nm / a.nxh / 2 + 1) : nm;
-        live = t < nlive;
-        if (!live) t = nlive - 1;
-    }
-    const int tb = (int)ode_slot(t, a.nxh, a.nkb, NM);      // its slot in the tables blocked by workgroup (checkpoints, homogeneous solutions)
+    if (NM == 4 && a.pair_xcd && (blk | 15u) < gridDim.x) blk = (blk & ~15u) + 2u * (blk & 7u) + ((blk >> 3) & 1u);
+    int t = (int)blk * NM + m;                        // the mode whose tables are read (NL = 4: kz <= nz/2, so the pair index is the mode index)
+    const int nlive = (NL == 4) ? a.nxh * (nm / a.nxh / 2 + 1) : nm;
+    const bool live = t < nlive;
+    if (!live) t = nlive - 1;
     const double lam = a.lam[t];
     unsigned fidx0[NQ];
     bool store[NQ];                                   // modes solved elsewhere (singular, low) are left alone, each of a pair on its own
-    const int kx_ = t % a.nxh, kz_ = t / a.nxh;
-    const unsigned rs = spec_row_stride(a.lay, kx_);  // from one row of a mode to the next, in complex values
-    fidx0[0] = spec_index(a.lay, kx_, 0, kz_);
+    fidx0[0] = (unsigned)((t % a.nxh) + a.nxh * a.ny * (t / a.nxh));
     store[0] = live && !a.skip[t];
     if (NL == 4) {
-        const int nz = nm / a.nxh, kz2 = (nz - kz_) % nz;
-        fidx0[NQ - 1] = spec_index(a.lay, kx_, 0, kz2);
-        store[NQ - 1] = live && kz2 != kz_ && !a.skip[kx_ + a.nxh * kz2];      // kz = 0, nz/2: their own mirror, stored once
+        const int nz = nm / a.nxh, kz = t / a.nxh, kz2 = (nz - kz) % nz;
+        fidx0[NQ - 1] = (unsigned)((t % a.nxh) + a.nxh * a.ny * kz2);
+        store[NQ - 1] = live && kz2 != kz && !a.skip[(t % a.nxh) + a.nxh * kz2];      // kz = 0, nz/2: their own mirror, stored once
     }
     const int j0 = c * OMR;
     const double2 *F = reinterpret_cast<const double2 *>(a.f_hat);
@@ -1407,7 +1355,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 double2 w = make_double2(0.0, 0.0);
-                if (j >= 0 && j <= n - 1) w = F[fidx0[q] + (unsigned)j * rs];
+                if (j >= 0 && j <= n - 1) w = F[fidx0[q] + (unsigned)(j * a.nxh)];
                 fl[p][2 * q] = w.x * a.fscale; fl[p][2 * q + 1] = w.y * a.fscale;
             }
         }
@@ -1418,7 +1366,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
             if (c == C - 1) SC(1, l) = fl[OMR][l];
         }
         // ---- v0' + lambda v0 = f, v0(1) = 0 ; f(n) = 0 ----
-        ode_solve<1, NM, OMR, NL>(a.T1, lam, a.chk1, nm, tb, c, C, m, fl, v_1, fn, reinterpret_cast<double (&)[OMR][NL]>(vh[1]), ext, s_w, s_k, s_fac);
+        ode_solve<1, NM, OMR, NL>(a.T1, lam, a.chk1, nm, t, c, C, m, fl, v_1, fn, reinterpret_cast<double (&)[OMR][NL]>(vh[1]), ext, s_w, s_k, s_fac);
     }
     // halo rows of v0 for the right-hand side of the u-solve
 #pragma unroll
@@ -1438,7 +1386,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) u_n[l] = SC(1, l);
     }
-    ode_solve<2, NM, OMR, NL>(a.T2, -lam, a.chk2, nm, tb, c, C, m, vh, v_1, u_n, u, ext, s_w, s_k, s_fac);
+    ode_solve<2, NM, OMR, NL>(a.T2, -lam, a.chk2, nm, t, c, C, m, vh, v_1, u_n, u, ext, s_w, s_k, s_fac);
     // ---- u0(1), v0(n), du0(n) -> the three constants (opr_odes.f90:350-356 with the LU of k_nn_constants) ----
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -1480,7 +1428,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
 #pragma unroll
     for (int p = 0; p < OMR; ++p) {
         const int j = j0 + p;
-        const unsigned h = (unsigned)(((tb / NM) * 5 * n + j) * NM + (tb % NM)), hs = (unsigned)(n * NM);       // hom_blocked[blk][5][n][NM]
+        const unsigned h = (unsigned)(((t / NM) * 5 * n + j) * NM + m), hs = (unsigned)(n * NM);       // hom_blocked[blk][5][n][NM]
         double hv1 = 0.0, hem = 0.0, hu1 = 0.0, hsp = 0.0, hep = 0.0;
         if (need) { hv1 = a.hom[h]; hem = a.hom[h + hs]; hu1 = a.hom[h + 2 * hs]; hsp = a.hom[h + 3 * hs]; if (!DD) hep = a.hom[h + 4 * hs]; }
         double uu[NL], vv[NL];
@@ -1509,7 +1457,7 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (!store[q]) continue;
-            const unsigned idx = fidx0[q] + (unsigned)j * rs;
+            const unsigned idx = fidx0[q] + (unsigned)(j * a.nxh);
             P[idx] = make_double2(uu[2 * q], uu[2 * q + 1]);
             D[idx] = make_double2(vv[2 * q], vv[2 * q + 1]);
         }
@@ -1742,7 +1690,6 @@ struct OdeSingArgs {
     double *p_hat, *dp_hat;
     double fscale;
     int n, nxh, ny, C, ns;
-    SpecLayout lay;                     // where f^, p^, dp^ live
 };
 
 template <int NM>
@@ -1756,7 +1703,7 @@ __global__ void __launch_bounds__(512) k_ode_sing(OdeSingArgs a) {
     double *s_fac = s_k + OK_SIZE * NM;
     const bool live = m < a.ns;
     const int t = a.modes[live ? m : 0];
-    const unsigned fidx0 = spec_index(a.lay, t % a.nxh, 0, t / a.nxh), rs = spec_row_stride(a.lay, t % a.nxh);
+    const unsigned fidx0 = (unsigned)((t % a.nxh) + a.nxh * a.ny * (t / a.nxh));
     const int j0 = c * OM;
     const double2 *F = reinterpret_cast<const double2 *>(a.f_hat);
     double vh[OM + 2][2], u[OM][2], ext[2];
@@ -1767,7 +1714,7 @@ __global__ void __launch_bounds__(512) k_ode_sing(OdeSingArgs a) {
         for (int p = 0; p < OM + 2; ++p) {
             const int j = j0 - 1 + p;
             double2 w = make_double2(0.0, 0.0);
-            if (j >= 0 && j <= n - 1) w = F[fidx0 + (unsigned)j * rs];
+            if (j >= 0 && j <= n - 1) w = F[fidx0 + (unsigned)(j * a.nxh)];
             fl[p][0] = w.x * a.fscale; fl[p][1] = w.y * a.fscale;
         }
         if (c == C - 1) { s_sc[2 * NM + m] = fl[OM][0]; s_sc[3 * NM + m] = fl[OM][1]; }      // Neumann datum at the top (opr_elliptic.f90:310-311)
@@ -1799,7 +1746,7 @@ __global__ void __launch_bounds__(512) k_ode_sing(OdeSingArgs a) {
     for (int p = 0; p < OM; ++p) {
         const int j = j0 + p;
         const double hu = a.u1[j * ns + m], hv = a.v1[j * ns + m];
-        const unsigned idx = fidx0 + (unsigned)j * rs;
+        const unsigned idx = fidx0 + (unsigned)(j * a.nxh);
         P[idx] = make_double2(u[p][0] + cc[0] * hu, u[p][1] + cc[1] * hu);
         D[idx] = make_double2(vh[p + 1][0] + cc[0] * hv, vh[p + 1][1] + cc[1] * hv);
     }
@@ -1915,20 +1862,18 @@ __global__ void k_sing_gather(const double *__restrict__ f_hat, const int *__res
 
 // columns of a list of modes between the spectral field layout (nxh, ny, nz) and a compact (ns, ny, 1) field (low-mode sub-plan)
 __global__ void k_modes_gather(const double2 *__restrict__ f_hat, const int *__restrict__ modes, int ns, int n, int nxh, int ny,
-                               double2 *__restrict__ out, SpecLayout lay = SpecLayout{0, 0, 0, 0}) {
+                               double2 *__restrict__ out) {
     const int s = threadIdx.x + blockIdx.x * blockDim.x, j = blockIdx.y;
     if (s >= ns || j >= n) return;
     const long long t = modes[s];
-    if (lay.nb > 0) { out[(long long)j * ns + s] = f_hat[spec_index(lay, (int)(t % nxh), j, (int)(t / nxh))]; return; }
     out[(long long)j * ns + s] = f_hat[(t % nxh) + (long long)nxh * ny * (t / nxh) + (long long)j * nxh];
 }
 __global__ void k_modes_scatter(const double2 *__restrict__ p_low, const double2 *__restrict__ dp_low, const int *__restrict__ modes, int ns,
-                                int n, int nxh, int ny, double2 *__restrict__ p_hat, double2 *__restrict__ dp_hat, SpecLayout lay = SpecLayout{0, 0, 0, 0}) {
+                                int n, int nxh, int ny, double2 *__restrict__ p_hat, double2 *__restrict__ dp_hat) {
     const int s = threadIdx.x + blockIdx.x * blockDim.x, j = blockIdx.y;
     if (s >= ns || j >= n) return;
     const long long t = modes[s];
-    const long long idx = lay.nb > 0 ? (long long)spec_index(lay, (int)(t % nxh), j, (int)(t / nxh))
-                                     : (t % nxh) + (long long)nxh * ny * (t / nxh) + (long long)j * nxh;
+    const long long idx = (t % nxh) + (long long)nxh * ny * (t / nxh) + (long long)j * nxh;
     p_hat[idx] = p_low[(long long)j * ns + s];
     dp_hat[idx] = dp_low[(long long)j * ns + s];
 }
@@ -1962,7 +1907,6 @@ struct DDCombineArgs {
     const int *sing;             // singular modes (handled separately)
     int ns;
     int hom_nm_block;            // 0: hom is SoA [(c*n + j)*nm + t]; NM > 0: blocked [blk][5][n][NM] (k_ode_block_layout)
-    int nkb;                     // ode_slot
     double *p_hat, *dp_hat;
     int n, nxh, ny;
     long long nm;
@@ -1970,15 +1914,14 @@ struct DDCombineArgs {
 
 // constants of OPR_ODE2_Factorize_DD that depend on the mode only (opr_odes.f90:452-454), for the chunked kernel: cst[5][nm]
 __global__ void __launch_bounds__(256) k_dd_constants(const double *__restrict__ hom, int hom_nm_block, const double *__restrict__ der,
-                                                      double *__restrict__ cst, int n, long long nm, int nxh = 1, int nkb = 0) {
+                                                      double *__restrict__ cst, int n, long long nm) {
 #pragma clang fp contract(off)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nm) return;
     auto H = [&](int c, int j) {
         if (hom_nm_block > 0) {
             const int NM = hom_nm_block;
-            const long long sl = ode_slot(t, nxh, nkb, NM);
-            return hom[(((sl / NM) * 5 + c) * n + j) * NM + (sl % NM)];
+            return hom[(((t / NM) * 5 + c) * n + j) * NM + (t % NM)];
         }
         return hom[((long long)c * n + j) * nm + t];
     };
@@ -2004,8 +1947,7 @@ __global__ void __launch_bounds__(256) k_dd_combine(DDCombineArgs a) {
     auto H = [&](int c, int j) {
         if (a.hom_nm_block > 0) {
             const int NM = a.hom_nm_block;
-            const long long sl = ode_slot(t, a.nxh, a.nkb, NM);
-            return a.hom[(((sl / NM) * 5 + c) * n + j) * NM + (sl % NM)];
+            return a.hom[(((t / NM) * 5 + c) * n + j) * NM + (t % NM)];
         }
         return a.hom[((long long)c * n + j) * nm + t];
     };
@@ -2198,13 +2140,6 @@ struct tlab_poisson_plan {
     DBuf d_bt[2], chk[2], chk_s[2], homb;       // chunked ODE kernel: boundary constants [3][4], PENTADFS checkpoints [blk][C][6][NM] of both systems,
                                       // homogeneous solutions re-laid out as [blk][5][ny][NM]
     bool use_chunked = false;
-    // BLOCKED spectral layout between the own transforms (SpecLayout): nb = the NM modes of a workgroup of k_ode_nn, or 0.  ode_nkb > 0: the workgroups
-    // of k_ode_nn are kx-blocks of one kz and the blocked tables are laid out by them (ode_slot), whatever layout the arrays of a call have.
-    int blk_nb = 0, ode_nkb = 0;
-    long long *blk_off = nullptr;     // (offset, width) per kx of the blocked layout for the own x transforms (FftxArgs::kxoff, kxw)
-    int *blk_w = nullptr;
-    SpecLayout lay(bool blocked) const { return SpecLayout{nxh, ny, nz, blocked ? blk_nb : 0}; }
-    void z_blocked(int dir, double *a, hipStream_t st) const { fz_own->exec(dir, a, a, st); }      // the z transform of a blocked array, in place: the planes are re-tiled, not the z axis
     int ode_nm_per_wg = 0;
     int ode_om = OM;                  // rows per thread of k_ode_nn
     bool ode_pair = false;            // k_ode_nn on mirror pairs (kx, kz), (kx, nz - kz): lambda symmetric to the bit, checked at creation
@@ -2214,8 +2149,6 @@ struct tlab_poisson_plan {
     int *d_low_modes = nullptr;
     int *d_hom_band = nullptr;                  // [2][nm] rows between which the homogeneous solutions of a mode are negligible (k_ode_hom_band)
     int n_low = 0;
-    int low_kx_lo = -1, low_kx_hi = 1 << 30;      // the low modes have kx <= low_kx_lo or kx >= low_kx_hi (the modified wavenumber vanishes at kx = nx/2 as well as at
-                                      // 0): the kx-batched stage transforms those two ends first and inverts them last
     DBuf low_f, low_p, low_dp;
     std::vector<int> sing_modes;      // flat mode indices t = kx + nxh*kz of the singular modes
     int *d_sing = nullptr;
@@ -2308,8 +2241,6 @@ struct tlab_poisson_plan {
         if (d_skip) (void)hipFree(d_skip);
         if (d_low_modes) (void)hipFree(d_low_modes);
         if (d_hom_band) (void)hipFree(d_hom_band);
-        if (blk_off) (void)hipFree(blk_off);
-        if (blk_w) (void)hipFree(blk_w);
         if (side) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -2404,8 +2335,7 @@ void launch_ode_nm(const OdeArgs &a, size_t lds, hipStream_t st) {
         attr_done = true;
     }
     const long long nlive = NL == 4 ? (long long)a.nxh * (a.nm / a.nxh / 2 + 1) : a.nm;
-    unsigned grid = (unsigned)((nlive + NM - 1) / NM);
-    if (a.nkb > 0) grid = (unsigned)((long long)(a.nkb_sub > 0 ? a.nkb_sub : a.nkb) * (NL == 4 ? a.nm / a.nxh / 2 + 1 : a.nm / a.nxh));      // kx-blocks x the kz planes with a workgroup
+    const unsigned grid = (unsigned)((nlive + NM - 1) / NM);
     hipLaunchKernelGGL((k_ode_nn<NM, DD, OMR, NL>), dim3(grid), dim3(NM * a.C), lds, st, a);
 }
 template <bool DD>
@@ -2423,10 +2353,8 @@ void launch_ode_pair(const OdeArgs &a, int NM, int om, size_t lds, hipStream_t s
 }
 bool ode_pair_geometry(int NM, int om) { return om == OM; }
 
-void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st, bool dd = false, bool blocked = false, int kxb0 = 0,
-                int nkb_sub = 0) {
+void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st, bool dd = false) {
     OdeArgs a{};
-    a.nkb = P.ode_nkb; a.lay = P.lay(blocked); a.kxb0 = kxb0; a.nkb_sub = nkb_sub;
     a.T1 = P.sys(0); a.T2 = P.sys(1);
     a.lam = P.lam.p; a.skip = P.d_skip; a.chk1 = P.chk[0].p; a.chk2 = P.chk[1].p; a.cst = dd ? P.cst_dd.p : P.cst.p; a.hom = P.homb.p; a.band = P.d_hom_band;
     a.f_hat = f_hat; a.p_hat = p_hat; a.dp_hat = dp_hat; a.fscale = P.norm;
@@ -2475,8 +2403,7 @@ static void launch_int2c(const Int2cArgs &k, size_t lds, hipStream_t st) {
 
 void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
     const int C = P.ny / P.ode_om, NM = P.ode_nm_per_wg;
-    const int nkb = P.ode_nkb, nxh = P.nxh;
-    const long long nblk = nkb > 0 ? (long long)nkb * (P.nm / nxh) : (P.nm + NM - 1) / NM;
+    const long long nblk = (P.nm + NM - 1) / NM;
     for (int w = 0; w < 2; ++w) {
         const Int1Tables &T = w == 0 ? P.tmin : P.tmax;
         std::vector<double> bt(12);
@@ -2484,16 +2411,14 @@ void build_checkpoints(tlab_poisson_plan &P, hipStream_t st) {
             for (int c = 0; c < 4; ++c) bt[j * 4 + c] = (w == 0) ? T.rb[j][c] : T.rt[j][c];
         P.d_bt[w].upload(bt);
         P.chk[w].alloc((size_t)C * 6 * nblk * NM);
-        if (nkb > 0) hipc(hipMemsetAsync(P.chk[w].p, 0, (size_t)C * 6 * nblk * NM * sizeof(double), st), "hipMemsetAsync");      // (the empty slots of the last kx-block)
     }
     const int grid = (int)((P.nm + 255) / 256);
-    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(grid), dim3(256), 0, st, P.sys(0), P.lam.p, 1.0, P.chk[0].p, P.nm, NM, C, P.ode_om, nxh, nkb);
-    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(grid), dim3(256), 0, st, P.sys(1), P.lam.p, -1.0, P.chk[1].p, P.nm, NM, C, P.ode_om, nxh, nkb);
+    hipLaunchKernelGGL((k_ode_checkpoint<1>), dim3(grid), dim3(256), 0, st, P.sys(0), P.lam.p, 1.0, P.chk[0].p, P.nm, NM, C, P.ode_om);
+    hipLaunchKernelGGL((k_ode_checkpoint<2>), dim3(grid), dim3(256), 0, st, P.sys(1), P.lam.p, -1.0, P.chk[1].p, P.nm, NM, C, P.ode_om);
     hipc(hipGetLastError(), "k_ode_checkpoint");
     P.homb.alloc((size_t)5 * P.ny * nblk * NM);
-    if (nkb > 0) hipc(hipMemsetAsync(P.homb.p, 0, (size_t)5 * P.ny * nblk * NM * sizeof(double), st), "hipMemsetAsync");
     const long long tot = (long long)5 * P.ny * P.nm;
-    hipLaunchKernelGGL(k_ode_block_layout, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.hom.p, P.homb.p, 5, P.ny, P.nm, NM, nxh, nkb);
+    hipLaunchKernelGGL(k_ode_block_layout, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.hom.p, P.homb.p, 5, P.ny, P.nm, NM);
     hipc(hipGetLastError(), "k_ode_block_layout");
     static const bool band_on = [] { const char *e = getenv("TLAB_ODE_HOM_BAND"); return !(e && atoi(e) == 0); }();
     if (band_on) {
@@ -2551,9 +2476,8 @@ void launch_ode_sing_nm(const OdeSingArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((k_ode_sing<NM>), dim3(1), dim3(NM * a.C), ode_lds_bytes(a.C, NM), st, a);
 }
 
-void launch_ode_sing(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st, bool blocked = false) {
+void launch_ode_sing(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
     OdeSingArgs a{};
-    a.lay = P.lay(blocked);
     a.T1 = P.sys(0); a.T2 = P.sys(1);
     a.chk1 = P.chk_s[0].p; a.chk2 = P.chk_s[1].p; a.modes = P.d_sing;
     a.v1 = P.s_v1.p; a.u1 = P.s_u1.p; a.du1 = P.s_du1.p;
@@ -2702,7 +2626,7 @@ void build_low_modes(tlab_poisson_plan &P, const std::vector<double> &nodes, con
     L->d_L0[0].upload(L->tmin.L0); L->d_L1[0].upload(L->tmin.L1); L->d_R[0].upload(L->tmin.R);
     L->d_L0[1].upload(L->tmax.L0); L->d_L1[1].upload(L->tmax.L1); L->d_R[1].upload(L->tmax.R);
     std::vector<double> sub(ns);
-    for (int s = 0; s < ns; ++s) { sub[s] = lam[cand[s]]; skip[cand[s]] = 1; const int kx = cand[s] % P.nxh; if (kx < P.nxh / 2) P.low_kx_lo = std::max(P.low_kx_lo, kx); else P.low_kx_hi = std::min(P.low_kx_hi, kx); }
+    for (int s = 0; s < ns; ++s) { sub[s] = lam[cand[s]]; skip[cand[s]] = 1; }
     L->lam.upload(sub);
     hipc(hipMalloc((void **)&L->d_skip, (size_t)ns), "hipMalloc");
     hipc(hipMemset(L->d_skip, 0, (size_t)ns), "hipMemset");
@@ -2915,32 +2839,11 @@ static int poisson_plan_create_impl(tlab_poisson_plan_t *out, tlab_fdm_plan_t gx
                         P->ode_pair = true; P->ode_om = om; P->ode_nm_per_wg = NMp;
                     }
                 }
-                {   // workgroups of k_ode_nn = kx-blocks of one kz, and the blocked spectral layout between the own transforms (SpecLayout), on single-device plans
-                    // whose transforms are all the library's own; TLAB_POISSON_BLOCKED=0: the reference's layout throughout (A/B, and what decomposed plans keep)
-                    const char *be = getenv("TLAB_POISSON_BLOCKED");
-                    const char *ke = getenv("TLAB_ODE_KXBLOCKS");
-                    if (!(ke && atoi(ke) == 0) && !helmholtz && nproc == 1 && nxl == 0 && nzt > 1 && P->fz_own && P->nxh == P->fx_nxh && P->fx_nz == nz)
-                        P->ode_nkb = (P->nxh + P->ode_nm_per_wg - 1) / P->ode_nm_per_wg;
-                    if (be && atoi(be) != 0 && P->ode_nkb > 0 && P->fx_own) {
-                        P->blk_nb = P->ode_nm_per_wg;
-                        std::vector<long long> off((size_t)P->nxh);
-                        std::vector<int> w((size_t)P->nxh);
-                        for (int kx = 0; kx < P->nxh; ++kx) {
-                            const int b = kx / P->blk_nb, wb = std::min(P->blk_nb, P->nxh - b * P->blk_nb);
-                            off[kx] = (long long)b * P->blk_nb * ny + (kx - b * P->blk_nb);      // element (line = j + ny kz, kx) at off + j w + kz nxh ny = off + line w + kz (nxh - w) ny
-                            w[kx] = wb;
-                        }
-                        hipc(hipMalloc((void **)&P->blk_off, off.size() * sizeof(long long)), "hipMalloc");
-                        hipc(hipMalloc((void **)&P->blk_w, w.size() * sizeof(int)), "hipMalloc");
-                        hipc(hipMemcpy(P->blk_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice), "hipMemcpy");
-                        hipc(hipMemcpy(P->blk_w, w.data(), w.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
-                    }
-                }
                 build_checkpoints(*P, st);
                 P->use_chunked = true;
                 if (ode_sing_nm(C) * C <= 512 && (int)P->sing_modes.size() <= ode_sing_nm(C) && ode_lds_bytes(C, ode_sing_nm(C)) <= (size_t)160 * 1024)
                     build_singular_checkpoints(*P, st);
-                else { P->use_chunked = false; P->blk_nb = 0; P->ode_nkb = 0; }
+                else P->use_chunked = false;
             }
         }
         if (P->use_chunked) build_low_modes(*P, gy->t.nodes, lam, skip, st);
@@ -3077,7 +2980,7 @@ static void poisson_dd_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat
     if (chunked) {
         if (P->cst_dd.n == 0) {
             P->cst_dd.alloc((size_t)5 * nm);
-            hipLaunchKernelGGL(k_dd_constants, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, P->homb.p, P->ode_nm_per_wg, P->der.p, P->cst_dd.p, n, nm, nxh, P->ode_nkb);
+            hipLaunchKernelGGL(k_dd_constants, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, P->homb.p, P->ode_nm_per_wg, P->der.p, P->cst_dd.p, n, nm);
             hipc(hipGetLastError(), "k_dd_constants");
         }
         hipc(hipEventRecord(P->ev_fork, st), "event record");
@@ -3145,7 +3048,6 @@ static void poisson_dd_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat
     c.u0 = P->u0.p; c.v0 = P->v0.p; c.du0 = P->du0.p; c.bcs = P->bcs.p; c.der = P->der.p; c.lam = P->lam.p;
     c.hom = P->use_chunked ? P->homb.p : P->hom.p;
     c.hom_nm_block = P->use_chunked ? P->ode_nm_per_wg : 0;
-    c.nkb = P->use_chunked ? P->ode_nkb : 0;
     c.sing = P->d_sing; c.ns = ns;
     c.p_hat = p_hat; c.dp_hat = dp_hat; c.n = n; c.nxh = nxh; c.ny = ny; c.nm = nm;
     hipLaunchKernelGGL(k_dd_combine, dim3((unsigned)((nm + 255) / 256), nm <= 4096 ? (unsigned)((n + 15) / 16) : 1u), dim3(256), 0, st, c);
@@ -3157,8 +3059,7 @@ static void poisson_dd_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat
     hipc(hipGetLastError(), "BCS_DD kernels");
 }
 
-static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st, bool blocked = false) {
-    if (blocked && !(P->use_chunked && P->blk_nb > 0)) throw std::logic_error("poisson_ode_stage: blocked arrays on a plan without the blocked layout");
+static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_hat, double *dp_hat, hipStream_t st) {
     if (P->direct) throw std::invalid_argument("direct elliptic plan: use tlab_poisson_direct_ode (there is no dp^/dy; dp/dy is OPR_Partial_Y of p)");
     const long long nm = P->nm;
     const int n = P->ny, nxh = P->nxh, ny = P->ny;
@@ -3179,7 +3080,7 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
     const int ns = (int)P->sing_modes.size();
     hipStream_t ss = P->side;   // independent of the regular modes until the scatter below
     if (ns > 0 && P->use_chunked) {
-        launch_ode_sing(*P, f_hat, p_hat, dp_hat, ss, blocked);      // one workgroup beside the regular modes; writes only the singular entries
+        launch_ode_sing(*P, f_hat, p_hat, dp_hat, ss);      // one workgroup beside the regular modes; writes only the singular entries
     }
     if (P->use_chunked && P->low) {                         // the lowest-lambda modes: marching sub-plan, also beside the regular ones
         const int nl = P->n_low;
@@ -3187,11 +3088,11 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
         hipStream_t ls = P->side_low;
         hipc(hipStreamWaitEvent(ls, P->ev_fork, 0), "stream wait");
         hipLaunchKernelGGL(k_modes_gather, g, blk, 0, ls, reinterpret_cast<const double2 *>(f_hat), P->d_low_modes, nl, n, nxh, ny,
-                           reinterpret_cast<double2 *>(P->low_f.p), P->lay(blocked));
+                           reinterpret_cast<double2 *>(P->low_f.p));
         poisson_ode_stage(P->low.get(), P->low_f.p, P->low_p.p, P->low_dp.p, ls);
         hipLaunchKernelGGL(k_modes_scatter, g, blk, 0, ls, reinterpret_cast<const double2 *>(P->low_p.p),
                            reinterpret_cast<const double2 *>(P->low_dp.p), P->d_low_modes, nl, n, nxh, ny, reinterpret_cast<double2 *>(p_hat),
-                           reinterpret_cast<double2 *>(dp_hat), P->lay(blocked));
+                           reinterpret_cast<double2 *>(dp_hat));
         hipc(hipEventRecord(P->ev_join_low, ls), "event record");
     }
     if (ns > 0 && P->use_chunked) {
@@ -3213,7 +3114,7 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
         ProfScope ps("k_nn_combine", st, (double)nm * n * (9 + 4) * 8.0);
         hipLaunchKernelGGL(k_nn_combine, dim3((unsigned)((nm + 255) / 256), nm <= 4096 ? (unsigned)((n + 15) / 16) : 1u), dim3(256), 0, st, c);
     } else {
-        launch_ode(*P, f_hat, p_hat, dp_hat, st, false, blocked);      // both solves, the constants and the final pass in one kernel
+        launch_ode(*P, f_hat, p_hat, dp_hat, st);      // both solves, the constants and the final pass in one kernel
     }
     // the singular modes write other entries than k_nn_combine (which skips them), but f^ must have been consumed by the regular
     // v-solve first when p_hat aliases it: order the scatter after it through the main stream
@@ -3226,61 +3127,6 @@ static void poisson_ode_stage(tlab_poisson_plan_t P, double *f_hat, double *p_ha
                            P->d_sing, ns, n, nxh, ny, p_hat, dp_hat);
     }
     hipc(hipGetLastError(), "poisson kernels");
-}
-
-// OPR_Poisson (BCS_NN) with the per-mode stage in kx-BATCHES (reference's spectral layout): forward z transform, k_ode_nn and the two inverse z transforms
-// of W values of kx at a time, so that what one kernel of the chain writes is still in the 256-MiB Infinity Cache when the next one reads it
-// (tools/mall_probe: a copy inside the cache 6.5 TB/s, through HBM 4.4).  The singular and the lowest-lambda modes (kx in the first batch, and kx = nx/2)
-// run beside the chain as before; their batches are transformed first and inverted last.
-//   tmp2 = x transform of the forcing;  per batch: tmp2 -> z -> tmp1 (f^) -> ode -> tmp1 (p^), tmp2 (dp^) -> z^-1 -> cwork (p), tmp1 (dp)
-static void poisson_nn_batched(tlab_poisson_plan_t P, double *tmp1, double *tmp2, hipStream_t st, int W) {
-    const int nxh = P->nxh, ny = P->ny, n = P->ny, NM = P->ode_nm_per_wg, nkb = P->ode_nkb;
-    W = std::max(NM, (W / NM) * NM);
-    const int nbk = W / NM;                                 // kx-blocks per batch
-    // the singular modes (kx = 0, nx/2) and the low modes (kx of a few units from either end) live in the first batch and in the blocks from last_blk on
-    const int last_blk = std::min((nxh - 1) / NM, P->low_kx_hi / NM);
-    const bool nyq_alone = last_blk >= nbk;
-    const int ntail = nkb - last_blk;
-    auto fwd = [&](int b0, int nb) { const int k0 = b0 * NM, w = std::min(nb * NM, nxh - k0); P->fz_own->exec_sub(1, tmp2, tmp1, nxh, k0, w, st); };
-    auto inv = [&](int b0, int nb) {
-        const int k0 = b0 * NM, w = std::min(nb * NM, nxh - k0);
-        P->fz_own->exec_sub(-1, tmp1, P->cwork.p, nxh, k0, w, st);
-        P->fz_own->exec_sub(-1, tmp2, tmp1, nxh, k0, w, st);
-    };
-    fwd(0, nbk);
-    if (nyq_alone) fwd(last_blk, ntail);
-    // ---- the singular and the low modes beside the chain (as poisson_ode_stage) ----
-    hipc(hipEventRecord(P->ev_fork, st), "event record");
-    hipc(hipStreamWaitEvent(P->side, P->ev_fork, 0), "stream wait");
-    const int ns = (int)P->sing_modes.size();
-    if (ns > 0) launch_ode_sing(*P, tmp1, tmp1, tmp2, P->side);
-    if (P->low) {
-        const int nl = P->n_low;
-        const dim3 g((nl + 63) / 64, n), blk(64);
-        hipStream_t ls = P->side_low;
-        hipc(hipStreamWaitEvent(ls, P->ev_fork, 0), "stream wait");
-        hipLaunchKernelGGL(k_modes_gather, g, blk, 0, ls, reinterpret_cast<const double2 *>(tmp1), P->d_low_modes, nl, n, nxh, ny, reinterpret_cast<double2 *>(P->low_f.p));
-        poisson_ode_stage(P->low.get(), P->low_f.p, P->low_p.p, P->low_dp.p, ls);
-        hipLaunchKernelGGL(k_modes_scatter, g, blk, 0, ls, reinterpret_cast<const double2 *>(P->low_p.p), reinterpret_cast<const double2 *>(P->low_dp.p), P->d_low_modes,
-                           nl, n, nxh, ny, reinterpret_cast<double2 *>(tmp1), reinterpret_cast<double2 *>(tmp2));
-        hipc(hipEventRecord(P->ev_join_low, ls), "event record");
-    }
-    // ---- the chain over the other batches ----
-    const int stop = nyq_alone ? last_blk : nkb;            // blocks [nbk, stop) in batches; the Nyquist block (alone in its row end) goes with the first batch
-    for (int b0 = nbk; b0 < stop; b0 += nbk) {
-        const int nb = std::min(nbk, stop - b0);
-        fwd(b0, nb);
-        launch_ode(*P, tmp1, tmp1, tmp2, st, false, false, b0, nb);
-        inv(b0, nb);
-    }
-    launch_ode(*P, tmp1, tmp1, tmp2, st, false, false, 0, std::min(nbk, nkb));
-    if (nyq_alone) launch_ode(*P, tmp1, tmp1, tmp2, st, false, false, last_blk, ntail);
-    hipc(hipEventRecord(P->ev_join, P->side), "event record");
-    hipc(hipStreamWaitEvent(st, P->ev_join, 0), "stream wait");
-    if (P->low) hipc(hipStreamWaitEvent(st, P->ev_join_low, 0), "stream wait");
-    inv(0, std::min(nbk, nkb));
-    if (nyq_alone) inv(last_blk, ntail);
-    hipc(hipGetLastError(), "poisson kernels (kx batches)");
 }
 
 #define POISSON_GUARD_BEGIN try {
@@ -3339,35 +3185,6 @@ int tlab_opr_poisson(tlab_poisson_plan_t P, int nx, int ny, int nz, int ibc, dou
     hipStream_t st = tlab_current_stream();
     // BC planes into the forcing (opr_elliptic.f90:285-286)
     hipLaunchKernelGGL(k_set_wall_planes, dim3((unsigned)(((long long)nx * nz + 255) / 256)), dim3(256), 0, st, p, bcs_hb, bcs_ht, nx, ny, nz);
-    if (P->blk_nb > 0 && ibc == TLAB_BCS_NN) {
-        // The same operations on the BLOCKED spectral layout (SpecLayout): x transform straight into tmp1's kx-blocks, z transform in place, per-mode stage
-        // on contiguous boxes (p^ over f^ in tmp1, dp^/dy in tmp2), z transforms in place, x transforms back.  No array is in the reference's spectral
-        // layout at any time; tmp1, tmp2 are scratch in the reference too.  Bit-identical to the other route (same arithmetic, other addresses).
-        P->fx_own->exec(p, tmp1, st, P->blk_off, P->blk_w, P->ny);
-        P->z_blocked(1, tmp1, st);
-        poisson_ode_stage(P, tmp1, tmp1, tmp2, st, true);
-        P->z_blocked(-1, tmp1, st);
-        P->fx_own->exec_inverse(tmp1, p, st, P->blk_off, P->blk_w, P->ny);
-        if (dpdy) {
-            P->z_blocked(-1, tmp2, st);
-            if (vf.armed) P->fx_own->exec_inverse_final(tmp2, vf.q, vf.h, vf.dte, vf.kco, vf.scale, ny, st, P->blk_off, P->blk_w, P->ny);
-            else P->fx_own->exec_inverse(tmp2, dpdy, st, P->blk_off, P->blk_w, P->ny);
-        }
-        return TLAB_OK;
-    }
-    {
-        static const int kxbatch = [] { const char *e = getenv("TLAB_POISSON_KXBATCH"); return e ? atoi(e) : 0; }();
-        if (getenv("TLAB_POISSON_DEBUG")) fprintf(stderr, "opr_poisson: kxbatch %d ibc %d chunked %d nkb %d fz_own %d nz %d use_2d %d low_kx_max %d NM %d\n", kxbatch, ibc, (int)P->use_chunked,
-                                                  P->ode_nkb, (int)(bool)P->fz_own, nz, (int)P->use_2d, P->low_kx_lo, P->ode_nm_per_wg);
-        if (kxbatch > 0 && ibc == TLAB_BCS_NN && P->use_chunked && P->ode_nkb > 0 && P->fz_own && nz > 1 && !P->use_2d && P->low_kx_lo < std::max(kxbatch, P->ode_nm_per_wg)) {
-            // the low modes must all lie in the first batch (or be kx = nx/2): they do for every grid in use (lambda h <= 0.06 means kx of a few units)
-            P->x_forward(p, tmp2, st);
-            poisson_nn_batched(P, tmp1, tmp2, st, kxbatch);
-            P->x_backward_p(P->cwork.p, p, st);
-            if (dpdy) P->x_backward_dpdy(tmp1, dpdy, st, vf);
-            return TLAB_OK;
-        }
-    }
     // forward transforms: p -> tmp2 -> tmp1 (:288-293); the scaling by norm (:295) is folded into the loads of the ODE stage
     if (P->use_2d) {
         P->f2_fwd.exec(p, tmp1, st);
