@@ -302,9 +302,11 @@ __device__ __forceinline__ void xstore(double *__restrict__ p, const double (&u)
 }
 
 // LV / LV2: table form of the first- / second-derivative system (see xcoef)
-template <int M, int MODE, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false, bool PER = false>
-__global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
-    static_assert(!CL || WPL > 1, "constants in LDS: several waves per line only");
+// OCC = 2: two workgroups per CU (two waves per SIMD) asked of the compiler, and the lane-variant tables re-read from LDS where they are used instead of
+// being kept in ~140 registers across the loop over lines and fields (512-point lines: 256 VGPRs + 102 AGPRs = one wave per SIMD otherwise)
+template <int M, int MODE, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false, bool PER = false, int OCC = 1>
+__global__ void __launch_bounds__(TPB, (OCC > 1 && TPB > 256) ? 1 : OCC) k_xline(XLineArgs a) {
+    // (CL with one wave per line: stage_red leaves the rows of the two-level reduction empty)
     extern __shared__ double xlds[];
     constexpr bool NEED1 = (MODE != MODE_P2);
     constexpr bool NEED2 = (MODE != MODE_P1);
@@ -345,9 +347,11 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
         auto stage_red = [&](const SystemDev &sd, double *d, int lv) {
             for (int idx = threadIdx.x; idx < XRL * P; idx += blockDim.x) {
                 const int l = idx % P, k = idx / P;
-                d[idx] = k < 15 ? sd.red[k * P + l] : sd.rowtab[(k == 15 ? 0 : 2) * n + (lv ? l * M : 0)];
+                // (one wave per line: the table has the 13 rows of the cyclic reduction only; rows 13, 14 and the interface constants belong to the two-level form)
+                d[idx] = k < 13 ? sd.red[k * P + l] : k < 15 ? (WPL > 1 ? sd.red[k * P + l] : 0.0) : sd.rowtab[(k == 15 ? 0 : 2) * n + (lv ? l * M : 0)];
             }
-            for (int idx = threadIdx.x; idx < 6 * WPL; idx += blockDim.x) d[XRL * P + idx] = sd.red[(15 + idx / WPL) * P + (idx % WPL) * 64];
+            if constexpr (WPL > 1)
+                for (int idx = threadIdx.x; idx < 6 * WPL; idx += blockDim.x) d[XRL * P + idx] = sd.red[(15 + idx / WPL) * P + (idx % WPL) * 64];
         };
         if (NEED1) stage_red(a.y1, red1, LV);
         if (NEED2) stage_red(a.y2, red2, LV2);
@@ -388,8 +392,8 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
         const long long noff = nline * n + gl * M;
         // many rows per lane: the lane-variant tables are loop-invariant and the compiler would keep all 2 x 5 x M of them in registers
         // (182 spilled VGPRs at M = 32); an opaque copy of the LDS pointers per line makes it re-read them where they are used
-        if constexpr (LV == 2 || (LV == 1 && M >= 16)) { if (NEED1) asm volatile("" : "+v"(y1.lds)); }
-        if constexpr (LV2 == 2 || (LV2 == 1 && M >= 16)) { if (NEED2) asm volatile("" : "+v"(y2.lds)); }
+        if constexpr (LV == 2 || (LV == 1 && (M >= 16 || OCC > 1))) { if (NEED1) asm volatile("" : "+v"(y1.lds)); }
+        if constexpr (LV2 == 2 || (LV2 == 1 && (M >= 16 || OCC > 1))) { if (NEED2) asm volatile("" : "+v"(y2.lds)); }
         if constexpr (MODE == MODE_BURGERS) {
             // the advecting velocity of the line is loaded once and serves every transported field (rhs_global_incompressible_1.f90:
             // 98-162 calls OPR_Burgers_X four times with the same u)
@@ -410,8 +414,8 @@ __global__ void __launch_bounds__(TPB) k_xline(XLineArgs a) {
                 const double *src = a.fs[f];
                 double *dst = a.fo[f];
                 const double nuf = a.ari ? a.fnu[f] * a.ari[line % a.ari_ny] : a.fnu[f];      // anelastic: ribackground(j) of this line on the diffusion term
-                if constexpr (LV == 2 || (LV == 1 && M >= 16)) asm volatile("" : "+v"(y1.lds));      // ... and per field
-                if constexpr (LV2 == 2 || (LV2 == 1 && M >= 16)) asm volatile("" : "+v"(y2.lds));
+                if constexpr (LV == 2 || (LV == 1 && (M >= 16 || OCC > 1))) asm volatile("" : "+v"(y1.lds));      // ... and per field
+                if constexpr (LV2 == 2 || (LV2 == 1 && (M >= 16 || OCC > 1))) asm volatile("" : "+v"(y2.lds));
                 double u[M];
                 if (src == a.in1) {
 #pragma unroll
@@ -961,14 +965,15 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ a,
 // ============================================================================================
 static inline int imin(long long a, long long b) { return (int)(a < b ? a : b); }
 
-template <int M, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false, bool PER = false>
+template <int M, int LV, int WPL, int LV2 = LV, int TPB = 256, bool CL = false, bool PER = false, int OCC = 1>
 static hipError_t launch_xline_m(int mode, const XLineArgs &a_in, hipStream_t st) {
     static const int lb = [] { const char *e = getenv("TLAB_XLINE_LINE_BARRIERS"); return e ? atoi(e) : 1; }();
     XLineArgs a = a_in;
     a.line_barriers = lb;
     constexpr int P = 64 * WPL, LPB = TPB / 64 / WPL;
     const long long blocks_needed = (a.nlines + LPB - 1) / LPB;
-    const int grid = imin(blocks_needed, 256 * 8 * 256 / TPB);
+    static const int gmul = [] { const char *e = getenv("TLAB_XLINE_GRID"); return e ? atoi(e) : 8; }();      // persistent workgroups per CU-slot (experiments)
+    const int grid = imin(blocks_needed, 256 * gmul * 256 / TPB);
     if (mode < 1 || mode > 4) return hipErrorInvalidValue;
     auto tabbytes = [](int lv) { return lv == 1 ? (size_t)5 * M * P * sizeof(double) : lv == 2 ? (size_t)5 * M * P * sizeof(float) : (size_t)0; };
     const size_t redbytes = CL ? ((size_t)XRL * P + 6 * WPL) * sizeof(double) : 0;
@@ -985,18 +990,18 @@ static hipError_t launch_xline_m(int mode, const XLineArgs &a_in, hipStream_t st
     }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL, PER, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL, PER, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL, PER, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL, PER, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     ProfScope ps(names[mode], st, bytes);
     switch (mode) {
-    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
-    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL, PER>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P1: hipLaunchKernelGGL((k_xline<M, MODE_P1, LV, WPL, LV2, TPB, CL, PER, OCC>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2: hipLaunchKernelGGL((k_xline<M, MODE_P2, LV, WPL, LV2, TPB, CL, PER, OCC>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_P2_P1: hipLaunchKernelGGL((k_xline<M, MODE_P2_P1, LV, WPL, LV2, TPB, CL, PER, OCC>), dim3(grid), dim3(TPB), lds, st, a); break;
+    case MODE_BURGERS: hipLaunchKernelGGL((k_xline<M, MODE_BURGERS, LV, WPL, LV2, TPB, CL, PER, OCC>), dim3(grid), dim3(TPB), lds, st, a); break;
     }
     return hipGetLastError();
 }
@@ -1053,7 +1058,17 @@ hipError_t launch_xline(int mode, int n, int chunks, bool lane_variant, const XL
         if (a.s1.periodic && lane_variant) return launch_xline_m<4, 1, 1, 1, 256, false, true>(mode, a, st);
         return lane_variant ? launch_xline_m<4, 1, 1>(mode, a, st) : launch_xline_m<4, 0, 1>(mode, a, st);
     case 512:         // (scalar loads of common rows are slower: see above)
+    {
+        // fused Burgers on 512-point periodic lines: constants of the reduction AND tables in LDS, re-read where they are used, two workgroups per CU
+        // (256 VGPRs, no AGPRs, two waves per SIMD) instead of everything in 256 + 102 registers and one wave per SIMD: 3.09 -> 2.94 ms on a box in
+        // its fast state, 3.26 -> 3.20 on one in its slow state (A/B, profiles/r05/xline_occupancy.txt); TLAB_XLINE_OCC=1 keeps the old form
+        static const int occ = [] { const char *e = getenv("TLAB_XLINE_OCC"); return e ? atoi(e) : 3; }();
+        if (a.s1.periodic && occ == 2 && mode == MODE_BURGERS) return launch_xline_m<8, 1, 1, 1, 256, false, true, 2>(mode, a, st);
+        if (a.s1.periodic && occ == 3 && mode == MODE_BURGERS) return launch_xline_m<8, 1, 1, 1, 256, true, true, 2>(mode, a, st);
+        if (a.s1.periodic && occ == 4 && mode == MODE_BURGERS) return launch_xline_m<8, 1, 1, 1, 512, true, true, 2>(mode, a, st);      // one 8-wave workgroup per CU sharing the tables
+        if (a.s1.periodic && occ == 5) return launch_xline_m<8, 1, 1, 1, 256, true, true, 2>(mode, a, st);                           // ... the derivative modes as well
         return a.s1.periodic ? launch_xline_m<8, 1, 1, 1, 256, false, true>(mode, a, st) : launch_xline_m<8, 1, 1>(mode, a, st);
+    }
     case 1024: return lane_variant ? launch_xline_m<16, 1, 1>(mode, a, st) : launch_xline_m<16, 0, 1>(mode, a, st);
     case 2048: return lane_variant ? launch_xline_m<32, 2, 1>(mode, a, st) : launch_xline_m<32, 0, 1>(mode, a, st);     // the caller checked xline_wide_ok
     }
