@@ -113,6 +113,26 @@ def pencil(npi, npk, nx, ny, nz, bcs):
                 walls=("freeslip", "freeslip", "neumann", "dirichlet") if bcs == "freeslip" else None, q0=f[:3], s0=f[3:4], sched=rk_sched(2e-3))
 
 
+# ---- tests/test_gpu_poisson_direct.py: EllipticOrder = CompactDirect6; dp/dy = OPR_Partial_Y(p) differentiates the rounding noise of p ----
+def poisson_direct(nx, ny, nz, ibc):
+    import glob
+    import os
+    g = np.load(sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "direct_y*.npz")))[0])
+    tab = {k[len("ny%d_" % ny):]: g[k] for k in g.files if k.startswith("ny%d_" % ny)}
+    y = tab["nodes"]
+    x = np.arange(nx) / nx * 2 * np.pi
+    z = np.arange(nz) / nz * np.pi if nz > 1 else np.zeros(1)
+    rng = np.random.default_rng(ny + ibc)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    f = (np.sin(X) * np.cos(2 * Z) * np.exp(Y) + 0.3 * rng.uniform(-1, 1, X.shape)).ravel()
+    hb, ht = rng.uniform(-1, 1, (nz, nx)), rng.uniform(-1, 1, (nz, nx))
+    return dict(key="poisson_direct.dpdy[%d-%d-%d-%d]" % (nx, ny, nz, ibc), x=x, y=y, z=z, tab=tab, mode2=16, ibc=ibc, f=f, hb=hb, ht=ht)
+
+
+def registry_direct():
+    return [(16, 64, 1, 3), (32, 128, 8, 3), (64, 512, 16, 3)]
+
+
 def make_oracle_factory(case, cls=None):
     """() -> a fresh oracle of the case (numpy DnsOracle, or another class with its interface) with the case's walls"""
     from oracle.tlab_oracle_rhs import DnsOracle

@@ -62,6 +62,34 @@ def worker(index, out, with_numpy):
     np.savez(out, **res)
 
 
+def worker_direct(index, out, with_ulp):
+    """dp/dy = OPR_Partial_Y(p) of the direct elliptic solver (opr_elliptic.f90:447-449) by the reference's own OPR_Partial_Y on the pressure of the numpy
+    oracle (bitwise the reference's per-mode arithmetic, FFTs by numpy): the two builds on the same p, and the plain build on p moved by one ulp"""
+    import cases as C
+    from oracle import ref_lib as R, tlab_oracle as O, tlab_oracle_poisson as OP
+    from scatter import one_ulp_noise
+    nx, ny, nz, ibc = C.registry_direct()[index]
+    case = C.poisson_direct(nx, ny, nz, ibc)
+    ogx, ogz = O.FdmPlan(case["x"], True, True), O.FdmPlan(case["z"], True, True) if nz > 1 else None
+    ogy = O.FdmPlan.from_tables(case["tab"], mode2=case["mode2"])
+    oplan = OP.PoissonDirectPlan(ogx, ogy, ogz if nz > 1 else ogx, nx, ny, nz)
+    p_ref, _ = OP.opr_poisson_fxz_direct(oplan, case["f"], case["hb"], case["ht"], ibc)
+    R.init(nx, ny, nz)
+    R.fdm_create(1, case["x"], True, True, 6, 16)
+    R.fdm_create(2, case["y"], False, False, 6, 16)
+    if nz > 1:
+        R.fdm_create(3, case["z"], True, True, 6, 16)
+    res = {"dpdy": R.partial(2, 1, nx, ny, nz, 0, p_ref)[0]}
+    if with_ulp:
+        rng = np.random.default_rng(1234)
+        sc = 0.0
+        for _ in range(2):
+            d = R.partial(2, 1, nx, ny, nz, 0, one_ulp_noise(p_ref, rng))[0]
+            sc = max(sc, float(np.abs(d - res["dpdy"]).max() / np.abs(res["dpdy"]).max()))
+        res["ulp"] = np.array(sc)
+    np.savez(out, **res)
+
+
 def rel(a, b):
     s = np.abs(b).max()
     return float(np.abs(a - b).max() / (s if s > 0 else 1.0))
@@ -111,11 +139,30 @@ def main():
                "made_by": "tests/golden/make_golden_yardsticks.py", "cases": table}
         with open(OUT, "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)
+    for index, (nx, ny, nz, ibc) in enumerate(C.registry_direct()):
+        key = "poisson_direct.dpdy[%d-%d-%d-%d]" % (nx, ny, nz, ibc)
+        if args.only and args.only not in key:
+            continue
+        outs = {}
+        for tag, lib in LIBS.items():
+            outs[tag] = os.path.join(tmp, "d%d_%s.npz" % (index, tag))
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--worker-direct", str(index), outs[tag], "1" if tag == "plain" else "0"], check=True,
+                           env=dict(os.environ, TLAB_REF_LIB=lib))
+        A, B = np.load(outs["fma"]), np.load(outs["plain"])
+        table[key] = {"grid": [nx, ny, nz], "substeps": 1, "diff": {"dpdy": [[rel(A["dpdy"], B["dpdy"])]]}, "ref_one_ulp_scatter": {"dpdy": [[float(B["ulp"])]]},
+                      "what": "OPR_Partial_Y of the reference on the oracle's pressure: two builds on the same p / the plain build on p moved by one ulp"}
+        print("%-48s ref-vs-ref %.2e  one-ulp %.2e" % (key, table[key]["diff"]["dpdy"][0][0], float(B["ulp"])), flush=True)
+        doc = json.load(open(OUT))
+        doc["cases"] = table
+        with open(OUT, "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
     print("wrote", OUT)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 4 and sys.argv[1] == "--worker":
+    if len(sys.argv) > 4 and sys.argv[1] == "--worker-direct":
+        worker_direct(int(sys.argv[2]), sys.argv[3], sys.argv[4] == "1")
+    elif len(sys.argv) > 4 and sys.argv[1] == "--worker":
         worker(int(sys.argv[2]), sys.argv[3], None if sys.argv[4] == "none" else sys.argv[4] == "1")
     else:
         main()
