@@ -456,6 +456,12 @@ long long tlab_pencil_dns_info(tlab_pencil_dns_t d, int what);   /* 0 imax, 1 km
 int tlab_pencil_dns_set_bcs(tlab_pencil_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
 int tlab_pencil_dns_begin_step(tlab_pencil_dns_t d);
 int tlab_pencil_dns_rhs(tlab_pencil_dns_t d, double dte);                                    /* RHS_GLOBAL_INCOMPRESSIBLE_1 */
+/* The transpositions are started AHEAD of independent launches (the reference's analogue: tools/dns/rhs_global_incompressible_nbc.f90:135-382): while one
+ * operator is applied to a transposed field, the forward transposition of the next field and the backward transposition of the previous result are in
+ * flight on the transport's stream; TLAB_PENCIL_OVERLAP=0 (read at creation) keeps the literal sequence.  tlab_pencil_dns_trace: on != 0 records, per
+ * RHS, one line per exchange start ("start forward i" / "start backward i"), per launch ("launch operator i" / "launch local") and per wait ("wait
+ * forward i" / "wait backward i"); the text of the last RHS is copied into buf (size bytes). */
+int tlab_pencil_dns_trace(tlab_pencil_dns_t d, int on, char *buf, int size);
 int tlab_pencil_dns_substep(tlab_pencil_dns_t d, double dte, double kco, int scale_tendencies);   /* + the update loops of time.f90:645-664, :272-297 */
 
 typedef struct tlab_slab_dns *tlab_slab_dns_t;

@@ -123,6 +123,57 @@ def test_native_pencil_driver_is_bit_identical_to_the_python_driver(T, npi, npk,
     nat.close()
 
 
+@pytest.mark.parametrize("npi,npk,ns", [(2, 2, 1), (2, 4, 2), (4, 1, 0), (1, 4, 3)])
+def test_native_pencil_driver_starts_its_transpositions_ahead_of_independent_launches(T, npi, npk, ns, monkeypatch):
+    """The overlapped schedule of tlab_pencil_dns_rhs (csrc/pencil.cpp::rhs_overlapped; reference: rhs_global_incompressible_nbc.f90:135-382): between EVERY
+    exchange start and its wait stands at least one launch that does not depend on it -- the operator of the previous field, a local y operator, a sum,
+    or the start / packing of the next exchange's payload -- read off the driver's own record of the order it issued things in
+    (tlab_pencil_dns_trace).  And the schedule changes no bit: the same fields as the literal sequence (TLAB_PENCIL_OVERLAP=0) after a full RK step."""
+    import ctypes
+    import torch
+    from tlab_amd.lib import load
+    from tlab_amd.pencil import NativePencilDns
+    nx, ny, nz = 64, 16, 32
+    x, y, z = grids(nx, ny, nz)
+    rng = np.random.default_rng(7 * npi + npk + ns)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    fields = [((np.sin(X + k) * np.cos(2 * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3 + ns)]
+    kw = dict(nscal=ns, visc=1.0 / 300.0, schmidt=(0.7, 1.3, 2.0)[:ns], yuniform=False, hyper_bc1_ext=REF_HYPER)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TLAB_PENCIL_OVERLAP", mode)
+        d = NativePencilDns("loopback", npi, npk, x, y, z, **kw)
+        for i in range(3 + ns):
+            d.scatter("q" if i < 3 else "s", i if i < 3 else i - 3, torch.from_numpy(fields[i]).cuda())
+        L = load()
+        L.tlab_pencil_dns_trace(d._h, 1, None, 0)
+        for k in range(3):
+            d.substep_of_cycle(k, 2e-3)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.tlab_pencil_dns_trace(d._h, 0, buf, len(buf))
+        out[mode] = ([t.clone() for r in range(npi * npk) for name in ("q", "s", "hq", "hs") for t in d.st[r][name]], buf.value.decode().splitlines())
+        d.close()
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert torch.equal(a, b)
+    events = out["1"][1]
+    assert out["0"][1] == []                                     # (the literal sequence records nothing: every start is followed by its wait)
+    starts = [i for i, e in enumerate(events) if e.startswith("start ")]
+    # transposed operators of ONE RHS (the record is per call): 3 + ns Burgers terms + 2 first derivatives per split direction, a forward and a backward exchange each
+    n_exchanges = (3 + ns + 2) * 2 * ((npi > 1) + (npk > 1))
+    assert len(starts) == n_exchanges, (len(starts), n_exchanges, events[:20])
+    for i in starts:
+        kind, which = events[i].split(" ", 1)[1].rsplit(" ", 1)
+        j = events.index("wait %s %s" % (kind, which), i)       # its wait (per RHS call the pairs are unique up to the pipeline restarts: first match after i)
+        between = events[i + 1:j]
+        idle_ok = "nothing left to overlap" in between
+        assert any(e.startswith("launch") for e in between) or idle_ok, (events[i], between)
+    # the driver says so itself where a pipeline has run out of independent work before its LAST backward transposition: at most once per pipeline (three per
+    # RHS: the Burgers terms, the divergence, the pressure gradient), never in the Burgers pipeline
+    assert sum(1 for e in events if e == "nothing left to overlap") <= 2, events
+
+
 def test_native_pencil_driver_refusals(T):
     from tlab_amd.pencil import NativePencilDns
     x, y, z = grids(32, 16, 12)

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -108,6 +109,8 @@ struct Rank {
     int r = 0, pi = 0, pk = 0;
     tlab_poisson_plan_t poisson = nullptr;
     double *hb = nullptr, *ht = nullptr, *rt = nullptr, *u_t = nullptr, *w_t = nullptr, *ta = nullptr, *tb = nullptr, *wire = nullptr;
+    // second set for the overlapped schedule (rhs_overlapped): two transposed operators are in flight at a time; tx = one more result field
+    double *rt2 = nullptr, *wire2 = nullptr, *wireb[2] = {nullptr, nullptr}, *tx = nullptr;
     double *pen[3] = {nullptr, nullptr, nullptr}, *pack[2] = {nullptr, nullptr};
     std::vector<double *> q, s, hq, hs, txc;
     bool bound = false;
@@ -127,11 +130,15 @@ struct tlab_pencil_dns {
     int flow_jmax[3] = {TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET, TLAB_DNS_BCS_DIRICHLET};
     std::vector<int> scal_jmin, scal_jmax;
     bool fresh = false;
+    bool overlap = true;              // rhs_overlapped (exchanges started ahead of independent launches) instead of the literal sequence; TLAB_PENCIL_OVERLAP=0
+    bool tracing = false;             // tlab_pencil_dns_trace: the order of exchange starts, launches and waits of the last RHS
+    std::string trace;
+    long long launches = 0;           // launches issued so far by the overlapped schedule (a wait looks whether any followed its start)
     std::vector<Rank> rk;
     ~tlab_pencil_dns() {
         for (Rank &R : rk) {
             if (R.poisson) (void)tlab_poisson_plan_destroy(R.poisson);
-            for (double *p : {R.hb, R.ht, R.rt, R.u_t, R.w_t, R.ta, R.tb, R.wire, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1]})
+            for (double *p : {R.hb, R.ht, R.rt, R.u_t, R.w_t, R.ta, R.tb, R.wire, R.pen[0], R.pen[1], R.pen[2], R.pack[0], R.pack[1], R.rt2, R.wire2, R.wireb[0], R.wireb[1], R.tx})
                 if (p) (void)hipFree(p);
         }
         if (tr.destroy && tr.ctx) tr.destroy(tr.ctx);
@@ -363,6 +370,282 @@ void rhs(D *d, double dte) {
     }
 }
 
+// ---- the same RHS with the transpositions started AHEAD of independent launches (missing 2; the reference's analogue:
+// tools/dns/rhs_global_incompressible_nbc.f90:135-382).  The exchanges of the transport run on its own stream between start and wait, so what is
+// issued on the compute stream in between overlaps them: while operator i is applied to the transposed field, the forward transposition of field
+// i + 1 and the backward transposition of result i - 1 are in flight, and the local y operators, the sums and the packing passes fill the rest.
+// Same kernels with the same arguments as rhs(): results are bit-identical (tests/test_gpu_pencil.py).
+struct TOp {                         // one operator along x (dir 1) or z (dir 3) through its transposition
+    int dir;
+    bool burg, self_vel;
+    double nu;
+    std::function<double *(Rank &)> src;
+    std::function<double *(Rank &)> dst;
+    int t_f = -1, t_b = -1;
+    long long mark_f = 0, mark_b = 0;  // d->launches when the exchange was started
+    int needs_local = -1;            // index of the launch in the local list that must have run before this operator's result is written (the sum that frees its slot)
+};
+struct LocalOp {                     // launches that touch no transposition; ready once the backward transpositions of ops <= after are complete
+    int after;                       // ... and once the local launch `needs` has run (-1: none)
+    std::function<void()> run;
+    int needs = -1;
+    bool done = false;
+};
+
+void note(D *d, const char *what, int i = -1) {
+    if (what[0] == 'l') ++d->launches;           // "launch ..."
+    if (!d->tracing) return;
+    d->trace += what;
+    if (i >= 0) d->trace += " " + std::to_string(i);
+    d->trace += "\n";
+}
+template <class FS, class FR>
+int a2a_start(D *d, int which, long long blk, FS send_of, FR recv_of) {
+    const int S = which == 1 ? d->npi : d->npk;
+    std::vector<double *> send, recv;
+    std::vector<long long> cnt((size_t)d->rk.size() * S, blk);
+    for (Rank &R : d->rk) { send.push_back(send_of(R)); recv.push_back(recv_of(R)); }
+    const int t = d->tr.alltoallv_start(d->tr.ctx, (void *)tlab_current_stream(), which, send.data(), cnt.data(), recv.data(), cnt.data());
+    tck(t, "alltoallv_start");
+    return t;
+}
+void a2a_wait(D *d, int t) { tck(d->tr.wait(d->tr.ctx, (void *)tlab_current_stream(), t), "wait"); }
+
+void run_pipeline(D *d, std::vector<TOp> &ops, std::vector<LocalOp> &local) {
+    const int m = (int)ops.size();
+    auto ta_of = [](Rank &R, int b) { return b ? R.tb : R.ta; };
+    auto rt_of = [](Rank &R, int b) { return b ? R.rt2 : R.rt; };
+    auto wf_of = [](Rank &R, int b) { return b ? R.wire2 : R.wire; };
+    auto decomposed = [&](const TOp &o) { return (o.dir == 1 ? d->npi : d->npk) > 1; };
+    auto tdst = [&](const TOp &o, Rank &R, int b) -> double * { return o.self_vel ? (o.dir == 1 ? R.u_t : R.w_t) : ta_of(R, b); };
+    std::function<bool()> fill_gap = [] { return false; };      // set below: one ready local launch, whatever the reserve policy says
+    auto f_start = [&](int i) {
+        TOp &o = ops[i];
+        if (!decomposed(o)) return;
+        const int b = i & 1;
+        if (o.dir == 1) {
+            o.t_f = a2a_start(d, 1, d->nlx * d->imax, o.src, [&](Rank &R) { return wf_of(R, b); });        // a is blocked by peer as it stands
+        } else {
+            note(d, "launch pack", i);
+            for (Rank &R : d->rk) trp_copy(o.src(R), wf_of(R, b), d->nlz, d->npk, d->kmax, 1);
+            o.t_f = a2a_start(d, 2, d->nlz * d->kmax, [&](Rank &R) { return wf_of(R, b); }, [&](Rank &R) { return tdst(o, R, b); });
+        }
+        note(d, "start forward", i);
+        o.mark_f = d->launches;
+    };
+    auto f_finish = [&](int i) {
+        TOp &o = ops[i];
+        if (!decomposed(o)) return;
+        const int b = i & 1;
+        if (d->launches == o.mark_f && !fill_gap()) note(d, "nothing left to overlap");
+        a2a_wait(d, o.t_f);
+        note(d, "wait forward", i);
+        if (o.dir == 1) for (Rank &R : d->rk) trp_copy(tdst(o, R, b), wf_of(R, b), d->imax, d->npi, d->nlx, 0);
+    };
+    auto apply = [&](int i) {
+        TOp &o = ops[i];
+        const int b = i & 1;
+        note(d, "launch operator", i);
+        if (o.needs_local >= 0 && !local[(size_t)o.needs_local].done) throw Fail(TLAB_EINVAL, "internal: pencil schedule would overwrite a term that has not been summed yet");
+        for (Rank &R : d->rk) {
+            if (!decomposed(o)) {      // not split in this direction: the operator acts on the block itself
+                if (o.burg) burgers(d, o.dir, o.self_vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, d->imax, d->ny, d->kmax, o.nu, o.src(R), R.q[o.dir - 1], o.dst(R), R.txc[8]);
+                else partial(d, o.dir, d->imax, d->ny, d->kmax, o.src(R), o.dst(R));
+                continue;
+            }
+            const double *st = tdst(o, R, b), *vel = o.dir == 1 ? R.u_t : R.w_t;
+            if (o.burg) {
+                if (o.dir == 1) burgers(d, 1, o.self_vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, d->nx, (int)d->nlx, 1, o.nu, st, vel, rt_of(R, b), R.txc[8]);
+                else burgers(d, 3, o.self_vel ? TLAB_OPR_B_SELF : TLAB_OPR_B_U_IN, (int)d->nlz, 1, d->nzt, o.nu, st, vel, rt_of(R, b), R.txc[8]);
+            } else {
+                if (o.dir == 1) partial(d, 1, d->nx, (int)d->nlx, 1, st, rt_of(R, b));
+                else partial(d, 3, (int)d->nlz, 1, d->nzt, st, rt_of(R, b));
+            }
+        }
+    };
+    auto b_start = [&](int i) {
+        TOp &o = ops[i];
+        if (!decomposed(o)) return;
+        const int b = i & 1;
+        if (o.dir == 1) {
+            note(d, "launch pack", i);
+            for (Rank &R : d->rk) trp_copy(rt_of(R, b), R.wireb[b], d->imax, d->npi, d->nlx, 1);
+            o.t_b = a2a_start(d, 1, d->nlx * d->imax, [&](Rank &R) { return R.wireb[b]; }, o.dst);
+        } else {
+            o.t_b = a2a_start(d, 2, d->nlz * d->kmax, [&](Rank &R) { return rt_of(R, b); }, [&](Rank &R) { return R.wireb[b]; });
+        }
+        note(d, "start backward", i);
+        o.mark_b = d->launches;
+    };
+    auto b_finish = [&](int i) {
+        TOp &o = ops[i];
+        if (!decomposed(o)) return;
+        const int b = i & 1;
+        if (d->launches == o.mark_b && !fill_gap()) note(d, "nothing left to overlap");
+        a2a_wait(d, o.t_b);
+        note(d, "wait backward", i);
+        if (o.dir == 3) for (Rank &R : d->rk) trp_copy(o.dst(R), R.wireb[b], d->nlz, d->npk, d->kmax, 0);
+    };
+    int finished = -1;               // backward transpositions complete up to this operator
+    auto ready = [&](const LocalOp &l) { return !l.done && l.after <= finished && (l.needs < 0 || local[(size_t)l.needs].done); };
+    auto run_one = [&](LocalOp &l) { note(d, "launch local"); l.run(); l.done = true; };
+    // one launch for a gap between a start and its wait.  Only two gaps have no operator launch of their own -- the first forward transposition and
+    // the last backward one -- so one launch that depends on nothing is held back for the end (keep_reserve)
+    auto run_local = [&](bool keep_reserve) {
+        int independent = 0;
+        for (const LocalOp &l : local) if (!l.done && l.after < 0 && l.needs < 0) ++independent;
+        for (LocalOp &l : local) {
+            if (!ready(l)) continue;
+            if (keep_reserve && l.after < 0 && l.needs < 0 && independent == 1) continue;
+            run_one(l);
+            return true;
+        }
+        return false;
+    };
+    fill_gap = [&] { return run_local(false); };
+    std::function<void(int)> force = [&](int j) {      // a launch an upcoming operator needs (the sum that frees its result slot), with what it needs itself
+        if (j < 0 || local[(size_t)j].done) return;
+        force(local[(size_t)j].needs);
+        if (local[(size_t)j].after > finished) throw Fail(TLAB_EINVAL, "internal: pencil schedule needs a sum whose terms have not arrived");
+        run_one(local[(size_t)j]);
+    };
+    std::vector<char> applied((size_t)m, 0);
+    if (m > 0) f_start(0);
+    for (int i = 0; i < m; ++i) {
+        if (i + 1 < m) {
+            f_start(i + 1);                        // the next field is on its way while this one is worked on
+            if (!decomposed(ops[i + 1])) {         // ... or, where its direction is not split, its operator is an independent launch: now
+                force(ops[i + 1].needs_local);
+                apply(i + 1);
+                applied[(size_t)i + 1] = 1;
+            }
+        }
+        if (i == 0) run_local(true);               // (the first forward transposition has no operator launch before its wait; f_finish fills the gap in any case)
+        f_finish(i);
+        if (!applied[(size_t)i]) { force(ops[i].needs_local); apply(i); }
+        b_start(i);
+        if (i > 0) { run_local(true); b_finish(i - 1); finished = i - 1; }
+    }
+    if (m > 0) {
+        b_finish(m - 1);
+        finished = m - 1;
+    }
+    for (bool any = true; any;) {                   // the rest, in dependency order
+        any = false;
+        for (LocalOp &l : local) if (ready(l)) { run_one(l); any = true; }
+    }
+    for (LocalOp &l : local) if (!l.done) throw Fail(TLAB_EINVAL, "internal: pencil schedule left a launch behind");
+}
+
+void rhs_overlapped(D *d, double dte) {
+    need_bound(d);
+    if (tlab_internal_anelastic() || tlab_internal_dealiasing())
+        throw Fail(TLAB_EUNSUPPORTED, "tlab_pencil_dns_rhs: the anelastic formulation / dealiasing filters are not built into the decomposed drivers");
+    const int nx = d->imax, ny = d->ny, kmax = d->kmax, ns = d->nscal;
+    const long long n = d->n;
+    const double nu = d->visc;
+    d->fresh = false;
+    d->trace.clear();
+    // result slots: three per equation, from three sets in rotation (the sums free a set two equations before it is written again)
+    auto slot = [](int eq, int k) { return [eq, k](Rank &R) -> double * { const int s = eq % 3; return s == 0 ? R.txc[k] : s == 1 ? R.txc[3 + k] : (k < 2 ? R.txc[6 + k] : R.tx); }; };
+    auto U = [](int i) { return [i](Rank &R) { return R.q[i]; }; };
+    std::vector<TOp> ops;
+    std::vector<LocalOp> local;
+    auto top = [&](int dir, bool self_vel, double nu_, std::function<double *(Rank &)> src, std::function<double *(Rank &)> dst) {
+        TOp o; o.dir = dir; o.burg = true; o.self_vel = self_vel; o.nu = nu_; o.src = src; o.dst = dst;
+        ops.push_back(o);
+        return (int)ops.size() - 1;
+    };
+    std::vector<int> sum_after, sum_index;      // per equation: the operator whose backward transposition completes its three terms; its sum in `local`
+    std::vector<int> y_index;
+    auto ylocal = [&](int ivel, double nu_, std::function<double *(Rank &)> s_of, std::function<double *(Rank &)> dst, int eq) {
+        // the y term of equation eq writes into the set equation eq - 3 summed from: not before that sum
+        if ((int)y_index.size() <= eq) y_index.resize(eq + 1, -1);
+        y_index[eq] = (int)local.size();
+        LocalOp l{eq >= 3 ? sum_after[eq - 3] : -1, [=]() { for (Rank &R : d->rk) burgers(d, 2, ivel, nx, ny, kmax, nu_, s_of(R), R.q[1], dst(R), R.txc[8]); }};
+        l.needs = eq >= 3 ? sum_index[eq - 3] : -1;
+        local.push_back(l);
+    };
+    // (k0, k1, k2: the order of the three terms in the reference's sum, rhs_global_incompressible_1.f90:106-112, :118-124, :130-136: the self-advection term first)
+    auto sum = [&](int after, std::function<double *(Rank &)> h_of, int eq, int k0 = 0, int k1 = 1, int k2 = 2) {
+        if ((int)sum_after.size() <= eq) { sum_after.resize(eq + 1, -1); sum_index.resize(eq + 1, -1); }
+        sum_after[eq] = after;
+        sum_index[eq] = (int)local.size();
+        LocalOp l{after, [=]() { for (Rank &R : d->rk) ok(tlab_pw_add3(h_of(R), slot(eq, k0)(R), slot(eq, k1)(R), slot(eq, k2)(R), n), "tlab_pw_add3"); }};
+        l.needs = (int)y_index.size() > eq ? y_index[eq] : -1;      // its own y term
+        local.push_back(l);
+    };
+    // equations 0, 1, 2 = u, v, w; slot 0 / 1 / 2 of an equation = its x / y / z Burgers term.  The two self-advecting transposed operators come first:
+    // they leave the transposed u and w every other operator along x / z needs (rhs_global_incompressible_1.f90:98-104)
+    const int o_xu = top(1, true, nu, U(0), slot(0, 0));                                   // :98
+    const int o_zw = top(3, true, nu, U(2), slot(2, 2));                                   // :100
+    ylocal(TLAB_OPR_B_SELF, nu, U(1), slot(1, 1), 1);                                      // :99
+    ylocal(TLAB_OPR_B_U_IN, nu, U(0), slot(0, 1), 0);                                      // :103
+    const int o_zu = top(3, false, nu, U(0), slot(0, 2));                                  // :104
+    sum(std::max(o_xu, o_zu), [](Rank &R) { return R.hq[0]; }, 0);
+    const int o_xv = top(1, false, nu, U(1), slot(1, 0));                                  // :115
+    const int o_zv = top(3, false, nu, U(1), slot(1, 2));                                  // :116
+    sum(std::max(o_xv, o_zv), [](Rank &R) { return R.hq[1]; }, 1, 1, 0, 2);                // tmp2 (y, self) + tmp7 (x) + tmp8 (z)
+    const int o_xw = top(1, false, nu, U(2), slot(2, 0));                                  // :127
+    ylocal(TLAB_OPR_B_U_IN, nu, U(2), slot(2, 1), 2);                                      // :128
+    sum(std::max(o_zw, o_xw), [](Rank &R) { return R.hq[2]; }, 2, 2, 0, 1);                // tmp3 (z, self) + tmp7 (x) + tmp8 (y)
+    for (int i = 0; i < ns; ++i) {                                                         // :149-162
+        const double kap = d->visc / d->schmidt[i];
+        auto sc = [i](Rank &R) { return R.s[i]; };
+        const int a = top(1, false, kap, sc, slot(3 + i, 0));
+        ops[a].needs_local = sum_index[i];
+        ylocal(TLAB_OPR_B_U_IN, kap, sc, slot(3 + i, 1), 3 + i);
+        const int b = top(3, false, kap, sc, slot(3 + i, 2));
+        ops[b].needs_local = sum_index[i];
+        sum(std::max(a, b), [i](Rank &R) { return R.hs[i]; }, 3 + i);
+    }
+    // (the y terms of equation k + 3 write the set of equation k: they must not run before its sum; the list order of `local` guarantees it, every
+    // sum of an earlier equation standing before the y term of a later one that reuses its set)
+    run_pipeline(d, ops, local);
+    // pressure (:188-260)
+    for (Rank &R : d->rk)
+        ok(tlab_pw_axpy3(R.txc[1], R.txc[2], R.txc[3], R.hq[1], R.hq[0], R.hq[2], R.q[1], R.q[0], R.q[2], 1.0 / dte, n), "tlab_pw_axpy3");
+    {
+        std::vector<TOp> po;
+        std::vector<LocalOp> pl;
+        TOp a; a.dir = 1; a.burg = false; a.self_vel = false; a.nu = 0.0; a.src = [](Rank &R) { return R.txc[2]; }; a.dst = [](Rank &R) { return R.txc[4]; };      // :229
+        TOp b; b.dir = 3; b.burg = false; b.self_vel = false; b.nu = 0.0; b.src = [](Rank &R) { return R.txc[3]; }; b.dst = [](Rank &R) { return R.txc[5]; };      // :230
+        po.push_back(a); po.push_back(b);
+        pl.push_back({-1, [=]() { for (Rank &R : d->rk) partial(d, 2, nx, ny, kmax, R.txc[1], R.txc[0]); }});                                                  // :228
+        pl.push_back({-1, [=]() { for (Rank &R : d->rk) ok(tlab_pw_get_wall_planes(R.hq[1], R.hb, R.ht, nx, ny, kmax), "tlab_pw_get_wall_planes"); }});
+        run_pipeline(d, po, pl);
+    }
+    for (Rank &R : d->rk) ok(tlab_pw_sum3(R.txc[0], R.txc[4], R.txc[5], n), "tlab_pw_sum3");
+    poisson(d);                                                                   // :284
+    {
+        std::vector<TOp> po;
+        std::vector<LocalOp> pl;
+        TOp a; a.dir = 1; a.burg = false; a.self_vel = false; a.nu = 0.0; a.src = [](Rank &R) { return R.txc[0]; }; a.dst = [](Rank &R) { return R.txc[1]; };      // :319
+        TOp b; b.dir = 3; b.burg = false; b.self_vel = false; b.nu = 0.0; b.src = [](Rank &R) { return R.txc[0]; }; b.dst = [](Rank &R) { return R.txc[3]; };      // :320
+        po.push_back(a); po.push_back(b);
+        // the wall conditions of the scalars (:379-396) do not involve the pressure: they fill the gaps of these two transpositions (scratch: txc[4], hb / ht
+        // are free again after the solver)
+        for (int i = 0; i < ns; ++i)
+            pl.push_back({-1, [=]() {
+                for (Rank &R : d->rk) {
+                    const int ibc = (d->scal_jmin[i] == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (d->scal_jmax[i] == TLAB_DNS_BCS_NEUMANN ? 2 : 0);
+                    if (ibc) ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, R.hs[i], R.hb, R.ht, R.txc[4]), "tlab_boundary_bcs_neumann_y");
+                    ok(tlab_pw_set_wall_planes(R.hs[i], (ibc & 1) ? R.hb : nullptr, (ibc & 2) ? R.ht : nullptr, nx, ny, kmax), "tlab_pw_set_wall_planes");
+                }
+            }});
+        run_pipeline(d, po, pl);
+    }
+    for (Rank &R : d->rk) ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
+    for (Rank &R : d->rk) {
+        auto walls = [&](double *h, int tmin, int tmax) {
+            const int ibc = (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0);
+            if (ibc) ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, h, R.hb, R.ht, R.txc[0]), "tlab_boundary_bcs_neumann_y");
+            ok(tlab_pw_set_wall_planes(h, (ibc & 1) ? R.hb : nullptr, (ibc & 2) ? R.ht : nullptr, nx, ny, kmax), "tlab_pw_set_wall_planes");
+        };
+        for (int i = 0; i < 3; ++i) walls(R.hq[i], d->flow_jmin[i], d->flow_jmax[i]);
+    }
+}
+
 template <class F>
 int guarded(F f) {
     try {
@@ -409,6 +692,7 @@ int tlab_pencil_dns_create(tlab_pencil_dns_t *out, const tlab_pencil_transport *
             throw Fail(TLAB_EUNSUPPORTED, "tlab_pencil_dns_create: the anelastic formulation / dealiasing filters are not built into the decomposed drivers");
         auto d = std::make_unique<tlab_pencil_dns>();
         d->g[0] = gx; d->g[1] = gy; d->g[2] = gz;
+        if (const char *e = getenv("TLAB_PENCIL_OVERLAP")) d->overlap = atoi(e) != 0;
         d->npi = npi; d->npk = npk; d->P = P; d->nx = nx; d->ny = ny; d->nzt = nz_total; d->imax = imax; d->kmax = kmax; d->kmax2 = kmax / npi;
         d->nxh = nx / 2 + 1; d->nscal = nscal; d->visc = visc;
         d->n = (long long)imax * ny * kmax;
@@ -427,6 +711,7 @@ int tlab_pencil_dns_create(tlab_pencil_dns_t *out, const tlab_pencil_transport *
             ok(tlab_poisson_plan_create_pencil(&R.poisson, gx, gy, gz, nx, ny, d->kmax2, nz_total, d->ioff[R.r], d->nxl[R.r]), "tlab_poisson_plan_create_pencil");
             R.hb = dalloc((size_t)imax * kmax); R.ht = dalloc((size_t)imax * kmax);
             for (double **p : {&R.rt, &R.u_t, &R.w_t, &R.ta, &R.tb, &R.wire}) *p = dalloc((size_t)d->n);
+            if (d->overlap) for (double **p : {&R.rt2, &R.wire2, &R.wireb[0], &R.wireb[1], &R.tx}) *p = dalloc((size_t)d->n);
             for (int i = 0; i < 3; ++i) R.pen[i] = dalloc((size_t)2 * d->nxl[R.r] * ny * nz_total);
             for (int i = 0; i < 2; ++i) R.pack[i] = dalloc((size_t)2 * d->nxh * ny * d->kmax2);
         }
@@ -494,17 +779,30 @@ int tlab_pencil_dns_begin_step(tlab_pencil_dns_t d) {
     });
 }
 
+// the order in which the last RHS started exchanges, issued launches and waited (one event per line): tests assert that work stands between every
+// start and its wait.  on != 0 switches the recording on (and returns the text recorded so far), 0 off.
+int tlab_pencil_dns_trace(tlab_pencil_dns_t d, int on, char *buf, int size) {
+    if (!d) return TLAB_EINVAL;
+    d->tracing = on != 0;
+    if (buf && size > 0) {
+        const size_t k = std::min((size_t)size - 1, d->trace.size());
+        std::memcpy(buf, d->trace.data(), k);
+        buf[k] = 0;
+    }
+    return TLAB_OK;
+}
+
 int tlab_pencil_dns_rhs(tlab_pencil_dns_t d, double dte) {
     return guarded([&] {
         if (!d || !(dte > 0.0)) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_rhs: bad arguments");
-        rhs(d, dte);
+        if (d->overlap) rhs_overlapped(d, dte); else rhs(d, dte);
     });
 }
 
 int tlab_pencil_dns_substep(tlab_pencil_dns_t d, double dte, double kco, int scale_tendencies) {
     return guarded([&] {
         if (!d || !(dte > 0.0)) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_substep: bad arguments");
-        rhs(d, dte);
+        if (d->overlap) rhs_overlapped(d, dte); else rhs(d, dte);
         for (Rank &R : d->rk) {      // time.f90:645-664, :272-297
             for (int i = 0; i < 3; ++i) ok(tlab_pw_rk_update(R.q[i], R.hq[i], dte, kco, scale_tendencies, d->n), "tlab_pw_rk_update");
             for (int i = 0; i < d->nscal; ++i) ok(tlab_pw_rk_update(R.s[i], R.hs[i], dte, kco, scale_tendencies, d->n), "tlab_pw_rk_update");

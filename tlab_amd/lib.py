@@ -117,6 +117,7 @@ SIGNATURES = {
     "tlab_pencil_dns_set_bcs": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "tlab_pencil_dns_begin_step": (c_int, [c_vp]),
     "tlab_pencil_dns_rhs": (c_int, [c_vp, c_dbl]),
+    "tlab_pencil_dns_trace": (c_int, [c_vp, c_int, ctypes.c_char_p, c_int]),
     "tlab_pencil_dns_substep": (c_int, [c_vp, c_dbl, c_dbl, c_int]),
     "tlab_slab_dns_rhs": (c_int, [c_vp, c_dbl]),
     "tlab_slab_dns_substep": (c_int, [c_vp, c_dbl, c_dbl, c_int]),
