@@ -719,7 +719,7 @@ void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, co
         a.periodic = d.periodic ? 1 : 0; a.ibc = d.periodic ? 0 : ibc;
         std::copy(d.rhs_b, d.rhs_b + 32, a.rb);
         std::copy(d.rhs_t, d.rhs_t + 35, a.rt);
-        auto tile = [&](const LineGeom &tg, const double *src, double *dst) {      // k_pentatile where the line length allows (32-row chunks, at most 16)
+        auto tile = [&](const LineGeom &tg, const double *src, double *dst, bool along_x = false) {      // k_pentatile where the line length allows (32-row chunks, at most 16)
             const int key = d.periodic ? 0 : ibc;
             auto &slot = g->penta_tile[key];
             if (!slot) {
@@ -734,8 +734,13 @@ void run_generic(tlab_fdm_plan_t g, const LineGeom &geom, int which, int ibc, co
             t.periodic = a.periodic; t.ibc = a.ibc;
             std::copy(d.rhs_b, d.rhs_b + 32, t.rb);
             std::copy(d.rhs_t, d.rhs_t + 35, t.rt);
-            hip_check(launch_pentatile(t, g_stream), "k_pentatile");
+            if (along_x) hip_check(launch_pentatile_x(t, g_stream), "k_pentatile<x>");
+            else hip_check(launch_pentatile(t, g_stream), "k_pentatile");
         };
+        if (geom.row_stride == 1 && pentatile_x_ok(geom)) {      // x lines of 64 .. 512 points: the tile kernel through an LDS tile, no transposes
+            tile(geom, in0, out, true);
+            return;
+        }
         if (geom.row_stride == 1 && geom.nlines >= 64) {
             // x lines: one thread per line strides through contiguous memory (64 cache lines per wave access; 243 GB/s at 256^3, measured).  Like the
             // reference (OPR_Partial_X: TLab_Transpose, solve, transpose back, opr_partial.f90:185-195) the lines are made the fastest index first:

@@ -133,6 +133,8 @@ struct PentaTileArgs {
 bool pentatile_ok(const LineGeom &g);
 void pentatile_build(int n, int C, bool periodic, int ibc, const double *lu, std::vector<double> &rows, std::vector<double> &blocks, std::vector<double> &smw);
 hipError_t launch_pentatile(const PentaTileArgs &a, hipStream_t st);
+bool pentatile_x_ok(const LineGeom &g);                                   // lines along x: 16 lines per workgroup through an LDS tile
+hipError_t launch_pentatile_x(const PentaTileArgs &a, hipStream_t st);
 
 bool xline_supported(int n);
 int rtile_chunk(int n);

@@ -248,7 +248,11 @@ void to_block(D *d, int idx) {
     trp_i_backward(d, [&](Rank &R) { return R.txc[idx]; }, [](Rank &R) { return R.tb; });
     for (Rank &R : d->rk) hk(hipMemcpyAsync(R.txc[idx], R.tb, (size_t)d->n * sizeof(double), hipMemcpyDeviceToDevice, tlab_current_stream()), "copy");
 }
+int pencil_exchange_start(D *d, bool forward, int pen_idx, int pack_idx);
 void pencil_exchange(D *d, bool forward, int pen_idx, int pack_idx) {
+    tck(d->tr.wait(d->tr.ctx, (void *)tlab_current_stream(), pencil_exchange_start(d, forward, pen_idx, pack_idx)), "wait");
+}
+int pencil_exchange_start(D *d, bool forward, int pen_idx, int pack_idx) {
     const int P = d->P;
     std::vector<double *> send, recv;
     std::vector<long long> scnt((size_t)d->rk.size() * P), rcnt((size_t)d->rk.size() * P);
@@ -264,7 +268,7 @@ void pencil_exchange(D *d, bool forward, int pen_idx, int pack_idx) {
     }
     const int t = d->tr.alltoallv_start(d->tr.ctx, (void *)tlab_current_stream(), 0, send.data(), scnt.data(), recv.data(), rcnt.data());
     tck(t, "alltoallv_start");
-    tck(d->tr.wait(d->tr.ctx, (void *)tlab_current_stream(), t), "wait");
+    return t;
 }
 void repack(D *d, Rank &R, double *slab, int pack_idx, int dir) {
     const int P = d->P;
@@ -295,10 +299,16 @@ void poisson(D *d) {
         ok(tlab_poisson_fft_z(R.poisson, -1, R.pen[2], R.pen[1]), "tlab_poisson_fft_z");
     }
     const int dst_of[2] = {0, 2};
+    // both inverse exchanges are started before the first is waited for (two pack buffers): the x transform and the I-transposition of p run under the
+    // exchange of dp/dy when the overlapped schedule is on
+    int tk[2] = {-1, -1};
+    if (d->overlap) for (int i = 0; i < 2; ++i) tk[i] = pencil_exchange_start(d, false, i, i);
     for (int i = 0; i < 2; ++i) {
-        pencil_exchange(d, false, i, 0);
+        const int pk = d->overlap ? i : 0;
+        if (d->overlap) tck(d->tr.wait(d->tr.ctx, (void *)tlab_current_stream(), tk[i]), "wait");
+        else pencil_exchange(d, false, i, 0);
         for (Rank &R : d->rk) {
-            repack(d, R, R.txc[1], 0, -1);
+            repack(d, R, R.txc[1], pk, -1);
             ok(tlab_poisson_fft_x(R.poisson, -1, R.txc[1], R.txc[dst_of[i]]), "tlab_poisson_fft_x");
         }
         to_block(d, dst_of[i]);

@@ -111,35 +111,70 @@ namespace {
 constexpr int PM = 32, PL = 32;      // rows per chunk, lines per tile
 
 // LDS: rows [9][n], blocks [2][C][C][4], periodic vectors [2][n], chunk-end values [C][2][PL] of the current sweep, four corner values [4][PL]
+// XD (lines along x, contiguous in memory): PL = 16 lines per workgroup are brought into an LDS tile [PL][n + 1] by coalesced row loads, the threads
+// pick their rows out of it (a thread owns a 32-row chunk of ONE line, so its rows are contiguous in the tile and the lines a wave holds are n + 1
+// doubles apart), and the result leaves through the same tile -- one read and one write of the field where OPR_Partial_X went through two
+// transposes around the y-direction kernel (the reference: TLab_Transpose + solve + TLab_Transpose, opr_partial.f90:185-195)
+template <int PL, bool XD>
 __global__ void __launch_bounds__(512, 1) k_pentatile(PentaTileArgs a) {
     extern __shared__ double s_pt[];
     const int n = a.g.n, C = n / PM;
-    double *s_rows = s_pt, *s_blk = s_rows + 9 * n, *s_fg = s_blk + 2 * C * C * 4, *s_end = s_fg + (a.periodic ? 2 * n : 0), *s_cor = s_end + C * 2 * PL;
+    // XD: the tables stay in global memory (read-only, the same for every workgroup: L2 / L1 hits, and the lanes of a wave ask for four addresses only) so
+    // that the LDS holds the tile and little else: two to four workgroups per CU instead of one
+    const double *s_rows = XD ? a.rows : s_pt;
+    const double *s_blk = XD ? a.blocks : s_pt + 9 * n;
+    const double *s_fg = XD ? a.smw : s_pt + 9 * n + 2 * C * C * 4;
+    double *s_end = XD ? s_pt : s_pt + 9 * n + 2 * C * C * 4 + (a.periodic ? 2 * n : 0), *s_cor = s_end + C * 2 * PL;
+    double *s_tile = s_cor + 4 * PL;      // XD: [PL][n + 1]
     const int l32 = threadIdx.x & (PL - 1), c = threadIdx.x / PL;
-    const long long rs = a.g.row_stride;
-    for (int i = threadIdx.x; i < 9 * n; i += blockDim.x) s_rows[i] = a.rows[i];
-    for (int i = threadIdx.x; i < 2 * C * C * 4; i += blockDim.x) s_blk[i] = a.blocks[i];
-    if (a.periodic)
-        for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) s_fg[i] = a.smw[i];
+    const long long rs = XD ? 1 : a.g.row_stride;
+    if constexpr (!XD) {
+        double *w = s_pt;
+        for (int i = threadIdx.x; i < 9 * n; i += blockDim.x) w[i] = a.rows[i];
+        for (int i = threadIdx.x; i < 2 * C * C * 4; i += blockDim.x) w[9 * n + i] = a.blocks[i];
+        if (a.periodic)
+            for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) w[9 * n + 2 * C * C * 4 + i] = a.smw[i];
+    }
     const int tiles_inner = (a.g.lines_inner + PL - 1) / PL;
     const long long outer = blockIdx.x / tiles_inner;
     const int l0 = (int)(blockIdx.x % tiles_inner) * PL;
     const bool valid = (l0 + l32) < a.g.lines_inner;
-    const long long base = outer * a.g.outer_stride + l0 + (valid ? l32 : 0);
+    long long base = outer * a.g.outer_stride + l0 + (valid ? l32 : 0);
     const int row0 = c * PM;
     const bool per = a.periodic != 0;
+    const double *src = a.in0;
+    if constexpr (XD) {      // the tile's lines are lines [blockIdx.x PL, + PL) of nlines; line L starts at L n
+        const long long line0 = (long long)blockIdx.x * PL;
+        const int nl = (int)((a.g.nlines - line0 < PL) ? a.g.nlines - line0 : PL);
+        const double2 *g2 = reinterpret_cast<const double2 *>(a.in0 + line0 * n);
+        const int tot = nl * (n / 2), bd = (int)blockDim.x;      // 16 B per lane along the lines, four requests in flight per lane
+        for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * bd) {
+            double2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = i0 + q * bd; v[q] = i < tot ? g2[i] : make_double2(0.0, 0.0); }      // (the lines of a tile are contiguous: g2[ln n/2 + r2] = g2[i])
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * bd;
+                if (i < tot) { const int ln = i / (n / 2), r2 = i - ln * (n / 2); s_tile[ln * (n + 1) + 2 * r2] = v[q].x; s_tile[ln * (n + 1) + 2 * r2 + 1] = v[q].y; }
+            }
+        }
+        __syncthreads();
+        src = s_tile;
+        base = (long long)(l32 < nl ? l32 : 0) * (n + 1);
+    }
+    const bool valid_x = XD ? ((long long)blockIdx.x * PL + l32 < a.g.nlines) : valid;
     // ---- operand rows + three rows on either side ----
     double e[PM + 6];
 #pragma unroll
-    for (int p = 0; p < PM; ++p) e[p + 3] = a.in0[base + (long long)(row0 + p) * rs];
+    for (int p = 0; p < PM; ++p) e[p + 3] = src[base + (long long)(row0 + p) * rs];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int rl = row0 - 3 + k, rr = row0 + PM + k;
         const bool okl = per || rl >= 0, okr = per || rr < n;
         if (rl < 0) rl += n;
         if (rr >= n) rr -= n;
-        e[k] = okl ? a.in0[base + (long long)rl * rs] : 0.0;
-        e[PM + 3 + k] = okr ? a.in0[base + (long long)rr * rs] : 0.0;
+        e[k] = okl ? src[base + (long long)rl * rs] : 0.0;
+        e[PM + 3 + k] = okr ? src[base + (long long)rr * rs] : 0.0;
     }
     // ---- MatMul_7d_antisym ----
     const double r6 = a.r6, r7 = a.r7;
@@ -248,7 +283,21 @@ __global__ void __launch_bounds__(512, 1) k_pentatile(PentaTileArgs a) {
 #pragma unroll
         for (int p = 0; p < PM; ++p) f[p] = f[p] - dummy1 * Fv[p] - dummy2 * Gv[p];
     }
-    if (valid) {
+    if constexpr (XD) {
+        // (every thread read its operand rows from the tile before the first barrier after the right-hand side: the tile is free)
+        if (valid_x) {
+#pragma unroll
+            for (int p = 0; p < PM; ++p) s_tile[base + row0 + p] = f[p];
+        }
+        __syncthreads();
+        const long long line0 = (long long)blockIdx.x * PL;
+        const int nl = (int)((a.g.nlines - line0 < PL) ? a.g.nlines - line0 : PL);
+        double2 *o2 = reinterpret_cast<double2 *>(a.out0 + line0 * n);
+        for (int i = threadIdx.x; i < nl * (n / 2); i += blockDim.x) {
+            const int ln = i / (n / 2), r2 = i - ln * (n / 2);
+            o2[i] = make_double2(s_tile[ln * (n + 1) + 2 * r2], s_tile[ln * (n + 1) + 2 * r2 + 1]);
+        }
+    } else if (valid) {
 #pragma unroll
         for (int p = 0; p < PM; ++p) a.out0[base + (long long)(row0 + p) * rs] = f[p];
     }
@@ -269,13 +318,43 @@ hipError_t launch_pentatile(const PentaTileArgs &a, hipStream_t st) {
     const size_t lds = ((size_t)9 * n + (size_t)2 * C * C * 4 + (a.periodic ? (size_t)2 * n : 0) + (size_t)C * 2 * PL + 4 * PL) * sizeof(double);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pentatile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pentatile<PL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         attr = true;
     }
     ProfScope ps("k_pentatile", st, (double)a.g.nlines * n * 16.0);
-    hipLaunchKernelGGL(k_pentatile, dim3((unsigned)tiles), dim3(PL * C), lds, st, a);
+    hipLaunchKernelGGL((k_pentatile<PL, false>), dim3((unsigned)tiles), dim3(PL * C), lds, st, a);
     return hipGetLastError();
+}
+
+// lines along x (row_stride == 1): 16 lines per workgroup through an LDS tile
+constexpr int PLX = 16;
+bool pentatile_x_ok(const LineGeom &g) {
+    static const bool off = [] { const char *e = getenv("TLAB_PENTA_TILE_X"); return e && atoi(e) == 0; }();
+    const int C = g.n / PM;
+    const size_t lds = ((size_t)C * 2 * PLX + 4 * PLX + (size_t)PLX * (g.n + 1)) * sizeof(double);
+    return !off && g.n % PM == 0 && g.n % 2 == 0 && C >= 2 && C <= 16 && g.row_stride == 1 && lds <= (size_t)160 * 1024;
+}
+template <int L>
+static hipError_t launch_pentatile_x_l(const PentaTileArgs &a, hipStream_t st) {
+    const int n = a.g.n, C = n / PM;
+    const long long tiles = (a.g.nlines + L - 1) / L;
+    const size_t lds = ((size_t)C * 2 * L + 4 * L + (size_t)L * (n + 1)) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pentatile<L, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr = true;
+    }
+    ProfScope ps("k_pentatile<x>", st, (double)a.g.nlines * n * 16.0);
+    hipLaunchKernelGGL((k_pentatile<L, true>), dim3((unsigned)tiles), dim3(L * C), lds, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_pentatile_x(const PentaTileArgs &a, hipStream_t st) {
+    static const int plx = [] { const char *e = getenv("TLAB_PENTA_PLX"); return e ? atoi(e) : PLX; }();      // lines per workgroup (experiments: 8, 16, 32)
+    if (plx == 8) return launch_pentatile_x_l<8>(a, st);
+    if (plx == 32 && a.g.n <= 256) return launch_pentatile_x_l<32>(a, st);
+    return launch_pentatile_x_l<PLX>(a, st);
 }
 
 }  // namespace tlab
