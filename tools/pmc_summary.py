@@ -106,8 +106,50 @@ def pmc(dfetch, dwrite, tjson=None, commit=None):
         json.dump(doc, open(tjson, "w"), indent=1)
 
 
+def clock(d, cname="GRBM_GUI_ACTIVE", kernels=("k_xline<BURGERS>", "k_htile<BURGERS>", "k_ptile<BURGERS>", "k_ode_nn", "k_fftz")):
+    """cycles per nanosecond of every launch of the named kernels over the course of ONE long bench run (one --pmc pass with the kernel trace): does the
+    clock fall under sustained load?  Prints, per kernel, launches, duration and counter / duration for the first and the last
+    quarter of the run and in between."""
+    disp = {}
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            did = r.get("Dispatch_Id") or r.get("Dispatch_ID") or r.get("dispatch_id")
+            t0 = float(r.get("Start_Timestamp") or r.get("Start_Time") or 0.0)
+            t1 = float(r.get("End_Timestamp") or r.get("End_Time") or 0.0)
+            disp[did] = (r.get("Kernel_Name", ""), t0, t1)
+    per = defaultdict(list)
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != cname:
+                continue
+            did = r.get("Dispatch_Id") or r.get("Dispatch_ID") or r.get("dispatch_id")
+            if did not in disp:
+                continue
+            name, t0, t1 = disp[did]
+            t = tag(name)
+            if t in kernels and t1 > t0:
+                per[t].append((t0, t1 - t0, float(r["Counter_Value"])))
+    print("# %s / duration per launch (counter units per ns; the absolute scale depends on how many instances of the counter the profiler sums -- the CHANGE "
+          "over the run is what is read); one bench.py run under rocprofv3 --kernel-trace --pmc %s" % (cname, cname))
+    print("%-22s %8s | %-34s | %-34s | %-34s" % ("kernel", "launches", "first quarter: ms, counter/ns", "middle half", "last quarter"))
+    for t in kernels:
+        v = sorted(per.get(t, []))
+        if len(v) < 8:
+            continue
+        q = len(v) // 4
+        parts = (v[:q], v[q:len(v) - q], v[len(v) - q:])
+        cells = []
+        for pt in parts:
+            ms = sum(x[1] for x in pt) / len(pt) * 1e-6
+            cl = sum(x[2] for x in pt) / sum(x[1] for x in pt)
+            cells.append("%.4f ms  %10.4f" % (ms, cl))
+        print("%-22s %8d | %-34s | %-34s | %-34s" % (t, len(v), cells[0], cells[1], cells[2]))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 3 and sys.argv[1] == "stats":
+    if len(sys.argv) >= 3 and sys.argv[1] == "clock":
+        clock(sys.argv[2], *(sys.argv[3:4]))
+    elif len(sys.argv) >= 3 and sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, sys.argv[5] if len(sys.argv) > 5 else None)

@@ -5,7 +5,7 @@
 # then copy gpurun_out/<round>/{*.csv,*.txt,*.json} to profiles/<round>/ and gpurun_out/<round>/traffic.json to profiles/traffic.json.
 # rocprofv3 rules of this pool: the program itself after `--` (no env / bash -c hops), --pmc passes separate from --stats, counters one per pass.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 COMMIT=${2:-unknown}
 ROOT=$(pwd)
 O=$ROOT/gpurun_out/$R
@@ -21,6 +21,11 @@ python3 "$ROOT/tools/pmc_summary.py" stats "$O/raw_stats" > "$O/rocprofv3_kernel
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/raw_fetch" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/raw_write" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_write.err"
 python3 "$ROOT/tools/pmc_summary.py" pmc "$O/raw_fetch" "$O/raw_write" "$O/traffic.json" "$COMMIT" > "$O/pmc_hbm_traffic_summary.txt"
+# 2b. the clock over a long run ("k_xline slows 5 % under sustained load -- clocks, presumably"): one counter pass of 150 substeps
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$O/raw_clock" -- python3 "$B" --steps 150 --warmup 3 --cpu-sample 0 --no-freeslip-leg > "$O/bench_under_clock_pass.json" 2> "$O/rocprof_clock.err"
+python3 "$ROOT/tools/pmc_summary.py" clock "$O/raw_clock" > "$O/clock_probe.txt" 2>> "$O/rocprof_clock.err"
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES --output-format csv -d "$O/raw_clock2" -- python3 "$B" --steps 150 --warmup 3 --cpu-sample 0 --no-freeslip-leg > /dev/null 2>> "$O/rocprof_clock.err"
+python3 "$ROOT/tools/pmc_summary.py" clock "$O/raw_clock2" SQ_BUSY_CYCLES >> "$O/clock_probe.txt" 2>> "$O/rocprof_clock.err"
 # (third argument "quick": the bench line, its kernel trace and the traffic file only -- after a change that leaves the other lines as they are)
 if [ "${3:-}" = "quick" ]; then rm -rf "$O"/raw_*; ls -la "$O"; exit 0; fi
 # 3. the north-star's own kernels stand-alone: OPR_Partial_{X,Y,Z}(OPR_P1) at 512^3, kernel trace + the same two counter passes
@@ -52,6 +57,9 @@ env $OFF python3 "$B" --grid 2048 1024 256 --nscal 3 --steps 6 --warmup 2 $Q > "
 env $OFF python3 "$B" --grid 1024 512 1024 --steps 6 --warmup 2 $Q > "$O/bench_configs3_one_device_long_line_routes_off.json" 2> /dev/null
 TLAB_XLINE_LINE_BARRIERS=0 python3 "$ROOT/tools/bench_xlines.py" 2> /dev/null | grep grid > "$O/xlines_workgroup_barriers.jsonl"
 TLAB_PROFILE_REPORT=1 python3 "$ROOT/tools/bench_poisson.py" > "$O/poisson_standalone.txt" 2>&1
+TLAB_XLINE_OCC=1 python3 "$B" --steps 20 --warmup 5 $Q > "$O/bench_xline_one_wave_per_simd.json" 2> /dev/null
+TLAB_PENCIL_OVERLAP=0 python3 "$B" --decomp 2x4 --slab-driver native --steps 6 --warmup 2 $Q > "$O/bench_decomp2x4_native_literal_sequence.json" 2> /dev/null
+"$ROOT/tools/mall_probe" > "$O/mall_probe.jsonl" 2> /dev/null
 python3 "$ROOT/tools/bench_xlines.py" 2> /dev/null | grep grid > "$O/xlines.jsonl"
 python3 "$ROOT/tools/bench_xlines.py" --exact-uniform --grids 2048x1024x64 2> /dev/null | grep grid > "$O/xlines_equal_rows_2048.jsonl"
 # the raw rocprofv3 trees are large: only the summaries travel back
