@@ -158,6 +158,28 @@ program test_dropin
     call TLab_AMD_Check(tlab_memcpy_d2h(c_loc(r_gpu), p_r, int(n, c_size_t)*8_c_size_t), 'd2h')
     err = maxval(abs(r_gpu - dphidy))/maxval(abs(dphidy)); worst = max(worst, err)
     print '(a,es10.3)', 'OPR_Poisson (direct, BCS_DD) dp/dy rel-err vs d(phi)/dy of the CPU operators ', err
+    ! ---- the SAME fdm_dt object built anew in place on another y grid (uniform nodes, where it was tanh-stretched): the drop-in must notice (its plan
+    ! cache is keyed by the object's address AND a fingerprint of its tables) and serve the new tables, not the device plan of the old ones ----
+    gr(2)%nodes = [(real(i - 1, wp)/real(ny - 1, wp), i=1, ny)]
+    gr(2)%scale = gr(2)%nodes(ny) - gr(2)%nodes(1)
+    if (allocated(g(2)%nodes)) deallocate (g(2)%nodes)
+    if (allocated(g(2)%jac)) deallocate (g(2)%jac)
+    if (allocated(g(2)%der1%lhs)) deallocate (g(2)%der1%lhs)
+    if (allocated(g(2)%der1%rhs)) deallocate (g(2)%der1%rhs)
+    if (allocated(g(2)%der1%lu)) deallocate (g(2)%der1%lu)
+    if (allocated(g(2)%der1%mwn)) deallocate (g(2)%der1%mwn)
+    if (allocated(g(2)%der2%lhs)) deallocate (g(2)%der2%lhs)
+    if (allocated(g(2)%der2%rhs)) deallocate (g(2)%der2%rhs)
+    if (allocated(g(2)%der2%lu)) deallocate (g(2)%der2%lu)
+    if (allocated(g(2)%der2%mwn)) deallocate (g(2)%der2%mwn)
+    g(2)%uniform = .true.
+    call FDM_CreatePlan(gr(2), g(2))
+    call TLab_AMD_Check(tlab_memcpy_h2d(p_u, c_loc(u), int(n, c_size_t)*8_c_size_t), 'h2d')
+    call CPU_Partial_Y(OPR_P2_P1, nx, ny, nz, bcs, g(2), u, r_cpu, t_cpu)
+    call GPU_Partial_Y(OPR_P2_P1, nx, ny, nz, bcs, g(2), d_u, d_r, d_t)
+    call TLab_AMD_Check(tlab_memcpy_d2h(c_loc(r_gpu), p_t, int(n, c_size_t)*8_c_size_t), 'd2h')
+    err = maxval(abs(r_gpu - t_cpu))/maxval(abs(t_cpu)); worst = max(worst, err)
+    print '(a,es10.3)', 'OPR_Partial_Y after FDM_CreatePlan on the same object, other grid: first derivative rel-err ', err
     print '(a,es10.3)', 'worst ', worst
     if (worst > 1.0e-11_wp) error stop 1
     print '(a)', 'dropin ok'
