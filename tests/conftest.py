@@ -115,9 +115,12 @@ def pytest_sessionfinish(session, exitstatus):
                "rows_above_1e-12_without_a_reference_made_figure": [r["test"] for r in table if (not r["within_1e-12"] or r["max_bound"] > 1e-12) and r["ref_build_diff"] is None
                                                                    and "difference between the reference" not in r["yardstick"]],
                "rows": table}
+        # a run of part of the suite must not replace the table of a whole one
+        fname = "parity_table.json" if getattr(session, "testscollected", 0) >= 300 else "parity_table_partial_run.json"
+        doc["tests_in_session"] = int(getattr(session, "testscollected", 0))
         for d in (os.path.join(ROOT, "profiles", PARITY_ROUND), os.path.join(ROOT, "gpurun_out", PARITY_ROUND)):
             os.makedirs(d, exist_ok=True)
-            with open(os.path.join(d, "parity_table.json"), "w") as f:
+            with open(os.path.join(d, fname), "w") as f:
                 json.dump(doc, f, indent=1)
     except Exception as e:       # noqa: BLE001  (bookkeeping must never fail a test session)
         print("parity table not written:", e)
