@@ -527,7 +527,11 @@ int tlab_transpose(const double *a, int nra, int nca, double *b);
 int tlab_last_kernel_path(void);
 /* force a kernel family (0 = automatic). */
 int tlab_force_kernel_path(int path);
-/* tuning knobs for experiments: key 1 = rows per wave of the register-tile kernel (16 | 32 | 64, 0 = automatic). */
+/* tuning knobs for experiments and tests: key 1 = rows per wave of the register-tile kernel (16 | 32 | 64, 0 = automatic); 2 = policy of the half-wave
+ * tile kernel (1 off, 2 forced, 0 automatic); 3 = lines per tile of the fused Burgers tiles (16 | 32); 4 = number of persistent workgroups of k_ptile
+ * (0 = one per CU, rounded down to a multiple of 8; tests force counts that are not).  Environment switches read once per process (A/B runs):
+ * TLAB_XLINE_OCC (1 = the one-wave-per-SIMD form of the fused x-Burgers kernel at 512 points), TLAB_PENCIL_OVERLAP (0 = literal operator sequence of the
+ * pencil driver), TLAB_PENTA_TILE_X (0 = pentadiagonal x derivative through two transposes); the others are listed where they are read (csrc/). */
 int tlab_set_tuning(int key, int value);
 
 /* Live kernel timing (HIP events on the library's stream around every kernel launch) for bench.py's roofline object.
