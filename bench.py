@@ -110,6 +110,40 @@ def cpu_baseline(n, nscal, budget_s=25.0):
                       % (nsub, n, nscal, threads, model, ncpu, cpu_quota()[0], cpu_quota()[1], dt, t_init)}
 
 
+def cpu_baseline_reference(n, nscal):
+    """Substeps of oracle/tlab_ref_rhs.py::RefComposedDns (the reference's compiled routines, oracle/_ref/libtlab_ref.so) on an n^3 box, one core, in a
+    child process (the library keeps one grid per process and this process may have loaded it for another)."""
+    import subprocess
+    lib = os.path.join(ROOT, "oracle", "_ref", "libtlab_ref.so")
+    if not os.path.exists(lib):
+        return {"error": "oracle/_ref/libtlab_ref.so not built (make -C oracle REF=/root/reference)"}
+    code = (
+        "import sys, time, json\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from oracle.tlab_ref_rhs import RefComposedDns\n"
+        "n, ns = %d, %d\n"
+        "x = np.arange(n) / n; y = np.arange(n) / (n - 1.0)\n"
+        "o = RefComposedDns(x, y, x.copy(), nscal=ns, visc=1.0 / 5000.0, schmidt=(1.0,) * ns, yuniform=True)\n"
+        "rng = np.random.default_rng(20250509)\n"
+        "for i in range(3): o.q[i] = rng.uniform(-1, 1, n ** 3) * 0.1\n"
+        "for i in range(ns): o.s[i] = rng.uniform(-1, 1, n ** 3)\n"
+        "o.time_substep(1e-3, 1.0, False)\n"
+        "t0 = time.time(); k = 0\n"
+        "while k < 2 or (time.time() - t0 < 8.0 and k < 6):\n"
+        "    o.time_substep(1e-3, 1.0, False); k += 1\n"
+        "print('RESULT ' + json.dumps({'nsub': k, 'seconds': time.time() - t0}))\n" % (ROOT, n, nscal))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    if r.returncode != 0 or not line:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    res = json.loads(line[0][7:])
+    return {"value": res["nsub"] * n ** 3 / res["seconds"], "unit": "grid-point-updates/s per RK substep", "cores": 1, "kind": "reference",
+            "sample": "%d RK substeps of the reference's own compiled routines (oracle/_ref: FDM_Der1/2_Solve, the Burgers composition, FDM_Int1 + OPR_ODE2_Factorize_NN "
+                      "per mode, serial amdflang -O2 build) composed by oracle/tlab_ref_rhs.py on a %d^3 box, %d scalar(s), %.1f s; Fourier transforms and the "
+                      "loop over the modes in numpy / Python (the reference's FFTW is not in the image)" % (res["nsub"], n, nscal, res["seconds"])}
+
+
 def cpu_quota():
     """CPUs this process may use at once: the cgroup's CPU bandwidth quota (cpu.max = quota period; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us) if
     there is one, else the affinity mask.  On the GPU boxes of this pool 256 logical CPUs are visible and 16 are granted."""
@@ -676,6 +710,14 @@ def main():
                     out["cpu_baseline"] = large
                 else:
                     out["cpu_baseline_large"] = large
+        if "cpu_baseline" in out:
+            # ... and the reference's OWN compiled routines composed into the same substep (oracle/tlab_ref_rhs.py: every derivative, Burgers operator and
+            # per-mode solve is the reference's Fortran built from /root/reference by oracle/Makefile; FFTW is not in the image, so the transforms and the
+            # loop over the Fourier modes are numpy / Python), serial, on a 128^3 sample: kind "reference" next to the parallel "port" above
+            try:
+                out["cpu_baseline_reference"] = cpu_baseline_reference(128, args.nscal)
+            except Exception as e:       # noqa: BLE001
+                out["cpu_baseline_reference"] = {"error": repr(e)}
         print(json.dumps(out))
     # the native slab driver owns an RCCL communicator of its own: release it while every rank is still here, not during interpreter teardown
     try:
