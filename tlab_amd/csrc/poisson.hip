@@ -132,16 +132,59 @@ __device__ __forceinline__ void load_f(const Int1Args &a, int j, long long t, lo
 // One FDM_Int1_Solve per thread (mode).  BC = 1: value given at the bottom (BCS_MIN), BC = 2: at the top (BCS_MAX).
 // SPLIT (with NL = 1): the two lines of a mode (real and imaginary part) on two threads, thread gid -> (mode gid % nm, line gid / nm).  The few
 // modes of the low-mode sub-plan are a latency chain of n dependent rows bound by the instructions per row: half of them per thread.
-template <int BC, int NL, int FS, int U, bool STORED, bool SPLIT = false>
+// LDSV (with SPLIT): the few lines of the low-mode sub-plan are a chain of 2 n dependent rows whose every block of U rows waited for a round trip to
+// memory -- 0.7 + 0.3 ms per substep at 512 rows beside a k_ode_nn that keeps the memory system busy, and on z-slabs / kx-pencils the critical path of
+// the ranks that own the low kx.  Here a workgroup stages what its LV1 = 4 (2 from 1024 rows on) lines read in a sweep (source and forward factors, then
+// the backward factors; the two right-hand-side coefficients) in LDS with all its threads, four lanes run the same recurrences on LDS operands (same
+// expressions, same order: the results are the marching kernel's to the bit), and the intermediate of the forward sweep stays in LDS.
+template <int BC, int NL, int FS, int U, bool STORED, bool SPLIT = false, bool LDSV = false, int LV1 = 4>
 __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma clang fp contract(off)
     static_assert(!SPLIT || (NL == 1 && STORED), "SPLIT: one line per thread, stored factors");
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (SPLIT ? 2 : 1) * a.nm) return;
-    const long long t = SPLIT ? gid % a.nm : gid;
-    const int part = SPLIT ? (int)(gid / a.nm) : 0;
+    static_assert(!LDSV || (SPLIT && FS != FS_UNIT), "LDSV: the low-mode form");
+    extern __shared__ double s_i1[];
     const int n = a.T.n;
     const long long nm = a.nm;
+    // LDS per line: four rows of n doubles -- forward sweep: source, a, b (forward factors), intermediate out; backward sweep: 1/c, -d, -e, intermediate
+    // (16 KiB per line at 512 rows: a workgroup of four lines fits beside ONE workgroup of k_ode_nn on a CU, so it is scheduled while that kernel runs)
+    double *s_b = s_i1, *s_R = s_b + LV1 * 4 * n;      // [LV1][4][n], [n][2]
+    auto stage = [&](bool forward) {
+        for (int idx = threadIdx.x; idx < LV1 * n; idx += blockDim.x) {
+            const int k = idx / n, j = idx - k * n;
+            const long long g = (long long)blockIdx.x * LV1 + k;
+            if (g >= 2 * nm) continue;
+            const long long tk = g % nm;
+            const int pk = (int)(g / nm);
+            if (forward) {
+                double fv;
+                if (FS == FS_FIELD) {
+                    const long long f0 = (tk % a.nxh) + (long long)a.nxh * a.ny * (tk / a.nxh);
+                    fv = a.fsrc[2 * (f0 + (long long)j * a.nxh) + pk];
+                } else {
+                    fv = (pk < a.nlf) ? a.fsrc[((long long)pk * n + j) * nm + tk] : 0.0;      // (line pk of the stored lines; lines >= nlf are zero)
+                }
+                s_b[(k * 4 + 0) * n + j] = fv;
+                s_b[(k * 4 + 1) * n + j] = a.fac[((long long)0 * n + j) * nm + tk];
+                s_b[(k * 4 + 2) * n + j] = a.fac[((long long)1 * n + j) * nm + tk];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) s_b[(k * 4 + q) * n + j] = a.fac[((long long)(2 + q) * n + j) * nm + tk];
+            }
+        }
+    };
+    bool active = true;      // LDSV: lanes beyond the workgroup's lines (and beyond the last line) repeat the work of its first line and store nothing: every
+                             // thread reaches the barriers between the sweeps
+    if constexpr (LDSV) {
+        stage(true);
+        for (int idx = threadIdx.x; idx < n; idx += blockDim.x) { s_R[idx * 2] = a.T.R[idx * 3]; s_R[idx * 2 + 1] = a.T.R[idx * 3 + 1]; }
+        __syncthreads();
+        active = threadIdx.x < LV1 && (long long)blockIdx.x * LV1 + threadIdx.x < 2 * nm;
+    }
+    const int myk = (LDSV && active) ? (int)threadIdx.x : 0;
+    const long long gid = LDSV ? (long long)blockIdx.x * LV1 + myk : (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!LDSV && gid >= (SPLIT ? 2 : 1) * a.nm) return;
+    const long long t = SPLIT ? gid % a.nm : gid;
+    const int part = SPLIT ? (int)(gid / a.nm) : 0;
     if (SPLIT && part) {      // line 1 of every array becomes this thread's line 0
         a.scratch += (long long)n * nm;
         a.dst += (long long)n * nm;
@@ -153,6 +196,14 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     }
     const double lam = a.lam_sign * a.lam[t];
     const long long fidx0 = (FS == FS_FIELD) ? (t % a.nxh) + (long long)a.nxh * a.ny * (t / a.nxh) : 0;
+    auto ldf = [&](int j, double (&f)[NL]) {      // row j of the source: from LDS (LDSV: the staged raw value, scaled / masked as load_f does) or from memory
+        if constexpr (LDSV) {
+            if (FS == FS_FIELD) f[0] = s_b[(myk * 4 + 0) * n + j] * a.fscale;
+            else f[0] = (0 < a.nlf) ? s_b[(myk * 4 + 0) * n + j] : 0.0;
+        } else {
+            load_f<NL, FS>(a, j, t, fidx0, f);
+        }
+    };
 
     // ---- boundary rows of the system of this mode (fdm_integral.f90:203-211 -> FDM_Bcs_Reduce at the opposite end) ----
     double l0[5], l1[5], l2[5], lN[5], lN1[5], lN2[5], rb[3][4], rt[3][4];
@@ -202,12 +253,14 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 
     // ---- boundary values: res0 (row 0) and resN (row n-1) as MatMul_3d sees them (fdm_integral.f90:240-245) ----
     double fb0[NL], fbN[NL], res0[NL], resN[NL];
-    load_f<NL, FS>(a, 0, t, fidx0, fb0);
-    load_f<NL, FS>(a, n - 1, t, fidx0, fbN);
+    ldf(0, fb0);
+    ldf(n - 1, fbN);
     if (FS == FS_FIELD && a.bcs_save != nullptr) {  // Neumann data travel in the forcing planes (opr_elliptic.f90:285-286,310-311)
         if (SPLIT) {
-            a.bcs_save[(long long)part * nm + t] = fb0[0];
-            a.bcs_save[(long long)(2 + part) * nm + t] = fbN[0];
+            if (active) {
+                a.bcs_save[(long long)part * nm + t] = fb0[0];
+                a.bcs_save[(long long)(2 + part) * nm + t] = fbN[0];
+            }
         } else {
             a.bcs_save[0 * nm + t] = fb0[0]; a.bcs_save[1 * nm + t] = fb0[NL > 1 ? 1 : 0];
             a.bcs_save[2 * nm + t] = fbN[0]; a.bcs_save[3 * nm + t] = fbN[NL > 1 ? 1 : 0];
@@ -222,8 +275,8 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 
     // ---- forward: right-hand side (MatMul_3d, BCS_BOTH), LU on the fly (PENTADFS), forward substitution (PENTADSS) ----
     double fm[NL], fc[NL], fp[NL];           // f[j-1], f[j], f[j+1]
-    load_f<NL, FS>(a, 1, t, fidx0, fc);
-    load_f<NL, FS>(a, 2, t, fidx0, fp);
+    ldf(1, fc);
+    ldf(2, fp);
     double f1[NL], fn2[NL];                   // f[1] and f[n-2] are needed again for du
     double bcs_b[NL], bcs_t[NL];
 #pragma unroll
@@ -248,12 +301,13 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jc = (jb + u <= nmax) ? jb + u : nmax;
-            Rb[u][0] = a.T.R[jc * 3 + 0]; Rb[u][1] = a.T.R[jc * 3 + 1];
+            if constexpr (LDSV) { Rb[u][0] = s_R[jc * 2 + 0]; Rb[u][1] = s_R[jc * 2 + 1]; }
+            else { Rb[u][0] = a.T.R[jc * 3 + 0]; Rb[u][1] = a.T.R[jc * 3 + 1]; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jr = jb + u + 2;
-            if (jr <= n - 1) load_f<NL, FS>(a, jr, t, fidx0, fqb[u]);
+            if (jr <= n - 1) ldf(jr, fqb[u]);
             else {
 #pragma unroll
                 for (int l = 0; l < NL; ++l) fqb[u][l] = 0.0;
@@ -261,8 +315,11 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
             fab[u][0] = fab[u][1] = 0.0;
             if (stored) {
                 const int jf = (jb + u <= nmax) ? jb + u : nmax;
-                fab[u][0] = a.fac[((long long)0 * n + jf) * nm + t];
-                fab[u][1] = a.fac[((long long)1 * n + jf) * nm + t];
+                if constexpr (LDSV) { fab[u][0] = s_b[(myk * 4 + 1) * n + jf]; fab[u][1] = s_b[(myk * 4 + 2) * n + jf]; }
+                else {
+                    fab[u][0] = a.fac[((long long)0 * n + jf) * nm + t];
+                    fab[u][1] = a.fac[((long long)1 * n + jf) * nm + t];
+                }
             }
         }
         // A block without one of the boundary rows 1, 2, n-3, n-2 (all but the first and the last one or two) takes the plain form of every
@@ -319,7 +376,8 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const double y = rhs[l] - y1[l] * bm - y2[l] * am;
-                a.scratch[((long long)l * n + j) * nm + t] = y;
+                if constexpr (LDSV) s_b[(myk * 4 + 3) * n + j] = y;      // (the lanes that repeat line 0 write the same value)
+                else a.scratch[((long long)l * n + j) * nm + t] = y;
                 y2[l] = y1[l];
                 y1[l] = y;
             }
@@ -347,6 +405,11 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
         }
     }
 
+    if constexpr (LDSV) {      // the backward factors take the place of the source and the forward factors
+        __syncthreads();
+        stage(false);
+        __syncthreads();
+    }
     // ---- backward substitution ----
     double x1[NL], x2[NL];                    // x[j+1], x[j+2]
     double xs1[NL], xs2[NL], xs3[NL];         // x[1], x[2], x[3]
@@ -360,11 +423,16 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
         for (int u = 0; u < U; ++u) {
             const int j = jb - u;
             const int jr = j >= 1 ? j : 1;
-            cb[u] = fsrc[((long long)0 * n + jr) * nm + t];
-            db[u] = fsrc[((long long)1 * n + jr) * nm + t];
-            eb[u] = fsrc[((long long)2 * n + jr) * nm + t];
+            if constexpr (LDSV) {
+                cb[u] = s_b[(myk * 4 + 0) * n + jr]; db[u] = s_b[(myk * 4 + 1) * n + jr]; eb[u] = s_b[(myk * 4 + 2) * n + jr];
+                yb[u][0] = s_b[(myk * 4 + 3) * n + jr];
+            } else {
+                cb[u] = fsrc[((long long)0 * n + jr) * nm + t];
+                db[u] = fsrc[((long long)1 * n + jr) * nm + t];
+                eb[u] = fsrc[((long long)2 * n + jr) * nm + t];
 #pragma unroll
-            for (int l = 0; l < NL; ++l) yb[u][l] = a.scratch[((long long)l * n + jr) * nm + t];
+                for (int l = 0; l < NL; ++l) yb[u][l] = a.scratch[((long long)l * n + jr) * nm + t];
+            }
         }
         const bool edge_blk = jb > n - 5 || jb - U + 1 < 4;       // holds one of the rows 1, 2, 3, n-4, n-3, n-2 (kept for the boundary formulas), or runs past row 1
         auto bwd_row = [&](auto edge_c, int u) {
@@ -374,7 +442,7 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const double x = (yb[u][l] + x1[l] * db[u] + x2[l] * eb[u]) * cb[u];
-                a.dst[((long long)l * n + j) * nm + t] = x;
+                if (active) a.dst[((long long)l * n + j) * nm + t] = x;
                 x2[l] = x1[l];
                 x1[l] = x;
                 if (EDGE) {
@@ -397,6 +465,7 @@ __global__ void __launch_bounds__(256) k_int1(Int1Args a) {
     }
 
     // ---- boundary value at the free end and derivative at the given end (fdm_integral.f90:265-311) ----
+    if (!active) return;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         if (BC == 2) {
@@ -2282,6 +2351,24 @@ void launch_int1(const Int1Args &a, hipStream_t st) {
         if (a.g_ndi == 3) hipLaunchKernelGGL((k_int1g<BC, NL, FS, 3>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_int1g<BC, NL, FS, 7>), dim3(grid), dim3(256), 0, st, a);
     } else if (a.fac && NL == 2 && a.nm <= 2048) {      // the low-mode sub-plan: one line per thread
+        static const bool ldsv = [] { const char *e = getenv("TLAB_INT1_LDS"); return !(e && atoi(e) == 0); }();
+        // four rows per line (source / factors of the sweep, intermediate) + the rhs coefficients; at most what is left of a CU beside one workgroup of k_ode_nn
+        auto lds_of = [&](int lv) { return ((size_t)lv * 4 * a.T.n + (size_t)2 * a.T.n) * sizeof(double); };
+        if constexpr (FS != FS_UNIT) {
+            auto go = [&](auto lv_c) {
+                constexpr int LV = decltype(lv_c)::value;
+                static bool attr = false;
+                if (!attr) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_int1<BC, 1, FS, 8, true, true, true, LV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+                    (void)hipGetLastError();
+                    attr = true;
+                }
+                hipLaunchKernelGGL((k_int1<BC, 1, FS, 8, true, true, true, LV>), dim3((unsigned)((2 * a.nm + LV - 1) / LV)), dim3(256), lds_of(LV), st, a);
+                hipc(hipGetLastError(), "k_int1 (LDS)");
+            };
+            if (ldsv && lds_of(4) <= (size_t)84 * 1024) { go(std::integral_constant<int, 4>{}); return; }
+            if (ldsv && lds_of(2) <= (size_t)84 * 1024) { go(std::integral_constant<int, 2>{}); return; }
+        }
         hipLaunchKernelGGL((k_int1<BC, 1, FS, 8, true, true>), dim3((unsigned)((2 * a.nm + 127) / 128)), dim3(128), 0, st, a);
     } else if (a.fac) {
         if (a.nm < 65536) hipLaunchKernelGGL((k_int1<BC, NL, FS, 8, true>), dim3(grid), dim3(256), 0, st, a);
