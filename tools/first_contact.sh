@@ -12,6 +12,7 @@
 #   2 trpN         : the same with all N ranks as 1 x N and, when N is even, as 2 x N/2 (x and z communicators by ncclCommSplit)
 #   3 slab2, slabN : z-slab substep (native C++ driver, RCCL transport) against the single domain each rank computes redundantly (tools/dist_check.py)
 #   4 bench1..N    : bench.py --gpus 1 / 2 / 4 / 8 exactly as the driver launches it; the line's config.rccl_ranks must equal N
+#   5 pencil2xK    : (N >= 4, even) bench.py --gpus N --decomp 2x(N/2): the native x/z pencil driver over the world / x / z communicators
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
@@ -83,5 +84,18 @@ EOF
 )
     if [ "$rc" -eq 0 ] && [ "${verdict%% *}" = "PASS" ]; then say "bench$P" PASS "${verdict#* }"; else say "bench$P" FAIL "rc=$rc ${verdict#* } (see $log)"; fi
 done
+# ---- 5: the x/z pencil decomposition of BASELINE configs[3] on all N ranks (native driver, transpositions started ahead of independent launches) ----
+if [ "$N" -ge 4 ] && [ $((N % 2)) -eq 0 ]; then
+    log="$OUT/pencil2x$((N / 2)).log"
+    timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port "$(port)" bench.py --gpus "$N" --decomp "2x$((N / 2))" \
+        --slab-driver native --steps 6 --warmup 2 > "$log" 2>&1
+    rc=$?
+    line=$(grep '^{' "$log" | tail -1)
+    if [ "$rc" -eq 0 ] && echo "$line" | grep -q '"fields_finite": true' && echo "$line" | grep -q "\"rccl_ranks\": $N"; then
+        say "pencil2x$((N / 2))" PASS "$(echo "$line" | python3 -c 'import json,sys; r=json.loads(sys.stdin.read()); print("ms_per_step=%.3f rccl_ranks=%s" % (r["ms_per_step"], r["config"]["rccl_ranks"]))')"
+    else
+        say "pencil2x$((N / 2))" FAIL "rc=$rc (see $log)"
+    fi
+fi
 if [ "$fail" -eq 0 ]; then echo "FIRST_CONTACT all PASS"; else echo "FIRST_CONTACT some steps FAILED (logs: $OUT)"; fi
 exit $fail
