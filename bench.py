@@ -271,6 +271,11 @@ def main():
     ap.add_argument("--slab-driver", default="native", choices=["native", "python"], help="z-slab runs (--gpus N > 1, --loopback P): native = the C++ driver behind "
                     "tlab_slab_dns_* (tlab_amd/csrc/slab.cpp; RCCL transport of libtlab_amd_comm.so), the code a Fortran / MPI host runs; python = its "
                     "cross-check tlab_amd/parallel.py::SlabDns over torch.distributed (diagnostic)")
+    ap.add_argument("--placement-trials", type=int, default=16, help="single GPU: random assignments tried by tlab_dns_place_arrays before the timed region (0: the "
+                    "arrays stay where the allocator put them)")
+    ap.add_argument("--placement-pool", type=int, default=40, help="candidate allocations of the placement search")
+    ap.add_argument("--time-every-launch", action="store_true", help="events around every kernel launch inside the timed region (the kernel table then comes "
+                    "from the timed region itself; costs ~0.2 ms per substep at 512^3)")
     ap.add_argument("--no-freeslip-leg", action="store_true", help="skip the extra `walls_freeslip` timing of the default single-GPU line")
     ap.add_argument("--cpu-sample", type=int, default=256, help="n of the n^3 CPU-baseline sample (0 disables)")
     ap.add_argument("--cpu-sample-large", type=int, default=512, help="second, larger CPU-baseline sample, run only on hosts with at least --cpu-large-min-cores CPUs (0 disables)")
@@ -327,6 +332,7 @@ def main():
             dist.init_process_group(bootstrap)
     reduce_dev = "cuda" if (world > 1 and bootstrap == "nccl") else "cpu"      # where the small control reductions live
 
+    placement = None
     import tlab_amd as T
     from tlab_amd.dns import Dns, RKM_EXP3
     from tlab_amd.lib import load
@@ -395,6 +401,9 @@ def main():
         if args.walls == "freeslip":
             d.set_bcs("freeslip", "freeslip", "neumann", "neumann")
         synthetic_fields(d.q + d.s, nx, ny, nz, 0, nz, rank)
+        # which allocations play q, s, hq, hs, txc: searched at start-up, outside the timed region, like a plan (tlab_dns_place_arrays)
+        if args.placement_trials > 0:
+            placement = d.place_arrays(pool=args.placement_pool, random_trials=args.placement_trials, dtime=dtime)
         state_fields = d.q + d.s
 
         def substep(k):
@@ -470,10 +479,37 @@ def main():
         def substep(k):
             d.substep_of_cycle(k, dtime)
 
-    for k in range(args.warmup):
-        substep(k)
+    import ctypes
+    pbuf = ctypes.create_string_buffer(1 << 16)
+
+    def profile_rows():
+        """the library's own event timings since the last reset: one row per kernel name, largest summed time first"""
+        L.tlab_profile_report(pbuf, len(pbuf))
+        rows = []
+        for line in pbuf.value.decode().strip().split("\n"):
+            if not line:
+                continue
+            name, calls, ms, nbytes = line.split("\t")
+            rows.append({"kernel": name, "calls": int(calls), "total_ms": float(ms), "avg_ms": float(ms) / int(calls),
+                         "alg_bytes_per_launch": float(nbytes) / int(calls)})
+        rows.sort(key=lambda k: -k["total_ms"])
+        for k in rows:
+            k["alg_GBps"] = k["alg_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9 if k["avg_ms"] > 0 else 0.0
+        return rows
+
+    # Every launch of the warm-up is timed by the library's events; the kernel with the largest summed time among the full-field kernels is the
+    # dominant one, and in the timed region only ITS launches carry events (two event records per timed launch hold the stream for ~3 us each: with
+    # all ~45 launches of a substep timed, 0.2 ms of the 16).  The table of all kernels comes from a pass of its own after the timed region.
+    L.tlab_profile_filter(None)
     L.tlab_profile_reset()
     L.tlab_profile_enable(1)
+    for k in range(args.warmup):
+        substep(k)
+    dom_tag = None
+    if args.warmup > 0 and not args.time_every_launch:
+        dom_tag = next((k["kernel"] for k in profile_rows() if k["alg_bytes_per_launch"] > 1e6), None)
+    L.tlab_profile_filter(dom_tag.encode() if dom_tag else None)
+    L.tlab_profile_reset()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -512,23 +548,24 @@ def main():
                   ("tlab_dns (csrc/rhs.cpp)" if (world == 1 and args.loopback <= 1) else
                    "tlab_slab_dns (csrc/slab.cpp)" if args.slab_driver == "native" else "tlab_amd/parallel.py::SlabDns (%s)" % args.slab_driver)
 
+    # dominant kernel = largest summed time among the full-field kernels (the <= 4 singular Poisson modes run beside the main stream and rocFFT
+    # carries no byte count): its launches inside the timed region
+    timed_rows = profile_rows()
+    dom = next((k for k in timed_rows if k["alg_bytes_per_launch"] > 1e6), None)
+    kernels, kernels_pass = timed_rows, "the timed region (every launch timed)"
+    if dom_tag is not None:      # the table of all kernels: a pass of its own, every launch timed, same fields (every rank takes part in the exchanges)
+        npass = min(args.steps, 6)
+        L.tlab_profile_filter(None)
+        L.tlab_profile_reset()
+        L.tlab_profile_enable(1)
+        for k in range(npass):
+            substep(args.warmup + args.steps + 1 + k)
+        torch.cuda.synchronize()
+        L.tlab_profile_enable(0)
+        kernels = profile_rows()
+        kernels_pass = "%d substeps after the timed region with every launch timed (in the timed region only %s carries events)" % (npass, dom_tag)
+        finite = finite and all(bool(torch.isfinite(t).all()) for t in state_fields)
     if rank == 0:
-        import ctypes
-        buf = ctypes.create_string_buffer(1 << 16)
-        L.tlab_profile_report(buf, len(buf))
-        kernels = []
-        for line in buf.value.decode().strip().split("\n"):
-            if not line:
-                continue
-            name, calls, ms, nbytes = line.split("\t")
-            kernels.append({"kernel": name, "calls": int(calls), "total_ms": float(ms), "avg_ms": float(ms) / int(calls),
-                            "alg_bytes_per_launch": float(nbytes) / int(calls)})
-        kernels.sort(key=lambda k: -k["total_ms"])
-        for k in kernels:
-            k["alg_GBps"] = k["alg_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9 if k["avg_ms"] > 0 else 0.0
-        # dominant kernel = largest summed time among the full-field kernels (the <= 4 singular Poisson modes run beside the
-        # main stream and rocFFT carries no byte count)
-        dom = next((k for k in kernels if k["alg_bytes_per_launch"] > 1e6), None)
         # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC passes of the SAME binaries (profiles/traffic.json is
         # regenerated by tools/profile_round.sh together with the rocprofv3 CSV and stamped with the commit and the kernel list of that session;
         # a kernel the file does not know gets null, never another kernel's or an older build's figure)
@@ -584,8 +621,13 @@ def main():
                 "share_of_step": dom["total_ms"] / (ms_per_step * args.steps)},
             "substep_alg_GBps": (736.0 + 152.0 * args.nscal) * npts / (ms_per_step * 1e-3) / 1e9,
             "kernels": [{k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in k.items()} for k in kernels],
+            "kernels_from": kernels_pass,
         }
         single = world == 1 and args.loopback <= 1 and not args.decomp
+        if single:
+            out["placement"] = None if placement is None else dict(
+                placement, what="tlab_dns_place_arrays before the timed region: ms per substep of the allocations in the order the allocator gave them "
+                                "(ms_first), of the assignment the run uses (ms_best) and of the median / worst assignment tried; --placement-trials 0 skips it")
         if single:
             # context for the roofline fraction: what a plain device copy of one field reaches on THIS box (read + write bytes), after the timed
             # region.  The 8 TB/s peak is not reachable by any kernel; the streaming kernels above are to be read against this figure too.

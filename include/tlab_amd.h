@@ -325,6 +325,17 @@ int tlab_dns_set_fusion(tlab_dns_t d, int on);
  * tell the driver: the next tlab_rhs_global_incompressible_1 / tlab_time_substep_incompressible_explicit treats them as zero (its first
  * operator launch overwrites instead of accumulating), whatever they contain. */
 int tlab_dns_begin_step(tlab_dns_t d);
+/* Which device allocations should play q, s, hq, hs, txc?  The rate of a kernel that streams many arrays at once depends on the SET of allocations
+ * it streams (not on any one of them): 4.8 .. 5.9 TB/s for one 13-stream kernel over sets of 1-GiB hipMalloc allocations, 16.0 .. 17.2 ms per substep
+ * of the 512^3 box from process to process (profiles/r05/placement_*.txt).  No rule predicts it, so it is searched: given a pool
+ * of npool >= 2 (3 + nscal) + 9 candidate arrays, each of at least isize_txc_field doubles, the substep itself (one three-stage Runge-Kutta step per
+ * trial, timed by events) is run on the assignment "pool in order", on random_trials random assignments and on one pass of single-role exchanges,
+ * and the fastest comes back: assignment[r] = index into pool of role r, roles in the order q[0..2], s[0..nscal-1], hq[0..2], hs[0..nscal-1],
+ * txc[0..8].  state: 3 + nscal device arrays the trial fields start from (NULL: zeros).  EVERY array of the pool is overwritten; the caller puts its
+ * fields into the chosen arrays afterwards.  report (NULL or 5 doubles): ms per substep of the first assignment, the best, the median, the worst,
+ * and the number of trials.  A start-up cost of (random_trials + nroles + 1) x 4 substeps; the results of the run do not depend on it. */
+int tlab_dns_place_arrays(tlab_dns_t d, int npool, double *const *pool, const double *const *state, double dtime, int random_trials,
+                          unsigned seed, int *assignment, double *report);
 /* Wall boundary conditions in y: BcsFlowJmin%type(1:3), BcsFlowJmax%type(1:3), BcsScalJmin%type(1:nscal), BcsScalJmax%type(1:nscal)
  * (tools/dns/boundary_bcs.f90:24-27, read at :102-190).  Values as in the reference: DNS_BCS_DIRICHLET / DNS_BCS_NEUMANN.
  * Default at creation: all Dirichlet ('noslip'; the reference's 'freeslip' is {NEUMANN, DIRICHLET, NEUMANN} for (u,v,w)).
@@ -537,6 +548,9 @@ int tlab_set_tuning(int key, int value);
 /* Live kernel timing (HIP events on the library's stream around every kernel launch) for bench.py's roofline object.
  * tlab_profile_report writes one line per kernel: "name<TAB>calls<TAB>total_ms<TAB>total_algorithmic_bytes". */
 int tlab_profile_enable(int on);
+/* tag != NULL and not empty: only launches with exactly this name are timed (two event records per timed launch cost the stream ~3 us each: with
+ * every launch of the 512^3 substep timed, 0.2 ms of its 16); NULL or "": all of them. */
+int tlab_profile_filter(const char *tag);
 int tlab_profile_reset(void);
 int tlab_profile_report(char *buf, int nbuf);
 

@@ -1,0 +1,66 @@
+"""tlab_dns_place_arrays (include/tlab_amd.h): the search for the allocations on which the substep runs fastest changes WHERE q, s, hq, hs, txc live and
+nothing else -- a run after it is the run before it, bit for bit."""
+import numpy as np
+import pytest
+
+import cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tlab_amd as T
+    T.init(0)
+    return T
+
+
+def _dns(nx, ny, nz, seed):
+    import torch
+    from tlab_amd.dns import Dns, RKM_EXP3
+    x, y, z = C.grids(nx, ny, nz, True)
+    d = Dns(x, y, z, nscal=1, visc=1.0 / 500.0, schmidt=(0.7,), yuniform=False, rkm_mode=RKM_EXP3, hyper_bc1_ext=0.1)
+    q0, s0 = C.init_fields(nx, ny, nz, x, y, z, seed)
+    for t, a in zip(d.q + d.s, q0 + s0):
+        t.copy_(torch.from_numpy(a))
+    return d
+
+
+def test_placed_arrays_give_the_same_run_bit_for_bit(T):
+    import torch
+    nx, ny, nz = 256, 64, 32
+    a, b = _dns(nx, ny, nz, 5), _dns(nx, ny, nz, 5)
+    before = [t.data_ptr() for t in b.q + b.s + b.hq + b.hs + b.txc]
+    rep = b.place_arrays(pool=24, random_trials=3, dtime=1e-3, seed=3)
+    after = [t.data_ptr() for t in b.q + b.s + b.hq + b.hs + b.txc]
+    assert len(set(after)) == 17 and not set(after) & set(before)                   # 17 distinct arrays out of the pool
+    assert rep["pool"] == 24 and rep["trials"] == 1 + 3 + 17
+    assert 0.0 < rep["ms_best"] <= rep["ms_first"] and rep["ms_best"] <= rep["ms_median"] <= rep["ms_worst"]
+    for t, u in zip(a.q + a.s, b.q + b.s):                                          # the fields came along
+        assert torch.equal(t, u)
+    for d in (a, b):
+        for _ in range(2):
+            d.TIME_RUNGEKUTTA(1e-3)
+    torch.cuda.synchronize()
+    for t, u in zip(a.q + a.s + a.hq + a.hs, b.q + b.s + b.hq + b.hs):
+        assert torch.equal(t, u)
+    assert all(bool(torch.isfinite(t).all()) for t in b.q + b.s)
+
+
+def test_place_arrays_refuses_a_pool_that_is_too_small(T):
+    import ctypes
+    import torch
+    from tlab_amd.lib import load, c_vp, TlabError, check
+    d = _dns(256, 64, 32, 6)
+    m = d.isize_txc_field
+    pool = [torch.zeros(m, dtype=torch.float64, device="cuda") for _ in range(16)]      # 17 roles
+    parr = (c_vp * 16)(*[t.data_ptr() for t in pool])
+    assign = (ctypes.c_int * 17)()
+    with pytest.raises(TlabError):
+        check(load().tlab_dns_place_arrays(d._h, 16, parr, None, 1e-3, 2, 0, assign, None), "tlab_dns_place_arrays")
+    parr2 = (c_vp * 17)(*([t.data_ptr() for t in pool] + [pool[0].data_ptr()]))        # the same array twice
+    with pytest.raises(TlabError):
+        check(load().tlab_dns_place_arrays(d._h, 17, parr2, None, 1e-3, 2, 0, assign, None), "tlab_dns_place_arrays")

@@ -17,6 +17,7 @@ struct Rec {
     double bytes;
 };
 bool g_on = false;
+std::string g_only;      // empty: every launch is timed
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open_a = nullptr;
@@ -35,7 +36,7 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-bool prof_enabled() { return g_on; }
+bool prof_enabled(const char *tag) { return g_on && (g_only.empty() || (tag && g_only == tag)); }
 
 void prof_begin(const char *tag, hipStream_t st, double bytes) {
     g_open_a = get_event();
@@ -58,6 +59,11 @@ extern "C" {
 
 int tlab_profile_enable(int on) {
     g_on = on != 0;
+    return TLAB_OK;
+}
+
+int tlab_profile_filter(const char *tag) {
+    g_only = tag ? tag : "";
     return TLAB_OK;
 }
 

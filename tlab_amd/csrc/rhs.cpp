@@ -875,6 +875,106 @@ int tlab_dns_begin_step(tlab_dns_t d) {
     return TLAB_OK;
 }
 
+// ---- which allocations play q, s, hq, hs, txc (include/tlab_amd.h: tlab_dns_place_arrays) ----
+// A kernel that streams many arrays at once runs at a rate that depends on WHICH device allocations they are -- not on any one of them (each alone
+// reads / writes at the same rate), on the set: tools/placement_probe measures 4.8 .. 5.9 TB/s for one 13-stream kernel over sets drawn from a pool
+// of 1-GiB hipMalloc allocations, reproducibly per set (profiles/r05/placement_*.txt).  It is what made "the slow state of the box" of rounds 3-5:
+// the same binary, the same box, 16.0 .. 17.2 ms per substep from process to process.  Neither the virtual alignment nor a skew between the arrays
+// of one allocation predicts it, so the assignment is searched: time the substep itself on candidate assignments and keep the fastest.
+int tlab_dns_place_arrays(tlab_dns_t d, int npool, double *const *pool, const double *const *state, double dtime, int random_trials, unsigned seed,
+                          int *assignment, double *report) {
+    try {
+        if (!d || !pool || !assignment || dtime <= 0.0 || random_trials < 0) throw Fail(TLAB_EINVAL, "tlab_dns_place_arrays: bad arguments");
+        const int ns = d->nscal, nroles = 2 * (3 + ns) + 9;
+        if (npool < nroles) throw Fail(TLAB_EINVAL, "tlab_dns_place_arrays: the pool must hold at least 2 (3 + nscal) + 9 arrays");
+        for (int i = 0; i < npool; ++i) {
+            if (!pool[i]) throw Fail(TLAB_EINVAL, "tlab_dns_place_arrays: null array in the pool");
+            for (int j = 0; j < i; ++j)
+                if (pool[j] == pool[i]) throw Fail(TLAB_EINVAL, "tlab_dns_place_arrays: the same array twice in the pool");
+        }
+        hipStream_t st = tlab_current_stream();
+        const size_t fbytes = (size_t)d->nx * d->ny * d->nz * sizeof(double);
+        hipEvent_t e0, e1;
+        hk(hipEventCreate(&e0), "hipEventCreate");
+        hk(hipEventCreate(&e1), "hipEventCreate");
+        // one Runge-Kutta step of three substeps (first one on fresh tendencies, the others accumulating and scaling: the kernels of a real step)
+        const double kdt[3] = {1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0}, kco[3] = {-5.0 / 9.0, -153.0 / 128.0, 1.0};
+        auto trial = [&](const std::vector<int> &a) {
+            std::vector<double *> q(3), s((size_t)std::max(ns, 1)), hq(3), hs((size_t)std::max(ns, 1)), txc(9);
+            int r = 0;
+            for (int i = 0; i < 3; ++i) q[i] = pool[a[r++]];
+            for (int i = 0; i < ns; ++i) s[i] = pool[a[r++]];
+            for (int i = 0; i < 3; ++i) hq[i] = pool[a[r++]];
+            for (int i = 0; i < ns; ++i) hs[i] = pool[a[r++]];
+            for (int i = 0; i < 9; ++i) txc[i] = pool[a[r++]];
+            for (int i = 0; i < 3 + ns; ++i) {
+                double *dst = i < 3 ? q[i] : s[i - 3];
+                if (state && state[i]) hk(hipMemcpyAsync(dst, state[i], fbytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+                else hk(hipMemsetAsync(dst, 0, fbytes, st), "hipMemsetAsync");
+            }
+            d->fresh = true;
+            rhs_impl(d, dtime * kdt[0], q.data(), s.data(), hq.data(), hs.data(), txc.data(), true, kco[0], 1);      // untimed: first touch of this assignment
+            hk(hipEventRecord(e0, st), "hipEventRecord");
+            d->fresh = true;
+            for (int k = 0; k < 3; ++k) rhs_impl(d, dtime * kdt[k], q.data(), s.data(), hq.data(), hs.data(), txc.data(), true, kco[k], k < 2);
+            hk(hipEventRecord(e1, st), "hipEventRecord");
+            hk(hipEventSynchronize(e1), "hipEventSynchronize");
+            float ms = 0.0f;
+            hk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+            return (double)ms / 3.0;
+        };
+        // xorshift: the same sequence everywhere
+        unsigned long long x = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)seed * 0xBF58476D1CE4E5B9ull + 1ull);
+        auto rnd = [&](int m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (int)(x % (unsigned long long)m); };
+        std::vector<int> ident((size_t)nroles);
+        for (int i = 0; i < nroles; ++i) ident[i] = i;
+        std::vector<double> all;
+        std::vector<int> best = ident;
+        const double first = trial(ident);
+        double bestms = first;
+        all.push_back(first);
+        for (int t = 0; t < random_trials; ++t) {
+            std::vector<int> perm((size_t)npool);
+            for (int i = 0; i < npool; ++i) perm[i] = i;
+            for (int i = npool - 1; i > 0; --i) std::swap(perm[i], perm[rnd(i + 1)]);
+            perm.resize((size_t)nroles);
+            const double ms = trial(perm);
+            all.push_back(ms);
+            if (ms < bestms) { bestms = ms; best = perm; }
+        }
+        // one pass of single-role exchanges against the unused arrays (skipped when the pool has none to spare)
+        if (npool > nroles && random_trials > 0) {
+            for (int r = 0; r < nroles; ++r) {
+                std::vector<char> used((size_t)npool, 0);
+                for (int v : best) used[v] = 1;
+                int cand = -1;
+                for (int tries = 0; tries < 4 * npool && cand < 0; ++tries) { const int c = rnd(npool); if (!used[c]) cand = c; }
+                if (cand < 0) continue;
+                std::vector<int> a = best;
+                a[r] = cand;
+                const double ms = trial(a);
+                all.push_back(ms);
+                if (ms < bestms * 0.999) { bestms = ms; best = a; }
+            }
+        }
+        hk(hipEventDestroy(e0), "hipEventDestroy");
+        hk(hipEventDestroy(e1), "hipEventDestroy");
+        for (int r = 0; r < nroles; ++r) assignment[r] = best[r];
+        if (report) {
+            std::vector<double> sorted = all;
+            std::sort(sorted.begin(), sorted.end());
+            report[0] = first; report[1] = bestms; report[2] = sorted[sorted.size() / 2]; report[3] = sorted.back(); report[4] = (double)all.size();
+        }
+        return TLAB_OK;
+    } catch (const Fail &f) {
+        tlab_set_error(f.what());
+        return f.code;
+    } catch (const std::exception &e) {
+        tlab_set_error(e.what());
+        return TLAB_EINVAL;
+    }
+}
+
 int tlab_dns_set_fusion(tlab_dns_t d, int on) {
     if (!d) return TLAB_EINVAL;
     d->fuse = on != 0;

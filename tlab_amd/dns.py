@@ -198,6 +198,41 @@ class Dns:
         """hq = hs = 0 of TIME_RUNGEKUTTA (time.f90:212-216) without touching the arrays: the next substep overwrites them."""
         check(load().tlab_dns_begin_step(self._h), "tlab_dns_begin_step")
 
+    def place_arrays(self, pool=40, random_trials=16, dtime=1e-3, seed=0):
+        """tlab_dns_place_arrays: q, s, hq, hs, txc move to the allocations (out of a pool of `pool` fresh ones of the txc size) on which the substep runs
+        fastest; the fields keep their values.  Returns {"ms_first", "ms_best", "ms_median", "ms_worst", "trials", "pool", "seconds"}."""
+        import time
+        import torch
+        nroles = 2 * (3 + self.nscal) + 9
+        m = self.isize_txc_field
+        free, _ = torch.cuda.mem_get_info()
+        pool = max(nroles, min(int(pool), int(0.6 * free / (8.0 * m))))
+        t0 = time.perf_counter()
+        state = [t.clone() for t in self.q + self.s]
+        dev = self.q[0].device
+        cand = [torch.zeros(m, dtype=torch.float64, device=dev) for _ in range(pool)]
+        parr = (c_vp * pool)(*[t.data_ptr() for t in cand])
+        sarr = (c_vp * len(state))(*[t.data_ptr() for t in state])
+        assign = (ctypes.c_int * nroles)()
+        rep = (ctypes.c_double * 5)()
+        _use_torch_stream()
+        check(load().tlab_dns_place_arrays(self._h, pool, parr, sarr, float(dtime), int(random_trials), int(seed), assign, rep), "tlab_dns_place_arrays")
+        a = [cand[i] for i in assign]
+        ns = self.nscal
+        self.q, self.s = [t[: self.n] for t in a[0:3]], [t[: self.n] for t in a[3:3 + ns]]
+        self.hq, self.hs = [t[: self.n] for t in a[3 + ns:6 + ns]], [t[: self.n] for t in a[6 + ns:6 + 2 * ns]]
+        self.txc = a[6 + 2 * ns:]
+        self._ptrs = None
+        for t, r in zip(self.q + self.s, state):
+            t.copy_(r)
+        for t in self.hq + self.hs:
+            t.zero_()
+        del cand, state, a
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return {"ms_first": rep[0], "ms_best": rep[1], "ms_median": rep[2], "ms_worst": rep[3], "trials": int(rep[4]), "pool": pool,
+                "seconds": time.perf_counter() - t0}
+
     def TIME_RUNGEKUTTA(self, dtime):
         """One time step: hq = hs = 0, then rkm_endstep substeps (time.f90:212-298)."""
         self.begin_step()

@@ -71,6 +71,7 @@ SIGNATURES = {
     "tlab_dns_destroy": (c_int, [c_vp]),
     "tlab_dns_set_fusion": (c_int, [c_vp, c_int]),
     "tlab_dns_begin_step": (c_int, [c_vp]),
+    "tlab_dns_place_arrays": (c_int, [c_vp, c_int, c_vp, c_vp, c_dbl, c_int, ctypes.c_uint, ctypes.POINTER(c_int), _dp]),
     "tlab_dns_set_slab": (c_int, [c_vp, c_int]),
     "tlab_dns_set_anelastic": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
     "tlab_dns_set_remove_divergence": (c_int, [c_vp, c_int]),
@@ -128,6 +129,7 @@ SIGNATURES = {
     "tlab_force_kernel_path": (c_int, [c_int]),
     "tlab_set_tuning": (c_int, [c_int, c_int]),
     "tlab_profile_enable": (c_int, [c_int]),
+    "tlab_profile_filter": (c_int, [ctypes.c_char_p]),
     "tlab_profile_reset": (c_int, []),
     "tlab_profile_report": (c_int, [ctypes.c_char_p, c_int]),
     "tlab_debug_host_chunked_solve": (c_int, [c_vp, c_int, c_int, c_int, _dp]),

@@ -146,8 +146,56 @@ def clock(d, cname="GRBM_GUI_ACTIVE", kernels=("k_xline<BURGERS>", "k_htile<BURG
         print("%-22s %8d | %-34s | %-34s | %-34s" % (t, len(v), cells[0], cells[1], cells[2]))
 
 
+def gaps(d, bench_json):
+    """per-tag kernel time per substep and the idle time of the device inside the timed region of one bench.py run under --kernel-trace: the window is
+    the last steps * ms_per_step before the end of the last library kernel (the bench line of the same run tells both)."""
+    line = [ln for ln in open(bench_json).read().splitlines() if ln.startswith("{")][-1]
+    b = json.loads(line)
+    steps, ms = int(b["steps"]), float(b["ms_per_step"])
+    rows = []
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            t0 = float(r.get("Start_Timestamp") or 0.0)
+            t1 = float(r.get("End_Timestamp") or 0.0)
+            rows.append((t0, t1, r.get("Kernel_Name", "")))
+    lib = [r for r in rows if "tlab" in r[2] or re.match(r"(void )?k_", r[2])]
+    end = max(r[1] for r in lib)
+    beg = end - steps * ms * 1e6
+    win = sorted(r for r in rows if r[0] >= beg and r[1] <= end + 1.0)
+    per = defaultdict(lambda: [0.0, 0])
+    for t0, t1, name in win:
+        a = per[tag(name)]
+        a[0] += t1 - t0
+        a[1] += 1
+    busy, cur0, cur1 = 0.0, None, None
+    for t0, t1, _ in win:
+        if cur1 is None or t0 > cur1:
+            if cur1 is not None:
+                busy += cur1 - cur0
+            cur0, cur1 = t0, t1
+        else:
+            cur1 = max(cur1, t1)
+    busy += (cur1 - cur0) if cur1 is not None else 0.0
+    tot = sum(a[0] for a in per.values())
+    print("# window: the last %d steps (%.3f ms each by the bench line); kernels in it: %d" % (steps, ms, len(win)))
+    print("# per step: sum of kernel durations %.3f ms, device busy (union of the kernels' intervals) %.3f ms, no kernel running %.3f ms" %
+          (tot * 1e-6 / steps, busy * 1e-6 / steps, ms - busy * 1e-6 / steps))
+    print("%-28s %10s %12s %12s" % ("kernel", "launches", "ms per step", "us / launch"))
+    for t, a in sorted(per.items(), key=lambda kv: -kv[1][0]):
+        print("%-28s %10.1f %12.4f %12.2f" % (t, a[1] / steps, a[0] * 1e-6 / steps, a[0] * 1e-3 / a[1]))
+    print("# the last step, launch by launch: start [us from the first], duration [us], idle before it [us] (negative: it overlaps an earlier kernel), kernel")
+    last = [r for r in win if r[0] >= end - ms * 1e6]
+    if last:
+        z, hi = last[0][0], last[0][0]
+        for t0, t1, name in last:
+            print("%10.1f %9.1f %8.1f  %s" % ((t0 - z) * 1e-3, (t1 - t0) * 1e-3, (t0 - hi) * 1e-3, tag(name)))
+            hi = max(hi, t1)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 3 and sys.argv[1] == "clock":
+    if len(sys.argv) >= 4 and sys.argv[1] == "gaps":
+        gaps(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "clock":
         clock(sys.argv[2], *(sys.argv[3:4]))
     elif len(sys.argv) >= 3 and sys.argv[1] == "stats":
         stats(sys.argv[2])
