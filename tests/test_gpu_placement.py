@@ -64,3 +64,27 @@ def test_place_arrays_refuses_a_pool_that_is_too_small(T):
     parr2 = (c_vp * 17)(*([t.data_ptr() for t in pool] + [pool[0].data_ptr()]))        # the same array twice
     with pytest.raises(TlabError):
         check(load().tlab_dns_place_arrays(d._h, 17, parr2, None, 1e-3, 2, 0, assign, None), "tlab_dns_place_arrays")
+
+
+def test_bench_line_of_one_gpu_carries_the_placement_report_and_times_the_dominant_kernel_only(T):
+    """bench.py's default single-GPU line at a small box: the placement search ran before the timed region (its report is in the line), the roofline
+    object comes from events around the dominant kernel only -- as many launches as timed substeps -- and the table of all kernels from its own pass."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--n", "256", "--steps", "6", "--warmup", "3", "--cpu-sample", "0", "--no-freeslip-leg", "--placement-trials", "4",
+           "--placement-pool", "24"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    pl = rec["placement"]
+    assert pl["pool"] == 24 and pl["trials"] == 1 + 4 + 17 and 0 < pl["ms_best"] <= pl["ms_first"]
+    rf = rec["roofline"]
+    assert rf["bound"] == "hbm" and rf["launches"] == 6 and 0 < rf["frac"] < 1
+    names = [k["kernel"] for k in rec["kernels"]]
+    assert rf["kernel"] in names and len(names) > 8 and "after the timed region" in rec["kernels_from"]
+    assert rec["config"]["fields_finite"] is True and rec["steps"] == 6
