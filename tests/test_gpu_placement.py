@@ -68,7 +68,7 @@ def test_place_arrays_refuses_a_pool_that_is_too_small(T):
 
 def test_bench_line_of_one_gpu_carries_the_placement_report_and_times_the_dominant_kernel_only(T):
     """bench.py's default single-GPU line at a small box: the placement search ran before the timed region (its report is in the line), the roofline
-    object comes from events around the dominant kernel only -- as many launches as timed substeps -- and the table of all kernels from its own pass."""
+    object comes from events around the dominant kernel only -- a few launches per timed substep -- and the table of all kernels from its own pass."""
     import json
     import os
     import subprocess
@@ -84,7 +84,7 @@ def test_bench_line_of_one_gpu_carries_the_placement_report_and_times_the_domina
     pl = rec["placement"]
     assert pl["pool"] == 24 and pl["trials"] == 1 + 4 + 17 and 0 < pl["ms_best"] <= pl["ms_first"]
     rf = rec["roofline"]
-    assert rf["bound"] == "hbm" and rf["launches"] == 6 and 0 < rf["frac"] < 1
+    assert rf["bound"] == "hbm" and rf["launches"] in (6, 12, 18) and 0 < rf["frac"] < 1      # one kernel name: 1 .. 3 launches per substep
     names = [k["kernel"] for k in rec["kernels"]]
     assert rf["kernel"] in names and len(names) > 8 and "after the timed region" in rec["kernels_from"]
     assert rec["config"]["fields_finite"] is True and rec["steps"] == 6
