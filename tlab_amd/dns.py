@@ -205,11 +205,14 @@ class Dns:
         import torch
         nroles = 2 * (3 + self.nscal) + 9
         m = self.isize_txc_field
-        free, _ = torch.cuda.mem_get_info()
-        pool = max(nroles, min(int(pool), int(0.6 * free / (8.0 * m))))
         t0 = time.perf_counter()
         state = [t.clone() for t in self.q + self.s]
         dev = self.q[0].device
+        self.q = self.s = self.hq = self.hs = self.txc = self._ptrs = None       # the driver's own arrays go back to the allocator before the pool is made
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        pool = max(nroles, min(int(pool), int(0.7 * free / (8.0 * m))))
         cand = [torch.zeros(m, dtype=torch.float64, device=dev) for _ in range(pool)]
         parr = (c_vp * pool)(*[t.data_ptr() for t in cand])
         sarr = (c_vp * len(state))(*[t.data_ptr() for t in state])
