@@ -146,6 +146,40 @@ def clock(d, cname="GRBM_GUI_ACTIVE", kernels=("k_xline<BURGERS>", "k_htile<BURG
         print("%-22s %8d | %-34s | %-34s | %-34s" % (t, len(v), cells[0], cells[1], cells[2]))
 
 
+def stats_window(d, bench_json):
+    """The kernel statistics of the TIMED REGION of one bench.py run under --kernel-trace (same columns as `stats`).  The trace of the default command
+    also holds the launches of the placement search (tlab_dns_place_arrays: 4 substeps per trial on assignments the run does not use), the warm-up, the
+    empty-queue substep and the pass that fills the kernel table; the timed region is found by COUNT: the dominant kernel (roofline.kernel of the bench
+    line of the same run, `lpp` launches per substep) is launched 4 lpp times per trial, then lpp warmup times, then lpp steps times -- the window runs
+    from the start of the first of those to the start of the launch after the last."""
+    b = json.loads([ln for ln in open(bench_json).read().splitlines() if ln.startswith("{")][-1])
+    steps, warmup = int(b["steps"]), int(b["warmup"])
+    dom = b["roofline"]["kernel"]
+    lpp = max(1, int(b["roofline"]["launches"]) // steps)
+    trials = int((b.get("placement") or {}).get("trials", 0))
+    rows = []
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            rows.append((float(r.get("Start_Timestamp") or 0.0), float(r.get("End_Timestamp") or 0.0), r.get("Kernel_Name", "")))
+    rows.sort()
+    doms = [r for r in rows if tag(r[2]) == dom]
+    i0 = lpp * (4 * trials + warmup)
+    if len(doms) <= i0 + lpp * steps:
+        sys.exit("stats_window: %d launches of %s in the trace, %d expected before the end of the timed region" % (len(doms), dom, i0 + lpp * steps + 1))
+    t0, t1 = doms[i0][0], doms[i0 + lpp * steps][0]
+    acc = defaultdict(list)
+    for a, e, name in rows:
+        if a >= t0 and a < t1:
+            acc[name].append(e - a)
+    tot = sum(sum(v) for v in acc.values())
+    w = csv.writer(sys.stdout)
+    w.writerow(["# launches that START inside the timed region of the run (%d substeps, window %.3f ms = %.3f ms per substep; the bench line of the same run says %.3f)"
+                % (steps, (t1 - t0) * 1e-6, (t1 - t0) * 1e-6 / steps, b["ms_per_step"])])
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for name, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([name, len(v), int(sum(v)), "%.1f" % (sum(v) / len(v)), "%.2f" % (100.0 * sum(v) / tot), int(min(v)), int(max(v))])
+
+
 def gaps(d, bench_json):
     """per-tag kernel time per substep and the idle time of the device inside the timed region of one bench.py run under --kernel-trace: the window is
     the last steps * ms_per_step before the end of the last library kernel (the bench line of the same run tells both)."""
@@ -193,7 +227,9 @@ def gaps(d, bench_json):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] == "gaps":
+    if len(sys.argv) >= 4 and sys.argv[1] == "stats_window":
+        stats_window(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 4 and sys.argv[1] == "gaps":
         gaps(sys.argv[2], sys.argv[3])
     elif len(sys.argv) >= 3 and sys.argv[1] == "clock":
         clock(sys.argv[2], *(sys.argv[3:4]))

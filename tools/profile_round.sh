@@ -17,14 +17,16 @@ B="$ROOT/bench.py"
 python3 "$B" > "$O/bench_default.json" 2> "$O/bench_default.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/raw_stats" -- python3 "$B" --steps 6 --warmup 2 --cpu-sample 0 --no-freeslip-leg > "$O/bench_under_rocprof.json" 2> "$O/rocprof_stats.err"
 python3 "$ROOT/tools/pmc_summary.py" stats "$O/raw_stats" > "$O/rocprofv3_kernel_stats_bench_steps6.csv"
-# 2. HBM traffic: two separate counter passes, kernel trace only
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/raw_fetch" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_fetch.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/raw_write" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg > /dev/null 2> "$O/rocprof_write.err"
+# (the trace of the default command also holds the launches of the placement search, the warm-up and the kernel-table pass: the timed region by itself)
+python3 "$ROOT/tools/pmc_summary.py" stats_window "$O/raw_stats" "$O/bench_under_rocprof.json" > "$O/rocprofv3_kernel_stats_bench_steps6_timed_region.csv" 2>> "$O/rocprof_stats.err"
+# 2. HBM traffic: two separate counter passes, kernel trace only (without the placement search: the bytes of a launch do not depend on where the arrays live)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/raw_fetch" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg --placement-trials 0 > /dev/null 2> "$O/rocprof_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/raw_write" -- python3 "$B" --steps 3 --warmup 1 --cpu-sample 0 --no-freeslip-leg --placement-trials 0 > /dev/null 2> "$O/rocprof_write.err"
 python3 "$ROOT/tools/pmc_summary.py" pmc "$O/raw_fetch" "$O/raw_write" "$O/traffic.json" "$COMMIT" > "$O/pmc_hbm_traffic_summary.txt"
 # 2b. the clock over a long run ("k_xline slows 5 % under sustained load -- clocks, presumably"): one counter pass of 150 substeps
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$O/raw_clock" -- python3 "$B" --steps 150 --warmup 3 --cpu-sample 0 --no-freeslip-leg > "$O/bench_under_clock_pass.json" 2> "$O/rocprof_clock.err"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$O/raw_clock" -- python3 "$B" --steps 150 --warmup 3 --cpu-sample 0 --no-freeslip-leg --placement-trials 0 > "$O/bench_under_clock_pass.json" 2> "$O/rocprof_clock.err"
 python3 "$ROOT/tools/pmc_summary.py" clock "$O/raw_clock" > "$O/clock_probe.txt" 2>> "$O/rocprof_clock.err"
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES --output-format csv -d "$O/raw_clock2" -- python3 "$B" --steps 150 --warmup 3 --cpu-sample 0 --no-freeslip-leg > /dev/null 2>> "$O/rocprof_clock.err"
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES --output-format csv -d "$O/raw_clock2" -- python3 "$B" --steps 150 --warmup 3 --cpu-sample 0 --no-freeslip-leg --placement-trials 0 > /dev/null 2>> "$O/rocprof_clock.err"
 python3 "$ROOT/tools/pmc_summary.py" clock "$O/raw_clock2" SQ_BUSY_CYCLES >> "$O/clock_probe.txt" 2>> "$O/rocprof_clock.err"
 # (third argument "quick": the bench line, its kernel trace and the traffic file only -- after a change that leaves the other lines as they are)
 if [ "${3:-}" = "quick" ]; then rm -rf "$O"/raw_*; ls -la "$O"; exit 0; fi
@@ -60,6 +62,18 @@ TLAB_PROFILE_REPORT=1 python3 "$ROOT/tools/bench_poisson.py" > "$O/poisson_stand
 TLAB_XLINE_OCC=1 python3 "$B" --steps 20 --warmup 5 $Q > "$O/bench_xline_one_wave_per_simd.json" 2> /dev/null
 TLAB_PENCIL_OVERLAP=0 python3 "$B" --decomp 2x4 --slab-driver native --steps 6 --warmup 2 $Q > "$O/bench_decomp2x4_native_literal_sequence.json" 2> /dev/null
 "$ROOT/tools/mall_probe" > "$O/mall_probe.jsonl" 2> /dev/null
+# which allocations the arrays live on: the placement search off / on, interleaved; the probes behind it
+for i in 1 2 3; do
+    python3 "$B" --steps 15 --warmup 3 $Q --placement-trials 0 > "$O/bench_placement_off_$i.json" 2> /dev/null
+    python3 "$B" --steps 15 --warmup 3 $Q > "$O/bench_placement_on_$i.json" 2> /dev/null
+done
+python3 "$B" --steps 15 --warmup 3 $Q --time-every-launch > "$O/bench_time_every_launch.json" 2> /dev/null
+timeout 300 "$ROOT/tools/placement_probe" > "$O/placement_probe.txt" 2>&1
+timeout 300 "$ROOT/tools/placement_probe" 100 2>&1 | grep -v '^  array' > "$O/placement_survey.txt"
+# all eight slab ranks' work on one GPU, kernel by kernel
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/raw_lb" -- python3 "$B" --loopback 8 --steps 6 --warmup 2 $Q > "$O/bench_loopback8_under_rocprof.json" 2> "$O/rocprof_lb.err"
+python3 "$ROOT/tools/pmc_summary.py" stats "$O/raw_lb" > "$O/rocprofv3_kernel_stats_loopback8_steps6.csv"
+python3 "$ROOT/tools/pmc_summary.py" gaps "$O/raw_lb" "$O/bench_loopback8_under_rocprof.json" > "$O/loopback8_timeline.txt" 2>> "$O/rocprof_lb.err"
 python3 "$ROOT/tools/bench_xlines.py" 2> /dev/null | grep grid > "$O/xlines.jsonl"
 python3 "$ROOT/tools/bench_xlines.py" --exact-uniform --grids 2048x1024x64 2> /dev/null | grep grid > "$O/xlines_equal_rows_2048.jsonl"
 # the raw rocprofv3 trees are large: only the summaries travel back
