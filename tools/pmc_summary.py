@@ -146,12 +146,12 @@ def clock(d, cname="GRBM_GUI_ACTIVE", kernels=("k_xline<BURGERS>", "k_htile<BURG
         print("%-22s %8d | %-34s | %-34s | %-34s" % (t, len(v), cells[0], cells[1], cells[2]))
 
 
-def stats_window(d, bench_json):
-    """The kernel statistics of the TIMED REGION of one bench.py run under --kernel-trace (same columns as `stats`).  The trace of the default command
-    also holds the launches of the placement search (tlab_dns_place_arrays: 4 substeps per trial on assignments the run does not use), the warm-up, the
-    empty-queue substep and the pass that fills the kernel table; the timed region is found by COUNT: the dominant kernel (roofline.kernel of the bench
-    line of the same run, `lpp` launches per substep) is launched 4 lpp times per trial, then lpp warmup times, then lpp steps times -- the window runs
-    from the start of the first of those to the start of the launch after the last."""
+def timed_window(d, bench_json):
+    """(rows, t0, t1, bench line): the kernel trace of one bench.py run and the bounds of its TIMED REGION.  The trace of the default command also holds the
+    launches of the placement search (tlab_dns_place_arrays: 4 substeps per trial on assignments the run does not use), the warm-up, the empty-queue
+    substep and the pass that fills the kernel table; the timed region is found by COUNT: the dominant kernel (roofline.kernel of the bench line of
+    the same run, `lpp` launches per substep) is launched 4 lpp times per trial, then lpp warmup times, then lpp steps times -- the window runs from
+    the start of the first of those to the start of the launch after the last."""
     b = json.loads([ln for ln in open(bench_json).read().splitlines() if ln.startswith("{")][-1])
     steps, warmup = int(b["steps"]), int(b["warmup"])
     dom = b["roofline"]["kernel"]
@@ -165,8 +165,14 @@ def stats_window(d, bench_json):
     doms = [r for r in rows if tag(r[2]) == dom]
     i0 = lpp * (4 * trials + warmup)
     if len(doms) <= i0 + lpp * steps:
-        sys.exit("stats_window: %d launches of %s in the trace, %d expected before the end of the timed region" % (len(doms), dom, i0 + lpp * steps + 1))
-    t0, t1 = doms[i0][0], doms[i0 + lpp * steps][0]
+        sys.exit("timed_window: %d launches of %s in the trace, %d expected before the end of the timed region" % (len(doms), dom, i0 + lpp * steps + 1))
+    return rows, doms[i0][0], doms[i0 + lpp * steps][0], b
+
+
+def stats_window(d, bench_json):
+    """The kernel statistics of the timed region of one bench.py run under --kernel-trace (same columns as `stats`)."""
+    rows, t0, t1, b = timed_window(d, bench_json)
+    steps = int(b["steps"])
     acc = defaultdict(list)
     for a, e, name in rows:
         if a >= t0 and a < t1:
@@ -181,49 +187,41 @@ def stats_window(d, bench_json):
 
 
 def gaps(d, bench_json):
-    """per-tag kernel time per substep and the idle time of the device inside the timed region of one bench.py run under --kernel-trace: the window is
-    the last steps * ms_per_step before the end of the last library kernel (the bench line of the same run tells both)."""
-    line = [ln for ln in open(bench_json).read().splitlines() if ln.startswith("{")][-1]
-    b = json.loads(line)
+    """per-tag kernel time per substep and the idle time of the device inside the timed region (timed_window) of one bench.py run under --kernel-trace,
+    and its last substep launch by launch."""
+    rows, t0, t1, b = timed_window(d, bench_json)
     steps, ms = int(b["steps"]), float(b["ms_per_step"])
-    rows = []
-    for f in find(d, "*kernel_trace.csv"):
-        for r in csv.DictReader(open(f)):
-            t0 = float(r.get("Start_Timestamp") or 0.0)
-            t1 = float(r.get("End_Timestamp") or 0.0)
-            rows.append((t0, t1, r.get("Kernel_Name", "")))
-    lib = [r for r in rows if "tlab" in r[2] or re.match(r"(void )?k_", r[2])]
-    end = max(r[1] for r in lib)
-    beg = end - steps * ms * 1e6
-    win = sorted(r for r in rows if r[0] >= beg and r[1] <= end + 1.0)
+    win = [r for r in rows if r[0] >= t0 and r[0] < t1]
     per = defaultdict(lambda: [0.0, 0])
-    for t0, t1, name in win:
-        a = per[tag(name)]
-        a[0] += t1 - t0
-        a[1] += 1
+    for a, e, name in win:
+        acc = per[tag(name)]
+        acc[0] += e - a
+        acc[1] += 1
     busy, cur0, cur1 = 0.0, None, None
-    for t0, t1, _ in win:
-        if cur1 is None or t0 > cur1:
+    for a, e, _ in win:
+        if cur1 is None or a > cur1:
             if cur1 is not None:
                 busy += cur1 - cur0
-            cur0, cur1 = t0, t1
+            cur0, cur1 = a, e
         else:
-            cur1 = max(cur1, t1)
+            cur1 = max(cur1, e)
     busy += (cur1 - cur0) if cur1 is not None else 0.0
-    tot = sum(a[0] for a in per.values())
-    print("# window: the last %d steps (%.3f ms each by the bench line); kernels in it: %d" % (steps, ms, len(win)))
-    print("# per step: sum of kernel durations %.3f ms, device busy (union of the kernels' intervals) %.3f ms, no kernel running %.3f ms" %
-          (tot * 1e-6 / steps, busy * 1e-6 / steps, ms - busy * 1e-6 / steps))
+    tot = sum(v[0] for v in per.values())
+    span = (t1 - t0) * 1e-6 / steps
+    print("# timed region: %d substeps, %.3f ms each in the trace (the bench line of the same run: %.3f); kernels in it: %d" % (steps, span, ms, len(win)))
+    print("# per substep: sum of kernel durations %.3f ms, device busy (union of the kernels' intervals) %.3f ms, no kernel running %.3f ms" %
+          (tot * 1e-6 / steps, busy * 1e-6 / steps, span - busy * 1e-6 / steps))
     print("%-28s %10s %12s %12s" % ("kernel", "launches", "ms per step", "us / launch"))
-    for t, a in sorted(per.items(), key=lambda kv: -kv[1][0]):
-        print("%-28s %10.1f %12.4f %12.2f" % (t, a[1] / steps, a[0] * 1e-6 / steps, a[0] * 1e-3 / a[1]))
-    print("# the last step, launch by launch: start [us from the first], duration [us], idle before it [us] (negative: it overlaps an earlier kernel), kernel")
-    last = [r for r in win if r[0] >= end - ms * 1e6]
+    for t, v in sorted(per.items(), key=lambda kv: -kv[1][0]):
+        print("%-28s %10.1f %12.4f %12.2f" % (t, v[1] / steps, v[0] * 1e-6 / steps, v[0] * 1e-3 / v[1]))
+    print("# the last substep of the timed region, launch by launch: start [us from the first], duration [us], idle before it [us] (negative: it overlaps an "
+          "earlier kernel), kernel")
+    last = [r for r in win if r[0] >= t1 - (t1 - t0) / steps]
     if last:
         z, hi = last[0][0], last[0][0]
-        for t0, t1, name in last:
-            print("%10.1f %9.1f %8.1f  %s" % ((t0 - z) * 1e-3, (t1 - t0) * 1e-3, (t0 - hi) * 1e-3, tag(name)))
-            hi = max(hi, t1)
+        for a, e, name in last:
+            print("%10.1f %9.1f %8.1f  %s" % ((a - z) * 1e-3, (e - a) * 1e-3, (a - hi) * 1e-3, tag(name)))
+            hi = max(hi, e)
 
 
 if __name__ == "__main__":
