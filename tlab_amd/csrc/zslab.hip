@@ -82,6 +82,7 @@ struct ZSlabArgs {
     double *fq;
     double fdte, fkco;
     int fscale, fnx, fny;
+    int dual;               // Burgers: both systems in one pass (z_solve2); 0 (TLAB_ZSLAB_DUAL=0): one after the other
 };
 
 // local solve of the slab system (sub-chunks through LDS), then phase handling. f: RHS in, y (phase A) / x (phase B) out
@@ -142,11 +143,90 @@ __device__ __forceinline__ void z_solve(double (&f)[M], const ZSysDev &sy, int k
     }
 }
 
-template <int M, int MODE, int PHASE>
+// Both systems of the Burgers operator in one pass (same arithmetic per system as z_solve, to the bit): the two recurrences of a chunk are
+// independent, so their dependent chains interleave and every barrier serves both -- three barriers per phase instead of six.
+template <int M, int PHASE>
+__device__ __forceinline__ void z_solve2(double (&f)[M], double (&g2)[M], const ZSysDev &sa, const ZSysDev &sb, int kmax, int w, int C, int lane, bool valid,
+                                         long long line, long long nlines, int isys, const ZSlabArgs &a, double *s_yl, double *s_r, double *s_x) {
+    const int row0 = w * M;
+    double fSa = 0.0, fSb = 0.0;
+    if (w == 0) { fSa = f[0]; f[0] = 0.0; fSb = g2[0]; g2[0] = 0.0; }
+    const double *La = sa.rowtab + row0, *Da = sa.rowtab + kmax + row0, *Ca = sa.rowtab + 2 * kmax + row0;
+    const double *Va = sa.rowtab + 3 * kmax + row0, *Wa = sa.rowtab + 4 * kmax + row0;
+    const double *Lb = sb.rowtab + row0, *Db = sb.rowtab + kmax + row0, *Cb = sb.rowtab + 2 * kmax + row0;
+    const double *Vb = sb.rowtab + 3 * kmax + row0, *Wb = sb.rowtab + 4 * kmax + row0;
+    double ga = 0.0, gb = 0.0;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        ga = f[p] + La[p] * ga;
+        gb = g2[p] + Lb[p] * gb;
+        f[p] = ga;
+        g2[p] = gb;
+    }
+    double ya = 0.0, yb = 0.0;
+#pragma unroll
+    for (int p = M - 1; p >= 1; --p) {
+        ya = f[p] * Da[p] + Ca[p] * ya;
+        yb = g2[p] * Db[p] + Cb[p] * yb;
+        f[p] = ya;
+        g2[p] = yb;
+    }
+    double *s_yl2 = s_yl + 8 * 64, *s_r2 = s_r + 8 * 64, *s_x2 = s_x + 2 * 64;
+    s_yl[w * 64 + lane] = f[M - 1];
+    s_yl2[w * 64 + lane] = g2[M - 1];
+    __syncthreads();
+    const int wm = (w + C - 1) % C, wp = (w + 1) % C;
+    s_r[w * 64 + lane] = f[0] - La[0] * s_yl[wm * 64 + lane] - Ca[0] * f[1];
+    s_r2[w * 64 + lane] = g2[0] - Lb[0] * s_yl2[wm * 64 + lane] - Cb[0] * g2[1];
+    __syncthreads();
+    double Xa = 0.0, Xra = 0.0, Xb = 0.0, Xrb = 0.0;
+    for (int q = 0; q < C; ++q) {
+        const double ra = s_r[q * 64 + lane], rb = s_r2[q * 64 + lane];
+        Xa += sa.ginv[w * C + q] * ra;
+        Xra += sa.ginv[wp * C + q] * ra;
+        Xb += sb.ginv[w * C + q] * rb;
+        Xrb += sb.ginv[wp * C + q] * rb;
+    }
+    f[0] = Xa;
+    g2[0] = Xb;
+#pragma unroll
+    for (int p = 1; p < M; ++p) {
+        f[p] = f[p] + Va[p] * Xa + Wa[p] * Xra;
+        g2[p] = g2[p] + Vb[p] * Xb + Wb[p] * Xrb;
+    }
+    if (PHASE == 1) {
+        if (valid) {
+            if (w == 0) {
+                a.head[(long long)isys * nlines + line] = fSa - sa.cS * f[1];
+                a.head[(long long)(isys + 1) * nlines + line] = fSb - sb.cS * g2[1];
+            }
+            if (w == C - 1) {
+                a.tail[(long long)isys * nlines + line] = f[M - 1];
+                a.tail[(long long)(isys + 1) * nlines + line] = g2[M - 1];
+            }
+        }
+    } else {
+        if (w == 0) { s_x[lane] = fSa - sa.cS * f[1]; s_x2[lane] = fSb - sb.cS * g2[1]; }
+        if (w == C - 1) { s_x[64 + lane] = f[M - 1]; s_x2[64 + lane] = g2[M - 1]; }
+        __syncthreads();
+        const double tla = valid ? a.tail_left[(long long)isys * nlines + line] : 0.0, tlb = valid ? a.tail_left[(long long)(isys + 1) * nlines + line] : 0.0;
+        const double hra = valid ? a.head_right[(long long)isys * nlines + line] : 0.0, hrb = valid ? a.head_right[(long long)(isys + 1) * nlines + line] : 0.0;
+        const double XSa = (s_x[lane] - sa.aS * tla) * sa.binv, XRa = (hra - sa.aSn * s_x[64 + lane]) * sa.binvn;
+        const double XSb = (s_x2[lane] - sb.aS * tlb) * sb.binv, XRb = (hrb - sb.aSn * s_x2[64 + lane]) * sb.binvn;
+        const double *Vra = sa.vw + row0, *Wra = sa.vw + kmax + row0, *Vrb = sb.vw + row0, *Wrb = sb.vw + kmax + row0;
+#pragma unroll
+        for (int p = 0; p < M; ++p) {
+            f[p] = f[p] + Vra[p] * XSa + Wra[p] * XRa;
+            g2[p] = g2[p] + Vrb[p] * XSb + Wrb[p] * XRb;
+        }
+    }
+}
+
+template <int M, int MODE, int PHASE, bool DUAL = false>
 __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
-    __shared__ double s_yl[8 * 64];
-    __shared__ double s_r[8 * 64];
-    __shared__ double s_x[2 * 64];
+    __shared__ double s_yl[(DUAL ? 2 : 1) * 8 * 64];      // DUAL: the second system's rows behind the first's (z_solve2)
+    __shared__ double s_r[(DUAL ? 2 : 1) * 8 * 64];
+    __shared__ double s_x[(DUAL ? 2 : 1) * 2 * 64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: coefficient rows become scalar loads
     const int C = blockDim.x >> 6;
@@ -203,14 +283,21 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
         for (int p = 0; p < M; ++p)
             x2[p] = a.c0_2 * e[p + 3] + e[p + 4] + e[p + 2] + a.c2_2 * (e[p + 5] + e[p + 1]) + a.c3_2 * (e[p + 6] + e[p]);
     }
-    z_solve<M, PHASE>(x1, a.y1, a.kmax, w, C, lane, valid, line, a.nlines, msg0, a, s_yl, s_r, s_x);
     double vl[(MODE == MODE_BURGERS && PHASE == 2) ? M : 1];
-    if constexpr (MODE == MODE_BURGERS && PHASE == 2) {   // issued before the second solve: its latency hides behind it
+    if constexpr (MODE == MODE_BURGERS && PHASE == 2) {   // issued before the solves: its latency hides behind them
         const double *pv = a.vel + (long long)row0 * rs;
 #pragma unroll
         for (int p = 0; p < M; ++p) { vl[p] = valid ? pv[base] : 0.0; pv += rs; }
     }
-    if constexpr (MODE == MODE_BURGERS) z_solve<M, PHASE>(x2, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, msg0 + 1, a, s_yl, s_r, s_x);
+    if constexpr (MODE == MODE_BURGERS) {
+        if constexpr (DUAL) z_solve2<M, PHASE>(x1, x2, a.y1, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, msg0, a, s_yl, s_r, s_x);
+        else {
+            z_solve<M, PHASE>(x1, a.y1, a.kmax, w, C, lane, valid, line, a.nlines, msg0, a, s_yl, s_r, s_x);
+            z_solve<M, PHASE>(x2, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, msg0 + 1, a, s_yl, s_r, s_x);
+        }
+    } else {
+        z_solve<M, PHASE>(x1, a.y1, a.kmax, w, C, lane, valid, line, a.nlines, msg0, a, s_yl, s_r, s_x);
+    }
     if constexpr (PHASE == 2) {
         if (!valid) return;
         if constexpr (MODE == MODE_BURGERS) {
@@ -397,6 +484,11 @@ void launch_m(int phase, int C, const ZSlabArgs &a, hipStream_t st) {
     const long long tiles = (a.nlines + 63) / 64;
     const long long nwg = (MODE == MODE_BURGERS) ? 8LL * a.nf * ((tiles + 7) / 8) : tiles;
     const dim3 grid((unsigned)nwg), block(64 * C);
+    if (MODE == MODE_BURGERS && a.dual) {
+        if (phase == 1) hipLaunchKernelGGL((k_zslab<M, MODE, 1, MODE == MODE_BURGERS>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_zslab<M, MODE, 2, MODE == MODE_BURGERS>), grid, block, 0, st, a);
+        return;
+    }
     if (phase == 1) hipLaunchKernelGGL((k_zslab<M, MODE, 1>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_zslab<M, MODE, 2>), grid, block, 0, st, a);
 }
@@ -437,6 +529,8 @@ ZSlabArgs base_args(const tlab_zslab_plan &P, int nx, int ny) {
     a.y1 = P.sys[0].dev();
     a.y2 = P.sys[1].dev();
     a.nf = 1;
+    static const int dual = [] { const char *e = getenv("TLAB_ZSLAB_DUAL"); return e ? atoi(e) : 1; }();
+    a.dual = dual;
     return a;
 }
 
