@@ -386,6 +386,8 @@ def main():
             d = SlabDns(LoopbackComm(args.loopback), x, y, z, **kw)
         if args.walls == "freeslip":
             d.set_bcs("freeslip", "freeslip", "neumann", "neumann")
+        if args.slab_driver == "native" and args.placement_trials > 0:
+            placement = d.redraw_arrays(pool=2 * (2 * (3 + args.nscal) + 9))
         state_fields = []
         for r in range(args.loopback):
             S = d.st[r]
@@ -440,6 +442,8 @@ def main():
             err = None
             try:
                 d = NativeSlabDns("rccl" if backend == "nccl" else "dist", x, y, z, **kw)
+                if args.placement_trials > 0:
+                    placement = d.redraw_arrays(pool=2 * (2 * (3 + args.nscal) + 9), seed=rank)
                 S = d.st[rank]
                 synthetic_fields(S["q"] + S["s"], nx, ny, nz, rank * d.kmax, d.kmax, rank)
             except Exception as e:      # noqa: BLE001
@@ -624,6 +628,8 @@ def main():
             "kernels_from": kernels_pass,
         }
         single = world == 1 and args.loopback <= 1 and not args.decomp
+        if not single and placement is not None:
+            out["placement"] = placement
         if single:
             out["placement"] = None if placement is None else dict(
                 placement, what="tlab_dns_place_arrays before the timed region: ms per substep of the allocations in the order the allocator gave them "

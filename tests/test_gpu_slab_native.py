@@ -81,6 +81,34 @@ def test_native_driver_is_bit_identical_to_the_python_driver(T, P, nx, ny, nz, b
     assert py.dilatation_bounds() == nat.dilatation_bounds()
 
 
+def test_redrawn_arrays_give_the_same_run_bit_for_bit(T):
+    """NativeSlabDns.redraw_arrays (what bench.py does before its timed region on slabs): the ranks' arrays move to other allocations, the fields come
+    along, and the run is the run without it."""
+    import torch
+    from tlab_amd.slab import NativeSlabDns
+    P, nx, ny, nz = 4, 64, 24, 256
+    x, y, z = _grid(nx, ny, nz)
+    f = _fields(x, y, z, 11)
+    kw = dict(nscal=1, visc=1.0 / 600.0, schmidt=(0.8,), yuniform=False, hyper_bc1_ext=REF_HYPER)
+    a, b = NativeSlabDns("loopback", x, y, z, size=P, **kw), NativeSlabDns("loopback", x, y, z, size=P, **kw)
+    for d in (a, b):
+        for i in range(3):
+            d.scatter("q", i, torch.from_numpy(f[i]).cuda())
+        d.scatter("s", 0, torch.from_numpy(f[3]).cuda())
+    a.substep_of_cycle(0, 2e-3); b.substep_of_cycle(0, 2e-3)          # mid-step: the tendencies carry values too
+    rep = b.redraw_arrays(pool=30, seed=5)
+    assert rep["pool"] == 30
+    ptrs = [t.data_ptr() for r in range(P) for name in ("q", "s", "hq", "hs", "txc") for t in b.st[r][name]]
+    assert len(set(ptrs)) == P * 17
+    for k in range(1, 5):
+        a.substep_of_cycle(k, 2e-3); b.substep_of_cycle(k, 2e-3)
+    torch.cuda.synchronize()
+    for name in ("q", "s", "hq", "hs"):
+        for r in range(P):
+            for u, v in zip(a.st[r][name], b.st[r][name]):
+                assert bool(torch.isfinite(v).all()) and torch.equal(u, v), (name, r)
+
+
 @pytest.mark.parametrize("bcs,fused,stages", [("freeslip", True, "2"), ("noslip", True, "2"), ("noslip", True, "1"), ("noslip", False, "2")])
 def test_native_driver_equals_single_domain_and_oracle(T, bcs, fused, stages, monkeypatch):
     """fused: the repack passes folded into the own x-transforms, v finished by the inverse transform of dp^/dy (no-slip walls)."""

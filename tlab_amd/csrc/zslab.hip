@@ -83,6 +83,7 @@ struct ZSlabArgs {
     double fdte, fkco;
     int fscale, fnx, fny;
     int dual;               // Burgers: both systems in one pass (z_solve2); 0 (TLAB_ZSLAB_DUAL=0): one after the other
+    int early;              // ... and the old tendencies requested ahead of the solves
 };
 
 // local solve of the slab system (sub-chunks through LDS), then phase handling. f: RHS in, y (phase A) / x (phase B) out
@@ -289,6 +290,17 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
 #pragma unroll
         for (int p = 0; p < M; ++p) { vl[p] = valid ? pv[base] : 0.0; pv += rs; }
     }
+    // DUAL phase B: the old tendencies are asked for before the solves too (TLAB_ZSLAB_EARLY=0: after them, as the one-system form does)
+    double oe[(MODE == MODE_BURGERS && PHASE == 2 && DUAL) ? M : 1];
+    bool early = false;
+    if constexpr (MODE == MODE_BURGERS && PHASE == 2 && DUAL) {
+        early = a.acc && a.early;
+        if (early) {
+            const double *po = out0 + (long long)row0 * rs;
+#pragma unroll
+            for (int p = 0; p < M; ++p) { oe[p] = valid ? __builtin_nontemporal_load(po + base) : 0.0; po += rs; }
+        }
+    }
     if constexpr (MODE == MODE_BURGERS) {
         if constexpr (DUAL) z_solve2<M, PHASE>(x1, x2, a.y1, a.y2, a.kmax, w, C, lane, valid, line, a.nlines, msg0, a, s_yl, s_r, s_x);
         else {
@@ -331,7 +343,12 @@ __global__ void __launch_bounds__(512) k_zslab(ZSlabArgs a) {
         }
         if (MODE == MODE_BURGERS) {     // tendencies: read once, written once -> non-temporal (as in k_htile; 2 % of the launch)
             double *const po0 = out0 + (long long)row0 * rs;
-            if (a.acc) {
+            if (early) {
+                if constexpr (DUAL) {
+#pragma unroll
+                    for (int p = 0; p < M; ++p) x1[p] = oe[p] + x1[p];
+                }
+            } else if (a.acc) {
                 double o[M];
                 const double *po = po0;
 #pragma unroll
@@ -531,6 +548,8 @@ ZSlabArgs base_args(const tlab_zslab_plan &P, int nx, int ny) {
     a.nf = 1;
     static const int dual = [] { const char *e = getenv("TLAB_ZSLAB_DUAL"); return e ? atoi(e) : 1; }();
     a.dual = dual;
+    static const int early = [] { const char *e = getenv("TLAB_ZSLAB_EARLY"); return e ? atoi(e) : 1; }();
+    a.early = early;
     return a;
 }
 
