@@ -358,6 +358,8 @@ def main():
         if args.slab_driver == "native":      # the C++ driver behind tlab_pencil_dns_* (csrc/pencil.cpp)
             d = NativePencilDns("rccl" if world > 1 else "loopback", npi, npk, x, y, z, **pkw)
             pranks = d.local_ranks
+            if args.placement_trials > 0:
+                placement = d.redraw_arrays(pool=2 * (2 * (3 + args.nscal) + 9), seed=rank)
         else:
             d = PencilDns(dist_comms(npi, npk) if world > 1 else loopback_comms(npi, npk), npi, npk, x, y, z, **pkw)
             pranks = d.world.local_ranks

@@ -123,6 +123,33 @@ def test_native_pencil_driver_is_bit_identical_to_the_python_driver(T, npi, npk,
     nat.close()
 
 
+def test_native_pencil_driver_with_redrawn_arrays_gives_the_same_run(T):
+    """NativePencilDns.redraw_arrays (tlab_amd/placement.py; what bench.py --decomp does before its timed region): other allocations, same run."""
+    import torch
+    from tlab_amd.pencil import NativePencilDns
+    npi, npk, nx, ny, nz = 2, 2, 32, 24, 16
+    x, y, z = grids(nx, ny, nz)
+    rng = np.random.default_rng(17)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * (Y - y[0]) / (y[-1] - y[0]))
+    fields = [((np.sin(X + k) * np.cos(2 * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(4)]
+    kw = dict(nscal=1, visc=1.0 / 300.0, schmidt=(0.7,), yuniform=False, hyper_bc1_ext=REF_HYPER)
+    a, b = NativePencilDns("loopback", npi, npk, x, y, z, **kw), NativePencilDns("loopback", npi, npk, x, y, z, **kw)
+    for d in (a, b):
+        for i in range(4):
+            d.scatter("q" if i < 3 else "s", i if i < 3 else i - 3, torch.from_numpy(fields[i]).cuda())
+    a.substep_of_cycle(0, 2e-3); b.substep_of_cycle(0, 2e-3)
+    b.redraw_arrays(pool=24, seed=2)
+    for k in range(1, 4):
+        a.substep_of_cycle(k, 2e-3); b.substep_of_cycle(k, 2e-3)
+    torch.cuda.synchronize()
+    for name in ("q", "s", "hq", "hs"):
+        for r in range(npi * npk):
+            for u, v in zip(a.st[r][name], b.st[r][name]):
+                assert float(v.abs().max()) > 0.0 and torch.equal(u, v), (name, r)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("npi,npk,ns", [(2, 2, 1), (2, 4, 2), (4, 1, 0), (1, 4, 3)])
 def test_native_pencil_driver_starts_its_transpositions_ahead_of_independent_launches(T, npi, npk, ns, monkeypatch):
     """The overlapped schedule of tlab_pencil_dns_rhs (csrc/pencil.cpp::rhs_overlapped; reference: rhs_global_incompressible_nbc.f90:135-382): between EVERY

@@ -442,6 +442,11 @@ class NativePencilDns:
             check(L.tlab_pencil_dns_bind(self._h, l, arr(S["q"]), arr(S["s"]), arr(S["hq"]), arr(S["hs"]), arr(S["txc"])), "tlab_pencil_dns_bind")
             self.st[r] = S
 
+    def redraw_arrays(self, pool=34, seed=0):
+        """As NativeSlabDns.redraw_arrays (tlab_amd/placement.py)."""
+        from .placement import redraw_rank_arrays
+        return redraw_rank_arrays(self, "tlab_pencil_dns_bind", pool=pool, seed=seed)
+
     def pro(self, r):
         return r % self.npi, r // self.npi
 

@@ -199,33 +199,10 @@ class NativeSlabDns:
             self.st[r] = S
 
     def redraw_arrays(self, pool=34, seed=0):
-        """Every local rank's q, s, hq, hs, txc move to allocations drawn at random from a pool of `pool` fresh ones per rank (the fields keep their
-        values).  Which allocations a many-stream kernel works on decides its rate (tlab_dns_place_arrays); arrays that were
-        allocated one after the other sit at the slow end more often than not, and on slabs the spread among random draws is small (0.7 % of the
-        substep against 1.3 % between the allocator's order and any of them: tools/placement_slab_probe.py), so this draws once instead of searching."""
-        import torch
-        rng = np.random.default_rng(seed)
-        L = load()
-        nroles = 2 * (3 + self.nscal) + 9
-        pool = max(int(pool), nroles)
-        for l, r in enumerate(self.local_ranks):
-            S = self.st[r]
-            dev = S["q"][0].device
-            cand = [torch.zeros(self.isize_txc, dtype=torch.float64, device=dev) for _ in range(pool)]
-            pick = [cand[i] for i in rng.permutation(pool)[:nroles]]
-            new, pos = {}, 0
-            for name, cnt, m in (("q", 3, self.n), ("s", self.nscal, self.n), ("hq", 3, self.n), ("hs", self.nscal, self.n), ("txc", 9, self.isize_txc)):
-                new[name] = [t[:m] for t in pick[pos:pos + cnt]]
-                pos += cnt
-                for a, b in zip(new[name], S[name]):
-                    a.copy_(b)
-            arr = lambda ts: (c_vp * max(len(ts), 1))(*[t.data_ptr() for t in ts])       # noqa: E731
-            check(L.tlab_slab_dns_bind(self._h, l, arr(new["q"]), arr(new["s"]), arr(new["hq"]), arr(new["hs"]), arr(new["txc"])), "tlab_slab_dns_bind")
-            self.st[r] = new
-            del cand, pick, S
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        return {"kind": "every rank's arrays drawn at random from a pool of %d fresh allocations (no search)" % pool, "pool": pool, "seed": int(seed)}
+        """Every local rank's q, s, hq, hs, txc move to allocations drawn at random from a pool of `pool` fresh ones per rank; the fields keep their
+        values (tlab_amd/placement.py; what bench.py does before its timed region on slabs)."""
+        from .placement import redraw_rank_arrays
+        return redraw_rank_arrays(self, "tlab_slab_dns_bind", pool=pool, seed=seed)
 
     def set_bcs(self, velocity_jmin="noslip", velocity_jmax="noslip", scalar_jmin="dirichlet", scalar_jmax="dirichlet"):
         """As Dns.set_bcs (dns.ini [BoundaryConditions] keywords, boundary_bcs.f90:102-190)."""
