@@ -29,7 +29,7 @@ def tag(name):
     m = re.match(r"k_(xline|rtile|htile)<(\d+), (\d+)", name)
     if m:
         return "k_%s<%s>" % (m.group(1), MODES.get(int(m.group(3)), m.group(3)))
-    m = re.match(r"k_zslab<(\d+), (\d+), (\d+)>", name)
+    m = re.match(r"k_zslab<(\d+), (\d+), (\d+)(?:, (?:true|false))?>", name)
     if m:
         return "k_zslab<%s,%s>" % (MODES.get(int(m.group(2)), m.group(2)), "A" if m.group(3) == "1" else "B")
     m = re.match(r"k_int1<(\d+), (\d+), (\d+)", name)
