@@ -18,25 +18,28 @@ def T():
     return T
 
 
-def _dns(nx, ny, nz, seed):
+def _dns(nx, ny, nz, seed, nscal=1):
     import torch
     from tlab_amd.dns import Dns, RKM_EXP3
     x, y, z = C.grids(nx, ny, nz, True)
-    d = Dns(x, y, z, nscal=1, visc=1.0 / 500.0, schmidt=(0.7,), yuniform=False, rkm_mode=RKM_EXP3, hyper_bc1_ext=0.1)
+    d = Dns(x, y, z, nscal=nscal, visc=1.0 / 500.0, schmidt=(0.7, 1.2)[:nscal], yuniform=False, rkm_mode=RKM_EXP3, hyper_bc1_ext=0.1)
     q0, s0 = C.init_fields(nx, ny, nz, x, y, z, seed)
+    s0 = (s0 + [0.5 * s0[0]])[:nscal]
     for t, a in zip(d.q + d.s, q0 + s0):
         t.copy_(torch.from_numpy(a))
     return d
 
 
-def test_placed_arrays_give_the_same_run_bit_for_bit(T):
+@pytest.mark.parametrize("nscal", [1, 0, 2])
+def test_placed_arrays_give_the_same_run_bit_for_bit(T, nscal):
     import torch
     nx, ny, nz = 256, 64, 32
-    a, b = _dns(nx, ny, nz, 5), _dns(nx, ny, nz, 5)
+    a, b = _dns(nx, ny, nz, 5, nscal), _dns(nx, ny, nz, 5, nscal)
+    nroles = 2 * (3 + nscal) + 9
     rep = b.place_arrays(pool=24, random_trials=3, dtime=1e-3, seed=3)
     after = [t.data_ptr() for t in b.q + b.s + b.hq + b.hs + b.txc]
-    assert len(set(after)) == 17                                                    # 17 distinct arrays out of the pool
-    assert rep["pool"] == 24 and rep["trials"] == 1 + 3 + 17
+    assert len(set(after)) == nroles                                                # distinct arrays out of the pool
+    assert rep["pool"] == 24 and rep["trials"] == 1 + 3 + nroles
     assert 0.0 < rep["ms_best"] <= rep["ms_first"] and rep["ms_best"] <= rep["ms_median"] <= rep["ms_worst"]
     for t, u in zip(a.q + a.s, b.q + b.s):                                          # the fields came along
         assert torch.equal(t, u)
