@@ -894,9 +894,16 @@ int tlab_dns_place_arrays(tlab_dns_t d, int npool, double *const *pool, const do
         }
         hipStream_t st = tlab_current_stream();
         const size_t fbytes = (size_t)d->nx * d->ny * d->nz * sizeof(double);
-        hipEvent_t e0, e1;
-        hk(hipEventCreate(&e0), "hipEventCreate");
-        hk(hipEventCreate(&e1), "hipEventCreate");
+        struct Events {      // released on every way out (a failing trial throws)
+            hipEvent_t a = nullptr, b = nullptr;
+            ~Events() {
+                if (a) (void)hipEventDestroy(a);
+                if (b) (void)hipEventDestroy(b);
+            }
+        } ev;
+        hk(hipEventCreate(&ev.a), "hipEventCreate");
+        hk(hipEventCreate(&ev.b), "hipEventCreate");
+        const hipEvent_t e0 = ev.a, e1 = ev.b;
         // one Runge-Kutta step of three substeps (first one on fresh tendencies, the others accumulating and scaling: the kernels of a real step)
         const double kdt[3] = {1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0}, kco[3] = {-5.0 / 9.0, -153.0 / 128.0, 1.0};
         auto trial = [&](const std::vector<int> &a) {
@@ -957,8 +964,6 @@ int tlab_dns_place_arrays(tlab_dns_t d, int npool, double *const *pool, const do
                 if (ms < bestms * 0.999) { bestms = ms; best = a; }
             }
         }
-        hk(hipEventDestroy(e0), "hipEventDestroy");
-        hk(hipEventDestroy(e1), "hipEventDestroy");
         for (int r = 0; r < nroles; ++r) assignment[r] = best[r];
         if (report) {
             std::vector<double> sorted = all;

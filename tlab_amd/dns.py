@@ -219,7 +219,10 @@ class Dns:
         assign = (ctypes.c_int * nroles)()
         rep = (ctypes.c_double * 5)()
         _use_torch_stream()
-        check(load().tlab_dns_place_arrays(self._h, pool, parr, sarr, float(dtime), int(random_trials), int(seed), assign, rep), "tlab_dns_place_arrays")
+        rc = load().tlab_dns_place_arrays(self._h, pool, parr, sarr, float(dtime), int(random_trials), int(seed), assign, rep)
+        if rc != 0:      # the driver stays usable: the pool in order
+            for i in range(nroles):
+                assign[i] = i
         a = [cand[i] for i in assign]
         ns = self.nscal
         self.q, self.s = [t[: self.n] for t in a[0:3]], [t[: self.n] for t in a[3:3 + ns]]
@@ -233,6 +236,7 @@ class Dns:
         del cand, state, a
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+        check(rc, "tlab_dns_place_arrays")
         return {"ms_first": rep[0], "ms_best": rep[1], "ms_median": rep[2], "ms_worst": rep[3], "trials": int(rep[4]), "pool": pool,
                 "seconds": time.perf_counter() - t0}
 
