@@ -407,7 +407,10 @@ def main():
         synthetic_fields(d.q + d.s, nx, ny, nz, 0, nz, rank)
         # which allocations play q, s, hq, hs, txc: searched at start-up, outside the timed region, like a plan (tlab_dns_place_arrays)
         if args.placement_trials > 0:
-            placement = d.place_arrays(pool=args.placement_pool, random_trials=args.placement_trials, dtime=dtime)
+            try:
+                placement = d.place_arrays(pool=args.placement_pool, random_trials=args.placement_trials, dtime=dtime)
+            except T.TlabError as e:      # the search failed inside the library: the arrays are the pool in order, the run goes on and says so
+                placement = {"error": str(e)}
         state_fields = d.q + d.s
 
         def substep(k):
@@ -633,7 +636,7 @@ def main():
         if not single and placement is not None:
             out["placement"] = placement
         if single:
-            out["placement"] = None if placement is None else dict(
+            out["placement"] = None if placement is None else placement if "error" in placement else dict(
                 placement, what="tlab_dns_place_arrays before the timed region: ms per substep of the allocations in the order the allocator gave them "
                                 "(ms_first), of the assignment the run uses (ms_best) and of the median / worst assignment tried; --placement-trials 0 skips it")
         if single:

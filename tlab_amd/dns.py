@@ -213,7 +213,17 @@ class Dns:
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info()
         pool = max(nroles, min(int(pool), int(0.7 * free / (8.0 * m))))
-        cand = [torch.zeros(m, dtype=torch.float64, device=dev) for _ in range(pool)]
+        cand = []
+        try:
+            for _ in range(pool):
+                cand.append(torch.zeros(m, dtype=torch.float64, device=dev))
+        except RuntimeError:      # out of memory: search among what there is (at least the roles themselves must fit, as they did before)
+            while len(cand) > nroles and len(cand) % 4:
+                cand.pop()
+            torch.cuda.empty_cache()
+            if len(cand) < nroles:
+                raise
+            pool = len(cand)
         parr = (c_vp * pool)(*[t.data_ptr() for t in cand])
         sarr = (c_vp * len(state))(*[t.data_ptr() for t in state])
         assign = (ctypes.c_int * nroles)()
