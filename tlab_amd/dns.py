@@ -218,7 +218,7 @@ class Dns:
             for _ in range(pool):
                 cand.append(torch.zeros(m, dtype=torch.float64, device=dev))
         except RuntimeError:      # out of memory: search among what there is (at least the roles themselves must fit, as they did before)
-            while len(cand) > nroles and len(cand) % 4:
+            for _ in range(min(4, max(0, len(cand) - nroles))):      # some headroom for what else the run allocates
                 cand.pop()
             torch.cuda.empty_cache()
             if len(cand) < nroles:
