@@ -60,6 +60,9 @@ def main():
             if len(p) >= 3:
                 ks[p[0]] = float(p[2]) / max(int(p[1]), 1)
         print("%-34s ms_per_substep %.3f  " % (label, ms) + "  ".join("%s %.3f" % (k.replace("BURGERS", "B"), ks.get(k, float("nan"))) for k in names), flush=True)
+        if os.environ.get("PLACEMENT_LOG"):
+            with open(os.environ["PLACEMENT_LOG"], "a") as f:
+                f.write(json.dumps({"label": label, "ms": ms, "ptr": [int(a.data_ptr()) for a in arrs[:17]], "kernels": ks}) + "\n")
         return ms
 
     print(buf.value.decode()[:0], end="")
@@ -68,7 +71,7 @@ def main():
     res = []
     for t in range(trials):
         idx = list(range(17)) if t == 0 else [int(i) for i in rng.permutation(P)[:17]]
-        ms = run([pool[i] for i in idx], "pool in allocation order" if t == 0 else "random assignment %d" % t)
+        ms = run([pool[i] for i in idx], "pool in allocation order" if t == 0 else "random assignment %d %s" % (t, ",".join(str(i) for i in idx)))
         res.append((ms, idx))
     res.sort()
     print("best %.3f  median %.3f  worst %.3f ms per substep over %d assignments" % (res[0][0], res[len(res) // 2][0], res[-1][0], len(res)))
