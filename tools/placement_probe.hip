@@ -221,6 +221,79 @@ int main(int argc, char **argv) {
         report(name, a, bytes);
         for (int k = 0; k < 13; ++k) { CK(hipMemUnmap(a[k], bytes)); CK(hipMemAddressFree(a[k], bytes)); CK(hipMemRelease(h[k])); }
     }
+    // (d) ONE virtual range for all 13 arrays (what a host's 2-D array q(isize_field, 3) is) backed by 13 physical allocations of their own:
+    // created one after the other / with throw-away allocations of irregular sizes created in between (released afterwards) / in shuffled order
+    for (int variant = 0; variant < 6; ++variant) {
+        std::vector<hipMemGenericAllocationHandle_t> h(13), junk;
+        std::vector<void *> a(13);
+        void *base = nullptr;
+        if (hipMemAddressReserve(&base, 13 * bytes, 0, nullptr, 0) != hipSuccess) { printf("hipMemAddressReserve of 13 arrays failed\n"); break; }
+        unsigned seed = 777u + (unsigned)variant;
+        auto rnd = [&] { seed = seed * 1664525u + 1013904223u; return seed >> 10; };
+        bool okay = true;
+        for (int k = 0; k < 13 && okay; ++k) {
+            if (variant >= 1 && variant <= 3) {      // a throw-away allocation of 2 .. 510 MiB in front of every array
+                hipMemGenericAllocationHandle_t j;
+                const size_t jb = ((size_t)(1 + rnd() % 255)) << 21;
+                if (hipMemCreate(&j, jb, &prop, 0) == hipSuccess) junk.push_back(j);
+            }
+            okay = hipMemCreate(&h[k], bytes, &prop, 0) == hipSuccess;
+        }
+        if (!okay) { printf("hipMemCreate failed\n"); break; }
+        std::vector<int> order(13);
+        for (int k = 0; k < 13; ++k) order[k] = k;
+        if (variant >= 4)
+            for (int k = 12; k > 0; --k) std::swap(order[k], order[rnd() % (k + 1)]);
+        for (int k = 0; k < 13; ++k) {
+            a[k] = (char *)base + (size_t)k * bytes;
+            CK(hipMemMap(a[k], bytes, 0, h[order[k]], 0));
+        }
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        CK(hipMemSetAccess(base, 13 * bytes, &acc, 1));
+        const char *names[6] = {"one range, 13 physical allocations in order", "one range, irregular throw-aways in between (1)", "one range, irregular throw-aways in between (2)",
+                                "one range, irregular throw-aways in between (3)", "one range, physical allocations shuffled (1)", "one range, physical allocations shuffled (2)"};
+        report(names[variant], a, bytes);
+        for (int k = 0; k < 13; ++k) CK(hipMemUnmap(a[k], bytes));
+        CK(hipMemAddressFree(base, 13 * bytes));
+        for (auto x : h) CK(hipMemRelease(x));
+        for (auto x : junk) CK(hipMemRelease(x));
+    }
+    // (e) the same with the arrays (1 GiB + pad) apart in the VIRTUAL range -- the physical allocations are what they are
+    for (size_t padm : {(size_t)0, (size_t)1, (size_t)2, (size_t)3, (size_t)5, (size_t)8, (size_t)13, (size_t)16, (size_t)21, (size_t)32, (size_t)64, (size_t)100, (size_t)257}) {
+        const size_t stride = bytes + (padm << 21);
+        std::vector<hipMemGenericAllocationHandle_t> h(13);
+        std::vector<void *> a(13);
+        void *base = nullptr;
+        if (hipMemAddressReserve(&base, 13 * stride, 0, nullptr, 0) != hipSuccess) { printf("hipMemAddressReserve failed\n"); break; }
+        bool okay = true;
+        for (int k = 0; k < 13 && okay; ++k) okay = hipMemCreate(&h[k], bytes, &prop, 0) == hipSuccess;
+        if (!okay) { printf("hipMemCreate failed\n"); break; }
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        for (int k = 0; k < 13; ++k) {
+            a[k] = (char *)base + (size_t)k * stride;
+            CK(hipMemMap(a[k], bytes, 0, h[k], 0));
+            CK(hipMemSetAccess(a[k], bytes, &acc, 1));
+        }
+        char name[96];
+        snprintf(name, sizeof name, "one range, arrays 1 GiB + %zu x 2 MiB apart", padm);
+        report(name, a, bytes);
+        for (int k = 0; k < 13; ++k) CK(hipMemUnmap(a[k], bytes));
+        CK(hipMemAddressFree(base, 13 * stride));
+        for (auto x : h) CK(hipMemRelease(x));
+    }
+    {   // one hipMalloc for all 13
+        char *arena;
+        if (hipMalloc((void **)&arena, 13 * bytes) == hipSuccess) {
+            std::vector<void *> a(13);
+            for (int k = 0; k < 13; ++k) a[k] = arena + (size_t)k * bytes;
+            report("one hipMalloc for all 13 arrays", a, bytes);
+            CK(hipFree(arena));
+        }
+    }
     {   // (a) again, at the end: has the state of the process changed?
         std::vector<void *> a(13);
         for (auto &p : a) CK(hipMalloc(&p, bytes));
