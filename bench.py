@@ -47,6 +47,28 @@ def synthetic_fields(targets, nx, ny, nz_total, k0, kmax, seed):
         t.copy_(((sh + 0.1 * (2.0 * torch.rand(kmax, ny, nx, dtype=torch.float64, device="cuda", generator=gen) - 1.0)) * wall).reshape(-1))
 
 
+def substep_traffic(kernels, kernels_substeps, per_launch, ms_per_step, grid, dominant_traffic=None):
+    """HBM bytes one substep really moves: PMC-measured bytes per launch (profiles/traffic.json) x the launches of ONE substep.  `kernels` is a
+    profile table whose `calls` are sums over `kernels_substeps` substeps (the table's own pass, not necessarily the timed region: round 5 divided
+    a 6-substep table by --steps and under-reported 3.3 x).  rocFFT's transforms are counted at their algorithmic 2 x 8 B per point of the
+    complex field.  A substep cannot move less than one launch of its dominant kernel: `consistent` says so."""
+    nx, ny, nz = grid
+    per_launch = {k: v for k, v in per_launch.items() if not k.startswith("_")}
+    moved, missing = 0.0, []
+    for k in kernels:
+        per = per_launch.get(k["kernel"])
+        if per is None and k["kernel"] == "rocfft":
+            per = 2.0 * 8.0 * (nx + 2) * ny * nz
+        if per is None:
+            missing.append(k["kernel"])
+            continue
+        moved += per * k["calls"] / float(kernels_substeps)
+    return {"hbm_bytes_per_step": moved, "GBps": moved / (ms_per_step * 1e-3) / 1e9, "frac_of_peak": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernels_without_counter_data": missing, "substeps_in_the_kernel_table": kernels_substeps,
+            "consistent": None if dominant_traffic is None else bool(moved >= dominant_traffic),
+            "what": "sum over the kernels of a step of the HBM bytes per launch measured with rocprofv3 PMC counters (profiles/traffic.json)"}
+
+
 def cpu_baseline(n, nscal, budget_s=25.0):
     """Times substeps of the C + OpenMP restatement of the reference's CPU algorithm (oracle/tlab_cpu.c: explicit transposes, separate
     right-hand-side and Thomas passes, per-mode pentadiagonal solves; validated against the golden vectors in tests/test_cpu_baseline.py)
@@ -562,6 +584,7 @@ def main():
     timed_rows = profile_rows()
     dom = next((k for k in timed_rows if k["alg_bytes_per_launch"] > 1e6), None)
     kernels, kernels_pass = timed_rows, "the timed region (every launch timed)"
+    kernels_substeps = args.steps          # the number of substeps the table `kernels` covers (its `calls` are sums over them)
     if dom_tag is not None:      # the table of all kernels: a pass of its own, every launch timed, same fields (every rank takes part in the exchanges)
         npass = min(args.steps, 6)
         L.tlab_profile_filter(None)
@@ -572,6 +595,7 @@ def main():
         torch.cuda.synchronize()
         L.tlab_profile_enable(0)
         kernels = profile_rows()
+        kernels_substeps = npass
         kernels_pass = "%d substeps after the timed region with every launch timed (in the timed region only %s carries events)" % (npass, dom_tag)
         finite = finite and all(bool(torch.isfinite(t).all()) for t in state_fields)
     if rank == 0:
@@ -698,19 +722,8 @@ def main():
                 except Exception:
                     tj = None
             if tj:
-                moved, missing = 0.0, []
-                tj = {k2: v for k2, v in tj.items() if not k2.startswith("_")}
-                for k in kernels:
-                    per = tj.get(k["kernel"])
-                    if per is None and k["kernel"] == "rocfft":
-                        per = 2.0 * 8.0 * (nx + 2) * ny * nz
-                    if per is None:
-                        missing.append(k["kernel"])
-                        continue
-                    moved += per * k["calls"] / args.steps
-                out["substep_traffic"] = {"hbm_bytes_per_step": moved, "GBps": moved / (ms_per_step * 1e-3) / 1e9,
-                                          "frac_of_peak": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels_without_counter_data": missing,
-                                          "what": "sum over the kernels of a step of the HBM bytes per launch measured with rocprofv3 PMC counters (profiles/traffic.json)"}
+                out["substep_traffic"] = substep_traffic(kernels, kernels_substeps, tj, ms_per_step, (nx, ny, nz),
+                                                         None if out["roofline"] is None else out["roofline"]["traffic"])
         if single and args.walls == "noslip" and not args.no_freeslip_leg:
             # the same workload with the reference's DEFAULT walls (VelocityJmin/Jmax = freeslip, Neumann scalars: BOUNDARY_BCS_NEUMANN_Y in the tail
             # of the substep), timed the same way right after the headline: the headline keeps no-slip / Dirichlet walls, this key says what the default costs

@@ -88,6 +88,27 @@ subroutine ref_fdm_create(idir, n, nodes, periodic, uniform, mode1, mode2) bind(
 end subroutine ref_fdm_create
 
 !########################################################################
+! The reference's routines on a plan whose second-derivative right-hand-side table is GIVEN (the from_arrays route of the product, on the reference's
+! side).  Why: Create_System_2der reads coef_bc1(7) of a 6-element array for the "extended rhs stencil" entry of the two wall rows
+! (fdm_com2_jacobian.f90:224 with icmax = 4); the flang build finds coef_bc2(1) = 0.1 there (DESIGN.md section 2, defect 1).  The consistent closure
+! (0.0, what bench.py times) changes that entry AND, through the second-order Jacobian FDM_CreatePlan derives with the very scheme (fdm.f90:216-224),
+! the three Jacobian-correction columns rhs(:, 8:10) -- so the whole table g%der2%rhs(n, 12) and jac(n, 3) are replaced (by the numpy oracle's, which is
+! bitwise the reference's at the closure the reference can compute: tests/test_oracle_derivs.py).  FDM_Der2_Solve hands g%rhs itself to MatMul_7d_sym
+! and MatMul_3d_add (fdm_derivative.f90:436-440); the LU comes from lhs, which does not depend on the closure.
+subroutine ref_fdm_set_der2_rhs(idir, n, ncols, rhs, jac) bind(C, name='ref_fdm_set_der2_rhs')
+    use iso_c_binding
+    use TLab_Constants, only: wp, wi
+    use ref_state
+    implicit none
+    integer(c_int), value :: idir, n, ncols
+    real(c_double), intent(in) :: rhs(n, ncols), jac(n, 3)
+
+    if (n /= gp(idir)%size .or. ncols /= size(gp(idir)%der2%rhs, 2)) error stop 'ref_fdm_set_der2_rhs: shape'
+    gp(idir)%der2%rhs(:, :) = rhs(:, :)
+    gp(idir)%jac(:, :) = jac(:, :)
+end subroutine ref_fdm_set_der2_rhs
+
+!########################################################################
 ! integer queries: 1 nb_diag1(1), 2 nb_diag1(2), 3 nb_diag2(1), 4 nb_diag2(2), 5 need_1der, 6 size(lu1,2), 7 size(lu2,2), 8 size(rhs2,2)
 integer(c_int) function ref_fdm_info(idir, what) bind(C, name='ref_fdm_info')
     use iso_c_binding

@@ -48,9 +48,36 @@ def init(nx, ny, nz):
     lib().ref_init(nx, ny, nz)
 
 
-def fdm_create(idir, nodes, periodic, uniform, mode1=6, mode2=7):
+def fdm_create(idir, nodes, periodic, uniform, mode1=6, mode2=7, hyper_bc1_ext=None):
+    """FDM_CreatePlan of the reference.  hyper_bc1_ext: None = the plan as the reference builds it (the flang build reads 0.1 out of bounds for the
+    extended wall-row entry of the default second derivative); a number = the second-derivative right-hand-side table and the Jacobians of the numpy
+    oracle's plan at that closure written into the reference's plan (ref_driver.f90::ref_fdm_set_der2_rhs; every other table is checked to be the
+    reference's own to the bit), so that the reference's solvers run on the closure the reference cannot build."""
     nodes = np.ascontiguousarray(nodes, dtype=np.float64)
     lib().ref_fdm_create(idir, nodes.shape[0], nodes, int(periodic), int(uniform), mode1, mode2)
+    if hyper_bc1_ext is not None and not periodic and mode2 == 7:
+        import ctypes
+        from . import tlab_oracle as O
+        n = nodes.shape[0]
+        o = O.FdmPlan(nodes, periodic, uniform, mode1, mode2, hyper_bc1_ext=hyper_bc1_ext)
+        a = fdm_arrays(idir, n)
+        for mine, theirs in ((o.der1.lhs, a["lhs1"]), (o.der1.rhs, a["rhs1"]), (o.der1.lu, a["lu1"]), (o.der2.lhs, a["lhs2"]), (o.der2.lu, a["lu2"]), (o.jac[:, 0], a["jac"][:, 0])):
+            theirs = theirs[:, :mine.shape[1]] if mine.ndim == 2 else theirs
+            # bitwise on the plain build; the build with fused multiply-adds rounds its own tables differently (<= 1e-14): there the written table is
+            # the plain build's, i.e. the two builds of a closure-0.0 yardstick share this one table and differ in everything else
+            if not np.array_equal(mine, theirs) and not np.abs(mine - theirs).max() <= 1e-13 * np.abs(theirs).max():
+                raise RuntimeError("the numpy plan at closure %r differs from the reference's in a table the closure does not touch" % hyper_bc1_ext)
+        rhs = np.asfortranarray(o.der2.rhs, dtype=np.float64)
+        jac = np.asfortranarray(o.jac, dtype=np.float64)
+        if rhs.shape != a["rhs2"].shape:
+            raise RuntimeError("der2 rhs table: %r against the reference's %r" % (rhs.shape, a["rhs2"].shape))
+        f = lib().ref_fdm_set_der2_rhs
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        f.restype = None
+        f(idir, n, rhs.shape[1], rhs.ctypes.data, jac.ctypes.data)
+        b = fdm_arrays(idir, n)
+        if not (np.array_equal(b["rhs2"], o.der2.rhs) and np.array_equal(b["jac"], o.jac)):
+            raise RuntimeError("ref_fdm_set_der2_rhs did not take")
 
 
 def fdm_arrays(idir, n):

@@ -23,15 +23,17 @@ _GRID = [None]
 
 
 class RefComposedDns(DnsOracle):
-    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True):
-        super().__init__(x, y, z, nscal=nscal, visc=visc, schmidt=schmidt, yuniform=yuniform)      # the numpy plans: lambda of the modes, singular flags, norm
-        key = (len(x), len(y), len(z), float(np.sum(x)), float(np.sum(y)), float(np.sum(z)), bool(yuniform))
+    def __init__(self, x, y, z, nscal=1, visc=1.0 / 5000.0, schmidt=(1.0,), yuniform=True, hyper_bc1_ext=None):
+        # hyper_bc1_ext: None = the reference's plans as it builds them; a number = the one wall-row entry of the default second derivative that the
+        # reference reads out of bounds replaced in ITS plan (ref_driver.f90::ref_fdm_set_hyper_bc1_ext) -- the reference's routines on the closure 0.0
+        super().__init__(x, y, z, nscal=nscal, visc=visc, schmidt=schmidt, yuniform=yuniform, hyper_bc1_ext=hyper_bc1_ext)      # the numpy plans: lambda of the modes, singular flags, norm
+        key = (len(x), len(y), len(z), float(np.sum(x)), float(np.sum(y)), float(np.sum(z)), bool(yuniform), hyper_bc1_ext)
         if _GRID[0] is not None and _GRID[0] != key:
             raise RuntimeError("the reference library holds one grid per process")
         if _GRID[0] is None:
             R.init(self.nx, self.ny, self.nz)
             R.fdm_create(1, x, True, True)
-            R.fdm_create(2, y, False, yuniform)
+            R.fdm_create(2, y, False, yuniform, hyper_bc1_ext=hyper_bc1_ext)
             if self.nz > 1:
                 R.fdm_create(3, z, True, True)
             _GRID[0] = key

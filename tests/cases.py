@@ -60,10 +60,13 @@ def rk_sched(dtime, nsub=2):
 
 
 # ---- tests/test_gpu_rhs.py ----
-def rhs_substep(nx, ny, nz, stretch):
+def rhs_substep(nx, ny, nz, stretch, hyper=None):
+    """hyper: None = the wall closure the reference as compiled reads (0.1); 0.0 = the consistent closure bench.py times -- its reference-made figures
+    come from the reference's own routines on ITS plan with that one entry replaced (oracle/ref_driver.f90::ref_fdm_set_hyper_bc1_ext)"""
     x, y, z = grids(nx, ny, nz, stretch)
     q0, s0 = init_fields(nx, ny, nz, x, y, z, 3)
-    return dict(key="rhs.substep[%d-%d-%d-%s]" % (nx, ny, nz, stretch), x=x, y=y, z=z, nscal=1, visc=1.0 / 800.0, sc=(0.7,), yuniform=not stretch, walls=None,
+    key = "rhs.substep[%d-%d-%d-%s]" % (nx, ny, nz, stretch) if hyper is None else "rhs.substep[%d-%d-%d-%s-closure%g]" % (nx, ny, nz, stretch, hyper)
+    return dict(key=key, x=x, y=y, z=z, nscal=1, visc=1.0 / 800.0, sc=(0.7,), yuniform=not stretch, walls=None, hyper=hyper,
                 q0=q0, s0=s0, sched=rk_sched(2e-3))
 
 
@@ -142,7 +145,8 @@ def make_oracle_factory(case, cls=None):
         return [DNS_BCS_DIRICHLET] * 3 if kind == "noslip" else [DNS_BCS_NEUMANN, DNS_BCS_DIRICHLET, DNS_BCS_NEUMANN]
 
     def make():
-        o = cls(case["x"], case["y"], case["z"], nscal=case["nscal"], visc=case["visc"], schmidt=case["sc"], yuniform=case["yuniform"])
+        kw = {} if case.get("hyper") is None else {"hyper_bc1_ext": case["hyper"]}
+        o = cls(case["x"], case["y"], case["z"], nscal=case["nscal"], visc=case["visc"], schmidt=case["sc"], yuniform=case["yuniform"], **kw)
         if case["walls"]:
             w = case["walls"]
             o.flow_jmin, o.flow_jmax = vel(w[0]), vel(w[1])
@@ -161,6 +165,8 @@ def registry():
         R[probe_key] = (fn, a, k)
     for g in [(32, 40, 16, True), (64, 32, 32, False), (256, 64, 64, True)]:
         add(rhs_substep, *g)
+    for g in [(32, 40, 16, True), (64, 32, 32, False), (256, 64, 64, True)]:      # the same from the consistent wall closure (what bench.py times)
+        add(rhs_substep, *g, hyper=0.0)
     for vel, scal in [(("freeslip", "freeslip"), ("neumann", "dirichlet")), (("noslip", "freeslip"), ("dirichlet", "neumann"))]:
         add(rhs_neumann, vel, scal)
     for vel, scal in [(("freeslip", "freeslip"), ("neumann", "neumann")), (("freeslip", "noslip"), ("dirichlet", "neumann"))]:

@@ -482,7 +482,7 @@ def test_poisson_dirichlet_marching_route_on_chunked_plans(T):
 @pytest.mark.parametrize("nx,ny,nz,stretch,ibc,alphas", [
     (32, 40, 16, True, 3, (-7.5,)), (16, 24, 1, True, 0, (-120.0,)), (64, 33, 8, False, 3, (-2.0e3,)), (128, 64, 32, True, 0, (-0.5, -40.0)),
     (32, 512, 8, True, 3, (-1.0e4, -3.0)), (16, 256, 8, False, 3, (-1.0, -2.0, -3.0, -4.0, -5.0, -1.0))])
-@pytest.mark.gpu_extra
+@pytest.mark.gpu
 def test_factorized_helmholtz_vs_oracle(T, nx, ny, nz, stretch, ibc, alphas):
     """OPR_Helmholtz_FourierXZ_Factorize (opr_elliptic.f90:466-557) on the plan of OPR_Poisson: per mode OPR_ODE2_Factorize_NN / _DD with
     sqrt(lambda - alpha).  Chunked (ny % 8 == 0) and marching (ny = 33) plans; the last case walks through more alphas than the plan keeps

@@ -98,7 +98,7 @@ def test_marching_and_chunked_direct_solvers_agree(T, ibc):
     assert not np.array_equal(out["0"], out["1"])         # (two different kernels did run)
 
 
-@pytest.mark.gpu_extra
+@pytest.mark.gpu
 @pytest.mark.parametrize("nx,ny,nz,ibc,alpha", [(16, 24, 8, 0, -12.5), (16, 64, 8, 3, -400.0), (32, 128, 8, 1, -3.0), (16, 64, 1, 2, -50.0), (64, 512, 16, 0, -1.0e4)])
 def test_helmholtz_direct_matches_oracle(T, nx, ny, nz, ibc, alpha):
     import torch
@@ -114,7 +114,7 @@ def test_helmholtz_direct_matches_oracle(T, nx, ny, nz, ibc, alpha):
     assert rel_err(a.cpu().numpy(), a_ref) <= TOL, rel_err(a.cpu().numpy(), a_ref)
 
 
-@pytest.mark.gpu_extra
+@pytest.mark.gpu
 def test_factorized_helmholtz_refuses_mixed_boundary_types(T):
     """OPR_Helmholtz_FourierXZ_Factorize knows BCS_NN and BCS_DD (opr_elliptic.f90:524-532)."""
     import torch

@@ -61,7 +61,7 @@ def test_substep_vs_oracle(T, nx, ny, nz, stretch, hyper, fuse):
     import torch
     from tlab_amd.dns import Dns
     from oracle.tlab_oracle_rhs import DnsOracle
-    case = C.rhs_substep(nx, ny, nz, stretch)
+    case = C.rhs_substep(nx, ny, nz, stretch, hyper=None if hyper == REF_HYPER else hyper)
     x, y, z, visc, sc, q0, s0, sched = (case[k] for k in ("x", "y", "z", "visc", "sc", "q0", "s0", "sched"))
     d = Dns(x, y, z, nscal=1, visc=visc, schmidt=sc, yuniform=not stretch, hyper_bc1_ext=hyper)
     d.set_fusion(fuse)
@@ -74,7 +74,7 @@ def test_substep_vs_oracle(T, nx, ny, nz, stretch, hyper, fuse):
                            q0, s0, sched, nsamples=2)
     for k, (dte, kco, scale) in enumerate(sched):
         d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(dte, kco, scale)
-        check_state(d, B, S, k, key=case["key"])      # (the reference-made figure is that of the closure 0.1 the reference as compiled reads; the case with 0.0 differs from it in two wall rows of one operator)
+        check_state(d, B, S, k, key=case["key"])      # (the reference-made figure is that of the SAME closure: for 0.0 the reference's routines on its own plan with the one out-of-bounds entry replaced, tests/cases.py)
 
 
 @pytest.mark.parametrize("fuse", [True, False])
@@ -572,7 +572,6 @@ def background(y):
     return rb, 1.0 / rb
 
 
-@pytest.mark.gpu_extra
 @pytest.mark.parametrize("nx,ny,nz,stretch", [(32, 40, 16, True), (64, 64, 64, False), (256, 64, 32, True)])
 def test_anelastic_burgers_operators_vs_oracle(T, nx, ny, nz, stretch):
     """OPR_Burgers_X/Y/Z with rhoinv active: generic kernels at (32, 40, 16), the fast derivative kernels at the other sizes."""

@@ -61,3 +61,18 @@ def test_tags_follow_the_kernel_templates():
     assert P.tag("void tlab::k_zslab<16, 1, 1>(tlab::ZSlabArgs)") == "k_zslab<P1,A>"
     assert P.tag("void tlab::k_xline<8, 4, 1, 1, 1, 256, true, true, 2>(tlab::XLineArgs)") == "k_xline<BURGERS>"
     assert P.tag("void tlab::k_ptile<32, 32, 16, true, false>(tlab::RTileArgs, long long)") == "k_ptile<BURGERS+div>"
+
+
+def test_substep_traffic_divides_by_the_substeps_of_its_own_table():
+    """bench.py's `substep_traffic`: the kernel table may come from a pass of 6 substeps while --steps is 20 (round 5 divided by --steps and
+    under-reported the substep's HBM bytes 3.3 x); a substep moves at least one launch of its dominant kernel."""
+    sys.path.insert(0, ROOT)
+    import bench as B
+    per = {"_meta": {"x": 1}, "k_a": 15.0e9, "k_b": 2.0e9}
+    kernels = [{"kernel": "k_a", "calls": 6}, {"kernel": "k_b", "calls": 30}, {"kernel": "rocfft", "calls": 6}, {"kernel": "k_unknown", "calls": 6}]
+    t = B.substep_traffic(kernels, 6, per, 16.0, (512, 512, 512), dominant_traffic=15.0e9)
+    fft = 2.0 * 8.0 * 514 * 512 * 512
+    assert abs(t["hbm_bytes_per_step"] - (15.0e9 + 5 * 2.0e9 + fft)) < 1.0
+    assert t["consistent"] is True and t["kernels_without_counter_data"] == ["k_unknown"] and t["substeps_in_the_kernel_table"] == 6
+    wrong = B.substep_traffic(kernels, 20, per, 16.0, (512, 512, 512), dominant_traffic=15.0e9)       # the round-5 mistake is visible in the line
+    assert wrong["consistent"] is False

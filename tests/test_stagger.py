@@ -120,7 +120,6 @@ def test_interpolatory_type_without_tables_is_refused(dev):
         device_partial(1, T.OPR_P0_INT_VP, g, n, 2, 2, torch.zeros(n * 4, dtype=torch.float64, device="cuda"))
 
 
-@pytest.mark.gpu_extra
 @pytest.mark.gpu
 @pytest.mark.parametrize("fuse", [True, False])
 def test_staggered_substeps_vs_oracle(dev, fuse):
