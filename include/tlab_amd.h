@@ -325,6 +325,25 @@ int tlab_dns_set_fusion(tlab_dns_t d, int on);
  * tell the driver: the next tlab_rhs_global_incompressible_1 / tlab_time_substep_incompressible_explicit treats them as zero (its first
  * operator launch overwrites instead of accumulating), whatever they contain. */
 int tlab_dns_begin_step(tlab_dns_t d);
+
+/* ---- The tail of the substep for a host whose time loop is NOT patched (csrc/deferred.cpp) ---------------------------------------------------
+ * tools/dns/time.f90 calls RHS_GLOBAL_INCOMPRESSIBLE_1() (:612), then DAXPY(n, dte, hq(1,is), 1, q(1,is), 1) per field (:649-660) and, in every
+ * substep but the last, DSCAL(n, kco, hq(1,is), 1) per field (:279-293); `hq = 0 ; hs = 0` opens a step (:212-216).  Executed one by one the BLAS
+ * calls are 2 (3 + ns) passes over the fields.  With tlab_deferred_enable(1) the entry points below only RECORD: when the recorded sequence is
+ * exactly that of time.f90 (the tendencies and states the RHS was given, dte as the factor, one kco for all) the library runs ONE
+ * tlab_time_substep_incompressible_explicit(dte, kco, scale) -- the call of the patched host, bit for bit -- and the
+ * zero fills become tlab_dns_begin_step.  Anything else is executed literally in the order it came.  A recorded sequence runs before any other
+ * launch of the library (every entry point that enqueues work, tlab_sync, the copies, tlab_free flush first).  NOT covered: host statements that
+ * read a device array directly without a call into the library -- call tlab_deferred_flush() (or tlab_sync()) before them.  Off by default:
+ * the four operations then execute immediately (tlab_rhs_global_incompressible_1, tlab_pw_rk_update, tlab_pw_scale, tlab_pw_fill). */
+int tlab_deferred_enable(int on);
+int tlab_deferred_rhs(tlab_dns_t d, double dte, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc);
+int tlab_deferred_axpy(long long n, double a, const double *x, double *y);      /* DAXPY with unit strides: y += a x */
+int tlab_deferred_scal(long long n, double a, double *x);                       /* DSCAL with unit stride:  x *= a   */
+int tlab_deferred_zero(double *a, long long n);                                 /* a(1:n) = 0                        */
+int tlab_deferred_flush(void);
+/* counts[6]: fused substeps run, sequences executed literally, begin_steps taken from zero fills, eager axpy, eager scal, eager zero fills */
+int tlab_deferred_stats(long long *counts);
 /* Which device allocations should play q, s, hq, hs, txc?  The rate of a kernel that streams many arrays at once depends on the SET of allocations
  * it streams (not on any one of them): 4.8 .. 5.9 TB/s for one 13-stream kernel over sets of 1-GiB hipMalloc allocations, 16.0 .. 17.2 ms per substep
  * of the 512^3 box from process to process (profiles/r05/placement_*.txt).  No rule predicts it, so it is searched: given a pool

@@ -21,7 +21,7 @@ def pytest_configure(config):
 # The driver runs `pytest tests/ -x -q -m gpu` under a wall-clock limit (round 4: killed at 1200 s after 294 of 398 tests).  Parity-critical tests
 # first, in the order of SURVEY.md section 8: the operators (a1-a9), the Poisson solver (a10-a13), the RHS / RK substep (n1, n2), the BASELINE
 # configs at size, the drop-in boundary (b), the decomposed drivers (e, a14), then the non-default schemes and formats (n3, n4).
-GPU_ORDER = ["test_gpu_derivs", "test_gpu_poisson.py", "test_gpu_rhs", "test_gpu_configs", "test_gpu_fortran_dropin", "test_gpu_valid_programs", "test_gpu_slab_native",
+GPU_ORDER = ["test_gpu_derivs", "test_gpu_poisson.py", "test_gpu_rhs", "test_gpu_deferred", "test_gpu_configs", "test_gpu_fortran_dropin", "test_gpu_valid_programs", "test_gpu_slab_native",
              "test_gpu_slab.py", "test_gpu_native_trp", "test_gpu_pencil", "test_gpu_dist", "test_io_formats", "test_gpu_poisson_direct", "test_direct_scheme",
              "test_gpu_filter", "test_gpu_placement", "test_stagger"]
 

@@ -373,3 +373,43 @@ def test_fortran_rk_driver_staggered_pressure(tmp_path, divergence):
     # and the staggered run is not the collocated one
     C, _ = substep_scatter(lambda: DnsOracle(x, y, z, nscal=1, visc=1.0 / re, schmidt=(sc,), yuniform=False), q0, s0, sched, nsamples=0)
     assert rel_err(q1[0], C[2]["q"][0]) > 1e-9
+
+
+def test_unchanged_time_loop_runs_the_fused_substep_bit_for_bit(tmp_path):
+    """The UNPATCHED time loop (RHS_GLOBAL_INCOMPRESSIBLE_1, then DAXPY per field, then DSCAL per field: time.f90:612-664, :272-297; `hq = 0` through
+    TLab_AMD_Zero) with the library's deferred tail (csrc/deferred.cpp, the Fortran host's default): every substep ran as ONE
+    tlab_time_substep_incompressible_explicit -- the fields equal those of the patched host (-DTLAB_AMD_FUSED_SUBSTEP) to the bit, none of the BLAS
+    calls was executed as a pass of its own, and the zero fills of the second step became tlab_dns_begin_step.  TLAB_AMD_DEFER=0 = the literal
+    sequence: same fields to round-off (another summation order in the tail), 8 + 8 BLAS passes per full step executed."""
+    import re
+    import numpy as np
+    from conftest import rel_err
+    _need_rk()
+    if not os.path.exists(RK_EXE_FUSED):
+        pytest.skip("tlab_amd/fortran/_build_rk_fused/test_rk_driver not built")
+    nx, ny, nz = 256, 64, 32
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(78)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * Y)
+    q0 = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3)]
+    s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    bcs = ["VelocityJmin=noslip", "VelocityJmax=noslip", "Scalar1Jmin=dirichlet", "Scalar1Jmax=dirichlet"]
+    res = {}
+    for tag, exe, env in (("fused", RK_EXE_FUSED, {}), ("deferred", RK_EXE, {}), ("literal", RK_EXE, {"TLAB_AMD_DEFER": "0"})):
+        d = tmp_path / tag
+        d.mkdir()
+        q1, s1, log = run_rk_driver(str(d), x, y, z, q0, s0, 1000.0, 0.7, 1e-3, 2, bcs, exe=exe, env=dict(env, TLAB_AMD_TIMING="0"))
+        m = re.search(r"DEFERRED: [a-z_ ]+?((?:\s+\d+){6})\s*$", log, re.M)
+        assert m, log[-1500:]
+        res[tag] = (q1 + s1, [int(v) for v in m.group(1).split()])
+    f_fused, f_def, f_lit = res["fused"][0], res["deferred"][0], res["literal"][0]
+    assert all(np.array_equal(a, b) for a, b in zip(f_def, f_fused))
+    fused_n, literal_n, begins, eaxpy, escal, ezero = res["deferred"][1]
+    # 2 steps x 3 substeps; the first step's zero fills come before the driver handle exists (executed as fills: hq and hs), the second's are begin_step
+    assert (fused_n, literal_n, begins, eaxpy, escal) == (6, 0, 1, 0, 0) and ezero == 2, res["deferred"][1]
+    assert res["literal"][1] == [0, 0, 0, 24, 16, 4], res["literal"][1]
+    d = max(rel_err(a, b) for a, b in zip(f_lit, f_fused))
+    assert 0.0 < d <= 1e-11, d

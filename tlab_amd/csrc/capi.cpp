@@ -82,7 +82,11 @@ double *workspace(size_t n) {
 void tlab_internal_filter_1d(int dir, tlab_filter_t f, int nx, int ny, int nz, const double *u, double *result, hipStream_t st);      // filter.hip
 
 // hooks for the other translation units (poisson.hip, rhs.hip)
-hipStream_t tlab_current_stream() { return g_stream; }
+int tlab_internal_deferred_flush();      // deferred.cpp: a recorded Runge-Kutta tail runs before anything else is enqueued (no-op unless tlab_deferred_enable)
+hipStream_t tlab_current_stream() {
+    (void)tlab_internal_deferred_flush();
+    return g_stream;
+}
 void tlab_set_error(const std::string &s) { g_err = s; }
 bool tlab_device_ready() { return g_device >= 0; }
 
@@ -430,11 +434,14 @@ int tlab_device_count(void) {
 }
 
 int tlab_set_stream(void *s) {
+    (void)tlab_internal_deferred_flush();
     g_stream = (hipStream_t)s;
     return TLAB_OK;
 }
 
 int tlab_sync(void) {
+    const int rcd = tlab_internal_deferred_flush();
+    if (rcd != TLAB_OK) return rcd;
     return guarded([&] { hip_check(hipStreamSynchronize(g_stream), "hipStreamSynchronize"); });
 }
 
@@ -442,15 +449,20 @@ int tlab_malloc(void **p, size_t bytes) {
     return guarded([&] { hip_check(hipMalloc(p, bytes), "hipMalloc"); });
 }
 int tlab_free(void *p) {
+    (void)tlab_internal_deferred_flush();
     return guarded([&] { hip_check(hipFree(p), "hipFree"); });
 }
 int tlab_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    const int rcd = tlab_internal_deferred_flush();
+    if (rcd != TLAB_OK) return rcd;
     return guarded([&] {
         hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream), "hipMemcpy h2d");
         hip_check(hipStreamSynchronize(g_stream), "sync");
     });
 }
 int tlab_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    const int rcd = tlab_internal_deferred_flush();
+    if (rcd != TLAB_OK) return rcd;
     return guarded([&] {
         hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream), "hipMemcpy d2h");
         hip_check(hipStreamSynchronize(g_stream), "sync");

@@ -22,6 +22,7 @@ using namespace tlab;
 extern hipStream_t tlab_current_stream();
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
+int tlab_internal_deferred_flush();      // deferred.cpp: a recorded substep runs before the driver's state changes under it
 bool tlab_internal_partial_p1_fused(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz, int ibc, const double *u, const double *ub,
                                     double scale, double *result, bool acc);
 bool tlab_internal_partial_p1_fusable(int dir, tlab_fdm_plan_t g, int nx, int ny, int nz);
@@ -168,6 +169,9 @@ bool neumann_weights(tlab_dns *d, int ibc) {
 }
 }  // namespace
 
+long long tlab_internal_dns_points(tlab_dns_t d) { return d ? (long long)d->nx * d->ny * d->nz : 0; }      // deferred.cpp
+int tlab_internal_dns_nscal(tlab_dns_t d) { return d ? d->nscal : 0; }
+
 extern "C" {
 
 // the wall-plane weights of a Neumann variant for the other drivers of the library (slab.cpp): 1 and (w = [2][K] device weights, K) when available
@@ -232,6 +236,7 @@ int tlab_dns_create(tlab_dns_t *out, tlab_fdm_plan_t gx, tlab_fdm_plan_t gy, tla
 }
 
 int tlab_dns_destroy(tlab_dns_t d) {
+    (void)tlab_internal_deferred_flush();
     // the operator state THIS driver switched on goes with it; one set through tlab_opr_burgers_set_anelastic (OPR_Burgers_AMD_Anelastic) or by
     // another driver since is not this driver's to clear
     if (d && d->anel_owner && d->rb) {
@@ -704,6 +709,7 @@ int tlab_time_substep_incompressible_explicit(tlab_dns_t d, double dte, double k
 }
 
 int tlab_dns_set_bcs(tlab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax) {
+    (void)tlab_internal_deferred_flush();
     auto valid = [](int t) { return t == TLAB_DNS_BCS_DIRICHLET || t == TLAB_DNS_BCS_NEUMANN; };
     if (!d || !flow_jmin || !flow_jmax || (d->nscal > 0 && (!scal_jmin || !scal_jmax))) {
         tlab_set_error("tlab_dns_set_bcs: bad arguments");
@@ -752,6 +758,7 @@ static void minmax_impl(tlab_dns_t d, const double *a, const double *v, const do
 // BcsScalJmin/Jmax%SfcType and %cpl of the scalars ([BoundaryConditions] Scalar<i>SfcTypeJmin/Jmax = static | linear, Scalar<i>CouplingJmin/Jmax;
 // boundary_bcs.f90:76-87): 0 = DNS_SFC_STATIC, 1 = DNS_SFC_LINEAR.  Single-domain driver only (the plane average is an all-reduce in a decomposed run).
 int tlab_dns_set_surface_bcs(tlab_dns_t d, const int *sfc_jmin, const int *sfc_jmax, const double *cpl_jmin, const double *cpl_jmax) {
+    (void)tlab_internal_deferred_flush();
     if (!d || (d->nscal > 0 && (!sfc_jmin || !sfc_jmax || !cpl_jmin || !cpl_jmax))) {
         tlab_set_error("tlab_dns_set_surface_bcs: bad arguments");
         return TLAB_EINVAL;
@@ -780,6 +787,7 @@ int tlab_dns_set_surface_bcs(tlab_dns_t d, const int *sfc_jmin, const int *sfc_j
 // nse_eqns == DNS_EQNS_ANELASTIC (tools/dns/rhs_global_incompressible_1.f90:211-214, 275-277, 326-329; physics/opr_burgers.f90:128-183) with the
 // background profiles the host's thermodynamics made: rbackground(1:ny), ribackground(1:ny) = 1 / rbackground (HOST pointers; NULL: incompressible)
 int tlab_dns_set_anelastic(tlab_dns_t d, const double *rbackground, const double *ribackground) {
+    (void)tlab_internal_deferred_flush();
     if (!d) return TLAB_EINVAL;
     try {
         if (!rbackground || !ribackground) ok(tlab_opr_burgers_set_anelastic(0, nullptr, nullptr), "tlab_opr_burgers_set_anelastic");
@@ -799,6 +807,7 @@ int tlab_dns_set_anelastic(tlab_dns_t d, const double *rbackground, const double
 // [PressureFilter] (operators/opr_filter.f90:46, 78; rhs_global_incompressible_1.f90:286-290): directional 1-D filters applied to p and dp/dy after
 // the Poisson solve; NULL = DNS_FILTER_NONE in that direction; repeat may be NULL (1 each).  The filters are not owned.
 int tlab_dns_set_pressure_filter(tlab_dns_t d, tlab_filter_t fx, tlab_filter_t fy, tlab_filter_t fz, const int *repeat) {
+    (void)tlab_internal_deferred_flush();
     if (!d) return TLAB_EINVAL;
     d->pfilter[0] = fx; d->pfilter[1] = fy; d->pfilter[2] = fz;
     for (int i = 0; i < 3; ++i) d->pfilter_rep[i] = repeat ? repeat[i] : 1;
@@ -806,12 +815,14 @@ int tlab_dns_set_pressure_filter(tlab_dns_t d, tlab_filter_t fx, tlab_filter_t f
 }
 
 int tlab_dns_set_remove_divergence(tlab_dns_t d, int on) {
+    (void)tlab_internal_deferred_flush();
     if (!d) return TLAB_EINVAL;
     d->remove_divergence = on != 0;
     return TLAB_OK;
 }
 
 int tlab_dns_set_slab(tlab_dns_t d, int koffset) {
+    (void)tlab_internal_deferred_flush();
     if (!d || koffset < 0 || koffset + d->nz > d->nz_total) { tlab_set_error("tlab_dns_set_slab: bad offset"); return TLAB_EINVAL; }
     d->koffset = koffset;
     return TLAB_OK;
@@ -870,6 +881,7 @@ int tlab_minmax(tlab_dns_t d, const double *a, int nx, int ny, int nz, double *a
 }
 
 int tlab_dns_begin_step(tlab_dns_t d) {
+    (void)tlab_internal_deferred_flush();
     if (!d) return TLAB_EINVAL;
     d->fresh = true;
     return TLAB_OK;
@@ -981,6 +993,7 @@ int tlab_dns_place_arrays(tlab_dns_t d, int npool, double *const *pool, const do
 }
 
 int tlab_dns_set_fusion(tlab_dns_t d, int on) {
+    (void)tlab_internal_deferred_flush();
     if (!d) return TLAB_EINVAL;
     d->fuse = on != 0;
     return TLAB_OK;

@@ -43,8 +43,10 @@ subroutine RHS_GLOBAL_INCOMPRESSIBLE_1()
     do is = 1, min(int(inb_txc), 16)
         ptxc(is) = c_loc(txc(1, is))
     end do
-    rc = tlab_rhs_global_incompressible_1(TLab_AMD_DNS_Handle(), real(dte, c_double), pq, ps, phq, phs, ptxc)
-    call TLab_AMD_Check(rc, 'tlab_rhs_global_incompressible_1')
+    ! = tlab_rhs_global_incompressible_1, or its description when the deferred tail is on (TLab_AMD_DNS_Handle): the DAXPY / DSCAL calls that follow
+    ! in time.f90 then complete it to ONE tlab_time_substep_incompressible_explicit (csrc/deferred.cpp)
+    rc = tlab_deferred_rhs(TLab_AMD_DNS_Handle(), real(dte, c_double), pq, ps, phq, phs, ptxc)
+    call TLab_AMD_Check(rc, 'tlab_deferred_rhs')
 
 end subroutine RHS_GLOBAL_INCOMPRESSIBLE_1
 

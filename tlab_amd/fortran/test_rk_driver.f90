@@ -203,7 +203,7 @@ program test_rk_driver
     use TLab_AMD_DNS, only: TLab_AMD_DNS_Finalize, TLab_AMD_DNS_Handle
     use TLabMPI_VARS
     use TLabMPI_Transpose
-    use TLab_AMD_C, only: tlab_sync, tlab_memcpy_d2h, TLab_AMD_Check, tlab_time_courant
+    use TLab_AMD_C, only: tlab_sync, tlab_memcpy_d2h, TLab_AMD_Check, tlab_time_courant, tlab_deferred_stats
     use, intrinsic :: iso_c_binding
     implicit none
 
@@ -225,6 +225,12 @@ program test_rk_driver
     real(c_double) pmax(2), dt_c
     type(c_ptr) pq(3)
     logical step_from_cfl
+    ! timing of the loop (TLAB_AMD_TIMING = number of untimed iterations in front): wall clock between two tlab_sync, per substep
+    integer(wi) warm_iters
+    integer(8) clock0, clock1, clock_rate
+    integer timing_stat
+    integer(c_long_long) dstat(6)
+    character(len=16) timing_env
 
     ! ###################################################################
     call TLab_Start()                                                          ! dns_main.f90:62
@@ -339,7 +345,15 @@ program test_rk_driver
     ! Do simulation: Integrate equations
     ! ###################################################################
     step_from_cfl = cfla > 0.0_wp               ! time.f90:530: the step follows the Courant numbers whenever TimeCFL > 0
+    warm_iters = -1
+    call get_environment_variable('TLAB_AMD_TIMING', timing_env, status=timing_stat)
+    if (timing_stat == 0) read (timing_env, *, iostat=timing_stat) warm_iters
+    if (timing_stat /= 0) warm_iters = -1
     do while (itime < nitera_last)                                             ! :246-250
+        if (warm_iters >= 0 .and. itime == nitera_first + warm_iters) then
+            call TLab_AMD_Check(tlab_sync(), 'tlab_sync')
+            call system_clock(clock0, clock_rate)
+        end if
         if (step_from_cfl) then                                                ! TIME_COURANT() at the start of the iteration (dns_main.f90:243, time.f90:365-548)
             pq = [c_loc(q(1, 1)), c_loc(q(1, 2)), c_loc(q(1, 3))]
             call TLab_AMD_Check(tlab_time_courant(TLab_AMD_DNS_Handle(), pq, real(cfla, c_double), real(cfld, c_double), pmax, dt_c), 'tlab_time_courant')
@@ -351,6 +365,16 @@ program test_rk_driver
         itime = itime + 1
         rtime = rtime + dtime
     end do
+    if (warm_iters >= 0 .and. nitera_last > nitera_first + warm_iters) then
+        call TLab_AMD_Check(tlab_sync(), 'tlab_sync')
+        call system_clock(clock1)
+        write (sRes, '(a,i0,a,es14.7)') 'TIMING: substeps ', (nitera_last - nitera_first - warm_iters)*rkm_endstep, ' ms_per_substep ', &
+            1.0e3_wp*real(clock1 - clock0, wp)/real(clock_rate, wp)/real((nitera_last - nitera_first - warm_iters)*rkm_endstep, wp)
+        call TLab_Write_ASCII(lfile, trim(sRes))
+        call TLab_AMD_Check(tlab_deferred_stats(dstat), 'tlab_deferred_stats')
+        write (sRes, '(a,6(1x,i0))') 'DEFERRED: fused literal begin_steps eager_axpy eager_scal eager_zero', dstat
+        call TLab_Write_ASCII(lfile, trim(sRes))
+    end if
 
     write (fname, *) itime; fname = trim(adjustl(tag_flow))//trim(adjustl(fname))
     call IO_Write_Fields_AMD(fname, imax, jmax, kmax, itime, inb_flow, q)      ! DNS control: IO_Write_Fields, dns_main.f90:344

@@ -195,6 +195,41 @@ module TLab_AMD_C
             import :: c_int, c_ptr
             type(c_ptr), value :: dns
         end function
+        ! ---- the substep's tail for an unpatched time loop (include/tlab_amd.h: tlab_deferred_*, csrc/deferred.cpp) ----
+        integer(c_int) function tlab_deferred_enable(on) bind(C, name='tlab_deferred_enable')
+            import :: c_int
+            integer(c_int), value :: on
+        end function
+        integer(c_int) function tlab_deferred_rhs(dns, dte, q, s, hq, hs, txc) bind(C, name='tlab_deferred_rhs')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: dns
+            real(c_double), value :: dte
+            type(c_ptr), intent(in) :: q(*), s(*), hq(*), hs(*), txc(*)
+        end function
+        integer(c_int) function tlab_deferred_axpy(n, a, x, y) bind(C, name='tlab_deferred_axpy')
+            import :: c_int, c_ptr, c_double, c_long_long
+            integer(c_long_long), value :: n
+            real(c_double), value :: a
+            type(c_ptr), value :: x, y
+        end function
+        integer(c_int) function tlab_deferred_scal(n, a, x) bind(C, name='tlab_deferred_scal')
+            import :: c_int, c_ptr, c_double, c_long_long
+            integer(c_long_long), value :: n
+            real(c_double), value :: a
+            type(c_ptr), value :: x
+        end function
+        integer(c_int) function tlab_deferred_zero(a, n) bind(C, name='tlab_deferred_zero')
+            import :: c_int, c_ptr, c_long_long
+            type(c_ptr), value :: a
+            integer(c_long_long), value :: n
+        end function
+        integer(c_int) function tlab_deferred_flush() bind(C, name='tlab_deferred_flush')
+            import :: c_int
+        end function
+        integer(c_int) function tlab_deferred_stats(counts) bind(C, name='tlab_deferred_stats')
+            import :: c_int, c_long_long
+            integer(c_long_long), intent(out) :: counts(6)
+        end function
         integer(c_int) function tlab_rhs_global_incompressible_1(dns, dte, q, s, hq, hs, txc) bind(C, name='tlab_rhs_global_incompressible_1')
             import :: c_int, c_ptr, c_double
             type(c_ptr), value :: dns

@@ -204,7 +204,8 @@ contains
         integer(c_int) :: rc, fj0(3), fj1(3), sj0(16), sj1(16)
         real(c_double) :: cp0(16), cp1(16)
         real(c_double) :: sc(16)
-        integer ns
+        integer ns, defer_stat
+        character(len=8) defer_env
         if (.not. c_associated(dns)) then
             if (inb_scal > 16) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_DNS_Handle: at most 16 scalars')
             ns = max(1, int(inb_scal))
@@ -221,6 +222,9 @@ contains
             call TLab_AMD_Check(rc, 'tlab_dns_set_bcs')
             rc = tlab_dns_set_remove_divergence(dns, merge(1_c_int, 0_c_int, remove_divergence))      ! dns.ini [Main] TermDivergence
             call TLab_AMD_Check(rc, 'tlab_dns_set_remove_divergence')
+            ! the UNPATCHED time loop (RHS, then DAXPY / DSCAL per field: time.f90:612-664, :272-297) as one fused substep: on unless TLAB_AMD_DEFER=0
+            call get_environment_variable('TLAB_AMD_DEFER', defer_env, status=defer_stat)
+            if (.not. (defer_stat == 0 .and. trim(defer_env) == '0')) call TLab_AMD_Check(tlab_deferred_enable(1_c_int), 'tlab_deferred_enable')
             if (inb_scal > 0) then          ! dynamic surface model of the scalars (BcsScalJmin%SfcType, %cpl)
                 sj0 = 0; sj1 = 0; cp0 = 0.0_c_double; cp1 = 0.0_c_double
                 sj0(1:inb_scal) = BcsScalJmin%SfcType(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%SfcType(1:inb_scal)
@@ -249,11 +253,13 @@ contains
     subroutine TLab_AMD_Zero(a, n)
         real(wp), intent(inout), target :: a(*)
         integer(wi), intent(in) :: n
-        call TLab_AMD_Check(tlab_pw_fill(c_loc(a), 0.0_c_double, int(n, c_long_long)), 'tlab_pw_fill')
+        ! recorded like DAXPY / DSCAL when the deferred tail is on: `hq = 0 ; hs = 0` in front of a substep becomes tlab_dns_begin_step
+        call TLab_AMD_Check(tlab_deferred_zero(c_loc(a), int(n, c_long_long)), 'tlab_deferred_zero')
     end subroutine TLab_AMD_Zero
 
     subroutine TLab_AMD_DNS_Finalize()
         integer(c_int) rc
+        rc = tlab_deferred_enable(0_c_int)            ! (runs what is still recorded)
         if (c_associated(slab)) rc = tlab_slab_dns_destroy(slab)
         slab = c_null_ptr
         if (c_associated(pencil)) rc = tlab_pencil_dns_destroy(pencil)
@@ -276,7 +282,9 @@ subroutine DAXPY(n, da, dx, incx, dy, incy)
     real(c_double), intent(in), target :: dx(*)
     real(c_double), intent(inout), target :: dy(*)
     if (incx /= 1 .or. incy /= 1) call TLab_AMD_Check(-1_c_int, 'DAXPY on device arrays (unit strides only)')
-    call TLab_AMD_Check(tlab_pw_rk_update(c_loc(dy), c_loc(dx), da, 1.0_c_double, 0_c_int, int(n, c_long_long)), 'tlab_pw_rk_update')    ! y = y + a x
+    ! y = y + a x -- executed at once, or (tlab_deferred_enable, the default of TLab_AMD_DNS_Handle) recorded: the update loops of
+    ! TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT then ride on the last kernels of the RHS they follow (csrc/deferred.cpp)
+    call TLab_AMD_Check(tlab_deferred_axpy(int(n, c_long_long), da, c_loc(dx), c_loc(dy)), 'tlab_deferred_axpy')
 end subroutine DAXPY
 
 subroutine DSCAL(n, da, dx, incx)
@@ -287,7 +295,7 @@ subroutine DSCAL(n, da, dx, incx)
     real(c_double), intent(in) :: da
     real(c_double), intent(inout), target :: dx(*)
     if (incx /= 1) call TLab_AMD_Check(-1_c_int, 'DSCAL on device arrays (unit stride only)')
-    call TLab_AMD_Check(tlab_pw_scale(c_loc(dx), da, int(n, c_long_long)), 'tlab_pw_scale')
+    call TLab_AMD_Check(tlab_deferred_scal(int(n, c_long_long), da, c_loc(dx)), 'tlab_deferred_scal')       ! (as DAXPY above)
 end subroutine DSCAL
 
 ! ###################################################################

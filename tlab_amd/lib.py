@@ -71,6 +71,13 @@ SIGNATURES = {
     "tlab_dns_destroy": (c_int, [c_vp]),
     "tlab_dns_set_fusion": (c_int, [c_vp, c_int]),
     "tlab_dns_begin_step": (c_int, [c_vp]),
+    "tlab_deferred_enable": (c_int, [c_int]),
+    "tlab_deferred_rhs": (c_int, [c_vp, c_dbl, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
+    "tlab_deferred_axpy": (c_int, [ctypes.c_longlong, c_dbl, c_vp, c_vp]),
+    "tlab_deferred_scal": (c_int, [ctypes.c_longlong, c_dbl, c_vp]),
+    "tlab_deferred_zero": (c_int, [c_vp, ctypes.c_longlong]),
+    "tlab_deferred_flush": (c_int, []),
+    "tlab_deferred_stats": (c_int, [ctypes.POINTER(ctypes.c_longlong)]),
     "tlab_dns_place_arrays": (c_int, [c_vp, c_int, c_vp, c_vp, c_dbl, c_int, ctypes.c_uint, ctypes.POINTER(c_int), _dp]),
     "tlab_dns_set_slab": (c_int, [c_vp, c_int]),
     "tlab_dns_set_anelastic": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
