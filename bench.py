@@ -431,8 +431,8 @@ def main():
         if args.placement_trials > 0:
             try:
                 placement = d.place_arrays(pool=args.placement_pool, random_trials=args.placement_trials, dtime=dtime)
-            except T.TlabError as e:      # the search failed inside the library: the arrays are the pool in order, the run goes on and says so
-                placement = {"error": str(e)}
+            except (T.TlabError, RuntimeError) as e:      # the search failed inside the library (the arrays are the pool in order) or the pool did not fit
+                placement = {"error": str(e)}                # (the driver has its arrays back): the run goes on and says so
         state_fields = d.q + d.s
 
         def substep(k):

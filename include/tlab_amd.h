@@ -355,6 +355,17 @@ int tlab_deferred_stats(long long *counts);
  * and the number of trials.  A start-up cost of (random_trials + nroles + 1) x 4 substeps; the results of the run do not depend on it. */
 int tlab_dns_place_arrays(tlab_dns_t d, int npool, double *const *pool, const double *const *state, double dtime, int random_trials,
                           unsigned seed, int *assignment, double *report);
+/* After the search the first assignment and the winner are timed again back to back (three steps each); the winner is kept only if its median is
+ * the lower one, and report[0], report[1] come from those repeats.  The begin_step flag of the driver is what it was on entry; the contents of
+ * EVERY pool array (state, tendencies, work arrays) are undefined afterwards. */
+/* The same search for a host whose arrays are two-dimensional (Tlab: q(isize_field, 3), s(isize_field, ns), hq, hs, txc(isize_txc_field, 9);
+ * base/tlab_memory.f90:201-207, dns_main.f90:103-104): components lie a fixed stride apart, so only whole BLOCKS can be placed.  cand_X[0..ncand-1]
+ * are candidate allocations for block X (index 0 = what the host holds now; q / hq: 3 n doubles, s / hs: nscal n, txc: 9 txc_stride); the substep
+ * is timed on the host's own combination, on random_trials random ones and on one pass of single-block exchanges, the winner confirmed as above.
+ * choice[5]: the candidate index per block in the order q, s, hq, hs, txc; report as tlab_dns_place_arrays.  All candidates are overwritten: call
+ * it BEFORE the fields are read, then point the host arrays at the chosen allocations and free the others. */
+int tlab_dns_place_blocks(tlab_dns_t d, int ncand, double *const *cand_q, double *const *cand_s, double *const *cand_hq, double *const *cand_hs,
+                          double *const *cand_txc, long long txc_stride, double dtime, int random_trials, unsigned seed, int *choice, double *report);
 /* Wall boundary conditions in y: BcsFlowJmin%type(1:3), BcsFlowJmax%type(1:3), BcsScalJmin%type(1:nscal), BcsScalJmax%type(1:nscal)
  * (tools/dns/boundary_bcs.f90:24-27, read at :102-190).  Values as in the reference: DNS_BCS_DIRICHLET / DNS_BCS_NEUMANN.
  * Default at creation: all Dirichlet ('noslip'; the reference's 'freeslip' is {NEUMANN, DIRICHLET, NEUMANN} for (u,v,w)).

@@ -398,18 +398,26 @@ def test_unchanged_time_loop_runs_the_fused_substep_bit_for_bit(tmp_path):
     s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
     bcs = ["VelocityJmin=noslip", "VelocityJmax=noslip", "Scalar1Jmin=dirichlet", "Scalar1Jmax=dirichlet"]
     res = {}
-    for tag, exe, env in (("fused", RK_EXE_FUSED, {}), ("deferred", RK_EXE, {}), ("literal", RK_EXE, {"TLAB_AMD_DEFER": "0"})):
+    logs = {}
+    for tag, exe, env in (("fused", RK_EXE_FUSED, {}), ("deferred", RK_EXE, {}), ("literal", RK_EXE, {"TLAB_AMD_DEFER": "0"}),
+                          ("deferred, arrays where the allocator put them", RK_EXE, {"TLAB_AMD_PLACE": "0"})):
         d = tmp_path / tag
         d.mkdir()
         q1, s1, log = run_rk_driver(str(d), x, y, z, q0, s0, 1000.0, 0.7, 1e-3, 2, bcs, exe=exe, env=dict(env, TLAB_AMD_TIMING="0"))
         m = re.search(r"DEFERRED: [a-z_ ]+?((?:\s+\d+){6})\s*$", log, re.M)
         assert m, log[-1500:]
         res[tag] = (q1 + s1, [int(v) for v in m.group(1).split()])
+        logs[tag] = log
     f_fused, f_def, f_lit = res["fused"][0], res["deferred"][0], res["literal"][0]
     assert all(np.array_equal(a, b) for a, b in zip(f_def, f_fused))
-    fused_n, literal_n, begins, eaxpy, escal, ezero = res["deferred"][1]
-    # 2 steps x 3 substeps; the first step's zero fills come before the driver handle exists (executed as fills: hq and hs), the second's are begin_step
-    assert (fused_n, literal_n, begins, eaxpy, escal) == (6, 0, 1, 0, 0) and ezero == 2, res["deferred"][1]
+    # 2 steps x 3 substeps, both steps' zero fills became begin_step (the placement search of the start-up created the driver handle, so the layer is on
+    # from the first statement of the loop)
+    assert res["deferred"][1] == [6, 0, 2, 0, 0, 0], res["deferred"][1]
+    # TLab_AMD_Place_Arrays ran (four candidates per block by default) and changed nothing but the addresses; without it the first step's fills come
+    # before the driver handle exists and are executed as fills (hq and hs)
+    assert "PLACEMENT: candidates 4" in logs["deferred"] and "PLACEMENT" not in logs["deferred, arrays where the allocator put them"]
+    assert all(np.array_equal(a, b) for a, b in zip(res["deferred, arrays where the allocator put them"][0], f_fused))
+    assert res["deferred, arrays where the allocator put them"][1] == [6, 0, 1, 0, 0, 2]
     assert res["literal"][1] == [0, 0, 0, 24, 16, 4], res["literal"][1]
     d = max(rel_err(a, b) for a, b in zip(f_lit, f_fused))
     assert 0.0 < d <= 1e-11, d

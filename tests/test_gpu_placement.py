@@ -40,7 +40,7 @@ def test_placed_arrays_give_the_same_run_bit_for_bit(T, nscal):
     after = [t.data_ptr() for t in b.q + b.s + b.hq + b.hs + b.txc]
     assert len(set(after)) == nroles                                                # distinct arrays out of the pool
     assert rep["pool"] == 24 and rep["trials"] == 1 + 3 + nroles
-    assert 0.0 < rep["ms_best"] <= rep["ms_first"] and rep["ms_best"] <= rep["ms_median"] <= rep["ms_worst"]
+    assert 0.0 < rep["ms_best"] <= rep["ms_first"] and rep["ms_median"] <= rep["ms_worst"]      # (first / best: the repeats at the end of the search)
     for t, u in zip(a.q + a.s, b.q + b.s):                                          # the fields came along
         assert torch.equal(t, u)
     for d in (a, b):
@@ -89,4 +89,48 @@ def test_bench_line_of_one_gpu_carries_the_placement_report_and_times_the_domina
     assert rf["bound"] == "hbm" and rf["launches"] in (6, 12, 18) and 0 < rf["frac"] < 1      # one kernel name: 1 .. 3 launches per substep
     names = [k["kernel"] for k in rec["kernels"]]
     assert rf["kernel"] in names and len(names) > 8 and "after the timed region" in rec["kernels_from"]
+    assert rec.get("substep_traffic") is None or rec["substep_traffic"]["consistent"] is not False      # (512^3 only: a substep moves at least its dominant kernel's bytes)
     assert rec["config"]["fields_finite"] is True and rec["steps"] == 6
+
+
+def test_place_blocks_for_a_host_with_two_dimensional_arrays(T):
+    """tlab_dns_place_blocks: the host's layout -- q(n, 3), s(n, ns), hq, hs, txc(m, 9) as ONE allocation each -- with three candidates per block:
+    the choice is one candidate per block, the begin_step flag of the driver survives the trial substeps, and a step on the chosen blocks equals the
+    step on separately allocated arrays to the bit (where the arrays live changes nothing but the time)."""
+    import ctypes
+    import torch
+    from tlab_amd.lib import load, c_vp, check, TlabError
+    nx, ny, nz, ns = 256, 64, 32, 1
+    ref = _dns(nx, ny, nz, 7, ns)
+    d = _dns(nx, ny, nz, 7, ns)
+    n, m = d.n, d.isize_txc_field
+    ncand = 3
+    blocks = {"q": [torch.zeros(3 * n, dtype=torch.float64, device="cuda") for _ in range(ncand)], "s": [torch.zeros(ns * n, dtype=torch.float64, device="cuda") for _ in range(ncand)],
+              "hq": [torch.zeros(3 * n, dtype=torch.float64, device="cuda") for _ in range(ncand)], "hs": [torch.zeros(ns * n, dtype=torch.float64, device="cuda") for _ in range(ncand)],
+              "txc": [torch.zeros(9 * m, dtype=torch.float64, device="cuda") for _ in range(ncand)]}
+    arr = {k: (c_vp * ncand)(*[t.data_ptr() for t in v]) for k, v in blocks.items()}
+    choice = (ctypes.c_int * 5)()
+    rep = (ctypes.c_double * 5)()
+    d.begin_step()
+    check(load().tlab_dns_place_blocks(d._h, ncand, arr["q"], arr["s"], arr["hq"], arr["hs"], arr["txc"], m, 1e-3, 4, 1, choice, rep), "tlab_dns_place_blocks")
+    c = list(choice)
+    assert all(0 <= v < ncand for v in c) and int(rep[4]) >= 1 + 4 + 5 * (ncand - 1) and 0 < rep[1] <= rep[0]
+    Q, S, HQ, HS, X = (blocks[k][c[i]] for i, k in enumerate(("q", "s", "hq", "hs", "txc")))
+    d.q, d.s = [Q[i * n:(i + 1) * n] for i in range(3)], [S[i * n:(i + 1) * n] for i in range(ns)]
+    d.hq, d.hs = [HQ[i * n:(i + 1) * n] for i in range(3)], [HS[i * n:(i + 1) * n] for i in range(ns)]
+    d.txc = [X[i * m:(i + 1) * m] for i in range(9)]
+    d._ptrs = None
+    for t, u in zip(d.q + d.s, ref.q + ref.s):
+        t.copy_(u)
+    for t in d.hq + d.hs:
+        t.fill_(3.0)            # the begin_step flag set before the search must still hold: the first substep overwrites this
+    for k in range(3):          # (d.begin_step() is NOT called again)
+        last = k == 2
+        d.TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT(1e-3 * d.kdt[k], 1.0 if last else d.kco[k], not last)
+    ref.TIME_RUNGEKUTTA(1e-3)
+    torch.cuda.synchronize()
+    for t, u in zip(d.q + d.s + d.hq + d.hs, ref.q + ref.s + ref.hq + ref.hs):
+        assert torch.equal(t, u)
+    with pytest.raises(TlabError):          # the same allocation twice among the candidates
+        bad = (c_vp * ncand)(*([blocks["hq"][0].data_ptr()] + [t.data_ptr() for t in blocks["q"][1:]]))
+        check(load().tlab_dns_place_blocks(d._h, ncand, bad, arr["s"], arr["hq"], arr["hs"], arr["txc"], m, 1e-3, 1, 1, choice, rep), "tlab_dns_place_blocks")

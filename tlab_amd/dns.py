@@ -200,7 +200,9 @@ class Dns:
 
     def place_arrays(self, pool=40, random_trials=16, dtime=1e-3, seed=0):
         """tlab_dns_place_arrays: q, s, hq, hs, txc move to the allocations (out of a pool of `pool` fresh ones of the txc size) on which the substep runs
-        fastest; the fields keep their values.  Returns {"ms_first", "ms_best", "ms_median", "ms_worst", "trials", "pool", "seconds"}."""
+        fastest; the fields keep their values, the tendencies are zeroed.  Returns {"ms_first", "ms_best", "ms_median", "ms_worst", "trials", "pool",
+        "seconds"}: ms_first / ms_best from the repeats at the end of the search (the allocator's order and the assignment kept, three steps each, back
+        to back), median / worst over the single timings of the search."""
         import time
         import torch
         nroles = 2 * (3 + self.nscal) + 9
@@ -222,6 +224,16 @@ class Dns:
                 cand.pop()
             torch.cuda.empty_cache()
             if len(cand) < nroles:
+                # not even the roles fit beside the saved state: the driver gets arrays of its original sizes back, with its fields, before the error leaves
+                cand = None
+                torch.cuda.empty_cache()
+                ns = self.nscal
+                self.q = [r for r in state[:3]]
+                self.s = [r for r in state[3:3 + ns]]
+                self.hq = [torch.zeros(self.n, dtype=torch.float64, device=dev) for _ in range(3)]
+                self.hs = [torch.zeros(self.n, dtype=torch.float64, device=dev) for _ in range(ns)]
+                self.txc = [torch.zeros(m, dtype=torch.float64, device=dev) for _ in range(9)]
+                self._ptrs = None
                 raise
             pool = len(cand)
         parr = (c_vp * pool)(*[t.data_ptr() for t in cand])

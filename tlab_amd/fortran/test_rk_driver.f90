@@ -200,7 +200,7 @@ program test_rk_driver
     use BOUNDARY_BCS
     use DNS_ARRAYS
     use TIME
-    use TLab_AMD_DNS, only: TLab_AMD_DNS_Finalize, TLab_AMD_DNS_Handle
+    use TLab_AMD_DNS, only: TLab_AMD_DNS_Finalize, TLab_AMD_DNS_Handle, TLab_AMD_Place_Arrays
     use TLabMPI_VARS
     use TLabMPI_Transpose
     use TLab_AMD_C, only: tlab_sync, tlab_memcpy_d2h, TLab_AMD_Check, tlab_time_courant, tlab_deferred_stats
@@ -301,6 +301,8 @@ program test_rk_driver
     call OPR_Elliptic_Initialize(ifile)                                        ! :131
 
     if (fourier_on) call OPR_Fourier_Initialize()                              ! :139
+
+    call TLab_AMD_Place_Arrays()                                               ! the ONE added call (INTEGRATION.md section 3c): which allocations play q, s, hq, hs, txc
 
     ! ###################################################################
     ! Initialize fields

@@ -195,6 +195,17 @@ module TLab_AMD_C
             import :: c_int, c_ptr
             type(c_ptr), value :: dns
         end function
+        integer(c_int) function tlab_dns_place_blocks(dns, ncand, cand_q, cand_s, cand_hq, cand_hs, cand_txc, txc_stride, dtime, random_trials, seed, &
+                                                      choice, report) bind(C, name='tlab_dns_place_blocks')
+            import :: c_int, c_ptr, c_double, c_long_long
+            type(c_ptr), value :: dns
+            integer(c_int), value :: ncand, random_trials, seed
+            type(c_ptr), intent(in) :: cand_q(*), cand_s(*), cand_hq(*), cand_hs(*), cand_txc(*)
+            integer(c_long_long), value :: txc_stride
+            real(c_double), value :: dtime
+            integer(c_int), intent(out) :: choice(5)
+            real(c_double), intent(out) :: report(5)
+        end function
         ! ---- the substep's tail for an unpatched time loop (include/tlab_amd.h: tlab_deferred_*, csrc/deferred.cpp) ----
         integer(c_int) function tlab_deferred_enable(on) bind(C, name='tlab_deferred_enable')
             import :: c_int

@@ -25,6 +25,7 @@ module TLab_AMD_DNS
     public :: TLab_AMD_DNS_Begin_Step      ! optional: tells the device RHS that hq, hs are zero (no fill, no read of the old tendencies)
     public :: TLab_AMD_Zero
     public :: TLab_AMD_DNS_Finalize
+    public :: TLab_AMD_Place_Arrays        ! optional, once, before the fields are read: which device allocations play q, s, hq, hs, txc (tlab_dns_place_blocks)
 
     type(c_ptr), save :: dns = c_null_ptr
     type(c_ptr), save :: slab = c_null_ptr
@@ -237,6 +238,100 @@ contains
         end if
         h = dns
     end function TLab_AMD_DNS_Handle
+
+    ! Where the arrays live decides 16.0 .. 17.0 ms per substep of the 512^3 box from process to process (DESIGN.md section 4; INTEGRATION.md section
+    ! 3c).  The host's arrays are two-dimensional -- components a fixed stride apart -- so whole blocks are placed: ncand - 1 more allocations per
+    ! block through the allocation hook's tlab_malloc, the substep timed on combinations (tlab_dns_place_blocks), the module arrays q, s, txc
+    ! (TLab_Arrays), hq, hs (DNS_ARRAYS) re-associated with the winners, the aliases of TLab_Pointers* reset, the losers freed.  ONE added call in
+    ! dns_main.f90, after the operators are initialised and before IO_Read_Fields (the arrays hold nothing yet; every candidate is overwritten).
+    ! TLAB_AMD_PLACE = number of candidates per block (default 4; 0 or 1: nothing happens); single-domain runs only.
+    subroutine TLab_AMD_Place_Arrays()
+        use TLab_Constants, only: lfile
+        use TLab_WorkFlow, only: TLab_Write_ASCII
+        use TLab_Memory, only: isize_field, isize_txc_field, inb_scal, inb_txc, TLab_AMD_Reset_Pointers
+        use TLab_Arrays, only: q, s, txc
+        use DNS_ARRAYS, only: hq, hs
+        integer, parameter :: maxcand = 8
+        type(c_ptr) :: cq(maxcand), cs(maxcand), chq(maxcand), chs(maxcand), ctxc(maxcand), p
+        integer(c_int) :: choice(5), rc
+        real(c_double) :: report(5)
+        integer(c_size_t) :: nb(5)
+        integer :: ncand, ic, ib, stat, nq, ns2, ntxc
+        character(len=16) :: val
+        character(len=256) :: line
+
+        ncand = 4
+        call get_environment_variable('TLAB_AMD_PLACE', val, status=stat)
+        if (stat == 0) then
+            read (val, *, iostat=stat) ncand
+            if (stat /= 0) ncand = 4
+        end if
+        ncand = min(ncand, maxcand)
+        if (ncand < 2 .or. TLab_AMD_Pencil_Active() .or. TLab_AMD_Slab_Active()) return
+        if (.not. (associated(q) .and. associated(hq) .and. associated(txc))) return
+        if (inb_scal > 0) then
+            if (.not. (associated(s) .and. associated(hs))) return
+        end if
+        nq = size(q, 2); ns2 = 0; ntxc = size(txc, 2)
+        if (inb_scal > 0) ns2 = size(s, 2)
+        if (nq /= 3 .or. size(hq, 2) /= 3 .or. ntxc < 9 .or. ns2 /= inb_scal) return             ! (incompressible layout only)
+        if (inb_scal > 0) then
+            if (size(hs, 2) /= inb_scal) return
+        end if
+        nb = [int(isize_field, c_size_t)*3_c_size_t, int(isize_field, c_size_t)*int(max(ns2, 1), c_size_t), int(isize_field, c_size_t)*3_c_size_t, &
+              int(isize_field, c_size_t)*int(max(ns2, 1), c_size_t), int(isize_txc_field, c_size_t)*int(ntxc, c_size_t)]*8_c_size_t
+        cq = c_null_ptr; cs = c_null_ptr; chq = c_null_ptr; chs = c_null_ptr; ctxc = c_null_ptr
+        cq(1) = c_loc(q(1, 1)); chq(1) = c_loc(hq(1, 1)); ctxc(1) = c_loc(txc(1, 1))
+        if (inb_scal > 0) then
+            cs(1) = c_loc(s(1, 1)); chs(1) = c_loc(hs(1, 1))
+        end if
+        alloc: do ic = 2, ncand                       ! as many complete sets of candidates as the memory gives
+            do ib = 1, 5
+                if ((ib == 2 .or. ib == 4) .and. inb_scal == 0) cycle
+                if (tlab_malloc(p, nb(ib)) /= 0) then
+                    if (ib > 1) rc = tlab_free(cq(ic))
+                    if (ib > 2 .and. inb_scal > 0) rc = tlab_free(cs(ic))
+                    if (ib > 3) rc = tlab_free(chq(ic))
+                    if (ib > 4 .and. inb_scal > 0) rc = tlab_free(chs(ic))
+                    ncand = ic - 1
+                    exit alloc
+                end if
+                select case (ib)
+                case (1); cq(ic) = p
+                case (2); cs(ic) = p
+                case (3); chq(ic) = p
+                case (4); chs(ic) = p
+                case (5); ctxc(ic) = p
+                end select
+            end do
+        end do alloc
+        if (ncand < 2) return
+        rc = tlab_dns_place_blocks(TLab_AMD_DNS_Handle(), int(ncand, c_int), cq, cs, chq, chs, ctxc, int(isize_txc_field, c_long_long), 1.0e-3_c_double, &
+                                   int(2*ncand, c_int), 1_c_int, choice, report)
+        call TLab_AMD_Check(rc, 'tlab_dns_place_blocks')
+        call TLab_AMD_Check(tlab_sync(), 'tlab_sync')
+        ! the winners become the host's arrays; everything else goes back
+        call c_f_pointer(cq(choice(1) + 1), q, [isize_field, 3])
+        call c_f_pointer(chq(choice(3) + 1), hq, [isize_field, 3])
+        call c_f_pointer(ctxc(choice(5) + 1), txc, [isize_txc_field, ntxc])
+        if (inb_scal > 0) then
+            call c_f_pointer(cs(choice(2) + 1), s, [isize_field, ns2])
+            call c_f_pointer(chs(choice(4) + 1), hs, [isize_field, ns2])
+        end if
+        do ic = 1, ncand
+            if (ic /= choice(1) + 1) rc = tlab_free(cq(ic))
+            if (ic /= choice(3) + 1) rc = tlab_free(chq(ic))
+            if (ic /= choice(5) + 1) rc = tlab_free(ctxc(ic))
+            if (inb_scal > 0) then
+                if (ic /= choice(2) + 1) rc = tlab_free(cs(ic))
+                if (ic /= choice(4) + 1) rc = tlab_free(chs(ic))
+            end if
+        end do
+        call TLab_AMD_Reset_Pointers()
+        write (line, '(a,i0,a,i0,a,f8.3,a,f8.3,a,f8.3,a,f8.3,a,5(1x,i0))') 'PLACEMENT: candidates ', ncand, ' trials ', int(report(5)), &
+            ' ms_first ', report(1), ' ms_kept ', report(2), ' ms_median ', report(3), ' ms_worst ', report(4), ' choice', choice
+        call TLab_Write_ASCII(lfile, trim(line))
+    end subroutine TLab_AMD_Place_Arrays
 
     subroutine TLab_AMD_DNS_Begin_Step()
         if (TLab_AMD_Pencil_Active()) then

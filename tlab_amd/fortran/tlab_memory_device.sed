@@ -17,7 +17,8 @@ s/end subroutine TLab_Allocate_Real$/end subroutine TLab_Allocate_Real_Host/
 i\
     interface TLab_Allocate_Real\
         module procedure TLab_Allocate_Real_Host, TLab_Allocate_Real_Device\
-    end interface TLab_Allocate_Real
+    end interface TLab_Allocate_Real\
+    public :: TLab_AMD_Reset_Pointers
 a\
 #include "tlab_allocate_real_device.inc"
 }
