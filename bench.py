@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--placement-pool", type=int, default=40, help="candidate allocations of the placement search")
     ap.add_argument("--time-every-launch", action="store_true", help="events around every kernel launch inside the timed region (the kernel table then comes "
                     "from the timed region itself; costs ~0.2 ms per substep at 512^3)")
+    ap.add_argument("--no-fortran-host", action="store_true", help="skip the `fortran_host` leg of the default single-GPU line (the Fortran mini-driver timed at the "
+                    "benchmark's size in a child process, after the timed region)")
     ap.add_argument("--no-freeslip-leg", action="store_true", help="skip the extra `walls_freeslip` timing of the default single-GPU line")
     ap.add_argument("--cpu-sample", type=int, default=256, help="n of the n^3 CPU-baseline sample (0 disables)")
     ap.add_argument("--cpu-sample-large", type=int, default=512, help="second, larger CPU-baseline sample, run only on hosts with at least --cpu-large-min-cores CPUs (0 disables)")
@@ -753,6 +755,24 @@ def main():
                                      "what": "same box and steps with VelocityJmin/Jmax = freeslip and Neumann scalars (the reference's default walls)"}
             del d2
             torch.cuda.empty_cache()
+        if single and not args.no_fortran_host and args.nscal == 1 and not args.ystretch and args.walls == "noslip":
+            # the configuration north_star names: the Fortran RK driver on the device path, at this size, in a child process of its own (its arrays in
+            # the host's layout q(isize_field, 3) ...): the UNCHANGED time loop (link-time RHS + the reference's DAXPY / DSCAL, which the library
+            # completes to one fused substep: csrc/deferred.cpp) and the six-line patch of time.f90, ms per substep by the driver's own clock
+            exe = os.path.join(ROOT, "tlab_amd", "fortran", "_build_rk", "test_rk_driver")
+            if os.path.exists(exe):
+                d = None
+                torch.cuda.empty_cache()
+                try:
+                    import subprocess
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fortran_host.py"), "--grid", str(nx), str(ny), str(nz), "--steps", "6", "--warmup", "1",
+                                        "--routes", "unchanged,fused"], capture_output=True, text=True, timeout=900)
+                    fl = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    out["fortran_host"] = json.loads(fl[-1]) if fl else {"error": (r.stdout + r.stderr)[-800:]}
+                except Exception as e:       # noqa: BLE001
+                    out["fortran_host"] = {"error": repr(e)}
+            else:
+                out["fortran_host"] = {"error": "tlab_amd/fortran/_build_rk/test_rk_driver not built (needs the reference's module files: build container only)"}
         if args.cpu_sample > 0 and world == 1 and args.loopback <= 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.nscal)
             # ... and the host used the way the reference uses it (one rank per core): independent instances on disjoint core ranges.  The larger of

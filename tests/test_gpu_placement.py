@@ -76,7 +76,7 @@ def test_bench_line_of_one_gpu_carries_the_placement_report_and_times_the_domina
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--n", "256", "--steps", "6", "--warmup", "3", "--cpu-sample", "0", "--no-freeslip-leg", "--placement-trials", "4",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--n", "256", "--steps", "6", "--warmup", "3", "--cpu-sample", "0", "--no-freeslip-leg", "--no-fortran-host", "--placement-trials", "4",
            "--placement-pool", "24"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
