@@ -1383,7 +1383,14 @@ __global__ void __launch_bounds__(512) k_ode_nn(OdeArgs a) {
     // the neighbour that owns the other half would sit on another XCD and the line would cross the fabric twice (PMC: 9.3 GB per launch, 8.3 with the pairing, against
     // 6.7 algorithmic).  Pair them: of every 16 consecutive workgroups, XCD x gets the adjacent blocks 2x and 2x + 1.
     unsigned blk = blockIdx.x;
-    if (NM == 4 && a.pair_xcd && (blk | 15u) < gridDim.x) blk = (blk & ~15u) + 2u * (blk & 7u) + ((blk >> 3) & 1u);
+    // pair_xcd = G (16, 32, 64, ...): of every G consecutive workgroups XCD x gets the G/8 ADJACENT blocks x G/8 .. -- the rows of f^ / p^ / dp^ are
+    // nxh = nx/2 + 1 complex numbers long, an ODD number of 16-B elements, so the 128-B lines are not aligned with any fixed window of kx: a line is
+    // shared by neighbouring blocks in every row but one of eight, and only neighbours on the same XCD (same L2) share it for free.  Counters at 512^3
+    // (profiles/r06/poisson_requests.txt): G = 16 read 4.06 GB per launch in 128-B requests where f^ + checkpoints + homogeneous solutions are 1.75.
+    if (a.pair_xcd >= 16) {
+        const unsigned G = (unsigned)a.pair_xcd;
+        if ((blk | (G - 1u)) < gridDim.x) blk = (blk & ~(G - 1u)) + (blk & 7u) * (G >> 3) + ((blk & (G - 1u)) >> 3);
+    }
     int t = (int)blk * NM + m;                        // the mode whose tables are read (NL = 4: kz <= nz/2, so the pair index is the mode index)
     const int nlive = (NL == 4) ? a.nxh * (nm / a.nxh / 2 + 1) : nm;
     const bool live = t < nlive;
@@ -2449,7 +2456,12 @@ void launch_ode(tlab_poisson_plan &P, double *f_hat, double *p_hat, double *dp_h
     const int NM = P.ode_nm_per_wg;
     {
         static int pair = -1;
-        if (pair < 0) { const char *e = getenv("TLAB_ODE_PAIR_XCD"); pair = e ? atoi(e) : 1; }
+        if (pair < 0) {      // TLAB_ODE_PAIR_XCD = 0 (blocks in dispatch order) or the group size G, a power of two >= 16 (1 = 16, the round-5 pairing)
+            const char *e = getenv("TLAB_ODE_PAIR_XCD");
+            pair = e ? atoi(e) : 128;      // 128: XCD x takes 16 adjacent blocks of every 128 (HBM reads of the launch 4.07 -> 3.15 GB, requests 3.18e7 -> 2.46e7 at 512^3)
+            if (pair == 1) pair = 16;
+            if (pair != 0 && (pair < 16 || (pair & (pair - 1)) != 0)) pair = 16;
+        }
         a.pair_xcd = pair;
     }
     const size_t lds = ode_lds_bytes(a.C, NM, P.ode_om, P.ode_pair ? 4 : 2);
