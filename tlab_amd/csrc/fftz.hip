@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -494,7 +495,9 @@ void FftzPlan::exec(int dir, const double *in, double *out, hipStream_t st) cons
     a.nlines = nlines; a.n = n; a.npass = (int)radix.size();
     for (size_t p = 0; p < radix.size(); ++p) a.radix[p] = radix[p];
     ProfScope ps("k_fftz", st, (double)nlines * n * 32.0);
-    if (n <= 1024) fftz_launch<8>(dir, a, st);       // 8 neighbouring lines per workgroup (128-B rows), n * 8 * 16 B of LDS
+    static const int t16 = [] { const char *e = getenv("TLAB_FFTZ_T"); return e ? atoi(e) : 8; }();      // experiment: 16 lines (256-B rows), 1024 threads, one workgroup per CU
+    if (n <= 512 && t16 == 16) fftz_launch<16>(dir, a, st);
+    else if (n <= 1024) fftz_launch<8>(dir, a, st);       // 8 neighbouring lines per workgroup (128-B rows), n * 8 * 16 B of LDS
     else fftz_launch<4>(dir, a, st);                 // n = 2048: 4 lines (64-B rows) to stay within 1024 threads / 128 KB
     if (hipGetLastError() != hipSuccess) throw std::runtime_error("k_fftz launch failed");
 }
