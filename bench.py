@@ -735,6 +735,12 @@ def main():
                      hyper_bc1_ext=HYPER_BC1_EXT)
             d2.set_bcs("freeslip", "freeslip", "neumann", "neumann")
             synthetic_fields(d2.q + d2.s, nx, ny, nz, 0, nz, rank)
+            pl2 = None
+            if args.placement_trials > 0:      # like for like with the headline: the same search for where the arrays live
+                try:
+                    pl2 = d2.place_arrays(pool=args.placement_pool, random_trials=args.placement_trials, dtime=dtime)
+                except (T.TlabError, RuntimeError) as e:
+                    pl2 = {"error": str(e)}
 
             def substep2(k):
                 s_ = k % d2.rkm_endstep
@@ -752,7 +758,8 @@ def main():
             el2 = time.perf_counter() - t0
             out["walls_freeslip"] = {"ms_per_step": el2 / args.steps * 1e3, "value": npts * args.steps / el2, "unit": "grid-point-updates/s",
                                      "steps": args.steps, "warmup": args.warmup, "fields_finite": all(bool(torch.isfinite(t).all()) for t in d2.q + d2.s),
-                                     "what": "same box and steps with VelocityJmin/Jmax = freeslip and Neumann scalars (the reference's default walls)"}
+                                     "placement": pl2,
+                                     "what": "same box and steps with VelocityJmin/Jmax = freeslip and Neumann scalars (the reference's default walls), arrays placed by the same search"}
             del d2
             torch.cuda.empty_cache()
         if single and args.walls == "noslip" and not args.no_freeslip_leg:
@@ -761,6 +768,12 @@ def main():
             # kernels, same bytes: only two table entries differ.
             d3 = Dns(x, y, z, nscal=args.nscal, visc=1.0 / 5000.0, schmidt=(1.0,) * args.nscal, yuniform=not args.ystretch, rkm_mode=RKM_EXP3, hyper_bc1_ext=0.1)
             synthetic_fields(d3.q + d3.s, nx, ny, nz, 0, nz, rank)
+            pl3 = None
+            if args.placement_trials > 0:
+                try:
+                    pl3 = d3.place_arrays(pool=args.placement_pool, random_trials=args.placement_trials, dtime=dtime)
+                except (T.TlabError, RuntimeError) as e:
+                    pl3 = {"error": str(e)}
 
             def substep3(k):
                 s_ = k % d3.rkm_endstep
@@ -778,8 +791,8 @@ def main():
             el3 = time.perf_counter() - t0
             out["closure_as_compiled_reference"] = {"hyper_bc1_ext": 0.1, "ms_per_step": el3 / args.steps * 1e3, "value": npts * args.steps / el3,
                                                     "unit": "grid-point-updates/s", "fields_finite": all(bool(torch.isfinite(t).all()) for t in d3.q + d3.s),
-                                                    "what": "same box, steps and kernels with the wall closure 0.1 of the flang-built reference (arrays where the allocator put them: "
-                                                            "compare with placement.ms_first, not ms_best)"}
+                                                    "placement": pl3,
+                                                    "what": "same box, steps and kernels with the wall closure 0.1 of the flang-built reference, arrays placed by the same search"}
             del d3
             torch.cuda.empty_cache()
         if single and not args.no_fortran_host and args.nscal == 1 and not args.ystretch and args.walls == "noslip":
