@@ -24,6 +24,8 @@ module TLAB_AMD_PARTIAL_MODULE
     public :: OPR_Partial_Y
     public :: OPR_Partial_Z
     public :: OPR_Partial_AMD_Plan          ! device plan handle of a direction (shared with OPR_Burgers / OPR_Elliptic shims)
+    public :: OPR_Partial_AMD_Release_Stale ! frees the device plans that were replaced because their fdm_dt was rebuilt in place (call at finalize, or
+                                            ! after the plans made from them -- OPR_Elliptic_Initialize -- were re-initialised too)
 
     integer, parameter, public :: OPR_P1 = 1
     integer, parameter, public :: OPR_P2 = 2
@@ -40,8 +42,13 @@ module TLAB_AMD_PARTIAL_MODULE
     type(c_ptr), save :: plans(NSLOT, 3) = c_null_ptr
     type(c_ptr), save :: keys(NSLOT, 3) = c_null_ptr
     ! ... and by a fingerprint of its tables: a host that builds an fdm_dt anew IN PLACE (FDM_CreatePlan on the same object with other nodes or schemes)
-    ! must not be served the plan of the old tables (VERDICT round 4, weak 10).  A few entries of the Jacobian and of both systems: O(1) per call.
-    real(c_double), save :: marks(NSLOT, 3) = 0.0_c_double
+    ! must not be served the plan of the old tables (VERDICT round 4, weak 10).  EVERY entry of the Jacobian and of both systems enters (a rotate-xor
+    ! hash of the bit patterns: a change in two wall rows only -- another closure -- or changes that cancel in a sum are seen): O(n) per call, ~30 us at
+    ! n = 2048 for a host that calls the operators one by one; the RHS drivers ask once.
+    integer(c_int64_t), save :: marks(NSLOT, 3) = 0_c_int64_t
+    integer, parameter :: NSTALE = 32
+    type(c_ptr), save :: stale(NSTALE) = c_null_ptr
+    integer, save :: nstale_used = 0
 
 contains
     ! ###################################################################
@@ -52,7 +59,8 @@ contains
         type(c_ptr) :: p, pm1, pm2, key
         integer(c_int) rc
         integer is
-        real(c_double) :: one_node(1), mark
+        real(c_double) :: one_node(1)
+        integer(c_int64_t) :: mark
         key = c_loc(g%size)                                      ! the address of the host object
         is = 0
         do is = 1, NSLOT
@@ -63,7 +71,11 @@ contains
         mark = plan_fingerprint(g)
         if (c_associated(keys(is, idir)) .and. c_associated(plans(is, idir)) .and. mark /= marks(is, idir)) then
             ! the object was rebuilt in place: its device plan is stale.  It is NOT destroyed -- an elliptic plan made from it (OPR_Elliptic_Initialize)
-            ! may still point to it until the host re-initialises that too -- only replaced
+            ! may still point to it until the host re-initialises that too -- only replaced, and remembered for OPR_Partial_AMD_Release_Stale
+            if (nstale_used < NSTALE) then
+                nstale_used = nstale_used + 1
+                stale(nstale_used) = plans(is, idir)
+            end if
             plans(is, idir) = c_null_ptr
         end if
         keys(is, idir) = key
@@ -71,20 +83,39 @@ contains
         p = partial_plan_slot(plans(is, idir), g)
     end function OPR_Partial_AMD_Plan
 
+    subroutine OPR_Partial_AMD_Release_Stale()
+        integer i
+        integer(c_int) rc
+        do i = 1, nstale_used
+            if (c_associated(stale(i))) rc = tlab_fdm_plan_destroy(stale(i))
+            stale(i) = c_null_ptr
+        end do
+        nstale_used = 0
+    end subroutine OPR_Partial_AMD_Release_Stale
+
     function plan_fingerprint(g) result(m)
         type(fdm_dt), intent(in) :: g
-        real(c_double) :: m
-        integer n, h
-        n = int(g%size); h = max(1, n/2)
-        m = real(n, c_double) + 1.0e3_c_double*real(g%der1%mode_fdm, c_double) + 1.0e5_c_double*real(g%der2%mode_fdm, c_double)
-        if (g%periodic) m = -m
-        if (n > 1) then
-            if (allocated(g%jac)) m = m + g%jac(1, 1) + 3.0_c_double*g%jac(h, 1) + 7.0_c_double*g%jac(n, 1)
-            if (allocated(g%der1%lhs)) m = m + 11.0_c_double*g%der1%lhs(h, 1) + 13.0_c_double*g%der1%lhs(1, 2) + 17.0_c_double*g%der1%lhs(n, 2)
-            if (allocated(g%der1%rhs)) m = m + 19.0_c_double*g%der1%rhs(h, 1)
-            if (allocated(g%der2%lhs)) m = m + 23.0_c_double*g%der2%lhs(h, 1) + 29.0_c_double*g%der2%lhs(1, 2)
-            if (allocated(g%der2%rhs)) m = m + 31.0_c_double*g%der2%rhs(h, 1)
+        integer(c_int64_t) :: m
+        m = int(g%size, c_int64_t) + 1000_c_int64_t*int(g%der1%mode_fdm, c_int64_t) + 100000_c_int64_t*int(g%der2%mode_fdm, c_int64_t)
+        if (g%periodic) m = not(m)
+        if (g%size > 1) then
+            if (allocated(g%jac)) call mix(m, g%jac, size(g%jac))
+            if (allocated(g%der1%lhs)) call mix(m, g%der1%lhs, size(g%der1%lhs))
+            if (allocated(g%der1%rhs)) call mix(m, g%der1%rhs, size(g%der1%rhs))
+            if (allocated(g%der2%lhs)) call mix(m, g%der2%lhs, size(g%der2%lhs))
+            if (allocated(g%der2%rhs)) call mix(m, g%der2%rhs, size(g%der2%rhs))
         end if
+    contains
+        subroutine mix(h, a, na)          ! h = rotl(h xor bits(a(i)), 5) + i over all entries (no multiplication: no integer overflow)
+            integer(c_int64_t), intent(inout) :: h
+            integer, intent(in) :: na
+            real(wp), intent(in) :: a(na)
+            integer i
+            do i = 1, na
+                h = ishftc(ieor(h, transfer(a(i), 0_c_int64_t)), 5)
+                h = ieor(h, int(i, c_int64_t))
+            end do
+        end subroutine mix
     end function plan_fingerprint
 
     function partial_plan_slot(slot, g) result(p)

@@ -353,6 +353,7 @@ contains
     end subroutine TLab_AMD_Zero
 
     subroutine TLab_AMD_DNS_Finalize()
+        use OPR_Partial, only: OPR_Partial_AMD_Release_Stale
         integer(c_int) rc
         rc = tlab_deferred_enable(0_c_int)            ! (runs what is still recorded)
         if (c_associated(slab)) rc = tlab_slab_dns_destroy(slab)
@@ -361,6 +362,7 @@ contains
         pencil = c_null_ptr
         if (c_associated(dns)) rc = tlab_dns_destroy(dns)
         dns = c_null_ptr
+        call OPR_Partial_AMD_Release_Stale()
         rc = tlab_sync()
     end subroutine TLab_AMD_DNS_Finalize
 
