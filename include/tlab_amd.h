@@ -529,6 +529,12 @@ int tlab_slab_dns_bind(tlab_slab_dns_t d, int l, double *const *q, double *const
 long long tlab_slab_dns_info(tlab_slab_dns_t d, int what);
 int tlab_slab_dns_set_bcs(tlab_slab_dns_t d, const int *flow_jmin, const int *flow_jmax, const int *scal_jmin, const int *scal_jmax);
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d);                 /* as tlab_dns_begin_step */
+/* The deferred tail (tlab_deferred_enable, above) behind the decomposed drivers: the link-time RHS_GLOBAL_INCOMPRESSIBLE_1 of an unpatched host calls these
+ * instead of tlab_slab_dns_rhs / tlab_pencil_dns_rhs; the DAXPY / DSCAL calls of time.f90 that follow (tlab_deferred_axpy / _scal on the BOUND arrays of
+ * the one local rank) complete the description to tlab_slab_dns_substep / tlab_pencil_dns_substep, zero fills to *_begin_step.  With several local
+ * ranks in one process (loopback runs) or the layer off they execute at once. */
+int tlab_deferred_slab_rhs(tlab_slab_dns_t d, double dte);
+int tlab_deferred_pencil_rhs(tlab_pencil_dns_t d, double dte);
 int tlab_slab_dns_set_remove_divergence(tlab_slab_dns_t d, int on);
 /* as tlab_dns_set_surface_bcs: the dynamic surface model of the scalars on z-slabs.  The plane average of BOUNDARY_BCS_SURFACE_Y (AVG1V2D,
  * boundary_bcs.f90:520,535) is an all-reduce: the transport's allreduce is called with op = 2 (MPI_SUM) on the ranks' plane averages. */

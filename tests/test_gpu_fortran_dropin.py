@@ -421,3 +421,36 @@ def test_unchanged_time_loop_runs_the_fused_substep_bit_for_bit(tmp_path):
     assert res["literal"][1] == [0, 0, 0, 24, 16, 4], res["literal"][1]
     d = max(rel_err(a, b) for a, b in zip(f_lit, f_fused))
     assert 0.0 < d <= 1e-11, d
+
+
+@pytest.mark.parametrize("route,nx,ny,nz", [("TLAB_AMD_FORCE_SLAB", 128, 32, 64), ("TLAB_AMD_FORCE_PENCIL", 64, 32, 32)])
+def test_unchanged_time_loop_behind_the_decomposed_drivers(tmp_path, route, nx, ny, nz):
+    """The deferred tail behind tlab_slab_dns / tlab_pencil_dns (tlab_deferred_slab_rhs / _pencil_rhs): the unpatched loop's RHS + DAXPY + DSCAL calls
+    become tlab_slab_dns_substep / tlab_pencil_dns_substep -- the fields equal those of the patched host to the bit, no BLAS pass runs on its own."""
+    import re
+    import numpy as np
+    _need_rk()
+    if not os.path.exists(RK_EXE_FUSED):
+        pytest.skip("tlab_amd/fortran/_build_rk_fused/test_rk_driver not built")
+    x = np.arange(nx) / nx * 2.0
+    z = np.arange(nz) / nz
+    y = 0.5 * (1 + np.tanh(1.5 * (2 * np.arange(ny) / (ny - 1) - 1)) / np.tanh(1.5))
+    rng = np.random.default_rng(79)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    wall = np.sin(np.pi * Y)
+    q0 = [((np.sin(np.pi * X + k) * np.cos(2 * np.pi * Z) + 0.1 * rng.uniform(-1, 1, X.shape)) * wall).ravel() for k in range(3)]
+    s0 = [(np.cos(np.pi * X) * Y + 0.1 * rng.uniform(-1, 1, X.shape)).ravel()]
+    bcs = ["VelocityJmin=noslip", "VelocityJmax=noslip", "Scalar1Jmin=dirichlet", "Scalar1Jmax=dirichlet"]
+    res = {}
+    for tag, exe in (("fused", RK_EXE_FUSED), ("deferred", RK_EXE)):
+        d = tmp_path / tag
+        d.mkdir()
+        q1, s1, log = run_rk_driver(str(d), x, y, z, q0, s0, 1000.0, 0.7, 1e-3, 2, bcs, exe=exe, env={route: "1", "TLAB_AMD_TIMING": "0"})
+        m = re.search(r"DEFERRED: [a-z_ ]+?((?:\s+\d+){6})\s*$", log, re.M)
+        assert m, log[-1500:]
+        res[tag] = (q1 + s1, [int(v) for v in m.group(1).split()])
+    assert all(np.array_equal(a, b) for a, b in zip(res["deferred"][0], res["fused"][0]))
+    fused_n, literal_n, begins, eaxpy, escal, ezero = res["deferred"][1]
+    # the first step's zero fills come before the driver handle exists and run as fills; everything else rides
+    assert (fused_n, literal_n, eaxpy, escal) == (6, 0, 0, 0) and begins == 1 and ezero == 2, res["deferred"][1]
+    assert res["fused"][1] == [0, 0, 0, 0, 0, 0]

@@ -27,12 +27,18 @@
 extern void tlab_set_error(const std::string &s);
 long long tlab_internal_dns_points(tlab_dns_t d);      // rhs.cpp
 int tlab_internal_dns_nscal(tlab_dns_t d);
+// the arrays a decomposed driver is bound to (one local rank: a Fortran / MPI host), slab.cpp / pencil.cpp; false: not bound, or several local ranks
+bool tlab_internal_slab_bound(tlab_slab_dns_t d, double *const **q, double *const **s, double *const **hq, double *const **hs, int *nscal, long long *n);
+bool tlab_internal_pencil_bound(tlab_pencil_dns_t d, double *const **q, double *const **s, double *const **hq, double *const **hs, int *nscal, long long *n);
 
 namespace {
 struct Range { double *p; long long n; };
 struct Pending {
     bool rhs = false;
+    int kind = 0;                                 // 0: tlab_dns (one domain), 1: tlab_slab_dns, 2: tlab_pencil_dns -- the same tail behind each of them
     tlab_dns_t d = nullptr;
+    tlab_slab_dns_t slab = nullptr;
+    tlab_pencil_dns_t pencil = nullptr;
     double dte = 0.0, kco = 1.0;
     int nf = 0;                                   // 3 + nscal
     long long n = 0;
@@ -78,6 +84,22 @@ bool zeros_are_the_tendencies(const Pending &p) {
     return true;
 }
 
+int run_begin(const Pending &p) {
+    return p.kind == 0 ? tlab_dns_begin_step(p.d) : p.kind == 1 ? tlab_slab_dns_begin_step(p.slab) : tlab_pencil_dns_begin_step(p.pencil);
+}
+int run_substep(Pending &p, double kco, int scale) {
+    if (p.kind == 1) return tlab_slab_dns_substep(p.slab, p.dte, kco, scale);
+    if (p.kind == 2) return tlab_pencil_dns_substep(p.pencil, p.dte, kco, scale);
+    return tlab_time_substep_incompressible_explicit(p.d, p.dte, kco, scale, p.q.data(), p.s.empty() ? nullptr : p.s.data(), p.hq.data(),
+                                                     p.hs.empty() ? nullptr : p.hs.data(), p.txc.data());
+}
+int run_rhs(Pending &p) {
+    if (p.kind == 1) return tlab_slab_dns_rhs(p.slab, p.dte);
+    if (p.kind == 2) return tlab_pencil_dns_rhs(p.pencil, p.dte);
+    return tlab_rhs_global_incompressible_1(p.d, p.dte, p.q.data(), p.s.empty() ? nullptr : p.s.data(), p.hq.data(), p.hs.empty() ? nullptr : p.hs.data(),
+                                            p.txc.data());
+}
+
 int flush_impl() {
     if (g_busy) return TLAB_OK;
     Busy b;
@@ -87,7 +109,7 @@ int flush_impl() {
     int rc = TLAB_OK;
     if (zeros_are_the_tendencies(p)) {
         ++g_stat[2];
-        rc = tlab_dns_begin_step(p.d);
+        rc = run_begin(p);
     } else {
         for (const Range &r : p.zeros) {
             ++g_stat[5];
@@ -95,20 +117,18 @@ int flush_impl() {
         }
     }
     if (rc != TLAB_OK) return rc;
-    double *const *s = p.s.empty() ? nullptr : p.s.data();
-    double *const *hs = p.hs.empty() ? nullptr : p.hs.data();
     if (p.nupd == p.nf && (p.nscl == 0 || p.nscl == p.nf)) {      // the whole substep, as the patched host would have called it
         ++g_stat[0];
-        return tlab_time_substep_incompressible_explicit(p.d, p.dte, p.nscl ? p.kco : 1.0, p.nscl ? 1 : 0, p.q.data(), s, p.hq.data(), hs, p.txc.data());
+        return run_substep(p, p.nscl ? p.kco : 1.0, p.nscl ? 1 : 0);
     }
     ++g_stat[1];
     if (p.nupd == p.nf) {                                           // all updated, some scaled: the substep without scaling, then those
-        rc = tlab_time_substep_incompressible_explicit(p.d, p.dte, 1.0, 0, p.q.data(), s, p.hq.data(), hs, p.txc.data());
+        rc = run_substep(p, 1.0, 0);
         for (int f = 0; f < p.nf && rc == TLAB_OK; ++f)
             if (p.scl[f]) rc = tlab_pw_scale(p.x[f], p.kco, p.n);
         return rc;
     }
-    rc = tlab_rhs_global_incompressible_1(p.d, p.dte, p.q.data(), s, p.hq.data(), hs, p.txc.data());
+    rc = run_rhs(p);
     for (int f = 0; f < p.nf && rc == TLAB_OK; ++f)
         if (p.upd[f]) rc = tlab_pw_rk_update(p.y[f], p.x[f], p.dte, 1.0, 0, p.n);
     return rc;
@@ -159,7 +179,8 @@ int tlab_deferred_rhs(tlab_dns_t d, double dte, double *const *q, double *const 
     }
     Pending &p = g_p;                    // (keeps the zero fills recorded so far)
     p.rhs = true;
-    p.d = d; p.dte = dte; p.kco = 1.0;
+    p.kind = 0; p.d = d; p.slab = nullptr; p.pencil = nullptr;
+    p.dte = dte; p.kco = 1.0;
     p.nf = 3 + ns; p.n = tlab_internal_dns_points(d);
     p.q.assign(q, q + 3); p.hq.assign(hq, hq + 3);
     p.s.clear(); p.hs.clear();
@@ -171,6 +192,42 @@ int tlab_deferred_rhs(tlab_dns_t d, double dte, double *const *q, double *const 
     p.upd.assign(p.nf, 0); p.scl.assign(p.nf, 0);
     p.nupd = p.nscl = 0;
     return TLAB_OK;
+}
+
+// the same for the decomposed drivers: their arrays are bound (tlab_slab_dns_bind / tlab_pencil_dns_bind), so the call carries the handle and dte only
+static int deferred_decomposed(int kind, tlab_slab_dns_t slab, tlab_pencil_dns_t pencil, double dte) {
+    double *const *q = nullptr, *const *s = nullptr, *const *hq = nullptr, *const *hs = nullptr;
+    int ns = 0;
+    long long n = 0;
+    const bool okb = kind == 1 ? tlab_internal_slab_bound(slab, &q, &s, &hq, &hs, &ns, &n) : tlab_internal_pencil_bound(pencil, &q, &s, &hq, &hs, &ns, &n);
+    if (!g_on || !okb || !(dte > 0.0)) {      // off, or nothing to match the BLAS calls against (several local ranks): at once
+        if (g_on) { const int rc = flush_impl(); if (rc != TLAB_OK) return rc; }
+        return kind == 1 ? tlab_slab_dns_rhs(slab, dte) : tlab_pencil_dns_rhs(pencil, dte);
+    }
+    if (g_p.rhs) {
+        const int rc = flush_impl();
+        if (rc != TLAB_OK) return rc;
+    }
+    Pending &p = g_p;
+    p.rhs = true;
+    p.kind = kind; p.d = nullptr; p.slab = slab; p.pencil = pencil;
+    p.dte = dte; p.kco = 1.0;
+    p.nf = 3 + ns; p.n = n;
+    p.q.clear(); p.s.clear(); p.hq.clear(); p.hs.clear(); p.txc.clear();
+    p.x.clear(); p.y.clear();
+    for (int i = 0; i < 3; ++i) { p.x.push_back(hq[i]); p.y.push_back(q[i]); }
+    for (int i = 0; i < ns; ++i) { p.x.push_back(hs[i]); p.y.push_back(s[i]); }
+    p.upd.assign(p.nf, 0); p.scl.assign(p.nf, 0);
+    p.nupd = p.nscl = 0;
+    return TLAB_OK;
+}
+int tlab_deferred_slab_rhs(tlab_slab_dns_t d, double dte) {
+    if (!d) { tlab_set_error("tlab_deferred_slab_rhs: null handle"); return TLAB_EINVAL; }
+    return deferred_decomposed(1, d, nullptr, dte);
+}
+int tlab_deferred_pencil_rhs(tlab_pencil_dns_t d, double dte) {
+    if (!d) { tlab_set_error("tlab_deferred_pencil_rhs: null handle"); return TLAB_EINVAL; }
+    return deferred_decomposed(2, nullptr, d, dte);
 }
 
 int tlab_deferred_axpy(long long n, double a, const double *x, double *y) {

@@ -25,6 +25,7 @@
 #include "../../include/tlab_amd.h"
 
 extern hipStream_t tlab_current_stream();
+int tlab_internal_deferred_flush();      // deferred.cpp
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
 extern "C" bool tlab_internal_anelastic();
@@ -731,6 +732,7 @@ int tlab_pencil_dns_create(tlab_pencil_dns_t *out, const tlab_pencil_transport *
 }
 
 int tlab_pencil_dns_destroy(tlab_pencil_dns_t d) {
+    (void)tlab_internal_deferred_flush();
     if (d) (void)hipDeviceSynchronize();
     delete d;
     return TLAB_OK;
@@ -821,3 +823,11 @@ int tlab_pencil_dns_substep(tlab_pencil_dns_t d, double dte, double kco, int sca
 }
 
 }  // extern "C"
+
+// deferred.cpp: the arrays of the ONE local rank of a Fortran / MPI host
+bool tlab_internal_pencil_bound(tlab_pencil_dns_t d, double *const **q, double *const **s, double *const **hq, double *const **hs, int *nscal, long long *n) {
+    if (!d || d->rk.size() != 1 || !d->rk[0].bound) return false;
+    *q = d->rk[0].q.data(); *s = d->rk[0].s.data(); *hq = d->rk[0].hq.data(); *hs = d->rk[0].hs.data();
+    *nscal = d->nscal; *n = d->n;
+    return true;
+}

@@ -25,6 +25,7 @@
 #include <vector>
 
 extern hipStream_t tlab_current_stream();
+int tlab_internal_deferred_flush();      // deferred.cpp
 extern void tlab_set_error(const std::string &s);
 extern bool tlab_device_ready();
 // zslab.hip: the z-slab operators with the neighbours' halo planes of every operand in buffers of their own ({lo, hi}, 3 planes each)
@@ -778,6 +779,7 @@ int tlab_slab_dns_create(tlab_slab_dns_t *out, const tlab_slab_transport *tr, tl
 }
 
 int tlab_slab_dns_destroy(tlab_slab_dns_t d) {
+    (void)tlab_internal_deferred_flush();
     delete d;
     return TLAB_OK;
 }
@@ -852,6 +854,7 @@ int tlab_slab_dns_set_surface_bcs(tlab_slab_dns_t d, const int *sfc_jmin, const 
 }
 
 int tlab_slab_dns_begin_step(tlab_slab_dns_t d) {
+    (void)tlab_internal_deferred_flush();
     if (!d) return TLAB_EINVAL;
     d->fresh = true;
     return TLAB_OK;
@@ -913,3 +916,11 @@ int tlab_slab_dns_dilatation_bounds(tlab_slab_dns_t d, double *dil_min, double *
 }
 
 }  // extern "C"
+
+// deferred.cpp: the arrays of the ONE local rank of a Fortran / MPI host (several local ranks -- loopback runs -- have no single DAXPY partner)
+bool tlab_internal_slab_bound(tlab_slab_dns_t d, double *const **q, double *const **s, double *const **hq, double *const **hs, int *nscal, long long *n) {
+    if (!d || d->rk.size() != 1 || !d->rk[0].bound) return false;
+    *q = d->rk[0].q.data(); *s = d->rk[0].s.data(); *hq = d->rk[0].hq.data(); *hs = d->rk[0].hs.data();
+    *nscal = d->nscal; *n = d->n;
+    return true;
+}

@@ -23,13 +23,14 @@ subroutine RHS_GLOBAL_INCOMPRESSIBLE_1()
     ! ims_npro_i > 1: the x/z pencil driver (tlab_amd/csrc/pencil.cpp): I- / K-transpositions around the x / z operators, exactly the MPI branches of
     ! OPR_Partial_X/Z and OPR_Burgers_X/Z (opr_partial.f90:66-147, :185-253; opr_burgers.f90:216-262, :386-426)
     if (TLab_AMD_Pencil_Active()) then
-        call TLab_AMD_Check(tlab_pencil_dns_rhs(TLab_AMD_Pencil_Handle(), real(dte, c_double)), 'tlab_pencil_dns_rhs')
+        ! (recorded when the deferred tail is on: the DAXPY / DSCAL calls of time.f90 complete it to tlab_pencil_dns_substep, csrc/deferred.cpp)
+        call TLab_AMD_Check(tlab_deferred_pencil_rhs(TLab_AMD_Pencil_Handle(), real(dte, c_double)), 'tlab_deferred_pencil_rhs')
         return
     end if
     ! ims_npro_k > 1: the z-slab driver (tlab_amd/csrc/slab.cpp) on the module arrays it was bound to -- the MPI branches of OPR_Partial_Z,
     ! OPR_Burgers_Z and OPR_Fourier_Z_* (opr_partial.f90:185-195, opr_burgers.f90:386-426, opr_fourier.f90:343-428) without a transposition per operator
     if (TLab_AMD_Slab_Active()) then
-        call TLab_AMD_Check(tlab_slab_dns_rhs(TLab_AMD_Slab_Handle(), real(dte, c_double)), 'tlab_slab_dns_rhs')
+        call TLab_AMD_Check(tlab_deferred_slab_rhs(TLab_AMD_Slab_Handle(), real(dte, c_double)), 'tlab_deferred_slab_rhs')       ! (likewise: tlab_slab_dns_substep)
         return
     end if
     if (inb_scal > 16 .or. inb_txc < 9) call TLab_AMD_Check(-1_c_int, 'RHS_GLOBAL_INCOMPRESSIBLE_1: needs inb_scal <= 16 and inb_txc >= 9')

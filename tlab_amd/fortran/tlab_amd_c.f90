@@ -217,6 +217,16 @@ module TLab_AMD_C
             real(c_double), value :: dte
             type(c_ptr), intent(in) :: q(*), s(*), hq(*), hs(*), txc(*)
         end function
+        integer(c_int) function tlab_deferred_slab_rhs(slab, dte) bind(C, name='tlab_deferred_slab_rhs')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: slab
+            real(c_double), value :: dte
+        end function
+        integer(c_int) function tlab_deferred_pencil_rhs(pencil, dte) bind(C, name='tlab_deferred_pencil_rhs')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: pencil
+            real(c_double), value :: dte
+        end function
         integer(c_int) function tlab_deferred_axpy(n, a, x, y) bind(C, name='tlab_deferred_axpy')
             import :: c_int, c_ptr, c_double, c_long_long
             integer(c_long_long), value :: n

@@ -32,6 +32,15 @@ module TLab_AMD_DNS
     type(c_ptr), save :: pencil = c_null_ptr
 
 contains
+    ! the UNPATCHED time loop (RHS, then DAXPY / DSCAL per field: time.f90:612-664, :272-297) as one fused substep of whichever driver runs the RHS
+    ! (csrc/deferred.cpp): on unless TLAB_AMD_DEFER=0
+    subroutine enable_deferred_tail()
+        integer defer_stat
+        character(len=8) defer_env
+        call get_environment_variable('TLAB_AMD_DEFER', defer_env, status=defer_stat)
+        if (.not. (defer_stat == 0 .and. trim(defer_env) == '0')) call TLab_AMD_Check(tlab_deferred_enable(1_c_int), 'tlab_deferred_enable')
+    end subroutine enable_deferred_tail
+
     logical function TLab_AMD_Slab_Active()
         use TLabMPI_VARS, only: ims_npro_k
         character(len=8) val
@@ -130,6 +139,7 @@ contains
                 ptxc(is) = c_loc(txc(1, is))
             end do
             call TLab_AMD_Check(tlab_pencil_dns_bind(pencil, 0_c_int, pq, ps, phq, phs, ptxc), 'tlab_pencil_dns_bind')
+            call enable_deferred_tail()
         end if
         h = pencil
     end function TLab_AMD_Pencil_Handle
@@ -189,6 +199,7 @@ contains
                 ptxc(is) = c_loc(txc(1, is))
             end do
             call TLab_AMD_Check(tlab_slab_dns_bind(slab, 0_c_int, pq, ps, phq, phs, ptxc), 'tlab_slab_dns_bind')
+            call enable_deferred_tail()
         end if
         h = slab
     end function TLab_AMD_Slab_Handle
@@ -205,8 +216,7 @@ contains
         integer(c_int) :: rc, fj0(3), fj1(3), sj0(16), sj1(16)
         real(c_double) :: cp0(16), cp1(16)
         real(c_double) :: sc(16)
-        integer ns, defer_stat
-        character(len=8) defer_env
+        integer ns
         if (.not. c_associated(dns)) then
             if (inb_scal > 16) call TLab_AMD_Check(-1_c_int, 'TLab_AMD_DNS_Handle: at most 16 scalars')
             ns = max(1, int(inb_scal))
@@ -223,9 +233,7 @@ contains
             call TLab_AMD_Check(rc, 'tlab_dns_set_bcs')
             rc = tlab_dns_set_remove_divergence(dns, merge(1_c_int, 0_c_int, remove_divergence))      ! dns.ini [Main] TermDivergence
             call TLab_AMD_Check(rc, 'tlab_dns_set_remove_divergence')
-            ! the UNPATCHED time loop (RHS, then DAXPY / DSCAL per field: time.f90:612-664, :272-297) as one fused substep: on unless TLAB_AMD_DEFER=0
-            call get_environment_variable('TLAB_AMD_DEFER', defer_env, status=defer_stat)
-            if (.not. (defer_stat == 0 .and. trim(defer_env) == '0')) call TLab_AMD_Check(tlab_deferred_enable(1_c_int), 'tlab_deferred_enable')
+            call enable_deferred_tail()
             if (inb_scal > 0) then          ! dynamic surface model of the scalars (BcsScalJmin%SfcType, %cpl)
                 sj0 = 0; sj1 = 0; cp0 = 0.0_c_double; cp1 = 0.0_c_double
                 sj0(1:inb_scal) = BcsScalJmin%SfcType(1:inb_scal); sj1(1:inb_scal) = BcsScalJmax%SfcType(1:inb_scal)

@@ -77,6 +77,8 @@ SIGNATURES = {
     "tlab_deferred_scal": (c_int, [ctypes.c_longlong, c_dbl, c_vp]),
     "tlab_deferred_zero": (c_int, [c_vp, ctypes.c_longlong]),
     "tlab_deferred_flush": (c_int, []),
+    "tlab_deferred_slab_rhs": (c_int, [c_vp, c_dbl]),
+    "tlab_deferred_pencil_rhs": (c_int, [c_vp, c_dbl]),
     "tlab_deferred_stats": (c_int, [ctypes.POINTER(ctypes.c_longlong)]),
     "tlab_dns_place_arrays": (c_int, [c_vp, c_int, c_vp, c_vp, c_dbl, c_int, ctypes.c_uint, ctypes.POINTER(c_int), _dp]),
     "tlab_dns_place_blocks": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
