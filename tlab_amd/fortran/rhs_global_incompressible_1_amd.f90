@@ -54,8 +54,9 @@ end subroutine RHS_GLOBAL_INCOMPRESSIBLE_1
 !########################################################################
 ! The whole of TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT (tools/dns/time.f90:559-664) AND the tendency scaling that follows it in TIME_RUNGEKUTTA
 ! (:272-297) in the fused device driver: RHS, q += dte hq, s += dte hs, hq *= kco, hs *= kco (the last only if scale).  For a host that accepts a
-! six-line patch of time.f90 (test_rk_driver.f90, -DTLAB_AMD_FUSED_SUBSTEP) instead of the link-time RHS alone: the update loops then ride on the
-! last kernels that touch each field (18.7 instead of ~24 ms per substep at 512^3 on an MI355X).
+! six-line patch of time.f90 (test_rk_driver.f90, -DTLAB_AMD_FUSED_SUBSTEP): the update loops ride on the last kernels that touch each field.  Since
+! round 6 the UNPATCHED loop reaches the same call by itself (the deferred tail, csrc/deferred.cpp: 15.96 ms per substep at 512^3 either way,
+! 19.5 with the BLAS calls executed one by one; profiles/r06/fortran_host.json); the patch remains for hosts that prefer to say it in their source.
 !########################################################################
 subroutine TIME_SUBSTEP_INCOMPRESSIBLE_EXPLICIT_AMD(kco_loc, scale_loc)
     use, intrinsic :: iso_c_binding
