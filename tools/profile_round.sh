@@ -49,6 +49,8 @@ python3 "$B" --decomp 2x4 --slab-driver python --steps 6 --warmup 2 $Q > "$O/ben
 "$ROOT/tools/yardstick" 512 > "$O/yardstick.jsonl" 2> /dev/null
 # the configuration north_star names: the Fortran mini-driver at the benchmark's size, three processes per route, final fields compared (round 6)
 python3 "$ROOT/tools/fortran_host.py" --compare --repeat 3 > "$O/fortran_host.json" 2> "$O/fortran_host.err"
+# launches of one slab's size against the single domain's, warm and cold (round 6: what the decomposition overhead is NOT)
+python3 "$ROOT/tools/small_launch_probe.py" 2> /dev/null | grep -v amdgpu.ids > "$O/small_launches.txt"
 AB=${4:-noab}      # fourth argument "ab": also the A/B lines of earlier rounds' switches
 if [ "$AB" = "ab" ]; then
 TLAB_HTILE_PERSIST=0 python3 "$B" --steps 20 --warmup 5 $Q > "$O/bench_no_ptile.json" 2> /dev/null
