@@ -132,6 +132,10 @@ struct tlab_pencil_dns {
     std::vector<int> scal_jmin, scal_jmax;
     bool fresh = false;
     bool overlap = true;              // rhs_overlapped (exchanges started ahead of independent launches) instead of the literal sequence; TLAB_PENCIL_OVERLAP=0
+    // tlab_pencil_dns_substep: the velocities are finished by ONE pass each behind the pressure gradient (h -= dp/dx_i, zero wall planes, q += dte h,
+    // h *= kco: k_final_update, the arithmetic of k_sub3 + k_set_wall_planes + k_rk_update in the same order) where all their walls are Dirichlet;
+    // TLAB_PENCIL_FINAL=0 keeps the three passes
+    struct { bool on = false, done = false; double dte = 0.0, kco = 1.0; int scale = 0; } fin;
     bool tracing = false;             // tlab_pencil_dns_trace: the order of exchange starts, launches and waits of the last RHS
     std::string trace;
     long long launches = 0;           // launches issued so far by the overlapped schedule (a wait looks whether any followed its start)
@@ -321,6 +325,31 @@ void need_bound(D *d) {
         if (!R.bound) throw Fail(TLAB_EINVAL, "tlab_pencil_dns: the arrays of every local rank must be bound first (tlab_pencil_dns_bind)");
 }
 
+// the tail of the velocities: sub3 + wall planes (+ Neumann planes) as the reference does it, or -- inside tlab_pencil_dns_substep with Dirichlet walls -- one
+// fused pass per component that also does the Runge-Kutta update (rhs_global_incompressible_1.f90:348-375, time.f90:645-664, :272-297)
+void finish_velocities(D *d) {
+    const int nx = d->imax, ny = d->ny, kmax = d->kmax;
+    const long long n = d->n;
+    static const bool fused_ok = [] { const char *e = getenv("TLAB_PENCIL_FINAL"); return !(e && atoi(e) == 0); }();
+    bool dirichlet = true;
+    for (int i = 0; i < 3; ++i) dirichlet = dirichlet && d->flow_jmin[i] != TLAB_DNS_BCS_NEUMANN && d->flow_jmax[i] != TLAB_DNS_BCS_NEUMANN;
+    d->fin.done = false;
+    if (d->fin.on && fused_ok && dirichlet) {
+        for (Rank &R : d->rk)
+            for (int i = 0; i < 3; ++i)
+                ok(tlab_pw_final_update(R.q[i], R.hq[i], R.txc[1 + i], nullptr, nullptr, d->fin.dte, d->fin.kco, d->fin.scale, nx, ny, kmax), "tlab_pw_final_update");
+        d->fin.done = true;
+        return;
+    }
+    for (Rank &R : d->rk) ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
+    for (Rank &R : d->rk)
+        for (int i = 0; i < 3; ++i) {
+            const int ibc = (d->flow_jmin[i] == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (d->flow_jmax[i] == TLAB_DNS_BCS_NEUMANN ? 2 : 0);
+            if (ibc) ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, R.hq[i], R.hb, R.ht, R.txc[0]), "tlab_boundary_bcs_neumann_y");
+            ok(tlab_pw_set_wall_planes(R.hq[i], (ibc & 1) ? R.hb : nullptr, (ibc & 2) ? R.ht : nullptr, nx, ny, kmax), "tlab_pw_set_wall_planes");
+        }
+}
+
 // tools/dns/rhs_global_incompressible_1.f90:98-398
 void rhs(D *d, double dte) {
     need_bound(d);
@@ -368,15 +397,14 @@ void rhs(D *d, double dte) {
     poisson(d);                                                                   // :284
     partial_t(d, 1, 0, 1);                                                        // :319
     partial_t(d, 3, 0, 3);                                                        // :320
-    for (Rank &R : d->rk) ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
     // boundary conditions (:360-398); y is never split, BOUNDARY_BCS_NEUMANN_Y needs no communication
+    finish_velocities(d);
     for (Rank &R : d->rk) {
         auto walls = [&](double *h, int tmin, int tmax) {
             const int ibc = (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0);
             if (ibc) ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, h, R.hb, R.ht, R.txc[0]), "tlab_boundary_bcs_neumann_y");
             ok(tlab_pw_set_wall_planes(h, (ibc & 1) ? R.hb : nullptr, (ibc & 2) ? R.ht : nullptr, nx, ny, kmax), "tlab_pw_set_wall_planes");
         };
-        for (int i = 0; i < 3; ++i) walls(R.hq[i], d->flow_jmin[i], d->flow_jmax[i]);
         for (int i = 0; i < ns; ++i) walls(R.hs[i], d->scal_jmin[i], d->scal_jmax[i]);
     }
 }
@@ -646,15 +674,7 @@ void rhs_overlapped(D *d, double dte) {
             }});
         run_pipeline(d, po, pl);
     }
-    for (Rank &R : d->rk) ok(tlab_pw_sub3(R.hq[0], R.hq[1], R.hq[2], R.txc[1], R.txc[2], R.txc[3], n), "tlab_pw_sub3");
-    for (Rank &R : d->rk) {
-        auto walls = [&](double *h, int tmin, int tmax) {
-            const int ibc = (tmin == TLAB_DNS_BCS_NEUMANN ? 1 : 0) + (tmax == TLAB_DNS_BCS_NEUMANN ? 2 : 0);
-            if (ibc) ok(tlab_boundary_bcs_neumann_y(d->g[1], ibc, nx, ny, kmax, h, R.hb, R.ht, R.txc[0]), "tlab_boundary_bcs_neumann_y");
-            ok(tlab_pw_set_wall_planes(h, (ibc & 1) ? R.hb : nullptr, (ibc & 2) ? R.ht : nullptr, nx, ny, kmax), "tlab_pw_set_wall_planes");
-        };
-        for (int i = 0; i < 3; ++i) walls(R.hq[i], d->flow_jmin[i], d->flow_jmax[i]);
-    }
+    finish_velocities(d);
 }
 
 template <class F>
@@ -814,9 +834,11 @@ int tlab_pencil_dns_rhs(tlab_pencil_dns_t d, double dte) {
 int tlab_pencil_dns_substep(tlab_pencil_dns_t d, double dte, double kco, int scale_tendencies) {
     return guarded([&] {
         if (!d || !(dte > 0.0)) throw Fail(TLAB_EINVAL, "tlab_pencil_dns_substep: bad arguments");
+        d->fin.on = true; d->fin.dte = dte; d->fin.kco = kco; d->fin.scale = scale_tendencies;
+        struct Off { D *d; ~Off() { d->fin.on = false; } } off{d};      // (also when the RHS throws)
         if (d->overlap) rhs_overlapped(d, dte); else rhs(d, dte);
         for (Rank &R : d->rk) {      // time.f90:645-664, :272-297
-            for (int i = 0; i < 3; ++i) ok(tlab_pw_rk_update(R.q[i], R.hq[i], dte, kco, scale_tendencies, d->n), "tlab_pw_rk_update");
+            for (int i = 0; i < 3 && !d->fin.done; ++i) ok(tlab_pw_rk_update(R.q[i], R.hq[i], dte, kco, scale_tendencies, d->n), "tlab_pw_rk_update");
             for (int i = 0; i < d->nscal; ++i) ok(tlab_pw_rk_update(R.s[i], R.hs[i], dte, kco, scale_tendencies, d->n), "tlab_pw_rk_update");
         }
     });
