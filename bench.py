@@ -659,6 +659,17 @@ def main():
             "kernels_from": kernels_pass,
         }
         single = world == 1 and args.loopback <= 1 and not args.decomp
+        if world == 1 and not single:
+            # all ranks on one GPU: the transports' exchanges are device copies (k_copy_blocks; the pencil driver's wire format passes k_trp_copy are
+            # packing work that stays on N GPUs) standing in for what xGMI carries on N GPUs.  Their share of the line, so that the work of the ranks
+            # can be read without it: summed launch durations of the kernel-table pass per substep
+            cp = [k for k in kernels if k["kernel"] == "k_copy_blocks"]
+            if cp:
+                ms_cp = sum(k["avg_ms"] * k["calls"] for k in cp) / float(kernels_substeps)
+                out["exchange_standin"] = {"kernel": "k_copy_blocks", "ms_per_step": ms_cp, "launches_per_step": sum(k["calls"] for k in cp) / float(kernels_substeps),
+                                           "ms_per_step_without": ms_per_step - ms_cp,
+                                           "what": "device copies of the loopback transport in place of the exchanges between GPUs; `ms_per_step_without` = the line minus "
+                                                   "their summed durations (they run on the compute stream in this mode: nothing overlaps them)"}
         if not single and placement is not None:
             out["placement"] = placement
         if single:

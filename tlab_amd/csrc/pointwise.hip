@@ -547,6 +547,10 @@ hipError_t launch_copy_blocks(int n, const double *const *src, double *const *ds
         }
         if (mx == 0) continue;
         const unsigned gx = (unsigned)std::min<long long>((mx / 2 + 255) / 256 + 1, 2048 / c.n + 1);
+        long long total = 0;
+        for (int b = 0; b < c.n; ++b) total += c.cnt[b];
+        // (the loopback transports' stand-in for an exchange: bench.py reports its share of a `--loopback` / `--decomp` line as `exchange_standin`)
+        ProfScope ps("k_copy_blocks", st, (double)total * 16.0);
         hipLaunchKernelGGL(k_copy_blocks, dim3(gx, (unsigned)c.n), dim3(256), 0, st, c);
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     }
