@@ -172,7 +172,7 @@ contains
             call DAXPY(ij_len, dte, hq(1, is), 1, q(1, is), 1)
         end do
 
-        do is = 1, inb_scal
+        do is = 1, inb_scal                                             ! (time.f90:658 asks `#ifdef BLAS` for this loop, not USE_BLAS: build the host with both)
             call DAXPY(ij_len, dte, hs(1, is), 1, s(1, is), 1)
         end do
 
