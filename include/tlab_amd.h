@@ -334,7 +334,9 @@ int tlab_dns_begin_step(tlab_dns_t d);
  * tlab_time_substep_incompressible_explicit(dte, kco, scale) -- the call of the patched host, bit for bit -- and the
  * zero fills become tlab_dns_begin_step.  Anything else is executed literally in the order it came.  A recorded sequence runs before any other
  * launch of the library (every entry point that enqueues work, tlab_sync, the copies, tlab_free flush first).  NOT covered: host statements that
- * read a device array directly without a call into the library -- call tlab_deferred_flush() (or tlab_sync()) before them.  Off by default:
+ * read a device array directly without a call into the library -- call tlab_deferred_flush() (or tlab_sync()) before them.  A recorded substep that
+ * FAILS when another entry point makes it run has no caller to report to: its code is returned by the next tlab_sync / tlab_deferred_flush (the text
+ * stays in tlab_last_error()).  Off by default:
  * the four operations then execute immediately (tlab_rhs_global_incompressible_1, tlab_pw_rk_update, tlab_pw_scale, tlab_pw_fill). */
 int tlab_deferred_enable(int on);
 int tlab_deferred_rhs(tlab_dns_t d, double dte, double *const *q, double *const *s, double *const *hq, double *const *hs, double *const *txc);

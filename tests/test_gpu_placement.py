@@ -134,3 +134,21 @@ def test_place_blocks_for_a_host_with_two_dimensional_arrays(T):
     with pytest.raises(TlabError):          # the same allocation twice among the candidates
         bad = (c_vp * ncand)(*([blocks["hq"][0].data_ptr()] + [t.data_ptr() for t in blocks["q"][1:]]))
         check(load().tlab_dns_place_blocks(d._h, ncand, bad, arr["s"], arr["hq"], arr["hs"], arr["txc"], m, 1e-3, 1, 1, choice, rep), "tlab_dns_place_blocks")
+
+
+def test_a_refused_allocation_leaves_no_error_behind(T):
+    """TLab_AMD_Place_Arrays asks tlab_malloc for candidates until the memory says no: the refusal comes back as an error code and the NEXT launch's
+    error check must not trip over it."""
+    import ctypes
+    import torch
+    from tlab_amd.lib import load, c_vp
+    L = load()
+    p = c_vp(0)
+    assert L.tlab_malloc(ctypes.byref(p), ctypes.c_size_t(1 << 42)) != 0          # 4 TiB
+    n = 64
+    g = T.FdmPlan(np.arange(n) / n, True, True)
+    u = torch.rand(n * 8 * 8, dtype=torch.float64, device="cuda")
+    r = torch.empty_like(u)
+    T.OPR_Partial_X(T.OPR_P1, n, 8, 8, 0, g, u, r, None)                            # raises if the stale error surfaces
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(r).all())

@@ -83,6 +83,7 @@ void tlab_internal_filter_1d(int dir, tlab_filter_t f, int nx, int ny, int nz, c
 
 // hooks for the other translation units (poisson.hip, rhs.hip)
 int tlab_internal_deferred_flush();      // deferred.cpp: a recorded Runge-Kutta tail runs before anything else is enqueued (no-op unless tlab_deferred_enable)
+int tlab_internal_deferred_take_error();
 hipStream_t tlab_current_stream() {
     (void)tlab_internal_deferred_flush();
     return g_stream;
@@ -421,6 +422,7 @@ int tlab_init(int device) {
 }
 
 int tlab_finalize(void) {
+    (void)tlab_deferred_enable(0);      // (runs what is still recorded)
     return guarded([&] {
         delete g_ws;
         g_ws = nullptr;
@@ -441,12 +443,18 @@ int tlab_set_stream(void *s) {
 
 int tlab_sync(void) {
     const int rcd = tlab_internal_deferred_flush();
+    const int rco = tlab_internal_deferred_take_error();      // a recorded substep that failed when another entry point made it run
     if (rcd != TLAB_OK) return rcd;
+    if (rco != TLAB_OK) return rco;
     return guarded([&] { hip_check(hipStreamSynchronize(g_stream), "hipStreamSynchronize"); });
 }
 
 int tlab_malloc(void **p, size_t bytes) {
-    return guarded([&] { hip_check(hipMalloc(p, bytes), "hipMalloc"); });
+    return guarded([&] {
+        const hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) (void)hipGetLastError();      // a refused allocation is an answer, not a fault: the next launch's error check must not find it
+        hip_check(e, "hipMalloc");                          // (TLab_AMD_Place_Arrays asks for candidates until the memory says no)
+    });
 }
 int tlab_free(void *p) {
     (void)tlab_internal_deferred_flush();

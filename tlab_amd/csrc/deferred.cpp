@@ -136,9 +136,20 @@ int flush_impl() {
 }      // namespace
 
 // capi.cpp: tlab_current_stream(), tlab_sync, the copies, tlab_free, tlab_set_stream
+// A recorded substep that runs because some OTHER entry point wanted the stream (the hook in tlab_current_stream()) has no caller to report a failure to:
+// the code is kept and handed to the next tlab_sync / tlab_deferred_* call (the error text stays in tlab_last_error()).
+static int g_sticky = TLAB_OK;
 int tlab_internal_deferred_flush() {
-    if (!g_on || g_busy || (!g_p.rhs && g_p.zeros.empty())) return TLAB_OK;
-    return flush_impl();
+    if (g_busy) return TLAB_OK;
+    int rc = TLAB_OK;
+    if (g_on && (g_p.rhs || !g_p.zeros.empty())) rc = flush_impl();
+    if (rc != TLAB_OK && g_sticky == TLAB_OK) g_sticky = rc;
+    return rc;
+}
+int tlab_internal_deferred_take_error() {      // capi.cpp: tlab_sync
+    const int rc = g_sticky;
+    g_sticky = TLAB_OK;
+    return rc;
 }
 
 extern "C" {
@@ -149,7 +160,11 @@ int tlab_deferred_enable(int on) {
     return rc;
 }
 
-int tlab_deferred_flush(void) { return tlab_internal_deferred_flush(); }
+int tlab_deferred_flush(void) {
+    const int rc = tlab_internal_deferred_flush();
+    const int old = tlab_internal_deferred_take_error();
+    return rc != TLAB_OK ? rc : old;
+}
 
 int tlab_deferred_stats(long long *counts) {
     if (!counts) return TLAB_EINVAL;
