@@ -93,28 +93,32 @@ def test_bench_line_of_one_gpu_carries_the_placement_report_and_times_the_domina
     assert rec["config"]["fields_finite"] is True and rec["steps"] == 6
 
 
-def test_place_blocks_for_a_host_with_two_dimensional_arrays(T):
+@pytest.mark.parametrize("ns", [1, 0])
+def test_place_blocks_for_a_host_with_two_dimensional_arrays(T, ns):
     """tlab_dns_place_blocks: the host's layout -- q(n, 3), s(n, ns), hq, hs, txc(m, 9) as ONE allocation each -- with three candidates per block:
     the choice is one candidate per block, the begin_step flag of the driver survives the trial substeps, and a step on the chosen blocks equals the
     step on separately allocated arrays to the bit (where the arrays live changes nothing but the time)."""
     import ctypes
     import torch
     from tlab_amd.lib import load, c_vp, check, TlabError
-    nx, ny, nz, ns = 256, 64, 32, 1
+    nx, ny, nz = 256, 64, 32
     ref = _dns(nx, ny, nz, 7, ns)
     d = _dns(nx, ny, nz, 7, ns)
     n, m = d.n, d.isize_txc_field
     ncand = 3
-    blocks = {"q": [torch.zeros(3 * n, dtype=torch.float64, device="cuda") for _ in range(ncand)], "s": [torch.zeros(ns * n, dtype=torch.float64, device="cuda") for _ in range(ncand)],
-              "hq": [torch.zeros(3 * n, dtype=torch.float64, device="cuda") for _ in range(ncand)], "hs": [torch.zeros(ns * n, dtype=torch.float64, device="cuda") for _ in range(ncand)],
+    blocks = {"q": [torch.zeros(3 * n, dtype=torch.float64, device="cuda") for _ in range(ncand)], "s": [torch.zeros(max(ns, 1) * n, dtype=torch.float64, device="cuda") for _ in range(ncand)],
+              "hq": [torch.zeros(3 * n, dtype=torch.float64, device="cuda") for _ in range(ncand)], "hs": [torch.zeros(max(ns, 1) * n, dtype=torch.float64, device="cuda") for _ in range(ncand)],
               "txc": [torch.zeros(9 * m, dtype=torch.float64, device="cuda") for _ in range(ncand)]}
     arr = {k: (c_vp * ncand)(*[t.data_ptr() for t in v]) for k, v in blocks.items()}
+    if ns == 0:      # a host without scalars hands over arrays of null pointers for s, hs (TLab_AMD_Place_Arrays): they are not looked at
+        arr["s"] = (c_vp * ncand)()
+        arr["hs"] = (c_vp * ncand)()
     choice = (ctypes.c_int * 5)()
     rep = (ctypes.c_double * 5)()
     d.begin_step()
     check(load().tlab_dns_place_blocks(d._h, ncand, arr["q"], arr["s"], arr["hq"], arr["hs"], arr["txc"], m, 1e-3, 4, 1, choice, rep), "tlab_dns_place_blocks")
     c = list(choice)
-    assert all(0 <= v < ncand for v in c) and int(rep[4]) >= 1 + 4 + 5 * (ncand - 1) and 0 < rep[1] <= rep[0]
+    assert all(0 <= v < ncand for v in c) and int(rep[4]) >= 1 + 4 + (5 if ns else 3) * (ncand - 1) and 0 < rep[1] <= rep[0]
     Q, S, HQ, HS, X = (blocks[k][c[i]] for i, k in enumerate(("q", "s", "hq", "hs", "txc")))
     d.q, d.s = [Q[i * n:(i + 1) * n] for i in range(3)], [S[i * n:(i + 1) * n] for i in range(ns)]
     d.hq, d.hs = [HQ[i * n:(i + 1) * n] for i in range(3)], [HS[i * n:(i + 1) * n] for i in range(ns)]

@@ -1043,7 +1043,7 @@ int tlab_dns_place_blocks(tlab_dns_t d, int ncand, double *const *cand_q, double
         const long long n = (long long)d->nx * d->ny * d->nz;
         if (ns > 0 && (!cand_s || !cand_hs)) throw Fail(TLAB_EINVAL, "tlab_dns_place_blocks: candidates for s, hs are missing");
         if (txc_stride < n) throw Fail(TLAB_EINVAL, "tlab_dns_place_blocks: txc_stride below the field size");
-        double *const *cands[5] = {cand_q, cand_s, cand_hq, cand_hs, cand_txc};
+        double *const *cands[5] = {cand_q, ns > 0 ? cand_s : nullptr, cand_hq, ns > 0 ? cand_hs : nullptr, cand_txc};      // (no scalars: whatever stands there is not looked at)
         for (int b = 0; b < 5; ++b) {
             if (!cands[b]) continue;
             for (int i = 0; i < ncand; ++i) {
