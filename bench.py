@@ -293,9 +293,9 @@ def main():
     ap.add_argument("--slab-driver", default="native", choices=["native", "python"], help="z-slab runs (--gpus N > 1, --loopback P): native = the C++ driver behind "
                     "tlab_slab_dns_* (tlab_amd/csrc/slab.cpp; RCCL transport of libtlab_amd_comm.so), the code a Fortran / MPI host runs; python = its "
                     "cross-check tlab_amd/parallel.py::SlabDns over torch.distributed (diagnostic)")
-    ap.add_argument("--placement-trials", type=int, default=16, help="single GPU: random assignments tried by tlab_dns_place_arrays before the timed region (0: the "
+    ap.add_argument("--placement-trials", type=int, default=32, help="single GPU: random assignments tried by tlab_dns_place_arrays before the timed region (0: the "
                     "arrays stay where the allocator put them)")
-    ap.add_argument("--placement-pool", type=int, default=40, help="candidate allocations of the placement search")
+    ap.add_argument("--placement-pool", type=int, default=56, help="candidate allocations of the placement search")
     ap.add_argument("--time-every-launch", action="store_true", help="events around every kernel launch inside the timed region (the kernel table then comes "
                     "from the timed region itself; costs ~0.2 ms per substep at 512^3)")
     ap.add_argument("--no-fortran-host", action="store_true", help="skip the `fortran_host` leg of the default single-GPU line (the Fortran mini-driver timed at the "
