@@ -315,7 +315,7 @@ contains
         end do alloc
         if (ncand < 2) return
         rc = tlab_dns_place_blocks(TLab_AMD_DNS_Handle(), int(ncand, c_int), cq, cs, chq, chs, ctxc, int(isize_txc_field, c_long_long), 1.0e-3_c_double, &
-                                   int(2*ncand, c_int), 1_c_int, choice, report)
+                                   int(4*ncand, c_int), 1_c_int, choice, report)
         call TLab_AMD_Check(rc, 'tlab_dns_place_blocks')
         call TLab_AMD_Check(tlab_sync(), 'tlab_sync')
         ! the winners become the host's arrays; everything else goes back
