@@ -413,9 +413,9 @@ def test_unchanged_time_loop_runs_the_fused_substep_bit_for_bit(tmp_path):
     # 2 steps x 3 substeps, both steps' zero fills became begin_step (the placement search of the start-up created the driver handle, so the layer is on
     # from the first statement of the loop)
     assert res["deferred"][1] == [6, 0, 2, 0, 0, 0], res["deferred"][1]
-    # TLab_AMD_Place_Arrays ran (four candidates per block by default) and changed nothing but the addresses; without it the first step's fills come
+    # TLab_AMD_Place_Arrays ran (six candidates per block by default) and changed nothing but the addresses; without it the first step's fills come
     # before the driver handle exists and are executed as fills (hq and hs)
-    assert "PLACEMENT: candidates 4" in logs["deferred"] and "PLACEMENT" not in logs["deferred, arrays where the allocator put them"]
+    assert "PLACEMENT: candidates 6" in logs["deferred"] and "PLACEMENT" not in logs["deferred, arrays where the allocator put them"]
     assert all(np.array_equal(a, b) for a, b in zip(res["deferred, arrays where the allocator put them"][0], f_fused))
     assert res["deferred, arrays where the allocator put them"][1] == [6, 0, 1, 0, 0, 2]
     assert res["literal"][1] == [0, 0, 0, 24, 16, 4], res["literal"][1]

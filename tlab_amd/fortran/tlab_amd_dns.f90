@@ -252,7 +252,7 @@ contains
     ! block through the allocation hook's tlab_malloc, the substep timed on combinations (tlab_dns_place_blocks), the module arrays q, s, txc
     ! (TLab_Arrays), hq, hs (DNS_ARRAYS) re-associated with the winners, the aliases of TLab_Pointers* reset, the losers freed.  ONE added call in
     ! dns_main.f90, after the operators are initialised and before IO_Read_Fields (the arrays hold nothing yet; every candidate is overwritten).
-    ! TLAB_AMD_PLACE = number of candidates per block (default 4; 0 or 1: nothing happens); single-domain runs only.
+    ! TLAB_AMD_PLACE = number of candidates per block (default 6, as many as the memory gives; 0 or 1: nothing happens); single-domain runs only.
     subroutine TLab_AMD_Place_Arrays()
         use TLab_Constants, only: lfile
         use TLab_WorkFlow, only: TLab_Write_ASCII
@@ -268,11 +268,11 @@ contains
         character(len=16) :: val
         character(len=256) :: line
 
-        ncand = 4
+        ncand = 6                       ! (four of four processes at 15.8 ms with 8 candidates, three of four with 4: profiles/r06/host_placement_candidates.txt)
         call get_environment_variable('TLAB_AMD_PLACE', val, status=stat)
         if (stat == 0) then
             read (val, *, iostat=stat) ncand
-            if (stat /= 0) ncand = 4
+            if (stat /= 0) ncand = 6
         end if
         ncand = min(ncand, maxcand)
         if (ncand < 2 .or. TLab_AMD_Pencil_Active() .or. TLab_AMD_Slab_Active()) return

@@ -142,7 +142,7 @@ def main():
     out = {"what": "Fortran mini-driver (tlab_amd/fortran/test_rk_driver.f90: dns_main.f90 start-up + module TIME of time.f90 on the drop-in modules), host layout "
                    "q(isize_field,3) etc., restart files in the reference's format; ms per RK substep = wall clock between two tlab_sync around %d Runge-Kutta steps "
                    "after %d untimed; the plans are the HOST's (the reference's own FDM_Initialize, i.e. the wall closure 0.1 the flang build reads; bench.py's headline times "
-                   "the consistent closure 0.0: same kernels, same bytes); TLab_AMD_Place_Arrays (4 candidates per block) ran at start-up" % (args.steps, args.warmup),
+                   "the consistent closure 0.0: same kernels, same bytes); TLab_AMD_Place_Arrays (6 candidates per block by default) ran at start-up" % (args.steps, args.warmup),
            "grid": [nx, ny, nz], "n_scalars": 1, "case_written_s": round(time.time() - t0, 1), "routes": {}}
     finals = {}
     for route in [r for r in args.routes.split(",") if r]:
